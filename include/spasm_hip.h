@@ -1,0 +1,251 @@
+/*
+ * spasm_hip.h -- C ABI of the MI355X (gfx950) echelonization hot path.
+ *
+ * This is the drop-in boundary: plain C, plain pointers and sizes, no C++ or
+ * torch types.  Two layers are exported by spasm_amd/csrc/libspasm_hip.so:
+ *
+ *  (H) host-pointer entry points with the reference's own signatures.  Each
+ *      one replaces the reference function named in its comment (file:line in
+ *      cbouilla/spasm) and takes/returns the reference's structs
+ *      (struct spasm_csr, struct spasm_lu, ...), allocated with malloc so the
+ *      reference's spasm_csr_free()/spasm_lu_free() can release them.
+ *
+ *  (D) device-pointer entry points (spasm_hip_d*) for callers that keep the
+ *      matrices resident in HBM between rounds (bench.py, the multi-GPU
+ *      driver).  They take device pointers + a hipStream_t passed as void*.
+ *
+ * If the reference's spasm.h was included first (_SPASM_H defined) its struct
+ * definitions are used; otherwise layout-identical ones are declared here.
+ *
+ * Error behaviour: like the reference (spasm_util.c:62-83, err()/errx()), a
+ * fatal condition -- no usable GPU, out of device memory, malformed input --
+ * prints "[spasm-hip] ..." on stderr and exits.  There is NO CPU fallback.
+ */
+#ifndef SPASM_HIP_H
+#define SPASM_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+#include <stdbool.h>
+#include <stdio.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#ifndef _SPASM_H
+/* ---- layout-compatible restatement of the reference's public types ---- */
+typedef uint8_t u8;
+typedef int64_t i64;
+typedef uint64_t u64;
+typedef uint32_t u32;
+typedef int32_t i32;
+
+typedef i32 spasm_ZZp;                 /* balanced representative mod p (spasm.h:27) */
+
+struct spasm_field_struct {            /* spasm.h:29-35 */
+	i64 p;
+	i64 halfp;
+	i64 mhalfp;
+	double dinvp;
+};
+typedef struct spasm_field_struct spasm_field[1];
+
+struct spasm_csr {                     /* spasm.h:37-50; n rows, m columns */
+	i64 nzmax;
+	int n;
+	int m;
+	i64 *p;
+	int *j;
+	spasm_ZZp *x;
+	spasm_field field;
+};
+
+struct spasm_triplet {                 /* spasm.h:52-61 */
+	i64 nzmax;
+	i64 nz;
+	int n;
+	int m;
+	int *i;
+	int *j;
+	spasm_ZZp *x;
+	spasm_field field;
+};
+
+struct spasm_lu {                      /* spasm.h:63-71 */
+	int r;
+	bool complete;
+	struct spasm_csr *L;
+	struct spasm_csr *U;
+	int *qinv;
+	int *p;
+	struct spasm_triplet *Ltmp;
+};
+
+struct echelonize_opts {               /* spasm.h:84-108 */
+	bool enable_greedy_pivot_search;
+	bool enable_tall_and_skinny;
+	bool enable_dense;
+	bool enable_GPLU;
+	bool L;
+	bool complete;
+	double min_pivot_proportion;
+	int max_round;
+	double sparsity_threshold;
+	int dense_block_size;
+	double low_rank_ratio;
+	double tall_and_skinny_ratio;
+	double low_rank_start_weight;
+};
+
+typedef enum {SPASM_DOUBLE, SPASM_FLOAT, SPASM_I64} spasm_datatype;   /* spasm.h:139 */
+#endif /* _SPASM_H */
+
+/* ======================================================================
+ * (H) host-pointer entry points, reference signatures
+ * ====================================================================== */
+
+/* library / device probe.  Returns the number of usable gfx950 devices (0 if none). */
+int spasm_hip_device_count(void);
+const char *spasm_hip_version(void);
+
+/* --- containers and field (replace spasm_util.c:85-191, spasm_ZZp.c) --- */
+void spasm_hip_field_init(i64 p, spasm_field F);                                   /* spasm_ZZp.c:5-15 */
+spasm_ZZp spasm_hip_ZZp_init(const spasm_field F, i64 x);                          /* spasm_ZZp.c:26 */
+spasm_ZZp spasm_hip_ZZp_add(const spasm_field F, spasm_ZZp a, spasm_ZZp b);        /* spasm_ZZp.c:32 */
+spasm_ZZp spasm_hip_ZZp_sub(const spasm_field F, spasm_ZZp a, spasm_ZZp b);        /* spasm_ZZp.c:37 */
+spasm_ZZp spasm_hip_ZZp_mul(const spasm_field F, spasm_ZZp a, spasm_ZZp b);        /* spasm_ZZp.c:42 */
+spasm_ZZp spasm_hip_ZZp_inverse(const spasm_field F, spasm_ZZp a);                 /* spasm_ZZp.c:67 */
+spasm_ZZp spasm_hip_ZZp_axpy(const spasm_field F, spasm_ZZp a, spasm_ZZp x, spasm_ZZp y);  /* spasm_ZZp.c:76 */
+
+struct spasm_csr *spasm_hip_csr_alloc(int n, int m, i64 nzmax, i64 prime, bool with_values);   /* spasm_util.c:86 */
+void spasm_hip_csr_realloc(struct spasm_csr *A, i64 nzmax);                        /* spasm_util.c:122 */
+void spasm_hip_csr_resize(struct spasm_csr *A, int n, int m);                      /* spasm_util.c:177 */
+void spasm_hip_csr_free(struct spasm_csr *A);                                      /* spasm_util.c:155 */
+struct spasm_triplet *spasm_hip_triplet_alloc(int n, int m, i64 nzmax, i64 prime, bool with_values); /* spasm_util.c:102 */
+void spasm_hip_triplet_realloc(struct spasm_triplet *T, i64 nzmax);                /* spasm_util.c:139 */
+void spasm_hip_triplet_free(struct spasm_triplet *T);                              /* spasm_util.c:165 */
+void spasm_hip_lu_free(struct spasm_lu *N);                                        /* spasm_util.c:208 */
+void spasm_hip_add_entry(struct spasm_triplet *T, int i, int j, i64 x);            /* spasm_triplet.c:7 */
+void spasm_hip_triplet_transpose(struct spasm_triplet *T);                         /* spasm_triplet.c:25 */
+struct spasm_csr *spasm_hip_compress(const struct spasm_triplet *T);               /* spasm_triplet.c:97 */
+struct spasm_csr *spasm_hip_transpose(const struct spasm_csr *C, int keep_values); /* spasm_transpose.c:5 */
+
+/* --- SMS / MatrixMarket I/O (replace spasm_io.c:60-192) --- */
+struct spasm_triplet *spasm_hip_triplet_load(FILE *f, i64 prime, u8 *hash);        /* spasm_io.c:60 */
+void spasm_hip_triplet_save(const struct spasm_triplet *A, FILE *f);               /* spasm_io.c:183 */
+void spasm_hip_csr_save(const struct spasm_csr *A, FILE *f);                       /* spasm_io.c:163 */
+
+/* --- host-side structural pivot search (stays on the CPU by design) --- */
+int spasm_hip_pivots_extract_structural(const struct spasm_csr *A, const int *p_in, struct spasm_lu *fact,
+                                        int *p, struct echelonize_opts *opts);     /* spasm_pivots.c:374 */
+
+/* --- the hot path: Schur complement on the GPU --- */
+
+/* replaces spasm_schur (spasm_schur.c:64-193).  Row k of the result is the
+ * reduction of row p[k] of A (the reference emits rows in thread-arrival
+ * order and records the mapping in p_out; here the order is always p's).
+ * Entries of a row are sorted by column. */
+struct spasm_csr *spasm_hip_schur(const struct spasm_csr *A, const int *p, int n, const struct spasm_lu *fact,
+                                  double est_density, struct spasm_triplet *L, const int *p_in, int *p_out);
+
+/* replaces spasm_schur_estimate_density (spasm_schur.c:12-48) */
+double spasm_hip_schur_estimate_density(const struct spasm_csr *A, const int *p, int n,
+                                        const struct spasm_csr *U, const int *qinv, int R);
+
+/* replaces spasm_schur_dense (spasm_schur.c:258-343) */
+void spasm_hip_schur_dense(const struct spasm_csr *A, const int *p, int n, const int *p_in,
+                           struct spasm_lu *fact, void *S, spasm_datatype datatype, int *q, int *p_out);
+
+/* replaces spasm_schur_dense_randomized (spasm_schur.c:357-425) */
+void spasm_hip_schur_dense_randomized(const struct spasm_csr *A, const int *p, int n, const struct spasm_csr *U,
+                                      const int *qinv, void *S, spasm_datatype datatype, int *q, int N, int w);
+
+/* replace spasm_ffpack_rref / spasm_ffpack_LU and the datatype helpers
+ * (spasm_ffpack.cpp:88-148): dense (reduced) echelon form mod p on the GPU */
+int spasm_hip_ffpack_rref(i64 prime, int n, int m, void *A, int ldA, spasm_datatype datatype, size_t *qinv);
+int spasm_hip_ffpack_LU(i64 prime, int n, int m, void *A, int ldA, spasm_datatype datatype, size_t *p, size_t *qinv);
+spasm_ZZp spasm_hip_datatype_read(const void *A, size_t i, spasm_datatype datatype);
+void spasm_hip_datatype_write(void *A, size_t i, spasm_datatype datatype, spasm_ZZp value);
+size_t spasm_hip_datatype_size(spasm_datatype datatype);
+spasm_datatype spasm_hip_datatype_choose(i64 prime);
+const char *spasm_hip_datatype_name(spasm_datatype datatype);
+
+/* --- drivers (replace spasm_echelonize.c:9-28, :478-616; spasm_rref.c:25; spasm_kernel.c:9) --- */
+void spasm_hip_echelonize_init_opts(struct echelonize_opts *opts);
+struct spasm_lu *spasm_hip_echelonize(const struct spasm_csr *A, struct echelonize_opts *opts);
+struct spasm_csr *spasm_hip_rref(const struct spasm_lu *fact, int *Rqinv);
+struct spasm_csr *spasm_hip_kernel(const struct spasm_lu *fact);
+
+/* ======================================================================
+ * (D) device-resident entry points
+ * ====================================================================== */
+
+/* A CSR matrix whose arrays live in HBM.  Same layout and value convention
+ * (balanced int32) as struct spasm_csr: p has n+1 int64, j/x have p[n] int32. */
+typedef struct {
+	int n;
+	int m;
+	i64 nnz;
+	const i64 *p;
+	const int *j;
+	const spasm_ZZp *x;
+} spasm_hip_dcsr;
+
+/* Device image of the factor (U, qinv): rows of U sorted by elimination
+ * level, columns relabelled so that the pivot of row c is column c, values in
+ * Montgomery form.  Built on the host from the reference structs, then
+ * uploaded.  See DESIGN.md "Data layout in HBM". */
+typedef struct spasm_hip_dfact spasm_hip_dfact;
+spasm_hip_dfact *spasm_hip_dfact_create(const struct spasm_csr *U, const int *qinv, void *stream);
+void spasm_hip_dfact_destroy(spasm_hip_dfact *F);
+int spasm_hip_dfact_rank(const spasm_hip_dfact *F);
+int spasm_hip_dfact_levels(const spasm_hip_dfact *F);
+i64 spasm_hip_dfact_nnz(const spasm_hip_dfact *F);
+
+/* Scratch + output pool for the device Schur complement.  pool_entries is the
+ * capacity of the row pool (one entry = one (column, value) pair). */
+typedef struct spasm_hip_dwork spasm_hip_dwork;
+spasm_hip_dwork *spasm_hip_dwork_create(int max_rows, int m, i64 pool_entries);
+void spasm_hip_dwork_destroy(spasm_hip_dwork *W);
+
+/* statistics of the last spasm_hip_dschur call on this workspace */
+typedef struct {
+	i64 nnz;                /* entries of S */
+	i64 eliminations;       /* pivot rows applied (sum over rows) */
+	i64 entries_streamed;   /* entries of U' read by those eliminations */
+	i64 input_entries;      /* entries of the reduced rows of A */
+	int rows;               /* rows reduced */
+	int rows_lds;           /* rows finished by the LDS hash kernel, small table */
+	int rows_lds_big;       /* ... by the large-table variant */
+	int rows_dense;         /* rows finished by the dense-accumulator kernel */
+	int status;             /* 0 = ok, 1 = pool too small (call again with a larger pool) */
+	float ms_eliminate;     /* device time of the elimination kernels (HIP events) */
+	float ms_total;         /* device time of the whole call */
+} spasm_hip_schur_stats;
+
+/* S = Schur complement of rows d_rows[0..nrows) of A w.r.t. F, left in the
+ * workspace (device).  Everything is enqueued on `stream`; the call returns
+ * after synchronising that stream (it has to read the total size back).
+ * Returns 0 on success, 1 if the pool was too small. */
+int spasm_hip_dschur(const spasm_hip_dcsr *A, const int *d_rows, int nrows, const spasm_hip_dfact *F,
+                     spasm_hip_dwork *W, void *stream, spasm_hip_schur_stats *stats);
+
+/* copies the result of the last spasm_hip_dschur into caller-provided device
+ * buffers (Sp: nrows+1 int64; Sj, Sx: stats.nnz int32 each). */
+void spasm_hip_dschur_fetch(const spasm_hip_dwork *W, i64 *d_Sp, int *d_Sj, spasm_ZZp *d_Sx, void *stream);
+
+/* dense rows of the Schur complement, left on the device: d_S is nrows x Sm
+ * (Sm = m - rank), row-major with leading dimension ldS, values in [0, p). */
+int spasm_hip_dschur_dense(const spasm_hip_dcsr *A, const int *d_rows, int nrows, const spasm_hip_dfact *F,
+                           spasm_hip_dwork *W, u32 *d_S, i64 ldS, void *stream);
+
+/* in-place reduced row echelon form of a dense n x m matrix mod p resident in
+ * HBM (values in [0,p), leading dimension ld).  On return d_pivcol[0..rank)
+ * holds the pivot column of each echelon row.  Returns the rank. */
+int spasm_hip_drref(i64 prime, int n, int m, u32 *d_A, i64 ld, int *d_pivcol, void *stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

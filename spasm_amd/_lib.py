@@ -1,0 +1,65 @@
+"""Loads spasm_amd/csrc/libspasm_hip.so and declares its C ABI (include/spasm_hip.h)."""
+import ctypes as C
+import os
+
+from .matrix import CCsr, CTriplet, CLu, EchelonizeOpts, CDcsr, CSchurStats, CField
+
+LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "csrc", "libspasm_hip.so")
+
+_lib = None
+
+
+def lib():
+    """the shared library; raises (never falls back) when it has not been built."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise ImportError(
+            "spasm_amd: %s is missing -- build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+            "(make -C spasm_amd/csrc).  There is no CPU fallback." % LIB_PATH)
+    L = C.CDLL(LIB_PATH)
+    i64, ci, vp = C.c_int64, C.c_int, C.c_void_p
+    pcsr, ptri, plu = C.POINTER(CCsr), C.POINTER(CTriplet), C.POINTER(CLu)
+    pint = C.POINTER(C.c_int)
+    sig = {
+        "spasm_hip_device_count": (ci, []),
+        "spasm_hip_version": (C.c_char_p, []),
+        "spasm_hip_csr_alloc": (pcsr, [ci, ci, i64, i64, C.c_bool]),
+        "spasm_hip_csr_free": (None, [pcsr]),
+        "spasm_hip_triplet_alloc": (ptri, [ci, ci, i64, i64, C.c_bool]),
+        "spasm_hip_triplet_free": (None, [ptri]),
+        "spasm_hip_add_entry": (None, [ptri, ci, ci, i64]),
+        "spasm_hip_triplet_transpose": (None, [ptri]),
+        "spasm_hip_compress": (pcsr, [ptri]),
+        "spasm_hip_transpose": (pcsr, [pcsr, ci]),
+        "spasm_hip_triplet_load": (ptri, [vp, i64, C.POINTER(C.c_uint8)]),
+        "spasm_hip_csr_save": (None, [pcsr, vp]),
+        "spasm_hip_triplet_save": (None, [ptri, vp]),
+        "spasm_hip_pivots_extract_structural": (ci, [pcsr, pint, plu, pint, C.POINTER(EchelonizeOpts)]),
+        "spasm_hip_schur": (pcsr, [pcsr, pint, ci, plu, C.c_double, ptri, pint, pint]),
+        "spasm_hip_dfact_create": (vp, [pcsr, pint, vp]),
+        "spasm_hip_dfact_destroy": (None, [vp]),
+        "spasm_hip_dfact_rank": (ci, [vp]),
+        "spasm_hip_dfact_levels": (ci, [vp]),
+        "spasm_hip_dfact_nnz": (i64, [vp]),
+        "spasm_hip_dwork_create": (vp, [ci, ci, i64]),
+        "spasm_hip_dwork_destroy": (None, [vp]),
+        "spasm_hip_dschur": (ci, [C.POINTER(CDcsr), vp, ci, vp, vp, vp, C.POINTER(CSchurStats)]),
+        "spasm_hip_dschur_fetch": (None, [vp, vp, vp, vp, vp]),
+    }
+    for name, (res, args) in sig.items():
+        fn = getattr(L, name)
+        fn.restype = res
+        fn.argtypes = args
+    _lib = L
+    return L
+
+
+def device_count():
+    return lib().spasm_hip_device_count()
+
+
+def require_gpu(what):
+    if device_count() < 1:
+        raise RuntimeError("spasm_amd.%s needs an MI355X: no HIP device is visible and there is no CPU path" % what)

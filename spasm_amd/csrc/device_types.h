@@ -1,0 +1,115 @@
+// Device-side data structures shared by the kernels and their launchers.
+#pragma once
+
+#include <hip/hip_runtime.h>
+
+#include <cstdint>
+#include <vector>
+
+#include "common.h"
+
+namespace sh {
+
+#define HIP_CHECK(expr)                                                                                  \
+	do {                                                                                             \
+		hipError_t e_ = (expr);                                                                  \
+		if (e_ != hipSuccess)                                                                    \
+			sh::die("%s failed: %s (%s:%d)", #expr, hipGetErrorString(e_), __FILE__, __LINE__); \
+	} while (0)
+
+struct MontDev {           // copy of sh::Mont for kernels
+	uint32_t p, pinv, r1, r2, half;
+};
+
+inline MontDev to_dev(const Mont &M) { return MontDev{M.p, M.pinv, M.r1, M.r2, M.half}; }
+
+// counters living in one small device array (spasm_hip_dwork::d_ctr)
+enum Ctr {
+	CTR_ROW_NEXT = 0,      // next row batch to hand out (tier 0)
+	CTR_ROW_NEXT2,         // ... tier 1 (large LDS table)
+	CTR_ROW_NEXT3,         // ... tier 2 (dense accumulator)
+	CTR_OVF1,              // rows that overflowed the small table
+	CTR_OVF2,              // rows that overflowed the large table
+	CTR_STATUS,            // bit 0: pool exhausted
+	CTR_DONE0, CTR_DONE1, CTR_DONE2,   // rows finished per tier
+	CTR_COUNT = 16
+};
+
+enum Ctr64 {
+	C64_POOL = 0,          // pool cursor (entries)
+	C64_ELIM,              // pivot rows applied
+	C64_STREAM,            // entries of U' streamed
+	C64_INPUT,             // entries of input rows
+	C64_COUNT = 8
+};
+
+struct SchurArgs {
+	// rows of A to reduce
+	const int64_t *Ap;
+	const int *Aj;
+	const int *Ax;
+	const int *rows;          // nrows row indices into A
+	int nrows;
+	// optional explicit work list (positions into rows[]); count read on device
+	const int *list;
+	const int *list_count;
+	// factor
+	const uint32_t *lab;      // column -> label
+	const int *q;             // label - r -> column
+	const uint64_t *rp;       // r + 1 offsets into ent
+	const uint2 *ent;         // (label, value * R mod p)
+	const uint32_t *lvl_end;  // label -> end of its level
+	int r;
+	int m;
+	MontDev F;
+	// output pool
+	int *pool_j;
+	int *pool_x;
+	int64_t pool_cap;
+	int64_t *row_off;
+	int *row_len;             // -1: not produced (pool full)
+	int *ovf_list;            // rows handed to the next tier
+	int *ctr;
+	unsigned long long *ctr64;
+	int next_ctr;             // which CTR_ROW_NEXT* this launch uses
+	int ovf_ctr;              // which CTR_OVF* receives overflowing rows
+	int done_ctr;
+};
+
+}  // namespace sh
+
+// opaque handles of the C ABI
+struct spasm_hip_dfact {
+	int m = 0, r = 0, Sm = 0, nlevels = 0;
+	int64_t nnz = 0;
+	int64_t prime = 0;
+	sh::Mont mont{};
+	uint32_t *d_lab = nullptr;
+	int *d_q = nullptr;
+	uint64_t *d_rp = nullptr;
+	uint2 *d_ent = nullptr;
+	uint32_t *d_lvl_end = nullptr;
+	int *d_kof = nullptr;          // label -> row of U
+	std::vector<int> h_q;          // host copy of q
+	std::vector<int> h_kof;
+};
+
+struct spasm_hip_dwork {
+	int max_rows = 0, m = 0;
+	int64_t pool_cap = 0;
+	int *d_pool_j = nullptr, *d_pool_x = nullptr;
+	int64_t *d_row_off = nullptr;
+	int *d_row_len = nullptr;
+	int *d_ovf1 = nullptr, *d_ovf2 = nullptr;
+	int *d_ctr = nullptr;
+	unsigned long long *d_ctr64 = nullptr;
+	int64_t *d_Sp = nullptr;
+	int64_t *d_blocksum = nullptr;
+	int *d_Sj = nullptr, *d_Sx = nullptr;
+	uint32_t *d_dense = nullptr;       // dense accumulators of the last tier
+	int dense_slots = 0;
+	int64_t dense_stride = 0;
+	hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
+	int last_rows = 0;
+	int64_t last_nnz = 0;
+};

@@ -1,0 +1,257 @@
+// Structural pivot search on the host (replaces spasm_pivots.c).  By design
+// this stage stays on the CPU: it is a graph search with no arithmetic.
+//   1. Faugere-Lachartre: leftmost entry of each row, sparsest row wins;
+//   2. the same idea on columns not touched by a pivotal row;
+//   3. greedy search for pivots that keep the pivot graph acyclic (PASCO'17),
+//      executed in row order (the outcome of the reference with one thread).
+// Then the pivotal rows are ordered topologically and appended to U, scaled so
+// that every pivot is 1 and stored first in its row.
+#include <vector>
+
+#include "common.h"
+
+using namespace sh;
+
+namespace {
+
+struct Search {
+	const struct spasm_csr *A;
+	std::vector<int> pinv;   // row -> pivot column or -1
+	std::vector<int> qinv;   // column -> pivot row or -1
+
+	int weight(int i) const { return (int) (A->p[i + 1] - A->p[i]); }
+
+	// returns 1 when neither the row nor the column had a pivot before
+	int take(int i, int j)
+	{
+		int fresh = 1;
+		if (pinv[i] != -1) {
+			qinv[pinv[i]] = -1;
+			fresh = 0;
+		}
+		if (qinv[j] != -1) {
+			pinv[qinv[j]] = -1;
+			fresh = 0;
+		}
+		pinv[i] = j;
+		qinv[j] = i;
+		return fresh;
+	}
+
+	int leftmost_entries()
+	{
+		int found = 0;
+		for (int i = 0; i < A->n; i++) {
+			int best = A->m + 1;
+			for (i64 px = A->p[i]; px < A->p[i + 1]; px++)
+				if (A->j[px] < best)
+					best = A->j[px];
+			if (best > A->m)
+				continue;
+			if (qinv[best] == -1 || weight(i) < weight(qinv[best]))
+				found += take(i, best);
+		}
+		return found;
+	}
+
+	int free_columns()
+	{
+		std::vector<char> open((size_t) (A->m > 0 ? A->m : 1), 1);
+		for (int i = 0; i < A->n; i++)
+			if (pinv[i] >= 0)
+				for (i64 px = A->p[i]; px < A->p[i + 1]; px++)
+					open[A->j[px]] = 0;
+		int found = 0;
+		for (int i = 0; i < A->n; i++) {
+			if (pinv[i] >= 0)
+				continue;
+			for (i64 px = A->p[i]; px < A->p[i + 1]; px++) {
+				int j = A->j[px];
+				if (!open[j] || qinv[j] >= 0)
+					continue;
+				found += take(i, j);
+				for (i64 py = A->p[i]; py < A->p[i + 1]; py++)
+					open[A->j[py]] = 0;
+				break;
+			}
+		}
+		return found;
+	}
+
+	// mark[j]: 1 = candidate entry of the current row, -1 = reached / pivotal, 0 = untouched
+	int acyclic_greedy()
+	{
+		const int n = A->n, m = A->m;
+		std::vector<signed char> mark((size_t) (m > 0 ? m : 1), 0);
+		std::vector<int> fifo((size_t) (m > 0 ? m : 1));
+		int found = 0;
+		for (int i = 0; i < n; i++) {
+			if (pinv[i] >= 0)
+				continue;
+			int head = 0, tail = 0, candidates = 0;
+			for (i64 px = A->p[i]; px < A->p[i + 1]; px++) {
+				int j = A->j[px];
+				if (qinv[j] < 0) {
+					mark[j] = 1;
+					candidates += 1;
+				} else {
+					fifo[tail++] = j;
+					candidates -= mark[j];
+					mark[j] = -1;
+				}
+			}
+			while (head < tail && candidates > 0) {
+				int row = qinv[fifo[head++]];
+				if (row == -1)
+					continue;
+				for (i64 px = A->p[row]; px < A->p[row + 1]; px++) {
+					int j = A->j[px];
+					if (mark[j] >= 0) {
+						fifo[tail++] = j;
+						candidates -= mark[j];
+						mark[j] = -1;
+					}
+				}
+			}
+			if (candidates > 0) {
+				int chosen = -1;
+				for (i64 px = A->p[i]; px < A->p[i + 1]; px++) {
+					chosen = A->j[px];
+					if (mark[chosen] == 1)
+						break;
+				}
+				found += take(i, chosen);
+			}
+			for (i64 px = A->p[i]; px < A->p[i + 1]; px++)
+				mark[A->j[px]] = 0;
+			for (int t = 0; t < tail; t++)
+				mark[fifo[t]] = 0;
+		}
+		return found;
+	}
+
+	// reverse post-order of the pivot graph: a pivotal column precedes all
+	// the pivotal columns its row touches
+	void topological_rows(int npiv, int *p) const
+	{
+		const int n = A->n, m = A->m;
+		std::vector<int> order;
+		order.reserve((size_t) m);
+		std::vector<char> seen((size_t) (m > 0 ? m : 1), 0);
+		std::vector<int> stack_col, stack_pos;
+		for (int j0 = 0; j0 < m; j0++) {
+			if (qinv[j0] == -1 || seen[j0])
+				continue;
+			stack_col.assign(1, j0);
+			stack_pos.assign(1, 0);
+			seen[j0] = 1;
+			while (!stack_col.empty()) {
+				int j = stack_col.back();
+				int i = qinv[j];
+				bool down = false;
+				if (i >= 0) {
+					i64 base = A->p[i];
+					int w = weight(i);
+					for (int k = stack_pos.back(); k < w; k++) {
+						int jj = A->j[base + k];
+						if (seen[jj])
+							continue;
+						stack_pos.back() = k + 1;
+						seen[jj] = 1;
+						stack_col.push_back(jj);
+						stack_pos.push_back(0);
+						down = true;
+						break;
+					}
+				}
+				if (!down) {
+					order.push_back(j);
+					stack_col.pop_back();
+					stack_pos.pop_back();
+				}
+			}
+		}
+		// the reference fills its output from the end: later finishes come first
+		// within one tree, later trees come before earlier ones
+		int k = 0;
+		for (size_t t = order.size(); t-- > 0;) {
+			int i = qinv[order[t]];
+			if (i != -1)
+				p[k++] = i;
+		}
+		if (k != npiv)
+			die("pivot reordering lost pivots (%d != %d)", k, npiv);
+		for (int i = 0; i < n; i++)
+			if (pinv[i] == -1)
+				p[k++] = i;
+	}
+};
+
+}  // namespace
+
+extern "C" int spasm_hip_pivots_extract_structural(const struct spasm_csr *A, const int *p_in, struct spasm_lu *fact,
+                                                   int *p, struct echelonize_opts *opts)
+{
+	const int n = A->n, m = A->m;
+	const i64 prime = A->field->p;
+	double t0 = wtime();
+	Search S;
+	S.A = A;
+	S.pinv.assign((size_t) (n > 0 ? n : 1), -1);
+	S.qinv.assign((size_t) (m > 0 ? m : 1), -1);
+	int npiv = S.leftmost_entries();
+	logmsg("[pivots] Faugere-Lachartre: %d pivots found [%.1fs]\n", npiv, wtime() - t0);
+	double t1 = wtime();
+	int extra = S.free_columns();
+	npiv += extra;
+	logmsg("[pivots] Faugere-Lachartre on columns: %d pivots found [%.1fs]\n", extra, wtime() - t1);
+	if (opts == nullptr || opts->enable_greedy_pivot_search) {
+		t1 = wtime();
+		extra = S.acyclic_greedy();
+		npiv += extra;
+		logmsg("[pivots] greedy alternating cycle-free search: %d pivots found [%.1fs]\n", extra, wtime() - t1);
+	}
+	logmsg("[pivots] %d pivots found\n", npiv);
+	S.topological_rows(npiv, p);
+
+	struct spasm_csr *U = fact->U;
+	struct spasm_triplet *L = fact->Ltmp;
+	i64 unz = U->p[U->n];
+	i64 need = 0;
+	for (int t = 0; t < npiv; t++)
+		need += S.weight(p[t]);
+	if (unz + need > U->nzmax)
+		spasm_hip_csr_realloc(U, unz + need);
+	for (int t = 0; t < npiv; t++) {
+		const int i = p[t];
+		const int j = S.pinv[i];
+		fact->qinv[j] = U->n;
+		spasm_ZZp pivot = 0;
+		for (i64 px = A->p[i]; px < A->p[i + 1]; px++)
+			if (A->j[px] == j && A->x[px] != 0) {
+				pivot = A->x[px];
+				break;
+			}
+		if (pivot == 0)
+			die("structural pivot (%d, %d) has no value", i, j);
+		if (L != nullptr) {
+			int i_out = (p_in != nullptr) ? p_in[i] : i;
+			spasm_hip_add_entry(L, i_out, U->n, pivot);
+			fact->p[U->n] = i_out;
+		}
+		const spasm_ZZp scale = zp_inverse(prime, pivot);
+		U->j[unz] = j;
+		U->x[unz] = 1;
+		unz += 1;
+		for (i64 px = A->p[i]; px < A->p[i + 1]; px++) {
+			if (A->j[px] == j)
+				continue;
+			U->j[unz] = A->j[px];
+			U->x[unz] = zp_mul(prime, scale, A->x[px]);
+			unz += 1;
+		}
+		U->n += 1;
+		U->p[U->n] = unz;
+	}
+	return npiv;
+}

@@ -1,0 +1,298 @@
+// Host-side containers, field arithmetic, triplet->CSR, transpose.
+// Mirrors the reference's C API for these (spasm_util.c, spasm_ZZp.c,
+// spasm_triplet.c, spasm_transpose.c) behind spasm_hip_* names; every array is
+// malloc-owned so the reference's own free functions can release them.
+#include <sys/time.h>
+
+#include <vector>
+
+#include "common.h"
+
+namespace sh {
+
+double wtime()
+{
+	struct timeval tv;
+	gettimeofday(&tv, nullptr);
+	return (double) tv.tv_sec + 1e-6 * (double) tv.tv_usec;
+}
+
+int verbose()
+{
+	static int v = -1;
+	if (v < 0) {
+		const char *e = std::getenv("SPASM_HIP_VERBOSE");
+		v = (e == nullptr) ? 1 : std::atoi(e);
+	}
+	return v;
+}
+
+void logmsg(const char *fmt, ...)
+{
+	if (!verbose())
+		return;
+	va_list ap;
+	va_start(ap, fmt);
+	std::vfprintf(stderr, fmt, ap);
+	va_end(ap);
+	std::fflush(stderr);
+}
+
+spasm_ZZp zp_inverse(int64_t p, spasm_ZZp a)
+{
+	int64_t v = a < 0 ? (int64_t) a + p : (int64_t) a;
+	int64_t r0 = p, r1 = v, t0 = 0, t1 = 1;
+	while (r1 != 0) {
+		int64_t q = r0 / r1;
+		int64_t r2 = r0 - q * r1, t2 = t0 - q * t1;
+		r0 = r1; r1 = r2;
+		t0 = t1; t1 = t2;
+	}
+	return zp_balance(p, t0);
+}
+
+Mont mont_setup(int64_t prime)
+{
+	if (prime < 3 || prime > 0xfffffffbLL || (prime & 1) == 0)
+		die("modulus %lld unsupported on the GPU path (need an odd prime below 2^32)", (long long) prime);
+	Mont M;
+	M.p = (uint32_t) prime;
+	uint32_t inv = M.p;                 // Newton iteration: inv * p == 1 mod 2^32
+	for (int it = 0; it < 5; it++)
+		inv *= 2u - M.p * inv;
+	M.pinv = inv;
+	M.r1 = (uint32_t) ((1ULL << 32) % (uint64_t) prime);
+	M.r2 = (uint32_t) (((uint64_t) M.r1 * M.r1) % (uint64_t) prime);
+	M.half = M.p / 2;
+	return M;
+}
+
+}  // namespace sh
+
+using namespace sh;
+
+extern "C" {
+
+const char *spasm_hip_version(void) { return "spasm-hip 0.1 (gfx950)"; }
+
+void spasm_hip_field_init(i64 p, spasm_field F)
+{
+	F->p = p;
+	if (p < 0)
+		return;
+	F->halfp = p / 2;
+	F->mhalfp = p / 2 - p + 1;
+	F->dinvp = 1.0 / (double) p;
+}
+
+spasm_ZZp spasm_hip_ZZp_init(const spasm_field F, i64 x) { return zp_init(F->p, x); }
+spasm_ZZp spasm_hip_ZZp_add(const spasm_field F, spasm_ZZp a, spasm_ZZp b) { return zp_balance(F->p, (i64) a + b); }
+spasm_ZZp spasm_hip_ZZp_sub(const spasm_field F, spasm_ZZp a, spasm_ZZp b) { return zp_balance(F->p, (i64) a - b); }
+spasm_ZZp spasm_hip_ZZp_mul(const spasm_field F, spasm_ZZp a, spasm_ZZp b) { return zp_mul(F->p, a, b); }
+spasm_ZZp spasm_hip_ZZp_inverse(const spasm_field F, spasm_ZZp a) { return zp_inverse(F->p, a); }
+spasm_ZZp spasm_hip_ZZp_axpy(const spasm_field F, spasm_ZZp a, spasm_ZZp x, spasm_ZZp y)
+{
+	return zp_axpy(F->p, a, x, y);
+}
+
+struct spasm_csr *spasm_hip_csr_alloc(int n, int m, i64 nzmax, i64 prime, bool with_values)
+{
+	struct spasm_csr *A = (struct spasm_csr *) xmalloc(sizeof(*A));
+	spasm_hip_field_init(prime, A->field);
+	A->n = n;
+	A->m = m;
+	A->nzmax = nzmax;
+	A->p = (i64 *) xmalloc(((i64) n + 1) * sizeof(i64));
+	A->j = (int *) xmalloc(nzmax * sizeof(int));
+	A->x = with_values ? (spasm_ZZp *) xmalloc(nzmax * sizeof(spasm_ZZp)) : nullptr;
+	A->p[0] = 0;
+	return A;
+}
+
+void spasm_hip_csr_realloc(struct spasm_csr *A, i64 nzmax)
+{
+	if (nzmax < 0)
+		nzmax = A->p[A->n];
+	A->j = (int *) xrealloc(A->j, nzmax * sizeof(int));
+	if (A->x != nullptr)
+		A->x = (spasm_ZZp *) xrealloc(A->x, nzmax * sizeof(spasm_ZZp));
+	A->nzmax = nzmax;
+}
+
+void spasm_hip_csr_resize(struct spasm_csr *A, int n, int m)
+{
+	A->m = m;
+	A->p = (i64 *) xrealloc(A->p, ((i64) n + 1) * sizeof(i64));
+	if (A->n < n)
+		for (int i = A->n; i < n + 1; i++)
+			A->p[i] = A->p[A->n];
+	A->n = n;
+}
+
+void spasm_hip_csr_free(struct spasm_csr *A)
+{
+	if (A == nullptr)
+		return;
+	std::free(A->p);
+	std::free(A->j);
+	std::free(A->x);
+	std::free(A);
+}
+
+struct spasm_triplet *spasm_hip_triplet_alloc(int n, int m, i64 nzmax, i64 prime, bool with_values)
+{
+	struct spasm_triplet *T = (struct spasm_triplet *) xmalloc(sizeof(*T));
+	spasm_hip_field_init(prime, T->field);
+	T->n = n;
+	T->m = m;
+	T->nzmax = nzmax;
+	T->nz = 0;
+	T->i = (int *) xmalloc(nzmax * sizeof(int));
+	T->j = (int *) xmalloc(nzmax * sizeof(int));
+	T->x = with_values ? (spasm_ZZp *) xmalloc(nzmax * sizeof(spasm_ZZp)) : nullptr;
+	return T;
+}
+
+void spasm_hip_triplet_realloc(struct spasm_triplet *T, i64 nzmax)
+{
+	if (nzmax < 0)
+		nzmax = T->nz;
+	T->i = (int *) xrealloc(T->i, nzmax * sizeof(int));
+	T->j = (int *) xrealloc(T->j, nzmax * sizeof(int));
+	if (T->x != nullptr)
+		T->x = (spasm_ZZp *) xrealloc(T->x, nzmax * sizeof(spasm_ZZp));
+	T->nzmax = nzmax;
+}
+
+void spasm_hip_triplet_free(struct spasm_triplet *T)
+{
+	if (T == nullptr)
+		return;
+	std::free(T->i);
+	std::free(T->j);
+	std::free(T->x);
+	std::free(T);
+}
+
+void spasm_hip_lu_free(struct spasm_lu *N)
+{
+	if (N == nullptr)
+		return;
+	std::free(N->qinv);
+	std::free(N->p);
+	spasm_hip_csr_free(N->U);
+	spasm_hip_csr_free(N->L);
+	std::free(N);
+}
+
+void spasm_hip_add_entry(struct spasm_triplet *T, int i, int j, i64 x)
+{
+	if (i < 0 || j < 0)
+		die("spasm_hip_add_entry: negative index (%d, %d)", i, j);
+	if (T->nz == T->nzmax)
+		spasm_hip_triplet_realloc(T, 1 + 2 * T->nzmax);
+	if (T->x != nullptr) {
+		spasm_ZZp v = zp_init(T->field->p, x);
+		if (v == 0)
+			return;
+		T->x[T->nz] = v;
+	}
+	T->i[T->nz] = i;
+	T->j[T->nz] = j;
+	T->nz += 1;
+	if (i + 1 > T->n) T->n = i + 1;
+	if (j + 1 > T->m) T->m = j + 1;
+}
+
+void spasm_hip_triplet_transpose(struct spasm_triplet *T)
+{
+	int *t = T->i; T->i = T->j; T->j = t;
+	int d = T->n; T->n = T->m; T->m = d;
+}
+
+// Same observable result as the reference: entries keep file order inside a
+// row, a repeated (i, j) is summed into its first occurrence, zeros vanish.
+struct spasm_csr *spasm_hip_compress(const struct spasm_triplet *T)
+{
+	const int n = T->n, m = T->m;
+	const i64 nz = T->nz;
+	const i64 prime = T->field->p;
+	const bool vals = (T->x != nullptr);
+	struct spasm_csr *C = spasm_hip_csr_alloc(n, m, nz, prime, vals);
+	std::vector<i64> fill((size_t) n + 1, 0);
+	for (i64 k = 0; k < nz; k++) {
+		if (T->i[k] >= n || T->j[k] >= m)
+			die("spasm_hip_compress: entry (%d, %d) outside %d x %d", T->i[k], T->j[k], n, m);
+		fill[T->i[k] + 1] += 1;
+	}
+	for (int i = 0; i < n; i++)
+		fill[i + 1] += fill[i];
+	std::vector<i64> start(fill.begin(), fill.end());
+	std::vector<int> bj((size_t) (nz > 0 ? nz : 1));
+	std::vector<spasm_ZZp> bx((size_t) (vals && nz > 0 ? nz : 1));
+	for (i64 k = 0; k < nz; k++) {
+		i64 dst = fill[T->i[k]]++;
+		bj[dst] = T->j[k];
+		if (vals)
+			bx[dst] = T->x[k];
+	}
+	std::vector<i64> slot((size_t) (m > 0 ? m : 1), -1);
+	i64 out = 0;
+	C->p[0] = 0;
+	for (int i = 0; i < n; i++) {
+		const i64 row0 = out;
+		for (i64 px = start[i]; px < start[i + 1]; px++) {
+			const int j = bj[px];
+			if (slot[j] < row0) {
+				slot[j] = out;
+				C->j[out] = j;
+				if (vals)
+					C->x[out] = bx[px];
+				out += 1;
+			} else if (vals) {
+				C->x[slot[j]] = zp_balance(prime, (i64) C->x[slot[j]] + bx[px]);
+			}
+		}
+		if (vals) {                 // squeeze out entries that cancelled
+			i64 w = row0;
+			for (i64 px = row0; px < out; px++) {
+				if (C->x[px] == 0)
+					continue;
+				C->j[w] = C->j[px];
+				C->x[w] = C->x[px];
+				w += 1;
+			}
+			out = w;
+		}
+		for (i64 px = start[i]; px < start[i + 1]; px++)
+			slot[bj[px]] = -1;          // positions moved: forget this row's columns
+		C->p[i + 1] = out;
+	}
+	spasm_hip_csr_realloc(C, -1);
+	return C;
+}
+
+struct spasm_csr *spasm_hip_transpose(const struct spasm_csr *A, int keep_values)
+{
+	const int n = A->n, m = A->m;
+	const i64 nnz = A->p[n];
+	const bool vals = keep_values && (A->x != nullptr);
+	struct spasm_csr *T = spasm_hip_csr_alloc(m, n, nnz, A->field->p, vals);
+	std::vector<i64> w((size_t) m + 1, 0);
+	for (i64 px = 0; px < nnz; px++)
+		w[A->j[px] + 1] += 1;
+	for (int j = 0; j < m; j++)
+		w[j + 1] += w[j];
+	for (int j = 0; j <= m; j++)
+		T->p[j] = w[j];
+	for (int i = 0; i < n; i++)
+		for (i64 px = A->p[i]; px < A->p[i + 1]; px++) {
+			i64 dst = w[A->j[px]]++;
+			T->j[dst] = i;
+			if (vals)
+				T->x[dst] = A->x[px];
+		}
+	return T;
+}
+
+}  // extern "C"

@@ -1,0 +1,519 @@
+// Launchers and C ABI of the sparse Schur complement (see include/spasm_hip.h).
+#include <algorithm>
+#include <cinttypes>
+#include <vector>
+
+#include "device_types.h"
+
+namespace sh {
+void launch_schur_lds(const SchurArgs &a, int table, bool wide, int blocks, hipStream_t stream);
+size_t schur_lds_bytes(int table, bool wide);
+void launch_finalize(const spasm_hip_dwork *W, int nrows, int sort_rows, hipStream_t stream);
+void launch_schur_dense_tier(const SchurArgs &a, const spasm_hip_dwork *W, int blocks, hipStream_t stream);
+void launch_schur_dense_rows(const SchurArgs &a, const spasm_hip_dwork *W, uint32_t *dS, int64_t ldS, int blocks,
+                             hipStream_t stream);
+int dense_tier_slots();
+int64_t dense_tier_stride(int m);
+void launch_all_rows_to_list(int *list, int *count, int *row_len, int nrows, hipStream_t stream);
+}  // namespace sh
+
+using namespace sh;
+
+namespace {
+
+int env_int(const char *name, int dflt)
+{
+	const char *e = std::getenv(name);
+	return (e == nullptr || *e == 0) ? dflt : std::atoi(e);
+}
+
+template <typename T> T *dalloc(int64_t count)
+{
+	T *p = nullptr;
+	HIP_CHECK(hipMalloc((void **) &p, (size_t) (count > 0 ? count : 1) * sizeof(T)));
+	return p;
+}
+
+template <typename T> void upload(T *dst, const T *src, int64_t count, hipStream_t s)
+{
+	if (count > 0)
+		HIP_CHECK(hipMemcpyAsync(dst, src, (size_t) count * sizeof(T), hipMemcpyHostToDevice, s));
+}
+
+int cu_count()
+{
+	static int cus = 0;
+	if (cus == 0) {
+		int dev = 0;
+		HIP_CHECK(hipGetDevice(&dev));
+		hipDeviceProp_t prop;
+		HIP_CHECK(hipGetDeviceProperties(&prop, dev));
+		cus = prop.multiProcessorCount;
+	}
+	return cus;
+}
+
+}  // namespace
+
+extern "C" {
+
+int spasm_hip_debug_plan(const struct spasm_csr *U, const int *qinv, int *label_of_row, int *lvl_end, int *lab);
+
+int spasm_hip_device_count(void)
+{
+	int n = 0;
+	if (hipGetDeviceCount(&n) != hipSuccess)
+		return 0;
+	return n;
+}
+
+// --------------------------------------------------------------------------
+// factor image
+// --------------------------------------------------------------------------
+// Host part of the factor image: checks U, computes the elimination levels,
+// the column labels and the relabelled rows.  No GPU involved (unit-tested on
+// the CPU through spasm_hip_debug_plan).
+struct FactPlan {
+	int m = 0, r = 0, nlevels = 0;
+	i64 prime = 0;
+	std::vector<uint32_t> lab, lvl_end;
+	std::vector<int> q, kof, label_of_row;
+	std::vector<uint64_t> rp;
+	std::vector<uint2> ent;
+};
+
+static void plan_factor(const struct spasm_csr *U, const int *qinv, FactPlan &P)
+{
+	const int r = U->n, m = U->m;
+	const i64 prime = U->field->p;
+	P.m = m;
+	P.r = r;
+	P.prime = prime;
+	for (int k = 0; k < r; k++) {
+		if (U->p[k + 1] == U->p[k])
+			die("row %d of U is empty", k);
+		const int j = U->j[U->p[k]];
+		if (j < 0 || j >= m || qinv[j] != k)
+			die("row %d of U does not start with its pivot (column %d, qinv says row %d)", k, j, (j >= 0 && j < m) ? qinv[j] : -1);
+		if (U->x[U->p[k]] != 1)
+			die("pivot of row %d of U is not 1", k);
+	}
+	int npivcols = 0;
+	for (int j = 0; j < m; j++)
+		if (qinv[j] >= 0) {
+			if (qinv[j] >= r)
+				die("qinv[%d] = %d but U has %d rows", j, qinv[j], r);
+			npivcols += 1;
+		}
+	if (npivcols != r)
+		die("qinv marks %d pivotal columns but U has %d rows", npivcols, r);
+
+	// height of every pivot row in the dependency DAG (row k depends on the
+	// pivot rows of the pivotal columns it touches); iterative DFS
+	std::vector<int> height((size_t) (r > 0 ? r : 1), 0);
+	{
+		std::vector<unsigned char> state((size_t) (r > 0 ? r : 1), 0);   // 0 new, 1 open, 2 done
+		std::vector<int> stk;
+		std::vector<i64> pos;
+		for (int root = 0; root < r; root++) {
+			if (state[root])
+				continue;
+			stk.assign(1, root);
+			pos.assign(1, U->p[root] + 1);
+			state[root] = 1;
+			while (!stk.empty()) {
+				const int k = stk.back();
+				bool down = false;
+				for (i64 px = pos.back(); px < U->p[k + 1]; px++) {
+					const int k2 = qinv[U->j[px]];
+					if (k2 < 0)
+						continue;
+					if (k2 == k)
+						die("row %d of U holds its pivot column twice", k);
+					if (state[k2] == 1)
+						die("the pivots of U are not triangular (cycle through rows %d and %d)", k, k2);
+					if (state[k2] == 0) {
+						pos.back() = px;        // come back to this entry
+						state[k2] = 1;
+						stk.push_back(k2);
+						pos.push_back(U->p[k2] + 1);
+						down = true;
+						break;
+					}
+					if (height[k2] + 1 > height[k])
+						height[k] = height[k2] + 1;
+				}
+				if (!down) {
+					state[k] = 2;
+					stk.pop_back();
+					pos.pop_back();
+				}
+			}
+		}
+	}
+	int hmax = 0;
+	for (int k = 0; k < r; k++)
+		hmax = std::max(hmax, height[k]);
+	const int nlev = (r > 0) ? hmax + 1 : 0;
+	P.nlevels = nlev;
+	// level = hmax - height; stable counting sort -> label of each row
+	std::vector<int> lvl_start((size_t) nlev + 1, 0);
+	for (int k = 0; k < r; k++)
+		lvl_start[hmax - height[k] + 1] += 1;
+	for (int l = 0; l < nlev; l++)
+		lvl_start[l + 1] += lvl_start[l];
+	P.label_of_row.assign((size_t) (r > 0 ? r : 1), 0);
+	{
+		std::vector<int> cursor(lvl_start.begin(), lvl_start.end());
+		for (int k = 0; k < r; k++)
+			P.label_of_row[k] = cursor[hmax - height[k]]++;
+	}
+	P.lvl_end.assign((size_t) (r > 0 ? r : 1), 0);
+	P.kof.assign((size_t) (r > 0 ? r : 1), 0);
+	for (int k = 0; k < r; k++) {
+		P.lvl_end[P.label_of_row[k]] = (uint32_t) lvl_start[hmax - height[k] + 1];
+		P.kof[P.label_of_row[k]] = k;
+	}
+	// column labels
+	P.lab.assign((size_t) (m > 0 ? m : 1), 0);
+	P.q.assign((size_t) (m - r > 0 ? m - r : 1), 0);
+	{
+		int np = 0;
+		for (int j = 0; j < m; j++) {
+			if (qinv[j] >= 0) {
+				P.lab[j] = (uint32_t) P.label_of_row[qinv[j]];
+			} else {
+				P.lab[j] = (uint32_t) (r + np);
+				P.q[np] = j;
+				np += 1;
+			}
+		}
+	}
+	// rows of U' in label order, pivot entry dropped, values * R mod p
+	const i64 nnz = U->p[r] - r;
+	P.rp.assign((size_t) r + 1, 0);
+	P.ent.assign((size_t) (nnz > 0 ? nnz : 1), uint2{0, 0});
+	i64 w = 0;
+	for (int c = 0; c < r; c++) {
+		const int k = P.kof[c];
+		P.rp[c] = (uint64_t) w;
+		for (i64 px = U->p[k] + 1; px < U->p[k + 1]; px++) {
+			const uint64_t v = zp_unsigned(prime, U->x[px]);
+			uint2 e;
+			e.x = P.lab[U->j[px]];
+			e.y = (uint32_t) ((v << 32) % (uint64_t) prime);
+			P.ent[w++] = e;
+		}
+	}
+	P.rp[r] = (uint64_t) w;
+}
+
+// CPU-only view of the plan, for tests: label of each row of U, end of the
+// level of each label, label of each column.  Arrays sized r, r, m.
+int spasm_hip_debug_plan(const struct spasm_csr *U, const int *qinv, int *label_of_row, int *lvl_end, int *lab)
+{
+	FactPlan P;
+	plan_factor(U, qinv, P);
+	for (int k = 0; k < P.r; k++) {
+		label_of_row[k] = P.label_of_row[k];
+		lvl_end[k] = (int) P.lvl_end[k];
+	}
+	for (int j = 0; j < P.m; j++)
+		lab[j] = (int) P.lab[j];
+	return P.nlevels;
+}
+
+spasm_hip_dfact *spasm_hip_dfact_create(const struct spasm_csr *U, const int *qinv, void *stream_)
+{
+	hipStream_t stream = (hipStream_t) stream_;
+	if (spasm_hip_device_count() == 0)
+		die("spasm_hip_dfact_create: no HIP device (this library has no CPU path)");
+	FactPlan P;
+	plan_factor(U, qinv, P);
+	const int r = P.r, m = P.m;
+	spasm_hip_dfact *F = new spasm_hip_dfact();
+	F->m = m;
+	F->r = r;
+	F->Sm = m - r;
+	F->prime = P.prime;
+	F->mont = mont_setup(P.prime);
+	F->nlevels = P.nlevels;
+	F->nnz = (i64) P.rp[r];
+	F->h_q = P.q;
+	F->h_kof = P.kof;
+	F->d_lab = dalloc<uint32_t>(m);
+	F->d_q = dalloc<int>(m - r);
+	F->d_rp = dalloc<uint64_t>(r + 1);
+	F->d_ent = dalloc<uint2>(F->nnz);
+	F->d_lvl_end = dalloc<uint32_t>(r);
+	F->d_kof = dalloc<int>(r);
+	upload(F->d_lab, P.lab.data(), m, stream);
+	upload(F->d_q, P.q.data(), m - r, stream);
+	upload(F->d_rp, P.rp.data(), (i64) r + 1, stream);
+	upload(F->d_ent, P.ent.data(), F->nnz, stream);
+	upload(F->d_lvl_end, P.lvl_end.data(), r, stream);
+	upload(F->d_kof, P.kof.data(), r, stream);
+	HIP_CHECK(hipStreamSynchronize(stream));    // the host vectors die here
+	return F;
+}
+
+void spasm_hip_dfact_destroy(spasm_hip_dfact *F)
+{
+	if (F == nullptr)
+		return;
+	(void) hipFree(F->d_lab);
+	(void) hipFree(F->d_q);
+	(void) hipFree(F->d_rp);
+	(void) hipFree(F->d_ent);
+	(void) hipFree(F->d_lvl_end);
+	(void) hipFree(F->d_kof);
+	delete F;
+}
+
+int spasm_hip_dfact_rank(const spasm_hip_dfact *F) { return F->r; }
+int spasm_hip_dfact_levels(const spasm_hip_dfact *F) { return F->nlevels; }
+i64 spasm_hip_dfact_nnz(const spasm_hip_dfact *F) { return F->nnz; }
+
+// --------------------------------------------------------------------------
+// workspace
+// --------------------------------------------------------------------------
+spasm_hip_dwork *spasm_hip_dwork_create(int max_rows, int m, i64 pool_entries)
+{
+	spasm_hip_dwork *W = new spasm_hip_dwork();
+	W->max_rows = max_rows;
+	W->m = m;
+	W->pool_cap = pool_entries;
+	W->d_pool_j = dalloc<int>(pool_entries);
+	W->d_pool_x = dalloc<int>(pool_entries);
+	W->d_Sj = dalloc<int>(pool_entries);
+	W->d_Sx = dalloc<int>(pool_entries);
+	W->d_row_off = dalloc<int64_t>(max_rows);
+	W->d_row_len = dalloc<int>(max_rows);
+	W->d_ovf1 = dalloc<int>(max_rows);
+	W->d_ovf2 = dalloc<int>(max_rows);
+	W->d_Sp = dalloc<int64_t>((i64) max_rows + 1);
+	W->d_blocksum = dalloc<int64_t>((max_rows + 1023) / 1024 + 1);
+	W->d_ctr = dalloc<int>(CTR_COUNT);
+	W->d_ctr64 = dalloc<unsigned long long>(C64_COUNT);
+	W->dense_slots = dense_tier_slots();
+	W->dense_stride = dense_tier_stride(m);
+	W->d_dense = dalloc<uint32_t>((i64) W->dense_slots * W->dense_stride);
+	HIP_CHECK(hipMemset(W->d_dense, 0, (size_t) W->dense_slots * W->dense_stride * sizeof(uint32_t)));
+	for (int e = 0; e < 4; e++)
+		HIP_CHECK(hipEventCreate(&W->ev[e]));
+	return W;
+}
+
+void spasm_hip_dwork_destroy(spasm_hip_dwork *W)
+{
+	if (W == nullptr)
+		return;
+	(void) hipFree(W->d_pool_j);
+	(void) hipFree(W->d_pool_x);
+	(void) hipFree(W->d_Sj);
+	(void) hipFree(W->d_Sx);
+	(void) hipFree(W->d_row_off);
+	(void) hipFree(W->d_row_len);
+	(void) hipFree(W->d_ovf1);
+	(void) hipFree(W->d_ovf2);
+	(void) hipFree(W->d_Sp);
+	(void) hipFree(W->d_blocksum);
+	(void) hipFree(W->d_ctr);
+	(void) hipFree(W->d_ctr64);
+	(void) hipFree(W->d_dense);
+	for (int e = 0; e < 4; e++)
+		if (W->ev[e] != nullptr)
+			(void) hipEventDestroy(W->ev[e]);
+	delete W;
+}
+
+// --------------------------------------------------------------------------
+// device Schur complement: three tiers (small LDS table, large LDS table,
+// dense accumulator in HBM), then row pointers + gather/sort.
+// --------------------------------------------------------------------------
+int spasm_hip_dschur(const spasm_hip_dcsr *A, const int *d_rows, int nrows, const spasm_hip_dfact *F,
+                     spasm_hip_dwork *W, void *stream_, spasm_hip_schur_stats *stats)
+{
+	hipStream_t stream = (hipStream_t) stream_;
+	if (nrows > W->max_rows)
+		die("spasm_hip_dschur: %d rows but the workspace was sized for %d", nrows, W->max_rows);
+	if (A->m != F->m || W->m < F->m)
+		die("spasm_hip_dschur: column count mismatch (A %d, factor %d, workspace %d)", A->m, F->m, W->m);
+	const bool wide = (F->prime >= (1LL << 19));   // lazy 32-bit sums: (6144 + 1) * p must stay below 2^32
+	const int sort_rows = env_int("SPASM_HIP_SORT_ROWS", 1);
+	const int small_table = 1024, big_table = 8192;
+
+	HIP_CHECK(hipMemsetAsync(W->d_ctr, 0, CTR_COUNT * sizeof(int), stream));
+	HIP_CHECK(hipMemsetAsync(W->d_ctr64, 0, C64_COUNT * sizeof(unsigned long long), stream));
+	HIP_CHECK(hipEventRecord(W->ev[0], stream));
+
+	SchurArgs a{};
+	a.Ap = A->p;
+	a.Aj = A->j;
+	a.Ax = A->x;
+	a.rows = d_rows;
+	a.nrows = nrows;
+	a.lab = F->d_lab;
+	a.q = F->d_q;
+	a.rp = F->d_rp;
+	a.ent = F->d_ent;
+	a.lvl_end = F->d_lvl_end;
+	a.r = F->r;
+	a.m = F->m;
+	a.F = to_dev(F->mont);
+	a.pool_j = W->d_pool_j;
+	a.pool_x = W->d_pool_x;
+	a.pool_cap = W->pool_cap;
+	a.row_off = W->d_row_off;
+	a.row_len = W->d_row_len;
+	a.ctr = W->d_ctr;
+	a.ctr64 = W->d_ctr64;
+
+	const int cus = cu_count();
+	const int force_tier = env_int("SPASM_HIP_FORCE_TIER", 0);     // tests: 1 = start at the large table, 2 = dense tier only
+	if (nrows > 0) {
+		// tier 0: small table, many waves per CU
+		a.list = nullptr;
+		a.list_count = nullptr;
+		a.ovf_list = W->d_ovf1;
+		a.next_ctr = CTR_ROW_NEXT;
+		a.ovf_ctr = CTR_OVF1;
+		a.done_ctr = CTR_DONE0;
+		const int per_cu0 = (int) std::min<size_t>(16, (size_t) (160 * 1024) / schur_lds_bytes(small_table, wide));
+		int blocks0 = std::min(cus * per_cu0 * env_int("SPASM_HIP_OVERSUB", 1), (nrows + 3) / 4);
+		if (force_tier == 0)
+			launch_schur_lds(a, small_table, wide, std::max(blocks0, 1), stream);
+		else
+			launch_all_rows_to_list(W->d_ovf1, W->d_ctr + CTR_OVF1, W->d_row_len, nrows, stream);
+		// tier 1: rows that did not fit, large table (one wave per CU)
+		a.list = W->d_ovf1;
+		a.list_count = W->d_ctr + CTR_OVF1;
+		a.ovf_list = W->d_ovf2;
+		a.next_ctr = CTR_ROW_NEXT2;
+		a.ovf_ctr = CTR_OVF2;
+		a.done_ctr = CTR_DONE1;
+		if (force_tier <= 1)
+			launch_schur_lds(a, big_table, wide, cus, stream);
+		else
+			launch_all_rows_to_list(W->d_ovf2, W->d_ctr + CTR_OVF2, W->d_row_len, nrows, stream);
+		// tier 2: dense accumulator in HBM, one workgroup per row
+		a.list = W->d_ovf2;
+		a.list_count = W->d_ctr + CTR_OVF2;
+		a.ovf_list = nullptr;
+		a.next_ctr = CTR_ROW_NEXT3;
+		a.ovf_ctr = CTR_OVF2;
+		a.done_ctr = CTR_DONE2;
+		launch_schur_dense_tier(a, W, W->dense_slots, stream);
+	}
+	HIP_CHECK(hipEventRecord(W->ev[1], stream));
+	launch_finalize(W, nrows, sort_rows, stream);
+	HIP_CHECK(hipEventRecord(W->ev[2], stream));
+
+	int ctr[CTR_COUNT];
+	unsigned long long ctr64[C64_COUNT];
+	i64 total = 0;
+	HIP_CHECK(hipMemcpyAsync(ctr, W->d_ctr, sizeof(ctr), hipMemcpyDeviceToHost, stream));
+	HIP_CHECK(hipMemcpyAsync(ctr64, W->d_ctr64, sizeof(ctr64), hipMemcpyDeviceToHost, stream));
+	HIP_CHECK(hipMemcpyAsync(&total, W->d_Sp + nrows, sizeof(i64), hipMemcpyDeviceToHost, stream));
+	HIP_CHECK(hipStreamSynchronize(stream));
+	W->last_rows = nrows;
+	W->last_nnz = total;
+	const int status = (ctr[CTR_STATUS] & 1) ? 1 : 0;
+	if (stats != nullptr) {
+		stats->nnz = total;
+		stats->eliminations = (i64) ctr64[C64_ELIM];
+		stats->entries_streamed = (i64) ctr64[C64_STREAM];
+		stats->input_entries = (i64) ctr64[C64_INPUT];
+		stats->rows = nrows;
+		stats->rows_lds = ctr[CTR_DONE0];
+		stats->rows_lds_big = ctr[CTR_DONE1];
+		stats->rows_dense = ctr[CTR_DONE2];
+		stats->status = status;
+		HIP_CHECK(hipEventElapsedTime(&stats->ms_eliminate, W->ev[0], W->ev[1]));
+		HIP_CHECK(hipEventElapsedTime(&stats->ms_total, W->ev[0], W->ev[2]));
+	}
+	return status;
+}
+
+void spasm_hip_dschur_fetch(const spasm_hip_dwork *W, i64 *d_Sp, int *d_Sj, spasm_ZZp *d_Sx, void *stream_)
+{
+	hipStream_t stream = (hipStream_t) stream_;
+	HIP_CHECK(hipMemcpyAsync(d_Sp, W->d_Sp, ((size_t) W->last_rows + 1) * sizeof(i64), hipMemcpyDefault, stream));
+	if (W->last_nnz > 0) {
+		HIP_CHECK(hipMemcpyAsync(d_Sj, W->d_Sj, (size_t) W->last_nnz * sizeof(int), hipMemcpyDefault, stream));
+		HIP_CHECK(hipMemcpyAsync(d_Sx, W->d_Sx, (size_t) W->last_nnz * sizeof(int), hipMemcpyDefault, stream));
+	}
+	HIP_CHECK(hipStreamSynchronize(stream));
+}
+
+// --------------------------------------------------------------------------
+// host-pointer drop-in for spasm_schur
+// --------------------------------------------------------------------------
+struct spasm_csr *spasm_hip_schur(const struct spasm_csr *A, const int *p, int n, const struct spasm_lu *fact,
+                                  double est_density, struct spasm_triplet *L, const int *p_in, int *p_out)
+{
+	if (spasm_hip_device_count() == 0)
+		die("spasm_hip_schur: no HIP device (this library has no CPU path)");
+	if (p == nullptr)
+		die("spasm_hip_schur: the row list p must not be NULL");
+	if (L != nullptr)
+		die("spasm_hip_schur: recording L on the GPU path is not available yet; run with opts->L = 0");
+	const int m = A->m;
+	const i64 prime = A->field->p;
+	const double t0 = wtime();
+	hipStream_t stream = nullptr;
+	spasm_hip_dfact *F = spasm_hip_dfact_create(fact->U, fact->qinv, stream);
+	// device image of A and of the row list
+	const i64 annz = A->p[A->n];
+	i64 *dAp = dalloc<i64>((i64) A->n + 1);
+	int *dAj = dalloc<int>(annz);
+	int *dAx = dalloc<int>(annz);
+	int *drows = dalloc<int>(n);
+	upload(dAp, A->p, (i64) A->n + 1, stream);
+	upload(dAj, A->j, annz, stream);
+	upload(dAx, A->x, annz, stream);
+	upload(drows, p, n, stream);
+	spasm_hip_dcsr dA{A->n, m, annz, dAp, dAj, dAx};
+
+	if (est_density < 0)
+		est_density = 0.0;     // the pool below is grown on demand instead of being estimated
+	i64 in_nnz = 0;
+	for (int k = 0; k < n; k++)
+		in_nnz += A->p[p[k] + 1] - A->p[p[k]];
+	i64 pool = std::max<i64>((i64) (est_density * n * (double) m * 1.5), 4 * in_nnz) + (i64) 4096 * 4096;
+	const i64 pool_max = (i64) n * (i64) (m - F->r) + (i64) 4096 * 4096;
+	pool = std::min(pool, pool_max);
+	spasm_hip_schur_stats st{};
+	spasm_hip_dwork *W = nullptr;
+	for (;;) {
+		W = spasm_hip_dwork_create(n, m, pool);
+		if (spasm_hip_dschur(&dA, drows, n, F, W, stream, &st) == 0)
+			break;
+		spasm_hip_dwork_destroy(W);
+		if (pool >= pool_max)
+			die("spasm_hip_schur: pool of %" PRId64 " entries still too small", pool);
+		pool = std::min(pool_max, 2 * pool + m);
+		logmsg("[schur/hip] pool too small, retrying with %" PRId64 " entries\n", pool);
+	}
+	struct spasm_csr *S = spasm_hip_csr_alloc(n, m, st.nnz, prime, true);
+	HIP_CHECK(hipMemcpy(S->p, W->d_Sp, ((size_t) n + 1) * sizeof(i64), hipMemcpyDeviceToHost));
+	if (st.nnz > 0) {
+		HIP_CHECK(hipMemcpy(S->j, W->d_Sj, (size_t) st.nnz * sizeof(int), hipMemcpyDeviceToHost));
+		HIP_CHECK(hipMemcpy(S->x, W->d_Sx, (size_t) st.nnz * sizeof(int), hipMemcpyDeviceToHost));
+	}
+	if (p_out != nullptr)
+		for (int k = 0; k < n; k++)
+			p_out[k] = (p_in != nullptr) ? p_in[p[k]] : p[k];
+	spasm_hip_dwork_destroy(W);
+	(void) hipFree(dAp);
+	(void) hipFree(dAj);
+	(void) hipFree(dAx);
+	(void) hipFree(drows);
+	spasm_hip_dfact_destroy(F);
+	const double density = (n > 0 && m > 0) ? (double) st.nnz / ((double) m * n) : 0.0;
+	logmsg("Schur complement: %d * %d [%" PRId64 " nz / density= %.3f], %.1fs (GPU kernels %.1f ms; tiers %d/%d/%d)\n", n, m,
+	       st.nnz, density, wtime() - t0, st.ms_total, st.rows_lds, st.rows_lds_big, st.rows_dense);
+	return S;
+}
+
+}  // extern "C"

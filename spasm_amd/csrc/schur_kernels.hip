@@ -1,0 +1,937 @@
+// HIP kernels (gfx950 / CDNA4, wave64) for the sparse Schur complement.
+//
+// One wavefront reduces one row of A against the factor.  The running row
+// lives in an LDS hash table private to the wave (keys = column labels,
+// values = lazily reduced sums); pivotal columns still to be eliminated sit
+// in an LDS pending list.  Labels are assigned so that pivots are sorted by
+// elimination level: every pending pivot of the lowest level present can be
+// eliminated in the same step, and the rows of U' they select are streamed
+// with coalesced 8-byte loads, flattened over the 64 lanes.
+// See DESIGN.md ("Kernels") for the algorithm and its byte accounting.
+#include "device_types.h"
+
+namespace sh {
+
+namespace {
+
+constexpr uint32_t EMPTY = 0xFFFFFFFFu;
+constexpr int ROWS_PER_GRAB = 4;
+constexpr int POOL_CHUNK = 2048;        // entries reserved from the pool at a time
+
+__device__ __forceinline__ uint32_t montmul(uint32_t a, uint32_t b, const MontDev &F)
+{
+	// a * b * 2^-32 mod p, for a * b < p * 2^32; result in [0, p)
+	uint64_t t = (uint64_t) a * b;
+	uint32_t mq = (uint32_t) t * F.pinv;
+	uint32_t q = __umulhi(mq, F.p);
+	uint32_t th = (uint32_t) (t >> 32);
+	uint32_t r = th - q;
+	return (th < q) ? r + F.p : r;
+}
+
+__device__ __forceinline__ uint32_t reduce_sum(uint32_t v, const MontDev &F) { return montmul(v, F.r1, F); }
+
+__device__ __forceinline__ uint32_t reduce_sum(unsigned long long v, const MontDev &F)
+{
+	uint32_t a = montmul((uint32_t) (v >> 32), F.r2, F);
+	uint32_t b = montmul((uint32_t) v, F.r1, F);
+	uint32_t s = a + b;
+	if (s < a || s >= F.p)
+		s -= F.p;
+	return s;
+}
+
+__device__ __forceinline__ int to_balanced(uint32_t v, const MontDev &F)
+{
+	return (v > F.half) ? (int) (v - F.p) : (int) v;
+}
+
+__device__ __forceinline__ uint32_t from_balanced(int a, const MontDev &F)
+{
+	return (a < 0) ? (uint32_t) a + F.p : (uint32_t) a;
+}
+
+__device__ __forceinline__ uint64_t lanes_below(int lane) { return (1ull << lane) - 1ull; }
+
+__device__ __forceinline__ int wave_exclusive_scan(int v, int lane, int &total)
+{
+	int x = v;
+#pragma unroll
+	for (int d = 1; d < 64; d <<= 1) {
+		int y = __shfl_up(x, d);
+		if (lane >= d)
+			x += y;
+	}
+	total = __shfl(x, 63);
+	return x - v;
+}
+
+__device__ __forceinline__ uint32_t wave_min(uint32_t v)
+{
+#pragma unroll
+	for (int d = 32; d >= 1; d >>= 1) {
+		uint32_t o = (uint32_t) __shfl_xor((int) v, d);
+		v = (o < v) ? o : v;
+	}
+	return v;
+}
+
+template <bool WIDE> struct Acc { using type = uint32_t; };
+template <> struct Acc<true> { using type = unsigned long long; };
+
+template <int H> __device__ __forceinline__ uint32_t slot_of(uint32_t c)
+{
+	constexpr int LOG = (H == 1024) ? 10 : (H == 2048) ? 11 : (H == 4096) ? 12 : 13;
+	static_assert(H == 1024 || H == 2048 || H == 4096 || H == 8192, "table size");
+	return (c * 0x9E3779B1u) >> (32 - LOG);
+}
+
+// LDS image of one wave.  vals first (8-byte aligned when WIDE).
+template <int H, bool WIDE> struct WaveLds {
+	using V = typename Acc<WIDE>::type;
+	static constexpr int PCAP = H / 2;
+	V vals[H];
+	uint32_t keys[H];
+	uint32_t pend[2][PCAP];
+	uint32_t cnt[4];
+};
+
+// x[c] += delta.  Returns true when c was not in the table before.  New
+// pivotal labels (c < r) are appended to the pending list.
+template <int H, bool WIDE>
+__device__ __forceinline__ bool table_add(WaveLds<H, WIDE> *T, uint32_t c, uint32_t delta,
+                                          int which, uint32_t r)
+{
+	using V = typename Acc<WIDE>::type;
+	volatile uint32_t *keys = T->keys;
+	uint32_t s = slot_of<H>(c);
+	bool fresh = false;
+	for (;;) {
+		uint32_t k = keys[s];
+		if (k == c)
+			break;
+		if (k == EMPTY) {
+			uint32_t old = atomicCAS(&T->keys[s], EMPTY, c);
+			if (old == EMPTY) {
+				fresh = true;
+				break;
+			}
+			if (old == c)
+				break;
+		}
+		s = (s + 1) & (H - 1);
+	}
+	atomicAdd(&T->vals[s], (V) delta);
+	if (fresh && c < r) {
+		uint32_t pos = atomicAdd(&T->cnt[which], 1u);
+		((volatile uint32_t *) T->pend[which])[pos] = c;
+	}
+	return fresh;
+}
+
+template <int H, bool WIDE>
+__device__ __forceinline__ typename Acc<WIDE>::type table_get(WaveLds<H, WIDE> *T, uint32_t c)
+{
+	using V = typename Acc<WIDE>::type;
+	volatile uint32_t *keys = T->keys;
+	uint32_t s = slot_of<H>(c);
+	for (int guard = 0; guard < H; guard++) {
+		if (keys[s] == c)
+			return ((volatile V *) T->vals)[s];
+		s = (s + 1) & (H - 1);
+	}
+	return 0;
+}
+
+}  // namespace
+
+// --------------------------------------------------------------------------
+// K1: one wave per row, LDS hash accumulator.
+// --------------------------------------------------------------------------
+template <int H, bool WIDE>
+__global__ __launch_bounds__(64) void schur_lds_kernel(SchurArgs a)
+{
+	extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
+	using L = WaveLds<H, WIDE>;
+	using V = typename Acc<WIDE>::type;
+	L *T = reinterpret_cast<L *>(lds_raw);
+	constexpr int PCAP = L::PCAP;
+	constexpr int CAPK = (H * 3) / 4 - 64;      // keys allowed before a batch of 64 inserts
+	constexpr int CAPP = PCAP - 64;
+	const int lane = threadIdx.x;
+	const uint32_t r = (uint32_t) a.r;
+	const MontDev F = a.F;
+	const int total_rows = (a.list != nullptr) ? *a.list_count : a.nrows;
+
+	int64_t arena_off = 0;
+	int arena_left = 0;
+	unsigned long long st_elim = 0, st_stream = 0, st_input = 0;
+	int st_done = 0;
+
+	for (;;) {
+		int kbase = 0;
+		if (lane == 0)
+			kbase = atomicAdd(&a.ctr[a.next_ctr], ROWS_PER_GRAB);
+		kbase = __builtin_amdgcn_readfirstlane(kbase);
+		if (kbase >= total_rows)
+			break;
+		const int kend = (kbase + ROWS_PER_GRAB < total_rows) ? kbase + ROWS_PER_GRAB : total_rows;
+		for (int kk = kbase; kk < kend; kk++) {
+			const int k = (a.list != nullptr) ? a.list[kk] : kk;
+			const int i = a.rows[k];
+
+			// ---- reset the table ----
+			for (int s = lane; s < H; s += 64) {
+				T->keys[s] = EMPTY;
+				T->vals[s] = 0;
+			}
+			if (lane < 4)
+				T->cnt[lane] = 0;
+			__builtin_amdgcn_wave_barrier();
+			__builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+
+			int nkeys = 0;
+			bool overflow = false;
+
+			// ---- scatter the input row (relabelled on the fly) ----
+			const int64_t lo = a.Ap[i], hi = a.Ap[i + 1];
+			st_input += (unsigned long long) (hi - lo);
+			for (int64_t base = lo; base < hi; base += 64) {
+				uint32_t pc = ((volatile uint32_t *) T->cnt)[0];
+				if (nkeys > CAPK || (int) pc > CAPP) {
+					overflow = true;
+					break;
+				}
+				const int64_t px = base + lane;
+				bool fresh = false;
+				if (px < hi) {
+					const int j = a.Aj[px];
+					const uint32_t c = a.lab[j];
+					const uint32_t v = from_balanced(a.Ax[px], F);
+					fresh = table_add<H, WIDE>(T, c, v, 0, r);
+				}
+				nkeys += __popcll(__ballot(fresh));
+			}
+
+			// ---- eliminate, one level per step ----
+			int cur = 0;
+			while (!overflow) {
+				__builtin_amdgcn_wave_barrier();
+				const int P = (int) ((volatile uint32_t *) T->cnt)[cur];
+				if (P == 0)
+					break;
+				volatile uint32_t *pcur = T->pend[cur];
+				uint32_t cmin = EMPTY;
+				for (int t = lane; t < P; t += 64) {
+					uint32_t c = pcur[t];
+					cmin = (c < cmin) ? c : cmin;
+				}
+				cmin = wave_min(cmin);
+				const uint32_t lend = a.lvl_end[__builtin_amdgcn_readfirstlane(cmin)];
+				const int nxt = cur ^ 1;
+				if (lane == 0)
+					((volatile uint32_t *) T->cnt)[nxt] = 0;
+				__builtin_amdgcn_wave_barrier();
+
+				for (int base = 0; base < P && !overflow; base += 64) {
+					if ((int) ((volatile uint32_t *) T->cnt)[nxt] > CAPP) {
+						overflow = true;
+						break;
+					}
+					const int t = base + lane;
+					const bool valid = t < P;
+					const uint32_t c = valid ? pcur[t] : EMPTY;
+					const bool sel = valid && (c < lend);
+					const bool keep = valid && !sel;
+					// survivors move to the other list
+					const uint64_t mk = __ballot(keep);
+					if (mk != 0) {
+						uint32_t off = 0;
+						if (lane == 0)
+							off = atomicAdd(&T->cnt[nxt], (uint32_t) __popcll(mk));
+						off = __builtin_amdgcn_readfirstlane(off);
+						if (keep)
+							((volatile uint32_t *) T->pend[nxt])[off + __popcll(mk & lanes_below(lane))] = c;
+					}
+					const uint64_t ms = __ballot(sel);
+					if (ms == 0)
+						continue;
+					// coefficient and row extent of each selected pivot
+					uint32_t v = 0;
+					if (sel)
+						v = reduce_sum(table_get<H, WIDE>(T, c), F);
+					int len = 0;
+					uint64_t start = 0;
+					if (v != 0) {
+						start = a.rp[c];
+						len = (int) (a.rp[c + 1] - start);
+					}
+					const uint32_t w = F.p - v;           // -v mod p (only used when v != 0)
+					st_elim += (unsigned long long) __popcll(__ballot(v != 0));
+					int tot;
+					const int excl = wave_exclusive_scan(len, lane, tot);
+					st_stream += (unsigned long long) tot;
+					const uint32_t start_lo = (uint32_t) start, start_hi = (uint32_t) (start >> 32);
+					for (int f0 = 0; f0 < tot; f0 += 64) {
+						uint32_t pc = ((volatile uint32_t *) T->cnt)[nxt];
+						if (nkeys > CAPK || (int) pc > CAPP) {
+							overflow = true;
+							break;
+						}
+						const int f = f0 + lane;
+						int owner = 0;
+#pragma unroll
+						for (int step = 32; step >= 1; step >>= 1) {
+							const int cand = owner + step;
+							const int e = __shfl(excl, cand);
+							if (e <= f)
+								owner = cand;
+						}
+						const uint32_t o_lo = (uint32_t) __shfl((int) start_lo, owner);
+						const uint32_t o_hi = (uint32_t) __shfl((int) start_hi, owner);
+						const uint32_t o_w = (uint32_t) __shfl((int) w, owner);
+						const int o_ex = __shfl(excl, owner);
+						bool fresh = false;
+						if (f < tot) {
+							const uint64_t idx = (((uint64_t) o_hi << 32) | o_lo) + (uint64_t) (f - o_ex);
+							const uint2 e = a.ent[idx];
+							const uint32_t delta = montmul(o_w, e.y, F);
+							fresh = table_add<H, WIDE>(T, e.x, delta, nxt, r);
+						}
+						nkeys += __popcll(__ballot(fresh));
+					}
+				}
+				cur = nxt;
+			}
+
+			if (overflow) {
+				if (lane == 0) {
+					int pos = atomicAdd(&a.ctr[a.ovf_ctr], 1);
+					a.ovf_list[pos] = k;
+					a.row_len[k] = -2;
+				}
+				continue;
+			}
+
+			// ---- emit the non-pivotal, non-zero entries ----
+			__builtin_amdgcn_wave_barrier();
+			int count = 0;
+			for (int s0 = 0; s0 < H; s0 += 64) {
+				const int s = s0 + lane;
+				const uint32_t key = ((volatile uint32_t *) T->keys)[s];
+				bool keep = (key != EMPTY) && (key >= r);
+				if (keep)
+					keep = reduce_sum(((volatile V *) T->vals)[s], F) != 0;
+				count += __popcll(__ballot(keep));
+			}
+			if (count > arena_left) {
+				const int want = (count > POOL_CHUNK) ? count : POOL_CHUNK;
+				unsigned long long got = 0;
+				if (lane == 0)
+					got = atomicAdd(&a.ctr64[C64_POOL], (unsigned long long) want);
+				const uint32_t g_lo = __builtin_amdgcn_readfirstlane((uint32_t) got);
+				const uint32_t g_hi = __builtin_amdgcn_readfirstlane((uint32_t) (got >> 32));
+				arena_off = (int64_t) (((uint64_t) g_hi << 32) | g_lo);
+				arena_left = want;
+				if (arena_off + want > a.pool_cap) {
+					arena_left = 0;
+					if (lane == 0) {
+						atomicOr(&a.ctr[CTR_STATUS], 1);
+						a.row_len[k] = -1;
+					}
+					continue;
+				}
+			}
+			int64_t wpos = arena_off;
+			for (int s0 = 0; s0 < H; s0 += 64) {
+				const int s = s0 + lane;
+				const uint32_t key = ((volatile uint32_t *) T->keys)[s];
+				bool keep = (key != EMPTY) && (key >= r);
+				uint32_t v = 0;
+				if (keep) {
+					v = reduce_sum(((volatile V *) T->vals)[s], F);
+					keep = v != 0;
+				}
+				const uint64_t mk = __ballot(keep);
+				if (keep) {
+					const int64_t dst = wpos + __popcll(mk & lanes_below(lane));
+					a.pool_j[dst] = a.q[key - r];
+					a.pool_x[dst] = to_balanced(v, F);
+				}
+				wpos += __popcll(mk);
+			}
+			if (lane == 0) {
+				a.row_off[k] = arena_off;
+				a.row_len[k] = count;
+			}
+			arena_off += count;
+			arena_left -= count;
+			st_done += 1;
+		}
+	}
+	if (lane == 0) {
+		atomicAdd(&a.ctr64[C64_ELIM], st_elim);
+		atomicAdd(&a.ctr64[C64_STREAM], st_stream);
+		atomicAdd(&a.ctr64[C64_INPUT], st_input);
+		atomicAdd(&a.ctr[a.done_ctr], st_done);
+	}
+}
+
+// --------------------------------------------------------------------------
+// K3: row lengths -> row pointers (three small passes), then gather + sort.
+// --------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void scan_block_sums(const int *row_len, int n, int64_t *blocksum)
+{
+	__shared__ int64_t part[256];
+	const int tid = threadIdx.x;
+	const int64_t base = (int64_t) blockIdx.x * 1024;
+	int64_t s = 0;
+	for (int t = 0; t < 4; t++) {
+		int64_t idx = base + tid * 4 + t;
+		if (idx < n) {
+			int l = row_len[idx];
+			s += (l > 0) ? l : 0;
+		}
+	}
+	part[tid] = s;
+	__syncthreads();
+	for (int d = 128; d > 0; d >>= 1) {
+		if (tid < d)
+			part[tid] += part[tid + d];
+		__syncthreads();
+	}
+	if (tid == 0)
+		blocksum[blockIdx.x] = part[0];
+}
+
+__global__ __launch_bounds__(256) void scan_of_sums(int64_t *blocksum, int nblocks)
+{
+	// single block: exclusive scan of up to a few hundred thousand block sums
+	__shared__ int64_t carry;
+	__shared__ int64_t buf[256];
+	const int tid = threadIdx.x;
+	if (tid == 0)
+		carry = 0;
+	__syncthreads();
+	for (int base = 0; base < nblocks; base += 256) {
+		int64_t v = (base + tid < nblocks) ? blocksum[base + tid] : 0;
+		buf[tid] = v;
+		__syncthreads();
+		for (int d = 1; d < 256; d <<= 1) {
+			int64_t add = (tid >= d) ? buf[tid - d] : 0;
+			__syncthreads();
+			buf[tid] += add;
+			__syncthreads();
+		}
+		int64_t incl = buf[tid];
+		int64_t c = carry;
+		__syncthreads();
+		if (base + tid < nblocks)
+			blocksum[base + tid] = c + incl - v;
+		if (tid == 255)
+			carry = c + incl;
+		__syncthreads();
+	}
+}
+
+__global__ __launch_bounds__(256) void scan_finish(const int *row_len, int n, const int64_t *blocksum, int64_t *Sp)
+{
+	__shared__ int64_t part[256];
+	const int tid = threadIdx.x;
+	const int64_t base = (int64_t) blockIdx.x * 1024;
+	int l[4];
+	int64_t s = 0;
+	for (int t = 0; t < 4; t++) {
+		int64_t idx = base + tid * 4 + t;
+		int v = (idx < n) ? row_len[idx] : 0;
+		l[t] = (v > 0) ? v : 0;
+		s += l[t];
+	}
+	part[tid] = s;
+	__syncthreads();
+	for (int d = 1; d < 256; d <<= 1) {
+		int64_t add = (tid >= d) ? part[tid - d] : 0;
+		__syncthreads();
+		part[tid] += add;
+		__syncthreads();
+	}
+	int64_t run = blocksum[blockIdx.x] + part[tid] - s;
+	for (int t = 0; t < 4; t++) {
+		int64_t idx = base + tid * 4 + t;
+		if (idx < n)
+			Sp[idx] = run;
+		run += l[t];
+	}
+	if (blockIdx.x == gridDim.x - 1 && tid == 255)
+		Sp[n] = run;
+}
+
+// one wave per row: copy from the pool to its final place, sorted by column.
+// Launched twice: rows of at most SORT_SMALL entries (small LDS footprint,
+// many waves per CU), then the few longer ones with a 64 KiB sort buffer.
+constexpr int SORT_SMALL = 1024;
+constexpr int SORT_LDS_MAX = 8192;
+
+template <int CAP>
+__global__ __launch_bounds__(64) void gather_rows_kernel(const int *pool_j, const int *pool_x, const int64_t *row_off,
+                                                        const int *row_len, int n, const int64_t *Sp, int *Sj, int *Sx,
+                                                        int sort_rows, int len_lo, int len_hi)
+{
+	__shared__ int kj[CAP];
+	__shared__ int kx[CAP];
+	const int lane = threadIdx.x;
+	for (int k = blockIdx.x; k < n; k += gridDim.x) {
+		const int len = row_len[k];
+		if (len <= len_lo || len > len_hi)
+			continue;
+		const int64_t raw = row_off[k];
+		const bool presorted = (raw >> 62) & 1;
+		const int64_t src = raw & ~(1LL << 62);
+		const int64_t dst = Sp[k];
+		if (!sort_rows || presorted || len > CAP) {
+			for (int t = lane; t < len; t += 64) {
+				Sj[dst + t] = pool_j[src + t];
+				Sx[dst + t] = pool_x[src + t];
+			}
+			continue;
+		}
+		if (len <= 64) {
+			int key = (lane < len) ? pool_j[src + lane] : 0x7FFFFFFF;
+			int val = (lane < len) ? pool_x[src + lane] : 0;
+#pragma unroll
+			for (int kk = 2; kk <= 64; kk <<= 1) {
+#pragma unroll
+				for (int jj = kk >> 1; jj > 0; jj >>= 1) {
+					const int pk = __shfl_xor(key, jj);
+					const int pv = __shfl_xor(val, jj);
+					const bool asc = (lane & kk) == 0;
+					const bool lower = (lane & jj) == 0;
+					const bool want_min = (lower == asc);
+					const bool take = want_min ? (pk < key) : (pk > key);
+					if (take) {
+						key = pk;
+						val = pv;
+					}
+				}
+			}
+			if (lane < len) {
+				Sj[dst + lane] = key;
+				Sx[dst + lane] = val;
+			}
+			continue;
+		}
+		int n2 = 128;
+		while (n2 < len)
+			n2 <<= 1;
+		for (int t = lane; t < n2; t += 64) {
+			kj[t] = (t < len) ? pool_j[src + t] : 0x7FFFFFFF;
+			kx[t] = (t < len) ? pool_x[src + t] : 0;
+		}
+		__syncthreads();
+		for (int kk = 2; kk <= n2; kk <<= 1) {
+			for (int jj = kk >> 1; jj > 0; jj >>= 1) {
+				for (int t = lane; t < n2; t += 64) {
+					const int o = t ^ jj;
+					if (o > t) {
+						const bool asc = (t & kk) == 0;
+						const int a0 = kj[t], a1 = kj[o];
+						if ((a0 > a1) == asc) {
+							kj[t] = a1;
+							kj[o] = a0;
+							const int b0 = kx[t];
+							kx[t] = kx[o];
+							kx[o] = b0;
+						}
+					}
+				}
+				__syncthreads();
+			}
+		}
+		for (int t = lane; t < len; t += 64) {
+			Sj[dst + t] = kj[t];
+			Sx[dst + t] = kx[t];
+		}
+		__syncthreads();
+	}
+}
+
+// --------------------------------------------------------------------------
+// launch helpers (called from schur_api.hip)
+// --------------------------------------------------------------------------
+template <int H, bool WIDE> static void launch_lds(const SchurArgs &a, int blocks, hipStream_t stream)
+{
+	using L = WaveLds<H, WIDE>;
+	const size_t bytes = sizeof(L);
+	static bool configured = false;
+	if (!configured) {
+		HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(&schur_lds_kernel<H, WIDE>),
+		                              hipFuncAttributeMaxDynamicSharedMemorySize, (int) bytes));
+		configured = true;
+	}
+	hipLaunchKernelGGL((schur_lds_kernel<H, WIDE>), dim3(blocks), dim3(64), bytes, stream, a);
+	HIP_CHECK(hipGetLastError());
+}
+
+void launch_schur_lds(const SchurArgs &a, int table, bool wide, int blocks, hipStream_t stream)
+{
+	if (table == 1024 && !wide)
+		launch_lds<1024, false>(a, blocks, stream);
+	else if (table == 1024 && wide)
+		launch_lds<1024, true>(a, blocks, stream);
+	else if (table == 8192 && !wide)
+		launch_lds<8192, false>(a, blocks, stream);
+	else if (table == 8192 && wide)
+		launch_lds<8192, true>(a, blocks, stream);
+	else
+		die("no LDS kernel for table size %d", table);
+}
+
+size_t schur_lds_bytes(int table, bool wide)
+{
+	if (table == 1024)
+		return wide ? sizeof(WaveLds<1024, true>) : sizeof(WaveLds<1024, false>);
+	return wide ? sizeof(WaveLds<8192, true>) : sizeof(WaveLds<8192, false>);
+}
+
+void launch_finalize(const spasm_hip_dwork *W, int nrows, int sort_rows, hipStream_t stream)
+{
+	const int nblocks = (nrows + 1023) / 1024;
+	if (nrows == 0) {
+		HIP_CHECK(hipMemsetAsync(W->d_Sp, 0, sizeof(int64_t), stream));
+		return;
+	}
+	hipLaunchKernelGGL(scan_block_sums, dim3(nblocks), dim3(256), 0, stream, W->d_row_len, nrows, W->d_blocksum);
+	hipLaunchKernelGGL(scan_of_sums, dim3(1), dim3(256), 0, stream, W->d_blocksum, nblocks);
+	hipLaunchKernelGGL(scan_finish, dim3(nblocks), dim3(256), 0, stream, W->d_row_len, nrows, W->d_blocksum, W->d_Sp);
+	int blocks = nrows < 16384 ? nrows : 16384;
+	hipLaunchKernelGGL((gather_rows_kernel<SORT_SMALL>), dim3(blocks), dim3(64), 0, stream, W->d_pool_j, W->d_pool_x,
+	                   W->d_row_off, W->d_row_len, nrows, W->d_Sp, W->d_Sj, W->d_Sx, sort_rows, 0, SORT_SMALL);
+	blocks = nrows < 512 ? nrows : 512;
+	hipLaunchKernelGGL((gather_rows_kernel<SORT_LDS_MAX>), dim3(blocks), dim3(64), 0, stream, W->d_pool_j, W->d_pool_x,
+	                   W->d_row_off, W->d_row_len, nrows, W->d_Sp, W->d_Sj, W->d_Sx, sort_rows, SORT_SMALL, 0x7FFFFFFF);
+	HIP_CHECK(hipGetLastError());
+}
+
+}  // namespace sh
+
+// --------------------------------------------------------------------------
+// K2: dense accumulator tier.  One 256-thread workgroup per row; the running
+// row is a dense vector in HBM (pivotal part xp[0..r), non-pivotal part
+// xn[0..Sm)), pending pivots are a bitmap over labels.  Used (a) for rows
+// whose reach does not fit the LDS tables and (b) to produce dense rows of
+// the Schur complement for the dense tail (xn is then the output row).
+// All traffic to xp/xn/bitmap that other waves may have updated goes through
+// agent-scope atomics (served by L2), phases are separated by barriers.
+// --------------------------------------------------------------------------
+namespace sh {
+
+namespace {
+
+constexpr int DT_THREADS = 256;
+constexpr int DT_ACT = 2048;           // pivots gathered per pass
+
+__device__ __forceinline__ uint32_t ld_l2(const uint32_t *p)
+{
+	return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+__device__ __forceinline__ void st_l2(uint32_t *p, uint32_t v)
+{
+	__hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+__device__ __forceinline__ void addmod_l2(uint32_t *p, uint32_t delta, uint32_t prime)
+{
+	uint32_t old = ld_l2(p);
+	for (;;) {
+		uint32_t s = old + delta;
+		if (s < old || s >= prime)
+			s -= prime;
+		uint32_t seen = atomicCAS(p, old, s);
+		if (seen == old)
+			return;
+		old = seen;
+	}
+}
+
+}  // namespace
+
+struct DenseTierArgs {
+	SchurArgs a;
+	uint32_t *scratch;        // per-workgroup slots
+	int64_t stride;           // words per slot
+	uint32_t *dense_out;      // non-null: write dense rows here instead of the pool
+	int64_t ldS;
+};
+
+__global__ __launch_bounds__(DT_THREADS) void schur_dense_kernel(DenseTierArgs d)
+{
+	const SchurArgs &a = d.a;
+	__shared__ uint32_t act[DT_ACT];
+	__shared__ int s_int[8];          // 0: row grab, 1: found label, 2: act count
+	__shared__ int64_t s_off;
+	__shared__ int wave_tot[DT_THREADS / 64];
+	const int tid = threadIdx.x;
+	const int lane = tid & 63, wave = tid >> 6;
+	const uint32_t r = (uint32_t) a.r;
+	const int Sm = a.m - a.r;
+	const MontDev F = a.F;
+	const int total_rows = (a.list != nullptr) ? *a.list_count : a.nrows;
+	const int nwords = (int) ((r + 31) / 32);
+
+	uint32_t *slot = d.scratch + (int64_t) blockIdx.x * d.stride;
+	uint32_t *xp = slot;                                           // r words
+	uint32_t *bm = slot + (((int64_t) r + 63) / 64) * 64;          // nwords words
+	uint32_t *xn_scratch = bm + (((int64_t) nwords + 63) / 64) * 64;   // Sm words (sparse-output mode)
+
+	unsigned long long st_elim = 0, st_stream = 0, st_input = 0;
+	int st_done = 0;
+
+	for (;;) {
+		__syncthreads();
+		if (tid == 0)
+			s_int[0] = atomicAdd(&a.ctr[a.next_ctr], 1);
+		__syncthreads();
+		const int kk = s_int[0];
+		if (kk >= total_rows)
+			break;
+		const int k = (a.list != nullptr) ? a.list[kk] : kk;
+		const int i = a.rows[k];
+		uint32_t *xn = (d.dense_out != nullptr) ? d.dense_out + (int64_t) k * d.ldS : xn_scratch;
+		if (d.dense_out != nullptr) {
+			for (int t = tid; t < Sm; t += DT_THREADS)
+				st_l2(&xn[t], 0u);
+			__syncthreads();
+		}
+
+		// ---- scatter the input row ----
+		const int64_t lo = a.Ap[i], hi = a.Ap[i + 1];
+		if (tid == 0)
+			st_input += (unsigned long long) (hi - lo);
+		for (int64_t px = lo + tid; px < hi; px += DT_THREADS) {
+			const uint32_t c = a.lab[a.Aj[px]];
+			uint32_t v = from_balanced(a.Ax[px], F);
+			if (v >= F.p)
+				v %= F.p;
+			if (c < r) {
+				addmod_l2(&xp[c], v, F.p);
+				atomicOr(&bm[c >> 5], 1u << (c & 31));
+			} else {
+				addmod_l2(&xn[c - r], v, F.p);
+			}
+		}
+		__syncthreads();
+
+		// ---- eliminate level by level ----
+		int word_cursor = 0;
+		for (;;) {
+			// first pending label at or after the cursor
+			if (tid == 0)
+				s_int[1] = 0x7FFFFFFF;
+			__syncthreads();
+			int found = 0x7FFFFFFF;
+			for (int base = word_cursor; base < nwords; base += DT_THREADS) {
+				const int wd = base + tid;
+				if (wd < nwords) {
+					const uint32_t bits = ld_l2(&bm[wd]);
+					if (bits != 0)
+						atomicMin(&s_int[1], wd * 32 + __builtin_ctz(bits));
+				}
+				__syncthreads();
+				found = s_int[1];
+				if (found != 0x7FFFFFFF)
+					break;
+			}
+			__syncthreads();
+			if (found == 0x7FFFFFFF)
+				break;
+			const uint32_t c0 = (uint32_t) found;
+			const uint32_t lend = a.lvl_end[c0];
+			// a pass covers at most DT_ACT labels (DT_ACT / 32 bitmap words), so act[] cannot overflow
+			uint32_t pass_lo = c0;
+			while (pass_lo < lend) {
+				const int wbase = (int) (pass_lo >> 5);
+				const int wall = (int) ((lend + 31) >> 5);
+				const int wlim = (wall < wbase + DT_ACT / 32) ? wall : wbase + DT_ACT / 32;
+				const uint32_t pass_hi = ((uint32_t) wlim * 32 < lend) ? (uint32_t) wlim * 32 : lend;
+				if (tid == 0)
+					s_int[2] = 0;
+				__syncthreads();
+				if (tid < wlim - wbase) {
+					const int wd = wbase + tid;
+					uint32_t bits = ld_l2(&bm[wd]);
+					const uint32_t first = (uint32_t) wd * 32;
+					if (first < pass_lo)
+						bits &= ~((1u << (pass_lo - first)) - 1u);
+					if (first + 32 > pass_hi)
+						bits &= (1u << (pass_hi - first)) - 1u;      // pass_hi - first is in [1, 31]
+					if (bits != 0) {
+						int w = atomicAdd(&s_int[2], __popc(bits));
+						uint32_t b = bits;
+						while (b) {
+							const int bit = __builtin_ctz(b);
+							b &= b - 1;
+							act[w++] = first + bit;
+						}
+						atomicAnd(&bm[wd], ~bits);
+					}
+				}
+				__syncthreads();
+				const int nact = s_int[2];
+				// apply: one wave per pivot
+				for (int t = wave; t < nact; t += DT_THREADS / 64) {
+					const uint32_t c = act[t];
+					const uint32_t v = ld_l2(&xp[c]);
+					if (lane == 0)
+						st_l2(&xp[c], 0u);
+					if (v == 0)
+						continue;
+					const uint64_t start = a.rp[c];
+					const int len = (int) (a.rp[c + 1] - start);
+					const uint32_t w = F.p - v;
+					if (lane == 0) {
+						st_elim += 1;
+						st_stream += (unsigned long long) len;
+					}
+					for (int l = lane; l < len; l += 64) {
+						const uint2 e = a.ent[start + l];
+						const uint32_t delta = montmul(w, e.y, F);
+						if (e.x < r) {
+							addmod_l2(&xp[e.x], delta, F.p);
+							atomicOr(&bm[e.x >> 5], 1u << (e.x & 31));
+						} else {
+							addmod_l2(&xn[e.x - r], delta, F.p);
+						}
+					}
+				}
+				__syncthreads();
+				pass_lo = pass_hi;
+			}
+			word_cursor = (int) (lend >> 5);
+		}
+
+		if (d.dense_out != nullptr) {
+			if (tid == 0) {
+				a.row_len[k] = Sm;
+				st_done += 1;
+			}
+			continue;
+		}
+
+		// ---- compact the non-pivotal part into the pool (sorted by column) ----
+		int mine = 0;
+		for (int t = tid; t < Sm; t += DT_THREADS)
+			mine += (ld_l2(&xn[t]) != 0);
+		// block reduce
+		for (int dlt = 32; dlt >= 1; dlt >>= 1)
+			mine += __shfl_xor(mine, dlt);
+		if (lane == 0)
+			wave_tot[wave] = mine;
+		__syncthreads();
+		int count = 0;
+		for (int wv = 0; wv < DT_THREADS / 64; wv++)
+			count += wave_tot[wv];
+		__syncthreads();
+		if (tid == 0) {
+			unsigned long long got = atomicAdd(&a.ctr64[C64_POOL], (unsigned long long) count);
+			s_off = (int64_t) got;
+		}
+		__syncthreads();
+		const int64_t off = s_off;
+		const bool fits = off + count <= a.pool_cap;
+		if (!fits && tid == 0) {
+			atomicOr(&a.ctr[CTR_STATUS], 1);
+			a.row_len[k] = -1;
+		}
+		int64_t wpos = off;
+		for (int base = 0; base < Sm; base += DT_THREADS) {
+			const int t = base + tid;
+			uint32_t v = (t < Sm) ? ld_l2(&xn[t]) : 0u;
+			if (t < Sm && v != 0)
+				st_l2(&xn[t], 0u);
+			const bool keep = v != 0;
+			const uint64_t mk = __ballot(keep);
+			if (lane == 0)
+				wave_tot[wave] = __popcll(mk);
+			__syncthreads();
+			int before = 0, all = 0;
+			for (int wv = 0; wv < DT_THREADS / 64; wv++) {
+				if (wv < wave)
+					before += wave_tot[wv];
+				all += wave_tot[wv];
+			}
+			if (keep && fits) {
+				const int64_t dst = wpos + before + __popcll(mk & lanes_below(lane));
+				a.pool_j[dst] = a.q[t];
+				a.pool_x[dst] = to_balanced(v, F);
+			}
+			wpos += all;
+			__syncthreads();
+		}
+		if (tid == 0 && fits) {
+			a.row_off[k] = off | (1LL << 62);       // already sorted by column
+			a.row_len[k] = count;
+			st_done += 1;
+		}
+	}
+	if (lane == 0) {
+		atomicAdd(&a.ctr64[C64_ELIM], st_elim);
+		atomicAdd(&a.ctr64[C64_STREAM], st_stream);
+	}
+	if (tid == 0) {
+		atomicAdd(&a.ctr64[C64_INPUT], st_input);
+		atomicAdd(&a.ctr[a.done_ctr], st_done);
+	}
+}
+
+int dense_tier_slots() { return 256; }
+
+__global__ void all_rows_to_list_kernel(int *list, int *count, int *row_len, int nrows)
+{
+	const int t = blockIdx.x * blockDim.x + threadIdx.x;
+	if (t < nrows) {
+		list[t] = t;
+		row_len[t] = -2;
+	}
+	if (t == 0)
+		*count = nrows;
+}
+
+void launch_all_rows_to_list(int *list, int *count, int *row_len, int nrows, hipStream_t stream)
+{
+	hipLaunchKernelGGL(all_rows_to_list_kernel, dim3((nrows + 255) / 256), dim3(256), 0, stream, list, count, row_len, nrows);
+	HIP_CHECK(hipGetLastError());
+}
+
+int64_t dense_tier_stride(int m)
+{
+	const int64_t rm = ((int64_t) m + 63) / 64 * 64;
+	return rm + (rm / 32 + 64) / 64 * 64 + 64 + rm + 128;
+}
+
+void launch_schur_dense_tier(const SchurArgs &a, const spasm_hip_dwork *W, int blocks, hipStream_t stream)
+{
+	DenseTierArgs d;
+	d.a = a;
+	d.scratch = W->d_dense;
+	d.stride = W->dense_stride;
+	d.dense_out = nullptr;
+	d.ldS = 0;
+	hipLaunchKernelGGL(schur_dense_kernel, dim3(blocks), dim3(DT_THREADS), 0, stream, d);
+	HIP_CHECK(hipGetLastError());
+}
+
+void launch_schur_dense_rows(const SchurArgs &a, const spasm_hip_dwork *W, uint32_t *dS, int64_t ldS, int blocks,
+                             hipStream_t stream)
+{
+	DenseTierArgs d;
+	d.a = a;
+	d.scratch = W->d_dense;
+	d.stride = W->dense_stride;
+	d.dense_out = dS;
+	d.ldS = ldS;
+	hipLaunchKernelGGL(schur_dense_kernel, dim3(blocks), dim3(DT_THREADS), 0, stream, d);
+	HIP_CHECK(hipGetLastError());
+}
+
+}  // namespace sh

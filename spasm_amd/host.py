@@ -1,0 +1,116 @@
+"""Host-pointer entry points: same names, argument meaning and results as the reference's C API."""
+import ctypes as C
+
+import numpy as np
+
+from ._lib import lib, require_gpu
+from .matrix import Csr, Fact, CLu, EchelonizeOpts, view_csr, copy_csr
+
+_libc = C.CDLL(None)
+_libc.fopen.restype = C.c_void_p
+_libc.fopen.argtypes = [C.c_char_p, C.c_char_p]
+_libc.fclose.argtypes = [C.c_void_p]
+
+
+def _ip(a):
+    return a.ctypes.data_as(C.POINTER(C.c_int))
+
+
+def load(path, prime, transpose_if_wide=False):
+    """spasm_triplet_load + spasm_compress (spasm_io.c:60, spasm_triplet.c:97) of an SMS / MatrixMarket file."""
+    L = lib()
+    f = _libc.fopen(path.encode(), b"r")
+    if not f:
+        raise OSError("cannot open %s" % path)
+    try:
+        T = L.spasm_hip_triplet_load(f, prime, None)
+    finally:
+        _libc.fclose(f)
+    if transpose_if_wide and T.contents.n < T.contents.m:
+        L.spasm_hip_triplet_transpose(T)
+    A = L.spasm_hip_compress(T)
+    out = copy_csr(A)
+    L.spasm_hip_csr_free(A)
+    L.spasm_hip_triplet_free(T)
+    return out
+
+
+def compress(prime, n, m, ti, tj, tx):
+    """triplets (0-based) -> Csr through spasm_hip_add_entry / spasm_hip_compress."""
+    L = lib()
+    T = L.spasm_hip_triplet_alloc(n, m, max(len(ti), 1), prime, True)
+    for a, b, c in zip(np.asarray(ti).tolist(), np.asarray(tj).tolist(), np.asarray(tx).tolist()):
+        L.spasm_hip_add_entry(T, a, b, c)
+    A = L.spasm_hip_compress(T)
+    out = copy_csr(A)
+    L.spasm_hip_csr_free(A)
+    L.spasm_hip_triplet_free(T)
+    return out
+
+
+def transpose(A):
+    L = lib()
+    a = view_csr(A)
+    t = L.spasm_hip_transpose(C.byref(a), 1)
+    out = copy_csr(t)
+    L.spasm_hip_csr_free(t)
+    return out
+
+
+def empty_fact(m, prime):
+    return Fact(Csr(0, m, np.zeros(1, np.int64), np.zeros(0, np.int32), np.zeros(0, np.int32), prime),
+                np.full(m, -1, np.int32))
+
+
+def _lu_for(F, extra_rows, extra_nz):
+    """library-owned struct spasm_lu initialised from a Fact, with room to grow."""
+    L = lib()
+    U = F.U
+    up = L.spasm_hip_csr_alloc(U.n + extra_rows, U.m, max(U.nnz + extra_nz, 1), U.prime, True)
+    s = up.contents
+    C.memmove(s.p, U.p.ctypes.data, 8 * (U.n + 1))
+    if U.nnz:
+        C.memmove(s.j, U.j.ctypes.data, 4 * U.nnz)
+        C.memmove(s.x, U.x.ctypes.data, 4 * U.nnz)
+    up.contents.n = U.n
+    qinv = F.qinv.copy()
+    lu = CLu()
+    lu.r = U.n
+    lu.complete = False
+    lu.L = None
+    lu.U = up
+    lu.qinv = _ip(qinv)
+    lu.p = None
+    lu.Ltmp = None
+    return lu, up, qinv
+
+
+def pivots_extract_structural(A, F, greedy=True):
+    """spasm_pivots_extract_structural (spasm_pivots.c:374): returns (npiv, p, F + new pivotal rows)."""
+    L = lib()
+    a = view_csr(A)
+    lu, up, qinv = _lu_for(F, A.n, A.nnz)
+    opts = EchelonizeOpts()
+    opts.enable_greedy_pivot_search = bool(greedy)
+    p = np.zeros(max(A.n, 1), np.int32)
+    npiv = L.spasm_hip_pivots_extract_structural(C.byref(a), None, C.byref(lu), _ip(p), C.byref(opts))
+    out = Fact(copy_csr(lu.U), qinv)
+    L.spasm_hip_csr_free(lu.U)
+    return npiv, p[:A.n], out
+
+
+def schur(A, p, F, p_in=None):
+    """spasm_schur (spasm_schur.c:64) on the GPU: returns (S, p_out)."""
+    require_gpu("schur")
+    L = lib()
+    a = view_csr(A)
+    lu, up, qinv = _lu_for(F, 0, 0)
+    p = np.ascontiguousarray(p, np.int32)
+    n = len(p)
+    p_out = np.zeros(max(n, 1), np.int32)
+    pin = _ip(np.ascontiguousarray(p_in, np.int32)) if p_in is not None else None
+    s = L.spasm_hip_schur(C.byref(a), _ip(p), n, C.byref(lu), -1.0, None, pin, _ip(p_out))
+    S = copy_csr(s)
+    L.spasm_hip_csr_free(s)
+    L.spasm_hip_csr_free(up)
+    return S, p_out[:n]

@@ -1,0 +1,133 @@
+"""GPU parity: the HIP Schur complement against the oracle, through the C ABI.
+
+Bit-exact: same rows (row k of S = reduction of row p[k]), same (column,
+value) sets, values compared as integers mod p.
+"""
+import os
+
+import numpy as np
+import pytest
+
+from conftest import ALL_MODULI, ALL_TEST_MATRICES, matrix_path
+
+import spasm_amd
+
+pytestmark = pytest.mark.gpu
+
+
+def _as_product(A):
+    return spasm_amd.Csr(A.n, A.m, A.p, A.j, A.x, A.prime)
+
+
+def _fact(F):
+    return spasm_amd.Fact(_as_product(F.U), F.qinv)
+
+
+def _round0(oracle, name, p):
+    A = oracle.load_sms(matrix_path(name), p)
+    npiv, perm, F = oracle.pivots_extract_structural(A, oracle.empty_fact(A.n, A.m, p))
+    return A, npiv, perm, F
+
+
+def _check(oracle, S_gpu, p_out_gpu, S_want, p_out_want, sorted_rows=True):
+    assert np.array_equal(p_out_gpu, p_out_want)
+    G = oracle.CSR(S_gpu.n, S_gpu.m, S_gpu.p, S_gpu.j, S_gpu.x, S_gpu.prime)
+    assert oracle.same_matrix(G, S_want)
+    P = S_gpu.prime
+    assert np.all(S_gpu.x <= P // 2) and np.all(S_gpu.x >= -(P // 2))          # balanced representatives
+    if sorted_rows:
+        for i in range(S_gpu.n):
+            jj, _ = S_gpu.row(i)
+            assert np.all(np.diff(jj) > 0)
+
+
+@pytest.mark.parametrize("name", ALL_TEST_MATRICES)
+@pytest.mark.parametrize("p", ALL_MODULI)
+def test_schur_reference_matrices(oracle, name, p):
+    A, npiv, perm, F = _round0(oracle, name, p)
+    rows = perm[npiv:]
+    want, p_out_want, _ = oracle.schur(A, rows, F)
+    S, p_out = spasm_amd.schur(_as_product(A), rows, _fact(F))
+    _check(oracle, S, p_out, want, p_out_want)
+    assert np.all(F.qinv[S.j] < 0)          # tests/schur.c:62-72
+
+
+@pytest.mark.parametrize("tier", [1, 2])
+@pytest.mark.parametrize("name", ["mat364.sms", "medium.sms", "trefethen_500.sms", "singular.sms", "rectangular_l.sms",
+                                  "BIOMD0000000424.int.mpl.sms", "void.sms", "empty.sms"])
+@pytest.mark.parametrize("p", [3, 42013, 4294967291])
+def test_schur_large_table_and_dense_tiers(oracle, name, p, tier, monkeypatch):
+    """same answers when every row is pushed through the large LDS table / the dense accumulator tier."""
+    monkeypatch.setenv("SPASM_HIP_FORCE_TIER", str(tier))
+    A, npiv, perm, F = _round0(oracle, name, p)
+    rows = perm[npiv:]
+    want, p_out_want, _ = oracle.schur(A, rows, F)
+    S, p_out = spasm_amd.schur(_as_product(A), rows, _fact(F))
+    _check(oracle, S, p_out, want, p_out_want)
+
+
+@pytest.mark.parametrize("name", ["mat364.sms", "medium.sms", "m1.sms", "trefethen_500.sms", "l1.sms", "G2.sms"])
+@pytest.mark.parametrize("p", [257, 42013, 189812507])
+def test_schur_second_round(oracle, name, p):
+    """factor with rows from two rounds: old rows of U meet columns that became pivotal later."""
+    A, npiv, perm, F = _round0(oracle, name, p)
+    S1, p_out1, _ = oracle.schur(A, perm[npiv:], F)
+    if S1.nnz == 0:
+        return
+    npiv2, perm2, F2 = oracle.pivots_extract_structural(S1, F)
+    rows = perm2[npiv2:]
+    want, p_out_want, _ = oracle.schur(S1, rows, F2, p_in=p_out1)
+    S, p_out = spasm_amd.schur(_as_product(S1), rows, _fact(F2), p_in=p_out1)
+    _check(oracle, S, p_out, want, p_out_want)
+
+
+def _random_sparse(rng, n, m, per_row, p):
+    ti = np.repeat(np.arange(n, dtype=np.int32), per_row)
+    tj = rng.integers(0, m, size=n * per_row).astype(np.int32)
+    tx = rng.integers(1, p, size=n * per_row).astype(np.int64)
+    return ti, tj, tx
+
+
+@pytest.mark.parametrize("p", [42013, 4294967291])
+@pytest.mark.parametrize("shape", [(3000, 2000, 3), (1500, 4000, 6), (6000, 1200, 2)])
+def test_schur_random_fill_in(oracle, shape, p):
+    """random matrices: heavy fill-in drives rows through every tier; full rows-vs-oracle equality."""
+    n, m, per_row = shape
+    rng = np.random.default_rng(n + m)
+    ti, tj, tx = _random_sparse(rng, n, m, per_row, p)
+    A = oracle.compress(p, n, m, ti, tj, tx)
+    npiv, perm, F = oracle.pivots_extract_structural(A, oracle.empty_fact(A.n, A.m, p))
+    rows = perm[npiv:]
+    want, p_out_want, _ = oracle.schur(A, rows, F)
+    S, p_out = spasm_amd.schur(_as_product(A), rows, _fact(F))
+    _check(oracle, S, p_out, want, p_out_want)
+
+
+def test_device_resident_path_and_stats(oracle):
+    """spasm_hip_dschur on tensors resident in HBM; statistics agree with the oracle's work count."""
+    import torch
+    p = 42013
+    A, npiv, perm, F = _round0(oracle, "mat364.sms", p)
+    rows = perm[npiv:]
+    want, _, _ = oracle.schur(A, rows, F)
+    dA = spasm_amd.DeviceCsr.from_host(_as_product(A))
+    dF = spasm_amd.DeviceFact(_fact(F))
+    W = spasm_amd.SchurWorkspace(len(rows), A.m, 4 * want.nnz + (1 << 22))
+    drows = torch.from_numpy(np.ascontiguousarray(rows, np.int32)).cuda()
+    stream = torch.cuda.Stream()
+    with torch.cuda.stream(stream):
+        S, st = spasm_amd.dschur(dA, drows, dF, W, stream=stream.cuda_stream)
+    assert st.status == 0 and st.nnz == want.nnz and st.rows == len(rows)
+    assert st.rows_lds + st.rows_lds_big + st.rows_dense == len(rows)
+    H = S.to_host()
+    assert oracle.same_matrix(oracle.CSR(H.n, H.m, H.p, H.j, H.x, p), want)
+    # a pool that is too small is reported, not silently truncated
+    W2 = spasm_amd.SchurWorkspace(len(rows), A.m, 16)
+    S2, st2 = spasm_amd.dschur(dA, drows, dF, W2)
+    assert S2 is None and st2.status == 1
+
+
+def test_empty_row_list(oracle):
+    A, npiv, perm, F = _round0(oracle, "small.sms", 257)
+    S, p_out = spasm_amd.schur(_as_product(A), np.zeros(0, np.int32), _fact(F))
+    assert S.n == 0 and S.nnz == 0
