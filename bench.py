@@ -1,0 +1,252 @@
+#!/usr/bin/env python3
+"""bench.py -- rows eliminated per second on the sparse Schur-complement hot path.
+
+Workload (BASELINE.json configs[1]): mk13.b5, the 135135 x 270270 boundary
+matrix of the matching complex of K13 (hpac "Homology" collection), mod 42013,
+processed the way tools/rank does: transposed to 270270 x 135135, structural
+pivots found on the host, then ONE STEP = the Schur complement of every
+non-pivotal row w.r.t. those pivots (spasm_schur, spasm_schur.c:64) -- here
+spasm_hip_dschur with A, the factor and the row list already resident in HBM.
+There is no network, so the matrix is regenerated from its definition (rows =
+5-edge matchings of K13, columns = 4-edge matchings, entries +-1); `data` says
+so.  Its dimensions and nnz (1,351,350) are those of the published file.
+
+Prints ONE JSON line (rank 0).  N > 1 (launched by torch.distributed.run): the
+row batch is sharded over the ranks, each rank reduces its slice, the slices
+are reassembled on every rank with an all-gatherv over RCCL (strong scaling).
+"""
+import argparse
+import itertools
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+os.environ.setdefault("SPASM_HIP_VERBOSE", "0")
+
+PRIME = 42013
+
+
+# --------------------------------------------------------------------------
+# workload
+# --------------------------------------------------------------------------
+def matching_complex_boundary(nv=13, k=5):
+    """boundary map from k-edge matchings to (k-1)-edge matchings of K_nv.
+    returns (n_rows, n_cols, ti, tj, tx): rows = (k-1)-matchings, cols = k-matchings."""
+    edges = list(itertools.combinations(range(nv), 2))
+    masks = [(1 << a) | (1 << b) for a, b in edges]
+    ne = len(edges)
+
+    def matchings(size):
+        out = []
+        cur = []
+
+        def rec(start, used):
+            if len(cur) == size:
+                out.append(tuple(cur))
+                return
+            for e in range(start, ne):
+                if masks[e] & used:
+                    continue
+                cur.append(e)
+                rec(e + 1, used | masks[e])
+                cur.pop()
+        rec(0, 0)
+        return out
+
+    big = matchings(k)
+    small = matchings(k - 1)
+    index = {s: i for i, s in enumerate(small)}
+    ti, tj, tx = [], [], []
+    for c, s in enumerate(big):
+        for t in range(k):
+            face = s[:t] + s[t + 1:]
+            ti.append(index[face])
+            tj.append(c)
+            tx.append(1 if t % 2 == 0 else -1)
+    return len(small), len(big), np.array(ti, np.int32), np.array(tj, np.int32), np.array(tx, np.int64)
+
+
+def build_workload(name):
+    """returns (A, rows, F, meta): host Csr, rows to reduce, factor with the structural pivots."""
+    import spasm_amd
+    cache = os.path.join("/tmp", "spasm_amd_bench_%s_%d.npz" % (name, PRIME))
+    if os.path.exists(cache):
+        z = np.load(cache)
+        A = spasm_amd.Csr(int(z["n"]), int(z["m"]), z["Ap"], z["Aj"], z["Ax"], PRIME)
+        F = spasm_amd.Fact(spasm_amd.Csr(int(z["r"]), int(z["m"]), z["Up"], z["Uj"], z["Ux"], PRIME), z["qinv"])
+        return A, z["rows"], F
+    if name == "mk13.b5":
+        n, m, ti, tj, tx = matching_complex_boundary(13, 5)
+    elif name == "mk9.b3":            # small sibling, used by tests
+        n, m, ti, tj, tx = matching_complex_boundary(9, 3)
+    else:
+        raise ValueError(name)
+    if n < m:                         # tools/rank.c:88-92: work on the tall orientation
+        ti, tj = tj, ti
+        n, m = m, n
+    A = spasm_amd.compress(PRIME, n, m, ti, tj, tx)
+    npiv, perm, F = spasm_amd.pivots_extract_structural(A, spasm_amd.empty_fact(A.m, PRIME))
+    rows = np.ascontiguousarray(perm[npiv:], np.int32)
+    np.savez(cache, n=A.n, m=A.m, Ap=A.p, Aj=A.j, Ax=A.x, r=F.U.n, Up=F.U.p, Uj=F.U.j, Ux=F.U.x,
+             qinv=F.qinv, rows=rows)
+    return A, rows, F
+
+
+# --------------------------------------------------------------------------
+# CPU baseline: the real reference (oracle/_ref, OpenMP) when it travelled
+# with the repo, else the single-thread oracle port.  Rank 0, N = 1 only.
+# --------------------------------------------------------------------------
+def cpu_baseline(A, rows, F, budget_s=20.0):
+    from oracle import oracle as orc
+    Ao = orc.CSR(A.n, A.m, A.p, A.j, A.x, A.prime)
+    Fo = orc.Fact(orc.CSR(F.U.n, F.U.m, F.U.p, F.U.j, F.U.x, A.prime), F.qinv)
+    cores = os.cpu_count() or 1
+    if orc.ref_available():
+        kind, threads = "reference", cores
+        run = lambda sub: orc.ref_schur(Ao, sub, Fo, threads=threads)
+    else:
+        kind, threads = "port", 1
+        run = lambda sub: orc.schur(Ao, sub, Fo)
+    # bounded sample: grow the slice until it costs a couple of seconds, then time one bigger slice
+    count = min(len(rows), 2000)
+    t = 0.0
+    while True:
+        t0 = time.perf_counter()
+        run(rows[:count])
+        t = time.perf_counter() - t0
+        if t > 2.0 or count == len(rows):
+            break
+        count = min(len(rows), count * 4)
+    final = min(len(rows), max(count, int(count * min(budget_s / max(t, 1e-3), 8.0))))
+    if final > count:
+        t0 = time.perf_counter()
+        run(rows[:final])
+        t = time.perf_counter() - t0
+        count = final
+    return {"value": count / t, "unit": "rows/s", "cores": threads, "kind": kind,
+            "sample": "first %d of %d non-pivotal rows, spasm_schur, %.1f s" % (count, len(rows), t)}
+
+
+# --------------------------------------------------------------------------
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--workload", default="mk13.b5")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    import torch
+    import spasm_amd
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus and world > 1:
+        raise SystemExit("--gpus %d but WORLD_SIZE=%d" % (args.gpus, world))
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        dist.init_process_group("nccl", device_id=dev)
+
+    A, rows, F = build_workload(args.workload)
+    from spasm_amd.dist import shard_rows, allgatherv_csr
+    my_rows = shard_rows(rows, rank, world)
+    dA = spasm_amd.DeviceCsr.from_host(A, dev)
+    dF = spasm_amd.DeviceFact(F)
+    drows = torch.from_numpy(np.ascontiguousarray(my_rows)).to(dev)
+    stream = torch.cuda.Stream(device=dev)
+
+    # size the pool with one probing run (not timed)
+    pool = 4 * A.nnz + (1 << 24)
+    while True:
+        W = spasm_amd.SchurWorkspace(max(len(my_rows), 1), A.m, pool)
+        with torch.cuda.stream(stream):
+            S, st = spasm_amd.dschur(dA, drows, dF, W, stream=stream.cuda_stream, fetch=False)
+        if st.status == 0:
+            break
+        W.close()
+        pool *= 2
+
+    def step():
+        with torch.cuda.stream(stream):
+            S, st = spasm_amd.dschur(dA, drows, dF, W, stream=stream.cuda_stream, fetch=(world > 1))
+            if world > 1:
+                allgatherv_csr(S, dist)
+        return st
+
+    for _ in range(args.warmup):
+        step()
+    torch.cuda.synchronize()
+    if dist is not None:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    k_ms, k_elim, k_stream, k_in, k_out = 0.0, 0, 0, 0, 0
+    for _ in range(args.steps):
+        st = step()
+        k_ms += st.ms_tier0
+        k_elim, k_stream, k_in, k_out = st.eliminations, st.entries_streamed, st.input_entries, st.nnz
+    torch.cuda.synchronize()
+    if dist is not None:
+        dist.barrier()
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    if dist is not None:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    if rank == 0:
+        total_rows = len(rows)
+        ms_per_step = 1e3 * elapsed / args.steps
+        # algorithmic bytes of the dominant kernel per launch (DESIGN.md "Byte accounting"):
+        # 8 B per entry read or written (column + value), 16 B of row extent per elimination,
+        # 20 B per reduced row (row id, two row pointers)
+        algo = 8 * (k_in + k_stream + k_out) + 16 * k_elim + 20 * len(my_rows)
+        kernel_ms = k_ms / args.steps
+        achieved = algo / (kernel_ms * 1e-3) / 1e9 if kernel_ms > 0 else 0.0
+        traffic = None
+        tfile = os.path.join(ROOT, "profiles", "traffic_r01.json")
+        if os.path.exists(tfile):
+            traffic = json.load(open(tfile)).get("schur_lds_kernel_bytes_per_launch")
+        out = {
+            "metric": "rows eliminated/sec (sparse Schur complement, mod 42013)",
+            "value": total_rows / (elapsed / args.steps),
+            "unit": "rows/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": ms_per_step,
+            "higher_is_better": True,
+            "scaling": "strong",
+            "vs_baseline": None,
+            "dtype": "u32",
+            "data": "synthetic (mk13.b5 regenerated from the definition of the matching complex of K13; no network)",
+            "config": {"workload": "%s (%dx%d, %d nnz) mod %d, round-0 Schur complement of %d non-pivotal rows "
+                                   "w.r.t. %d structural pivots" % (args.workload, A.n, A.m, A.nnz, PRIME,
+                                                                   total_rows, F.U.n),
+                       "rows_per_step": total_rows, "pivots": int(F.U.n), "levels": dF.levels,
+                       "eliminations_per_step": int(k_elim), "schur_nnz": int(k_out),
+                       "sharding": "rows over %d rank(s)%s" % (world, ", all-gatherv of S" if world > 1 else "")},
+            "roofline": {"bound": "hbm", "achieved": achieved, "peak": 8000.0, "unit": "GB/s",
+                         "frac": achieved / 8000.0, "traffic": traffic,
+                         "kernel": "schur_lds_kernel<1024,false>", "kernel_ms": kernel_ms,
+                         "algorithmic_bytes": int(algo)},
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(A, rows, F)
+        print(json.dumps(out))
+    if dist is not None:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -220,7 +220,8 @@ typedef struct {
 	int rows_lds_big;       /* ... by the large-table variant */
 	int rows_dense;         /* rows finished by the dense-accumulator kernel */
 	int status;             /* 0 = ok, 1 = pool too small (call again with a larger pool) */
-	float ms_eliminate;     /* device time of the elimination kernels (HIP events) */
+	float ms_eliminate;     /* device time of the elimination kernels, all tiers (HIP events) */
+	float ms_tier0;         /* ... of the dominant kernel alone (small-table LDS kernel) */
 	float ms_total;         /* device time of the whole call */
 } spasm_hip_schur_stats;
 

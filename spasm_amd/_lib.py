@@ -18,6 +18,12 @@ def lib():
         raise ImportError(
             "spasm_amd: %s is missing -- build it with `python -c 'import __graft_entry__ as g; g.build()'` "
             "(make -C spasm_amd/csrc).  There is no CPU fallback." % LIB_PATH)
+    # torch wheels bundle their own libamdhip64.so.7; it has to be the HIP runtime of the process
+    # (two runtimes in one process cannot both own the GPU), so let torch load it first.
+    try:
+        import torch  # noqa: F401
+    except ImportError:
+        pass
     L = C.CDLL(LIB_PATH)
     i64, ci, vp = C.c_int64, C.c_int, C.c_void_p
     pcsr, ptri, plu = C.POINTER(CCsr), C.POINTER(CTriplet), C.POINTER(CLu)

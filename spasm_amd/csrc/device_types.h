@@ -59,7 +59,9 @@ struct SchurArgs {
 	const uint64_t *rp;       // r + 1 offsets into ent
 	const uint2 *ent;         // (label, value * R mod p)
 	const uint32_t *lvl_end;  // label -> end of its level
-	int r;
+	const uint32_t *lvl_end_w;// 32-label word -> first word of the next level
+	int r;                    // size of the (padded) pivot label space; labels >= r are non-pivotal
+	int Sm;                   // number of non-pivotal columns
 	int m;
 	MontDev F;
 	// output pool
@@ -81,6 +83,7 @@ struct SchurArgs {
 // opaque handles of the C ABI
 struct spasm_hip_dfact {
 	int m = 0, r = 0, Sm = 0, nlevels = 0;
+	int rpad = 0, maxdeg = 0;
 	int64_t nnz = 0;
 	int64_t prime = 0;
 	sh::Mont mont{};
@@ -89,7 +92,8 @@ struct spasm_hip_dfact {
 	uint64_t *d_rp = nullptr;
 	uint2 *d_ent = nullptr;
 	uint32_t *d_lvl_end = nullptr;
-	int *d_kof = nullptr;          // label -> row of U
+	uint32_t *d_lvl_end_w = nullptr;
+	int *d_kof = nullptr;          // label -> row of U (-1: padding label)
 	std::vector<int> h_q;          // host copy of q
 	std::vector<int> h_kof;
 };
@@ -106,9 +110,10 @@ struct spasm_hip_dwork {
 	int64_t *d_Sp = nullptr;
 	int64_t *d_blocksum = nullptr;
 	int *d_Sj = nullptr, *d_Sx = nullptr;
-	uint32_t *d_dense = nullptr;       // dense accumulators of the last tier
-	int dense_slots = 0;
-	int64_t dense_stride = 0;
+	unsigned char *d_scratch = nullptr;   // per-wave dense accumulators (all zero between calls)
+	int64_t scratch_bytes = 0;
+	int scratch_slots = 0;
+	int64_t slot_bytes = 0, off_bm = 0, off_xn = 0;
 	hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
 	int last_rows = 0;
 	int64_t last_nnz = 0;

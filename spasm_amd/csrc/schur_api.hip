@@ -9,11 +9,9 @@ namespace sh {
 void launch_schur_lds(const SchurArgs &a, int table, bool wide, int blocks, hipStream_t stream);
 size_t schur_lds_bytes(int table, bool wide);
 void launch_finalize(const spasm_hip_dwork *W, int nrows, int sort_rows, hipStream_t stream);
-void launch_schur_dense_tier(const SchurArgs &a, const spasm_hip_dwork *W, int blocks, hipStream_t stream);
-void launch_schur_dense_rows(const SchurArgs &a, const spasm_hip_dwork *W, uint32_t *dS, int64_t ldS, int blocks,
-                             hipStream_t stream);
-int dense_tier_slots();
-int64_t dense_tier_stride(int m);
+void wave_dense_geometry(int rpad, int Sm, bool wide, int64_t *slot_bytes, int64_t *off_bm, int64_t *off_xn);
+void launch_schur_wave_dense(const SchurArgs &a, unsigned char *scratch, int64_t slot_bytes, int64_t off_bm, int64_t off_xn,
+                             bool wide, uint32_t *dense_out, int64_t ldS, int blocks, hipStream_t stream);
 void launch_all_rows_to_list(int *list, int *count, int *row_len, int nrows, hipStream_t stream);
 }  // namespace sh
 
@@ -57,7 +55,8 @@ int cu_count()
 
 extern "C" {
 
-int spasm_hip_debug_plan(const struct spasm_csr *U, const int *qinv, int *label_of_row, int *lvl_end, int *lab);
+int spasm_hip_debug_plan(const struct spasm_csr *U, const int *qinv, int *label_of_row, int *lvl_end_of_row, int *lab,
+                         int *info);
 
 int spasm_hip_device_count(void)
 {
@@ -75,10 +74,13 @@ int spasm_hip_device_count(void)
 // the CPU through spasm_hip_debug_plan).
 struct FactPlan {
 	int m = 0, r = 0, nlevels = 0;
+	int rpad = 0;                 // size of the label space of the pivots: every level starts on a multiple of 32
+	int maxdeg = 0;               // largest number of rows of U' that hold one given label
 	i64 prime = 0;
-	std::vector<uint32_t> lab, lvl_end;
-	std::vector<int> q, kof, label_of_row;
-	std::vector<uint64_t> rp;
+	std::vector<uint32_t> lab, lvl_end;     // lvl_end is indexed by (padded) label
+	std::vector<uint32_t> lvl_end_w;        // per 32-label word: first word of the next level
+	std::vector<int> q, kof, label_of_row;  // kof: label -> row of U, -1 for padding labels
+	std::vector<uint64_t> rp;               // rpad + 1
 	std::vector<uint2> ent;
 };
 
@@ -156,25 +158,66 @@ static void plan_factor(const struct spasm_csr *U, const int *qinv, FactPlan &P)
 		hmax = std::max(hmax, height[k]);
 	const int nlev = (r > 0) ? hmax + 1 : 0;
 	P.nlevels = nlev;
-	// level = hmax - height; stable counting sort -> label of each row
-	std::vector<int> lvl_start((size_t) nlev + 1, 0);
+	// level = hmax - height; stable counting sort inside a level; every level
+	// starts on a multiple of 32 labels so that a level is a whole number of
+	// words of the pending bitmaps
+	std::vector<int> lvl_count((size_t) nlev + 1, 0);
 	for (int k = 0; k < r; k++)
-		lvl_start[hmax - height[k] + 1] += 1;
-	for (int l = 0; l < nlev; l++)
-		lvl_start[l + 1] += lvl_start[l];
+		lvl_count[hmax - height[k]] += 1;
+	std::vector<int> lvl_start((size_t) nlev + 1, 0);
+	// (levels of fewer than 32 pivots are packed without padding, so that chains of tiny levels
+	// do not inflate the label space; a bitmap word shared by several levels is marked MIXED)
+	for (int l = 0; l < nlev; l++) {
+		int begin = lvl_start[l];
+		if (lvl_count[l] >= 32)
+			begin = (begin + 31) / 32 * 32;
+		lvl_start[l] = begin;
+		lvl_start[l + 1] = begin + lvl_count[l];
+	}
+	const int rpad = (lvl_start[nlev] + 31) / 32 * 32;
+	P.rpad = rpad;
 	P.label_of_row.assign((size_t) (r > 0 ? r : 1), 0);
 	{
 		std::vector<int> cursor(lvl_start.begin(), lvl_start.end());
 		for (int k = 0; k < r; k++)
 			P.label_of_row[k] = cursor[hmax - height[k]]++;
 	}
-	P.lvl_end.assign((size_t) (r > 0 ? r : 1), 0);
-	P.kof.assign((size_t) (r > 0 ? r : 1), 0);
-	for (int k = 0; k < r; k++) {
-		P.lvl_end[P.label_of_row[k]] = (uint32_t) lvl_start[hmax - height[k] + 1];
-		P.kof[P.label_of_row[k]] = k;
+	P.lvl_end.assign((size_t) (rpad > 0 ? rpad : 1), 0);
+	P.lvl_end_w.assign((size_t) (rpad / 32 > 0 ? rpad / 32 : 1), 0);
+	P.kof.assign((size_t) (rpad > 0 ? rpad : 1), -1);
+	// labels in the gap before an aligned level belong to no row; give them the end of the gap
+	{
+		int prev_end = 0;
+		std::vector<int> owners((size_t) (rpad / 32 > 0 ? rpad / 32 : 1), 0);    // levels touching each word
+		for (int l = 0; l < nlev; l++) {
+			for (int c = prev_end; c < lvl_start[l]; c++)
+				P.lvl_end[c] = (uint32_t) lvl_start[l];
+			for (int c = lvl_start[l]; c < lvl_start[l + 1]; c++)
+				P.lvl_end[c] = (uint32_t) lvl_start[l + 1];
+			if (lvl_count[l] > 0)
+				for (int w = lvl_start[l] / 32; w <= (lvl_start[l + 1] - 1) / 32; w++)
+					owners[w] += 1;
+			prev_end = lvl_start[l + 1];
+		}
+		for (int c = prev_end; c < rpad; c++)
+			P.lvl_end[c] = (uint32_t) rpad;
+		for (int w = 0; w < rpad / 32; w++)
+			P.lvl_end_w[w] = 0xFFFFFFFFu;                 // MIXED unless proven otherwise
+		for (int l = 0; l < nlev; l++) {
+			if (lvl_count[l] == 0)
+				continue;
+			// a level may claim its words when it starts on a word boundary and no other
+			// level shares its last word
+			const int w0 = lvl_start[l] / 32, w1 = (lvl_start[l + 1] - 1) / 32;
+			if (lvl_start[l] % 32 != 0 || owners[w1] != 1)
+				continue;
+			for (int w = w0; w <= w1; w++)
+				P.lvl_end_w[w] = (uint32_t) (w1 + 1);
+		}
 	}
-	// column labels
+	for (int k = 0; k < r; k++)
+		P.kof[P.label_of_row[k]] = k;
+	// column labels: pivotal columns get the label of their row, the others follow
 	P.lab.assign((size_t) (m > 0 ? m : 1), 0);
 	P.q.assign((size_t) (m - r > 0 ? m - r : 1), 0);
 	{
@@ -183,7 +226,7 @@ static void plan_factor(const struct spasm_csr *U, const int *qinv, FactPlan &P)
 			if (qinv[j] >= 0) {
 				P.lab[j] = (uint32_t) P.label_of_row[qinv[j]];
 			} else {
-				P.lab[j] = (uint32_t) (r + np);
+				P.lab[j] = (uint32_t) (rpad + np);
 				P.q[np] = j;
 				np += 1;
 			}
@@ -191,35 +234,46 @@ static void plan_factor(const struct spasm_csr *U, const int *qinv, FactPlan &P)
 	}
 	// rows of U' in label order, pivot entry dropped, values * R mod p
 	const i64 nnz = U->p[r] - r;
-	P.rp.assign((size_t) r + 1, 0);
+	P.rp.assign((size_t) rpad + 1, 0);
 	P.ent.assign((size_t) (nnz > 0 ? nnz : 1), uint2{0, 0});
+	std::vector<int> deg((size_t) (m > 0 ? m : 1), 0);
 	i64 w = 0;
-	for (int c = 0; c < r; c++) {
+	for (int c = 0; c < rpad; c++) {
 		const int k = P.kof[c];
 		P.rp[c] = (uint64_t) w;
+		if (k < 0)
+			continue;
 		for (i64 px = U->p[k] + 1; px < U->p[k + 1]; px++) {
 			const uint64_t v = zp_unsigned(prime, U->x[px]);
 			uint2 e;
 			e.x = P.lab[U->j[px]];
 			e.y = (uint32_t) ((v << 32) % (uint64_t) prime);
 			P.ent[w++] = e;
+			deg[U->j[px]] += 1;
 		}
 	}
-	P.rp[r] = (uint64_t) w;
+	P.rp[rpad] = (uint64_t) w;
+	for (int j = 0; j < m; j++)
+		P.maxdeg = std::max(P.maxdeg, deg[j]);
 }
 
 // CPU-only view of the plan, for tests: label of each row of U, end of the
 // level of each label, label of each column.  Arrays sized r, r, m.
-int spasm_hip_debug_plan(const struct spasm_csr *U, const int *qinv, int *label_of_row, int *lvl_end, int *lab)
+// label_of_row: r ints; lvl_end_of_row: r ints (end of the level of that row's label);
+// lab: m ints; info[0] = rpad, info[1] = maxdeg.
+int spasm_hip_debug_plan(const struct spasm_csr *U, const int *qinv, int *label_of_row, int *lvl_end_of_row, int *lab,
+                         int *info)
 {
 	FactPlan P;
 	plan_factor(U, qinv, P);
 	for (int k = 0; k < P.r; k++) {
 		label_of_row[k] = P.label_of_row[k];
-		lvl_end[k] = (int) P.lvl_end[k];
+		lvl_end_of_row[k] = (int) P.lvl_end[P.label_of_row[k]];
 	}
 	for (int j = 0; j < P.m; j++)
 		lab[j] = (int) P.lab[j];
+	info[0] = P.rpad;
+	info[1] = P.maxdeg;
 	return P.nlevels;
 }
 
@@ -230,29 +284,33 @@ spasm_hip_dfact *spasm_hip_dfact_create(const struct spasm_csr *U, const int *qi
 		die("spasm_hip_dfact_create: no HIP device (this library has no CPU path)");
 	FactPlan P;
 	plan_factor(U, qinv, P);
-	const int r = P.r, m = P.m;
+	const int r = P.r, m = P.m, rpad = P.rpad;
 	spasm_hip_dfact *F = new spasm_hip_dfact();
 	F->m = m;
 	F->r = r;
+	F->rpad = rpad;
+	F->maxdeg = P.maxdeg;
 	F->Sm = m - r;
 	F->prime = P.prime;
 	F->mont = mont_setup(P.prime);
 	F->nlevels = P.nlevels;
-	F->nnz = (i64) P.rp[r];
+	F->nnz = (i64) P.rp[rpad];
 	F->h_q = P.q;
 	F->h_kof = P.kof;
 	F->d_lab = dalloc<uint32_t>(m);
 	F->d_q = dalloc<int>(m - r);
-	F->d_rp = dalloc<uint64_t>(r + 1);
+	F->d_rp = dalloc<uint64_t>(rpad + 1);
 	F->d_ent = dalloc<uint2>(F->nnz);
-	F->d_lvl_end = dalloc<uint32_t>(r);
-	F->d_kof = dalloc<int>(r);
+	F->d_lvl_end = dalloc<uint32_t>(rpad);
+	F->d_lvl_end_w = dalloc<uint32_t>(rpad / 32);
+	F->d_kof = dalloc<int>(rpad);
 	upload(F->d_lab, P.lab.data(), m, stream);
 	upload(F->d_q, P.q.data(), m - r, stream);
-	upload(F->d_rp, P.rp.data(), (i64) r + 1, stream);
+	upload(F->d_rp, P.rp.data(), (i64) rpad + 1, stream);
 	upload(F->d_ent, P.ent.data(), F->nnz, stream);
-	upload(F->d_lvl_end, P.lvl_end.data(), r, stream);
-	upload(F->d_kof, P.kof.data(), r, stream);
+	upload(F->d_lvl_end, P.lvl_end.data(), rpad, stream);
+	upload(F->d_lvl_end_w, P.lvl_end_w.data(), rpad / 32, stream);
+	upload(F->d_kof, P.kof.data(), rpad, stream);
 	HIP_CHECK(hipStreamSynchronize(stream));    // the host vectors die here
 	return F;
 }
@@ -266,6 +324,7 @@ void spasm_hip_dfact_destroy(spasm_hip_dfact *F)
 	(void) hipFree(F->d_rp);
 	(void) hipFree(F->d_ent);
 	(void) hipFree(F->d_lvl_end);
+	(void) hipFree(F->d_lvl_end_w);
 	(void) hipFree(F->d_kof);
 	delete F;
 }
@@ -295,10 +354,6 @@ spasm_hip_dwork *spasm_hip_dwork_create(int max_rows, int m, i64 pool_entries)
 	W->d_blocksum = dalloc<int64_t>((max_rows + 1023) / 1024 + 1);
 	W->d_ctr = dalloc<int>(CTR_COUNT);
 	W->d_ctr64 = dalloc<unsigned long long>(C64_COUNT);
-	W->dense_slots = dense_tier_slots();
-	W->dense_stride = dense_tier_stride(m);
-	W->d_dense = dalloc<uint32_t>((i64) W->dense_slots * W->dense_stride);
-	HIP_CHECK(hipMemset(W->d_dense, 0, (size_t) W->dense_slots * W->dense_stride * sizeof(uint32_t)));
 	for (int e = 0; e < 4; e++)
 		HIP_CHECK(hipEventCreate(&W->ev[e]));
 	return W;
@@ -320,7 +375,7 @@ void spasm_hip_dwork_destroy(spasm_hip_dwork *W)
 	(void) hipFree(W->d_blocksum);
 	(void) hipFree(W->d_ctr);
 	(void) hipFree(W->d_ctr64);
-	(void) hipFree(W->d_dense);
+	(void) hipFree(W->d_scratch);
 	for (int e = 0; e < 4; e++)
 		if (W->ev[e] != nullptr)
 			(void) hipEventDestroy(W->ev[e]);
@@ -339,9 +394,41 @@ int spasm_hip_dschur(const spasm_hip_dcsr *A, const int *d_rows, int nrows, cons
 		die("spasm_hip_dschur: %d rows but the workspace was sized for %d", nrows, W->max_rows);
 	if (A->m != F->m || W->m < F->m)
 		die("spasm_hip_dschur: column count mismatch (A %d, factor %d, workspace %d)", A->m, F->m, W->m);
-	const bool wide = (F->prime >= (1LL << 19));   // lazy 32-bit sums: (6144 + 1) * p must stay below 2^32
+	// lazy 32-bit sums in the LDS tables: at most 6144 + 1 terms below p each
+	const bool wide_lds = ((double) F->prime * 6146.0 >= 4294967296.0);
+	// ... and in the dense accumulators: a column receives at most maxdeg + 1 terms
+	const bool wide_dense = ((double) F->prime * ((double) F->maxdeg + 3.0) >= 4294967296.0);
 	const int sort_rows = env_int("SPASM_HIP_SORT_ROWS", 1);
 	const int small_table = 1024, big_table = 8192;
+	const int cus = cu_count();
+	// tests: 1 = start at the large LDS table, 2 = dense accumulators only.  The large table is otherwise
+	// skipped (one wave per CU: slower than the dense tier) unless SPASM_HIP_USE_BIG_TABLE=1.
+	const int force_tier = env_int("SPASM_HIP_FORCE_TIER", 0);
+	const bool use_big = (force_tier == 1) || env_int("SPASM_HIP_USE_BIG_TABLE", 0);
+
+	// per-wave dense scratch, (re)allocated when the factor geometry needs more
+	{
+		i64 slot_bytes, off_bm, off_xn;
+		wave_dense_geometry(F->rpad, F->Sm, wide_dense, &slot_bytes, &off_bm, &off_xn);
+		int slots = env_int("SPASM_HIP_WAVE_SLOTS", cus * 20);
+		const i64 budget = (i64) env_int("SPASM_HIP_SCRATCH_GB", 48) << 30;
+		slots = (int) std::max<i64>(cus, std::min<i64>(slots, budget / slot_bytes));
+		slots = std::max(1, std::min(slots, nrows));
+		const i64 need = slot_bytes * slots;
+		if (need > W->scratch_bytes) {
+			if (W->d_scratch != nullptr)
+				(void) hipFree(W->d_scratch);
+			HIP_CHECK(hipMalloc((void **) &W->d_scratch, (size_t) need));
+			W->scratch_bytes = need;
+			HIP_CHECK(hipMemsetAsync(W->d_scratch, 0, (size_t) need, stream));
+		} else if (slot_bytes != W->slot_bytes || off_bm != W->off_bm || off_xn != W->off_xn) {
+			// same buffer, other layout: it is all zero anyway (the kernels restore that invariant)
+		}
+		W->scratch_slots = slots;
+		W->slot_bytes = slot_bytes;
+		W->off_bm = off_bm;
+		W->off_xn = off_xn;
+	}
 
 	HIP_CHECK(hipMemsetAsync(W->d_ctr, 0, CTR_COUNT * sizeof(int), stream));
 	HIP_CHECK(hipMemsetAsync(W->d_ctr64, 0, C64_COUNT * sizeof(unsigned long long), stream));
@@ -358,7 +445,9 @@ int spasm_hip_dschur(const spasm_hip_dcsr *A, const int *d_rows, int nrows, cons
 	a.rp = F->d_rp;
 	a.ent = F->d_ent;
 	a.lvl_end = F->d_lvl_end;
-	a.r = F->r;
+	a.lvl_end_w = F->d_lvl_end_w;
+	a.r = F->rpad;              // kernels only see the padded label space
+	a.Sm = F->m - F->r;
 	a.m = F->m;
 	a.F = to_dev(F->mont);
 	a.pool_j = W->d_pool_j;
@@ -369,41 +458,44 @@ int spasm_hip_dschur(const spasm_hip_dcsr *A, const int *d_rows, int nrows, cons
 	a.ctr = W->d_ctr;
 	a.ctr64 = W->d_ctr64;
 
-	const int cus = cu_count();
-	const int force_tier = env_int("SPASM_HIP_FORCE_TIER", 0);     // tests: 1 = start at the large table, 2 = dense tier only
 	if (nrows > 0) {
-		// tier 0: small table, many waves per CU
+		// tier 0: small LDS table, many waves per CU
 		a.list = nullptr;
 		a.list_count = nullptr;
 		a.ovf_list = W->d_ovf1;
 		a.next_ctr = CTR_ROW_NEXT;
 		a.ovf_ctr = CTR_OVF1;
 		a.done_ctr = CTR_DONE0;
-		const int per_cu0 = (int) std::min<size_t>(16, (size_t) (160 * 1024) / schur_lds_bytes(small_table, wide));
-		int blocks0 = std::min(cus * per_cu0 * env_int("SPASM_HIP_OVERSUB", 1), (nrows + 3) / 4);
+		const int per_cu0 = (int) std::min<size_t>(16, (size_t) (160 * 1024) / schur_lds_bytes(small_table, wide_lds));
+		int blocks0 = std::min(cus * per_cu0, (nrows + 3) / 4);
 		if (force_tier == 0)
-			launch_schur_lds(a, small_table, wide, std::max(blocks0, 1), stream);
+			launch_schur_lds(a, small_table, wide_lds, std::max(blocks0, 1), stream);
 		else
 			launch_all_rows_to_list(W->d_ovf1, W->d_ctr + CTR_OVF1, W->d_row_len, nrows, stream);
-		// tier 1: rows that did not fit, large table (one wave per CU)
-		a.list = W->d_ovf1;
-		a.list_count = W->d_ctr + CTR_OVF1;
-		a.ovf_list = W->d_ovf2;
-		a.next_ctr = CTR_ROW_NEXT2;
-		a.ovf_ctr = CTR_OVF2;
-		a.done_ctr = CTR_DONE1;
-		if (force_tier <= 1)
-			launch_schur_lds(a, big_table, wide, cus, stream);
-		else
-			launch_all_rows_to_list(W->d_ovf2, W->d_ctr + CTR_OVF2, W->d_row_len, nrows, stream);
-		// tier 2: dense accumulator in HBM, one workgroup per row
-		a.list = W->d_ovf2;
-		a.list_count = W->d_ctr + CTR_OVF2;
+		HIP_CHECK(hipEventRecord(W->ev[3], stream));
+		// tier 1 (optional): large LDS table, one wave per CU
+		const int *last_list = W->d_ovf1;
+		const int *last_count = W->d_ctr + CTR_OVF1;
+		if (use_big) {
+			a.list = W->d_ovf1;
+			a.list_count = W->d_ctr + CTR_OVF1;
+			a.ovf_list = W->d_ovf2;
+			a.next_ctr = CTR_ROW_NEXT2;
+			a.ovf_ctr = CTR_OVF2;
+			a.done_ctr = CTR_DONE1;
+			launch_schur_lds(a, big_table, wide_lds, cus, stream);
+			last_list = W->d_ovf2;
+			last_count = W->d_ctr + CTR_OVF2;
+		}
+		// tier 2: dense accumulators in HBM, one wave per row, thousands of rows in flight
+		a.list = last_list;
+		a.list_count = last_count;
 		a.ovf_list = nullptr;
 		a.next_ctr = CTR_ROW_NEXT3;
 		a.ovf_ctr = CTR_OVF2;
 		a.done_ctr = CTR_DONE2;
-		launch_schur_dense_tier(a, W, W->dense_slots, stream);
+		launch_schur_wave_dense(a, W->d_scratch, W->slot_bytes, W->off_bm, W->off_xn, wide_dense, nullptr, 0,
+		                        W->scratch_slots, stream);
 	}
 	HIP_CHECK(hipEventRecord(W->ev[1], stream));
 	launch_finalize(W, nrows, sort_rows, stream);
@@ -430,6 +522,9 @@ int spasm_hip_dschur(const spasm_hip_dcsr *A, const int *d_rows, int nrows, cons
 		stats->rows_dense = ctr[CTR_DONE2];
 		stats->status = status;
 		HIP_CHECK(hipEventElapsedTime(&stats->ms_eliminate, W->ev[0], W->ev[1]));
+		stats->ms_tier0 = 0.0f;
+		if (nrows > 0)
+			HIP_CHECK(hipEventElapsedTime(&stats->ms_tier0, W->ev[0], W->ev[3]));
 		HIP_CHECK(hipEventElapsedTime(&stats->ms_total, W->ev[0], W->ev[2]));
 	}
 	return status;

@@ -614,277 +614,7 @@ void launch_finalize(const spasm_hip_dwork *W, int nrows, int sort_rows, hipStre
 
 }  // namespace sh
 
-// --------------------------------------------------------------------------
-// K2: dense accumulator tier.  One 256-thread workgroup per row; the running
-// row is a dense vector in HBM (pivotal part xp[0..r), non-pivotal part
-// xn[0..Sm)), pending pivots are a bitmap over labels.  Used (a) for rows
-// whose reach does not fit the LDS tables and (b) to produce dense rows of
-// the Schur complement for the dense tail (xn is then the output row).
-// All traffic to xp/xn/bitmap that other waves may have updated goes through
-// agent-scope atomics (served by L2), phases are separated by barriers.
-// --------------------------------------------------------------------------
 namespace sh {
-
-namespace {
-
-constexpr int DT_THREADS = 256;
-constexpr int DT_ACT = 2048;           // pivots gathered per pass
-
-__device__ __forceinline__ uint32_t ld_l2(const uint32_t *p)
-{
-	return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-}
-
-__device__ __forceinline__ void st_l2(uint32_t *p, uint32_t v)
-{
-	__hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-}
-
-__device__ __forceinline__ void addmod_l2(uint32_t *p, uint32_t delta, uint32_t prime)
-{
-	uint32_t old = ld_l2(p);
-	for (;;) {
-		uint32_t s = old + delta;
-		if (s < old || s >= prime)
-			s -= prime;
-		uint32_t seen = atomicCAS(p, old, s);
-		if (seen == old)
-			return;
-		old = seen;
-	}
-}
-
-}  // namespace
-
-struct DenseTierArgs {
-	SchurArgs a;
-	uint32_t *scratch;        // per-workgroup slots
-	int64_t stride;           // words per slot
-	uint32_t *dense_out;      // non-null: write dense rows here instead of the pool
-	int64_t ldS;
-};
-
-__global__ __launch_bounds__(DT_THREADS) void schur_dense_kernel(DenseTierArgs d)
-{
-	const SchurArgs &a = d.a;
-	__shared__ uint32_t act[DT_ACT];
-	__shared__ int s_int[8];          // 0: row grab, 1: found label, 2: act count
-	__shared__ int64_t s_off;
-	__shared__ int wave_tot[DT_THREADS / 64];
-	const int tid = threadIdx.x;
-	const int lane = tid & 63, wave = tid >> 6;
-	const uint32_t r = (uint32_t) a.r;
-	const int Sm = a.m - a.r;
-	const MontDev F = a.F;
-	const int total_rows = (a.list != nullptr) ? *a.list_count : a.nrows;
-	const int nwords = (int) ((r + 31) / 32);
-
-	uint32_t *slot = d.scratch + (int64_t) blockIdx.x * d.stride;
-	uint32_t *xp = slot;                                           // r words
-	uint32_t *bm = slot + (((int64_t) r + 63) / 64) * 64;          // nwords words
-	uint32_t *xn_scratch = bm + (((int64_t) nwords + 63) / 64) * 64;   // Sm words (sparse-output mode)
-
-	unsigned long long st_elim = 0, st_stream = 0, st_input = 0;
-	int st_done = 0;
-
-	for (;;) {
-		__syncthreads();
-		if (tid == 0)
-			s_int[0] = atomicAdd(&a.ctr[a.next_ctr], 1);
-		__syncthreads();
-		const int kk = s_int[0];
-		if (kk >= total_rows)
-			break;
-		const int k = (a.list != nullptr) ? a.list[kk] : kk;
-		const int i = a.rows[k];
-		uint32_t *xn = (d.dense_out != nullptr) ? d.dense_out + (int64_t) k * d.ldS : xn_scratch;
-		if (d.dense_out != nullptr) {
-			for (int t = tid; t < Sm; t += DT_THREADS)
-				st_l2(&xn[t], 0u);
-			__syncthreads();
-		}
-
-		// ---- scatter the input row ----
-		const int64_t lo = a.Ap[i], hi = a.Ap[i + 1];
-		if (tid == 0)
-			st_input += (unsigned long long) (hi - lo);
-		for (int64_t px = lo + tid; px < hi; px += DT_THREADS) {
-			const uint32_t c = a.lab[a.Aj[px]];
-			uint32_t v = from_balanced(a.Ax[px], F);
-			if (v >= F.p)
-				v %= F.p;
-			if (c < r) {
-				addmod_l2(&xp[c], v, F.p);
-				atomicOr(&bm[c >> 5], 1u << (c & 31));
-			} else {
-				addmod_l2(&xn[c - r], v, F.p);
-			}
-		}
-		__syncthreads();
-
-		// ---- eliminate level by level ----
-		int word_cursor = 0;
-		for (;;) {
-			// first pending label at or after the cursor
-			if (tid == 0)
-				s_int[1] = 0x7FFFFFFF;
-			__syncthreads();
-			int found = 0x7FFFFFFF;
-			for (int base = word_cursor; base < nwords; base += DT_THREADS) {
-				const int wd = base + tid;
-				if (wd < nwords) {
-					const uint32_t bits = ld_l2(&bm[wd]);
-					if (bits != 0)
-						atomicMin(&s_int[1], wd * 32 + __builtin_ctz(bits));
-				}
-				__syncthreads();
-				found = s_int[1];
-				if (found != 0x7FFFFFFF)
-					break;
-			}
-			__syncthreads();
-			if (found == 0x7FFFFFFF)
-				break;
-			const uint32_t c0 = (uint32_t) found;
-			const uint32_t lend = a.lvl_end[c0];
-			// a pass covers at most DT_ACT labels (DT_ACT / 32 bitmap words), so act[] cannot overflow
-			uint32_t pass_lo = c0;
-			while (pass_lo < lend) {
-				const int wbase = (int) (pass_lo >> 5);
-				const int wall = (int) ((lend + 31) >> 5);
-				const int wlim = (wall < wbase + DT_ACT / 32) ? wall : wbase + DT_ACT / 32;
-				const uint32_t pass_hi = ((uint32_t) wlim * 32 < lend) ? (uint32_t) wlim * 32 : lend;
-				if (tid == 0)
-					s_int[2] = 0;
-				__syncthreads();
-				if (tid < wlim - wbase) {
-					const int wd = wbase + tid;
-					uint32_t bits = ld_l2(&bm[wd]);
-					const uint32_t first = (uint32_t) wd * 32;
-					if (first < pass_lo)
-						bits &= ~((1u << (pass_lo - first)) - 1u);
-					if (first + 32 > pass_hi)
-						bits &= (1u << (pass_hi - first)) - 1u;      // pass_hi - first is in [1, 31]
-					if (bits != 0) {
-						int w = atomicAdd(&s_int[2], __popc(bits));
-						uint32_t b = bits;
-						while (b) {
-							const int bit = __builtin_ctz(b);
-							b &= b - 1;
-							act[w++] = first + bit;
-						}
-						atomicAnd(&bm[wd], ~bits);
-					}
-				}
-				__syncthreads();
-				const int nact = s_int[2];
-				// apply: one wave per pivot
-				for (int t = wave; t < nact; t += DT_THREADS / 64) {
-					const uint32_t c = act[t];
-					const uint32_t v = ld_l2(&xp[c]);
-					if (lane == 0)
-						st_l2(&xp[c], 0u);
-					if (v == 0)
-						continue;
-					const uint64_t start = a.rp[c];
-					const int len = (int) (a.rp[c + 1] - start);
-					const uint32_t w = F.p - v;
-					if (lane == 0) {
-						st_elim += 1;
-						st_stream += (unsigned long long) len;
-					}
-					for (int l = lane; l < len; l += 64) {
-						const uint2 e = a.ent[start + l];
-						const uint32_t delta = montmul(w, e.y, F);
-						if (e.x < r) {
-							addmod_l2(&xp[e.x], delta, F.p);
-							atomicOr(&bm[e.x >> 5], 1u << (e.x & 31));
-						} else {
-							addmod_l2(&xn[e.x - r], delta, F.p);
-						}
-					}
-				}
-				__syncthreads();
-				pass_lo = pass_hi;
-			}
-			word_cursor = (int) (lend >> 5);
-		}
-
-		if (d.dense_out != nullptr) {
-			if (tid == 0) {
-				a.row_len[k] = Sm;
-				st_done += 1;
-			}
-			continue;
-		}
-
-		// ---- compact the non-pivotal part into the pool (sorted by column) ----
-		int mine = 0;
-		for (int t = tid; t < Sm; t += DT_THREADS)
-			mine += (ld_l2(&xn[t]) != 0);
-		// block reduce
-		for (int dlt = 32; dlt >= 1; dlt >>= 1)
-			mine += __shfl_xor(mine, dlt);
-		if (lane == 0)
-			wave_tot[wave] = mine;
-		__syncthreads();
-		int count = 0;
-		for (int wv = 0; wv < DT_THREADS / 64; wv++)
-			count += wave_tot[wv];
-		__syncthreads();
-		if (tid == 0) {
-			unsigned long long got = atomicAdd(&a.ctr64[C64_POOL], (unsigned long long) count);
-			s_off = (int64_t) got;
-		}
-		__syncthreads();
-		const int64_t off = s_off;
-		const bool fits = off + count <= a.pool_cap;
-		if (!fits && tid == 0) {
-			atomicOr(&a.ctr[CTR_STATUS], 1);
-			a.row_len[k] = -1;
-		}
-		int64_t wpos = off;
-		for (int base = 0; base < Sm; base += DT_THREADS) {
-			const int t = base + tid;
-			uint32_t v = (t < Sm) ? ld_l2(&xn[t]) : 0u;
-			if (t < Sm && v != 0)
-				st_l2(&xn[t], 0u);
-			const bool keep = v != 0;
-			const uint64_t mk = __ballot(keep);
-			if (lane == 0)
-				wave_tot[wave] = __popcll(mk);
-			__syncthreads();
-			int before = 0, all = 0;
-			for (int wv = 0; wv < DT_THREADS / 64; wv++) {
-				if (wv < wave)
-					before += wave_tot[wv];
-				all += wave_tot[wv];
-			}
-			if (keep && fits) {
-				const int64_t dst = wpos + before + __popcll(mk & lanes_below(lane));
-				a.pool_j[dst] = a.q[t];
-				a.pool_x[dst] = to_balanced(v, F);
-			}
-			wpos += all;
-			__syncthreads();
-		}
-		if (tid == 0 && fits) {
-			a.row_off[k] = off | (1LL << 62);       // already sorted by column
-			a.row_len[k] = count;
-			st_done += 1;
-		}
-	}
-	if (lane == 0) {
-		atomicAdd(&a.ctr64[C64_ELIM], st_elim);
-		atomicAdd(&a.ctr64[C64_STREAM], st_stream);
-	}
-	if (tid == 0) {
-		atomicAdd(&a.ctr64[C64_INPUT], st_input);
-		atomicAdd(&a.ctr[a.done_ctr], st_done);
-	}
-}
-
-int dense_tier_slots() { return 256; }
 
 __global__ void all_rows_to_list_kernel(int *list, int *count, int *row_len, int nrows)
 {
@@ -903,34 +633,319 @@ void launch_all_rows_to_list(int *list, int *count, int *row_len, int nrows, hip
 	HIP_CHECK(hipGetLastError());
 }
 
-int64_t dense_tier_stride(int m)
+}  // namespace sh
+
+// --------------------------------------------------------------------------
+// K2w: dense accumulators in HBM, ONE WAVE per row, thousands of rows in
+// flight.  For rows whose reach does not fit an LDS table (on mk13.b5 that is
+// most of them: ~8000 eliminations and ~10^4 distinct columns per row).
+//
+// Per wave: xp[0..r) pivotal part, bm = bitmap of pending pivots, xn[0..Sm)
+// non-pivotal part, all private to the wave, all zero between rows.  Updates
+// are fire-and-forget wavefront-scope atomics (performed in the XCD's L2),
+// every read of that state is an sc1 load (served by L2, never by the L1).
+// A step = find the first pending label, take every pending label of its
+// level, stream the rows of U' they select (flattened over the 64 lanes).
+// --------------------------------------------------------------------------
+namespace sh {
+
+namespace {
+
+constexpr int WD_ACT = 2048;             // labels gathered per pass (64 bitmap words)
+constexpr uint32_t MIXED = 0xFFFFFFFFu;
+
+template <typename V> __device__ __forceinline__ V ld_sc1(const V *p)
 {
-	const int64_t rm = ((int64_t) m + 63) / 64 * 64;
-	return rm + (rm / 32 + 64) / 64 * 64 + 64 + rm + 128;
+	return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
-void launch_schur_dense_tier(const SchurArgs &a, const spasm_hip_dwork *W, int blocks, hipStream_t stream)
+template <typename V> __device__ __forceinline__ void add_ff(V *p, uint32_t delta)
 {
-	DenseTierArgs d;
-	d.a = a;
-	d.scratch = W->d_dense;
-	d.stride = W->dense_stride;
-	d.dense_out = nullptr;
-	d.ldS = 0;
-	hipLaunchKernelGGL(schur_dense_kernel, dim3(blocks), dim3(DT_THREADS), 0, stream, d);
-	HIP_CHECK(hipGetLastError());
+	(void) __hip_atomic_fetch_add(p, (V) delta, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
 }
 
-void launch_schur_dense_rows(const SchurArgs &a, const spasm_hip_dwork *W, uint32_t *dS, int64_t ldS, int blocks,
-                             hipStream_t stream)
+__device__ __forceinline__ void or_ff(uint32_t *p, uint32_t bits)
 {
-	DenseTierArgs d;
+	(void) __hip_atomic_fetch_or(p, bits, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+}
+
+__device__ __forceinline__ void drain_vmem() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
+
+}  // namespace
+
+struct WaveDenseArgs {
+	SchurArgs a;
+	unsigned char *scratch;   // per-wave slots
+	int64_t slot_bytes;
+	int64_t off_bm, off_xn;   // byte offsets of the bitmap and of xn inside a slot
+	uint32_t *dense_out;      // non-null: dense rows (values in [0,p)) instead of the pool
+	int64_t ldS;
+};
+
+template <bool WIDE>
+__global__ __launch_bounds__(64) void schur_wave_dense_kernel(WaveDenseArgs d)
+{
+	using V = typename Acc<WIDE>::type;
+	__shared__ uint32_t act[WD_ACT];
+	const SchurArgs &a = d.a;
+	const int lane = threadIdx.x;
+	const uint32_t r = (uint32_t) a.r;
+	const int Sm = a.Sm;
+	const MontDev F = a.F;
+	const int nw = (int) (r / 32);
+	const int total_rows = (a.list != nullptr) ? *a.list_count : a.nrows;
+
+	unsigned char *slot = d.scratch + (int64_t) blockIdx.x * d.slot_bytes;
+	V *xp = reinterpret_cast<V *>(slot);
+	uint32_t *bm = reinterpret_cast<uint32_t *>(slot + d.off_bm);
+	V *xn = reinterpret_cast<V *>(slot + d.off_xn);
+
+	unsigned long long st_elim = 0, st_stream = 0, st_input = 0;
+	int st_done = 0;
+
+	for (;;) {
+		int kk = 0;
+		if (lane == 0)
+			kk = atomicAdd(&a.ctr[a.next_ctr], 1);
+		kk = __builtin_amdgcn_readfirstlane(kk);
+		if (kk >= total_rows)
+			break;
+		const int k = (a.list != nullptr) ? a.list[kk] : kk;
+		const int i = a.rows[k];
+
+		// ---- scatter the input row ----
+		const int64_t lo = a.Ap[i], hi = a.Ap[i + 1];
+		st_input += (unsigned long long) (hi - lo);
+		for (int64_t px = lo + lane; px < hi; px += 64) {
+			const uint32_t c = a.lab[a.Aj[px]];
+			const uint32_t v = reduce_sum(from_balanced(a.Ax[px], F), F);
+			if (c < r) {
+				add_ff(&xp[c], v);
+				or_ff(&bm[c >> 5], 1u << (c & 31));
+			} else {
+				add_ff(&xn[c - r], v);
+			}
+		}
+
+		// ---- eliminate level by level ----
+		uint32_t cursor = 0;
+		for (;;) {
+			drain_vmem();                       // every earlier atomic has reached L2
+			// first pending label at or after the cursor
+			int wi = -1;
+			uint32_t fbits = 0, lwe = 0;
+			const int wstart = (int) (cursor >> 5);
+			for (int base = wstart; base < nw; base += 64) {
+				const int w = base + lane;
+				uint32_t bits = 0, lw = 0;
+				if (w < nw) {
+					bits = ld_sc1(&bm[w]);
+					lw = a.lvl_end_w[w];
+					if (w == wstart)
+						bits &= ~((1u << (cursor & 31)) - 1u);
+				}
+				const uint64_t mask = __ballot(bits != 0);
+				if (mask != 0) {
+					const int fl = __builtin_ctzll(mask);
+					wi = base + fl;
+					fbits = (uint32_t) __shfl((int) bits, fl);
+					lwe = (uint32_t) __shfl((int) lw, fl);
+					break;
+				}
+			}
+			if (wi < 0)
+				break;
+			const uint32_t c0 = (uint32_t) wi * 32 + (uint32_t) __builtin_ctz(fbits);
+			const uint32_t lend = (lwe != MIXED) ? lwe * 32 : a.lvl_end[c0];
+			const int wl = (int) ((lend + 31) >> 5);
+
+			// gather the pending labels of [c0, lend), 64 words per pass
+			for (int wb = wi; wb < wl; wb += 64) {
+				const int w = wb + lane;
+				uint32_t bits = 0;
+				if (w < wl) {
+					const uint32_t orig = ld_sc1(&bm[w]);
+					bits = orig;
+					if (w == wi)
+						bits &= ~((1u << (c0 & 31)) - 1u);
+					if ((uint32_t) w * 32 + 32 > lend)
+						bits &= (1u << (lend & 31)) - 1u;       // lend & 31 != 0 here
+					if (bits != 0)      // atomic: updates to later levels' bits of this word may still be in flight
+						(void) __hip_atomic_fetch_and(&bm[w], ~bits, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+				}
+				int tot;
+				int pos = wave_exclusive_scan(__popc(bits), lane, tot);
+				uint32_t b = bits;
+				while (b) {
+					const int bit = __builtin_ctz(b);
+					b &= b - 1;
+					act[pos++] = (uint32_t) w * 32 + bit;
+				}
+				__builtin_amdgcn_wave_barrier();
+				__builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+
+				// apply the gathered pivots, 64 at a time
+				for (int t0 = 0; t0 < tot; t0 += 64) {
+					const int t = t0 + lane;
+					const bool sel = t < tot;
+					const uint32_t c = sel ? ((volatile uint32_t *) act)[t] : 0u;
+					uint32_t v = 0;
+					uint64_t start = 0;
+					int len = 0;
+					if (sel) {
+						const V raw = ld_sc1(&xp[c]);
+						start = a.rp[c];
+						len = (int) (a.rp[c + 1] - start);
+						v = reduce_sum(raw, F);
+						__hip_atomic_store(&xp[c], (V) 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+					}
+					if (v == 0)
+						len = 0;
+					const uint32_t w_neg = F.p - v;
+					st_elim += (unsigned long long) __popcll(__ballot(v != 0));
+					int ftot;
+					const int excl = wave_exclusive_scan(len, lane, ftot);
+					st_stream += (unsigned long long) ftot;
+					const uint32_t start_lo = (uint32_t) start, start_hi = (uint32_t) (start >> 32);
+					for (int f0 = 0; f0 < ftot; f0 += 64) {
+						const int f = f0 + lane;
+						int owner = 0;
+#pragma unroll
+						for (int step = 32; step >= 1; step >>= 1) {
+							const int cand = owner + step;
+							const int e = __shfl(excl, cand);
+							if (e <= f)
+								owner = cand;
+						}
+						const uint32_t o_lo = (uint32_t) __shfl((int) start_lo, owner);
+						const uint32_t o_hi = (uint32_t) __shfl((int) start_hi, owner);
+						const uint32_t o_w = (uint32_t) __shfl((int) w_neg, owner);
+						const int o_ex = __shfl(excl, owner);
+						if (f < ftot) {
+							const uint64_t idx = (((uint64_t) o_hi << 32) | o_lo) + (uint64_t) (f - o_ex);
+							const uint2 e = a.ent[idx];
+							const uint32_t delta = montmul(o_w, e.y, F);
+							if (e.x < r) {
+								add_ff(&xp[e.x], delta);
+								or_ff(&bm[e.x >> 5], 1u << (e.x & 31));
+							} else {
+								add_ff(&xn[e.x - r], delta);
+							}
+						}
+					}
+				}
+				__builtin_amdgcn_wave_barrier();
+			}
+			cursor = lend;
+		}
+		drain_vmem();
+
+		// ---- the non-pivotal part is the row of S ----
+		if (d.dense_out != nullptr) {
+			uint32_t *out = d.dense_out + (int64_t) k * d.ldS;
+			for (int t = lane; t < Sm; t += 64) {
+				const V raw = ld_sc1(&xn[t]);
+				out[t] = reduce_sum(raw, F);
+				if (raw != 0)
+					__hip_atomic_store(&xn[t], (V) 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+			}
+			if (lane == 0)
+				a.row_len[k] = Sm;
+			st_done += 1;
+			continue;
+		}
+		int count = 0;
+		for (int t0 = 0; t0 < Sm; t0 += 256) {
+			V raw[4];
+#pragma unroll
+			for (int u = 0; u < 4; u++) {
+				const int t = t0 + u * 64 + lane;
+				raw[u] = (t < Sm) ? ld_sc1(&xn[t]) : (V) 0;
+			}
+#pragma unroll
+			for (int u = 0; u < 4; u++) {
+				const bool keep = (raw[u] != 0) && (reduce_sum(raw[u], F) != 0);
+				count += __popcll(__ballot(keep));
+			}
+		}
+		unsigned long long got = 0;
+		if (lane == 0)
+			got = atomicAdd(&a.ctr64[C64_POOL], (unsigned long long) count);
+		const uint32_t g_lo = __builtin_amdgcn_readfirstlane((uint32_t) got);
+		const uint32_t g_hi = __builtin_amdgcn_readfirstlane((uint32_t) (got >> 32));
+		const int64_t off = (int64_t) (((uint64_t) g_hi << 32) | g_lo);
+		const bool fits = off + count <= a.pool_cap;
+		int64_t wpos = off;
+		for (int t0 = 0; t0 < Sm; t0 += 256) {
+			V raw[4];
+#pragma unroll
+			for (int u = 0; u < 4; u++) {
+				const int t = t0 + u * 64 + lane;
+				raw[u] = (t < Sm) ? ld_sc1(&xn[t]) : (V) 0;
+			}
+#pragma unroll
+			for (int u = 0; u < 4; u++) {
+				const int t = t0 + u * 64 + lane;
+				uint32_t v = 0;
+				if (raw[u] != 0) {
+					v = reduce_sum(raw[u], F);
+					__hip_atomic_store(&xn[t], (V) 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+				}
+				const bool keep = v != 0;
+				const uint64_t mk = __ballot(keep);
+				if (keep && fits) {
+					const int64_t dst = wpos + __popcll(mk & lanes_below(lane));
+					a.pool_j[dst] = a.q[t];
+					a.pool_x[dst] = to_balanced(v, F);
+				}
+				wpos += __popcll(mk);
+			}
+		}
+		if (lane == 0) {
+			if (fits) {
+				a.row_off[k] = off | (1LL << 62);       // sorted by column already
+				a.row_len[k] = count;
+			} else {
+				atomicOr(&a.ctr[CTR_STATUS], 1);
+				a.row_len[k] = -1;
+			}
+		}
+		st_done += fits ? 1 : 0;
+	}
+	drain_vmem();
+	if (lane == 0) {
+		atomicAdd(&a.ctr64[C64_ELIM], st_elim);
+		atomicAdd(&a.ctr64[C64_STREAM], st_stream);
+		atomicAdd(&a.ctr64[C64_INPUT], st_input);
+		atomicAdd(&a.ctr[a.done_ctr], st_done);
+	}
+}
+
+// slot geometry: xp (rpad accumulators) | bitmap (rpad/32 words) | xn (Sm accumulators), 256-byte aligned parts
+void wave_dense_geometry(int rpad, int Sm, bool wide, int64_t *slot_bytes, int64_t *off_bm, int64_t *off_xn)
+{
+	const int64_t vb = wide ? 8 : 4;
+	auto up = [](int64_t x) { return (x + 255) / 256 * 256; };
+	*off_bm = up((int64_t) rpad * vb);
+	*off_xn = *off_bm + up((int64_t) (rpad / 32 + 1) * 4);
+	*slot_bytes = *off_xn + up((int64_t) Sm * vb) + 256;
+}
+
+void launch_schur_wave_dense(const SchurArgs &a, unsigned char *scratch, int64_t slot_bytes, int64_t off_bm, int64_t off_xn,
+                             bool wide, uint32_t *dense_out, int64_t ldS, int blocks, hipStream_t stream)
+{
+	WaveDenseArgs d;
 	d.a = a;
-	d.scratch = W->d_dense;
-	d.stride = W->dense_stride;
-	d.dense_out = dS;
+	d.scratch = scratch;
+	d.slot_bytes = slot_bytes;
+	d.off_bm = off_bm;
+	d.off_xn = off_xn;
+	d.dense_out = dense_out;
 	d.ldS = ldS;
-	hipLaunchKernelGGL(schur_dense_kernel, dim3(blocks), dim3(DT_THREADS), 0, stream, d);
+	if (wide)
+		hipLaunchKernelGGL((schur_wave_dense_kernel<true>), dim3(blocks), dim3(64), 0, stream, d);
+	else
+		hipLaunchKernelGGL((schur_wave_dense_kernel<false>), dim3(blocks), dim3(64), 0, stream, d);
 	HIP_CHECK(hipGetLastError());
 }
 

@@ -1,0 +1,74 @@
+"""Row-batch sharding of the Schur complement over the GPUs of one node.
+
+Rows of a Schur complement are independent (spasm_schur.c:88-171 hands them to
+OpenMP threads one by one), so every rank reduces a contiguous slice of the
+row list against its own replica of (A, factor) and the slices are reassembled
+with an all-gatherv: sizes first, then the padded payload through
+all_gather_into_tensor (RCCL over xGMI on GPUs; gloo in the CPU tests).
+"""
+import numpy as np
+
+
+def shard_bounds(n, rank, world):
+    """[lo, hi) of the contiguous slice of n rows owned by `rank` (sizes differ by at most one)."""
+    base, extra = divmod(n, world)
+    lo = rank * base + min(rank, extra)
+    return lo, lo + base + (1 if rank < extra else 0)
+
+
+def shard_rows(rows, rank, world):
+    lo, hi = shard_bounds(len(rows), rank, world)
+    return rows[lo:hi]
+
+
+def allgatherv_csr(S, dist, group=None):
+    """S: DeviceCsr-like (n, m, p, j, x tensors, prime) holding this rank's rows.
+    Returns the concatenation over ranks, in rank order, as the same kind of object."""
+    import torch
+    from .device import DeviceCsr
+    world = dist.get_world_size(group)
+    dev = S.p.device
+    nnz = int(S.p[S.n].item()) if S.n > 0 else 0
+    mine = torch.tensor([S.n, nnz], dtype=torch.int64, device=dev)
+    sizes = torch.empty(2 * world, dtype=torch.int64, device=dev)
+    dist.all_gather_into_tensor(sizes, mine, group=group)
+    sizes = sizes.view(world, 2).cpu()
+    max_n, max_nz = int(sizes[:, 0].max()), int(sizes[:, 1].max())
+    # row lengths (int64) and the two entry arrays, padded to the largest slice
+    lens = torch.zeros(max(max_n, 1), dtype=torch.int64, device=dev)
+    if S.n:
+        lens[:S.n] = S.p[1:S.n + 1] - S.p[:S.n]
+    jx = torch.zeros(2, max(max_nz, 1), dtype=torch.int32, device=dev)
+    if nnz:
+        jx[0, :nnz] = S.j[:nnz]
+        jx[1, :nnz] = S.x[:nnz]
+    all_lens = torch.empty(world * lens.numel(), dtype=torch.int64, device=dev)
+    all_jx = torch.empty(world * jx.numel(), dtype=torch.int32, device=dev)
+    dist.all_gather_into_tensor(all_lens, lens, group=group)
+    dist.all_gather_into_tensor(all_jx, jx.view(-1), group=group)
+    all_lens = all_lens.view(world, -1)
+    all_jx = all_jx.view(world, 2, -1)
+    n_tot = int(sizes[:, 0].sum())
+    keep_lens = torch.cat([all_lens[r, :int(sizes[r, 0])] for r in range(world)]) if n_tot else lens[:0]
+    p = torch.zeros(n_tot + 1, dtype=torch.int64, device=dev)
+    if n_tot:
+        p[1:] = torch.cumsum(keep_lens, 0)
+    j = torch.cat([all_jx[r, 0, :int(sizes[r, 1])] for r in range(world)])
+    x = torch.cat([all_jx[r, 1, :int(sizes[r, 1])] for r in range(world)])
+    if j.numel() == 0:
+        j = torch.zeros(1, dtype=torch.int32, device=dev)
+        x = torch.zeros(1, dtype=torch.int32, device=dev)
+    return DeviceCsr(n_tot, S.m, p, j, x, S.prime)
+
+
+def sharded_schur(A, rows, F, W, dist, reduce_rows, stream=0, group=None):
+    """Schur complement of `rows` computed by all ranks of `group`.
+
+    reduce_rows(my_rows) -> DeviceCsr of this rank's slice; the product passes
+    the HIP path (spasm_amd.device.dschur), the CPU tests pass a stand-in so the
+    sharding + all-gatherv logic can run under gloo without a GPU.
+    """
+    rank, world = dist.get_rank(group), dist.get_world_size(group)
+    mine = shard_rows(rows, rank, world)
+    S = reduce_rows(mine)
+    return allgatherv_csr(S, dist, group=group)

@@ -88,8 +88,9 @@ def _plan(F):
     lab = np.zeros(max(m, 1), np.int32)
     ip = lambda a: a.ctypes.data_as(C.POINTER(C.c_int))
     q = np.ascontiguousarray(F.qinv, np.int32)
-    nlev = L.spasm_hip_debug_plan(C.byref(u), ip(q), ip(label), ip(lvl_end), ip(lab))
-    return nlev, label[:r], lvl_end[:r], lab[:m]
+    info = np.zeros(2, np.int32)
+    nlev = L.spasm_hip_debug_plan(C.byref(u), ip(q), ip(label), ip(lvl_end), ip(lab), ip(info))
+    return nlev, label[:r], lvl_end[:r], lab[:m], int(info[0])
 
 
 def _multi_round_fact(oracle, name, p):
@@ -110,10 +111,13 @@ def test_level_schedule_is_valid_and_eliminates_correctly(oracle, name):
     level; simulating the level-by-level elimination (what the kernels do) reproduces the oracle."""
     p = 65537
     A, S, rows2, F = _multi_round_fact(oracle, name, p)
-    nlev, label, lvl_end, lab = _plan(F)
+    nlev, label, lvl_end_row, lab, rpad = _plan(F)
     U, qinv = F.U, F.qinv
     r = U.n
-    assert sorted(label.tolist()) == list(range(r))
+    assert len(set(label.tolist())) == r and (r == 0 or (label.min() >= 0 and label.max() < rpad))
+    assert rpad % 32 == 0 and rpad <= r + 32 * max(nlev, 0)
+    lvl_end = np.zeros(max(rpad, 1), np.int64)          # by label
+    lvl_end[label] = lvl_end_row
     for k in range(r):
         jj, _ = U.row(k)
         assert lab[jj[0]] == label[k]
@@ -121,12 +125,13 @@ def test_level_schedule_is_valid_and_eliminates_correctly(oracle, name):
             if qinv[j] >= 0:
                 assert lab[j] >= lvl_end[label[k]]
             else:
-                assert lab[j] >= r
+                assert lab[j] >= rpad
+    r_real, r = r, rpad                                  # below, "r" is the size of the pivot label space
     # simulate on the second-round rows of S
     if len(rows2) == 0:
         return
     kof = np.zeros(max(r, 1), np.int64)
-    kof[label] = np.arange(r)
+    kof[label] = np.arange(r_real)
     want, _, _ = oracle.schur(S, rows2[:40], F)
     for t, i in enumerate(rows2[:40]):
         x = {}
