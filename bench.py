@@ -190,9 +190,14 @@ def main():
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     k_ms, k_elim, k_stream, k_in, k_out = 0.0, 0, 0, 0, 0
+    t_tiers = [0.0, 0.0, 0.0, 0.0]
+    rows_by_tier = (0, 0, 0)
     for _ in range(args.steps):
         st = step()
-        k_ms += st.ms_tier0
+        k_ms += st.ms_tier2
+        for q, v in enumerate((st.ms_tier0, st.ms_tier1, st.ms_tier2, st.ms_finalize)):
+            t_tiers[q] += v
+        rows_by_tier = (st.rows_lds, st.rows_lds_big, st.rows_dense)
         k_elim, k_stream, k_in, k_out = st.eliminations, st.entries_streamed, st.input_entries, st.nnz
     torch.cuda.synchronize()
     if dist is not None:
@@ -207,10 +212,11 @@ def main():
     if rank == 0:
         total_rows = len(rows)
         ms_per_step = 1e3 * elapsed / args.steps
-        # algorithmic bytes of the dominant kernel per launch (DESIGN.md "Byte accounting"):
-        # 8 B per entry read or written (column + value), 16 B of row extent per elimination,
+        # algorithmic bytes per launch (DESIGN.md "Byte accounting"), the traffic of the reference's own
+        # algorithm on a dense x: per streamed entry of U' 8 B read + 8 B read-modify-write of x;
+        # per elimination 16 B of row extent + 4 B coefficient; per input/output entry 8 B;
         # 20 B per reduced row (row id, two row pointers)
-        algo = 8 * (k_in + k_stream + k_out) + 16 * k_elim + 20 * len(my_rows)
+        algo = 16 * k_stream + 8 * (k_in + k_out) + 20 * k_elim + 20 * len(my_rows)
         kernel_ms = k_ms / args.steps
         achieved = algo / (kernel_ms * 1e-3) / 1e9 if kernel_ms > 0 else 0.0
         traffic = None
@@ -238,8 +244,14 @@ def main():
                        "sharding": "rows over %d rank(s)%s" % (world, ", all-gatherv of S" if world > 1 else "")},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": 8000.0, "unit": "GB/s",
                          "frac": achieved / 8000.0, "traffic": traffic,
-                         "kernel": "schur_lds_kernel<1024,false>", "kernel_ms": kernel_ms,
-                         "algorithmic_bytes": int(algo)},
+                         "kernel": "schur_wave_dense_kernel<false>", "kernel_ms": kernel_ms,
+                         "algorithmic_bytes": int(algo),
+                         "ms_by_kernel": {"schur_lds_kernel<1024>": t_tiers[0] / args.steps,
+                                          "schur_lds_kernel<8192>": t_tiers[1] / args.steps,
+                                          "schur_wave_dense_kernel": t_tiers[2] / args.steps,
+                                          "scan+gather_rows": t_tiers[3] / args.steps},
+                         "rows_by_kernel": {"lds_small": rows_by_tier[0], "lds_big": rows_by_tier[1],
+                                            "wave_dense": rows_by_tier[2]}},
         }
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(A, rows, F)

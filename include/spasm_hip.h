@@ -220,8 +220,11 @@ typedef struct {
 	int rows_lds_big;       /* ... by the large-table variant */
 	int rows_dense;         /* rows finished by the dense-accumulator kernel */
 	int status;             /* 0 = ok, 1 = pool too small (call again with a larger pool) */
-	float ms_eliminate;     /* device time of the elimination kernels, all tiers (HIP events) */
-	float ms_tier0;         /* ... of the dominant kernel alone (small-table LDS kernel) */
+	float ms_eliminate;     /* device time of the elimination kernels, all tiers (HIP events on the call's stream) */
+	float ms_tier0;         /* ... small-table LDS kernel (schur_lds_kernel<1024>) */
+	float ms_tier1;         /* ... large-table LDS kernel (0 when skipped) */
+	float ms_tier2;         /* ... dense-accumulator kernel (schur_wave_dense_kernel) */
+	float ms_finalize;      /* row pointers + sorted gather */
 	float ms_total;         /* device time of the whole call */
 } spasm_hip_schur_stats;
 

@@ -114,7 +114,7 @@ struct spasm_hip_dwork {
 	int64_t scratch_bytes = 0;
 	int scratch_slots = 0;
 	int64_t slot_bytes = 0, off_bm = 0, off_xn = 0;
-	hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
+	hipEvent_t ev[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
 	int last_rows = 0;
 	int64_t last_nnz = 0;
 };

@@ -354,7 +354,7 @@ spasm_hip_dwork *spasm_hip_dwork_create(int max_rows, int m, i64 pool_entries)
 	W->d_blocksum = dalloc<int64_t>((max_rows + 1023) / 1024 + 1);
 	W->d_ctr = dalloc<int>(CTR_COUNT);
 	W->d_ctr64 = dalloc<unsigned long long>(C64_COUNT);
-	for (int e = 0; e < 4; e++)
+	for (int e = 0; e < 6; e++)
 		HIP_CHECK(hipEventCreate(&W->ev[e]));
 	return W;
 }
@@ -376,7 +376,7 @@ void spasm_hip_dwork_destroy(spasm_hip_dwork *W)
 	(void) hipFree(W->d_ctr);
 	(void) hipFree(W->d_ctr64);
 	(void) hipFree(W->d_scratch);
-	for (int e = 0; e < 4; e++)
+	for (int e = 0; e < 6; e++)
 		if (W->ev[e] != nullptr)
 			(void) hipEventDestroy(W->ev[e]);
 	delete W;
@@ -487,6 +487,7 @@ int spasm_hip_dschur(const spasm_hip_dcsr *A, const int *d_rows, int nrows, cons
 			last_list = W->d_ovf2;
 			last_count = W->d_ctr + CTR_OVF2;
 		}
+		HIP_CHECK(hipEventRecord(W->ev[4], stream));
 		// tier 2: dense accumulators in HBM, one wave per row, thousands of rows in flight
 		a.list = last_list;
 		a.list_count = last_count;
@@ -522,9 +523,13 @@ int spasm_hip_dschur(const spasm_hip_dcsr *A, const int *d_rows, int nrows, cons
 		stats->rows_dense = ctr[CTR_DONE2];
 		stats->status = status;
 		HIP_CHECK(hipEventElapsedTime(&stats->ms_eliminate, W->ev[0], W->ev[1]));
-		stats->ms_tier0 = 0.0f;
-		if (nrows > 0)
+		stats->ms_tier0 = stats->ms_tier1 = stats->ms_tier2 = 0.0f;
+		if (nrows > 0) {
 			HIP_CHECK(hipEventElapsedTime(&stats->ms_tier0, W->ev[0], W->ev[3]));
+			HIP_CHECK(hipEventElapsedTime(&stats->ms_tier1, W->ev[3], W->ev[4]));
+			HIP_CHECK(hipEventElapsedTime(&stats->ms_tier2, W->ev[4], W->ev[1]));
+		}
+		HIP_CHECK(hipEventElapsedTime(&stats->ms_finalize, W->ev[1], W->ev[2]));
 		HIP_CHECK(hipEventElapsedTime(&stats->ms_total, W->ev[0], W->ev[2]));
 	}
 	return status;
