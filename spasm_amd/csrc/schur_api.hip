@@ -410,7 +410,7 @@ int spasm_hip_dschur(const spasm_hip_dcsr *A, const int *d_rows, int nrows, cons
 	{
 		i64 slot_bytes, off_bm, off_xn;
 		wave_dense_geometry(F->rpad, F->Sm, wide_dense, &slot_bytes, &off_bm, &off_xn);
-		int slots = env_int("SPASM_HIP_WAVE_SLOTS", cus * 20);
+		int slots = env_int("SPASM_HIP_WAVE_SLOTS", cus * 32);
 		const i64 budget = (i64) env_int("SPASM_HIP_SCRATCH_GB", 48) << 30;
 		slots = (int) std::max<i64>(cus, std::min<i64>(slots, budget / slot_bytes));
 		slots = std::max(1, std::min(slots, nrows));

@@ -651,7 +651,6 @@ namespace sh {
 
 namespace {
 
-constexpr int WD_ACT = 2048;             // labels gathered per pass (64 bitmap words)
 constexpr uint32_t MIXED = 0xFFFFFFFFu;
 
 template <typename V> __device__ __forceinline__ V ld_sc1(const V *p)
@@ -662,11 +661,6 @@ template <typename V> __device__ __forceinline__ V ld_sc1(const V *p)
 template <typename V> __device__ __forceinline__ void add_ff(V *p, uint32_t delta)
 {
 	(void) __hip_atomic_fetch_add(p, (V) delta, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
-}
-
-__device__ __forceinline__ void or_ff(uint32_t *p, uint32_t bits)
-{
-	(void) __hip_atomic_fetch_or(p, bits, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
 }
 
 __device__ __forceinline__ void drain_vmem() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
@@ -686,18 +680,15 @@ template <bool WIDE>
 __global__ __launch_bounds__(64) void schur_wave_dense_kernel(WaveDenseArgs d)
 {
 	using V = typename Acc<WIDE>::type;
-	__shared__ uint32_t act[WD_ACT];
 	const SchurArgs &a = d.a;
 	const int lane = threadIdx.x;
 	const uint32_t r = (uint32_t) a.r;
 	const int Sm = a.Sm;
 	const MontDev F = a.F;
-	const int nw = (int) (r / 32);
 	const int total_rows = (a.list != nullptr) ? *a.list_count : a.nrows;
 
 	unsigned char *slot = d.scratch + (int64_t) blockIdx.x * d.slot_bytes;
 	V *xp = reinterpret_cast<V *>(slot);
-	uint32_t *bm = reinterpret_cast<uint32_t *>(slot + d.off_bm);
 	V *xn = reinterpret_cast<V *>(slot + d.off_xn);
 
 	unsigned long long st_elim = 0, st_stream = 0, st_input = 0;
@@ -719,122 +710,89 @@ __global__ __launch_bounds__(64) void schur_wave_dense_kernel(WaveDenseArgs d)
 		for (int64_t px = lo + lane; px < hi; px += 64) {
 			const uint32_t c = a.lab[a.Aj[px]];
 			const uint32_t v = reduce_sum(from_balanced(a.Ax[px], F), F);
-			if (c < r) {
+			if (c < r)
 				add_ff(&xp[c], v);
-				or_ff(&bm[c >> 5], 1u << (c & 31));
-			} else {
+			else
 				add_ff(&xn[c - r], v);
-			}
 		}
 
-		// ---- eliminate level by level ----
+		// ---- eliminate level by level.  Pending pivots are the non-zero entries of xp at or after
+		// the cursor (labels are sorted by level, contributions only go to later levels) ----
 		uint32_t cursor = 0;
 		for (;;) {
-			drain_vmem();                       // every earlier atomic has reached L2
-			// first pending label at or after the cursor
-			int wi = -1;
-			uint32_t fbits = 0, lwe = 0;
-			const int wstart = (int) (cursor >> 5);
-			for (int base = wstart; base < nw; base += 64) {
-				const int w = base + lane;
-				uint32_t bits = 0, lw = 0;
-				if (w < nw) {
-					bits = ld_sc1(&bm[w]);
-					lw = a.lvl_end_w[w];
-					if (w == wstart)
-						bits &= ~((1u << (cursor & 31)) - 1u);
-				}
-				const uint64_t mask = __ballot(bits != 0);
-				if (mask != 0) {
-					const int fl = __builtin_ctzll(mask);
-					wi = base + fl;
-					fbits = (uint32_t) __shfl((int) bits, fl);
-					lwe = (uint32_t) __shfl((int) lw, fl);
-					break;
-				}
-			}
-			if (wi < 0)
-				break;
-			const uint32_t c0 = (uint32_t) wi * 32 + (uint32_t) __builtin_ctz(fbits);
-			const uint32_t lend = (lwe != MIXED) ? lwe * 32 : a.lvl_end[c0];
-			const int wl = (int) ((lend + 31) >> 5);
-
-			// gather the pending labels of [c0, lend), 64 words per pass
-			for (int wb = wi; wb < wl; wb += 64) {
-				const int w = wb + lane;
-				uint32_t bits = 0;
-				if (w < wl) {
-					const uint32_t orig = ld_sc1(&bm[w]);
-					bits = orig;
-					if (w == wi)
-						bits &= ~((1u << (c0 & 31)) - 1u);
-					if ((uint32_t) w * 32 + 32 > lend)
-						bits &= (1u << (lend & 31)) - 1u;       // lend & 31 != 0 here
-					if (bits != 0)      // atomic: updates to later levels' bits of this word may still be in flight
-						(void) __hip_atomic_fetch_and(&bm[w], ~bits, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
-				}
-				int tot;
-				int pos = wave_exclusive_scan(__popc(bits), lane, tot);
-				uint32_t b = bits;
-				while (b) {
-					const int bit = __builtin_ctz(b);
-					b &= b - 1;
-					act[pos++] = (uint32_t) w * 32 + bit;
-				}
-				__builtin_amdgcn_wave_barrier();
-				__builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
-
-				// apply the gathered pivots, 64 at a time
-				for (int t0 = 0; t0 < tot; t0 += 64) {
-					const int t = t0 + lane;
-					const bool sel = t < tot;
-					const uint32_t c = sel ? ((volatile uint32_t *) act)[t] : 0u;
-					uint32_t v = 0;
-					uint64_t start = 0;
-					int len = 0;
-					if (sel) {
-						const V raw = ld_sc1(&xp[c]);
-						start = a.rp[c];
-						len = (int) (a.rp[c + 1] - start);
-						v = reduce_sum(raw, F);
-						__hip_atomic_store(&xp[c], (V) 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
-					}
-					if (v == 0)
-						len = 0;
-					const uint32_t w_neg = F.p - v;
-					st_elim += (unsigned long long) __popcll(__ballot(v != 0));
-					int ftot;
-					const int excl = wave_exclusive_scan(len, lane, ftot);
-					st_stream += (unsigned long long) ftot;
-					const uint32_t start_lo = (uint32_t) start, start_hi = (uint32_t) (start >> 32);
-					for (int f0 = 0; f0 < ftot; f0 += 64) {
-						const int f = f0 + lane;
-						int owner = 0;
+			drain_vmem();                       // every earlier update has been performed
+			// first pending label at or after the cursor: sweep xp, 256 labels per trip
+			uint32_t c0 = 0xFFFFFFFFu;
+			for (uint32_t base = cursor & ~63u; base < r; base += 256) {
+				V raw[4];
 #pragma unroll
-						for (int step = 32; step >= 1; step >>= 1) {
-							const int cand = owner + step;
-							const int e = __shfl(excl, cand);
-							if (e <= f)
-								owner = cand;
-						}
-						const uint32_t o_lo = (uint32_t) __shfl((int) start_lo, owner);
-						const uint32_t o_hi = (uint32_t) __shfl((int) start_hi, owner);
-						const uint32_t o_w = (uint32_t) __shfl((int) w_neg, owner);
-						const int o_ex = __shfl(excl, owner);
-						if (f < ftot) {
-							const uint64_t idx = (((uint64_t) o_hi << 32) | o_lo) + (uint64_t) (f - o_ex);
-							const uint2 e = a.ent[idx];
-							const uint32_t delta = montmul(o_w, e.y, F);
-							if (e.x < r) {
-								add_ff(&xp[e.x], delta);
-								or_ff(&bm[e.x >> 5], 1u << (e.x & 31));
-							} else {
-								add_ff(&xn[e.x - r], delta);
-							}
-						}
+				for (int u = 0; u < 4; u++) {
+					const uint32_t c = base + u * 64 + lane;
+					raw[u] = (c < r && c >= cursor) ? ld_sc1(&xp[c]) : (V) 0;
+				}
+#pragma unroll
+				for (int u = 0; u < 4; u++) {
+					const uint64_t mask = __ballot(raw[u] != 0);
+					if (mask != 0 && c0 == 0xFFFFFFFFu)
+						c0 = base + u * 64 + (uint32_t) __builtin_ctzll(mask);
+				}
+				if (c0 != 0xFFFFFFFFu)
+					break;
+			}
+			if (c0 == 0xFFFFFFFFu)
+				break;
+			const uint32_t lwe = a.lvl_end_w[c0 >> 5];
+			const uint32_t lend = (lwe != MIXED) ? lwe * 32 : a.lvl_end[c0];
+
+			// every pending pivot of [c0, lend), 64 labels at a time
+			for (uint32_t base = c0 & ~63u; base < lend; base += 64) {
+				const uint32_t c = base + lane;
+				const bool inrange = (c >= c0) && (c < lend);
+				const V raw = inrange ? ld_sc1(&xp[c]) : (V) 0;
+				const bool sel = raw != 0;
+				if (__ballot(sel) == 0)
+					continue;
+				uint32_t v = 0;
+				uint64_t start = 0;
+				int len = 0;
+				if (sel) {
+					start = a.rp[c];
+					len = (int) (a.rp[c + 1] - start);
+					v = reduce_sum(raw, F);
+					__hip_atomic_store(&xp[c], (V) 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+				}
+				if (v == 0)
+					len = 0;
+				const uint32_t w_neg = F.p - v;
+				st_elim += (unsigned long long) __popcll(__ballot(v != 0));
+				int ftot;
+				const int excl = wave_exclusive_scan(len, lane, ftot);
+				st_stream += (unsigned long long) ftot;
+				const uint32_t start_lo = (uint32_t) start, start_hi = (uint32_t) (start >> 32);
+				for (int f0 = 0; f0 < ftot; f0 += 64) {
+					const int f = f0 + lane;
+					int owner = 0;
+#pragma unroll
+					for (int step = 32; step >= 1; step >>= 1) {
+						const int cand = owner + step;
+						const int e = __shfl(excl, cand);
+						if (e <= f)
+							owner = cand;
+					}
+					const uint32_t o_lo = (uint32_t) __shfl((int) start_lo, owner);
+					const uint32_t o_hi = (uint32_t) __shfl((int) start_hi, owner);
+					const uint32_t o_w = (uint32_t) __shfl((int) w_neg, owner);
+					const int o_ex = __shfl(excl, owner);
+					if (f < ftot) {
+						const uint64_t idx = (((uint64_t) o_hi << 32) | o_lo) + (uint64_t) (f - o_ex);
+						const uint2 e = a.ent[idx];
+						const uint32_t delta = montmul(o_w, e.y, F);
+						if (e.x < r)
+							add_ff(&xp[e.x], delta);
+						else
+							add_ff(&xn[e.x - r], delta);
 					}
 				}
-				__builtin_amdgcn_wave_barrier();
 			}
 			cursor = lend;
 		}
