@@ -222,7 +222,7 @@ def main():
         traffic = None
         tfile = os.path.join(ROOT, "profiles", "traffic_r01.json")
         if os.path.exists(tfile):
-            traffic = json.load(open(tfile)).get("schur_lds_kernel_bytes_per_launch")
+            traffic = json.load(open(tfile)).get("schur_wave_dense_kernel_bytes_per_launch")
         out = {
             "metric": "rows eliminated/sec (sparse Schur complement, mod 42013)",
             "value": total_rows / (elapsed / args.steps),
