@@ -53,6 +53,11 @@ def lib():
         "spasm_hip_dwork_destroy": (None, [vp]),
         "spasm_hip_dschur": (ci, [C.POINTER(CDcsr), vp, ci, vp, vp, vp, C.POINTER(CSchurStats)]),
         "spasm_hip_dschur_fetch": (None, [vp, vp, vp, vp, vp]),
+        "spasm_hip_schur_dense": (None, [pcsr, pint, ci, pint, plu, vp, ci, pint, pint]),
+        "spasm_hip_ffpack_rref": (ci, [i64, ci, ci, vp, ci, ci, C.POINTER(C.c_size_t)]),
+        "spasm_hip_dschur_dense": (ci, [C.POINTER(CDcsr), vp, ci, vp, vp, vp, i64, vp]),
+        "spasm_hip_drref": (ci, [i64, ci, ci, vp, i64, vp, vp]),
+        "spasm_hip_drref_timed": (ci, [i64, ci, ci, vp, i64, vp, vp, ci, C.POINTER(C.c_float)]),
     }
     for name, (res, args) in sig.items():
         fn = getattr(L, name)

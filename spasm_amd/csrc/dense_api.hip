@@ -1,0 +1,244 @@
+// C ABI of the dense tail: dense rows of the Schur complement and dense RREF mod p.
+#include <algorithm>
+#include <cinttypes>
+#include <vector>
+
+#include "device_types.h"
+
+namespace sh {
+int device_rref(int64_t prime, int n, int m, uint32_t *dA, int64_t ld, int *d_pivcol, hipStream_t stream, int use_mfma,
+                float *ms_update);
+void wave_dense_geometry(int rpad, int Sm, bool wide, int64_t *slot_bytes, int64_t *off_bm, int64_t *off_xn);
+void launch_schur_wave_dense(const SchurArgs &a, unsigned char *scratch, int64_t slot_bytes, int64_t off_bm, int64_t off_xn,
+                             bool wide, uint32_t *dense_out, int64_t ldS, int blocks, hipStream_t stream);
+}  // namespace sh
+
+using namespace sh;
+
+namespace {
+
+int env_int(const char *name, int dflt)
+{
+	const char *e = std::getenv(name);
+	return (e == nullptr || *e == 0) ? dflt : std::atoi(e);
+}
+
+template <typename T> T *dalloc(int64_t count)
+{
+	T *p = nullptr;
+	HIP_CHECK(hipMalloc((void **) &p, (size_t) (count > 0 ? count : 1) * sizeof(T)));
+	return p;
+}
+
+}  // namespace
+
+extern "C" {
+
+int spasm_hip_drref(i64 prime, int n, int m, u32 *d_A, i64 ld, int *d_pivcol, void *stream)
+{
+	if (spasm_hip_device_count() == 0)
+		die("spasm_hip_drref: no HIP device (this library has no CPU path)");
+	return device_rref(prime, n, m, d_A, ld, d_pivcol, (hipStream_t) stream, env_int("SPASM_HIP_RREF_MFMA", 1), nullptr);
+}
+
+// timing variant used by bench/profiles: ms of the trailing-update kernels only
+int spasm_hip_drref_timed(i64 prime, int n, int m, u32 *d_A, i64 ld, int *d_pivcol, void *stream, int use_mfma,
+                          float *ms_update)
+{
+	return device_rref(prime, n, m, d_A, ld, d_pivcol, (hipStream_t) stream, use_mfma, ms_update);
+}
+
+int spasm_hip_dschur_dense(const spasm_hip_dcsr *A, const int *d_rows, int nrows, const spasm_hip_dfact *F,
+                           spasm_hip_dwork *W, u32 *d_S, i64 ldS, void *stream_)
+{
+	hipStream_t stream = (hipStream_t) stream_;
+	if (nrows > W->max_rows)
+		die("spasm_hip_dschur_dense: %d rows but the workspace was sized for %d", nrows, W->max_rows);
+	if (A->m != F->m)
+		die("spasm_hip_dschur_dense: column count mismatch (A %d, factor %d)", A->m, F->m);
+	if (ldS < F->Sm)
+		die("spasm_hip_dschur_dense: leading dimension %" PRId64 " below the %d non-pivotal columns", ldS, F->Sm);
+	if (nrows == 0)
+		return 0;
+	const bool wide = ((double) F->prime * ((double) F->maxdeg + 3.0) >= 4294967296.0);
+	int dev = 0;
+	HIP_CHECK(hipGetDevice(&dev));
+	hipDeviceProp_t prop;
+	HIP_CHECK(hipGetDeviceProperties(&prop, dev));
+	const int cus = prop.multiProcessorCount;
+	i64 slot_bytes, off_bm, off_xn;
+	wave_dense_geometry(F->rpad, F->Sm, wide, &slot_bytes, &off_bm, &off_xn);
+	int slots = env_int("SPASM_HIP_WAVE_SLOTS", cus * 32);
+	const i64 budget = (i64) env_int("SPASM_HIP_SCRATCH_GB", 48) << 30;
+	slots = (int) std::max<i64>(cus, std::min<i64>(slots, budget / slot_bytes));
+	slots = std::max(1, std::min(slots, nrows));
+	const i64 need = slot_bytes * slots;
+	if (need > W->scratch_bytes) {
+		if (W->d_scratch != nullptr)
+			(void) hipFree(W->d_scratch);
+		HIP_CHECK(hipMalloc((void **) &W->d_scratch, (size_t) need));
+		W->scratch_bytes = need;
+		HIP_CHECK(hipMemsetAsync(W->d_scratch, 0, (size_t) need, stream));
+	}
+	HIP_CHECK(hipMemsetAsync(W->d_ctr, 0, CTR_COUNT * sizeof(int), stream));
+	HIP_CHECK(hipMemsetAsync(W->d_ctr64, 0, C64_COUNT * sizeof(unsigned long long), stream));
+	SchurArgs a{};
+	a.Ap = A->p;
+	a.Aj = A->j;
+	a.Ax = A->x;
+	a.rows = d_rows;
+	a.nrows = nrows;
+	a.lab = F->d_lab;
+	a.q = F->d_q;
+	a.rp = F->d_rp;
+	a.ent = F->d_ent;
+	a.lvl_end = F->d_lvl_end;
+	a.lvl_end_w = F->d_lvl_end_w;
+	a.r = F->rpad;
+	a.Sm = F->Sm;
+	a.m = F->m;
+	a.F = to_dev(F->mont);
+	a.pool_j = W->d_pool_j;
+	a.pool_x = W->d_pool_x;
+	a.pool_cap = W->pool_cap;
+	a.row_off = W->d_row_off;
+	a.row_len = W->d_row_len;
+	a.ctr = W->d_ctr;
+	a.ctr64 = W->d_ctr64;
+	a.list = nullptr;
+	a.list_count = nullptr;
+	a.ovf_list = nullptr;
+	a.next_ctr = CTR_ROW_NEXT3;
+	a.ovf_ctr = CTR_OVF2;
+	a.done_ctr = CTR_DONE2;
+	launch_schur_wave_dense(a, W->d_scratch, slot_bytes, off_bm, off_xn, wide, d_S, ldS, slots, stream);
+	HIP_CHECK(hipStreamSynchronize(stream));
+	return 0;
+}
+
+// --------------------------------------------------------------------------
+// host-pointer drop-ins
+// --------------------------------------------------------------------------
+void spasm_hip_schur_dense(const struct spasm_csr *A, const int *p, int n, const int *p_in, struct spasm_lu *fact, void *S,
+                           spasm_datatype datatype, int *q, int *p_out)
+{
+	if (spasm_hip_device_count() == 0)
+		die("spasm_hip_schur_dense: no HIP device (this library has no CPU path)");
+	if (fact->Ltmp != nullptr)
+		die("spasm_hip_schur_dense: recording L on the GPU path is not available yet; run with opts->L = 0");
+	const int m = A->m;
+	const i64 prime = A->field->p;
+	const double t0 = wtime();
+	hipStream_t stream = nullptr;
+	spasm_hip_dfact *F = spasm_hip_dfact_create(fact->U, fact->qinv, stream);
+	const int Sm = F->Sm;
+	for (int l = 0; l < Sm; l++)
+		q[l] = F->h_q[l];
+	for (int k = 0; k < n; k++)
+		p_out[k] = (p_in != nullptr) ? p_in[p[k]] : p[k];
+	if (n > 0 && Sm > 0) {
+		const i64 annz = A->p[A->n];
+		i64 *dAp = dalloc<i64>((i64) A->n + 1);
+		int *dAj = dalloc<int>(annz);
+		int *dAx = dalloc<int>(annz);
+		int *drows = dalloc<int>(n);
+		HIP_CHECK(hipMemcpy(dAp, A->p, ((size_t) A->n + 1) * sizeof(i64), hipMemcpyHostToDevice));
+		if (annz > 0) {
+			HIP_CHECK(hipMemcpy(dAj, A->j, (size_t) annz * sizeof(int), hipMemcpyHostToDevice));
+			HIP_CHECK(hipMemcpy(dAx, A->x, (size_t) annz * sizeof(int), hipMemcpyHostToDevice));
+		}
+		HIP_CHECK(hipMemcpy(drows, p, (size_t) n * sizeof(int), hipMemcpyHostToDevice));
+		spasm_hip_dcsr dA{A->n, m, annz, dAp, dAj, dAx};
+		spasm_hip_dwork *W = spasm_hip_dwork_create(n, m, 64);
+		u32 *dS = dalloc<u32>((i64) n * Sm);
+		spasm_hip_dschur_dense(&dA, drows, n, F, W, dS, Sm, stream);
+		std::vector<u32> h((size_t) n * Sm);
+		HIP_CHECK(hipMemcpy(h.data(), dS, (size_t) n * Sm * sizeof(u32), hipMemcpyDeviceToHost));
+		const u32 half = (u32) (prime / 2);
+		for (i64 t = 0; t < (i64) n * Sm; t++) {
+			const i64 v = (h[t] > half) ? (i64) h[t] - prime : (i64) h[t];
+			switch (datatype) {
+			case SPASM_DOUBLE: ((double *) S)[t] = (double) v; break;
+			case SPASM_FLOAT: ((float *) S)[t] = (float) v; break;
+			case SPASM_I64: ((i64 *) S)[t] = v; break;
+			}
+		}
+		(void) hipFree(dS);
+		spasm_hip_dwork_destroy(W);
+		(void) hipFree(dAp);
+		(void) hipFree(dAj);
+		(void) hipFree(dAx);
+		(void) hipFree(drows);
+	}
+	spasm_hip_dfact_destroy(F);
+	logmsg("[schur/dense/hip] %d x %d dense rows in %.1fs\n", n, Sm, wtime() - t0);
+}
+
+// Same contract as the reference wrapper (spasm_ffpack.cpp:23-49 as consumed by
+// update_U_after_rref, spasm_echelonize.c:189-222): returns the rank r; qinv[0..r) are the pivot
+// columns in echelon-row order, qinv[r..m) the other columns (increasing); for i < r and k >= r,
+// A[i*ldA + k] is the coefficient of echelon row i on column qinv[k]; A[i*ldA + k] for k < r is
+// the identity.
+int spasm_hip_ffpack_rref(i64 prime, int n, int m, void *A, int ldA, spasm_datatype datatype, size_t *qinv)
+{
+	if (spasm_hip_device_count() == 0)
+		die("spasm_hip_ffpack_rref: no HIP device (this library has no CPU path)");
+	const double t0 = wtime();
+	for (int j = 0; j < m; j++)
+		qinv[j] = (size_t) j;
+	if (n == 0 || m == 0)
+		return 0;
+	std::vector<u32> h((size_t) n * m);
+	for (int i = 0; i < n; i++)
+		for (int j = 0; j < m; j++) {
+			const size_t src = (size_t) i * ldA + j;
+			i64 v = 0;
+			switch (datatype) {
+			case SPASM_DOUBLE: v = (i64) ((double *) A)[src]; break;
+			case SPASM_FLOAT: v = (i64) ((float *) A)[src]; break;
+			case SPASM_I64: v = ((i64 *) A)[src]; break;
+			}
+			v %= prime;
+			if (v < 0)
+				v += prime;
+			h[(size_t) i * m + j] = (u32) v;
+		}
+	u32 *dA = dalloc<u32>((i64) n * m);
+	int *dpiv = dalloc<int>(m);
+	HIP_CHECK(hipMemcpy(dA, h.data(), (size_t) n * m * sizeof(u32), hipMemcpyHostToDevice));
+	const int r = spasm_hip_drref(prime, n, m, dA, m, dpiv, nullptr);
+	HIP_CHECK(hipMemcpy(h.data(), dA, (size_t) n * m * sizeof(u32), hipMemcpyDeviceToHost));
+	std::vector<int> pivcol((size_t) (r > 0 ? r : 1));
+	if (r > 0)
+		HIP_CHECK(hipMemcpy(pivcol.data(), dpiv, (size_t) r * sizeof(int), hipMemcpyDeviceToHost));
+	(void) hipFree(dA);
+	(void) hipFree(dpiv);
+	std::vector<char> is_piv((size_t) m, 0);
+	for (int i = 0; i < r; i++) {
+		qinv[i] = (size_t) pivcol[i];
+		is_piv[pivcol[i]] = 1;
+	}
+	int k = r;
+	for (int j = 0; j < m; j++)
+		if (!is_piv[j])
+			qinv[k++] = (size_t) j;
+	const u32 half = (u32) (prime / 2);
+	for (int i = 0; i < n; i++)
+		for (int kk = 0; kk < m; kk++) {
+			i64 v = 0;
+			if (i < r) {
+				const u32 raw = h[(size_t) i * m + qinv[kk]];
+				v = (raw > half) ? (i64) raw - prime : (i64) raw;
+			}
+			const size_t dst = (size_t) i * ldA + kk;
+			switch (datatype) {
+			case SPASM_DOUBLE: ((double *) A)[dst] = (double) v; break;
+			case SPASM_FLOAT: ((float *) A)[dst] = (float) v; break;
+			case SPASM_I64: ((i64 *) A)[dst] = v; break;
+			}
+		}
+	logmsg("[rref/hip] %d x %d mod %" PRId64 ": rank %d [%.1fs]\n", n, m, prime, r, wtime() - t0);
+	return r;
+}
+
+}  // extern "C"

@@ -1,0 +1,433 @@
+// Dense reduced row echelon form mod p on the GPU (replaces the FFLAS-FFPACK
+// calls behind spasm_ffpack_rref, spasm_ffpack.cpp:23-49).
+//
+// Blocked Gauss-Jordan with column-rank-profile pivots, rows stay in place:
+//   for each panel of NB columns
+//     1. panel kernel (one workgroup): eliminate inside the panel, carrying k
+//        extra "selector" columns J so that the composite row transformation
+//        T = I + M e_rho^T is known explicitly (M = T J - J, n x k);
+//     2. gather B = A[rho, rest] (the k new pivot rows, old values);
+//     3. trailing update A[:, rest] += M B  (GEMM mod p).  For p < 2^16 the
+//        GEMM runs on the matrix cores: operands are split into two signed
+//        base-256 digits and multiplied with v_mfma_i32_32x32x32_i8 (four
+//        digit products, i32 accumulators, recombined mod p).  Larger primes
+//        use a tiled 64-bit VALU kernel.
+// Values are canonical representatives in [0, p) stored as u32.
+#include "device_types.h"
+
+namespace sh {
+
+namespace {
+
+constexpr int NB = 64;                  // panel width
+constexpr int PW = 2 * NB;              // panel + selector columns
+constexpr int PANEL_THREADS = 1024;
+
+__device__ __forceinline__ uint32_t mont_mul(uint32_t a, uint32_t b, const MontDev &F)
+{
+	uint64_t t = (uint64_t) a * b;
+	uint32_t mq = (uint32_t) t * F.pinv;
+	uint32_t q = __umulhi(mq, F.p);
+	uint32_t th = (uint32_t) (t >> 32);
+	uint32_t r = th - q;
+	return (th < q) ? r + F.p : r;
+}
+
+// a * b mod p for a, b in [0, p)
+__device__ __forceinline__ uint32_t mulmod(uint32_t a, uint32_t b, const MontDev &F)
+{
+	return mont_mul(mont_mul(a, b, F), F.r2, F);
+}
+
+__device__ __forceinline__ uint32_t submod(uint32_t a, uint32_t b, const MontDev &F)
+{
+	return (a >= b) ? a - b : a + (F.p - b);
+}
+
+__device__ uint32_t invmod(uint32_t a, const MontDev &F)
+{
+	// Fermat: a^(p-2)
+	uint32_t result = 1 % F.p, base = a;
+	uint32_t e = F.p - 2;
+	while (e) {
+		if (e & 1)
+			result = mulmod(result, base, F);
+		base = mulmod(base, base, F);
+		e >>= 1;
+	}
+	return result;
+}
+
+}  // namespace
+
+struct PanelArgs {
+	uint32_t *A;          // n x m, leading dimension ld
+	int64_t ld;
+	int n, m;
+	int c0, width;        // panel columns [c0, c0 + width)
+	uint32_t *P;          // workspace n x PW: panel copy | selector columns
+	int *is_pivot_row;    // n flags
+	int *pivrow;          // global list: pivot row of the t-th pivot
+	int *pivcol;          // ... and its column
+	int *rank;            // running rank (device scalar)
+	int *knew;            // out: pivots found in this panel
+	int *rho;             // out: their rows (NB)
+	MontDev F;
+};
+
+// One workgroup.  Thread t owns rows t, t + 1024, ...
+__global__ __launch_bounds__(PANEL_THREADS) void rref_panel_kernel(PanelArgs g)
+{
+	__shared__ uint32_t piv[PW];
+	__shared__ int s_row;
+	__shared__ int s_k;
+	const int tid = threadIdx.x;
+	const MontDev F = g.F;
+	const int n = g.n, W = g.width;
+	// copy the panel, clear the selector columns
+	for (int i = tid; i < n; i += PANEL_THREADS) {
+		uint32_t *Pi = g.P + (int64_t) i * PW;
+		const uint32_t *Ai = g.A + (int64_t) i * g.ld + g.c0;
+		for (int c = 0; c < W; c++)
+			Pi[c] = Ai[c];
+		for (int c = W; c < PW; c++)
+			Pi[c] = 0;
+	}
+	if (tid == 0)
+		s_k = 0;
+	__syncthreads();
+	for (int c = 0; c < W; c++) {
+		// lowest free row with a non-zero in column c
+		if (tid == 0)
+			s_row = 0x7FFFFFFF;
+		__syncthreads();
+		int mine = 0x7FFFFFFF;
+		for (int i = tid; i < n; i += PANEL_THREADS)
+			if (!g.is_pivot_row[i] && g.P[(int64_t) i * PW + c] != 0) {
+				mine = i;
+				break;
+			}
+		if (mine != 0x7FFFFFFF)
+			atomicMin(&s_row, mine);
+		__syncthreads();
+		const int rho = s_row;
+		if (rho == 0x7FFFFFFF) {
+			__syncthreads();
+			continue;
+		}
+		const int k = s_k;
+		// scale the pivot row (panel columns >= c and the selector columns), publish it
+		if (tid == 0) {
+			g.is_pivot_row[rho] = 1;
+			g.P[(int64_t) rho * PW + NB + k] = 1;      // selector column of this pivot
+		}
+		__syncthreads();
+		{
+			uint32_t *Pr = g.P + (int64_t) rho * PW;
+			const uint32_t inv = invmod(Pr[c], F);
+			for (int cc = tid; cc < PW; cc += PANEL_THREADS)
+				piv[cc] = (cc < W || cc >= NB) ? mulmod(Pr[cc], inv, F) : 0u;
+		}
+		__syncthreads();
+		if (tid < PW)
+			g.P[(int64_t) rho * PW + tid] = piv[tid];
+		// eliminate column c from every other row
+		for (int i = tid; i < n; i += PANEL_THREADS) {
+			if (i == rho)
+				continue;
+			uint32_t *Pi = g.P + (int64_t) i * PW;
+			const uint32_t f = Pi[c];
+			if (f == 0)
+				continue;
+			for (int cc = c; cc < W; cc++)
+				Pi[cc] = submod(Pi[cc], mulmod(f, piv[cc], F), F);
+			for (int cc = NB; cc <= NB + k; cc++)
+				Pi[cc] = submod(Pi[cc], mulmod(f, piv[cc], F), F);
+		}
+		if (tid == 0) {
+			const int rk = *g.rank;
+			g.pivrow[rk] = rho;
+			g.pivcol[rk] = g.c0 + c;
+			*g.rank = rk + 1;
+			g.rho[k] = rho;
+			s_k = k + 1;
+		}
+		__syncthreads();
+	}
+	// write the eliminated panel back; M = T J - J: subtract the selector ones
+	const int k = s_k;
+	for (int i = tid; i < n; i += PANEL_THREADS) {
+		uint32_t *Pi = g.P + (int64_t) i * PW;
+		uint32_t *Ai = g.A + (int64_t) i * g.ld + g.c0;
+		for (int c = 0; c < W; c++)
+			Ai[c] = Pi[c];
+	}
+	__syncthreads();
+	if (tid < k) {
+		uint32_t *Pr = g.P + (int64_t) g.rho[tid] * PW + NB + tid;
+		*Pr = submod(*Pr, 1u, F);
+	}
+	if (tid == 0)
+		*g.knew = k;
+}
+
+// B[t, :] = A[rho[t], c1:]  (old values of the new pivot rows), k x mr, row-major ld = mr
+__global__ void rref_gather_pivot_rows(const uint32_t *A, int64_t ld, int c1, int mr, const int *rho, const int *knew,
+                                       uint32_t *B)
+{
+	const int k = *knew;
+	const int64_t total = (int64_t) k * mr;
+	for (int64_t t = (int64_t) blockIdx.x * blockDim.x + threadIdx.x; t < total; t += (int64_t) gridDim.x * blockDim.x) {
+		const int row = (int) (t / mr), col = (int) (t % mr);
+		B[t] = A[(int64_t) rho[row] * ld + c1 + col];
+	}
+}
+
+// ---- trailing update, generic prime: C[i, j] += sum_t M[i, t] B[t, j]  (64-bit VALU) ----
+constexpr int GT_ROWS = 64, GT_COLS = 64;
+
+__global__ __launch_bounds__(256) void rref_update_valu(uint32_t *A, int64_t ld, int n, int c1, int mr, const uint32_t *P,
+                                                        const uint32_t *B, const int *knew, MontDev F)
+{
+	__shared__ uint32_t sM[GT_ROWS][NB + 1];
+	__shared__ uint32_t sB[NB][GT_COLS + 1];
+	const int k = *knew;
+	if (k == 0)
+		return;
+	const int tid = threadIdx.x;
+	const int row0 = blockIdx.y * GT_ROWS, col0 = blockIdx.x * GT_COLS;
+	for (int t = tid; t < GT_ROWS * NB; t += 256) {
+		const int rr = t / NB, cc = t % NB;
+		const int i = row0 + rr;
+		sM[rr][cc] = (i < n && cc < k) ? P[(int64_t) i * PW + NB + cc] : 0u;
+	}
+	for (int t = tid; t < NB * GT_COLS; t += 256) {
+		const int rr = t / GT_COLS, cc = t % GT_COLS;
+		const int j = col0 + cc;
+		sB[rr][cc] = (rr < k && j < mr) ? B[(int64_t) rr * mr + j] : 0u;
+	}
+	__syncthreads();
+	const int tx = tid % 16, ty = tid / 16;       // 16 x 16 threads, 4 x 4 outputs each
+	const bool small = F.p < 65536u;
+	for (int a = 0; a < 4; a++)
+		for (int b = 0; b < 4; b++) {
+			const int rr = ty * 4 + a, cc = tx * 4 + b;
+			const int i = row0 + rr, j = col0 + cc;
+			if (i >= n || j >= mr)
+				continue;
+			unsigned long long acc = 0;
+			if (small) {
+				for (int t = 0; t < k; t++)
+					acc += (unsigned long long) (sM[rr][t] * sB[t][cc]);     // < 2^32 each
+				acc %= F.p;
+			} else {
+				for (int t = 0; t < k; t++)
+					acc += mulmod(sM[rr][t], sB[t][cc], F);
+				acc %= F.p;
+			}
+			uint32_t *dst = A + (int64_t) i * ld + c1 + j;
+			uint32_t s = *dst + (uint32_t) acc;
+			if (s < (uint32_t) acc || s >= F.p)
+				s -= F.p;
+			*dst = s;
+		}
+}
+
+// ---- trailing update on the matrix cores, p < 2^16 ----
+// Digits: v in [0,p) -> balanced b = v or v - p in (-p/2, p/2]; b = hi * 256 + lo with lo in
+// [-128, 127], |hi| <= 128 (hi = 128 cannot occur for p < 2^16: |b| < 32768 -> hi in [-128, 127]).
+// One wave computes a 32 x 32 tile of C with v_mfma_i32_32x32x32_i8 over K = 64 (two MFMAs per
+// digit pair, four digit pairs).  A-operand lane map (i8, 32x32x32): lane l holds row (l & 31),
+// k = 16 * (l >> 5) ... wait for the exact map see below: 8 consecutive k per lane half-block.
+typedef int v4i __attribute__((ext_vector_type(4)));
+typedef int v16i __attribute__((ext_vector_type(16)));
+
+__device__ __forceinline__ void split_digits(uint32_t v, const MontDev &F, int &hi, int &lo)
+{
+	int b = (v > F.half) ? (int) v - (int) F.p : (int) v;
+	lo = ((b + 128) & 255) - 128;
+	hi = (b - lo) >> 8;
+}
+
+// Workgroup = 4 waves = a 64 x 64 tile of C (2 x 2 wave tiles of 32 x 32).  K = NB = 64.
+// LDS holds the digit planes of M (64 x 64) and B (64 x 64) as int8.
+__global__ __launch_bounds__(256) void rref_update_mfma(uint32_t *A, int64_t ld, int n, int c1, int mr, const uint32_t *P,
+                                                        const uint32_t *B, const int *knew, MontDev F)
+{
+	__shared__ __attribute__((aligned(16))) signed char Mhi[64][64 + 16], Mlo[64][64 + 16];   // [row][k]
+	__shared__ __attribute__((aligned(16))) signed char Bhi[64][64 + 16], Blo[64][64 + 16];   // [col][k]  (transposed)
+	const int k = *knew;
+	if (k == 0)
+		return;
+	const int tid = threadIdx.x;
+	const int row0 = blockIdx.y * 64, col0 = blockIdx.x * 64;
+	for (int t = tid; t < 64 * 64; t += 256) {
+		const int rr = t / 64, kk = t % 64;
+		const int i = row0 + rr;
+		const uint32_t v = (i < n && kk < k) ? P[(int64_t) i * PW + NB + kk] : 0u;
+		int hi, lo;
+		split_digits(v, F, hi, lo);
+		Mhi[rr][kk] = (signed char) hi;
+		Mlo[rr][kk] = (signed char) lo;
+	}
+	for (int t = tid; t < 64 * 64; t += 256) {
+		const int kk = t / 64, cc = t % 64;          // coalesced read of B rows
+		const int j = col0 + cc;
+		const uint32_t v = (kk < k && j < mr) ? B[(int64_t) kk * mr + j] : 0u;
+		int hi, lo;
+		split_digits(v, F, hi, lo);
+		Bhi[cc][kk] = (signed char) hi;
+		Blo[cc][kk] = (signed char) lo;
+	}
+	__syncthreads();
+	const int wave = tid >> 6, lane = tid & 63;
+	const int wr = (wave >> 1) * 32, wc = (wave & 1) * 32;      // this wave's 32 x 32 tile
+	// i8 32x32x32: lane l supplies A[row = l & 31][k = 16 * (l >> 5) + 0..15] and
+	// B[k = 16 * (l >> 5) + 0..15][col = l & 31] as 16 bytes (4 VGPRs)
+	const int rsel = lane & 31, khalf = (lane >> 5) * 16;
+	v16i acc_hh = {0}, acc_hl = {0}, acc_lh = {0}, acc_ll = {0};
+#pragma unroll
+	for (int ks = 0; ks < 64; ks += 32) {
+		const v4i a_hi = *reinterpret_cast<const v4i *>(&Mhi[wr + rsel][ks + khalf]);
+		const v4i a_lo = *reinterpret_cast<const v4i *>(&Mlo[wr + rsel][ks + khalf]);
+		const v4i b_hi = *reinterpret_cast<const v4i *>(&Bhi[wc + rsel][ks + khalf]);
+		const v4i b_lo = *reinterpret_cast<const v4i *>(&Blo[wc + rsel][ks + khalf]);
+		acc_hh = __builtin_amdgcn_mfma_i32_32x32x32_i8(a_hi, b_hi, acc_hh, 0, 0, 0);
+		acc_hl = __builtin_amdgcn_mfma_i32_32x32x32_i8(a_hi, b_lo, acc_hl, 0, 0, 0);
+		acc_lh = __builtin_amdgcn_mfma_i32_32x32x32_i8(a_lo, b_hi, acc_lh, 0, 0, 0);
+		acc_ll = __builtin_amdgcn_mfma_i32_32x32x32_i8(a_lo, b_lo, acc_ll, 0, 0, 0);
+	}
+	// C/D map of the 32x32 shapes: col = lane & 31, row = (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5)
+	const long long pp = (long long) F.p;
+#pragma unroll
+	for (int reg = 0; reg < 16; reg++) {
+		const int rr = (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5);
+		const int cc = lane & 31;
+		const int i = row0 + wr + rr, j = col0 + wc + cc;
+		if (i >= n || j >= mr)
+			continue;
+		long long s = (long long) acc_hh[reg] * 65536 + ((long long) acc_hl[reg] + (long long) acc_lh[reg]) * 256 +
+		              (long long) acc_ll[reg];
+		long long mred = s % pp;
+		if (mred < 0)
+			mred += pp;
+		uint32_t *dst = A + (int64_t) i * ld + c1 + j;
+		uint32_t sum = *dst + (uint32_t) mred;
+		if (sum >= F.p)
+			sum -= F.p;
+		*dst = sum;
+	}
+}
+
+// echelon rows to the top, in pivot-column order (rows that hold no pivot are zero after the
+// full elimination): tmp[t, :] = A[pivrow[t], :], then copied back.
+__global__ void rref_rows_to_tmp(const uint32_t *A, int64_t ld, int m, const int *pivrow, int rank, uint32_t *tmp)
+{
+	const int64_t total = (int64_t) rank * m;
+	for (int64_t t = (int64_t) blockIdx.x * blockDim.x + threadIdx.x; t < total; t += (int64_t) gridDim.x * blockDim.x)
+		tmp[t] = A[(int64_t) pivrow[t / m] * ld + (t % m)];
+}
+
+__global__ void rref_tmp_to_rows(uint32_t *A, int64_t ld, int n, int m, int rank, const uint32_t *tmp)
+{
+	const int64_t total = (int64_t) n * m;
+	for (int64_t t = (int64_t) blockIdx.x * blockDim.x + threadIdx.x; t < total; t += (int64_t) gridDim.x * blockDim.x) {
+		const int64_t i = t / m, j = t % m;
+		A[i * ld + j] = (i < rank) ? tmp[i * m + j] : 0u;
+	}
+}
+
+// ---- driver: everything resident on the device.  On return rows 0..rank-1 of A are the reduced
+// echelon rows (pivot columns increasing, listed in d_pivcol), the other rows are zero. ----
+int device_rref(int64_t prime, int n, int m, uint32_t *dA, int64_t ld, int *d_pivcol, hipStream_t stream, int use_mfma,
+                float *ms_update)
+{
+	if (n == 0 || m == 0)
+		return 0;
+	const Mont M = mont_setup(prime);
+	const MontDev F = to_dev(M);
+	uint32_t *P = nullptr, *B = nullptr;
+	int *flags = nullptr, *pivrow = nullptr, *rank_d = nullptr, *knew = nullptr, *rho = nullptr;
+	const int rmax = (n < m) ? n : m;
+	HIP_CHECK(hipMalloc((void **) &P, (size_t) n * PW * sizeof(uint32_t)));
+	HIP_CHECK(hipMalloc((void **) &B, (size_t) NB * (size_t) m * sizeof(uint32_t)));
+	HIP_CHECK(hipMalloc((void **) &flags, (size_t) n * sizeof(int)));
+	HIP_CHECK(hipMalloc((void **) &pivrow, (size_t) rmax * sizeof(int) + 64));
+	HIP_CHECK(hipMalloc((void **) &rank_d, 64));
+	HIP_CHECK(hipMalloc((void **) &knew, 64));
+	HIP_CHECK(hipMalloc((void **) &rho, NB * sizeof(int)));
+	HIP_CHECK(hipMemsetAsync(flags, 0, (size_t) n * sizeof(int), stream));
+	HIP_CHECK(hipMemsetAsync(rank_d, 0, 64, stream));
+	hipEvent_t e0 = nullptr, e1 = nullptr;
+	if (ms_update != nullptr) {
+		HIP_CHECK(hipEventCreate(&e0));
+		HIP_CHECK(hipEventCreate(&e1));
+	}
+	float total_update = 0.f;
+	const bool mfma_ok = use_mfma && prime <= 65279;      // two signed base-256 digits must fit int8
+	for (int c0 = 0; c0 < m; c0 += NB) {
+		const int width = (m - c0 < NB) ? m - c0 : NB;
+		PanelArgs g;
+		g.A = dA;
+		g.ld = ld;
+		g.n = n;
+		g.m = m;
+		g.c0 = c0;
+		g.width = width;
+		g.P = P;
+		g.is_pivot_row = flags;
+		g.pivrow = pivrow;
+		g.pivcol = d_pivcol;
+		g.rank = rank_d;
+		g.knew = knew;
+		g.rho = rho;
+		g.F = F;
+		hipLaunchKernelGGL(rref_panel_kernel, dim3(1), dim3(PANEL_THREADS), 0, stream, g);
+		const int c1 = c0 + width;
+		const int mr = m - c1;
+		if (mr > 0) {
+			hipLaunchKernelGGL(rref_gather_pivot_rows, dim3(512), dim3(256), 0, stream, dA, ld, c1, mr, rho, knew, B);
+			dim3 grid((mr + 63) / 64, (n + 63) / 64);
+			if (ms_update != nullptr)
+				HIP_CHECK(hipEventRecord(e0, stream));
+			if (mfma_ok)
+				hipLaunchKernelGGL(rref_update_mfma, grid, dim3(256), 0, stream, dA, ld, n, c1, mr, P, B, knew, F);
+			else
+				hipLaunchKernelGGL(rref_update_valu, grid, dim3(256), 0, stream, dA, ld, n, c1, mr, P, B, knew, F);
+			if (ms_update != nullptr) {
+				HIP_CHECK(hipEventRecord(e1, stream));
+				HIP_CHECK(hipEventSynchronize(e1));
+				float ms;
+				HIP_CHECK(hipEventElapsedTime(&ms, e0, e1));
+				total_update += ms;
+			}
+		}
+		HIP_CHECK(hipGetLastError());
+	}
+	int rank = 0;
+	HIP_CHECK(hipMemcpyAsync(&rank, rank_d, sizeof(int), hipMemcpyDeviceToHost, stream));
+	HIP_CHECK(hipStreamSynchronize(stream));
+	if (rank > 0) {
+		uint32_t *tmp = nullptr;
+		HIP_CHECK(hipMalloc((void **) &tmp, (size_t) rank * (size_t) m * sizeof(uint32_t)));
+		hipLaunchKernelGGL(rref_rows_to_tmp, dim3(1024), dim3(256), 0, stream, dA, ld, m, pivrow, rank, tmp);
+		hipLaunchKernelGGL(rref_tmp_to_rows, dim3(1024), dim3(256), 0, stream, dA, ld, n, m, rank, tmp);
+		HIP_CHECK(hipStreamSynchronize(stream));
+		(void) hipFree(tmp);
+	}
+	if (ms_update != nullptr) {
+		*ms_update = total_update;
+		(void) hipEventDestroy(e0);
+		(void) hipEventDestroy(e1);
+	}
+	(void) hipFree(P);
+	(void) hipFree(B);
+	(void) hipFree(flags);
+	(void) hipFree(pivrow);
+	(void) hipFree(rank_d);
+	(void) hipFree(knew);
+	(void) hipFree(rho);
+	return rank;
+}
+
+}  // namespace sh

@@ -23,24 +23,12 @@ double spasm_hip_schur_estimate_density(const struct spasm_csr *, const int *, i
 	NOT_YET("spasm_hip_schur_estimate_density");
 }
 
-void spasm_hip_schur_dense(const struct spasm_csr *, const int *, int, const int *, struct spasm_lu *, void *,
-                           spasm_datatype, int *, int *)
-{
-	NOT_YET("spasm_hip_schur_dense");
-}
 
-int spasm_hip_ffpack_rref(i64, int, int, void *, int, spasm_datatype, size_t *) { NOT_YET("spasm_hip_ffpack_rref"); }
 
 struct spasm_lu *spasm_hip_echelonize(const struct spasm_csr *, struct echelonize_opts *) { NOT_YET("spasm_hip_echelonize"); }
 
 struct spasm_csr *spasm_hip_rref(const struct spasm_lu *, int *) { NOT_YET("spasm_hip_rref"); }
 
-int spasm_hip_dschur_dense(const spasm_hip_dcsr *, const int *, int, const spasm_hip_dfact *, spasm_hip_dwork *, u32 *,
-                           i64, void *)
-{
-	NOT_YET("spasm_hip_dschur_dense");
-}
 
-int spasm_hip_drref(i64, int, int, u32 *, i64, int *, void *) { NOT_YET("spasm_hip_drref"); }
 
 }  // extern "C"

@@ -114,3 +114,36 @@ def schur(A, p, F, p_in=None):
     L.spasm_hip_csr_free(s)
     L.spasm_hip_csr_free(up)
     return S, p_out[:n]
+
+
+SPASM_DOUBLE, SPASM_FLOAT, SPASM_I64 = 0, 1, 2      # spasm_datatype (spasm.h:139)
+_NP_OF = {SPASM_DOUBLE: np.float64, SPASM_FLOAT: np.float32, SPASM_I64: np.int64}
+
+
+def schur_dense(A, p, F, p_in=None, datatype=SPASM_I64):
+    """spasm_schur_dense (spasm_schur.c:258) on the GPU: returns (S [n, Sm], q, p_out)."""
+    require_gpu("schur_dense")
+    L = lib()
+    a = view_csr(A)
+    lu, up, qinv = _lu_for(F, 0, 0)
+    p = np.ascontiguousarray(p, np.int32)
+    n = len(p)
+    Sm = A.m - F.U.n
+    S = np.zeros(max(n * Sm, 1), _NP_OF[datatype])
+    q = np.zeros(max(Sm, 1), np.int32)
+    p_out = np.zeros(max(n, 1), np.int32)
+    pin = _ip(np.ascontiguousarray(p_in, np.int32)) if p_in is not None else None
+    L.spasm_hip_schur_dense(C.byref(a), _ip(p), n, pin, C.byref(lu), S.ctypes.data, datatype, _ip(q), _ip(p_out))
+    L.spasm_hip_csr_free(up)
+    return S[:n * Sm].reshape(n, Sm), q[:Sm], p_out[:n]
+
+
+def ffpack_rref(prime, M, datatype=SPASM_I64):
+    """spasm_ffpack_rref (spasm_ffpack.cpp:88) on the GPU, on a copy of M: returns (rank, R, qinv)."""
+    require_gpu("ffpack_rref")
+    L = lib()
+    M = np.ascontiguousarray(M, _NP_OF[datatype]).copy()
+    n, m = M.shape
+    qinv = np.zeros(max(m, 1), np.uint64)
+    r = L.spasm_hip_ffpack_rref(prime, n, m, M.ctypes.data, m, datatype, qinv.ctypes.data_as(C.POINTER(C.c_size_t)))
+    return r, M, qinv[:m].astype(np.int64)

@@ -1,0 +1,88 @@
+"""GPU parity of the dense tail: dense Schur rows and dense RREF mod p, against the oracle."""
+import numpy as np
+import pytest
+
+from conftest import ALL_MODULI, ALL_TEST_MATRICES, matrix_path
+
+import spasm_amd
+
+pytestmark = pytest.mark.gpu
+
+SMALL_SET = [m for m in ALL_TEST_MATRICES if m not in ("mat364.sms", "trefethen_500.sms", "medium.sms", "m1.sms")]
+
+
+def _as_product(A):
+    return spasm_amd.Csr(A.n, A.m, A.p, A.j, A.x, A.prime)
+
+
+def _fact(F):
+    return spasm_amd.Fact(_as_product(F.U), F.qinv)
+
+
+@pytest.mark.parametrize("name", ALL_TEST_MATRICES)
+@pytest.mark.parametrize("p", [3, 42013, 65537, 4294967291])
+def test_schur_dense_reference_matrices(oracle, name, p):
+    A = oracle.load_sms(matrix_path(name), p)
+    npiv, perm, F = oracle.pivots_extract_structural(A, oracle.empty_fact(A.n, A.m, p))
+    rows = perm[npiv:]
+    want, q_want, p_out_want = oracle.schur_dense(A, rows, F)
+    S, q, p_out = spasm_amd.schur_dense(_as_product(A), rows, _fact(F))
+    assert np.array_equal(q, q_want) and np.array_equal(p_out, p_out_want)
+    assert S.shape == want.shape and np.array_equal(S, want)
+
+
+@pytest.mark.parametrize("dt", [spasm_amd.host.SPASM_DOUBLE, spasm_amd.host.SPASM_FLOAT])
+def test_schur_dense_datatypes(oracle, dt):
+    p = 257
+    A = oracle.load_sms(matrix_path("mat364.sms"), p)
+    npiv, perm, F = oracle.pivots_extract_structural(A, oracle.empty_fact(A.n, A.m, p))
+    want, _, _ = oracle.schur_dense(A, perm[npiv:], F)
+    S, _, _ = spasm_amd.schur_dense(_as_product(A), perm[npiv:], _fact(F), datatype=dt)
+    assert np.array_equal(S.astype(np.int64), want)
+
+
+def _check_rref(oracle, p, M):
+    r_want, R_want, q_want = oracle.dense_rref(p, M)
+    r, R, q = spasm_amd.ffpack_rref(p, M)
+    assert r == r_want
+    assert np.array_equal(q, q_want)
+    assert np.array_equal(R[:r], R_want[:r])
+    assert not np.any(R[r:])
+
+
+@pytest.mark.parametrize("name", SMALL_SET + ["mat364.sms", "trefethen_500.sms"])
+@pytest.mark.parametrize("p", ALL_MODULI + [42013])
+def test_rref_reference_matrices(oracle, name, p):
+    A = oracle.load_sms(matrix_path(name), p)
+    if A.n == 0 or A.m == 0:
+        r, R, q = spasm_amd.ffpack_rref(p, np.zeros((A.n, A.m), np.int64))
+        assert r == 0
+        return
+    _check_rref(oracle, p, A.to_dense())
+
+
+@pytest.mark.parametrize("p", [3, 257, 42013, 65267, 65537, 4294967291])
+@pytest.mark.parametrize("shape,rank", [((200, 300), 200), ((300, 200), 150), ((130, 64), 64), ((65, 129), 40),
+                                        ((700, 900), 333), ((1, 1), 1), ((5, 2000), 5), ((1500, 70), 10)])
+def test_rref_random_low_rank(oracle, shape, rank, p):
+    """random matrices of prescribed rank: shapes straddle the 64-column panels and the 64 x 64 update tiles."""
+    n, m = shape
+    rng = np.random.default_rng(n * 7 + m)
+    k = min(rank, n, m)
+    L = rng.integers(0, p, size=(n, k), dtype=np.int64).astype(object)
+    R = rng.integers(0, p, size=(k, m), dtype=np.int64).astype(object)
+    M = np.array((L.dot(R)) % p, dtype=np.int64)
+    M[:, : m // 7] = 0                       # leading zero columns: pivots do not start at column 0
+    _check_rref(oracle, p, M)
+
+
+def test_rref_mfma_and_valu_agree(oracle, monkeypatch):
+    p = 42013
+    rng = np.random.default_rng(5)
+    M = rng.integers(0, p, size=(257, 515), dtype=np.int64)
+    monkeypatch.setenv("SPASM_HIP_RREF_MFMA", "0")
+    r0, R0, q0 = spasm_amd.ffpack_rref(p, M)
+    monkeypatch.setenv("SPASM_HIP_RREF_MFMA", "1")
+    r1, R1, q1 = spasm_amd.ffpack_rref(p, M)
+    assert r0 == r1 and np.array_equal(q0, q1) and np.array_equal(R0, R1)
+    _check_rref(oracle, p, M)
