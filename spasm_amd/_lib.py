@@ -53,6 +53,12 @@ def lib():
         "spasm_hip_dwork_destroy": (None, [vp]),
         "spasm_hip_dschur": (ci, [C.POINTER(CDcsr), vp, ci, vp, vp, vp, C.POINTER(CSchurStats)]),
         "spasm_hip_dschur_fetch": (None, [vp, vp, vp, vp, vp]),
+        "spasm_hip_echelonize_init_opts": (None, [C.POINTER(EchelonizeOpts)]),
+        "spasm_hip_echelonize": (plu, [pcsr, C.POINTER(EchelonizeOpts)]),
+        "spasm_hip_rref": (pcsr, [plu, pint]),
+        "spasm_hip_kernel": (pcsr, [plu]),
+        "spasm_hip_lu_free": (None, [plu]),
+        "spasm_hip_schur_estimate_density": (C.c_double, [pcsr, pint, ci, pcsr, pint, ci]),
         "spasm_hip_schur_dense": (None, [pcsr, pint, ci, pint, plu, vp, ci, pint, pint]),
         "spasm_hip_ffpack_rref": (ci, [i64, ci, ci, vp, ci, ci, C.POINTER(C.c_size_t)]),
         "spasm_hip_dschur_dense": (ci, [C.POINTER(CDcsr), vp, ci, vp, vp, vp, i64, vp]),

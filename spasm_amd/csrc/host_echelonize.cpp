@@ -1,0 +1,535 @@
+// The echelonization driver (replaces spasm_echelonize.c).  Control flow and
+// options are the reference's; every arithmetic stage is a GPU call:
+//   rounds of [structural pivots on the host -> sparse Schur complement on the
+//   GPU], then a finishing stage: dense blocks (dense Schur rows + RREF on the
+//   GPU), the low-rank variant (random combinations, then the same), or --
+//   where the reference runs its sequential GPLU loop -- further structural
+//   rounds on the GPU until the remainder is empty.
+#include <cinttypes>
+#include <cmath>
+#include <vector>
+
+#include "common.h"
+#include "sha256.h"
+
+using namespace sh;
+
+// --------------------------------------------------------------------------
+// SHA-256 counter-mode generator (same stream as spasm_prng.c, so that seeded
+// runs draw the same coefficients as the reference)
+// --------------------------------------------------------------------------
+namespace sh {
+
+struct Prng {
+	uint8_t block[44];
+	uint8_t hash[32];
+	uint32_t prime, mask;
+	uint32_t counter;
+	int pos;
+
+	static void be32(uint8_t *dst, uint32_t v)
+	{
+		dst[0] = (uint8_t) (v >> 24);
+		dst[1] = (uint8_t) (v >> 16);
+		dst[2] = (uint8_t) (v >> 8);
+		dst[3] = (uint8_t) v;
+	}
+
+	void rehash()
+	{
+		Sha256 h;
+		h.reset();
+		h.update(block, 44);
+		h.finish(hash);
+		counter += 1;
+		be32(block + 36, counter);
+		pos = 0;
+	}
+
+	void seed(i64 p, uint64_t s, uint32_t seq)
+	{
+		std::memset(block, 0, sizeof(block));
+		be32(block + 0, (uint32_t) (s & 0xffffffffu));
+		be32(block + 4, (uint32_t) (s >> 32));
+		prime = (uint32_t) p;
+		i64 m = 1;
+		while (m < p)
+			m <<= 1;
+		mask = (uint32_t) (m - 1);
+		be32(block + 32, (uint32_t) p);
+		be32(block + 40, seq);
+		counter = 0;
+		rehash();
+	}
+
+	uint32_t next_u32()
+	{
+		if (pos == 8)
+			rehash();
+		const uint8_t *b = hash + 4 * pos;
+		pos += 1;
+		return ((uint32_t) b[0] << 24) | ((uint32_t) b[1] << 16) | ((uint32_t) b[2] << 8) | b[3];
+	}
+
+	spasm_ZZp next_zp()
+	{
+		for (;;) {
+			uint32_t x = next_u32() & mask;
+			if (x < prime)
+				return zp_init(prime, x);
+		}
+	}
+};
+
+}  // namespace sh
+
+extern "C" {
+
+// exported for the tests: the first `count` values of the stream (prime, seed, seq)
+void spasm_hip_debug_prng(i64 prime, uint64_t seed, uint32_t seq, int count, spasm_ZZp *out)
+{
+	Prng g;
+	g.seed(prime, seed, seq);
+	for (int i = 0; i < count; i++)
+		out[i] = g.next_zp();
+}
+
+// replaces spasm_schur_estimate_density (spasm_schur.c:12-48): average density of R sampled rows
+double spasm_hip_schur_estimate_density(const struct spasm_csr *A, const int *p, int n, const struct spasm_csr *U,
+                                        const int *qinv, int R)
+{
+	if (n == 0)
+		return 0;
+	std::vector<int> sample((size_t) R);
+	uint64_t state = 0x9E3779B97F4A7C15ULL ^ (uint64_t) n;
+	for (int t = 0; t < R; t++) {
+		state = state * 6364136223846793005ULL + 1442695040888963407ULL;
+		sample[t] = p[(state >> 33) % (uint64_t) n];
+	}
+	struct spasm_lu tmp;
+	tmp.r = U->n;
+	tmp.complete = false;
+	tmp.L = nullptr;
+	tmp.U = (struct spasm_csr *) U;
+	tmp.qinv = (int *) qinv;
+	tmp.p = nullptr;
+	tmp.Ltmp = nullptr;
+	const int keep = verbose();
+	struct spasm_csr *S = spasm_hip_schur(A, sample.data(), R, &tmp, 0.0, nullptr, nullptr, nullptr);
+	(void) keep;
+	const i64 nnz = S->p[S->n];
+	spasm_hip_csr_free(S);
+	const int Sm = A->m - U->n;
+	return (Sm > 0) ? ((double) nnz) / Sm / R : 0.0;
+}
+
+// replaces spasm_schur_dense_randomized (spasm_schur.c:357-425).  The N random combinations are
+// formed on the host (sparse rows, cheap: N * w * row weight), their reduction by U and the dense
+// output are the GPU dense-row kernel.
+void spasm_hip_schur_dense_randomized(const struct spasm_csr *A, const int *p, int n, const struct spasm_csr *U,
+                                      const int *qinv, void *S, spasm_datatype datatype, int *q, int N, int w)
+{
+	if (p == nullptr || n <= 0)
+		die("spasm_hip_schur_dense_randomized: empty row list");
+	const int m = A->m;
+	const i64 prime = A->field->p;
+	// Y = C * A[p, :]  with C random, N x n
+	struct spasm_triplet *T = spasm_hip_triplet_alloc(N, m, (i64) N * 16, prime, true);
+	std::vector<spasm_ZZp> y((size_t) m, 0);
+	std::vector<int> touched;
+	std::vector<char> mark((size_t) m, 0);
+	uint64_t state = 0xD1B54A32D192ED03ULL;
+	for (int k = 0; k < N; k++) {
+		Prng g;
+		g.seed(prime, (uint64_t) k, 0);
+		touched.clear();
+		auto axpy_row = [&](int row, spasm_ZZp coeff) {
+			for (i64 px = A->p[row]; px < A->p[row + 1]; px++) {
+				const int j = A->j[px];
+				if (!mark[j]) {
+					mark[j] = 1;
+					touched.push_back(j);
+				}
+				y[j] = zp_axpy(prime, coeff, A->x[px], y[j]);
+			}
+		};
+		if (w <= 0) {
+			for (int i = 0; i < n; i++)
+				axpy_row(p[i], g.next_zp());
+		} else {
+			for (int i = 0; i < w; i++) {
+				state = state * 6364136223846793005ULL + 1442695040888963407ULL;
+				const int row = p[(state >> 33) % (uint64_t) n];
+				axpy_row(row, (i == 0) ? 1 : g.next_zp());
+			}
+		}
+		for (int j : touched) {
+			if (y[j] != 0)
+				spasm_hip_add_entry(T, k, j, y[j]);
+			y[j] = 0;
+			mark[j] = 0;
+		}
+	}
+	T->n = N;
+	T->m = m;
+	struct spasm_csr *Y = spasm_hip_compress(T);
+	spasm_hip_triplet_free(T);
+	std::vector<int> rows((size_t) N), dummy((size_t) N);
+	for (int k = 0; k < N; k++)
+		rows[k] = k;
+	struct spasm_lu tmp;
+	tmp.r = U->n;
+	tmp.complete = false;
+	tmp.L = nullptr;
+	tmp.U = (struct spasm_csr *) U;
+	tmp.qinv = (int *) qinv;
+	tmp.p = nullptr;
+	tmp.Ltmp = nullptr;
+	spasm_hip_schur_dense(Y, rows.data(), N, nullptr, &tmp, S, datatype, q, dummy.data());
+	spasm_hip_csr_free(Y);
+}
+
+}  // extern "C"
+
+// --------------------------------------------------------------------------
+// the driver
+// --------------------------------------------------------------------------
+namespace {
+
+// append the echelon rows of a dense RREF to U (update_U_after_rref, spasm_echelonize.c:189-222)
+void absorb_rref(int rr, int Sm, const void *S, spasm_datatype datatype, const size_t *Sqinv, const int *q,
+                 struct spasm_lu *fact)
+{
+	struct spasm_csr *U = fact->U;
+	i64 unz = U->p[U->n];
+	spasm_hip_csr_realloc(U, unz + (i64) (1 + Sm - rr) * rr);
+	for (i64 i = 0; i < rr; i++) {
+		const int jp = q[Sqinv[i]];
+		U->j[unz] = jp;
+		U->x[unz] = 1;
+		unz += 1;
+		fact->qinv[jp] = U->n;
+		for (i64 k = rr; k < Sm; k++) {
+			const spasm_ZZp x = spasm_hip_datatype_read(S, (size_t) (i * Sm + k), datatype);
+			if (x == 0)
+				continue;
+			U->j[unz] = q[Sqinv[k]];
+			U->x[unz] = x;
+			unz += 1;
+		}
+		U->n += 1;
+		U->p[U->n] = unz;
+	}
+}
+
+// spasm_echelonize_test_completion (spasm_echelonize.c:30-52)
+bool remainder_is_zero(const struct spasm_csr *A, const int *p, int n, struct spasm_lu *fact)
+{
+	if (n == 0 || A->p[A->n] == 0)
+		return true;
+	const int m = A->m;
+	const i64 Sm = m - fact->U->n;
+	const i64 prime = A->field->p;
+	if (Sm <= 0)
+		return true;
+	const spasm_datatype dt = spasm_hip_datatype_choose(prime);
+	const int Sn = (int) std::ceil(128.0 / std::log2((double) prime));
+	std::vector<unsigned char> S((size_t) Sn * Sm * spasm_hip_datatype_size(dt));
+	std::vector<int> q((size_t) Sm);
+	std::vector<size_t> Sp((size_t) Sm);
+	logmsg("[echelonize/completion] testing completion with %d random linear combinations (rank %d)\n", Sn, fact->U->n);
+	spasm_hip_schur_dense_randomized(A, p, n, fact->U, fact->qinv, S.data(), dt, q.data(), Sn, 0);
+	const int rr = spasm_hip_ffpack_rref(prime, Sn, (int) Sm, S.data(), (int) Sm, dt, Sp.data());
+	return rr == 0;
+}
+
+// echelonize_dense_lowrank (spasm_echelonize.c:299-372)
+void finish_lowrank(const struct spasm_csr *A, const int *p, int n, struct spasm_lu *fact, struct echelonize_opts *opts)
+{
+	struct spasm_csr *U = fact->U;
+	const int m = A->m;
+	int Sm = m - U->n;
+	const i64 prime = A->field->p;
+	const spasm_datatype dt = spasm_hip_datatype_choose(prime);
+	const int block = opts->dense_block_size;
+	std::vector<unsigned char> S((size_t) block * Sm * spasm_hip_datatype_size(dt));
+	std::vector<int> q((size_t) Sm);
+	std::vector<size_t> Sp((size_t) Sm);
+	const double start = wtime();
+	const int old_un = U->n;
+	int round = 0;
+	int rank_ub = (n < Sm) ? n : Sm;
+	logmsg("[echelonize/dense/low-rank] dense schur complement of dimension %d x %d; block size=%d\n", n, Sm, block);
+	int w = (opts->low_rank_start_weight < 0) ? (int) std::ceil(-std::log(0.01) * n / (rank_ub > 0 ? rank_ub : 1))
+	                                          : (int) opts->low_rank_start_weight;
+	for (;;) {
+		int Sn = (rank_ub < block) ? rank_ub : block;
+		if (w == 0 && Sn > 16)
+			Sn = 16;          // full combinations are formed on the host: keep the chunk small
+		if (Sn <= 0)
+			break;
+		logmsg("[echelonize/dense/low-rank] round %d, weight %d, chunk %d x %d\n", round, w, Sn, Sm);
+		spasm_hip_schur_dense_randomized(A, p, n, U, fact->qinv, S.data(), dt, q.data(), Sn, w);
+		const int rr = spasm_hip_ffpack_rref(prime, Sn, Sm, S.data(), Sm, dt, Sp.data());
+		if (rr == 0) {
+			if (remainder_is_zero(A, p, n, fact))
+				break;
+			logmsg("[echelonize/dense/low-rank] failed termination test; switching to full linear combinations\n");
+			w = 0;
+		}
+		if (rr < 0.9 * Sn && w > 0)
+			w *= 2;
+		absorb_rref(rr, Sm, S.data(), dt, Sp.data(), q.data(), fact);
+		Sm -= rr;
+		rank_ub -= rr;
+		round += 1;
+	}
+	logmsg("[echelonize/dense/low-rank] completed in %.1fs. %d new pivots found\n", wtime() - start, U->n - old_un);
+}
+
+// echelonize_dense (spasm_echelonize.c:379-467), L not recorded
+void finish_dense(const struct spasm_csr *A, const int *p, int n, const int *p_in, struct spasm_lu *fact,
+                  struct echelonize_opts *opts)
+{
+	struct spasm_csr *U = fact->U;
+	const int m = A->m;
+	int Sm = m - U->n;
+	const i64 prime = A->field->p;
+	const spasm_datatype dt = spasm_hip_datatype_choose(prime);
+	const int block = opts->dense_block_size;
+	std::vector<unsigned char> S((size_t) block * Sm * spasm_hip_datatype_size(dt));
+	std::vector<int> p_out((size_t) block), q((size_t) (Sm > 0 ? Sm : 1));
+	std::vector<size_t> Sqinv((size_t) (Sm > 0 ? Sm : 1));
+	int processed = 0, round = 0;
+	const double start = wtime();
+	const int old_un = U->n;
+	bool lowrank = false;
+	int rank_ub = std::min(A->n - U->n, A->m - U->n);
+	logmsg("[echelonize/dense] dense schur complement of dimension %d x %d; block size=%d\n", n, Sm, block);
+	for (;;) {
+		const int Sn = std::min(block, n - processed);
+		if (Sn <= 0 || Sm <= 0)
+			break;
+		logmsg("[echelonize/dense] round %d. processing S[%d:%d] (%d x %d)\n", round, processed, processed + Sn, Sn, Sm);
+		spasm_hip_schur_dense(A, p, Sn, p_in, fact, S.data(), dt, q.data(), p_out.data());
+		const int rr = spasm_hip_ffpack_rref(prime, Sn, Sm, S.data(), Sm, dt, Sqinv.data());
+		absorb_rref(rr, Sm, S.data(), dt, Sqinv.data(), q.data(), fact);
+		round += 1;
+		processed += Sn;
+		p += Sn;
+		Sm = m - U->n;
+		rank_ub = std::min(A->n - U->n, A->m - U->n);
+		if (opts->enable_tall_and_skinny && rr < opts->low_rank_ratio * Sn) {
+			lowrank = true;
+			break;
+		}
+	}
+	if (rank_ub > 0 && n - processed > 0 && lowrank) {
+		logmsg("[echelonize/dense] too few pivots; switching to low-rank mode\n");
+		finish_lowrank(A, p, n - processed, fact, opts);
+	} else {
+		logmsg("[echelonize/dense] completed in %.1fs. %d new pivots found\n", wtime() - start, U->n - old_un);
+	}
+}
+
+}  // namespace
+
+extern "C" struct spasm_lu *spasm_hip_echelonize(const struct spasm_csr *A0, struct echelonize_opts *opts)
+{
+	if (spasm_hip_device_count() == 0)
+		die("spasm_hip_echelonize: no HIP device (this library has no CPU path)");
+	struct echelonize_opts dflt;
+	if (opts == nullptr) {
+		spasm_hip_echelonize_init_opts(&dflt);
+		opts = &dflt;
+	}
+	if (opts->L || opts->complete)
+		die("spasm_hip_echelonize: computing L on the GPU path is not available yet (opts->L / opts->complete)");
+	const struct spasm_csr *A = A0;
+	int n = A->n;
+	const int m = A->m;
+	const i64 prime = A->field->p;
+	logmsg("[echelonize] start on %d x %d matrix with %" PRId64 " nnz\n", n, m, A->p[A->n]);
+	struct spasm_csr *U = spasm_hip_csr_alloc(n, m, A->p[A->n], prime, true);
+	U->n = 0;
+	int *Uqinv = (int *) xmalloc((i64) m * sizeof(int));
+	for (int j = 0; j < m; j++)
+		Uqinv[j] = -1;
+	struct spasm_lu *fact = (struct spasm_lu *) xmalloc(sizeof(*fact));
+	fact->L = nullptr;
+	fact->p = nullptr;
+	fact->U = U;
+	fact->qinv = Uqinv;
+	fact->Ltmp = nullptr;
+	fact->complete = false;
+
+	int *p = (int *) xmalloc((i64) n * sizeof(int));
+	int *p_in = nullptr;
+	const double start = wtime();
+	double density = (n > 0 && m > 0) ? (double) A->p[A->n] / n / m : 0.0;
+	int npiv = 0, status = 0, round;
+	// status 0: round limit reached / 1: nothing left / 2: pivots found, Schur complement not computed
+	for (round = 0; round < opts->max_round; round++) {
+		if (A->p[A->n] == 0) {
+			status = 1;
+			break;
+		}
+		logmsg("[echelonize] round %d\n", round);
+		npiv = spasm_hip_pivots_extract_structural(A, p_in, fact, p, opts);
+		if (npiv < opts->min_pivot_proportion * std::min(n, m - U->n)) {
+			logmsg("[echelonize] not enough pivots found; stopping\n");
+			status = 2;
+			break;
+		}
+		density = spasm_hip_schur_estimate_density(A, p + npiv, n - npiv, U, Uqinv, 100);
+		if (density > opts->sparsity_threshold) {
+			logmsg("[echelonize] Schur complement is dense (estimated %.2f%%)\n", 100 * density);
+			status = 2;
+			break;
+		}
+		logmsg("[echelonize] Schur complement is %d x %d, estimated density : %.4f\n", n - npiv, m - U->n, density);
+		int *p_out = (int *) xmalloc((i64) (n - npiv) * sizeof(int));
+		struct spasm_csr *S = spasm_hip_schur(A, p + npiv, n - npiv, fact, density, nullptr, p_in, p_out);
+		if (A != A0)
+			spasm_hip_csr_free((struct spasm_csr *) A);
+		A = S;
+		n = n - npiv;
+		std::free(p_in);
+		p_in = p_out;
+	}
+	if (status == 0) {
+		npiv = 0;
+		for (int i = 0; i < n; i++)
+			p[i] = i;
+	}
+	if (status != 1) {
+		const double aspect = (m - U->n > 0) ? (double) (n - npiv) / (m - U->n) : 0.0;
+		logmsg("[echelonize] finishing; density = %.3f; aspect ratio = %.1f\n", density, aspect);
+		if (opts->enable_tall_and_skinny && aspect > opts->tall_and_skinny_ratio) {
+			finish_lowrank(A, p + npiv, n - npiv, fact, opts);
+		} else if (opts->enable_dense && density > opts->sparsity_threshold) {
+			finish_dense(A, p + npiv, n - npiv, p_in, fact, opts);
+		} else if (opts->enable_GPLU) {
+			// The reference reduces the remaining rows one by one (GPLU, a sequential loop).  Here the
+			// remainder keeps going through structural rounds on the GPU: each one finds at least one
+			// pivot while the remainder is non-zero, so this terminates with the same row space.
+			// A remainder that turns dense is handed to the dense code.
+			int extra = 0;
+			for (;;) {
+				if (status == 2 && extra == 0) {
+					// pivots of the last search are already in U: eliminate them first
+				} else {
+					if (A->p[A->n] == 0)
+						break;
+					npiv = spasm_hip_pivots_extract_structural(A, p_in, fact, p, opts);
+					if (npiv == 0)
+						die("structural pivot search found nothing on a non-zero matrix");
+				}
+				if (n - npiv == 0)
+					break;
+				density = spasm_hip_schur_estimate_density(A, p + npiv, n - npiv, U, Uqinv, 100);
+				if (opts->enable_dense && density > opts->sparsity_threshold) {
+					finish_dense(A, p + npiv, n - npiv, p_in, fact, opts);
+					break;
+				}
+				int *p_out = (int *) xmalloc((i64) (n - npiv) * sizeof(int));
+				struct spasm_csr *S = spasm_hip_schur(A, p + npiv, n - npiv, fact, density, nullptr, p_in, p_out);
+				if (A != A0)
+					spasm_hip_csr_free((struct spasm_csr *) A);
+				A = S;
+				n = n - npiv;
+				std::free(p_in);
+				p_in = p_out;
+				extra += 1;
+				logmsg("[echelonize/rounds] extra round %d: rank >= %d, %d rows left\n", extra, U->n, n);
+			}
+		} else {
+			logmsg("[echelonize] cannot finish (no valid method enabled); incomplete echelonization returned\n");
+		}
+	}
+	std::free(p);
+	std::free(p_in);
+	logmsg("[echelonize] done in %.1fs. Rank %d, %" PRId64 " nz in basis\n", wtime() - start, U->n, U->p[U->n]);
+	spasm_hip_csr_resize(U, U->n, m);
+	spasm_hip_csr_realloc(U, -1);
+	if (A != A0)
+		spasm_hip_csr_free((struct spasm_csr *) A);
+	fact->r = U->n;
+	return fact;
+}
+
+// replaces spasm_rref (spasm_rref.c:25-146).  Row i of R is U[i] reduced by every other pivotal
+// row.  U[i] minus its pivot entry only meets pivots of later rows, whose rows never reach back
+// to column pivot(i), so reducing it against the whole of U gives the same row: one GPU call.
+extern "C" struct spasm_csr *spasm_hip_rref(const struct spasm_lu *fact, int *Rqinv)
+{
+	const struct spasm_csr *U = fact->U;
+	const int n = U->n, m = U->m;
+	const i64 prime = U->field->p;
+	struct spasm_csr *T = spasm_hip_csr_alloc(n, m, U->p[n], prime, true);
+	i64 w = 0;
+	std::vector<int> rows((size_t) (n > 0 ? n : 1));
+	for (int i = 0; i < n; i++) {
+		rows[i] = i;
+		for (i64 px = U->p[i] + 1; px < U->p[i + 1]; px++) {
+			T->j[w] = U->j[px];
+			T->x[w] = U->x[px];
+			w += 1;
+		}
+		T->p[i + 1] = w;
+	}
+	struct spasm_csr *S = spasm_hip_schur(T, rows.data(), n, fact, 0.0, nullptr, nullptr, nullptr);
+	spasm_hip_csr_free(T);
+	struct spasm_csr *R = spasm_hip_csr_alloc(n, m, S->p[n] + n, prime, true);
+	w = 0;
+	for (int j = 0; j < m; j++)
+		Rqinv[j] = -1;
+	for (int i = 0; i < n; i++) {
+		const int piv = U->j[U->p[i]];
+		R->j[w] = piv;
+		R->x[w] = 1;
+		w += 1;
+		Rqinv[piv] = i;
+		for (i64 px = S->p[i]; px < S->p[i + 1]; px++) {
+			R->j[w] = S->j[px];
+			R->x[w] = S->x[px];
+			w += 1;
+		}
+		R->p[i + 1] = w;
+	}
+	spasm_hip_csr_free(S);
+	return R;
+}
+
+// replaces spasm_kernel (spasm_kernel.c:9-140) through the RREF (spasm_kernel_from_rref, :146-178):
+// for every non-pivotal column j the row  -e_j + sum_i R[i, j] e_{pivot(i)}.
+extern "C" struct spasm_csr *spasm_hip_kernel(const struct spasm_lu *fact)
+{
+	const int m = fact->U->m;
+	const i64 prime = fact->U->field->p;
+	std::vector<int> Rqinv((size_t) (m > 0 ? m : 1));
+	struct spasm_csr *R = spasm_hip_rref(fact, Rqinv.data());
+	struct spasm_csr *Rt = spasm_hip_transpose(R, 1);
+	const int n = R->n;
+	struct spasm_csr *K = spasm_hip_csr_alloc(m - n, m, R->p[n] - n + (m - n), prime, true);
+	K->n = 0;
+	i64 w = 0;
+	for (int j = 0; j < m; j++) {
+		if (Rqinv[j] >= 0)
+			continue;
+		K->j[w] = j;
+		K->x[w] = zp_init(prime, prime - 1);
+		w += 1;
+		for (i64 px = Rt->p[j]; px < Rt->p[j + 1]; px++) {
+			const int i = Rt->j[px];
+			K->j[w] = R->j[R->p[i]];
+			K->x[w] = Rt->x[px];
+			w += 1;
+		}
+		K->n += 1;
+		K->p[K->n] = w;
+	}
+	spasm_hip_csr_free(Rt);
+	spasm_hip_csr_free(R);
+	return K;
+}

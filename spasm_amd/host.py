@@ -147,3 +147,47 @@ def ffpack_rref(prime, M, datatype=SPASM_I64):
     qinv = np.zeros(max(m, 1), np.uint64)
     r = L.spasm_hip_ffpack_rref(prime, n, m, M.ctypes.data, m, datatype, qinv.ctypes.data_as(C.POINTER(C.c_size_t)))
     return r, M, qinv[:m].astype(np.int64)
+
+
+def default_opts():
+    o = EchelonizeOpts()
+    lib().spasm_hip_echelonize_init_opts(C.byref(o))
+    return o
+
+
+def echelonize(A, opts=None):
+    """spasm_echelonize (spasm_echelonize.c:478): returns Fact(U, qinv) with rank = U.n."""
+    require_gpu("echelonize")
+    L = lib()
+    a = view_csr(A)
+    lu = L.spasm_hip_echelonize(C.byref(a), C.byref(opts) if opts is not None else None)
+    s = lu.contents
+    U = copy_csr(s.U)
+    qinv = np.ctypeslib.as_array(s.qinv, shape=(max(A.m, 1),))[:A.m].copy()
+    L.spasm_hip_lu_free(lu)
+    return Fact(U, qinv)
+
+
+def rref(F):
+    """spasm_rref (spasm_rref.c:25): returns (R, Rqinv)."""
+    require_gpu("rref")
+    L = lib()
+    lu, up, qinv = _lu_for(F, 0, 0)
+    Rq = np.zeros(max(F.U.m, 1), np.int32)
+    r = L.spasm_hip_rref(C.byref(lu), _ip(Rq))
+    R = copy_csr(r)
+    L.spasm_hip_csr_free(r)
+    L.spasm_hip_csr_free(up)
+    return R, Rq[:F.U.m]
+
+
+def kernel(F):
+    """spasm_kernel (spasm_kernel.c:9): basis of the right kernel, one vector per row."""
+    require_gpu("kernel")
+    L = lib()
+    lu, up, qinv = _lu_for(F, 0, 0)
+    k = L.spasm_hip_kernel(C.byref(lu))
+    K = copy_csr(k)
+    L.spasm_hip_csr_free(k)
+    L.spasm_hip_csr_free(up)
+    return K

@@ -1,0 +1,100 @@
+"""GPU parity of the driver: ranks equal to the oracle's, echelon form, row-space equality."""
+import numpy as np
+import pytest
+
+from conftest import ALL_MODULI, ALL_TEST_MATRICES, matrix_path
+
+import spasm_amd
+
+pytestmark = pytest.mark.gpu
+
+SMALL_SET = [m for m in ALL_TEST_MATRICES if m not in ("mat364.sms", "trefethen_500.sms", "medium.sms", "m1.sms")]
+
+
+def _as_product(A):
+    return spasm_amd.Csr(A.n, A.m, A.p, A.j, A.x, A.prime)
+
+
+def _as_oracle(orc, A):
+    return orc.CSR(A.n, A.m, A.p, A.j, A.x, A.prime)
+
+
+def _check_echelon(oracle, A, F):
+    U, qinv = F.U, F.qinv
+    seen = set()
+    for i in range(U.n):                       # tests/echelonize.c:33-52
+        jj, xx = U.row(i)
+        assert len(jj) > 0 and xx[0] == 1 and int(jj[0]) not in seen
+        seen.add(int(jj[0]))
+        assert qinv[jj[0]] == i
+    Uo = _as_oracle(oracle, U)
+    for i in range(A.n):                       # tests/echelonize.c:80-117: rowspan(A) inside rowspan(U)
+        pat, x = oracle.solve_row(Uo, qinv, A, i)
+        assert not any(x[j] != 0 and qinv[j] < 0 for j in pat)
+
+
+@pytest.mark.parametrize("name", ALL_TEST_MATRICES)
+@pytest.mark.parametrize("p", ALL_MODULI + [42013])
+def test_echelonize_rank_matches_oracle(oracle, name, p):
+    A = oracle.load_sms(matrix_path(name), p)
+    want = oracle.echelonize(A)
+    F = spasm_amd.echelonize(_as_product(A))
+    assert F.U.n == want.U.n                   # bit-exact rank
+    _check_echelon(oracle, A, F)
+    # equal rank + inclusion of the oracle's U in ours => identical row spaces
+    Uo = _as_oracle(oracle, F.U)
+    for i in range(want.U.n):
+        pat, x = oracle.solve_row(Uo, F.qinv, want.U, i)
+        assert not any(x[j] != 0 and F.qinv[j] < 0 for j in pat)
+
+
+@pytest.mark.parametrize("name", ["mat364.sms", "medium.sms", "m1.sms", "singular.sms", "rectangular_l.sms", "G2.sms"])
+@pytest.mark.parametrize("mode", ["dense", "lowrank", "rounds", "norounds-dense"])
+def test_echelonize_every_finishing_mode(oracle, name, mode):
+    p = 42013
+    A = oracle.load_sms(matrix_path(name), p)
+    want = oracle.echelonize(A).U.n
+    o = spasm_amd.default_opts()
+    if mode == "dense":
+        o.sparsity_threshold = -1.0
+        o.enable_tall_and_skinny = False
+        o.dense_block_size = 37
+    elif mode == "lowrank":
+        o.sparsity_threshold = -1.0
+        o.tall_and_skinny_ratio = 0.0
+        o.dense_block_size = 50
+    elif mode == "rounds":
+        o.enable_dense = False
+        o.enable_tall_and_skinny = False
+        o.max_round = 1
+    else:
+        o.max_round = 0
+        o.sparsity_threshold = -1.0
+        o.enable_tall_and_skinny = False
+    F = spasm_amd.echelonize(_as_product(A), o)
+    assert F.U.n == want
+    _check_echelon(oracle, A, F)
+
+
+@pytest.mark.parametrize("name", SMALL_SET + ["mat364.sms"])
+@pytest.mark.parametrize("p", [257, 4294967291])
+def test_rref_and_kernel(oracle, name, p):
+    A = oracle.load_sms(matrix_path(name), p)
+    F = spasm_amd.echelonize(_as_product(A))
+    R, Rq = spasm_amd.rref(F)
+    Fo = oracle.Fact(_as_oracle(oracle, F.U), F.qinv)
+    R_want, Rq_want = oracle.rref(Fo)
+    assert np.array_equal(Rq, Rq_want)
+    assert oracle.same_matrix(_as_oracle(oracle, R), R_want)
+    for i in range(R.n):                       # tests/echelonize.c:55-77 (rref_check)
+        jj, xx = R.row(i)
+        assert Rq[jj[0]] == i and xx[0] == 1 and np.all(Rq[jj[1:]] < 0)
+    K = spasm_amd.kernel(F)
+    assert K.n == A.m - F.U.n
+    if A.n and A.m and K.n:
+        D = A.to_dense().astype(object)
+        Kd = _as_oracle(oracle, K).to_dense().astype(object)
+        assert not np.any((D.dot(Kd.T)) % p)
+        from test_oracle import numpy_rank
+        if p < 2**31:
+            assert numpy_rank(np.array(Kd, dtype=np.int64), p) == K.n

@@ -157,3 +157,16 @@ def test_level_schedule_is_valid_and_eliminates_correctly(oracle, name):
         wj, wx = want.row(t)
         ref = sorted((int(lab[j]), int(v) % p) for j, v in zip(wj.tolist(), wx.tolist()))
         assert got == ref
+
+
+def test_prng_matches_reference_golden_vector():
+    """tests/Expected/prng of the reference (SHA-256 counter mode, rejection sampling)."""
+    L = C.CDLL(spasm_amd.LIB_PATH)
+    L.spasm_hip_debug_prng.argtypes = [C.c_int64, C.c_uint64, C.c_uint32, C.c_int, C.POINTER(C.c_int32)]
+    lines = open(matrix_path("../Expected/prng")).read().strip().split("\n")
+    cases = [(257, 0, 0), (257, 0, 1), (257, 1, 0), (257, 1, 1), (65537, 0xdead00000000beef, 0)]
+    for line, (p, seed, seq) in zip(lines, cases):
+        want = [int(t) for t in line.split("out=")[1].split(",")]
+        out = (C.c_int32 * 10)()
+        L.spasm_hip_debug_prng(p, seed, seq, 10, out)
+        assert list(out) == want
