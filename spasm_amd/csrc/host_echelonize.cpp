@@ -138,10 +138,14 @@ void spasm_hip_schur_dense_randomized(const struct spasm_csr *A, const int *p, i
 	std::vector<spasm_ZZp> y((size_t) m, 0);
 	std::vector<int> touched;
 	std::vector<char> mark((size_t) m, 0);
-	uint64_t state = 0xD1B54A32D192ED03ULL;
+	// every call draws fresh combinations (the reference reseeds with k alone and relies on rand() for
+	// the row choice; a per-call salt keeps the stream deterministic and never repeats a combination)
+	static uint64_t call_id = 0;
+	call_id += 1;
+	uint64_t state = 0xD1B54A32D192ED03ULL ^ (call_id * 0x9E3779B97F4A7C15ULL);
 	for (int k = 0; k < N; k++) {
 		Prng g;
-		g.seed(prime, (uint64_t) k, 0);
+		g.seed(prime, (call_id << 32) | (uint64_t) k, 0);
 		touched.clear();
 		auto axpy_row = [&](int row, spasm_ZZp coeff) {
 			for (i64 px = A->p[row]; px < A->p[row + 1]; px++) {
