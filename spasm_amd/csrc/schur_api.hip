@@ -10,6 +10,9 @@ void launch_schur_lds(const SchurArgs &a, int table, bool wide, int blocks, hipS
 size_t schur_lds_bytes(int table, bool wide);
 void launch_finalize(const spasm_hip_dwork *W, int nrows, int sort_rows, hipStream_t stream);
 void wave_dense_geometry(int rpad, int Sm, bool wide, int64_t *slot_bytes, int64_t *off_bm, int64_t *off_xn);
+void group_geometry(int rpad, int Sm, bool wide, int64_t *slot_bytes, int64_t *off_bm);
+void launch_schur_group(const SchurArgs &a, unsigned char *scratch, int64_t slot_bytes, int64_t off_bm, bool wide,
+                        uint32_t *dense_out, int64_t ldS, int blocks, hipStream_t stream);
 void launch_schur_wave_dense(const SchurArgs &a, unsigned char *scratch, int64_t slot_bytes, int64_t off_bm, int64_t off_xn,
                              bool wide, uint32_t *dense_out, int64_t ldS, int blocks, hipStream_t stream);
 void launch_all_rows_to_list(int *list, int *count, int *row_len, int nrows, hipStream_t stream);
@@ -406,6 +409,10 @@ int spasm_hip_dschur(const spasm_hip_dcsr *A, const int *d_rows, int nrows, cons
 	const int force_tier = env_int("SPASM_HIP_FORCE_TIER", 0);
 	const bool use_big = (force_tier == 1) || env_int("SPASM_HIP_USE_BIG_TABLE", 0);
 
+	// 1 = row-group kernel (64 consecutive rows per wave, label-major state) for every row
+	const int group_mode = env_int("SPASM_HIP_GROUP", 0);
+	int group_slots = 0;
+	i64 group_slot_bytes = 0, group_off_bm = 0;
 	// per-wave dense scratch, (re)allocated when the factor geometry needs more
 	{
 		i64 slot_bytes, off_bm, off_xn;
@@ -414,7 +421,14 @@ int spasm_hip_dschur(const spasm_hip_dcsr *A, const int *d_rows, int nrows, cons
 		const i64 budget = (i64) env_int("SPASM_HIP_SCRATCH_GB", 48) << 30;
 		slots = (int) std::max<i64>(cus, std::min<i64>(slots, budget / slot_bytes));
 		slots = std::max(1, std::min(slots, nrows));
-		const i64 need = slot_bytes * slots;
+		i64 need = slot_bytes * slots;
+		if (group_mode) {
+			group_geometry(F->rpad, F->Sm, wide_dense, &group_slot_bytes, &group_off_bm);
+			const int ngroups = (nrows + 63) / 64;
+			group_slots = (int) std::min<i64>(env_int("SPASM_HIP_GROUP_SLOTS", cus * 20), budget / group_slot_bytes);
+			group_slots = std::max(1, std::min(group_slots, ngroups));
+			need = group_slot_bytes * group_slots;
+		}
 		if (need > W->scratch_bytes) {
 			if (W->d_scratch != nullptr)
 				(void) hipFree(W->d_scratch);
@@ -468,6 +482,14 @@ int spasm_hip_dschur(const spasm_hip_dcsr *A, const int *d_rows, int nrows, cons
 		a.done_ctr = CTR_DONE0;
 		const int per_cu0 = (int) std::min<size_t>(16, (size_t) (160 * 1024) / schur_lds_bytes(small_table, wide_lds));
 		int blocks0 = std::min(cus * per_cu0, (nrows + 3) / 4);
+		if (group_mode) {
+			a.next_ctr = CTR_ROW_NEXT3;
+			a.done_ctr = CTR_DONE2;
+			HIP_CHECK(hipEventRecord(W->ev[3], stream));
+			HIP_CHECK(hipEventRecord(W->ev[4], stream));
+			launch_schur_group(a, W->d_scratch, group_slot_bytes, group_off_bm, wide_dense, nullptr, 0, group_slots, stream);
+			goto eliminated;
+		}
 		if (force_tier == 0)
 			launch_schur_lds(a, small_table, wide_lds, std::max(blocks0, 1), stream);
 		else
@@ -498,6 +520,7 @@ int spasm_hip_dschur(const spasm_hip_dcsr *A, const int *d_rows, int nrows, cons
 		launch_schur_wave_dense(a, W->d_scratch, W->slot_bytes, W->off_bm, W->off_xn, wide_dense, nullptr, 0,
 		                        W->scratch_slots, stream);
 	}
+eliminated:
 	HIP_CHECK(hipEventRecord(W->ev[1], stream));
 	launch_finalize(W, nrows, sort_rows, stream);
 	HIP_CHECK(hipEventRecord(W->ev[2], stream));

@@ -908,3 +908,298 @@ void launch_schur_wave_dense(const SchurArgs &a, unsigned char *scratch, int64_t
 }
 
 }  // namespace sh
+
+// --------------------------------------------------------------------------
+// K2g: "row-group" kernel.  A wave owns 64 CONSECUTIVE rows of the row list,
+// lane = row.  The accumulators of the group are stored label-major:
+// X[label][64] (one 256-byte line per label), so that eliminating pivot c in
+// all the rows that hold it is a wave-uniform loop over the entries of U'[c]
+// and every update is ONE coalesced 256-byte atomic instruction (lanes whose
+// row does not hold c are masked).  Rows that are neighbours in the matrix
+// have almost the same reach (mk13.b5: the union of 16 reaches is 1.07x one
+// reach), which is what makes this layout pay: the random-access traffic of
+// the per-row kernel is divided by the number of rows sharing a line.
+// Pending pivots of the group = a bitmap in HBM, touched by one lane.
+// --------------------------------------------------------------------------
+namespace sh {
+
+namespace {
+constexpr int GR_ACT = 2048;
+constexpr int GR_PB = 4;            // pivots whose loads are issued together
+}
+
+struct GroupArgs {
+	SchurArgs a;
+	unsigned char *scratch;
+	int64_t slot_bytes;       // X | bitmap
+	int64_t off_bm;
+	uint32_t *dense_out;
+	int64_t ldS;
+};
+
+template <bool WIDE>
+__global__ __launch_bounds__(64) void schur_group_kernel(GroupArgs d)
+{
+	using V = typename Acc<WIDE>::type;
+	__shared__ uint32_t act[GR_ACT];
+	const SchurArgs &a = d.a;
+	const int lane = threadIdx.x;
+	const uint32_t r = (uint32_t) a.r;
+	const int Sm = a.Sm;
+	const MontDev F = a.F;
+	const int nw = (int) (r / 32);
+	const int ngroups = (a.nrows + 63) / 64;
+
+	unsigned char *slot = d.scratch + (int64_t) blockIdx.x * d.slot_bytes;
+	V *X = reinterpret_cast<V *>(slot);                 // X[label * 64 + lane]
+	uint32_t *bm = reinterpret_cast<uint32_t *>(slot + d.off_bm);
+
+	unsigned long long st_elim = 0, st_stream = 0, st_input = 0;
+	int st_done = 0;
+
+	for (;;) {
+		int g = 0;
+		if (lane == 0)
+			g = atomicAdd(&a.ctr[a.next_ctr], 1);
+		g = __builtin_amdgcn_readfirstlane(g);
+		if (g >= ngroups)
+			break;
+		const int k = g * 64 + lane;
+		const bool have_row = k < a.nrows;
+
+		// ---- scatter the 64 input rows (each lane its own) ----
+		if (have_row) {
+			const int i = a.rows[k];
+			const int64_t lo = a.Ap[i], hi = a.Ap[i + 1];
+			st_input += (unsigned long long) (hi - lo);
+			for (int64_t px = lo; px < hi; px++) {
+				const uint32_t c = a.lab[a.Aj[px]];
+				const uint32_t v = reduce_sum(from_balanced(a.Ax[px], F), F);
+				add_ff(&X[(int64_t) c * 64 + lane], v);
+				if (c < r)
+					(void) __hip_atomic_fetch_or(&bm[c >> 5], 1u << (c & 31), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+			}
+		}
+
+		// ---- eliminate level by level ----
+		uint32_t cursor = 0;
+		for (;;) {
+			drain_vmem();
+			int wi = -1;
+			uint32_t fbits = 0, lwe = 0;
+			const int wstart = (int) (cursor >> 5);
+			for (int base = wstart; base < nw; base += 64) {
+				const int w = base + lane;
+				uint32_t bits = 0, lw = 0;
+				if (w < nw) {
+					bits = ld_sc1(&bm[w]);
+					lw = a.lvl_end_w[w];
+					if (w == wstart)
+						bits &= ~((1u << (cursor & 31)) - 1u);
+				}
+				const uint64_t mask = __ballot(bits != 0);
+				if (mask != 0) {
+					const int fl = __builtin_ctzll(mask);
+					wi = base + fl;
+					fbits = (uint32_t) __shfl((int) bits, fl);
+					lwe = (uint32_t) __shfl((int) lw, fl);
+					break;
+				}
+			}
+			if (wi < 0)
+				break;
+			const uint32_t c0 = (uint32_t) wi * 32 + (uint32_t) __builtin_ctz(fbits);
+			const uint32_t lend = (lwe != MIXED) ? lwe * 32 : a.lvl_end[c0];
+			const int wl = (int) ((lend + 31) >> 5);
+
+			for (int wb = wi; wb < wl; wb += 64) {
+				// pending labels of this chunk of the level -> act[]
+				const int w = wb + lane;
+				uint32_t bits = 0;
+				if (w < wl) {
+					bits = ld_sc1(&bm[w]);
+					if (w == wi)
+						bits &= ~((1u << (c0 & 31)) - 1u);
+					if ((uint32_t) w * 32 + 32 > lend)
+						bits &= (1u << (lend & 31)) - 1u;
+					if (bits != 0)
+						(void) __hip_atomic_fetch_and(&bm[w], ~bits, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+				}
+				int tot;
+				int pos = wave_exclusive_scan(__popc(bits), lane, tot);
+				uint32_t b = bits;
+				while (b) {
+					const int bit = __builtin_ctz(b);
+					b &= b - 1;
+					act[pos++] = (uint32_t) w * 32 + bit;
+				}
+				__builtin_amdgcn_wave_barrier();
+				__builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+
+				// apply them: uniform loop, GR_PB pivots per trip so that their loads overlap
+				for (int t0 = 0; t0 < tot; t0 += GR_PB) {
+					uint32_t cc[GR_PB];
+					V raw[GR_PB];
+					uint64_t start[GR_PB];
+					int len[GR_PB];
+#pragma unroll
+					for (int u = 0; u < GR_PB; u++) {
+						const int t = t0 + u;
+						cc[u] = (t < tot) ? ((volatile uint32_t *) act)[t] : 0xFFFFFFFFu;
+						cc[u] = __builtin_amdgcn_readfirstlane(cc[u]);
+						raw[u] = 0;
+						start[u] = 0;
+						len[u] = 0;
+						if (cc[u] != 0xFFFFFFFFu) {
+							raw[u] = ld_sc1(&X[(int64_t) cc[u] * 64 + lane]);
+							start[u] = a.rp[cc[u]];
+							len[u] = (int) (a.rp[cc[u] + 1] - start[u]);
+						}
+					}
+#pragma unroll
+					for (int u = 0; u < GR_PB; u++) {
+						if (cc[u] == 0xFFFFFFFFu)
+							continue;
+						const uint32_t v = (raw[u] != 0) ? reduce_sum(raw[u], F) : 0u;
+						if (raw[u] != 0)
+							__hip_atomic_store(&X[(int64_t) cc[u] * 64 + lane], (V) 0, __ATOMIC_RELAXED,
+							                   __HIP_MEMORY_SCOPE_WAVEFRONT);
+						const uint64_t active = __ballot(v != 0);
+						if (active == 0)
+							continue;
+						const int nact = __popcll(active);
+						st_elim += (unsigned long long) nact;
+						st_stream += (unsigned long long) nact * (unsigned long long) len[u];
+						const uint32_t w_neg = F.p - v;
+						const uint64_t s0 = start[u];
+						const int L = len[u];
+						for (int e0 = 0; e0 < L; e0 += 4) {
+							uint2 ent[4];
+#pragma unroll
+							for (int q = 0; q < 4; q++)
+								ent[q] = (e0 + q < L) ? a.ent[s0 + e0 + q] : uint2{0xFFFFFFFFu, 0u};
+#pragma unroll
+							for (int q = 0; q < 4; q++) {
+								if (ent[q].x == 0xFFFFFFFFu)
+									continue;
+								const uint32_t tgt = ent[q].x;
+								if (v != 0)
+									add_ff(&X[(int64_t) tgt * 64 + lane], montmul(w_neg, ent[q].y, F));
+								if (tgt < r && lane == 0)
+									(void) __hip_atomic_fetch_or(&bm[tgt >> 5], 1u << (tgt & 31), __ATOMIC_RELAXED,
+									                             __HIP_MEMORY_SCOPE_WAVEFRONT);
+							}
+						}
+					}
+				}
+				__builtin_amdgcn_wave_barrier();
+			}
+			cursor = lend;
+		}
+		drain_vmem();
+
+		// ---- output: lane = row, the non-pivotal labels in order are the sorted row ----
+		V *Xn = X + (int64_t) r * 64;
+		if (d.dense_out != nullptr) {
+			for (int t = 0; t < Sm; t++) {
+				const V rawv = ld_sc1(&Xn[(int64_t) t * 64 + lane]);
+				if (have_row)
+					d.dense_out[(int64_t) k * d.ldS + t] = reduce_sum(rawv, F);
+				if (rawv != 0)
+					__hip_atomic_store(&Xn[(int64_t) t * 64 + lane], (V) 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+			}
+			if (have_row)
+				a.row_len[k] = Sm;
+			st_done += __popcll(__ballot(have_row));
+			continue;
+		}
+		int count = 0;
+		for (int t0 = 0; t0 < Sm; t0 += 8) {
+			V rv[8];
+#pragma unroll
+			for (int u = 0; u < 8; u++)
+				rv[u] = (t0 + u < Sm) ? ld_sc1(&Xn[(int64_t) (t0 + u) * 64 + lane]) : (V) 0;
+#pragma unroll
+			for (int u = 0; u < 8; u++)
+				count += (rv[u] != 0 && reduce_sum(rv[u], F) != 0) ? 1 : 0;
+		}
+		int gtot;
+		const int excl = wave_exclusive_scan(count, lane, gtot);
+		unsigned long long got = 0;
+		if (lane == 0)
+			got = atomicAdd(&a.ctr64[C64_POOL], (unsigned long long) gtot);
+		const uint32_t g_lo = __builtin_amdgcn_readfirstlane((uint32_t) got);
+		const uint32_t g_hi = __builtin_amdgcn_readfirstlane((uint32_t) (got >> 32));
+		const int64_t base_off = (int64_t) (((uint64_t) g_hi << 32) | g_lo);
+		const bool fits = base_off + gtot <= a.pool_cap;
+		int64_t wpos = base_off + excl;
+		for (int t0 = 0; t0 < Sm; t0 += 8) {
+			V rv[8];
+#pragma unroll
+			for (int u = 0; u < 8; u++)
+				rv[u] = (t0 + u < Sm) ? ld_sc1(&Xn[(int64_t) (t0 + u) * 64 + lane]) : (V) 0;
+#pragma unroll
+			for (int u = 0; u < 8; u++) {
+				if (rv[u] == 0)
+					continue;
+				__hip_atomic_store(&Xn[(int64_t) (t0 + u) * 64 + lane], (V) 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+				const uint32_t v = reduce_sum(rv[u], F);
+				if (v != 0 && fits) {
+					a.pool_j[wpos] = a.q[t0 + u];
+					a.pool_x[wpos] = to_balanced(v, F);
+					wpos += 1;
+				}
+			}
+		}
+		if (have_row) {
+			if (fits) {
+				a.row_off[k] = (base_off + excl) | (1LL << 62);
+				a.row_len[k] = count;
+			} else {
+				a.row_len[k] = -1;
+			}
+		}
+		if (!fits && lane == 0)
+			atomicOr(&a.ctr[CTR_STATUS], 1);
+		st_done += fits ? __popcll(__ballot(have_row)) : 0;
+	}
+	drain_vmem();
+	// per-lane statistics -> wave totals
+	for (int dlt = 32; dlt >= 1; dlt >>= 1) {
+		const uint32_t lo = (uint32_t) __shfl_xor((int) (uint32_t) st_input, dlt);
+		const uint32_t hi = (uint32_t) __shfl_xor((int) (uint32_t) (st_input >> 32), dlt);
+		st_input += ((unsigned long long) hi << 32) | lo;
+	}
+	if (lane == 0) {
+		atomicAdd(&a.ctr64[C64_ELIM], st_elim);
+		atomicAdd(&a.ctr64[C64_STREAM], st_stream);
+		atomicAdd(&a.ctr64[C64_INPUT], st_input);
+		atomicAdd(&a.ctr[a.done_ctr], st_done);
+	}
+}
+
+void group_geometry(int rpad, int Sm, bool wide, int64_t *slot_bytes, int64_t *off_bm)
+{
+	const int64_t vb = wide ? 8 : 4;
+	*off_bm = ((int64_t) rpad + Sm) * 64 * vb;
+	*slot_bytes = *off_bm + ((int64_t) (rpad / 32 + 1) * 4 + 255) / 256 * 256;
+}
+
+void launch_schur_group(const SchurArgs &a, unsigned char *scratch, int64_t slot_bytes, int64_t off_bm, bool wide,
+                        uint32_t *dense_out, int64_t ldS, int blocks, hipStream_t stream)
+{
+	GroupArgs d;
+	d.a = a;
+	d.scratch = scratch;
+	d.slot_bytes = slot_bytes;
+	d.off_bm = off_bm;
+	d.dense_out = dense_out;
+	d.ldS = ldS;
+	if (wide)
+		hipLaunchKernelGGL((schur_group_kernel<true>), dim3(blocks), dim3(64), 0, stream, d);
+	else
+		hipLaunchKernelGGL((schur_group_kernel<false>), dim3(blocks), dim3(64), 0, stream, d);
+	HIP_CHECK(hipGetLastError());
+}
+
+}  // namespace sh

@@ -131,3 +131,30 @@ def test_empty_row_list(oracle):
     A, npiv, perm, F = _round0(oracle, "small.sms", 257)
     S, p_out = spasm_amd.schur(_as_product(A), np.zeros(0, np.int32), _fact(F))
     assert S.n == 0 and S.nnz == 0
+
+
+@pytest.mark.parametrize("name", ["mat364.sms", "medium.sms", "trefethen_500.sms", "singular.sms", "rectangular_l.sms",
+                                  "BIOMD0000000424.int.mpl.sms", "void.sms", "empty.sms", "m1.sms", "small.sms"])
+@pytest.mark.parametrize("p", [3, 42013, 65537, 4294967291])
+def test_schur_row_group_kernel(oracle, name, p, monkeypatch):
+    """the 64-rows-per-wave kernel (label-major accumulators) gives the same matrix."""
+    monkeypatch.setenv("SPASM_HIP_GROUP", "1")
+    A, npiv, perm, F = _round0(oracle, name, p)
+    rows = perm[npiv:]
+    want, p_out_want, _ = oracle.schur(A, rows, F)
+    S, p_out = spasm_amd.schur(_as_product(A), rows, _fact(F))
+    _check(oracle, S, p_out, want, p_out_want)
+
+
+@pytest.mark.parametrize("p", [42013, 4294967291])
+def test_schur_row_group_kernel_random(oracle, p, monkeypatch):
+    monkeypatch.setenv("SPASM_HIP_GROUP", "1")
+    n, m, per_row = 3000, 2000, 3
+    rng = np.random.default_rng(99)
+    ti, tj, tx = _random_sparse(rng, n, m, per_row, p)
+    A = oracle.compress(p, n, m, ti, tj, tx)
+    npiv, perm, F = oracle.pivots_extract_structural(A, oracle.empty_fact(A.n, A.m, p))
+    rows = perm[npiv:]
+    want, p_out_want, _ = oracle.schur(A, rows, F)
+    S, p_out = spasm_amd.schur(_as_product(A), rows, _fact(F))
+    _check(oracle, S, p_out, want, p_out_want)
