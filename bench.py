@@ -198,7 +198,9 @@ def main():
         for q, v in enumerate((st.ms_tier0, st.ms_tier1, st.ms_tier2, st.ms_finalize)):
             t_tiers[q] += v
         rows_by_tier = (st.rows_lds, st.rows_lds_big, st.rows_dense)
+        group = bool(st.used_group_kernel)
         k_elim, k_stream, k_in, k_out = st.eliminations, st.entries_streamed, st.input_entries, st.nnz
+        k_gp = st.group_pivots
     torch.cuda.synchronize()
     if dist is not None:
         dist.barrier()
@@ -222,7 +224,7 @@ def main():
         traffic = None
         tfile = os.path.join(ROOT, "profiles", "traffic_r01.json")
         if os.path.exists(tfile):
-            traffic = json.load(open(tfile)).get("schur_wave_dense_kernel_bytes_per_launch")
+            traffic = json.load(open(tfile)).get("schur_group_kernel_bytes_per_launch" if group else "schur_wave_dense_kernel_bytes_per_launch")
         out = {
             "metric": "rows eliminated/sec (sparse Schur complement, mod 42013)",
             "value": total_rows / (elapsed / args.steps),
@@ -240,18 +242,20 @@ def main():
                                    "w.r.t. %d structural pivots" % (args.workload, A.n, A.m, A.nnz, PRIME,
                                                                    total_rows, F.U.n),
                        "rows_per_step": total_rows, "pivots": int(F.U.n), "levels": dF.levels,
-                       "eliminations_per_step": int(k_elim), "schur_nnz": int(k_out),
+                       "eliminations_per_step": int(k_elim), "schur_nnz": int(k_out), "group_pivots": int(k_gp),
                        "sharding": "rows over %d rank(s)%s" % (world, ", all-gatherv of S" if world > 1 else "")},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": 8000.0, "unit": "GB/s",
                          "frac": achieved / 8000.0, "traffic": traffic,
-                         "kernel": "schur_wave_dense_kernel<false>", "kernel_ms": kernel_ms,
+                         "kernel": "schur_group_kernel<false,true>" if group else "schur_wave_dense_kernel<false>",
+                         "kernel_ms": kernel_ms,
                          "algorithmic_bytes": int(algo),
                          "ms_by_kernel": {"schur_lds_kernel<1024>": t_tiers[0] / args.steps,
                                           "schur_lds_kernel<8192>": t_tiers[1] / args.steps,
-                                          "schur_wave_dense_kernel": t_tiers[2] / args.steps,
+                                          ("schur_group_kernel" if group else "schur_wave_dense_kernel"): t_tiers[2] / args.steps,
                                           "scan+gather_rows": t_tiers[3] / args.steps},
                          "rows_by_kernel": {"lds_small": rows_by_tier[0], "lds_big": rows_by_tier[1],
-                                            "wave_dense": rows_by_tier[2]}},
+                                            ("row_group" if group else "wave_dense"): rows_by_tier[2]},
+                         "lane_efficiency": (k_elim / (64.0 * k_gp)) if (group and k_gp) else None},
         }
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(A, rows, F)

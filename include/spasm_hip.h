@@ -215,11 +215,13 @@ typedef struct {
 	i64 eliminations;       /* pivot rows applied (sum over rows) */
 	i64 entries_streamed;   /* entries of U' read by those eliminations */
 	i64 input_entries;      /* entries of the reduced rows of A */
+	i64 group_pivots;       /* row-group kernel: (group, pivot) pairs applied; eliminations / (64 * this) = lane efficiency */
 	int rows;               /* rows reduced */
 	int rows_lds;           /* rows finished by the LDS hash kernel, small table */
 	int rows_lds_big;       /* ... by the large-table variant */
 	int rows_dense;         /* rows finished by the dense-accumulator kernel */
 	int status;             /* 0 = ok, 1 = pool too small (call again with a larger pool) */
+	int used_group_kernel;  /* 1: all rows went through the row-group kernel (rows_dense counts them) */
 	float ms_eliminate;     /* device time of the elimination kernels, all tiers (HIP events on the call's stream) */
 	float ms_tier0;         /* ... small-table LDS kernel (schur_lds_kernel<1024>) */
 	float ms_tier1;         /* ... large-table LDS kernel (0 when skipped) */

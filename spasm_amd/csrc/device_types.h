@@ -40,6 +40,7 @@ enum Ctr64 {
 	C64_ELIM,              // pivot rows applied
 	C64_STREAM,            // entries of U' streamed
 	C64_INPUT,             // entries of input rows
+	C64_WAVEPIV,           // row-group kernel: pivots applied per group (wave-level count)
 	C64_COUNT = 8
 };
 

@@ -409,8 +409,12 @@ int spasm_hip_dschur(const spasm_hip_dcsr *A, const int *d_rows, int nrows, cons
 	const int force_tier = env_int("SPASM_HIP_FORCE_TIER", 0);
 	const bool use_big = (force_tier == 1) || env_int("SPASM_HIP_USE_BIG_TABLE", 0);
 
-	// 1 = row-group kernel (64 consecutive rows per wave, label-major state) for every row
-	const int group_mode = env_int("SPASM_HIP_GROUP", 0);
+	// row-group kernel (64 consecutive rows per wave, label-major state) for every row: default for
+	// batches large enough to fill the GPU with groups; SPASM_HIP_GROUP=0/1 forces the choice.
+	// Small batches (density samples, dense blocks) stay on the per-row tiers.
+	int group_mode = env_int("SPASM_HIP_GROUP", -1);
+	if (group_mode < 0)
+		group_mode = (nrows >= 64 * 32 && force_tier == 0) ? 1 : 0;
 	int group_slots = 0;
 	i64 group_slot_bytes = 0, group_off_bm = 0;
 	// per-wave dense scratch, (re)allocated when the factor geometry needs more
@@ -418,7 +422,13 @@ int spasm_hip_dschur(const spasm_hip_dcsr *A, const int *d_rows, int nrows, cons
 		i64 slot_bytes, off_bm, off_xn;
 		wave_dense_geometry(F->rpad, F->Sm, wide_dense, &slot_bytes, &off_bm, &off_xn);
 		int slots = env_int("SPASM_HIP_WAVE_SLOTS", cus * 32);
-		const i64 budget = (i64) env_int("SPASM_HIP_SCRATCH_GB", 48) << 30;
+		// accumulator slices may take up to half of the free HBM (288 GB parts: be generous), or what
+		// SPASM_HIP_SCRATCH_GB says
+		size_t free_b = 0, total_b = 0;
+		HIP_CHECK(hipMemGetInfo(&free_b, &total_b));
+		i64 budget = (i64) ((free_b + (size_t) W->scratch_bytes) / 2);
+		if (env_int("SPASM_HIP_SCRATCH_GB", 0) > 0)
+			budget = (i64) env_int("SPASM_HIP_SCRATCH_GB", 0) << 30;
 		slots = (int) std::max<i64>(cus, std::min<i64>(slots, budget / slot_bytes));
 		slots = std::max(1, std::min(slots, nrows));
 		i64 need = slot_bytes * slots;
@@ -540,6 +550,8 @@ eliminated:
 		stats->eliminations = (i64) ctr64[C64_ELIM];
 		stats->entries_streamed = (i64) ctr64[C64_STREAM];
 		stats->input_entries = (i64) ctr64[C64_INPUT];
+		stats->group_pivots = (i64) ctr64[C64_WAVEPIV];
+		stats->used_group_kernel = group_mode ? 1 : 0;
 		stats->rows = nrows;
 		stats->rows_lds = ctr[CTR_DONE0];
 		stats->rows_lds_big = ctr[CTR_DONE1];

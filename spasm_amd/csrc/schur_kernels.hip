@@ -924,8 +924,9 @@ void launch_schur_wave_dense(const SchurArgs &a, unsigned char *scratch, int64_t
 namespace sh {
 
 namespace {
-constexpr int GR_ACT = 2048;
-constexpr int GR_PB = 4;            // pivots whose loads are issued together
+constexpr int GR_ACT = 512;             // pending labels gathered per pass (GR_ACT / 32 bitmap words)
+constexpr int GR_LBM_MAX_BYTES = 48 * 1024;   // largest pending bitmap kept in LDS
+constexpr int GR_PB = 8;            // pivots whose loads are issued together
 }
 
 struct GroupArgs {
@@ -937,10 +938,12 @@ struct GroupArgs {
 	int64_t ldS;
 };
 
-template <bool WIDE>
+// LBM: the pending bitmap of the group lives in LDS (rpad / 8 bytes, dynamic) instead of HBM.
+template <bool WIDE, bool LBM>
 __global__ __launch_bounds__(64) void schur_group_kernel(GroupArgs d)
 {
 	using V = typename Acc<WIDE>::type;
+	extern __shared__ __attribute__((aligned(16))) unsigned char lds_dyn[];
 	__shared__ uint32_t act[GR_ACT];
 	const SchurArgs &a = d.a;
 	const int lane = threadIdx.x;
@@ -952,9 +955,27 @@ __global__ __launch_bounds__(64) void schur_group_kernel(GroupArgs d)
 
 	unsigned char *slot = d.scratch + (int64_t) blockIdx.x * d.slot_bytes;
 	V *X = reinterpret_cast<V *>(slot);                 // X[label * 64 + lane]
-	uint32_t *bm = reinterpret_cast<uint32_t *>(slot + d.off_bm);
+	uint32_t *bm = LBM ? reinterpret_cast<uint32_t *>(lds_dyn) : reinterpret_cast<uint32_t *>(slot + d.off_bm);
+	if (LBM) {
+		for (int w = lane; w < nw; w += 64)
+			bm[w] = 0;
+		__builtin_amdgcn_wave_barrier();
+	}
+	auto bm_load = [&](int w) -> uint32_t { return LBM ? ((volatile uint32_t *) bm)[w] : ld_sc1(&bm[w]); };
+	auto bm_or = [&](uint32_t c) {
+		if (LBM)
+			atomicOr(&bm[c >> 5], 1u << (c & 31));
+		else
+			(void) __hip_atomic_fetch_or(&bm[c >> 5], 1u << (c & 31), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+	};
+	auto bm_clear = [&](int w, uint32_t bits) {
+		if (LBM)
+			atomicAnd(&bm[w], ~bits);
+		else
+			(void) __hip_atomic_fetch_and(&bm[w], ~bits, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+	};
 
-	unsigned long long st_elim = 0, st_stream = 0, st_input = 0;
+	unsigned long long st_elim = 0, st_stream = 0, st_input = 0, st_wavepiv = 0;
 	int st_done = 0;
 
 	for (;;) {
@@ -977,7 +998,7 @@ __global__ __launch_bounds__(64) void schur_group_kernel(GroupArgs d)
 				const uint32_t v = reduce_sum(from_balanced(a.Ax[px], F), F);
 				add_ff(&X[(int64_t) c * 64 + lane], v);
 				if (c < r)
-					(void) __hip_atomic_fetch_or(&bm[c >> 5], 1u << (c & 31), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+					bm_or(c);
 			}
 		}
 
@@ -985,15 +1006,15 @@ __global__ __launch_bounds__(64) void schur_group_kernel(GroupArgs d)
 		uint32_t cursor = 0;
 		for (;;) {
 			drain_vmem();
+			__builtin_amdgcn_wave_barrier();
 			int wi = -1;
-			uint32_t fbits = 0, lwe = 0;
+			uint32_t fbits = 0;
 			const int wstart = (int) (cursor >> 5);
 			for (int base = wstart; base < nw; base += 64) {
 				const int w = base + lane;
-				uint32_t bits = 0, lw = 0;
+				uint32_t bits = 0;
 				if (w < nw) {
-					bits = ld_sc1(&bm[w]);
-					lw = a.lvl_end_w[w];
+					bits = bm_load(w);
 					if (w == wstart)
 						bits &= ~((1u << (cursor & 31)) - 1u);
 				}
@@ -1002,28 +1023,28 @@ __global__ __launch_bounds__(64) void schur_group_kernel(GroupArgs d)
 					const int fl = __builtin_ctzll(mask);
 					wi = base + fl;
 					fbits = (uint32_t) __shfl((int) bits, fl);
-					lwe = (uint32_t) __shfl((int) lw, fl);
 					break;
 				}
 			}
 			if (wi < 0)
 				break;
 			const uint32_t c0 = (uint32_t) wi * 32 + (uint32_t) __builtin_ctz(fbits);
+			const uint32_t lwe = a.lvl_end_w[wi];
 			const uint32_t lend = (lwe != MIXED) ? lwe * 32 : a.lvl_end[c0];
 			const int wl = (int) ((lend + 31) >> 5);
 
-			for (int wb = wi; wb < wl; wb += 64) {
+			for (int wb = wi; wb < wl; wb += GR_ACT / 32) {
 				// pending labels of this chunk of the level -> act[]
 				const int w = wb + lane;
 				uint32_t bits = 0;
-				if (w < wl) {
-					bits = ld_sc1(&bm[w]);
+				if (w < wl && lane < GR_ACT / 32) {
+					bits = bm_load(w);
 					if (w == wi)
 						bits &= ~((1u << (c0 & 31)) - 1u);
 					if ((uint32_t) w * 32 + 32 > lend)
 						bits &= (1u << (lend & 31)) - 1u;
 					if (bits != 0)
-						(void) __hip_atomic_fetch_and(&bm[w], ~bits, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+						bm_clear(w, bits);
 				}
 				int tot;
 				int pos = wave_exclusive_scan(__popc(bits), lane, tot);
@@ -1036,26 +1057,40 @@ __global__ __launch_bounds__(64) void schur_group_kernel(GroupArgs d)
 				__builtin_amdgcn_wave_barrier();
 				__builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
 
-				// apply them: uniform loop, GR_PB pivots per trip so that their loads overlap
-				for (int t0 = 0; t0 < tot; t0 += GR_PB) {
-					uint32_t cc[GR_PB];
-					V raw[GR_PB];
-					uint64_t start[GR_PB];
-					int len[GR_PB];
+				// apply them: uniform loop, GR_PB pivots per trip; the loads of trip t+1 (accumulator lines and
+				// row extents) are issued before the entries of trip t are streamed
+				uint32_t cc[GR_PB], ncc[GR_PB];
+				V raw[GR_PB], nraw[GR_PB];
+				uint64_t start[GR_PB], nstart[GR_PB];
+				int len[GR_PB], nlen[GR_PB];
+				auto fetch = [&](int t0, uint32_t *C, V *R, uint64_t *S, int *L) {
 #pragma unroll
 					for (int u = 0; u < GR_PB; u++) {
 						const int t = t0 + u;
-						cc[u] = (t < tot) ? ((volatile uint32_t *) act)[t] : 0xFFFFFFFFu;
-						cc[u] = __builtin_amdgcn_readfirstlane(cc[u]);
-						raw[u] = 0;
-						start[u] = 0;
-						len[u] = 0;
-						if (cc[u] != 0xFFFFFFFFu) {
-							raw[u] = ld_sc1(&X[(int64_t) cc[u] * 64 + lane]);
-							start[u] = a.rp[cc[u]];
-							len[u] = (int) (a.rp[cc[u] + 1] - start[u]);
+						uint32_t c = (t < tot) ? ((volatile uint32_t *) act)[t] : 0xFFFFFFFFu;
+						c = __builtin_amdgcn_readfirstlane(c);
+						C[u] = c;
+						R[u] = 0;
+						S[u] = 0;
+						L[u] = 0;
+						if (c != 0xFFFFFFFFu) {
+							R[u] = ld_sc1(&X[(int64_t) c * 64 + lane]);
+							S[u] = a.rp[c];
+							L[u] = (int) (a.rp[c + 1] - S[u]);
 						}
 					}
+				};
+				fetch(0, ncc, nraw, nstart, nlen);
+				for (int t0 = 0; t0 < tot; t0 += GR_PB) {
+#pragma unroll
+					for (int u = 0; u < GR_PB; u++) {
+						cc[u] = ncc[u];
+						raw[u] = nraw[u];
+						start[u] = nstart[u];
+						len[u] = nlen[u];
+					}
+					if (t0 + GR_PB < tot)
+						fetch(t0 + GR_PB, ncc, nraw, nstart, nlen);
 #pragma unroll
 					for (int u = 0; u < GR_PB; u++) {
 						if (cc[u] == 0xFFFFFFFFu)
@@ -1068,6 +1103,7 @@ __global__ __launch_bounds__(64) void schur_group_kernel(GroupArgs d)
 						if (active == 0)
 							continue;
 						const int nact = __popcll(active);
+						st_wavepiv += 1;
 						st_elim += (unsigned long long) nact;
 						st_stream += (unsigned long long) nact * (unsigned long long) len[u];
 						const uint32_t w_neg = F.p - v;
@@ -1086,8 +1122,7 @@ __global__ __launch_bounds__(64) void schur_group_kernel(GroupArgs d)
 								if (v != 0)
 									add_ff(&X[(int64_t) tgt * 64 + lane], montmul(w_neg, ent[q].y, F));
 								if (tgt < r && lane == 0)
-									(void) __hip_atomic_fetch_or(&bm[tgt >> 5], 1u << (tgt & 31), __ATOMIC_RELAXED,
-									                             __HIP_MEMORY_SCOPE_WAVEFRONT);
+									bm_or(tgt);
 							}
 						}
 					}
@@ -1101,12 +1136,21 @@ __global__ __launch_bounds__(64) void schur_group_kernel(GroupArgs d)
 		// ---- output: lane = row, the non-pivotal labels in order are the sorted row ----
 		V *Xn = X + (int64_t) r * 64;
 		if (d.dense_out != nullptr) {
-			for (int t = 0; t < Sm; t++) {
-				const V rawv = ld_sc1(&Xn[(int64_t) t * 64 + lane]);
-				if (have_row)
-					d.dense_out[(int64_t) k * d.ldS + t] = reduce_sum(rawv, F);
-				if (rawv != 0)
-					__hip_atomic_store(&Xn[(int64_t) t * 64 + lane], (V) 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+			for (int t0 = 0; t0 < Sm; t0 += 16) {
+				V rv[16];
+#pragma unroll
+				for (int u = 0; u < 16; u++)
+					rv[u] = (t0 + u < Sm) ? ld_sc1(&Xn[(int64_t) (t0 + u) * 64 + lane]) : (V) 0;
+#pragma unroll
+				for (int u = 0; u < 16; u++) {
+					if (t0 + u >= Sm)
+						continue;
+					if (have_row)
+						d.dense_out[(int64_t) k * d.ldS + t0 + u] = reduce_sum(rv[u], F);
+					if (rv[u] != 0)
+						__hip_atomic_store(&Xn[(int64_t) (t0 + u) * 64 + lane], (V) 0, __ATOMIC_RELAXED,
+						                   __HIP_MEMORY_SCOPE_WAVEFRONT);
+				}
 			}
 			if (have_row)
 				a.row_len[k] = Sm;
@@ -1114,13 +1158,13 @@ __global__ __launch_bounds__(64) void schur_group_kernel(GroupArgs d)
 			continue;
 		}
 		int count = 0;
-		for (int t0 = 0; t0 < Sm; t0 += 8) {
-			V rv[8];
+		for (int t0 = 0; t0 < Sm; t0 += 32) {
+			V rv[32];
 #pragma unroll
-			for (int u = 0; u < 8; u++)
+			for (int u = 0; u < 32; u++)
 				rv[u] = (t0 + u < Sm) ? ld_sc1(&Xn[(int64_t) (t0 + u) * 64 + lane]) : (V) 0;
 #pragma unroll
-			for (int u = 0; u < 8; u++)
+			for (int u = 0; u < 32; u++)
 				count += (rv[u] != 0 && reduce_sum(rv[u], F) != 0) ? 1 : 0;
 		}
 		int gtot;
@@ -1133,13 +1177,13 @@ __global__ __launch_bounds__(64) void schur_group_kernel(GroupArgs d)
 		const int64_t base_off = (int64_t) (((uint64_t) g_hi << 32) | g_lo);
 		const bool fits = base_off + gtot <= a.pool_cap;
 		int64_t wpos = base_off + excl;
-		for (int t0 = 0; t0 < Sm; t0 += 8) {
-			V rv[8];
+		for (int t0 = 0; t0 < Sm; t0 += 32) {
+			V rv[32];
 #pragma unroll
-			for (int u = 0; u < 8; u++)
+			for (int u = 0; u < 32; u++)
 				rv[u] = (t0 + u < Sm) ? ld_sc1(&Xn[(int64_t) (t0 + u) * 64 + lane]) : (V) 0;
 #pragma unroll
-			for (int u = 0; u < 8; u++) {
+			for (int u = 0; u < 32; u++) {
 				if (rv[u] == 0)
 					continue;
 				__hip_atomic_store(&Xn[(int64_t) (t0 + u) * 64 + lane], (V) 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
@@ -1174,6 +1218,7 @@ __global__ __launch_bounds__(64) void schur_group_kernel(GroupArgs d)
 		atomicAdd(&a.ctr64[C64_ELIM], st_elim);
 		atomicAdd(&a.ctr64[C64_STREAM], st_stream);
 		atomicAdd(&a.ctr64[C64_INPUT], st_input);
+		atomicAdd(&a.ctr64[C64_WAVEPIV], st_wavepiv);
 		atomicAdd(&a.ctr[a.done_ctr], st_done);
 	}
 }
@@ -1195,10 +1240,26 @@ void launch_schur_group(const SchurArgs &a, unsigned char *scratch, int64_t slot
 	d.off_bm = off_bm;
 	d.dense_out = dense_out;
 	d.ldS = ldS;
-	if (wide)
-		hipLaunchKernelGGL((schur_group_kernel<true>), dim3(blocks), dim3(64), 0, stream, d);
-	else
-		hipLaunchKernelGGL((schur_group_kernel<false>), dim3(blocks), dim3(64), 0, stream, d);
+	const size_t bm_bytes = ((size_t) a.r / 32 + 1) * 4;
+	const bool lbm = bm_bytes <= (size_t) GR_LBM_MAX_BYTES;
+	if (lbm) {
+		static bool configured = false;
+		if (!configured) {
+			HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(&schur_group_kernel<true, true>),
+			                              hipFuncAttributeMaxDynamicSharedMemorySize, GR_LBM_MAX_BYTES));
+			HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(&schur_group_kernel<false, true>),
+			                              hipFuncAttributeMaxDynamicSharedMemorySize, GR_LBM_MAX_BYTES));
+			configured = true;
+		}
+		if (wide)
+			hipLaunchKernelGGL((schur_group_kernel<true, true>), dim3(blocks), dim3(64), bm_bytes, stream, d);
+		else
+			hipLaunchKernelGGL((schur_group_kernel<false, true>), dim3(blocks), dim3(64), bm_bytes, stream, d);
+	} else if (wide) {
+		hipLaunchKernelGGL((schur_group_kernel<true, false>), dim3(blocks), dim3(64), 0, stream, d);
+	} else {
+		hipLaunchKernelGGL((schur_group_kernel<false, false>), dim3(blocks), dim3(64), 0, stream, d);
+	}
 	HIP_CHECK(hipGetLastError());
 }
 

@@ -8,7 +8,7 @@ OUT=gpurun_out/prof_$TAG
 mkdir -p $OUT
 cd "$(dirname "$0")/.." || exit 1
 export TMPDIR=/tmp
-ARGS="bench.py --steps 3 --warmup 1 --no-cpu-baseline"
+ARGS="${BENCH_ARGS:-bench.py --steps 3 --warmup 1 --no-cpu-baseline}"
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -- python3 $ARGS > $OUT/bench_trace.json 2> $OUT/trace.log
 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $OUT/pmc_fetch -- python3 $ARGS > /dev/null 2> $OUT/pmc_fetch.log
 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $OUT/pmc_write -- python3 $ARGS > /dev/null 2> $OUT/pmc_write.log
