@@ -8,6 +8,12 @@
 namespace sh {
 int device_rref(int64_t prime, int n, int m, uint32_t *dA, int64_t ld, int *d_pivcol, hipStream_t stream, int use_mfma,
                 float *ms_update);
+void launch_combine(const int64_t *Ap, const int *Aj, const int *Ax, const int *rows, int nrows, int N, int w, int m,
+                    uint64_t salt, unsigned long long *Y, const Mont &M, hipStream_t stream);
+void launch_dense_count(const unsigned long long *Y, int N, int m, uint32_t p, int *row_len, hipStream_t stream);
+void launch_dense_pack(const unsigned long long *Y, int N, int m, uint32_t p, const int64_t *Sp, int *Sj, int *Sx,
+                       hipStream_t stream);
+void launch_row_scan(const int *row_len, int n, int64_t *blocksum, int64_t *Sp, hipStream_t stream);
 void wave_dense_geometry(int rpad, int Sm, bool wide, int64_t *slot_bytes, int64_t *off_bm, int64_t *off_xn);
 void launch_schur_wave_dense(const SchurArgs &a, unsigned char *scratch, int64_t slot_bytes, int64_t off_bm, int64_t off_xn,
                              bool wide, uint32_t *dense_out, int64_t ldS, int blocks, hipStream_t stream);
@@ -172,6 +178,89 @@ void spasm_hip_schur_dense(const struct spasm_csr *A, const int *p, int n, const
 	}
 	spasm_hip_dfact_destroy(F);
 	logmsg("[schur/dense/hip] %d x %d dense rows in %.1fs\n", n, Sm, wtime() - t0);
+}
+
+// replaces spasm_schur_dense_randomized (spasm_schur.c:357-425): N random combinations of the rows
+// p[0..n) of A (w > 0: of w random rows each, first coefficient 1; w <= 0: of all the rows), reduced
+// by U, as dense rows on the non-pivotal columns.  Everything runs on the device.
+void spasm_hip_schur_dense_randomized(const struct spasm_csr *A, const int *p, int n, const struct spasm_csr *U,
+                                      const int *qinv, void *S, spasm_datatype datatype, int *q, int N, int w)
+{
+	if (spasm_hip_device_count() == 0)
+		die("spasm_hip_schur_dense_randomized: no HIP device (this library has no CPU path)");
+	if (p == nullptr || n <= 0)
+		die("spasm_hip_schur_dense_randomized: empty row list");
+	static uint64_t call_id = 0;       // every call draws fresh combinations
+	call_id += 1;
+	const int m = A->m;
+	const i64 prime = A->field->p;
+	const double t0 = wtime();
+	hipStream_t stream = nullptr;
+	spasm_hip_dfact *F = spasm_hip_dfact_create(U, qinv, stream);
+	const int Sm = F->Sm;
+	for (int l = 0; l < Sm; l++)
+		q[l] = F->h_q[l];
+	if (N > 0 && Sm > 0) {
+		const i64 annz = A->p[A->n];
+		i64 *dAp = dalloc<i64>((i64) A->n + 1);
+		int *dAj = dalloc<int>(annz);
+		int *dAx = dalloc<int>(annz);
+		int *drows = dalloc<int>(n);
+		HIP_CHECK(hipMemcpy(dAp, A->p, ((size_t) A->n + 1) * sizeof(i64), hipMemcpyHostToDevice));
+		if (annz > 0) {
+			HIP_CHECK(hipMemcpy(dAj, A->j, (size_t) annz * sizeof(int), hipMemcpyHostToDevice));
+			HIP_CHECK(hipMemcpy(dAx, A->x, (size_t) annz * sizeof(int), hipMemcpyHostToDevice));
+		}
+		HIP_CHECK(hipMemcpy(drows, p, (size_t) n * sizeof(int), hipMemcpyHostToDevice));
+		// Y = C * A[p, :], dense 64-bit accumulators, then CSR
+		unsigned long long *dY = dalloc<unsigned long long>((i64) N * m);
+		HIP_CHECK(hipMemsetAsync(dY, 0, (size_t) N * m * sizeof(unsigned long long), stream));
+		launch_combine(dAp, dAj, dAx, drows, n, N, w, m, call_id * 0x9E3779B97F4A7C15ULL, dY, F->mont, stream);
+		spasm_hip_dwork *W = spasm_hip_dwork_create(N, m, 64);
+		launch_dense_count(dY, N, m, (uint32_t) prime, W->d_row_len, stream);
+		launch_row_scan(W->d_row_len, N, W->d_blocksum, W->d_Sp, stream);
+		i64 ynnz = 0;
+		HIP_CHECK(hipMemcpyAsync(&ynnz, W->d_Sp + N, sizeof(i64), hipMemcpyDeviceToHost, stream));
+		HIP_CHECK(hipStreamSynchronize(stream));
+		int *dYj = dalloc<int>(ynnz);
+		int *dYx = dalloc<int>(ynnz);
+		launch_dense_pack(dY, N, m, (uint32_t) prime, W->d_Sp, dYj, dYx, stream);
+		i64 *dYp = dalloc<i64>((i64) N + 1);
+		HIP_CHECK(hipMemcpyAsync(dYp, W->d_Sp, ((size_t) N + 1) * sizeof(i64), hipMemcpyDeviceToDevice, stream));
+		std::vector<int> ident((size_t) N);
+		for (int k = 0; k < N; k++)
+			ident[k] = k;
+		int *dident = dalloc<int>(N);
+		HIP_CHECK(hipMemcpyAsync(dident, ident.data(), (size_t) N * sizeof(int), hipMemcpyHostToDevice, stream));
+		HIP_CHECK(hipStreamSynchronize(stream));
+		(void) hipFree(dY);
+		spasm_hip_dcsr dYcsr{N, m, ynnz, dYp, dYj, dYx};
+		u32 *dS = dalloc<u32>((i64) N * Sm);
+		spasm_hip_dschur_dense(&dYcsr, dident, N, F, W, dS, Sm, stream);
+		std::vector<u32> h((size_t) N * Sm);
+		HIP_CHECK(hipMemcpy(h.data(), dS, (size_t) N * Sm * sizeof(u32), hipMemcpyDeviceToHost));
+		const u32 half = (u32) (prime / 2);
+		for (i64 t = 0; t < (i64) N * Sm; t++) {
+			const i64 v = (h[t] > half) ? (i64) h[t] - prime : (i64) h[t];
+			switch (datatype) {
+			case SPASM_DOUBLE: ((double *) S)[t] = (double) v; break;
+			case SPASM_FLOAT: ((float *) S)[t] = (float) v; break;
+			case SPASM_I64: ((i64 *) S)[t] = v; break;
+			}
+		}
+		(void) hipFree(dS);
+		(void) hipFree(dident);
+		(void) hipFree(dYp);
+		(void) hipFree(dYj);
+		(void) hipFree(dYx);
+		spasm_hip_dwork_destroy(W);
+		(void) hipFree(dAp);
+		(void) hipFree(dAj);
+		(void) hipFree(dAx);
+		(void) hipFree(drows);
+	}
+	spasm_hip_dfact_destroy(F);
+	logmsg("[schur/dense/random/hip] %d combinations (weight %d) of %d rows, %d columns, %.1fs\n", N, w, n, Sm, wtime() - t0);
 }
 
 // Same contract as the reference wrapper (spasm_ffpack.cpp:23-49 as consumed by

@@ -431,3 +431,141 @@ int device_rref(int64_t prime, int n, int m, uint32_t *dA, int64_t ld, int *d_pi
 }
 
 }  // namespace sh
+
+// --------------------------------------------------------------------------
+// Random linear combinations of sparse rows, formed on the device (the first
+// half of spasm_schur_dense_randomized, spasm_schur.c:380-400): Y[k, :] =
+// sum_t c(k,t) A[rows(k,t), :] into a dense 64-bit accumulator, then packed
+// to CSR so that the dense-row elimination kernel can take it as input.
+// Coefficients come from a counter-based generator (splitmix64 of (salt, k,
+// t)); the reference's own stream depends on rand() and thread timing.
+// --------------------------------------------------------------------------
+namespace sh {
+
+namespace {
+
+__device__ __forceinline__ uint64_t mix64(uint64_t z)
+{
+	z += 0x9E3779B97F4A7C15ULL;
+	z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ULL;
+	z = (z ^ (z >> 27)) * 0x94D049BB133111EBULL;
+	return z ^ (z >> 31);
+}
+
+__device__ __forceinline__ uint32_t uniform_below(uint64_t h, uint32_t bound)
+{
+	return (uint32_t) (((h >> 32) * (uint64_t) bound) >> 32);
+}
+
+}  // namespace
+
+// one wave per (combination k, term t).  w > 0: term t picks a random row of the list (coefficient 1
+// for t = 0); w == 0: term t is row t of the list, every row taken, random coefficient.
+__global__ __launch_bounds__(64) void combine_rows_kernel(const int64_t *Ap, const int *Aj, const int *Ax, const int *rows,
+                                                         int nrows, int N, int w, int m, uint64_t salt,
+                                                         unsigned long long *Y, MontDev F)
+{
+	const int lane = threadIdx.x;
+	const int64_t terms = (w > 0) ? (int64_t) w : (int64_t) nrows;
+	const int64_t total = (int64_t) N * terms;
+	for (int64_t task = blockIdx.x; task < total; task += gridDim.x) {
+		const int k = (int) (task / terms);
+		const int64_t t = task % terms;
+		const uint64_t h = mix64(salt ^ mix64(((uint64_t) k << 32) ^ (uint64_t) t));
+		int i;
+		uint32_t coeff;
+		if (w > 0) {
+			i = rows[uniform_below(mix64(h ^ 0x51ED270B1ULL), (uint32_t) nrows)];
+			coeff = (t == 0) ? 1u : uniform_below(h, F.p);
+		} else {
+			i = rows[t];
+			coeff = uniform_below(h, F.p);
+		}
+		if (coeff == 0)
+			continue;
+		const uint32_t cm = mont_mul(coeff, F.r2, F);          // coefficient in Montgomery form
+		unsigned long long *Yk = Y + (int64_t) k * m;
+		for (int64_t px = Ap[i] + lane; px < Ap[i + 1]; px += 64) {
+			const int a = Ax[px];
+			const uint32_t v = (a < 0) ? (uint32_t) a + F.p : (uint32_t) a;
+			atomicAdd(&Yk[Aj[px]], (unsigned long long) mont_mul(cm, v % F.p, F));
+		}
+	}
+}
+
+// per row of the dense accumulator: number of entries that are non-zero mod p
+__global__ __launch_bounds__(256) void dense_count_kernel(const unsigned long long *Y, int N, int m, uint32_t p, int *row_len)
+{
+	__shared__ int part[256];
+	const int k = blockIdx.x;
+	int c = 0;
+	for (int j = threadIdx.x; j < m; j += 256)
+		c += (Y[(int64_t) k * m + j] % p) != 0;
+	part[threadIdx.x] = c;
+	__syncthreads();
+	for (int d = 128; d > 0; d >>= 1) {
+		if ((int) threadIdx.x < d)
+			part[threadIdx.x] += part[threadIdx.x + d];
+		__syncthreads();
+	}
+	if (threadIdx.x == 0)
+		row_len[k] = part[0];
+}
+
+// pack row k (sorted by column); one workgroup per row
+__global__ __launch_bounds__(256) void dense_pack_kernel(const unsigned long long *Y, int N, int m, uint32_t p,
+                                                        const int64_t *Sp, int *Sj, int *Sx)
+{
+	__shared__ int wave_tot[4];
+	const int k = blockIdx.x;
+	const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+	int64_t wpos = Sp[k];
+	for (int base = 0; base < m; base += 256) {
+		const int j = base + threadIdx.x;
+		const uint32_t v = (j < m) ? (uint32_t) (Y[(int64_t) k * m + j] % p) : 0u;
+		const bool keep = v != 0;
+		const uint64_t mk = __ballot(keep);
+		if (lane == 0)
+			wave_tot[wave] = __popcll(mk);
+		__syncthreads();
+		int before = 0, all = 0;
+		for (int wv = 0; wv < 4; wv++) {
+			if (wv < wave)
+				before += wave_tot[wv];
+			all += wave_tot[wv];
+		}
+		if (keep) {
+			const int64_t dst = wpos + before + __popcll(mk & ((1ull << lane) - 1ull));
+			Sj[dst] = j;
+			Sx[dst] = (int) v;      // in [0, p): the elimination kernels accept either representative
+		}
+		wpos += all;
+		__syncthreads();
+	}
+}
+
+void launch_combine(const int64_t *Ap, const int *Aj, const int *Ax, const int *rows, int nrows, int N, int w, int m,
+                    uint64_t salt, unsigned long long *Y, const Mont &M, hipStream_t stream)
+{
+	const int64_t terms = (w > 0) ? (int64_t) w : (int64_t) nrows;
+	const int64_t total = (int64_t) N * terms;
+	const int blocks = (int) (total < 65536 ? (total > 0 ? total : 1) : 65536);
+	hipLaunchKernelGGL(combine_rows_kernel, dim3(blocks), dim3(64), 0, stream, Ap, Aj, Ax, rows, nrows, N, w, m, salt, Y,
+	                   to_dev(M));
+	HIP_CHECK(hipGetLastError());
+}
+
+void launch_dense_count(const unsigned long long *Y, int N, int m, uint32_t p, int *row_len, hipStream_t stream)
+{
+	hipLaunchKernelGGL(dense_count_kernel, dim3(N), dim3(256), 0, stream, Y, N, m, p, row_len);
+	HIP_CHECK(hipGetLastError());
+}
+
+void launch_dense_pack(const unsigned long long *Y, int N, int m, uint32_t p, const int64_t *Sp, int *Sj, int *Sx,
+                       hipStream_t stream)
+{
+	hipLaunchKernelGGL(dense_pack_kernel, dim3(N), dim3(256), 0, stream, Y, N, m, p, Sp, Sj, Sx);
+	HIP_CHECK(hipGetLastError());
+}
+
+}  // namespace sh

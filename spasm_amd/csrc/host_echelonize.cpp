@@ -123,76 +123,6 @@ double spasm_hip_schur_estimate_density(const struct spasm_csr *A, const int *p,
 	return (Sm > 0) ? ((double) nnz) / Sm / R : 0.0;
 }
 
-// replaces spasm_schur_dense_randomized (spasm_schur.c:357-425).  The N random combinations are
-// formed on the host (sparse rows, cheap: N * w * row weight), their reduction by U and the dense
-// output are the GPU dense-row kernel.
-void spasm_hip_schur_dense_randomized(const struct spasm_csr *A, const int *p, int n, const struct spasm_csr *U,
-                                      const int *qinv, void *S, spasm_datatype datatype, int *q, int N, int w)
-{
-	if (p == nullptr || n <= 0)
-		die("spasm_hip_schur_dense_randomized: empty row list");
-	const int m = A->m;
-	const i64 prime = A->field->p;
-	// Y = C * A[p, :]  with C random, N x n
-	struct spasm_triplet *T = spasm_hip_triplet_alloc(N, m, (i64) N * 16, prime, true);
-	std::vector<spasm_ZZp> y((size_t) m, 0);
-	std::vector<int> touched;
-	std::vector<char> mark((size_t) m, 0);
-	// every call draws fresh combinations (the reference reseeds with k alone and relies on rand() for
-	// the row choice; a per-call salt keeps the stream deterministic and never repeats a combination)
-	static uint64_t call_id = 0;
-	call_id += 1;
-	uint64_t state = 0xD1B54A32D192ED03ULL ^ (call_id * 0x9E3779B97F4A7C15ULL);
-	for (int k = 0; k < N; k++) {
-		Prng g;
-		g.seed(prime, (call_id << 32) | (uint64_t) k, 0);
-		touched.clear();
-		auto axpy_row = [&](int row, spasm_ZZp coeff) {
-			for (i64 px = A->p[row]; px < A->p[row + 1]; px++) {
-				const int j = A->j[px];
-				if (!mark[j]) {
-					mark[j] = 1;
-					touched.push_back(j);
-				}
-				y[j] = zp_axpy(prime, coeff, A->x[px], y[j]);
-			}
-		};
-		if (w <= 0) {
-			for (int i = 0; i < n; i++)
-				axpy_row(p[i], g.next_zp());
-		} else {
-			for (int i = 0; i < w; i++) {
-				state = state * 6364136223846793005ULL + 1442695040888963407ULL;
-				const int row = p[(state >> 33) % (uint64_t) n];
-				axpy_row(row, (i == 0) ? 1 : g.next_zp());
-			}
-		}
-		for (int j : touched) {
-			if (y[j] != 0)
-				spasm_hip_add_entry(T, k, j, y[j]);
-			y[j] = 0;
-			mark[j] = 0;
-		}
-	}
-	T->n = N;
-	T->m = m;
-	struct spasm_csr *Y = spasm_hip_compress(T);
-	spasm_hip_triplet_free(T);
-	std::vector<int> rows((size_t) N), dummy((size_t) N);
-	for (int k = 0; k < N; k++)
-		rows[k] = k;
-	struct spasm_lu tmp;
-	tmp.r = U->n;
-	tmp.complete = false;
-	tmp.L = nullptr;
-	tmp.U = (struct spasm_csr *) U;
-	tmp.qinv = (int *) qinv;
-	tmp.p = nullptr;
-	tmp.Ltmp = nullptr;
-	spasm_hip_schur_dense(Y, rows.data(), N, nullptr, &tmp, S, datatype, q, dummy.data());
-	spasm_hip_csr_free(Y);
-}
-
 }  // extern "C"
 
 // --------------------------------------------------------------------------
@@ -268,8 +198,6 @@ void finish_lowrank(const struct spasm_csr *A, const int *p, int n, struct spasm
 	                                          : (int) opts->low_rank_start_weight;
 	for (;;) {
 		int Sn = (rank_ub < block) ? rank_ub : block;
-		if (w == 0 && Sn > 16)
-			Sn = 16;          // full combinations are formed on the host: keep the chunk small
 		if (Sn <= 0)
 			break;
 		logmsg("[echelonize/dense/low-rank] round %d, weight %d, chunk %d x %d\n", round, w, Sn, Sm);

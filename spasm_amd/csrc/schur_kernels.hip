@@ -593,6 +593,20 @@ size_t schur_lds_bytes(int table, bool wide)
 	return wide ? sizeof(WaveLds<8192, true>) : sizeof(WaveLds<8192, false>);
 }
 
+// exclusive scan of max(row_len, 0) into Sp[0..n]
+void launch_row_scan(const int *row_len, int n, int64_t *blocksum, int64_t *Sp, hipStream_t stream)
+{
+	if (n == 0) {
+		HIP_CHECK(hipMemsetAsync(Sp, 0, sizeof(int64_t), stream));
+		return;
+	}
+	const int nblocks = (n + 1023) / 1024;
+	hipLaunchKernelGGL(scan_block_sums, dim3(nblocks), dim3(256), 0, stream, row_len, n, blocksum);
+	hipLaunchKernelGGL(scan_of_sums, dim3(1), dim3(256), 0, stream, blocksum, nblocks);
+	hipLaunchKernelGGL(scan_finish, dim3(nblocks), dim3(256), 0, stream, row_len, n, blocksum, Sp);
+	HIP_CHECK(hipGetLastError());
+}
+
 void launch_finalize(const spasm_hip_dwork *W, int nrows, int sort_rows, hipStream_t stream)
 {
 	const int nblocks = (nrows + 1023) / 1024;
