@@ -6,6 +6,10 @@
 //      executed in row order (the outcome of the reference with one thread).
 // Then the pivotal rows are ordered topologically and appended to U, scaled so
 // that every pivot is 1 and stored first in its row.
+#include <atomic>
+#include <mutex>
+#include <thread>
+#include <algorithm>
 #include <vector>
 
 #include "common.h"
@@ -130,6 +134,115 @@ struct Search {
 		return found;
 	}
 
+	// The same search with T threads and optimistic transactions (the scheme of the reference,
+	// spasm_pivots.c:147-305): a thread explores its row against the pivots it can see, then commits
+	// under a lock if no pivot appeared meanwhile; otherwise it replays the journal of new pivots on
+	// its marks and goes on.  The set of pivots depends on timing (as in the reference); it is always
+	// cycle-free.
+	int acyclic_greedy_threads(int T)
+	{
+		const int n = A->n, m = A->m;
+		std::vector<std::atomic<int>> q((size_t) (m > 0 ? m : 1));
+		for (int j = 0; j < m; j++)
+			q[j].store(qinv[j], std::memory_order_relaxed);
+		std::vector<int> journal((size_t) (n > 0 ? n : 1));
+		std::atomic<int> npiv{0};
+		std::atomic<int> next_row{0};
+		std::mutex commit;
+		auto worker = [&]() {
+			std::vector<signed char> mark((size_t) (m > 0 ? m : 1), 0);
+			std::vector<int> fifo((size_t) (m > 0 ? m : 1));
+			for (;;) {
+				const int begin = next_row.fetch_add(256);
+				if (begin >= n)
+					break;
+				const int end = std::min(n, begin + 256);
+				for (int i = begin; i < end; i++) {
+					if (pinv[i] >= 0)
+						continue;
+					int seen = npiv.load(std::memory_order_acquire);
+					int head = 0, tail = 0, candidates = 0;
+					auto push = [&](int j) {
+						fifo[tail++] = j;
+						candidates -= mark[j];
+						mark[j] = -1;
+					};
+					for (i64 px = A->p[i]; px < A->p[i + 1]; px++) {
+						const int j = A->j[px];
+						if (q[j].load(std::memory_order_relaxed) < 0) {
+							mark[j] = 1;
+							candidates += 1;
+						} else {
+							push(j);
+						}
+					}
+					for (;;) {
+						while (head < tail && candidates > 0) {
+							const int row = q[fifo[head++]].load(std::memory_order_relaxed);
+							if (row == -1)
+								continue;
+							for (i64 px = A->p[row]; px < A->p[row + 1]; px++) {
+								const int j = A->j[px];
+								if (mark[j] >= 0)
+									push(j);
+							}
+						}
+						if (candidates == 0)
+							break;
+						int chosen = -1;
+						for (i64 px = A->p[i]; px < A->p[i + 1]; px++) {
+							chosen = A->j[px];
+							if (mark[chosen] == 1)
+								break;
+						}
+						int target = -1;
+						{
+							std::lock_guard<std::mutex> lock(commit);
+							const int now = npiv.load(std::memory_order_relaxed);
+							if (now == seen) {
+								q[chosen].store(i, std::memory_order_relaxed);
+								pinv[i] = chosen;
+								journal[now] = chosen;
+								npiv.store(now + 1, std::memory_order_release);
+							} else {
+								target = now;
+							}
+						}
+						if (target < 0)
+							break;                    // committed
+						for (; seen < target; seen++) {   // pivots that appeared behind our back
+							const int jn = journal[seen];
+							if (mark[jn] == 0)
+								continue;
+							if (mark[jn] == 1) {
+								push(jn);             // a candidate became pivotal
+							} else {
+								const int row = q[jn].load(std::memory_order_relaxed);
+								for (i64 px = A->p[row]; px < A->p[row + 1]; px++) {
+									const int j = A->j[px];
+									if (mark[j] >= 0)
+										push(j);
+								}
+							}
+						}
+					}
+					for (i64 px = A->p[i]; px < A->p[i + 1]; px++)
+						mark[A->j[px]] = 0;
+					for (int t = 0; t < tail; t++)
+						mark[fifo[t]] = 0;
+				}
+			}
+		};
+		std::vector<std::thread> pool;
+		for (int t = 0; t < T; t++)
+			pool.emplace_back(worker);
+		for (auto &th : pool)
+			th.join();
+		for (int j = 0; j < m; j++)
+			qinv[j] = q[j].load(std::memory_order_relaxed);
+		return npiv.load();
+	}
+
 	// reverse post-order of the pivot graph: a pivotal column precedes all
 	// the pivotal columns its row touches
 	void topological_rows(int npiv, int *p) const
@@ -207,7 +320,17 @@ extern "C" int spasm_hip_pivots_extract_structural(const struct spasm_csr *A, co
 	logmsg("[pivots] Faugere-Lachartre on columns: %d pivots found [%.1fs]\n", extra, wtime() - t1);
 	if (opts == nullptr || opts->enable_greedy_pivot_search) {
 		t1 = wtime();
-		extra = S.acyclic_greedy();
+		int threads = 0;
+		if (const char *e = std::getenv("SPASM_HIP_THREADS"))
+			threads = std::atoi(e);
+		if (threads <= 0) {
+			threads = (int) std::thread::hardware_concurrency();
+			if (threads > 32)
+				threads = 32;
+		}
+		if (A->n < 20000)
+			threads = 1;                  // small inputs: the sequential search (deterministic) is as fast
+		extra = (threads > 1) ? S.acyclic_greedy_threads(threads) : S.acyclic_greedy();
 		npiv += extra;
 		logmsg("[pivots] greedy alternating cycle-free search: %d pivots found [%.1fs]\n", extra, wtime() - t1);
 	}
