@@ -72,8 +72,10 @@ def matching_complex_boundary(nv=13, k=5):
 
 
 def build_workload(name):
-    """returns (A, rows, F, meta): host Csr, rows to reduce, factor with the structural pivots."""
+    """returns (A, rows, F): host Csr, rows to reduce, factor with the structural pivots.  The pivot
+    search runs single-threaded here so that every rank (and every run) gets the same pivots."""
     import spasm_amd
+    os.environ["SPASM_HIP_THREADS"] = "1"
     cache = os.path.join("/tmp", "spasm_amd_bench_%s_%d.npz" % (name, PRIME))
     if os.path.exists(cache):
         z = np.load(cache)
@@ -92,8 +94,10 @@ def build_workload(name):
     A = spasm_amd.compress(PRIME, n, m, ti, tj, tx)
     npiv, perm, F = spasm_amd.pivots_extract_structural(A, spasm_amd.empty_fact(A.m, PRIME))
     rows = np.ascontiguousarray(perm[npiv:], np.int32)
-    np.savez(cache, n=A.n, m=A.m, Ap=A.p, Aj=A.j, Ax=A.x, r=F.U.n, Up=F.U.p, Uj=F.U.j, Ux=F.U.x,
+    tmp = "%s.%d.tmp.npz" % (cache, os.getpid())       # ranks build concurrently: publish atomically
+    np.savez(tmp, n=A.n, m=A.m, Ap=A.p, Aj=A.j, Ax=A.x, r=F.U.n, Up=F.U.p, Uj=F.U.j, Ux=F.U.x,
              qinv=F.qinv, rows=rows)
+    os.replace(tmp, cache)
     return A, rows, F
 
 
