@@ -366,6 +366,13 @@ int device_rref(int64_t prime, int n, int m, uint32_t *dA, int64_t ld, int *d_pi
 	float total_update = 0.f;
 	const bool mfma_ok = use_mfma && prime <= 65279;      // two signed base-256 digits must fit int8
 	for (int c0 = 0; c0 < m; c0 += NB) {
+		if (c0 > 0 && (c0 / NB) % 8 == 0) {           // every row already holds a pivot: the rest is reduced
+			int rk = 0;
+			HIP_CHECK(hipMemcpyAsync(&rk, rank_d, sizeof(int), hipMemcpyDeviceToHost, stream));
+			HIP_CHECK(hipStreamSynchronize(stream));
+			if (rk >= n)
+				break;
+		}
 		const int width = (m - c0 < NB) ? m - c0 : NB;
 		PanelArgs g;
 		g.A = dA;
