@@ -75,7 +75,8 @@ struct PanelArgs {
 	MontDev F;
 };
 
-// One workgroup.  Thread t owns rows t, t + 1024, ...
+// One workgroup.  Thread t owns rows t, t + 1024, ...  The panel copy P is COLUMN-major
+// (P[c * n + i]) so that the threads of a wave touch consecutive addresses in every loop.
 __global__ __launch_bounds__(PANEL_THREADS) void rref_panel_kernel(PanelArgs g)
 {
 	__shared__ uint32_t piv[PW];
@@ -84,15 +85,15 @@ __global__ __launch_bounds__(PANEL_THREADS) void rref_panel_kernel(PanelArgs g)
 	const int tid = threadIdx.x;
 	const MontDev F = g.F;
 	const int n = g.n, W = g.width;
-	// copy the panel, clear the selector columns
-	for (int i = tid; i < n; i += PANEL_THREADS) {
-		uint32_t *Pi = g.P + (int64_t) i * PW;
-		const uint32_t *Ai = g.A + (int64_t) i * g.ld + g.c0;
-		for (int c = 0; c < W; c++)
-			Pi[c] = Ai[c];
-		for (int c = W; c < PW; c++)
-			Pi[c] = 0;
+	const int64_t nn = n;
+	// copy the panel in (transposing), clear the selector columns
+	for (int64_t t = tid; t < nn * W; t += PANEL_THREADS) {
+		const int64_t i = t / W;
+		const int c = (int) (t % W);
+		g.P[(int64_t) c * nn + i] = g.A[i * g.ld + g.c0 + c];
 	}
+	for (int64_t t = tid; t < nn * NB; t += PANEL_THREADS)
+		g.P[(int64_t) NB * nn + t] = 0;
 	if (tid == 0)
 		s_k = 0;
 	__syncthreads();
@@ -101,9 +102,10 @@ __global__ __launch_bounds__(PANEL_THREADS) void rref_panel_kernel(PanelArgs g)
 		if (tid == 0)
 			s_row = 0x7FFFFFFF;
 		__syncthreads();
+		const uint32_t *Pc = g.P + (int64_t) c * nn;
 		int mine = 0x7FFFFFFF;
 		for (int i = tid; i < n; i += PANEL_THREADS)
-			if (!g.is_pivot_row[i] && g.P[(int64_t) i * PW + c] != 0) {
+			if (Pc[i] != 0 && !g.is_pivot_row[i]) {
 				mine = i;
 				break;
 			}
@@ -111,40 +113,51 @@ __global__ __launch_bounds__(PANEL_THREADS) void rref_panel_kernel(PanelArgs g)
 			atomicMin(&s_row, mine);
 		__syncthreads();
 		const int rho = s_row;
-		if (rho == 0x7FFFFFFF) {
-			__syncthreads();
+		if (rho == 0x7FFFFFFF)
 			continue;
-		}
 		const int k = s_k;
-		// scale the pivot row (panel columns >= c and the selector columns), publish it
-		if (tid == 0) {
-			g.is_pivot_row[rho] = 1;
-			g.P[(int64_t) rho * PW + NB + k] = 1;      // selector column of this pivot
-		}
-		__syncthreads();
+		// the scaled pivot row: panel columns >= c and the selector columns 0..k (k = its own, value 1)
 		{
-			uint32_t *Pr = g.P + (int64_t) rho * PW;
-			const uint32_t inv = invmod(Pr[c], F);
-			for (int cc = tid; cc < PW; cc += PANEL_THREADS)
-				piv[cc] = (cc < W || cc >= NB) ? mulmod(Pr[cc], inv, F) : 0u;
+			const uint32_t inv = invmod(Pc[rho], F);
+			for (int cc = tid; cc < PW; cc += PANEL_THREADS) {
+				uint32_t v = 0;
+				if (cc >= c && cc < W)
+					v = g.P[(int64_t) cc * nn + rho];
+				else if (cc >= NB && cc < NB + k)
+					v = g.P[(int64_t) cc * nn + rho];
+				else if (cc == NB + k)
+					v = 1;
+				piv[cc] = (v != 0) ? mulmod(v, inv, F) : 0u;
+			}
 		}
 		__syncthreads();
-		if (tid < PW)
-			g.P[(int64_t) rho * PW + tid] = piv[tid];
-		// eliminate column c from every other row
+		// eliminate column c from every other row; the pivot row itself becomes piv[]
 		for (int i = tid; i < n; i += PANEL_THREADS) {
-			if (i == rho)
+			if (i == rho) {
+				for (int cc = c; cc < W; cc++)
+					g.P[(int64_t) cc * nn + i] = piv[cc];
+				for (int cc = NB; cc <= NB + k; cc++)
+					g.P[(int64_t) cc * nn + i] = piv[cc];
 				continue;
-			uint32_t *Pi = g.P + (int64_t) i * PW;
-			const uint32_t f = Pi[c];
+			}
+			const uint32_t f = Pc[i];
 			if (f == 0)
 				continue;
-			for (int cc = c; cc < W; cc++)
-				Pi[cc] = submod(Pi[cc], mulmod(f, piv[cc], F), F);
-			for (int cc = NB; cc <= NB + k; cc++)
-				Pi[cc] = submod(Pi[cc], mulmod(f, piv[cc], F), F);
+			for (int cc = c; cc < W; cc++) {
+				if (piv[cc] == 0)
+					continue;
+				uint32_t *x = g.P + (int64_t) cc * nn + i;
+				*x = submod(*x, mulmod(f, piv[cc], F), F);
+			}
+			for (int cc = NB; cc <= NB + k; cc++) {
+				if (piv[cc] == 0)
+					continue;
+				uint32_t *x = g.P + (int64_t) cc * nn + i;
+				*x = submod(*x, mulmod(f, piv[cc], F), F);
+			}
 		}
 		if (tid == 0) {
+			g.is_pivot_row[rho] = 1;
 			const int rk = *g.rank;
 			g.pivrow[rk] = rho;
 			g.pivcol[rk] = g.c0 + c;
@@ -156,19 +169,159 @@ __global__ __launch_bounds__(PANEL_THREADS) void rref_panel_kernel(PanelArgs g)
 	}
 	// write the eliminated panel back; M = T J - J: subtract the selector ones
 	const int k = s_k;
-	for (int i = tid; i < n; i += PANEL_THREADS) {
-		uint32_t *Pi = g.P + (int64_t) i * PW;
-		uint32_t *Ai = g.A + (int64_t) i * g.ld + g.c0;
-		for (int c = 0; c < W; c++)
-			Ai[c] = Pi[c];
+	for (int64_t t = tid; t < nn * W; t += PANEL_THREADS) {
+		const int64_t i = t / W;
+		const int c = (int) (t % W);
+		g.A[i * g.ld + g.c0 + c] = g.P[(int64_t) c * nn + i];
 	}
 	__syncthreads();
 	if (tid < k) {
-		uint32_t *Pr = g.P + (int64_t) g.rho[tid] * PW + NB + tid;
+		uint32_t *Pr = g.P + (int64_t) (NB + tid) * nn + g.rho[tid];
 		*Pr = submod(*Pr, 1u, F);
 	}
 	if (tid == 0)
 		*g.knew = k;
+}
+
+// ---- the same panel step spread over several workgroups (tall blocks: one CU cannot stream the
+// panel fast enough).  Row i belongs to workgroup (i / COOP_THREADS) % gridDim.x.  Two grid-wide
+// barriers per pivot: after the candidate search (everybody then reads the pivot row) and before
+// the elimination (the owner overwrites the pivot row with its scaled image).  The barrier is a
+// monotonic counter with the agent-scope release / acquire recipe of the CDNA guide (Guideline 16);
+// spins are bounded: on a timeout the error flag is raised and every later barrier falls through.
+constexpr int COOP_THREADS = 256;
+
+__device__ __forceinline__ void grid_barrier(unsigned int *counter, unsigned int target, int *err)
+{
+	asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+	__syncthreads();
+	if (threadIdx.x == 0) {
+		__builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+		asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+		__hip_atomic_fetch_add(counter, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+		long spins = 0;
+		while (__hip_atomic_load(counter, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) {
+			__builtin_amdgcn_s_sleep(2);
+			if (++spins > 20000000L || __hip_atomic_load(err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) {
+				__hip_atomic_store(err, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+				break;
+			}
+		}
+		__builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+		asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+	}
+	__syncthreads();
+}
+
+struct CoopPanelArgs {
+	PanelArgs g;
+	unsigned int *barrier;    // zeroed before the launch
+	int *cand;                // NB ints, 0x7FFFFFFF before the launch
+	int *err;
+};
+
+__global__ __launch_bounds__(COOP_THREADS) void rref_panel_coop_kernel(CoopPanelArgs ca)
+{
+	const PanelArgs &g = ca.g;
+	__shared__ uint32_t piv[PW];
+	__shared__ int s_min;
+	const int tid = threadIdx.x;
+	const MontDev F = g.F;
+	const int n = g.n, W = g.width;
+	const int64_t nn = n;
+	const int G = gridDim.x;
+	const int stride = G * COOP_THREADS;
+	const int first = blockIdx.x * COOP_THREADS + tid;          // rows first, first + stride, ...
+	unsigned int phase = 0;
+	// copy the panel in (each workgroup its own rows), clear the selector columns
+	for (int i = first; i < n; i += stride) {
+		for (int c = 0; c < W; c++)
+			g.P[(int64_t) c * nn + i] = g.A[(int64_t) i * g.ld + g.c0 + c];
+		for (int c = NB; c < PW; c++)
+			g.P[(int64_t) c * nn + i] = 0;
+	}
+	int k = 0;
+	for (int c = 0; c < W; c++) {
+		if (tid == 0)
+			s_min = 0x7FFFFFFF;
+		__syncthreads();
+		const uint32_t *Pc = g.P + (int64_t) c * nn;
+		int mine = 0x7FFFFFFF;
+		for (int i = first; i < n; i += stride)
+			if (Pc[i] != 0 && !g.is_pivot_row[i]) {
+				mine = i;
+				break;
+			}
+		if (mine != 0x7FFFFFFF)
+			atomicMin(&s_min, mine);
+		__syncthreads();
+		if (tid == 0 && s_min != 0x7FFFFFFF)
+			atomicMin(&ca.cand[c], s_min);
+		grid_barrier(ca.barrier, (++phase) * (unsigned int) G, ca.err);
+		const int rho = __hip_atomic_load(&ca.cand[c], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+		if (rho == 0x7FFFFFFF || rho >= n)
+			continue;
+		{
+			const uint32_t inv = invmod(Pc[rho], F);
+			for (int cc = tid; cc < PW; cc += COOP_THREADS) {
+				uint32_t v = 0;
+				if (cc >= c && cc < W)
+					v = g.P[(int64_t) cc * nn + rho];
+				else if (cc >= NB && cc < NB + k)
+					v = g.P[(int64_t) cc * nn + rho];
+				else if (cc == NB + k)
+					v = 1;
+				piv[cc] = (v != 0) ? mulmod(v, inv, F) : 0u;
+			}
+		}
+		grid_barrier(ca.barrier, (++phase) * (unsigned int) G, ca.err);      // everybody holds piv[]
+		for (int i = first; i < n; i += stride) {
+			if (i == rho) {
+				for (int cc = c; cc < W; cc++)
+					g.P[(int64_t) cc * nn + i] = piv[cc];
+				for (int cc = NB; cc <= NB + k; cc++)
+					g.P[(int64_t) cc * nn + i] = piv[cc];
+				g.is_pivot_row[rho] = 1;
+				continue;
+			}
+			const uint32_t f = Pc[i];
+			if (f == 0)
+				continue;
+			for (int cc = c; cc < W; cc++) {
+				if (piv[cc] == 0)
+					continue;
+				uint32_t *x = g.P + (int64_t) cc * nn + i;
+				*x = submod(*x, mulmod(f, piv[cc], F), F);
+			}
+			for (int cc = NB; cc <= NB + k; cc++) {
+				if (piv[cc] == 0)
+					continue;
+				uint32_t *x = g.P + (int64_t) cc * nn + i;
+				*x = submod(*x, mulmod(f, piv[cc], F), F);
+			}
+		}
+		if (blockIdx.x == 0 && tid == 0) {
+			const int rk = *g.rank;
+			g.pivrow[rk] = rho;
+			g.pivcol[rk] = g.c0 + c;
+			*g.rank = rk + 1;
+			g.rho[k] = rho;
+		}
+		k += 1;
+	}
+	// write the eliminated panel back (own rows); M = T J - J
+	for (int i = first; i < n; i += stride)
+		for (int c = 0; c < W; c++)
+			g.A[(int64_t) i * g.ld + g.c0 + c] = g.P[(int64_t) c * nn + i];
+	grid_barrier(ca.barrier, (++phase) * (unsigned int) G, ca.err);
+	if (blockIdx.x == 0) {
+		if (tid < k) {
+			uint32_t *Pr = g.P + (int64_t) (NB + tid) * nn + g.rho[tid];
+			*Pr = submod(*Pr, 1u, F);
+		}
+		if (tid == 0)
+			*g.knew = k;
+	}
 }
 
 // B[t, :] = A[rho[t], c1:]  (old values of the new pivot rows), k x mr, row-major ld = mr
@@ -197,9 +350,9 @@ __global__ __launch_bounds__(256) void rref_update_valu(uint32_t *A, int64_t ld,
 	const int tid = threadIdx.x;
 	const int row0 = blockIdx.y * GT_ROWS, col0 = blockIdx.x * GT_COLS;
 	for (int t = tid; t < GT_ROWS * NB; t += 256) {
-		const int rr = t / NB, cc = t % NB;
+		const int cc = t / GT_ROWS, rr = t % GT_ROWS;       // consecutive threads: consecutive rows of a column of M
 		const int i = row0 + rr;
-		sM[rr][cc] = (i < n && cc < k) ? P[(int64_t) i * PW + NB + cc] : 0u;
+		sM[rr][cc] = (i < n && cc < k) ? P[(int64_t) (NB + cc) * n + i] : 0u;
 	}
 	for (int t = tid; t < NB * GT_COLS; t += 256) {
 		const int rr = t / GT_COLS, cc = t % GT_COLS;
@@ -262,9 +415,9 @@ __global__ __launch_bounds__(256) void rref_update_mfma(uint32_t *A, int64_t ld,
 	const int tid = threadIdx.x;
 	const int row0 = blockIdx.y * 64, col0 = blockIdx.x * 64;
 	for (int t = tid; t < 64 * 64; t += 256) {
-		const int rr = t / 64, kk = t % 64;
+		const int kk = t / 64, rr = t % 64;                 // consecutive threads: consecutive rows of a column of M
 		const int i = row0 + rr;
-		const uint32_t v = (i < n && kk < k) ? P[(int64_t) i * PW + NB + kk] : 0u;
+		const uint32_t v = (i < n && kk < k) ? P[(int64_t) (NB + kk) * n + i] : 0u;
 		int hi, lo;
 		split_digits(v, F, hi, lo);
 		Mhi[rr][kk] = (signed char) hi;
@@ -358,6 +511,16 @@ int device_rref(int64_t prime, int n, int m, uint32_t *dA, int64_t ld, int *d_pi
 	HIP_CHECK(hipMalloc((void **) &rho, NB * sizeof(int)));
 	HIP_CHECK(hipMemsetAsync(flags, 0, (size_t) n * sizeof(int), stream));
 	HIP_CHECK(hipMemsetAsync(rank_d, 0, 64, stream));
+	// tall blocks: the panel step is spread over several workgroups (SPASM_HIP_COOP_ROWS rows and up)
+	int coop_min_rows = 2048;
+	if (const char *e = std::getenv("SPASM_HIP_COOP_ROWS"))
+		coop_min_rows = std::atoi(e);
+	unsigned int *coop_barrier = nullptr;
+	int *coop_cand = nullptr, *coop_err = nullptr;
+	HIP_CHECK(hipMalloc((void **) &coop_barrier, 64));
+	HIP_CHECK(hipMalloc((void **) &coop_cand, NB * sizeof(int)));
+	HIP_CHECK(hipMalloc((void **) &coop_err, 64));
+	HIP_CHECK(hipMemsetAsync(coop_err, 0, 64, stream));
 	hipEvent_t e0 = nullptr, e1 = nullptr;
 	if (ms_update != nullptr) {
 		HIP_CHECK(hipEventCreate(&e0));
@@ -389,7 +552,21 @@ int device_rref(int64_t prime, int n, int m, uint32_t *dA, int64_t ld, int *d_pi
 		g.knew = knew;
 		g.rho = rho;
 		g.F = F;
-		hipLaunchKernelGGL(rref_panel_kernel, dim3(1), dim3(PANEL_THREADS), 0, stream, g);
+		if (n >= coop_min_rows) {
+			CoopPanelArgs ca;
+			ca.g = g;
+			ca.barrier = coop_barrier;
+			ca.cand = coop_cand;
+			ca.err = coop_err;
+			HIP_CHECK(hipMemsetAsync(coop_barrier, 0, sizeof(unsigned int), stream));
+			HIP_CHECK(hipMemsetAsync(coop_cand, 0x7F, NB * sizeof(int), stream));     // 0x7F7F7F7F >= any row index
+			int G = (n + COOP_THREADS - 1) / COOP_THREADS;
+			if (G > 64)
+				G = 64;
+			hipLaunchKernelGGL(rref_panel_coop_kernel, dim3(G), dim3(COOP_THREADS), 0, stream, ca);
+		} else {
+			hipLaunchKernelGGL(rref_panel_kernel, dim3(1), dim3(PANEL_THREADS), 0, stream, g);
+		}
 		const int c1 = c0 + width;
 		const int mr = m - c1;
 		if (mr > 0) {
@@ -411,9 +588,15 @@ int device_rref(int64_t prime, int n, int m, uint32_t *dA, int64_t ld, int *d_pi
 		}
 		HIP_CHECK(hipGetLastError());
 	}
-	int rank = 0;
+	int rank = 0, coop_failed = 0;
 	HIP_CHECK(hipMemcpyAsync(&rank, rank_d, sizeof(int), hipMemcpyDeviceToHost, stream));
+	HIP_CHECK(hipMemcpyAsync(&coop_failed, coop_err, sizeof(int), hipMemcpyDeviceToHost, stream));
 	HIP_CHECK(hipStreamSynchronize(stream));
+	(void) hipFree(coop_barrier);
+	(void) hipFree(coop_cand);
+	(void) hipFree(coop_err);
+	if (coop_failed)
+		die("dense RREF: a grid-wide barrier timed out (cooperative panel kernel)");
 	if (rank > 0) {
 		uint32_t *tmp = nullptr;
 		HIP_CHECK(hipMalloc((void **) &tmp, (size_t) rank * (size_t) m * sizeof(uint32_t)));

@@ -86,3 +86,19 @@ def test_rref_mfma_and_valu_agree(oracle, monkeypatch):
     r1, R1, q1 = spasm_amd.ffpack_rref(p, M)
     assert r0 == r1 and np.array_equal(q0, q1) and np.array_equal(R0, R1)
     _check_rref(oracle, p, M)
+
+
+@pytest.mark.parametrize("p", [3, 42013, 65537, 4294967291])
+@pytest.mark.parametrize("shape,rank", [((700, 900), 333), ((300, 200), 150), ((1500, 70), 10), ((2100, 130), 130),
+                                        ((257, 515), 257)])
+def test_rref_cooperative_panel_kernel(oracle, shape, rank, p, monkeypatch):
+    """the multi-workgroup panel kernel (grid-wide barriers), forced on small blocks."""
+    monkeypatch.setenv("SPASM_HIP_COOP_ROWS", "1")
+    n, m = shape
+    rng = np.random.default_rng(n * 3 + m)
+    k = min(rank, n, m)
+    L = rng.integers(0, p, size=(n, k), dtype=np.int64).astype(object)
+    R = rng.integers(0, p, size=(k, m), dtype=np.int64).astype(object)
+    M = np.array((L.dot(R)) % p, dtype=np.int64)
+    M[:, : m // 9] = 0
+    _check_rref(oracle, p, M)
