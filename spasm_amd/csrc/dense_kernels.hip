@@ -39,6 +39,17 @@ __device__ __forceinline__ uint32_t mulmod(uint32_t a, uint32_t b, const MontDev
 	return mont_mul(mont_mul(a, b, F), F.r2, F);
 }
 
+// v mod p for any 64-bit v: (hi * 2^32 + lo) mod p with two Montgomery products
+__device__ __forceinline__ uint32_t reduce64(unsigned long long v, const MontDev &F)
+{
+	uint32_t a = mont_mul((uint32_t) (v >> 32), F.r2, F);
+	uint32_t b = mont_mul((uint32_t) v, F.r1, F);
+	uint32_t s = a + b;
+	if (s < a || s >= F.p)
+		s -= F.p;
+	return s;
+}
+
 __device__ __forceinline__ uint32_t submod(uint32_t a, uint32_t b, const MontDev &F)
 {
 	return (a >= b) ? a - b : a + (F.p - b);
@@ -372,12 +383,11 @@ __global__ __launch_bounds__(256) void rref_update_valu(uint32_t *A, int64_t ld,
 			if (small) {
 				for (int t = 0; t < k; t++)
 					acc += (unsigned long long) (sM[rr][t] * sB[t][cc]);     // < 2^32 each
-				acc %= F.p;
 			} else {
 				for (int t = 0; t < k; t++)
 					acc += mulmod(sM[rr][t], sB[t][cc], F);
-				acc %= F.p;
 			}
+			acc = reduce64(acc, F);
 			uint32_t *dst = A + (int64_t) i * ld + c1 + j;
 			uint32_t s = *dst + (uint32_t) acc;
 			if (s < (uint32_t) acc || s >= F.p)
@@ -451,7 +461,8 @@ __global__ __launch_bounds__(256) void rref_update_mfma(uint32_t *A, int64_t ld,
 		acc_ll = __builtin_amdgcn_mfma_i32_32x32x32_i8(a_lo, b_lo, acc_ll, 0, 0, 0);
 	}
 	// C/D map of the 32x32 shapes: col = lane & 31, row = (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5)
-	const long long pp = (long long) F.p;
+	// |sum| <= 64 * (p/2)^2 < p * 2^26 for p < 2^16: shift by that multiple of p to stay non-negative
+	const long long offset = (long long) F.p << 26;
 #pragma unroll
 	for (int reg = 0; reg < 16; reg++) {
 		const int rr = (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5);
@@ -459,13 +470,11 @@ __global__ __launch_bounds__(256) void rref_update_mfma(uint32_t *A, int64_t ld,
 		const int i = row0 + wr + rr, j = col0 + wc + cc;
 		if (i >= n || j >= mr)
 			continue;
-		long long s = (long long) acc_hh[reg] * 65536 + ((long long) acc_hl[reg] + (long long) acc_lh[reg]) * 256 +
-		              (long long) acc_ll[reg];
-		long long mred = s % pp;
-		if (mred < 0)
-			mred += pp;
+		const long long s = (long long) acc_hh[reg] * 65536 + ((long long) acc_hl[reg] + (long long) acc_lh[reg]) * 256 +
+		                    (long long) acc_ll[reg] + offset;
+		const uint32_t mred = reduce64((unsigned long long) s, F);
 		uint32_t *dst = A + (int64_t) i * ld + c1 + j;
-		uint32_t sum = *dst + (uint32_t) mred;
+		uint32_t sum = *dst + mred;
 		if (sum >= F.p)
 			sum -= F.p;
 		*dst = sum;

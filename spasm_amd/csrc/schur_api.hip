@@ -41,6 +41,37 @@ template <typename T> void upload(T *dst, const T *src, int64_t count, hipStream
 		HIP_CHECK(hipMemcpyAsync(dst, src, (size_t) count * sizeof(T), hipMemcpyHostToDevice, s));
 }
 
+// The dense accumulator scratch is large (tens of GB on big inputs) and expensive to allocate;
+// host-level entry points park it here between calls instead of freeing it (it is all zero
+// whenever no kernel is running).
+struct ScratchCache {
+	unsigned char *ptr = nullptr;
+	int64_t bytes = 0;
+};
+ScratchCache g_scratch_cache;
+
+void scratch_adopt(spasm_hip_dwork *W)
+{
+	if (g_scratch_cache.ptr != nullptr && W->d_scratch == nullptr) {
+		W->d_scratch = g_scratch_cache.ptr;
+		W->scratch_bytes = g_scratch_cache.bytes;
+		g_scratch_cache.ptr = nullptr;
+		g_scratch_cache.bytes = 0;
+	}
+}
+
+void scratch_park(spasm_hip_dwork *W)
+{
+	if (W->d_scratch == nullptr)
+		return;
+	if (g_scratch_cache.ptr != nullptr)
+		(void) hipFree(g_scratch_cache.ptr);
+	g_scratch_cache.ptr = W->d_scratch;
+	g_scratch_cache.bytes = W->scratch_bytes;
+	W->d_scratch = nullptr;
+	W->scratch_bytes = 0;
+}
+
 int cu_count()
 {
 	static int cus = 0;
@@ -598,6 +629,7 @@ struct spasm_csr *spasm_hip_schur(const struct spasm_csr *A, const int *p, int n
 	const double t0 = wtime();
 	hipStream_t stream = nullptr;
 	spasm_hip_dfact *F = spasm_hip_dfact_create(fact->U, fact->qinv, stream);
+	const double t_fact = wtime() - t0;
 	// device image of A and of the row list
 	const i64 annz = A->p[A->n];
 	i64 *dAp = dalloc<i64>((i64) A->n + 1);
@@ -615,21 +647,27 @@ struct spasm_csr *spasm_hip_schur(const struct spasm_csr *A, const int *p, int n
 	i64 in_nnz = 0;
 	for (int k = 0; k < n; k++)
 		in_nnz += A->p[p[k] + 1] - A->p[p[k]];
-	i64 pool = std::max<i64>((i64) (est_density * n * (double) m * 1.5), 4 * in_nnz) + (i64) 4096 * 4096;
+	// est_density is relative to the non-pivotal columns (spasm_schur_estimate_density divides by m - r)
+	i64 pool = std::max<i64>((i64) (est_density * n * (double) (m - F->r) * 1.3), 4 * in_nnz) + (i64) 4096 * 4096;
 	const i64 pool_max = (i64) n * (i64) (m - F->r) + (i64) 4096 * 4096;
 	pool = std::min(pool, pool_max);
 	spasm_hip_schur_stats st{};
 	spasm_hip_dwork *W = nullptr;
+	const double t1 = wtime();
 	for (;;) {
 		W = spasm_hip_dwork_create(n, m, pool);
+		scratch_adopt(W);
 		if (spasm_hip_dschur(&dA, drows, n, F, W, stream, &st) == 0)
 			break;
+		scratch_park(W);
 		spasm_hip_dwork_destroy(W);
 		if (pool >= pool_max)
 			die("spasm_hip_schur: pool of %" PRId64 " entries still too small", pool);
 		pool = std::min(pool_max, 2 * pool + m);
 		logmsg("[schur/hip] pool too small, retrying with %" PRId64 " entries\n", pool);
 	}
+	const double t_run = wtime() - t1;
+	const double t2 = wtime();
 	struct spasm_csr *S = spasm_hip_csr_alloc(n, m, st.nnz, prime, true);
 	HIP_CHECK(hipMemcpy(S->p, W->d_Sp, ((size_t) n + 1) * sizeof(i64), hipMemcpyDeviceToHost));
 	if (st.nnz > 0) {
@@ -639,6 +677,9 @@ struct spasm_csr *spasm_hip_schur(const struct spasm_csr *A, const int *p, int n
 	if (p_out != nullptr)
 		for (int k = 0; k < n; k++)
 			p_out[k] = (p_in != nullptr) ? p_in[p[k]] : p[k];
+	const double t_down = wtime() - t2;
+	const double t3 = wtime();
+	scratch_park(W);
 	spasm_hip_dwork_destroy(W);
 	(void) hipFree(dAp);
 	(void) hipFree(dAj);
@@ -646,8 +687,9 @@ struct spasm_csr *spasm_hip_schur(const struct spasm_csr *A, const int *p, int n
 	(void) hipFree(drows);
 	spasm_hip_dfact_destroy(F);
 	const double density = (n > 0 && m > 0) ? (double) st.nnz / ((double) m * n) : 0.0;
-	logmsg("Schur complement: %d * %d [%" PRId64 " nz / density= %.3f], %.1fs (GPU kernels %.1f ms; tiers %d/%d/%d)\n", n, m,
-	       st.nnz, density, wtime() - t0, st.ms_total, st.rows_lds, st.rows_lds_big, st.rows_dense);
+	logmsg("Schur complement: %d * %d [%" PRId64 " nz / density= %.3f], %.1fs (GPU kernels %.1f ms; tiers %d/%d/%d; "
+	       "factor image %.2fs, alloc+run %.2fs, download %.2fs, free %.2fs)\n", n, m, st.nnz, density, wtime() - t0,
+	       st.ms_total, st.rows_lds, st.rows_lds_big, st.rows_dense, t_fact, t_run, t_down, wtime() - t3);
 	return S;
 }
 
