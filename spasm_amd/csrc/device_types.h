@@ -113,6 +113,7 @@ struct spasm_hip_dwork {
 	int *d_Sj = nullptr, *d_Sx = nullptr;
 	unsigned char *d_scratch = nullptr;   // per-wave dense accumulators (all zero between calls)
 	int64_t scratch_bytes = 0;
+	int64_t scratch_budget = 0;           // 0: up to half of the free HBM; else a cap in bytes
 	int scratch_slots = 0;
 	int64_t slot_bytes = 0, off_bm = 0, off_xn = 0;
 	hipEvent_t ev[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};

@@ -458,6 +458,8 @@ int spasm_hip_dschur(const spasm_hip_dcsr *A, const int *d_rows, int nrows, cons
 		size_t free_b = 0, total_b = 0;
 		HIP_CHECK(hipMemGetInfo(&free_b, &total_b));
 		i64 budget = (i64) ((free_b + (size_t) W->scratch_bytes) / 2);
+		if (W->scratch_budget > 0)
+			budget = std::min(budget, std::max(W->scratch_budget, W->scratch_bytes));
 		if (env_int("SPASM_HIP_SCRATCH_GB", 0) > 0)
 			budget = (i64) env_int("SPASM_HIP_SCRATCH_GB", 0) << 30;
 		slots = (int) std::max<i64>(cus, std::min<i64>(slots, budget / slot_bytes));
@@ -656,6 +658,10 @@ struct spasm_csr *spasm_hip_schur(const struct spasm_csr *A, const int *p, int n
 	const double t1 = wtime();
 	for (;;) {
 		W = spasm_hip_dwork_create(n, m, pool);
+		// one-shot call: allocating tens of GB costs more than the kernel gains from having every
+		// row group resident at once (hipMalloc is ~30 ms per GB); the device-level API keeps its
+		// workspace and takes the large budget
+		W->scratch_budget = (i64) 24 << 30;
 		scratch_adopt(W);
 		if (spasm_hip_dschur(&dA, drows, n, F, W, stream, &st) == 0)
 			break;
