@@ -196,12 +196,12 @@ def main():
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     k_ms, k_elim, k_stream, k_in, k_out = 0.0, 0, 0, 0, 0
-    t_tiers = [0.0, 0.0, 0.0, 0.0]
+    t_tiers = [0.0, 0.0, 0.0, 0.0, 0.0]
     rows_by_tier = (0, 0, 0)
     for _ in range(args.steps):
         st = step()
-        k_ms += st.ms_tier2
-        for q, v in enumerate((st.ms_tier0, st.ms_tier1, st.ms_tier2, st.ms_finalize)):
+        k_ms += st.ms_group if st.used_group_kernel else st.ms_tier2
+        for q, v in enumerate((st.ms_tier0, st.ms_tier1, st.ms_tier2, st.ms_finalize, st.ms_group)):
             t_tiers[q] += v
         rows_by_tier = (st.rows_lds, st.rows_lds_big, st.rows_dense)
         group = bool(st.used_group_kernel)
@@ -257,7 +257,8 @@ def main():
                          "algorithmic_bytes": int(algo),
                          "ms_by_kernel": {"schur_lds_kernel<1024>": t_tiers[0] / args.steps,
                                           "schur_lds_kernel<8192>": t_tiers[1] / args.steps,
-                                          ("schur_group_kernel" if group else "schur_wave_dense_kernel"): t_tiers[2] / args.steps,
+                                          "schur_wave_dense_kernel": t_tiers[2] / args.steps,
+                                          "schur_group_kernel": t_tiers[4] / args.steps,
                                           "scan+gather_rows": t_tiers[3] / args.steps},
                          "rows_by_kernel": {"lds_small": rows_by_tier[0], "lds_big": rows_by_tier[1],
                                             ("row_group" if group else "wave_dense"): rows_by_tier[2]},

@@ -28,10 +28,13 @@ enum Ctr {
 	CTR_ROW_NEXT = 0,      // next row batch to hand out (tier 0)
 	CTR_ROW_NEXT2,         // ... tier 1 (large LDS table)
 	CTR_ROW_NEXT3,         // ... tier 2 (dense accumulator)
+	CTR_ROW_NEXT_G,        // ... row-group kernel (groups)
 	CTR_OVF1,              // rows that overflowed the small table
 	CTR_OVF2,              // rows that overflowed the large table
 	CTR_STATUS,            // bit 0: pool exhausted
 	CTR_DONE0, CTR_DONE1, CTR_DONE2,   // rows finished per tier
+	CTR_GROUP_ABORT,       // row-group kernel gave up (poor lane efficiency)
+	CTR_GROUPS_DONE,
 	CTR_COUNT = 16
 };
 
@@ -77,6 +80,7 @@ struct SchurArgs {
 	int next_ctr;             // which CTR_ROW_NEXT* this launch uses
 	int ovf_ctr;              // which CTR_OVF* receives overflowing rows
 	int done_ctr;
+	int skip_done;            // tier 0 only: leave rows alone whose row_len is no longer -1
 };
 
 }  // namespace sh

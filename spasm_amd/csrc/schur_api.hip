@@ -12,7 +12,8 @@ void launch_finalize(const spasm_hip_dwork *W, int nrows, int sort_rows, hipStre
 void wave_dense_geometry(int rpad, int Sm, bool wide, int64_t *slot_bytes, int64_t *off_bm, int64_t *off_xn);
 void group_geometry(int rpad, int Sm, bool wide, int64_t *slot_bytes, int64_t *off_bm);
 void launch_schur_group(const SchurArgs &a, unsigned char *scratch, int64_t slot_bytes, int64_t off_bm, bool wide,
-                        uint32_t *dense_out, int64_t ldS, int blocks, hipStream_t stream);
+                        uint32_t *dense_out, int64_t ldS, int blocks, hipStream_t stream, int sel_mod, int sel_rem,
+                        int sel_invert);
 void launch_schur_wave_dense(const SchurArgs &a, unsigned char *scratch, int64_t slot_bytes, int64_t off_bm, int64_t off_xn,
                              bool wide, uint32_t *dense_out, int64_t ldS, int blocks, hipStream_t stream);
 void launch_all_rows_to_list(int *list, int *count, int *row_len, int nrows, hipStream_t stream);
@@ -444,8 +445,11 @@ int spasm_hip_dschur(const spasm_hip_dcsr *A, const int *d_rows, int nrows, cons
 	// batches large enough to fill the GPU with groups; SPASM_HIP_GROUP=0/1 forces the choice.
 	// Small batches (density samples, dense blocks) stay on the per-row tiers.
 	int group_mode = env_int("SPASM_HIP_GROUP", -1);
-	if (group_mode < 0)
+	bool probe = false;            // auto: run a few groups first and look at their lane efficiency
+	if (group_mode < 0) {
 		group_mode = (nrows >= 64 * 32 && force_tier == 0) ? 1 : 0;
+		probe = group_mode && nrows >= env_int("SPASM_HIP_GROUP_WATCH_ROWS", 64 * 256);
+	}
 	int group_slots = 0;
 	i64 group_slot_bytes = 0, group_off_bm = 0;
 	// per-wave dense scratch, (re)allocated when the factor geometry needs more
@@ -470,7 +474,8 @@ int spasm_hip_dschur(const spasm_hip_dcsr *A, const int *d_rows, int nrows, cons
 			const int ngroups = (nrows + 63) / 64;
 			group_slots = (int) std::min<i64>(env_int("SPASM_HIP_GROUP_SLOTS", cus * 20), budget / group_slot_bytes);
 			group_slots = std::max(1, std::min(group_slots, ngroups));
-			need = group_slot_bytes * group_slots;
+			// with the automatic fallback the per-row tier may run in the same buffer afterwards
+			need = probe ? std::max(need, group_slot_bytes * group_slots) : group_slot_bytes * group_slots;
 		}
 		if (need > W->scratch_bytes) {
 			if (W->d_scratch != nullptr)
@@ -526,12 +531,24 @@ int spasm_hip_dschur(const spasm_hip_dcsr *A, const int *d_rows, int nrows, cons
 		const int per_cu0 = (int) std::min<size_t>(16, (size_t) (160 * 1024) / schur_lds_bytes(small_table, wide_lds));
 		int blocks0 = std::min(cus * per_cu0, (nrows + 3) / 4);
 		if (group_mode) {
-			a.next_ctr = CTR_ROW_NEXT3;
+			a.next_ctr = CTR_ROW_NEXT_G;
 			a.done_ctr = CTR_DONE2;
-			HIP_CHECK(hipEventRecord(W->ev[3], stream));
-			HIP_CHECK(hipEventRecord(W->ev[4], stream));
-			launch_schur_group(a, W->d_scratch, group_slot_bytes, group_off_bm, wide_dense, nullptr, 0, group_slots, stream);
-			goto eliminated;
+			// auto mode: the kernel watches its own lane efficiency (eliminations / (64 * applied pivots)) and
+			// stops handing out groups when it falls under ~0.15 -- below that, one coalesced atomic
+			// instruction per pivot entry (2.6 G/s) loses to one scattered update per row (23 G/s), see
+			// DESIGN.md section 5.  Rows it did not produce keep row_len == -1 and go to the per-row tiers.
+			HIP_CHECK(hipMemsetAsync(W->d_row_len, 0xFF, (size_t) nrows * sizeof(int), stream));
+			launch_schur_group(a, W->d_scratch, group_slot_bytes, group_off_bm, wide_dense, nullptr, 0, group_slots, stream,
+			                   probe ? 1 : 0, 0, 0);
+			HIP_CHECK(hipEventRecord(W->ev[5], stream));
+			if (!probe) {
+				HIP_CHECK(hipEventRecord(W->ev[3], stream));
+				HIP_CHECK(hipEventRecord(W->ev[4], stream));
+				goto eliminated;
+			}
+			a.skip_done = 1;
+			a.next_ctr = CTR_ROW_NEXT;
+			a.done_ctr = CTR_DONE0;
 		}
 		if (force_tier == 0)
 			launch_schur_lds(a, small_table, wide_lds, std::max(blocks0, 1), stream);
@@ -591,9 +608,12 @@ eliminated:
 		stats->rows_dense = ctr[CTR_DONE2];
 		stats->status = status;
 		HIP_CHECK(hipEventElapsedTime(&stats->ms_eliminate, W->ev[0], W->ev[1]));
-		stats->ms_tier0 = stats->ms_tier1 = stats->ms_tier2 = 0.0f;
+		stats->ms_tier0 = stats->ms_tier1 = stats->ms_tier2 = stats->ms_group = 0.0f;
+		stats->group_aborted = ctr[CTR_GROUP_ABORT] ? 1 : 0;
 		if (nrows > 0) {
-			HIP_CHECK(hipEventElapsedTime(&stats->ms_tier0, W->ev[0], W->ev[3]));
+			if (group_mode)
+				HIP_CHECK(hipEventElapsedTime(&stats->ms_group, W->ev[0], W->ev[5]));
+			HIP_CHECK(hipEventElapsedTime(&stats->ms_tier0, group_mode ? W->ev[5] : W->ev[0], W->ev[3]));
 			HIP_CHECK(hipEventElapsedTime(&stats->ms_tier1, W->ev[3], W->ev[4]));
 			HIP_CHECK(hipEventElapsedTime(&stats->ms_tier2, W->ev[4], W->ev[1]));
 		}

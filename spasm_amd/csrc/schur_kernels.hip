@@ -178,6 +178,8 @@ __global__ __launch_bounds__(64) void schur_lds_kernel(SchurArgs a)
 		const int kend = (kbase + ROWS_PER_GRAB < total_rows) ? kbase + ROWS_PER_GRAB : total_rows;
 		for (int kk = kbase; kk < kend; kk++) {
 			const int k = (a.list != nullptr) ? a.list[kk] : kk;
+			if (a.skip_done && a.row_len[k] != -1)
+				continue;               // already produced by the row-group probe
 			const int i = a.rows[k];
 
 			// ---- reset the table ----
@@ -945,6 +947,7 @@ constexpr int GR_PB = 8;            // pivots whose loads are issued together
 
 struct GroupArgs {
 	SchurArgs a;
+	int watch;                // 1: stop handing out groups when the lane efficiency is poor (CTR_GROUP_ABORT)
 	unsigned char *scratch;
 	int64_t slot_bytes;       // X | bitmap
 	int64_t off_bm;
@@ -999,6 +1002,13 @@ __global__ __launch_bounds__(64) void schur_group_kernel(GroupArgs d)
 		g = __builtin_amdgcn_readfirstlane(g);
 		if (g >= ngroups)
 			break;
+		if (d.watch) {
+			int stop = 0;
+			if (lane == 0)
+				stop = __hip_atomic_load(&a.ctr[CTR_GROUP_ABORT], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+			if (__builtin_amdgcn_readfirstlane(stop))
+				break;
+		}
 		const int k = g * 64 + lane;
 		const bool have_row = k < a.nrows;
 
@@ -1220,6 +1230,20 @@ __global__ __launch_bounds__(64) void schur_group_kernel(GroupArgs d)
 		if (!fits && lane == 0)
 			atomicOr(&a.ctr[CTR_STATUS], 1);
 		st_done += fits ? __popcll(__ballot(have_row)) : 0;
+		if (d.watch && lane == 0) {
+			// publish this group's counters, then judge the batch once enough groups are in
+			const unsigned long long e = atomicAdd(&a.ctr64[C64_ELIM], st_elim) + st_elim;
+			const unsigned long long w = atomicAdd(&a.ctr64[C64_WAVEPIV], st_wavepiv) + st_wavepiv;
+			atomicAdd(&a.ctr64[C64_STREAM], st_stream);
+			const int finished = atomicAdd(&a.ctr[CTR_GROUPS_DONE], 1) + 1;
+			if (finished >= 8 && w > 4096 && (double) e < 0.15 * 64.0 * (double) w)
+				atomicOr(&a.ctr[CTR_GROUP_ABORT], 1);
+		}
+		if (d.watch) {
+			st_elim = 0;
+			st_wavepiv = 0;
+			st_stream = 0;
+		}
 	}
 	drain_vmem();
 	// per-lane statistics -> wave totals
@@ -1245,10 +1269,11 @@ void group_geometry(int rpad, int Sm, bool wide, int64_t *slot_bytes, int64_t *o
 }
 
 void launch_schur_group(const SchurArgs &a, unsigned char *scratch, int64_t slot_bytes, int64_t off_bm, bool wide,
-                        uint32_t *dense_out, int64_t ldS, int blocks, hipStream_t stream)
+                        uint32_t *dense_out, int64_t ldS, int blocks, hipStream_t stream, int watch, int, int)
 {
 	GroupArgs d;
 	d.a = a;
+	d.watch = watch;
 	d.scratch = scratch;
 	d.slot_bytes = slot_bytes;
 	d.off_bm = off_bm;

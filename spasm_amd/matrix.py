@@ -78,8 +78,8 @@ class CDcsr(C.Structure):          # spasm_hip_dcsr
 class CSchurStats(C.Structure):    # spasm_hip_schur_stats
     _fields_ = [("nnz", C.c_int64), ("eliminations", C.c_int64), ("entries_streamed", C.c_int64),
                 ("input_entries", C.c_int64), ("group_pivots", C.c_int64), ("rows", C.c_int), ("rows_lds", C.c_int),
-                ("rows_lds_big", C.c_int), ("rows_dense", C.c_int), ("status", C.c_int), ("used_group_kernel", C.c_int),
-                ("ms_eliminate", C.c_float), ("ms_tier0", C.c_float), ("ms_tier1", C.c_float),
+                ("rows_lds_big", C.c_int), ("rows_dense", C.c_int), ("status", C.c_int), ("used_group_kernel", C.c_int), ("group_aborted", C.c_int),
+                ("ms_eliminate", C.c_float), ("ms_group", C.c_float), ("ms_tier0", C.c_float), ("ms_tier1", C.c_float),
                 ("ms_tier2", C.c_float), ("ms_finalize", C.c_float), ("ms_total", C.c_float)]
 
 

@@ -158,3 +158,45 @@ def test_schur_row_group_kernel_random(oracle, p, monkeypatch):
     want, p_out_want, _ = oracle.schur(A, rows, F)
     S, p_out = spasm_amd.schur(_as_product(A), rows, _fact(F))
     _check(oracle, S, p_out, want, p_out_want)
+
+
+def test_row_group_kernel_gives_up_on_unrelated_rows(oracle, monkeypatch):
+    """rows that are neighbours in the list but live in different diagonal blocks share nothing: the row-group
+    kernel must notice (lane efficiency), stop, and the per-row kernels must finish the batch -- same matrix."""
+    import torch
+    monkeypatch.setenv("SPASM_HIP_GROUP_WATCH_ROWS", "0")
+    p = 42013
+    rng = np.random.default_rng(11)
+    B, W, extra = 520, 32, 8
+    ti, tj, tx = [], [], []
+    row = 0
+    for b in range(B):                      # W chain rows (structural pivots) + `extra` rows per block
+        c0 = b * W
+        for i in range(W):
+            ti += [row, row]
+            tj += [c0 + i, c0 + min(i + 1, W - 1)] if i + 1 < W else [c0 + i, c0 + i]
+            tx += [int(rng.integers(1, p)), int(rng.integers(1, p))]
+            row += 1
+    n_chain = row
+    blocks = rng.permutation(np.repeat(np.arange(B), extra))      # neighbours in the list: different blocks
+    for b in blocks:
+        cols = rng.choice(W, size=3, replace=False) + b * W
+        for c in cols:
+            ti.append(row)
+            tj.append(int(c))
+            tx.append(int(rng.integers(1, p)))
+        row += 1
+    A = oracle.compress(p, row, B * W, np.array(ti, np.int32), np.array(tj, np.int32), np.array(tx, np.int64))
+    npiv, perm, F = oracle.pivots_extract_structural(A, oracle.empty_fact(A.n, A.m, p))
+    rows = perm[npiv:]
+    assert len(rows) >= 2048
+    want, _, _ = oracle.schur(A, rows, F)
+    dA = spasm_amd.DeviceCsr.from_host(_as_product(A))
+    dF = spasm_amd.DeviceFact(_fact(F))
+    Wk = spasm_amd.SchurWorkspace(len(rows), A.m, 4 * want.nnz + (1 << 22))
+    drows = torch.from_numpy(np.ascontiguousarray(rows, np.int32)).cuda()
+    S, st = spasm_amd.dschur(dA, drows, dF, Wk)
+    assert st.status == 0 and st.used_group_kernel == 1 and st.group_aborted == 1
+    assert st.rows_lds + st.rows_lds_big + st.rows_dense == len(rows)
+    H = S.to_host()
+    assert oracle.same_matrix(oracle.CSR(H.n, H.m, H.p, H.j, H.x, p), want)
