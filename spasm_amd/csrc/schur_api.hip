@@ -12,8 +12,8 @@ void launch_finalize(const spasm_hip_dwork *W, int nrows, int sort_rows, hipStre
 void wave_dense_geometry(int rpad, int Sm, bool wide, int64_t *slot_bytes, int64_t *off_bm, int64_t *off_xn);
 void group_geometry(int rpad, int Sm, bool wide, int64_t *slot_bytes, int64_t *off_bm);
 void launch_schur_group(const SchurArgs &a, unsigned char *scratch, int64_t slot_bytes, int64_t off_bm, bool wide,
-                        uint32_t *dense_out, int64_t ldS, int blocks, hipStream_t stream, int sel_mod, int sel_rem,
-                        int sel_invert);
+                        uint32_t *dense_out, int64_t ldS, int blocks, hipStream_t stream, int watch, float min_eff,
+                        long long min_w);
 void launch_schur_wave_dense(const SchurArgs &a, unsigned char *scratch, int64_t slot_bytes, int64_t off_bm, int64_t off_xn,
                              bool wide, uint32_t *dense_out, int64_t ldS, int blocks, hipStream_t stream);
 void launch_all_rows_to_list(int *list, int *count, int *row_len, int nrows, hipStream_t stream);
@@ -533,13 +533,18 @@ int spasm_hip_dschur(const spasm_hip_dcsr *A, const int *d_rows, int nrows, cons
 		if (group_mode) {
 			a.next_ctr = CTR_ROW_NEXT_G;
 			a.done_ctr = CTR_DONE2;
-			// auto mode: the kernel watches its own lane efficiency (eliminations / (64 * applied pivots)) and
-			// stops handing out groups when it falls under ~0.15 -- below that, one coalesced atomic
-			// instruction per pivot entry (2.6 G/s) loses to one scattered update per row (23 G/s), see
-			// DESIGN.md section 5.  Rows it did not produce keep row_len == -1 and go to the per-row tiers.
+			// auto mode: the kernel watches its own lane efficiency (eliminations / (64 * applied pivots)).
+			// The break-even against the per-row kernel is near 0.15 (one coalesced atomic instruction per
+			// pivot entry at 2.6 G/s against one scattered update per row at 23 G/s),
+			// but the efficiency of a healthy batch starts low (the first eliminations of a row are its
+			// own, the shared part of the reach comes later: mk13.b5 is under 0.15 for its first 10 ms),
+			// so the kernel only bails out of hopeless batches: under 0.04 after 500,000 applied pivots.
+			// Abandoned rows keep row_len == -1 and go to the per-row tiers.
 			HIP_CHECK(hipMemsetAsync(W->d_row_len, 0xFF, (size_t) nrows * sizeof(int), stream));
+			const float min_eff = (float) env_int("SPASM_HIP_GROUP_MIN_EFF_PCT", 4) / 100.0f;
+			const long long min_w = env_int("SPASM_HIP_GROUP_MIN_PIVOTS", 500000);
 			launch_schur_group(a, W->d_scratch, group_slot_bytes, group_off_bm, wide_dense, nullptr, 0, group_slots, stream,
-			                   probe ? 1 : 0, 0, 0);
+			                   probe ? 1 : 0, min_eff, min_w);
 			HIP_CHECK(hipEventRecord(W->ev[5], stream));
 			if (!probe) {
 				HIP_CHECK(hipEventRecord(W->ev[3], stream));

@@ -161,6 +161,8 @@ __global__ __launch_bounds__(64) void schur_lds_kernel(SchurArgs a)
 	const int lane = threadIdx.x;
 	const uint32_t r = (uint32_t) a.r;
 	const MontDev F = a.F;
+	if (a.skip_done && a.ctr[CTR_GROUP_ABORT] == 0)
+		return;                     // the row-group kernel finished the batch: nothing left for the per-row tiers
 	const int total_rows = (a.list != nullptr) ? *a.list_count : a.nrows;
 
 	int64_t arena_off = 0;
@@ -701,6 +703,8 @@ __global__ __launch_bounds__(64) void schur_wave_dense_kernel(WaveDenseArgs d)
 	const uint32_t r = (uint32_t) a.r;
 	const int Sm = a.Sm;
 	const MontDev F = a.F;
+	if (a.skip_done && a.ctr[CTR_GROUP_ABORT] == 0)
+		return;
 	const int total_rows = (a.list != nullptr) ? *a.list_count : a.nrows;
 
 	unsigned char *slot = d.scratch + (int64_t) blockIdx.x * d.slot_bytes;
@@ -947,7 +951,9 @@ constexpr int GR_PB = 8;            // pivots whose loads are issued together
 
 struct GroupArgs {
 	SchurArgs a;
-	int watch;                // 1: stop handing out groups when the lane efficiency is poor (CTR_GROUP_ABORT)
+	int watch;                // 1: give up when the lane efficiency is hopeless (CTR_GROUP_ABORT)
+	float min_eff;            // ... below this fraction of active lanes per applied pivot
+	unsigned long long min_w; // ... judged once this many pivots have been applied over all groups
 	unsigned char *scratch;
 	int64_t slot_bytes;       // X | bitmap
 	int64_t off_bm;
@@ -1028,9 +1034,38 @@ __global__ __launch_bounds__(64) void schur_group_kernel(GroupArgs d)
 
 		// ---- eliminate level by level ----
 		uint32_t cursor = 0;
+		bool abandoned = false;
 		for (;;) {
 			drain_vmem();
 			__builtin_amdgcn_wave_barrier();
+			if (d.watch) {
+				// publish progress every 256 applied pivots; whoever publishes judges the batch:
+				// all running groups contribute in proportion to their work, so the ratio is not biased
+				// towards the cheap groups that finish first
+				int stop = 0;
+				if (lane == 0) {
+					if (st_wavepiv >= 256) {
+						const unsigned long long e = atomicAdd(&a.ctr64[C64_ELIM], st_elim) + st_elim;
+						const unsigned long long w = atomicAdd(&a.ctr64[C64_WAVEPIV], st_wavepiv) + st_wavepiv;
+						atomicAdd(&a.ctr64[C64_STREAM], st_stream);
+						if (w > d.min_w && (double) e < (double) d.min_eff * 64.0 * (double) w)
+							atomicOr(&a.ctr[CTR_GROUP_ABORT], 1);
+						stop = -1;          // counters were flushed
+					}
+					const int flag = __hip_atomic_load(&a.ctr[CTR_GROUP_ABORT], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+					stop = (flag != 0) ? 1 : stop;
+				}
+				stop = __builtin_amdgcn_readfirstlane(stop);
+				if (stop != 0) {
+					st_elim = 0;
+					st_wavepiv = 0;
+					st_stream = 0;
+				}
+				if (stop == 1) {
+					abandoned = true;
+					break;
+				}
+			}
 			int wi = -1;
 			uint32_t fbits = 0;
 			const int wstart = (int) (cursor >> 5);
@@ -1156,6 +1191,17 @@ __global__ __launch_bounds__(64) void schur_group_kernel(GroupArgs d)
 			cursor = lend;
 		}
 		drain_vmem();
+		if (abandoned) {
+			// the batch went to the per-row kernels: restore the all-zero state of this slice and leave
+			// (rows keep row_len == -1)
+			const int64_t lines = (int64_t) r + Sm;
+			for (int64_t c = 0; c < lines; c++)
+				X[c * 64 + lane] = 0;
+			for (int w = lane; w < nw; w += 64)
+				bm[w] = 0;
+			drain_vmem();
+			break;
+		}
 
 		// ---- output: lane = row, the non-pivotal labels in order are the sorted row ----
 		V *Xn = X + (int64_t) r * 64;
@@ -1230,20 +1276,6 @@ __global__ __launch_bounds__(64) void schur_group_kernel(GroupArgs d)
 		if (!fits && lane == 0)
 			atomicOr(&a.ctr[CTR_STATUS], 1);
 		st_done += fits ? __popcll(__ballot(have_row)) : 0;
-		if (d.watch && lane == 0) {
-			// publish this group's counters, then judge the batch once enough groups are in
-			const unsigned long long e = atomicAdd(&a.ctr64[C64_ELIM], st_elim) + st_elim;
-			const unsigned long long w = atomicAdd(&a.ctr64[C64_WAVEPIV], st_wavepiv) + st_wavepiv;
-			atomicAdd(&a.ctr64[C64_STREAM], st_stream);
-			const int finished = atomicAdd(&a.ctr[CTR_GROUPS_DONE], 1) + 1;
-			if (finished >= 8 && w > 4096 && (double) e < 0.15 * 64.0 * (double) w)
-				atomicOr(&a.ctr[CTR_GROUP_ABORT], 1);
-		}
-		if (d.watch) {
-			st_elim = 0;
-			st_wavepiv = 0;
-			st_stream = 0;
-		}
 	}
 	drain_vmem();
 	// per-lane statistics -> wave totals
@@ -1269,11 +1301,14 @@ void group_geometry(int rpad, int Sm, bool wide, int64_t *slot_bytes, int64_t *o
 }
 
 void launch_schur_group(const SchurArgs &a, unsigned char *scratch, int64_t slot_bytes, int64_t off_bm, bool wide,
-                        uint32_t *dense_out, int64_t ldS, int blocks, hipStream_t stream, int watch, int, int)
+                        uint32_t *dense_out, int64_t ldS, int blocks, hipStream_t stream, int watch, float min_eff,
+                        long long min_w)
 {
 	GroupArgs d;
 	d.a = a;
 	d.watch = watch;
+	d.min_eff = min_eff;
+	d.min_w = (unsigned long long) min_w;
 	d.scratch = scratch;
 	d.slot_bytes = slot_bytes;
 	d.off_bm = off_bm;

@@ -165,6 +165,7 @@ def test_row_group_kernel_gives_up_on_unrelated_rows(oracle, monkeypatch):
     kernel must notice (lane efficiency), stop, and the per-row kernels must finish the batch -- same matrix."""
     import torch
     monkeypatch.setenv("SPASM_HIP_GROUP_WATCH_ROWS", "0")
+    monkeypatch.setenv("SPASM_HIP_GROUP_MIN_PIVOTS", "20000")      # the batch is small: judge early
     p = 42013
     rng = np.random.default_rng(11)
     B, W, extra = 520, 32, 8
