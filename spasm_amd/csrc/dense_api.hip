@@ -15,6 +15,10 @@ void launch_dense_pack(const unsigned long long *Y, int N, int m, uint32_t p, co
                        hipStream_t stream);
 void launch_row_scan(const int *row_len, int n, int64_t *blocksum, int64_t *Sp, hipStream_t stream);
 void wave_dense_geometry(int rpad, int Sm, bool wide, int64_t *slot_bytes, int64_t *off_bm, int64_t *off_xn);
+void group_geometry(int rpad, int Sm, bool wide, int64_t *slot_bytes, int64_t *off_bm);
+void launch_schur_group(const SchurArgs &a, unsigned char *scratch, int64_t slot_bytes, int64_t off_bm, bool wide,
+                        uint32_t *dense_out, int64_t ldS, int blocks, hipStream_t stream, int watch, float min_eff,
+                        long long min_w);
 void launch_schur_wave_dense(const SchurArgs &a, unsigned char *scratch, int64_t slot_bytes, int64_t off_bm, int64_t off_xn,
                              bool wide, uint32_t *dense_out, int64_t ldS, int blocks, hipStream_t stream);
 }  // namespace sh
@@ -78,7 +82,19 @@ int spasm_hip_dschur_dense(const spasm_hip_dcsr *A, const int *d_rows, int nrows
 	const i64 budget = (i64) env_int("SPASM_HIP_SCRATCH_GB", 48) << 30;
 	slots = (int) std::max<i64>(cus, std::min<i64>(slots, budget / slot_bytes));
 	slots = std::max(1, std::min(slots, nrows));
-	const i64 need = slot_bytes * slots;
+	i64 need = slot_bytes * slots;
+	// dense blocks are small batches: per-row kernel by default; the row-group kernel (64 consecutive rows
+	// per wave) on request or for blocks of at least 4096 rows
+	int group_mode = env_int("SPASM_HIP_GROUP", -1);
+	if (group_mode < 0)
+		group_mode = nrows >= 4096 ? 1 : 0;
+	i64 gslot = 0, goff = 0;
+	int gslots = 0;
+	if (group_mode) {
+		group_geometry(F->rpad, F->Sm, wide, &gslot, &goff);
+		gslots = (int) std::max<i64>(1, std::min<i64>((nrows + 63) / 64, std::min<i64>(cus * 10, budget / gslot)));
+		need = gslot * gslots;
+	}
 	if (need > W->scratch_bytes) {
 		if (W->d_scratch != nullptr)
 			(void) hipFree(W->d_scratch);
@@ -117,7 +133,12 @@ int spasm_hip_dschur_dense(const spasm_hip_dcsr *A, const int *d_rows, int nrows
 	a.next_ctr = CTR_ROW_NEXT3;
 	a.ovf_ctr = CTR_OVF2;
 	a.done_ctr = CTR_DONE2;
-	launch_schur_wave_dense(a, W->d_scratch, slot_bytes, off_bm, off_xn, wide, d_S, ldS, slots, stream);
+	if (group_mode) {
+		a.next_ctr = CTR_ROW_NEXT_G;
+		launch_schur_group(a, W->d_scratch, gslot, goff, wide, d_S, ldS, gslots, stream, 0, 0.0f, 0);
+	} else {
+		launch_schur_wave_dense(a, W->d_scratch, slot_bytes, off_bm, off_xn, wide, d_S, ldS, slots, stream);
+	}
 	HIP_CHECK(hipStreamSynchronize(stream));
 	return 0;
 }

@@ -14,6 +14,7 @@
 //        use a tiled 64-bit VALU kernel.
 // Values are canonical representatives in [0, p) stored as u32.
 #include "device_types.h"
+#include "field_dev.h"
 
 namespace sh {
 
@@ -22,38 +23,6 @@ namespace {
 constexpr int NB = 64;                  // panel width
 constexpr int PW = 2 * NB;              // panel + selector columns
 constexpr int PANEL_THREADS = 1024;
-
-__device__ __forceinline__ uint32_t mont_mul(uint32_t a, uint32_t b, const MontDev &F)
-{
-	uint64_t t = (uint64_t) a * b;
-	uint32_t mq = (uint32_t) t * F.pinv;
-	uint32_t q = __umulhi(mq, F.p);
-	uint32_t th = (uint32_t) (t >> 32);
-	uint32_t r = th - q;
-	return (th < q) ? r + F.p : r;
-}
-
-// a * b mod p for a, b in [0, p)
-__device__ __forceinline__ uint32_t mulmod(uint32_t a, uint32_t b, const MontDev &F)
-{
-	return mont_mul(mont_mul(a, b, F), F.r2, F);
-}
-
-// v mod p for any 64-bit v: (hi * 2^32 + lo) mod p with two Montgomery products
-__device__ __forceinline__ uint32_t reduce64(unsigned long long v, const MontDev &F)
-{
-	uint32_t a = mont_mul((uint32_t) (v >> 32), F.r2, F);
-	uint32_t b = mont_mul((uint32_t) v, F.r1, F);
-	uint32_t s = a + b;
-	if (s < a || s >= F.p)
-		s -= F.p;
-	return s;
-}
-
-__device__ __forceinline__ uint32_t submod(uint32_t a, uint32_t b, const MontDev &F)
-{
-	return (a >= b) ? a - b : a + (F.p - b);
-}
 
 __device__ uint32_t invmod(uint32_t a, const MontDev &F)
 {
@@ -387,7 +356,7 @@ __global__ __launch_bounds__(256) void rref_update_valu(uint32_t *A, int64_t ld,
 				for (int t = 0; t < k; t++)
 					acc += mulmod(sM[rr][t], sB[t][cc], F);
 			}
-			acc = reduce64(acc, F);
+			acc = reduce_sum(acc, F);
 			uint32_t *dst = A + (int64_t) i * ld + c1 + j;
 			uint32_t s = *dst + (uint32_t) acc;
 			if (s < (uint32_t) acc || s >= F.p)
@@ -472,7 +441,7 @@ __global__ __launch_bounds__(256) void rref_update_mfma(uint32_t *A, int64_t ld,
 			continue;
 		const long long s = (long long) acc_hh[reg] * 65536 + ((long long) acc_hl[reg] + (long long) acc_lh[reg]) * 256 +
 		                    (long long) acc_ll[reg] + offset;
-		const uint32_t mred = reduce64((unsigned long long) s, F);
+		const uint32_t mred = reduce_sum((unsigned long long) s, F);
 		uint32_t *dst = A + (int64_t) i * ld + c1 + j;
 		uint32_t sum = *dst + mred;
 		if (sum >= F.p)
@@ -682,12 +651,12 @@ __global__ __launch_bounds__(64) void combine_rows_kernel(const int64_t *Ap, con
 		}
 		if (coeff == 0)
 			continue;
-		const uint32_t cm = mont_mul(coeff, F.r2, F);          // coefficient in Montgomery form
+		const uint32_t cm = montmul(coeff, F.r2, F);          // coefficient in Montgomery form
 		unsigned long long *Yk = Y + (int64_t) k * m;
 		for (int64_t px = Ap[i] + lane; px < Ap[i + 1]; px += 64) {
 			const int a = Ax[px];
 			const uint32_t v = (a < 0) ? (uint32_t) a + F.p : (uint32_t) a;
-			atomicAdd(&Yk[Aj[px]], (unsigned long long) mont_mul(cm, v % F.p, F));
+			atomicAdd(&Yk[Aj[px]], (unsigned long long) montmul(cm, v % F.p, F));
 		}
 	}
 }

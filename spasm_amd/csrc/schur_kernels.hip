@@ -9,6 +9,7 @@
 // with coalesced 8-byte loads, flattened over the 64 lanes.
 // See DESIGN.md ("Kernels") for the algorithm and its byte accounting.
 #include "device_types.h"
+#include "field_dev.h"
 
 namespace sh {
 
@@ -17,39 +18,6 @@ namespace {
 constexpr uint32_t EMPTY = 0xFFFFFFFFu;
 constexpr int ROWS_PER_GRAB = 4;
 constexpr int POOL_CHUNK = 2048;        // entries reserved from the pool at a time
-
-__device__ __forceinline__ uint32_t montmul(uint32_t a, uint32_t b, const MontDev &F)
-{
-	// a * b * 2^-32 mod p, for a * b < p * 2^32; result in [0, p)
-	uint64_t t = (uint64_t) a * b;
-	uint32_t mq = (uint32_t) t * F.pinv;
-	uint32_t q = __umulhi(mq, F.p);
-	uint32_t th = (uint32_t) (t >> 32);
-	uint32_t r = th - q;
-	return (th < q) ? r + F.p : r;
-}
-
-__device__ __forceinline__ uint32_t reduce_sum(uint32_t v, const MontDev &F) { return montmul(v, F.r1, F); }
-
-__device__ __forceinline__ uint32_t reduce_sum(unsigned long long v, const MontDev &F)
-{
-	uint32_t a = montmul((uint32_t) (v >> 32), F.r2, F);
-	uint32_t b = montmul((uint32_t) v, F.r1, F);
-	uint32_t s = a + b;
-	if (s < a || s >= F.p)
-		s -= F.p;
-	return s;
-}
-
-__device__ __forceinline__ int to_balanced(uint32_t v, const MontDev &F)
-{
-	return (v > F.half) ? (int) (v - F.p) : (int) v;
-}
-
-__device__ __forceinline__ uint32_t from_balanced(int a, const MontDev &F)
-{
-	return (a < 0) ? (uint32_t) a + F.p : (uint32_t) a;
-}
 
 __device__ __forceinline__ uint64_t lanes_below(int lane) { return (1ull << lane) - 1ull; }
 

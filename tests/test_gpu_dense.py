@@ -102,3 +102,17 @@ def test_rref_cooperative_panel_kernel(oracle, shape, rank, p, monkeypatch):
     M = np.array((L.dot(R)) % p, dtype=np.int64)
     M[:, : m // 9] = 0
     _check_rref(oracle, p, M)
+
+
+@pytest.mark.parametrize("name", ["mat364.sms", "medium.sms", "trefethen_500.sms", "singular.sms", "small.sms"])
+@pytest.mark.parametrize("p", [42013, 4294967291])
+def test_schur_dense_row_group_kernel(oracle, name, p, monkeypatch):
+    """dense rows produced by the 64-rows-per-wave kernel."""
+    monkeypatch.setenv("SPASM_HIP_GROUP", "1")
+    A = oracle.load_sms(matrix_path(name), p)
+    npiv, perm, F = oracle.pivots_extract_structural(A, oracle.empty_fact(A.n, A.m, p))
+    rows = perm[npiv:]
+    want, q_want, p_out_want = oracle.schur_dense(A, rows, F)
+    S, q, p_out = spasm_amd.schur_dense(_as_product(A), rows, _fact(F))
+    assert np.array_equal(q, q_want) and np.array_equal(p_out, p_out_want)
+    assert np.array_equal(S, want)
