@@ -44,6 +44,7 @@ enum Ctr64 {
 	C64_STREAM,            // entries of U' streamed
 	C64_INPUT,             // entries of input rows
 	C64_WAVEPIV,           // row-group kernel: pivots applied per group (wave-level count)
+	C64_LPOOL,             // cursor of the L pool
 	C64_COUNT = 8
 };
 
@@ -81,6 +82,13 @@ struct SchurArgs {
 	int ovf_ctr;              // which CTR_OVF* receives overflowing rows
 	int done_ctr;
 	int skip_done;            // tier 0 only: leave rows alone whose row_len is no longer -1
+	// optional record of the elimination coefficients (the L factor): triplets (row, pivot index, value)
+	int *L_i;                 // null: not recorded.  Pool pre-filled with -1; unused slots stay -1
+	int *L_j;
+	int *L_x;
+	int64_t L_cap;
+	const int *kof;           // label -> row of U
+	const int *row_orig;      // output row k -> row index to record (p_in[p[k]] or p[k])
 };
 
 }  // namespace sh

@@ -421,8 +421,18 @@ void spasm_hip_dwork_destroy(spasm_hip_dwork *W)
 // device Schur complement: three tiers (small LDS table, large LDS table,
 // dense accumulator in HBM), then row pointers + gather/sort.
 // --------------------------------------------------------------------------
-int spasm_hip_dschur(const spasm_hip_dcsr *A, const int *d_rows, int nrows, const spasm_hip_dfact *F,
-                     spasm_hip_dwork *W, void *stream_, spasm_hip_schur_stats *stats)
+}  // extern "C"
+
+namespace {
+struct LOut {                 // device pools for the elimination coefficients (triplets)
+	const int *row_orig = nullptr;
+	int *Li = nullptr, *Lj = nullptr, *Lx = nullptr;
+	i64 cap = 0;
+	i64 used = 0;             // out: pool cursor after the call (slots handed out, some may be unused)
+};
+
+int dschur_impl(const spasm_hip_dcsr *A, const int *d_rows, int nrows, const spasm_hip_dfact *F, spasm_hip_dwork *W,
+                void *stream_, spasm_hip_schur_stats *stats, LOut *Lout)
 {
 	hipStream_t stream = (hipStream_t) stream_;
 	if (nrows > W->max_rows)
@@ -438,7 +448,9 @@ int spasm_hip_dschur(const spasm_hip_dcsr *A, const int *d_rows, int nrows, cons
 	const int cus = cu_count();
 	// tests: 1 = start at the large LDS table, 2 = dense accumulators only.  The large table is otherwise
 	// skipped (one wave per CU: slower than the dense tier) unless SPASM_HIP_USE_BIG_TABLE=1.
-	const int force_tier = env_int("SPASM_HIP_FORCE_TIER", 0);
+	int force_tier = env_int("SPASM_HIP_FORCE_TIER", 0);
+	if (Lout != nullptr)
+		force_tier = 2;         // rows must not be restarted once coefficients have been recorded: no LDS tiers
 	const bool use_big = (force_tier == 1) || env_int("SPASM_HIP_USE_BIG_TABLE", 0);
 
 	// row-group kernel (64 consecutive rows per wave, label-major state) for every row: default for
@@ -447,8 +459,8 @@ int spasm_hip_dschur(const spasm_hip_dcsr *A, const int *d_rows, int nrows, cons
 	int group_mode = env_int("SPASM_HIP_GROUP", -1);
 	bool probe = false;            // auto: run a few groups first and look at their lane efficiency
 	if (group_mode < 0) {
-		group_mode = (nrows >= 64 * 32 && force_tier == 0) ? 1 : 0;
-		probe = group_mode && nrows >= env_int("SPASM_HIP_GROUP_WATCH_ROWS", 64 * 256);
+		group_mode = (nrows >= 64 * 32 && (force_tier == 0 || Lout != nullptr)) ? 1 : 0;
+		probe = group_mode && Lout == nullptr && nrows >= env_int("SPASM_HIP_GROUP_WATCH_ROWS", 64 * 256);
 	}
 	int group_slots = 0;
 	i64 group_slot_bytes = 0, group_off_bm = 0;
@@ -519,6 +531,14 @@ int spasm_hip_dschur(const spasm_hip_dcsr *A, const int *d_rows, int nrows, cons
 	a.row_len = W->d_row_len;
 	a.ctr = W->d_ctr;
 	a.ctr64 = W->d_ctr64;
+	if (Lout != nullptr) {
+		a.L_i = Lout->Li;
+		a.L_j = Lout->Lj;
+		a.L_x = Lout->Lx;
+		a.L_cap = Lout->cap;
+		a.kof = F->d_kof;
+		a.row_orig = Lout->row_orig;
+	}
 
 	if (nrows > 0) {
 		// tier 0: small LDS table, many waves per CU
@@ -599,7 +619,9 @@ eliminated:
 	HIP_CHECK(hipStreamSynchronize(stream));
 	W->last_rows = nrows;
 	W->last_nnz = total;
-	const int status = (ctr[CTR_STATUS] & 1) ? 1 : 0;
+	const int status = ctr[CTR_STATUS] & 3;      // bit 0: row pool exhausted, bit 1: L pool exhausted
+	if (Lout != nullptr)
+		Lout->used = (i64) ctr64[C64_LPOOL];
 	if (stats != nullptr) {
 		stats->nnz = total;
 		stats->eliminations = (i64) ctr64[C64_ELIM];
@@ -627,6 +649,15 @@ eliminated:
 	}
 	return status;
 }
+}  // namespace
+
+extern "C" {
+
+int spasm_hip_dschur(const spasm_hip_dcsr *A, const int *d_rows, int nrows, const spasm_hip_dfact *F,
+                     spasm_hip_dwork *W, void *stream, spasm_hip_schur_stats *stats)
+{
+	return dschur_impl(A, d_rows, nrows, F, W, stream, stats, nullptr);
+}
 
 void spasm_hip_dschur_fetch(const spasm_hip_dwork *W, i64 *d_Sp, int *d_Sj, spasm_ZZp *d_Sx, void *stream_)
 {
@@ -649,8 +680,6 @@ struct spasm_csr *spasm_hip_schur(const struct spasm_csr *A, const int *p, int n
 		die("spasm_hip_schur: no HIP device (this library has no CPU path)");
 	if (p == nullptr)
 		die("spasm_hip_schur: the row list p must not be NULL");
-	if (L != nullptr)
-		die("spasm_hip_schur: recording L on the GPU path is not available yet; run with opts->L = 0");
 	const int m = A->m;
 	const i64 prime = A->field->p;
 	const double t0 = wtime();
@@ -681,21 +710,80 @@ struct spasm_csr *spasm_hip_schur(const struct spasm_csr *A, const int *p, int n
 	spasm_hip_schur_stats st{};
 	spasm_hip_dwork *W = nullptr;
 	const double t1 = wtime();
+	// L requested: pools for the elimination coefficients, grown on demand
+	LOut lout;
+	i64 lcap = (L != nullptr) ? std::max<i64>(16 * in_nnz, (i64) 1 << 24) : 0;
+	int *d_row_orig = nullptr;
+	if (L != nullptr) {
+		std::vector<int> ro((size_t) (n > 0 ? n : 1));
+		for (int k = 0; k < n; k++)
+			ro[k] = (p_in != nullptr) ? p_in[p[k]] : p[k];
+		d_row_orig = dalloc<int>(n);
+		upload(d_row_orig, ro.data(), n, stream);
+		HIP_CHECK(hipStreamSynchronize(stream));
+	}
 	for (;;) {
+		if (L != nullptr) {
+			lout.row_orig = d_row_orig;
+			lout.cap = lcap;
+			lout.Li = dalloc<int>(lcap);
+			lout.Lj = dalloc<int>(lcap);
+			lout.Lx = dalloc<int>(lcap);
+			HIP_CHECK(hipMemsetAsync(lout.Li, 0xFF, (size_t) lcap * sizeof(int), stream));
+		}
 		W = spasm_hip_dwork_create(n, m, pool);
 		// one-shot call: allocating tens of GB costs more than the kernel gains from having every
 		// row group resident at once (hipMalloc is ~30 ms per GB); the device-level API keeps its
 		// workspace and takes the large budget
 		W->scratch_budget = (i64) 24 << 30;
 		scratch_adopt(W);
-		if (spasm_hip_dschur(&dA, drows, n, F, W, stream, &st) == 0)
+		const int rc = dschur_impl(&dA, drows, n, F, W, stream, &st, (L != nullptr) ? &lout : nullptr);
+		if (rc == 0)
 			break;
 		scratch_park(W);
 		spasm_hip_dwork_destroy(W);
-		if (pool >= pool_max)
-			die("spasm_hip_schur: pool of %" PRId64 " entries still too small", pool);
-		pool = std::min(pool_max, 2 * pool + m);
-		logmsg("[schur/hip] pool too small, retrying with %" PRId64 " entries\n", pool);
+		if (L != nullptr) {
+			(void) hipFree(lout.Li);
+			(void) hipFree(lout.Lj);
+			(void) hipFree(lout.Lx);
+		}
+		if (rc & 1) {
+			if (pool >= pool_max)
+				die("spasm_hip_schur: pool of %" PRId64 " entries still too small", pool);
+			pool = std::min(pool_max, 2 * pool + m);
+			logmsg("[schur/hip] pool too small, retrying with %" PRId64 " entries\n", pool);
+		}
+		if (rc & 2) {
+			lcap *= 4;
+			logmsg("[schur/hip] L pool too small, retrying with %" PRId64 " entries\n", lcap);
+		}
+	}
+	if (L != nullptr) {
+		// bring the coefficient triplets back; slots never written still hold -1
+		const i64 used = std::min(lout.used, lcap);
+		std::vector<int> hi((size_t) (used > 0 ? used : 1)), hj((size_t) (used > 0 ? used : 1)), hx((size_t) (used > 0 ? used : 1));
+		if (used > 0) {
+			HIP_CHECK(hipMemcpy(hi.data(), lout.Li, (size_t) used * sizeof(int), hipMemcpyDeviceToHost));
+			HIP_CHECK(hipMemcpy(hj.data(), lout.Lj, (size_t) used * sizeof(int), hipMemcpyDeviceToHost));
+			HIP_CHECK(hipMemcpy(hx.data(), lout.Lx, (size_t) used * sizeof(int), hipMemcpyDeviceToHost));
+		}
+		i64 extra = 0;
+		for (i64 t = 0; t < used; t++)
+			extra += hi[t] >= 0;
+		if (L->nz + extra > L->nzmax)
+			spasm_hip_triplet_realloc(L, 2 * L->nzmax + extra);
+		for (i64 t = 0; t < used; t++) {
+			if (hi[t] < 0)
+				continue;
+			L->i[L->nz] = hi[t];
+			L->j[L->nz] = hj[t];
+			L->x[L->nz] = hx[t];
+			L->nz += 1;
+		}
+		(void) hipFree(lout.Li);
+		(void) hipFree(lout.Lj);
+		(void) hipFree(lout.Lx);
+		(void) hipFree(d_row_orig);
 	}
 	const double t_run = wtime() - t1;
 	const double t2 = wtime();

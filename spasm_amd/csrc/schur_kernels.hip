@@ -21,6 +21,45 @@ constexpr int POOL_CHUNK = 2048;        // entries reserved from the pool at a t
 
 __device__ __forceinline__ uint64_t lanes_below(int lane) { return (1ull << lane) - 1ull; }
 
+// L factor: append (row, pivot index, coefficient) for the lanes that have one.  Space comes from a
+// per-wave arena refilled from the pool 4096 entries at a time; status bit 1 (value 2) = pool exhausted.
+struct LArena {
+	int64_t off = 0;
+	int left = 0;
+};
+
+__device__ __forceinline__ void record_L(const SchurArgs &a, LArena &ar, bool has, int row, uint32_t label, uint32_t v,
+                                         int lane, const MontDev &F)
+{
+	const uint64_t mask = __ballot(has);
+	const int cnt = __popcll(mask);
+	if (cnt == 0)
+		return;
+	if (cnt > ar.left) {
+		unsigned long long got = 0;
+		if (lane == 0)
+			got = atomicAdd(&a.ctr64[C64_LPOOL], 4096ull);
+		const uint32_t lo = __builtin_amdgcn_readfirstlane((uint32_t) got);
+		const uint32_t hi = __builtin_amdgcn_readfirstlane((uint32_t) (got >> 32));
+		ar.off = (int64_t) (((uint64_t) hi << 32) | lo);
+		ar.left = 4096;
+		if (ar.off + 4096 > a.L_cap) {
+			ar.left = 0;
+			if (lane == 0)
+				atomicOr(&a.ctr[CTR_STATUS], 2);
+			return;
+		}
+	}
+	if (has) {
+		const int64_t dst = ar.off + __popcll(mask & ((1ull << lane) - 1ull));
+		a.L_i[dst] = row;
+		a.L_j[dst] = a.kof[label];
+		a.L_x[dst] = (v > F.half) ? (int) (v - F.p) : (int) v;
+	}
+	ar.off += cnt;
+	ar.left -= cnt;
+}
+
 __device__ __forceinline__ int wave_exclusive_scan(int v, int lane, int &total)
 {
 	int x = v;
@@ -681,6 +720,7 @@ __global__ __launch_bounds__(64) void schur_wave_dense_kernel(WaveDenseArgs d)
 
 	unsigned long long st_elim = 0, st_stream = 0, st_input = 0;
 	int st_done = 0;
+	LArena larena;
 
 	for (;;) {
 		int kk = 0;
@@ -691,6 +731,7 @@ __global__ __launch_bounds__(64) void schur_wave_dense_kernel(WaveDenseArgs d)
 			break;
 		const int k = (a.list != nullptr) ? a.list[kk] : kk;
 		const int i = a.rows[k];
+		const int row_to_record = (a.L_i != nullptr) ? a.row_orig[k] : 0;
 
 		// ---- scatter the input row ----
 		const int64_t lo = a.Ap[i], hi = a.Ap[i + 1];
@@ -753,6 +794,8 @@ __global__ __launch_bounds__(64) void schur_wave_dense_kernel(WaveDenseArgs d)
 					len = 0;
 				const uint32_t w_neg = F.p - v;
 				st_elim += (unsigned long long) __popcll(__ballot(v != 0));
+				if (a.L_i != nullptr)
+					record_L(a, larena, v != 0, row_to_record, c, v, lane, F);
 				int ftot;
 				const int excl = wave_exclusive_scan(len, lane, ftot);
 				st_stream += (unsigned long long) ftot;
@@ -968,6 +1011,7 @@ __global__ __launch_bounds__(64) void schur_group_kernel(GroupArgs d)
 
 	unsigned long long st_elim = 0, st_stream = 0, st_input = 0, st_wavepiv = 0;
 	int st_done = 0;
+	LArena larena;
 
 	for (;;) {
 		int g = 0;
@@ -985,6 +1029,7 @@ __global__ __launch_bounds__(64) void schur_group_kernel(GroupArgs d)
 		}
 		const int k = g * 64 + lane;
 		const bool have_row = k < a.nrows;
+		const int row_to_record = (a.L_i != nullptr && have_row) ? a.row_orig[k] : 0;
 
 		// ---- scatter the 64 input rows (each lane its own) ----
 		if (have_row) {
@@ -1132,6 +1177,8 @@ __global__ __launch_bounds__(64) void schur_group_kernel(GroupArgs d)
 						const int nact = __popcll(active);
 						st_wavepiv += 1;
 						st_elim += (unsigned long long) nact;
+						if (a.L_i != nullptr)
+							record_L(a, larena, v != 0, row_to_record, cc[u], v, lane, F);
 						st_stream += (unsigned long long) nact * (unsigned long long) len[u];
 						const uint32_t w_neg = F.p - v;
 						const uint64_t s0 = start[u];

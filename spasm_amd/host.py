@@ -99,8 +99,9 @@ def pivots_extract_structural(A, F, greedy=True):
     return npiv, p[:A.n], out
 
 
-def schur(A, p, F, p_in=None):
-    """spasm_schur (spasm_schur.c:64) on the GPU: returns (S, p_out)."""
+def schur(A, p, F, p_in=None, want_L=False):
+    """spasm_schur (spasm_schur.c:64) on the GPU: returns (S, p_out), or (S, p_out, (Li, Lj, Lx)) with
+    want_L: the elimination coefficients as triplets (row, index of the pivot row in U, value)."""
     require_gpu("schur")
     L = lib()
     a = view_csr(A)
@@ -109,11 +110,18 @@ def schur(A, p, F, p_in=None):
     n = len(p)
     p_out = np.zeros(max(n, 1), np.int32)
     pin = _ip(np.ascontiguousarray(p_in, np.int32)) if p_in is not None else None
-    s = L.spasm_hip_schur(C.byref(a), _ip(p), n, C.byref(lu), -1.0, None, pin, _ip(p_out))
+    T = L.spasm_hip_triplet_alloc(max(A.n, 1), max(F.U.n, 1), 16, A.prime, True) if want_L else None
+    s = L.spasm_hip_schur(C.byref(a), _ip(p), n, C.byref(lu), -1.0, T, pin, _ip(p_out))
     S = copy_csr(s)
     L.spasm_hip_csr_free(s)
     L.spasm_hip_csr_free(up)
-    return S, p_out[:n]
+    if not want_L:
+        return S, p_out[:n]
+    t = T.contents
+    nz = int(t.nz)
+    trip = tuple(np.ctypeslib.as_array(arr, shape=(max(nz, 1),))[:nz].copy() for arr in (t.i, t.j, t.x))
+    L.spasm_hip_triplet_free(T)
+    return S, p_out[:n], trip
 
 
 SPASM_DOUBLE, SPASM_FLOAT, SPASM_I64 = 0, 1, 2      # spasm_datatype (spasm.h:139)

@@ -201,3 +201,24 @@ def test_row_group_kernel_gives_up_on_unrelated_rows(oracle, monkeypatch):
     assert st.rows_lds + st.rows_lds_big + st.rows_dense == len(rows)
     H = S.to_host()
     assert oracle.same_matrix(oracle.CSR(H.n, H.m, H.p, H.j, H.x, p), want)
+
+
+def _triplet_set(trip, p):
+    return sorted(zip(trip[0].tolist(), trip[1].tolist(), (np.asarray(trip[2], np.int64) % p).tolist()))
+
+
+@pytest.mark.parametrize("group", ["0", "1"])
+@pytest.mark.parametrize("name", ["mat364.sms", "medium.sms", "m1.sms", "singular.sms", "small.sms", "G2.sms", "void.sms"])
+@pytest.mark.parametrize("p", [257, 42013, 4294967291])
+def test_schur_records_L(oracle, name, p, group, monkeypatch):
+    """the elimination coefficients (L parameter of spasm_schur, spasm_schur.c:160-167): same triplets."""
+    monkeypatch.setenv("SPASM_HIP_GROUP", group)
+    A, npiv, perm, F = _round0(oracle, name, p)
+    rows = perm[npiv:]
+    p_in = np.arange(A.n, dtype=np.int32)[::-1].copy()            # a non-trivial row relabelling
+    want, p_out_want, L_want = oracle.schur(A, rows, F, p_in=p_in, want_L=True)
+    S, p_out, L_got = spasm_amd.schur(_as_product(A), rows, _fact(F), p_in=p_in, want_L=True)
+    _check(oracle, S, p_out, want, p_out_want)
+    assert _triplet_set(L_got, p) == _triplet_set(L_want, p)
+    P = p
+    assert np.all(L_got[2] <= P // 2) and np.all(L_got[2] >= -(P // 2))
