@@ -275,8 +275,20 @@ extern "C" struct spasm_lu *spasm_hip_echelonize(const struct spasm_csr *A0, str
 		spasm_hip_echelonize_init_opts(&dflt);
 		opts = &dflt;
 	}
-	if (opts->L || opts->complete)
-		die("spasm_hip_echelonize: computing L on the GPU path is not available yet (opts->L / opts->complete)");
+	struct echelonize_opts local = *opts;
+	opts = &local;
+	if (opts->complete)
+		opts->L = 1;
+	if (opts->L) {
+		// L is recorded by the structural rounds (pivot extraction + Schur complements on the GPU).  The
+		// dense finishing modes would need a dense PLUQ with an explicit L (spasm_ffpack_LU), which is not
+		// on the GPU yet: with L the remainder always goes through further structural rounds.  Every row
+		// is carried to the end, so the factorization is complete (A == L*U) whatever opts->complete says.
+		opts->enable_tall_and_skinny = 0;
+		opts->enable_dense = 0;
+		opts->enable_GPLU = 1;
+		logmsg("[echelonize] L requested: dense finishing modes disabled, structural rounds only\n");
+	}
 	const struct spasm_csr *A = A0;
 	int n = A->n;
 	const int m = A->m;
@@ -294,6 +306,12 @@ extern "C" struct spasm_lu *spasm_hip_echelonize(const struct spasm_csr *A0, str
 	fact->qinv = Uqinv;
 	fact->Ltmp = nullptr;
 	fact->complete = false;
+	if (opts->L) {
+		fact->Ltmp = spasm_hip_triplet_alloc(n, n, A->p[A->n] + 16, prime, true);
+		fact->p = (int *) xmalloc((i64) (n > 0 ? n : 1) * sizeof(int));
+		for (int j = 0; j < n; j++)
+			fact->p[j] = -1;
+	}
 
 	int *p = (int *) xmalloc((i64) n * sizeof(int));
 	int *p_in = nullptr;
@@ -321,7 +339,7 @@ extern "C" struct spasm_lu *spasm_hip_echelonize(const struct spasm_csr *A0, str
 		}
 		logmsg("[echelonize] Schur complement is %d x %d, estimated density : %.4f\n", n - npiv, m - U->n, density);
 		int *p_out = (int *) xmalloc((i64) (n - npiv) * sizeof(int));
-		struct spasm_csr *S = spasm_hip_schur(A, p + npiv, n - npiv, fact, density, nullptr, p_in, p_out);
+		struct spasm_csr *S = spasm_hip_schur(A, p + npiv, n - npiv, fact, density, fact->Ltmp, p_in, p_out);
 		if (A != A0)
 			spasm_hip_csr_free((struct spasm_csr *) A);
 		A = S;
@@ -365,7 +383,7 @@ extern "C" struct spasm_lu *spasm_hip_echelonize(const struct spasm_csr *A0, str
 					break;
 				}
 				int *p_out = (int *) xmalloc((i64) (n - npiv) * sizeof(int));
-				struct spasm_csr *S = spasm_hip_schur(A, p + npiv, n - npiv, fact, density, nullptr, p_in, p_out);
+				struct spasm_csr *S = spasm_hip_schur(A, p + npiv, n - npiv, fact, density, fact->Ltmp, p_in, p_out);
 				if (A != A0)
 					spasm_hip_csr_free((struct spasm_csr *) A);
 				A = S;
@@ -386,6 +404,15 @@ extern "C" struct spasm_lu *spasm_hip_echelonize(const struct spasm_csr *A0, str
 	spasm_hip_csr_realloc(U, -1);
 	if (A != A0)
 		spasm_hip_csr_free((struct spasm_csr *) A);
+	if (opts->L) {
+		fact->Ltmp->n = A0->n;
+		fact->Ltmp->m = U->n;
+		fact->p = (int *) xrealloc(fact->p, (i64) (U->n > 0 ? U->n : 1) * sizeof(int));
+		fact->L = spasm_hip_compress(fact->Ltmp);
+		spasm_hip_triplet_free(fact->Ltmp);
+		fact->Ltmp = nullptr;
+		fact->complete = true;
+	}
 	fact->r = U->n;
 	return fact;
 }

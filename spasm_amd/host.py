@@ -172,8 +172,13 @@ def echelonize(A, opts=None):
     s = lu.contents
     U = copy_csr(s.U)
     qinv = np.ctypeslib.as_array(s.qinv, shape=(max(A.m, 1),))[:A.m].copy()
+    F = Fact(U, qinv)
+    F.L, F.Lp = None, None
+    if bool(s.L):                       # opts.L: A == L * U, pivot j of L sits on row Lp[j]
+        F.L = copy_csr(s.L)
+        F.Lp = np.ctypeslib.as_array(s.p, shape=(max(U.n, 1),))[:U.n].copy()
     L.spasm_hip_lu_free(lu)
-    return Fact(U, qinv)
+    return F
 
 
 def rref(F):

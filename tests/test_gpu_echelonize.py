@@ -98,3 +98,24 @@ def test_rref_and_kernel(oracle, name, p):
         from test_oracle import numpy_rank
         if p < 2**31:
             assert numpy_rank(np.array(Kd, dtype=np.int64), p) == K.n
+
+
+@pytest.mark.parametrize("name", SMALL_SET + ["mat364.sms", "medium.sms"])
+@pytest.mark.parametrize("p", [257, 42013, 4294967291])
+def test_echelonize_with_L(oracle, name, p):
+    """opts.L: the factorization is returned too and A == L * U (what tests/lu.c checks)."""
+    A = oracle.load_sms(matrix_path(name), p)
+    o = spasm_amd.default_opts()
+    o.L = True
+    F = spasm_amd.echelonize(_as_product(A), o)
+    assert F.U.n == oracle.echelonize(A).U.n
+    _check_echelon(oracle, A, F)
+    if A.n == 0 or A.m == 0:
+        return
+    assert F.L is not None and (F.L.n, F.L.m) == (A.n, F.U.n)
+    Ld = _as_oracle(oracle, F.L).to_dense().astype(object)
+    Ud = _as_oracle(oracle, F.U).to_dense().astype(object)
+    Ad = A.to_dense().astype(object)
+    assert not np.any((Ld.dot(Ud) - Ad) % p)
+    for j in range(F.U.n):                   # the pivot of column j of L sits on row Lp[j]
+        assert Ld[F.Lp[j], j] % p != 0
