@@ -145,7 +145,8 @@ int spasm_hip_pivots_extract_structural(const struct spasm_csr *A, const int *p_
 /* replaces spasm_schur (spasm_schur.c:64-193).  Row k of the result is the
  * reduction of row p[k] of A (the reference emits rows in thread-arrival
  * order and records the mapping in p_out; here the order is always p's).
- * Entries of a row are sorted by column. */
+ * Entries of a row are sorted by column.  L != NULL: the elimination coefficients are appended to L
+ * as (p_in[row] or row, index of the pivot row in U, coefficient), like the reference. */
 struct spasm_csr *spasm_hip_schur(const struct spasm_csr *A, const int *p, int n, const struct spasm_lu *fact,
                                   double est_density, struct spasm_triplet *L, const int *p_in, int *p_out);
 
