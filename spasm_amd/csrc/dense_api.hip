@@ -114,6 +114,7 @@ int spasm_hip_dschur_dense(const spasm_hip_dcsr *A, const int *d_rows, int nrows
 	a.q = F->d_q;
 	a.rp = F->d_rp;
 	a.ent = F->d_ent;
+	a.head = F->d_head;
 	a.lvl_end = F->d_lvl_end;
 	a.lvl_end_w = F->d_lvl_end_w;
 	a.r = F->rpad;

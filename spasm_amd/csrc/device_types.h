@@ -63,6 +63,7 @@ struct SchurArgs {
 	const int *q;             // label - r -> column
 	const uint64_t *rp;       // r + 1 offsets into ent
 	const uint2 *ent;         // (label, value * R mod p)
+	const uint2 *head;        // label * 4: first four entries of the row (0xFFFFFFFF-padded)
 	const uint32_t *lvl_end;  // label -> end of its level
 	const uint32_t *lvl_end_w;// 32-label word -> first word of the next level
 	int r;                    // size of the (padded) pivot label space; labels >= r are non-pivotal
@@ -104,6 +105,7 @@ struct spasm_hip_dfact {
 	int *d_q = nullptr;
 	uint64_t *d_rp = nullptr;
 	uint2 *d_ent = nullptr;
+	uint2 *d_head = nullptr;
 	uint32_t *d_lvl_end = nullptr;
 	uint32_t *d_lvl_end_w = nullptr;
 	int *d_kof = nullptr;          // label -> row of U (-1: padding label)

@@ -117,6 +117,7 @@ struct FactPlan {
 	std::vector<int> q, kof, label_of_row;  // kof: label -> row of U, -1 for padding labels
 	std::vector<uint64_t> rp;               // rpad + 1
 	std::vector<uint2> ent;
+	std::vector<uint2> head;                // 4 entries per label: the first entries of the row, 0xFFFFFFFF-padded
 };
 
 static void plan_factor(const struct spasm_csr *U, const int *qinv, FactPlan &P)
@@ -290,6 +291,14 @@ static void plan_factor(const struct spasm_csr *U, const int *qinv, FactPlan &P)
 	P.rp[rpad] = (uint64_t) w;
 	for (int j = 0; j < m; j++)
 		P.maxdeg = std::max(P.maxdeg, deg[j]);
+	// the first four entries of every row again, at a fixed place (label * 4): the row-group kernel
+	// fetches them together with the accumulator line, without waiting for the row extent
+	P.head.assign((size_t) (rpad > 0 ? rpad : 1) * 4, uint2{0xFFFFFFFFu, 0u});
+	for (int c = 0; c < rpad; c++) {
+		const uint64_t len = P.rp[c + 1] - P.rp[c];
+		for (uint64_t t = 0; t < len && t < 4; t++)
+			P.head[(size_t) c * 4 + t] = P.ent[P.rp[c] + t];
+	}
 }
 
 // CPU-only view of the plan, for tests: label of each row of U, end of the
@@ -336,6 +345,8 @@ spasm_hip_dfact *spasm_hip_dfact_create(const struct spasm_csr *U, const int *qi
 	F->d_q = dalloc<int>(m - r);
 	F->d_rp = dalloc<uint64_t>(rpad + 1);
 	F->d_ent = dalloc<uint2>(F->nnz);
+	F->d_head = dalloc<uint2>((i64) rpad * 4);
+	upload(F->d_head, P.head.data(), (i64) rpad * 4, stream);
 	F->d_lvl_end = dalloc<uint32_t>(rpad);
 	F->d_lvl_end_w = dalloc<uint32_t>(rpad / 32);
 	F->d_kof = dalloc<int>(rpad);
@@ -358,6 +369,7 @@ void spasm_hip_dfact_destroy(spasm_hip_dfact *F)
 	(void) hipFree(F->d_q);
 	(void) hipFree(F->d_rp);
 	(void) hipFree(F->d_ent);
+	(void) hipFree(F->d_head);
 	(void) hipFree(F->d_lvl_end);
 	(void) hipFree(F->d_lvl_end_w);
 	(void) hipFree(F->d_kof);
@@ -518,6 +530,7 @@ int dschur_impl(const spasm_hip_dcsr *A, const int *d_rows, int nrows, const spa
 	a.q = F->d_q;
 	a.rp = F->d_rp;
 	a.ent = F->d_ent;
+	a.head = F->d_head;
 	a.lvl_end = F->d_lvl_end;
 	a.lvl_end_w = F->d_lvl_end_w;
 	a.r = F->rpad;              // kernels only see the padded label space

@@ -957,7 +957,7 @@ namespace sh {
 namespace {
 constexpr int GR_ACT = 512;             // pending labels gathered per pass (GR_ACT / 32 bitmap words)
 constexpr int GR_LBM_MAX_BYTES = 48 * 1024;   // largest pending bitmap kept in LDS
-constexpr int GR_PB = 8;            // pivots whose loads are issued together
+constexpr int GR_PB = 2;            // pivots per trip (their row heads sit in SGPRs: keep it small)
 }
 
 struct GroupArgs {
@@ -986,6 +986,11 @@ __global__ __launch_bounds__(64) void schur_group_kernel(GroupArgs d)
 	const MontDev F = a.F;
 	const int nw = (int) (r / 32);
 	const int ngroups = (a.nrows + 63) / 64;
+
+	typedef const uint32_t __attribute__((address_space(4))) *const_u32_ptr;
+	typedef const uint64_t __attribute__((address_space(4))) *const_u64_ptr;
+	const const_u32_ptr head_k = (const_u32_ptr) (uintptr_t) a.head;
+	const const_u64_ptr rp_k = (const_u64_ptr) (uintptr_t) a.rp;
 
 	unsigned char *slot = d.scratch + (int64_t) blockIdx.x * d.slot_bytes;
 	V *X = reinterpret_cast<V *>(slot);                 // X[label * 64 + lane]
@@ -1131,11 +1136,16 @@ __global__ __launch_bounds__(64) void schur_group_kernel(GroupArgs d)
 
 				// apply them: uniform loop, GR_PB pivots per trip; the loads of trip t+1 (accumulator lines and
 				// row extents) are issued before the entries of trip t are streamed
+				// apply them: uniform loop, GR_PB pivots per trip.  Everything trip t+1 needs is fetched while trip t
+				// is applied: the accumulator lines X[c][lane] (vector loads) and, through the constant address
+				// space (wave-uniform read-only data -> scalar loads, SGPRs), the row extents and the first four
+				// entries of each row, so that the atomics of a trip issue back to back.
 				uint32_t cc[GR_PB], ncc[GR_PB];
 				V raw[GR_PB], nraw[GR_PB];
-				uint64_t start[GR_PB], nstart[GR_PB];
 				int len[GR_PB], nlen[GR_PB];
-				auto fetch = [&](int t0, uint32_t *C, V *R, uint64_t *S, int *L) {
+				uint64_t start[GR_PB], nstart[GR_PB];
+				uint2 hd[GR_PB][4], nhd[GR_PB][4];
+				auto fetch = [&](int t0, uint32_t *C, V *R, uint64_t *S, int *L, uint2 (*H)[4]) {
 #pragma unroll
 					for (int u = 0; u < GR_PB; u++) {
 						const int t = t0 + u;
@@ -1145,14 +1155,22 @@ __global__ __launch_bounds__(64) void schur_group_kernel(GroupArgs d)
 						R[u] = 0;
 						S[u] = 0;
 						L[u] = 0;
+#pragma unroll
+						for (int q = 0; q < 4; q++)
+							H[u][q] = uint2{0xFFFFFFFFu, 0u};
 						if (c != 0xFFFFFFFFu) {
 							R[u] = ld_sc1(&X[(int64_t) c * 64 + lane]);
-							S[u] = a.rp[c];
-							L[u] = (int) (a.rp[c + 1] - S[u]);
+							S[u] = rp_k[c];
+							L[u] = (int) (rp_k[c + 1] - S[u]);
+#pragma unroll
+							for (int q = 0; q < 4; q++) {
+								H[u][q].x = head_k[((int64_t) c * 4 + q) * 2];
+								H[u][q].y = head_k[((int64_t) c * 4 + q) * 2 + 1];
+							}
 						}
 					}
 				};
-				fetch(0, ncc, nraw, nstart, nlen);
+				fetch(0, ncc, nraw, nstart, nlen, nhd);
 				for (int t0 = 0; t0 < tot; t0 += GR_PB) {
 #pragma unroll
 					for (int u = 0; u < GR_PB; u++) {
@@ -1160,9 +1178,12 @@ __global__ __launch_bounds__(64) void schur_group_kernel(GroupArgs d)
 						raw[u] = nraw[u];
 						start[u] = nstart[u];
 						len[u] = nlen[u];
+#pragma unroll
+						for (int q = 0; q < 4; q++)
+							hd[u][q] = nhd[u][q];
 					}
 					if (t0 + GR_PB < tot)
-						fetch(t0 + GR_PB, ncc, nraw, nstart, nlen);
+						fetch(t0 + GR_PB, ncc, nraw, nstart, nlen, nhd);
 #pragma unroll
 					for (int u = 0; u < GR_PB; u++) {
 						if (cc[u] == 0xFFFFFFFFu)
@@ -1177,27 +1198,33 @@ __global__ __launch_bounds__(64) void schur_group_kernel(GroupArgs d)
 						const int nact = __popcll(active);
 						st_wavepiv += 1;
 						st_elim += (unsigned long long) nact;
+						st_stream += (unsigned long long) nact * (unsigned long long) len[u];
 						if (a.L_i != nullptr)
 							record_L(a, larena, v != 0, row_to_record, cc[u], v, lane, F);
-						st_stream += (unsigned long long) nact * (unsigned long long) len[u];
 						const uint32_t w_neg = F.p - v;
 						const uint64_t s0 = start[u];
 						const int L = len[u];
-						for (int e0 = 0; e0 < L; e0 += 4) {
+						auto apply = [&](const uint2 &e) {
+							const uint32_t tgt = e.x;
+							if (v != 0)
+								add_ff(&X[(int64_t) tgt * 64 + lane], montmul(w_neg, e.y, F));
+							if (tgt < r && lane == 0)
+								bm_or(tgt);
+						};
+						// the first four entries came with the fetch; longer rows stream the rest
+#pragma unroll
+						for (int q = 0; q < 4; q++)
+							if (hd[u][q].x != 0xFFFFFFFFu)
+								apply(hd[u][q]);
+						for (int e0 = 4; e0 < L; e0 += 4) {
 							uint2 ent[4];
 #pragma unroll
 							for (int q = 0; q < 4; q++)
 								ent[q] = (e0 + q < L) ? a.ent[s0 + e0 + q] : uint2{0xFFFFFFFFu, 0u};
 #pragma unroll
-							for (int q = 0; q < 4; q++) {
-								if (ent[q].x == 0xFFFFFFFFu)
-									continue;
-								const uint32_t tgt = ent[q].x;
-								if (v != 0)
-									add_ff(&X[(int64_t) tgt * 64 + lane], montmul(w_neg, ent[q].y, F));
-								if (tgt < r && lane == 0)
-									bm_or(tgt);
-							}
+							for (int q = 0; q < 4; q++)
+								if (ent[q].x != 0xFFFFFFFFu)
+									apply(ent[q]);
 						}
 					}
 				}
