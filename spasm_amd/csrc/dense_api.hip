@@ -8,6 +8,7 @@
 namespace sh {
 int device_rref(int64_t prime, int n, int m, uint32_t *dA, int64_t ld, int *d_pivcol, hipStream_t stream, int use_mfma,
                 float *ms_update);
+spasm_hip_dfact *cached_dfact(const struct spasm_csr *U, const int *qinv, hipStream_t stream);
 void launch_combine(const int64_t *Ap, const int *Aj, const int *Ax, const int *rows, int nrows, int N, int w, int m,
                     uint64_t salt, unsigned long long *Y, const Mont &M, hipStream_t stream);
 void launch_dense_count(const unsigned long long *Y, int N, int m, uint32_t p, int *row_len, hipStream_t stream);
@@ -158,7 +159,7 @@ void spasm_hip_schur_dense(const struct spasm_csr *A, const int *p, int n, const
 	const i64 prime = A->field->p;
 	const double t0 = wtime();
 	hipStream_t stream = nullptr;
-	spasm_hip_dfact *F = spasm_hip_dfact_create(fact->U, fact->qinv, stream);
+	spasm_hip_dfact *F = cached_dfact(fact->U, fact->qinv, stream);
 	const int Sm = F->Sm;
 	for (int l = 0; l < Sm; l++)
 		q[l] = F->h_q[l];
@@ -198,7 +199,6 @@ void spasm_hip_schur_dense(const struct spasm_csr *A, const int *p, int n, const
 		(void) hipFree(dAx);
 		(void) hipFree(drows);
 	}
-	spasm_hip_dfact_destroy(F);
 	logmsg("[schur/dense/hip] %d x %d dense rows in %.1fs\n", n, Sm, wtime() - t0);
 }
 
@@ -218,7 +218,7 @@ void spasm_hip_schur_dense_randomized(const struct spasm_csr *A, const int *p, i
 	const i64 prime = A->field->p;
 	const double t0 = wtime();
 	hipStream_t stream = nullptr;
-	spasm_hip_dfact *F = spasm_hip_dfact_create(U, qinv, stream);
+	spasm_hip_dfact *F = cached_dfact(U, qinv, stream);
 	const int Sm = F->Sm;
 	for (int l = 0; l < Sm; l++)
 		q[l] = F->h_q[l];
@@ -281,7 +281,6 @@ void spasm_hip_schur_dense_randomized(const struct spasm_csr *A, const int *p, i
 		(void) hipFree(dAx);
 		(void) hipFree(drows);
 	}
-	spasm_hip_dfact_destroy(F);
 	logmsg("[schur/dense/random/hip] %d combinations (weight %d) of %d rows, %d columns, %.1fs\n", N, w, n, Sm, wtime() - t0);
 }
 

@@ -88,6 +88,50 @@ int cu_count()
 
 }  // namespace
 
+// ---- one-entry cache of the factor image for the host-pointer wrappers -------------------------
+// A round of the driver calls spasm_hip_schur_estimate_density, spasm_hip_schur and the dense-row
+// functions on the same (U, qinv): planning + uploading the image once is enough.  The key is the
+// shape of U plus a checksum of qinv and of the row pointers (U only ever grows).
+namespace sh {
+struct FactCacheKey {
+	const void *Uj = nullptr;
+	int n = -1, m = -1;
+	i64 nnz = -1, prime = -1;
+	uint64_t sum = 0;
+	bool operator==(const FactCacheKey &o) const
+	{
+		return Uj == o.Uj && n == o.n && m == o.m && nnz == o.nnz && prime == o.prime && sum == o.sum;
+	}
+};
+static FactCacheKey g_fact_key;
+static spasm_hip_dfact *g_fact = nullptr;
+
+spasm_hip_dfact *cached_dfact(const struct spasm_csr *U, const int *qinv, hipStream_t stream)
+{
+	FactCacheKey key;
+	key.Uj = U->j;
+	key.n = U->n;
+	key.m = U->m;
+	key.nnz = U->p[U->n];
+	key.prime = U->field->p;
+	uint64_t h = 1469598103934665603ULL;
+	for (int j = 0; j < U->m; j++)
+		h = (h ^ (uint64_t) (uint32_t) qinv[j]) * 1099511628211ULL;
+	for (int i = 0; i <= U->n; i += (U->n > 4096 ? U->n / 4096 : 1))
+		h = (h ^ (uint64_t) U->p[i]) * 1099511628211ULL;
+	for (i64 t = 0; t < key.nnz; t += (key.nnz > 8192 ? key.nnz / 8192 : 1))
+		h = (h ^ ((uint64_t) (uint32_t) U->j[t] << 32 | (uint32_t) U->x[t])) * 1099511628211ULL;
+	key.sum = h;
+	if (g_fact != nullptr && key == g_fact_key)
+		return g_fact;
+	if (g_fact != nullptr)
+		spasm_hip_dfact_destroy(g_fact);
+	g_fact = spasm_hip_dfact_create(U, qinv, stream);
+	g_fact_key = key;
+	return g_fact;
+}
+}  // namespace sh
+
 extern "C" {
 
 int spasm_hip_debug_plan(const struct spasm_csr *U, const int *qinv, int *label_of_row, int *lvl_end_of_row, int *lab,
@@ -697,7 +741,7 @@ struct spasm_csr *spasm_hip_schur(const struct spasm_csr *A, const int *p, int n
 	const i64 prime = A->field->p;
 	const double t0 = wtime();
 	hipStream_t stream = nullptr;
-	spasm_hip_dfact *F = spasm_hip_dfact_create(fact->U, fact->qinv, stream);
+	spasm_hip_dfact *F = cached_dfact(fact->U, fact->qinv, stream);
 	const double t_fact = wtime() - t0;
 	// device image of A and of the row list
 	const i64 annz = A->p[A->n];
@@ -817,7 +861,6 @@ struct spasm_csr *spasm_hip_schur(const struct spasm_csr *A, const int *p, int n
 	(void) hipFree(dAj);
 	(void) hipFree(dAx);
 	(void) hipFree(drows);
-	spasm_hip_dfact_destroy(F);
 	const double density = (n > 0 && m > 0) ? (double) st.nnz / ((double) m * n) : 0.0;
 	logmsg("Schur complement: %d * %d [%" PRId64 " nz / density= %.3f], %.1fs (GPU kernels %.1f ms; tiers %d/%d/%d; "
 	       "factor image %.2fs, alloc+run %.2fs, download %.2fs, free %.2fs)\n", n, m, st.nnz, density, wtime() - t0,
