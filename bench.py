@@ -264,6 +264,14 @@ def main():
                                             ("row_group" if group else "wave_dense"): rows_by_tier[2]},
                          "lane_efficiency": (k_elim / (64.0 * k_gp)) if (group and k_gp) else None},
         }
+        if world == 1:
+            # the other half of the headline metric: wall-clock time of the whole rank computation
+            # (host I/O excluded: the matrix is already in memory), default options of tools/rank
+            os.environ.pop("SPASM_HIP_THREADS", None)
+            t0 = time.perf_counter()
+            fact = spasm_amd.echelonize(A)
+            out["end_to_end"] = {"what": "spasm_hip_echelonize on the same matrix, default options", "rank": int(fact.U.n),
+                                 "seconds": time.perf_counter() - t0}
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(A, rows, F)
         print(json.dumps(out))
