@@ -61,6 +61,7 @@ def lib():
         "spasm_hip_schur_estimate_density": (C.c_double, [pcsr, pint, ci, pcsr, pint, ci]),
         "spasm_hip_schur_dense": (None, [pcsr, pint, ci, pint, plu, vp, ci, pint, pint]),
         "spasm_hip_ffpack_rref": (ci, [i64, ci, ci, vp, ci, ci, C.POINTER(C.c_size_t)]),
+        "spasm_hip_ffpack_LU": (ci, [i64, ci, ci, vp, ci, ci, C.POINTER(C.c_size_t), C.POINTER(C.c_size_t)]),
         "spasm_hip_dschur_dense": (ci, [C.POINTER(CDcsr), vp, ci, vp, vp, vp, i64, vp]),
         "spasm_hip_drref": (ci, [i64, ci, ci, vp, i64, vp, vp]),
         "spasm_hip_drref_timed": (ci, [i64, ci, ci, vp, i64, vp, vp, ci, C.POINTER(C.c_float)]),

@@ -8,6 +8,7 @@
 namespace sh {
 int device_rref(int64_t prime, int n, int m, uint32_t *dA, int64_t ld, int *d_pivcol, hipStream_t stream, int use_mfma,
                 float *ms_update);
+int device_lu(int64_t prime, int n, int m, uint32_t *dA, int64_t ld, int *dP, int *dQ, hipStream_t stream);
 spasm_hip_dfact *cached_dfact(const struct spasm_csr *U, const int *qinv, hipStream_t stream);
 void launch_combine(const int64_t *Ap, const int *Aj, const int *Ax, const int *rows, int nrows, int N, int w, int m,
                     uint64_t salt, unsigned long long *Y, const Mont &M, hipStream_t stream);
@@ -59,8 +60,12 @@ int spasm_hip_drref_timed(i64 prime, int n, int m, u32 *d_A, i64 ld, int *d_pivc
 	return device_rref(prime, n, m, d_A, ld, d_pivcol, (hipStream_t) stream, use_mfma, ms_update);
 }
 
-int spasm_hip_dschur_dense(const spasm_hip_dcsr *A, const int *d_rows, int nrows, const spasm_hip_dfact *F,
-                           spasm_hip_dwork *W, u32 *d_S, i64 ldS, void *stream_)
+}  // extern "C"
+
+// dense rows; Lout != nullptr: also record the elimination coefficients.  Returns the status bits of
+// the kernels (2 = L pool exhausted).
+static int dschur_dense_impl(const spasm_hip_dcsr *A, const int *d_rows, int nrows, const spasm_hip_dfact *F,
+                             spasm_hip_dwork *W, u32 *d_S, i64 ldS, void *stream_, LOut *Lout)
 {
 	hipStream_t stream = (hipStream_t) stream_;
 	if (nrows > W->max_rows)
@@ -135,14 +140,36 @@ int spasm_hip_dschur_dense(const spasm_hip_dcsr *A, const int *d_rows, int nrows
 	a.next_ctr = CTR_ROW_NEXT3;
 	a.ovf_ctr = CTR_OVF2;
 	a.done_ctr = CTR_DONE2;
+	if (Lout != nullptr) {
+		a.L_i = Lout->Li;
+		a.L_j = Lout->Lj;
+		a.L_x = Lout->Lx;
+		a.L_cap = Lout->cap;
+		a.kof = F->d_kof;
+		a.row_orig = Lout->row_orig;
+	}
 	if (group_mode) {
 		a.next_ctr = CTR_ROW_NEXT_G;
 		launch_schur_group(a, W->d_scratch, gslot, goff, wide, d_S, ldS, gslots, stream, 0, 0.0f, 0);
 	} else {
 		launch_schur_wave_dense(a, W->d_scratch, slot_bytes, off_bm, off_xn, wide, d_S, ldS, slots, stream);
 	}
+	int ctr[CTR_COUNT];
+	unsigned long long ctr64[C64_COUNT];
+	HIP_CHECK(hipMemcpyAsync(ctr, W->d_ctr, sizeof(ctr), hipMemcpyDeviceToHost, stream));
+	HIP_CHECK(hipMemcpyAsync(ctr64, W->d_ctr64, sizeof(ctr64), hipMemcpyDeviceToHost, stream));
 	HIP_CHECK(hipStreamSynchronize(stream));
-	return 0;
+	if (Lout != nullptr)
+		Lout->used = (i64) ctr64[C64_LPOOL];
+	return ctr[CTR_STATUS] & 2;
+}
+
+extern "C" {
+
+int spasm_hip_dschur_dense(const spasm_hip_dcsr *A, const int *d_rows, int nrows, const spasm_hip_dfact *F,
+                           spasm_hip_dwork *W, u32 *d_S, i64 ldS, void *stream)
+{
+	return dschur_dense_impl(A, d_rows, nrows, F, W, d_S, ldS, stream, nullptr);
 }
 
 // --------------------------------------------------------------------------
@@ -153,8 +180,6 @@ void spasm_hip_schur_dense(const struct spasm_csr *A, const int *p, int n, const
 {
 	if (spasm_hip_device_count() == 0)
 		die("spasm_hip_schur_dense: no HIP device (this library has no CPU path)");
-	if (fact->Ltmp != nullptr)
-		die("spasm_hip_schur_dense: recording L on the GPU path is not available yet; run with opts->L = 0");
 	const int m = A->m;
 	const i64 prime = A->field->p;
 	const double t0 = wtime();
@@ -180,7 +205,54 @@ void spasm_hip_schur_dense(const struct spasm_csr *A, const int *p, int n, const
 		spasm_hip_dcsr dA{A->n, m, annz, dAp, dAj, dAx};
 		spasm_hip_dwork *W = spasm_hip_dwork_create(n, m, 64);
 		u32 *dS = dalloc<u32>((i64) n * Sm);
-		spasm_hip_dschur_dense(&dA, drows, n, F, W, dS, Sm, stream);
+		struct spasm_triplet *L = fact->Ltmp;
+		if (L == nullptr) {
+			dschur_dense_impl(&dA, drows, n, F, W, dS, Sm, stream, nullptr);
+		} else {
+			// elimination coefficients -> L, pool grown on demand
+			int *d_row_orig = dalloc<int>(n);
+			HIP_CHECK(hipMemcpy(d_row_orig, p_out, (size_t) n * sizeof(int), hipMemcpyHostToDevice));
+			i64 lcap = std::max<i64>((i64) n * 1024, (i64) 1 << 22);
+			for (;;) {
+				LOut lout;
+				lout.row_orig = d_row_orig;
+				lout.cap = lcap;
+				lout.Li = dalloc<int>(lcap);
+				lout.Lj = dalloc<int>(lcap);
+				lout.Lx = dalloc<int>(lcap);
+				HIP_CHECK(hipMemset(lout.Li, 0xFF, (size_t) lcap * sizeof(int)));
+				const int rc = dschur_dense_impl(&dA, drows, n, F, W, dS, Sm, stream, &lout);
+				if (rc == 0) {
+					const i64 used = std::min(lout.used, lcap);
+					std::vector<int> hi((size_t) (used > 0 ? used : 1)), hj(hi.size()), hx(hi.size());
+					if (used > 0) {
+						HIP_CHECK(hipMemcpy(hi.data(), lout.Li, (size_t) used * sizeof(int), hipMemcpyDeviceToHost));
+						HIP_CHECK(hipMemcpy(hj.data(), lout.Lj, (size_t) used * sizeof(int), hipMemcpyDeviceToHost));
+						HIP_CHECK(hipMemcpy(hx.data(), lout.Lx, (size_t) used * sizeof(int), hipMemcpyDeviceToHost));
+					}
+					i64 extra = 0;
+					for (i64 t = 0; t < used; t++)
+						extra += hi[t] >= 0;
+					if (L->nz + extra > L->nzmax)
+						spasm_hip_triplet_realloc(L, 2 * L->nzmax + extra);
+					for (i64 t = 0; t < used; t++) {
+						if (hi[t] < 0)
+							continue;
+						L->i[L->nz] = hi[t];
+						L->j[L->nz] = hj[t];
+						L->x[L->nz] = hx[t];
+						L->nz += 1;
+					}
+				}
+				(void) hipFree(lout.Li);
+				(void) hipFree(lout.Lj);
+				(void) hipFree(lout.Lx);
+				if (rc == 0)
+					break;
+				lcap *= 4;
+			}
+			(void) hipFree(d_row_orig);
+		}
 		std::vector<u32> h((size_t) n * Sm);
 		HIP_CHECK(hipMemcpy(h.data(), dS, (size_t) n * Sm * sizeof(u32), hipMemcpyDeviceToHost));
 		const u32 half = (u32) (prime / 2);
@@ -258,7 +330,7 @@ void spasm_hip_schur_dense_randomized(const struct spasm_csr *A, const int *p, i
 		(void) hipFree(dY);
 		spasm_hip_dcsr dYcsr{N, m, ynnz, dYp, dYj, dYx};
 		u32 *dS = dalloc<u32>((i64) N * Sm);
-		spasm_hip_dschur_dense(&dYcsr, dident, N, F, W, dS, Sm, stream);
+		dschur_dense_impl(&dYcsr, dident, N, F, W, dS, Sm, stream, nullptr);
 		std::vector<u32> h((size_t) N * Sm);
 		HIP_CHECK(hipMemcpy(h.data(), dS, (size_t) N * Sm * sizeof(u32), hipMemcpyDeviceToHost));
 		const u32 half = (u32) (prime / 2);
@@ -348,6 +420,72 @@ int spasm_hip_ffpack_rref(i64 prime, int n, int m, void *A, int ldA, spasm_datat
 			}
 		}
 	logmsg("[rref/hip] %d x %d mod %" PRId64 ": rank %d [%.1fs]\n", n, m, prime, r, wtime() - t0);
+	return r;
+}
+
+// replaces spasm_ffpack_LU (spasm_ffpack.cpp:57-86, 137-145).  On return (r = rank): p[i] = original row
+// of packed row i, qinv[j] = original column of packed column j; A[i*ldA + j] holds L for
+// j < min(i + 1, r) and, on the rows i < r, U for j > i (unit diagonal implied); A == L * U.
+int spasm_hip_ffpack_LU(i64 prime, int n, int m, void *A, int ldA, spasm_datatype datatype, size_t *p, size_t *qinv)
+{
+	if (spasm_hip_device_count() == 0)
+		die("spasm_hip_ffpack_LU: no HIP device (this library has no CPU path)");
+	const double t0 = wtime();
+	for (int i = 0; i < n; i++)
+		p[i] = (size_t) i;
+	for (int j = 0; j < m; j++)
+		qinv[j] = (size_t) j;
+	if (n == 0 || m == 0)
+		return 0;
+	std::vector<u32> h((size_t) n * m);
+	for (int i = 0; i < n; i++)
+		for (int j = 0; j < m; j++) {
+			const size_t src = (size_t) i * ldA + j;
+			i64 v = 0;
+			switch (datatype) {
+			case SPASM_DOUBLE: v = (i64) ((double *) A)[src]; break;
+			case SPASM_FLOAT: v = (i64) ((float *) A)[src]; break;
+			case SPASM_I64: v = ((i64 *) A)[src]; break;
+			}
+			v %= prime;
+			if (v < 0)
+				v += prime;
+			h[(size_t) i * m + j] = (u32) v;
+		}
+	std::vector<int> hp((size_t) n), hq((size_t) m);
+	for (int i = 0; i < n; i++)
+		hp[i] = i;
+	for (int j = 0; j < m; j++)
+		hq[j] = j;
+	u32 *dA = dalloc<u32>((i64) n * m);
+	int *dP = dalloc<int>(n), *dQ = dalloc<int>(m);
+	HIP_CHECK(hipMemcpy(dA, h.data(), (size_t) n * m * sizeof(u32), hipMemcpyHostToDevice));
+	HIP_CHECK(hipMemcpy(dP, hp.data(), (size_t) n * sizeof(int), hipMemcpyHostToDevice));
+	HIP_CHECK(hipMemcpy(dQ, hq.data(), (size_t) m * sizeof(int), hipMemcpyHostToDevice));
+	const int r = device_lu(prime, n, m, dA, m, dP, dQ, nullptr);
+	HIP_CHECK(hipMemcpy(h.data(), dA, (size_t) n * m * sizeof(u32), hipMemcpyDeviceToHost));
+	HIP_CHECK(hipMemcpy(hp.data(), dP, (size_t) n * sizeof(int), hipMemcpyDeviceToHost));
+	HIP_CHECK(hipMemcpy(hq.data(), dQ, (size_t) m * sizeof(int), hipMemcpyDeviceToHost));
+	(void) hipFree(dA);
+	(void) hipFree(dP);
+	(void) hipFree(dQ);
+	for (int i = 0; i < n; i++)
+		p[i] = (size_t) hp[i];
+	for (int j = 0; j < m; j++)
+		qinv[j] = (size_t) hq[j];
+	const u32 half = (u32) (prime / 2);
+	for (int i = 0; i < n; i++)
+		for (int j = 0; j < m; j++) {
+			const u32 raw = h[(size_t) i * m + j];
+			const i64 v = (raw > half) ? (i64) raw - prime : (i64) raw;
+			const size_t dst = (size_t) i * ldA + j;
+			switch (datatype) {
+			case SPASM_DOUBLE: ((double *) A)[dst] = (double) v; break;
+			case SPASM_FLOAT: ((float *) A)[dst] = (float) v; break;
+			case SPASM_I64: ((i64 *) A)[dst] = v; break;
+			}
+		}
+	logmsg("[LU/hip] %d x %d mod %" PRId64 ": rank %d [%.1fs]\n", n, m, prime, r, wtime() - t0);
 	return r;
 }
 

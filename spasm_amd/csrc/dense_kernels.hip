@@ -737,3 +737,132 @@ void launch_dense_pack(const unsigned long long *Y, int N, int m, uint32_t p, co
 }
 
 }  // namespace sh
+
+// --------------------------------------------------------------------------
+// Dense PLUQ mod p (replaces FFPACK::pPLUQ behind spasm_ffpack_LU, spasm_ffpack.cpp:57-86).
+// Contract consumed by update_fact_after_LU (spasm_echelonize.c:228-297) and
+// tests/dense_lu_ffpack.c: on return, with r = rank,
+//   row i of the packed matrix corresponds to original row P[i], column j to original column Qinv[j];
+//   M[i][j], j < min(i+1, r)  : L (lower trapezoid, pivots on its diagonal);
+//   M[i][j], i < r, j > i     : U (unit diagonal implied);      A == L * U in original coordinates.
+// Right-looking elimination, one pivot per step, rows and columns physically swapped; a column
+// with no non-zero below the current step is swapped to the end.  O(r) small launches: this is
+// the L-recording variant of the dense tail, not the fast path (that is device_rref above).
+// --------------------------------------------------------------------------
+namespace sh {
+
+// first row >= t of column t holding a non-zero, or -1; single workgroup
+__global__ __launch_bounds__(1024) void lu_find_pivot(const uint32_t *A, int64_t ld, int n, int t, int *out)
+{
+	__shared__ int best;
+	if (threadIdx.x == 0)
+		best = 0x7FFFFFFF;
+	__syncthreads();
+	int mine = 0x7FFFFFFF;
+	for (int i = t + threadIdx.x; i < n; i += 1024)
+		if (A[(int64_t) i * ld + t] != 0) {
+			mine = i;
+			break;
+		}
+	if (mine != 0x7FFFFFFF)
+		atomicMin(&best, mine);
+	__syncthreads();
+	if (threadIdx.x == 0)
+		*out = (best == 0x7FFFFFFF) ? -1 : best;
+}
+
+__global__ void lu_swap_rows(uint32_t *A, int64_t ld, int m, int a, int b, int *P)
+{
+	const int j = blockIdx.x * blockDim.x + threadIdx.x;
+	if (j < m) {
+		const uint32_t x = A[(int64_t) a * ld + j];
+		A[(int64_t) a * ld + j] = A[(int64_t) b * ld + j];
+		A[(int64_t) b * ld + j] = x;
+	}
+	if (j == 0) {
+		const int x = P[a];
+		P[a] = P[b];
+		P[b] = x;
+	}
+}
+
+__global__ void lu_swap_cols(uint32_t *A, int64_t ld, int n, int a, int b, int *Q)
+{
+	const int i = blockIdx.x * blockDim.x + threadIdx.x;
+	if (i < n) {
+		const uint32_t x = A[(int64_t) i * ld + a];
+		A[(int64_t) i * ld + a] = A[(int64_t) i * ld + b];
+		A[(int64_t) i * ld + b] = x;
+	}
+	if (i == 0) {
+		const int x = Q[a];
+		Q[a] = Q[b];
+		Q[b] = x;
+	}
+}
+
+// row t: U[t][j] = A[t][j] / pivot for j > t (in place)
+__global__ void lu_scale_row(uint32_t *A, int64_t ld, int m, int t, MontDev F)
+{
+	const uint32_t inv = invmod(A[(int64_t) t * ld + t], F);
+	const int j = t + 1 + blockIdx.x * blockDim.x + threadIdx.x;
+	if (j < m)
+		A[(int64_t) t * ld + j] = mulmod(A[(int64_t) t * ld + j], inv, F);
+}
+
+// A[i][j] -= A[i][t] * A[t][j]   for i > t, j > t
+__global__ __launch_bounds__(256) void lu_rank1_update(uint32_t *A, int64_t ld, int n, int m, int t, MontDev F)
+{
+	const int j = t + 1 + blockIdx.x * 256 + threadIdx.x;
+	const int i0 = t + 1 + blockIdx.y * 16;
+	if (j >= m)
+		return;
+	const uint32_t u = A[(int64_t) t * ld + j];
+	if (u == 0)
+		return;
+	for (int i = i0; i < i0 + 16 && i < n; i++) {
+		const uint32_t l = A[(int64_t) i * ld + t];
+		if (l != 0) {
+			uint32_t *x = A + (int64_t) i * ld + j;
+			*x = submod(*x, mulmod(l, u, F), F);
+		}
+	}
+}
+
+int device_lu(int64_t prime, int n, int m, uint32_t *dA, int64_t ld, int *dP, int *dQ, hipStream_t stream)
+{
+	const Mont M = mont_setup(prime);
+	const MontDev F = to_dev(M);
+	int *d_piv = nullptr;
+	HIP_CHECK(hipMalloc((void **) &d_piv, 64));
+	int t = 0;
+	int mlast = m;                   // columns [mlast, m) are known to be zero below the diagonal block
+	const int rmax = (n < m) ? n : m;
+	while (t < rmax && t < mlast) {
+		hipLaunchKernelGGL(lu_find_pivot, dim3(1), dim3(1024), 0, stream, dA, ld, n, t, d_piv);
+		int row = -1;
+		HIP_CHECK(hipMemcpyAsync(&row, d_piv, sizeof(int), hipMemcpyDeviceToHost, stream));
+		HIP_CHECK(hipStreamSynchronize(stream));
+		if (row < 0) {               // dead column: move it out of the way and try the one that takes its place
+			mlast -= 1;
+			if (mlast > t)
+				hipLaunchKernelGGL(lu_swap_cols, dim3((n + 255) / 256), dim3(256), 0, stream, dA, ld, n, t, mlast, dQ);
+			continue;
+		}
+		if (row != t)
+			hipLaunchKernelGGL(lu_swap_rows, dim3((m + 255) / 256), dim3(256), 0, stream, dA, ld, m, t, row, dP);
+		if (t + 1 < m)
+			hipLaunchKernelGGL(lu_scale_row, dim3((m - t - 1 + 255) / 256), dim3(256), 0, stream, dA, ld, m, t, F);
+		if (t + 1 < m && t + 1 < n) {
+			dim3 grid((m - t - 1 + 255) / 256, (n - t - 1 + 15) / 16);
+			hipLaunchKernelGGL(lu_rank1_update, grid, dim3(256), 0, stream, dA, ld, n, m, t, F);
+		}
+		HIP_CHECK(hipGetLastError());
+		t += 1;
+	}
+	HIP_CHECK(hipStreamSynchronize(stream));
+	(void) hipFree(d_piv);
+	return t;
+}
+
+}  // namespace sh

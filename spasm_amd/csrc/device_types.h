@@ -92,6 +92,14 @@ struct SchurArgs {
 	const int *row_orig;      // output row k -> row index to record (p_in[p[k]] or p[k])
 };
 
+// device pools receiving the elimination coefficients (triplets) of a Schur call
+struct LOut {
+	const int *row_orig = nullptr;
+	int *Li = nullptr, *Lj = nullptr, *Lx = nullptr;
+	int64_t cap = 0;
+	int64_t used = 0;         // out: pool cursor after the call (slots handed out, some may be unused)
+};
+
 }  // namespace sh
 
 // opaque handles of the C ABI

@@ -156,6 +156,67 @@ void absorb_rref(int rr, int Sm, const void *S, spasm_datatype datatype, const s
 	}
 }
 
+// transfer a dense PLUQ to the factorization (update_fact_after_LU, spasm_echelonize.c:228-297)
+void absorb_LU(int n, int Sm, int r, const void *S, spasm_datatype datatype, const size_t *Sp, const size_t *Sqinv,
+               const int *q, const int *p_in, i64 lnz_before, bool complete, std::vector<char> &pivotal,
+               struct spasm_lu *fact)
+{
+	struct spasm_csr *U = fact->U;
+	struct spasm_triplet *L = fact->Ltmp;
+	i64 unz = U->p[U->n];
+	spasm_hip_csr_realloc(U, unz + (i64) (1 + 2 * (i64) Sm - r) * r);
+	if (!complete) {
+		// keep, among the coefficients recorded by the dense Schur rows, those of the pivotal rows only
+		for (i64 i = 0; i < r; i++)
+			pivotal[p_in[Sp[i]]] = 1;
+		i64 w = lnz_before;
+		for (i64 px = lnz_before; px < L->nz; px++) {
+			if (!pivotal[L->i[px]])
+				continue;
+			L->i[w] = L->i[px];
+			L->j[w] = L->j[px];
+			L->x[w] = L->x[px];
+			w += 1;
+		}
+		L->nz = w;
+	}
+	const i64 rows_L = complete ? n : r;
+	for (i64 i = 0; i < rows_L; i++) {
+		const int iorig = p_in[Sp[i]];
+		const i64 jmax = (i + 1 < r) ? i + 1 : r;
+		for (i64 j = 0; j < jmax; j++) {
+			const spasm_ZZp v = spasm_hip_datatype_read(S, (size_t) (i * Sm + j), datatype);
+			if (v == 0)
+				continue;
+			if (L->nz == L->nzmax)
+				spasm_hip_triplet_realloc(L, 2 * L->nzmax + Sm);
+			L->i[L->nz] = iorig;
+			L->j[L->nz] = U->n + (int) j;
+			L->x[L->nz] = v;
+			L->nz += 1;
+		}
+		if (i < r)
+			fact->p[U->n + i] = iorig;
+	}
+	for (i64 i = 0; i < r; i++) {
+		const int jp = q[Sqinv[i]];
+		U->j[unz] = jp;
+		U->x[unz] = 1;
+		unz += 1;
+		fact->qinv[jp] = U->n;
+		for (i64 j = i + 1; j < Sm; j++) {
+			const spasm_ZZp x = spasm_hip_datatype_read(S, (size_t) (i * Sm + j), datatype);
+			if (x == 0)
+				continue;
+			U->j[unz] = q[Sqinv[j]];
+			U->x[unz] = x;
+			unz += 1;
+		}
+		U->n += 1;
+		U->p[U->n] = unz;
+	}
+}
+
 // spasm_echelonize_test_completion (spasm_echelonize.c:30-52)
 bool remainder_is_zero(const struct spasm_csr *A, const int *p, int n, struct spasm_lu *fact)
 {
@@ -231,7 +292,8 @@ void finish_dense(const struct spasm_csr *A, const int *p, int n, const int *p_i
 	const int block = opts->dense_block_size;
 	std::vector<unsigned char> S((size_t) block * Sm * spasm_hip_datatype_size(dt));
 	std::vector<int> p_out((size_t) block), q((size_t) (Sm > 0 ? Sm : 1));
-	std::vector<size_t> Sqinv((size_t) (Sm > 0 ? Sm : 1));
+	std::vector<size_t> Sqinv((size_t) (Sm > 0 ? Sm : 1)), Sp((size_t) block);
+	std::vector<char> pivotal((size_t) (opts->L ? fact->Ltmp->n + 1 : 1), 0);
 	int processed = 0, round = 0;
 	const double start = wtime();
 	const int old_un = U->n;
@@ -243,9 +305,17 @@ void finish_dense(const struct spasm_csr *A, const int *p, int n, const int *p_i
 		if (Sn <= 0 || Sm <= 0)
 			break;
 		logmsg("[echelonize/dense] round %d. processing S[%d:%d] (%d x %d)\n", round, processed, processed + Sn, Sn, Sm);
+		const i64 lnz_before = opts->L ? fact->Ltmp->nz : -1;
 		spasm_hip_schur_dense(A, p, Sn, p_in, fact, S.data(), dt, q.data(), p_out.data());
-		const int rr = spasm_hip_ffpack_rref(prime, Sn, Sm, S.data(), Sm, dt, Sqinv.data());
-		absorb_rref(rr, Sm, S.data(), dt, Sqinv.data(), q.data(), fact);
+		int rr;
+		if (opts->L) {
+			rr = spasm_hip_ffpack_LU(prime, Sn, Sm, S.data(), Sm, dt, Sp.data(), Sqinv.data());
+			absorb_LU(Sn, Sm, rr, S.data(), dt, Sp.data(), Sqinv.data(), q.data(), p_out.data(), lnz_before, opts->complete,
+			          pivotal, fact);
+		} else {
+			rr = spasm_hip_ffpack_rref(prime, Sn, Sm, S.data(), Sm, dt, Sqinv.data());
+			absorb_rref(rr, Sm, S.data(), dt, Sqinv.data(), q.data(), fact);
+		}
 		round += 1;
 		processed += Sn;
 		p += Sn;
@@ -279,16 +349,8 @@ extern "C" struct spasm_lu *spasm_hip_echelonize(const struct spasm_csr *A0, str
 	opts = &local;
 	if (opts->complete)
 		opts->L = 1;
-	if (opts->L) {
-		// L is recorded by the structural rounds (pivot extraction + Schur complements on the GPU).  The
-		// dense finishing modes would need a dense PLUQ with an explicit L (spasm_ffpack_LU), which is not
-		// on the GPU yet: with L the remainder always goes through further structural rounds.  Every row
-		// is carried to the end, so the factorization is complete (A == L*U) whatever opts->complete says.
-		opts->enable_tall_and_skinny = 0;
-		opts->enable_dense = 0;
-		opts->enable_GPLU = 1;
-		logmsg("[echelonize] L requested: dense finishing modes disabled, structural rounds only\n");
-	}
+	if (opts->L)
+		opts->enable_tall_and_skinny = 0;      // as the reference: no L in the low-rank mode
 	const struct spasm_csr *A = A0;
 	int n = A->n;
 	const int m = A->m;
@@ -411,7 +473,7 @@ extern "C" struct spasm_lu *spasm_hip_echelonize(const struct spasm_csr *A0, str
 		fact->L = spasm_hip_compress(fact->Ltmp);
 		spasm_hip_triplet_free(fact->Ltmp);
 		fact->Ltmp = nullptr;
-		fact->complete = true;
+		fact->complete = opts->complete;
 	}
 	fact->r = U->n;
 	return fact;

@@ -480,13 +480,6 @@ void spasm_hip_dwork_destroy(spasm_hip_dwork *W)
 }  // extern "C"
 
 namespace {
-struct LOut {                 // device pools for the elimination coefficients (triplets)
-	const int *row_orig = nullptr;
-	int *Li = nullptr, *Lj = nullptr, *Lx = nullptr;
-	i64 cap = 0;
-	i64 used = 0;             // out: pool cursor after the call (slots handed out, some may be unused)
-};
-
 int dschur_impl(const spasm_hip_dcsr *A, const int *d_rows, int nrows, const spasm_hip_dfact *F, spasm_hip_dwork *W,
                 void *stream_, spasm_hip_schur_stats *stats, LOut *Lout)
 {

@@ -157,6 +157,19 @@ def ffpack_rref(prime, M, datatype=SPASM_I64):
     return r, M, qinv[:m].astype(np.int64)
 
 
+def ffpack_LU(prime, M, datatype=SPASM_I64):
+    """spasm_ffpack_LU (spasm_ffpack.cpp:137) on the GPU, on a copy of M: returns (rank, packed LU, P, Qinv)."""
+    require_gpu("ffpack_LU")
+    L = lib()
+    M = np.ascontiguousarray(M, _NP_OF[datatype]).copy()
+    n, m = M.shape
+    P = np.zeros(max(n, 1), np.uint64)
+    Q = np.zeros(max(m, 1), np.uint64)
+    r = L.spasm_hip_ffpack_LU(prime, n, m, M.ctypes.data, m, datatype, P.ctypes.data_as(C.POINTER(C.c_size_t)),
+                              Q.ctypes.data_as(C.POINTER(C.c_size_t)))
+    return r, M, P[:n].astype(np.int64), Q[:m].astype(np.int64)
+
+
 def default_opts():
     o = EchelonizeOpts()
     lib().spasm_hip_echelonize_init_opts(C.byref(o))

@@ -116,3 +116,45 @@ def test_schur_dense_row_group_kernel(oracle, name, p, monkeypatch):
     S, q, p_out = spasm_amd.schur_dense(_as_product(A), rows, _fact(F))
     assert np.array_equal(q, q_want) and np.array_equal(p_out, p_out_want)
     assert np.array_equal(S, want)
+
+
+def _check_LU(oracle, p, M):
+    """tests/dense_lu_ffpack.c:80-170: rebuild L and U from the packed result, L * U == A."""
+    n, m = M.shape
+    r, R, P, Q = spasm_amd.ffpack_LU(p, M)
+    r_want, _, _ = oracle.dense_rref(p, M)
+    assert r == r_want
+    assert sorted(P.tolist()) == list(range(n)) and sorted(Q.tolist()) == list(range(m))
+    Lm = np.zeros((n, r), dtype=object)
+    Um = np.zeros((r, m), dtype=object)
+    for i in range(n):
+        for j in range(min(i + 1, r)):
+            Lm[P[i], j] = int(R[i, j])
+    for i in range(r):
+        Um[i, Q[i]] = 1
+        for j in range(i + 1, m):
+            Um[i, Q[j]] = int(R[i, j])
+    A = np.array(M, dtype=object)
+    assert not np.any((Lm.dot(Um) - A) % p)
+
+
+@pytest.mark.parametrize("name", SMALL_SET)
+@pytest.mark.parametrize("p", [3, 257, 42013, 4294967291])
+def test_LU_reference_matrices(oracle, name, p):
+    A = oracle.load_sms(matrix_path(name), p)
+    if A.n == 0 or A.m == 0:
+        return
+    _check_LU(oracle, p, A.to_dense())
+
+
+@pytest.mark.parametrize("p", [257, 42013, 4294967291])
+@pytest.mark.parametrize("shape,rank", [((60, 90), 33), ((90, 60), 60), ((40, 40), 40), ((50, 300), 7), ((130, 70), 20)])
+def test_LU_random_low_rank(oracle, shape, rank, p):
+    n, m = shape
+    rng = np.random.default_rng(n + 13 * m)
+    k = min(rank, n, m)
+    Lf = rng.integers(0, p, size=(n, k), dtype=np.int64).astype(object)
+    Rf = rng.integers(0, p, size=(k, m), dtype=np.int64).astype(object)
+    M = np.array((Lf.dot(Rf)) % p, dtype=np.int64)
+    M[:, 2:5] = 0                            # dead columns in the leading block
+    _check_LU(oracle, p, M)

@@ -119,3 +119,28 @@ def test_echelonize_with_L(oracle, name, p):
     assert not np.any((Ld.dot(Ud) - Ad) % p)
     for j in range(F.U.n):                   # the pivot of column j of L sits on row Lp[j]
         assert Ld[F.Lp[j], j] % p != 0
+
+
+@pytest.mark.parametrize("name", ["mat364.sms", "medium.sms", "singular.sms", "rectangular_l.sms", "G2.sms", "m1.sms"])
+@pytest.mark.parametrize("complete", [True, False])
+def test_echelonize_with_L_dense_finish(oracle, name, complete):
+    """opts.L with the dense finishing mode: dense Schur rows record their coefficients, the blocks are
+    factored by the dense PLUQ.  complete: A == L*U; otherwise L is right on the pivotal rows."""
+    p = 42013
+    A = oracle.load_sms(matrix_path(name), p)
+    o = spasm_amd.default_opts()
+    o.L = True
+    o.complete = complete
+    o.sparsity_threshold = -1.0              # dense finish straight after the first pivot search
+    o.dense_block_size = 41
+    F = spasm_amd.echelonize(_as_product(A), o)
+    assert F.U.n == oracle.echelonize(A).U.n
+    _check_echelon(oracle, A, F)
+    Ld = _as_oracle(oracle, F.L).to_dense().astype(object)
+    Ud = _as_oracle(oracle, F.U).to_dense().astype(object)
+    Ad = A.to_dense().astype(object)
+    diff = (Ld.dot(Ud) - Ad) % p
+    if complete:
+        assert not np.any(diff)
+    else:
+        assert not np.any(diff[F.Lp])
