@@ -103,10 +103,11 @@ def test_rref_and_kernel(oracle, name, p):
 @pytest.mark.parametrize("name", SMALL_SET + ["mat364.sms", "medium.sms"])
 @pytest.mark.parametrize("p", [257, 42013, 4294967291])
 def test_echelonize_with_L(oracle, name, p):
-    """opts.L: the factorization is returned too and A == L * U (what tests/lu.c checks)."""
+    """opts.complete: the factorization is returned too and A == L * U (what tests/lu.c checks)."""
     A = oracle.load_sms(matrix_path(name), p)
     o = spasm_amd.default_opts()
     o.L = True
+    o.complete = True
     F = spasm_amd.echelonize(_as_product(A), o)
     assert F.U.n == oracle.echelonize(A).U.n
     _check_echelon(oracle, A, F)
