@@ -493,13 +493,19 @@ __global__ __launch_bounds__(64) void gather_rows_kernel(const int *pool_j, cons
 	const int lane = threadIdx.x;
 	for (int k = blockIdx.x; k < n; k += gridDim.x) {
 		const int len = row_len[k];
-		if (len <= len_lo || len > len_hi)
+		if (len <= 0)
 			continue;
 		const int64_t raw = row_off[k];
 		const bool presorted = (raw >> 62) & 1;
+		// rows that only need copying (already sorted, or sorting is off) all belong to the first launch
+		// (small LDS footprint, many waves); the second launch takes the long rows that must be sorted
+		const bool copy_only = !sort_rows || presorted;
+		const bool mine = (len_lo == 0) ? (copy_only || len <= len_hi) : (!copy_only && len > len_lo);
+		if (!mine)
+			continue;
 		const int64_t src = raw & ~(1LL << 62);
 		const int64_t dst = Sp[k];
-		if (!sort_rows || presorted || len > CAP) {
+		if (copy_only || len > CAP) {
 			for (int t = lane; t < len; t += 64) {
 				Sj[dst + t] = pool_j[src + t];
 				Sx[dst + t] = pool_x[src + t];
