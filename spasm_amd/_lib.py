@@ -4,7 +4,8 @@ import os
 
 from .matrix import CCsr, CTriplet, CLu, EchelonizeOpts, CDcsr, CSchurStats, CField
 
-LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "csrc", "libspasm_hip.so")
+# SPASM_HIP_LIB: load another build of the same library (A/B runs of a kernel variant)
+LIB_PATH = os.environ.get("SPASM_HIP_LIB") or os.path.join(os.path.dirname(os.path.abspath(__file__)), "csrc", "libspasm_hip.so")
 
 _lib = None
 

@@ -1000,25 +1000,31 @@ __global__ __launch_bounds__(64) void schur_group_kernel(GroupArgs d)
 
 	unsigned char *slot = d.scratch + (int64_t) blockIdx.x * d.slot_bytes;
 	V *X = reinterpret_cast<V *>(slot);                 // X[label * 64 + lane]
-	uint32_t *bm = LBM ? reinterpret_cast<uint32_t *>(lds_dyn) : reinterpret_cast<uint32_t *>(slot + d.off_bm);
+	// LDS is addressed through address_space(3) pointers: a generic pointer would turn every access into a
+	// FLAT instruction, which counts in vmcnt and makes the wave wait for all its outstanding atomics
+	typedef uint32_t __attribute__((address_space(3))) lds_u32;
+	lds_u32 *const act_l = (lds_u32 *) act;
+	lds_u32 *const bm_l = (lds_u32 *) lds_dyn;
+	uint32_t *const bm_g = reinterpret_cast<uint32_t *>(slot + d.off_bm);
 	if (LBM) {
 		for (int w = lane; w < nw; w += 64)
-			bm[w] = 0;
+			bm_l[w] = 0;
 		__builtin_amdgcn_wave_barrier();
 	}
-	auto bm_load = [&](int w) -> uint32_t { return LBM ? ((volatile uint32_t *) bm)[w] : ld_sc1(&bm[w]); };
+	auto bm_load = [&](int w) -> uint32_t { return LBM ? *(volatile lds_u32 *) (bm_l + w) : ld_sc1(&bm_g[w]); };
 	auto bm_or = [&](uint32_t c) {
 		if (LBM)
-			atomicOr(&bm[c >> 5], 1u << (c & 31));
+			(void) __hip_atomic_fetch_or(bm_l + (c >> 5), 1u << (c & 31), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
 		else
-			(void) __hip_atomic_fetch_or(&bm[c >> 5], 1u << (c & 31), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+			(void) __hip_atomic_fetch_or(&bm_g[c >> 5], 1u << (c & 31), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
 	};
 	auto bm_clear = [&](int w, uint32_t bits) {
 		if (LBM)
-			atomicAnd(&bm[w], ~bits);
+			(void) __hip_atomic_fetch_and(bm_l + w, ~bits, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
 		else
-			(void) __hip_atomic_fetch_and(&bm[w], ~bits, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+			(void) __hip_atomic_fetch_and(&bm_g[w], ~bits, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
 	};
+	auto act_load = [&](int t) -> uint32_t { return *(volatile lds_u32 *) (act_l + t); };
 
 	unsigned long long st_elim = 0, st_stream = 0, st_input = 0, st_wavepiv = 0;
 	int st_done = 0;
@@ -1135,7 +1141,7 @@ __global__ __launch_bounds__(64) void schur_group_kernel(GroupArgs d)
 				while (b) {
 					const int bit = __builtin_ctz(b);
 					b &= b - 1;
-					act[pos++] = (uint32_t) w * 32 + bit;
+					act_l[pos++] = (uint32_t) w * 32 + bit;
 				}
 				__builtin_amdgcn_wave_barrier();
 				__builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
@@ -1155,7 +1161,7 @@ __global__ __launch_bounds__(64) void schur_group_kernel(GroupArgs d)
 #pragma unroll
 					for (int u = 0; u < GR_PB; u++) {
 						const int t = t0 + u;
-						uint32_t c = (t < tot) ? ((volatile uint32_t *) act)[t] : 0xFFFFFFFFu;
+						uint32_t c = (t < tot) ? act_load(t) : 0xFFFFFFFFu;
 						c = __builtin_amdgcn_readfirstlane(c);
 						C[u] = c;
 						R[u] = 0;
@@ -1245,8 +1251,12 @@ __global__ __launch_bounds__(64) void schur_group_kernel(GroupArgs d)
 			const int64_t lines = (int64_t) r + Sm;
 			for (int64_t c = 0; c < lines; c++)
 				X[c * 64 + lane] = 0;
-			for (int w = lane; w < nw; w += 64)
-				bm[w] = 0;
+			for (int w = lane; w < nw; w += 64) {
+				if (LBM)
+					bm_l[w] = 0;
+				else
+					bm_g[w] = 0;
+			}
 			drain_vmem();
 			break;
 		}
