@@ -76,7 +76,8 @@ static int dschur_dense_impl(const spasm_hip_dcsr *A, const int *d_rows, int nro
 		die("spasm_hip_dschur_dense: leading dimension %" PRId64 " below the %d non-pivotal columns", ldS, F->Sm);
 	if (nrows == 0)
 		return 0;
-	const bool wide = ((double) F->prime * ((double) F->maxdeg + 3.0) >= 4294967296.0);
+	// a column receives at most maxdeg + 1 terms, each below 2p (the row-group kernel adds unreduced products)
+	const bool wide = (2.0 * (double) F->prime * ((double) F->maxdeg + 3.0) >= 4294967296.0);
 	int dev = 0;
 	HIP_CHECK(hipGetDevice(&dev));
 	hipDeviceProp_t prop;

@@ -45,7 +45,8 @@ enum Ctr64 {
 	C64_INPUT,             // entries of input rows
 	C64_WAVEPIV,           // row-group kernel: pivots applied per group (wave-level count)
 	C64_LPOOL,             // cursor of the L pool
-	C64_COUNT = 8
+	C64_PROF0 = 8,         // -DSPASM_GROUP_PROFILE builds: cycles per phase of the row-group kernel (8 slots)
+	C64_COUNT = 16
 };
 
 struct SchurArgs {

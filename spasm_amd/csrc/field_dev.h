@@ -16,6 +16,16 @@ __device__ __forceinline__ uint32_t montmul(uint32_t a, uint32_t b, const MontDe
 	return (th < q) ? r + F.p : r;
 }
 
+// same product without the final correction: a value in (0, 2p) congruent to a * b * 2^-32; two instructions
+// shorter, for sums that are reduced later anyway (needs p < 2^31)
+__device__ __forceinline__ uint32_t montmul_lazy(uint32_t a, uint32_t b, const MontDev &F)
+{
+	uint64_t t = (uint64_t) a * b;
+	uint32_t mq = (uint32_t) t * F.pinv;
+	uint32_t q = __umulhi(mq, F.p);
+	return (uint32_t) (t >> 32) - q + F.p;
+}
+
 // v mod p for any 32-bit v
 __device__ __forceinline__ uint32_t reduce_sum(uint32_t v, const MontDev &F) { return montmul(v, F.r1, F); }
 

@@ -490,8 +490,9 @@ int dschur_impl(const spasm_hip_dcsr *A, const int *d_rows, int nrows, const spa
 		die("spasm_hip_dschur: column count mismatch (A %d, factor %d, workspace %d)", A->m, F->m, W->m);
 	// lazy 32-bit sums in the LDS tables: at most 6144 + 1 terms below p each
 	const bool wide_lds = ((double) F->prime * 6146.0 >= 4294967296.0);
-	// ... and in the dense accumulators: a column receives at most maxdeg + 1 terms
-	const bool wide_dense = ((double) F->prime * ((double) F->maxdeg + 3.0) >= 4294967296.0);
+	// ... and in the dense accumulators: a column receives at most maxdeg + 1 terms, each below 2p (the
+	// row-group kernel adds unreduced products)
+	const bool wide_dense = (2.0 * (double) F->prime * ((double) F->maxdeg + 3.0) >= 4294967296.0);
 	const int sort_rows = env_int("SPASM_HIP_SORT_ROWS", 1);
 	const int small_table = 1024, big_table = 8192;
 	const int cus = cu_count();
@@ -670,6 +671,14 @@ eliminated:
 	W->last_rows = nrows;
 	W->last_nnz = total;
 	const int status = ctr[CTR_STATUS] & 3;      // bit 0: row pool exhausted, bit 1: L pool exhausted
+#ifdef SPASM_GROUP_PROFILE
+	if (group_mode) {
+		static const char *const phase[8] = {"drain", "watch", "bitmap scan", "level end", "gather pending", "apply+scatter", "output count", "output write"};
+		const double g = (double) ((nrows + 63) / 64);
+		for (int q = 0; q < 8; q++)
+			fprintf(stderr, "[spasm_hip profile] %-15s %12.0f per group\n", phase[q], (double) ctr64[C64_PROF0 + q] / g);
+	}
+#endif
 	if (Lout != nullptr)
 		Lout->used = (i64) ctr64[C64_LPOOL];
 	if (stats != nullptr) {

@@ -8,6 +8,7 @@
 // eliminated in the same step, and the rows of U' they select are streamed
 // with coalesced 8-byte loads, flattened over the 64 lanes.
 // See DESIGN.md ("Kernels") for the algorithm and its byte accounting.
+#include <type_traits>
 #include "device_types.h"
 #include "field_dev.h"
 
@@ -71,6 +72,20 @@ __device__ __forceinline__ int wave_exclusive_scan(int v, int lane, int &total)
 	}
 	total = __shfl(x, 63);
 	return x - v;
+}
+
+// exclusive scan of small counts (v < 16) without LDS traffic: one ballot + mbcnt per bit plane
+__device__ __forceinline__ int wave_exclusive_scan_small(int v, int &total)
+{
+	int pos = 0, tot = 0;
+#pragma unroll
+	for (int b = 0; b < 4; b++) {
+		const uint64_t m = __ballot((v >> b) & 1);
+		pos += (int) __builtin_amdgcn_mbcnt_hi((uint32_t) (m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t) m, 0u)) << b;
+		tot += __popcll(m) << b;
+	}
+	total = tot;
+	return pos;
 }
 
 __device__ __forceinline__ uint32_t wave_min(uint32_t v)
@@ -696,6 +711,121 @@ template <typename V> __device__ __forceinline__ void add_ff(V *p, uint32_t delt
 
 __device__ __forceinline__ void drain_vmem() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
 
+// ---- software-managed vmcnt ------------------------------------------------
+// On CDNA every vector memory instruction of a wave (loads, stores, atomics
+// without return) retires in issue order and counts in vmcnt.  The compiler
+// only knows how many instructions follow a load when that number is static;
+// in the elimination loop it is not (rows have any number of entries), so it
+// waits with vmcnt(0) before every use of a prefetched accumulator line --
+// i.e. for the round trip of every atomic issued so far -- and a row group
+// advances at one trip per memory latency.  The group kernel therefore keeps
+// its prefetched lines away from the compiler: the loads are inline asm that
+// writes ACCUMULATION registers (a0.., which the compiler never allocates in a
+// kernel without MFMA and below 256 VGPRs), and a line is taken out with
+// s_waitcnt vmcnt(n) + v_accvgpr_read, n = a lower bound, kept by the kernel,
+// of the number of vector memory instructions issued after the load.  A lower
+// bound is always safe: outstanding <= n <= (instructions issued after the
+// load) means the load has retired.  (A value the compiler knows about cannot
+// be used for this: it is free to copy a register before the wait.)
+template <bool WIDE> __device__ __forceinline__ void ring_reserve()
+{
+	// make the kernel allocate the ring: a0..a31 (32-bit lines) or a0..a47 (64-bit lines)
+	asm volatile("" ::: "a0", "a1", "a2", "a3", "a4", "a5", "a6", "a7", "a8", "a9", "a10", "a11", "a12", "a13", "a14", "a15");
+	asm volatile("" ::: "a16", "a17", "a18", "a19", "a20", "a21", "a22", "a23", "a24", "a25", "a26", "a27", "a28", "a29",
+	             "a30", "a31");
+	if constexpr (WIDE)
+		asm volatile("" ::: "a32", "a33", "a34", "a35", "a36", "a37", "a38", "a39", "a40", "a41", "a42", "a43", "a44", "a45",
+		             "a46", "a47");
+}
+template <int I> __device__ __forceinline__ void ring_issue(const uint32_t *p)
+{
+	static_assert(I < 48, "ring too large");
+	asm volatile("global_load_dword a%1, %0, off sc1" : : "v"(p), "n"(I) : "memory");
+}
+template <int I> __device__ __forceinline__ void ring_issue(const unsigned long long *p)
+{
+	static_assert(I % 2 == 0 && I + 1 < 48, "64-bit tuples are even-aligned");
+	asm volatile("global_load_dwordx2 a[%1:%2], %0, off sc1" : : "v"(p), "n"(I), "n"(I + 1) : "memory");
+}
+template <int I> __device__ __forceinline__ void ring_issue_x4(const void *p)          // read-only data: no sc1
+{
+	static_assert(I % 2 == 0 && I + 3 < 48, "128-bit tuples are even-aligned");
+	asm volatile("global_load_dwordx4 a[%1:%2], %0, off" : : "v"(p), "n"(I), "n"(I + 3) : "memory");
+}
+template <int I> __device__ __forceinline__ void ring_issue_ro(const uint32_t *p)
+{
+	asm volatile("global_load_dword a%1, %0, off" : : "v"(p), "n"(I) : "memory");
+}
+template <int I> __device__ __forceinline__ void ring_read(uint32_t &x)
+{
+	asm volatile("v_accvgpr_read_b32 %0, a%1" : "=v"(x) : "n"(I) : "memory");
+}
+template <int I> __device__ __forceinline__ void ring_read(unsigned long long &x)
+{
+	uint32_t lo, hi;
+	asm volatile("v_accvgpr_read_b32 %0, a%2\n\tv_accvgpr_read_b32 %1, a%3" : "=v"(lo), "=v"(hi) : "n"(I), "n"(I + 1) : "memory");
+	x = ((unsigned long long) hi << 32) | lo;
+}
+
+// wait until at most n (wave-uniform, held in an SGPR) vector memory instructions are outstanding
+#define SPASM_W(K) asm volatile("s_waitcnt vmcnt(" #K ")" ::: "memory")
+__device__ __forceinline__ void wait_vm_at_most(int n)
+{
+	n = __builtin_amdgcn_readfirstlane(n);
+	if (n >= 64)            // the counter has 6 bits: with 64 younger instructions issued, the awaited one has retired
+		return;
+	if (n < 32) {
+		if (n < 16) {
+			if (n < 8) {
+				if (n < 4) {
+					if (n < 2) {
+						if (n < 1) SPASM_W(0); else SPASM_W(1);
+					} else {
+						if (n < 3) SPASM_W(2); else SPASM_W(3);
+					}
+				} else {
+					if (n < 6) SPASM_W(4); else SPASM_W(6);
+				}
+			} else {
+				if (n < 12) {
+					if (n < 10) SPASM_W(8); else SPASM_W(10);
+				} else {
+					if (n < 14) SPASM_W(12); else SPASM_W(14);
+				}
+			}
+		} else {
+			if (n < 24) {
+				if (n < 20) SPASM_W(16); else SPASM_W(20);
+			} else {
+				if (n < 28) SPASM_W(24); else SPASM_W(28);
+			}
+		}
+	} else {
+		if (n < 48) {
+			if (n < 40) {
+				if (n < 36) SPASM_W(32); else SPASM_W(36);
+			} else {
+				if (n < 44) SPASM_W(40); else SPASM_W(44);
+			}
+		} else {
+			if (n < 56) {
+				if (n < 52) SPASM_W(48); else SPASM_W(52);
+			} else {
+				if (n < 60) SPASM_W(56); else SPASM_W(60);
+			}
+		}
+	}
+}
+#undef SPASM_W
+
+template <int I, int N, typename Fn> __device__ __forceinline__ void static_for(Fn &&f)
+{
+	if constexpr (I < N) {
+		f(std::integral_constant<int, I>{});
+		static_for<I + 1, N>(f);
+	}
+}
+
 }  // namespace
 
 struct WaveDenseArgs {
@@ -963,7 +1093,7 @@ namespace sh {
 namespace {
 constexpr int GR_ACT = 512;             // pending labels gathered per pass (GR_ACT / 32 bitmap words)
 constexpr int GR_LBM_MAX_BYTES = 48 * 1024;   // largest pending bitmap kept in LDS
-constexpr int GR_PB = 2;            // pivots per trip (their row heads sit in SGPRs: keep it small)
+constexpr int GR_RB = 8;            // accumulator lines are loaded one block of this many pivots ahead
 }
 
 struct GroupArgs {
@@ -979,6 +1109,12 @@ struct GroupArgs {
 };
 
 // LBM: the pending bitmap of the group lives in LDS (rpad / 8 bytes, dynamic) instead of HBM.
+#ifdef SPASM_GROUP_PROFILE
+#define GR_TICK(q) do { const unsigned long long t_now = __builtin_readcyclecounter(); prof[q] += t_now - t_last; t_last = t_now; } while (0)
+#else
+#define GR_TICK(q) do { } while (0)
+#endif
+
 template <bool WIDE, bool LBM>
 __global__ __launch_bounds__(64) void schur_group_kernel(GroupArgs d)
 {
@@ -987,16 +1123,13 @@ __global__ __launch_bounds__(64) void schur_group_kernel(GroupArgs d)
 	__shared__ uint32_t act[GR_ACT];
 	const SchurArgs &a = d.a;
 	const int lane = threadIdx.x;
+	ring_reserve<WIDE>();
 	const uint32_t r = (uint32_t) a.r;
 	const int Sm = a.Sm;
 	const MontDev F = a.F;
 	const int nw = (int) (r / 32);
 	const int ngroups = (a.nrows + 63) / 64;
 
-	typedef const uint32_t __attribute__((address_space(4))) *const_u32_ptr;
-	typedef const uint64_t __attribute__((address_space(4))) *const_u64_ptr;
-	const const_u32_ptr head_k = (const_u32_ptr) (uintptr_t) a.head;
-	const const_u64_ptr rp_k = (const_u64_ptr) (uintptr_t) a.rp;
 
 	unsigned char *slot = d.scratch + (int64_t) blockIdx.x * d.slot_bytes;
 	V *X = reinterpret_cast<V *>(slot);                 // X[label * 64 + lane]
@@ -1025,10 +1158,20 @@ __global__ __launch_bounds__(64) void schur_group_kernel(GroupArgs d)
 			(void) __hip_atomic_fetch_and(&bm_g[w], ~bits, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
 	};
 	auto act_load = [&](int t) -> uint32_t { return *(volatile lds_u32 *) (act_l + t); };
+	// non-pivotal labels (>= r) that received something: bits r.. of the bitmap in HBM, whatever LBM says; the
+	// output only visits those lines
+	auto touch = [&](uint32_t c) {
+		(void) __hip_atomic_fetch_or(&bm_g[c >> 5], 1u << (c & 31), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+	};
+	const int nwS = (Sm + 31) / 32;
 
 	unsigned long long st_elim = 0, st_stream = 0, st_input = 0, st_wavepiv = 0;
 	int st_done = 0;
 	LArena larena;
+#ifdef SPASM_GROUP_PROFILE
+	unsigned long long prof[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+	unsigned long long t_last = __builtin_readcyclecounter();
+#endif
 
 	for (;;) {
 		int g = 0;
@@ -1059,15 +1202,23 @@ __global__ __launch_bounds__(64) void schur_group_kernel(GroupArgs d)
 				add_ff(&X[(int64_t) c * 64 + lane], v);
 				if (c < r)
 					bm_or(c);
+				else
+					touch(c);
 			}
 		}
 
 		// ---- eliminate level by level ----
 		uint32_t cursor = 0;
 		bool abandoned = false;
+		int round = 0;
 		for (;;) {
-			drain_vmem();
+			GR_TICK(5);
+			// the pending bitmap in LDS is ordered by lgkmcnt: the atomics of the previous level only have to
+			// land before its successor's accumulator lines are read (below), and complete meanwhile
+			if (!LBM)
+				drain_vmem();
 			__builtin_amdgcn_wave_barrier();
+			GR_TICK(0);
 			if (d.watch) {
 				// publish progress every 256 applied pivots; whoever publishes judges the batch:
 				// all running groups contribute in proportion to their work, so the ratio is not biased
@@ -1082,9 +1233,13 @@ __global__ __launch_bounds__(64) void schur_group_kernel(GroupArgs d)
 							atomicOr(&a.ctr[CTR_GROUP_ABORT], 1);
 						stop = -1;          // counters were flushed
 					}
-					const int flag = __hip_atomic_load(&a.ctr[CTR_GROUP_ABORT], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-					stop = (flag != 0) ? 1 : stop;
+					if (stop != 0 || (round & 15) == 0) {
+						// (a global load per round would add its latency to the chain of the group)
+						const int flag = __hip_atomic_load(&a.ctr[CTR_GROUP_ABORT], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+						stop = (flag != 0) ? 1 : stop;
+					}
 				}
+				round += 1;
 				stop = __builtin_amdgcn_readfirstlane(stop);
 				if (stop != 0) {
 					st_elim = 0;
@@ -1096,6 +1251,7 @@ __global__ __launch_bounds__(64) void schur_group_kernel(GroupArgs d)
 					break;
 				}
 			}
+			GR_TICK(1);
 			int wi = -1;
 			uint32_t fbits = 0;
 			const int wstart = (int) (cursor >> 5);
@@ -1115,28 +1271,37 @@ __global__ __launch_bounds__(64) void schur_group_kernel(GroupArgs d)
 					break;
 				}
 			}
+			GR_TICK(2);
 			if (wi < 0)
 				break;
 			const uint32_t c0 = (uint32_t) wi * 32 + (uint32_t) __builtin_ctz(fbits);
-			const uint32_t lwe = a.lvl_end_w[wi];
-			const uint32_t lend = (lwe != MIXED) ? lwe * 32 : a.lvl_end[c0];
+			// (scalar loads: a vector load would return after every atomic issued before it)
+			typedef const uint32_t __attribute__((address_space(4))) *const_u32_ptr;
+			const uint32_t lwe = ((const_u32_ptr) (uintptr_t) a.lvl_end_w)[wi];
+			const uint32_t lend = (lwe != MIXED) ? lwe * 32 : ((const_u32_ptr) (uintptr_t) a.lvl_end)[c0];
 			const int wl = (int) ((lend + 31) >> 5);
+#ifdef SPASM_GROUP_PROFILE
+			asm volatile("" : : "v"(lend) : "memory");
+#endif
+			GR_TICK(3);
 
 			for (int wb = wi; wb < wl; wb += GR_ACT / 32) {
-				// pending labels of this chunk of the level -> act[]
-				const int w = wb + lane;
+				// pending labels of this chunk of the level -> act[]: lane l takes byte l % 4 of word wb + l / 4
+				const int w = wb + (lane >> 2);
+				const int sh = (lane & 3) * 8;
 				uint32_t bits = 0;
-				if (w < wl && lane < GR_ACT / 32) {
+				if (w < wl) {
 					bits = bm_load(w);
 					if (w == wi)
 						bits &= ~((1u << (c0 & 31)) - 1u);
 					if ((uint32_t) w * 32 + 32 > lend)
 						bits &= (1u << (lend & 31)) - 1u;
+					bits &= 0xFFu << sh;
 					if (bits != 0)
 						bm_clear(w, bits);
 				}
 				int tot;
-				int pos = wave_exclusive_scan(__popc(bits), lane, tot);
+				int pos = wave_exclusive_scan_small(__popc(bits), tot);
 				uint32_t b = bits;
 				while (b) {
 					const int bit = __builtin_ctz(b);
@@ -1144,107 +1309,157 @@ __global__ __launch_bounds__(64) void schur_group_kernel(GroupArgs d)
 					act_l[pos++] = (uint32_t) w * 32 + bit;
 				}
 				__builtin_amdgcn_wave_barrier();
-				__builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+				asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");     // LDS only: a fence would also wait for the atomics in flight
 
-				// apply them: uniform loop, GR_PB pivots per trip; the loads of trip t+1 (accumulator lines and
-				// row extents) are issued before the entries of trip t are streamed
-				// apply them: uniform loop, GR_PB pivots per trip.  Everything trip t+1 needs is fetched while trip t
-				// is applied: the accumulator lines X[c][lane] (vector loads) and, through the constant address
-				// space (wave-uniform read-only data -> scalar loads, SGPRs), the row extents and the first four
-				// entries of each row, so that the atomics of a trip issue back to back.
-				uint32_t cc[GR_PB], ncc[GR_PB];
-				V raw[GR_PB], nraw[GR_PB];
-				int len[GR_PB], nlen[GR_PB];
-				uint64_t start[GR_PB], nstart[GR_PB];
-				uint2 hd[GR_PB][4], nhd[GR_PB][4];
-				auto fetch = [&](int t0, uint32_t *C, V *R, uint64_t *S, int *L, uint2 (*H)[4]) {
-#pragma unroll
-					for (int u = 0; u < GR_PB; u++) {
-						const int t = t0 + u;
-						uint32_t c = (t < tot) ? act_load(t) : 0xFFFFFFFFu;
-						c = __builtin_amdgcn_readfirstlane(c);
-						C[u] = c;
-						R[u] = 0;
-						S[u] = 0;
-						L[u] = 0;
-#pragma unroll
-						for (int q = 0; q < 4; q++)
-							H[u][q] = uint2{0xFFFFFFFFu, 0u};
-						if (c != 0xFFFFFFFFu) {
-							R[u] = ld_sc1(&X[(int64_t) c * 64 + lane]);
-							S[u] = rp_k[c];
-							L[u] = (int) (rp_k[c + 1] - S[u]);
-#pragma unroll
-							for (int q = 0; q < 4; q++) {
-								H[u][q].x = head_k[((int64_t) c * 4 + q) * 2];
-								H[u][q].y = head_k[((int64_t) c * 4 + q) * 2 + 1];
-							}
-						}
-					}
+				// apply them: uniform loop over blocks of GR_RB pivots.  Everything a block needs is fetched with
+				// vector loads one block ahead, into the two halves of the accumulation-register ring
+				// (software-managed vmcnt, above), so that the atomics keep issuing back to back behind the loads:
+				//   regs 0-3  row extents rp[c], rp[c+1]: lane u holds those of pivot u
+				//   reg  4    the first four entries of every row: lane 8u + d holds dword d of the head of pivot u
+				//   regs 6..  the accumulator lines X[c][lane]
+				// Wave-uniform values are then picked out of these with v_readlane.  `issued` counts (a subset of)
+				// the vector memory instructions issued so far.
+				constexpr int NL = WIDE ? 2 : 1;
+				constexpr int HALF_REGS = 6 + GR_RB * NL;
+				static_assert(GR_RB == 8, "one head load covers 8 pivots x 8 dwords = 64 lanes");
+				tot = __builtin_amdgcn_readfirstlane(tot);
+				GR_TICK(4);
+				if (LBM && wb == wi)     // (pivots of one level never update each other's lines)
+					drain_vmem();
+				GR_TICK(0);
+				int issued = 0;
+				int base_blk[2] = {0, 0};
+				auto issue_block = [&](int b0, auto half) -> uint32_t {
+					constexpr int R0 = decltype(half)::value * HALF_REGS;
+					base_blk[decltype(half)::value] = issued;
+					const int th = b0 + (lane >> 3), tr = b0 + (lane & 7);
+					const uint32_t ch = (th < tot) ? act_load(th) : 0xFFFFFFFFu;      // pivot of this lane's head dword
+					const uint32_t cr = (tr < tot) ? act_load(tr) : 0u;
+					ring_issue_x4<R0>(a.rp + cr);
+					ring_issue_ro<R0 + 4>(reinterpret_cast<const uint32_t *>(a.head) + (int64_t) (ch != 0xFFFFFFFFu ? ch : 0u) * 8 + (lane & 7));
+					static_for<0, GR_RB>([&](auto uu) {
+						constexpr int u = decltype(uu)::value;
+						// slots past the end load line 0 (harmless, keeps the instruction count static)
+						uint32_t c = __builtin_amdgcn_readlane(ch, 8 * u);
+						c = (c != 0xFFFFFFFFu) ? c : 0u;
+						ring_issue<R0 + 6 + u * NL>(&X[(int64_t) c * 64 + lane]);
+					});
+					issued += GR_RB + 2;
+					return ch;
 				};
-				fetch(0, ncc, nraw, nstart, nlen, nhd);
-				for (int t0 = 0; t0 < tot; t0 += GR_PB) {
-#pragma unroll
-					for (int u = 0; u < GR_PB; u++) {
-						cc[u] = ncc[u];
-						raw[u] = nraw[u];
-						start[u] = nstart[u];
-						len[u] = nlen[u];
-#pragma unroll
-						for (int q = 0; q < 4; q++)
-							hd[u][q] = nhd[u][q];
-					}
-					if (t0 + GR_PB < tot)
-						fetch(t0 + GR_PB, ncc, nraw, nstart, nlen, nhd);
-#pragma unroll
-					for (int u = 0; u < GR_PB; u++) {
-						if (cc[u] == 0xFFFFFFFFu)
-							continue;
-						const uint32_t v = (raw[u] != 0) ? reduce_sum(raw[u], F) : 0u;
-						if (raw[u] != 0)
-							__hip_atomic_store(&X[(int64_t) cc[u] * 64 + lane], (V) 0, __ATOMIC_RELAXED,
-							                   __HIP_MEMORY_SCOPE_WAVEFRONT);
+				auto process_block = [&](int b0, auto half, const uint32_t ch) {
+					constexpr int R0 = decltype(half)::value * HALF_REGS;
+					const int base = base_blk[decltype(half)::value];
+					// one wait for the whole block: its last line (slots past the end were loaded too) and
+					// everything older.  The block was issued while the previous one was applied.
+					wait_vm_at_most(issued - (base + 2 + GR_RB - 1) - 1);
+					uint32_t hv;
+					unsigned long long rp_lo, rp_hi;
+					ring_read<R0 + 4>(hv);
+					ring_read<R0>(rp_lo);
+					ring_read<R0 + 2>(rp_hi);
+					uint32_t applied = 0;        // bit u: pivot u of the block was applied to some row
+					static_for<0, GR_RB>([&](auto uu) {
+						constexpr int u = decltype(uu)::value;
+						if (b0 + u >= tot)
+							return;
+						const uint32_t c = __builtin_amdgcn_readlane(ch, 8 * u);
+						V rawv;
+						ring_read<R0 + 6 + u * NL>(rawv);
+						const uint32_t v = (rawv != 0) ? reduce_sum(rawv, F) : 0u;
+						if (__ballot(rawv != 0) != 0) {
+							if (rawv != 0)
+								__hip_atomic_store(&X[(int64_t) c * 64 + lane], (V) 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+							issued += 1;
+						}
 						const uint64_t active = __ballot(v != 0);
 						if (active == 0)
-							continue;
+							return;
+						applied |= 1u << u;
 						const int nact = __popcll(active);
+#ifdef SPASM_GROUP_PROFILE
+						// 64-byte quarters of the line with an active lane (x 1000, on top of the watch phase)
+						prof[1] += 1000ull * (((active & 0xFFFFull) != 0) + ((active & 0xFFFF0000ull) != 0) +
+						                      ((active & 0xFFFF00000000ull) != 0) + ((active >> 48) != 0));
+#endif
 						st_wavepiv += 1;
 						st_elim += (unsigned long long) nact;
-						st_stream += (unsigned long long) nact * (unsigned long long) len[u];
 						if (a.L_i != nullptr)
-							record_L(a, larena, v != 0, row_to_record, cc[u], v, lane, F);
+							record_L(a, larena, v != 0, row_to_record, c, v, lane, F);
 						const uint32_t w_neg = F.p - v;
-						const uint64_t s0 = start[u];
-						const int L = len[u];
-						auto apply = [&](const uint2 &e) {
-							const uint32_t tgt = e.x;
+						auto apply = [&](const uint32_t tgt, const uint32_t val) {
+							// 32-bit sums take the product unreduced, in (0, 2p): they are reduced when read
 							if (v != 0)
-								add_ff(&X[(int64_t) tgt * 64 + lane], montmul(w_neg, e.y, F));
-							if (tgt < r && lane == 0)
-								bm_or(tgt);
+								add_ff(&X[(int64_t) tgt * 64 + lane], WIDE ? montmul(w_neg, val, F) : montmul_lazy(w_neg, val, F));
+							issued += 1;      // some lane has v != 0: the instruction is issued
 						};
-						// the first four entries came with the fetch; longer rows stream the rest
+						int L = 0;
 #pragma unroll
-						for (int q = 0; q < 4; q++)
-							if (hd[u][q].x != 0xFFFFFFFFu)
-								apply(hd[u][q]);
-						for (int e0 = 4; e0 < L; e0 += 4) {
-							uint2 ent[4];
-#pragma unroll
-							for (int q = 0; q < 4; q++)
-								ent[q] = (e0 + q < L) ? a.ent[s0 + e0 + q] : uint2{0xFFFFFFFFu, 0u};
-#pragma unroll
-							for (int q = 0; q < 4; q++)
-								if (ent[q].x != 0xFFFFFFFFu)
-									apply(ent[q]);
+						for (int q = 0; q < 4; q++) {
+							const uint32_t tgt = __builtin_amdgcn_readlane(hv, 8 * u + 2 * q);
+							if (tgt != 0xFFFFFFFFu) {
+								apply(tgt, __builtin_amdgcn_readlane(hv, 8 * u + 2 * q + 1));
+								L += 1;
+							}
 						}
+						if (L == 4) {
+							// the row may go on: stream the rest
+							const uint32_t s_lo = __builtin_amdgcn_readlane((uint32_t) rp_lo, u);
+							const uint32_t s_hi = __builtin_amdgcn_readlane((uint32_t) (rp_lo >> 32), u);
+							const uint32_t e_lo = __builtin_amdgcn_readlane((uint32_t) rp_hi, u);
+							const uint64_t s0 = ((uint64_t) s_hi << 32) | s_lo;
+							L = (int) (e_lo - s_lo);
+							for (int e0 = 4; e0 < L; e0 += 4) {
+								uint2 ent[4];
+#pragma unroll
+								for (int q = 0; q < 4; q++)
+									ent[q] = (e0 + q < L) ? a.ent[s0 + e0 + q] : uint2{0xFFFFFFFFu, 0u};
+#pragma unroll
+								for (int q = 0; q < 4; q++)
+									if (ent[q].x != 0xFFFFFFFFu) {
+										apply(ent[q].x, ent[q].y);
+										if (lane == 0) {
+											if (ent[q].x < r)
+												bm_or(ent[q].x);
+											else
+												touch(ent[q].x);
+										}
+									}
+							}
+						}
+						st_stream += (unsigned long long) nact * (unsigned long long) L;
+					});
+					// the targets among the heads of the applied pivots become pending (pivotal ones) or touched:
+					// one LDS and one global instruction for the block (lane 8u + 2q holds target q of pivot u)
+					if (applied != 0 && (lane & 1) == 0 && ((applied >> (lane >> 3)) & 1u) && hv != 0xFFFFFFFFu) {
+						if (hv < r)
+							bm_or(hv);
+						else
+							touch(hv);
+					}
+				};
+				using H0 = std::integral_constant<int, 0>;
+				using H1 = std::integral_constant<int, 1>;
+				if (tot > 0) {
+					uint32_t chA = issue_block(0, H0{}), chB = 0;
+					for (int b0 = 0; b0 < tot; b0 += 2 * GR_RB) {
+						if (b0 + GR_RB < tot)
+							chB = issue_block(b0 + GR_RB, H1{});
+						process_block(b0, H0{}, chA);
+						if (b0 + GR_RB >= tot)
+							break;
+						if (b0 + 2 * GR_RB < tot)
+							chA = issue_block(b0 + 2 * GR_RB, H0{});
+						process_block(b0 + GR_RB, H1{}, chB);
 					}
 				}
 				__builtin_amdgcn_wave_barrier();
 			}
 			cursor = lend;
 		}
+		GR_TICK(5);
 		drain_vmem();
+		GR_TICK(0);
 		if (abandoned) {
 			// the batch went to the per-row kernels: restore the all-zero state of this slice and leave
 			// (rows keep row_len == -1)
@@ -1257,6 +1472,8 @@ __global__ __launch_bounds__(64) void schur_group_kernel(GroupArgs d)
 				else
 					bm_g[w] = 0;
 			}
+			for (int w = lane; w < nwS; w += 64)
+				bm_g[nw + w] = 0;
 			drain_vmem();
 			break;
 		}
@@ -1280,21 +1497,51 @@ __global__ __launch_bounds__(64) void schur_group_kernel(GroupArgs d)
 						                   __HIP_MEMORY_SCOPE_WAVEFRONT);
 				}
 			}
+			for (int w = lane; w < nwS; w += 64)
+				bm_g[nw + w] = 0;
 			if (have_row)
 				a.row_len[k] = Sm;
 			st_done += __popcll(__ballot(have_row));
 			continue;
 		}
+		GR_TICK(5);
+		// two passes over the touched lines only (a few percent of the Sm non-pivotal labels): count, then write.
+		// Chunks of 512 labels: their touched ones are listed in act[] (lane l: byte l % 4 of word l / 4).
+		auto list_touched = [&](int wb) -> int {
+			const int w = wb + (lane >> 2);
+			uint32_t bits = 0;
+			if (w < nwS)
+				bits = ld_sc1(&bm_g[nw + w]) & (0xFFu << ((lane & 3) * 8));
+			int tot;
+			int pos = wave_exclusive_scan_small(__popc(bits), tot);
+			uint32_t b = bits;
+			while (b) {
+				const int bit = __builtin_ctz(b);
+				b &= b - 1;
+				act_l[pos++] = (uint32_t) w * 32 + bit;
+			}
+			__builtin_amdgcn_wave_barrier();
+			asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");     // LDS only: a fence would also wait for the atomics in flight
+			return __builtin_amdgcn_readfirstlane(tot);
+		};
+		constexpr int OB = 16;
 		int count = 0;
-		for (int t0 = 0; t0 < Sm; t0 += 32) {
-			V rv[32];
+		for (int wb = 0; wb < nwS; wb += GR_ACT / 32) {
+			const int tot = list_touched(wb);
+			for (int b0 = 0; b0 < tot; b0 += OB) {
+				V rv[OB];
 #pragma unroll
-			for (int u = 0; u < 32; u++)
-				rv[u] = (t0 + u < Sm) ? ld_sc1(&Xn[(int64_t) (t0 + u) * 64 + lane]) : (V) 0;
+				for (int u = 0; u < OB; u++) {
+					const uint32_t t = (b0 + u < tot) ? __builtin_amdgcn_readfirstlane(act_load(b0 + u)) : 0xFFFFFFFFu;
+					rv[u] = (t != 0xFFFFFFFFu) ? ld_sc1(&Xn[(int64_t) t * 64 + lane]) : (V) 0;
+				}
 #pragma unroll
-			for (int u = 0; u < 32; u++)
-				count += (rv[u] != 0 && reduce_sum(rv[u], F) != 0) ? 1 : 0;
+				for (int u = 0; u < OB; u++)
+					count += (rv[u] != 0 && reduce_sum(rv[u], F) != 0) ? 1 : 0;
+			}
+			__builtin_amdgcn_wave_barrier();
 		}
+		GR_TICK(6);
 		int gtot;
 		const int excl = wave_exclusive_scan(count, lane, gtot);
 		unsigned long long got = 0;
@@ -1305,24 +1552,34 @@ __global__ __launch_bounds__(64) void schur_group_kernel(GroupArgs d)
 		const int64_t base_off = (int64_t) (((uint64_t) g_hi << 32) | g_lo);
 		const bool fits = base_off + gtot <= a.pool_cap;
 		int64_t wpos = base_off + excl;
-		for (int t0 = 0; t0 < Sm; t0 += 32) {
-			V rv[32];
+		for (int wb = 0; wb < nwS; wb += GR_ACT / 32) {
+			const int tot = list_touched(wb);
+			if ((lane & 3) == 0 && wb + (lane >> 2) < nwS)
+				bm_g[nw + wb + (lane >> 2)] = 0;
+			for (int b0 = 0; b0 < tot; b0 += OB) {
+				V rv[OB];
+				uint32_t tt[OB];
 #pragma unroll
-			for (int u = 0; u < 32; u++)
-				rv[u] = (t0 + u < Sm) ? ld_sc1(&Xn[(int64_t) (t0 + u) * 64 + lane]) : (V) 0;
+				for (int u = 0; u < OB; u++) {
+					tt[u] = (b0 + u < tot) ? __builtin_amdgcn_readfirstlane(act_load(b0 + u)) : 0xFFFFFFFFu;
+					rv[u] = (tt[u] != 0xFFFFFFFFu) ? ld_sc1(&Xn[(int64_t) tt[u] * 64 + lane]) : (V) 0;
+				}
 #pragma unroll
-			for (int u = 0; u < 32; u++) {
-				if (rv[u] == 0)
-					continue;
-				__hip_atomic_store(&Xn[(int64_t) (t0 + u) * 64 + lane], (V) 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
-				const uint32_t v = reduce_sum(rv[u], F);
-				if (v != 0 && fits) {
-					a.pool_j[wpos] = a.q[t0 + u];
-					a.pool_x[wpos] = to_balanced(v, F);
-					wpos += 1;
+				for (int u = 0; u < OB; u++) {
+					if (rv[u] == 0)
+						continue;
+					__hip_atomic_store(&Xn[(int64_t) tt[u] * 64 + lane], (V) 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+					const uint32_t v = reduce_sum(rv[u], F);
+					if (v != 0 && fits) {
+						a.pool_j[wpos] = a.q[tt[u]];
+						a.pool_x[wpos] = to_balanced(v, F);
+						wpos += 1;
+					}
 				}
 			}
+			__builtin_amdgcn_wave_barrier();
 		}
+		GR_TICK(7);
 		if (have_row) {
 			if (fits) {
 				a.row_off[k] = (base_off + excl) | (1LL << 62);
@@ -1336,6 +1593,12 @@ __global__ __launch_bounds__(64) void schur_group_kernel(GroupArgs d)
 		st_done += fits ? __popcll(__ballot(have_row)) : 0;
 	}
 	drain_vmem();
+#ifdef SPASM_GROUP_PROFILE
+	GR_TICK(7);
+	if (lane == 0)
+		for (int q = 0; q < 8; q++)
+			atomicAdd(&a.ctr64[C64_PROF0 + q], prof[q]);
+#endif
 	// per-lane statistics -> wave totals
 	for (int dlt = 32; dlt >= 1; dlt >>= 1) {
 		const uint32_t lo = (uint32_t) __shfl_xor((int) (uint32_t) st_input, dlt);
@@ -1355,7 +1618,7 @@ void group_geometry(int rpad, int Sm, bool wide, int64_t *slot_bytes, int64_t *o
 {
 	const int64_t vb = wide ? 8 : 4;
 	*off_bm = ((int64_t) rpad + Sm) * 64 * vb;
-	*slot_bytes = *off_bm + ((int64_t) (rpad / 32 + 1) * 4 + 255) / 256 * 256;
+	*slot_bytes = *off_bm + ((int64_t) ((rpad + Sm) / 32 + 2) * 4 + 255) / 256 * 256;      // one bit per label
 }
 
 void launch_schur_group(const SchurArgs &a, unsigned char *scratch, int64_t slot_bytes, int64_t off_bm, bool wide,
