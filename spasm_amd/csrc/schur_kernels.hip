@@ -729,28 +729,39 @@ __device__ __forceinline__ void drain_vmem() { asm volatile("s_waitcnt vmcnt(0)"
 // be used for this: it is free to copy a register before the wait.)
 template <bool WIDE> __device__ __forceinline__ void ring_reserve()
 {
-	// make the kernel allocate the ring: a0..a31 (32-bit lines) or a0..a47 (64-bit lines)
+	// make the kernel allocate the ring: a0..a47 (32-bit lines) or a0..a63 (64-bit lines)
 	asm volatile("" ::: "a0", "a1", "a2", "a3", "a4", "a5", "a6", "a7", "a8", "a9", "a10", "a11", "a12", "a13", "a14", "a15");
 	asm volatile("" ::: "a16", "a17", "a18", "a19", "a20", "a21", "a22", "a23", "a24", "a25", "a26", "a27", "a28", "a29",
 	             "a30", "a31");
+	asm volatile("" ::: "a32", "a33", "a34", "a35", "a36", "a37", "a38", "a39", "a40", "a41", "a42", "a43", "a44", "a45",
+	             "a46", "a47");
 	if constexpr (WIDE)
-		asm volatile("" ::: "a32", "a33", "a34", "a35", "a36", "a37", "a38", "a39", "a40", "a41", "a42", "a43", "a44", "a45",
-		             "a46", "a47");
+		asm volatile("" ::: "a48", "a49", "a50", "a51", "a52", "a53", "a54", "a55", "a56", "a57", "a58", "a59", "a60", "a61",
+		             "a62", "a63");
 }
 template <int I> __device__ __forceinline__ void ring_issue(const uint32_t *p)
 {
-	static_assert(I < 48, "ring too large");
+	static_assert(I < 64, "ring too large");
 	asm volatile("global_load_dword a%1, %0, off sc1" : : "v"(p), "n"(I) : "memory");
 }
 template <int I> __device__ __forceinline__ void ring_issue(const unsigned long long *p)
 {
-	static_assert(I % 2 == 0 && I + 1 < 48, "64-bit tuples are even-aligned");
+	static_assert(I % 2 == 0 && I + 1 < 64, "64-bit tuples are even-aligned");
 	asm volatile("global_load_dwordx2 a[%1:%2], %0, off sc1" : : "v"(p), "n"(I), "n"(I + 1) : "memory");
 }
 template <int I> __device__ __forceinline__ void ring_issue_x4(const void *p)          // read-only data: no sc1
 {
-	static_assert(I % 2 == 0 && I + 3 < 48, "128-bit tuples are even-aligned");
+	static_assert(I % 2 == 0 && I + 3 < 64, "128-bit tuples are even-aligned");
 	asm volatile("global_load_dwordx4 a[%1:%2], %0, off" : : "v"(p), "n"(I), "n"(I + 3) : "memory");
+}
+template <int I> __device__ __forceinline__ void ring_issue_x2_ro(const void *p)
+{
+	static_assert(I % 2 == 0 && I + 1 < 64, "64-bit tuples are even-aligned");
+	asm volatile("global_load_dwordx2 a[%1:%2], %0, off" : : "v"(p), "n"(I), "n"(I + 1) : "memory");
+}
+template <int I> __device__ __forceinline__ void ring_read2(uint32_t &x, uint32_t &y)
+{
+	asm volatile("v_accvgpr_read_b32 %0, a%2\n\tv_accvgpr_read_b32 %1, a%3" : "=v"(x), "=v"(y) : "n"(I), "n"(I + 1) : "memory");
 }
 template <int I> __device__ __forceinline__ void ring_issue_ro(const uint32_t *p)
 {
@@ -1349,6 +1360,7 @@ __global__ __launch_bounds__(64) void schur_group_kernel(GroupArgs d)
 				};
 				auto process_block = [&](int b0, auto half, const uint32_t ch) {
 					constexpr int R0 = decltype(half)::value * HALF_REGS;
+					constexpr int OV0 = 2 * HALF_REGS;       // 8 x 2 registers: entries 4.. of long rows
 					const int base = base_blk[decltype(half)::value];
 					// one wait for the whole block: its last line (slots past the end were loaded too) and
 					// everything older.  The block was issued while the previous one was applied.
@@ -1358,15 +1370,22 @@ __global__ __launch_bounds__(64) void schur_group_kernel(GroupArgs d)
 					ring_read<R0 + 4>(hv);
 					ring_read<R0>(rp_lo);
 					ring_read<R0 + 2>(rp_hi);
+					// pass 1: the multipliers (lane = row) of the 8 pivots; long rows of applied pivots start
+					// fetching their entries 4.. now, 64 per instruction (lane e holds entry 4 + e)
+					uint32_t vv[GR_RB];
+					int seq_ov[GR_RB];
 					uint32_t applied = 0;        // bit u: pivot u of the block was applied to some row
 					static_for<0, GR_RB>([&](auto uu) {
 						constexpr int u = decltype(uu)::value;
+						vv[u] = 0;
+						seq_ov[u] = 0;
 						if (b0 + u >= tot)
 							return;
 						const uint32_t c = __builtin_amdgcn_readlane(ch, 8 * u);
 						V rawv;
 						ring_read<R0 + 6 + u * NL>(rawv);
 						const uint32_t v = (rawv != 0) ? reduce_sum(rawv, F) : 0u;
+						vv[u] = v;
 						if (__ballot(rawv != 0) != 0) {
 							if (rawv != 0)
 								__hip_atomic_store(&X[(int64_t) c * 64 + lane], (V) 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
@@ -1386,6 +1405,26 @@ __global__ __launch_bounds__(64) void schur_group_kernel(GroupArgs d)
 						st_elim += (unsigned long long) nact;
 						if (a.L_i != nullptr)
 							record_L(a, larena, v != 0, row_to_record, c, v, lane, F);
+						if (__builtin_amdgcn_readlane(hv, 8 * u + 6) != 0xFFFFFFFFu) {
+							// four head entries: the row may go on
+							const uint32_t s_lo = __builtin_amdgcn_readlane((uint32_t) rp_lo, u);
+							const uint32_t s_hi = __builtin_amdgcn_readlane((uint32_t) (rp_lo >> 32), u);
+							const int L = (int) (__builtin_amdgcn_readlane((uint32_t) rp_hi, u) - s_lo);
+							if (L > 4) {
+								const uint64_t s0 = ((uint64_t) s_hi << 32) | s_lo;
+								seq_ov[u] = issued;
+								ring_issue_x2_ro<OV0 + 2 * u>(a.ent + s0 + (uint64_t) min(4 + lane, L - 1));
+								issued += 1;
+							}
+						}
+						st_stream += (unsigned long long) nact * 4ull;       // (rows longer than the head add theirs below)
+					});
+					// pass 2: the updates
+					static_for<0, GR_RB>([&](auto uu) {
+						constexpr int u = decltype(uu)::value;
+						if (((applied >> u) & 1u) == 0)
+							return;
+						const uint32_t v = vv[u];
 						const uint32_t w_neg = F.p - v;
 						auto apply = [&](const uint32_t tgt, const uint32_t val) {
 							// 32-bit sums take the product unreduced, in (0, 2p): they are reduced when read
@@ -1393,41 +1432,46 @@ __global__ __launch_bounds__(64) void schur_group_kernel(GroupArgs d)
 								add_ff(&X[(int64_t) tgt * 64 + lane], WIDE ? montmul(w_neg, val, F) : montmul_lazy(w_neg, val, F));
 							issued += 1;      // some lane has v != 0: the instruction is issued
 						};
-						int L = 0;
+						bool full = true;
 #pragma unroll
 						for (int q = 0; q < 4; q++) {
 							const uint32_t tgt = __builtin_amdgcn_readlane(hv, 8 * u + 2 * q);
-							if (tgt != 0xFFFFFFFFu) {
+							if (tgt != 0xFFFFFFFFu)
 								apply(tgt, __builtin_amdgcn_readlane(hv, 8 * u + 2 * q + 1));
-								L += 1;
-							}
+							else
+								full = false;
 						}
-						if (L == 4) {
-							// the row may go on: stream the rest
-							const uint32_t s_lo = __builtin_amdgcn_readlane((uint32_t) rp_lo, u);
-							const uint32_t s_hi = __builtin_amdgcn_readlane((uint32_t) (rp_lo >> 32), u);
-							const uint32_t e_lo = __builtin_amdgcn_readlane((uint32_t) rp_hi, u);
-							const uint64_t s0 = ((uint64_t) s_hi << 32) | s_lo;
-							L = (int) (e_lo - s_lo);
-							for (int e0 = 4; e0 < L; e0 += 4) {
-								uint2 ent[4];
-#pragma unroll
-								for (int q = 0; q < 4; q++)
-									ent[q] = (e0 + q < L) ? a.ent[s0 + e0 + q] : uint2{0xFFFFFFFFu, 0u};
-#pragma unroll
-								for (int q = 0; q < 4; q++)
-									if (ent[q].x != 0xFFFFFFFFu) {
-										apply(ent[q].x, ent[q].y);
-										if (lane == 0) {
-											if (ent[q].x < r)
-												bm_or(ent[q].x);
-											else
-												touch(ent[q].x);
-										}
-									}
+						if (!full)
+							return;
+						const uint32_t s_lo = __builtin_amdgcn_readlane((uint32_t) rp_lo, u);
+						const uint32_t s_hi = __builtin_amdgcn_readlane((uint32_t) (rp_lo >> 32), u);
+						const int L = (int) (__builtin_amdgcn_readlane((uint32_t) rp_hi, u) - s_lo);
+						if (L <= 4)
+							return;
+						const uint64_t s0 = ((uint64_t) s_hi << 32) | s_lo;
+						const int nact = __popcll(__ballot(v != 0));
+						st_stream += (unsigned long long) nact * (unsigned long long) (L - 4);
+						wait_vm_at_most(issued - seq_ov[u] - 1);
+						for (int done = 4;;) {
+							uint32_t ot, oc;
+							ring_read2<OV0 + 2 * u>(ot, oc);
+							const int n = min(L - done, 64);
+							for (int e = 0; e < n; e++)
+								apply(__builtin_amdgcn_readlane(ot, e), __builtin_amdgcn_readlane(oc, e));
+							if (lane < n) {
+								if (ot < r)
+									bm_or(ot);
+								else
+									touch(ot);
 							}
+							done += n;
+							if (done >= L)
+								break;
+							// rows with more than 68 entries: the next 64, through the same registers
+							ring_issue_x2_ro<OV0 + 2 * u>(a.ent + s0 + (uint64_t) min(done + lane, L - 1));
+							issued += 1;
+							wait_vm_at_most(0);
 						}
-						st_stream += (unsigned long long) nact * (unsigned long long) L;
 					});
 					// the targets among the heads of the applied pivots become pending (pivotal ones) or touched:
 					// one LDS and one global instruction for the block (lane 8u + 2q holds target q of pivot u)

@@ -160,6 +160,30 @@ def test_schur_row_group_kernel_random(oracle, p, monkeypatch):
     _check(oracle, S, p_out, want, p_out_want)
 
 
+@pytest.mark.parametrize("p", [42013, 4294967291])
+@pytest.mark.parametrize("row_len", [5, 9, 68, 69, 150, 300])
+def test_schur_row_group_kernel_long_pivot_rows(oracle, p, row_len, monkeypatch):
+    """pivot rows beyond the four-entry head: entries 4.. are fetched 64 per instruction (lane = entry), rows
+    over 68 entries in several chunks.  Upper-trapezoidal pivot block with long rows + rows to reduce."""
+    monkeypatch.setenv("SPASM_HIP_GROUP", "1")
+    rng = np.random.default_rng(row_len)
+    npiv_rows, m, nred = 400, 900, 200
+    ti, tj, tx = [], [], []
+    for k in range(npiv_rows):          # row k: pivot on column k, then row_len - 1 entries to its right
+        cols = np.concatenate(([k], k + 1 + rng.choice(m - k - 1, size=min(row_len - 1, m - k - 1), replace=False)))
+        ti += [k] * len(cols); tj += list(cols); tx += list(rng.integers(1, p, size=len(cols)))
+    for k in range(nred):               # rows to reduce: a few entries anywhere
+        cols = rng.choice(m, size=6, replace=False)
+        ti += [npiv_rows + k] * 6; tj += list(cols); tx += list(rng.integers(1, p, size=6))
+    A = oracle.compress(p, npiv_rows + nred, m, np.array(ti, np.int32), np.array(tj, np.int32), np.array(tx, np.int64))
+    npiv, perm, F = oracle.pivots_extract_structural(A, oracle.empty_fact(A.n, A.m, p))
+    assert npiv >= npiv_rows // 2
+    rows = perm[npiv:]
+    want, p_out_want, _ = oracle.schur(A, rows, F)
+    S, p_out = spasm_amd.schur(_as_product(A), rows, _fact(F))
+    _check(oracle, S, p_out, want, p_out_want)
+
+
 def test_row_group_kernel_gives_up_on_unrelated_rows(oracle, monkeypatch):
     """rows that are neighbours in the list but live in different diagonal blocks share nothing: the row-group
     kernel must notice (lane efficiency), stop, and the per-row kernels must finish the batch -- same matrix."""
