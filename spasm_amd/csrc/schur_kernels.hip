@@ -1370,27 +1370,34 @@ __global__ __launch_bounds__(64) void schur_group_kernel(GroupArgs d)
 					ring_read<R0 + 4>(hv);
 					ring_read<R0>(rp_lo);
 					ring_read<R0 + 2>(rp_hi);
-					// pass 1: the multipliers (lane = row) of the 8 pivots; long rows of applied pivots start
-					// fetching their entries 4.. now, 64 per instruction (lane e holds entry 4 + e)
+					// pass 1: the multipliers (lane = row) of the 8 pivots, computed side by side (independent
+					// chains of multiplications); long rows of applied pivots start fetching their entries 4.. now,
+					// 64 per instruction (lane e holds entry 4 + e)
+					V raw[GR_RB];
 					uint32_t vv[GR_RB];
+					static_for<0, GR_RB>([&](auto uu) {
+						constexpr int u = decltype(uu)::value;
+						ring_read<R0 + 6 + u * NL>(raw[u]);
+					});
+#pragma unroll
+					for (int u = 0; u < GR_RB; u++)
+						vv[u] = reduce_sum(raw[u], F);          // (0 stays 0)
 					int seq_ov[GR_RB];
 					uint32_t applied = 0;        // bit u: pivot u of the block was applied to some row
 					static_for<0, GR_RB>([&](auto uu) {
 						constexpr int u = decltype(uu)::value;
-						vv[u] = 0;
 						seq_ov[u] = 0;
-						if (b0 + u >= tot)
+						if (b0 + u >= tot) {
+							vv[u] = 0;       // (slots past the end hold line 0)
 							return;
+						}
 						const uint32_t c = __builtin_amdgcn_readlane(ch, 8 * u);
-						V rawv;
-						ring_read<R0 + 6 + u * NL>(rawv);
-						const uint32_t v = (rawv != 0) ? reduce_sum(rawv, F) : 0u;
-						vv[u] = v;
-						if (__ballot(rawv != 0) != 0) {
-							if (rawv != 0)
+						if (__ballot(raw[u] != 0) != 0) {
+							if (raw[u] != 0)
 								__hip_atomic_store(&X[(int64_t) c * 64 + lane], (V) 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
 							issued += 1;
 						}
+						const uint32_t v = vv[u];
 						const uint64_t active = __ballot(v != 0);
 						if (active == 0)
 							return;
@@ -1419,29 +1426,32 @@ __global__ __launch_bounds__(64) void schur_group_kernel(GroupArgs d)
 						}
 						st_stream += (unsigned long long) nact * 4ull;       // (rows longer than the head add theirs below)
 					});
-					// pass 2: the updates
+					// pass 2: the updates.  32-bit sums take the products unreduced, in (0, 2p): they are reduced
+					// when read.
 					static_for<0, GR_RB>([&](auto uu) {
 						constexpr int u = decltype(uu)::value;
 						if (((applied >> u) & 1u) == 0)
 							return;
 						const uint32_t v = vv[u];
 						const uint32_t w_neg = F.p - v;
-						auto apply = [&](const uint32_t tgt, const uint32_t val) {
-							// 32-bit sums take the product unreduced, in (0, 2p): they are reduced when read
-							if (v != 0)
-								add_ff(&X[(int64_t) tgt * 64 + lane], WIDE ? montmul(w_neg, val, F) : montmul_lazy(w_neg, val, F));
-							issued += 1;      // some lane has v != 0: the instruction is issued
-						};
-						bool full = true;
+						// the four products first (independent), then the atomics under one exec mask
+						uint32_t tgt[4], prod[4];
+						int nvalid = 0;
 #pragma unroll
 						for (int q = 0; q < 4; q++) {
-							const uint32_t tgt = __builtin_amdgcn_readlane(hv, 8 * u + 2 * q);
-							if (tgt != 0xFFFFFFFFu)
-								apply(tgt, __builtin_amdgcn_readlane(hv, 8 * u + 2 * q + 1));
-							else
-								full = false;
+							tgt[q] = __builtin_amdgcn_readlane(hv, 8 * u + 2 * q);
+							const uint32_t val = __builtin_amdgcn_readlane(hv, 8 * u + 2 * q + 1);
+							prod[q] = WIDE ? montmul(w_neg, val, F) : montmul_lazy(w_neg, val, F);
+							nvalid += (tgt[q] != 0xFFFFFFFFu) ? 1 : 0;
 						}
-						if (!full)
+						if (v != 0) {
+#pragma unroll
+							for (int q = 0; q < 4; q++)
+								if (tgt[q] != 0xFFFFFFFFu)
+									add_ff(&X[(int64_t) tgt[q] * 64 + lane], prod[q]);
+						}
+						issued += nvalid;      // some lane has v != 0: the instructions are issued
+						if (nvalid < 4)
 							return;
 						const uint32_t s_lo = __builtin_amdgcn_readlane((uint32_t) rp_lo, u);
 						const uint32_t s_hi = __builtin_amdgcn_readlane((uint32_t) (rp_lo >> 32), u);
@@ -1456,8 +1466,13 @@ __global__ __launch_bounds__(64) void schur_group_kernel(GroupArgs d)
 							uint32_t ot, oc;
 							ring_read2<OV0 + 2 * u>(ot, oc);
 							const int n = min(L - done, 64);
-							for (int e = 0; e < n; e++)
-								apply(__builtin_amdgcn_readlane(ot, e), __builtin_amdgcn_readlane(oc, e));
+							for (int e = 0; e < n; e++) {
+								const uint32_t t = __builtin_amdgcn_readlane(ot, e);
+								const uint32_t val = __builtin_amdgcn_readlane(oc, e);
+								if (v != 0)
+									add_ff(&X[(int64_t) t * 64 + lane], WIDE ? montmul(w_neg, val, F) : montmul_lazy(w_neg, val, F));
+							}
+							issued += n;
 							if (lane < n) {
 								if (ot < r)
 									bm_or(ot);
