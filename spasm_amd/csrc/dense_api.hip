@@ -20,7 +20,7 @@ void wave_dense_geometry(int rpad, int Sm, bool wide, int64_t *slot_bytes, int64
 void group_geometry(int rpad, int Sm, bool wide, int64_t *slot_bytes, int64_t *off_bm);
 void launch_schur_group(const SchurArgs &a, unsigned char *scratch, int64_t slot_bytes, int64_t off_bm, bool wide,
                         uint32_t *dense_out, int64_t ldS, int blocks, hipStream_t stream, int watch, float min_eff,
-                        long long min_w);
+                        long long min_w, int waves);
 void launch_schur_wave_dense(const SchurArgs &a, unsigned char *scratch, int64_t slot_bytes, int64_t off_bm, int64_t off_xn,
                              bool wide, uint32_t *dense_out, int64_t ldS, int blocks, hipStream_t stream);
 }  // namespace sh
@@ -96,10 +96,11 @@ static int dschur_dense_impl(const spasm_hip_dcsr *A, const int *d_rows, int nro
 	if (group_mode < 0)
 		group_mode = nrows >= 4096 ? 1 : 0;
 	i64 gslot = 0, goff = 0;
-	int gslots = 0;
+	int gslots = 0, gwaves = 1;
 	if (group_mode) {
 		group_geometry(F->rpad, F->Sm, wide, &gslot, &goff);
-		gslots = (int) std::max<i64>(1, std::min<i64>((nrows + 63) / 64, std::min<i64>(cus * 10, budget / gslot)));
+		gwaves = env_int("SPASM_HIP_GROUP_WAVES", (nrows + 63) / 64 <= cus * 3 ? 4 : 1) >= 4 ? 4 : 1;
+		gslots = (int) std::max<i64>(1, std::min<i64>((nrows + 63) / 64, std::min<i64>(gwaves == 4 ? cus * 3 : cus * 10, budget / gslot)));
 		need = gslot * gslots;
 	}
 	if (need > W->scratch_bytes) {
@@ -151,7 +152,7 @@ static int dschur_dense_impl(const spasm_hip_dcsr *A, const int *d_rows, int nro
 	}
 	if (group_mode) {
 		a.next_ctr = CTR_ROW_NEXT_G;
-		launch_schur_group(a, W->d_scratch, gslot, goff, wide, d_S, ldS, gslots, stream, 0, 0.0f, 0);
+		launch_schur_group(a, W->d_scratch, gslot, goff, wide, d_S, ldS, gslots, stream, 0, 0.0f, 0, gwaves);
 	} else {
 		launch_schur_wave_dense(a, W->d_scratch, slot_bytes, off_bm, off_xn, wide, d_S, ldS, slots, stream);
 	}

@@ -13,7 +13,7 @@ void wave_dense_geometry(int rpad, int Sm, bool wide, int64_t *slot_bytes, int64
 void group_geometry(int rpad, int Sm, bool wide, int64_t *slot_bytes, int64_t *off_bm);
 void launch_schur_group(const SchurArgs &a, unsigned char *scratch, int64_t slot_bytes, int64_t off_bm, bool wide,
                         uint32_t *dense_out, int64_t ldS, int blocks, hipStream_t stream, int watch, float min_eff,
-                        long long min_w);
+                        long long min_w, int waves);
 void launch_schur_wave_dense(const SchurArgs &a, unsigned char *scratch, int64_t slot_bytes, int64_t off_bm, int64_t off_xn,
                              bool wide, uint32_t *dense_out, int64_t ldS, int blocks, hipStream_t stream);
 void launch_all_rows_to_list(int *list, int *count, int *row_len, int nrows, hipStream_t stream);
@@ -512,7 +512,7 @@ int dschur_impl(const spasm_hip_dcsr *A, const int *d_rows, int nrows, const spa
 		group_mode = (nrows >= 64 * 32 && (force_tier == 0 || Lout != nullptr)) ? 1 : 0;
 		probe = group_mode && Lout == nullptr && nrows >= env_int("SPASM_HIP_GROUP_WATCH_ROWS", 64 * 256);
 	}
-	int group_slots = 0;
+	int group_slots = 0, group_waves = 1;
 	i64 group_slot_bytes = 0, group_off_bm = 0;
 	// per-wave dense scratch, (re)allocated when the factor geometry needs more
 	{
@@ -534,7 +534,11 @@ int dschur_impl(const spasm_hip_dcsr *A, const int *d_rows, int nrows, const spa
 		if (group_mode) {
 			group_geometry(F->rpad, F->Sm, wide_dense, &group_slot_bytes, &group_off_bm);
 			const int ngroups = (nrows + 63) / 64;
-			group_slots = (int) std::min<i64>(env_int("SPASM_HIP_GROUP_SLOTS", cus * 20), budget / group_slot_bytes);
+			// four waves per group when every group can be resident that way (3 workgroups per CU): with few
+			// groups the run time is the chain of level rounds of one group, which the waves split between them
+			group_waves = env_int("SPASM_HIP_GROUP_WAVES", ngroups <= cus * 3 ? 4 : 1) >= 4 ? 4 : 1;
+			group_slots = (int) std::min<i64>(env_int("SPASM_HIP_GROUP_SLOTS", group_waves == 4 ? cus * 3 : cus * 20),
+			                                  budget / group_slot_bytes);
 			group_slots = std::max(1, std::min(group_slots, ngroups));
 			// with the automatic fallback the per-row tier may run in the same buffer afterwards
 			need = probe ? std::max(need, group_slot_bytes * group_slots) : group_slot_bytes * group_slots;
@@ -615,7 +619,7 @@ int dschur_impl(const spasm_hip_dcsr *A, const int *d_rows, int nrows, const spa
 			const float min_eff = (float) env_int("SPASM_HIP_GROUP_MIN_EFF_PCT", 4) / 100.0f;
 			const long long min_w = env_int("SPASM_HIP_GROUP_MIN_PIVOTS", 500000);
 			launch_schur_group(a, W->d_scratch, group_slot_bytes, group_off_bm, wide_dense, nullptr, 0, group_slots, stream,
-			                   probe ? 1 : 0, min_eff, min_w);
+			                   probe ? 1 : 0, min_eff, min_w, group_waves);
 			HIP_CHECK(hipEventRecord(W->ev[5], stream));
 			if (!probe) {
 				HIP_CHECK(hipEventRecord(W->ev[3], stream));

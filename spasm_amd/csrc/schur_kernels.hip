@@ -1126,14 +1126,31 @@ struct GroupArgs {
 #define GR_TICK(q) do { } while (0)
 #endif
 
-template <bool WIDE, bool LBM>
-__global__ __launch_bounds__(64) void schur_group_kernel(GroupArgs d)
+// NW: waves per row group (workgroup = 64 NW threads).  Every wave has lane = row; the waves share the pending
+// bitmap and split the pivots of a level (and the input entries, and the output chunks) between them: a group
+// is a chain of ~1000 dependent level rounds, and when there are fewer groups than the chip has room for, the
+// length of that chain is the run time.  Wave 0 finds the level and lists its pending pivots while the others
+// wait for their atomics to land; two workgroup barriers per round.
+template <bool WIDE, bool LBM, int NW>
+__global__ __launch_bounds__(64 * NW) void schur_group_kernel(GroupArgs d)
 {
 	using V = typename Acc<WIDE>::type;
 	extern __shared__ __attribute__((aligned(16))) unsigned char lds_dyn[];
-	__shared__ uint32_t act[GR_ACT];
+	__shared__ uint32_t act[GR_ACT * NW];      // [0, GR_ACT): pending pivots of the level; output: one list per wave
+	__shared__ int ctl[8];
+	__shared__ int cnt_w[NW][64];
 	const SchurArgs &a = d.a;
-	const int lane = threadIdx.x;
+	const int lane = threadIdx.x & 63;
+	const int wv = threadIdx.x >> 6;
+	// workgroup barrier that waits for the LDS queue only (__syncthreads would drain the atomics in flight too)
+	auto wg_sync = [&]() {
+		if (NW > 1)
+			asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+		else {
+			__builtin_amdgcn_wave_barrier();
+			asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+		}
+	};
 	ring_reserve<WIDE>();
 	const uint32_t r = (uint32_t) a.r;
 	const int Sm = a.Sm;
@@ -1148,12 +1165,13 @@ __global__ __launch_bounds__(64) void schur_group_kernel(GroupArgs d)
 	// FLAT instruction, which counts in vmcnt and makes the wave wait for all its outstanding atomics
 	typedef uint32_t __attribute__((address_space(3))) lds_u32;
 	lds_u32 *const act_l = (lds_u32 *) act;
+	volatile int __attribute__((address_space(3))) *const ctl_l = (volatile int __attribute__((address_space(3))) *) ctl;
 	lds_u32 *const bm_l = (lds_u32 *) lds_dyn;
 	uint32_t *const bm_g = reinterpret_cast<uint32_t *>(slot + d.off_bm);
 	if (LBM) {
-		for (int w = lane; w < nw; w += 64)
+		for (int w = threadIdx.x; w < nw; w += 64 * NW)
 			bm_l[w] = 0;
-		__builtin_amdgcn_wave_barrier();
+		wg_sync();
 	}
 	auto bm_load = [&](int w) -> uint32_t { return LBM ? *(volatile lds_u32 *) (bm_l + w) : ld_sc1(&bm_g[w]); };
 	auto bm_or = [&](uint32_t c) {
@@ -1185,19 +1203,14 @@ __global__ __launch_bounds__(64) void schur_group_kernel(GroupArgs d)
 #endif
 
 	for (;;) {
-		int g = 0;
-		if (lane == 0)
-			g = atomicAdd(&a.ctr[a.next_ctr], 1);
-		g = __builtin_amdgcn_readfirstlane(g);
-		if (g >= ngroups)
-			break;
-		if (d.watch) {
-			int stop = 0;
-			if (lane == 0)
-				stop = __hip_atomic_load(&a.ctr[CTR_GROUP_ABORT], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-			if (__builtin_amdgcn_readfirstlane(stop))
-				break;
+		if (threadIdx.x == 0) {
+			ctl_l[0] = atomicAdd(&a.ctr[a.next_ctr], 1);
+			ctl_l[1] = d.watch ? __hip_atomic_load(&a.ctr[CTR_GROUP_ABORT], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0;
 		}
+		wg_sync();
+		const int g = __builtin_amdgcn_readfirstlane(ctl_l[0]);
+		if (g >= ngroups || __builtin_amdgcn_readfirstlane(ctl_l[1]) != 0)
+			break;
 		const int k = g * 64 + lane;
 		const bool have_row = k < a.nrows;
 		const int row_to_record = (a.L_i != nullptr && have_row) ? a.row_orig[k] : 0;
@@ -1206,8 +1219,9 @@ __global__ __launch_bounds__(64) void schur_group_kernel(GroupArgs d)
 		if (have_row) {
 			const int i = a.rows[k];
 			const int64_t lo = a.Ap[i], hi = a.Ap[i + 1];
-			st_input += (unsigned long long) (hi - lo);
-			for (int64_t px = lo; px < hi; px++) {
+			if (wv == 0)
+				st_input += (unsigned long long) (hi - lo);
+			for (int64_t px = lo + wv; px < hi; px += NW) {
 				const uint32_t c = a.lab[a.Aj[px]];
 				const uint32_t v = reduce_sum(from_balanced(a.Ax[px], F), F);
 				add_ff(&X[(int64_t) c * 64 + lane], v);
@@ -1219,109 +1233,144 @@ __global__ __launch_bounds__(64) void schur_group_kernel(GroupArgs d)
 		}
 
 		// ---- eliminate level by level ----
-		uint32_t cursor = 0;
+		// ctl[2]: 0 = apply the pivots listed in act[], 1 = no pivot left, 2 = the batch was abandoned
+		// ctl[3]: number of listed pivots; ctl[4]: 1 = another chunk of the same level follows
+		uint32_t cursor = 0;          // (wave 0)
 		bool abandoned = false;
 		int round = 0;
+		// wave 0: state of the level being worked on, between the chunks of a wide level
+		int wi = 0, wl = 0, wb = 0;
+		uint32_t c0 = 0, lend = 0;
+		bool more_chunks = false;
 		for (;;) {
 			GR_TICK(5);
-			// the pending bitmap in LDS is ordered by lgkmcnt: the atomics of the previous level only have to
-			// land before its successor's accumulator lines are read (below), and complete meanwhile
+			// barrier A: every wave's pending marks are in the bitmap and act[] is free.  With the bitmap in LDS
+			// the atomics only have to land before the next accumulator lines are read (barrier B): they
+			// complete while wave 0 looks for the level.
 			if (!LBM)
 				drain_vmem();
-			__builtin_amdgcn_wave_barrier();
+			wg_sync();
 			GR_TICK(0);
-			if (d.watch) {
-				// publish progress every 256 applied pivots; whoever publishes judges the batch:
-				// all running groups contribute in proportion to their work, so the ratio is not biased
-				// towards the cheap groups that finish first
-				int stop = 0;
+			bool published = false;
+			if (d.watch && st_wavepiv >= 256 / NW) {
+				// publish progress every 256 applied pivots of the group; whoever publishes judges the batch: all
+				// running groups contribute in proportion to their work, so the ratio is not biased towards the
+				// cheap groups that finish first
 				if (lane == 0) {
-					if (st_wavepiv >= 256) {
-						const unsigned long long e = atomicAdd(&a.ctr64[C64_ELIM], st_elim) + st_elim;
-						const unsigned long long w = atomicAdd(&a.ctr64[C64_WAVEPIV], st_wavepiv) + st_wavepiv;
-						atomicAdd(&a.ctr64[C64_STREAM], st_stream);
-						if (w > d.min_w && (double) e < (double) d.min_eff * 64.0 * (double) w)
-							atomicOr(&a.ctr[CTR_GROUP_ABORT], 1);
-						stop = -1;          // counters were flushed
-					}
-					if (stop != 0 || (round & 15) == 0) {
+					const unsigned long long e = atomicAdd(&a.ctr64[C64_ELIM], st_elim) + st_elim;
+					const unsigned long long w = atomicAdd(&a.ctr64[C64_WAVEPIV], st_wavepiv) + st_wavepiv;
+					atomicAdd(&a.ctr64[C64_STREAM], st_stream);
+					if (w > d.min_w && (double) e < (double) d.min_eff * 64.0 * (double) w)
+						atomicOr(&a.ctr[CTR_GROUP_ABORT], 1);
+				}
+				st_elim = 0;
+				st_wavepiv = 0;
+				st_stream = 0;
+				published = true;
+			}
+			if (wv == 0) {
+				int status = 0;
+				if (!more_chunks) {
+					if (d.watch) {
 						// (a global load per round would add its latency to the chain of the group)
-						const int flag = __hip_atomic_load(&a.ctr[CTR_GROUP_ABORT], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-						stop = (flag != 0) ? 1 : stop;
+						int stop = 0;
+						if (lane == 0 && (published || (round & 15) == 0))
+							stop = __hip_atomic_load(&a.ctr[CTR_GROUP_ABORT], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+						round += 1;
+						if (__builtin_amdgcn_readfirstlane(stop) != 0)
+							status = 2;
 					}
-				}
-				round += 1;
-				stop = __builtin_amdgcn_readfirstlane(stop);
-				if (stop != 0) {
-					st_elim = 0;
-					st_wavepiv = 0;
-					st_stream = 0;
-				}
-				if (stop == 1) {
-					abandoned = true;
-					break;
-				}
-			}
-			GR_TICK(1);
-			int wi = -1;
-			uint32_t fbits = 0;
-			const int wstart = (int) (cursor >> 5);
-			for (int base = wstart; base < nw; base += 64) {
-				const int w = base + lane;
-				uint32_t bits = 0;
-				if (w < nw) {
-					bits = bm_load(w);
-					if (w == wstart)
-						bits &= ~((1u << (cursor & 31)) - 1u);
-				}
-				const uint64_t mask = __ballot(bits != 0);
-				if (mask != 0) {
-					const int fl = __builtin_ctzll(mask);
-					wi = base + fl;
-					fbits = (uint32_t) __shfl((int) bits, fl);
-					break;
-				}
-			}
-			GR_TICK(2);
-			if (wi < 0)
-				break;
-			const uint32_t c0 = (uint32_t) wi * 32 + (uint32_t) __builtin_ctz(fbits);
-			// (scalar loads: a vector load would return after every atomic issued before it)
-			typedef const uint32_t __attribute__((address_space(4))) *const_u32_ptr;
-			const uint32_t lwe = ((const_u32_ptr) (uintptr_t) a.lvl_end_w)[wi];
-			const uint32_t lend = (lwe != MIXED) ? lwe * 32 : ((const_u32_ptr) (uintptr_t) a.lvl_end)[c0];
-			const int wl = (int) ((lend + 31) >> 5);
+					GR_TICK(1);
+					if (status == 0) {
+						wi = -1;
+						uint32_t fbits = 0;
+						const int wstart = (int) (cursor >> 5);
+						for (int base = wstart; base < nw; base += 64) {
+							const int w = base + lane;
+							uint32_t bits = 0;
+							if (w < nw) {
+								bits = bm_load(w);
+								if (w == wstart)
+									bits &= ~((1u << (cursor & 31)) - 1u);
+							}
+							const uint64_t mask = __ballot(bits != 0);
+							if (mask != 0) {
+								const int fl = __builtin_ctzll(mask);
+								wi = base + fl;
+								fbits = (uint32_t) __shfl((int) bits, fl);
+								break;
+							}
+						}
+						GR_TICK(2);
+						if (wi < 0) {
+							status = 1;
+						} else {
+							c0 = (uint32_t) wi * 32 + (uint32_t) __builtin_ctz(fbits);
+							// (scalar loads: a vector load would return after every atomic issued before it)
+							typedef const uint32_t __attribute__((address_space(4))) *const_u32_ptr;
+							const uint32_t lwe = ((const_u32_ptr) (uintptr_t) a.lvl_end_w)[wi];
+							lend = (lwe != MIXED) ? lwe * 32 : ((const_u32_ptr) (uintptr_t) a.lvl_end)[c0];
+							wl = (int) ((lend + 31) >> 5);
+							wb = wi;
 #ifdef SPASM_GROUP_PROFILE
-			asm volatile("" : : "v"(lend) : "memory");
+							asm volatile("" : : "v"(lend) : "memory");
 #endif
-			GR_TICK(3);
-
-			for (int wb = wi; wb < wl; wb += GR_ACT / 32) {
-				// pending labels of this chunk of the level -> act[]: lane l takes byte l % 4 of word wb + l / 4
-				const int w = wb + (lane >> 2);
-				const int sh = (lane & 3) * 8;
-				uint32_t bits = 0;
-				if (w < wl) {
-					bits = bm_load(w);
-					if (w == wi)
-						bits &= ~((1u << (c0 & 31)) - 1u);
-					if ((uint32_t) w * 32 + 32 > lend)
-						bits &= (1u << (lend & 31)) - 1u;
-					bits &= 0xFFu << sh;
-					if (bits != 0)
-						bm_clear(w, bits);
+						}
+					}
+					GR_TICK(3);
 				}
-				int tot;
-				int pos = wave_exclusive_scan_small(__popc(bits), tot);
-				uint32_t b = bits;
-				while (b) {
-					const int bit = __builtin_ctz(b);
-					b &= b - 1;
-					act_l[pos++] = (uint32_t) w * 32 + bit;
+				int tot = 0;
+				if (status == 0) {
+					// pending labels of this chunk of the level -> act[]: lane l takes byte l % 4 of word wb + l / 4
+					const int w = wb + (lane >> 2);
+					const int sh = (lane & 3) * 8;
+					uint32_t bits = 0;
+					if (w < wl) {
+						bits = bm_load(w);
+						if (w == wi)
+							bits &= ~((1u << (c0 & 31)) - 1u);
+						if ((uint32_t) w * 32 + 32 > lend)
+							bits &= (1u << (lend & 31)) - 1u;
+						bits &= 0xFFu << sh;
+						if (bits != 0)
+							bm_clear(w, bits);
+					}
+					int pos = wave_exclusive_scan_small(__popc(bits), tot);
+					uint32_t b = bits;
+					while (b) {
+						const int bit = __builtin_ctz(b);
+						b &= b - 1;
+						act_l[pos++] = (uint32_t) w * 32 + bit;
+					}
+					wb += GR_ACT / 32;
+					more_chunks = wb < wl;
+					if (!more_chunks)
+						cursor = lend;
 				}
-				__builtin_amdgcn_wave_barrier();
-				asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");     // LDS only: a fence would also wait for the atomics in flight
-
+				if (lane == 0) {
+					ctl_l[2] = status;
+					ctl_l[3] = tot;
+				}
+				GR_TICK(4);
+			}
+			// barrier B: the list is there, and so are the updates of the previous level: every wave has waited
+			// for its own atomics (pivots of one level never update each other's lines, so this wait is only
+			// needed once per level; it costs nothing when it has nothing to wait for)
+			if (LBM)
+				drain_vmem();
+			wg_sync();
+			GR_TICK(0);
+			const int status = __builtin_amdgcn_readfirstlane(ctl_l[2]);
+			if (status != 0) {
+				abandoned = status == 2;
+				break;
+			}
+			const int tot = __builtin_amdgcn_readfirstlane(ctl_l[3]);
+			// this wave's share of the list
+			const int share = (tot + NW - 1) / NW;
+			const int t_lo = wv * share;
+			const int t_hi = min(tot, t_lo + share);
+			{
 				// apply them: uniform loop over blocks of GR_RB pivots.  Everything a block needs is fetched with
 				// vector loads one block ahead, into the two halves of the accumulation-register ring
 				// (software-managed vmcnt, above), so that the atomics keep issuing back to back behind the loads:
@@ -1333,19 +1382,14 @@ __global__ __launch_bounds__(64) void schur_group_kernel(GroupArgs d)
 				constexpr int NL = WIDE ? 2 : 1;
 				constexpr int HALF_REGS = 6 + GR_RB * NL;
 				static_assert(GR_RB == 8, "one head load covers 8 pivots x 8 dwords = 64 lanes");
-				tot = __builtin_amdgcn_readfirstlane(tot);
-				GR_TICK(4);
-				if (LBM && wb == wi)     // (pivots of one level never update each other's lines)
-					drain_vmem();
-				GR_TICK(0);
 				int issued = 0;
 				int base_blk[2] = {0, 0};
 				auto issue_block = [&](int b0, auto half) -> uint32_t {
 					constexpr int R0 = decltype(half)::value * HALF_REGS;
 					base_blk[decltype(half)::value] = issued;
 					const int th = b0 + (lane >> 3), tr = b0 + (lane & 7);
-					const uint32_t ch = (th < tot) ? act_load(th) : 0xFFFFFFFFu;      // pivot of this lane's head dword
-					const uint32_t cr = (tr < tot) ? act_load(tr) : 0u;
+					const uint32_t ch = (th < t_hi) ? act_load(th) : 0xFFFFFFFFu;      // pivot of this lane's head dword
+					const uint32_t cr = (tr < t_hi) ? act_load(tr) : 0u;
 					ring_issue_x4<R0>(a.rp + cr);
 					ring_issue_ro<R0 + 4>(reinterpret_cast<const uint32_t *>(a.head) + (int64_t) (ch != 0xFFFFFFFFu ? ch : 0u) * 8 + (lane & 7));
 					static_for<0, GR_RB>([&](auto uu) {
@@ -1387,7 +1431,7 @@ __global__ __launch_bounds__(64) void schur_group_kernel(GroupArgs d)
 					static_for<0, GR_RB>([&](auto uu) {
 						constexpr int u = decltype(uu)::value;
 						seq_ov[u] = 0;
-						if (b0 + u >= tot) {
+						if (b0 + u >= t_hi) {
 							vv[u] = 0;       // (slots past the end hold line 0)
 							return;
 						}
@@ -1499,39 +1543,38 @@ __global__ __launch_bounds__(64) void schur_group_kernel(GroupArgs d)
 				};
 				using H0 = std::integral_constant<int, 0>;
 				using H1 = std::integral_constant<int, 1>;
-				if (tot > 0) {
-					uint32_t chA = issue_block(0, H0{}), chB = 0;
-					for (int b0 = 0; b0 < tot; b0 += 2 * GR_RB) {
-						if (b0 + GR_RB < tot)
+				if (t_lo < t_hi) {
+					uint32_t chA = issue_block(t_lo, H0{}), chB = 0;
+					for (int b0 = t_lo; b0 < t_hi; b0 += 2 * GR_RB) {
+						if (b0 + GR_RB < t_hi)
 							chB = issue_block(b0 + GR_RB, H1{});
 						process_block(b0, H0{}, chA);
-						if (b0 + GR_RB >= tot)
+						if (b0 + GR_RB >= t_hi)
 							break;
-						if (b0 + 2 * GR_RB < tot)
+						if (b0 + 2 * GR_RB < t_hi)
 							chA = issue_block(b0 + 2 * GR_RB, H0{});
 						process_block(b0 + GR_RB, H1{}, chB);
 					}
 				}
-				__builtin_amdgcn_wave_barrier();
 			}
-			cursor = lend;
 		}
 		GR_TICK(5);
 		drain_vmem();
+		wg_sync();
 		GR_TICK(0);
 		if (abandoned) {
 			// the batch went to the per-row kernels: restore the all-zero state of this slice and leave
 			// (rows keep row_len == -1)
 			const int64_t lines = (int64_t) r + Sm;
-			for (int64_t c = 0; c < lines; c++)
+			for (int64_t c = wv; c < lines; c += NW)
 				X[c * 64 + lane] = 0;
-			for (int w = lane; w < nw; w += 64) {
+			for (int w = threadIdx.x; w < nw; w += 64 * NW) {
 				if (LBM)
 					bm_l[w] = 0;
 				else
 					bm_g[w] = 0;
 			}
-			for (int w = lane; w < nwS; w += 64)
+			for (int w = threadIdx.x; w < nwS; w += 64 * NW)
 				bm_g[nw + w] = 0;
 			drain_vmem();
 			break;
@@ -1540,7 +1583,7 @@ __global__ __launch_bounds__(64) void schur_group_kernel(GroupArgs d)
 		// ---- output: lane = row, the non-pivotal labels in order are the sorted row ----
 		V *Xn = X + (int64_t) r * 64;
 		if (d.dense_out != nullptr) {
-			for (int t0 = 0; t0 < Sm; t0 += 16) {
+			for (int t0 = 16 * wv; t0 < Sm; t0 += 16 * NW) {
 				V rv[16];
 #pragma unroll
 				for (int u = 0; u < 16; u++)
@@ -1556,16 +1599,19 @@ __global__ __launch_bounds__(64) void schur_group_kernel(GroupArgs d)
 						                   __HIP_MEMORY_SCOPE_WAVEFRONT);
 				}
 			}
-			for (int w = lane; w < nwS; w += 64)
+			for (int w = threadIdx.x; w < nwS; w += 64 * NW)
 				bm_g[nw + w] = 0;
-			if (have_row)
+			if (have_row && wv == 0)
 				a.row_len[k] = Sm;
-			st_done += __popcll(__ballot(have_row));
+			if (wv == 0)
+				st_done += __popcll(__ballot(have_row));
 			continue;
 		}
 		GR_TICK(5);
 		// two passes over the touched lines only (a few percent of the Sm non-pivotal labels): count, then write.
-		// Chunks of 512 labels: their touched ones are listed in act[] (lane l: byte l % 4 of word l / 4).
+		// Chunks of 512 labels, a contiguous range of chunks per wave; the touched labels of a chunk are listed in
+		// this wave's part of act[] (lane l: byte l % 4 of word l / 4).
+		lds_u32 *const my_act = act_l + wv * GR_ACT;
 		auto list_touched = [&](int wb) -> int {
 			const int w = wb + (lane >> 2);
 			uint32_t bits = 0;
@@ -1577,21 +1623,26 @@ __global__ __launch_bounds__(64) void schur_group_kernel(GroupArgs d)
 			while (b) {
 				const int bit = __builtin_ctz(b);
 				b &= b - 1;
-				act_l[pos++] = (uint32_t) w * 32 + bit;
+				my_act[pos++] = (uint32_t) w * 32 + bit;
 			}
 			__builtin_amdgcn_wave_barrier();
 			asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");     // LDS only: a fence would also wait for the atomics in flight
 			return __builtin_amdgcn_readfirstlane(tot);
 		};
+		auto my_act_load = [&](int t) -> uint32_t { return *(volatile lds_u32 *) (my_act + t); };
 		constexpr int OB = 16;
+		constexpr int CW = GR_ACT / 32;            // words per chunk
+		const int nchunks = (nwS + CW - 1) / CW;
+		const int ch_per = (nchunks + NW - 1) / NW;
+		const int wb_lo = wv * ch_per * CW, wb_hi = min(nwS, (wv + 1) * ch_per * CW);
 		int count = 0;
-		for (int wb = 0; wb < nwS; wb += GR_ACT / 32) {
+		for (int wb = wb_lo; wb < wb_hi; wb += CW) {
 			const int tot = list_touched(wb);
 			for (int b0 = 0; b0 < tot; b0 += OB) {
 				V rv[OB];
 #pragma unroll
 				for (int u = 0; u < OB; u++) {
-					const uint32_t t = (b0 + u < tot) ? __builtin_amdgcn_readfirstlane(act_load(b0 + u)) : 0xFFFFFFFFu;
+					const uint32_t t = (b0 + u < tot) ? __builtin_amdgcn_readfirstlane(my_act_load(b0 + u)) : 0xFFFFFFFFu;
 					rv[u] = (t != 0xFFFFFFFFu) ? ld_sc1(&Xn[(int64_t) t * 64 + lane]) : (V) 0;
 				}
 #pragma unroll
@@ -1601,17 +1652,36 @@ __global__ __launch_bounds__(64) void schur_group_kernel(GroupArgs d)
 			__builtin_amdgcn_wave_barrier();
 		}
 		GR_TICK(6);
+		// row lengths = sums over the waves; the entries of wave w come after those of the waves before it
+		int before = 0, row_count = count;
+		if (NW > 1) {
+			((volatile int __attribute__((address_space(3))) *) &cnt_w[0][0])[wv * 64 + lane] = count;
+			wg_sync();
+			row_count = 0;
+#pragma unroll
+			for (int w2 = 0; w2 < NW; w2++) {
+				const int cw = ((volatile int __attribute__((address_space(3))) *) &cnt_w[0][0])[w2 * 64 + lane];
+				row_count += cw;
+				before += (w2 < wv) ? cw : 0;
+			}
+		}
 		int gtot;
-		const int excl = wave_exclusive_scan(count, lane, gtot);
-		unsigned long long got = 0;
-		if (lane == 0)
-			got = atomicAdd(&a.ctr64[C64_POOL], (unsigned long long) gtot);
-		const uint32_t g_lo = __builtin_amdgcn_readfirstlane((uint32_t) got);
-		const uint32_t g_hi = __builtin_amdgcn_readfirstlane((uint32_t) (got >> 32));
+		const int excl = wave_exclusive_scan(row_count, lane, gtot);
+		if (wv == 0) {
+			unsigned long long got = 0;
+			if (lane == 0) {
+				got = atomicAdd(&a.ctr64[C64_POOL], (unsigned long long) gtot);
+				ctl_l[5] = (int) (uint32_t) got;
+				ctl_l[6] = (int) (uint32_t) (got >> 32);
+			}
+		}
+		wg_sync();
+		const uint32_t g_lo = (uint32_t) __builtin_amdgcn_readfirstlane(ctl_l[5]);
+		const uint32_t g_hi = (uint32_t) __builtin_amdgcn_readfirstlane(ctl_l[6]);
 		const int64_t base_off = (int64_t) (((uint64_t) g_hi << 32) | g_lo);
 		const bool fits = base_off + gtot <= a.pool_cap;
-		int64_t wpos = base_off + excl;
-		for (int wb = 0; wb < nwS; wb += GR_ACT / 32) {
+		int64_t wpos = base_off + excl + before;
+		for (int wb = wb_lo; wb < wb_hi; wb += CW) {
 			const int tot = list_touched(wb);
 			if ((lane & 3) == 0 && wb + (lane >> 2) < nwS)
 				bm_g[nw + wb + (lane >> 2)] = 0;
@@ -1620,7 +1690,7 @@ __global__ __launch_bounds__(64) void schur_group_kernel(GroupArgs d)
 				uint32_t tt[OB];
 #pragma unroll
 				for (int u = 0; u < OB; u++) {
-					tt[u] = (b0 + u < tot) ? __builtin_amdgcn_readfirstlane(act_load(b0 + u)) : 0xFFFFFFFFu;
+					tt[u] = (b0 + u < tot) ? __builtin_amdgcn_readfirstlane(my_act_load(b0 + u)) : 0xFFFFFFFFu;
 					rv[u] = (tt[u] != 0xFFFFFFFFu) ? ld_sc1(&Xn[(int64_t) tt[u] * 64 + lane]) : (V) 0;
 				}
 #pragma unroll
@@ -1639,22 +1709,24 @@ __global__ __launch_bounds__(64) void schur_group_kernel(GroupArgs d)
 			__builtin_amdgcn_wave_barrier();
 		}
 		GR_TICK(7);
-		if (have_row) {
-			if (fits) {
-				a.row_off[k] = (base_off + excl) | (1LL << 62);
-				a.row_len[k] = count;
-			} else {
-				a.row_len[k] = -1;
+		if (wv == 0) {
+			if (have_row) {
+				if (fits) {
+					a.row_off[k] = (base_off + excl) | (1LL << 62);
+					a.row_len[k] = row_count;
+				} else {
+					a.row_len[k] = -1;
+				}
 			}
+			if (!fits && lane == 0)
+				atomicOr(&a.ctr[CTR_STATUS], 1);
+			st_done += fits ? __popcll(__ballot(have_row)) : 0;
 		}
-		if (!fits && lane == 0)
-			atomicOr(&a.ctr[CTR_STATUS], 1);
-		st_done += fits ? __popcll(__ballot(have_row)) : 0;
 	}
 	drain_vmem();
 #ifdef SPASM_GROUP_PROFILE
 	GR_TICK(7);
-	if (lane == 0)
+	if (threadIdx.x == 0)
 		for (int q = 0; q < 8; q++)
 			atomicAdd(&a.ctr64[C64_PROF0 + q], prof[q]);
 #endif
@@ -1680,9 +1752,22 @@ void group_geometry(int rpad, int Sm, bool wide, int64_t *slot_bytes, int64_t *o
 	*slot_bytes = *off_bm + ((int64_t) ((rpad + Sm) / 32 + 2) * 4 + 255) / 256 * 256;      // one bit per label
 }
 
+template <bool WIDE, bool LBM, int NW>
+static void launch_group_variant(const GroupArgs &d, int blocks, size_t lds_bytes, hipStream_t stream)
+{
+	static bool configured = false;
+	if (LBM && !configured) {
+		HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(&schur_group_kernel<WIDE, LBM, NW>),
+		                              hipFuncAttributeMaxDynamicSharedMemorySize, GR_LBM_MAX_BYTES));
+		configured = true;
+	}
+	hipLaunchKernelGGL((schur_group_kernel<WIDE, LBM, NW>), dim3(blocks), dim3(64 * NW), LBM ? lds_bytes : 0, stream, d);
+}
+
+// waves: 1 or 4 waves per row group (4: few groups, the chain of a group is the run time)
 void launch_schur_group(const SchurArgs &a, unsigned char *scratch, int64_t slot_bytes, int64_t off_bm, bool wide,
                         uint32_t *dense_out, int64_t ldS, int blocks, hipStream_t stream, int watch, float min_eff,
-                        long long min_w)
+                        long long min_w, int waves)
 {
 	GroupArgs d;
 	d.a = a;
@@ -1696,23 +1781,16 @@ void launch_schur_group(const SchurArgs &a, unsigned char *scratch, int64_t slot
 	d.ldS = ldS;
 	const size_t bm_bytes = ((size_t) a.r / 32 + 1) * 4;
 	const bool lbm = bm_bytes <= (size_t) GR_LBM_MAX_BYTES;
+	const bool four = waves >= 4;
 	if (lbm) {
-		static bool configured = false;
-		if (!configured) {
-			HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(&schur_group_kernel<true, true>),
-			                              hipFuncAttributeMaxDynamicSharedMemorySize, GR_LBM_MAX_BYTES));
-			HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(&schur_group_kernel<false, true>),
-			                              hipFuncAttributeMaxDynamicSharedMemorySize, GR_LBM_MAX_BYTES));
-			configured = true;
-		}
 		if (wide)
-			hipLaunchKernelGGL((schur_group_kernel<true, true>), dim3(blocks), dim3(64), bm_bytes, stream, d);
+			four ? launch_group_variant<true, true, 4>(d, blocks, bm_bytes, stream) : launch_group_variant<true, true, 1>(d, blocks, bm_bytes, stream);
 		else
-			hipLaunchKernelGGL((schur_group_kernel<false, true>), dim3(blocks), dim3(64), bm_bytes, stream, d);
+			four ? launch_group_variant<false, true, 4>(d, blocks, bm_bytes, stream) : launch_group_variant<false, true, 1>(d, blocks, bm_bytes, stream);
 	} else if (wide) {
-		hipLaunchKernelGGL((schur_group_kernel<true, false>), dim3(blocks), dim3(64), 0, stream, d);
+		four ? launch_group_variant<true, false, 4>(d, blocks, 0, stream) : launch_group_variant<true, false, 1>(d, blocks, 0, stream);
 	} else {
-		hipLaunchKernelGGL((schur_group_kernel<false, false>), dim3(blocks), dim3(64), 0, stream, d);
+		four ? launch_group_variant<false, false, 4>(d, blocks, 0, stream) : launch_group_variant<false, false, 1>(d, blocks, 0, stream);
 	}
 	HIP_CHECK(hipGetLastError());
 }
