@@ -231,6 +231,10 @@ def main():
         tfile = os.path.join(ROOT, "profiles", "traffic_r01.json")
         if os.path.exists(tfile):
             traffic = json.load(open(tfile)).get("schur_group_kernel_bytes_per_launch" if group else "schur_wave_dense_kernel_bytes_per_launch")
+        # waves per row group: the library's own rule (schur_api.hip), for the kernel name rocprofv3 shows
+        cus = torch.cuda.get_device_properties(0).multi_processor_count
+        ngroups_rank = (len(my_rows) + 63) // 64
+        group_waves = int(os.environ.get("SPASM_HIP_GROUP_WAVES", 4 if ngroups_rank <= 3 * cus else 2 if ngroups_rank <= 12 * cus else 1))
         out = {
             "metric": "rows eliminated/sec (sparse Schur complement, mod 42013)",
             "value": total_rows / (elapsed / args.steps),
@@ -252,7 +256,7 @@ def main():
                        "sharding": "rows over %d rank(s)%s" % (world, ", all-gatherv of S" if use_dist else "")},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": 8000.0, "unit": "GB/s",
                          "frac": achieved / 8000.0, "traffic": traffic,
-                         "kernel": "schur_group_kernel<false,true>" if group else "schur_wave_dense_kernel<false>",
+                         "kernel": ("schur_group_kernel<false,true,%d>" % group_waves) if group else "schur_wave_dense_kernel<false>",
                          "kernel_ms": kernel_ms,
                          "algorithmic_bytes": int(algo),
                          "ms_by_kernel": {"schur_lds_kernel<1024>": t_tiers[0] / args.steps,

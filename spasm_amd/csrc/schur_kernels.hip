@@ -1764,7 +1764,7 @@ static void launch_group_variant(const GroupArgs &d, int blocks, size_t lds_byte
 	hipLaunchKernelGGL((schur_group_kernel<WIDE, LBM, NW>), dim3(blocks), dim3(64 * NW), LBM ? lds_bytes : 0, stream, d);
 }
 
-// waves: 1 or 4 waves per row group (4: few groups, the chain of a group is the run time)
+// waves: 1, 2 or 4 waves per row group (more when groups are few: the chain of a group is then the run time)
 void launch_schur_group(const SchurArgs &a, unsigned char *scratch, int64_t slot_bytes, int64_t off_bm, bool wide,
                         uint32_t *dense_out, int64_t ldS, int blocks, hipStream_t stream, int watch, float min_eff,
                         long long min_w, int waves)
@@ -1781,17 +1781,25 @@ void launch_schur_group(const SchurArgs &a, unsigned char *scratch, int64_t slot
 	d.ldS = ldS;
 	const size_t bm_bytes = ((size_t) a.r / 32 + 1) * 4;
 	const bool lbm = bm_bytes <= (size_t) GR_LBM_MAX_BYTES;
-	const bool four = waves >= 4;
-	if (lbm) {
-		if (wide)
-			four ? launch_group_variant<true, true, 4>(d, blocks, bm_bytes, stream) : launch_group_variant<true, true, 1>(d, blocks, bm_bytes, stream);
-		else
-			four ? launch_group_variant<false, true, 4>(d, blocks, bm_bytes, stream) : launch_group_variant<false, true, 1>(d, blocks, bm_bytes, stream);
-	} else if (wide) {
-		four ? launch_group_variant<true, false, 4>(d, blocks, 0, stream) : launch_group_variant<true, false, 1>(d, blocks, 0, stream);
-	} else {
-		four ? launch_group_variant<false, false, 4>(d, blocks, 0, stream) : launch_group_variant<false, false, 1>(d, blocks, 0, stream);
-	}
+	const int nwv = waves >= 4 ? 4 : waves >= 2 ? 2 : 1;
+#define SPASM_LAUNCH_GROUP(WIDE_, LBM_, LDS_)                                                    \
+	do {                                                                                        \
+		if (nwv == 4)                                                                           \
+			launch_group_variant<WIDE_, LBM_, 4>(d, blocks, LDS_, stream);                      \
+		else if (nwv == 2)                                                                      \
+			launch_group_variant<WIDE_, LBM_, 2>(d, blocks, LDS_, stream);                      \
+		else                                                                                    \
+			launch_group_variant<WIDE_, LBM_, 1>(d, blocks, LDS_, stream);                      \
+	} while (0)
+	if (lbm && wide)
+		SPASM_LAUNCH_GROUP(true, true, bm_bytes);
+	else if (lbm)
+		SPASM_LAUNCH_GROUP(false, true, bm_bytes);
+	else if (wide)
+		SPASM_LAUNCH_GROUP(true, false, 0);
+	else
+		SPASM_LAUNCH_GROUP(false, false, 0);
+#undef SPASM_LAUNCH_GROUP
 	HIP_CHECK(hipGetLastError());
 }
 

@@ -1,15 +1,23 @@
-import os, sys, time
-sys.path.insert(0, "/root/repo"); os.environ["SPASM_HIP_VERBOSE"]="0"
+"""Row-group kernel: run time against the number of row groups (mk13.b5, every k-th row), for 1 and 4 waves per
+group.  With few groups the run time is the chain of level rounds of one group, not the throughput of the chip.
+Run on a GPU box: python tools/probe_groups.py"""
+import os, sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+os.environ["SPASM_HIP_VERBOSE"] = "0"
 import numpy as np, torch, bench, spasm_amd
+
 A, rows, F = bench.build_workload("mk13.b5")
-dA = spasm_amd.DeviceCsr.from_host(A); dF = spasm_amd.DeviceFact(F)
-n = len(rows)
-cases = [("every 16th", rows[::16]), ("all", rows)]
-for name, sub in cases:
-    sub = np.ascontiguousarray(sub)
-    W = spasm_amd.SchurWorkspace(len(sub), A.m, 4 * A.nnz + (1 << 28))
+dA = spasm_amd.DeviceCsr.from_host(A)
+dF = spasm_amd.DeviceFact(F)
+for step in (1, 2, 3, 4, 8, 16, 64):
+    sub = np.ascontiguousarray(rows[::step])
     d = torch.from_numpy(sub).cuda()
-    for _ in range(2):
-        S, st = spasm_amd.dschur(dA, d, dF, W, fetch=False)
-    print("%-14s rows %6d groups %4d: group kernel %.1f ms, elim %.3e, wave-pivots %.3e, streamed %.3e, eff %.2f" % (name, len(sub), (len(sub)+63)//64, st.ms_group, st.eliminations, st.group_pivots, st.entries_streamed, st.eliminations / (64.0 * max(1, st.group_pivots))), flush=True)
-    W.close()
+    line = "every %2d. row: %6d rows %4d groups:" % (step, len(sub), (len(sub) + 63) // 64)
+    for waves in (1, 2, 4):
+        os.environ["SPASM_HIP_GROUP_WAVES"] = str(waves)
+        W = spasm_amd.SchurWorkspace(len(sub), A.m, 4 * A.nnz + (1 << 28))
+        for _ in range(3):
+            S, st = spasm_amd.dschur(dA, d, dF, W, fetch=False)
+        line += "  %d wave(s) %6.2f ms" % (waves, st.ms_group if st.used_group_kernel else st.ms_eliminate)
+        W.close()
+    print(line + "  (lane efficiency %.2f)" % (st.eliminations / (64.0 * max(1, st.group_pivots))), flush=True)
