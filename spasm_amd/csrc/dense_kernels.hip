@@ -13,6 +13,9 @@
 //        digit products, i32 accumulators, recombined mod p).  Larger primes
 //        use a tiled 64-bit VALU kernel.
 // Values are canonical representatives in [0, p) stored as u32.
+#include <algorithm>
+#include <cstring>
+#include <type_traits>
 #include "device_types.h"
 #include "field_dev.h"
 
@@ -304,6 +307,355 @@ __global__ __launch_bounds__(COOP_THREADS) void rref_panel_coop_kernel(CoopPanel
 	}
 }
 
+// --------------------------------------------------------------------------
+// Tournament panel step (default).  The column-by-column panel kernels above
+// pay one grid-wide synchronisation per column.  Instead:
+//   1. rref_free_list: the rows that hold no pivot yet;
+//   2. rref_select_kernel, a tree of them: a workgroup takes 256 candidate rows (one per thread, their 64 panel
+//      entries column-major in LDS), runs a fraction-free forward elimination with "first non-zero" pivoting and
+//      passes on the <= 64 rows it picked -- a basis of the row space of its 256 rows restricted to the panel.
+//      The root of the tree therefore holds k <= 64 ACTUAL rows rho spanning what every free row has in the panel;
+//   3. rref_block_gj (one workgroup): Gauss-Jordan of [ A[rho, panel] | I ]: pivot columns gamma (the column rank
+//      profile of the panel: leftmost, because the k rows span everything) and Ginv with Ginv A[rho, gamma] = I;
+//   4. rref_multipliers: M = -A[:, gamma] Ginv (+ Ginv on the pivot rows), n x k, so that T = I + M e_rho^T;
+//   5. the usual gather + GEMM update, from the first column of the panel on.
+// Everything is exact arithmetic: any basis gives the same (unique) reduced echelon form.
+// --------------------------------------------------------------------------
+constexpr int SEL_ROWS = 256;
+
+// list[0 .. count) = rows i with flags[i] == 0, increasing.  One workgroup.
+__global__ __launch_bounds__(1024) void rref_free_list(const int *flags, int n, int *list, int *count)
+{
+	__shared__ int part[1024];
+	const int tid = threadIdx.x;
+	const int per = (n + 1023) / 1024;
+	const int lo = min(n, tid * per), hi = min(n, lo + per);
+	int c = 0;
+	for (int i = lo; i < hi; i++)
+		c += flags[i] == 0;
+	part[tid] = c;
+	__syncthreads();
+	for (int d = 1; d < 1024; d <<= 1) {
+		const int v = (tid >= d) ? part[tid - d] : 0;
+		__syncthreads();
+		part[tid] += v;
+		__syncthreads();
+	}
+	int pos = part[tid] - c;
+	for (int i = lo; i < hi; i++)
+		if (flags[i] == 0)
+			list[pos++] = i;
+	if (tid == 1023)
+		*count = part[1023];
+}
+
+// pv * x - f * y mod p, up to a common non-zero factor (fraction-free elimination step).
+//   SMALL (p < 46341, so that 2 p^2 < 2^32): 24-bit multiplies (full rate) and one Barrett reduction;
+//   otherwise two Montgomery products (a common factor 2^-32, which does not matter here).
+template <bool SMALL> struct ElimArith {
+	uint32_t p, pinv, pp, m;
+	__device__ explicit ElimArith(const MontDev &F) : p(F.p), pinv(F.pinv), pp(SMALL ? F.p * F.p : 0u), m(SMALL ? (uint32_t) (0x100000000ull / F.p) : 0u) {}
+	__device__ __forceinline__ uint32_t mulsub(uint32_t pv, uint32_t x, uint32_t f, uint32_t y) const
+	{
+		if constexpr (SMALL) {
+			const uint32_t v = __umul24(pv, x) + (pp - __umul24(f, y));       // in (0, 2 p^2) < 2^32
+			const uint32_t q = __umulhi(v, m);                                // floor(v / p) - 2 <= q <= floor(v / p)
+			uint32_t rem = v - __umul24(q, p);
+			rem = (rem >= p) ? rem - p : rem;
+			rem = (rem >= p) ? rem - p : rem;
+			return rem;
+		} else {
+			const MontDev F{p, pinv, 0u, 0u, 0u};
+			return submod(montmul(pv, x, F), montmul(f, y, F), F);
+		}
+	}
+};
+
+template <int I, int N, typename Fn> __device__ __forceinline__ void dense_static_for(Fn &&f)
+{
+	if constexpr (I < N) {
+		f(std::integral_constant<int, I>{});
+		dense_static_for<I + 1, N>(f);
+	}
+}
+
+// cand_in: n_in row indices (-1 = nothing); n_in_dev (if not null) overrides n_in.  Output: 64 slots per workgroup.
+// One row per thread, kept in 64 registers (the column loop is unrolled: static register indices); the pivot row
+// of a step is broadcast through LDS.
+template <bool SMALL>
+__global__ __launch_bounds__(SEL_ROWS) void rref_select_kernel(const uint32_t *A, int64_t ld, int c0, int width, const int *cand_in,
+                                                               int n_in, const int *n_in_dev, int *cand_out, MontDev F,
+                                                               const int *skip, int *full)
+{
+	__shared__ __attribute__((aligned(16))) uint32_t prow[NB];
+	__shared__ unsigned long long wave_nz[SEL_ROWS / 64];
+	const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+	const ElimArith<SMALL> E(F);
+	// skip: the first 256 free rows already gave a pivot in every column of the panel (tournament not needed)
+	if (skip != nullptr && *skip != 0)
+		return;
+	if (n_in_dev != nullptr)
+		n_in = (full != nullptr) ? min(*n_in_dev, SEL_ROWS) : *n_in_dev;
+	const int idx = blockIdx.x * SEL_ROWS + tid;
+	const int row = (idx < n_in) ? cand_in[idx] : -1;
+	if (blockIdx.x * SEL_ROWS >= n_in) {          // nothing for this workgroup
+		if (tid < NB)
+			cand_out[blockIdx.x * NB + tid] = -1;
+		if (full != nullptr && tid == 0)
+			*full = 0;
+		return;
+	}
+	uint32_t x[NB];
+	{
+		const uint32_t *src = A + (int64_t) (row >= 0 ? row : 0) * ld + c0;
+#pragma unroll
+		for (int j = 0; j < NB; j++)
+			x[j] = (row >= 0 && j < width) ? src[j] : 0u;
+	}
+	bool selected = false;
+	int nsel = 0;
+	dense_static_for<0, NB>([&](auto cc) {
+		constexpr int col = decltype(cc)::value;
+		if (col >= width)
+			return;
+		const uint32_t mine = x[col];
+		const unsigned long long nz = __ballot(!selected && mine != 0);
+		if (lane == 0)
+			wave_nz[wave] = nz;
+		__syncthreads();
+		int winner = -1;
+#pragma unroll
+		for (int q = SEL_ROWS / 64 - 1; q >= 0; q--) {
+			const unsigned long long w = wave_nz[q];
+			if (w != 0)
+				winner = q * 64 + __builtin_ctzll(w);
+		}
+		if (winner < 0) {
+			__syncthreads();            // (wave_nz is rewritten by the next column)
+			return;
+		}
+		if (tid == winner) {
+#pragma unroll
+			for (int j = col; j < NB; j++)
+				prow[j] = x[j];
+			selected = true;
+			cand_out[blockIdx.x * NB + nsel] = row;
+		}
+		nsel += 1;
+		__syncthreads();
+		if (!selected && mine != 0) {
+			const uint32_t pv = prow[col];
+#pragma unroll
+			for (int j = col + 1; j < NB; j++)
+				x[j] = E.mulsub(pv, x[j], mine, prow[j]);
+		}
+		__syncthreads();                // (prow is rewritten by the next column)
+	});
+	if (tid >= nsel && tid < NB)
+		cand_out[blockIdx.x * NB + tid] = -1;
+	if (full != nullptr && tid == 0)
+		*full = (nsel == width) ? 1 : 0;
+}
+
+struct BlockGjArgs {
+	const uint32_t *A;
+	int64_t ld;
+	int n, c0, width;
+	const int *cand;       // NB slots, -1 = nothing: independent rows (output of the root of the tournament)
+	const int *cand_first; // ... or of the first 256 free rows, when *full says they gave a pivot in every column
+	const int *full;
+	uint32_t *Ginv;        // NB x NB, Montgomery form (value * 2^32 mod p), row s = pivot s, column r = candidate r
+	int *gamma;            // NB: pivot columns inside the panel, increasing
+	int *is_pivot_row;
+	int *pivrow, *pivcol, *rank, *knew, *rho;
+	MontDev F;
+};
+
+// One workgroup of 256 threads, Gauss-Jordan of [R | I] (64 x 128).  Thread t keeps column t % 128 of the rows of
+// parity t / 128 in 32 registers; per step the column being eliminated and the pivot row go through LDS.
+template <bool SMALL>
+__global__ __launch_bounds__(256) void rref_block_gj(BlockGjArgs g)
+{
+	__shared__ uint32_t colbuf[NB];
+	__shared__ uint32_t prow[PW];
+	__shared__ uint32_t diag[NB];
+	__shared__ int s_rows[NB], s_gamma[NB], s_prow_of[NB];
+	__shared__ int s_k, s_piv;
+	const int tid = threadIdx.x;
+	const MontDev F = g.F;
+	const ElimArith<SMALL> E(F);
+	if (tid < NB) {
+		const int *cand = (*g.full != 0) ? g.cand_first : g.cand;
+		const int c = cand[tid];
+		const unsigned long long have = __ballot(c >= 0);
+		if (c >= 0)
+			s_rows[__popcll(have & ((1ull << tid) - 1ull))] = c;
+		if (tid == 0)
+			s_k = __popcll(have);
+		s_prow_of[tid] = -1;          // pivot index held by row r
+	}
+	__syncthreads();
+	const int k = s_k;
+	if (k == 0) {
+		if (tid == 0)
+			*g.knew = 0;
+		return;
+	}
+	const int j = tid & (PW - 1), par = tid >> 7;          // my column; my rows: r = 2 i + par
+	uint32_t x[NB / 2];
+#pragma unroll
+	for (int i = 0; i < NB / 2; i++) {
+		const int r = 2 * i + par;
+		uint32_t v = 0;
+		if (r < k) {
+			if (j < NB)
+				v = (j < g.width) ? g.A[(int64_t) s_rows[r] * g.ld + g.c0 + j] : 0u;
+			else
+				v = (j - NB == r) ? 1u : 0u;
+		}
+		x[i] = v;
+	}
+	int npiv = 0;
+	for (int col = 0; col < g.width && npiv < k; col++) {
+		if (j == col) {
+#pragma unroll
+			for (int i = 0; i < NB / 2; i++)
+				colbuf[2 * i + par] = x[i];
+		}
+		__syncthreads();
+		if (tid < 64) {
+			// first row that holds no pivot yet and is non-zero in this column: one ballot of wave 0
+			const unsigned long long nz = __ballot(tid < k && s_prow_of[tid] < 0 && colbuf[tid] != 0);
+			if (tid == 0)
+				s_piv = (nz != 0) ? __builtin_ctzll(nz) : -1;
+		}
+		__syncthreads();
+		const int pr = s_piv;
+		if (pr < 0)
+			continue;               // (uniform; colbuf is rewritten after the next barrier only by column col + 1's owners)
+		if ((pr & 1) == par) {
+			uint32_t mine = 0;
+#pragma unroll
+			for (int i = 0; i < NB / 2; i++)
+				mine = (i == (pr >> 1)) ? x[i] : mine;
+			prow[j] = mine;
+		}
+		__syncthreads();
+		const uint32_t pv = colbuf[pr], pj = prow[j];
+#pragma unroll
+		for (int i = 0; i < NB / 2; i++) {
+			const int r = 2 * i + par;
+			const uint32_t f = colbuf[r];
+			if (r != pr && f != 0)
+				x[i] = (j == col) ? 0u : E.mulsub(pv, x[i], f, pj);
+		}
+		if (tid == 0) {
+			s_prow_of[pr] = npiv;
+			s_gamma[npiv] = col;
+		}
+		npiv += 1;
+		__syncthreads();
+	}
+	// (the candidates are independent: npiv == k; a defect would show as a wrong rank in the tests)
+	// scale: pivot row s has d at gamma_s, zeros at the other pivot columns; Ginv[s][r] = aug[s][r] / d
+#pragma unroll
+	for (int i = 0; i < NB / 2; i++) {
+		const int r = 2 * i + par;
+		if (r < k && s_prow_of[r] >= 0 && j == s_gamma[s_prow_of[r]])
+			diag[r] = x[i];
+	}
+	__syncthreads();
+	if (tid < k && s_prow_of[tid] >= 0)
+		diag[tid] = invmod(diag[tid], F);
+	__syncthreads();
+#pragma unroll
+	for (int i = 0; i < NB / 2; i++) {
+		const int r = 2 * i + par;
+		if (r < k && j >= NB && j - NB < k && s_prow_of[r] >= 0)
+			// Montgomery form of (aug / d): mulmod gives the plain product, one more montmul by r2 lifts it
+			g.Ginv[s_prow_of[r] * NB + (j - NB)] = montmul(mulmod(x[i], diag[r], F), F.r2, F);
+	}
+	const int base = *g.rank;
+	__syncthreads();
+	if (tid < npiv)
+		g.gamma[tid] = s_gamma[tid];
+	if (tid < k) {
+		g.rho[tid] = s_rows[tid];
+		const int s = s_prow_of[tid];
+		if (s >= 0) {
+			g.is_pivot_row[s_rows[tid]] = 1;
+			g.pivrow[base + s] = s_rows[tid];
+			g.pivcol[base + s] = g.c0 + s_gamma[s];
+		}
+	}
+	if (tid == 0) {
+		*g.rank = base + npiv;
+		*g.knew = k;
+	}
+}
+
+// M[i][r] = -sum_s A[i, c0 + gamma_s] Ginv[s][r]  (+ Ginv[s][r] on the row that became pivot s), stored where the
+// update kernels read it: P[(NB + r) * n + i].  Thread = (row, 4 consecutive r).
+__global__ __launch_bounds__(256) void rref_multipliers(const uint32_t *A, int64_t ld, int n, int c0, const uint32_t *Ginv,
+                                                        const int *gamma, const int *knew, uint32_t *P, MontDev F)
+{
+	__shared__ uint32_t sG[NB][NB + 1];
+	__shared__ int sgam[NB];
+	const int k = *knew;
+	if (k == 0)
+		return;
+	const int tid = threadIdx.x;
+	for (int t = tid; t < NB * NB; t += 256)
+		sG[t / NB][t % NB] = (t / NB < k && t % NB < k) ? Ginv[t] : 0u;
+	if (tid < NB)
+		sgam[tid] = (tid < k) ? gamma[tid] : 0;
+	__syncthreads();
+	// 64 rows per workgroup: thread (tid & 63) = row, (tid >> 6) = quarter of the r range
+	const int i = blockIdx.x * 64 + (tid & 63);
+	const int q = tid >> 6;
+	if (i >= n)
+		return;
+	uint32_t acc[16];
+#pragma unroll
+	for (int u = 0; u < 16; u++)
+		acc[u] = 0;
+	for (int s = 0; s < k; s++) {
+		const uint32_t a = A[(int64_t) i * ld + c0 + sgam[s]];
+		if (a == 0)
+			continue;
+#pragma unroll
+		for (int u = 0; u < 16; u++) {
+			uint32_t v = acc[u] + montmul(a, sG[s][q * 16 + u], F);
+			acc[u] = (v >= F.p || v < acc[u]) ? v - F.p : v;
+		}
+	}
+	// (the new pivot rows get their extra term from rref_multipliers_fix)
+#pragma unroll
+	for (int u = 0; u < 16; u++) {
+		const int r = q * 16 + u;
+		if (r < k)
+			P[(int64_t) (NB + r) * n + i] = (acc[u] == 0) ? 0u : F.p - acc[u];
+	}
+}
+
+// pivot rows: M[rho_r'][r] += Ginv[s(r')][r] where s(r') is the pivot index of candidate r'
+__global__ __launch_bounds__(256) void rref_multipliers_fix(int n, const uint32_t *Ginv, const int *rho, const int *pivrow,
+                                                            const int *rank, const int *knew, uint32_t *P, MontDev F)
+{
+	const int k = *knew;
+	const int base = *rank - k;         // (every candidate became a pivot)
+	for (int t = threadIdx.x; t < k * k; t += 256) {
+		const int s = t / k, r = t % k;
+		const int i = pivrow[base + s];
+		const uint32_t g = montmul(Ginv[s * NB + r], 1u, F);       // out of Montgomery form
+		uint32_t *dst = &P[(int64_t) (NB + r) * n + i];
+		uint32_t v = *dst + g;
+		if (v >= F.p || v < g)
+			v -= F.p;
+		*dst = v;
+	}
+}
+
 // B[t, :] = A[rho[t], c1:]  (old values of the new pivot rows), k x mr, row-major ld = mr
 __global__ void rref_gather_pivot_rows(const uint32_t *A, int64_t ld, int c1, int mr, const int *rho, const int *knew,
                                        uint32_t *B)
@@ -493,6 +845,23 @@ int device_rref(int64_t prime, int n, int m, uint32_t *dA, int64_t ld, int *d_pi
 	int coop_min_rows = 2048;
 	if (const char *e = std::getenv("SPASM_HIP_COOP_ROWS"))
 		coop_min_rows = std::atoi(e);
+	// panel step: tournament (default) or the column-by-column kernels (SPASM_HIP_RREF_PANEL=columns)
+	bool tournament = true;
+	const bool small_prime = prime < 46341;          // 2 p^2 < 2^32: the panel kernels use 24-bit multiplies
+	if (const char *e = std::getenv("SPASM_HIP_RREF_PANEL"))
+		tournament = std::strcmp(e, "columns") != 0;
+	int *candA = nullptr, *candB = nullptr, *free_count = nullptr, *gamma = nullptr, *cand_first = nullptr, *full_flag = nullptr;
+	uint32_t *Ginv = nullptr;
+	if (tournament) {
+		const size_t cand_len = (size_t) std::max(n, ((n + SEL_ROWS - 1) / SEL_ROWS) * NB) + NB;
+		HIP_CHECK(hipMalloc((void **) &candA, cand_len * sizeof(int)));
+		HIP_CHECK(hipMalloc((void **) &candB, cand_len * sizeof(int)));
+		HIP_CHECK(hipMalloc((void **) &free_count, 64));
+		HIP_CHECK(hipMalloc((void **) &gamma, NB * sizeof(int)));
+		HIP_CHECK(hipMalloc((void **) &cand_first, NB * sizeof(int)));
+		HIP_CHECK(hipMalloc((void **) &full_flag, 64));
+		HIP_CHECK(hipMalloc((void **) &Ginv, NB * NB * sizeof(uint32_t)));
+	}
 	unsigned int *coop_barrier = nullptr;
 	int *coop_cand = nullptr, *coop_err = nullptr;
 	HIP_CHECK(hipMalloc((void **) &coop_barrier, 64));
@@ -530,7 +899,59 @@ int device_rref(int64_t prime, int n, int m, uint32_t *dA, int64_t ld, int *d_pi
 		g.knew = knew;
 		g.rho = rho;
 		g.F = F;
-		if (n >= coop_min_rows) {
+		if (tournament) {
+			hipLaunchKernelGGL(rref_free_list, dim3(1), dim3(1024), 0, stream, flags, n, candA, free_count);
+			// the first 256 free rows alone: when they give a pivot in every column of the panel (the usual case
+			// while the block is not exhausted) the tournament below returns at once
+			if (small_prime)
+				hipLaunchKernelGGL(rref_select_kernel<true>, dim3(1), dim3(SEL_ROWS), 0, stream, dA, ld, c0, width, candA, n,
+				                   free_count, cand_first, F, nullptr, full_flag);
+			else
+				hipLaunchKernelGGL(rref_select_kernel<false>, dim3(1), dim3(SEL_ROWS), 0, stream, dA, ld, c0, width, candA, n,
+				                   free_count, cand_first, F, nullptr, full_flag);
+			int n_in = n;
+			const int *count_dev = free_count;
+			int *src = candA, *dst = candB;
+			for (;;) {
+				const int wgs = (n_in + SEL_ROWS - 1) / SEL_ROWS;
+				if (small_prime)
+					hipLaunchKernelGGL(rref_select_kernel<true>, dim3(wgs), dim3(SEL_ROWS), 0, stream, dA, ld, c0, width, src, n_in,
+					                   count_dev, dst, F, full_flag, nullptr);
+				else
+					hipLaunchKernelGGL(rref_select_kernel<false>, dim3(wgs), dim3(SEL_ROWS), 0, stream, dA, ld, c0, width, src, n_in,
+					                   count_dev, dst, F, full_flag, nullptr);
+				// (the first level reads candA and writes candB; candA is then free)
+				std::swap(src, dst);
+				n_in = wgs * NB;
+				count_dev = nullptr;
+				if (wgs == 1)
+					break;
+			}
+			BlockGjArgs bg;
+			bg.A = dA;
+			bg.ld = ld;
+			bg.n = n;
+			bg.c0 = c0;
+			bg.width = width;
+			bg.cand = src;
+			bg.cand_first = cand_first;
+			bg.full = full_flag;
+			bg.Ginv = Ginv;
+			bg.gamma = gamma;
+			bg.is_pivot_row = flags;
+			bg.pivrow = pivrow;
+			bg.pivcol = d_pivcol;
+			bg.rank = rank_d;
+			bg.knew = knew;
+			bg.rho = rho;
+			bg.F = F;
+			if (small_prime)
+				hipLaunchKernelGGL(rref_block_gj<true>, dim3(1), dim3(256), 0, stream, bg);
+			else
+				hipLaunchKernelGGL(rref_block_gj<false>, dim3(1), dim3(256), 0, stream, bg);
+			hipLaunchKernelGGL(rref_multipliers, dim3((n + 63) / 64), dim3(256), 0, stream, dA, ld, n, c0, Ginv, gamma, knew, P, F);
+			hipLaunchKernelGGL(rref_multipliers_fix, dim3(1), dim3(256), 0, stream, n, Ginv, rho, pivrow, rank_d, knew, P, F);
+		} else if (n >= coop_min_rows) {
 			CoopPanelArgs ca;
 			ca.g = g;
 			ca.barrier = coop_barrier;
@@ -545,7 +966,8 @@ int device_rref(int64_t prime, int n, int m, uint32_t *dA, int64_t ld, int *d_pi
 		} else {
 			hipLaunchKernelGGL(rref_panel_kernel, dim3(1), dim3(PANEL_THREADS), 0, stream, g);
 		}
-		const int c1 = c0 + width;
+		// (the tournament step leaves the panel columns themselves to the update)
+		const int c1 = tournament ? c0 : c0 + width;
 		const int mr = m - c1;
 		if (mr > 0) {
 			hipLaunchKernelGGL(rref_gather_pivot_rows, dim3(512), dim3(256), 0, stream, dA, ld, c1, mr, rho, knew, B);
@@ -570,6 +992,15 @@ int device_rref(int64_t prime, int n, int m, uint32_t *dA, int64_t ld, int *d_pi
 	HIP_CHECK(hipMemcpyAsync(&rank, rank_d, sizeof(int), hipMemcpyDeviceToHost, stream));
 	HIP_CHECK(hipMemcpyAsync(&coop_failed, coop_err, sizeof(int), hipMemcpyDeviceToHost, stream));
 	HIP_CHECK(hipStreamSynchronize(stream));
+	if (tournament) {
+		(void) hipFree(candA);
+		(void) hipFree(candB);
+		(void) hipFree(free_count);
+		(void) hipFree(gamma);
+		(void) hipFree(cand_first);
+		(void) hipFree(full_flag);
+		(void) hipFree(Ginv);
+	}
 	(void) hipFree(coop_barrier);
 	(void) hipFree(coop_cand);
 	(void) hipFree(coop_err);
