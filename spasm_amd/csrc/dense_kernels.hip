@@ -802,6 +802,140 @@ __global__ __launch_bounds__(256) void rref_update_mfma(uint32_t *A, int64_t ld,
 	}
 }
 
+// ---- super-panels: the trailing update of up to four panels in one pass (K up to 256) ----
+// Four consecutive panels T1..T4 are factored with the columns of their super-panel kept up to date (K = 64
+// updates of at most 192 columns); beyond the super-panel, T4 T3 T2 T1 C = C + sum_i M_i B_i with
+// B_i = rows rho_i of (T_{i-1} .. T_1 C) = C[rho_i] + sum_{j<i} M_j[rho_i, :] B_j: the B_i cost a few 64 x 64 x m
+// products, then C is read and written once instead of four times, and reduced mod p once per element.
+struct UpdSets {
+	const uint32_t *P[4];     // multipliers of set s: P[s][(NB + t) * n + i]
+	const uint32_t *B[4];     // k_s x mr, row-major
+	const int *knew[4];
+	int nsets;
+};
+
+// Bt_i[t, :] = A[rho_i[t], c1:] + sum_{j < i} M_j[rho_i[t], :] B_j.   grid (column chunks, NB), 256 threads
+template <bool SMALL16>
+__global__ __launch_bounds__(256) void rref_trailing_B(const uint32_t *A, int64_t ld, int n, int c1, int mr, UpdSets S,
+                                                       const int *rho_i, const int *knew_i, uint32_t *Bt, MontDev F)
+{
+	__shared__ uint32_t mrow[4][NB];
+	const int t = blockIdx.y;
+	if (t >= *knew_i)
+		return;
+	const int row = rho_i[t];
+	const int tid = threadIdx.x;
+	{
+		const int j = tid >> 6, s = tid & 63;
+		uint32_t v = 0;
+		if (j < S.nsets && s < *S.knew[j]) {
+			v = S.P[j][(int64_t) (NB + s) * n + row];
+			if (!SMALL16)
+				v = montmul(v, F.r2, F);          // Montgomery form: montmul(v, b) = v b
+		}
+		mrow[j][s] = v;
+	}
+	__syncthreads();
+	const int col = blockIdx.x * 256 + tid;
+	if (col >= mr)
+		return;
+	const uint32_t a = A[(int64_t) row * ld + c1 + col];
+	if (SMALL16) {
+		unsigned long long acc = a;                 // < 2^16 + 256 * 2^32
+		for (int j = 0; j < S.nsets; j++) {
+			const int kj = *S.knew[j];
+			const uint32_t *Bj = S.B[j] + col;
+			for (int s = 0; s < kj; s++)
+				acc += (unsigned long long) mrow[j][s] * Bj[(int64_t) s * mr];
+		}
+		Bt[(int64_t) t * mr + col] = reduce_sum(acc, F);
+	} else {
+		uint32_t acc = a;
+		for (int j = 0; j < S.nsets; j++) {
+			const int kj = *S.knew[j];
+			const uint32_t *Bj = S.B[j] + col;
+			for (int s = 0; s < kj; s++) {
+				const uint32_t v = acc + montmul(mrow[j][s], Bj[(int64_t) s * mr], F);
+				acc = (v >= F.p || v < acc) ? v - F.p : v;
+			}
+		}
+		Bt[(int64_t) t * mr + col] = acc;
+	}
+}
+
+// C[:, c1:] += sum_s M_s B_s on the matrix cores (p <= 65279), 64 x 64 tile per workgroup, one epilogue.
+__global__ __launch_bounds__(256) void rref_update_mfma_multi(uint32_t *A, int64_t ld, int n, int c1, int mr, UpdSets S, MontDev F)
+{
+	__shared__ __attribute__((aligned(16))) signed char Mhi[64][64 + 16], Mlo[64][64 + 16];   // [row][k]
+	__shared__ __attribute__((aligned(16))) signed char Bhi[64][64 + 16], Blo[64][64 + 16];   // [col][k]  (transposed)
+	const int tid = threadIdx.x;
+	const int row0 = blockIdx.y * 64, col0 = blockIdx.x * 64;
+	const int wave = tid >> 6, lane = tid & 63;
+	const int wr = (wave >> 1) * 32, wc = (wave & 1) * 32;      // this wave's 32 x 32 tile
+	const int rsel = lane & 31, khalf = (lane >> 5) * 16;
+	v16i acc_hh = {0}, acc_hl = {0}, acc_lh = {0}, acc_ll = {0};
+	bool any = false;
+	for (int s = 0; s < S.nsets; s++) {
+		const int k = *S.knew[s];
+		if (k == 0)
+			continue;
+		if (any)
+			__syncthreads();          // the previous set's tiles have been consumed
+		any = true;
+		const uint32_t *P = S.P[s], *B = S.B[s];
+		for (int t = tid; t < 64 * 64; t += 256) {
+			const int kk = t / 64, rr = t % 64;                 // consecutive threads: consecutive rows of a column of M
+			const int i = row0 + rr;
+			const uint32_t v = (i < n && kk < k) ? P[(int64_t) (NB + kk) * n + i] : 0u;
+			int hi, lo;
+			split_digits(v, F, hi, lo);
+			Mhi[rr][kk] = (signed char) hi;
+			Mlo[rr][kk] = (signed char) lo;
+		}
+		for (int t = tid; t < 64 * 64; t += 256) {
+			const int kk = t / 64, cc = t % 64;          // coalesced read of B rows
+			const int j = col0 + cc;
+			const uint32_t v = (kk < k && j < mr) ? B[(int64_t) kk * mr + j] : 0u;
+			int hi, lo;
+			split_digits(v, F, hi, lo);
+			Bhi[cc][kk] = (signed char) hi;
+			Blo[cc][kk] = (signed char) lo;
+		}
+		__syncthreads();
+#pragma unroll
+		for (int ks = 0; ks < 64; ks += 32) {
+			const v4i a_hi = *reinterpret_cast<const v4i *>(&Mhi[wr + rsel][ks + khalf]);
+			const v4i a_lo = *reinterpret_cast<const v4i *>(&Mlo[wr + rsel][ks + khalf]);
+			const v4i b_hi = *reinterpret_cast<const v4i *>(&Bhi[wc + rsel][ks + khalf]);
+			const v4i b_lo = *reinterpret_cast<const v4i *>(&Blo[wc + rsel][ks + khalf]);
+			acc_hh = __builtin_amdgcn_mfma_i32_32x32x32_i8(a_hi, b_hi, acc_hh, 0, 0, 0);
+			acc_hl = __builtin_amdgcn_mfma_i32_32x32x32_i8(a_hi, b_lo, acc_hl, 0, 0, 0);
+			acc_lh = __builtin_amdgcn_mfma_i32_32x32x32_i8(a_lo, b_hi, acc_lh, 0, 0, 0);
+			acc_ll = __builtin_amdgcn_mfma_i32_32x32x32_i8(a_lo, b_lo, acc_ll, 0, 0, 0);
+		}
+	}
+	if (!any)
+		return;
+	// |sum| <= 256 (p/2)^2 < p 2^22 for p < 2^16: shift by a multiple of p to stay non-negative
+	const long long offset = (long long) F.p << 23;
+#pragma unroll
+	for (int reg = 0; reg < 16; reg++) {
+		const int rr = (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5);
+		const int cc = lane & 31;
+		const int i = row0 + wr + rr, j = col0 + wc + cc;
+		if (i >= n || j >= mr)
+			continue;
+		const long long sv = (long long) acc_hh[reg] * 65536 + ((long long) acc_hl[reg] + (long long) acc_lh[reg]) * 256 +
+		                     (long long) acc_ll[reg] + offset;
+		const uint32_t mred = reduce_sum((unsigned long long) sv, F);
+		uint32_t *dst = A + (int64_t) i * ld + c1 + j;
+		uint32_t sum = *dst + mred;
+		if (sum >= F.p)
+			sum -= F.p;
+		*dst = sum;
+	}
+}
+
 // echelon rows to the top, in pivot-column order (rows that hold no pivot are zero after the
 // full elimination): tmp[t, :] = A[pivrow[t], :], then copied back.
 __global__ void rref_rows_to_tmp(const uint32_t *A, int64_t ld, int m, const int *pivrow, int rank, uint32_t *tmp)
@@ -851,7 +985,8 @@ int device_rref(int64_t prime, int n, int m, uint32_t *dA, int64_t ld, int *d_pi
 	if (const char *e = std::getenv("SPASM_HIP_RREF_PANEL"))
 		tournament = std::strcmp(e, "columns") != 0;
 	int *candA = nullptr, *candB = nullptr, *free_count = nullptr, *gamma = nullptr, *cand_first = nullptr, *full_flag = nullptr;
-	uint32_t *Ginv = nullptr;
+	uint32_t *Ginv = nullptr, *P4 = nullptr, *Bt4 = nullptr;
+	int *rho4 = nullptr, *knew4 = nullptr;
 	if (tournament) {
 		const size_t cand_len = (size_t) std::max(n, ((n + SEL_ROWS - 1) / SEL_ROWS) * NB) + NB;
 		HIP_CHECK(hipMalloc((void **) &candA, cand_len * sizeof(int)));
@@ -859,6 +994,10 @@ int device_rref(int64_t prime, int n, int m, uint32_t *dA, int64_t ld, int *d_pi
 		HIP_CHECK(hipMalloc((void **) &free_count, 64));
 		HIP_CHECK(hipMalloc((void **) &gamma, NB * sizeof(int)));
 		HIP_CHECK(hipMalloc((void **) &cand_first, NB * sizeof(int)));
+		HIP_CHECK(hipMalloc((void **) &P4, (size_t) 4 * (size_t) n * PW * sizeof(uint32_t)));
+		HIP_CHECK(hipMalloc((void **) &Bt4, (size_t) 4 * (size_t) NB * (size_t) m * sizeof(uint32_t)));
+		HIP_CHECK(hipMalloc((void **) &rho4, 4 * NB * sizeof(int)));
+		HIP_CHECK(hipMalloc((void **) &knew4, 4 * 16 * sizeof(int)));
 		HIP_CHECK(hipMalloc((void **) &full_flag, 64));
 		HIP_CHECK(hipMalloc((void **) &Ginv, NB * NB * sizeof(uint32_t)));
 	}
@@ -875,118 +1014,193 @@ int device_rref(int64_t prime, int n, int m, uint32_t *dA, int64_t ld, int *d_pi
 	}
 	float total_update = 0.f;
 	const bool mfma_ok = use_mfma && prime <= 65279;      // two signed base-256 digits must fit int8
-	for (int c0 = 0; c0 < m; c0 += NB) {
-		if (c0 > 0 && (c0 / NB) % 8 == 0) {           // every row already holds a pivot: the rest is reduced
-			int rk = 0;
-			HIP_CHECK(hipMemcpyAsync(&rk, rank_d, sizeof(int), hipMemcpyDeviceToHost, stream));
-			HIP_CHECK(hipStreamSynchronize(stream));
-			if (rk >= n)
-				break;
+	auto timed = [&](auto &&launch) {
+		if (ms_update != nullptr)
+			HIP_CHECK(hipEventRecord(e0, stream));
+		launch();
+		if (ms_update != nullptr) {
+			HIP_CHECK(hipEventRecord(e1, stream));
+			HIP_CHECK(hipEventSynchronize(e1));
+			float ms;
+			HIP_CHECK(hipEventElapsedTime(&ms, e0, e1));
+			total_update += ms;
 		}
-		const int width = (m - c0 < NB) ? m - c0 : NB;
-		PanelArgs g;
-		g.A = dA;
-		g.ld = ld;
-		g.n = n;
-		g.m = m;
-		g.c0 = c0;
-		g.width = width;
-		g.P = P;
-		g.is_pivot_row = flags;
-		g.pivrow = pivrow;
-		g.pivcol = d_pivcol;
-		g.rank = rank_d;
-		g.knew = knew;
-		g.rho = rho;
-		g.F = F;
-		if (tournament) {
-			hipLaunchKernelGGL(rref_free_list, dim3(1), dim3(1024), 0, stream, flags, n, candA, free_count);
-			// the first 256 free rows alone: when they give a pivot in every column of the panel (the usual case
-			// while the block is not exhausted) the tournament below returns at once
-			if (small_prime)
-				hipLaunchKernelGGL(rref_select_kernel<true>, dim3(1), dim3(SEL_ROWS), 0, stream, dA, ld, c0, width, candA, n,
-				                   free_count, cand_first, F, nullptr, full_flag);
-			else
-				hipLaunchKernelGGL(rref_select_kernel<false>, dim3(1), dim3(SEL_ROWS), 0, stream, dA, ld, c0, width, candA, n,
-				                   free_count, cand_first, F, nullptr, full_flag);
-			int n_in = n;
-			const int *count_dev = free_count;
-			int *src = candA, *dst = candB;
-			for (;;) {
-				const int wgs = (n_in + SEL_ROWS - 1) / SEL_ROWS;
-				if (small_prime)
-					hipLaunchKernelGGL(rref_select_kernel<true>, dim3(wgs), dim3(SEL_ROWS), 0, stream, dA, ld, c0, width, src, n_in,
-					                   count_dev, dst, F, full_flag, nullptr);
-				else
-					hipLaunchKernelGGL(rref_select_kernel<false>, dim3(wgs), dim3(SEL_ROWS), 0, stream, dA, ld, c0, width, src, n_in,
-					                   count_dev, dst, F, full_flag, nullptr);
-				// (the first level reads candA and writes candB; candA is then free)
-				std::swap(src, dst);
-				n_in = wgs * NB;
-				count_dev = nullptr;
-				if (wgs == 1)
+	};
+	if (tournament) {
+		const bool small16 = prime < 65536;
+		constexpr int SPW = 4;                       // panels per super-panel
+		for (int sp0 = 0, spi = 0; sp0 < m; sp0 += SPW * NB, spi++) {
+			if (spi > 0 && spi % 2 == 0) {           // every row already holds a pivot: the rest is reduced
+				int rk = 0;
+				HIP_CHECK(hipMemcpyAsync(&rk, rank_d, sizeof(int), hipMemcpyDeviceToHost, stream));
+				HIP_CHECK(hipStreamSynchronize(stream));
+				if (rk >= n)
 					break;
 			}
-			BlockGjArgs bg;
-			bg.A = dA;
-			bg.ld = ld;
-			bg.n = n;
-			bg.c0 = c0;
-			bg.width = width;
-			bg.cand = src;
-			bg.cand_first = cand_first;
-			bg.full = full_flag;
-			bg.Ginv = Ginv;
-			bg.gamma = gamma;
-			bg.is_pivot_row = flags;
-			bg.pivrow = pivrow;
-			bg.pivcol = d_pivcol;
-			bg.rank = rank_d;
-			bg.knew = knew;
-			bg.rho = rho;
-			bg.F = F;
-			if (small_prime)
-				hipLaunchKernelGGL(rref_block_gj<true>, dim3(1), dim3(256), 0, stream, bg);
-			else
-				hipLaunchKernelGGL(rref_block_gj<false>, dim3(1), dim3(256), 0, stream, bg);
-			hipLaunchKernelGGL(rref_multipliers, dim3((n + 63) / 64), dim3(256), 0, stream, dA, ld, n, c0, Ginv, gamma, knew, P, F);
-			hipLaunchKernelGGL(rref_multipliers_fix, dim3(1), dim3(256), 0, stream, n, Ginv, rho, pivrow, rank_d, knew, P, F);
-		} else if (n >= coop_min_rows) {
-			CoopPanelArgs ca;
-			ca.g = g;
-			ca.barrier = coop_barrier;
-			ca.cand = coop_cand;
-			ca.err = coop_err;
-			HIP_CHECK(hipMemsetAsync(coop_barrier, 0, sizeof(unsigned int), stream));
-			HIP_CHECK(hipMemsetAsync(coop_cand, 0x7F, NB * sizeof(int), stream));     // 0x7F7F7F7F >= any row index
-			int G = (n + COOP_THREADS - 1) / COOP_THREADS;
-			if (G > 64)
-				G = 64;
-			hipLaunchKernelGGL(rref_panel_coop_kernel, dim3(G), dim3(COOP_THREADS), 0, stream, ca);
-		} else {
-			hipLaunchKernelGGL(rref_panel_kernel, dim3(1), dim3(PANEL_THREADS), 0, stream, g);
-		}
-		// (the tournament step leaves the panel columns themselves to the update)
-		const int c1 = tournament ? c0 : c0 + width;
-		const int mr = m - c1;
-		if (mr > 0) {
-			hipLaunchKernelGGL(rref_gather_pivot_rows, dim3(512), dim3(256), 0, stream, dA, ld, c1, mr, rho, knew, B);
-			dim3 grid((mr + 63) / 64, (n + 63) / 64);
-			if (ms_update != nullptr)
-				HIP_CHECK(hipEventRecord(e0, stream));
-			if (mfma_ok)
-				hipLaunchKernelGGL(rref_update_mfma, grid, dim3(256), 0, stream, dA, ld, n, c1, mr, P, B, knew, F);
-			else
-				hipLaunchKernelGGL(rref_update_valu, grid, dim3(256), 0, stream, dA, ld, n, c1, mr, P, B, knew, F);
-			if (ms_update != nullptr) {
-				HIP_CHECK(hipEventRecord(e1, stream));
-				HIP_CHECK(hipEventSynchronize(e1));
-				float ms;
-				HIP_CHECK(hipEventElapsedTime(&ms, e0, e1));
-				total_update += ms;
+			const int sp_end = std::min(m, sp0 + SPW * NB);
+			const int mrT = m - sp_end;              // columns beyond the super-panel
+			UpdSets S{};
+			int nsets = 0;
+			for (int c0 = sp0; c0 < sp_end; c0 += NB, nsets++) {
+				const int width = std::min(NB, m - c0);
+				uint32_t *P_s = P4 + (size_t) nsets * (size_t) n * PW;
+				int *rho_s = rho4 + nsets * NB, *knew_s = knew4 + nsets * 16;
+				hipLaunchKernelGGL(rref_free_list, dim3(1), dim3(1024), 0, stream, flags, n, candA, free_count);
+				// the first 256 free rows alone: when they give a pivot in every column of the panel (the usual case
+				// while the block is not exhausted) the tournament below returns at once
+				if (small_prime)
+					hipLaunchKernelGGL(rref_select_kernel<true>, dim3(1), dim3(SEL_ROWS), 0, stream, dA, ld, c0, width, candA, n,
+					                   free_count, cand_first, F, nullptr, full_flag);
+				else
+					hipLaunchKernelGGL(rref_select_kernel<false>, dim3(1), dim3(SEL_ROWS), 0, stream, dA, ld, c0, width, candA, n,
+					                   free_count, cand_first, F, nullptr, full_flag);
+				int n_in = n;
+				const int *count_dev = free_count;
+				int *src = candA, *dst = candB;
+				for (;;) {
+					const int wgs = (n_in + SEL_ROWS - 1) / SEL_ROWS;
+					if (small_prime)
+						hipLaunchKernelGGL(rref_select_kernel<true>, dim3(wgs), dim3(SEL_ROWS), 0, stream, dA, ld, c0, width, src, n_in,
+						                   count_dev, dst, F, full_flag, nullptr);
+					else
+						hipLaunchKernelGGL(rref_select_kernel<false>, dim3(wgs), dim3(SEL_ROWS), 0, stream, dA, ld, c0, width, src, n_in,
+						                   count_dev, dst, F, full_flag, nullptr);
+					// (the first level reads candA and writes candB; candA is then free)
+					std::swap(src, dst);
+					n_in = wgs * NB;
+					count_dev = nullptr;
+					if (wgs == 1)
+						break;
+				}
+				BlockGjArgs bg;
+				bg.A = dA;
+				bg.ld = ld;
+				bg.n = n;
+				bg.c0 = c0;
+				bg.width = width;
+				bg.cand = src;
+				bg.cand_first = cand_first;
+				bg.full = full_flag;
+				bg.Ginv = Ginv;
+				bg.gamma = gamma;
+				bg.is_pivot_row = flags;
+				bg.pivrow = pivrow;
+				bg.pivcol = d_pivcol;
+				bg.rank = rank_d;
+				bg.knew = knew_s;
+				bg.rho = rho_s;
+				bg.F = F;
+				if (small_prime)
+					hipLaunchKernelGGL(rref_block_gj<true>, dim3(1), dim3(256), 0, stream, bg);
+				else
+					hipLaunchKernelGGL(rref_block_gj<false>, dim3(1), dim3(256), 0, stream, bg);
+				hipLaunchKernelGGL(rref_multipliers, dim3((n + 63) / 64), dim3(256), 0, stream, dA, ld, n, c0, Ginv, gamma, knew_s, P_s, F);
+				hipLaunchKernelGGL(rref_multipliers_fix, dim3(1), dim3(256), 0, stream, n, Ginv, rho_s, pivrow, rank_d, knew_s, P_s, F);
+				// the columns of the super-panel, from this panel on: K = 64 update now
+				const int mr_sp = sp_end - c0;
+				hipLaunchKernelGGL(rref_gather_pivot_rows, dim3(512), dim3(256), 0, stream, dA, ld, c0, mr_sp, rho_s, knew_s, B);
+				UpdSets one{};
+				one.P[0] = P_s;
+				one.B[0] = B;
+				one.knew[0] = knew_s;
+				one.nsets = 1;
+				timed([&]() {
+					dim3 grid((mr_sp + 63) / 64, (n + 63) / 64);
+					if (mfma_ok)
+						hipLaunchKernelGGL(rref_update_mfma_multi, grid, dim3(256), 0, stream, dA, ld, n, c0, mr_sp, one, F);
+					else
+						hipLaunchKernelGGL(rref_update_valu, grid, dim3(256), 0, stream, dA, ld, n, c0, mr_sp, P_s, B, knew_s, F);
+				});
+				// beyond the super-panel: only the rows rho of this panel are brought up to date (B_i)
+				if (mrT > 0) {
+					S.nsets = nsets;          // the sets before this one
+					uint32_t *Bt_s = Bt4 + (size_t) nsets * (size_t) NB * (size_t) m;
+					dim3 grid((mrT + 255) / 256, NB);
+					if (small16)
+						hipLaunchKernelGGL(rref_trailing_B<true>, grid, dim3(256), 0, stream, dA, ld, n, sp_end, mrT, S, rho_s, knew_s, Bt_s, F);
+					else
+						hipLaunchKernelGGL(rref_trailing_B<false>, grid, dim3(256), 0, stream, dA, ld, n, sp_end, mrT, S, rho_s, knew_s, Bt_s, F);
+					S.P[nsets] = P_s;
+					S.B[nsets] = Bt_s;
+					S.knew[nsets] = knew_s;
+				}
+				HIP_CHECK(hipGetLastError());
+			}
+			if (mrT > 0) {
+				S.nsets = nsets;
+				timed([&]() {
+					dim3 grid((mrT + 63) / 64, (n + 63) / 64);
+					if (mfma_ok) {
+						hipLaunchKernelGGL(rref_update_mfma_multi, grid, dim3(256), 0, stream, dA, ld, n, sp_end, mrT, S, F);
+					} else {
+						for (int s = 0; s < nsets; s++)
+							hipLaunchKernelGGL(rref_update_valu, grid, dim3(256), 0, stream, dA, ld, n, sp_end, mrT, S.P[s], S.B[s], S.knew[s], F);
+					}
+				});
+				HIP_CHECK(hipGetLastError());
 			}
 		}
-		HIP_CHECK(hipGetLastError());
+	} else {
+		for (int c0 = 0; c0 < m; c0 += NB) {
+			if (c0 > 0 && (c0 / NB) % 8 == 0) {           // every row already holds a pivot: the rest is reduced
+				int rk = 0;
+				HIP_CHECK(hipMemcpyAsync(&rk, rank_d, sizeof(int), hipMemcpyDeviceToHost, stream));
+				HIP_CHECK(hipStreamSynchronize(stream));
+				if (rk >= n)
+					break;
+			}
+			const int width = (m - c0 < NB) ? m - c0 : NB;
+			PanelArgs g;
+			g.A = dA;
+			g.ld = ld;
+			g.n = n;
+			g.m = m;
+			g.c0 = c0;
+			g.width = width;
+			g.P = P;
+			g.is_pivot_row = flags;
+			g.pivrow = pivrow;
+			g.pivcol = d_pivcol;
+			g.rank = rank_d;
+			g.knew = knew;
+			g.rho = rho;
+			g.F = F;
+			if (n >= coop_min_rows) {
+				CoopPanelArgs ca;
+				ca.g = g;
+				ca.barrier = coop_barrier;
+				ca.cand = coop_cand;
+				ca.err = coop_err;
+				HIP_CHECK(hipMemsetAsync(coop_barrier, 0, sizeof(unsigned int), stream));
+				HIP_CHECK(hipMemsetAsync(coop_cand, 0x7F, NB * sizeof(int), stream));     // 0x7F7F7F7F >= any row index
+				int G = (n + COOP_THREADS - 1) / COOP_THREADS;
+				if (G > 64)
+					G = 64;
+				hipLaunchKernelGGL(rref_panel_coop_kernel, dim3(G), dim3(COOP_THREADS), 0, stream, ca);
+			} else {
+				hipLaunchKernelGGL(rref_panel_kernel, dim3(1), dim3(PANEL_THREADS), 0, stream, g);
+			}
+			const int c1 = c0 + width;
+			const int mr = m - c1;
+			if (mr > 0) {
+				hipLaunchKernelGGL(rref_gather_pivot_rows, dim3(512), dim3(256), 0, stream, dA, ld, c1, mr, rho, knew, B);
+				dim3 grid((mr + 63) / 64, (n + 63) / 64);
+				if (ms_update != nullptr)
+					HIP_CHECK(hipEventRecord(e0, stream));
+				if (mfma_ok)
+					hipLaunchKernelGGL(rref_update_mfma, grid, dim3(256), 0, stream, dA, ld, n, c1, mr, P, B, knew, F);
+				else
+					hipLaunchKernelGGL(rref_update_valu, grid, dim3(256), 0, stream, dA, ld, n, c1, mr, P, B, knew, F);
+				if (ms_update != nullptr) {
+					HIP_CHECK(hipEventRecord(e1, stream));
+					HIP_CHECK(hipEventSynchronize(e1));
+					float ms;
+					HIP_CHECK(hipEventElapsedTime(&ms, e0, e1));
+					total_update += ms;
+				}
+			}
+			HIP_CHECK(hipGetLastError());
+		}
 	}
 	int rank = 0, coop_failed = 0;
 	HIP_CHECK(hipMemcpyAsync(&rank, rank_d, sizeof(int), hipMemcpyDeviceToHost, stream));
@@ -998,6 +1212,10 @@ int device_rref(int64_t prime, int n, int m, uint32_t *dA, int64_t ld, int *d_pi
 		(void) hipFree(free_count);
 		(void) hipFree(gamma);
 		(void) hipFree(cand_first);
+		(void) hipFree(P4);
+		(void) hipFree(Bt4);
+		(void) hipFree(rho4);
+		(void) hipFree(knew4);
 		(void) hipFree(full_flag);
 		(void) hipFree(Ginv);
 	}
