@@ -811,8 +811,60 @@ struct UpdSets {
 	const uint32_t *P[4];     // multipliers of set s: P[s][(NB + t) * n + i]
 	const uint32_t *B[4];     // k_s x mr, row-major
 	const int *knew[4];
+	// the same as signed base-256 digits (matrix-core path): M8[plane][i][64], B8[plane][col][64], zero beyond k_s
+	const signed char *Mh[4], *Ml[4], *Bh[4], *Bl[4];
 	int nsets;
 };
+
+// digits of the multipliers of one set: one thread per row
+__global__ __launch_bounds__(256) void rref_split_M(const uint32_t *P, int n, const int *knew, signed char *Mh, signed char *Ml, MontDev F)
+{
+	const int i = blockIdx.x * 256 + threadIdx.x;
+	if (i >= n)
+		return;
+	const int k = *knew;
+	int4 *dh = reinterpret_cast<int4 *>(Mh + (int64_t) i * 64), *dl = reinterpret_cast<int4 *>(Ml + (int64_t) i * 64);
+#pragma unroll
+	for (int part = 0; part < 4; part++) {
+		unsigned int wh[4] = {0, 0, 0, 0}, wl[4] = {0, 0, 0, 0};
+#pragma unroll
+		for (int b = 0; b < 16; b++) {
+			const int kk = part * 16 + b;
+			const uint32_t v = (kk < k) ? P[(int64_t) (NB + kk) * n + i] : 0u;
+			int hi, lo;
+			split_digits(v, F, hi, lo);
+			wh[b >> 2] |= (unsigned int) (hi & 255) << (8 * (b & 3));
+			wl[b >> 2] |= (unsigned int) (lo & 255) << (8 * (b & 3));
+		}
+		dh[part] = make_int4((int) wh[0], (int) wh[1], (int) wh[2], (int) wh[3]);
+		dl[part] = make_int4((int) wl[0], (int) wl[1], (int) wl[2], (int) wl[3]);
+	}
+}
+
+// digits of B (k x mr, row-major): one thread per column
+__global__ __launch_bounds__(256) void rref_split_B(const uint32_t *B, int mr, const int *knew, signed char *Bh, signed char *Bl, MontDev F)
+{
+	const int col = blockIdx.x * 256 + threadIdx.x;
+	if (col >= mr)
+		return;
+	const int k = *knew;
+	int4 *dh = reinterpret_cast<int4 *>(Bh + (int64_t) col * 64), *dl = reinterpret_cast<int4 *>(Bl + (int64_t) col * 64);
+#pragma unroll
+	for (int part = 0; part < 4; part++) {
+		unsigned int wh[4] = {0, 0, 0, 0}, wl[4] = {0, 0, 0, 0};
+#pragma unroll
+		for (int b = 0; b < 16; b++) {
+			const int kk = part * 16 + b;
+			const uint32_t v = (kk < k) ? B[(int64_t) kk * mr + col] : 0u;
+			int hi, lo;
+			split_digits(v, F, hi, lo);
+			wh[b >> 2] |= (unsigned int) (hi & 255) << (8 * (b & 3));
+			wl[b >> 2] |= (unsigned int) (lo & 255) << (8 * (b & 3));
+		}
+		dh[part] = make_int4((int) wh[0], (int) wh[1], (int) wh[2], (int) wh[3]);
+		dl[part] = make_int4((int) wl[0], (int) wl[1], (int) wl[2], (int) wl[3]);
+	}
+}
 
 // Bt_i[t, :] = A[rho_i[t], c1:] + sum_{j < i} M_j[rho_i[t], :] B_j.   grid (column chunks, NB), 256 threads
 template <bool SMALL16>
@@ -882,24 +934,19 @@ __global__ __launch_bounds__(256) void rref_update_mfma_multi(uint32_t *A, int64
 		if (any)
 			__syncthreads();          // the previous set's tiles have been consumed
 		any = true;
-		const uint32_t *P = S.P[s], *B = S.B[s];
-		for (int t = tid; t < 64 * 64; t += 256) {
-			const int kk = t / 64, rr = t % 64;                 // consecutive threads: consecutive rows of a column of M
-			const int i = row0 + rr;
-			const uint32_t v = (i < n && kk < k) ? P[(int64_t) (NB + kk) * n + i] : 0u;
-			int hi, lo;
-			split_digits(v, F, hi, lo);
-			Mhi[rr][kk] = (signed char) hi;
-			Mlo[rr][kk] = (signed char) lo;
-		}
-		for (int t = tid; t < 64 * 64; t += 256) {
-			const int kk = t / 64, cc = t % 64;          // coalesced read of B rows
-			const int j = col0 + cc;
-			const uint32_t v = (kk < k && j < mr) ? B[(int64_t) kk * mr + j] : 0u;
-			int hi, lo;
-			split_digits(v, F, hi, lo);
-			Bhi[cc][kk] = (signed char) hi;
-			Blo[cc][kk] = (signed char) lo;
+		{
+			// 64 rows (columns) x 64 digit bytes per plane: thread t moves 16 bytes of row (column) t / 4
+			const int rr = tid >> 2, part = (tid & 3) * 16;
+			const int i = row0 + rr, j = col0 + rr;
+			const int4 zero = make_int4(0, 0, 0, 0);
+			const int4 mh = (i < n) ? *reinterpret_cast<const int4 *>(S.Mh[s] + (int64_t) i * 64 + part) : zero;
+			const int4 ml = (i < n) ? *reinterpret_cast<const int4 *>(S.Ml[s] + (int64_t) i * 64 + part) : zero;
+			const int4 bh = (j < mr) ? *reinterpret_cast<const int4 *>(S.Bh[s] + (int64_t) j * 64 + part) : zero;
+			const int4 bl = (j < mr) ? *reinterpret_cast<const int4 *>(S.Bl[s] + (int64_t) j * 64 + part) : zero;
+			*reinterpret_cast<int4 *>(&Mhi[rr][part]) = mh;
+			*reinterpret_cast<int4 *>(&Mlo[rr][part]) = ml;
+			*reinterpret_cast<int4 *>(&Bhi[rr][part]) = bh;
+			*reinterpret_cast<int4 *>(&Blo[rr][part]) = bl;
 		}
 		__syncthreads();
 #pragma unroll
@@ -987,6 +1034,7 @@ int device_rref(int64_t prime, int n, int m, uint32_t *dA, int64_t ld, int *d_pi
 	int *candA = nullptr, *candB = nullptr, *free_count = nullptr, *gamma = nullptr, *cand_first = nullptr, *full_flag = nullptr;
 	uint32_t *Ginv = nullptr, *P4 = nullptr, *Bt4 = nullptr;
 	int *rho4 = nullptr, *knew4 = nullptr;
+	signed char *M8 = nullptr, *B8 = nullptr;
 	if (tournament) {
 		const size_t cand_len = (size_t) std::max(n, ((n + SEL_ROWS - 1) / SEL_ROWS) * NB) + NB;
 		HIP_CHECK(hipMalloc((void **) &candA, cand_len * sizeof(int)));
@@ -997,6 +1045,9 @@ int device_rref(int64_t prime, int n, int m, uint32_t *dA, int64_t ld, int *d_pi
 		HIP_CHECK(hipMalloc((void **) &P4, (size_t) 4 * (size_t) n * PW * sizeof(uint32_t)));
 		HIP_CHECK(hipMalloc((void **) &Bt4, (size_t) 4 * (size_t) NB * (size_t) m * sizeof(uint32_t)));
 		HIP_CHECK(hipMalloc((void **) &rho4, 4 * NB * sizeof(int)));
+		// digit planes: per set M (2 x n x 64) and trailing B (2 x m x 64); one more B pair for the super-panel's own columns
+		HIP_CHECK(hipMalloc((void **) &M8, (size_t) 4 * 2 * (size_t) n * 64));
+		HIP_CHECK(hipMalloc((void **) &B8, (size_t) 5 * 2 * (size_t) m * 64));
 		HIP_CHECK(hipMalloc((void **) &knew4, 4 * 16 * sizeof(int)));
 		HIP_CHECK(hipMalloc((void **) &full_flag, 64));
 		HIP_CHECK(hipMalloc((void **) &Ginv, NB * NB * sizeof(uint32_t)));
@@ -1104,6 +1155,16 @@ int device_rref(int64_t prime, int n, int m, uint32_t *dA, int64_t ld, int *d_pi
 				one.B[0] = B;
 				one.knew[0] = knew_s;
 				one.nsets = 1;
+				signed char *Mh_s = M8 + (size_t) nsets * 2 * (size_t) n * 64, *Ml_s = Mh_s + (size_t) n * 64;
+				if (mfma_ok) {
+					signed char *Bh_p = B8 + (size_t) 4 * 2 * (size_t) m * 64, *Bl_p = Bh_p + (size_t) m * 64;
+					hipLaunchKernelGGL(rref_split_M, dim3((n + 255) / 256), dim3(256), 0, stream, P_s, n, knew_s, Mh_s, Ml_s, F);
+					hipLaunchKernelGGL(rref_split_B, dim3((mr_sp + 255) / 256), dim3(256), 0, stream, B, mr_sp, knew_s, Bh_p, Bl_p, F);
+					one.Mh[0] = Mh_s;
+					one.Ml[0] = Ml_s;
+					one.Bh[0] = Bh_p;
+					one.Bl[0] = Bl_p;
+				}
 				timed([&]() {
 					dim3 grid((mr_sp + 63) / 64, (n + 63) / 64);
 					if (mfma_ok)
@@ -1123,6 +1184,14 @@ int device_rref(int64_t prime, int n, int m, uint32_t *dA, int64_t ld, int *d_pi
 					S.P[nsets] = P_s;
 					S.B[nsets] = Bt_s;
 					S.knew[nsets] = knew_s;
+					if (mfma_ok) {
+						signed char *Bh_s = B8 + (size_t) nsets * 2 * (size_t) m * 64, *Bl_s = Bh_s + (size_t) m * 64;
+						hipLaunchKernelGGL(rref_split_B, dim3((mrT + 255) / 256), dim3(256), 0, stream, Bt_s, mrT, knew_s, Bh_s, Bl_s, F);
+						S.Mh[nsets] = Mh_s;
+						S.Ml[nsets] = Ml_s;
+						S.Bh[nsets] = Bh_s;
+						S.Bl[nsets] = Bl_s;
+					}
 				}
 				HIP_CHECK(hipGetLastError());
 			}
@@ -1215,6 +1284,8 @@ int device_rref(int64_t prime, int n, int m, uint32_t *dA, int64_t ld, int *d_pi
 		(void) hipFree(P4);
 		(void) hipFree(Bt4);
 		(void) hipFree(rho4);
+		(void) hipFree(M8);
+		(void) hipFree(B8);
 		(void) hipFree(knew4);
 		(void) hipFree(full_flag);
 		(void) hipFree(Ginv);
