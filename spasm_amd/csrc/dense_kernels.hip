@@ -464,6 +464,7 @@ struct BlockGjArgs {
 	const int *cand;       // NB slots, -1 = nothing: independent rows (output of the root of the tournament)
 	const int *cand_first; // ... or of the first 256 free rows, when *full says they gave a pivot in every column
 	const int *full;
+	const unsigned short *invtab;   // p < 46341: inverses of 0 .. p-1 (global copy of the LDS table)
 	uint32_t *Ginv;        // NB x NB, Montgomery form (value * 2^32 mod p), row s = pivot s, column r = candidate r
 	int *gamma;            // NB: pivot columns inside the panel, increasing
 	int *is_pivot_row;
@@ -471,11 +472,23 @@ struct BlockGjArgs {
 	MontDev F;
 };
 
+// inverses mod p of 1 .. p-1 (p < 46341), for the small-prime Gauss-Jordan below
+__global__ __launch_bounds__(256) void rref_inverse_table(unsigned short *tab, MontDev F)
+{
+	const uint32_t a = blockIdx.x * 256 + threadIdx.x;
+	if (a < F.p)
+		tab[a] = (a == 0) ? 0 : (unsigned short) invmod(a, F);
+}
+
 // One workgroup of 256 threads, Gauss-Jordan of [R | I] (64 x 128).  Thread t keeps column t % 128 of the rows of
 // parity t / 128 in 32 registers; per step the column being eliminated and the pivot row go through LDS.
+//   SMALL (p < 46341): the table of inverses sits in LDS (2 p bytes, dynamic), pivot rows are normalised, an
+//   update is one 24-bit multiply + Barrett and only touches the columns where the pivot row is non-zero;
+//   otherwise: fraction-free steps (two Montgomery products per element), one inversion per pivot at the end.
 template <bool SMALL>
 __global__ __launch_bounds__(256) void rref_block_gj(BlockGjArgs g)
 {
+	extern __shared__ unsigned short invtab[];
 	__shared__ uint32_t colbuf[NB];
 	__shared__ uint32_t prow[PW];
 	__shared__ uint32_t diag[NB];
@@ -501,6 +514,13 @@ __global__ __launch_bounds__(256) void rref_block_gj(BlockGjArgs g)
 			*g.knew = 0;
 		return;
 	}
+	if constexpr (SMALL) {
+		// (p is odd: 2 p bytes = (p + 1) / 2 dwords, rounded up; the table is padded to a multiple of 4 bytes)
+		const uint32_t *src = reinterpret_cast<const uint32_t *>(g.invtab);
+		uint32_t *dst = reinterpret_cast<uint32_t *>(invtab);
+		for (uint32_t t = tid; t < (F.p + 1) / 2; t += 256)
+			dst[t] = src[t];
+	}
 	const int j = tid & (PW - 1), par = tid >> 7;          // my column; my rows: r = 2 i + par
 	uint32_t x[NB / 2];
 #pragma unroll
@@ -515,6 +535,14 @@ __global__ __launch_bounds__(256) void rref_block_gj(BlockGjArgs g)
 		}
 		x[i] = v;
 	}
+	const uint32_t bm = SMALL ? (uint32_t) (0x100000000ull / F.p) : 0u;
+	auto barrett = [&](uint32_t v) -> uint32_t {           // v < 2^32 -> v mod p (p < 2^16)
+		const uint32_t q = __umulhi(v, bm);
+		uint32_t rem = v - __umul24(q, F.p);
+		rem = (rem >= F.p) ? rem - F.p : rem;
+		rem = (rem >= F.p) ? rem - F.p : rem;
+		return rem;
+	};
 	int npiv = 0;
 	for (int col = 0; col < g.width && npiv < k; col++) {
 		if (j == col) {
@@ -533,21 +561,41 @@ __global__ __launch_bounds__(256) void rref_block_gj(BlockGjArgs g)
 		const int pr = s_piv;
 		if (pr < 0)
 			continue;               // (uniform; colbuf is rewritten after the next barrier only by column col + 1's owners)
+		const uint32_t pv = colbuf[pr];
 		if ((pr & 1) == par) {
 			uint32_t mine = 0;
 #pragma unroll
 			for (int i = 0; i < NB / 2; i++)
 				mine = (i == (pr >> 1)) ? x[i] : mine;
+			if constexpr (SMALL) {
+				// normalise the pivot row (in its registers too)
+				mine = barrett(__umul24(mine, (uint32_t) invtab[pv]));
+#pragma unroll
+				for (int i = 0; i < NB / 2; i++)
+					x[i] = (i == (pr >> 1)) ? mine : x[i];
+			}
 			prow[j] = mine;
 		}
 		__syncthreads();
-		const uint32_t pv = colbuf[pr], pj = prow[j];
+		const uint32_t pj = prow[j];
+		if constexpr (SMALL) {
+			if (pj != 0) {
 #pragma unroll
-		for (int i = 0; i < NB / 2; i++) {
-			const int r = 2 * i + par;
-			const uint32_t f = colbuf[r];
-			if (r != pr && f != 0)
-				x[i] = (j == col) ? 0u : E.mulsub(pv, x[i], f, pj);
+				for (int i = 0; i < NB / 2; i++) {
+					const int r = 2 * i + par;
+					const uint32_t f = colbuf[r];
+					if (r != pr && f != 0)
+						x[i] = barrett(x[i] + __umul24(F.p - f, pj));          // < p + p^2 < 2^32
+				}
+			}
+		} else {
+#pragma unroll
+			for (int i = 0; i < NB / 2; i++) {
+				const int r = 2 * i + par;
+				const uint32_t f = colbuf[r];
+				if (r != pr && f != 0)
+					x[i] = (j == col) ? 0u : E.mulsub(pv, x[i], f, pj);
+			}
 		}
 		if (tid == 0) {
 			s_prow_of[pr] = npiv;
@@ -557,23 +605,33 @@ __global__ __launch_bounds__(256) void rref_block_gj(BlockGjArgs g)
 		__syncthreads();
 	}
 	// (the candidates are independent: npiv == k; a defect would show as a wrong rank in the tests)
-	// scale: pivot row s has d at gamma_s, zeros at the other pivot columns; Ginv[s][r] = aug[s][r] / d
+	if constexpr (SMALL) {
+		// pivot rows are normalised: the right half is Ginv
 #pragma unroll
-	for (int i = 0; i < NB / 2; i++) {
-		const int r = 2 * i + par;
-		if (r < k && s_prow_of[r] >= 0 && j == s_gamma[s_prow_of[r]])
-			diag[r] = x[i];
-	}
-	__syncthreads();
-	if (tid < k && s_prow_of[tid] >= 0)
-		diag[tid] = invmod(diag[tid], F);
-	__syncthreads();
+		for (int i = 0; i < NB / 2; i++) {
+			const int r = 2 * i + par;
+			if (r < k && j >= NB && j - NB < k && s_prow_of[r] >= 0)
+				g.Ginv[s_prow_of[r] * NB + (j - NB)] = montmul(x[i], F.r2, F);          // Montgomery form
+		}
+	} else {
+		// scale: pivot row s has d at gamma_s, zeros at the other pivot columns; Ginv[s][r] = aug[s][r] / d
 #pragma unroll
-	for (int i = 0; i < NB / 2; i++) {
-		const int r = 2 * i + par;
-		if (r < k && j >= NB && j - NB < k && s_prow_of[r] >= 0)
-			// Montgomery form of (aug / d): mulmod gives the plain product, one more montmul by r2 lifts it
-			g.Ginv[s_prow_of[r] * NB + (j - NB)] = montmul(mulmod(x[i], diag[r], F), F.r2, F);
+		for (int i = 0; i < NB / 2; i++) {
+			const int r = 2 * i + par;
+			if (r < k && s_prow_of[r] >= 0 && j == s_gamma[s_prow_of[r]])
+				diag[r] = x[i];
+		}
+		__syncthreads();
+		if (tid < k && s_prow_of[tid] >= 0)
+			diag[tid] = invmod(diag[tid], F);
+		__syncthreads();
+#pragma unroll
+		for (int i = 0; i < NB / 2; i++) {
+			const int r = 2 * i + par;
+			if (r < k && j >= NB && j - NB < k && s_prow_of[r] >= 0)
+				// Montgomery form of (aug / d): mulmod gives the plain product, one more montmul by r2 lifts it
+				g.Ginv[s_prow_of[r] * NB + (j - NB)] = montmul(mulmod(x[i], diag[r], F), F.r2, F);
+		}
 	}
 	const int base = *g.rank;
 	__syncthreads();
@@ -1035,6 +1093,8 @@ int device_rref(int64_t prime, int n, int m, uint32_t *dA, int64_t ld, int *d_pi
 	uint32_t *Ginv = nullptr, *P4 = nullptr, *Bt4 = nullptr;
 	int *rho4 = nullptr, *knew4 = nullptr;
 	signed char *M8 = nullptr, *B8 = nullptr;
+	unsigned short *invtab = nullptr;
+	size_t invtab_bytes = 0;
 	if (tournament) {
 		const size_t cand_len = (size_t) std::max(n, ((n + SEL_ROWS - 1) / SEL_ROWS) * NB) + NB;
 		HIP_CHECK(hipMalloc((void **) &candA, cand_len * sizeof(int)));
@@ -1045,6 +1105,17 @@ int device_rref(int64_t prime, int n, int m, uint32_t *dA, int64_t ld, int *d_pi
 		HIP_CHECK(hipMalloc((void **) &P4, (size_t) 4 * (size_t) n * PW * sizeof(uint32_t)));
 		HIP_CHECK(hipMalloc((void **) &Bt4, (size_t) 4 * (size_t) NB * (size_t) m * sizeof(uint32_t)));
 		HIP_CHECK(hipMalloc((void **) &rho4, 4 * NB * sizeof(int)));
+		if (small_prime) {
+			invtab_bytes = ((size_t) prime * 2 + 7) / 4 * 4;
+			HIP_CHECK(hipMalloc((void **) &invtab, invtab_bytes + 64));
+			hipLaunchKernelGGL(rref_inverse_table, dim3(((unsigned) prime + 255) / 256), dim3(256), 0, stream, invtab, F);
+			static bool configured = false;
+			if (!configured) {
+				HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(&rref_block_gj<true>),
+				                              hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024));
+				configured = true;
+			}
+		}
 		// digit planes: per set M (2 x n x 64) and trailing B (2 x m x 64); one more B pair for the super-panel's own columns
 		HIP_CHECK(hipMalloc((void **) &M8, (size_t) 4 * 2 * (size_t) n * 64));
 		HIP_CHECK(hipMalloc((void **) &B8, (size_t) 5 * 2 * (size_t) m * 64));
@@ -1141,8 +1212,9 @@ int device_rref(int64_t prime, int n, int m, uint32_t *dA, int64_t ld, int *d_pi
 				bg.knew = knew_s;
 				bg.rho = rho_s;
 				bg.F = F;
+				bg.invtab = invtab;
 				if (small_prime)
-					hipLaunchKernelGGL(rref_block_gj<true>, dim3(1), dim3(256), 0, stream, bg);
+					hipLaunchKernelGGL(rref_block_gj<true>, dim3(1), dim3(256), invtab_bytes, stream, bg);
 				else
 					hipLaunchKernelGGL(rref_block_gj<false>, dim3(1), dim3(256), 0, stream, bg);
 				hipLaunchKernelGGL(rref_multipliers, dim3((n + 63) / 64), dim3(256), 0, stream, dA, ld, n, c0, Ginv, gamma, knew_s, P_s, F);
@@ -1285,6 +1357,7 @@ int device_rref(int64_t prime, int n, int m, uint32_t *dA, int64_t ld, int *d_pi
 		(void) hipFree(Bt4);
 		(void) hipFree(rho4);
 		(void) hipFree(M8);
+		(void) hipFree(invtab);
 		(void) hipFree(B8);
 		(void) hipFree(knew4);
 		(void) hipFree(full_flag);
