@@ -3,15 +3,15 @@
 //
 // Blocked Gauss-Jordan with column-rank-profile pivots, rows stay in place:
 //   for each panel of NB columns
-//     1. panel kernel (one workgroup): eliminate inside the panel, carrying k
-//        extra "selector" columns J so that the composite row transformation
-//        T = I + M e_rho^T is known explicitly (M = T J - J, n x k);
+//     1. panel step: k <= NB new pivots (rows rho, columns gamma) and the n x k multipliers M such that the
+//        composite row transformation of the panel is T = I + M e_rho^T.  Default: a tournament over the free
+//        rows + one Gauss-Jordan of a 64 x 128 block (see "Tournament panel step" below); the older kernels
+//        eliminate column by column (one workgroup, or several with a grid barrier per column);
 //     2. gather B = A[rho, rest] (the k new pivot rows, old values);
-//     3. trailing update A[:, rest] += M B  (GEMM mod p).  For p < 2^16 the
-//        GEMM runs on the matrix cores: operands are split into two signed
-//        base-256 digits and multiplied with v_mfma_i32_32x32x32_i8 (four
-//        digit products, i32 accumulators, recombined mod p).  Larger primes
-//        use a tiled 64-bit VALU kernel.
+//     3. trailing update A[:, rest] += M B  (GEMM mod p), deferred over super-panels of four panels (K <= 256).
+//        For p < 2^16 the GEMM runs on the matrix cores: operands are split into two signed base-256 digits and
+//        multiplied with v_mfma_i32_32x32x32_i8 (four digit products, i32 accumulators, recombined mod p).
+//        Larger primes use a tiled 64-bit VALU kernel.
 // Values are canonical representatives in [0, p) stored as u32.
 #include <algorithm>
 #include <cstring>
