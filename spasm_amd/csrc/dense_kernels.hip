@@ -860,6 +860,28 @@ __global__ __launch_bounds__(256) void rref_update_mfma(uint32_t *A, int64_t ld,
 	}
 }
 
+// out[0] |= 1 when a row without pivot has a non-zero entry in columns >= c_from (when none has, the echelon form
+// is complete: what is left of the block is zero)
+__global__ __launch_bounds__(256) void rref_free_nonzero(const uint32_t *A, int64_t ld, int n, int m, int c_from, const int *flags, int *out)
+{
+	const int lane = threadIdx.x & 63;
+	const int wave = (blockIdx.x * 256 + threadIdx.x) >> 6, nwaves = (gridDim.x * 256) >> 6;
+	for (int i = wave; i < n; i += nwaves) {
+		if (flags[i] != 0)
+			continue;
+		if (*(volatile int *) out != 0)
+			return;
+		bool nz = false;
+		for (int j = c_from + lane; j < m; j += 64)
+			nz |= A[(int64_t) i * ld + j] != 0;
+		if (__ballot(nz) != 0) {
+			if (lane == 0)
+				atomicOr(out, 1);
+			return;
+		}
+	}
+}
+
 // ---- super-panels: the trailing update of up to four panels in one pass (K up to 256) ----
 // Four consecutive panels T1..T4 are factored with the columns of their super-panel kept up to date (K = 64
 // updates of at most 192 columns); beyond the super-panel, T4 T3 T2 T1 C = C + sum_i M_i B_i with
@@ -1152,11 +1174,16 @@ int device_rref(int64_t prime, int n, int m, uint32_t *dA, int64_t ld, int *d_pi
 		const bool small16 = prime < 65536;
 		constexpr int SPW = 4;                       // panels per super-panel
 		for (int sp0 = 0, spi = 0; sp0 < m; sp0 += SPW * NB, spi++) {
-			if (spi > 0 && spi % 2 == 0) {           // every row already holds a pivot: the rest is reduced
-				int rk = 0;
-				HIP_CHECK(hipMemcpyAsync(&rk, rank_d, sizeof(int), hipMemcpyDeviceToHost, stream));
+			if (spi > 0) {
+				// done when every row holds a pivot, or when the rows that do not are zero from here on (a block of
+				// low rank: most of its panels would find nothing)
+				int rk_nz[2] = {0, 0};
+				HIP_CHECK(hipMemsetAsync(free_count + 8, 0, sizeof(int), stream));
+				hipLaunchKernelGGL(rref_free_nonzero, dim3(512), dim3(256), 0, stream, dA, ld, n, m, sp0, flags, free_count + 8);
+				HIP_CHECK(hipMemcpyAsync(&rk_nz[0], rank_d, sizeof(int), hipMemcpyDeviceToHost, stream));
+				HIP_CHECK(hipMemcpyAsync(&rk_nz[1], free_count + 8, sizeof(int), hipMemcpyDeviceToHost, stream));
 				HIP_CHECK(hipStreamSynchronize(stream));
-				if (rk >= n)
+				if (rk_nz[0] >= n || rk_nz[1] == 0)
 					break;
 			}
 			const int sp_end = std::min(m, sp0 + SPW * NB);
