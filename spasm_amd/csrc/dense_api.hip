@@ -1,6 +1,8 @@
 // C ABI of the dense tail: dense rows of the Schur complement and dense RREF mod p.
 #include <algorithm>
 #include <cinttypes>
+#include <cstring>
+#include <thread>
 #include <vector>
 
 #include "device_types.h"
@@ -373,25 +375,43 @@ int spasm_hip_ffpack_rref(i64 prime, int n, int m, void *A, int ldA, spasm_datat
 	if (n == 0 || m == 0)
 		return 0;
 	std::vector<u32> h((size_t) n * m);
-	for (int i = 0; i < n; i++)
-		for (int j = 0; j < m; j++) {
-			const size_t src = (size_t) i * ldA + j;
-			i64 v = 0;
-			switch (datatype) {
-			case SPASM_DOUBLE: v = (i64) ((double *) A)[src]; break;
-			case SPASM_FLOAT: v = (i64) ((float *) A)[src]; break;
-			case SPASM_I64: v = ((i64 *) A)[src]; break;
-			}
-			v %= prime;
-			if (v < 0)
-				v += prime;
-			h[(size_t) i * m + j] = (u32) v;
+	// rows in parallel: the conversion of a tall block would otherwise cost more than its elimination
+	auto rows_in_parallel = [&](int nrows, auto &&body) {
+		int nt = (int) std::min<i64>(16, std::max<i64>(1, (i64) nrows * m / (1 << 20)));
+		nt = std::min(nt, std::max(1, (int) std::thread::hardware_concurrency()));
+		if (nt <= 1) {
+			body(0, nrows);
+			return;
 		}
+		std::vector<std::thread> pool;
+		for (int t = 0; t < nt; t++)
+			pool.emplace_back([&, t]() { body((int) ((i64) nrows * t / nt), (int) ((i64) nrows * (t + 1) / nt)); });
+		for (auto &th : pool)
+			th.join();
+	};
+	rows_in_parallel(n, [&](int lo, int hi) {
+		for (int i = lo; i < hi; i++)
+			for (int j = 0; j < m; j++) {
+				const size_t src = (size_t) i * ldA + j;
+				i64 v = 0;
+				switch (datatype) {
+				case SPASM_DOUBLE: v = (i64) ((double *) A)[src]; break;
+				case SPASM_FLOAT: v = (i64) ((float *) A)[src]; break;
+				case SPASM_I64: v = ((i64 *) A)[src]; break;
+				}
+				if (v >= prime || v <= -prime)
+					v %= prime;
+				if (v < 0)
+					v += prime;
+				h[(size_t) i * m + j] = (u32) v;
+			}
+	});
 	u32 *dA = dalloc<u32>((i64) n * m);
 	int *dpiv = dalloc<int>(m);
 	HIP_CHECK(hipMemcpy(dA, h.data(), (size_t) n * m * sizeof(u32), hipMemcpyHostToDevice));
 	const int r = spasm_hip_drref(prime, n, m, dA, m, dpiv, nullptr);
-	HIP_CHECK(hipMemcpy(h.data(), dA, (size_t) n * m * sizeof(u32), hipMemcpyDeviceToHost));
+	if (r > 0)          // (rows r.. are zero)
+		HIP_CHECK(hipMemcpy(h.data(), dA, (size_t) r * m * sizeof(u32), hipMemcpyDeviceToHost));
 	std::vector<int> pivcol((size_t) (r > 0 ? r : 1));
 	if (r > 0)
 		HIP_CHECK(hipMemcpy(pivcol.data(), dpiv, (size_t) r * sizeof(int), hipMemcpyDeviceToHost));
@@ -407,20 +427,25 @@ int spasm_hip_ffpack_rref(i64 prime, int n, int m, void *A, int ldA, spasm_datat
 		if (!is_piv[j])
 			qinv[k++] = (size_t) j;
 	const u32 half = (u32) (prime / 2);
-	for (int i = 0; i < n; i++)
-		for (int kk = 0; kk < m; kk++) {
-			i64 v = 0;
-			if (i < r) {
-				const u32 raw = h[(size_t) i * m + qinv[kk]];
-				v = (raw > half) ? (i64) raw - prime : (i64) raw;
+	const size_t esize = (datatype == SPASM_FLOAT) ? sizeof(float) : 8;
+	rows_in_parallel(n, [&](int lo, int hi) {
+		for (int i = lo; i < hi; i++) {
+			if (i >= r) {          // zero row: all-zero bits in every datatype
+				std::memset((char *) A + (size_t) i * ldA * esize, 0, (size_t) m * esize);
+				continue;
 			}
-			const size_t dst = (size_t) i * ldA + kk;
-			switch (datatype) {
-			case SPASM_DOUBLE: ((double *) A)[dst] = (double) v; break;
-			case SPASM_FLOAT: ((float *) A)[dst] = (float) v; break;
-			case SPASM_I64: ((i64 *) A)[dst] = v; break;
+			for (int kk = 0; kk < m; kk++) {
+				const u32 raw = h[(size_t) i * m + qinv[kk]];
+				const i64 v = (raw > half) ? (i64) raw - prime : (i64) raw;
+				const size_t dst = (size_t) i * ldA + kk;
+				switch (datatype) {
+				case SPASM_DOUBLE: ((double *) A)[dst] = (double) v; break;
+				case SPASM_FLOAT: ((float *) A)[dst] = (float) v; break;
+				case SPASM_I64: ((i64 *) A)[dst] = v; break;
+				}
 			}
 		}
+	});
 	logmsg("[rref/hip] %d x %d mod %" PRId64 ": rank %d [%.1fs]\n", n, m, prime, r, wtime() - t0);
 	return r;
 }
