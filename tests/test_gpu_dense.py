@@ -76,6 +76,32 @@ def test_rref_random_low_rank(oracle, shape, rank, p):
     _check_rref(oracle, p, M)
 
 
+@pytest.mark.parametrize("p", [3, 42013, 46349, 65537, 4294967291])
+@pytest.mark.parametrize("case", ["zeros_first", "late_rows", "staircase", "one_column_each"])
+def test_rref_tournament_panel_tall_blocks(oracle, case, p):
+    """tournament panel step on tall blocks where the first 256 free rows do NOT hold the pivots of a panel: the
+    tree of selection kernels (several levels) has to find them; 46349 > 46340 takes the Montgomery path."""
+    rng = np.random.default_rng(11)
+    n, m = 5000, 150
+    M = np.zeros((n, m), dtype=np.int64)
+    if case == "zeros_first":                # rank 150, all of it in rows 3000..
+        M[3000:] = rng.integers(0, p, size=(n - 3000, m))
+    elif case == "late_rows":                # the first 4000 rows span 3 dimensions only
+        basis = rng.integers(0, p, size=(3, m))
+        M[:4000] = (rng.integers(0, p, size=(4000, 3)).astype(object).dot(basis.astype(object)) % p).astype(np.int64)
+        M[4000:] = rng.integers(0, p, size=(1000, m))
+    elif case == "staircase":                # row i has its first non-zero at column (i * 7) % m
+        for i in range(n):
+            c = (i * 7) % m
+            M[i, c:] = rng.integers(0, p, size=m - c)
+            M[i, c] = 1 + (i % (p - 1))
+    else:                                     # one_column_each: a single entry per row, columns visited in a scrambled order
+        cols = rng.permutation(m)
+        for i in range(n):
+            M[i, cols[(i // 31) % m]] = 1 + rng.integers(0, p - 1)
+    _check_rref(oracle, p, M)
+
+
 def test_rref_mfma_and_valu_agree(oracle, monkeypatch):
     p = 42013
     rng = np.random.default_rng(5)
@@ -92,7 +118,8 @@ def test_rref_mfma_and_valu_agree(oracle, monkeypatch):
 @pytest.mark.parametrize("shape,rank", [((700, 900), 333), ((300, 200), 150), ((1500, 70), 10), ((2100, 130), 130),
                                         ((257, 515), 257)])
 def test_rref_cooperative_panel_kernel(oracle, shape, rank, p, monkeypatch):
-    """the multi-workgroup panel kernel (grid-wide barriers), forced on small blocks."""
+    """the older column-by-column panel kernels, multi-workgroup variant (grid-wide barriers) forced on small blocks."""
+    monkeypatch.setenv("SPASM_HIP_RREF_PANEL", "columns")
     monkeypatch.setenv("SPASM_HIP_COOP_ROWS", "1")
     n, m = shape
     rng = np.random.default_rng(n * 3 + m)
