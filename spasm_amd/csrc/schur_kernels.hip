@@ -1451,6 +1451,7 @@ __global__ __launch_bounds__(64 * NW) void schur_group_kernel(GroupArgs d)
 						// 64-byte quarters of the line with an active lane (x 1000, on top of the watch phase)
 						prof[1] += 1000ull * (((active & 0xFFFFull) != 0) + ((active & 0xFFFF0000ull) != 0) +
 						                      ((active & 0xFFFF00000000ull) != 0) + ((active >> 48) != 0));
+						prof[2] += 1000ull * ((nact + 15) / 16);      // (on top of the bitmap scan: quarters if the active lanes were packed)
 #endif
 						st_wavepiv += 1;
 						st_elim += (unsigned long long) nact;
