@@ -1124,9 +1124,9 @@ int device_rref(int64_t prime, int n, int m, uint32_t *dA, int64_t ld, int *d_pi
 		HIP_CHECK(hipMalloc((void **) &free_count, 64));
 		HIP_CHECK(hipMalloc((void **) &gamma, NB * sizeof(int)));
 		HIP_CHECK(hipMalloc((void **) &cand_first, NB * sizeof(int)));
-		HIP_CHECK(hipMalloc((void **) &P4, (size_t) 4 * (size_t) n * PW * sizeof(uint32_t)));
+		HIP_CHECK(hipMalloc((void **) &P4, (size_t) 8 * (size_t) n * PW * sizeof(uint32_t)));
 		HIP_CHECK(hipMalloc((void **) &Bt4, (size_t) 4 * (size_t) NB * (size_t) m * sizeof(uint32_t)));
-		HIP_CHECK(hipMalloc((void **) &rho4, 4 * NB * sizeof(int)));
+		HIP_CHECK(hipMalloc((void **) &rho4, 8 * NB * sizeof(int)));
 		if (small_prime) {
 			invtab_bytes = ((size_t) prime * 2 + 7) / 4 * 4;
 			HIP_CHECK(hipMalloc((void **) &invtab, invtab_bytes + 64));
@@ -1139,9 +1139,9 @@ int device_rref(int64_t prime, int n, int m, uint32_t *dA, int64_t ld, int *d_pi
 			}
 		}
 		// digit planes: per set M (2 x n x 64) and trailing B (2 x m x 64); one more B pair for the super-panel's own columns
-		HIP_CHECK(hipMalloc((void **) &M8, (size_t) 4 * 2 * (size_t) n * 64));
+		HIP_CHECK(hipMalloc((void **) &M8, (size_t) 8 * 2 * (size_t) n * 64));
 		HIP_CHECK(hipMalloc((void **) &B8, (size_t) 5 * 2 * (size_t) m * 64));
-		HIP_CHECK(hipMalloc((void **) &knew4, 4 * 16 * sizeof(int)));
+		HIP_CHECK(hipMalloc((void **) &knew4, 8 * 16 * sizeof(int)));
 		HIP_CHECK(hipMalloc((void **) &full_flag, 64));
 		HIP_CHECK(hipMalloc((void **) &Ginv, NB * NB * sizeof(uint32_t)));
 	}
@@ -1158,6 +1158,13 @@ int device_rref(int64_t prime, int n, int m, uint32_t *dA, int64_t ld, int *d_pi
 	}
 	float total_update = 0.f;
 	const bool mfma_ok = use_mfma && prime <= 65279;      // two signed base-256 digits must fit int8
+	hipStream_t stream2 = nullptr;
+	hipEvent_t ev_near = nullptr, ev_far = nullptr;
+	if (tournament && mfma_ok && !std::getenv("SPASM_HIP_RREF_ONE_STREAM")) {
+		HIP_CHECK(hipStreamCreateWithFlags(&stream2, hipStreamNonBlocking));
+		HIP_CHECK(hipEventCreate(&ev_near));
+		HIP_CHECK(hipEventCreate(&ev_far));
+	}
 	auto timed = [&](auto &&launch) {
 		if (ms_update != nullptr)
 			HIP_CHECK(hipEventRecord(e0, stream));
@@ -1173,8 +1180,14 @@ int device_rref(int64_t prime, int n, int m, uint32_t *dA, int64_t ld, int *d_pi
 	if (tournament) {
 		const bool small16 = prime < 65536;
 		constexpr int SPW = 4;                       // panels per super-panel
+		bool far_pending = false;
+		uint32_t *set_P[4] = {nullptr, nullptr, nullptr, nullptr};
+		int *set_rho[4] = {nullptr, nullptr, nullptr, nullptr}, *set_knew[4] = {nullptr, nullptr, nullptr, nullptr};
+		signed char *set_Mh[4] = {nullptr, nullptr, nullptr, nullptr}, *set_Ml[4] = {nullptr, nullptr, nullptr, nullptr};
 		for (int sp0 = 0, spi = 0; sp0 < m; sp0 += SPW * NB, spi++) {
-			if (spi > 0) {
+			if (spi == 1 || spi == 2 || (spi > 0 && spi % 4 == 0)) {
+				if (far_pending)
+					HIP_CHECK(hipStreamWaitEvent(stream, ev_far, 0));
 				// done when every row holds a pivot, or when the rows that do not are zero from here on (a block of
 				// low rank: most of its panels would find nothing)
 				int rk_nz[2] = {0, 0};
@@ -1192,8 +1205,11 @@ int device_rref(int64_t prime, int n, int m, uint32_t *dA, int64_t ld, int *d_pi
 			int nsets = 0;
 			for (int c0 = sp0; c0 < sp_end; c0 += NB, nsets++) {
 				const int width = std::min(NB, m - c0);
-				uint32_t *P_s = P4 + (size_t) nsets * (size_t) n * PW;
-				int *rho_s = rho4 + nsets * NB, *knew_s = knew4 + nsets * 16;
+				// (sets alternate between two halves by super-panel: the far update of the previous super-panel may
+				//  still be reading its multipliers on the second stream)
+				const int slot = (spi & 1) * 4 + nsets;
+				uint32_t *P_s = P4 + (size_t) slot * (size_t) n * PW;
+				int *rho_s = rho4 + slot * NB, *knew_s = knew4 + slot * 16;
 				hipLaunchKernelGGL(rref_free_list, dim3(1), dim3(1024), 0, stream, flags, n, candA, free_count);
 				// the first 256 free rows alone: when they give a pivot in every column of the panel (the usual case
 				// while the block is not exhausted) the tournament below returns at once
@@ -1254,7 +1270,7 @@ int device_rref(int64_t prime, int n, int m, uint32_t *dA, int64_t ld, int *d_pi
 				one.B[0] = B;
 				one.knew[0] = knew_s;
 				one.nsets = 1;
-				signed char *Mh_s = M8 + (size_t) nsets * 2 * (size_t) n * 64, *Ml_s = Mh_s + (size_t) n * 64;
+				signed char *Mh_s = M8 + (size_t) slot * 2 * (size_t) n * 64, *Ml_s = Mh_s + (size_t) n * 64;
 				if (mfma_ok) {
 					signed char *Bh_p = B8 + (size_t) 4 * 2 * (size_t) m * 64, *Bl_p = Bh_p + (size_t) m * 64;
 					hipLaunchKernelGGL(rref_split_M, dim3((n + 255) / 256), dim3(256), 0, stream, P_s, n, knew_s, Mh_s, Ml_s, F);
@@ -1271,43 +1287,78 @@ int device_rref(int64_t prime, int n, int m, uint32_t *dA, int64_t ld, int *d_pi
 					else
 						hipLaunchKernelGGL(rref_update_valu, grid, dim3(256), 0, stream, dA, ld, n, c0, mr_sp, P_s, B, knew_s, F);
 				});
-				// beyond the super-panel: only the rows rho of this panel are brought up to date (B_i)
-				if (mrT > 0) {
-					S.nsets = nsets;          // the sets before this one
-					uint32_t *Bt_s = Bt4 + (size_t) nsets * (size_t) NB * (size_t) m;
-					dim3 grid((mrT + 255) / 256, NB);
-					if (small16)
-						hipLaunchKernelGGL(rref_trailing_B<true>, grid, dim3(256), 0, stream, dA, ld, n, sp_end, mrT, S, rho_s, knew_s, Bt_s, F);
-					else
-						hipLaunchKernelGGL(rref_trailing_B<false>, grid, dim3(256), 0, stream, dA, ld, n, sp_end, mrT, S, rho_s, knew_s, Bt_s, F);
-					S.P[nsets] = P_s;
-					S.B[nsets] = Bt_s;
-					S.knew[nsets] = knew_s;
-					if (mfma_ok) {
-						signed char *Bh_s = B8 + (size_t) nsets * 2 * (size_t) m * 64, *Bl_s = Bh_s + (size_t) m * 64;
-						hipLaunchKernelGGL(rref_split_B, dim3((mrT + 255) / 256), dim3(256), 0, stream, Bt_s, mrT, knew_s, Bh_s, Bl_s, F);
-						S.Mh[nsets] = Mh_s;
-						S.Ml[nsets] = Ml_s;
-						S.Bh[nsets] = Bh_s;
-						S.Bl[nsets] = Bl_s;
-					}
-				}
+				set_P[nsets] = P_s;
+				set_rho[nsets] = rho_s;
+				set_knew[nsets] = knew_s;
+				set_Mh[nsets] = Mh_s;
+				set_Ml[nsets] = Ml_s;
 				HIP_CHECK(hipGetLastError());
 			}
 			if (mrT > 0) {
-				S.nsets = nsets;
-				timed([&]() {
-					dim3 grid((mrT + 63) / 64, (n + 63) / 64);
+				// beyond the super-panel.  Its rows rho_i are brought up to date first (B_i); they read columns that the
+				// far update of the previous super-panel writes on the second stream: wait for it here, not earlier --
+				// the four panel steps above (latency-bound, one workgroup most of the time) ran beside it.
+				if (far_pending)
+					HIP_CHECK(hipStreamWaitEvent(stream, ev_far, 0));
+				for (int s = 0; s < nsets; s++) {
+					S.nsets = s;          // the sets before this one
+					uint32_t *Bt_s = Bt4 + (size_t) s * (size_t) NB * (size_t) m;
+					dim3 grid((mrT + 255) / 256, NB);
+					if (small16)
+						hipLaunchKernelGGL(rref_trailing_B<true>, grid, dim3(256), 0, stream, dA, ld, n, sp_end, mrT, S, set_rho[s], set_knew[s], Bt_s, F);
+					else
+						hipLaunchKernelGGL(rref_trailing_B<false>, grid, dim3(256), 0, stream, dA, ld, n, sp_end, mrT, S, set_rho[s], set_knew[s], Bt_s, F);
+					S.P[s] = set_P[s];
+					S.B[s] = Bt_s;
+					S.knew[s] = set_knew[s];
 					if (mfma_ok) {
-						hipLaunchKernelGGL(rref_update_mfma_multi, grid, dim3(256), 0, stream, dA, ld, n, sp_end, mrT, S, F);
+						signed char *Bh_s = B8 + (size_t) s * 2 * (size_t) m * 64, *Bl_s = Bh_s + (size_t) m * 64;
+						hipLaunchKernelGGL(rref_split_B, dim3((mrT + 255) / 256), dim3(256), 0, stream, Bt_s, mrT, set_knew[s], Bh_s, Bl_s, F);
+						S.Mh[s] = set_Mh[s];
+						S.Ml[s] = set_Ml[s];
+						S.Bh[s] = Bh_s;
+						S.Bl[s] = Bl_s;
+					}
+				}
+				S.nsets = nsets;
+				// near part (the next super-panel's own columns) on this stream, far part on the second one
+				const int near = (mfma_ok && stream2 != nullptr) ? std::min(mrT, SPW * NB) : mrT;
+				timed([&]() {
+					dim3 grid((near + 63) / 64, (n + 63) / 64);
+					if (mfma_ok) {
+						hipLaunchKernelGGL(rref_update_mfma_multi, grid, dim3(256), 0, stream, dA, ld, n, sp_end, near, S, F);
 					} else {
 						for (int s = 0; s < nsets; s++)
 							hipLaunchKernelGGL(rref_update_valu, grid, dim3(256), 0, stream, dA, ld, n, sp_end, mrT, S.P[s], S.B[s], S.knew[s], F);
 					}
 				});
+				far_pending = false;
+				if (near < mrT) {
+					UpdSets Sf = S;
+					for (int s = 0; s < nsets; s++) {
+						Sf.Bh[s] = S.Bh[s] + (size_t) near * 64;
+						Sf.Bl[s] = S.Bl[s] + (size_t) near * 64;
+					}
+					HIP_CHECK(hipEventRecord(ev_near, stream));
+					HIP_CHECK(hipStreamWaitEvent(stream2, ev_near, 0));
+					dim3 grid((mrT - near + 63) / 64, (n + 63) / 64);
+					if (ms_update != nullptr)
+						HIP_CHECK(hipEventRecord(e0, stream2));
+					hipLaunchKernelGGL(rref_update_mfma_multi, grid, dim3(256), 0, stream2, dA, ld, n, sp_end + near, mrT - near, Sf, F);
+					HIP_CHECK(hipEventRecord(ev_far, stream2));
+					far_pending = true;
+					if (ms_update != nullptr) {          // (timing runs serialise the two streams)
+						HIP_CHECK(hipEventSynchronize(ev_far));
+						float ms;
+						HIP_CHECK(hipEventElapsedTime(&ms, e0, ev_far));
+						total_update += ms;
+					}
+				}
 				HIP_CHECK(hipGetLastError());
 			}
 		}
+		if (far_pending)
+			HIP_CHECK(hipStreamWaitEvent(stream, ev_far, 0));
 	} else {
 		for (int c0 = 0; c0 < m; c0 += NB) {
 			if (c0 > 0 && (c0 / NB) % 8 == 0) {           // every row already holds a pivot: the rest is reduced
@@ -1372,6 +1423,12 @@ int device_rref(int64_t prime, int n, int m, uint32_t *dA, int64_t ld, int *d_pi
 	}
 	int rank = 0, coop_failed = 0;
 	HIP_CHECK(hipMemcpyAsync(&rank, rank_d, sizeof(int), hipMemcpyDeviceToHost, stream));
+	if (stream2 != nullptr) {
+		HIP_CHECK(hipStreamSynchronize(stream2));
+		(void) hipStreamDestroy(stream2);
+		(void) hipEventDestroy(ev_near);
+		(void) hipEventDestroy(ev_far);
+	}
 	HIP_CHECK(hipMemcpyAsync(&coop_failed, coop_err, sizeof(int), hipMemcpyDeviceToHost, stream));
 	HIP_CHECK(hipStreamSynchronize(stream));
 	if (tournament) {
