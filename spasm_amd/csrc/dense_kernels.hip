@@ -488,12 +488,12 @@ __global__ __launch_bounds__(256) void rref_inverse_table(unsigned short *tab, M
 template <bool SMALL>
 __global__ __launch_bounds__(256) void rref_block_gj(BlockGjArgs g)
 {
-	extern __shared__ unsigned short invtab[];
-	__shared__ uint32_t colbuf[NB];
+	extern __shared__ __attribute__((aligned(16))) unsigned short invtab[];
+	__shared__ uint32_t colbuf[2][NB];
 	__shared__ uint32_t prow[PW];
 	__shared__ uint32_t diag[NB];
 	__shared__ int s_rows[NB], s_gamma[NB], s_prow_of[NB];
-	__shared__ int s_k, s_piv;
+	__shared__ int s_k;
 	const int tid = threadIdx.x;
 	const MontDev F = g.F;
 	const ElimArith<SMALL> E(F);
@@ -515,10 +515,10 @@ __global__ __launch_bounds__(256) void rref_block_gj(BlockGjArgs g)
 		return;
 	}
 	if constexpr (SMALL) {
-		// (p is odd: 2 p bytes = (p + 1) / 2 dwords, rounded up; the table is padded to a multiple of 4 bytes)
-		const uint32_t *src = reinterpret_cast<const uint32_t *>(g.invtab);
-		uint32_t *dst = reinterpret_cast<uint32_t *>(invtab);
-		for (uint32_t t = tid; t < (F.p + 1) / 2; t += 256)
+		// (2 p bytes, copied 16 at a time; both copies are padded)
+		const uint4 *src = reinterpret_cast<const uint4 *>(g.invtab);
+		uint4 *dst = reinterpret_cast<uint4 *>(invtab);
+		for (uint32_t t = tid; t < (2 * F.p + 15) / 16; t += 256)
 			dst[t] = src[t];
 	}
 	const int j = tid & (PW - 1), par = tid >> 7;          // my column; my rows: r = 2 i + par
@@ -543,25 +543,34 @@ __global__ __launch_bounds__(256) void rref_block_gj(BlockGjArgs g)
 		rem = (rem >= F.p) ? rem - F.p : rem;
 		return rem;
 	};
+	// Two barriers per column: every wave finds the pivot row of the column by itself (one ballot over the column's
+	// 64 entries, which the owner of the column published during the previous step), the owners of that row
+	// publish it (normalised), barrier, everybody updates its registers and the owner of the NEXT column publishes
+	// it, barrier.
+	const int lane = tid & 63;
 	int npiv = 0;
-	for (int col = 0; col < g.width && npiv < k; col++) {
-		if (j == col) {
+	if (j == 0) {
 #pragma unroll
-			for (int i = 0; i < NB / 2; i++)
-				colbuf[2 * i + par] = x[i];
+		for (int i = 0; i < NB / 2; i++)
+			colbuf[0][2 * i + par] = x[i];
+	}
+	__syncthreads();
+	for (int col = 0; col < g.width && npiv < k; col++) {
+		const uint32_t *cb = colbuf[col & 1];
+		uint32_t *cb_next = colbuf[(col + 1) & 1];
+		const unsigned long long nz = __ballot(lane < k && s_prow_of[lane] < 0 && cb[lane] != 0);
+		const int pr = (nz != 0) ? (int) __builtin_ctzll(nz) : -1;
+		if (pr < 0) {
+			// no pivot in this column (uniform): only the next column has to be published
+			if (j == col + 1) {
+#pragma unroll
+				for (int i = 0; i < NB / 2; i++)
+					cb_next[2 * i + par] = x[i];
+			}
+			__syncthreads();
+			continue;
 		}
-		__syncthreads();
-		if (tid < 64) {
-			// first row that holds no pivot yet and is non-zero in this column: one ballot of wave 0
-			const unsigned long long nz = __ballot(tid < k && s_prow_of[tid] < 0 && colbuf[tid] != 0);
-			if (tid == 0)
-				s_piv = (nz != 0) ? __builtin_ctzll(nz) : -1;
-		}
-		__syncthreads();
-		const int pr = s_piv;
-		if (pr < 0)
-			continue;               // (uniform; colbuf is rewritten after the next barrier only by column col + 1's owners)
-		const uint32_t pv = colbuf[pr];
+		const uint32_t pv = cb[pr];
 		if ((pr & 1) == par) {
 			uint32_t mine = 0;
 #pragma unroll
@@ -577,13 +586,17 @@ __global__ __launch_bounds__(256) void rref_block_gj(BlockGjArgs g)
 			prow[j] = mine;
 		}
 		__syncthreads();
+		if (tid == 0) {           // (read again only after the barrier below)
+			s_prow_of[pr] = npiv;
+			s_gamma[npiv] = col;
+		}
 		const uint32_t pj = prow[j];
 		if constexpr (SMALL) {
 			if (pj != 0) {
 #pragma unroll
 				for (int i = 0; i < NB / 2; i++) {
 					const int r = 2 * i + par;
-					const uint32_t f = colbuf[r];
+					const uint32_t f = cb[r];
 					if (r != pr && f != 0)
 						x[i] = barrett(x[i] + __umul24(F.p - f, pj));          // < p + p^2 < 2^32
 				}
@@ -592,14 +605,15 @@ __global__ __launch_bounds__(256) void rref_block_gj(BlockGjArgs g)
 #pragma unroll
 			for (int i = 0; i < NB / 2; i++) {
 				const int r = 2 * i + par;
-				const uint32_t f = colbuf[r];
+				const uint32_t f = cb[r];
 				if (r != pr && f != 0)
 					x[i] = (j == col) ? 0u : E.mulsub(pv, x[i], f, pj);
 			}
 		}
-		if (tid == 0) {
-			s_prow_of[pr] = npiv;
-			s_gamma[npiv] = col;
+		if (j == col + 1) {
+#pragma unroll
+			for (int i = 0; i < NB / 2; i++)
+				cb_next[2 * i + par] = x[i];
 		}
 		npiv += 1;
 		__syncthreads();
@@ -1128,7 +1142,7 @@ int device_rref(int64_t prime, int n, int m, uint32_t *dA, int64_t ld, int *d_pi
 		HIP_CHECK(hipMalloc((void **) &Bt4, (size_t) 4 * (size_t) NB * (size_t) m * sizeof(uint32_t)));
 		HIP_CHECK(hipMalloc((void **) &rho4, 8 * NB * sizeof(int)));
 		if (small_prime) {
-			invtab_bytes = ((size_t) prime * 2 + 7) / 4 * 4;
+			invtab_bytes = ((size_t) prime * 2 + 15) / 16 * 16;
 			HIP_CHECK(hipMalloc((void **) &invtab, invtab_bytes + 64));
 			hipLaunchKernelGGL(rref_inverse_table, dim3(((unsigned) prime + 255) / 256), dim3(256), 0, stream, invtab, F);
 			static bool configured = false;
