@@ -480,13 +480,13 @@ __global__ __launch_bounds__(256) void rref_inverse_table(unsigned short *tab, M
 		tab[a] = (a == 0) ? 0 : (unsigned short) invmod(a, F);
 }
 
-// One workgroup of 256 threads, Gauss-Jordan of [R | I] (64 x 128).  Thread t keeps column t % 128 of the rows of
-// parity t / 128 in 32 registers; per step the column being eliminated and the pivot row go through LDS.
+// One workgroup of 128 NPAR threads, Gauss-Jordan of [R | I] (64 x 128).  Thread t keeps column t % 128 of the rows
+// r = t / 128 mod NPAR in 64 / NPAR registers; per step the column being eliminated and the pivot row go through LDS.
 //   SMALL (p < 46341): the table of inverses sits in LDS (2 p bytes, dynamic), pivot rows are normalised, an
 //   update is one 24-bit multiply + Barrett and only touches the columns where the pivot row is non-zero;
 //   otherwise: fraction-free steps (two Montgomery products per element), one inversion per pivot at the end.
-template <bool SMALL>
-__global__ __launch_bounds__(256) void rref_block_gj(BlockGjArgs g)
+template <bool SMALL, int NPAR>
+__global__ __launch_bounds__(128 * NPAR) void rref_block_gj(BlockGjArgs g)
 {
 	extern __shared__ __attribute__((aligned(16))) unsigned short invtab[];
 	__shared__ uint32_t colbuf[2][NB];
@@ -518,14 +518,15 @@ __global__ __launch_bounds__(256) void rref_block_gj(BlockGjArgs g)
 		// (2 p bytes, copied 16 at a time; both copies are padded)
 		const uint4 *src = reinterpret_cast<const uint4 *>(g.invtab);
 		uint4 *dst = reinterpret_cast<uint4 *>(invtab);
-		for (uint32_t t = tid; t < (2 * F.p + 15) / 16; t += 256)
+		for (uint32_t t = tid; t < (2 * F.p + 15) / 16; t += 128 * NPAR)
 			dst[t] = src[t];
 	}
-	const int j = tid & (PW - 1), par = tid >> 7;          // my column; my rows: r = 2 i + par
-	uint32_t x[NB / 2];
+	constexpr int RPT = NB / NPAR;                          // rows per thread
+	const int j = tid & (PW - 1), par = tid >> 7;          // my column; my rows: r = NPAR i + par
+	uint32_t x[RPT];
 #pragma unroll
-	for (int i = 0; i < NB / 2; i++) {
-		const int r = 2 * i + par;
+	for (int i = 0; i < RPT; i++) {
+		const int r = NPAR * i + par;
 		uint32_t v = 0;
 		if (r < k) {
 			if (j < NB)
@@ -551,8 +552,8 @@ __global__ __launch_bounds__(256) void rref_block_gj(BlockGjArgs g)
 	int npiv = 0;
 	if (j == 0) {
 #pragma unroll
-		for (int i = 0; i < NB / 2; i++)
-			colbuf[0][2 * i + par] = x[i];
+		for (int i = 0; i < RPT; i++)
+			colbuf[0][NPAR * i + par] = x[i];
 	}
 	__syncthreads();
 	for (int col = 0; col < g.width && npiv < k; col++) {
@@ -564,24 +565,24 @@ __global__ __launch_bounds__(256) void rref_block_gj(BlockGjArgs g)
 			// no pivot in this column (uniform): only the next column has to be published
 			if (j == col + 1) {
 #pragma unroll
-				for (int i = 0; i < NB / 2; i++)
-					cb_next[2 * i + par] = x[i];
+				for (int i = 0; i < RPT; i++)
+					cb_next[NPAR * i + par] = x[i];
 			}
 			__syncthreads();
 			continue;
 		}
 		const uint32_t pv = cb[pr];
-		if ((pr & 1) == par) {
+		if ((pr % NPAR) == par) {
 			uint32_t mine = 0;
 #pragma unroll
-			for (int i = 0; i < NB / 2; i++)
-				mine = (i == (pr >> 1)) ? x[i] : mine;
+			for (int i = 0; i < RPT; i++)
+				mine = (i == (pr / NPAR)) ? x[i] : mine;
 			if constexpr (SMALL) {
 				// normalise the pivot row (in its registers too)
 				mine = barrett(__umul24(mine, (uint32_t) invtab[pv]));
 #pragma unroll
-				for (int i = 0; i < NB / 2; i++)
-					x[i] = (i == (pr >> 1)) ? mine : x[i];
+				for (int i = 0; i < RPT; i++)
+					x[i] = (i == (pr / NPAR)) ? mine : x[i];
 			}
 			prow[j] = mine;
 		}
@@ -594,8 +595,8 @@ __global__ __launch_bounds__(256) void rref_block_gj(BlockGjArgs g)
 		if constexpr (SMALL) {
 			if (pj != 0) {
 #pragma unroll
-				for (int i = 0; i < NB / 2; i++) {
-					const int r = 2 * i + par;
+				for (int i = 0; i < RPT; i++) {
+					const int r = NPAR * i + par;
 					const uint32_t f = cb[r];
 					if (r != pr && f != 0)
 						x[i] = barrett(x[i] + __umul24(F.p - f, pj));          // < p + p^2 < 2^32
@@ -603,8 +604,8 @@ __global__ __launch_bounds__(256) void rref_block_gj(BlockGjArgs g)
 			}
 		} else {
 #pragma unroll
-			for (int i = 0; i < NB / 2; i++) {
-				const int r = 2 * i + par;
+			for (int i = 0; i < RPT; i++) {
+				const int r = NPAR * i + par;
 				const uint32_t f = cb[r];
 				if (r != pr && f != 0)
 					x[i] = (j == col) ? 0u : E.mulsub(pv, x[i], f, pj);
@@ -612,8 +613,8 @@ __global__ __launch_bounds__(256) void rref_block_gj(BlockGjArgs g)
 		}
 		if (j == col + 1) {
 #pragma unroll
-			for (int i = 0; i < NB / 2; i++)
-				cb_next[2 * i + par] = x[i];
+			for (int i = 0; i < RPT; i++)
+				cb_next[NPAR * i + par] = x[i];
 		}
 		npiv += 1;
 		__syncthreads();
@@ -622,16 +623,16 @@ __global__ __launch_bounds__(256) void rref_block_gj(BlockGjArgs g)
 	if constexpr (SMALL) {
 		// pivot rows are normalised: the right half is Ginv
 #pragma unroll
-		for (int i = 0; i < NB / 2; i++) {
-			const int r = 2 * i + par;
+		for (int i = 0; i < RPT; i++) {
+			const int r = NPAR * i + par;
 			if (r < k && j >= NB && j - NB < k && s_prow_of[r] >= 0)
 				g.Ginv[s_prow_of[r] * NB + (j - NB)] = montmul(x[i], F.r2, F);          // Montgomery form
 		}
 	} else {
 		// scale: pivot row s has d at gamma_s, zeros at the other pivot columns; Ginv[s][r] = aug[s][r] / d
 #pragma unroll
-		for (int i = 0; i < NB / 2; i++) {
-			const int r = 2 * i + par;
+		for (int i = 0; i < RPT; i++) {
+			const int r = NPAR * i + par;
 			if (r < k && s_prow_of[r] >= 0 && j == s_gamma[s_prow_of[r]])
 				diag[r] = x[i];
 		}
@@ -640,8 +641,8 @@ __global__ __launch_bounds__(256) void rref_block_gj(BlockGjArgs g)
 			diag[tid] = invmod(diag[tid], F);
 		__syncthreads();
 #pragma unroll
-		for (int i = 0; i < NB / 2; i++) {
-			const int r = 2 * i + par;
+		for (int i = 0; i < RPT; i++) {
+			const int r = NPAR * i + par;
 			if (r < k && j >= NB && j - NB < k && s_prow_of[r] >= 0)
 				// Montgomery form of (aug / d): mulmod gives the plain product, one more montmul by r2 lifts it
 				g.Ginv[s_prow_of[r] * NB + (j - NB)] = montmul(mulmod(x[i], diag[r], F), F.r2, F);
@@ -1147,7 +1148,7 @@ int device_rref(int64_t prime, int n, int m, uint32_t *dA, int64_t ld, int *d_pi
 			hipLaunchKernelGGL(rref_inverse_table, dim3(((unsigned) prime + 255) / 256), dim3(256), 0, stream, invtab, F);
 			static bool configured = false;
 			if (!configured) {
-				HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(&rref_block_gj<true>),
+				HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(&rref_block_gj<true, 8>),
 				                              hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024));
 				configured = true;
 			}
@@ -1271,9 +1272,9 @@ int device_rref(int64_t prime, int n, int m, uint32_t *dA, int64_t ld, int *d_pi
 				bg.F = F;
 				bg.invtab = invtab;
 				if (small_prime)
-					hipLaunchKernelGGL(rref_block_gj<true>, dim3(1), dim3(256), invtab_bytes, stream, bg);
+					hipLaunchKernelGGL((rref_block_gj<true, 8>), dim3(1), dim3(1024), invtab_bytes, stream, bg);
 				else
-					hipLaunchKernelGGL(rref_block_gj<false>, dim3(1), dim3(256), 0, stream, bg);
+					hipLaunchKernelGGL((rref_block_gj<false, 8>), dim3(1), dim3(1024), 0, stream, bg);
 				hipLaunchKernelGGL(rref_multipliers, dim3((n + 63) / 64), dim3(256), 0, stream, dA, ld, n, c0, Ginv, gamma, knew_s, P_s, F);
 				hipLaunchKernelGGL(rref_multipliers_fix, dim3(1), dim3(256), 0, stream, n, Ginv, rho_s, pivrow, rank_d, knew_s, P_s, F);
 				// the columns of the super-panel, from this panel on: K = 64 update now
