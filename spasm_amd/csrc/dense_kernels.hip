@@ -457,6 +457,83 @@ __global__ __launch_bounds__(SEL_ROWS) void rref_select_kernel(const uint32_t *A
 		*full = (nsel == width) ? 1 : 0;
 }
 
+// The first 64 free rows alone, four lanes per row (16 of the 64 panel entries each): the usual case is that they
+// already give a pivot in every column of the panel, and a short step matters more than many candidates (the step
+// time of rref_select_kernel is set by the 64 entries one thread owns).  Same elimination, same output format;
+// *full = 1 when every column of the panel got a pivot -- the tournament over all free rows then returns at once.
+template <bool SMALL>
+__global__ __launch_bounds__(256) void rref_select_first(const uint32_t *A, int64_t ld, int c0, int width, const int *cand_in,
+                                                         const int *n_in_dev, int *cand_out, MontDev F, int *full)
+{
+	__shared__ __attribute__((aligned(16))) uint32_t prow[NB];
+	__shared__ unsigned long long wave_nz[4];
+	const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+	const int slot = tid >> 2, q = tid & 3;
+	const ElimArith<SMALL> E(F);
+	const int n_in = min(*n_in_dev, NB);
+	const int row = (slot < n_in) ? cand_in[slot] : -1;
+	uint32_t x[16];
+	{
+		const uint32_t *src = A + (int64_t) (row >= 0 ? row : 0) * ld + c0 + 16 * q;
+#pragma unroll
+		for (int e = 0; e < 16; e++)
+			x[e] = (row >= 0 && 16 * q + e < width) ? src[e] : 0u;
+	}
+	bool selected = false;
+	int nsel = 0;
+	dense_static_for<0, NB>([&](auto cc) {
+		constexpr int col = decltype(cc)::value;
+		constexpr int qc = col / 16, ec = col % 16;
+		if (col >= width)
+			return;
+		// my row's entry in this column sits in the lane of quarter qc
+		const uint32_t f = (uint32_t) __shfl((int) x[ec], (lane & ~3) | qc);
+		const unsigned long long nz = __ballot(!selected && f != 0);
+		if (lane == 0)
+			wave_nz[wave] = nz;
+		__syncthreads();
+		int winner = -1;          // a thread of the first row that qualifies (rows are in thread order)
+#pragma unroll
+		for (int w = 3; w >= 0; w--) {
+			const unsigned long long v = wave_nz[w];
+			if (v != 0)
+				winner = w * 64 + __builtin_ctzll(v);
+		}
+		if (winner < 0) {
+			__syncthreads();            // (wave_nz is rewritten by the next column)
+			return;
+		}
+		if (slot == (winner >> 2)) {
+#pragma unroll
+			for (int e = 0; e < 16; e++)
+				prow[16 * q + e] = x[e];
+			selected = true;
+			if (q == 0)
+				cand_out[nsel] = row;
+		}
+		nsel += 1;
+		__syncthreads();
+		if (!selected && f != 0) {
+			const uint32_t pv = prow[col];
+			if (q > qc) {
+#pragma unroll
+				for (int e = 0; e < 16; e++)
+					x[e] = E.mulsub(pv, x[e], f, prow[16 * q + e]);
+			} else if (q == qc) {
+#pragma unroll
+				for (int e = ec + 1; e < 16; e++)
+					x[e] = E.mulsub(pv, x[e], f, prow[16 * qc + e]);
+				x[ec] = 0;
+			}
+		}
+		__syncthreads();                // (prow is rewritten by the next column)
+	});
+	if (tid >= nsel && tid < NB)
+		cand_out[tid] = -1;
+	if (tid == 0)
+		*full = (nsel == width) ? 1 : 0;
+}
+
 struct BlockGjArgs {
 	const uint32_t *A;
 	int64_t ld;
@@ -1226,14 +1303,14 @@ int device_rref(int64_t prime, int n, int m, uint32_t *dA, int64_t ld, int *d_pi
 				uint32_t *P_s = P4 + (size_t) slot * (size_t) n * PW;
 				int *rho_s = rho4 + slot * NB, *knew_s = knew4 + slot * 16;
 				hipLaunchKernelGGL(rref_free_list, dim3(1), dim3(1024), 0, stream, flags, n, candA, free_count);
-				// the first 256 free rows alone: when they give a pivot in every column of the panel (the usual case
+				// the first 64 free rows alone: when they give a pivot in every column of the panel (the usual case
 				// while the block is not exhausted) the tournament below returns at once
 				if (small_prime)
-					hipLaunchKernelGGL(rref_select_kernel<true>, dim3(1), dim3(SEL_ROWS), 0, stream, dA, ld, c0, width, candA, n,
-					                   free_count, cand_first, F, nullptr, full_flag);
+					hipLaunchKernelGGL(rref_select_first<true>, dim3(1), dim3(256), 0, stream, dA, ld, c0, width, candA, free_count,
+					                   cand_first, F, full_flag);
 				else
-					hipLaunchKernelGGL(rref_select_kernel<false>, dim3(1), dim3(SEL_ROWS), 0, stream, dA, ld, c0, width, candA, n,
-					                   free_count, cand_first, F, nullptr, full_flag);
+					hipLaunchKernelGGL(rref_select_first<false>, dim3(1), dim3(256), 0, stream, dA, ld, c0, width, candA, free_count,
+					                   cand_first, F, full_flag);
 				int n_in = n;
 				const int *count_dev = free_count;
 				int *src = candA, *dst = candB;
