@@ -323,11 +323,36 @@ __global__ __launch_bounds__(COOP_THREADS) void rref_panel_coop_kernel(CoopPanel
 // --------------------------------------------------------------------------
 constexpr int SEL_ROWS = 256;
 
-// list[0 .. count) = rows i with flags[i] == 0, increasing.  One workgroup.
-__global__ __launch_bounds__(1024) void rref_free_list(const int *flags, int n, int *list, int *count)
+// out[0 .. *count) = the first (at most 64) rows without pivot, found by one wave from *hint on; *hint moves up to
+// the first of them.
+__global__ __launch_bounds__(64) void rref_first_free(const int *flags, int n, int *hint, int *out, int *count)
+{
+	const int lane = threadIdx.x;
+	int found = 0, first = -1;
+	for (int base = *hint; base < n && found < NB; base += 64) {
+		const int i = base + lane;
+		const bool fr = i < n && flags[i] == 0;
+		const unsigned long long mk = __ballot(fr);
+		const int pos = found + __popcll(mk & ((1ull << lane) - 1ull));
+		if (fr && pos < NB)
+			out[pos] = i;
+		if (first < 0 && mk != 0)
+			first = base + __builtin_ctzll(mk);
+		found += __popcll(mk);
+	}
+	if (lane == 0) {
+		*count = min(found, NB);
+		*hint = (first >= 0) ? first : n;
+	}
+}
+
+// list[0 .. count) = rows i with flags[i] == 0, increasing.  One workgroup.  (skip: see rref_select_kernel)
+__global__ __launch_bounds__(1024) void rref_free_list(const int *flags, int n, int *list, int *count, const int *skip)
 {
 	__shared__ int part[1024];
 	const int tid = threadIdx.x;
+	if (skip != nullptr && *skip != 0)
+		return;
 	const int per = (n + 1023) / 1024;
 	const int lo = min(n, tid * per), hi = min(n, lo + per);
 	int c = 0;
@@ -487,7 +512,7 @@ __global__ __launch_bounds__(256) void rref_select_first(const uint32_t *A, int6
 		if (col >= width)
 			return;
 		// my row's entry in this column sits in the lane of quarter qc
-		const uint32_t f = (uint32_t) __shfl((int) x[ec], (lane & ~3) | qc);
+		const uint32_t f = (uint32_t) __builtin_amdgcn_mov_dpp((int) x[ec], qc * 0x55, 0xf, 0xf, true);    // quad_perm: all four lanes read lane qc
 		const unsigned long long nz = __ballot(!selected && f != 0);
 		if (lane == 0)
 			wave_nz[wave] = nz;
@@ -746,7 +771,7 @@ __global__ __launch_bounds__(128 * NPAR) void rref_block_gj(BlockGjArgs g)
 
 // M[i][r] = -sum_s A[i, c0 + gamma_s] Ginv[s][r]  (+ Ginv[s][r] on the row that became pivot s), stored where the
 // update kernels read it: P[(NB + r) * n + i].  Thread = (row, 4 consecutive r).
-__global__ __launch_bounds__(256) void rref_multipliers(const uint32_t *A, int64_t ld, int n, int c0, const uint32_t *Ginv,
+__global__ __launch_bounds__(256) void rref_multipliers(const uint32_t *A, int64_t ld, int n, int m, int c0, const uint32_t *Ginv,
                                                         const int *gamma, const int *knew, uint32_t *P, MontDev F)
 {
 	__shared__ uint32_t sG[NB][NB + 1];
@@ -759,6 +784,13 @@ __global__ __launch_bounds__(256) void rref_multipliers(const uint32_t *A, int64
 		sG[t / NB][t % NB] = (t / NB < k && t % NB < k) ? Ginv[t] : 0u;
 	if (tid < NB)
 		sgam[tid] = (tid < k) ? gamma[tid] : 0;
+	// the panel entries of the workgroup's 64 rows, read row by row (256 contiguous bytes each)
+	__shared__ uint32_t tile[64][NB + 1];
+	for (int t = tid; t < 64 * NB; t += 256) {
+		const int rr = t / NB, cc = t % NB;
+		const int irow = blockIdx.x * 64 + rr;
+		tile[rr][cc] = (irow < n && c0 + cc < m) ? A[(int64_t) irow * ld + c0 + cc] : 0u;
+	}
 	__syncthreads();
 	// 64 rows per workgroup: thread (tid & 63) = row, (tid >> 6) = quarter of the r range
 	const int i = blockIdx.x * 64 + (tid & 63);
@@ -770,7 +802,7 @@ __global__ __launch_bounds__(256) void rref_multipliers(const uint32_t *A, int64
 	for (int u = 0; u < 16; u++)
 		acc[u] = 0;
 	for (int s = 0; s < k; s++) {
-		const uint32_t a = A[(int64_t) i * ld + c0 + sgam[s]];
+		const uint32_t a = tile[tid & 63][sgam[s]];
 		if (a == 0)
 			continue;
 #pragma unroll
@@ -1203,7 +1235,7 @@ int device_rref(int64_t prime, int n, int m, uint32_t *dA, int64_t ld, int *d_pi
 	const bool small_prime = prime < 46341;          // 2 p^2 < 2^32: the panel kernels use 24-bit multiplies
 	if (const char *e = std::getenv("SPASM_HIP_RREF_PANEL"))
 		tournament = std::strcmp(e, "columns") != 0;
-	int *candA = nullptr, *candB = nullptr, *free_count = nullptr, *gamma = nullptr, *cand_first = nullptr, *full_flag = nullptr;
+	int *candA = nullptr, *candB = nullptr, *free_count = nullptr, *gamma = nullptr, *cand_first = nullptr, *full_flag = nullptr, *first64 = nullptr;
 	uint32_t *Ginv = nullptr, *P4 = nullptr, *Bt4 = nullptr;
 	int *rho4 = nullptr, *knew4 = nullptr;
 	signed char *M8 = nullptr, *B8 = nullptr;
@@ -1216,6 +1248,8 @@ int device_rref(int64_t prime, int n, int m, uint32_t *dA, int64_t ld, int *d_pi
 		HIP_CHECK(hipMalloc((void **) &free_count, 64));
 		HIP_CHECK(hipMalloc((void **) &gamma, NB * sizeof(int)));
 		HIP_CHECK(hipMalloc((void **) &cand_first, NB * sizeof(int)));
+		HIP_CHECK(hipMalloc((void **) &first64, NB * sizeof(int)));
+		HIP_CHECK(hipMemsetAsync(free_count, 0, 64, stream));          // [4]: scan hint of rref_first_free
 		HIP_CHECK(hipMalloc((void **) &P4, (size_t) 8 * (size_t) n * PW * sizeof(uint32_t)));
 		HIP_CHECK(hipMalloc((void **) &Bt4, (size_t) 4 * (size_t) NB * (size_t) m * sizeof(uint32_t)));
 		HIP_CHECK(hipMalloc((void **) &rho4, 8 * NB * sizeof(int)));
@@ -1302,15 +1336,17 @@ int device_rref(int64_t prime, int n, int m, uint32_t *dA, int64_t ld, int *d_pi
 				const int slot = (spi & 1) * 4 + nsets;
 				uint32_t *P_s = P4 + (size_t) slot * (size_t) n * PW;
 				int *rho_s = rho4 + slot * NB, *knew_s = knew4 + slot * 16;
-				hipLaunchKernelGGL(rref_free_list, dim3(1), dim3(1024), 0, stream, flags, n, candA, free_count);
+				hipLaunchKernelGGL(rref_first_free, dim3(1), dim3(64), 0, stream, flags, n, free_count + 4, first64, free_count + 2);
 				// the first 64 free rows alone: when they give a pivot in every column of the panel (the usual case
 				// while the block is not exhausted) the tournament below returns at once
 				if (small_prime)
-					hipLaunchKernelGGL(rref_select_first<true>, dim3(1), dim3(256), 0, stream, dA, ld, c0, width, candA, free_count,
+					hipLaunchKernelGGL(rref_select_first<true>, dim3(1), dim3(256), 0, stream, dA, ld, c0, width, first64, free_count + 2,
 					                   cand_first, F, full_flag);
 				else
-					hipLaunchKernelGGL(rref_select_first<false>, dim3(1), dim3(256), 0, stream, dA, ld, c0, width, candA, free_count,
+					hipLaunchKernelGGL(rref_select_first<false>, dim3(1), dim3(256), 0, stream, dA, ld, c0, width, first64, free_count + 2,
 					                   cand_first, F, full_flag);
+				// (everything from here to the Gauss-Jordan block returns at once when that was enough)
+				hipLaunchKernelGGL(rref_free_list, dim3(1), dim3(1024), 0, stream, flags, n, candA, free_count, full_flag);
 				int n_in = n;
 				const int *count_dev = free_count;
 				int *src = candA, *dst = candB;
@@ -1352,7 +1388,7 @@ int device_rref(int64_t prime, int n, int m, uint32_t *dA, int64_t ld, int *d_pi
 					hipLaunchKernelGGL((rref_block_gj<true, 8>), dim3(1), dim3(1024), invtab_bytes, stream, bg);
 				else
 					hipLaunchKernelGGL((rref_block_gj<false, 8>), dim3(1), dim3(1024), 0, stream, bg);
-				hipLaunchKernelGGL(rref_multipliers, dim3((n + 63) / 64), dim3(256), 0, stream, dA, ld, n, c0, Ginv, gamma, knew_s, P_s, F);
+				hipLaunchKernelGGL(rref_multipliers, dim3((n + 63) / 64), dim3(256), 0, stream, dA, ld, n, m, c0, Ginv, gamma, knew_s, P_s, F);
 				hipLaunchKernelGGL(rref_multipliers_fix, dim3(1), dim3(256), 0, stream, n, Ginv, rho_s, pivrow, rank_d, knew_s, P_s, F);
 				// the columns of the super-panel, from this panel on: K = 64 update now
 				const int mr_sp = sp_end - c0;
@@ -1529,6 +1565,7 @@ int device_rref(int64_t prime, int n, int m, uint32_t *dA, int64_t ld, int *d_pi
 		(void) hipFree(free_count);
 		(void) hipFree(gamma);
 		(void) hipFree(cand_first);
+		(void) hipFree(first64);
 		(void) hipFree(P4);
 		(void) hipFree(Bt4);
 		(void) hipFree(rho4);
