@@ -229,7 +229,7 @@ def main():
         achieved = algo / (kernel_ms * 1e-3) / 1e9 if kernel_ms > 0 else 0.0
         traffic = None
         tfile = os.path.join(ROOT, "profiles", "traffic_r01.json")
-        if os.path.exists(tfile):
+        if os.path.exists(tfile) and world == 1:          # (measured on the whole batch: says nothing about a rank's slice)
             traffic = json.load(open(tfile)).get("schur_group_kernel_bytes_per_launch" if group else "schur_wave_dense_kernel_bytes_per_launch")
         # waves per row group: the library's own rule (schur_api.hip), for the kernel name rocprofv3 shows
         cus = torch.cuda.get_device_properties(0).multi_processor_count
