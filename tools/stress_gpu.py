@@ -1,0 +1,64 @@
+#!/usr/bin/env python3
+"""Randomised parity stress on a GPU box (not part of the test suite: minutes, not seconds).
+Sparse Schur complements through every waves-per-group variant of the row-group kernel and dense RREFs of random
+rank-deficient blocks, each compared with the oracle.  python tools/stress_gpu.py [seconds]"""
+import os
+import sys
+import time
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests"))
+os.environ.setdefault("SPASM_HIP_VERBOSE", "0")
+import numpy as np
+import spasm_amd
+from oracle import oracle as orc
+
+budget = float(sys.argv[1]) if len(sys.argv) > 1 else 120.0
+t_end = time.time() + budget
+rng = np.random.default_rng(int(time.time()))
+primes = [3, 257, 42013, 46349, 65521, 4294967291]
+cases = fails = 0
+
+
+def as_product(A):
+    return spasm_amd.Csr(A.n, A.m, A.p, A.j, A.x, A.prime)
+
+
+while time.time() < t_end:
+    p = int(rng.choice(primes))
+    # ---- sparse Schur complement
+    n, m, per_row = int(rng.integers(200, 6000)), int(rng.integers(100, 4000)), int(rng.integers(2, 7))
+    ti = np.repeat(np.arange(n, dtype=np.int32), per_row)
+    tj = rng.integers(0, m, size=n * per_row).astype(np.int32)
+    tx = rng.integers(1, p, size=n * per_row).astype(np.int64)
+    A = orc.compress(p, n, m, ti, tj, tx)
+    npiv, perm, F = orc.pivots_extract_structural(A, orc.empty_fact(A.n, A.m, p))
+    rows = perm[npiv:]
+    if len(rows):
+        want, p_out_want, _ = orc.schur(A, rows, F)
+        for waves in ("1", "2", "4"):
+            os.environ["SPASM_HIP_GROUP"] = "1"
+            os.environ["SPASM_HIP_GROUP_WAVES"] = waves
+            S, p_out = spasm_amd.schur(as_product(A), rows, spasm_amd.Fact(as_product(F.U), F.qinv))
+            ok = orc.same_matrix(orc.CSR(S.n, S.m, S.p, S.j, S.x, p), want) and np.array_equal(np.asarray(p_out), np.asarray(p_out_want))
+            cases += 1
+            if not ok:
+                fails += 1
+                print("MISMATCH schur n=%d m=%d per_row=%d p=%d waves=%s" % (n, m, per_row, p, waves), flush=True)
+        os.environ.pop("SPASM_HIP_GROUP", None)
+        os.environ.pop("SPASM_HIP_GROUP_WAVES", None)
+    # ---- dense RREF of a rank-deficient block
+    dn, dm = int(rng.integers(1, 1500)), int(rng.integers(1, 700))
+    k = int(rng.integers(0, min(dn, dm) + 1))
+    L = rng.integers(0, p, size=(dn, max(k, 1)), dtype=np.int64).astype(object)
+    R = rng.integers(0, p, size=(max(k, 1), dm), dtype=np.int64).astype(object)
+    M = np.array((L.dot(R)) % p, dtype=np.int64) if k > 0 else np.zeros((dn, dm), np.int64)
+    M[:, : int(rng.integers(0, dm + 1)) // 3] = 0
+    r, Rm, q = spasm_amd.ffpack_rref(p, M)
+    r0, R0, q0 = orc.dense_rref(p, M)
+    cases += 1
+    if r != r0 or not np.array_equal(np.asarray(q)[:r], np.asarray(q0)[:r]) or not np.array_equal(np.asarray(Rm)[:r], np.asarray(R0)[:r]):
+        fails += 1
+        print("MISMATCH rref %dx%d rank %d p=%d (got rank %d)" % (dn, dm, r0, p, r), flush=True)
+print("stress: %d cases, %d mismatches" % (cases, fails))
+sys.exit(1 if fails else 0)
