@@ -102,7 +102,7 @@ static int dschur_dense_impl(const spasm_hip_dcsr *A, const int *d_rows, int nro
 	if (group_mode) {
 		group_geometry(F->rpad, F->Sm, wide, &gslot, &goff);
 		gwaves = env_int("SPASM_HIP_GROUP_WAVES", (nrows + 63) / 64 <= cus * 3 ? 4 : (nrows + 63) / 64 <= cus * 12 ? 2 : 1);
-		gslots = (int) std::max<i64>(1, std::min<i64>((nrows + 63) / 64, std::min<i64>(gwaves >= 4 ? cus * 3 : gwaves >= 2 ? cus * 6 : cus * 10, budget / gslot)));
+		gslots = (int) std::max<i64>(1, std::min<i64>((nrows + 63) / 64, std::min<i64>(gwaves >= 4 ? cus * 2 : gwaves >= 2 ? cus * 4 : cus * 8, budget / gslot)));
 		need = gslot * gslots;
 	}
 	if (need > W->scratch_bytes) {

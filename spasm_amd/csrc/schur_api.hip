@@ -536,8 +536,10 @@ int dschur_impl(const spasm_hip_dcsr *A, const int *d_rows, int nrows, const spa
 			const int ngroups = (nrows + 63) / 64;
 			// four (two) waves per group while there are at most 3 (12) groups per CU: with few groups the run time is
 			// the chain of level rounds of one group, which the waves split between them (tools/probe_groups.py)
+			// (slots = workgroups = accumulator slices: as many as are resident at two waves per SIMD; the others
+			//  would only wait for a CU and find the queue of groups empty)
 			group_waves = env_int("SPASM_HIP_GROUP_WAVES", ngroups <= cus * 3 ? 4 : ngroups <= cus * 12 ? 2 : 1);
-			group_slots = (int) std::min<i64>(env_int("SPASM_HIP_GROUP_SLOTS", group_waves >= 4 ? cus * 3 : group_waves >= 2 ? cus * 6 : cus * 20),
+			group_slots = (int) std::min<i64>(env_int("SPASM_HIP_GROUP_SLOTS", group_waves >= 4 ? cus * 2 : group_waves >= 2 ? cus * 4 : cus * 8),
 			                                  budget / group_slot_bytes);
 			group_slots = std::max(1, std::min(group_slots, ngroups));
 			// with the automatic fallback the per-row tier may run in the same buffer afterwards
