@@ -1120,7 +1120,7 @@ __global__ __launch_bounds__(256) void rref_trailing_B(const uint32_t *A, int64_
 }
 
 // C[:, c1:] += sum_s M_s B_s on the matrix cores (p <= 65279), 64 x 64 tile per workgroup, one epilogue.
-__global__ __launch_bounds__(256) void rref_update_mfma_multi(uint32_t *A, int64_t ld, int n, int c1, int mr, UpdSets S, MontDev F)
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) void rref_update_mfma_multi(uint32_t *A, int64_t ld, int n, int c1, int mr, UpdSets S, MontDev F)
 {
 	__shared__ __attribute__((aligned(16))) signed char Mhi[64][64 + 16], Mlo[64][64 + 16];   // [row][k]
 	__shared__ __attribute__((aligned(16))) signed char Bhi[64][64 + 16], Blo[64][64 + 16];   // [col][k]  (transposed)
@@ -1130,9 +1130,22 @@ __global__ __launch_bounds__(256) void rref_update_mfma_multi(uint32_t *A, int64
 	const int wr = (wave >> 1) * 32, wc = (wave & 1) * 32;      // this wave's 32 x 32 tile
 	const int rsel = lane & 31, khalf = (lane >> 5) * 16;
 	v16i acc_hh = {0}, acc_hl = {0}, acc_lh = {0}, acc_ll = {0};
+	// a workgroup is a chain of dependent loads (few workgroups fit on a CU): fetch what does not depend on anything
+	// first -- the pivot counts of all sets and this thread's 16 entries of C
+	int ks[4];
+#pragma unroll
+	for (int s = 0; s < 4; s++)
+		ks[s] = (s < S.nsets) ? *S.knew[s] : 0;
+	uint32_t cval[16];
+#pragma unroll
+	for (int reg = 0; reg < 16; reg++) {
+		const int i = row0 + wr + (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5), j = col0 + wc + (lane & 31);
+		cval[reg] = (i < n && j < mr) ? A[(int64_t) i * ld + c1 + j] : 0u;
+	}
 	bool any = false;
-	for (int s = 0; s < S.nsets; s++) {
-		const int k = *S.knew[s];
+#pragma unroll
+	for (int s = 0; s < 4; s++) {
+		const int k = ks[s];
 		if (k == 0)
 			continue;
 		if (any)
@@ -1167,8 +1180,9 @@ __global__ __launch_bounds__(256) void rref_update_mfma_multi(uint32_t *A, int64
 	}
 	if (!any)
 		return;
-	// |sum| <= 256 (p/2)^2 < p 2^22 for p < 2^16: shift by a multiple of p to stay non-negative
-	const long long offset = (long long) F.p << 23;
+	// recombination and reduction in double precision: |digit sums| <= 256 * 128 * 128 = 2^22, so the recombined
+	// value (< 2^39 in magnitude) and q * p are exact; the quotient estimate is off by at most one
+	const double pd = (double) F.p, invp = 1.0 / pd;
 #pragma unroll
 	for (int reg = 0; reg < 16; reg++) {
 		const int rr = (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5);
@@ -1176,14 +1190,16 @@ __global__ __launch_bounds__(256) void rref_update_mfma_multi(uint32_t *A, int64
 		const int i = row0 + wr + rr, j = col0 + wc + cc;
 		if (i >= n || j >= mr)
 			continue;
-		const long long sv = (long long) acc_hh[reg] * 65536 + ((long long) acc_hl[reg] + (long long) acc_lh[reg]) * 256 +
-		                     (long long) acc_ll[reg] + offset;
-		const uint32_t mred = reduce_sum((unsigned long long) sv, F);
-		uint32_t *dst = A + (int64_t) i * ld + c1 + j;
-		uint32_t sum = *dst + mred;
+		const double sd = fma((double) acc_hh[reg], 65536.0, fma((double) (acc_hl[reg] + acc_lh[reg]), 256.0, (double) acc_ll[reg]));
+		const double qd = floor(sd * invp);
+		double rd = fma(-qd, pd, sd);
+		rd = (rd < 0.0) ? rd + pd : rd;
+		rd = (rd >= pd) ? rd - pd : rd;
+		const uint32_t mred = (uint32_t) rd;
+		uint32_t sum = cval[reg] + mred;
 		if (sum >= F.p)
 			sum -= F.p;
-		*dst = sum;
+		A[(int64_t) i * ld + c1 + j] = sum;
 	}
 }
 
