@@ -1130,42 +1130,40 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
 	const int wr = (wave >> 1) * 32, wc = (wave & 1) * 32;      // this wave's 32 x 32 tile
 	const int rsel = lane & 31, khalf = (lane >> 5) * 16;
 	v16i acc_hh = {0}, acc_hl = {0}, acc_lh = {0}, acc_ll = {0};
-	// a workgroup is a chain of dependent loads (few workgroups fit on a CU): fetch what does not depend on anything
-	// first -- the pivot counts of all sets and this thread's 16 entries of C
-	int ks[4];
-#pragma unroll
-	for (int s = 0; s < 4; s++)
-		ks[s] = (s < S.nsets) ? *S.knew[s] : 0;
+	// a workgroup is a chain of dependent loads (few workgroups fit on a CU): this thread's 16 entries of C are
+	// fetched first, and the digit planes of set s + 1 while set s is multiplied.  Sets that found no pivot have
+	// all-zero planes (rref_split_M/B): they are multiplied like the others rather than tested for.
 	uint32_t cval[16];
 #pragma unroll
 	for (int reg = 0; reg < 16; reg++) {
 		const int i = row0 + wr + (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5), j = col0 + wc + (lane & 31);
 		cval[reg] = (i < n && j < mr) ? A[(int64_t) i * ld + c1 + j] : 0u;
 	}
-	bool any = false;
+	// 64 rows (columns) x 64 digit bytes per plane: thread t moves 16 bytes of row (column) t / 4
+	const int rr_t = tid >> 2, part = (tid & 3) * 16;
+	const int i_t = row0 + rr_t, j_t = col0 + rr_t;
+	const int4 zero = make_int4(0, 0, 0, 0);
+	int4 mh, ml, bh, bl;
+	auto fetch = [&](int s) {
+		mh = (i_t < n) ? *reinterpret_cast<const int4 *>(S.Mh[s] + (int64_t) i_t * 64 + part) : zero;
+		ml = (i_t < n) ? *reinterpret_cast<const int4 *>(S.Ml[s] + (int64_t) i_t * 64 + part) : zero;
+		bh = (j_t < mr) ? *reinterpret_cast<const int4 *>(S.Bh[s] + (int64_t) j_t * 64 + part) : zero;
+		bl = (j_t < mr) ? *reinterpret_cast<const int4 *>(S.Bl[s] + (int64_t) j_t * 64 + part) : zero;
+	};
+	fetch(0);
 #pragma unroll
-	for (int s = 0; s < 4; s++) {
-		const int k = ks[s];
-		if (k == 0)
-			continue;
-		if (any)
+	for (int s = 0; s < 4; s++) {          // (static indices into the kernel arguments)
+		if (s >= S.nsets)
+			break;
+		if (s > 0)
 			__syncthreads();          // the previous set's tiles have been consumed
-		any = true;
-		{
-			// 64 rows (columns) x 64 digit bytes per plane: thread t moves 16 bytes of row (column) t / 4
-			const int rr = tid >> 2, part = (tid & 3) * 16;
-			const int i = row0 + rr, j = col0 + rr;
-			const int4 zero = make_int4(0, 0, 0, 0);
-			const int4 mh = (i < n) ? *reinterpret_cast<const int4 *>(S.Mh[s] + (int64_t) i * 64 + part) : zero;
-			const int4 ml = (i < n) ? *reinterpret_cast<const int4 *>(S.Ml[s] + (int64_t) i * 64 + part) : zero;
-			const int4 bh = (j < mr) ? *reinterpret_cast<const int4 *>(S.Bh[s] + (int64_t) j * 64 + part) : zero;
-			const int4 bl = (j < mr) ? *reinterpret_cast<const int4 *>(S.Bl[s] + (int64_t) j * 64 + part) : zero;
-			*reinterpret_cast<int4 *>(&Mhi[rr][part]) = mh;
-			*reinterpret_cast<int4 *>(&Mlo[rr][part]) = ml;
-			*reinterpret_cast<int4 *>(&Bhi[rr][part]) = bh;
-			*reinterpret_cast<int4 *>(&Blo[rr][part]) = bl;
-		}
+		*reinterpret_cast<int4 *>(&Mhi[rr_t][part]) = mh;
+		*reinterpret_cast<int4 *>(&Mlo[rr_t][part]) = ml;
+		*reinterpret_cast<int4 *>(&Bhi[rr_t][part]) = bh;
+		*reinterpret_cast<int4 *>(&Blo[rr_t][part]) = bl;
 		__syncthreads();
+		if (s + 1 < 4 && s + 1 < S.nsets)
+			fetch(s + 1 < 4 ? s + 1 : 3);
 #pragma unroll
 		for (int ks = 0; ks < 64; ks += 32) {
 			const v4i a_hi = *reinterpret_cast<const v4i *>(&Mhi[wr + rsel][ks + khalf]);
@@ -1178,8 +1176,6 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
 			acc_ll = __builtin_amdgcn_mfma_i32_32x32x32_i8(a_lo, b_lo, acc_ll, 0, 0, 0);
 		}
 	}
-	if (!any)
-		return;
 	// recombination and reduction in double precision: |digit sums| <= 256 * 128 * 128 = 2^22, so the recombined
 	// value (< 2^39 in magnitude) and q * p are exact; the quotient estimate is off by at most one
 	const double pd = (double) F.p, invp = 1.0 / pd;
