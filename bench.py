@@ -274,8 +274,11 @@ def main():
             os.environ.pop("SPASM_HIP_THREADS", None)
             t0 = time.perf_counter()
             fact = spasm_amd.echelonize(A)
+            cold = time.perf_counter() - t0          # first call of the process: one-time allocations included
+            t0 = time.perf_counter()
+            fact = spasm_amd.echelonize(A)
             out["end_to_end"] = {"what": "spasm_hip_echelonize on the same matrix, default options", "rank": int(fact.U.n),
-                                 "seconds": time.perf_counter() - t0}
+                                 "seconds": time.perf_counter() - t0, "seconds_first_call": cold}
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(A, rows, F)
         print(json.dumps(out))
