@@ -159,7 +159,20 @@ def main():
     use_dist = world > 1 or os.environ.get("SPASM_BENCH_FORCE_DIST") == "1"   # the flag lets a 1-GPU box run the RCCL path
     if use_dist:
         import torch.distributed as dist
-        dist.init_process_group("nccl", device_id=dev)
+        # RCCL prints a version banner on stdout when the communicator is created: stdout carries the one JSON line
+        # only, so the banner goes to stderr (file descriptor level: it is printed by the C library)
+        sys.stdout.flush()
+        saved_stdout = os.dup(1)
+        os.dup2(2, 1)
+        try:
+            dist.init_process_group("nccl", device_id=dev)
+            warm = torch.zeros(1, device=dev)
+            dist.all_reduce(warm)
+            torch.cuda.synchronize()
+        finally:
+            sys.stdout.flush()
+            os.dup2(saved_stdout, 1)
+            os.close(saved_stdout)
 
     A, rows, F = build_workload(args.workload)
     from spasm_amd.dist import shard_rows, allgatherv_csr
