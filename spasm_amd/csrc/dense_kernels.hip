@@ -771,6 +771,8 @@ __global__ __launch_bounds__(128 * NPAR) void rref_block_gj(BlockGjArgs g)
 
 // M[i][r] = -sum_s A[i, c0 + gamma_s] Ginv[s][r]  (+ Ginv[s][r] on the row that became pivot s), stored where the
 // update kernels read it: P[(NB + r) * n + i].  Thread = (row, 4 consecutive r).
+// SMALL16 (p < 2^16): plain 24-bit products summed in 64 bits, one reduction per multiplier.
+template <bool SMALL16>
 __global__ __launch_bounds__(256) void rref_multipliers(const uint32_t *A, int64_t ld, int n, int m, int c0, const uint32_t *Ginv,
                                                         const int *gamma, const int *knew, uint32_t *P, MontDev F)
 {
@@ -781,7 +783,7 @@ __global__ __launch_bounds__(256) void rref_multipliers(const uint32_t *A, int64
 		return;
 	const int tid = threadIdx.x;
 	for (int t = tid; t < NB * NB; t += 256)
-		sG[t / NB][t % NB] = (t / NB < k && t % NB < k) ? Ginv[t] : 0u;
+		sG[t / NB][t % NB] = (t / NB < k && t % NB < k) ? (SMALL16 ? montmul(Ginv[t], 1u, F) : Ginv[t]) : 0u;   // (plain / Montgomery form)
 	if (tid < NB)
 		sgam[tid] = (tid < k) ? gamma[tid] : 0;
 	// the panel entries of the workgroup's 64 rows, read row by row (256 contiguous bytes each)
@@ -801,14 +803,32 @@ __global__ __launch_bounds__(256) void rref_multipliers(const uint32_t *A, int64
 #pragma unroll
 	for (int u = 0; u < 16; u++)
 		acc[u] = 0;
-	for (int s = 0; s < k; s++) {
-		const uint32_t a = tile[tid & 63][sgam[s]];
-		if (a == 0)
-			continue;
+	if constexpr (SMALL16) {
+		unsigned long long wide[16];
 #pragma unroll
-		for (int u = 0; u < 16; u++) {
-			uint32_t v = acc[u] + montmul(a, sG[s][q * 16 + u], F);
-			acc[u] = (v >= F.p || v < acc[u]) ? v - F.p : v;
+		for (int u = 0; u < 16; u++)
+			wide[u] = 0;
+		for (int s = 0; s < k; s++) {
+			const uint32_t a = tile[tid & 63][sgam[s]];
+			if (a == 0)
+				continue;
+#pragma unroll
+			for (int u = 0; u < 16; u++)
+				wide[u] += (uint32_t) __umul24(a, sG[s][q * 16 + u]);          // < 2^32 each (HIP declares __umul24 as int), at most 64 of them
+		}
+#pragma unroll
+		for (int u = 0; u < 16; u++)
+			acc[u] = reduce_sum(wide[u], F);
+	} else {
+		for (int s = 0; s < k; s++) {
+			const uint32_t a = tile[tid & 63][sgam[s]];
+			if (a == 0)
+				continue;
+#pragma unroll
+			for (int u = 0; u < 16; u++) {
+				uint32_t v = acc[u] + montmul(a, sG[s][q * 16 + u], F);
+				acc[u] = (v >= F.p || v < acc[u]) ? v - F.p : v;
+			}
 		}
 	}
 	// (the new pivot rows get their extra term from rref_multipliers_fix)
@@ -1400,7 +1420,10 @@ int device_rref(int64_t prime, int n, int m, uint32_t *dA, int64_t ld, int *d_pi
 					hipLaunchKernelGGL((rref_block_gj<true, 8>), dim3(1), dim3(1024), invtab_bytes, stream, bg);
 				else
 					hipLaunchKernelGGL((rref_block_gj<false, 8>), dim3(1), dim3(1024), 0, stream, bg);
-				hipLaunchKernelGGL(rref_multipliers, dim3((n + 63) / 64), dim3(256), 0, stream, dA, ld, n, m, c0, Ginv, gamma, knew_s, P_s, F);
+				if (small16)
+					hipLaunchKernelGGL(rref_multipliers<true>, dim3((n + 63) / 64), dim3(256), 0, stream, dA, ld, n, m, c0, Ginv, gamma, knew_s, P_s, F);
+				else
+					hipLaunchKernelGGL(rref_multipliers<false>, dim3((n + 63) / 64), dim3(256), 0, stream, dA, ld, n, m, c0, Ginv, gamma, knew_s, P_s, F);
 				hipLaunchKernelGGL(rref_multipliers_fix, dim3(1), dim3(256), 0, stream, n, Ginv, rho_s, pivrow, rank_d, knew_s, P_s, F);
 				// the columns of the super-panel, from this panel on: K = 64 update now
 				const int mr_sp = sp_end - c0;
