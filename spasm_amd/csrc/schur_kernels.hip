@@ -121,11 +121,11 @@ template <int H, bool WIDE> struct WaveLds {
 // x[c] += delta.  Returns true when c was not in the table before.  New
 // pivotal labels (c < r) are appended to the pending list.
 template <int H, bool WIDE>
-__device__ __forceinline__ bool table_add(WaveLds<H, WIDE> *T, uint32_t c, uint32_t delta,
+__device__ __forceinline__ bool table_add(WaveLds<H, WIDE> __attribute__((address_space(3))) *T, uint32_t c, uint32_t delta,
                                           int which, uint32_t r)
 {
 	using V = typename Acc<WIDE>::type;
-	volatile uint32_t *keys = T->keys;
+	volatile uint32_t __attribute__((address_space(3))) *keys = T->keys;
 	uint32_t s = slot_of<H>(c);
 	bool fresh = false;
 	for (;;) {
@@ -133,7 +133,8 @@ __device__ __forceinline__ bool table_add(WaveLds<H, WIDE> *T, uint32_t c, uint3
 		if (k == c)
 			break;
 		if (k == EMPTY) {
-			uint32_t old = atomicCAS(&T->keys[s], EMPTY, c);
+			uint32_t old = EMPTY;          // LDS compare-and-swap: `old` receives what was there
+			(void) __hip_atomic_compare_exchange_strong(&T->keys[s], &old, c, __ATOMIC_RELAXED, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
 			if (old == EMPTY) {
 				fresh = true;
 				break;
@@ -143,23 +144,23 @@ __device__ __forceinline__ bool table_add(WaveLds<H, WIDE> *T, uint32_t c, uint3
 		}
 		s = (s + 1) & (H - 1);
 	}
-	atomicAdd(&T->vals[s], (V) delta);
+	(void) __hip_atomic_fetch_add(&T->vals[s], (V) delta, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
 	if (fresh && c < r) {
-		uint32_t pos = atomicAdd(&T->cnt[which], 1u);
-		((volatile uint32_t *) T->pend[which])[pos] = c;
+		uint32_t pos = __hip_atomic_fetch_add(&T->cnt[which], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+		((volatile uint32_t __attribute__((address_space(3))) *) T->pend[which])[pos] = c;
 	}
 	return fresh;
 }
 
 template <int H, bool WIDE>
-__device__ __forceinline__ typename Acc<WIDE>::type table_get(WaveLds<H, WIDE> *T, uint32_t c)
+__device__ __forceinline__ typename Acc<WIDE>::type table_get(WaveLds<H, WIDE> __attribute__((address_space(3))) *T, uint32_t c)
 {
 	using V = typename Acc<WIDE>::type;
-	volatile uint32_t *keys = T->keys;
+	volatile uint32_t __attribute__((address_space(3))) *keys = T->keys;
 	uint32_t s = slot_of<H>(c);
 	for (int guard = 0; guard < H; guard++) {
 		if (keys[s] == c)
-			return ((volatile V *) T->vals)[s];
+			return ((volatile V __attribute__((address_space(3))) *) T->vals)[s];
 		s = (s + 1) & (H - 1);
 	}
 	return 0;
@@ -176,7 +177,9 @@ __global__ __launch_bounds__(64) void schur_lds_kernel(SchurArgs a)
 	extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
 	using L = WaveLds<H, WIDE>;
 	using V = typename Acc<WIDE>::type;
-	L *T = reinterpret_cast<L *>(lds_raw);
+	// (address_space(3): generic pointers to LDS become FLAT instructions, which count in vmcnt and lgkmcnt)
+	typedef L __attribute__((address_space(3))) LdsL;
+	LdsL *T = (LdsL *) lds_raw;
 	constexpr int PCAP = L::PCAP;
 	constexpr int CAPK = (H * 3) / 4 - 64;      // keys allowed before a batch of 64 inserts
 	constexpr int CAPP = PCAP - 64;
@@ -223,7 +226,7 @@ __global__ __launch_bounds__(64) void schur_lds_kernel(SchurArgs a)
 			const int64_t lo = a.Ap[i], hi = a.Ap[i + 1];
 			st_input += (unsigned long long) (hi - lo);
 			for (int64_t base = lo; base < hi; base += 64) {
-				uint32_t pc = ((volatile uint32_t *) T->cnt)[0];
+				uint32_t pc = ((volatile uint32_t __attribute__((address_space(3))) *) T->cnt)[0];
 				if (nkeys > CAPK || (int) pc > CAPP) {
 					overflow = true;
 					break;
@@ -243,10 +246,10 @@ __global__ __launch_bounds__(64) void schur_lds_kernel(SchurArgs a)
 			int cur = 0;
 			while (!overflow) {
 				__builtin_amdgcn_wave_barrier();
-				const int P = (int) ((volatile uint32_t *) T->cnt)[cur];
+				const int P = (int) ((volatile uint32_t __attribute__((address_space(3))) *) T->cnt)[cur];
 				if (P == 0)
 					break;
-				volatile uint32_t *pcur = T->pend[cur];
+				volatile uint32_t __attribute__((address_space(3))) *pcur = T->pend[cur];
 				uint32_t cmin = EMPTY;
 				for (int t = lane; t < P; t += 64) {
 					uint32_t c = pcur[t];
@@ -256,11 +259,11 @@ __global__ __launch_bounds__(64) void schur_lds_kernel(SchurArgs a)
 				const uint32_t lend = a.lvl_end[__builtin_amdgcn_readfirstlane(cmin)];
 				const int nxt = cur ^ 1;
 				if (lane == 0)
-					((volatile uint32_t *) T->cnt)[nxt] = 0;
+					((volatile uint32_t __attribute__((address_space(3))) *) T->cnt)[nxt] = 0;
 				__builtin_amdgcn_wave_barrier();
 
 				for (int base = 0; base < P && !overflow; base += 64) {
-					if ((int) ((volatile uint32_t *) T->cnt)[nxt] > CAPP) {
+					if ((int) ((volatile uint32_t __attribute__((address_space(3))) *) T->cnt)[nxt] > CAPP) {
 						overflow = true;
 						break;
 					}
@@ -274,10 +277,10 @@ __global__ __launch_bounds__(64) void schur_lds_kernel(SchurArgs a)
 					if (mk != 0) {
 						uint32_t off = 0;
 						if (lane == 0)
-							off = atomicAdd(&T->cnt[nxt], (uint32_t) __popcll(mk));
+							off = __hip_atomic_fetch_add(&T->cnt[nxt], (uint32_t) __popcll(mk), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
 						off = __builtin_amdgcn_readfirstlane(off);
 						if (keep)
-							((volatile uint32_t *) T->pend[nxt])[off + __popcll(mk & lanes_below(lane))] = c;
+							((volatile uint32_t __attribute__((address_space(3))) *) T->pend[nxt])[off + __popcll(mk & lanes_below(lane))] = c;
 					}
 					const uint64_t ms = __ballot(sel);
 					if (ms == 0)
@@ -299,7 +302,7 @@ __global__ __launch_bounds__(64) void schur_lds_kernel(SchurArgs a)
 					st_stream += (unsigned long long) tot;
 					const uint32_t start_lo = (uint32_t) start, start_hi = (uint32_t) (start >> 32);
 					for (int f0 = 0; f0 < tot; f0 += 64) {
-						uint32_t pc = ((volatile uint32_t *) T->cnt)[nxt];
+						uint32_t pc = ((volatile uint32_t __attribute__((address_space(3))) *) T->cnt)[nxt];
 						if (nkeys > CAPK || (int) pc > CAPP) {
 							overflow = true;
 							break;
@@ -344,10 +347,10 @@ __global__ __launch_bounds__(64) void schur_lds_kernel(SchurArgs a)
 			int count = 0;
 			for (int s0 = 0; s0 < H; s0 += 64) {
 				const int s = s0 + lane;
-				const uint32_t key = ((volatile uint32_t *) T->keys)[s];
+				const uint32_t key = ((volatile uint32_t __attribute__((address_space(3))) *) T->keys)[s];
 				bool keep = (key != EMPTY) && (key >= r);
 				if (keep)
-					keep = reduce_sum(((volatile V *) T->vals)[s], F) != 0;
+					keep = reduce_sum(((volatile V __attribute__((address_space(3))) *) T->vals)[s], F) != 0;
 				count += __popcll(__ballot(keep));
 			}
 			if (count > arena_left) {
@@ -371,11 +374,11 @@ __global__ __launch_bounds__(64) void schur_lds_kernel(SchurArgs a)
 			int64_t wpos = arena_off;
 			for (int s0 = 0; s0 < H; s0 += 64) {
 				const int s = s0 + lane;
-				const uint32_t key = ((volatile uint32_t *) T->keys)[s];
+				const uint32_t key = ((volatile uint32_t __attribute__((address_space(3))) *) T->keys)[s];
 				bool keep = (key != EMPTY) && (key >= r);
 				uint32_t v = 0;
 				if (keep) {
-					v = reduce_sum(((volatile V *) T->vals)[s], F);
+					v = reduce_sum(((volatile V __attribute__((address_space(3))) *) T->vals)[s], F);
 					keep = v != 0;
 				}
 				const uint64_t mk = __ballot(keep);
