@@ -571,6 +571,7 @@ struct BlockGjArgs {
 	int *gamma;            // NB: pivot columns inside the panel, increasing
 	int *is_pivot_row;
 	int *pivrow, *pivcol, *rank, *knew, *rho;
+	int *cand_pivot;       // NB: pivot index of candidate r (every candidate becomes a pivot row)
 	MontDev F;
 };
 
@@ -757,6 +758,7 @@ __global__ __launch_bounds__(128 * NPAR) void rref_block_gj(BlockGjArgs g)
 	if (tid < k) {
 		g.rho[tid] = s_rows[tid];
 		const int s = s_prow_of[tid];
+		g.cand_pivot[tid] = s;
 		if (s >= 0) {
 			g.is_pivot_row[s_rows[tid]] = 1;
 			g.pivrow[base + s] = s_rows[tid];
@@ -771,17 +773,39 @@ __global__ __launch_bounds__(128 * NPAR) void rref_block_gj(BlockGjArgs g)
 
 // M[i][r] = -sum_s A[i, c0 + gamma_s] Ginv[s][r]  (+ Ginv[s][r] on the row that became pivot s), stored where the
 // update kernels read it: P[(NB + r) * n + i].  Thread = (row, 4 consecutive r).
+// signed base-256 digits of the balanced representative (see the matrix-core update below)
+__device__ __forceinline__ void split_digits(uint32_t v, const MontDev &F, int &hi, int &lo)
+{
+	int b = (v > F.half) ? (int) v - (int) F.p : (int) v;
+	lo = ((b + 128) & 255) - 128;
+	hi = (b - lo) >> 8;
+}
+
 // SMALL16 (p < 2^16): plain 24-bit products summed in 64 bits, one reduction per multiplier.
 template <bool SMALL16>
 __global__ __launch_bounds__(256) void rref_multipliers(const uint32_t *A, int64_t ld, int n, int m, int c0, const uint32_t *Ginv,
-                                                        const int *gamma, const int *knew, uint32_t *P, MontDev F)
+                                                        const int *gamma, const int *knew, uint32_t *P, MontDev F,
+                                                        const int *rho, const int *cand_pivot, signed char *Mh, signed char *Ml)
 {
 	__shared__ uint32_t sG[NB][NB + 1];
-	__shared__ int sgam[NB];
+	__shared__ int sgam[NB], srho[NB], spiv[NB];
 	const int k = *knew;
-	if (k == 0)
-		return;
 	const int tid = threadIdx.x;
+	if (k == 0) {
+		// no pivot in this panel: all-zero digit planes (the update kernels multiply every set)
+		if (Mh != nullptr) {
+			const int i = blockIdx.x * 64 + (tid & 63), q = tid >> 6;
+			if (i < n) {
+				*reinterpret_cast<int4 *>(Mh + (int64_t) i * 64 + q * 16) = make_int4(0, 0, 0, 0);
+				*reinterpret_cast<int4 *>(Ml + (int64_t) i * 64 + q * 16) = make_int4(0, 0, 0, 0);
+			}
+		}
+		return;
+	}
+	if (tid < NB) {
+		srho[tid] = (tid < k) ? rho[tid] : -1;
+		spiv[tid] = (tid < k) ? cand_pivot[tid] : -1;
+	}
 	for (int t = tid; t < NB * NB; t += 256)
 		sG[t / NB][t % NB] = (t / NB < k && t % NB < k) ? (SMALL16 ? montmul(Ginv[t], 1u, F) : Ginv[t]) : 0u;   // (plain / Montgomery form)
 	if (tid < NB)
@@ -831,12 +855,32 @@ __global__ __launch_bounds__(256) void rref_multipliers(const uint32_t *A, int64
 			}
 		}
 	}
-	// (the new pivot rows get their extra term from rref_multipliers_fix)
+	// M = -acc; the row that became pivot s gets + Ginv[s][.] (see the definition of T above)
+	int my_pivot = -1;
+	for (int r = 0; r < k; r++)
+		my_pivot = (srho[r] == i) ? spiv[r] : my_pivot;
+	unsigned int wh[4] = {0, 0, 0, 0}, wl[4] = {0, 0, 0, 0};
 #pragma unroll
 	for (int u = 0; u < 16; u++) {
 		const int r = q * 16 + u;
+		uint32_t mval = (acc[u] == 0) ? 0u : F.p - acc[u];
+		if (my_pivot >= 0) {
+			const uint32_t g = SMALL16 ? sG[my_pivot][r] : montmul(sG[my_pivot][r], 1u, F);
+			mval += g;
+			mval = (mval >= F.p || mval < g) ? mval - F.p : mval;
+		}
 		if (r < k)
-			P[(int64_t) (NB + r) * n + i] = (acc[u] == 0) ? 0u : F.p - acc[u];
+			P[(int64_t) (NB + r) * n + i] = mval;
+		else
+			mval = 0;
+		int hi, lo;
+		split_digits(mval, F, hi, lo);
+		wh[u >> 2] |= (unsigned int) (hi & 255) << (8 * (u & 3));
+		wl[u >> 2] |= (unsigned int) (lo & 255) << (8 * (u & 3));
+	}
+	if (Mh != nullptr) {
+		*reinterpret_cast<int4 *>(Mh + (int64_t) i * 64 + q * 16) = make_int4((int) wh[0], (int) wh[1], (int) wh[2], (int) wh[3]);
+		*reinterpret_cast<int4 *>(Ml + (int64_t) i * 64 + q * 16) = make_int4((int) wl[0], (int) wl[1], (int) wl[2], (int) wl[3]);
 	}
 }
 
@@ -928,12 +972,6 @@ __global__ __launch_bounds__(256) void rref_update_valu(uint32_t *A, int64_t ld,
 typedef int v4i __attribute__((ext_vector_type(4)));
 typedef int v16i __attribute__((ext_vector_type(16)));
 
-__device__ __forceinline__ void split_digits(uint32_t v, const MontDev &F, int &hi, int &lo)
-{
-	int b = (v > F.half) ? (int) v - (int) F.p : (int) v;
-	lo = ((b + 128) & 255) - 128;
-	hi = (b - lo) >> 8;
-}
 
 // Workgroup = 4 waves = a 64 x 64 tile of C (2 x 2 wave tiles of 32 x 32).  K = NB = 64.
 // LDS holds the digit planes of M (64 x 64) and B (64 x 64) as int8.
@@ -1267,7 +1305,7 @@ int device_rref(int64_t prime, int n, int m, uint32_t *dA, int64_t ld, int *d_pi
 	const bool small_prime = prime < 46341;          // 2 p^2 < 2^32: the panel kernels use 24-bit multiplies
 	if (const char *e = std::getenv("SPASM_HIP_RREF_PANEL"))
 		tournament = std::strcmp(e, "columns") != 0;
-	int *candA = nullptr, *candB = nullptr, *free_count = nullptr, *gamma = nullptr, *cand_first = nullptr, *full_flag = nullptr, *first64 = nullptr;
+	int *candA = nullptr, *candB = nullptr, *free_count = nullptr, *gamma = nullptr, *cand_first = nullptr, *full_flag = nullptr, *first64 = nullptr, *cand_pivot = nullptr;
 	uint32_t *Ginv = nullptr, *P4 = nullptr, *Bt4 = nullptr;
 	int *rho4 = nullptr, *knew4 = nullptr;
 	signed char *M8 = nullptr, *B8 = nullptr;
@@ -1281,6 +1319,7 @@ int device_rref(int64_t prime, int n, int m, uint32_t *dA, int64_t ld, int *d_pi
 		HIP_CHECK(hipMalloc((void **) &gamma, NB * sizeof(int)));
 		HIP_CHECK(hipMalloc((void **) &cand_first, NB * sizeof(int)));
 		HIP_CHECK(hipMalloc((void **) &first64, NB * sizeof(int)));
+		HIP_CHECK(hipMalloc((void **) &cand_pivot, NB * sizeof(int)));
 		HIP_CHECK(hipMemsetAsync(free_count, 0, 64, stream));          // [4]: scan hint of rref_first_free
 		HIP_CHECK(hipMalloc((void **) &P4, (size_t) 8 * (size_t) n * PW * sizeof(uint32_t)));
 		HIP_CHECK(hipMalloc((void **) &Bt4, (size_t) 4 * (size_t) NB * (size_t) m * sizeof(uint32_t)));
@@ -1414,17 +1453,23 @@ int device_rref(int64_t prime, int n, int m, uint32_t *dA, int64_t ld, int *d_pi
 				bg.rank = rank_d;
 				bg.knew = knew_s;
 				bg.rho = rho_s;
+				bg.cand_pivot = cand_pivot;
 				bg.F = F;
 				bg.invtab = invtab;
 				if (small_prime)
 					hipLaunchKernelGGL((rref_block_gj<true, 8>), dim3(1), dim3(1024), invtab_bytes, stream, bg);
 				else
 					hipLaunchKernelGGL((rref_block_gj<false, 8>), dim3(1), dim3(1024), 0, stream, bg);
-				if (small16)
-					hipLaunchKernelGGL(rref_multipliers<true>, dim3((n + 63) / 64), dim3(256), 0, stream, dA, ld, n, m, c0, Ginv, gamma, knew_s, P_s, F);
-				else
-					hipLaunchKernelGGL(rref_multipliers<false>, dim3((n + 63) / 64), dim3(256), 0, stream, dA, ld, n, m, c0, Ginv, gamma, knew_s, P_s, F);
-				hipLaunchKernelGGL(rref_multipliers_fix, dim3(1), dim3(256), 0, stream, n, Ginv, rho_s, pivrow, rank_d, knew_s, P_s, F);
+				signed char *Mh_s = M8 + (size_t) slot * 2 * (size_t) n * 64, *Ml_s = Mh_s + (size_t) n * 64;
+				{
+					signed char *mh = mfma_ok ? Mh_s : nullptr, *ml = mfma_ok ? Ml_s : nullptr;
+					if (small16)
+						hipLaunchKernelGGL(rref_multipliers<true>, dim3((n + 63) / 64), dim3(256), 0, stream, dA, ld, n, m, c0, Ginv, gamma, knew_s,
+						                   P_s, F, rho_s, cand_pivot, mh, ml);
+					else
+						hipLaunchKernelGGL(rref_multipliers<false>, dim3((n + 63) / 64), dim3(256), 0, stream, dA, ld, n, m, c0, Ginv, gamma, knew_s,
+						                   P_s, F, rho_s, cand_pivot, mh, ml);
+				}
 				// the columns of the super-panel, from this panel on: K = 64 update now
 				const int mr_sp = sp_end - c0;
 				hipLaunchKernelGGL(rref_gather_pivot_rows, dim3(512), dim3(256), 0, stream, dA, ld, c0, mr_sp, rho_s, knew_s, B);
@@ -1433,10 +1478,8 @@ int device_rref(int64_t prime, int n, int m, uint32_t *dA, int64_t ld, int *d_pi
 				one.B[0] = B;
 				one.knew[0] = knew_s;
 				one.nsets = 1;
-				signed char *Mh_s = M8 + (size_t) slot * 2 * (size_t) n * 64, *Ml_s = Mh_s + (size_t) n * 64;
 				if (mfma_ok) {
 					signed char *Bh_p = B8 + (size_t) 4 * 2 * (size_t) m * 64, *Bl_p = Bh_p + (size_t) m * 64;
-					hipLaunchKernelGGL(rref_split_M, dim3((n + 255) / 256), dim3(256), 0, stream, P_s, n, knew_s, Mh_s, Ml_s, F);
 					hipLaunchKernelGGL(rref_split_B, dim3((mr_sp + 255) / 256), dim3(256), 0, stream, B, mr_sp, knew_s, Bh_p, Bl_p, F);
 					one.Mh[0] = Mh_s;
 					one.Ml[0] = Ml_s;
@@ -1601,6 +1644,7 @@ int device_rref(int64_t prime, int n, int m, uint32_t *dA, int64_t ld, int *d_pi
 		(void) hipFree(gamma);
 		(void) hipFree(cand_first);
 		(void) hipFree(first64);
+		(void) hipFree(cand_pivot);
 		(void) hipFree(P4);
 		(void) hipFree(Bt4);
 		(void) hipFree(rho4);
