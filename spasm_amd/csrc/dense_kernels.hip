@@ -884,23 +884,6 @@ __global__ __launch_bounds__(256) void rref_multipliers(const uint32_t *A, int64
 	}
 }
 
-// pivot rows: M[rho_r'][r] += Ginv[s(r')][r] where s(r') is the pivot index of candidate r'
-__global__ __launch_bounds__(256) void rref_multipliers_fix(int n, const uint32_t *Ginv, const int *rho, const int *pivrow,
-                                                            const int *rank, const int *knew, uint32_t *P, MontDev F)
-{
-	const int k = *knew;
-	const int base = *rank - k;         // (every candidate became a pivot)
-	for (int t = threadIdx.x; t < k * k; t += 256) {
-		const int s = t / k, r = t % k;
-		const int i = pivrow[base + s];
-		const uint32_t g = montmul(Ginv[s * NB + r], 1u, F);       // out of Montgomery form
-		uint32_t *dst = &P[(int64_t) (NB + r) * n + i];
-		uint32_t v = *dst + g;
-		if (v >= F.p || v < g)
-			v -= F.p;
-		*dst = v;
-	}
-}
 
 // B[t, :] = A[rho[t], c1:]  (old values of the new pivot rows), k x mr, row-major ld = mr
 __global__ void rref_gather_pivot_rows(const uint32_t *A, int64_t ld, int c1, int mr, const int *rho, const int *knew,
@@ -1078,21 +1061,30 @@ struct UpdSets {
 	int nsets;
 };
 
-// digits of the multipliers of one set: one thread per row
-__global__ __launch_bounds__(256) void rref_split_M(const uint32_t *P, int n, const int *knew, signed char *Mh, signed char *Ml, MontDev F)
+
+// B[t, :] = A[rho[t], c1 : c1 + mr] (old values of the new pivot rows) as digit planes, one thread per column; the
+// 32-bit copy is written too when B is not null (VALU update)
+__global__ __launch_bounds__(256) void rref_gather_split_B(const uint32_t *A, int64_t ld, int c1, int mr, const int *rho, const int *knew,
+                                                           signed char *Bh, signed char *Bl, uint32_t *B, MontDev F)
 {
-	const int i = blockIdx.x * 256 + threadIdx.x;
-	if (i >= n)
-		return;
+	__shared__ int srho[NB];
 	const int k = *knew;
-	int4 *dh = reinterpret_cast<int4 *>(Mh + (int64_t) i * 64), *dl = reinterpret_cast<int4 *>(Ml + (int64_t) i * 64);
+	if (threadIdx.x < NB)
+		srho[threadIdx.x] = (threadIdx.x < k) ? rho[threadIdx.x] : 0;
+	__syncthreads();
+	const int col = blockIdx.x * 256 + threadIdx.x;
+	if (col >= mr)
+		return;
+	int4 *dh = reinterpret_cast<int4 *>(Bh + (int64_t) col * 64), *dl = reinterpret_cast<int4 *>(Bl + (int64_t) col * 64);
 #pragma unroll
 	for (int part = 0; part < 4; part++) {
 		unsigned int wh[4] = {0, 0, 0, 0}, wl[4] = {0, 0, 0, 0};
 #pragma unroll
 		for (int b = 0; b < 16; b++) {
 			const int kk = part * 16 + b;
-			const uint32_t v = (kk < k) ? P[(int64_t) (NB + kk) * n + i] : 0u;
+			const uint32_t v = (kk < k) ? A[(int64_t) srho[kk] * ld + c1 + col] : 0u;
+			if (B != nullptr && kk < k)
+				B[(int64_t) kk * mr + col] = v;
 			int hi, lo;
 			split_digits(v, F, hi, lo);
 			wh[b >> 2] |= (unsigned int) (hi & 255) << (8 * (b & 3));
@@ -1190,7 +1182,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
 	v16i acc_hh = {0}, acc_hl = {0}, acc_lh = {0}, acc_ll = {0};
 	// a workgroup is a chain of dependent loads (few workgroups fit on a CU): this thread's 16 entries of C are
 	// fetched first, and the digit planes of set s + 1 while set s is multiplied.  Sets that found no pivot have
-	// all-zero planes (rref_split_M/B): they are multiplied like the others rather than tested for.
+	// all-zero planes (rref_multipliers, rref_split_B): they are multiplied like the others rather than tested for.
 	uint32_t cval[16];
 #pragma unroll
 	for (int reg = 0; reg < 16; reg++) {
@@ -1472,15 +1464,17 @@ int device_rref(int64_t prime, int n, int m, uint32_t *dA, int64_t ld, int *d_pi
 				}
 				// the columns of the super-panel, from this panel on: K = 64 update now
 				const int mr_sp = sp_end - c0;
-				hipLaunchKernelGGL(rref_gather_pivot_rows, dim3(512), dim3(256), 0, stream, dA, ld, c0, mr_sp, rho_s, knew_s, B);
 				UpdSets one{};
 				one.P[0] = P_s;
 				one.B[0] = B;
 				one.knew[0] = knew_s;
 				one.nsets = 1;
+				if (!mfma_ok)
+					hipLaunchKernelGGL(rref_gather_pivot_rows, dim3(512), dim3(256), 0, stream, dA, ld, c0, mr_sp, rho_s, knew_s, B);
 				if (mfma_ok) {
 					signed char *Bh_p = B8 + (size_t) 4 * 2 * (size_t) m * 64, *Bl_p = Bh_p + (size_t) m * 64;
-					hipLaunchKernelGGL(rref_split_B, dim3((mr_sp + 255) / 256), dim3(256), 0, stream, B, mr_sp, knew_s, Bh_p, Bl_p, F);
+					hipLaunchKernelGGL(rref_gather_split_B, dim3((mr_sp + 255) / 256), dim3(256), 0, stream, dA, ld, c0, mr_sp, rho_s, knew_s,
+					                   Bh_p, Bl_p, (uint32_t *) nullptr, F);
 					one.Mh[0] = Mh_s;
 					one.Ml[0] = Ml_s;
 					one.Bh[0] = Bh_p;
