@@ -102,6 +102,21 @@ def test_rref_tournament_panel_tall_blocks(oracle, case, p):
     _check_rref(oracle, p, M)
 
 
+@pytest.mark.parametrize("env", [{"SPASM_HIP_RREF_ONE_STREAM": "1"}, {"SPASM_HIP_RREF_MFMA": "0"}, {}])
+@pytest.mark.parametrize("shape,rank", [((700, 1500), 333), ((300, 2000), 300)])
+def test_rref_super_panels_and_streams(oracle, shape, rank, env, monkeypatch):
+    """several super-panels with a far part: one stream, two streams, VALU updates -- same echelon form."""
+    for key, val in env.items():
+        monkeypatch.setenv(key, val)
+    p = 42013
+    n, m = shape
+    rng = np.random.default_rng(n + 3 * m)
+    k = min(rank, n, m)
+    L = rng.integers(0, p, size=(n, k), dtype=np.int64).astype(object)
+    R = rng.integers(0, p, size=(k, m), dtype=np.int64).astype(object)
+    _check_rref(oracle, p, np.array((L.dot(R)) % p, dtype=np.int64))
+
+
 def test_rref_mfma_and_valu_agree(oracle, monkeypatch):
     p = 42013
     rng = np.random.default_rng(5)
