@@ -1120,6 +1120,7 @@ struct GroupArgs {
 	int64_t off_bm;
 	uint32_t *dense_out;
 	int64_t ldS;
+	int touched_lds;          // LBM only: the bits of the non-pivotal labels sit in LDS too (they fit), else in HBM
 };
 
 // LBM: the pending bitmap of the group lives in LDS (rpad / 8 bytes, dynamic) instead of HBM.
@@ -1172,7 +1173,7 @@ __global__ __launch_bounds__(64 * NW) void schur_group_kernel(GroupArgs d)
 	lds_u32 *const bm_l = (lds_u32 *) lds_dyn;
 	uint32_t *const bm_g = reinterpret_cast<uint32_t *>(slot + d.off_bm);
 	if (LBM) {
-		for (int w = threadIdx.x; w < nw; w += 64 * NW)
+		for (int w = threadIdx.x; w < nw + (d.touched_lds ? (Sm + 31) / 32 : 0); w += 64 * NW)
 			bm_l[w] = 0;
 		wg_sync();
 	}
@@ -1190,10 +1191,21 @@ __global__ __launch_bounds__(64 * NW) void schur_group_kernel(GroupArgs d)
 			(void) __hip_atomic_fetch_and(&bm_g[w], ~bits, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
 	};
 	auto act_load = [&](int t) -> uint32_t { return *(volatile lds_u32 *) (act_l + t); };
-	// non-pivotal labels (>= r) that received something: bits r.. of the bitmap in HBM, whatever LBM says; the
-	// output only visits those lines
+	// non-pivotal labels (>= r) that received something: bits r.. of the same bitmap; the output only visits
+	// those lines
+	const bool tl = LBM && d.touched_lds != 0;
 	auto touch = [&](uint32_t c) {
-		(void) __hip_atomic_fetch_or(&bm_g[c >> 5], 1u << (c & 31), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+		if (tl)
+			(void) __hip_atomic_fetch_or(bm_l + (c >> 5), 1u << (c & 31), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+		else
+			(void) __hip_atomic_fetch_or(&bm_g[c >> 5], 1u << (c & 31), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+	};
+	auto touched_load = [&](int w) -> uint32_t { return tl ? *(volatile lds_u32 *) (bm_l + nw + w) : ld_sc1(&bm_g[nw + w]); };
+	auto touched_clear = [&](int w) {
+		if (tl)
+			bm_l[nw + w] = 0;
+		else
+			bm_g[nw + w] = 0;
 	};
 	const int nwS = (Sm + 31) / 32;
 
@@ -1579,7 +1591,7 @@ __global__ __launch_bounds__(64 * NW) void schur_group_kernel(GroupArgs d)
 					bm_g[w] = 0;
 			}
 			for (int w = threadIdx.x; w < nwS; w += 64 * NW)
-				bm_g[nw + w] = 0;
+				touched_clear(w);
 			drain_vmem();
 			break;
 		}
@@ -1604,7 +1616,7 @@ __global__ __launch_bounds__(64 * NW) void schur_group_kernel(GroupArgs d)
 				}
 			}
 			for (int w = threadIdx.x; w < nwS; w += 64 * NW)
-				bm_g[nw + w] = 0;
+				touched_clear(w);
 			if (have_row && wv == 0)
 				a.row_len[k] = Sm;
 			if (wv == 0)
@@ -1620,7 +1632,7 @@ __global__ __launch_bounds__(64 * NW) void schur_group_kernel(GroupArgs d)
 			const int w = wb + (lane >> 2);
 			uint32_t bits = 0;
 			if (w < nwS)
-				bits = ld_sc1(&bm_g[nw + w]) & (0xFFu << ((lane & 3) * 8));
+				bits = touched_load(w) & (0xFFu << ((lane & 3) * 8));
 			int tot;
 			int pos = wave_exclusive_scan_small(__popc(bits), tot);
 			uint32_t b = bits;
@@ -1688,7 +1700,7 @@ __global__ __launch_bounds__(64 * NW) void schur_group_kernel(GroupArgs d)
 		for (int wb = wb_lo; wb < wb_hi; wb += CW) {
 			const int tot = list_touched(wb);
 			if ((lane & 3) == 0 && wb + (lane >> 2) < nwS)
-				bm_g[nw + wb + (lane >> 2)] = 0;
+				touched_clear(wb + (lane >> 2));
 			for (int b0 = 0; b0 < tot; b0 += OB) {
 				V rv[OB];
 				uint32_t tt[OB];
@@ -1783,8 +1795,12 @@ void launch_schur_group(const SchurArgs &a, unsigned char *scratch, int64_t slot
 	d.off_bm = off_bm;
 	d.dense_out = dense_out;
 	d.ldS = ldS;
-	const size_t bm_bytes = ((size_t) a.r / 32 + 1) * 4;
-	const bool lbm = bm_bytes <= (size_t) GR_LBM_MAX_BYTES;
+	// pending bitmap of the pivotal labels in LDS when it fits; the bits of the non-pivotal labels too when both do
+	const size_t piv_bytes = ((size_t) a.r / 32 + 1) * 4;
+	const size_t all_bytes = (((size_t) a.r + (size_t) a.Sm) / 32 + 2) * 4;
+	const bool lbm = piv_bytes <= (size_t) GR_LBM_MAX_BYTES;
+	d.touched_lds = (lbm && all_bytes <= (size_t) GR_LBM_MAX_BYTES && getenv("SPASM_HIP_GROUP_TOUCHED_HBM") == nullptr) ? 1 : 0;     // (the knob: tests)
+	const size_t bm_bytes = d.touched_lds ? all_bytes : piv_bytes;
 	const int nwv = waves >= 4 ? 4 : waves >= 2 ? 2 : 1;
 #define SPASM_LAUNCH_GROUP(WIDE_, LBM_, LDS_)                                                    \
 	do {                                                                                        \

@@ -146,13 +146,17 @@ def test_schur_row_group_kernel(oracle, name, p, monkeypatch):
     _check(oracle, S, p_out, want, p_out_want)
 
 
+@pytest.mark.parametrize("touched_hbm", [False, True])
 @pytest.mark.parametrize("waves", ["1", "2", "4"])
 @pytest.mark.parametrize("name", ["mat364.sms", "trefethen_500.sms", "BIOMD0000000424.int.mpl.sms"])
 @pytest.mark.parametrize("p", [257, 42013, 4294967291])
-def test_schur_row_group_kernel_waves_per_group(oracle, name, p, waves, monkeypatch):
-    """every waves-per-group variant of the row-group kernel (32- and 64-bit sums) gives the same matrix."""
+def test_schur_row_group_kernel_waves_per_group(oracle, name, p, waves, touched_hbm, monkeypatch):
+    """every waves-per-group variant of the row-group kernel (32- and 64-bit sums; bits of the touched non-pivotal
+    labels in LDS or in HBM) gives the same matrix."""
     monkeypatch.setenv("SPASM_HIP_GROUP", "1")
     monkeypatch.setenv("SPASM_HIP_GROUP_WAVES", waves)
+    if touched_hbm:
+        monkeypatch.setenv("SPASM_HIP_GROUP_TOUCHED_HBM", "1")
     A, npiv, perm, F = _round0(oracle, name, p)
     rows = perm[npiv:]
     want, p_out_want, _ = oracle.schur(A, rows, F)
