@@ -60,5 +60,18 @@ while time.time() < t_end:
     if r != r0 or not np.array_equal(np.asarray(q)[:r], np.asarray(q0)[:r]) or not np.array_equal(np.asarray(Rm)[:r], np.asarray(R0)[:r]):
         fails += 1
         print("MISMATCH rref %dx%d rank %d p=%d (got rank %d)" % (dn, dm, r0, p, r), flush=True)
+    # ---- the whole driver on a random sparse matrix: rank against the oracle's driver
+    if cases % 7 == 0:
+        en, em, eper = int(rng.integers(50, 1500)), int(rng.integers(50, 1500)), int(rng.integers(1, 6))
+        ti = np.repeat(np.arange(en, dtype=np.int32), eper)
+        tj = rng.integers(0, em, size=en * eper).astype(np.int32)
+        tx = rng.integers(1, p, size=en * eper).astype(np.int64)
+        E = orc.compress(p, en, em, ti, tj, tx)
+        want_rank = orc.echelonize(E).U.n
+        got = spasm_amd.echelonize(as_product(E)).U.n
+        cases += 1
+        if got != want_rank:
+            fails += 1
+            print("MISMATCH echelonize %dx%d per_row=%d p=%d: rank %d, oracle %d" % (en, em, eper, p, got, want_rank), flush=True)
 print("stress: %d cases, %d mismatches" % (cases, fails))
 sys.exit(1 if fails else 0)
