@@ -35,6 +35,8 @@ enum Ctr {
 	CTR_DONE0, CTR_DONE1, CTR_DONE2,   // rows finished per tier
 	CTR_GROUP_ABORT,       // row-group kernel gave up (poor lane efficiency)
 	CTR_GROUPS_DONE,
+	CTR_GROUP_ABORT2,      // second attempt of the row-group kernel (rows regrouped by their first pivot) gave up too
+	CTR_ROW_NEXT_G2,       // ... its queue of groups
 	CTR_COUNT = 16
 };
 
@@ -45,6 +47,8 @@ enum Ctr64 {
 	C64_INPUT,             // entries of input rows
 	C64_WAVEPIV,           // row-group kernel: pivots applied per group (wave-level count)
 	C64_LPOOL,             // cursor of the L pool
+	C64_ELIM2,             // progress of the second attempt of the row-group kernel, for its own verdict
+	C64_WAVEPIV2,
 	C64_PROF0 = 8,         // -DSPASM_GROUP_PROFILE builds: cycles per phase of the row-group kernel (8 slots)
 	C64_COUNT = 16
 };
@@ -84,6 +88,9 @@ struct SchurArgs {
 	int ovf_ctr;              // which CTR_OVF* receives overflowing rows
 	int done_ctr;
 	int skip_done;            // tier 0 only: leave rows alone whose row_len is no longer -1
+	int skip_ctr;             // ... and do nothing at all unless ctr[skip_ctr] says the row-group kernel gave up
+	const uint32_t *comp;     // label -> component of the pivot graph (rows of different components share nothing)
+	const int *order;         // row-group kernel: list positions in processing order (null: 0, 1, 2, ...)
 	// optional record of the elimination coefficients (the L factor): triplets (row, pivot index, value)
 	int *L_i;                 // null: not recorded.  Pool pre-filled with -1; unused slots stay -1
 	int *L_j;
@@ -115,6 +122,7 @@ struct spasm_hip_dfact {
 	uint64_t *d_rp = nullptr;
 	uint2 *d_ent = nullptr;
 	uint2 *d_head = nullptr;
+	uint32_t *d_comp = nullptr;     // label -> smallest label of its connected component in the pivot graph
 	uint32_t *d_lvl_end = nullptr;
 	uint32_t *d_lvl_end_w = nullptr;
 	int *d_kof = nullptr;          // label -> row of U (-1: padding label)
@@ -133,6 +141,8 @@ struct spasm_hip_dwork {
 	unsigned long long *d_ctr64 = nullptr;
 	int64_t *d_Sp = nullptr;
 	int64_t *d_blocksum = nullptr;
+	int *d_order = nullptr, *d_sortbuf = nullptr;   // rows regrouped by first pivot label (second attempt of the row-group kernel)
+	int64_t sortbuf_ints = 0;
 	int *d_Sj = nullptr, *d_Sx = nullptr;
 	unsigned char *d_scratch = nullptr;   // per-wave dense accumulators (all zero between calls)
 	int64_t scratch_bytes = 0;

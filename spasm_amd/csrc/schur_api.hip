@@ -11,9 +11,11 @@ size_t schur_lds_bytes(int table, bool wide);
 void launch_finalize(const spasm_hip_dwork *W, int nrows, int sort_rows, hipStream_t stream);
 void wave_dense_geometry(int rpad, int Sm, bool wide, int64_t *slot_bytes, int64_t *off_bm, int64_t *off_xn);
 void group_geometry(int rpad, int Sm, bool wide, int64_t *slot_bytes, int64_t *off_bm);
+int64_t regroup_scratch_ints(int nrows, int r);
+void launch_regroup_rows(const SchurArgs &a, int *sortbuf, int *order, hipStream_t stream);
 void launch_schur_group(const SchurArgs &a, unsigned char *scratch, int64_t slot_bytes, int64_t off_bm, bool wide,
                         uint32_t *dense_out, int64_t ldS, int blocks, hipStream_t stream, int watch, float min_eff,
-                        long long min_w, int waves);
+                        long long min_w, int waves, int attempt);
 void launch_schur_wave_dense(const SchurArgs &a, unsigned char *scratch, int64_t slot_bytes, int64_t off_bm, int64_t off_xn,
                              bool wide, uint32_t *dense_out, int64_t ldS, int blocks, hipStream_t stream);
 void launch_all_rows_to_list(int *list, int *count, int *row_len, int nrows, hipStream_t stream);
@@ -162,6 +164,7 @@ struct FactPlan {
 	std::vector<uint64_t> rp;               // rpad + 1
 	std::vector<uint2> ent;
 	std::vector<uint2> head;                // 4 entries per label: the first entries of the row, 0xFFFFFFFF-padded
+	std::vector<uint32_t> comp;             // per label: smallest label of its connected component in the pivot graph
 };
 
 static void plan_factor(const struct spasm_csr *U, const int *qinv, FactPlan &P)
@@ -343,6 +346,31 @@ static void plan_factor(const struct spasm_csr *U, const int *qinv, FactPlan &P)
 		for (uint64_t t = 0; t < len && t < 4; t++)
 			P.head[(size_t) c * 4 + t] = P.ent[P.rp[c] + t];
 	}
+	// connected components of the pivot graph (row c -- the pivots it touches): rows of the matrix whose pivotal
+	// entries lie in different components share no elimination at all; the row-group kernel regroups rows by
+	// component when the order of the row list turns out to be unrelated to the structure
+	P.comp.assign((size_t) (rpad > 0 ? rpad : 1), 0);
+	{
+		std::vector<uint32_t> parent((size_t) (rpad > 0 ? rpad : 1));
+		for (int c = 0; c < rpad; c++)
+			parent[c] = (uint32_t) c;
+		auto find = [&](uint32_t x) {
+			while (parent[x] != x) {
+				parent[x] = parent[parent[x]];
+				x = parent[x];
+			}
+			return x;
+		};
+		for (int c = 0; c < rpad; c++)
+			for (uint64_t e = P.rp[c]; e < P.rp[c + 1]; e++)
+				if (P.ent[e].x < (uint32_t) rpad) {
+					const uint32_t a = find((uint32_t) c), b = find(P.ent[e].x);
+					if (a != b)
+						parent[std::max(a, b)] = std::min(a, b);          // the root is the smallest label
+				}
+		for (int c = 0; c < rpad; c++)
+			P.comp[c] = find((uint32_t) c);
+	}
 }
 
 // CPU-only view of the plan, for tests: label of each row of U, end of the
@@ -391,6 +419,8 @@ spasm_hip_dfact *spasm_hip_dfact_create(const struct spasm_csr *U, const int *qi
 	F->d_ent = dalloc<uint2>(F->nnz);
 	F->d_head = dalloc<uint2>((i64) rpad * 4);
 	upload(F->d_head, P.head.data(), (i64) rpad * 4, stream);
+	F->d_comp = dalloc<uint32_t>(rpad);
+	upload(F->d_comp, P.comp.data(), (i64) rpad, stream);
 	F->d_lvl_end = dalloc<uint32_t>(rpad);
 	F->d_lvl_end_w = dalloc<uint32_t>(rpad / 32);
 	F->d_kof = dalloc<int>(rpad);
@@ -414,6 +444,7 @@ void spasm_hip_dfact_destroy(spasm_hip_dfact *F)
 	(void) hipFree(F->d_rp);
 	(void) hipFree(F->d_ent);
 	(void) hipFree(F->d_head);
+	(void) hipFree(F->d_comp);
 	(void) hipFree(F->d_lvl_end);
 	(void) hipFree(F->d_lvl_end_w);
 	(void) hipFree(F->d_kof);
@@ -464,6 +495,10 @@ void spasm_hip_dwork_destroy(spasm_hip_dwork *W)
 	(void) hipFree(W->d_ovf2);
 	(void) hipFree(W->d_Sp);
 	(void) hipFree(W->d_blocksum);
+	if (W->d_order != nullptr)
+		(void) hipFree(W->d_order);
+	if (W->d_sortbuf != nullptr)
+		(void) hipFree(W->d_sortbuf);
 	(void) hipFree(W->d_ctr);
 	(void) hipFree(W->d_ctr64);
 	(void) hipFree(W->d_scratch);
@@ -575,6 +610,7 @@ int dschur_impl(const spasm_hip_dcsr *A, const int *d_rows, int nrows, const spa
 	a.rp = F->d_rp;
 	a.ent = F->d_ent;
 	a.head = F->d_head;
+	a.comp = F->d_comp;
 	a.lvl_end = F->d_lvl_end;
 	a.lvl_end_w = F->d_lvl_end_w;
 	a.r = F->rpad;              // kernels only see the padded label space
@@ -621,7 +657,29 @@ int dschur_impl(const spasm_hip_dcsr *A, const int *d_rows, int nrows, const spa
 			const float min_eff = (float) env_int("SPASM_HIP_GROUP_MIN_EFF_PCT", 4) / 100.0f;
 			const long long min_w = env_int("SPASM_HIP_GROUP_MIN_PIVOTS", 500000);
 			launch_schur_group(a, W->d_scratch, group_slot_bytes, group_off_bm, wide_dense, nullptr, 0, group_slots, stream,
-			                   probe ? 1 : 0, min_eff, min_w, group_waves);
+			                   probe ? 1 : 0, min_eff, min_w, group_waves, 0);
+			a.skip_ctr = CTR_GROUP_ABORT;
+			if (probe && env_int("SPASM_HIP_GROUP_RETRY", 1)) {
+				// second attempt, on the device's own verdict: when the kernel gave up (neighbours in the list that
+				// share nothing), the rows are regrouped by their first pivot and it tries once more before the
+				// batch goes to the per-row kernels.  Everything below returns at once when it did not give up.
+				const int64_t need = regroup_scratch_ints(nrows, F->rpad);
+				if (W->sortbuf_ints < need) {
+					if (W->d_sortbuf != nullptr)
+						(void) hipFree(W->d_sortbuf);
+					W->d_sortbuf = dalloc<int>(need);
+					W->sortbuf_ints = need;
+				}
+				if (W->d_order == nullptr)
+					W->d_order = dalloc<int>(W->max_rows);
+				launch_regroup_rows(a, W->d_sortbuf, W->d_order, stream);
+				a.order = W->d_order;
+				a.next_ctr = CTR_ROW_NEXT_G2;
+				launch_schur_group(a, W->d_scratch, group_slot_bytes, group_off_bm, wide_dense, nullptr, 0, group_slots, stream,
+				                   1, min_eff, min_w, group_waves, 1);
+				a.order = nullptr;
+				a.skip_ctr = CTR_GROUP_ABORT2;
+			}
 			HIP_CHECK(hipEventRecord(W->ev[5], stream));
 			if (!probe) {
 				HIP_CHECK(hipEventRecord(W->ev[3], stream));

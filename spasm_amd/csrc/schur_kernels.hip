@@ -186,7 +186,7 @@ __global__ __launch_bounds__(64) void schur_lds_kernel(SchurArgs a)
 	const int lane = threadIdx.x;
 	const uint32_t r = (uint32_t) a.r;
 	const MontDev F = a.F;
-	if (a.skip_done && a.ctr[CTR_GROUP_ABORT] == 0)
+	if (a.skip_done && a.ctr[a.skip_ctr] == 0)
 		return;                     // the row-group kernel finished the batch: nothing left for the per-row tiers
 	const int total_rows = (a.list != nullptr) ? *a.list_count : a.nrows;
 
@@ -860,7 +860,7 @@ __global__ __launch_bounds__(64) void schur_wave_dense_kernel(WaveDenseArgs d)
 	const uint32_t r = (uint32_t) a.r;
 	const int Sm = a.Sm;
 	const MontDev F = a.F;
-	if (a.skip_done && a.ctr[CTR_GROUP_ABORT] == 0)
+	if (a.skip_done && a.ctr[a.skip_ctr] == 0)
 		return;
 	const int total_rows = (a.list != nullptr) ? *a.list_count : a.nrows;
 
@@ -1091,6 +1091,74 @@ void launch_schur_wave_dense(const SchurArgs &a, unsigned char *scratch, int64_t
 }  // namespace sh
 
 // --------------------------------------------------------------------------
+// Regrouping for the second attempt of the row-group kernel: rows that are neighbours in the list but unrelated
+// in structure waste its lanes.  A counting sort by the connected component (of the pivot graph) a row's pivotal
+// entries fall in puts rows that can share eliminations next to each other; rows that are
+// have nothing to eliminate go last, rows that are already done are not listed (order[] ends with -1s).
+// keys / order: nrows ints; hist, cursor: r + 2 ints.
+// --------------------------------------------------------------------------
+namespace sh {
+
+__global__ __launch_bounds__(256) void row_first_pivot_kernel(SchurArgs a, int *keys, int *hist)
+{
+	const int k = blockIdx.x * 256 + threadIdx.x;
+	if (k >= a.nrows || a.ctr[CTR_GROUP_ABORT] == 0)
+		return;
+	if (a.row_len[k] != -1) {
+		keys[k] = -1;                             // done: not listed
+		return;
+	}
+	uint32_t key = (uint32_t) a.r;                // nothing pivotal
+	const int i = a.rows[k];
+	for (int64_t px = a.Ap[i]; px < a.Ap[i + 1]; px++) {
+		const uint32_t c = a.lab[a.Aj[px]];
+		if (c < (uint32_t) a.r) {
+			const uint32_t comp = a.comp[c];
+			key = (comp < key) ? comp : key;
+		}
+	}
+	keys[k] = (int) key;
+	atomicAdd(&hist[key], 1);
+}
+
+__global__ __launch_bounds__(256) void row_regroup_kernel(int nrows, const int *keys, const int64_t *offsets, int *cursor, int *order,
+                                                          const int *ctr)
+{
+	const int k = blockIdx.x * 256 + threadIdx.x;
+	if (k >= nrows || ctr[CTR_GROUP_ABORT] == 0)
+		return;
+	const int key = keys[k];
+	if (key >= 0)
+		order[offsets[key] + atomicAdd(&cursor[key], 1)] = k;
+}
+
+// sortbuf: keys[nrows] | hist[r + 2] | cursor[r + 2] (ints, zeroed here), then offsets[r + 3] and block sums (int64)
+int64_t regroup_scratch_ints(int nrows, int r)
+{
+	const int64_t bins = (int64_t) r + 2;
+	return nrows + 2 * bins + 2 * (bins + 2) + 2 * ((bins + 1023) / 1024 + 2) + 8;
+}
+
+void launch_regroup_rows(const SchurArgs &a, int *sortbuf, int *order, hipStream_t stream)
+{
+	const int bins = a.r + 2;
+	int *keys = sortbuf, *hist = keys + a.nrows, *cursor = hist + bins;
+	int64_t *offsets = reinterpret_cast<int64_t *>(((uintptr_t) (cursor + bins) + 7) & ~(uintptr_t) 7);
+	int64_t *blocksum = offsets + bins + 2;
+	HIP_CHECK(hipMemsetAsync(hist, 0, (size_t) 2 * bins * sizeof(int), stream));
+	hipLaunchKernelGGL(row_first_pivot_kernel, dim3((a.nrows + 255) / 256), dim3(256), 0, stream, a, keys, hist);
+	const int nblocks = (bins + 1023) / 1024;
+	hipLaunchKernelGGL(scan_block_sums, dim3(nblocks), dim3(256), 0, stream, hist, bins, blocksum);
+	hipLaunchKernelGGL(scan_of_sums, dim3(1), dim3(256), 0, stream, blocksum, nblocks);
+	hipLaunchKernelGGL(scan_finish, dim3(nblocks), dim3(256), 0, stream, hist, bins, blocksum, offsets);
+	HIP_CHECK(hipMemsetAsync(order, 0xFF, (size_t) a.nrows * sizeof(int), stream));          // -1: no row
+	hipLaunchKernelGGL(row_regroup_kernel, dim3((a.nrows + 255) / 256), dim3(256), 0, stream, a.nrows, keys, offsets, cursor, order, a.ctr);
+	HIP_CHECK(hipGetLastError());
+}
+
+}  // namespace sh
+
+// --------------------------------------------------------------------------
 // K2g: "row-group" kernel.  A wave owns 64 CONSECUTIVE rows of the row list,
 // lane = row.  The accumulators of the group are stored label-major:
 // X[label][64] (one 256-byte line per label), so that eliminating pivot c in
@@ -1120,6 +1188,7 @@ struct GroupArgs {
 	int64_t off_bm;
 	uint32_t *dense_out;
 	int64_t ldS;
+	int attempt;              // 1: second attempt (rows regrouped): runs only if the first one gave up, skips finished rows
 	int touched_lds;          // LBM only: the bits of the non-pivotal labels sit in LDS too (they fit), else in HBM
 };
 
@@ -1146,6 +1215,11 @@ __global__ __launch_bounds__(64 * NW) void schur_group_kernel(GroupArgs d)
 	const SchurArgs &a = d.a;
 	const int lane = threadIdx.x & 63;
 	const int wv = threadIdx.x >> 6;
+	// which give-up flag and progress counters this launch answers to
+	const int abort_ctr = d.attempt ? CTR_GROUP_ABORT2 : CTR_GROUP_ABORT;
+	const int elim64 = d.attempt ? C64_ELIM2 : C64_ELIM, wavepiv64 = d.attempt ? C64_WAVEPIV2 : C64_WAVEPIV;
+	if (d.attempt && a.ctr[CTR_GROUP_ABORT] == 0)
+		return;                     // the first attempt finished the batch
 	// workgroup barrier that waits for the LDS queue only (__syncthreads would drain the atomics in flight too)
 	auto wg_sync = [&]() {
 		if (NW > 1)
@@ -1220,14 +1294,19 @@ __global__ __launch_bounds__(64 * NW) void schur_group_kernel(GroupArgs d)
 	for (;;) {
 		if (threadIdx.x == 0) {
 			ctl_l[0] = atomicAdd(&a.ctr[a.next_ctr], 1);
-			ctl_l[1] = d.watch ? __hip_atomic_load(&a.ctr[CTR_GROUP_ABORT], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0;
+			ctl_l[1] = d.watch ? __hip_atomic_load(&a.ctr[abort_ctr], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0;
 		}
 		wg_sync();
 		const int g = __builtin_amdgcn_readfirstlane(ctl_l[0]);
 		if (g >= ngroups || __builtin_amdgcn_readfirstlane(ctl_l[1]) != 0)
 			break;
-		const int k = g * 64 + lane;
-		const bool have_row = k < a.nrows;
+		const int kpos = g * 64 + lane;
+		bool have_row = kpos < a.nrows;
+		int k = have_row ? (a.order != nullptr ? a.order[kpos] : kpos) : 0;       // position in the row list
+		if (k < 0) {                    // (the regrouped list only holds the rows the first attempt left)
+			have_row = false;
+			k = 0;
+		}
 		const int row_to_record = (a.L_i != nullptr && have_row) ? a.row_orig[k] : 0;
 
 		// ---- scatter the 64 input rows (each lane its own) ----
@@ -1272,11 +1351,15 @@ __global__ __launch_bounds__(64 * NW) void schur_group_kernel(GroupArgs d)
 				// running groups contribute in proportion to their work, so the ratio is not biased towards the
 				// cheap groups that finish first
 				if (lane == 0) {
-					const unsigned long long e = atomicAdd(&a.ctr64[C64_ELIM], st_elim) + st_elim;
-					const unsigned long long w = atomicAdd(&a.ctr64[C64_WAVEPIV], st_wavepiv) + st_wavepiv;
+					const unsigned long long e = atomicAdd(&a.ctr64[elim64], st_elim) + st_elim;
+					const unsigned long long w = atomicAdd(&a.ctr64[wavepiv64], st_wavepiv) + st_wavepiv;
 					atomicAdd(&a.ctr64[C64_STREAM], st_stream);
+					if (d.attempt) {          // (the statistics of the call count both attempts)
+						atomicAdd(&a.ctr64[C64_ELIM], st_elim);
+						atomicAdd(&a.ctr64[C64_WAVEPIV], st_wavepiv);
+					}
 					if (w > d.min_w && (double) e < (double) d.min_eff * 64.0 * (double) w)
-						atomicOr(&a.ctr[CTR_GROUP_ABORT], 1);
+						atomicOr(&a.ctr[abort_ctr], 1);
 				}
 				st_elim = 0;
 				st_wavepiv = 0;
@@ -1290,7 +1373,7 @@ __global__ __launch_bounds__(64 * NW) void schur_group_kernel(GroupArgs d)
 						// (a global load per round would add its latency to the chain of the group)
 						int stop = 0;
 						if (lane == 0 && (published || (round & 15) == 0))
-							stop = __hip_atomic_load(&a.ctr[CTR_GROUP_ABORT], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+							stop = __hip_atomic_load(&a.ctr[abort_ctr], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 						round += 1;
 						if (__builtin_amdgcn_readfirstlane(stop) != 0)
 							status = 2;
@@ -1581,9 +1664,27 @@ __global__ __launch_bounds__(64 * NW) void schur_group_kernel(GroupArgs d)
 		if (abandoned) {
 			// the batch went to the per-row kernels: restore the all-zero state of this slice and leave
 			// (rows keep row_len == -1)
-			const int64_t lines = (int64_t) r + Sm;
-			for (int64_t c = wv; c < lines; c += NW)
-				X[c * 64 + lane] = 0;
+			// Only lines whose bit is set can be non-zero: a line is marked when it is written, and a pending pivot
+			// whose bit was cleared has been consumed (and zeroed) within the same round -- rounds are never cut short.
+			const int nwt = nw + nwS;
+			for (int wb0 = wv * 64; wb0 < nwt; wb0 += 64 * NW) {
+				const int w = wb0 + lane;
+				const uint32_t bits = (w < nwt) ? (w < nw ? bm_load(w) : touched_load(w - nw)) : 0u;
+				unsigned long long holders = __ballot(bits != 0);
+				while (holders != 0) {
+					const int l = __builtin_ctzll(holders);
+					holders &= holders - 1;
+					uint32_t b = (uint32_t) __shfl((int) bits, l);
+					const int wq = wb0 + l;
+					const int64_t first = (wq < nw) ? (int64_t) wq * 32 : (int64_t) r + (int64_t) (wq - nw) * 32;
+					while (b != 0) {
+						const int bit = __builtin_ctz(b);
+						b &= b - 1;
+						X[(first + bit) * 64 + lane] = 0;
+					}
+				}
+			}
+			wg_sync();
 			for (int w = threadIdx.x; w < nw; w += 64 * NW) {
 				if (LBM)
 					bm_l[w] = 0;
@@ -1783,10 +1884,11 @@ static void launch_group_variant(const GroupArgs &d, int blocks, size_t lds_byte
 // waves: 1, 2 or 4 waves per row group (more when groups are few: the chain of a group is then the run time)
 void launch_schur_group(const SchurArgs &a, unsigned char *scratch, int64_t slot_bytes, int64_t off_bm, bool wide,
                         uint32_t *dense_out, int64_t ldS, int blocks, hipStream_t stream, int watch, float min_eff,
-                        long long min_w, int waves)
+                        long long min_w, int waves, int attempt)
 {
 	GroupArgs d;
 	d.a = a;
+	d.attempt = attempt;
 	d.watch = watch;
 	d.min_eff = min_eff;
 	d.min_w = (unsigned long long) min_w;
