@@ -659,10 +659,17 @@ int dschur_impl(const spasm_hip_dcsr *A, const int *d_rows, int nrows, const spa
 			launch_schur_group(a, W->d_scratch, group_slot_bytes, group_off_bm, wide_dense, nullptr, 0, group_slots, stream,
 			                   probe ? 1 : 0, min_eff, min_w, group_waves, 0);
 			a.skip_ctr = CTR_GROUP_ABORT;
-			if (probe && env_int("SPASM_HIP_GROUP_RETRY", 1)) {
-				// second attempt, on the device's own verdict: when the kernel gave up (neighbours in the list that
-				// share nothing), the rows are regrouped by their first pivot and it tries once more before the
-				// batch goes to the per-row kernels.  Everything below returns at once when it did not give up.
+			// did it give up?  (one small read-back: the call blocks at its end anyway, and nothing is launched
+			// for nothing -- the kernels below also check the flags themselves)
+			int gave_up = 0;
+			if (probe) {
+				HIP_CHECK(hipMemcpyAsync(&gave_up, W->d_ctr + CTR_GROUP_ABORT, sizeof(int), hipMemcpyDeviceToHost, stream));
+				HIP_CHECK(hipStreamSynchronize(stream));
+			}
+			if (probe && gave_up && env_int("SPASM_HIP_GROUP_RETRY", 1)) {
+				// second attempt: the neighbours in the list share nothing; the rows are regrouped by connected
+				// component of the pivot graph and the kernel tries once more before the batch goes to the
+				// per-row kernels.
 				const int64_t need = regroup_scratch_ints(nrows, F->rpad);
 				if (W->sortbuf_ints < need) {
 					if (W->d_sortbuf != nullptr)
@@ -679,9 +686,11 @@ int dschur_impl(const spasm_hip_dcsr *A, const int *d_rows, int nrows, const spa
 				                   1, min_eff, min_w, group_waves, 1);
 				a.order = nullptr;
 				a.skip_ctr = CTR_GROUP_ABORT2;
+				HIP_CHECK(hipMemcpyAsync(&gave_up, W->d_ctr + CTR_GROUP_ABORT2, sizeof(int), hipMemcpyDeviceToHost, stream));
+				HIP_CHECK(hipStreamSynchronize(stream));
 			}
 			HIP_CHECK(hipEventRecord(W->ev[5], stream));
-			if (!probe) {
+			if (!probe || !gave_up) {
 				HIP_CHECK(hipEventRecord(W->ev[3], stream));
 				HIP_CHECK(hipEventRecord(W->ev[4], stream));
 				goto eliminated;
