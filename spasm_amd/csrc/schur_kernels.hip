@@ -1092,67 +1092,77 @@ void launch_schur_wave_dense(const SchurArgs &a, unsigned char *scratch, int64_t
 
 // --------------------------------------------------------------------------
 // Regrouping for the second attempt of the row-group kernel: rows that are neighbours in the list but unrelated
-// in structure waste its lanes.  A counting sort by the connected component (of the pivot graph) a row's pivotal
-// entries fall in puts rows that can share eliminations next to each other; rows that are
-// have nothing to eliminate go last, rows that are already done are not listed (order[] ends with -1s).
-// keys / order: nrows ints; hist, cursor: r + 2 ints.
+// in structure waste its lanes.  The rows the first attempt left are sorted by (connected component of the pivot
+// graph their pivotal entries fall in, position in the list): rows that can share eliminations come together, and
+// inside a component the order of the list -- often meaningful -- is kept.  Rows with nothing to eliminate go last,
+// rows that are done are not listed (order[] ends with -1s).  A bitonic sort of 64-bit keys in HBM: a rare path.
 // --------------------------------------------------------------------------
 namespace sh {
 
-__global__ __launch_bounds__(256) void row_first_pivot_kernel(SchurArgs a, int *keys, int *hist)
+__global__ __launch_bounds__(256) void row_component_key_kernel(SchurArgs a, unsigned long long *keys, int npad)
 {
 	const int k = blockIdx.x * 256 + threadIdx.x;
-	if (k >= a.nrows || a.ctr[CTR_GROUP_ABORT] == 0)
+	if (k >= npad)
 		return;
-	if (a.row_len[k] != -1) {
-		keys[k] = -1;                             // done: not listed
-		return;
-	}
-	uint32_t key = (uint32_t) a.r;                // nothing pivotal
-	const int i = a.rows[k];
-	for (int64_t px = a.Ap[i]; px < a.Ap[i + 1]; px++) {
-		const uint32_t c = a.lab[a.Aj[px]];
-		if (c < (uint32_t) a.r) {
-			const uint32_t comp = a.comp[c];
-			key = (comp < key) ? comp : key;
+	unsigned long long key = ~0ull;                   // padding, and rows that are done
+	if (k < a.nrows && a.row_len[k] == -1) {
+		uint32_t comp = (uint32_t) a.r;               // nothing pivotal
+		const int i = a.rows[k];
+		for (int64_t px = a.Ap[i]; px < a.Ap[i + 1]; px++) {
+			const uint32_t c = a.lab[a.Aj[px]];
+			if (c < (uint32_t) a.r) {
+				const uint32_t cc = a.comp[c];
+				comp = (cc < comp) ? cc : comp;
+			}
 		}
+		key = ((unsigned long long) comp << 32) | (unsigned int) k;
 	}
-	keys[k] = (int) key;
-	atomicAdd(&hist[key], 1);
+	keys[k] = key;
 }
 
-__global__ __launch_bounds__(256) void row_regroup_kernel(int nrows, const int *keys, const int64_t *offsets, int *cursor, int *order,
-                                                          const int *ctr)
+__global__ __launch_bounds__(256) void bitonic_step_kernel(unsigned long long *keys, int npad, int size, int stride)
 {
-	const int k = blockIdx.x * 256 + threadIdx.x;
-	if (k >= nrows || ctr[CTR_GROUP_ABORT] == 0)
+	const int t = blockIdx.x * 256 + threadIdx.x;
+	const int partner = t ^ stride;
+	if (t >= npad || partner <= t)
 		return;
-	const int key = keys[k];
-	if (key >= 0)
-		order[offsets[key] + atomicAdd(&cursor[key], 1)] = k;
+	const unsigned long long x = keys[t], y = keys[partner];
+	const bool ascending = (t & size) == 0;
+	if ((x > y) == ascending) {
+		keys[t] = y;
+		keys[partner] = x;
+	}
 }
 
-// sortbuf: keys[nrows] | hist[r + 2] | cursor[r + 2] (ints, zeroed here), then offsets[r + 3] and block sums (int64)
+__global__ __launch_bounds__(256) void row_order_kernel(const unsigned long long *keys, int nrows, int *order)
+{
+	const int t = blockIdx.x * 256 + threadIdx.x;
+	if (t < nrows)
+		order[t] = (keys[t] == ~0ull) ? -1 : (int) (unsigned int) keys[t];
+}
+
+// sortbuf: 64-bit keys, padded to a power of two
 int64_t regroup_scratch_ints(int nrows, int r)
 {
-	const int64_t bins = (int64_t) r + 2;
-	return nrows + 2 * bins + 2 * (bins + 2) + 2 * ((bins + 1023) / 1024 + 2) + 8;
+	(void) r;
+	int64_t npad = 1;
+	while (npad < nrows)
+		npad <<= 1;
+	return 2 * npad + 8;
 }
 
 void launch_regroup_rows(const SchurArgs &a, int *sortbuf, int *order, hipStream_t stream)
 {
-	const int bins = a.r + 2;
-	int *keys = sortbuf, *hist = keys + a.nrows, *cursor = hist + bins;
-	int64_t *offsets = reinterpret_cast<int64_t *>(((uintptr_t) (cursor + bins) + 7) & ~(uintptr_t) 7);
-	int64_t *blocksum = offsets + bins + 2;
-	HIP_CHECK(hipMemsetAsync(hist, 0, (size_t) 2 * bins * sizeof(int), stream));
-	hipLaunchKernelGGL(row_first_pivot_kernel, dim3((a.nrows + 255) / 256), dim3(256), 0, stream, a, keys, hist);
-	const int nblocks = (bins + 1023) / 1024;
-	hipLaunchKernelGGL(scan_block_sums, dim3(nblocks), dim3(256), 0, stream, hist, bins, blocksum);
-	hipLaunchKernelGGL(scan_of_sums, dim3(1), dim3(256), 0, stream, blocksum, nblocks);
-	hipLaunchKernelGGL(scan_finish, dim3(nblocks), dim3(256), 0, stream, hist, bins, blocksum, offsets);
-	HIP_CHECK(hipMemsetAsync(order, 0xFF, (size_t) a.nrows * sizeof(int), stream));          // -1: no row
-	hipLaunchKernelGGL(row_regroup_kernel, dim3((a.nrows + 255) / 256), dim3(256), 0, stream, a.nrows, keys, offsets, cursor, order, a.ctr);
+	int npad = 1;
+	while (npad < a.nrows)
+		npad <<= 1;
+	unsigned long long *keys = reinterpret_cast<unsigned long long *>(((uintptr_t) sortbuf + 7) & ~(uintptr_t) 7);
+	const dim3 grid((npad + 255) / 256), block(256);
+	hipLaunchKernelGGL(row_component_key_kernel, grid, block, 0, stream, a, keys, npad);
+	for (int size = 2; size <= npad; size <<= 1)
+		for (int stride = size >> 1; stride > 0; stride >>= 1)
+			hipLaunchKernelGGL(bitonic_step_kernel, grid, block, 0, stream, keys, npad, size, stride);
+	hipLaunchKernelGGL(row_order_kernel, dim3((a.nrows + 255) / 256), block, 0, stream, keys, a.nrows, order);
 	HIP_CHECK(hipGetLastError());
 }
 
