@@ -545,7 +545,7 @@ int dschur_impl(const spasm_hip_dcsr *A, const int *d_rows, int nrows, const spa
 	bool probe = false;            // auto: run a few groups first and look at their lane efficiency
 	if (group_mode < 0) {
 		group_mode = (nrows >= 64 * 32 && (force_tier == 0 || Lout != nullptr)) ? 1 : 0;
-		probe = group_mode && Lout == nullptr && nrows >= env_int("SPASM_HIP_GROUP_WATCH_ROWS", 64 * 256);
+		probe = group_mode && Lout == nullptr && nrows >= env_int("SPASM_HIP_GROUP_WATCH_ROWS", 0);
 	}
 	int group_slots = 0, group_waves = 1;
 	i64 group_slot_bytes = 0, group_off_bm = 0;
