@@ -223,10 +223,9 @@ typedef struct {
 	int rows_dense;         /* rows finished by the dense-accumulator kernel */
 	int status;             /* 0 = ok, 1 = pool too small (call again with a larger pool) */
 	int used_group_kernel;  /* 1: the row-group kernel ran (its rows are counted in rows_dense) */
-	int group_aborted;      /* 1: its first attempt stopped early (poor lane efficiency); a second attempt on regrouped rows,
-	                           then if need be the per-row tiers (rows_lds > 0), finished the batch */
+	int group_aborted;      /* 1: it stopped early (poor lane efficiency), the per-row tiers finished the batch */
 	float ms_eliminate;     /* device time of the elimination kernels, all tiers (HIP events on the call's stream) */
-	float ms_group;         /* ... row-group kernel (schur_group_kernel, both attempts), 0 when not used */
+	float ms_group;         /* ... row-group kernel (schur_group_kernel), 0 when not used */
 	float ms_tier0;         /* ... small-table LDS kernel (schur_lds_kernel<1024>) */
 	float ms_tier1;         /* ... large-table LDS kernel (0 when skipped) */
 	float ms_tier2;         /* ... dense-accumulator kernel (schur_wave_dense_kernel) */

@@ -22,7 +22,7 @@ void wave_dense_geometry(int rpad, int Sm, bool wide, int64_t *slot_bytes, int64
 void group_geometry(int rpad, int Sm, bool wide, int64_t *slot_bytes, int64_t *off_bm);
 void launch_schur_group(const SchurArgs &a, unsigned char *scratch, int64_t slot_bytes, int64_t off_bm, bool wide,
                         uint32_t *dense_out, int64_t ldS, int blocks, hipStream_t stream, int watch, float min_eff,
-                        long long min_w, int waves, int attempt);
+                        long long min_w, int waves);
 void launch_schur_wave_dense(const SchurArgs &a, unsigned char *scratch, int64_t slot_bytes, int64_t off_bm, int64_t off_xn,
                              bool wide, uint32_t *dense_out, int64_t ldS, int blocks, hipStream_t stream);
 }  // namespace sh
@@ -154,7 +154,7 @@ static int dschur_dense_impl(const spasm_hip_dcsr *A, const int *d_rows, int nro
 	}
 	if (group_mode) {
 		a.next_ctr = CTR_ROW_NEXT_G;
-		launch_schur_group(a, W->d_scratch, gslot, goff, wide, d_S, ldS, gslots, stream, 0, 0.0f, 0, gwaves, 0);
+		launch_schur_group(a, W->d_scratch, gslot, goff, wide, d_S, ldS, gslots, stream, 0, 0.0f, 0, gwaves);
 	} else {
 		launch_schur_wave_dense(a, W->d_scratch, slot_bytes, off_bm, off_xn, wide, d_S, ldS, slots, stream);
 	}

@@ -35,8 +35,6 @@ enum Ctr {
 	CTR_DONE0, CTR_DONE1, CTR_DONE2,   // rows finished per tier
 	CTR_GROUP_ABORT,       // row-group kernel gave up (poor lane efficiency)
 	CTR_GROUPS_DONE,
-	CTR_GROUP_ABORT2,      // second attempt of the row-group kernel (rows regrouped by their first pivot) gave up too
-	CTR_ROW_NEXT_G2,       // ... its queue of groups
 	CTR_COUNT = 16
 };
 
@@ -47,8 +45,6 @@ enum Ctr64 {
 	C64_INPUT,             // entries of input rows
 	C64_WAVEPIV,           // row-group kernel: pivots applied per group (wave-level count)
 	C64_LPOOL,             // cursor of the L pool
-	C64_ELIM2,             // progress of the second attempt of the row-group kernel, for its own verdict
-	C64_WAVEPIV2,
 	C64_PROF0 = 8,         // -DSPASM_GROUP_PROFILE builds: cycles per phase of the row-group kernel (8 slots)
 	C64_COUNT = 16
 };
@@ -114,6 +110,7 @@ struct LOut {
 struct spasm_hip_dfact {
 	int m = 0, r = 0, Sm = 0, nlevels = 0;
 	int rpad = 0, maxdeg = 0;
+	int ncomp = 0;                  // connected components of the pivot graph
 	int64_t nnz = 0;
 	int64_t prime = 0;
 	sh::Mont mont{};
@@ -141,7 +138,7 @@ struct spasm_hip_dwork {
 	unsigned long long *d_ctr64 = nullptr;
 	int64_t *d_Sp = nullptr;
 	int64_t *d_blocksum = nullptr;
-	int *d_order = nullptr, *d_sortbuf = nullptr;   // rows regrouped by first pivot label (second attempt of the row-group kernel)
+	int *d_order = nullptr, *d_sortbuf = nullptr;   // rows regrouped by connected component of the pivot graph
 	int64_t sortbuf_ints = 0;
 	int *d_Sj = nullptr, *d_Sx = nullptr;
 	unsigned char *d_scratch = nullptr;   // per-wave dense accumulators (all zero between calls)

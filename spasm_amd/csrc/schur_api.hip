@@ -15,7 +15,7 @@ int64_t regroup_scratch_ints(int nrows, int r);
 void launch_regroup_rows(const SchurArgs &a, int *sortbuf, int *order, hipStream_t stream);
 void launch_schur_group(const SchurArgs &a, unsigned char *scratch, int64_t slot_bytes, int64_t off_bm, bool wide,
                         uint32_t *dense_out, int64_t ldS, int blocks, hipStream_t stream, int watch, float min_eff,
-                        long long min_w, int waves, int attempt);
+                        long long min_w, int waves);
 void launch_schur_wave_dense(const SchurArgs &a, unsigned char *scratch, int64_t slot_bytes, int64_t off_bm, int64_t off_xn,
                              bool wide, uint32_t *dense_out, int64_t ldS, int blocks, hipStream_t stream);
 void launch_all_rows_to_list(int *list, int *count, int *row_len, int nrows, hipStream_t stream);
@@ -157,6 +157,7 @@ struct FactPlan {
 	int m = 0, r = 0, nlevels = 0;
 	int rpad = 0;                 // size of the label space of the pivots: every level starts on a multiple of 32
 	int maxdeg = 0;               // largest number of rows of U' that hold one given label
+	int ncomp = 0;                // connected components of the pivot graph (labels that hold a row)
 	i64 prime = 0;
 	std::vector<uint32_t> lab, lvl_end;     // lvl_end is indexed by (padded) label
 	std::vector<uint32_t> lvl_end_w;        // per 32-label word: first word of the next level
@@ -368,8 +369,11 @@ static void plan_factor(const struct spasm_csr *U, const int *qinv, FactPlan &P)
 					if (a != b)
 						parent[std::max(a, b)] = std::min(a, b);          // the root is the smallest label
 				}
-		for (int c = 0; c < rpad; c++)
+		for (int c = 0; c < rpad; c++) {
 			P.comp[c] = find((uint32_t) c);
+			if (P.comp[c] == (uint32_t) c && P.kof[c] >= 0)
+				P.ncomp += 1;
+		}
 	}
 }
 
@@ -406,6 +410,7 @@ spasm_hip_dfact *spasm_hip_dfact_create(const struct spasm_csr *U, const int *qi
 	F->r = r;
 	F->rpad = rpad;
 	F->maxdeg = P.maxdeg;
+	F->ncomp = P.ncomp;
 	F->Sm = m - r;
 	F->prime = P.prime;
 	F->mont = mont_setup(P.prime);
@@ -656,20 +661,11 @@ int dschur_impl(const spasm_hip_dcsr *A, const int *d_rows, int nrows, const spa
 			HIP_CHECK(hipMemsetAsync(W->d_row_len, 0xFF, (size_t) nrows * sizeof(int), stream));
 			const float min_eff = (float) env_int("SPASM_HIP_GROUP_MIN_EFF_PCT", 4) / 100.0f;
 			const long long min_w = env_int("SPASM_HIP_GROUP_MIN_PIVOTS", 500000);
-			launch_schur_group(a, W->d_scratch, group_slot_bytes, group_off_bm, wide_dense, nullptr, 0, group_slots, stream,
-			                   probe ? 1 : 0, min_eff, min_w, group_waves, 0);
-			a.skip_ctr = CTR_GROUP_ABORT;
-			// did it give up?  (one small read-back: the call blocks at its end anyway, and nothing is launched
-			// for nothing -- the kernels below also check the flags themselves)
-			int gave_up = 0;
-			if (probe) {
-				HIP_CHECK(hipMemcpyAsync(&gave_up, W->d_ctr + CTR_GROUP_ABORT, sizeof(int), hipMemcpyDeviceToHost, stream));
-				HIP_CHECK(hipStreamSynchronize(stream));
-			}
-			if (probe && gave_up && env_int("SPASM_HIP_GROUP_RETRY", 1)) {
-				// second attempt: the neighbours in the list share nothing; the rows are regrouped by connected
-				// component of the pivot graph and the kernel tries once more before the batch goes to the
-				// per-row kernels.
+			// several connected components in the pivot graph: rows of different components share nothing, so the
+			// rows are grouped by component from the start (the order of the list is kept inside a component; with a
+			// single component, mk13.b5 for one, this is the list itself and nothing is done)
+			const bool regroup_enabled = env_int("SPASM_HIP_GROUP_REGROUP", 1) != 0;
+			auto regroup = [&]() {
 				const int64_t need = regroup_scratch_ints(nrows, F->rpad);
 				if (W->sortbuf_ints < need) {
 					if (W->d_sortbuf != nullptr)
@@ -680,13 +676,21 @@ int dschur_impl(const spasm_hip_dcsr *A, const int *d_rows, int nrows, const spa
 				if (W->d_order == nullptr)
 					W->d_order = dalloc<int>(W->max_rows);
 				launch_regroup_rows(a, W->d_sortbuf, W->d_order, stream);
+			};
+			const bool grouped_first = regroup_enabled && F->ncomp > 1 && Lout == nullptr;
+			if (grouped_first) {
+				regroup();
 				a.order = W->d_order;
-				a.next_ctr = CTR_ROW_NEXT_G2;
-				launch_schur_group(a, W->d_scratch, group_slot_bytes, group_off_bm, wide_dense, nullptr, 0, group_slots, stream,
-				                   1, min_eff, min_w, group_waves, 1);
-				a.order = nullptr;
-				a.skip_ctr = CTR_GROUP_ABORT2;
-				HIP_CHECK(hipMemcpyAsync(&gave_up, W->d_ctr + CTR_GROUP_ABORT2, sizeof(int), hipMemcpyDeviceToHost, stream));
+			}
+			launch_schur_group(a, W->d_scratch, group_slot_bytes, group_off_bm, wide_dense, nullptr, 0, group_slots, stream,
+			                   probe ? 1 : 0, min_eff, min_w, group_waves);
+			a.order = nullptr;
+			a.skip_ctr = CTR_GROUP_ABORT;
+			// did it give up?  (one small read-back: the call blocks at its end anyway, and nothing is launched
+			// for nothing -- the kernels below also check the flags themselves)
+			int gave_up = 0;
+			if (probe) {
+				HIP_CHECK(hipMemcpyAsync(&gave_up, W->d_ctr + CTR_GROUP_ABORT, sizeof(int), hipMemcpyDeviceToHost, stream));
 				HIP_CHECK(hipStreamSynchronize(stream));
 			}
 			HIP_CHECK(hipEventRecord(W->ev[5], stream));

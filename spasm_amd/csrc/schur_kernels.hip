@@ -1091,11 +1091,11 @@ void launch_schur_wave_dense(const SchurArgs &a, unsigned char *scratch, int64_t
 }  // namespace sh
 
 // --------------------------------------------------------------------------
-// Regrouping for the second attempt of the row-group kernel: rows that are neighbours in the list but unrelated
-// in structure waste its lanes.  The rows the first attempt left are sorted by (connected component of the pivot
-// graph their pivotal entries fall in, position in the list): rows that can share eliminations come together, and
-// inside a component the order of the list -- often meaningful -- is kept.  Rows with nothing to eliminate go last,
-// rows that are done are not listed (order[] ends with -1s).  A bitonic sort of 64-bit keys in HBM: a rare path.
+// Regrouping for the row-group kernel when the pivot graph has several connected components: rows that are
+// neighbours in the list but lie in different components share nothing and waste its lanes.  The rows are sorted by
+// (component their pivotal entries fall in, position in the list): rows that can share eliminations come together,
+// and inside a component the order of the list -- often meaningful -- is kept.  Rows with nothing to eliminate go
+// last.  A bitonic sort of 64-bit keys in HBM (about 1 ms for 160,000 rows).
 // --------------------------------------------------------------------------
 namespace sh {
 
@@ -1104,8 +1104,8 @@ __global__ __launch_bounds__(256) void row_component_key_kernel(SchurArgs a, uns
 	const int k = blockIdx.x * 256 + threadIdx.x;
 	if (k >= npad)
 		return;
-	unsigned long long key = ~0ull;                   // padding, and rows that are done
-	if (k < a.nrows && a.row_len[k] == -1) {
+	unsigned long long key = ~0ull;                   // padding
+	if (k < a.nrows) {
 		uint32_t comp = (uint32_t) a.r;               // nothing pivotal
 		const int i = a.rows[k];
 		for (int64_t px = a.Ap[i]; px < a.Ap[i + 1]; px++) {
@@ -1138,7 +1138,7 @@ __global__ __launch_bounds__(256) void row_order_kernel(const unsigned long long
 {
 	const int t = blockIdx.x * 256 + threadIdx.x;
 	if (t < nrows)
-		order[t] = (keys[t] == ~0ull) ? -1 : (int) (unsigned int) keys[t];
+		order[t] = (int) (unsigned int) keys[t];          // (the nrows real keys sort before the padding)
 }
 
 // sortbuf: 64-bit keys, padded to a power of two
@@ -1198,7 +1198,6 @@ struct GroupArgs {
 	int64_t off_bm;
 	uint32_t *dense_out;
 	int64_t ldS;
-	int attempt;              // 1: second attempt (rows regrouped): runs only if the first one gave up, skips finished rows
 	int touched_lds;          // LBM only: the bits of the non-pivotal labels sit in LDS too (they fit), else in HBM
 };
 
@@ -1225,11 +1224,6 @@ __global__ __launch_bounds__(64 * NW) void schur_group_kernel(GroupArgs d)
 	const SchurArgs &a = d.a;
 	const int lane = threadIdx.x & 63;
 	const int wv = threadIdx.x >> 6;
-	// which give-up flag and progress counters this launch answers to
-	const int abort_ctr = d.attempt ? CTR_GROUP_ABORT2 : CTR_GROUP_ABORT;
-	const int elim64 = d.attempt ? C64_ELIM2 : C64_ELIM, wavepiv64 = d.attempt ? C64_WAVEPIV2 : C64_WAVEPIV;
-	if (d.attempt && a.ctr[CTR_GROUP_ABORT] == 0)
-		return;                     // the first attempt finished the batch
 	// workgroup barrier that waits for the LDS queue only (__syncthreads would drain the atomics in flight too)
 	auto wg_sync = [&]() {
 		if (NW > 1)
@@ -1304,19 +1298,15 @@ __global__ __launch_bounds__(64 * NW) void schur_group_kernel(GroupArgs d)
 	for (;;) {
 		if (threadIdx.x == 0) {
 			ctl_l[0] = atomicAdd(&a.ctr[a.next_ctr], 1);
-			ctl_l[1] = d.watch ? __hip_atomic_load(&a.ctr[abort_ctr], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0;
+			ctl_l[1] = d.watch ? __hip_atomic_load(&a.ctr[CTR_GROUP_ABORT], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0;
 		}
 		wg_sync();
 		const int g = __builtin_amdgcn_readfirstlane(ctl_l[0]);
 		if (g >= ngroups || __builtin_amdgcn_readfirstlane(ctl_l[1]) != 0)
 			break;
 		const int kpos = g * 64 + lane;
-		bool have_row = kpos < a.nrows;
-		int k = have_row ? (a.order != nullptr ? a.order[kpos] : kpos) : 0;       // position in the row list
-		if (k < 0) {                    // (the regrouped list only holds the rows the first attempt left)
-			have_row = false;
-			k = 0;
-		}
+		const bool have_row = kpos < a.nrows;
+		const int k = have_row ? (a.order != nullptr ? a.order[kpos] : kpos) : 0;       // position in the row list
 		const int row_to_record = (a.L_i != nullptr && have_row) ? a.row_orig[k] : 0;
 
 		// ---- scatter the 64 input rows (each lane its own) ----
@@ -1361,15 +1351,11 @@ __global__ __launch_bounds__(64 * NW) void schur_group_kernel(GroupArgs d)
 				// running groups contribute in proportion to their work, so the ratio is not biased towards the
 				// cheap groups that finish first
 				if (lane == 0) {
-					const unsigned long long e = atomicAdd(&a.ctr64[elim64], st_elim) + st_elim;
-					const unsigned long long w = atomicAdd(&a.ctr64[wavepiv64], st_wavepiv) + st_wavepiv;
+					const unsigned long long e = atomicAdd(&a.ctr64[C64_ELIM], st_elim) + st_elim;
+					const unsigned long long w = atomicAdd(&a.ctr64[C64_WAVEPIV], st_wavepiv) + st_wavepiv;
 					atomicAdd(&a.ctr64[C64_STREAM], st_stream);
-					if (d.attempt) {          // (the statistics of the call count both attempts)
-						atomicAdd(&a.ctr64[C64_ELIM], st_elim);
-						atomicAdd(&a.ctr64[C64_WAVEPIV], st_wavepiv);
-					}
 					if (w > d.min_w && (double) e < (double) d.min_eff * 64.0 * (double) w)
-						atomicOr(&a.ctr[abort_ctr], 1);
+						atomicOr(&a.ctr[CTR_GROUP_ABORT], 1);
 				}
 				st_elim = 0;
 				st_wavepiv = 0;
@@ -1383,7 +1369,7 @@ __global__ __launch_bounds__(64 * NW) void schur_group_kernel(GroupArgs d)
 						// (a global load per round would add its latency to the chain of the group)
 						int stop = 0;
 						if (lane == 0 && (published || (round & 15) == 0))
-							stop = __hip_atomic_load(&a.ctr[abort_ctr], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+							stop = __hip_atomic_load(&a.ctr[CTR_GROUP_ABORT], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 						round += 1;
 						if (__builtin_amdgcn_readfirstlane(stop) != 0)
 							status = 2;
@@ -1894,11 +1880,10 @@ static void launch_group_variant(const GroupArgs &d, int blocks, size_t lds_byte
 // waves: 1, 2 or 4 waves per row group (more when groups are few: the chain of a group is then the run time)
 void launch_schur_group(const SchurArgs &a, unsigned char *scratch, int64_t slot_bytes, int64_t off_bm, bool wide,
                         uint32_t *dense_out, int64_t ldS, int blocks, hipStream_t stream, int watch, float min_eff,
-                        long long min_w, int waves, int attempt)
+                        long long min_w, int waves)
 {
 	GroupArgs d;
 	d.a = a;
-	d.attempt = attempt;
 	d.watch = watch;
 	d.min_eff = min_eff;
 	d.min_w = (unsigned long long) min_w;

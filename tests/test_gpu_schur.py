@@ -202,13 +202,14 @@ def test_schur_row_group_kernel_long_pivot_rows(oracle, p, row_len, monkeypatch)
     _check(oracle, S, p_out, want, p_out_want)
 
 
-@pytest.mark.parametrize("retry", ["1", "0"])
-def test_row_group_kernel_gives_up_on_unrelated_rows(oracle, retry, monkeypatch):
-    """rows that are neighbours in the list but live in different diagonal blocks share nothing: the row-group
-    kernel must notice (lane efficiency) and stop.  retry=1: the rows are regrouped by their first pivot (rows of a
-    block come together) and a second attempt finishes the batch; retry=0: the per-row kernels do -- same matrix."""
+@pytest.mark.parametrize("regroup", ["1", "0"])
+def test_row_group_kernel_gives_up_on_unrelated_rows(oracle, regroup, monkeypatch):
+    """rows that are neighbours in the list but live in different diagonal blocks share nothing.  regroup=1 (default):
+    the pivot graph has one connected component per block, the rows are grouped by component first and the row-group
+    kernel finishes the batch; regroup=0: it must notice (lane efficiency), stop, and the per-row kernels finish the
+    batch -- same matrix either way."""
     import torch
-    monkeypatch.setenv("SPASM_HIP_GROUP_RETRY", retry)
+    monkeypatch.setenv("SPASM_HIP_GROUP_REGROUP", regroup)
     monkeypatch.setenv("SPASM_HIP_GROUP_WATCH_ROWS", "0")
     monkeypatch.setenv("SPASM_HIP_GROUP_MIN_PIVOTS", "20000")      # the batch is small: judge early
     p = 42013
@@ -242,10 +243,10 @@ def test_row_group_kernel_gives_up_on_unrelated_rows(oracle, retry, monkeypatch)
     Wk = spasm_amd.SchurWorkspace(len(rows), A.m, 4 * want.nnz + (1 << 22))
     drows = torch.from_numpy(np.ascontiguousarray(rows, np.int32)).cuda()
     S, st = spasm_amd.dschur(dA, drows, dF, Wk)
-    assert st.status == 0 and st.used_group_kernel == 1 and st.group_aborted == 1
+    assert st.status == 0 and st.used_group_kernel == 1 and st.group_aborted == (0 if regroup == "1" else 1)
     assert st.rows_lds + st.rows_lds_big + st.rows_dense == len(rows)
     # (rows this small end in the LDS tier when the per-row kernels get them)
-    assert (st.rows_lds == 0) if retry == "1" else (st.rows_lds > 0)
+    assert (st.rows_lds == 0) if regroup == "1" else (st.rows_lds > 0)
     H = S.to_host()
     assert oracle.same_matrix(oracle.CSR(H.n, H.m, H.p, H.j, H.x, p), want)
 
