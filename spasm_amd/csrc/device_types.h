@@ -110,7 +110,7 @@ struct LOut {
 struct spasm_hip_dfact {
 	int m = 0, r = 0, Sm = 0, nlevels = 0;
 	int rpad = 0, maxdeg = 0;
-	int ncomp = 0;                  // connected components of the pivot graph
+	int ncomp = 0, comp_largest = 0;   // connected components of the pivot graph, rows of the largest one
 	int64_t nnz = 0;
 	int64_t prime = 0;
 	sh::Mont mont{};

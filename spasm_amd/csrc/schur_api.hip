@@ -157,7 +157,7 @@ struct FactPlan {
 	int m = 0, r = 0, nlevels = 0;
 	int rpad = 0;                 // size of the label space of the pivots: every level starts on a multiple of 32
 	int maxdeg = 0;               // largest number of rows of U' that hold one given label
-	int ncomp = 0;                // connected components of the pivot graph (labels that hold a row)
+	int ncomp = 0, comp_largest = 0;   // connected components of the pivot graph (labels that hold a row), size of the largest
 	i64 prime = 0;
 	std::vector<uint32_t> lab, lvl_end;     // lvl_end is indexed by (padded) label
 	std::vector<uint32_t> lvl_end_w;        // per 32-label word: first word of the next level
@@ -369,11 +369,17 @@ static void plan_factor(const struct spasm_csr *U, const int *qinv, FactPlan &P)
 					if (a != b)
 						parent[std::max(a, b)] = std::min(a, b);          // the root is the smallest label
 				}
+		std::vector<int> members((size_t) (rpad > 0 ? rpad : 1), 0);
 		for (int c = 0; c < rpad; c++) {
 			P.comp[c] = find((uint32_t) c);
-			if (P.comp[c] == (uint32_t) c && P.kof[c] >= 0)
-				P.ncomp += 1;
+			if (P.kof[c] >= 0)
+				members[P.comp[c]] += 1;
 		}
+		for (int c = 0; c < rpad; c++)
+			if (members[c] > 0) {
+				P.ncomp += 1;
+				P.comp_largest = std::max(P.comp_largest, members[c]);
+			}
 	}
 }
 
@@ -411,6 +417,7 @@ spasm_hip_dfact *spasm_hip_dfact_create(const struct spasm_csr *U, const int *qi
 	F->rpad = rpad;
 	F->maxdeg = P.maxdeg;
 	F->ncomp = P.ncomp;
+	F->comp_largest = P.comp_largest;
 	F->Sm = m - r;
 	F->prime = P.prime;
 	F->mont = mont_setup(P.prime);
@@ -663,7 +670,7 @@ int dschur_impl(const spasm_hip_dcsr *A, const int *d_rows, int nrows, const spa
 			const long long min_w = env_int("SPASM_HIP_GROUP_MIN_PIVOTS", 500000);
 			// several connected components in the pivot graph: rows of different components share nothing, so the
 			// rows are grouped by component from the start (the order of the list is kept inside a component; with a
-			// single component, mk13.b5 for one, this is the list itself and nothing is done)
+			// single or a dominant component -- mk13.b5: 109,966 of its 111,177 pivots -- nothing is done)
 			const bool regroup_enabled = env_int("SPASM_HIP_GROUP_REGROUP", 1) != 0;
 			auto regroup = [&]() {
 				const int64_t need = regroup_scratch_ints(nrows, F->rpad);
@@ -677,7 +684,8 @@ int dschur_impl(const spasm_hip_dcsr *A, const int *d_rows, int nrows, const spa
 					W->d_order = dalloc<int>(W->max_rows);
 				launch_regroup_rows(a, W->d_sortbuf, W->d_order, stream);
 			};
-			const bool grouped_first = regroup_enabled && F->ncomp > 1 && Lout == nullptr;
+			const bool grouped_first = regroup_enabled && F->ncomp > 1 && Lout == nullptr &&
+			                           (i64) F->comp_largest * 10 < (i64) F->r * 9;          // (a giant component: the list order is what matters)
 			if (grouped_first) {
 				regroup();
 				a.order = W->d_order;
