@@ -1134,6 +1134,34 @@ __global__ __launch_bounds__(256) void bitonic_step_kernel(unsigned long long *k
 	}
 }
 
+// all the steps of one merge stage whose partners lie inside a block of 2048 keys (stride <= 1024), in LDS
+constexpr int BITONIC_LOCAL = 2048;
+__global__ __launch_bounds__(256) void bitonic_local_kernel(unsigned long long *keys, int npad, int size, int first_stride)
+{
+	__shared__ unsigned long long s[BITONIC_LOCAL];
+	const int base = blockIdx.x * BITONIC_LOCAL;
+	for (int t = threadIdx.x; t < BITONIC_LOCAL; t += 256)
+		s[t] = (base + t < npad) ? keys[base + t] : ~0ull;
+	__syncthreads();
+	for (int stride = first_stride; stride > 0; stride >>= 1) {
+		for (int q = threadIdx.x; q < BITONIC_LOCAL / 2; q += 256) {
+			// the q-th pair of this step: t has bit `stride` clear
+			const int t = ((q & ~(stride - 1)) << 1) | (q & (stride - 1));
+			const int partner = t | stride;
+			const unsigned long long x = s[t], y = s[partner];
+			const bool ascending = ((base + t) & size) == 0;
+			if ((x > y) == ascending) {
+				s[t] = y;
+				s[partner] = x;
+			}
+		}
+		__syncthreads();
+	}
+	for (int t = threadIdx.x; t < BITONIC_LOCAL; t += 256)
+		if (base + t < npad)
+			keys[base + t] = s[t];
+}
+
 __global__ __launch_bounds__(256) void row_order_kernel(const unsigned long long *keys, int nrows, int *order)
 {
 	const int t = blockIdx.x * 256 + threadIdx.x;
@@ -1159,9 +1187,13 @@ void launch_regroup_rows(const SchurArgs &a, int *sortbuf, int *order, hipStream
 	unsigned long long *keys = reinterpret_cast<unsigned long long *>(((uintptr_t) sortbuf + 7) & ~(uintptr_t) 7);
 	const dim3 grid((npad + 255) / 256), block(256);
 	hipLaunchKernelGGL(row_component_key_kernel, grid, block, 0, stream, a, keys, npad);
-	for (int size = 2; size <= npad; size <<= 1)
-		for (int stride = size >> 1; stride > 0; stride >>= 1)
+	for (int size = 2; size <= npad; size <<= 1) {
+		int stride = size >> 1;
+		for (; stride >= BITONIC_LOCAL; stride >>= 1)
 			hipLaunchKernelGGL(bitonic_step_kernel, grid, block, 0, stream, keys, npad, size, stride);
+		// (npad is a power of two: either one partial block or whole blocks)
+		hipLaunchKernelGGL(bitonic_local_kernel, dim3((npad + BITONIC_LOCAL - 1) / BITONIC_LOCAL), block, 0, stream, keys, npad, size, stride);
+	}
 	hipLaunchKernelGGL(row_order_kernel, dim3((a.nrows + 255) / 256), block, 0, stream, keys, a.nrows, order);
 	HIP_CHECK(hipGetLastError());
 }

@@ -209,3 +209,36 @@ def test_row_group_kernels_keep_the_accumulation_registers_to_the_prefetch_ring(
             if regs:
                 assert max(regs) < limit, (name, line)
                 assert re.search(r"global_load_dword|v_accvgpr_read", ins), (name, line)
+
+
+def test_bitonic_network_of_the_row_regrouping_sorts():
+    """the compare-exchange schedule of launch_regroup_rows (csrc/schur_kernels.hip: global steps for strides >= 2048,
+    one in-LDS kernel per merge stage for the shorter ones), replayed here on random 64-bit keys."""
+    LOCAL = 2048
+    rng = np.random.default_rng(5)
+    for npad in (1, 2, 64, 2048, 8192):
+        keys = rng.integers(0, 1 << 62, size=npad, dtype=np.int64)
+
+        def step(lo, hi, size, stride):          # bitonic_step_kernel / one pass of bitonic_local_kernel on [lo, hi)
+            t = np.arange(lo, hi)
+            t = t[(t & stride) == 0]
+            partner = t | stride
+            asc = (t & size) == 0
+            x, y = keys[t].copy(), keys[partner].copy()
+            swap = (x > y) == asc
+            keys[t] = np.where(swap, y, x)
+            keys[partner] = np.where(swap, x, y)
+
+        size = 2
+        while size <= npad:
+            stride = size >> 1
+            while stride >= LOCAL:
+                step(0, npad, size, stride)
+                stride >>= 1
+            for base in range(0, npad, LOCAL):            # bitonic_local_kernel: one workgroup per 2048 keys
+                s = stride
+                while s > 0:
+                    step(base, min(base + LOCAL, npad), size, s)
+                    s >>= 1
+            size <<= 1
+        assert np.all(np.diff(keys) >= 0), npad
