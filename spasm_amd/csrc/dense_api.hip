@@ -23,6 +23,8 @@ void group_geometry(int rpad, int Sm, bool wide, int64_t *slot_bytes, int64_t *o
 void launch_schur_group(const SchurArgs &a, unsigned char *scratch, int64_t slot_bytes, int64_t off_bm, bool wide,
                         uint32_t *dense_out, int64_t ldS, int blocks, hipStream_t stream, int watch, float min_eff,
                         long long min_w, int waves);
+int64_t regroup_scratch_ints(int nrows, int r);
+void launch_regroup_rows(const SchurArgs &a, int *sortbuf, int *order, hipStream_t stream);
 void launch_schur_wave_dense(const SchurArgs &a, unsigned char *scratch, int64_t slot_bytes, int64_t off_bm, int64_t off_xn,
                              bool wide, uint32_t *dense_out, int64_t ldS, int blocks, hipStream_t stream);
 }  // namespace sh
@@ -154,6 +156,21 @@ static int dschur_dense_impl(const spasm_hip_dcsr *A, const int *d_rows, int nro
 	}
 	if (group_mode) {
 		a.next_ctr = CTR_ROW_NEXT_G;
+		// rows grouped by connected component of the pivot graph when there are several (schur_api.hip)
+		if (Lout == nullptr && F->ncomp > 1 && (i64) F->comp_largest * 10 < (i64) F->r * 9 && env_int("SPASM_HIP_GROUP_REGROUP", 1)) {
+			a.comp = F->d_comp;
+			const int64_t need = regroup_scratch_ints(nrows, F->rpad);
+			if (W->sortbuf_ints < need) {
+				if (W->d_sortbuf != nullptr)
+					(void) hipFree(W->d_sortbuf);
+				HIP_CHECK(hipMalloc((void **) &W->d_sortbuf, (size_t) need * sizeof(int)));
+				W->sortbuf_ints = need;
+			}
+			if (W->d_order == nullptr)
+				HIP_CHECK(hipMalloc((void **) &W->d_order, (size_t) W->max_rows * sizeof(int)));
+			launch_regroup_rows(a, W->d_sortbuf, W->d_order, stream);
+			a.order = W->d_order;
+		}
 		launch_schur_group(a, W->d_scratch, gslot, goff, wide, d_S, ldS, gslots, stream, 0, 0.0f, 0, gwaves);
 	} else {
 		launch_schur_wave_dense(a, W->d_scratch, slot_bytes, off_bm, off_xn, wide, d_S, ldS, slots, stream);
