@@ -241,9 +241,17 @@ def main():
         kernel_ms = k_ms / args.steps
         achieved = algo / (kernel_ms * 1e-3) / 1e9 if kernel_ms > 0 else 0.0
         traffic = None
+        atomic_info = None
         tfile = os.path.join(ROOT, "profiles", "traffic_r01.json")
         if os.path.exists(tfile) and world == 1:          # (measured on the whole batch: says nothing about a rank's slice)
-            traffic = json.load(open(tfile)).get("schur_group_kernel_bytes_per_launch" if group else "schur_wave_dense_kernel_bytes_per_launch")
+            tj = json.load(open(tfile))
+            traffic = tj.get("schur_group_kernel_bytes_per_launch" if group else "schur_wave_dense_kernel_bytes_per_launch")
+            if group and tj.get("schur_group_kernel_atomic_requests_per_launch"):
+                # what actually bounds the kernel: 64-byte atomic requests to the memory side
+                atomic_info = {"requests_per_launch": tj["schur_group_kernel_atomic_requests_per_launch"],
+                               "achieved_per_s": tj["schur_group_kernel_atomic_requests_per_launch"] / (kernel_ms * 1e-3),
+                               "measured_ceiling_per_s": tj.get("atomic_request_ceiling_per_s"),
+                               "source": "rocprofv3 TCC_ATOMIC_sum (profiles/r01_g_atomic_counters.txt); ceiling: tools/microbench_atomics.hip"}
         # waves per row group: the library's own rule (schur_api.hip), for the kernel name rocprofv3 shows
         cus = torch.cuda.get_device_properties(0).multi_processor_count
         ngroups_rank = (len(my_rows) + 63) // 64
@@ -272,6 +280,7 @@ def main():
                          "kernel": ("schur_group_kernel<false,true,%d>" % group_waves) if group else "schur_wave_dense_kernel<false>",
                          "kernel_ms": kernel_ms,
                          "algorithmic_bytes": int(algo),
+                         "atomic_requests": atomic_info,
                          "ms_by_kernel": {"schur_lds_kernel<1024>": t_tiers[0] / args.steps,
                                           "schur_lds_kernel<8192>": t_tiers[1] / args.steps,
                                           "schur_wave_dense_kernel": t_tiers[2] / args.steps,
