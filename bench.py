@@ -16,7 +16,6 @@ row batch is sharded over the ranks, each rank reduces its slice, the slices
 are reassembled on every rank with an all-gatherv over RCCL (strong scaling).
 """
 import argparse
-import itertools
 import json
 import os
 import sys
@@ -34,71 +33,12 @@ PRIME = 42013
 # --------------------------------------------------------------------------
 # workload
 # --------------------------------------------------------------------------
-def matching_complex_boundary(nv=13, k=5):
-    """boundary map from k-edge matchings to (k-1)-edge matchings of K_nv.
-    returns (n_rows, n_cols, ti, tj, tx): rows = (k-1)-matchings, cols = k-matchings."""
-    edges = list(itertools.combinations(range(nv), 2))
-    masks = [(1 << a) | (1 << b) for a, b in edges]
-    ne = len(edges)
-
-    def matchings(size):
-        out = []
-        cur = []
-
-        def rec(start, used):
-            if len(cur) == size:
-                out.append(tuple(cur))
-                return
-            for e in range(start, ne):
-                if masks[e] & used:
-                    continue
-                cur.append(e)
-                rec(e + 1, used | masks[e])
-                cur.pop()
-        rec(0, 0)
-        return out
-
-    big = matchings(k)
-    small = matchings(k - 1)
-    index = {s: i for i, s in enumerate(small)}
-    ti, tj, tx = [], [], []
-    for c, s in enumerate(big):
-        for t in range(k):
-            face = s[:t] + s[t + 1:]
-            ti.append(index[face])
-            tj.append(c)
-            tx.append(1 if t % 2 == 0 else -1)
-    return len(small), len(big), np.array(ti, np.int32), np.array(tj, np.int32), np.array(tx, np.int64)
-
-
 def build_workload(name):
-    """returns (A, rows, F): host Csr, rows to reduce, factor with the structural pivots.  The pivot
-    search runs single-threaded here so that every rank (and every run) gets the same pivots."""
-    import spasm_amd
-    os.environ["SPASM_HIP_THREADS"] = "1"
-    cache = os.path.join("/tmp", "spasm_amd_bench_%s_%d.npz" % (name, PRIME))
-    if os.path.exists(cache):
-        z = np.load(cache)
-        A = spasm_amd.Csr(int(z["n"]), int(z["m"]), z["Ap"], z["Aj"], z["Ax"], PRIME)
-        F = spasm_amd.Fact(spasm_amd.Csr(int(z["r"]), int(z["m"]), z["Up"], z["Uj"], z["Ux"], PRIME), z["qinv"])
-        return A, z["rows"], F
-    if name == "mk13.b5":
-        n, m, ti, tj, tx = matching_complex_boundary(13, 5)
-    elif name == "mk9.b3":            # small sibling, used by tests
-        n, m, ti, tj, tx = matching_complex_boundary(9, 3)
-    else:
-        raise ValueError(name)
-    if n < m:                         # tools/rank.c:88-92: work on the tall orientation
-        ti, tj = tj, ti
-        n, m = m, n
-    A = spasm_amd.compress(PRIME, n, m, ti, tj, tx)
-    npiv, perm, F = spasm_amd.pivots_extract_structural(A, spasm_amd.empty_fact(A.m, PRIME))
-    rows = np.ascontiguousarray(perm[npiv:], np.int32)
-    tmp = "%s.%d.tmp.npz" % (cache, os.getpid())       # ranks build concurrently: publish atomically
-    np.savez(tmp, n=A.n, m=A.m, Ap=A.p, Aj=A.j, Ax=A.x, r=F.U.n, Up=F.U.p, Uj=F.U.j, Ux=F.U.x,
-             qinv=F.qinv, rows=rows)
-    os.replace(tmp, cache)
-    return A, rows, F
+    """(A, rows, F, source) -- tools/workloads.py: the matrix as tools/rank prepares it, its structural pivots
+    (single-threaded search: the same pivots on every rank and in every run), the non-pivotal rows."""
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import workloads
+    return workloads.round0(name, PRIME)
 
 
 # --------------------------------------------------------------------------
@@ -174,7 +114,7 @@ def main():
             os.dup2(saved_stdout, 1)
             os.close(saved_stdout)
 
-    A, rows, F = build_workload(args.workload)
+    A, rows, F, source = build_workload(args.workload)
     from spasm_amd.dist import shard_rows, allgatherv_csr
     my_rows = shard_rows(rows, rank, world)
     dA = spasm_amd.DeviceCsr.from_host(A, dev)
@@ -194,6 +134,7 @@ def main():
         pool *= 2
 
     def step():
+        dF.forget()          # a step is the whole of spasm_schur: derived factor state (the back-substituted rows) is rebuilt
         with torch.cuda.stream(stream):
             S, st = spasm_amd.dschur(dA, drows, dF, W, stream=stream.cuda_stream, fetch=use_dist)
             if use_dist:

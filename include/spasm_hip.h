@@ -175,6 +175,10 @@ const char *spasm_hip_datatype_name(spasm_datatype datatype);
 /* --- drivers (replace spasm_echelonize.c:9-28, :478-616; spasm_rref.c:25; spasm_kernel.c:9) --- */
 void spasm_hip_echelonize_init_opts(struct echelonize_opts *opts);
 struct spasm_lu *spasm_hip_echelonize(const struct spasm_csr *A, struct echelonize_opts *opts);
+/* seconds the last spasm_hip_echelonize call spent in: [0] the whole call, [1] the host pivot search, [2] density
+ * estimates, [3] sparse Schur complements, [4] the dense / low-rank finish, [5] number of sparse Schur rounds,
+ * [6] the structural-rounds finish that replaces GPLU, [7] unused.  out has 8 doubles. */
+void spasm_hip_echelonize_profile(double *out);
 struct spasm_csr *spasm_hip_rref(const struct spasm_lu *fact, int *Rqinv);
 struct spasm_csr *spasm_hip_kernel(const struct spasm_lu *fact);
 
@@ -200,6 +204,9 @@ typedef struct {
 typedef struct spasm_hip_dfact spasm_hip_dfact;
 spasm_hip_dfact *spasm_hip_dfact_create(const struct spasm_csr *U, const int *qinv, void *stream);
 void spasm_hip_dfact_destroy(spasm_hip_dfact *F);
+/* forgets derived state cached in the image (the back-substituted rows R): the next Schur call rebuilds it.
+ * bench.py calls this before every step so that a step is the whole of spasm_schur. */
+void spasm_hip_dfact_forget(spasm_hip_dfact *F);
 int spasm_hip_dfact_rank(const spasm_hip_dfact *F);
 int spasm_hip_dfact_levels(const spasm_hip_dfact *F);
 i64 spasm_hip_dfact_nnz(const spasm_hip_dfact *F);
@@ -231,6 +238,13 @@ typedef struct {
 	float ms_tier2;         /* ... dense-accumulator kernel (schur_wave_dense_kernel) */
 	float ms_finalize;      /* row pointers + sorted gather */
 	float ms_total;         /* device time of the whole call */
+	int used_backsolve;     /* 1: the rows were computed from the back-substituted factor image (S = A_n - A_p R) */
+	int backsolve_built;    /* 1: ... and R was (re)built by this call (ms_backsolve, bytes_backsolve say at what cost) */
+	float ms_backsolve;     /* device time of building R = U_pp^-1 U_pn (memset + init + backsolve_kernel) */
+	float ms_apply;         /* device time of bs_apply_kernel (S rows from R) */
+	i64 bytes_backsolve;    /* algorithmic bytes of that build */
+	i64 bytes_apply;        /* ... of the apply kernel */
+	char kernel[64];        /* name of the dominant elimination kernel this call launched, as rocprofv3 shows it */
 } spasm_hip_schur_stats;
 
 /* S = Schur complement of rows d_rows[0..nrows) of A w.r.t. F, left in the

@@ -47,6 +47,7 @@ def lib():
         "spasm_hip_schur": (pcsr, [pcsr, pint, ci, plu, C.c_double, ptri, pint, pint]),
         "spasm_hip_dfact_create": (vp, [pcsr, pint, vp]),
         "spasm_hip_dfact_destroy": (None, [vp]),
+        "spasm_hip_dfact_forget": (None, [vp]),
         "spasm_hip_dfact_rank": (ci, [vp]),
         "spasm_hip_dfact_levels": (ci, [vp]),
         "spasm_hip_dfact_nnz": (i64, [vp]),
@@ -56,6 +57,7 @@ def lib():
         "spasm_hip_dschur_fetch": (None, [vp, vp, vp, vp, vp]),
         "spasm_hip_echelonize_init_opts": (None, [C.POINTER(EchelonizeOpts)]),
         "spasm_hip_echelonize": (plu, [pcsr, C.POINTER(EchelonizeOpts)]),
+        "spasm_hip_echelonize_profile": (None, [C.POINTER(C.c_double)]),
         "spasm_hip_rref": (pcsr, [plu, pint]),
         "spasm_hip_kernel": (pcsr, [plu]),
         "spasm_hip_lu_free": (None, [plu]),

@@ -27,6 +27,9 @@ int64_t regroup_scratch_ints(int nrows, int r);
 void launch_regroup_rows(const SchurArgs &a, int *sortbuf, int *order, hipStream_t stream);
 void launch_schur_wave_dense(const SchurArgs &a, unsigned char *scratch, int64_t slot_bytes, int64_t off_bm, int64_t off_xn,
                              bool wide, uint32_t *dense_out, int64_t ldS, int blocks, hipStream_t stream);
+void backsolve_build(const spasm_hip_dfact *F, hipStream_t stream);
+void launch_backsolve_apply(const SchurArgs &a, const spasm_hip_dfact *F, uint32_t *dense_out, int64_t ldS, hipStream_t stream);
+bool backsolve_wanted(const spasm_hip_dfact *F, bool other_path_forced);
 }  // namespace sh
 
 using namespace sh;
@@ -80,6 +83,31 @@ static int dschur_dense_impl(const spasm_hip_dcsr *A, const int *d_rows, int nro
 		die("spasm_hip_dschur_dense: leading dimension %" PRId64 " below the %d non-pivotal columns", ldS, F->Sm);
 	if (nrows == 0)
 		return 0;
+	if (Lout == nullptr && backsolve_wanted(F, env_int("SPASM_HIP_FORCE_TIER", 0) != 0 || env_int("SPASM_HIP_GROUP", -1) >= 0)) {
+		// dense rows straight from the back-substituted image (backsolve.hip)
+		if (!F->bs.valid)
+			backsolve_build(F, stream);
+		HIP_CHECK(hipMemsetAsync(W->d_ctr, 0, CTR_COUNT * sizeof(int), stream));
+		HIP_CHECK(hipMemsetAsync(W->d_ctr64, 0, C64_COUNT * sizeof(unsigned long long), stream));
+		SchurArgs a{};
+		a.Ap = A->p;
+		a.Aj = A->j;
+		a.Ax = A->x;
+		a.rows = d_rows;
+		a.nrows = nrows;
+		a.q = F->d_q;
+		a.r = F->rpad;
+		a.Sm = F->Sm;
+		a.m = F->m;
+		a.F = to_dev(F->mont);
+		a.row_len = W->d_row_len;
+		a.ctr = W->d_ctr;
+		a.ctr64 = W->d_ctr64;
+		a.done_ctr = CTR_DONE2;
+		launch_backsolve_apply(a, F, d_S, ldS, stream);
+		HIP_CHECK(hipStreamSynchronize(stream));
+		return 0;
+	}
 	// a column receives at most maxdeg + 1 terms, each below 2p (the row-group kernel adds unreduced products)
 	const bool wide = (2.0 * (double) F->prime * ((double) F->maxdeg + 3.0) >= 4294967296.0);
 	int dev = 0;
@@ -103,6 +131,11 @@ static int dschur_dense_impl(const spasm_hip_dcsr *A, const int *d_rows, int nro
 	int gslots = 0, gwaves = 1;
 	if (group_mode) {
 		group_geometry(F->rpad, F->Sm, wide, &gslot, &goff);
+		// (very wide matrices: too few slices fit the budget to fill the chip -- per-row kernel instead, as in schur_api.hip)
+		if (budget / gslot < 1 || (budget / gslot < std::min<i64>((nrows + 63) / 64, cus / 2) && env_int("SPASM_HIP_GROUP", -1) < 0))
+			group_mode = 0;
+	}
+	if (group_mode) {
 		gwaves = env_int("SPASM_HIP_GROUP_WAVES", (nrows + 63) / 64 <= cus * 3 ? 4 : (nrows + 63) / 64 <= cus * 12 ? 2 : 1);
 		gslots = (int) std::max<i64>(1, std::min<i64>((nrows + 63) / 64, std::min<i64>(gwaves >= 4 ? cus * 2 : gwaves >= 2 ? cus * 4 : cus * 8, budget / gslot)));
 		need = gslot * gslots;

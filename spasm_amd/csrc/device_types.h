@@ -104,6 +104,56 @@ struct LOut {
 	int64_t used = 0;         // out: pool cursor after the call (slots handed out, some may be unused)
 };
 
+// Host part of the factor image (built by plan_factor, schur_api.hip).
+struct FactPlan {
+	int m = 0, r = 0, nlevels = 0;
+	int rpad = 0;                 // size of the label space of the pivots: every level starts on a multiple of 32
+	int maxdeg = 0;               // largest number of rows of U' that hold one given label
+	int ncomp = 0, comp_largest = 0;   // connected components of the pivot graph (labels that hold a row), size of the largest
+	int64_t prime = 0;
+	std::vector<uint32_t> lab, lvl_end;     // lvl_end is indexed by (padded) label
+	std::vector<uint32_t> lvl_end_w;        // per 32-label word: first word of the next level
+	std::vector<int> q, kof, label_of_row;  // kof: label -> row of U, -1 for padding labels
+	std::vector<int> lvl_count;             // rows per level
+	std::vector<uint64_t> rp;               // rpad + 1
+	std::vector<uint2> ent;
+	std::vector<uint2> head;                // 4 entries per label: the first entries of the row, 0xFFFFFFFF-padded
+	std::vector<uint32_t> comp;             // per label: smallest label of its connected component in the pivot graph
+};
+
+// ---- back-substituted factor ("R image", backsolve.hip) ------------------------------------------
+// R = U_pp^-1 U_pn: row c = the non-pivotal part of the fully reduced pivot row c (what spasm_rref would
+// give).  With it the Schur complement of a row a is a_n - a_p R: no elimination order, no atomics.
+// Rows are numbered by COMPACT id = rank of their label among the labels that hold a row (so level order).
+struct BsChunk {              // a run of consecutive compact rows solved inside LDS by one workgroup per column slab
+	int lo, hi;               // compact rows [lo, hi)
+	int step0, nsteps;        // phase-B steps (one per level that has rows with dependencies inside the chunk)
+	int near0, nnear;         // their entries: (slot of the dependency, value * 2^32 mod p)
+	int brow0, nbrow;         // rows with dependencies inside the chunk: (slot | count << 16, first entry - near0)
+};
+
+struct BsImage {
+	bool planned = false;     // the host plan below was built and uploaded (the factor is eligible)
+	bool valid = false;       // d_R holds R
+	int r = 0, Sm = 0, nchunks = 0;
+	int64_t ldR = 0;          // Sm rounded up to 256
+	int64_t nfar = 0, nnear = 0, nnp = 0, ndeps = 0;
+	uint32_t *d_R = nullptr;
+	int *d_col = nullptr;             // column -> compact row id of its pivot, or r + index among the non-pivotal columns
+	BsChunk *d_chunk = nullptr;
+	int2 *d_step = nullptr;           // [first, last) into d_brow
+	uint2 *d_brow = nullptr;
+	uint2 *d_near = nullptr;
+	uint4 *d_far_head = nullptr;      // per compact row: its first two dependencies outside the chunk (t0, y0, t1, y1); t = ~0: none
+	uint64_t *d_far_rp = nullptr;     // per compact row: the others, [r + 1] offsets into d_far
+	uint2 *d_far = nullptr;
+	uint64_t *d_np_rp = nullptr;      // per compact row: non-pivotal entries (index among the non-pivotal columns, value * 2^32 mod p)
+	uint2 *d_np = nullptr;
+	int *d_chunk_extra = nullptr;     // per chunk: some row has more than two dependencies outside the chunk
+	hipEvent_t ev0 = nullptr, ev1 = nullptr;     // around the last build (memset + init + backsolve kernel)
+	int builds = 0;
+};
+
 }  // namespace sh
 
 // opaque handles of the C ABI
@@ -125,6 +175,7 @@ struct spasm_hip_dfact {
 	int *d_kof = nullptr;          // label -> row of U (-1: padding label)
 	std::vector<int> h_q;          // host copy of q
 	std::vector<int> h_kof;
+	mutable sh::BsImage bs;        // back-substituted image, built on first use when the factor is eligible
 };
 
 struct spasm_hip_dwork {

@@ -336,8 +336,29 @@ void finish_dense(const struct spasm_csr *A, const int *p, int n, const int *p_i
 
 }  // namespace
 
+// where the last spasm_hip_echelonize call spent its time (seconds): read by bench.py / tools through
+// spasm_hip_echelonize_profile
+static double g_prof[8];
+
+extern "C" void spasm_hip_echelonize_profile(double *out)
+{
+	for (int k = 0; k < 8; k++)
+		out[k] = g_prof[k];
+}
+
+namespace {
+struct Stopwatch {          // adds the time of its scope to a slot of g_prof
+	double t0;
+	int slot;
+	explicit Stopwatch(int s) : t0(wtime()), slot(s) {}
+	~Stopwatch() { g_prof[slot] += wtime() - t0; }
+};
+}  // namespace
+
 extern "C" struct spasm_lu *spasm_hip_echelonize(const struct spasm_csr *A0, struct echelonize_opts *opts)
 {
+	for (int k = 0; k < 8; k++)
+		g_prof[k] = 0.0;
 	if (spasm_hip_device_count() == 0)
 		die("spasm_hip_echelonize: no HIP device (this library has no CPU path)");
 	struct echelonize_opts dflt;
@@ -387,13 +408,19 @@ extern "C" struct spasm_lu *spasm_hip_echelonize(const struct spasm_csr *A0, str
 			break;
 		}
 		logmsg("[echelonize] round %d\n", round);
-		npiv = spasm_hip_pivots_extract_structural(A, p_in, fact, p, opts);
+		{
+			Stopwatch sw(1);
+			npiv = spasm_hip_pivots_extract_structural(A, p_in, fact, p, opts);
+		}
 		if (npiv < opts->min_pivot_proportion * std::min(n, m - U->n)) {
 			logmsg("[echelonize] not enough pivots found; stopping\n");
 			status = 2;
 			break;
 		}
-		density = spasm_hip_schur_estimate_density(A, p + npiv, n - npiv, U, Uqinv, 100);
+		{
+			Stopwatch sw(2);
+			density = spasm_hip_schur_estimate_density(A, p + npiv, n - npiv, U, Uqinv, 100);
+		}
 		if (density > opts->sparsity_threshold) {
 			logmsg("[echelonize] Schur complement is dense (estimated %.2f%%)\n", 100 * density);
 			status = 2;
@@ -401,7 +428,12 @@ extern "C" struct spasm_lu *spasm_hip_echelonize(const struct spasm_csr *A0, str
 		}
 		logmsg("[echelonize] Schur complement is %d x %d, estimated density : %.4f\n", n - npiv, m - U->n, density);
 		int *p_out = (int *) xmalloc((i64) (n - npiv) * sizeof(int));
-		struct spasm_csr *S = spasm_hip_schur(A, p + npiv, n - npiv, fact, density, fact->Ltmp, p_in, p_out);
+		struct spasm_csr *S;
+		{
+			Stopwatch sw(3);
+			S = spasm_hip_schur(A, p + npiv, n - npiv, fact, density, fact->Ltmp, p_in, p_out);
+		}
+		g_prof[5] += 1.0;
 		if (A != A0)
 			spasm_hip_csr_free((struct spasm_csr *) A);
 		A = S;
@@ -418,10 +450,13 @@ extern "C" struct spasm_lu *spasm_hip_echelonize(const struct spasm_csr *A0, str
 		const double aspect = (m - U->n > 0) ? (double) (n - npiv) / (m - U->n) : 0.0;
 		logmsg("[echelonize] finishing; density = %.3f; aspect ratio = %.1f\n", density, aspect);
 		if (opts->enable_tall_and_skinny && aspect > opts->tall_and_skinny_ratio) {
+			Stopwatch sw(4);
 			finish_lowrank(A, p + npiv, n - npiv, fact, opts);
 		} else if (opts->enable_dense && density > opts->sparsity_threshold) {
+			Stopwatch sw(4);
 			finish_dense(A, p + npiv, n - npiv, p_in, fact, opts);
 		} else if (opts->enable_GPLU) {
+			Stopwatch sw(6);
 			// The reference reduces the remaining rows one by one (GPLU, a sequential loop).  Here the
 			// remainder keeps going through structural rounds on the GPU: each one finds at least one
 			// pivot while the remainder is non-zero, so this terminates with the same row space.
@@ -461,6 +496,7 @@ extern "C" struct spasm_lu *spasm_hip_echelonize(const struct spasm_csr *A0, str
 	}
 	std::free(p);
 	std::free(p_in);
+	g_prof[0] = wtime() - start;
 	logmsg("[echelonize] done in %.1fs. Rank %d, %" PRId64 " nz in basis\n", wtime() - start, U->n, U->p[U->n]);
 	spasm_hip_csr_resize(U, U->n, m);
 	spasm_hip_csr_realloc(U, -1);

@@ -1,6 +1,7 @@
 // Launchers and C ABI of the sparse Schur complement (see include/spasm_hip.h).
 #include <algorithm>
 #include <cinttypes>
+#include <mutex>
 #include <vector>
 
 #include "device_types.h"
@@ -19,6 +20,13 @@ void launch_schur_group(const SchurArgs &a, unsigned char *scratch, int64_t slot
 void launch_schur_wave_dense(const SchurArgs &a, unsigned char *scratch, int64_t slot_bytes, int64_t off_bm, int64_t off_xn,
                              bool wide, uint32_t *dense_out, int64_t ldS, int blocks, hipStream_t stream);
 void launch_all_rows_to_list(int *list, int *count, int *row_len, int nrows, hipStream_t stream);
+void schur_group_variant_name(int r, bool wide, int waves, char *out, size_t cap);
+bool backsolve_eligible(int r, int Sm, int64_t nnz_u, int64_t *bytes);
+void backsolve_plan(const FactPlan &P, spasm_hip_dfact *F, hipStream_t stream);
+void backsolve_free(spasm_hip_dfact *F);
+void backsolve_build(const spasm_hip_dfact *F, hipStream_t stream);
+void launch_backsolve_apply(const SchurArgs &a, const spasm_hip_dfact *F, uint32_t *dense_out, int64_t ldS, hipStream_t stream);
+bool backsolve_wanted(const spasm_hip_dfact *F, bool other_path_forced);
 }  // namespace sh
 
 using namespace sh;
@@ -93,36 +101,65 @@ int cu_count()
 // ---- one-entry cache of the factor image for the host-pointer wrappers -------------------------
 // A round of the driver calls spasm_hip_schur_estimate_density, spasm_hip_schur and the dense-row
 // functions on the same (U, qinv): planning + uploading the image once is enough.  The key is the
-// shape of U plus a checksum of qinv and of the row pointers (U only ever grows).
+// device, the shape of U and a hash of ALL of U->p, U->j, U->x and qinv (one linear pass: far cheaper
+// than planning + uploading), so a factor edited in place or reallocated at the same address is never
+// mistaken for the cached one.  One mutex serialises the cache (host entry points may be called from
+// several threads).
 namespace sh {
 struct FactCacheKey {
-	const void *Uj = nullptr;
+	int device = -1;
 	int n = -1, m = -1;
 	i64 nnz = -1, prime = -1;
 	uint64_t sum = 0;
 	bool operator==(const FactCacheKey &o) const
 	{
-		return Uj == o.Uj && n == o.n && m == o.m && nnz == o.nnz && prime == o.prime && sum == o.sum;
+		return device == o.device && n == o.n && m == o.m && nnz == o.nnz && prime == o.prime && sum == o.sum;
 	}
 };
 static FactCacheKey g_fact_key;
 static spasm_hip_dfact *g_fact = nullptr;
+static std::mutex g_fact_mutex;
+
+static uint64_t hash_words(uint64_t h, const void *data, size_t bytes)
+{
+	// four independent multiply-xor lanes over 8-byte words (memory-bound), folded at the end
+	const uint64_t *w = static_cast<const uint64_t *>(data);
+	const size_t nw = bytes / 8;
+	uint64_t l0 = h, l1 = h ^ 0x9E3779B97F4A7C15ULL, l2 = h ^ 0xC2B2AE3D27D4EB4FULL, l3 = h ^ 0x165667B19E3779F9ULL;
+	size_t t = 0;
+	for (; t + 4 <= nw; t += 4) {
+		l0 = (l0 ^ w[t]) * 0x100000001B3ULL;
+		l1 = (l1 ^ w[t + 1]) * 0x100000001B3ULL;
+		l2 = (l2 ^ w[t + 2]) * 0x100000001B3ULL;
+		l3 = (l3 ^ w[t + 3]) * 0x100000001B3ULL;
+		l0 ^= l0 >> 29;
+	}
+	for (; t < nw; t++)
+		l0 = (l0 ^ w[t]) * 0x100000001B3ULL;
+	const unsigned char *tail = static_cast<const unsigned char *>(data) + nw * 8;
+	for (size_t b = 0; b < bytes % 8; b++)
+		l1 = (l1 ^ tail[b]) * 0x100000001B3ULL;
+	uint64_t r = l0;
+	r = (r ^ (l1 + (r << 6) + (r >> 2))) * 0x100000001B3ULL;
+	r = (r ^ (l2 + (r << 6) + (r >> 2))) * 0x100000001B3ULL;
+	r = (r ^ (l3 + (r << 6) + (r >> 2))) * 0x100000001B3ULL;
+	return r;
+}
 
 spasm_hip_dfact *cached_dfact(const struct spasm_csr *U, const int *qinv, hipStream_t stream)
 {
+	std::lock_guard<std::mutex> guard(g_fact_mutex);
 	FactCacheKey key;
-	key.Uj = U->j;
+	HIP_CHECK(hipGetDevice(&key.device));
 	key.n = U->n;
 	key.m = U->m;
 	key.nnz = U->p[U->n];
 	key.prime = U->field->p;
 	uint64_t h = 1469598103934665603ULL;
-	for (int j = 0; j < U->m; j++)
-		h = (h ^ (uint64_t) (uint32_t) qinv[j]) * 1099511628211ULL;
-	for (int i = 0; i <= U->n; i += (U->n > 4096 ? U->n / 4096 : 1))
-		h = (h ^ (uint64_t) U->p[i]) * 1099511628211ULL;
-	for (i64 t = 0; t < key.nnz; t += (key.nnz > 8192 ? key.nnz / 8192 : 1))
-		h = (h ^ ((uint64_t) (uint32_t) U->j[t] << 32 | (uint32_t) U->x[t])) * 1099511628211ULL;
+	h = hash_words(h, qinv, (size_t) U->m * sizeof(int));
+	h = hash_words(h, U->p, ((size_t) U->n + 1) * sizeof(i64));
+	h = hash_words(h, U->j, (size_t) key.nnz * sizeof(int));
+	h = hash_words(h, U->x, (size_t) key.nnz * sizeof(spasm_ZZp));
 	key.sum = h;
 	if (g_fact != nullptr && key == g_fact_key)
 		return g_fact;
@@ -131,6 +168,28 @@ spasm_hip_dfact *cached_dfact(const struct spasm_csr *U, const int *qinv, hipStr
 	g_fact = spasm_hip_dfact_create(U, qinv, stream);
 	g_fact_key = key;
 	return g_fact;
+}
+}  // namespace sh
+
+namespace sh {
+// Should this Schur complement go through the back-substituted image?  SPASM_HIP_BACKSOLVE=0 never, =1 whenever the
+// factor has a plan; default: whenever it has one, R fits comfortably in the free HBM and no other path was forced
+// (tests force tiers / the row-group kernel through their own knobs).
+bool backsolve_wanted(const spasm_hip_dfact *F, bool other_path_forced)
+{
+	const char *e = std::getenv("SPASM_HIP_BACKSOLVE");
+	const int mode = (e == nullptr || *e == 0) ? -1 : std::atoi(e);
+	if (mode == 0 || !F->bs.planned)
+		return false;
+	if (F->bs.d_R == nullptr) {
+		size_t free_b = 0, total_b = 0;
+		HIP_CHECK(hipMemGetInfo(&free_b, &total_b));
+		if ((size_t) F->bs.r * (size_t) F->bs.ldR * 4 > free_b / 2)
+			return false;
+	}
+	if (mode == 1)
+		return true;
+	return !other_path_forced;
 }
 }  // namespace sh
 
@@ -150,24 +209,9 @@ int spasm_hip_device_count(void)
 // --------------------------------------------------------------------------
 // factor image
 // --------------------------------------------------------------------------
-// Host part of the factor image: checks U, computes the elimination levels,
+// Host part of the factor image (sh::FactPlan, device_types.h): checks U, computes the elimination levels,
 // the column labels and the relabelled rows.  No GPU involved (unit-tested on
 // the CPU through spasm_hip_debug_plan).
-struct FactPlan {
-	int m = 0, r = 0, nlevels = 0;
-	int rpad = 0;                 // size of the label space of the pivots: every level starts on a multiple of 32
-	int maxdeg = 0;               // largest number of rows of U' that hold one given label
-	int ncomp = 0, comp_largest = 0;   // connected components of the pivot graph (labels that hold a row), size of the largest
-	i64 prime = 0;
-	std::vector<uint32_t> lab, lvl_end;     // lvl_end is indexed by (padded) label
-	std::vector<uint32_t> lvl_end_w;        // per 32-label word: first word of the next level
-	std::vector<int> q, kof, label_of_row;  // kof: label -> row of U, -1 for padding labels
-	std::vector<uint64_t> rp;               // rpad + 1
-	std::vector<uint2> ent;
-	std::vector<uint2> head;                // 4 entries per label: the first entries of the row, 0xFFFFFFFF-padded
-	std::vector<uint32_t> comp;             // per label: smallest label of its connected component in the pivot graph
-};
-
 static void plan_factor(const struct spasm_csr *U, const int *qinv, FactPlan &P)
 {
 	const int r = U->n, m = U->m;
@@ -248,6 +292,7 @@ static void plan_factor(const struct spasm_csr *U, const int *qinv, FactPlan &P)
 	std::vector<int> lvl_count((size_t) nlev + 1, 0);
 	for (int k = 0; k < r; k++)
 		lvl_count[hmax - height[k]] += 1;
+	P.lvl_count = lvl_count;
 	std::vector<int> lvl_start((size_t) nlev + 1, 0);
 	// (levels of fewer than 32 pivots are packed without padding, so that chains of tiny levels
 	// do not inflate the label space; a bitmap word shared by several levels is marked MIXED)
@@ -444,6 +489,11 @@ spasm_hip_dfact *spasm_hip_dfact_create(const struct spasm_csr *U, const int *qi
 	upload(F->d_lvl_end_w, P.lvl_end_w.data(), rpad / 32, stream);
 	upload(F->d_kof, P.kof.data(), rpad, stream);
 	HIP_CHECK(hipStreamSynchronize(stream));    // the host vectors die here
+	// back-substituted image (backsolve.hip): planned when the non-pivotal columns are few enough for dense rows
+	// of R; R itself is computed by the first Schur complement that wants it
+	int64_t bs_bytes = 0;
+	if (env_int("SPASM_HIP_BACKSOLVE", -1) != 0 && backsolve_eligible(r, m - r, F->nnz, &bs_bytes))
+		backsolve_plan(P, F, stream);
 	return F;
 }
 
@@ -451,6 +501,7 @@ void spasm_hip_dfact_destroy(spasm_hip_dfact *F)
 {
 	if (F == nullptr)
 		return;
+	backsolve_free(F);
 	(void) hipFree(F->d_lab);
 	(void) hipFree(F->d_q);
 	(void) hipFree(F->d_rp);
@@ -461,6 +512,12 @@ void spasm_hip_dfact_destroy(spasm_hip_dfact *F)
 	(void) hipFree(F->d_lvl_end_w);
 	(void) hipFree(F->d_kof);
 	delete F;
+}
+
+void spasm_hip_dfact_forget(spasm_hip_dfact *F)
+{
+	if (F != nullptr)
+		F->bs.valid = false;          // (the buffer stays: only the contents are forgotten)
 }
 
 int spasm_hip_dfact_rank(const spasm_hip_dfact *F) { return F->r; }
@@ -561,8 +618,11 @@ int dschur_impl(const spasm_hip_dcsr *A, const int *d_rows, int nrows, const spa
 	}
 	int group_slots = 0, group_waves = 1;
 	i64 group_slot_bytes = 0, group_off_bm = 0;
+	// S = A_n - A_p R from the back-substituted image (backsolve.hip) when the factor has one: no accumulator scratch
+	const bool want_bs = nrows > 0 && Lout == nullptr &&
+	                     backsolve_wanted(F, env_int("SPASM_HIP_FORCE_TIER", 0) != 0 || env_int("SPASM_HIP_GROUP", -1) >= 0);
 	// per-wave dense scratch, (re)allocated when the factor geometry needs more
-	{
+	if (!want_bs) {
 		i64 slot_bytes, off_bm, off_xn;
 		wave_dense_geometry(F->rpad, F->Sm, wide_dense, &slot_bytes, &off_bm, &off_xn);
 		int slots = env_int("SPASM_HIP_WAVE_SLOTS", cus * 32);
@@ -580,6 +640,17 @@ int dschur_impl(const spasm_hip_dcsr *A, const int *d_rows, int nrows, const spa
 		i64 need = slot_bytes * slots;
 		if (group_mode) {
 			group_geometry(F->rpad, F->Sm, wide_dense, &group_slot_bytes, &group_off_bm);
+			const int ngroups = (nrows + 63) / 64;
+			// a slice costs (rpad + Sm) * 256 B (512 B with 64-bit sums): on very wide matrices the budget holds
+			// fewer slices than there are CUs (or none) and the chip would idle -- the per-row tiers need 4 B per
+			// label per wave and run at full occupancy, so they take such batches
+			const i64 slices_that_fit = budget / group_slot_bytes;
+			if (slices_that_fit < 1 || (slices_that_fit < std::min<i64>(ngroups, cus / 2) && env_int("SPASM_HIP_GROUP", -1) < 0)) {
+				group_mode = 0;
+				probe = false;
+			}
+		}
+		if (group_mode) {
 			const int ngroups = (nrows + 63) / 64;
 			// four (two) waves per group while there are at most 3 (12) groups per CU: with few groups the run time is
 			// the chain of level rounds of one group, which the waves split between them (tools/probe_groups.py)
@@ -645,6 +716,24 @@ int dschur_impl(const spasm_hip_dcsr *A, const int *d_rows, int nrows, const spa
 		a.row_orig = Lout->row_orig;
 	}
 
+	bool used_bs = false, built_bs = false;
+	if (want_bs) {
+		// R is built on first use
+		used_bs = true;
+		group_mode = 0;
+		if (!F->bs.valid) {
+			backsolve_build(F, stream);
+			built_bs = true;
+		}
+		HIP_CHECK(hipEventRecord(W->ev[5], stream));
+		a.list = nullptr;
+		a.list_count = nullptr;
+		a.done_ctr = CTR_DONE2;
+		launch_backsolve_apply(a, F, nullptr, 0, stream);
+		HIP_CHECK(hipEventRecord(W->ev[3], stream));
+		HIP_CHECK(hipEventRecord(W->ev[4], stream));
+		goto eliminated;
+	}
 	if (nrows > 0) {
 		// tier 0: small LDS table, many waves per CU
 		a.list = nullptr;
@@ -781,7 +870,28 @@ eliminated:
 		HIP_CHECK(hipEventElapsedTime(&stats->ms_eliminate, W->ev[0], W->ev[1]));
 		stats->ms_tier0 = stats->ms_tier1 = stats->ms_tier2 = stats->ms_group = 0.0f;
 		stats->group_aborted = ctr[CTR_GROUP_ABORT] ? 1 : 0;
-		if (nrows > 0) {
+		stats->used_backsolve = used_bs ? 1 : 0;
+		stats->backsolve_built = built_bs ? 1 : 0;
+		stats->ms_backsolve = stats->ms_apply = 0.0f;
+		stats->bytes_backsolve = stats->bytes_apply = 0;
+		stats->kernel[0] = 0;
+		if (used_bs) {
+			const BsImage &B = F->bs;
+			if (built_bs) {
+				HIP_CHECK(hipEventElapsedTime(&stats->ms_backsolve, B.ev0, B.ev1));
+				// every row of R written once and read once per dependency; the entries of U' read once
+				stats->bytes_backsolve = ((i64) B.r + B.ndeps) * (i64) B.Sm * 4 + 8 * F->nnz;
+			}
+			HIP_CHECK(hipEventElapsedTime(&stats->ms_apply, W->ev[5], W->ev[1]));
+			// one row of R per pivotal entry of the reduced rows, the entries in and out, 20 B per row
+			stats->bytes_apply = (i64) ctr64[C64_ELIM] * (i64) B.Sm * 4 + 8 * ((i64) ctr64[C64_INPUT] + total) + 20 * (i64) nrows;
+			snprintf(stats->kernel, sizeof(stats->kernel), "%s", (stats->ms_backsolve > stats->ms_apply) ? "backsolve_kernel" : "bs_apply_kernel");
+		} else if (group_mode && !stats->group_aborted) {
+			schur_group_variant_name(F->rpad, wide_dense, group_waves, stats->kernel, sizeof(stats->kernel));
+		} else {
+			snprintf(stats->kernel, sizeof(stats->kernel), "schur_wave_dense_kernel<%s>", wide_dense ? "true" : "false");
+		}
+		if (nrows > 0 && !used_bs) {
 			if (group_mode)
 				HIP_CHECK(hipEventElapsedTime(&stats->ms_group, W->ev[0], W->ev[5]));
 			HIP_CHECK(hipEventElapsedTime(&stats->ms_tier0, group_mode ? W->ev[5] : W->ev[0], W->ev[3]));

@@ -707,9 +707,11 @@ template <typename V> __device__ __forceinline__ V ld_sc1(const V *p)
 	return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
-template <typename V> __device__ __forceinline__ void add_ff(V *p, uint32_t delta)
+// (SCOPE: wavefront for state private to one wave; workgroup when several waves of a workgroup update the same
+//  lines -- on gfx950 both are the same instruction, the scope only tells the compiler what may race)
+template <typename V, int SCOPE = __HIP_MEMORY_SCOPE_WAVEFRONT> __device__ __forceinline__ void add_ff(V *p, uint32_t delta)
 {
-	(void) __hip_atomic_fetch_add(p, (V) delta, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+	(void) __hip_atomic_fetch_add(p, (V) delta, __ATOMIC_RELAXED, SCOPE);
 }
 
 __device__ __forceinline__ void drain_vmem() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
@@ -1248,6 +1250,8 @@ struct GroupArgs {
 template <bool WIDE, bool LBM, int NW>
 __global__ __launch_bounds__(64 * NW) void schur_group_kernel(GroupArgs d)
 {
+	// several waves of the workgroup update the same lines and bitmap words when NW > 1
+	constexpr int SCOPE = (NW > 1) ? __HIP_MEMORY_SCOPE_WORKGROUP : __HIP_MEMORY_SCOPE_WAVEFRONT;
 	using V = typename Acc<WIDE>::type;
 	extern __shared__ __attribute__((aligned(16))) unsigned char lds_dyn[];
 	__shared__ uint32_t act[GR_ACT * NW];      // [0, GR_ACT): pending pivots of the level; output: one list per wave
@@ -1290,15 +1294,15 @@ __global__ __launch_bounds__(64 * NW) void schur_group_kernel(GroupArgs d)
 	auto bm_load = [&](int w) -> uint32_t { return LBM ? *(volatile lds_u32 *) (bm_l + w) : ld_sc1(&bm_g[w]); };
 	auto bm_or = [&](uint32_t c) {
 		if (LBM)
-			(void) __hip_atomic_fetch_or(bm_l + (c >> 5), 1u << (c & 31), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+			(void) __hip_atomic_fetch_or(bm_l + (c >> 5), 1u << (c & 31), __ATOMIC_RELAXED, SCOPE);
 		else
-			(void) __hip_atomic_fetch_or(&bm_g[c >> 5], 1u << (c & 31), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+			(void) __hip_atomic_fetch_or(&bm_g[c >> 5], 1u << (c & 31), __ATOMIC_RELAXED, SCOPE);
 	};
 	auto bm_clear = [&](int w, uint32_t bits) {
 		if (LBM)
-			(void) __hip_atomic_fetch_and(bm_l + w, ~bits, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+			(void) __hip_atomic_fetch_and(bm_l + w, ~bits, __ATOMIC_RELAXED, SCOPE);
 		else
-			(void) __hip_atomic_fetch_and(&bm_g[w], ~bits, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+			(void) __hip_atomic_fetch_and(&bm_g[w], ~bits, __ATOMIC_RELAXED, SCOPE);
 	};
 	auto act_load = [&](int t) -> uint32_t { return *(volatile lds_u32 *) (act_l + t); };
 	// non-pivotal labels (>= r) that received something: bits r.. of the same bitmap; the output only visits
@@ -1306,9 +1310,9 @@ __global__ __launch_bounds__(64 * NW) void schur_group_kernel(GroupArgs d)
 	const bool tl = LBM && d.touched_lds != 0;
 	auto touch = [&](uint32_t c) {
 		if (tl)
-			(void) __hip_atomic_fetch_or(bm_l + (c >> 5), 1u << (c & 31), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+			(void) __hip_atomic_fetch_or(bm_l + (c >> 5), 1u << (c & 31), __ATOMIC_RELAXED, SCOPE);
 		else
-			(void) __hip_atomic_fetch_or(&bm_g[c >> 5], 1u << (c & 31), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+			(void) __hip_atomic_fetch_or(&bm_g[c >> 5], 1u << (c & 31), __ATOMIC_RELAXED, SCOPE);
 	};
 	auto touched_load = [&](int w) -> uint32_t { return tl ? *(volatile lds_u32 *) (bm_l + nw + w) : ld_sc1(&bm_g[nw + w]); };
 	auto touched_clear = [&](int w) {
@@ -1350,7 +1354,7 @@ __global__ __launch_bounds__(64 * NW) void schur_group_kernel(GroupArgs d)
 			for (int64_t px = lo + wv; px < hi; px += NW) {
 				const uint32_t c = a.lab[a.Aj[px]];
 				const uint32_t v = reduce_sum(from_balanced(a.Ax[px], F), F);
-				add_ff(&X[(int64_t) c * 64 + lane], v);
+				add_ff<V, SCOPE>(&X[(int64_t) c * 64 + lane], v);
 				if (c < r)
 					bm_or(c);
 				else
@@ -1564,7 +1568,7 @@ __global__ __launch_bounds__(64 * NW) void schur_group_kernel(GroupArgs d)
 						const uint32_t c = __builtin_amdgcn_readlane(ch, 8 * u);
 						if (__ballot(raw[u] != 0) != 0) {
 							if (raw[u] != 0)
-								__hip_atomic_store(&X[(int64_t) c * 64 + lane], (V) 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+								__hip_atomic_store(&X[(int64_t) c * 64 + lane], (V) 0, __ATOMIC_RELAXED, SCOPE);
 							issued += 1;
 						}
 						const uint32_t v = vv[u];
@@ -1619,7 +1623,7 @@ __global__ __launch_bounds__(64 * NW) void schur_group_kernel(GroupArgs d)
 #pragma unroll
 							for (int q = 0; q < 4; q++)
 								if (tgt[q] != 0xFFFFFFFFu)
-									add_ff(&X[(int64_t) tgt[q] * 64 + lane], prod[q]);
+									add_ff<V, SCOPE>(&X[(int64_t) tgt[q] * 64 + lane], prod[q]);
 						}
 						issued += nvalid;      // some lane has v != 0: the instructions are issued
 						if (nvalid < 4)
@@ -1641,7 +1645,7 @@ __global__ __launch_bounds__(64 * NW) void schur_group_kernel(GroupArgs d)
 								const uint32_t t = __builtin_amdgcn_readlane(ot, e);
 								const uint32_t val = __builtin_amdgcn_readlane(oc, e);
 								if (v != 0)
-									add_ff(&X[(int64_t) t * 64 + lane], WIDE ? montmul(w_neg, val, F) : montmul_lazy(w_neg, val, F));
+									add_ff<V, SCOPE>(&X[(int64_t) t * 64 + lane], WIDE ? montmul(w_neg, val, F) : montmul_lazy(w_neg, val, F));
 							}
 							issued += n;
 							if (lane < n) {
@@ -1741,7 +1745,7 @@ __global__ __launch_bounds__(64 * NW) void schur_group_kernel(GroupArgs d)
 						d.dense_out[(int64_t) k * d.ldS + t0 + u] = reduce_sum(rv[u], F);
 					if (rv[u] != 0)
 						__hip_atomic_store(&Xn[(int64_t) (t0 + u) * 64 + lane], (V) 0, __ATOMIC_RELAXED,
-						                   __HIP_MEMORY_SCOPE_WAVEFRONT);
+						                   SCOPE);
 				}
 			}
 			for (int w = threadIdx.x; w < nwS; w += 64 * NW)
@@ -1842,7 +1846,7 @@ __global__ __launch_bounds__(64 * NW) void schur_group_kernel(GroupArgs d)
 				for (int u = 0; u < OB; u++) {
 					if (rv[u] == 0)
 						continue;
-					__hip_atomic_store(&Xn[(int64_t) tt[u] * 64 + lane], (V) 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+					__hip_atomic_store(&Xn[(int64_t) tt[u] * 64 + lane], (V) 0, __ATOMIC_RELAXED, SCOPE);
 					const uint32_t v = reduce_sum(rv[u], F);
 					if (v != 0 && fits) {
 						a.pool_j[wpos] = a.q[tt[u]];
@@ -1907,6 +1911,15 @@ static void launch_group_variant(const GroupArgs &d, int blocks, size_t lds_byte
 		configured = true;
 	}
 	hipLaunchKernelGGL((schur_group_kernel<WIDE, LBM, NW>), dim3(blocks), dim3(64 * NW), LBM ? lds_bytes : 0, stream, d);
+}
+
+// name of the variant launch_schur_group picks, as rocprofv3 prints it (the bench line quotes it)
+void schur_group_variant_name(int r, bool wide, int waves, char *out, size_t cap)
+{
+	const size_t piv_bytes = ((size_t) r / 32 + 1) * 4;
+	const bool lbm = piv_bytes <= (size_t) GR_LBM_MAX_BYTES;
+	snprintf(out, cap, "schur_group_kernel<%s,%s,%d>", wide ? "true" : "false", lbm ? "true" : "false",
+	         waves >= 4 ? 4 : waves >= 2 ? 2 : 1);
 }
 
 // waves: 1, 2 or 4 waves per row group (more when groups are few: the chain of a group is then the run time)

@@ -63,6 +63,10 @@ class DeviceFact:
         self.m = F.U.m
         self.prime = F.U.prime
 
+    def forget(self):
+        """drops derived state (the back-substituted rows): the next dschur pays for it again."""
+        lib().spasm_hip_dfact_forget(self._h)
+
     def close(self):
         if self._h:
             lib().spasm_hip_dfact_destroy(self._h)

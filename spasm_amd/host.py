@@ -194,6 +194,15 @@ def echelonize(A, opts=None):
     return F
 
 
+def echelonize_profile():
+    """seconds of the last echelonize() call: dict(total, pivot_search, density_estimates, sparse_schur, dense_finish,
+    sparse_rounds, structural_finish)."""
+    out = (C.c_double * 8)()
+    lib().spasm_hip_echelonize_profile(out)
+    return {"total": out[0], "pivot_search": out[1], "density_estimates": out[2], "sparse_schur": out[3],
+            "dense_finish": out[4], "sparse_rounds": int(out[5]), "structural_finish": out[6]}
+
+
 def rref(F):
     """spasm_rref (spasm_rref.c:25): returns (R, Rqinv)."""
     require_gpu("rref")

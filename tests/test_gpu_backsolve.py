@@ -1,0 +1,145 @@
+"""GPU parity of the back-substituted factor image (spasm_amd/csrc/backsolve.hip): S = A_n - A_p R with
+R = U_pp^-1 U_pn must be the matrix spasm_schur computes (spasm_schur.c:64-193), bit for bit.
+
+The shapes below aim at the kernel's own seams: chains longer than a chunk (768 rows), levels wider than a
+workgroup pass, rows with more than two dependencies outside their chunk, dependencies that straddle chunk
+boundaries, column counts around the 16-column slabs and 64-column tiles, 32-bit primes."""
+import numpy as np
+import pytest
+
+import spasm_amd
+
+pytestmark = pytest.mark.gpu
+
+
+def _as_product(A):
+    return spasm_amd.Csr(A.n, A.m, A.p, A.j, A.x, A.prime)
+
+
+def _fact(F):
+    return spasm_amd.Fact(_as_product(F.U), F.qinv)
+
+
+def _triangular_system(rng, p, npiv, nnon, nred, deps, reach, np_per_row, red_entries):
+    """npiv pivot rows (row k: pivot on column k, then `deps(k)` pivotal entries within `reach` columns to the
+    right and np_per_row entries on the nnon trailing non-pivotal columns), then nred rows to reduce."""
+    m = npiv + nnon
+    ti, tj, tx = [], [], []
+    for k in range(npiv):
+        cols = [k]
+        room = min(reach, npiv - k - 1)
+        d = min(deps(k), room)
+        if d > 0:
+            cols += list(k + 1 + rng.choice(room, size=d, replace=False))
+        if nnon > 0 and np_per_row > 0:
+            cols += list(npiv + rng.choice(nnon, size=min(np_per_row, nnon), replace=False))
+        ti += [k] * len(cols)
+        tj += [int(c) for c in cols]
+        tx += [1] + [int(v) for v in rng.integers(1, p, size=len(cols) - 1)]
+    for k in range(nred):
+        cols = rng.choice(m, size=min(red_entries, m), replace=False)
+        ti += [npiv + k] * len(cols)
+        tj += [int(c) for c in cols]
+        tx += [int(v) for v in rng.integers(1, p, size=len(cols))]
+    return npiv + nred, m, np.array(ti, np.int32), np.array(tj, np.int32), np.array(tx, np.int64)
+
+
+def _run(oracle, monkeypatch, p, n, m, ti, tj, tx, min_pivots, dense=False):
+    monkeypatch.setenv("SPASM_HIP_BACKSOLVE", "1")
+    A = oracle.compress(p, n, m, ti, tj, tx)
+    npiv, perm, F = oracle.pivots_extract_structural(A, oracle.empty_fact(A.n, A.m, p))
+    assert npiv >= min_pivots
+    rows = perm[npiv:]
+    want, p_out_want, _ = oracle.schur(A, rows, F)
+    S, p_out = spasm_amd.schur(_as_product(A), rows, _fact(F))
+    assert np.array_equal(p_out, p_out_want)
+    assert oracle.same_matrix(oracle.CSR(S.n, S.m, S.p, S.j, S.x, p), want)
+    for i in range(S.n):
+        jj, _ = S.row(i)
+        assert np.all(np.diff(jj) > 0)
+    return A, rows, F, want
+
+
+@pytest.mark.parametrize("p", [3, 42013, 4294967291])
+@pytest.mark.parametrize("nnon", [1, 15, 16, 17, 63, 64, 65, 300])
+def test_backsolve_column_counts(oracle, monkeypatch, p, nnon):
+    rng = np.random.default_rng(nnon)
+    sysm = _triangular_system(rng, p, npiv=500, nnon=nnon, nred=300, deps=lambda k: 2, reach=40, np_per_row=3, red_entries=5)
+    _run(oracle, monkeypatch, p, *sysm, min_pivots=400)
+
+
+@pytest.mark.parametrize("p", [42013, 4294967291])
+def test_backsolve_chain_longer_than_a_chunk(oracle, monkeypatch, p):
+    """one dependency on the next row: 2500 levels of one row each -- every chunk is a pure chain."""
+    rng = np.random.default_rng(5)
+    sysm = _triangular_system(rng, p, npiv=2500, nnon=40, nred=400, deps=lambda k: 1, reach=1, np_per_row=2, red_entries=4)
+    _run(oracle, monkeypatch, p, *sysm, min_pivots=2000)
+
+
+@pytest.mark.parametrize("p", [257, 42013, 4294967291])
+@pytest.mark.parametrize("ndeps,reach", [(3, 3000), (8, 3000), (40, 3000), (6, 100), (150, 800)])
+def test_backsolve_many_dependencies(oracle, monkeypatch, p, ndeps, reach):
+    """rows of U with many pivotal entries, near (inside the chunk) and far (beyond the two inline ones)."""
+    rng = np.random.default_rng(ndeps + reach)
+    sysm = _triangular_system(rng, p, npiv=3000, nnon=100, nred=500, deps=lambda k: ndeps, reach=reach, np_per_row=4, red_entries=6)
+    _run(oracle, monkeypatch, p, *sysm, min_pivots=1500)
+
+
+def test_backsolve_wide_levels(oracle, monkeypatch):
+    """no dependencies between most pivot rows: a few levels of thousands of rows (levels wider than a chunk)."""
+    p = 42013
+    rng = np.random.default_rng(8)
+    sysm = _triangular_system(rng, p, npiv=4000, nnon=200, nred=600, deps=lambda k: 1 if k % 7 == 0 else 0, reach=3000,
+                              np_per_row=5, red_entries=8)
+    _run(oracle, monkeypatch, p, *sysm, min_pivots=3000)
+
+
+def test_backsolve_long_input_rows(oracle, monkeypatch):
+    """rows to reduce with hundreds of pivotal entries (more than one pass of the apply kernel's list)."""
+    p = 42013
+    rng = np.random.default_rng(9)
+    sysm = _triangular_system(rng, p, npiv=2000, nnon=130, nred=200, deps=lambda k: 2, reach=50, np_per_row=3, red_entries=900)
+    _run(oracle, monkeypatch, p, *sysm, min_pivots=1500)
+
+
+@pytest.mark.parametrize("p", [42013, 4294967291])
+def test_backsolve_dense_rows(oracle, monkeypatch, p):
+    """spasm_schur_dense (spasm_schur.c:258-343) through the same image."""
+    monkeypatch.setenv("SPASM_HIP_BACKSOLVE", "1")
+    rng = np.random.default_rng(21)
+    n, m, ti, tj, tx = _triangular_system(rng, p, npiv=1200, nnon=90, nred=300, deps=lambda k: 2, reach=60, np_per_row=3, red_entries=6)
+    A = oracle.compress(p, n, m, ti, tj, tx)
+    npiv, perm, F = oracle.pivots_extract_structural(A, oracle.empty_fact(A.n, A.m, p))
+    rows = perm[npiv:]
+    want, q_want, p_out_want = oracle.schur_dense(A, rows, F)
+    got, q, p_out = spasm_amd.schur_dense(_as_product(A), rows, _fact(F))
+    assert np.array_equal(q, q_want) and np.array_equal(p_out, p_out_want)
+    assert np.array_equal(np.asarray(got, np.int64) % p, np.asarray(want, np.int64) % p)
+
+
+def test_backsolve_is_rebuilt_after_forget(oracle, monkeypatch):
+    """device API: the image is built by the first call, reused by the second, rebuilt after forget()."""
+    import torch
+    monkeypatch.setenv("SPASM_HIP_BACKSOLVE", "1")
+    p = 42013
+    rng = np.random.default_rng(33)
+    n, m, ti, tj, tx = _triangular_system(rng, p, npiv=1500, nnon=70, nred=400, deps=lambda k: 2, reach=30, np_per_row=3, red_entries=5)
+    A = oracle.compress(p, n, m, ti, tj, tx)
+    npiv, perm, F = oracle.pivots_extract_structural(A, oracle.empty_fact(A.n, A.m, p))
+    rows = perm[npiv:]
+    want, _, _ = oracle.schur(A, rows, F)
+    dA = spasm_amd.DeviceCsr.from_host(_as_product(A))
+    dF = spasm_amd.DeviceFact(_fact(F))
+    W = spasm_amd.SchurWorkspace(len(rows), A.m, 4 * want.nnz + (1 << 20))
+    drows = torch.from_numpy(np.ascontiguousarray(rows, np.int32)).cuda()
+    built = []
+    for step in range(3):
+        if step == 2:
+            dF.forget()
+        S, st = spasm_amd.dschur(dA, drows, dF, W)
+        assert st.status == 0 and st.used_backsolve == 1 and st.nnz == want.nnz
+        assert st.kernel.decode() in ("backsolve_kernel", "bs_apply_kernel")
+        built.append(st.backsolve_built)
+        H = S.to_host()
+        assert oracle.same_matrix(oracle.CSR(H.n, H.m, H.p, H.j, H.x, p), want)
+    assert built == [1, 0, 1]

@@ -41,9 +41,18 @@ def _check(oracle, S_gpu, p_out_gpu, S_want, p_out_want, sorted_rows=True):
             assert np.all(np.diff(jj) > 0)
 
 
+@pytest.fixture(params=["auto", "rows"])
+def schur_path(request, monkeypatch):
+    """auto: the library chooses (factors with few non-pivotal columns go through the back-substituted image,
+    backsolve.hip); rows: the row-by-row elimination kernels only."""
+    if request.param == "rows":
+        monkeypatch.setenv("SPASM_HIP_BACKSOLVE", "0")
+    return request.param
+
+
 @pytest.mark.parametrize("name", ALL_TEST_MATRICES)
 @pytest.mark.parametrize("p", ALL_MODULI)
-def test_schur_reference_matrices(oracle, name, p):
+def test_schur_reference_matrices(oracle, name, p, schur_path):
     A, npiv, perm, F = _round0(oracle, name, p)
     rows = perm[npiv:]
     want, p_out_want, _ = oracle.schur(A, rows, F)
@@ -68,7 +77,7 @@ def test_schur_large_table_and_dense_tiers(oracle, name, p, tier, monkeypatch):
 
 @pytest.mark.parametrize("name", ["mat364.sms", "medium.sms", "m1.sms", "trefethen_500.sms", "l1.sms", "G2.sms"])
 @pytest.mark.parametrize("p", [257, 42013, 189812507])
-def test_schur_second_round(oracle, name, p):
+def test_schur_second_round(oracle, name, p, schur_path):
     """factor with rows from two rounds: old rows of U meet columns that became pivotal later."""
     A, npiv, perm, F = _round0(oracle, name, p)
     S1, p_out1, _ = oracle.schur(A, perm[npiv:], F)
@@ -90,7 +99,7 @@ def _random_sparse(rng, n, m, per_row, p):
 
 @pytest.mark.parametrize("p", [42013, 4294967291])
 @pytest.mark.parametrize("shape", [(3000, 2000, 3), (1500, 4000, 6), (6000, 1200, 2)])
-def test_schur_random_fill_in(oracle, shape, p):
+def test_schur_random_fill_in(oracle, shape, p, schur_path):
     """random matrices: heavy fill-in drives rows through every tier; full rows-vs-oracle equality."""
     n, m, per_row = shape
     rng = np.random.default_rng(n + m)
@@ -210,6 +219,7 @@ def test_row_group_kernel_gives_up_on_unrelated_rows(oracle, regroup, monkeypatc
     batch -- same matrix either way."""
     import torch
     monkeypatch.setenv("SPASM_HIP_GROUP_REGROUP", regroup)
+    monkeypatch.setenv("SPASM_HIP_BACKSOLVE", "0")
     monkeypatch.setenv("SPASM_HIP_GROUP_WATCH_ROWS", "0")
     monkeypatch.setenv("SPASM_HIP_GROUP_MIN_PIVOTS", "20000")      # the batch is small: judge early
     p = 42013

@@ -1,0 +1,136 @@
+"""The BASELINE workloads at full size on the GPU, against the compiled reference (oracle/_ref) or the oracle.
+
+mk13.b5 is regenerated from its definition (tools/workloads.py); the other BASELINE matrices run when their
+.sms files are found under $SPASM_DATA (default tests/data/) and are reported as skipped otherwise.
+
+What is compared (tools/rank.c:88-92 orientation, spasm_schur.c:64-193):
+  * the round-0 Schur complement of EVERY non-pivotal row, computed by spasm_hip_dschur on the full batch, once per
+    elimination path (back-substituted image; row-group kernel);
+  * a deterministic sample of >= 2000 of its rows, spread over the whole batch (so over all row groups), entry for
+    entry against the reference's spasm_schur on the same rows;
+  * its total number of entries against the reference's on the whole batch (real reference only: the single-thread
+    oracle would take minutes);
+  * the rank through the drop-in tools/rank binary.
+"""
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+from conftest import ROOT
+
+import spasm_amd
+
+sys.path.insert(0, os.path.join(ROOT, "tools"))
+import workloads  # noqa: E402
+
+pytestmark = pytest.mark.gpu
+
+PRIME = 42013
+RANKS = {"mk13.b5": 134211}          # oracle/orc_echelonize on the CPU (single thread), see DESIGN.md section 5
+
+
+def _available(name):
+    c = workloads.config(name)
+    return c["generator"] is not None or workloads.find_data(c["file"]) is not None
+
+
+def _device_rows(S, ks):
+    """rows ks of a DeviceCsr as host (j, x) pairs."""
+    Sp = S.p.cpu().numpy()
+    out = []
+    for k in ks:
+        lo, hi = int(Sp[k]), int(Sp[k + 1])
+        out.append((S.j[lo:hi].cpu().numpy(), S.x[lo:hi].cpu().numpy()))
+    return Sp, out
+
+
+def _full_schur(A, rows, F, env):
+    import torch
+    saved = {k: os.environ.get(k) for k in env}
+    os.environ.update(env)
+    try:
+        dA = spasm_amd.DeviceCsr.from_host(A)
+        dF = spasm_amd.DeviceFact(F)
+        drows = torch.from_numpy(np.ascontiguousarray(rows, np.int32)).cuda()
+        pool = 4 * A.nnz + (1 << 24)
+        while True:
+            W = spasm_amd.SchurWorkspace(len(rows), A.m, pool)
+            S, st = spasm_amd.dschur(dA, drows, dF, W, fetch=True)
+            if st.status == 0:
+                break
+            W.close()
+            pool *= 2
+        return S, st, W, dF
+    finally:
+        for k, v in saved.items():
+            if v is None:
+                os.environ.pop(k, None)
+            else:
+                os.environ[k] = v
+
+
+@pytest.mark.parametrize("name", [c["name"] for c in workloads.CONFIGS])
+@pytest.mark.parametrize("path", ["backsolve", "row_groups"])
+def test_round0_schur_of_baseline_workload(oracle, name, path):
+    if not _available(name):
+        pytest.skip("%s: data file absent (SPASM_DATA=%s)" % (name, workloads.data_dir()))
+    A, rows, F, source = workloads.round0(name, PRIME)
+    env = {"SPASM_HIP_BACKSOLVE": "1"} if path == "backsolve" else {"SPASM_HIP_BACKSOLVE": "0", "SPASM_HIP_GROUP": "1"}
+    S, st, W, dF = _full_schur(A, rows, F, env)
+    if path == "backsolve" and not st.used_backsolve:
+        pytest.skip("%s: the factor is not eligible for the back-substituted image" % name)
+    assert st.rows == len(rows) and (st.used_backsolve == 1) == (path == "backsolve")
+    Ao = oracle.CSR(A.n, A.m, A.p, A.j, A.x, PRIME)
+    Fo = oracle.Fact(oracle.CSR(F.U.n, F.U.m, F.U.p, F.U.j, F.U.x, PRIME), F.qinv)
+    # >= 2000 rows spread evenly over the batch, first and last included
+    count = min(len(rows), 2048)
+    ks = np.unique(np.linspace(0, len(rows) - 1, count).astype(np.int64))
+    if oracle.ref_available():
+        want, p_out = oracle.ref_schur(Ao, rows[ks], Fo, threads=os.cpu_count() or 1)
+        order = {int(r): t for t, r in enumerate(p_out)}          # the reference emits rows in thread-arrival order
+    else:
+        want, p_out, _ = oracle.schur(Ao, rows[ks], Fo)
+        order = {int(r): t for t, r in enumerate(p_out)}
+    Sp, got = _device_rows(S, ks)
+    for k, (gj, gx) in zip(ks, got):
+        wj, wx = want.row(order[int(rows[k])])
+        o = np.argsort(wj)
+        assert np.array_equal(gj, wj[o]) and np.array_equal(np.asarray(gx, np.int64) % PRIME, np.asarray(wx[o], np.int64) % PRIME), \
+            "row %d of the batch (row %d of A) differs" % (k, rows[k])
+        assert np.all(np.diff(gj) > 0)
+    assert int(Sp[-1]) == st.nnz
+    if oracle.ref_available() and len(rows) <= 400000:
+        full, _ = oracle.ref_schur(Ao, rows, Fo, threads=os.cpu_count() or 1)
+        assert full.nnz == st.nnz
+    W.close()
+    dF.close()
+
+
+@pytest.mark.parametrize("name", [c["name"] for c in workloads.CONFIGS])
+def test_rank_tool_on_baseline_workload(name, tmp_path):
+    """tools/rank with the options of the BASELINE config; rank against the CPU value where one is recorded."""
+    if not _available(name):
+        pytest.skip("%s: data file absent (SPASM_DATA=%s)" % (name, workloads.data_dir()))
+    c = workloads.config(name)
+    path = workloads.find_data(c["file"])
+    if path is None:
+        A, _ = workloads.load_matrix(name, PRIME, tall=False)
+        path = str(tmp_path / (name + ".sms"))
+        workloads.save_sms(A, path)
+    elif path.endswith(".gz"):
+        path, _ = workloads._open_plain(path)
+    tool = os.path.join(ROOT, "tools", "rank")
+    if not os.path.exists(tool):
+        subprocess.run(["make", "-C", os.path.join(ROOT, "tools")], check=True)
+    env = dict(os.environ, SPASM_HIP_VERBOSE="0")
+    out = subprocess.run([tool, "--matrix", path, "--modulus", str(PRIME)] + c["rank_args"], capture_output=True, text=True,
+                         env=env, timeout=3000)
+    assert out.returncode == 0, out.stderr[-2000:]
+    rank = int(out.stdout.strip().split()[-1])
+    if name in RANKS:
+        assert rank == RANKS[name]
+    else:
+        assert rank > 0

@@ -1,0 +1,193 @@
+"""Workloads of BASELINE.json: where they come from and how tools/rank prepares them.
+
+Five matrices are named there.  One of them (mk13.b5) has a closed-form
+definition and is regenerated here; the other four are data files of the
+hpac / SuiteSparse collections that cannot be fetched in this environment.
+They are looked up under $SPASM_DATA (default: tests/data/) as
+<name>.sms[.gz]; `discover()` says which are present.  Nothing is ever
+substituted silently: an absent file is reported as absent.
+
+Naming of the matching-complex boundaries (hpac "Homology/mk"): mkN.bK maps the
+(K+1)-edge matchings of the complete graph K_N (rows) to its K-edge matchings
+(columns), K+1 entries +-1 per row.  Checked against the published sizes:
+mk9.b1 378 x 36 (756 nnz), mk12.b3 51975 x 13860 (207900 nnz), mk13.b5
+135135 x 270270 (810810 nnz).
+"""
+import gzip
+import itertools
+import os
+import shutil
+import tempfile
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+PRIME = 42013
+
+# BASELINE.json "configs", in order.  `file` is the data file looked up under $SPASM_DATA; `generator`
+# regenerates the matrix when the file is absent; `rank_args` are the tools/rank options of the config.
+CONFIGS = [
+    {"name": "kneser_10_4_1", "file": "kneser_10_4_1.sms", "generator": None, "rank_args": [],
+     "what": "tools/rank plumbing (CPU reference config)"},
+    {"name": "mk13.b5", "file": "mk13.b5.sms", "generator": ("mk", 13, 5), "rank_args": [],
+     "what": "sparse Schur complement, single GPU (the bench line)"},
+    {"name": "GL7d19", "file": "GL7d19.sms", "generator": None, "rank_args": ["--dense-threshold", "0.01"],
+     "what": "sparse rounds + dense tail on the matrix cores"},
+    {"name": "relat9", "file": "relat9.sms", "generator": None, "rank_args": [],
+     "what": "Schur row batches sharded over 8 GPUs"},
+    {"name": "M0,6-D9", "file": "M0,6-D9.sms", "generator": None, "rank_args": ["--no-greedy-pivot-search"],
+     "what": "fill-in stress case, greedy pivot search disabled, 8 GPUs"},
+]
+
+
+def data_dir():
+    return os.environ.get("SPASM_DATA", os.path.join(ROOT, "tests", "data"))
+
+
+def find_data(filename):
+    """path of <filename> or <filename>.gz under $SPASM_DATA, or None."""
+    for cand in (filename, filename + ".gz"):
+        path = os.path.join(data_dir(), cand)
+        if os.path.exists(path):
+            return path
+    return None
+
+
+def config(name):
+    for c in CONFIGS:
+        if c["name"] == name:
+            return c
+    return None
+
+
+def discover():
+    """[(config, 'file' | 'generated' | 'absent', path or None)] for every BASELINE config."""
+    out = []
+    for c in CONFIGS:
+        path = find_data(c["file"])
+        if path is not None:
+            out.append((c, "file", path))
+        elif c["generator"] is not None:
+            out.append((c, "generated", None))
+        else:
+            out.append((c, "absent", None))
+    return out
+
+
+# --------------------------------------------------------------------------
+# matching complexes
+# --------------------------------------------------------------------------
+def _matchings(nv, size):
+    edges = list(itertools.combinations(range(nv), 2))
+    masks = [(1 << a) | (1 << b) for a, b in edges]
+    ne = len(edges)
+    out, cur = [], []
+
+    def rec(start, used):
+        if len(cur) == size:
+            out.append(tuple(cur))
+            return
+        for e in range(start, ne):
+            if masks[e] & used:
+                continue
+            cur.append(e)
+            rec(e + 1, used | masks[e])
+            cur.pop()
+    rec(0, 0)
+    return out
+
+
+def mk_boundary(nv, K):
+    """mk<nv>.b<K> in its published orientation: rows = (K+1)-edge matchings of K_nv, columns = K-edge
+    matchings, entry (-1)^t for the face that drops the t-th edge.  Returns (n, m, ti, tj, tx)."""
+    big = _matchings(nv, K + 1)
+    small = _matchings(nv, K)
+    index = {s: i for i, s in enumerate(small)}
+    ti, tj, tx = [], [], []
+    for r, s in enumerate(big):
+        for t in range(K + 1):
+            ti.append(r)
+            tj.append(index[s[:t] + s[t + 1:]])
+            tx.append(1 if t % 2 == 0 else -1)
+    return len(big), len(small), np.array(ti, np.int32), np.array(tj, np.int32), np.array(tx, np.int64)
+
+
+def _triplets_of(name):
+    kind = name.split(".")[0]
+    if kind.startswith("mk") and ".b" in name:
+        return mk_boundary(int(kind[2:]), int(name.split(".b")[1]))
+    raise ValueError("no generator for %s" % name)
+
+
+def _open_plain(path):
+    """SMS files may be gzipped: the C loader wants a plain file."""
+    if not path.endswith(".gz"):
+        return path, None
+    tmp = tempfile.NamedTemporaryFile(prefix="spasm_amd_", suffix=".sms", delete=False)
+    with gzip.open(path, "rb") as src:
+        shutil.copyfileobj(src, tmp)
+    tmp.close()
+    return tmp.name, tmp.name
+
+
+def load_matrix(name, prime=PRIME, tall=True):
+    """(A, source): the matrix as tools/rank works on it (tools/rank.c:76-92: load, transpose when
+    n < m unless asked not to).  source = 'file:<path>' or 'generated'.  Raises FileNotFoundError for a
+    BASELINE matrix that is neither on disk nor regenerable."""
+    import spasm_amd
+    c = config(name)
+    path = find_data(c["file"] if c else name + ".sms")
+    if path is not None:
+        plain, tmp = _open_plain(path)
+        try:
+            A = spasm_amd.load(plain, prime, transpose_if_wide=tall)
+        finally:
+            if tmp:
+                os.unlink(tmp)
+        return A, "file:" + path
+    if c is not None and c["generator"] is None:
+        raise FileNotFoundError("%s not found under %s (set SPASM_DATA)" % (c["file"], data_dir()))
+    n, m, ti, tj, tx = _triplets_of(name)
+    if tall and n < m:
+        ti, tj = tj, ti
+        n, m = m, n
+    return spasm_amd.compress(prime, n, m, ti, tj, tx), "generated"
+
+
+def round0(name, prime=PRIME, cache=True):
+    """(A, rows, F, source): the matrix, its structural pivots (single-threaded search: the same pivots on
+    every rank and in every run) and the non-pivotal rows -- the input of the first Schur complement."""
+    import spasm_amd
+    path = os.path.join(tempfile.gettempdir(), "spasm_amd_r0_v3_%s_%d.npz" % (name.replace("/", "_"), prime))
+    if cache and os.path.exists(path):
+        z = np.load(path, allow_pickle=False)
+        A = spasm_amd.Csr(int(z["n"]), int(z["m"]), z["Ap"], z["Aj"], z["Ax"], prime)
+        F = spasm_amd.Fact(spasm_amd.Csr(int(z["r"]), int(z["m"]), z["Up"], z["Uj"], z["Ux"], prime), z["qinv"])
+        return A, z["rows"], F, str(z["source"])
+    A, source = load_matrix(name, prime)
+    saved = os.environ.get("SPASM_HIP_THREADS")
+    os.environ["SPASM_HIP_THREADS"] = "1"
+    try:
+        npiv, perm, F = spasm_amd.pivots_extract_structural(A, spasm_amd.empty_fact(A.m, prime))
+    finally:
+        if saved is None:
+            os.environ.pop("SPASM_HIP_THREADS", None)
+        else:
+            os.environ["SPASM_HIP_THREADS"] = saved
+    rows = np.ascontiguousarray(perm[npiv:], np.int32)
+    if cache:
+        tmp = "%s.%d.tmp.npz" % (path, os.getpid())          # ranks build concurrently: publish atomically
+        np.savez(tmp, n=A.n, m=A.m, Ap=A.p, Aj=A.j, Ax=A.x, r=F.U.n, Up=F.U.p, Uj=F.U.j, Ux=F.U.x, qinv=F.qinv,
+                 rows=rows, source=np.array(source))
+        os.replace(tmp, path)
+    return A, rows, F, source
+
+
+def save_sms(A, path):
+    """writes a Csr as SMS (1-based triplets, terminated by 0 0 0)."""
+    with open(path, "w") as f:
+        f.write("%d %d M\n" % (A.n, A.m))
+        for i in range(A.n):
+            for px in range(A.p[i], A.p[i + 1]):
+                f.write("%d %d %d\n" % (i + 1, A.j[px] + 1, A.x[px]))
+        f.write("0 0 0\n")
