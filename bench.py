@@ -1,23 +1,30 @@
 #!/usr/bin/env python3
 """bench.py -- rows eliminated per second on the sparse Schur-complement hot path.
 
-Workload (BASELINE.json configs[1]): mk13.b5, the 135135 x 270270 boundary
-matrix of the matching complex of K13 (hpac "Homology" collection), mod 42013,
-processed the way tools/rank does: transposed to 270270 x 135135, structural
-pivots found on the host, then ONE STEP = the Schur complement of every
-non-pivotal row w.r.t. those pivots (spasm_schur, spasm_schur.c:64) -- here
-spasm_hip_dschur with A, the factor and the row list already resident in HBM.
-There is no network, so the matrix is regenerated from its definition (rows =
-5-edge matchings of K13, columns = 4-edge matchings, entries +-1); `data` says
-so.  Its dimensions and nnz (1,351,350) are those of the published file.
+Workload (BASELINE.json configs[1]): mk13.b5, the 135135 x 270270 boundary matrix of the matching complex
+of K13 (hpac "Homology" collection; rows = 6-edge matchings, columns = 5-edge matchings, 810,810 entries
++-1), mod 42013, processed the way tools/rank does (tools/rank.c:76-104): transposed to 270270 x 135135,
+structural pivots found on the host, then ONE STEP = the Schur complement of every non-pivotal row w.r.t.
+those pivots (spasm_schur, spasm_schur.c:64) -- here spasm_hip_dschur with A, the factor image and the row
+list already resident in HBM.  Derived factor state (the back-substituted rows R = U_pp^-1 U_pn) is
+forgotten before every step, so a step pays for all of spasm_schur.  There is no network: the matrix is
+regenerated from its definition (tools/workloads.py) unless $SPASM_DATA/mk13.b5.sms exists; `data` says which.
+The other BASELINE configs are data files; `configs` in the output says which are present.
 
-Prints ONE JSON line (rank 0).  N > 1 (launched by torch.distributed.run): the
-row batch is sharded over the ranks, each rank reduces its slice, the slices
-are reassembled on every rank with an all-gatherv over RCCL (strong scaling).
+Prints ONE JSON line (rank 0).  N > 1 (launched by torch.distributed.run): the row batch is sharded over
+the ranks, each rank reduces its slice, the slices are reassembled on every rank with an all-gatherv over
+RCCL (strong scaling: the matrix is fixed).
+
+Everything in the `roofline` object is measured in this run (HIP events of the library on the launch
+stream, the kernels' own work counters) except `traffic`, which rocprofv3 has to collect in separate
+passes: it is quoted from profiles/r02_traffic.json (written by tools/profile.sh) only when that file was
+recorded for the same kernel on the same workload, with its path in `traffic_source`; otherwise null.
 """
 import argparse
+import ctypes as C
 import json
 import os
+import statistics
 import sys
 import time
 
@@ -25,20 +32,12 @@ import numpy as np
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tools"))
 os.environ.setdefault("SPASM_HIP_VERBOSE", "0")
 
 PRIME = 42013
-
-
-# --------------------------------------------------------------------------
-# workload
-# --------------------------------------------------------------------------
-def build_workload(name):
-    """(A, rows, F, source) -- tools/workloads.py: the matrix as tools/rank prepares it, its structural pivots
-    (single-threaded search: the same pivots on every rank and in every run), the non-pivotal rows."""
-    sys.path.insert(0, os.path.join(ROOT, "tools"))
-    import workloads
-    return workloads.round0(name, PRIME)
+HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8 TB/s
+MFMA_I8_PEAK_TOPS = 5000.0     # dense i8 (the guide's ~5 P op/s class; AMD's sparsity figures are not used)
 
 
 # --------------------------------------------------------------------------
@@ -76,6 +75,72 @@ def cpu_baseline(A, rows, F, budget_s=20.0):
             "sample": "first %d of %d non-pivotal rows, spasm_schur, %.1f s" % (count, len(rows), t)}
 
 
+def quoted_traffic(kernel, workload, rows):
+    """HBM bytes per launch of `kernel` from the rocprofv3 PMC passes of this round, if they were recorded on
+    this workload.  (value, fetch_doubled_upper_bound, source) or (None, None, None)."""
+    path = os.path.join(ROOT, "profiles", "r02_traffic.json")
+    if not os.path.exists(path):
+        return None, None, None
+    try:
+        t = json.load(open(path))
+    except ValueError:
+        return None, None, None
+    if t.get("workload") != workload or t.get("rows") != rows:
+        return None, None, None
+    k = t.get("kernels", {}).get(kernel)
+    if not k:
+        return None, None, None
+    return k.get("bytes_per_launch"), k.get("bytes_per_launch_fetch_doubled"), "profiles/r02_traffic.json"
+
+
+def dense_tail_probe(torch, spasm_amd, dev, n=4096, m=32768):
+    """the dense tail on its own: RREF mod 42013 of a random full-rank n x m block resident in HBM
+    (spasm_hip_drref); useful multiply-adds of the trailing updates per second against the i8 MFMA peak."""
+    L = spasm_amd.lib()
+    g = torch.Generator(device=dev)
+    g.manual_seed(1)
+    A0 = torch.randint(0, PRIME, (n, m), dtype=torch.int64, device=dev, generator=g).to(torch.int32)
+    piv = torch.zeros(m, dtype=torch.int32, device=dev)
+    best = None
+    r = 0
+    for _ in range(3):
+        A = A0.clone()
+        torch.cuda.synchronize()
+        ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        ev0.record()
+        r = L.spasm_hip_drref(PRIME, n, m, A.data_ptr(), m, piv.data_ptr(), 0)
+        ev1.record()
+        torch.cuda.synchronize()
+        ms = ev0.elapsed_time(ev1)
+        best = ms if best is None else min(best, ms)
+    A = A0.clone()
+    ms_upd = C.c_float(0)
+    r = L.spasm_hip_drref_timed(PRIME, n, m, A.data_ptr(), m, piv.data_ptr(), 0, 1, C.byref(ms_upd))
+    macs, c, left = 0, 0, r
+    while left > 0 and c < m:
+        k = min(64, left)
+        macs += n * k * max(m - c - 64, 0)
+        c += 64
+        left -= k
+    tmacs_total = macs / (best * 1e-3) / 1e12
+    tmacs_upd = macs / (ms_upd.value * 1e-3) / 1e12 if ms_upd.value > 0 else None
+    out = {"what": "spasm_hip_drref, random full-rank block mod %d" % PRIME, "shape": [n, m], "rank": int(r),
+           "ms": best, "useful_Tmacs_per_s": tmacs_total,
+           "update_kernels_ms_serialised": ms_upd.value, "update_kernels_Tmacs_per_s": tmacs_upd,
+           # 4 int8 digit products per useful multiply-add (two base-256 digits each side), 2 ops per product
+           "mfma_i8_frac_of_peak": (8 * tmacs_upd / MFMA_I8_PEAK_TOPS) if tmacs_upd else None}
+    path = os.path.join(ROOT, "profiles", "r02_dense_tail.json")
+    if os.path.exists(path):
+        try:
+            q = json.load(open(path))
+            if q.get("shape") == [n, m]:
+                out["mfma_busy_pct"] = q.get("mfma_busy_pct")
+                out["mfma_busy_source"] = "profiles/r02_dense_tail.json"
+        except ValueError:
+            pass
+    return out
+
+
 # --------------------------------------------------------------------------
 def main():
     ap = argparse.ArgumentParser()
@@ -84,10 +149,13 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--workload", default="mk13.b5")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-extras", action="store_true",
+                    help="skip the row-by-row comparison, the dense-tail probe and the end-to-end runs")
     args = ap.parse_args()
 
     import torch
     import spasm_amd
+    import workloads
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
@@ -114,7 +182,14 @@ def main():
             os.dup2(saved_stdout, 1)
             os.close(saved_stdout)
 
-    A, rows, F, source = build_workload(args.workload)
+    try:
+        A, rows, F, source = workloads.round0(args.workload, PRIME)
+    except FileNotFoundError as e:
+        if rank == 0:
+            print(json.dumps({"metric": "rows eliminated/sec (sparse Schur complement, mod 42013)", "value": None,
+                              "unit": "rows/s", "n_gpus": world, "data": "absent", "config": {"workload": args.workload},
+                              "error": str(e)}))
+        return
     from spasm_amd.dist import shard_rows, allgatherv_csr
     my_rows = shard_rows(rows, rank, world)
     dA = spasm_amd.DeviceCsr.from_host(A, dev)
@@ -142,30 +217,44 @@ def main():
                 assert full.n == len(rows)
         return st
 
+    def run_steps(count):
+        """count timed steps: (seconds, per-kernel device ms summed over the steps, their algorithmic bytes, last stats)"""
+        ms = {}
+        by = {}
+        st = None
+        t0 = time.perf_counter()
+        for _ in range(count):
+            st = step()
+            if st.used_backsolve:
+                parts = (("backsolve_kernel (+ memset, bs_init_kernel)", st.ms_backsolve, st.bytes_backsolve),
+                         ("bs_apply_kernel", st.ms_apply, st.bytes_apply))
+            else:
+                # algorithmic bytes of the reference's own algorithm on a dense x (DESIGN.md section 4): per streamed
+                # entry of U' 8 B read + 8 B read-modify-write of x; per elimination 16 B of row extent + 4 B
+                # coefficient; per input/output entry 8 B; 20 B per reduced row
+                algo = 16 * st.entries_streamed + 8 * (st.input_entries + st.nnz) + 20 * st.eliminations + 20 * st.rows
+                name = st.kernel.decode()
+                parts = ((name, st.ms_group if st.used_group_kernel and not st.group_aborted else st.ms_tier2, algo),
+                         ("schur_lds_kernel<1024>", st.ms_tier0, 0), ("schur_lds_kernel<8192>", st.ms_tier1, 0))
+            parts += (("scan_* + gather_rows_kernel", st.ms_finalize, 16 * st.nnz + 12 * st.rows),)
+            for name, m_, b_ in parts:
+                ms[name] = ms.get(name, 0.0) + m_
+                by[name] = b_
+        torch.cuda.synchronize()
+        return time.perf_counter() - t0, ms, by, st
+
     for _ in range(args.warmup):
         step()
     torch.cuda.synchronize()
     if dist is not None:
         dist.barrier()
     torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    k_ms, k_elim, k_stream, k_in, k_out = 0.0, 0, 0, 0, 0
-    t_tiers = [0.0, 0.0, 0.0, 0.0, 0.0]
-    rows_by_tier = (0, 0, 0)
-    for _ in range(args.steps):
-        st = step()
-        k_ms += st.ms_group if st.used_group_kernel else st.ms_tier2
-        for q, v in enumerate((st.ms_tier0, st.ms_tier1, st.ms_tier2, st.ms_finalize, st.ms_group)):
-            t_tiers[q] += v
-        rows_by_tier = (st.rows_lds, st.rows_lds_big, st.rows_dense)
-        group = bool(st.used_group_kernel)
-        k_elim, k_stream, k_in, k_out = st.eliminations, st.entries_streamed, st.input_entries, st.nnz
-        k_gp = st.group_pivots
-    torch.cuda.synchronize()
+    t_begin = time.perf_counter()
+    _, ms_sum, bytes_of, st = run_steps(args.steps)
     if dist is not None:
         dist.barrier()
     torch.cuda.synchronize()
-    elapsed = time.perf_counter() - t0
+    elapsed = time.perf_counter() - t_begin
     if dist is not None:
         t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -174,29 +263,30 @@ def main():
     if rank == 0:
         total_rows = len(rows)
         ms_per_step = 1e3 * elapsed / args.steps
-        # algorithmic bytes per launch (DESIGN.md "Byte accounting"), the traffic of the reference's own
-        # algorithm on a dense x: per streamed entry of U' 8 B read + 8 B read-modify-write of x;
-        # per elimination 16 B of row extent + 4 B coefficient; per input/output entry 8 B;
-        # 20 B per reduced row (row id, two row pointers)
-        algo = 16 * k_stream + 8 * (k_in + k_out) + 20 * k_elim + 20 * len(my_rows)
-        kernel_ms = k_ms / args.steps
-        achieved = algo / (kernel_ms * 1e-3) / 1e9 if kernel_ms > 0 else 0.0
-        traffic = None
-        atomic_info = None
-        tfile = os.path.join(ROOT, "profiles", "traffic_r01.json")
-        if os.path.exists(tfile) and world == 1:          # (measured on the whole batch: says nothing about a rank's slice)
-            tj = json.load(open(tfile))
-            traffic = tj.get("schur_group_kernel_bytes_per_launch" if group else "schur_wave_dense_kernel_bytes_per_launch")
-            if group and tj.get("schur_group_kernel_atomic_requests_per_launch"):
-                # what actually bounds the kernel: 64-byte atomic requests to the memory side
-                atomic_info = {"requests_per_launch": tj["schur_group_kernel_atomic_requests_per_launch"],
-                               "achieved_per_s": tj["schur_group_kernel_atomic_requests_per_launch"] / (kernel_ms * 1e-3),
-                               "measured_ceiling_per_s": tj.get("atomic_request_ceiling_per_s"),
-                               "source": "rocprofv3 TCC_ATOMIC_sum (profiles/r01_g_atomic_counters.txt); ceiling: tools/microbench_atomics.hip"}
-        # waves per row group: the library's own rule (schur_api.hip), for the kernel name rocprofv3 shows
-        cus = torch.cuda.get_device_properties(0).multi_processor_count
-        ngroups_rank = (len(my_rows) + 63) // 64
-        group_waves = int(os.environ.get("SPASM_HIP_GROUP_WAVES", 4 if ngroups_rank <= 3 * cus else 2 if ngroups_rank <= 12 * cus else 1))
+        kernels = {}
+        for name, total in ms_sum.items():
+            k_ms = total / args.steps
+            if k_ms <= 0.0005 or (k_ms < 0.02 and bytes_of[name] == 0):
+                continue
+            kernels[name] = {"ms": k_ms, "algorithmic_bytes": int(bytes_of[name]),
+                             "GB_per_s": bytes_of[name] / (k_ms * 1e-3) / 1e9}
+        dom_name = max(kernels, key=lambda k: kernels[k]["ms"])
+        dom = kernels[dom_name]
+        kernel_id = dom_name.split(" ")[0]
+        traffic, traffic_hi, traffic_src = (None, None, None)
+        if world == 1:
+            traffic, traffic_hi, traffic_src = quoted_traffic(kernel_id, args.workload, total_rows)
+        step_bytes = sum(k["algorithmic_bytes"] for k in kernels.values())
+        roof = {"bound": "hbm", "achieved": dom["GB_per_s"], "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                "frac": dom["GB_per_s"] / HBM_PEAK_GBS, "traffic": traffic,
+                "kernel": kernel_id, "kernel_ms": dom["ms"], "algorithmic_bytes": dom["algorithmic_bytes"],
+                "what_frac_is": "algorithmic bytes of this kernel (DESIGN.md section 4) / its device time / 8 TB/s",
+                "hbm_frac": (traffic / (dom["ms"] * 1e-3) / 1e9 / HBM_PEAK_GBS) if traffic else None,
+                "hbm_frac_fetch_doubled": (traffic_hi / (dom["ms"] * 1e-3) / 1e9 / HBM_PEAK_GBS) if traffic_hi else None,
+                "traffic_source": traffic_src,
+                "kernels": kernels,
+                "step_algorithmic_bytes": int(step_bytes),
+                "step_GB_per_s": step_bytes / (ms_per_step * 1e-3) / 1e9}
         out = {
             "metric": "rows eliminated/sec (sparse Schur complement, mod 42013)",
             "value": total_rows / (elapsed / args.steps),
@@ -209,39 +299,63 @@ def main():
             "scaling": "strong",
             "vs_baseline": None,
             "dtype": "u32",
-            "data": "synthetic (mk13.b5 regenerated from the definition of the matching complex of K13; no network)",
+            "data": ("synthetic (%s regenerated from the definition of the matching complex; no network)" % args.workload)
+            if source == "generated" else source,
             "config": {"workload": "%s (%dx%d, %d nnz) mod %d, round-0 Schur complement of %d non-pivotal rows "
                                    "w.r.t. %d structural pivots" % (args.workload, A.n, A.m, A.nnz, PRIME,
                                                                    total_rows, F.U.n),
                        "rows_per_step": total_rows, "pivots": int(F.U.n), "levels": dF.levels,
-                       "eliminations_per_step": int(k_elim), "schur_nnz": int(k_out), "group_pivots": int(k_gp),
+                       "non_pivotal_columns": int(A.m - F.U.n), "schur_nnz": int(st.nnz),
+                       "path": "back-substituted factor image" if st.used_backsolve else "row-by-row elimination",
                        "sharding": "rows over %d rank(s)%s" % (world, ", all-gatherv of S" if use_dist else "")},
-            "roofline": {"bound": "hbm", "achieved": achieved, "peak": 8000.0, "unit": "GB/s",
-                         "frac": achieved / 8000.0, "traffic": traffic,
-                         "kernel": ("schur_group_kernel<false,true,%d>" % group_waves) if group else "schur_wave_dense_kernel<false>",
-                         "kernel_ms": kernel_ms,
-                         "algorithmic_bytes": int(algo),
-                         "atomic_requests": atomic_info,
-                         "ms_by_kernel": {"schur_lds_kernel<1024>": t_tiers[0] / args.steps,
-                                          "schur_lds_kernel<8192>": t_tiers[1] / args.steps,
-                                          "schur_wave_dense_kernel": t_tiers[2] / args.steps,
-                                          "schur_group_kernel": t_tiers[4] / args.steps,
-                                          "scan+gather_rows": t_tiers[3] / args.steps},
-                         "rows_by_kernel": {"lds_small": rows_by_tier[0], "lds_big": rows_by_tier[1],
-                                            ("row_group" if group else "wave_dense"): rows_by_tier[2]},
-                         "lane_efficiency": (k_elim / (64.0 * k_gp)) if (group and k_gp) else None},
+            "roofline": roof,
         }
-        if world == 1:
-            # the other half of the headline metric: wall-clock time of the whole rank computation
-            # (host I/O excluded: the matrix is already in memory), default options of tools/rank
+        extras = world == 1 and not args.no_extras
+        if extras and st.used_backsolve:
+            # the same batch through the row-by-row elimination kernels (what round 1 measured), a few steps
+            os.environ["SPASM_HIP_BACKSOLVE"] = "0"
+            try:
+                for _ in range(2):
+                    step()
+                n_alt = max(3, min(5, args.steps))
+                el2, ms2, by2, st2 = run_steps(n_alt)
+            finally:
+                os.environ.pop("SPASM_HIP_BACKSOLVE", None)
+            name2 = st2.kernel.decode()
+            k_ms2 = ms2[name2] / n_alt
+            out["row_by_row_path"] = {
+                "what": "same batch with SPASM_HIP_BACKSOLVE=0 (%d steps)" % n_alt, "ms_per_step": 1e3 * el2 / n_alt,
+                "rows_per_s": total_rows / (el2 / n_alt), "kernel": name2, "kernel_ms": k_ms2,
+                "eliminations_per_step": int(st2.eliminations), "entries_streamed": int(st2.entries_streamed),
+                "group_pivots": int(st2.group_pivots),
+                "lane_efficiency": (st2.eliminations / (64.0 * st2.group_pivots)) if st2.group_pivots else None,
+                "algorithmic_bytes": int(by2[name2]), "GB_per_s": by2[name2] / (k_ms2 * 1e-3) / 1e9,
+                "frac": by2[name2] / (k_ms2 * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                "same_nnz": bool(st2.nnz == st.nnz)}
+            tr2 = quoted_traffic(name2, args.workload, total_rows)
+            if tr2[0]:
+                out["row_by_row_path"].update({"traffic": tr2[0], "hbm_frac": tr2[0] / (k_ms2 * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                                               "traffic_source": tr2[2]})
+        if extras:
+            out["dense_tail"] = dense_tail_probe(torch, spasm_amd, dev)
+            # the other half of the headline metric: wall-clock time of the whole rank computation (host I/O excluded:
+            # the matrix is already in memory), default options of tools/rank, five calls
             os.environ.pop("SPASM_HIP_THREADS", None)
-            t0 = time.perf_counter()
-            fact = spasm_amd.echelonize(A)
-            cold = time.perf_counter() - t0          # first call of the process: one-time allocations included
-            t0 = time.perf_counter()
-            fact = spasm_amd.echelonize(A)
-            out["end_to_end"] = {"what": "spasm_hip_echelonize on the same matrix, default options", "rank": int(fact.U.n),
-                                 "seconds": time.perf_counter() - t0, "seconds_first_call": cold}
+            runs = []
+            for _ in range(5):
+                t0 = time.perf_counter()
+                fact = spasm_amd.echelonize(A)
+                runs.append((time.perf_counter() - t0, spasm_amd.echelonize_profile(), int(fact.U.n)))
+            secs = [r[0] for r in runs]
+            med = sorted(runs, key=lambda r: r[0])[len(runs) // 2]
+            out["end_to_end"] = {"what": "spasm_hip_echelonize on the same matrix, default options, 5 calls",
+                                 "rank": med[2], "ranks_agree": len({r[2] for r in runs}) == 1,
+                                 "seconds_min": min(secs), "seconds_median": statistics.median(secs), "seconds_all": secs,
+                                 "split_of_median_call": med[1]}
+        out["configs"] = [{"name": c["name"], "status": status, "what": c["what"],
+                           "bench": "python bench.py --workload %s" % c["name"],
+                           "rank": "./tools/rank --matrix $SPASM_DATA/%s --modulus %d %s" % (c["file"], PRIME, " ".join(c["rank_args"]))}
+                          for c, status, _ in workloads.discover()]
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(A, rows, F)
         print(json.dumps(out))

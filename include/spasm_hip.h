@@ -118,6 +118,11 @@ spasm_ZZp spasm_hip_ZZp_mul(const spasm_field F, spasm_ZZp a, spasm_ZZp b);     
 spasm_ZZp spasm_hip_ZZp_inverse(const spasm_field F, spasm_ZZp a);                 /* spasm_ZZp.c:67 */
 spasm_ZZp spasm_hip_ZZp_axpy(const spasm_field F, spasm_ZZp a, spasm_ZZp x, spasm_ZZp y);  /* spasm_ZZp.c:76 */
 
+void *spasm_hip_malloc(i64 size);                                                  /* spasm_util.c:65 */
+void *spasm_hip_calloc(i64 count, i64 size);                                       /* spasm_util.c:73 */
+void *spasm_hip_realloc(void *ptr, i64 size);                                      /* spasm_util.c:81 */
+i64 spasm_hip_nnz(const struct spasm_csr *A);                                      /* spasm_util.c:16 */
+double spasm_hip_wtime(void);                                                      /* spasm_util.c:9 */
 struct spasm_csr *spasm_hip_csr_alloc(int n, int m, i64 nzmax, i64 prime, bool with_values);   /* spasm_util.c:86 */
 void spasm_hip_csr_realloc(struct spasm_csr *A, i64 nzmax);                        /* spasm_util.c:122 */
 void spasm_hip_csr_resize(struct spasm_csr *A, int n, int m);                      /* spasm_util.c:177 */

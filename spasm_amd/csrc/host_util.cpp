@@ -73,7 +73,20 @@ using namespace sh;
 
 extern "C" {
 
-const char *spasm_hip_version(void) { return "spasm-hip 0.1 (gfx950)"; }
+const char *spasm_hip_version(void) { return "spasm-hip 0.2 (gfx950)"; }
+
+// spasm_malloc / spasm_calloc / spasm_realloc (spasm_util.c:65-83): die instead of returning NULL
+void *spasm_hip_malloc(i64 size) { return xmalloc(size); }
+void *spasm_hip_calloc(i64 count, i64 size)
+{
+	void *q = std::calloc(count > 0 ? (size_t) count : 1, size > 0 ? (size_t) size : 1);
+	if (q == nullptr)
+		die("calloc failed (%lld x %lld bytes)", (long long) count, (long long) size);
+	return q;
+}
+void *spasm_hip_realloc(void *ptr, i64 size) { return xrealloc(ptr, size); }
+i64 spasm_hip_nnz(const struct spasm_csr *A) { return A->p[A->n]; }          // spasm_util.c:16
+double spasm_hip_wtime(void) { return wtime(); }                             // spasm_util.c:9
 
 void spasm_hip_field_init(i64 p, spasm_field F)
 {

@@ -64,3 +64,68 @@ def test_echelonize_tool_outputs_sms(oracle, name):
         for i in range(A.n):
             pat, x = oracle.solve_row(U, qinv, A, i)
             assert not any(x[j] != 0 and qinv[j] < 0 for j in pat)
+
+
+# --------------------------------------------------------------------------
+# the reference's own tool sources, unmodified, bound to the HIP library (oracle/Makefile `dropin`)
+# --------------------------------------------------------------------------
+REF_BIN = os.path.join(ROOT, "oracle", "_ref")
+
+
+def _ref_tool(name):
+    path = os.path.join(REF_BIN, name)
+    if not os.path.exists(path):
+        pytest.skip("%s was not built (needs the reference tree at build time)" % name)
+    return path
+
+
+@pytest.mark.parametrize("name", ["mat364.sms", "medium.sms", "rectangular_h.sms", "singular.sms"])
+def test_reference_rank_c_linked_against_the_facade(oracle, name):
+    """tools/rank.c of the reference, unmodified: its spasm_echelonize is the GPU one."""
+    tool = _ref_tool("ref_rank_facade")
+    A = oracle.load_sms(matrix_path(name), 42013)
+    want = oracle.echelonize(A).U.n
+    env = dict(os.environ, SPASM_HIP_VERBOSE="0")
+    out = subprocess.run([tool, "--matrix", matrix_path(name), "--modulus", "42013"], capture_output=True, text=True, env=env,
+                         timeout=300)
+    assert out.returncode == 0, out.stderr[-2000:]
+    assert ("rank = %d" % want) in out.stderr
+
+
+def test_reference_rank_c_certificate_through_the_facade(oracle, tmp_path):
+    """--certificate: the reference's certificate code (spasm_certificate.c) on top of the L and U of the GPU echelonization,
+    verified by the reference's own spasm_certificate_rank_verify (tools/rank.c:107-128)."""
+    tool = _ref_tool("ref_rank_facade")
+    env = dict(os.environ, SPASM_HIP_VERBOSE="0")
+    out = subprocess.run([tool, "--matrix", matrix_path("mat364.sms"), "--modulus", "42013", "--certificate"],
+                         capture_output=True, text=True, env=env, timeout=300, cwd=str(tmp_path))
+    assert out.returncode == 0, out.stderr[-3000:]
+    assert "rank = " in out.stderr
+
+
+@pytest.mark.parametrize("name", ["mat364.sms", "singular2.sms", "rectangular_l.sms"])
+def test_reference_echelonize_c_compiled_with_the_shim(oracle, name):
+    tool = _ref_tool("ref_echelonize_shim")
+    A = oracle.load_sms(matrix_path(name), 42013)
+    want = oracle.echelonize(A).U.n
+    env = dict(os.environ, SPASM_HIP_VERBOSE="0")
+    with open(matrix_path(name)) as f:
+        out = subprocess.run([tool], stdin=f, capture_output=True, text=True, env=env, timeout=300)
+    assert out.returncode == 0, out.stderr[-2000:]
+    n, m, kind = out.stdout.split("\n")[0].split()
+    assert (int(n), int(m)) == (want, A.m)
+
+
+def test_reference_kernel_c_linked_against_the_facade(oracle):
+    """tools/kernel.c: spasm_echelonize + spasm_kernel from the GPU library; K * A^T == 0 is checked on the output."""
+    tool = _ref_tool("ref_kernel_facade")
+    p = 42013
+    name = "singular.sms"
+    A = oracle.load_sms(matrix_path(name), p)
+    env = dict(os.environ, SPASM_HIP_VERBOSE="0")
+    with open(matrix_path(name)) as f:
+        out = subprocess.run([tool, "--modulus", str(p)], stdin=f, capture_output=True, text=True, env=env, timeout=300)
+    assert out.returncode == 0, out.stderr[-2000:]
+    lines = out.stdout.strip().split("\n")
+    kn, km, _ = lines[0].split()
+    assert int(kn) > 0

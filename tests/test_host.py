@@ -216,3 +216,60 @@ def test_bitonic_network_of_the_row_regrouping_sorts():
                     s >>= 1
             size <<= 1
         assert np.all(np.diff(keys) >= 0), npad
+
+
+# --------------------------------------------------------------------------
+# drop-in: the reference's own tool sources, unmodified, bound to the HIP library
+# --------------------------------------------------------------------------
+REF_TOOLS = "/root/reference/tools"
+DROPIN = {name: os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "oracle", "_ref", name)
+          for name in ("ref_echelonize_shim", "ref_rank_facade", "ref_kernel_facade")}
+
+
+def _undefined(path):
+    import subprocess
+    out = subprocess.run(["nm", "-D", "--undefined-only", path], check=True, capture_output=True, text=True).stdout
+    return {line.split()[-1] for line in out.splitlines() if "spasm" in line}
+
+
+def _defined(path):
+    import subprocess
+    out = subprocess.run(["nm", "-D", "--defined-only", path], check=True, capture_output=True, text=True).stdout
+    return {line.split()[-1] for line in out.splitlines() if "spasm" in line}
+
+
+@pytest.mark.skipif(not os.path.isdir(REF_TOOLS), reason="the reference tree is not on this machine")
+def test_reference_tools_compile_and_link_against_the_hip_library():
+    """tools/echelonize.c through the -include shim (every spasm_* call becomes its spasm_hip_ twin: the prototypes of
+    include/spasm_hip.h must agree with the reference's spasm.h or this does not compile), tools/rank.c and
+    tools/kernel.c through the facade library (hot path from the GPU library, the rest from the reference's)."""
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    subprocess.run(["make", "-C", os.path.join(root, "oracle"), "dropin"], check=True, capture_output=True)
+    for path in DROPIN.values():
+        assert os.path.exists(path), path
+    # shim build: nothing un-prefixed is left, and every symbol it wants is exported by libspasm_hip.so
+    want = _undefined(DROPIN["ref_echelonize_shim"])
+    assert want and all(s.startswith("spasm_hip_") for s in want), want
+    assert want <= _defined(spasm_amd.LIB_PATH)
+    # facade build: the hot-path symbols can only come from the facade (the reference library here is built without
+    # spasm_echelonize.c / spasm_ffpack.cpp), the facade forwards to libspasm_hip.so
+    facade = os.path.join(os.path.dirname(spasm_amd.LIB_PATH), "libspasm_hip_facade.so")
+    provided = _defined(facade)
+    for tool in ("ref_rank_facade", "ref_kernel_facade"):
+        need = _undefined(DROPIN[tool])
+        assert "spasm_echelonize" in need and "spasm_echelonize" in provided
+        ref_lib = _defined(os.path.join(os.path.dirname(DROPIN[tool]), "libspasm_ref.so"))
+        assert "spasm_echelonize" not in ref_lib
+        assert need <= (provided | ref_lib), need - (provided | ref_lib)
+    assert _undefined(facade) <= _defined(spasm_amd.LIB_PATH)
+
+
+@pytest.mark.skipif(not os.path.exists(DROPIN["ref_echelonize_shim"]), reason="drop-in programs not built")
+def test_reference_tool_bound_to_the_hip_library_dies_loudly_without_a_gpu():
+    import subprocess
+    if spasm_amd.device_count() > 0:
+        pytest.skip("a GPU is present")
+    with open(matrix_path("small.sms")) as f:
+        out = subprocess.run([DROPIN["ref_echelonize_shim"]], stdin=f, capture_output=True, text=True, timeout=120)
+    assert out.returncode != 0 and "no HIP device" in out.stderr

@@ -1,35 +1,87 @@
 #!/usr/bin/env python3
-"""Condenses a tools/profile.sh output directory: per-kernel time table from the kernel trace and
-FETCH_SIZE / WRITE_SIZE per launch of each kernel (raw counter values; see DESIGN.md for the gfx950
-correction of FETCH_SIZE)."""
+"""Condenses one tools/profile.sh pass directory: per-kernel time table from the kernel trace, FETCH_SIZE / WRITE_SIZE
+per launch of each kernel, and <dir>/traffic.json in the form bench.py quotes (profiles/r02_traffic.json).
+
+FETCH_SIZE / WRITE_SIZE are in KiB.  MI355X_MICROARCH.md (HBM): on gfx950 FETCH_SIZE reports half of the bytes of
+wide (16 B per lane) coalesced reads and is uncalibrated for other widths; these kernels read 4 B per lane, so the raw
+sum is given as `bytes_per_launch` and the sum with FETCH doubled as an upper bound.
+
+  summarize_profile.py <dir>                      summary on stdout, <dir>/traffic.json
+  summarize_profile.py --merge a.json b.json      union of the `kernels` of several passes on stdout
+"""
 import csv
 import glob
+import json
 import os
+import re
 import sys
 from collections import defaultdict
 
-out = sys.argv[1]
-
 
 def short(name):
-    return name.split("(")[0].replace("void ", "").replace("sh::", "")[:60]
+    """kernel name as the library reports it in spasm_hip_schur_stats.kernel"""
+    name = name.replace("void ", "").replace("sh::", "").replace("(anonymous namespace)::", "")
+    name = name.split("(")[0]
+    return re.sub(r"\s+", "", name)[:80]
 
 
-rows = defaultdict(list)
-for f in glob.glob(os.path.join(out, "trace", "**", "*kernel_trace.csv"), recursive=True):
-    for r in csv.DictReader(open(f)):
-        rows[short(r["Kernel_Name"])].append((int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3)
-print("== kernel trace (us) ==")
-print("%-62s %8s %12s %12s %12s" % ("kernel", "calls", "total_us", "avg_us", "max_us"))
-for k, v in sorted(rows.items(), key=lambda kv: -sum(kv[1])):
-    print("%-62s %8d %12.1f %12.1f %12.1f" % (k, len(v), sum(v), sum(v) / len(v), max(v)))
-
-for ctr, sub in (("FETCH_SIZE", "pmc_fetch"), ("WRITE_SIZE", "pmc_write")):
-    acc = defaultdict(list)
-    for f in glob.glob(os.path.join(out, sub, "**", "*counter_collection.csv"), recursive=True):
+def main():
+    if sys.argv[1] == "--merge":
+        merged = None
+        for p in sys.argv[2:]:
+            if not os.path.exists(p):
+                continue
+            t = json.load(open(p))
+            if merged is None:
+                merged = t
+            elif (t.get("workload"), t.get("rows")) == (merged.get("workload"), merged.get("rows")):
+                for k, v in t["kernels"].items():
+                    merged["kernels"].setdefault(k, v)
+        print(json.dumps(merged, indent=1))
+        return
+    out = sys.argv[1]
+    rows = defaultdict(list)
+    for f in glob.glob(os.path.join(out, "trace", "**", "*kernel_trace.csv"), recursive=True):
         for r in csv.DictReader(open(f)):
-            if r.get("Counter_Name") == ctr:
-                acc[short(r["Kernel_Name"])].append(float(r["Counter_Value"]))
-    print("\n== %s per launch (counter units: KiB) ==" % ctr)
-    for k, v in sorted(acc.items(), key=lambda kv: -sum(kv[1])):
-        print("%-62s launches %5d  avg %16.1f  max %16.1f" % (k, len(v), sum(v) / len(v), max(v)))
+            rows[short(r["Kernel_Name"])].append((int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3)
+    print("== kernel trace (us) ==")
+    print("%-62s %8s %12s %12s %12s" % ("kernel", "calls", "total_us", "avg_us", "max_us"))
+    for k, v in sorted(rows.items(), key=lambda kv: -sum(kv[1])):
+        print("%-62s %8d %12.1f %12.1f %12.1f" % (k, len(v), sum(v), sum(v) / len(v), max(v)))
+    per = {}
+    for ctr, sub in (("FETCH_SIZE", "pmc_fetch"), ("WRITE_SIZE", "pmc_write")):
+        acc = defaultdict(list)
+        for f in glob.glob(os.path.join(out, sub, "**", "*counter_collection.csv"), recursive=True):
+            for r in csv.DictReader(open(f)):
+                if r.get("Counter_Name") == ctr:
+                    acc[short(r["Kernel_Name"])].append(float(r["Counter_Value"]))
+        print("\n== %s per launch (counter units: KiB) ==" % ctr)
+        for k, v in sorted(acc.items(), key=lambda kv: -sum(kv[1])):
+            print("%-62s launches %5d  avg %16.1f  max %16.1f" % (k, len(v), sum(v) / len(v), max(v)))
+            per.setdefault(k, {})[ctr] = sum(v) / len(v) * 1024.0
+            per[k]["launches_" + ctr] = len(v)
+    bench = {}
+    try:
+        for line in open(os.path.join(out, "bench_trace.json")):
+            if line.startswith("{"):
+                bench = json.loads(line)
+    except (OSError, ValueError):
+        pass
+    cfg = bench.get("config", {})
+    traffic = {"source": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes) of `bench.py --steps 3 --warmup 1 "
+                         "--no-cpu-baseline --no-extras`, tools/profile.sh; raw counter sums (KiB * 1024)",
+               "workload": (cfg.get("workload") or "").split(" ")[0], "rows": cfg.get("rows_per_step"),
+               "bench_line_under_trace": {k: bench.get(k) for k in ("value", "ms_per_step")},
+               "kernels": {}}
+    for k, v in per.items():
+        if "FETCH_SIZE" in v and "WRITE_SIZE" in v:
+            traffic["kernels"][k] = {"fetch_bytes_raw": v["FETCH_SIZE"], "write_bytes_raw": v["WRITE_SIZE"],
+                                     "bytes_per_launch": v["FETCH_SIZE"] + v["WRITE_SIZE"],
+                                     "bytes_per_launch_fetch_doubled": 2 * v["FETCH_SIZE"] + v["WRITE_SIZE"],
+                                     "launches": v["launches_FETCH_SIZE"],
+                                     "avg_us_in_trace": (sum(rows[k]) / len(rows[k])) if k in rows else None}
+    json.dump(traffic, open(os.path.join(out, "traffic.json"), "w"), indent=1)
+
+
+if __name__ == "__main__":
+    main()
