@@ -165,22 +165,37 @@ def main():
     dev = torch.device("cuda", local)
     dist = None
     use_dist = world > 1 or os.environ.get("SPASM_BENCH_FORCE_DIST") == "1"   # the flag lets a 1-GPU box run the RCCL path
+    class stdout_to_stderr:
+        """RCCL prints a version banner on stdout when a communicator is created: stdout carries the one JSON line only, so
+        the banner goes to stderr (file descriptor level: it is printed by the C library)"""
+
+        def __enter__(self):
+            sys.stdout.flush()
+            self.saved = os.dup(1)
+            os.dup2(2, 1)
+
+        def __exit__(self, *exc):
+            sys.stdout.flush()
+            C.CDLL(None).fflush(None)          # the banner sits in the C library's stdio buffer when stdout is a pipe
+            os.dup2(self.saved, 1)
+            os.close(self.saved)
+
+    comm = None
     if use_dist:
         import torch.distributed as dist
-        # RCCL prints a version banner on stdout when the communicator is created: stdout carries the one JSON line
-        # only, so the banner goes to stderr (file descriptor level: it is printed by the C library)
-        sys.stdout.flush()
-        saved_stdout = os.dup(1)
-        os.dup2(2, 1)
-        try:
+        from spasm_amd.dist import Comm
+        with stdout_to_stderr():
             dist.init_process_group("nccl", device_id=dev)
             warm = torch.zeros(1, device=dev)
             dist.all_reduce(warm)
             torch.cuda.synchronize()
-        finally:
-            sys.stdout.flush()
-            os.dup2(saved_stdout, 1)
-            os.close(saved_stdout)
+
+            # the library's own RCCL communicator (C ABI, section (M)); its id travels through torch.distributed
+            def exchange(raw):
+                box = [raw]
+                dist.broadcast_object_list(box, src=0)
+                return box[0]
+            comm = Comm(rank, world, exchange)
 
     try:
         A, rows, F, source = workloads.round0(args.workload, PRIME)
@@ -190,7 +205,7 @@ def main():
                               "unit": "rows/s", "n_gpus": world, "data": "absent", "config": {"workload": args.workload},
                               "error": str(e)}))
         return
-    from spasm_amd.dist import shard_rows, allgatherv_csr
+    from spasm_amd.dist import shard_rows
     my_rows = shard_rows(rows, rank, world)
     dA = spasm_amd.DeviceCsr.from_host(A, dev)
     dF = spasm_amd.DeviceFact(F)
@@ -211,9 +226,9 @@ def main():
     def step():
         dF.forget()          # a step is the whole of spasm_schur: derived factor state (the back-substituted rows) is rebuilt
         with torch.cuda.stream(stream):
-            S, st = spasm_amd.dschur(dA, drows, dF, W, stream=stream.cuda_stream, fetch=use_dist)
+            S, st = spasm_amd.dschur(dA, drows, dF, W, stream=stream.cuda_stream, fetch=False)
             if use_dist:
-                full = allgatherv_csr(S, dist)
+                full = comm.allgatherv(W, A.m, PRIME, stream=stream.cuda_stream)      # all-gatherv of S on the devices
                 assert full.n == len(rows)
         return st
 
@@ -226,8 +241,10 @@ def main():
         for _ in range(count):
             st = step()
             if st.used_backsolve:
-                parts = (("backsolve_kernel (+ memset, bs_init_kernel)", st.ms_backsolve, st.bytes_backsolve),
-                         ("bs_apply_kernel", st.ms_apply, st.bytes_apply))
+                names = (st.kernel.decode(), st.kernel_other.decode())
+                build_name = [x for x in names if x.startswith("backsolve_kernel")][0]
+                apply_name = [x for x in names if x.startswith("bs_apply_kernel")][0]
+                parts = ((build_name, st.ms_backsolve, st.bytes_backsolve), (apply_name, st.ms_apply, st.bytes_apply))
             else:
                 # algorithmic bytes of the reference's own algorithm on a dense x: per streamed
                 # entry of U' 8 B read + 8 B read-modify-write of x; per elimination 16 B of row extent + 4 B
@@ -236,7 +253,8 @@ def main():
                 name = st.kernel.decode()
                 parts = ((name, st.ms_group if st.used_group_kernel and not st.group_aborted else st.ms_tier2, algo),
                          ("schur_lds_kernel<1024>", st.ms_tier0, 0), ("schur_lds_kernel<8192>", st.ms_tier1, 0))
-            parts += (("scan_* + gather_rows_kernel", st.ms_finalize, 16 * st.nnz + 12 * st.rows),)
+            if st.ms_finalize > 0.05:          # (the back-substituted path writes S in its final place: no gather pass)
+                parts += (("scan_* + gather_rows_kernel", st.ms_finalize, 16 * st.nnz + 12 * st.rows),)
             for name, m_, b_ in parts:
                 ms[name] = ms.get(name, 0.0) + m_
                 by[name] = b_
@@ -359,6 +377,8 @@ def main():
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(A, rows, F)
         print(json.dumps(out))
+    if comm is not None:
+        comm.close()
     if dist is not None:
         dist.destroy_process_group()
 

@@ -207,6 +207,7 @@ typedef struct {
  * Montgomery form.  Built on the host from the reference structs, then
  * uploaded.  See DESIGN.md "Data layout in HBM". */
 typedef struct spasm_hip_dfact spasm_hip_dfact;
+typedef struct spasm_hip_comm spasm_hip_comm;
 spasm_hip_dfact *spasm_hip_dfact_create(const struct spasm_csr *U, const int *qinv, void *stream);
 void spasm_hip_dfact_destroy(spasm_hip_dfact *F);
 /* forgets derived state cached in the image (the back-substituted rows R): the next Schur call rebuilds it.
@@ -250,6 +251,7 @@ typedef struct {
 	i64 bytes_backsolve;    /* algorithmic bytes of that build */
 	i64 bytes_apply;        /* ... of the apply kernel */
 	char kernel[64];        /* name of the dominant elimination kernel this call launched, as rocprofv3 shows it */
+	char kernel_other[64];  /* back-substituted path: the other of its two kernels (build of R / apply) */
 } spasm_hip_schur_stats;
 
 /* S = Schur complement of rows d_rows[0..nrows) of A w.r.t. F, left in the
@@ -272,6 +274,33 @@ int spasm_hip_dschur_dense(const spasm_hip_dcsr *A, const int *d_rows, int nrows
  * HBM (values in [0,p), leading dimension ld).  On return d_pivcol[0..rank)
  * holds the pivot column of each echelon row.  Returns the rank. */
 int spasm_hip_drref(i64 prime, int n, int m, u32 *d_A, i64 ld, int *d_pivcol, void *stream);
+
+/* ======================================================================
+ * (M) multi-GPU: one process per GPU, RCCL over xGMI (spasm_amd/csrc/dist_api.hip)
+ *
+ * What shards is what the reference hands to its OpenMP threads: the rows of a Schur complement
+ * (spasm_schur.c:86-171).  Every rank holds A and the factor and reduces a contiguous slice of the row list; the
+ * slices are reassembled on the devices with an all-gatherv.  With a communicator installed, the entry points of
+ * section (H) shard by themselves and stay in step: every rank makes the same calls with the same arguments.
+ * ====================================================================== */
+int spasm_hip_comm_id_bytes(void);                      /* size of the opaque id below (an ncclUniqueId) */
+void spasm_hip_comm_new_id(void *id);                   /* one process draws an id and hands it to the others (any channel) */
+spasm_hip_comm *spasm_hip_comm_create(const void *id, int rank, int world);     /* collective; the thread's current device */
+void spasm_hip_comm_destroy(spasm_hip_comm *c);
+int spasm_hip_comm_rank(const spasm_hip_comm *c);
+int spasm_hip_comm_world(const spasm_hip_comm *c);
+void spasm_hip_set_comm(spasm_hip_comm *c);             /* NULL: back to one GPU */
+void spasm_hip_shard(int n, int rank, int world, int *lo, int *hi);             /* slice [lo, hi) of n rows owned by rank */
+
+/* all-gatherv of what the last spasm_hip_dschur left in every rank's workspace: rows of rank 0, then rank 1, ... as one
+ * CSR in device buffers (d_Sp: total rows + 1, d_Sj / d_Sx: cap entries).  Returns 1 (nothing moved, *total_nnz set) when
+ * cap is too small -- call it with cap = -1 to learn the sizes. */
+int spasm_hip_dschur_allgatherv(spasm_hip_comm *c, const spasm_hip_dwork *W, i64 *d_Sp, int *d_Sj, spasm_ZZp *d_Sx, i64 cap,
+                                int *total_rows, i64 *total_nnz, void *stream);
+
+/* spasm_echelonize (spasm_echelonize.c:478) with every round's Schur complement sharded over the ranks of c; the pivot
+ * search runs on rank 0 and is broadcast.  Collective; same rank of the matrix on every rank. */
+struct spasm_lu *spasm_hip_echelonize_dist(const struct spasm_csr *A, struct echelonize_opts *opts, spasm_hip_comm *c);
 
 #ifdef __cplusplus
 }

@@ -68,6 +68,16 @@ def lib():
         "spasm_hip_dschur_dense": (ci, [C.POINTER(CDcsr), vp, ci, vp, vp, vp, i64, vp]),
         "spasm_hip_drref": (ci, [i64, ci, ci, vp, i64, vp, vp]),
         "spasm_hip_drref_timed": (ci, [i64, ci, ci, vp, i64, vp, vp, ci, C.POINTER(C.c_float)]),
+        "spasm_hip_comm_id_bytes": (ci, []),
+        "spasm_hip_comm_new_id": (None, [vp]),
+        "spasm_hip_comm_create": (vp, [vp, ci, ci]),
+        "spasm_hip_comm_destroy": (None, [vp]),
+        "spasm_hip_comm_rank": (ci, [vp]),
+        "spasm_hip_comm_world": (ci, [vp]),
+        "spasm_hip_set_comm": (None, [vp]),
+        "spasm_hip_shard": (None, [ci, ci, ci, pint, pint]),
+        "spasm_hip_dschur_allgatherv": (ci, [vp, vp, vp, vp, vp, i64, pint, C.POINTER(i64), vp]),
+        "spasm_hip_echelonize_dist": (plu, [pcsr, C.POINTER(EchelonizeOpts), vp]),
     }
     for name, (res, args) in sig.items():
         fn = getattr(L, name)

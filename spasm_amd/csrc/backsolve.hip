@@ -24,6 +24,7 @@
 //   phase C: the ring is written back to R.
 #include <algorithm>
 #include <cinttypes>
+#include <type_traits>
 #include <vector>
 
 #include "device_types.h"
@@ -33,16 +34,16 @@ namespace sh {
 
 namespace {
 
-constexpr int BS_CW = 16;          // columns per slab (one 64-byte segment of a row of R)
-constexpr int BS_NW = 8;           // waves per workgroup
-constexpr int BS_RING = 768;       // rows per chunk (LDS ring: RING * 64 bytes)
+constexpr int BS_RING = 768;       // rows per chunk (the LDS ring holds RING rows of one slab)
 constexpr int BS_NEARCAP = 1024;   // dependencies inside a chunk
 constexpr int BS_STEPCAP = 128;    // levels with such dependencies inside a chunk
-constexpr int BS_ROWS_PER_ITER = (64 / BS_CW) * BS_NW;          // rows handled by one instruction of every wave
-constexpr int BS_ITERS = BS_RING / BS_ROWS_PER_ITER;            // 24
-constexpr int BS_UNR = 8;                                      // rows in flight per lane in phase A
-static_assert(BS_ITERS % BS_UNR == 0, "phase A is unrolled in parts of BS_UNR rows");
 constexpr uint32_t BS_NONE = 0xFFFFFFFFu;
+
+int env_bs(const char *name, int dflt)
+{
+	const char *e = std::getenv(name);
+	return (e == nullptr || *e == 0) ? dflt : std::atoi(e);
+}
 
 template <typename T> T *dalloc(int64_t count)
 {
@@ -58,7 +59,7 @@ template <typename T> void upload(T *dst, const std::vector<T> &src, hipStream_t
 }
 
 struct BsArgs {
-	uint32_t *R;
+	void *R;                      // r x ldR elements of T (uint16_t when p < 2^16, else uint32_t)
 	int64_t ldR;
 	int nchunks;
 	const BsChunk *chunk;
@@ -71,162 +72,320 @@ struct BsArgs {
 	const uint2 *far;
 	const uint64_t *np_rp;
 	const uint2 *np;
+	const int *np_row;            // compact row of every entry of np
+	int sparse_init;              // 1: the kernel scatters U_n itself (few entries); 0: R was pre-filled by bs_init_kernel
 	int r;
+	int dbg;                      // timing experiments only (SPASM_HIP_BS_DEBUG): bit 0/1/2 = skip phase A/B/C (wrong results)
 	MontDev F;
 };
 
-// R <- U_n (values out of Montgomery form); R was zeroed before
-__global__ __launch_bounds__(256) void bs_init_kernel(BsArgs b)
+// ---- storage of R ---------------------------------------------------------------------------------
+// A lane always moves 32-bit WORDS.  PACKED = false: a word is one entry of R (any odd p < 2^32).  PACKED = true
+// (p < 2^16; 42013, the reference's default, qualifies): a word holds two consecutive 16-bit entries -- half the
+// traffic, half the LDS, the same number of memory instructions.
+template <bool PACKED> struct Word {
+	static constexpr int CPL = PACKED ? 2 : 1;            // columns per lane
+	using Elem = typename std::conditional<PACKED, uint16_t, uint32_t>::type;
+};
+
+// x - v * y, component-wise (y = coefficient * 2^32 mod p)
+template <bool PACKED> __device__ __forceinline__ uint32_t w_submul(uint32_t x, uint32_t v, uint32_t y, const MontDev &F)
+{
+	if constexpr (!PACKED) {
+		return submod(x, montmul(v, y, F), F);
+	} else {
+		const uint32_t lo = submod(x & 0xFFFFu, montmul(v & 0xFFFFu, y, F), F);
+		const uint32_t hi = submod(x >> 16, montmul(v >> 16, y, F), F);
+		return lo | (hi << 16);
+	}
+}
+
+// R <- U_n (values out of Montgomery form); R was zeroed before.  Only for factors whose rows hold many non-pivotal
+// entries: otherwise the backsolve kernel scatters them itself and R is never pre-filled.
+template <typename T> __global__ __launch_bounds__(256) void bs_init_kernel(BsArgs b)
 {
 	const int c = blockIdx.x * blockDim.x + threadIdx.x;
 	if (c >= b.r)
 		return;
-	uint32_t *row = b.R + (int64_t) c * b.ldR;
+	T *row = static_cast<T *>(b.R) + (int64_t) c * b.ldR;
 	for (uint64_t e = b.np_rp[c]; e < b.np_rp[c + 1]; e++) {
 		const uint2 en = b.np[e];
-		row[en.x] = montmul(en.y, 1u, b.F);
+		row[en.x] = (T) montmul(en.y, 1u, b.F);
 	}
 }
 
-__global__ __launch_bounds__(64 * BS_NW, 4) void backsolve_kernel(BsArgs b)
+// LPR lanes (words) per row of a slab: a row of a slab is LPR * 4 bytes (128 B with LPR = 32: whole cache lines, half
+// as many requests as 64-byte segments -- the kernel is bound by the rate of such requests).
+// NW waves per workgroup; a wave instruction covers 64 / LPR rows.
+template <bool PACKED, int LPR, int NW> struct BsGeom {
+	static constexpr int THREADS = 64 * NW;
+	static constexpr int RS = 64 / LPR;
+	static constexpr int CW = LPR * Word<PACKED>::CPL;     // columns per slab
+	static constexpr int ROWS_PER_ITER = RS * NW;
+	static constexpr int ITERS = BS_RING / ROWS_PER_ITER;
+	static constexpr int UNR = (ITERS % 12 == 0) ? 12 : 8;  // rows in flight per lane in phase A
+	static_assert(BS_RING % ROWS_PER_ITER == 0 && ITERS % UNR == 0, "phase A is unrolled in passes of UNR rows");
+	static constexpr int N_NEAR = (BS_NEARCAP + THREADS - 1) / THREADS;      // metadata words a thread carries for the next chunk
+	static constexpr int N_ROW = (BS_RING + THREADS - 1) / THREADS;
+	static_assert(BS_STEPCAP <= THREADS, "one step descriptor per thread");
+	static constexpr size_t FH_BYTES = (size_t) BS_RING * sizeof(uint4);
+	static constexpr size_t LDS_BYTES = FH_BYTES + (size_t) BS_NEARCAP * sizeof(uint2) + (size_t) BS_RING * sizeof(uint2) +
+	                                    (size_t) BS_STEPCAP * sizeof(int2) + (size_t) BS_RING * LPR * 4;
+};
+
+template <bool PACKED, int LPR, int NW>
+__global__ __launch_bounds__(64 * NW) void backsolve_kernel(BsArgs b)
 {
-	__shared__ uint32_t ring[BS_RING * BS_CW];
-	__shared__ uint2 near[BS_NEARCAP];
-	__shared__ uint2 brow[BS_RING];
-	__shared__ int2 step[BS_STEPCAP];
+	using G = BsGeom<PACKED, LPR, NW>;
+	using Elem = typename Word<PACKED>::Elem;
+	extern __shared__ __attribute__((aligned(16))) unsigned char bs_lds[];
+	uint4 *fh = reinterpret_cast<uint4 *>(bs_lds);                          // first two outside dependencies of every row
+	uint2 *near = reinterpret_cast<uint2 *>(bs_lds + G::FH_BYTES);
+	uint2 *brow = near + BS_NEARCAP;
+	int2 *step = reinterpret_cast<int2 *>(brow + BS_RING);
+	uint32_t *ring = reinterpret_cast<uint32_t *>(step + BS_STEPCAP);
 	const int tid = threadIdx.x;
 	const int lane = tid & 63, wave = tid >> 6;
-	const int rs = lane >> 4, col = lane & 15;
+	const int rs = lane / LPR, wl = lane % LPR;           // row slot of the lane, its word inside the row
 	const MontDev F = b.F;
-	const int64_t ldR = b.ldR;
-	uint32_t *Rs = b.R + (int64_t) blockIdx.x * BS_CW + col;
-	const int slot0 = wave * (64 / BS_CW) + rs;          // this lane's row slot within an iteration
+	const int64_t ldw = b.ldR / Word<PACKED>::CPL;       // row stride of R in words
+	uint32_t *Rs = static_cast<uint32_t *>(b.R) + (int64_t) blockIdx.x * LPR + wl;
+	const int slot0 = wave * G::RS + rs;          // this lane's row slot within an iteration
+	const int col_lo = blockIdx.x * G::CW;        // columns [col_lo, col_lo + CW) belong to this workgroup
+
+	// metadata of a chunk (the same for every slab: served by the L2) travels through registers: the loads for chunk
+	// k + 1 are issued when chunk k starts and land in LDS when it is done
+	uint2 m_near[G::N_NEAR], m_brow[G::N_ROW];
+	uint4 m_fh[G::N_ROW];
+	int2 m_step;
+	auto load_meta = [&](int k) {
+		const BsChunk c = b.chunk[k];
+#pragma unroll
+		for (int q = 0; q < G::N_NEAR; q++) {
+			const int t = tid + q * G::THREADS;
+			m_near[q] = (t < c.nnear) ? b.near[c.near0 + t] : uint2{0u, 0u};
+		}
+#pragma unroll
+		for (int q = 0; q < G::N_ROW; q++) {
+			const int t = tid + q * G::THREADS;
+			m_brow[q] = (t < c.nbrow) ? b.brow[c.brow0 + t] : uint2{0u, 0u};
+			m_fh[q] = (t < c.hi - c.lo) ? b.far_head[c.lo + t] : uint4{BS_NONE, 0u, BS_NONE, 0u};
+		}
+		m_step = (tid < c.nsteps) ? b.step[c.step0 + tid] : int2{0, 0};
+	};
+	auto store_meta = [&]() {
+#pragma unroll
+		for (int q = 0; q < G::N_NEAR; q++)
+			if (tid + q * G::THREADS < BS_NEARCAP)
+				near[tid + q * G::THREADS] = m_near[q];
+#pragma unroll
+		for (int q = 0; q < G::N_ROW; q++)
+			if (tid + q * G::THREADS < BS_RING) {
+				brow[tid + q * G::THREADS] = m_brow[q];
+				fh[tid + q * G::THREADS] = m_fh[q];
+			}
+		if (tid < BS_STEPCAP)
+			step[tid] = m_step;
+	};
+	if (b.nchunks > 0) {
+		load_meta(0);
+		store_meta();
+	}
+	__syncthreads();
 
 	for (int k = 0; k < b.nchunks; k++) {
 		const BsChunk ch = b.chunk[k];
 		const int nrows = ch.hi - ch.lo;
-		// metadata of phase B into LDS (the same for every slab: served by the L2)
-		for (int t = tid; t < ch.nnear; t += 64 * BS_NW)
-			near[t] = b.near[ch.near0 + t];
-		for (int t = tid; t < ch.nbrow; t += 64 * BS_NW)
-			brow[t] = b.brow[ch.brow0 + t];
-		for (int t = tid; t < ch.nsteps; t += 64 * BS_NW)
-			step[t] = b.step[ch.step0 + t];
+		if (k + 1 < b.nchunks)
+			load_meta(k + 1);
 
-		// ---- phase A: own row + dependencies outside the chunk, BS_UNR rows in flight per lane ----
-		for (int half = 0; half < BS_ITERS / BS_UNR; half++) {
-			if (half * BS_UNR * BS_ROWS_PER_ITER >= nrows)
+		if (b.sparse_init) {
+			// the rows start as U_n: few entries, scattered from the list (R itself is never read for them)
+			for (int t = tid; t < nrows * LPR; t += G::THREADS)
+				ring[t] = 0;
+			__syncthreads();
+			const uint64_t e0 = b.np_rp[ch.lo], e1 = b.np_rp[ch.hi];
+			for (uint64_t e = e0 + tid; e < e1; e += G::THREADS) {
+				const uint2 en = b.np[e];
+				const int cc = (int) en.x - col_lo;
+				if (cc >= 0 && cc < G::CW)
+					reinterpret_cast<Elem *>(ring)[(b.np_row[e] - ch.lo) * G::CW + cc] = (Elem) montmul(en.y, 1u, F);
+			}
+			__syncthreads();
+		}
+
+		// ---- phase A: own row + dependencies outside the chunk, up to 3 * UNR loads in flight per lane ----
+		for (int pass = 0; pass < G::ITERS / G::UNR; pass++) {
+			if (pass * G::UNR * G::ROWS_PER_ITER >= nrows || (b.dbg & 1))
 				break;
-			uint4 hd[BS_UNR];
-			uint32_t acc[BS_UNR];
+			uint32_t acc[G::UNR], v0[G::UNR], v1[G::UNR];
 #pragma unroll
-			for (int u = 0; u < BS_UNR; u++) {
-				const int s = (half * BS_UNR + u) * BS_ROWS_PER_ITER + slot0;
+			for (int u = 0; u < G::UNR; u++) {
+				const int s = (pass * G::UNR + u) * G::ROWS_PER_ITER + slot0;
 				const bool ok = s < nrows;
+				const uint4 h = fh[ok ? s : 0];
 				const int c = ch.lo + (ok ? s : 0);
-				hd[u] = b.far_head[c];
-				acc[u] = Rs[(int64_t) c * ldR];
-				if (!ok)
-					hd[u].x = hd[u].z = BS_NONE;
-			}
-			uint32_t v0[BS_UNR], v1[BS_UNR];
-#pragma unroll
-			for (int u = 0; u < BS_UNR; u++) {
-				v0[u] = (hd[u].x != BS_NONE) ? Rs[(int64_t) hd[u].x * ldR] : 0u;
-				v1[u] = (hd[u].z != BS_NONE) ? Rs[(int64_t) hd[u].z * ldR] : 0u;
+				acc[u] = b.sparse_init ? 0u : Rs[(int64_t) c * ldw];
+				v0[u] = (ok && h.x != BS_NONE) ? Rs[(int64_t) h.x * ldw] : 0u;
+				v1[u] = (ok && h.z != BS_NONE) ? Rs[(int64_t) h.z * ldw] : 0u;
 			}
 #pragma unroll
-			for (int u = 0; u < BS_UNR; u++) {
-				const int s = (half * BS_UNR + u) * BS_ROWS_PER_ITER + slot0;
-				uint32_t x = acc[u];
-				if (hd[u].x != BS_NONE)
-					x = submod(x, montmul(v0[u], hd[u].y, F), F);
-				if (hd[u].z != BS_NONE)
-					x = submod(x, montmul(v1[u], hd[u].w, F), F);
-				if (s < nrows)
-					ring[s * BS_CW + col] = x;
+			for (int u = 0; u < G::UNR; u++) {
+				const int s = (pass * G::UNR + u) * G::ROWS_PER_ITER + slot0;
+				if (s < nrows) {
+					const uint4 h = fh[s];
+					uint32_t x = b.sparse_init ? ring[s * LPR + wl] : acc[u];
+					if (h.x != BS_NONE)
+						x = w_submul<PACKED>(x, v0[u], h.y, F);
+					if (h.z != BS_NONE)
+						x = w_submul<PACKED>(x, v1[u], h.w, F);
+					ring[s * LPR + wl] = x;
+				}
 			}
 		}
 		__syncthreads();
 		if (b.chunk_extra[k]) {
 			// rows with more than two outside dependencies (long rows of U): the rest of their lists
-			for (int s = slot0; s < nrows; s += BS_ROWS_PER_ITER) {
+			for (int s = slot0; s < nrows; s += G::ROWS_PER_ITER) {
 				const int c = ch.lo + s;
 				const uint64_t e0 = b.far_rp[c], e1 = b.far_rp[c + 1];
 				if (e0 == e1)
 					continue;
-				uint32_t x = ring[s * BS_CW + col];
+				uint32_t x = ring[s * LPR + wl];
 				for (uint64_t e = e0; e < e1; e++) {
 					const uint2 en = b.far[e];
-					x = submod(x, montmul(Rs[(int64_t) en.x * ldR], en.y, F), F);
+					x = w_submul<PACKED>(x, Rs[(int64_t) en.x * ldw], en.y, F);
 				}
-				ring[s * BS_CW + col] = x;
+				ring[s * LPR + wl] = x;
 			}
 			__syncthreads();
 		}
 
 		// ---- phase B: the chain of levels, in LDS ----
-		for (int st = 0; st < ch.nsteps; st++) {
-			const int2 sp = step[st];
-			for (int q = sp.x + slot0; q < sp.y; q += BS_ROWS_PER_ITER) {
-				const uint2 br = brow[q];
-				const int slot = (int) (br.x & 0xFFFFu), cnt = (int) (br.x >> 16);
-				uint32_t x = ring[slot * BS_CW + col];
-				for (int j = 0; j < cnt; j++) {
-					const uint2 en = near[br.y + j];
-					x = submod(x, montmul(ring[en.x * BS_CW + col], en.y, F), F);
+		// What a row needs besides the values -- the rows of its step, its slot and list of dependencies, the first of
+		// them: a chain of three dependent LDS reads -- does not depend on the values.  It is fetched ahead, one link
+		// per step, so that a step is ONE round of independent LDS reads -> multiply -> ring write -> barrier.
+		{
+			const int nsteps = (b.dbg & 2) ? 0 : ch.nsteps;
+			auto rd_step = [&](int i) { return (i < nsteps) ? step[i] : int2{0, 0}; };
+			auto rd_brow = [&](int2 sp) { return (sp.x + slot0 < sp.y) ? brow[sp.x + slot0] : uint2{0u, 0u}; };
+			auto rd_near = [&](uint2 br) { return ((br.x >> 16) != 0) ? near[br.y] : uint2{0u, 0u}; };
+			int2 S0 = rd_step(0), S1 = rd_step(1), S2 = rd_step(2);
+			uint2 B0 = rd_brow(S0), B1 = rd_brow(S1);
+			uint2 D0 = rd_near(B0);
+			for (int st = 0; st < nsteps; st++) {
+				const int slot = (int) (B0.x & 0xFFFFu), cnt = (int) (B0.x >> 16);      // cnt != 0: this lane has a row in the step
+				uint32_t x = 0, v = 0;
+				if (cnt != 0) {
+					x = ring[slot * LPR + wl];
+					v = ring[D0.x * LPR + wl];
 				}
-				ring[slot * BS_CW + col] = x;
+				const uint2 D1 = rd_near(B1);
+				const uint2 B2 = rd_brow(S2);
+				const int2 S3 = rd_step(st + 3);
+				if (cnt != 0) {
+					x = w_submul<PACKED>(x, v, D0.y, F);
+					for (int j = 1; j < cnt; j++) {
+						const uint2 en = near[B0.y + j];
+						x = w_submul<PACKED>(x, ring[en.x * LPR + wl], en.y, F);
+					}
+					ring[slot * LPR + wl] = x;
+				}
+				// levels wider than one pass of the workgroup
+				for (int q = S0.x + slot0 + G::ROWS_PER_ITER; q < S0.y; q += G::ROWS_PER_ITER) {
+					const uint2 bq = brow[q];
+					const int sq = (int) (bq.x & 0xFFFFu), cq = (int) (bq.x >> 16);
+					uint32_t y = ring[sq * LPR + wl];
+					for (int j = 0; j < cq; j++) {
+						const uint2 en = near[bq.y + j];
+						y = w_submul<PACKED>(y, ring[en.x * LPR + wl], en.y, F);
+					}
+					ring[sq * LPR + wl] = y;
+				}
+				__syncthreads();
+				S0 = S1;
+				S1 = S2;
+				S2 = S3;
+				B0 = B1;
+				B1 = B2;
+				D0 = D1;
 			}
-			__syncthreads();
 		}
 
 		// ---- phase C: write the chunk back ----
-		for (int s = slot0; s < nrows; s += BS_ROWS_PER_ITER)
-			Rs[(int64_t) (ch.lo + s) * ldR] = ring[s * BS_CW + col];
-		__syncthreads();          // (workgroup-scope release/acquire: later chunks read these rows)
+		for (int s = slot0; s < ((b.dbg & 4) ? 0 : nrows); s += G::ROWS_PER_ITER)
+			Rs[(int64_t) (ch.lo + s) * ldw] = ring[s * LPR + wl];
+		__syncthreads();          // (workgroup-scope release/acquire: later chunks read these rows; LDS metadata is free)
+		if (k + 1 < b.nchunks)
+			store_meta();
+		__syncthreads();
 	}
 }
 
 // --------------------------------------------------------------------------
-// S = A_n - A_p R, one wave per row.  The row of S is accumulated in LDS (one
-// u32 per non-pivotal column), the pivotal entries of the input row are
-// collected in a small LDS list and applied tile by tile.
+// S = A_n - A_p R, one wave per row.  The row of S is accumulated in LDS (one word per lane and tile), the pivotal
+// entries of the input row are collected in a small LDS list and applied tile by tile.
 // --------------------------------------------------------------------------
 constexpr int AP_LIST = 256;       // pivotal entries applied per pass
-constexpr int AP_TU = 4;           // 64-column tiles per inner step
+constexpr int AP_TU = 4;           // 64-word tiles per inner step
 
 struct ApplyArgs {
 	SchurArgs a;
-	const uint32_t *R;
-	int64_t ldR;
+	const void *R;
+	int64_t ldR;                  // in entries
 	const int *col;               // column -> compact id
 	int r;                        // rows of R
-	int Smpad;                    // Sm rounded up to 64 * AP_TU
+	int Smpad;                    // Sm rounded up to whole tile groups (= ldR)
 	int waves;                    // waves per workgroup
+	size_t wave_bytes;            // LDS per wave: row buffer + list
 	uint32_t *dense_out;
 	int64_t ldS;
+	// direct sparse output (no pool, no gather pass): rows are handed out in order through a ticket, every row
+	// publishes its length and finds its offset by looking back over the rows before it (single-pass chained scan)
+	int direct;
+	unsigned long long *status;   // per row: flag << 62 | value; flag 1: value = length of the row, 2: = offset past the row
+	int *ticket;
+	int64_t *Sp;
+	int *Sj;
+	int *Sx;
+	int64_t cap;
 };
 
-__global__ __launch_bounds__(512) void bs_apply_kernel(ApplyArgs d)
+constexpr unsigned long long LB_FLAG_LEN = 1ull << 62, LB_FLAG_END = 2ull << 62, LB_VALUE = (1ull << 62) - 1;
+constexpr int LB_PER_LANE = 4;             // predecessors inspected per lane and poll (256 per wave)
+
+template <bool PACKED> __global__ __launch_bounds__(512) void bs_apply_kernel(ApplyArgs d)
 {
-	extern __shared__ unsigned char lds_raw[];
+	constexpr int CPL = Word<PACKED>::CPL;
+	using Elem = typename Word<PACKED>::Elem;
+	extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
 	const SchurArgs &a = d.a;
 	const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
 	const MontDev F = a.F;
-	const int Sm = a.Sm, Smpad = d.Smpad;
-	uint32_t *xbuf = reinterpret_cast<uint32_t *>(lds_raw) + (size_t) wave * ((size_t) Smpad + 2 * AP_LIST);
-	uint2 *plist = reinterpret_cast<uint2 *>(xbuf + Smpad);
-	const int64_t ldR = d.ldR;
+	const int Sm = a.Sm;
+	const int nwords = d.Smpad / CPL;                     // a multiple of 64 * AP_TU / CPL >= 128
+	uint2 *plist = reinterpret_cast<uint2 *>(lds_raw + (size_t) wave * d.wave_bytes);
+	uint32_t *xw = reinterpret_cast<uint32_t *>(plist + AP_LIST);
+	Elem *xe = reinterpret_cast<Elem *>(xw);
+	const uint32_t *R = static_cast<const uint32_t *>(d.R);
+	const int64_t ldw = d.ldR / CPL;
 	unsigned long long st_input = 0, st_piv = 0;
 	int st_done = 0;
 
-	for (int k = blockIdx.x * d.waves + wave; k < a.nrows; k += gridDim.x * d.waves) {
+	for (int k = blockIdx.x * d.waves + wave;; k += gridDim.x * d.waves) {
+		if (d.direct) {                      // rows in ticket order: whoever waits for a row knows a running wave holds it
+			int t = 0;
+			if (lane == 0)
+				t = atomicAdd(d.ticket, 1);
+			k = __builtin_amdgcn_readfirstlane(t);
+		}
+		if (k >= a.nrows)
+			break;
 		const int i = a.rows[k];
 		const int64_t lo = a.Ap[i], hi = a.Ap[i + 1];
 		st_input += (unsigned long long) (hi - lo);
-		for (int t = lane; t < Smpad; t += 64)
-			xbuf[t] = 0;
+		for (int t = lane; t < nwords; t += 64)
+			xw[t] = 0;
 		int npl = 0;                         // entries waiting in plist (wave-uniform)
 		for (int64_t base = lo;; base += 64) {
 			// non-pivotal entries go straight into the row buffer, pivotal ones are queued
@@ -237,10 +396,10 @@ __global__ __launch_bounds__(512) void bs_apply_kernel(ApplyArgs d)
 				v = reduce_sum(from_balanced(a.Ax[base + lane], F), F);
 				if (cid >= (uint32_t) d.r) {
 					const uint32_t t = cid - (uint32_t) d.r;
-					uint32_t sum = xbuf[t] + v;
+					uint32_t sum = (uint32_t) xe[t] + v;
 					if (sum < v || sum >= F.p)
 						sum -= F.p;
-					xbuf[t] = sum;
+					xe[t] = (Elem) sum;
 				} else {
 					piv = v != 0;
 				}
@@ -253,38 +412,41 @@ __global__ __launch_bounds__(512) void bs_apply_kernel(ApplyArgs d)
 			const bool last = base + 64 >= hi;
 			if (npl > 0 && (last || npl + 64 > AP_LIST)) {
 				// apply the queued pivotal entries: x[tile] -= sum_e a_e R[e][tile]
-				for (int t0 = 0; t0 < Smpad; t0 += 64 * AP_TU) {
+				for (int t0 = 0; t0 < nwords; t0 += 64 * AP_TU) {
 					uint32_t acc[AP_TU];
 #pragma unroll
 					for (int u = 0; u < AP_TU; u++)
-						acc[u] = xbuf[t0 + u * 64 + lane];
+						acc[u] = (t0 + u * 64 < nwords) ? xw[t0 + u * 64 + lane] : 0u;
 					int e = 0;
 					for (; e + 2 <= npl; e += 2) {
 						const uint2 p0 = plist[e], p1 = plist[e + 1];
-						const uint32_t *r0 = d.R + (int64_t) p0.x * ldR + t0 + lane;
-						const uint32_t *r1 = d.R + (int64_t) p1.x * ldR + t0 + lane;
+						const uint32_t *r0 = R + (int64_t) p0.x * ldw + t0 + lane;
+						const uint32_t *r1 = R + (int64_t) p1.x * ldw + t0 + lane;
 						uint32_t w0[AP_TU], w1[AP_TU];
 #pragma unroll
 						for (int u = 0; u < AP_TU; u++) {
-							w0[u] = r0[u * 64];
-							w1[u] = r1[u * 64];
+							const bool in = t0 + u * 64 < nwords;
+							w0[u] = in ? r0[u * 64] : 0u;
+							w1[u] = in ? r1[u * 64] : 0u;
 						}
 #pragma unroll
 						for (int u = 0; u < AP_TU; u++) {
-							acc[u] = submod(acc[u], montmul(w0[u], p0.y, F), F);
-							acc[u] = submod(acc[u], montmul(w1[u], p1.y, F), F);
+							acc[u] = w_submul<PACKED>(acc[u], w0[u], p0.y, F);
+							acc[u] = w_submul<PACKED>(acc[u], w1[u], p1.y, F);
 						}
 					}
 					if (e < npl) {
 						const uint2 p0 = plist[e];
-						const uint32_t *r0 = d.R + (int64_t) p0.x * ldR + t0 + lane;
+						const uint32_t *r0 = R + (int64_t) p0.x * ldw + t0 + lane;
 #pragma unroll
 						for (int u = 0; u < AP_TU; u++)
-							acc[u] = submod(acc[u], montmul(r0[u * 64], p0.y, F), F);
+							if (t0 + u * 64 < nwords)
+								acc[u] = w_submul<PACKED>(acc[u], r0[u * 64], p0.y, F);
 					}
 #pragma unroll
 					for (int u = 0; u < AP_TU; u++)
-						xbuf[t0 + u * 64 + lane] = acc[u];
+						if (t0 + u * 64 < nwords)
+							xw[t0 + u * 64 + lane] = acc[u];
 				}
 				npl = 0;
 			}
@@ -296,42 +458,138 @@ __global__ __launch_bounds__(512) void bs_apply_kernel(ApplyArgs d)
 		if (d.dense_out != nullptr) {
 			uint32_t *out = d.dense_out + (int64_t) k * d.ldS;
 			for (int t = lane; t < Sm; t += 64)
-				out[t] = xbuf[t];
+				out[t] = xe[t];
 			if (lane == 0)
 				a.row_len[k] = Sm;
 			st_done += 1;
 			continue;
 		}
+		// lane l of a tile holds columns CPL * (t0 + l) ..: entries come out sorted by column
 		int count = 0;
-		for (int t0 = 0; t0 < Smpad; t0 += 64)
-			count += __popcll(__ballot(xbuf[t0 + lane] != 0));
-		unsigned long long got = 0;
-		if (lane == 0)
-			got = atomicAdd(&a.ctr64[C64_POOL], (unsigned long long) count);
-		const uint32_t g_lo = __builtin_amdgcn_readfirstlane((uint32_t) got);
-		const uint32_t g_hi = __builtin_amdgcn_readfirstlane((uint32_t) (got >> 32));
-		const int64_t off = (int64_t) (((uint64_t) g_hi << 32) | g_lo);
-		const bool fits = off + count <= a.pool_cap;
+		for (int t0 = 0; t0 < nwords; t0 += 64) {
+			const uint32_t w = xw[t0 + lane];
+			if constexpr (PACKED)
+				count += __popcll(__ballot((w & 0xFFFFu) != 0)) + __popcll(__ballot((w >> 16) != 0));
+			else
+				count += __popcll(__ballot(w != 0));
+		}
+		int64_t off = 0;
+		int *out_j = a.pool_j, *out_x = a.pool_x;
+		bool fits;
+		if (d.direct) {
+			// publish the length, then add up the lengths of the rows before this one, back to the nearest row that
+			// already knows where it ends
+			if (lane == 0)
+				__hip_atomic_store(&d.status[k], LB_FLAG_LEN | (unsigned long long) count, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+			unsigned long long prior = 0;
+			bool lost = false;
+			long long polls = 0;
+			for (int j = k - 1; j >= 0;) {
+				unsigned long long val[LB_PER_LANE];
+#pragma unroll
+				for (int u = 0; u < LB_PER_LANE; u++) {
+					const int idx = j - (u * 64 + lane);
+					val[u] = (idx >= 0) ? __hip_atomic_load(&d.status[idx], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : LB_FLAG_END;
+				}
+				// position (in look-back order) of the nearest row that knows its end; every row nearer must have a length
+				int first_end = 64 * LB_PER_LANE;
+				bool hole = false;
+				unsigned long long sum = 0;
+#pragma unroll
+				for (int u = LB_PER_LANE - 1; u >= 0; u--) {
+					const uint64_t m_end = __ballot((val[u] >> 62) == 2);
+					if (m_end != 0)
+						first_end = u * 64 + __builtin_ctzll(m_end);
+				}
+#pragma unroll
+				for (int u = 0; u < LB_PER_LANE; u++) {
+					const int pos = u * 64 + lane;
+					const bool counts = pos <= first_end;
+					hole = hole || (counts && (val[u] >> 62) == 0);
+					sum += counts ? (val[u] & LB_VALUE) : 0ull;
+				}
+				if (__ballot(hole) != 0) {          // a row in between has not published its length yet: look again
+					if (++polls > (1ll << 24)) {
+						lost = true;
+						break;
+					}
+					__builtin_amdgcn_s_sleep(2);
+					continue;
+				}
+				// wave-wide sum (64-bit, two halves through DPP-free shuffles)
+				for (int sft = 32; sft >= 1; sft >>= 1) {
+					const uint32_t lo32 = (uint32_t) __shfl_xor((int) (uint32_t) sum, sft);
+					const uint32_t hi32 = (uint32_t) __shfl_xor((int) (uint32_t) (sum >> 32), sft);
+					sum += ((unsigned long long) hi32 << 32) | lo32;
+				}
+				prior += sum;
+				if (first_end < 64 * LB_PER_LANE)
+					break;
+				j -= 64 * LB_PER_LANE;
+			}
+			if (lane == 0) {
+				__hip_atomic_store(&d.status[k], LB_FLAG_END | ((prior + (unsigned long long) count) & LB_VALUE), __ATOMIC_RELAXED,
+				                   __HIP_MEMORY_SCOPE_AGENT);
+				d.Sp[k] = (int64_t) prior;
+				if (k == a.nrows - 1)
+					d.Sp[a.nrows] = (int64_t) (prior + (unsigned long long) count);
+				if (lost)
+					atomicOr(&a.ctr[CTR_STATUS], 4);
+			}
+			off = (int64_t) prior;
+			out_j = d.Sj;
+			out_x = d.Sx;
+			fits = !lost && off + count <= d.cap;
+		} else {
+			unsigned long long got = 0;
+			if (lane == 0)
+				got = atomicAdd(&a.ctr64[C64_POOL], (unsigned long long) count);
+			const uint32_t g_lo = __builtin_amdgcn_readfirstlane((uint32_t) got);
+			const uint32_t g_hi = __builtin_amdgcn_readfirstlane((uint32_t) (got >> 32));
+			off = (int64_t) (((uint64_t) g_hi << 32) | g_lo);
+			fits = off + count <= a.pool_cap;
+		}
 		if (fits) {
 			int64_t wpos = off;
-			for (int t0 = 0; t0 < Smpad; t0 += 64) {
-				const uint32_t v = xbuf[t0 + lane];
-				const uint64_t mk = __ballot(v != 0);
-				if (v != 0) {
-					const int64_t dst = wpos + __popcll(mk & ((1ull << lane) - 1ull));
-					a.pool_j[dst] = a.q[t0 + lane];
-					a.pool_x[dst] = to_balanced(v, F);
+			const uint64_t below = (1ull << lane) - 1ull;
+			for (int t0 = 0; t0 < nwords; t0 += 64) {
+				const uint32_t w = xw[t0 + lane];
+				if constexpr (PACKED) {
+					const uint32_t v0 = w & 0xFFFFu, v1 = w >> 16;
+					const uint64_t m0 = __ballot(v0 != 0), m1 = __ballot(v1 != 0);
+					const int before = __popcll(m0 & below) + __popcll(m1 & below);
+					const int c0 = 2 * (t0 + lane);
+					if (v0 != 0) {
+						out_j[wpos + before] = a.q[c0];
+						out_x[wpos + before] = to_balanced(v0, F);
+					}
+					if (v1 != 0) {
+						const int64_t dst = wpos + before + (v0 != 0 ? 1 : 0);
+						out_j[dst] = a.q[c0 + 1];
+						out_x[dst] = to_balanced(v1, F);
+					}
+					wpos += __popcll(m0) + __popcll(m1);
+				} else {
+					const uint64_t mk = __ballot(w != 0);
+					if (w != 0) {
+						const int64_t dst = wpos + __popcll(mk & below);
+						out_j[dst] = a.q[t0 + lane];
+						out_x[dst] = to_balanced(w, F);
+					}
+					wpos += __popcll(mk);
 				}
-				wpos += __popcll(mk);
 			}
 		}
 		if (lane == 0) {
 			if (fits) {
-				a.row_off[k] = off | (1LL << 62);       // sorted by column already
-				a.row_len[k] = count;
+				if (!d.direct) {
+					a.row_off[k] = off | (1LL << 62);       // sorted by column already
+					a.row_len[k] = count;
+				}
 			} else {
 				atomicOr(&a.ctr[CTR_STATUS], 1);
-				a.row_len[k] = -1;
+				if (!d.direct)
+					a.row_len[k] = -1;
 			}
 		}
 		st_done += fits ? 1 : 0;
@@ -343,6 +601,165 @@ __global__ __launch_bounds__(512) void bs_apply_kernel(ApplyArgs d)
 	}
 }
 
+// Dense rows for FEW, LONG input rows (the completion test combines every remaining row: ~10 rows of ~10^5 entries):
+// one wave per row would leave the chip idle, so a workgroup takes (row, group of 256 words) and its waves split the
+// entries of the row; partial sums meet in LDS.
+constexpr int AW_NW = 8;
+
+template <bool PACKED> __global__ __launch_bounds__(64 * AW_NW) void bs_apply_wide_kernel(ApplyArgs d)
+{
+	constexpr int CPL = Word<PACKED>::CPL;
+	__shared__ uint32_t part[AW_NW][AP_TU * 64];
+	const SchurArgs &a = d.a;
+	const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+	const MontDev F = a.F;
+	const int k = blockIdx.y;
+	const int w0 = blockIdx.x * 64 * AP_TU;                 // first word of this workgroup's tile group
+	const int nwords = d.Smpad / CPL;
+	const uint32_t *R = static_cast<const uint32_t *>(d.R);
+	const int64_t ldw = d.ldR / CPL;
+	const int i = a.rows[k];
+	const int64_t lo = a.Ap[i], hi = a.Ap[i + 1];
+	uint32_t acc[AP_TU];
+#pragma unroll
+	for (int u = 0; u < AP_TU; u++)
+		acc[u] = 0;
+	for (int64_t base = lo + 64 * wave; base < hi; base += 64 * AW_NW) {
+		uint32_t cid = 0xFFFFFFFFu, v = 0;
+		if (base + lane < hi) {
+			cid = (uint32_t) d.col[a.Aj[base + lane]];
+			v = reduce_sum(from_balanced(a.Ax[base + lane], F), F);
+		}
+		// non-pivotal entries of this tile group: added by the lane that owns the column
+		const bool np_here = v != 0 && cid != 0xFFFFFFFFu && cid >= (uint32_t) d.r;
+		uint64_t todo = __ballot(np_here);
+		while (todo != 0) {
+			const int src = __builtin_ctzll(todo);
+			todo &= todo - 1;
+			const uint32_t t = (uint32_t) __shfl((int) cid, src) - (uint32_t) d.r;      // column among the non-pivotal ones
+			const uint32_t val = (uint32_t) __shfl((int) v, src);
+			const int word = (int) (t / CPL) - w0;
+			if (word >= 0 && word < 64 * AP_TU && (word & 63) == lane) {
+				const int u = word >> 6;
+#pragma unroll
+				for (int q = 0; q < AP_TU; q++)
+					if (q == u) {
+						if constexpr (PACKED) {
+							const int sh = (t & 1) ? 16 : 0;
+							uint32_t part_v = ((acc[q] >> sh) & 0xFFFFu) + val;
+							if (part_v >= F.p)
+								part_v -= F.p;
+							acc[q] = (acc[q] & ~(0xFFFFu << sh)) | (part_v << sh);
+						} else {
+							uint32_t sum = acc[q] + val;
+							if (sum < val || sum >= F.p)
+								sum -= F.p;
+							acc[q] = sum;
+						}
+					}
+			}
+		}
+		// pivotal entries: their rows of R, tile group by tile group
+		const bool piv = v != 0 && cid < (uint32_t) d.r;
+		const uint32_t ay = piv ? montmul(v, F.r2, F) : 0u;
+		todo = __ballot(piv);
+		while (todo != 0) {
+			const int s0 = __builtin_ctzll(todo);
+			todo &= todo - 1;
+			int s1 = -1;
+			if (todo != 0) {
+				s1 = __builtin_ctzll(todo);
+				todo &= todo - 1;
+			}
+			const uint32_t c0 = (uint32_t) __shfl((int) cid, s0), y0 = (uint32_t) __shfl((int) ay, s0);
+			const uint32_t *r0 = R + (int64_t) c0 * ldw + w0 + lane;
+			uint32_t x0[AP_TU], x1[AP_TU];
+#pragma unroll
+			for (int u = 0; u < AP_TU; u++)
+				x0[u] = (w0 + u * 64 < nwords) ? r0[u * 64] : 0u;
+			uint32_t y1 = 0;
+			if (s1 >= 0) {
+				const uint32_t c1 = (uint32_t) __shfl((int) cid, s1);
+				y1 = (uint32_t) __shfl((int) ay, s1);
+				const uint32_t *r1 = R + (int64_t) c1 * ldw + w0 + lane;
+#pragma unroll
+				for (int u = 0; u < AP_TU; u++)
+					x1[u] = (w0 + u * 64 < nwords) ? r1[u * 64] : 0u;
+			}
+#pragma unroll
+			for (int u = 0; u < AP_TU; u++) {
+				acc[u] = w_submul<PACKED>(acc[u], x0[u], y0, F);
+				if (s1 >= 0)
+					acc[u] = w_submul<PACKED>(acc[u], x1[u], y1, F);
+			}
+		}
+	}
+#pragma unroll
+	for (int u = 0; u < AP_TU; u++)
+		part[wave][u * 64 + lane] = acc[u];
+	__syncthreads();
+	if (wave == 0) {
+		uint32_t *out = d.dense_out + (int64_t) k * d.ldS;
+#pragma unroll
+		for (int u = 0; u < AP_TU; u++) {
+			uint32_t lo_s = 0, hi_s = 0;
+			for (int w = 0; w < AW_NW; w++) {
+				const uint32_t x = part[w][u * 64 + lane];
+				if constexpr (PACKED) {
+					lo_s += x & 0xFFFFu;
+					hi_s += x >> 16;
+					if (lo_s >= F.p)
+						lo_s -= F.p;
+					if (hi_s >= F.p)
+						hi_s -= F.p;
+				} else {
+					const uint32_t sum = lo_s + x;
+					lo_s = (sum < x || sum >= F.p) ? sum - F.p : sum;
+				}
+			}
+			const int word = w0 + u * 64 + lane;
+			if constexpr (PACKED) {
+				if (2 * word < a.Sm)
+					out[2 * word] = lo_s;
+				if (2 * word + 1 < a.Sm)
+					out[2 * word + 1] = hi_s;
+			} else {
+				if (word < a.Sm)
+					out[word] = lo_s;
+			}
+		}
+		if (lane == 0 && blockIdx.x == 0) {
+			a.row_len[k] = a.Sm;
+			atomicAdd(&a.ctr[a.done_ctr], 1);
+			atomicAdd(&a.ctr64[C64_INPUT], (unsigned long long) (hi - lo));
+		}
+	}
+}
+
+template <bool PACKED, int LPR, int NW> void launch_backsolve_variant(const BsArgs &b, int Sm, hipStream_t stream)
+{
+	using G = BsGeom<PACKED, LPR, NW>;
+	static bool configured = false;
+	if (!configured) {
+		HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(&backsolve_kernel<PACKED, LPR, NW>),
+		                              hipFuncAttributeMaxDynamicSharedMemorySize, (int) G::LDS_BYTES));
+		configured = true;
+	}
+	hipLaunchKernelGGL((backsolve_kernel<PACKED, LPR, NW>), dim3((unsigned) ((Sm + G::CW - 1) / G::CW)), dim3(64 * NW), G::LDS_BYTES,
+	                   stream, b);
+}
+
+template <bool PACKED> void launch_apply_variant(const ApplyArgs &d, int blocks, size_t lds, hipStream_t stream)
+{
+	static size_t configured = 0;
+	if (lds > configured) {
+		HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(&bs_apply_kernel<PACKED>), hipFuncAttributeMaxDynamicSharedMemorySize,
+		                              (int) lds));
+		configured = lds;
+	}
+	hipLaunchKernelGGL((bs_apply_kernel<PACKED>), dim3(blocks), dim3(64 * d.waves), lds, stream, d);
+}
+
 }  // namespace
 
 // --------------------------------------------------------------------------
@@ -352,7 +769,7 @@ __global__ __launch_bounds__(512) void bs_apply_kernel(ApplyArgs d)
 bool backsolve_eligible(int r, int Sm, int64_t nnz_u, int64_t *bytes)
 {
 	const int64_t ldR = ((int64_t) Sm + 255) / 256 * 256;
-	*bytes = (int64_t) r * ldR * 4;
+	*bytes = (int64_t) r * ldR * 4;          // (2 bytes per entry when p < 2^16)
 	if (r <= 0 || Sm <= 0)
 		return false;
 	if (Sm > 24576)                       // the apply kernel keeps one row of S in LDS (96 KB)
@@ -398,16 +815,19 @@ void backsolve_plan(const FactPlan &P, spasm_hip_dfact *F, hipStream_t stream)
 	// split every row into pivotal dependencies (compact ids) and non-pivotal entries
 	std::vector<uint64_t> dep_rp((size_t) r + 1, 0), np_rp((size_t) r + 1, 0);
 	std::vector<uint2> dep, np;
+	std::vector<int> np_row;
 	dep.reserve(P.ent.size());
 	np.reserve(P.ent.size());
 	for (int n = 0; n < r; n++) {
 		const int c = label_of[n];
 		for (uint64_t e = P.rp[c]; e < P.rp[c + 1]; e++) {
 			const uint2 en = P.ent[e];
-			if (en.x < (uint32_t) rpad)
+			if (en.x < (uint32_t) rpad) {
 				dep.push_back(uint2{(uint32_t) cid[en.x], en.y});
-			else
+			} else {
 				np.push_back(uint2{en.x - (uint32_t) rpad, en.y});
+				np_row.push_back(n);
+			}
 		}
 		dep_rp[n + 1] = dep.size();
 		np_rp[n + 1] = np.size();
@@ -540,6 +960,7 @@ void backsolve_plan(const FactPlan &P, spasm_hip_dfact *F, hipStream_t stream)
 	B.d_far = dalloc<uint2>((int64_t) far.size());
 	B.d_np_rp = dalloc<uint64_t>((int64_t) r + 1);
 	B.d_np = dalloc<uint2>((int64_t) np.size());
+	B.d_np_row = dalloc<int>((int64_t) np_row.size());
 	B.d_chunk_extra = dalloc<int>((int64_t) chunk_extra.size());
 	upload(B.d_col, colmap, stream);
 	upload(B.d_chunk, chunks, stream);
@@ -552,6 +973,7 @@ void backsolve_plan(const FactPlan &P, spasm_hip_dfact *F, hipStream_t stream)
 	upload(B.d_far, far, stream);
 	upload(B.d_np_rp, np_rp, stream);
 	upload(B.d_np, np, stream);
+	upload(B.d_np_row, np_row, stream);
 	HIP_CHECK(hipStreamSynchronize(stream));      // the host vectors die here
 	B.planned = true;
 	B.valid = false;
@@ -572,6 +994,7 @@ void backsolve_free(spasm_hip_dfact *F)
 	(void) hipFree(B.d_far);
 	(void) hipFree(B.d_np_rp);
 	(void) hipFree(B.d_np);
+	(void) hipFree(B.d_np_row);
 	if (B.ev0 != nullptr)
 		(void) hipEventDestroy(B.ev0);
 	if (B.ev1 != nullptr)
@@ -579,14 +1002,26 @@ void backsolve_free(spasm_hip_dfact *F)
 	B = BsImage{};
 }
 
-// (re)computes R on `stream`.  The caller synchronises before reading B.ms_build.
+// (re)computes R on `stream`.  The caller synchronises before reading the events.
 void backsolve_build(const spasm_hip_dfact *F, hipStream_t stream)
 {
 	BsImage &B = F->bs;
 	if (!B.planned)
 		die("backsolve_build: the factor has no back-substitution plan");
-	if (B.d_R == nullptr)
-		B.d_R = dalloc<uint32_t>((int64_t) B.r * B.ldR);
+	// R is stored in 16 bits when the prime allows (42013, the reference's default, does): half the traffic, half the LDS
+	const bool packed = F->prime < 65536 && env_bs("SPASM_HIP_BS_PACKED", 1) != 0;
+	const int elem = packed ? 2 : 4;
+	const size_t bytes = (size_t) B.r * (size_t) B.ldR * (size_t) elem;
+	if (B.d_R != nullptr && B.elem_bytes != elem) {
+		(void) hipFree(B.d_R);
+		B.d_R = nullptr;
+	}
+	bool fresh = false;
+	if (B.d_R == nullptr) {
+		HIP_CHECK(hipMalloc(&B.d_R, bytes));
+		B.elem_bytes = elem;
+		fresh = true;
+	}
 	if (B.ev0 == nullptr) {
 		HIP_CHECK(hipEventCreate(&B.ev0));
 		HIP_CHECK(hipEventCreate(&B.ev1));
@@ -605,20 +1040,97 @@ void backsolve_build(const spasm_hip_dfact *F, hipStream_t stream)
 	b.far = B.d_far;
 	b.np_rp = B.d_np_rp;
 	b.np = B.d_np;
+	b.np_row = B.d_np_row;
 	b.r = B.r;
 	b.F = to_dev(F->mont);
+	b.dbg = env_bs("SPASM_HIP_BS_DEBUG", 0);
+	// few non-pivotal entries per row of U (mk13.b5: 0.08): the kernel scatters them into its LDS ring itself and R is
+	// neither zeroed nor read for them; many (factors that already hold dense rows): R is pre-filled instead
+	b.sparse_init = (B.nnp <= 4 * (int64_t) B.r && env_bs("SPASM_HIP_BS_SPARSE_INIT", 1) != 0) ? 1 : 0;
 	HIP_CHECK(hipEventRecord(B.ev0, stream));
-	HIP_CHECK(hipMemsetAsync(B.d_R, 0, (size_t) B.r * (size_t) B.ldR * 4, stream));
-	hipLaunchKernelGGL(bs_init_kernel, dim3((B.r + 255) / 256), dim3(256), 0, stream, b);
-	hipLaunchKernelGGL(backsolve_kernel, dim3((unsigned) ((B.Sm + BS_CW - 1) / BS_CW)), dim3(64 * BS_NW), 0, stream, b);     // (padding columns stay zero)
+	if (fresh || !b.sparse_init)        // (the padding columns beyond the last slab must be zero: once is enough for them)
+		HIP_CHECK(hipMemsetAsync(B.d_R, 0, bytes, stream));
+	if (!b.sparse_init) {
+		if (packed)
+			hipLaunchKernelGGL(bs_init_kernel<uint16_t>, dim3((B.r + 255) / 256), dim3(256), 0, stream, b);
+		else
+			hipLaunchKernelGGL(bs_init_kernel<uint32_t>, dim3((B.r + 255) / 256), dim3(256), 0, stream, b);
+	}
+	// shape of a workgroup: 0 = 128-byte slab rows, 16 waves; 1 = 128 B, 8 waves; 2 = 64 B, 8 waves.  The chain of levels
+	// (phase B) is bound by instruction issue -- every wave runs every step -- so the small workgroup wins while all its
+	// slabs are resident at once (mk13.b5: 4.4 against 4.9 ms); with more slabs than that, whole cache lines per request
+	// matter more (phase A is bound by the rate of memory requests)
+	int cus = 0;
+	{
+		int dev = 0;
+		HIP_CHECK(hipGetDevice(&dev));
+		hipDeviceProp_t prop;
+		HIP_CHECK(hipGetDeviceProperties(&prop, dev));
+		cus = prop.multiProcessorCount;
+	}
+	const int slabs_small = packed ? (B.Sm + 31) / 32 : (B.Sm + 15) / 16;
+	const int shape = env_bs("SPASM_HIP_BS_SHAPE", slabs_small <= (packed ? 2 * cus : cus) ? 2 : 0);
+	snprintf(B.kernel_build, sizeof(B.kernel_build), "backsolve_kernel<%s,%d,%d>", packed ? "true" : "false", shape == 2 ? 16 : 32,
+	         shape == 0 ? 16 : 8);
+	if (packed) {
+		if (shape == 1)
+			launch_backsolve_variant<true, 32, 8>(b, B.Sm, stream);
+		else if (shape == 2)
+			launch_backsolve_variant<true, 16, 8>(b, B.Sm, stream);
+		else
+			launch_backsolve_variant<true, 32, 16>(b, B.Sm, stream);
+	} else {
+		if (shape == 1)
+			launch_backsolve_variant<false, 32, 8>(b, B.Sm, stream);
+		else if (shape == 2)
+			launch_backsolve_variant<false, 16, 8>(b, B.Sm, stream);
+		else
+			launch_backsolve_variant<false, 32, 16>(b, B.Sm, stream);
+	}
 	HIP_CHECK(hipGetLastError());
 	HIP_CHECK(hipEventRecord(B.ev1, stream));
 	B.valid = true;
 	B.builds += 1;
+	if (env_bs("SPASM_HIP_BS_CHECK", 0) && b.sparse_init && bytes < ((size_t) 1 << 30)) {
+		// debugging aid: the same build with R pre-filled (the other way of starting the rows), compared entry by entry
+		void *R2 = nullptr;
+		HIP_CHECK(hipMalloc(&R2, bytes));
+		BsArgs c = b;
+		c.R = R2;
+		c.sparse_init = 0;
+		HIP_CHECK(hipMemsetAsync(R2, 0, bytes, stream));
+		if (packed)
+			hipLaunchKernelGGL(bs_init_kernel<uint16_t>, dim3((B.r + 255) / 256), dim3(256), 0, stream, c);
+		else
+			hipLaunchKernelGGL(bs_init_kernel<uint32_t>, dim3((B.r + 255) / 256), dim3(256), 0, stream, c);
+		if (packed)
+			launch_backsolve_variant<true, 32, 16>(c, B.Sm, stream);
+		else
+			launch_backsolve_variant<false, 32, 16>(c, B.Sm, stream);
+		std::vector<unsigned char> h1(bytes), h2(bytes);
+		HIP_CHECK(hipMemcpyAsync(h1.data(), B.d_R, bytes, hipMemcpyDeviceToHost, stream));
+		HIP_CHECK(hipMemcpyAsync(h2.data(), R2, bytes, hipMemcpyDeviceToHost, stream));
+		HIP_CHECK(hipStreamSynchronize(stream));
+		int shown = 0;
+		int64_t bad = 0;
+		for (int64_t t = 0; t < (int64_t) B.r * B.ldR; t++) {
+			const uint32_t x1 = packed ? ((uint16_t *) h1.data())[t] : ((uint32_t *) h1.data())[t];
+			const uint32_t x2 = packed ? ((uint16_t *) h2.data())[t] : ((uint32_t *) h2.data())[t];
+			if (x1 != x2) {
+				bad += 1;
+				if (shown++ < 12)
+					fprintf(stderr, "[bs check] row %lld col %lld: sparse-init %u, pre-filled %u (r %d, Sm %d, ldR %lld, chunks %d)\n",
+					        (long long) (t / B.ldR), (long long) (t % B.ldR), x1, x2, B.r, B.Sm, (long long) B.ldR, B.nchunks);
+			}
+		}
+		fprintf(stderr, "[bs check] %lld entries differ\n", (long long) bad);
+		(void) hipFree(R2);
+	}
 }
 
 // S rows from R: sparse rows into the pool of `a` (dense_out == nullptr) or dense rows.
-void launch_backsolve_apply(const SchurArgs &a, const spasm_hip_dfact *F, uint32_t *dense_out, int64_t ldS, hipStream_t stream)
+void launch_backsolve_apply(const SchurArgs &a, const spasm_hip_dfact *F, uint32_t *dense_out, int64_t ldS, hipStream_t stream,
+                            const BsDirectOut *direct)
 {
 	const BsImage &B = F->bs;
 	if (!B.valid)
@@ -631,27 +1143,47 @@ void launch_backsolve_apply(const SchurArgs &a, const spasm_hip_dfact *F, uint32
 	d.r = B.r;
 	static_assert(64 * AP_TU == 256, "ldR is padded to whole tiles of the apply kernel");
 	d.Smpad = (int) B.ldR;
-	const size_t per_wave = ((size_t) d.Smpad + 2 * AP_LIST) * 4;
+	d.dense_out = dense_out;
+	d.ldS = ldS;
+	if (direct != nullptr && dense_out == nullptr) {
+		d.direct = 1;
+		d.status = direct->status;
+		d.ticket = direct->ticket;
+		d.Sp = direct->Sp;
+		d.Sj = direct->Sj;
+		d.Sx = direct->Sx;
+		d.cap = direct->cap;
+	}
+	const bool packed = B.elem_bytes == 2;
+	int dev = 0;
+	HIP_CHECK(hipGetDevice(&dev));
+	hipDeviceProp_t prop;
+	HIP_CHECK(hipGetDeviceProperties(&prop, dev));
+	// few long rows asked for as dense rows (the completion test: combinations of every remaining row): workgroups split
+	// the columns AND the entries of a row; otherwise one wave per row
+	if (dense_out != nullptr && a.nrows > 0 && a.nrows < prop.multiProcessorCount && a.avg_row_entries >= 1024) {
+		const int nwords = d.Smpad / (packed ? 2 : 1);
+		const dim3 grid((unsigned) ((nwords + 64 * AP_TU - 1) / (64 * AP_TU)), (unsigned) a.nrows);
+		if (packed)
+			hipLaunchKernelGGL(bs_apply_wide_kernel<true>, grid, dim3(64 * AW_NW), 0, stream, d);
+		else
+			hipLaunchKernelGGL(bs_apply_wide_kernel<false>, grid, dim3(64 * AW_NW), 0, stream, d);
+		HIP_CHECK(hipGetLastError());
+		return;
+	}
+	const size_t per_wave = ((size_t) d.Smpad * (size_t) B.elem_bytes + (size_t) AP_LIST * sizeof(uint2) + 15) / 16 * 16;
 	if (per_wave > 150 * 1024)
 		die("launch_backsolve_apply: %d non-pivotal columns do not fit the LDS row buffer", B.Sm);
 	// as many waves as fit half of a CU's LDS (two workgroups per CU), at most 8, at least 1
 	const int waves = (int) std::max<size_t>(1, std::min<size_t>(8, (size_t) (76 * 1024) / per_wave));
 	d.waves = waves;
-	d.dense_out = dense_out;
-	d.ldS = ldS;
+	d.wave_bytes = per_wave;
 	const size_t lds = per_wave * (size_t) waves;
-	static size_t configured = 0;
-	if (lds > configured) {
-		HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(&bs_apply_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
-		                              (int) lds));
-		configured = lds;
-	}
-	int dev = 0;
-	HIP_CHECK(hipGetDevice(&dev));
-	hipDeviceProp_t prop;
-	HIP_CHECK(hipGetDeviceProperties(&prop, dev));
 	const int blocks = std::max(1, std::min((a.nrows + waves - 1) / waves, prop.multiProcessorCount * 8));
-	hipLaunchKernelGGL(bs_apply_kernel, dim3(blocks), dim3(64 * waves), lds, stream, d);
+	if (packed)
+		launch_apply_variant<true>(d, blocks, lds, stream);
+	else
+		launch_apply_variant<false>(d, blocks, lds, stream);
 	HIP_CHECK(hipGetLastError());
 }
 

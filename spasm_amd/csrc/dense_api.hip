@@ -1,6 +1,7 @@
 // C ABI of the dense tail: dense rows of the Schur complement and dense RREF mod p.
 #include <algorithm>
 #include <cinttypes>
+#include <cmath>
 #include <cstring>
 #include <thread>
 #include <vector>
@@ -28,7 +29,8 @@ void launch_regroup_rows(const SchurArgs &a, int *sortbuf, int *order, hipStream
 void launch_schur_wave_dense(const SchurArgs &a, unsigned char *scratch, int64_t slot_bytes, int64_t off_bm, int64_t off_xn,
                              bool wide, uint32_t *dense_out, int64_t ldS, int blocks, hipStream_t stream);
 void backsolve_build(const spasm_hip_dfact *F, hipStream_t stream);
-void launch_backsolve_apply(const SchurArgs &a, const spasm_hip_dfact *F, uint32_t *dense_out, int64_t ldS, hipStream_t stream);
+void launch_backsolve_apply(const SchurArgs &a, const spasm_hip_dfact *F, uint32_t *dense_out, int64_t ldS, hipStream_t stream,
+                            const BsDirectOut *direct);
 bool backsolve_wanted(const spasm_hip_dfact *F, bool other_path_forced);
 }  // namespace sh
 
@@ -104,7 +106,8 @@ static int dschur_dense_impl(const spasm_hip_dcsr *A, const int *d_rows, int nro
 		a.ctr = W->d_ctr;
 		a.ctr64 = W->d_ctr64;
 		a.done_ctr = CTR_DONE2;
-		launch_backsolve_apply(a, F, d_S, ldS, stream);
+		a.avg_row_entries = (A->nnz > 0 && A->n > 0) ? (int) std::min<i64>(A->nnz / A->n, 1 << 30) : 0;
+		launch_backsolve_apply(a, F, d_S, ldS, stream, nullptr);
 		HIP_CHECK(hipStreamSynchronize(stream));
 		return 0;
 	}
@@ -217,6 +220,216 @@ static int dschur_dense_impl(const spasm_hip_dcsr *A, const int *d_rows, int nro
 		Lout->used = (i64) ctr64[C64_LPOOL];
 	return ctr[CTR_STATUS] & 2;
 }
+
+
+namespace sh {
+// N random combinations of the rows d_rows[0..n) of A (w > 0: of w random rows each, first coefficient 1; w <= 0: of all
+// the rows), reduced by F, as dense rows on the non-pivotal columns: d_S is N x ldS, values in [0, p).  Everything on
+// `stream`, which is synchronised before returning.  W needs max_rows >= N.
+void device_random_dense_rows(const spasm_hip_dcsr &dA, const int *d_rows, int n, const spasm_hip_dfact *F, int N, int w,
+                              uint64_t salt, u32 *d_S, i64 ldS, spasm_hip_dwork *W, hipStream_t stream)
+{
+	const int m = dA.m;
+	const double t0 = wtime();
+	// Y = C * A[p, :], dense 64-bit accumulators, then CSR
+	unsigned long long *dY = dalloc<unsigned long long>((i64) N * m);
+	HIP_CHECK(hipMemsetAsync(dY, 0, (size_t) N * m * sizeof(unsigned long long), stream));
+	launch_combine(dA.p, dA.j, dA.x, d_rows, n, N, w, m, salt, dY, F->mont, stream);
+	launch_dense_count(dY, N, m, (uint32_t) F->prime, W->d_row_len, stream);
+	launch_row_scan(W->d_row_len, N, W->d_blocksum, W->d_Sp, stream);
+	i64 ynnz = 0;
+	HIP_CHECK(hipMemcpyAsync(&ynnz, W->d_Sp + N, sizeof(i64), hipMemcpyDeviceToHost, stream));
+	HIP_CHECK(hipStreamSynchronize(stream));
+	int *dYj = dalloc<int>(ynnz);
+	int *dYx = dalloc<int>(ynnz);
+	launch_dense_pack(dY, N, m, (uint32_t) F->prime, W->d_Sp, dYj, dYx, stream);
+	i64 *dYp = dalloc<i64>((i64) N + 1);
+	HIP_CHECK(hipMemcpyAsync(dYp, W->d_Sp, ((size_t) N + 1) * sizeof(i64), hipMemcpyDeviceToDevice, stream));
+	std::vector<int> ident((size_t) N);
+	for (int k = 0; k < N; k++)
+		ident[k] = k;
+	int *dident = dalloc<int>(N);
+	HIP_CHECK(hipMemcpyAsync(dident, ident.data(), (size_t) N * sizeof(int), hipMemcpyHostToDevice, stream));
+	HIP_CHECK(hipStreamSynchronize(stream));
+	const double t1 = wtime();
+	(void) hipFree(dY);
+	spasm_hip_dcsr dYcsr{N, m, ynnz, dYp, dYj, dYx};
+	dschur_dense_impl(&dYcsr, dident, N, F, W, d_S, ldS, stream, nullptr);
+	if (verbose() >= 2)
+		logmsg("[dense rows] %d combinations: combine + pack %.3fs (%" PRId64 " entries), reduction %.3fs\n", N, t1 - t0, ynnz, wtime() - t1);
+	(void) hipFree(dident);
+	(void) hipFree(dYp);
+	(void) hipFree(dYj);
+	(void) hipFree(dYx);
+}
+}  // namespace sh
+
+
+// --------------------------------------------------------------------------
+// Device-resident dense finish (echelonize_dense / echelonize_dense_lowrank, spasm_echelonize.c:299-467).
+//
+// The reference loops: dense rows of the Schur complement (a block of rows, or random combinations of all of them)
+// -> FFPACK RREF of the block -> the new pivotal rows are appended to U -> the next block is reduced by the larger U.
+// Every trip goes through the host and, here, would rebuild the factor image of a U that has grown.  With the
+// back-substituted image R of the factor at hand the whole loop lives in the space of its Sm non-pivotal columns:
+// blocks are reduced by the ORIGINAL factor only (a_n - a_p R), stacked under the echelon rows E found so far, and one
+// dense RREF of [E; Y] on the matrix cores both reduces Y by E and extends E.  A, R, E and the blocks never leave HBM;
+// the host gets the final E once and appends it to U.  Same row space, same rank; the control flow (block size, weights,
+// low-rank switch, completion test) is the reference's.
+// --------------------------------------------------------------------------
+namespace sh {
+
+bool finish_on_device(const struct spasm_csr *A, const int *p, int n, struct spasm_lu *fact, struct echelonize_opts *opts,
+                      bool lowrank_first)
+{
+	if (opts->L || env_int("SPASM_HIP_DEVICE_FINISH", 1) == 0 || n <= 0)
+		return false;
+	hipStream_t stream = nullptr;
+	spasm_hip_dfact *F = cached_dfact(fact->U, fact->qinv, stream);
+	const int Sm0 = F->Sm, m = A->m;
+	if (Sm0 <= 0 || !backsolve_wanted(F, env_int("SPASM_HIP_FORCE_TIER", 0) != 0 || env_int("SPASM_HIP_GROUP", -1) >= 0))
+		return false;
+	const i64 prime = A->field->p;
+	const int block = std::max(1, opts->dense_block_size);
+	const int Sn_test = (int) std::ceil(128.0 / std::log2((double) prime));
+	const double start = wtime();
+	const i64 annz = A->p[A->n];
+	i64 *dAp = dalloc<i64>((i64) A->n + 1);
+	int *dAj = dalloc<int>(annz);
+	int *dAx = dalloc<int>(annz);
+	int *drows = dalloc<int>(n);
+	HIP_CHECK(hipMemcpy(dAp, A->p, ((size_t) A->n + 1) * sizeof(i64), hipMemcpyHostToDevice));
+	if (annz > 0) {
+		HIP_CHECK(hipMemcpy(dAj, A->j, (size_t) annz * sizeof(int), hipMemcpyHostToDevice));
+		HIP_CHECK(hipMemcpy(dAx, A->x, (size_t) annz * sizeof(int), hipMemcpyHostToDevice));
+	}
+	HIP_CHECK(hipMemcpy(drows, p, (size_t) n * sizeof(int), hipMemcpyHostToDevice));
+	spasm_hip_dcsr dA{A->n, m, annz, dAp, dAj, dAx};
+	const int maxblock = std::max(block, Sn_test);
+	spasm_hip_dwork *W = spasm_hip_dwork_create(maxblock, m, 64);
+	const i64 ld = Sm0;
+	const i64 cap_rows = (i64) std::min(n, Sm0) + maxblock;
+	u32 *dM = dalloc<u32>(cap_rows * ld);
+	int *dpiv = dalloc<int>(Sm0);
+	static uint64_t salt = 0x5DEECE66DULL;
+	int k = 0;                           // echelon rows found so far: rows [0, k) of dM, in reduced form
+	int rank_ub = std::min(n, Sm0);
+	int processed = 0, round = 0;
+	bool lowrank = lowrank_first;
+	double t_rows = 0.0, t_rref = 0.0;
+	auto stack_and_reduce = [&](int rows_added) {
+		const double t0 = wtime();
+		const int rk = spasm_hip_drref(prime, k + rows_added, Sm0, dM, ld, dpiv, stream);
+		t_rref += wtime() - t0;
+		const int rr = rk - k;
+		k = rk;
+		return rr;
+	};
+	if (!lowrank) {
+		// echelonize_dense: the rows themselves, block by block
+		logmsg("[echelonize/dense/device] dense schur complement of dimension %d x %d; block size=%d\n", n, Sm0, block);
+		for (;;) {
+			const int Sn = std::min(block, n - processed);
+			if (Sn <= 0 || k >= Sm0)
+				break;
+			dschur_dense_impl(&dA, drows + processed, Sn, F, W, dM + (i64) k * ld, ld, stream, nullptr);
+			const int rr = stack_and_reduce(Sn);
+			logmsg("[echelonize/dense/device] round %d: S[%d:%d], %d new pivots (%d in all)\n", round, processed, processed + Sn, rr, k);
+			round += 1;
+			processed += Sn;
+			rank_ub = std::min(n - processed + 0, Sm0 - k);
+			if (opts->enable_tall_and_skinny && rr < opts->low_rank_ratio * Sn) {
+				lowrank = true;
+				break;
+			}
+		}
+		if (!(lowrank && rank_ub > 0 && n - processed > 0))
+			lowrank = false;
+		else
+			logmsg("[echelonize/dense/device] too few pivots; switching to low-rank mode\n");
+	}
+	if (lowrank) {
+		// echelonize_dense_lowrank: random combinations of the remaining rows
+		const int nleft = n - processed;
+		const int *rows_left = drows + processed;
+		rank_ub = std::min(nleft, Sm0 - k);
+		int w = (opts->low_rank_start_weight < 0) ? (int) std::ceil(-std::log(0.01) * nleft / (rank_ub > 0 ? rank_ub : 1))
+		                                          : (int) opts->low_rank_start_weight;
+		logmsg("[echelonize/dense/low-rank/device] dense schur complement of dimension %d x %d; block size=%d\n", nleft, Sm0 - k, block);
+		for (;;) {
+			const int Sn = std::min(rank_ub, block);
+			if (Sn <= 0)
+				break;
+			salt += 0x9E3779B97F4A7C15ULL;
+			const double tr0 = wtime();
+			device_random_dense_rows(dA, rows_left, nleft, F, Sn, w, salt, dM + (i64) k * ld, ld, W, stream);
+			t_rows += wtime() - tr0;
+			int rr = stack_and_reduce(Sn);
+			logmsg("[echelonize/dense/low-rank/device] round %d, weight %d, %d combinations: %d new pivots (%d in all)\n", round, w, Sn, rr, k);
+			if (rr == 0) {
+				// spasm_echelonize_test_completion (spasm_echelonize.c:30-52): a few combinations of ALL the rows
+				salt += 0x9E3779B97F4A7C15ULL;
+				device_random_dense_rows(dA, rows_left, nleft, F, Sn_test, 0, salt, dM + (i64) k * ld, ld, W, stream);
+				rr = stack_and_reduce(Sn_test);
+				if (rr == 0)
+					break;
+				logmsg("[echelonize/dense/low-rank/device] failed termination test; switching to full linear combinations\n");
+				w = 0;
+			}
+			if (rr < 0.9 * Sn && w > 0)
+				w *= 2;
+			rank_ub -= rr;
+			round += 1;
+		}
+	}
+	// the echelon rows join U: pivot first (value 1), then the other entries, on the original columns
+	std::vector<u32> E((size_t) std::max<i64>(1, (i64) k * ld));
+	std::vector<int> piv((size_t) std::max(1, k));
+	if (k > 0) {
+		HIP_CHECK(hipMemcpy(E.data(), dM, (size_t) k * ld * sizeof(u32), hipMemcpyDeviceToHost));
+		HIP_CHECK(hipMemcpy(piv.data(), dpiv, (size_t) k * sizeof(int), hipMemcpyDeviceToHost));
+	}
+	struct spasm_csr *U = fact->U;
+	const std::vector<int> &q0 = F->h_q;
+	i64 extra = 0;
+	for (i64 t = 0; t < (i64) k * ld; t++)
+		extra += E[t] != 0;
+	i64 unz = U->p[U->n];
+	spasm_hip_csr_realloc(U, unz + extra + k);
+	const u32 half = (u32) (prime / 2);
+	const int old_un = U->n;
+	for (int i = 0; i < k; i++) {
+		const u32 *row = E.data() + (size_t) i * ld;
+		const int jp = piv[i];
+		if (row[jp] != 1)
+			die("finish_on_device: echelon row %d does not have a unit pivot on column %d", i, jp);
+		U->j[unz] = q0[jp];
+		U->x[unz] = 1;
+		unz += 1;
+		fact->qinv[q0[jp]] = U->n;
+		for (int j = 0; j < Sm0; j++) {
+			if (j == jp || row[j] == 0)
+				continue;
+			U->j[unz] = q0[j];
+			U->x[unz] = (row[j] > half) ? (spasm_ZZp) ((i64) row[j] - prime) : (spasm_ZZp) row[j];
+			unz += 1;
+		}
+		U->n += 1;
+		U->p[U->n] = unz;
+	}
+	(void) hipFree(dM);
+	(void) hipFree(dpiv);
+	spasm_hip_dwork_destroy(W);
+	(void) hipFree(dAp);
+	(void) hipFree(dAj);
+	(void) hipFree(dAx);
+	(void) hipFree(drows);
+	logmsg("[echelonize/dense/device] completed in %.2fs (dense rows %.2fs, RREF %.2fs). %d new pivots found\n", wtime() - start,
+	       t_rows, t_rref, U->n - old_un);
+	return true;
+}
+
+}  // namespace sh
 
 extern "C" {
 
@@ -360,31 +573,10 @@ void spasm_hip_schur_dense_randomized(const struct spasm_csr *A, const int *p, i
 			HIP_CHECK(hipMemcpy(dAx, A->x, (size_t) annz * sizeof(int), hipMemcpyHostToDevice));
 		}
 		HIP_CHECK(hipMemcpy(drows, p, (size_t) n * sizeof(int), hipMemcpyHostToDevice));
-		// Y = C * A[p, :], dense 64-bit accumulators, then CSR
-		unsigned long long *dY = dalloc<unsigned long long>((i64) N * m);
-		HIP_CHECK(hipMemsetAsync(dY, 0, (size_t) N * m * sizeof(unsigned long long), stream));
-		launch_combine(dAp, dAj, dAx, drows, n, N, w, m, call_id * 0x9E3779B97F4A7C15ULL, dY, F->mont, stream);
+		spasm_hip_dcsr dA{A->n, m, annz, dAp, dAj, dAx};
 		spasm_hip_dwork *W = spasm_hip_dwork_create(N, m, 64);
-		launch_dense_count(dY, N, m, (uint32_t) prime, W->d_row_len, stream);
-		launch_row_scan(W->d_row_len, N, W->d_blocksum, W->d_Sp, stream);
-		i64 ynnz = 0;
-		HIP_CHECK(hipMemcpyAsync(&ynnz, W->d_Sp + N, sizeof(i64), hipMemcpyDeviceToHost, stream));
-		HIP_CHECK(hipStreamSynchronize(stream));
-		int *dYj = dalloc<int>(ynnz);
-		int *dYx = dalloc<int>(ynnz);
-		launch_dense_pack(dY, N, m, (uint32_t) prime, W->d_Sp, dYj, dYx, stream);
-		i64 *dYp = dalloc<i64>((i64) N + 1);
-		HIP_CHECK(hipMemcpyAsync(dYp, W->d_Sp, ((size_t) N + 1) * sizeof(i64), hipMemcpyDeviceToDevice, stream));
-		std::vector<int> ident((size_t) N);
-		for (int k = 0; k < N; k++)
-			ident[k] = k;
-		int *dident = dalloc<int>(N);
-		HIP_CHECK(hipMemcpyAsync(dident, ident.data(), (size_t) N * sizeof(int), hipMemcpyHostToDevice, stream));
-		HIP_CHECK(hipStreamSynchronize(stream));
-		(void) hipFree(dY);
-		spasm_hip_dcsr dYcsr{N, m, ynnz, dYp, dYj, dYx};
 		u32 *dS = dalloc<u32>((i64) N * Sm);
-		dschur_dense_impl(&dYcsr, dident, N, F, W, dS, Sm, stream, nullptr);
+		device_random_dense_rows(dA, drows, n, F, N, w, call_id * 0x9E3779B97F4A7C15ULL, dS, Sm, W, stream);
 		std::vector<u32> h((size_t) N * Sm);
 		HIP_CHECK(hipMemcpy(h.data(), dS, (size_t) N * Sm * sizeof(u32), hipMemcpyDeviceToHost));
 		const u32 half = (u32) (prime / 2);
@@ -397,10 +589,6 @@ void spasm_hip_schur_dense_randomized(const struct spasm_csr *A, const int *p, i
 			}
 		}
 		(void) hipFree(dS);
-		(void) hipFree(dident);
-		(void) hipFree(dYp);
-		(void) hipFree(dYj);
-		(void) hipFree(dYx);
 		spasm_hip_dwork_destroy(W);
 		(void) hipFree(dAp);
 		(void) hipFree(dAj);

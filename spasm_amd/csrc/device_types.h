@@ -94,6 +94,7 @@ struct SchurArgs {
 	int64_t L_cap;
 	const int *kof;           // label -> row of U
 	const int *row_orig;      // output row k -> row index to record (p_in[p[k]] or p[k])
+	int avg_row_entries;      // host hint: entries of A per reduced row (0: unknown)
 };
 
 // device pools receiving the elimination coefficients (triplets) of a Schur call
@@ -138,7 +139,8 @@ struct BsImage {
 	int r = 0, Sm = 0, nchunks = 0;
 	int64_t ldR = 0;          // Sm rounded up to 256
 	int64_t nfar = 0, nnear = 0, nnp = 0, ndeps = 0;
-	uint32_t *d_R = nullptr;
+	void *d_R = nullptr;              // r x ldR entries of elem_bytes each (uint16_t when p < 2^16, else uint32_t)
+	int elem_bytes = 4;
 	int *d_col = nullptr;             // column -> compact row id of its pivot, or r + index among the non-pivotal columns
 	BsChunk *d_chunk = nullptr;
 	int2 *d_step = nullptr;           // [first, last) into d_brow
@@ -149,9 +151,20 @@ struct BsImage {
 	uint2 *d_far = nullptr;
 	uint64_t *d_np_rp = nullptr;      // per compact row: non-pivotal entries (index among the non-pivotal columns, value * 2^32 mod p)
 	uint2 *d_np = nullptr;
+	int *d_np_row = nullptr;          // compact row of every entry of d_np
 	int *d_chunk_extra = nullptr;     // per chunk: some row has more than two dependencies outside the chunk
 	hipEvent_t ev0 = nullptr, ev1 = nullptr;     // around the last build (memset + init + backsolve kernel)
 	int builds = 0;
+	char kernel_build[48] = "backsolve_kernel";      // variant launched by the last build, as rocprofv3 prints it
+};
+
+// where bs_apply_kernel writes a sparse result directly in its final place (rows in order, offsets by look-back)
+struct BsDirectOut {
+	unsigned long long *status;   // nrows words, zeroed before the launch
+	int *ticket;                  // zeroed before the launch
+	int64_t *Sp;                  // nrows + 1
+	int *Sj, *Sx;
+	int64_t cap;                  // capacity of Sj / Sx
 };
 
 }  // namespace sh
@@ -192,6 +205,7 @@ struct spasm_hip_dwork {
 	int *d_order = nullptr, *d_sortbuf = nullptr;   // rows regrouped by connected component of the pivot graph
 	int64_t sortbuf_ints = 0;
 	int *d_Sj = nullptr, *d_Sx = nullptr;
+	unsigned long long *d_lb_status = nullptr;   // look-back words of the direct sparse output (max_rows + 1: the last one is the ticket)
 	unsigned char *d_scratch = nullptr;   // per-wave dense accumulators (all zero between calls)
 	int64_t scratch_bytes = 0;
 	int64_t scratch_budget = 0;           // 0: up to half of the free HBM; else a cap in bytes

@@ -1,0 +1,191 @@
+// Multi-GPU layer of the C ABI: one process per GPU, RCCL over xGMI (include/spasm_hip.h, section (M)).
+//
+// What shards is what the reference hands to OpenMP threads: the rows of a Schur complement (spasm_schur.c:86-171).
+// Every rank holds A and the factor, reduces a contiguous slice of the row list on its GPU, and the slices are
+// reassembled ON THE DEVICES with an all-gatherv -- one ncclAllGather for the sizes, then one grouped round of
+// ncclBroadcast per rank and array with the exact counts (no padding, no host staging).  The host pivot search runs
+// once, on rank 0 (it is threaded and timing dependent), and its outcome is broadcast.  With a communicator installed
+// (spasm_hip_set_comm) the ordinary entry points -- spasm_hip_pivots_extract_structural, spasm_hip_schur and with them
+// spasm_hip_echelonize -- do all this by themselves; every rank must make the same calls in the same order.
+#include <rccl/rccl.h>
+
+#include <algorithm>
+#include <cinttypes>
+#include <cstring>
+#include <vector>
+
+#include "device_types.h"
+
+#define NCCL_CHECK(expr)                                                                                     \
+	do {                                                                                                 \
+		ncclResult_t r_ = (expr);                                                                    \
+		if (r_ != ncclSuccess)                                                                       \
+			sh::die("%s failed: %s (%s:%d)", #expr, ncclGetErrorString(r_), __FILE__, __LINE__);   \
+	} while (0)
+
+struct spasm_hip_comm {
+	ncclComm_t comm = nullptr;
+	int rank = 0, world = 1;
+	hipStream_t stream = nullptr;       // host-driven exchanges (broadcasts of pivot search results)
+	int64_t *d_sizes = nullptr;         // 2 * world
+	void *d_stage = nullptr;            // staging buffer of comm_bcast_host
+	size_t stage_bytes = 0;
+};
+
+namespace sh {
+
+static spasm_hip_comm *g_comm = nullptr;
+
+spasm_hip_comm *current_comm() { return g_comm; }
+int comm_rank(const spasm_hip_comm *c) { return c->rank; }
+int comm_world(const spasm_hip_comm *c) { return c->world; }
+
+__global__ void rebase_offsets_kernel(int64_t *Sp, int n, int64_t base)
+{
+	const int t = blockIdx.x * blockDim.x + threadIdx.x;
+	if (t < n)
+		Sp[t] += base;
+}
+
+// broadcast of a host buffer from `root` (staged through device memory: RCCL moves device buffers)
+void comm_bcast_host(spasm_hip_comm *c, void *buf, size_t bytes, int root)
+{
+	if (c == nullptr || c->world == 1 || bytes == 0)
+		return;
+	if (c->stage_bytes < bytes) {
+		if (c->d_stage != nullptr)
+			(void) hipFree(c->d_stage);
+		HIP_CHECK(hipMalloc(&c->d_stage, bytes));
+		c->stage_bytes = bytes;
+	}
+	if (c->rank == root)
+		HIP_CHECK(hipMemcpyAsync(c->d_stage, buf, bytes, hipMemcpyHostToDevice, c->stream));
+	NCCL_CHECK(ncclBroadcast(c->d_stage, c->d_stage, bytes, ncclUint8, root, c->comm, c->stream));
+	if (c->rank != root)
+		HIP_CHECK(hipMemcpyAsync(buf, c->d_stage, bytes, hipMemcpyDeviceToHost, c->stream));
+	HIP_CHECK(hipStreamSynchronize(c->stream));
+}
+
+}  // namespace sh
+
+using namespace sh;
+
+extern "C" {
+
+int spasm_hip_comm_id_bytes(void) { return (int) sizeof(ncclUniqueId); }
+
+void spasm_hip_comm_new_id(void *id)
+{
+	ncclUniqueId u;
+	NCCL_CHECK(ncclGetUniqueId(&u));
+	std::memcpy(id, &u, sizeof(u));
+}
+
+// collective over the `world` processes that hold the same id; uses the calling thread's current HIP device
+spasm_hip_comm *spasm_hip_comm_create(const void *id, int rank, int world)
+{
+	if (spasm_hip_device_count() == 0)
+		die("spasm_hip_comm_create: no HIP device (this library has no CPU path)");
+	if (world < 1 || rank < 0 || rank >= world)
+		die("spasm_hip_comm_create: rank %d of %d", rank, world);
+	spasm_hip_comm *c = new spasm_hip_comm();
+	c->rank = rank;
+	c->world = world;
+	ncclUniqueId u;
+	std::memcpy(&u, id, sizeof(u));
+	NCCL_CHECK(ncclCommInitRank(&c->comm, world, u, rank));
+	HIP_CHECK(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
+	HIP_CHECK(hipMalloc((void **) &c->d_sizes, (size_t) 2 * world * sizeof(int64_t)));
+	return c;
+}
+
+void spasm_hip_comm_destroy(spasm_hip_comm *c)
+{
+	if (c == nullptr)
+		return;
+	if (g_comm == c)
+		g_comm = nullptr;
+	(void) hipFree(c->d_sizes);
+	if (c->d_stage != nullptr)
+		(void) hipFree(c->d_stage);
+	(void) hipStreamDestroy(c->stream);
+	(void) ncclCommDestroy(c->comm);
+	delete c;
+}
+
+int spasm_hip_comm_rank(const spasm_hip_comm *c) { return c->rank; }
+int spasm_hip_comm_world(const spasm_hip_comm *c) { return c->world; }
+
+// installs (or, with NULL, removes) the communicator the host-pointer entry points use
+void spasm_hip_set_comm(spasm_hip_comm *c) { g_comm = c; }
+
+// [lo, hi) of the contiguous slice of n rows owned by `rank` (sizes differ by at most one)
+void spasm_hip_shard(int n, int rank, int world, int *lo, int *hi)
+{
+	const int base = n / world, extra = n % world;
+	*lo = rank * base + std::min(rank, extra);
+	*hi = *lo + base + (rank < extra ? 1 : 0);
+}
+
+// All-gatherv of the Schur complements the ranks left in their workspaces (last spasm_hip_dschur on W): the rows of
+// rank 0, then rank 1, ... as one CSR in caller-provided device buffers (d_Sp: total rows + 1; d_Sj, d_Sx: cap entries).
+// Returns 0, or 1 when cap is too small (nothing is moved then; *total_nnz says what is needed).  total_rows / total_nnz
+// may be NULL.  Everything is enqueued on `stream`, which is synchronised once for the sizes.
+int spasm_hip_dschur_allgatherv(spasm_hip_comm *c, const spasm_hip_dwork *W, i64 *d_Sp, int *d_Sj, spasm_ZZp *d_Sx, i64 cap,
+                                int *total_rows, i64 *total_nnz, void *stream_)
+{
+	hipStream_t stream = (hipStream_t) stream_;
+	const int world = c->world;
+	const int64_t mine[2] = {(int64_t) W->last_rows, (int64_t) W->last_nnz};
+	HIP_CHECK(hipMemcpyAsync(c->d_sizes + 2 * c->rank, mine, sizeof(mine), hipMemcpyHostToDevice, stream));
+	NCCL_CHECK(ncclAllGather(c->d_sizes + 2 * c->rank, c->d_sizes, 2, ncclInt64, c->comm, stream));
+	std::vector<int64_t> sizes((size_t) 2 * world);
+	HIP_CHECK(hipMemcpyAsync(sizes.data(), c->d_sizes, sizes.size() * sizeof(int64_t), hipMemcpyDeviceToHost, stream));
+	HIP_CHECK(hipStreamSynchronize(stream));
+	std::vector<int64_t> row_base((size_t) world + 1, 0), nz_base((size_t) world + 1, 0);
+	for (int r = 0; r < world; r++) {
+		row_base[r + 1] = row_base[r] + sizes[2 * r];
+		nz_base[r + 1] = nz_base[r] + sizes[2 * r + 1];
+	}
+	if (total_rows != nullptr)
+		*total_rows = (int) row_base[world];
+	if (total_nnz != nullptr)
+		*total_nnz = nz_base[world];
+	if (cap < 0 || nz_base[world] > cap)
+		return 1;
+	// exact counts: one broadcast per rank and array, all in one group (they run concurrently over the links)
+	NCCL_CHECK(ncclGroupStart());
+	for (int r = 0; r < world; r++) {
+		const int64_t nr = sizes[2 * r], nz = sizes[2 * r + 1];
+		if (nr > 0)
+			NCCL_CHECK(ncclBroadcast(W->d_Sp, d_Sp + row_base[r], (size_t) nr, ncclInt64, r, c->comm, stream));
+		if (nz > 0) {
+			NCCL_CHECK(ncclBroadcast(W->d_Sj, d_Sj + nz_base[r], (size_t) nz, ncclInt32, r, c->comm, stream));
+			NCCL_CHECK(ncclBroadcast(W->d_Sx, d_Sx + nz_base[r], (size_t) nz, ncclInt32, r, c->comm, stream));
+		}
+	}
+	NCCL_CHECK(ncclGroupEnd());
+	// the row pointers of a slice start at 0: shift them to where the slice went
+	for (int r = 0; r < world; r++) {
+		const int nr = (int) sizes[2 * r];
+		if (nr > 0 && nz_base[r] != 0)
+			hipLaunchKernelGGL(rebase_offsets_kernel, dim3((nr + 255) / 256), dim3(256), 0, stream, d_Sp + row_base[r], nr, nz_base[r]);
+	}
+	HIP_CHECK(hipMemcpyAsync(d_Sp + row_base[world], &nz_base[world], sizeof(int64_t), hipMemcpyHostToDevice, stream));
+	HIP_CHECK(hipStreamSynchronize(stream));        // (nz_base dies here)
+	return 0;
+}
+
+// spasm_echelonize with the Schur complements of every round sharded over the ranks of `c` (one process per GPU).
+// Collective: every rank passes the same A and options and gets the same rank; the factorization returned on rank 0 is
+// the reference one (the random combinations of a dense finish are drawn per rank).
+struct spasm_lu *spasm_hip_echelonize_dist(const struct spasm_csr *A, struct echelonize_opts *opts, spasm_hip_comm *c)
+{
+	spasm_hip_comm *saved = g_comm;
+	g_comm = c;
+	struct spasm_lu *fact = spasm_hip_echelonize(A, opts);
+	g_comm = saved;
+	return fact;
+}
+
+}  // extern "C"

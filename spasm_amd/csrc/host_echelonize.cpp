@@ -12,6 +12,12 @@
 #include "common.h"
 #include "sha256.h"
 
+namespace sh {
+// device-resident dense / low-rank finish (dense_api.hip); false: not applicable, use the loops below
+bool finish_on_device(const struct spasm_csr *A, const int *p, int n, struct spasm_lu *fact, struct echelonize_opts *opts,
+                      bool lowrank_first);
+}  // namespace sh
+
 using namespace sh;
 
 // --------------------------------------------------------------------------
@@ -451,10 +457,12 @@ extern "C" struct spasm_lu *spasm_hip_echelonize(const struct spasm_csr *A0, str
 		logmsg("[echelonize] finishing; density = %.3f; aspect ratio = %.1f\n", density, aspect);
 		if (opts->enable_tall_and_skinny && aspect > opts->tall_and_skinny_ratio) {
 			Stopwatch sw(4);
-			finish_lowrank(A, p + npiv, n - npiv, fact, opts);
+			if (!finish_on_device(A, p + npiv, n - npiv, fact, opts, true))
+				finish_lowrank(A, p + npiv, n - npiv, fact, opts);
 		} else if (opts->enable_dense && density > opts->sparsity_threshold) {
 			Stopwatch sw(4);
-			finish_dense(A, p + npiv, n - npiv, p_in, fact, opts);
+			if (!finish_on_device(A, p + npiv, n - npiv, fact, opts, false))
+				finish_dense(A, p + npiv, n - npiv, p_in, fact, opts);
 		} else if (opts->enable_GPLU) {
 			Stopwatch sw(6);
 			// The reference reduces the remaining rows one by one (GPLU, a sequential loop).  Here the
@@ -476,7 +484,8 @@ extern "C" struct spasm_lu *spasm_hip_echelonize(const struct spasm_csr *A0, str
 					break;
 				density = spasm_hip_schur_estimate_density(A, p + npiv, n - npiv, U, Uqinv, 100);
 				if (opts->enable_dense && density > opts->sparsity_threshold) {
-					finish_dense(A, p + npiv, n - npiv, p_in, fact, opts);
+					if (!finish_on_device(A, p + npiv, n - npiv, fact, opts, false))
+						finish_dense(A, p + npiv, n - npiv, p_in, fact, opts);
 					break;
 				}
 				int *p_out = (int *) xmalloc((i64) (n - npiv) * sizeof(int));

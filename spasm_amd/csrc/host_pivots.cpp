@@ -16,6 +16,14 @@
 
 using namespace sh;
 
+namespace sh {
+// multi-GPU layer (dist_api.hip)
+spasm_hip_comm *current_comm();
+int comm_rank(const spasm_hip_comm *c);
+int comm_world(const spasm_hip_comm *c);
+void comm_bcast_host(spasm_hip_comm *c, void *buf, size_t bytes, int root);
+}  // namespace sh
+
 namespace {
 
 struct Search {
@@ -312,30 +320,43 @@ extern "C" int spasm_hip_pivots_extract_structural(const struct spasm_csr *A, co
 	S.A = A;
 	S.pinv.assign((size_t) (n > 0 ? n : 1), -1);
 	S.qinv.assign((size_t) (m > 0 ? m : 1), -1);
-	int npiv = S.leftmost_entries();
-	logmsg("[pivots] Faugere-Lachartre: %d pivots found [%.1fs]\n", npiv, wtime() - t0);
-	double t1 = wtime();
-	int extra = S.free_columns();
-	npiv += extra;
-	logmsg("[pivots] Faugere-Lachartre on columns: %d pivots found [%.1fs]\n", extra, wtime() - t1);
-	if (opts == nullptr || opts->enable_greedy_pivot_search) {
-		t1 = wtime();
-		int threads = 0;
-		if (const char *e = std::getenv("SPASM_HIP_THREADS"))
-			threads = std::atoi(e);
-		if (threads <= 0) {
-			threads = (int) std::thread::hardware_concurrency();
-			if (threads > 16)          // (commits serialise the searches: 16 threads 0.57 s, 32: 0.63 s, 128: 1.0 s on mk13.b5)
-				threads = 16;
-		}
-		if (A->n < 20000)
-			threads = 1;                  // small inputs: the sequential search (deterministic) is as fast
-		extra = (threads > 1) ? S.acyclic_greedy_threads(threads) : S.acyclic_greedy();
+	// one process per GPU (dist_api.hip): the search is threaded and its outcome depends on timing, so rank 0 searches
+	// and every rank gets its result -- the pivots (pinv) and the row order (p); the rows of U follow from them
+	spasm_hip_comm *comm = current_comm();
+	const bool dist = comm != nullptr && comm_world(comm) > 1;
+	int npiv = 0;
+	if (!dist || comm_rank(comm) == 0) {
+		npiv = S.leftmost_entries();
+		logmsg("[pivots] Faugere-Lachartre: %d pivots found [%.1fs]\n", npiv, wtime() - t0);
+		double t1 = wtime();
+		int extra = S.free_columns();
 		npiv += extra;
-		logmsg("[pivots] greedy alternating cycle-free search: %d pivots found [%.1fs]\n", extra, wtime() - t1);
+		logmsg("[pivots] Faugere-Lachartre on columns: %d pivots found [%.1fs]\n", extra, wtime() - t1);
+		if (opts == nullptr || opts->enable_greedy_pivot_search) {
+			t1 = wtime();
+			int threads = 0;
+			if (const char *e = std::getenv("SPASM_HIP_THREADS"))
+				threads = std::atoi(e);
+			if (threads <= 0) {
+				threads = (int) std::thread::hardware_concurrency();
+				if (threads > 16)          // (commits serialise the searches: 16 threads 0.57 s, 32: 0.63 s, 128: 1.0 s on mk13.b5)
+					threads = 16;
+			}
+			if (A->n < 20000)
+				threads = 1;                  // small inputs: the sequential search (deterministic) is as fast
+			extra = (threads > 1) ? S.acyclic_greedy_threads(threads) : S.acyclic_greedy();
+			npiv += extra;
+			logmsg("[pivots] greedy alternating cycle-free search: %d pivots found [%.1fs]\n", extra, wtime() - t1);
+		}
+		logmsg("[pivots] %d pivots found\n", npiv);
+		S.topological_rows(npiv, p);
+
 	}
-	logmsg("[pivots] %d pivots found\n", npiv);
-	S.topological_rows(npiv, p);
+	if (dist) {
+		comm_bcast_host(comm, &npiv, sizeof(int), 0);
+		comm_bcast_host(comm, p, (size_t) n * sizeof(int), 0);
+		comm_bcast_host(comm, S.pinv.data(), (size_t) n * sizeof(int), 0);
+	}
 
 	struct spasm_csr *U = fact->U;
 	struct spasm_triplet *L = fact->Ltmp;

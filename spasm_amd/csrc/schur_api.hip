@@ -25,8 +25,13 @@ bool backsolve_eligible(int r, int Sm, int64_t nnz_u, int64_t *bytes);
 void backsolve_plan(const FactPlan &P, spasm_hip_dfact *F, hipStream_t stream);
 void backsolve_free(spasm_hip_dfact *F);
 void backsolve_build(const spasm_hip_dfact *F, hipStream_t stream);
-void launch_backsolve_apply(const SchurArgs &a, const spasm_hip_dfact *F, uint32_t *dense_out, int64_t ldS, hipStream_t stream);
+void launch_backsolve_apply(const SchurArgs &a, const spasm_hip_dfact *F, uint32_t *dense_out, int64_t ldS, hipStream_t stream,
+                            const BsDirectOut *direct);
 bool backsolve_wanted(const spasm_hip_dfact *F, bool other_path_forced);
+// multi-GPU layer (dist_api.hip)
+spasm_hip_comm *current_comm();
+int comm_rank(const spasm_hip_comm *c);
+int comm_world(const spasm_hip_comm *c);
 }  // namespace sh
 
 using namespace sh;
@@ -194,6 +199,10 @@ bool backsolve_wanted(const spasm_hip_dfact *F, bool other_path_forced)
 }  // namespace sh
 
 extern "C" {
+
+void spasm_hip_shard(int n, int rank, int world, int *lo, int *hi);
+int spasm_hip_dschur_allgatherv(spasm_hip_comm *c, const spasm_hip_dwork *W, i64 *d_Sp, int *d_Sj, spasm_ZZp *d_Sx, i64 cap,
+                                int *total_rows, i64 *total_nnz, void *stream);
 
 int spasm_hip_debug_plan(const struct spasm_csr *U, const int *qinv, int *label_of_row, int *lvl_end_of_row, int *lab,
                          int *info);
@@ -564,6 +573,8 @@ void spasm_hip_dwork_destroy(spasm_hip_dwork *W)
 	(void) hipFree(W->d_ovf2);
 	(void) hipFree(W->d_Sp);
 	(void) hipFree(W->d_blocksum);
+	if (W->d_lb_status != nullptr)
+		(void) hipFree(W->d_lb_status);
 	if (W->d_order != nullptr)
 		(void) hipFree(W->d_order);
 	if (W->d_sortbuf != nullptr)
@@ -716,7 +727,7 @@ int dschur_impl(const spasm_hip_dcsr *A, const int *d_rows, int nrows, const spa
 		a.row_orig = Lout->row_orig;
 	}
 
-	bool used_bs = false, built_bs = false;
+	bool used_bs = false, built_bs = false, bs_direct = false;
 	if (want_bs) {
 		// R is built on first use
 		used_bs = true;
@@ -729,7 +740,17 @@ int dschur_impl(const spasm_hip_dcsr *A, const int *d_rows, int nrows, const spa
 		a.list = nullptr;
 		a.list_count = nullptr;
 		a.done_ctr = CTR_DONE2;
-		launch_backsolve_apply(a, F, nullptr, 0, stream);
+		// rows straight into W->d_Sj / d_Sx in their final order (offsets by look-back): no pool, no gather pass
+		bs_direct = env_int("SPASM_HIP_BS_DIRECT", 1) != 0;
+		if (bs_direct) {
+			if (W->d_lb_status == nullptr)
+				W->d_lb_status = dalloc<unsigned long long>((i64) W->max_rows + 2);
+			HIP_CHECK(hipMemsetAsync(W->d_lb_status, 0, ((size_t) nrows + 2) * sizeof(unsigned long long), stream));
+			BsDirectOut out{W->d_lb_status, reinterpret_cast<int *>(W->d_lb_status + nrows + 1), W->d_Sp, W->d_Sj, W->d_Sx, W->pool_cap};
+			launch_backsolve_apply(a, F, nullptr, 0, stream, &out);
+		} else {
+			launch_backsolve_apply(a, F, nullptr, 0, stream, nullptr);
+		}
 		HIP_CHECK(hipEventRecord(W->ev[3], stream));
 		HIP_CHECK(hipEventRecord(W->ev[4], stream));
 		goto eliminated;
@@ -832,7 +853,8 @@ int dschur_impl(const spasm_hip_dcsr *A, const int *d_rows, int nrows, const spa
 	}
 eliminated:
 	HIP_CHECK(hipEventRecord(W->ev[1], stream));
-	launch_finalize(W, nrows, sort_rows, stream);
+	if (!bs_direct)
+		launch_finalize(W, nrows, sort_rows, stream);
 	HIP_CHECK(hipEventRecord(W->ev[2], stream));
 
 	int ctr[CTR_COUNT];
@@ -844,6 +866,8 @@ eliminated:
 	HIP_CHECK(hipStreamSynchronize(stream));
 	W->last_rows = nrows;
 	W->last_nnz = total;
+	if (ctr[CTR_STATUS] & 4)
+		die("spasm_hip_dschur: a row waited for its predecessors' lengths for too long (look-back of the direct output)");
 	const int status = ctr[CTR_STATUS] & 3;      // bit 0: row pool exhausted, bit 1: L pool exhausted
 #ifdef SPASM_GROUP_PROFILE
 	if (group_mode) {
@@ -875,17 +899,22 @@ eliminated:
 		stats->ms_backsolve = stats->ms_apply = 0.0f;
 		stats->bytes_backsolve = stats->bytes_apply = 0;
 		stats->kernel[0] = 0;
+		stats->kernel_other[0] = 0;
 		if (used_bs) {
 			const BsImage &B = F->bs;
 			if (built_bs) {
 				HIP_CHECK(hipEventElapsedTime(&stats->ms_backsolve, B.ev0, B.ev1));
 				// every row of R written once and read once per dependency; the entries of U' read once
-				stats->bytes_backsolve = ((i64) B.r + B.ndeps) * (i64) B.Sm * 4 + 8 * F->nnz;
+				stats->bytes_backsolve = ((i64) B.r + B.ndeps) * (i64) B.Sm * B.elem_bytes + 8 * F->nnz;
 			}
 			HIP_CHECK(hipEventElapsedTime(&stats->ms_apply, W->ev[5], W->ev[1]));
 			// one row of R per pivotal entry of the reduced rows, the entries in and out, 20 B per row
-			stats->bytes_apply = (i64) ctr64[C64_ELIM] * (i64) B.Sm * 4 + 8 * ((i64) ctr64[C64_INPUT] + total) + 20 * (i64) nrows;
-			snprintf(stats->kernel, sizeof(stats->kernel), "%s", (stats->ms_backsolve > stats->ms_apply) ? "backsolve_kernel" : "bs_apply_kernel");
+			stats->bytes_apply = (i64) ctr64[C64_ELIM] * (i64) B.Sm * B.elem_bytes + 8 * ((i64) ctr64[C64_INPUT] + total) + 20 * (i64) nrows;
+			char apply_name[32];
+			snprintf(apply_name, sizeof(apply_name), "bs_apply_kernel<%s>", B.elem_bytes == 2 ? "true" : "false");
+			const bool build_dominates = stats->ms_backsolve > stats->ms_apply;
+			snprintf(stats->kernel, sizeof(stats->kernel), "%s", build_dominates ? B.kernel_build : apply_name);
+			snprintf(stats->kernel_other, sizeof(stats->kernel_other), "%s", build_dominates ? apply_name : B.kernel_build);
 		} else if (group_mode && !stats->group_aborted) {
 			schur_group_variant_name(F->rpad, wide_dense, group_waves, stats->kernel, sizeof(stats->kernel));
 		} else {
@@ -945,6 +974,19 @@ struct spasm_csr *spasm_hip_schur(const struct spasm_csr *A, const int *p, int n
 	i64 *dAp = dalloc<i64>((i64) A->n + 1);
 	int *dAj = dalloc<int>(annz);
 	int *dAx = dalloc<int>(annz);
+	// one process per GPU with a communicator installed (dist_api.hip): this rank reduces rows [lo, hi) of the list, the
+	// slices are reassembled on the devices.  Small batches (density samples) and calls that record L are not sharded:
+	// every rank computes them whole, which keeps the ranks in step without a collective.
+	spasm_hip_comm *comm = current_comm();
+	int lo = 0, hi = n;
+	const bool shard = comm != nullptr && L == nullptr && (comm_world(comm) > 1 || env_int("SPASM_HIP_SHARD_FORCE", 0) != 0) &&
+	                   n >= env_int("SPASM_HIP_SHARD_MIN_ROWS", 2048) * comm_world(comm);
+	if (shard)
+		spasm_hip_shard(n, comm_rank(comm), comm_world(comm), &lo, &hi);
+	const int n_all = n;
+	const int *p_all = p;
+	p += lo;
+	n = hi - lo;
 	int *drows = dalloc<int>(n);
 	upload(dAp, A->p, (i64) A->n + 1, stream);
 	upload(dAj, A->j, annz, stream);
@@ -1041,15 +1083,39 @@ struct spasm_csr *spasm_hip_schur(const struct spasm_csr *A, const int *p, int n
 	}
 	const double t_run = wtime() - t1;
 	const double t2 = wtime();
-	struct spasm_csr *S = spasm_hip_csr_alloc(n, m, st.nnz, prime, true);
-	HIP_CHECK(hipMemcpy(S->p, W->d_Sp, ((size_t) n + 1) * sizeof(i64), hipMemcpyDeviceToHost));
-	if (st.nnz > 0) {
-		HIP_CHECK(hipMemcpy(S->j, W->d_Sj, (size_t) st.nnz * sizeof(int), hipMemcpyDeviceToHost));
-		HIP_CHECK(hipMemcpy(S->x, W->d_Sx, (size_t) st.nnz * sizeof(int), hipMemcpyDeviceToHost));
+	struct spasm_csr *S = nullptr;
+	if (shard) {
+		// all-gatherv of the slices (sizes first, then exact-count broadcasts), then one download of the whole
+		i64 total = 0;
+		int rows_all = 0;
+		(void) spasm_hip_dschur_allgatherv(comm, W, nullptr, nullptr, nullptr, -1, &rows_all, &total, stream);
+		if (rows_all != n_all)
+			die("spasm_hip_schur: the ranks reduced %d rows in all, %d expected", rows_all, n_all);
+		i64 *gSp = dalloc<i64>((i64) n_all + 1);
+		int *gSj = dalloc<int>(total);
+		int *gSx = dalloc<int>(total);
+		if (spasm_hip_dschur_allgatherv(comm, W, gSp, gSj, gSx, total, nullptr, nullptr, stream) != 0)
+			die("spasm_hip_schur: all-gatherv of the slices failed");
+		S = spasm_hip_csr_alloc(n_all, m, total, prime, true);
+		HIP_CHECK(hipMemcpy(S->p, gSp, ((size_t) n_all + 1) * sizeof(i64), hipMemcpyDeviceToHost));
+		if (total > 0) {
+			HIP_CHECK(hipMemcpy(S->j, gSj, (size_t) total * sizeof(int), hipMemcpyDeviceToHost));
+			HIP_CHECK(hipMemcpy(S->x, gSx, (size_t) total * sizeof(int), hipMemcpyDeviceToHost));
+		}
+		(void) hipFree(gSp);
+		(void) hipFree(gSj);
+		(void) hipFree(gSx);
+	} else {
+		S = spasm_hip_csr_alloc(n, m, st.nnz, prime, true);
+		HIP_CHECK(hipMemcpy(S->p, W->d_Sp, ((size_t) n + 1) * sizeof(i64), hipMemcpyDeviceToHost));
+		if (st.nnz > 0) {
+			HIP_CHECK(hipMemcpy(S->j, W->d_Sj, (size_t) st.nnz * sizeof(int), hipMemcpyDeviceToHost));
+			HIP_CHECK(hipMemcpy(S->x, W->d_Sx, (size_t) st.nnz * sizeof(int), hipMemcpyDeviceToHost));
+		}
 	}
 	if (p_out != nullptr)
-		for (int k = 0; k < n; k++)
-			p_out[k] = (p_in != nullptr) ? p_in[p[k]] : p[k];
+		for (int k = 0; k < n_all; k++)
+			p_out[k] = (p_in != nullptr) ? p_in[p_all[k]] : p_all[k];
 	const double t_down = wtime() - t2;
 	const double t3 = wtime();
 	scratch_park(W);
@@ -1058,9 +1124,9 @@ struct spasm_csr *spasm_hip_schur(const struct spasm_csr *A, const int *p, int n
 	(void) hipFree(dAj);
 	(void) hipFree(dAx);
 	(void) hipFree(drows);
-	const double density = (n > 0 && m > 0) ? (double) st.nnz / ((double) m * n) : 0.0;
+	const double density = (S->n > 0 && m > 0) ? (double) S->p[S->n] / ((double) m * S->n) : 0.0;
 	logmsg("Schur complement: %d * %d [%" PRId64 " nz / density= %.3f], %.1fs (GPU kernels %.1f ms; tiers %d/%d/%d; "
-	       "factor image %.2fs, alloc+run %.2fs, download %.2fs, free %.2fs)\n", n, m, st.nnz, density, wtime() - t0,
+	       "factor image %.2fs, alloc+run %.2fs, download %.2fs, free %.2fs)\n", S->n, m, S->p[S->n], density, wtime() - t0,
 	       st.ms_total, st.rows_lds, st.rows_lds_big, st.rows_dense, t_fact, t_run, t_down, wtime() - t3);
 	return S;
 }

@@ -6,7 +6,77 @@ row list against its own replica of (A, factor) and the slices are reassembled
 with an all-gatherv: sizes first, then the padded payload through
 all_gather_into_tensor (RCCL over xGMI on GPUs; gloo in the CPU tests).
 """
+import ctypes as C
+
 import numpy as np
+
+
+class Comm:
+    """RCCL communicator of the library itself (spasm_hip_comm, spasm_amd/csrc/dist_api.hip): one process per GPU.
+
+    The id is drawn by rank 0 and handed to the others through `exchange(bytes or None) -> bytes` (bench.py broadcasts
+    it with torch.distributed; any channel will do).  world == 1 needs no exchange."""
+
+    def __init__(self, rank, world, exchange=None):
+        from ._lib import lib, require_gpu
+        require_gpu("Comm")
+        L = lib()
+        nbytes = L.spasm_hip_comm_id_bytes()
+        buf = (C.c_ubyte * nbytes)()
+        if rank == 0:
+            L.spasm_hip_comm_new_id(buf)
+        if world > 1:
+            raw = exchange(bytes(buf) if rank == 0 else None)
+            buf = (C.c_ubyte * nbytes).from_buffer_copy(raw)
+        self.rank, self.world = rank, world
+        self._h = L.spasm_hip_comm_create(buf, rank, world)
+
+    def install(self):
+        """the host-pointer entry points (schur, echelonize, ...) shard over this communicator from now on"""
+        from ._lib import lib
+        lib().spasm_hip_set_comm(self._h)
+
+    def uninstall(self):
+        from ._lib import lib
+        lib().spasm_hip_set_comm(None)
+
+    def allgatherv(self, W, m, prime, stream=0):
+        """all-gatherv (on the devices) of what the last dschur left in every rank's workspace W -> DeviceCsr"""
+        import torch
+        from ._lib import lib
+        from .device import DeviceCsr
+        L = lib()
+        rows, nnz = C.c_int(0), C.c_int64(0)
+        L.spasm_hip_dschur_allgatherv(self._h, W._h, None, None, None, -1, C.byref(rows), C.byref(nnz), stream)
+        dev = torch.device("cuda", torch.cuda.current_device())
+        Sp = torch.empty(rows.value + 1, dtype=torch.int64, device=dev)
+        Sj = torch.empty(max(nnz.value, 1), dtype=torch.int32, device=dev)
+        Sx = torch.empty(max(nnz.value, 1), dtype=torch.int32, device=dev)
+        rc = L.spasm_hip_dschur_allgatherv(self._h, W._h, Sp.data_ptr(), Sj.data_ptr(), Sx.data_ptr(), nnz.value, None, None, stream)
+        if rc != 0:
+            raise RuntimeError("spasm_hip_dschur_allgatherv failed")
+        return DeviceCsr(rows.value, m, Sp, Sj, Sx, prime)
+
+    def close(self):
+        if self._h:
+            from ._lib import lib
+            lib().spasm_hip_comm_destroy(self._h)
+            self._h = None
+
+
+def echelonize_dist(A, comm, opts=None):
+    """spasm_hip_echelonize_dist: echelonize with every round's Schur complement sharded over the ranks of comm."""
+    import ctypes as C
+    from ._lib import lib
+    from .matrix import view_csr, copy_csr, Fact
+    L = lib()
+    a = view_csr(A)
+    lu = L.spasm_hip_echelonize_dist(C.byref(a), C.byref(opts) if opts is not None else None, comm._h)
+    s = lu.contents
+    U = copy_csr(s.U)
+    qinv = np.ctypeslib.as_array(s.qinv, shape=(max(A.m, 1),))[:A.m].copy()
+    L.spasm_hip_lu_free(lu)
+    return Fact(U, qinv)
 
 
 def shard_bounds(n, rank, world):

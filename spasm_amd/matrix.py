@@ -82,7 +82,8 @@ class CSchurStats(C.Structure):    # spasm_hip_schur_stats
                 ("ms_eliminate", C.c_float), ("ms_group", C.c_float), ("ms_tier0", C.c_float), ("ms_tier1", C.c_float),
                 ("ms_tier2", C.c_float), ("ms_finalize", C.c_float), ("ms_total", C.c_float),
                 ("used_backsolve", C.c_int), ("backsolve_built", C.c_int), ("ms_backsolve", C.c_float), ("ms_apply", C.c_float),
-                ("bytes_backsolve", C.c_int64), ("bytes_apply", C.c_int64), ("kernel", C.c_char * 64)]
+                ("bytes_backsolve", C.c_int64), ("bytes_apply", C.c_int64), ("kernel", C.c_char * 64),
+                ("kernel_other", C.c_char * 64)]
 
 
 def field_of(prime):

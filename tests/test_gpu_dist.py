@@ -1,0 +1,81 @@
+"""The multi-GPU layer of the C ABI (spasm_amd/csrc/dist_api.hip) on ONE GPU: a world of one rank runs the same code --
+communicator, size exchange, exact-count broadcasts, row-pointer rebasing, the sharded spasm_hip_schur and the driver on
+top of it -- with the HIP kernels doing the compute (the gloo tests in test_dist_cpu.py cover world sizes 2 and 3 with a
+stand-in for the compute)."""
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+from conftest import ROOT, matrix_path
+
+import spasm_amd
+from spasm_amd.dist import Comm, echelonize_dist
+
+pytestmark = pytest.mark.gpu
+
+
+def _as_product(A):
+    return spasm_amd.Csr(A.n, A.m, A.p, A.j, A.x, A.prime)
+
+
+@pytest.fixture(scope="module")
+def comm():
+    c = Comm(0, 1)
+    yield c
+    c.close()
+
+
+@pytest.mark.parametrize("name", ["mat364.sms", "medium.sms", "trefethen_500.sms", "void.sms"])
+def test_allgatherv_of_a_world_of_one_is_the_identity(oracle, comm, name):
+    import torch
+    p = 42013
+    A = oracle.load_sms(matrix_path(name), p)
+    npiv, perm, F = oracle.pivots_extract_structural(A, oracle.empty_fact(A.n, A.m, p))
+    rows = perm[npiv:]
+    want, _, _ = oracle.schur(A, rows, F)
+    dA = spasm_amd.DeviceCsr.from_host(_as_product(A))
+    dF = spasm_amd.DeviceFact(spasm_amd.Fact(_as_product(F.U), F.qinv))
+    W = spasm_amd.SchurWorkspace(max(len(rows), 1), A.m, 4 * want.nnz + (1 << 20))
+    drows = torch.from_numpy(np.ascontiguousarray(rows, np.int32)).cuda()
+    S, st = spasm_amd.dschur(dA, drows, dF, W, fetch=False)
+    assert st.status == 0
+    full = comm.allgatherv(W, A.m, p)
+    H = full.to_host()
+    assert oracle.same_matrix(oracle.CSR(H.n, H.m, H.p, H.j, H.x, p), want)
+
+
+@pytest.mark.parametrize("name", ["mat364.sms", "medium.sms", "m1.sms", "singular.sms", "rectangular_l.sms"])
+@pytest.mark.parametrize("p", [42013, 4294967291])
+def test_echelonize_dist_shards_every_round(oracle, comm, name, p, monkeypatch):
+    """spasm_hip_echelonize_dist: every Schur complement goes through the sharded path (slice of the row list, all-gatherv
+    on the device, download) even in a world of one; same rank as the oracle, valid echelon form."""
+    monkeypatch.setenv("SPASM_HIP_SHARD_FORCE", "1")
+    monkeypatch.setenv("SPASM_HIP_SHARD_MIN_ROWS", "1")
+    A = oracle.load_sms(matrix_path(name), p)
+    want = oracle.echelonize(A).U.n
+    o = spasm_amd.default_opts()
+    o.enable_dense = False              # keep the sparse rounds going: more sharded Schur complements
+    o.enable_tall_and_skinny = False
+    F = echelonize_dist(_as_product(A), comm, o)
+    assert F.U.n == want
+    seen = set()
+    for i in range(F.U.n):
+        jj, xx = F.U.row(i)
+        assert xx[0] == 1 and int(jj[0]) not in seen and F.qinv[jj[0]] == i
+        seen.add(int(jj[0]))
+
+
+def test_bench_runs_its_rccl_path_on_one_gpu():
+    """bench.py with the all-gatherv of the C ABI forced on (world of one), on a small sibling of the bench matrix."""
+    env = dict(os.environ, SPASM_BENCH_FORCE_DIST="1", SPASM_HIP_VERBOSE="0", MASTER_ADDR="127.0.0.1", MASTER_PORT="29871",
+               RANK="0", WORLD_SIZE="1", LOCAL_RANK="0")
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--workload", "mk11.b4", "--steps", "2", "--warmup", "1",
+                          "--no-extras", "--no-cpu-baseline"], capture_output=True, text=True, env=env, timeout=600)
+    assert out.returncode == 0, out.stderr[-3000:]
+    import json
+    line = [x for x in out.stdout.splitlines() if x.startswith("{")][-1]
+    d = json.loads(line)
+    assert d["value"] > 0 and "all-gatherv" in d["config"]["sharding"]

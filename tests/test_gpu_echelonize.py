@@ -48,9 +48,15 @@ def test_echelonize_rank_matches_oracle(oracle, name, p):
         assert not any(x[j] != 0 and F.qinv[j] < 0 for j in pat)
 
 
+@pytest.mark.parametrize("finish", ["device", "host-loop"])
 @pytest.mark.parametrize("name", ["mat364.sms", "medium.sms", "m1.sms", "singular.sms", "rectangular_l.sms", "G2.sms"])
 @pytest.mark.parametrize("mode", ["dense", "lowrank", "rounds", "norounds-dense"])
-def test_echelonize_every_finishing_mode(oracle, name, mode):
+def test_echelonize_every_finishing_mode(oracle, name, mode, finish, monkeypatch):
+    """finish = device: the dense / low-rank finish stays in HBM (blocks reduced through the back-substituted image,
+    stacked under the echelon rows found so far, one RREF per block: dense_api.hip finish_on_device); host-loop: the
+    reference's loop through spasm_hip_schur_dense* / spasm_hip_ffpack_rref, one host round trip per block."""
+    if finish == "host-loop":
+        monkeypatch.setenv("SPASM_HIP_DEVICE_FINISH", "0")
     p = 42013
     A = oracle.load_sms(matrix_path(name), p)
     want = oracle.echelonize(A).U.n
@@ -145,3 +151,28 @@ def test_echelonize_with_L_dense_finish(oracle, name, complete):
         assert not np.any(diff)
     else:
         assert not np.any(diff[F.Lp])
+
+
+@pytest.mark.parametrize("p", [257, 42013, 4294967291])
+@pytest.mark.parametrize("shape", [(900, 300, 4, 64), (2500, 700, 3, 100), (1200, 1200, 5, 1000)])
+def test_device_finish_on_random_matrices(oracle, shape, p):
+    """random sparse matrices whose Schur complement is dense: dense and low-rank device finishes (several blocks,
+    weights doubling, the completion test) give the oracle's rank and a valid echelon form."""
+    n, m, per_row, block = shape
+    rng = np.random.default_rng(n * 7 + m)
+    ti = np.repeat(np.arange(n, dtype=np.int32), per_row)
+    tj = rng.integers(0, m, size=n * per_row).astype(np.int32)
+    tx = rng.integers(1, min(p, 1 << 31), size=n * per_row).astype(np.int64)
+    A = oracle.compress(p, n, m, ti, tj, tx)
+    want = oracle.echelonize(A).U.n
+    for lowrank in (False, True):
+        o = spasm_amd.default_opts()
+        o.sparsity_threshold = -1.0
+        o.dense_block_size = block
+        if lowrank:
+            o.tall_and_skinny_ratio = 0.0
+        else:
+            o.enable_tall_and_skinny = False
+        F = spasm_amd.echelonize(_as_product(A), o)
+        assert F.U.n == want
+        _check_echelon(oracle, A, F)

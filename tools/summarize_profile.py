@@ -57,9 +57,12 @@ def main():
                     acc[short(r["Kernel_Name"])].append(float(r["Counter_Value"]))
         print("\n== %s per launch (counter units: KiB) ==" % ctr)
         for k, v in sorted(acc.items(), key=lambda kv: -sum(kv[1])):
-            print("%-62s launches %5d  avg %16.1f  max %16.1f" % (k, len(v), sum(v) / len(v), max(v)))
-            per.setdefault(k, {})[ctr] = sum(v) / len(v) * 1024.0
-            per[k]["launches_" + ctr] = len(v)
+            # bench.py sizes its row pool by probing: launches that ran out of pool stop early and move fewer bytes.
+            # The per-launch figure is the mean over the full-size launches (within 10 % of the largest).
+            full = [x for x in v if x >= 0.9 * max(v)]
+            print("%-62s launches %5d  avg %16.1f  max %16.1f  full-size %5d  avg %16.1f" % (k, len(v), sum(v) / len(v), max(v), len(full), sum(full) / len(full)))
+            per.setdefault(k, {})[ctr] = sum(full) / len(full) * 1024.0
+            per[k]["launches_" + ctr] = len(full)
     bench = {}
     try:
         for line in open(os.path.join(out, "bench_trace.json")):
@@ -79,7 +82,7 @@ def main():
                                      "bytes_per_launch": v["FETCH_SIZE"] + v["WRITE_SIZE"],
                                      "bytes_per_launch_fetch_doubled": 2 * v["FETCH_SIZE"] + v["WRITE_SIZE"],
                                      "launches": v["launches_FETCH_SIZE"],
-                                     "avg_us_in_trace": (sum(rows[k]) / len(rows[k])) if k in rows else None}
+                                     "avg_us_in_trace_full_size": (lambda t: sum(t) / len(t))([x for x in rows[k] if x >= 0.9 * max(rows[k])]) if k in rows else None}
     json.dump(traffic, open(os.path.join(out, "traffic.json"), "w"), indent=1)
 
 

@@ -136,7 +136,7 @@ def load_matrix(name, prime=PRIME, tall=True):
     BASELINE matrix that is neither on disk nor regenerable."""
     import spasm_amd
     c = config(name)
-    path = find_data(c["file"] if c else name + ".sms")
+    path = find_data(c["file"] if c else name + ".sms")          # (any mkN.bK can be generated: small siblings for tests)
     if path is not None:
         plain, tmp = _open_plain(path)
         try:
