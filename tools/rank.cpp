@@ -46,7 +46,11 @@ int main(int argc, char **argv)
 		case 'm': filename = optarg; break;
 		case 'p': prime = atoll(optarg); break;
 		case 't': allow_transpose = false; break;
-		case 'c': fprintf(stderr, "rank certificates need L: not available on the GPU path yet\n"); return 1;
+		case 'c':
+			fprintf(stderr, "rank certificates are built by the reference's own code (spasm_certificate.c) on top of the L and U computed "
+			                "here:\nlink the reference's tools/rank.c against libspasm_hip_facade.so (INTEGRATION.md, option B) and run "
+			                "that with --certificate\n");
+			return 1;
 		case NO_LOW_RANK: opts.enable_tall_and_skinny = 0; break;
 		case NO_DENSE: opts.enable_dense = 0; break;
 		case NO_GPLU: opts.enable_GPLU = 0; break;
