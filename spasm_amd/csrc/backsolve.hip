@@ -417,31 +417,24 @@ template <bool PACKED> __global__ __launch_bounds__(512) void bs_apply_kernel(Ap
 #pragma unroll
 					for (int u = 0; u < AP_TU; u++)
 						acc[u] = (t0 + u * 64 < nwords) ? xw[t0 + u * 64 + lane] : 0u;
-					int e = 0;
-					for (; e + 2 <= npl; e += 2) {
-						const uint2 p0 = plist[e], p1 = plist[e + 1];
-						const uint32_t *r0 = R + (int64_t) p0.x * ldw + t0 + lane;
-						const uint32_t *r1 = R + (int64_t) p1.x * ldw + t0 + lane;
-						uint32_t w0[AP_TU], w1[AP_TU];
+					// four rows of R at a time: up to 16 loads in flight per lane (a row of mk13.b5 has three pivotal entries:
+					// one round trip per tile group)
+					for (int e = 0; e < npl; e += 4) {
+						uint2 pe[4];
+						uint32_t w[4][AP_TU];
 #pragma unroll
-						for (int u = 0; u < AP_TU; u++) {
-							const bool in = t0 + u * 64 < nwords;
-							w0[u] = in ? r0[u * 64] : 0u;
-							w1[u] = in ? r1[u * 64] : 0u;
+						for (int q = 0; q < 4; q++) {
+							pe[q] = (e + q < npl) ? plist[e + q] : uint2{0u, 0u};          // (coefficient 0: row 0 of R, no effect)
+							const uint32_t *rq = R + (int64_t) pe[q].x * ldw + t0 + lane;
+#pragma unroll
+							for (int u = 0; u < AP_TU; u++)
+								w[q][u] = (e + q < npl && t0 + u * 64 < nwords) ? rq[u * 64] : 0u;
 						}
 #pragma unroll
-						for (int u = 0; u < AP_TU; u++) {
-							acc[u] = w_submul<PACKED>(acc[u], w0[u], p0.y, F);
-							acc[u] = w_submul<PACKED>(acc[u], w1[u], p1.y, F);
-						}
-					}
-					if (e < npl) {
-						const uint2 p0 = plist[e];
-						const uint32_t *r0 = R + (int64_t) p0.x * ldw + t0 + lane;
+						for (int q = 0; q < 4; q++)
 #pragma unroll
-						for (int u = 0; u < AP_TU; u++)
-							if (t0 + u * 64 < nwords)
-								acc[u] = w_submul<PACKED>(acc[u], r0[u * 64], p0.y, F);
+							for (int u = 0; u < AP_TU; u++)
+								acc[u] = w_submul<PACKED>(acc[u], w[q][u], pe[q].y, F);
 					}
 #pragma unroll
 					for (int u = 0; u < AP_TU; u++)

@@ -488,13 +488,18 @@ __global__ __launch_bounds__(SEL_ROWS) void rref_select_kernel(const uint32_t *A
 // *full = 1 when every column of the panel got a pivot -- the tournament over all free rows then returns at once.
 template <bool SMALL>
 __global__ __launch_bounds__(256) void rref_select_first(const uint32_t *A, int64_t ld, int c0, int width, const int *cand_in,
-                                                         const int *n_in_dev, int *cand_out, MontDev F, int *full)
+                                                         const int *n_in_dev, int *cand_out, MontDev F, int *full, const int *gj_done)
 {
 	__shared__ __attribute__((aligned(16))) uint32_t prow[NB];
 	__shared__ unsigned long long wave_nz[4];
 	const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
 	const int slot = tid >> 2, q = tid & 3;
 	const ElimArith<SMALL> E(F);
+	if (gj_done != nullptr && *gj_done != 0) {          // rref_block_gj in try mode already did the panel
+		if (tid == 0)
+			*full = 1;                                  // (the tournament kernels return at once on this)
+		return;
+	}
 	const int n_in = min(*n_in_dev, NB);
 	const int row = (slot < n_in) ? cand_in[slot] : -1;
 	uint32_t x[16];
@@ -572,6 +577,15 @@ struct BlockGjArgs {
 	int *is_pivot_row;
 	int *pivrow, *pivcol, *rank, *knew, *rho;
 	int *cand_pivot;       // NB: pivot index of candidate r (every candidate becomes a pivot row)
+	// try mode (mode == 1): Gauss-Jordan straight on the first free rows (try_rows[0 .. *try_count)), before any selection.
+	// When they give a pivot in every column of the panel -- the usual case while the block is not exhausted -- the
+	// panel step is done (*gj_done = 1) and the selection kernels and the regular call return at once; otherwise
+	// nothing is written.  try_state[0] = failures in a row: after two the try is skipped (a block of low rank, or
+	// rows that are already reduced, would pay for it on every panel), and taken up again every eighth panel.
+	int mode;
+	const int *try_rows, *try_count;
+	int *gj_done, *try_state;
+	int panel_index;
 	MontDev F;
 };
 
@@ -600,9 +614,19 @@ __global__ __launch_bounds__(128 * NPAR) void rref_block_gj(BlockGjArgs g)
 	const int tid = threadIdx.x;
 	const MontDev F = g.F;
 	const ElimArith<SMALL> E(F);
+	if (g.mode == 0 && *g.gj_done != 0)
+		return;                       // the try on the first free rows already did this panel
+	if (g.mode == 1) {
+		const bool skip = g.try_state[0] >= 2 && (g.panel_index & 7) != 0;
+		if (skip || *g.try_count < g.width || g.width < NB) {
+			if (tid == 0)
+				*g.gj_done = 0;
+			return;
+		}
+	}
 	if (tid < NB) {
-		const int *cand = (*g.full != 0) ? g.cand_first : g.cand;
-		const int c = cand[tid];
+		const int *cand = (g.mode == 1) ? g.try_rows : (*g.full != 0) ? g.cand_first : g.cand;
+		const int c = (g.mode == 1 && tid >= *g.try_count) ? -1 : cand[tid];
 		const unsigned long long have = __ballot(c >= 0);
 		if (c >= 0)
 			s_rows[__popcll(have & ((1ull << tid) - 1ull))] = c;
@@ -723,6 +747,15 @@ __global__ __launch_bounds__(128 * NPAR) void rref_block_gj(BlockGjArgs g)
 		__syncthreads();
 	}
 	// (the candidates are independent: npiv == k; a defect would show as a wrong rank in the tests)
+	if (g.mode == 1) {
+		const bool ok = npiv == g.width && npiv == k;
+		if (tid == 0) {
+			*g.gj_done = ok ? 1 : 0;
+			g.try_state[0] = ok ? 0 : g.try_state[0] + 1;
+		}
+		if (!ok)
+			return;                   // nothing written: the selection kernels and the regular call take over
+	}
 	if constexpr (SMALL) {
 		// pivot rows are normalised: the right half is Ginv
 #pragma unroll
@@ -770,6 +803,10 @@ __global__ __launch_bounds__(128 * NPAR) void rref_block_gj(BlockGjArgs g)
 		*g.knew = k;
 	}
 }
+
+// (Tried: the same elimination BLK = 4 columns per round -- every wave factors the 64 x 4 block by itself, two barriers
+//  per round instead of two per column.  115 us against 88 us per panel: the 64 x 128 x 64 elimination is ~5 M
+//  lane-instructions, i.e. bound by the instruction issue of ONE compute unit, not by its 128 barriers.)
 
 // M[i][r] = -sum_s A[i, c0 + gamma_s] Ginv[s][r]  (+ Ginv[s][r] on the row that became pivot s), stored where the
 // update kernels read it: P[(NB + r) * n + i].  Thread = (row, 4 consecutive r).
@@ -1332,6 +1369,7 @@ int device_rref(int64_t prime, int n, int m, uint32_t *dA, int64_t ld, int *d_pi
 		HIP_CHECK(hipMalloc((void **) &B8, (size_t) 5 * 2 * (size_t) m * 64));
 		HIP_CHECK(hipMalloc((void **) &knew4, 8 * 16 * sizeof(int)));
 		HIP_CHECK(hipMalloc((void **) &full_flag, 64));
+		HIP_CHECK(hipMemsetAsync(full_flag, 0, 64, stream));          // [0] full, [4] gj_done, [8] try_state
 		HIP_CHECK(hipMalloc((void **) &Ginv, NB * NB * sizeof(uint32_t)));
 	}
 	unsigned int *coop_barrier = nullptr;
@@ -1368,6 +1406,7 @@ int device_rref(int64_t prime, int n, int m, uint32_t *dA, int64_t ld, int *d_pi
 	};
 	if (tournament) {
 		const bool small16 = prime < 65536;
+		const bool try_first = std::getenv("SPASM_HIP_RREF_TRY") == nullptr || std::atoi(std::getenv("SPASM_HIP_RREF_TRY")) != 0;
 		constexpr int SPW = 4;                       // panels per super-panel
 		bool far_pending = false;
 		uint32_t *set_P[4] = {nullptr, nullptr, nullptr, nullptr};
@@ -1400,14 +1439,47 @@ int device_rref(int64_t prime, int n, int m, uint32_t *dA, int64_t ld, int *d_pi
 				uint32_t *P_s = P4 + (size_t) slot * (size_t) n * PW;
 				int *rho_s = rho4 + slot * NB, *knew_s = knew4 + slot * 16;
 				hipLaunchKernelGGL(rref_first_free, dim3(1), dim3(64), 0, stream, flags, n, free_count + 4, first64, free_count + 2);
-				// the first 64 free rows alone: when they give a pivot in every column of the panel (the usual case
-				// while the block is not exhausted) the tournament below returns at once
+				// Gauss-Jordan straight on the first 64 free rows (try mode): when they give a pivot in every column of the
+				// panel (the usual case while the block is not exhausted) everything up to the regular call returns at once
+				BlockGjArgs bg;
+				bg.A = dA;
+				bg.ld = ld;
+				bg.n = n;
+				bg.c0 = c0;
+				bg.width = width;
+				bg.cand = nullptr;
+				bg.cand_first = cand_first;
+				bg.full = full_flag;
+				bg.Ginv = Ginv;
+				bg.gamma = gamma;
+				bg.is_pivot_row = flags;
+				bg.pivrow = pivrow;
+				bg.pivcol = d_pivcol;
+				bg.rank = rank_d;
+				bg.knew = knew_s;
+				bg.rho = rho_s;
+				bg.cand_pivot = cand_pivot;
+				bg.F = F;
+				bg.invtab = invtab;
+				bg.mode = 1;
+				bg.try_rows = first64;
+				bg.try_count = free_count + 2;
+				bg.gj_done = full_flag + 4;
+				bg.try_state = full_flag + 8;
+				bg.panel_index = c0 / NB;
+				if (try_first) {
+					if (small_prime)
+						hipLaunchKernelGGL((rref_block_gj<true, 8>), dim3(1), dim3(1024), invtab_bytes, stream, bg);
+					else
+						hipLaunchKernelGGL((rref_block_gj<false, 8>), dim3(1), dim3(1024), 0, stream, bg);
+				}
+				// the first 64 free rows alone, by selection (when the try was skipped or failed)
 				if (small_prime)
 					hipLaunchKernelGGL(rref_select_first<true>, dim3(1), dim3(256), 0, stream, dA, ld, c0, width, first64, free_count + 2,
-					                   cand_first, F, full_flag);
+					                   cand_first, F, full_flag, full_flag + 4);
 				else
 					hipLaunchKernelGGL(rref_select_first<false>, dim3(1), dim3(256), 0, stream, dA, ld, c0, width, first64, free_count + 2,
-					                   cand_first, F, full_flag);
+					                   cand_first, F, full_flag, full_flag + 4);
 				// (everything from here to the Gauss-Jordan block returns at once when that was enough)
 				hipLaunchKernelGGL(rref_free_list, dim3(1), dim3(1024), 0, stream, flags, n, candA, free_count, full_flag);
 				int n_in = n;
@@ -1428,26 +1500,8 @@ int device_rref(int64_t prime, int n, int m, uint32_t *dA, int64_t ld, int *d_pi
 					if (wgs == 1)
 						break;
 				}
-				BlockGjArgs bg;
-				bg.A = dA;
-				bg.ld = ld;
-				bg.n = n;
-				bg.c0 = c0;
-				bg.width = width;
 				bg.cand = src;
-				bg.cand_first = cand_first;
-				bg.full = full_flag;
-				bg.Ginv = Ginv;
-				bg.gamma = gamma;
-				bg.is_pivot_row = flags;
-				bg.pivrow = pivrow;
-				bg.pivcol = d_pivcol;
-				bg.rank = rank_d;
-				bg.knew = knew_s;
-				bg.rho = rho_s;
-				bg.cand_pivot = cand_pivot;
-				bg.F = F;
-				bg.invtab = invtab;
+				bg.mode = 0;
 				if (small_prime)
 					hipLaunchKernelGGL((rref_block_gj<true, 8>), dim3(1), dim3(1024), invtab_bytes, stream, bg);
 				else
