@@ -213,6 +213,9 @@ void spasm_hip_dfact_destroy(spasm_hip_dfact *F);
 /* forgets derived state cached in the image (the back-substituted rows R): the next Schur call rebuilds it.
  * bench.py calls this before every step so that a step is the whole of spasm_schur. */
 void spasm_hip_dfact_forget(spasm_hip_dfact *F);
+/* expected density (entries / (rows * non-pivotal columns)) of the Schur complements computed with this factor; < 0:
+ * unknown.  Dense results (>= 0.25) go through the back-substituted image even when its rows are long. */
+void spasm_hip_dfact_hint_density(spasm_hip_dfact *F, double density);
 int spasm_hip_dfact_rank(const spasm_hip_dfact *F);
 int spasm_hip_dfact_levels(const spasm_hip_dfact *F);
 i64 spasm_hip_dfact_nnz(const spasm_hip_dfact *F);

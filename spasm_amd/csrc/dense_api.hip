@@ -287,6 +287,7 @@ bool finish_on_device(const struct spasm_csr *A, const int *p, int n, struct spa
 	hipStream_t stream = nullptr;
 	spasm_hip_dfact *F = cached_dfact(fact->U, fact->qinv, stream);
 	const int Sm0 = F->Sm, m = A->m;
+	F->bs.density_hint = 1.0;            // (this is the finish of a Schur complement that was found dense)
 	if (Sm0 <= 0 || !backsolve_wanted(F, env_int("SPASM_HIP_FORCE_TIER", 0) != 0 || env_int("SPASM_HIP_GROUP", -1) >= 0))
 		return false;
 	const i64 prime = A->field->p;

@@ -155,6 +155,7 @@ struct BsImage {
 	int *d_chunk_extra = nullptr;     // per chunk: some row has more than two dependencies outside the chunk
 	hipEvent_t ev0 = nullptr, ev1 = nullptr;     // around the last build (memset + init + backsolve kernel)
 	int builds = 0;
+	double density_hint = -1.0;       // expected density of the Schur complements of this factor (< 0: unknown)
 	char kernel_build[48] = "backsolve_kernel";      // variant launched by the last build, as rocprofv3 prints it
 };
 

@@ -177,9 +177,13 @@ spasm_hip_dfact *cached_dfact(const struct spasm_csr *U, const int *qinv, hipStr
 }  // namespace sh
 
 namespace sh {
-// Should this Schur complement go through the back-substituted image?  SPASM_HIP_BACKSOLVE=0 never, =1 whenever the
-// factor has a plan; default: whenever it has one, R fits comfortably in the free HBM and no other path was forced
-// (tests force tiers / the row-group kernel through their own knobs).
+// Should this Schur complement go through the back-substituted image?  Its cost per reduced row is a few rows of R
+// (Sm entries each) whatever the result looks like; the row-by-row kernels pay for the actual fill-in.  Measured
+// (DESIGN.md section 5): mk13.b5, Sm = 4,952, S 72 % dense: 8.5 ms against 52.6 ms; mk13.b4, Sm = 23,958, S 4.4 % dense:
+// 53 ms against 26 ms.  So: SPASM_HIP_BACKSOLVE=0 never, =1 whenever the factor has a plan; otherwise, when no other path
+// was forced (tests force tiers / the row-group kernel through their own knobs) and R fits comfortably in the free HBM:
+// yes when R is already there, when its rows are short (Sm <= 8192: at worst a small loss), or when the caller expects
+// a dense result (density hint >= 0.25: spasm_hip_schur's est_density, spasm_hip_dfact_hint_density, the dense finish).
 bool backsolve_wanted(const spasm_hip_dfact *F, bool other_path_forced)
 {
 	const char *e = std::getenv("SPASM_HIP_BACKSOLVE");
@@ -194,7 +198,9 @@ bool backsolve_wanted(const spasm_hip_dfact *F, bool other_path_forced)
 	}
 	if (mode == 1)
 		return true;
-	return !other_path_forced;
+	if (other_path_forced)
+		return false;
+	return F->bs.valid || F->bs.Sm <= 8192 || F->bs.density_hint >= 0.25;
 }
 }  // namespace sh
 
@@ -521,6 +527,12 @@ void spasm_hip_dfact_destroy(spasm_hip_dfact *F)
 	(void) hipFree(F->d_lvl_end_w);
 	(void) hipFree(F->d_kof);
 	delete F;
+}
+
+void spasm_hip_dfact_hint_density(spasm_hip_dfact *F, double density)
+{
+	if (F != nullptr)
+		F->bs.density_hint = density;
 }
 
 void spasm_hip_dfact_forget(spasm_hip_dfact *F)
@@ -968,6 +980,8 @@ struct spasm_csr *spasm_hip_schur(const struct spasm_csr *A, const int *p, int n
 	const double t0 = wtime();
 	hipStream_t stream = nullptr;
 	spasm_hip_dfact *F = cached_dfact(fact->U, fact->qinv, stream);
+	if (est_density >= 0)
+		F->bs.density_hint = est_density;      // (a dense result is cheaper through the back-substituted image)
 	const double t_fact = wtime() - t0;
 	// device image of A and of the row list
 	const i64 annz = A->p[A->n];

@@ -63,6 +63,10 @@ class DeviceFact:
         self.m = F.U.m
         self.prime = F.U.prime
 
+    def hint_density(self, density):
+        """expected density of the Schur complements of this factor (dense ones go through the back-substituted image)"""
+        lib().spasm_hip_dfact_hint_density(self._h, float(density))
+
     def forget(self):
         """drops derived state (the back-substituted rows): the next dschur pays for it again."""
         lib().spasm_hip_dfact_forget(self._h)
