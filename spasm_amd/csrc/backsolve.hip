@@ -73,6 +73,7 @@ struct BsArgs {
 	const uint64_t *np_rp;
 	const uint2 *np;
 	const int *np_row;            // compact row of every entry of np
+	int plain;                    // coefficients (y) are plain residues (p < 2^16), not Montgomery form
 	int sparse_init;              // 1: the kernel scatters U_n itself (few entries); 0: R was pre-filled by bs_init_kernel
 	int r;
 	int dbg;                      // timing experiments only (SPASM_HIP_BS_DEBUG): bit 0/1/2 = skip phase A/B/C (wrong results)
@@ -88,21 +89,32 @@ template <bool PACKED> struct Word {
 	using Elem = typename std::conditional<PACKED, uint16_t, uint32_t>::type;
 };
 
-// x - v * y, component-wise (y = coefficient * 2^32 mod p)
-template <bool PACKED> __device__ __forceinline__ uint32_t w_submul(uint32_t x, uint32_t v, uint32_t y, const MontDev &F)
+// x - v * y, component-wise.  Coefficients y are in Montgomery form (value * 2^32 mod p) for p >= 2^16; for p < 2^16
+// (PLAIN) they are the plain residues: v * y < 2^32 is one full-rate 24-bit multiply and a Barrett reduction (one
+// quarter-rate multiply instead of the four of a Montgomery product), bm = floor(2^32 / p).
+template <bool PACKED, bool PLAIN> __device__ __forceinline__ uint32_t w_submul(uint32_t x, uint32_t v, uint32_t y, const MontDev &F, uint32_t bm)
 {
-	if constexpr (!PACKED) {
-		return submod(x, montmul(v, y, F), F);
+	auto small = [&](uint32_t xe, uint32_t ve) -> uint32_t {
+		const uint32_t t = __umul24(ve, y);                  // ve, y < p < 2^16
+		const uint32_t q = __umulhi(t, bm);                   // floor(t / p) - 2 <= q <= floor(t / p); q < p
+		uint32_t rem = t - __umul24(q, F.p);
+		rem = (rem >= F.p) ? rem - F.p : rem;
+		rem = (rem >= F.p) ? rem - F.p : rem;
+		return (xe >= rem) ? xe - rem : xe + F.p - rem;
+	};
+	if constexpr (PACKED) {
+		static_assert(PLAIN, "packed entries only exist for p < 2^16");
+		return small(x & 0xFFFFu, v & 0xFFFFu) | (small(x >> 16, v >> 16) << 16);
+	} else if constexpr (PLAIN) {
+		return small(x, v);
 	} else {
-		const uint32_t lo = submod(x & 0xFFFFu, montmul(v & 0xFFFFu, y, F), F);
-		const uint32_t hi = submod(x >> 16, montmul(v >> 16, y, F), F);
-		return lo | (hi << 16);
+		return submod(x, montmul(v, y, F), F);
 	}
 }
 
 // R <- U_n (values out of Montgomery form); R was zeroed before.  Only for factors whose rows hold many non-pivotal
 // entries: otherwise the backsolve kernel scatters them itself and R is never pre-filled.
-template <typename T> __global__ __launch_bounds__(256) void bs_init_kernel(BsArgs b)
+template <typename T> __global__ __launch_bounds__(256) void bs_init_kernel(BsArgs b)          // (b.plain: entries hold plain residues)
 {
 	const int c = blockIdx.x * blockDim.x + threadIdx.x;
 	if (c >= b.r)
@@ -110,7 +122,7 @@ template <typename T> __global__ __launch_bounds__(256) void bs_init_kernel(BsAr
 	T *row = static_cast<T *>(b.R) + (int64_t) c * b.ldR;
 	for (uint64_t e = b.np_rp[c]; e < b.np_rp[c + 1]; e++) {
 		const uint2 en = b.np[e];
-		row[en.x] = (T) montmul(en.y, 1u, b.F);
+		row[en.x] = (T) (b.plain ? en.y : montmul(en.y, 1u, b.F));
 	}
 }
 
@@ -133,9 +145,10 @@ template <bool PACKED, int LPR, int NW> struct BsGeom {
 	                                    (size_t) BS_STEPCAP * sizeof(int2) + (size_t) BS_RING * LPR * 4;
 };
 
-template <bool PACKED, int LPR, int NW>
+template <bool PACKED, bool PLAIN, int LPR, int NW>
 __global__ __launch_bounds__(64 * NW) void backsolve_kernel(BsArgs b)
 {
+	const uint32_t bm = PLAIN ? (uint32_t) (0x100000000ull / b.F.p) : 0u;
 	using G = BsGeom<PACKED, LPR, NW>;
 	using Elem = typename Word<PACKED>::Elem;
 	extern __shared__ __attribute__((aligned(16))) unsigned char bs_lds[];
@@ -209,7 +222,7 @@ __global__ __launch_bounds__(64 * NW) void backsolve_kernel(BsArgs b)
 				const uint2 en = b.np[e];
 				const int cc = (int) en.x - col_lo;
 				if (cc >= 0 && cc < G::CW)
-					reinterpret_cast<Elem *>(ring)[(b.np_row[e] - ch.lo) * G::CW + cc] = (Elem) montmul(en.y, 1u, F);
+					reinterpret_cast<Elem *>(ring)[(b.np_row[e] - ch.lo) * G::CW + cc] = (Elem) (PLAIN ? en.y : montmul(en.y, 1u, F));
 			}
 			__syncthreads();
 		}
@@ -236,9 +249,9 @@ __global__ __launch_bounds__(64 * NW) void backsolve_kernel(BsArgs b)
 					const uint4 h = fh[s];
 					uint32_t x = b.sparse_init ? ring[s * LPR + wl] : acc[u];
 					if (h.x != BS_NONE)
-						x = w_submul<PACKED>(x, v0[u], h.y, F);
+						x = w_submul<PACKED, PLAIN>(x, v0[u], h.y, F, bm);
 					if (h.z != BS_NONE)
-						x = w_submul<PACKED>(x, v1[u], h.w, F);
+						x = w_submul<PACKED, PLAIN>(x, v1[u], h.w, F, bm);
 					ring[s * LPR + wl] = x;
 				}
 			}
@@ -254,7 +267,7 @@ __global__ __launch_bounds__(64 * NW) void backsolve_kernel(BsArgs b)
 				uint32_t x = ring[s * LPR + wl];
 				for (uint64_t e = e0; e < e1; e++) {
 					const uint2 en = b.far[e];
-					x = w_submul<PACKED>(x, Rs[(int64_t) en.x * ldw], en.y, F);
+					x = w_submul<PACKED, PLAIN>(x, Rs[(int64_t) en.x * ldw], en.y, F, bm);
 				}
 				ring[s * LPR + wl] = x;
 			}
@@ -284,10 +297,10 @@ __global__ __launch_bounds__(64 * NW) void backsolve_kernel(BsArgs b)
 				const uint2 B2 = rd_brow(S2);
 				const int2 S3 = rd_step(st + 3);
 				if (cnt != 0) {
-					x = w_submul<PACKED>(x, v, D0.y, F);
+					x = w_submul<PACKED, PLAIN>(x, v, D0.y, F, bm);
 					for (int j = 1; j < cnt; j++) {
 						const uint2 en = near[B0.y + j];
-						x = w_submul<PACKED>(x, ring[en.x * LPR + wl], en.y, F);
+						x = w_submul<PACKED, PLAIN>(x, ring[en.x * LPR + wl], en.y, F, bm);
 					}
 					ring[slot * LPR + wl] = x;
 				}
@@ -298,7 +311,7 @@ __global__ __launch_bounds__(64 * NW) void backsolve_kernel(BsArgs b)
 					uint32_t y = ring[sq * LPR + wl];
 					for (int j = 0; j < cq; j++) {
 						const uint2 en = near[bq.y + j];
-						y = w_submul<PACKED>(y, ring[en.x * LPR + wl], en.y, F);
+						y = w_submul<PACKED, PLAIN>(y, ring[en.x * LPR + wl], en.y, F, bm);
 					}
 					ring[sq * LPR + wl] = y;
 				}
@@ -354,8 +367,9 @@ struct ApplyArgs {
 constexpr unsigned long long LB_FLAG_LEN = 1ull << 62, LB_FLAG_END = 2ull << 62, LB_VALUE = (1ull << 62) - 1;
 constexpr int LB_PER_LANE = 4;             // predecessors inspected per lane and poll (256 per wave)
 
-template <bool PACKED> __global__ __launch_bounds__(512) void bs_apply_kernel(ApplyArgs d)
+template <bool PACKED, bool PLAIN> __global__ __launch_bounds__(512) void bs_apply_kernel(ApplyArgs d)
 {
+	const uint32_t bm = PLAIN ? (uint32_t) (0x100000000ull / d.a.F.p) : 0u;
 	constexpr int CPL = Word<PACKED>::CPL;
 	using Elem = typename Word<PACKED>::Elem;
 	extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
@@ -406,7 +420,7 @@ template <bool PACKED> __global__ __launch_bounds__(512) void bs_apply_kernel(Ap
 			}
 			const uint64_t mk = __ballot(piv);
 			if (piv)
-				plist[npl + __popcll(mk & ((1ull << lane) - 1ull))] = uint2{cid, montmul(v, F.r2, F)};
+				plist[npl + __popcll(mk & ((1ull << lane) - 1ull))] = uint2{cid, PLAIN ? v : montmul(v, F.r2, F)};
 			npl += __popcll(mk);
 			st_piv += (unsigned long long) __popcll(mk);
 			const bool last = base + 64 >= hi;
@@ -434,7 +448,7 @@ template <bool PACKED> __global__ __launch_bounds__(512) void bs_apply_kernel(Ap
 						for (int q = 0; q < 4; q++)
 #pragma unroll
 							for (int u = 0; u < AP_TU; u++)
-								acc[u] = w_submul<PACKED>(acc[u], w[q][u], pe[q].y, F);
+								acc[u] = w_submul<PACKED, PLAIN>(acc[u], w[q][u], pe[q].y, F, bm);
 					}
 #pragma unroll
 					for (int u = 0; u < AP_TU; u++)
@@ -599,8 +613,9 @@ template <bool PACKED> __global__ __launch_bounds__(512) void bs_apply_kernel(Ap
 // entries of the row; partial sums meet in LDS.
 constexpr int AW_NW = 8;
 
-template <bool PACKED> __global__ __launch_bounds__(64 * AW_NW) void bs_apply_wide_kernel(ApplyArgs d)
+template <bool PACKED, bool PLAIN> __global__ __launch_bounds__(64 * AW_NW) void bs_apply_wide_kernel(ApplyArgs d)
 {
+	const uint32_t bm = PLAIN ? (uint32_t) (0x100000000ull / d.a.F.p) : 0u;
 	constexpr int CPL = Word<PACKED>::CPL;
 	__shared__ uint32_t part[AW_NW][AP_TU * 64];
 	const SchurArgs &a = d.a;
@@ -654,7 +669,7 @@ template <bool PACKED> __global__ __launch_bounds__(64 * AW_NW) void bs_apply_wi
 		}
 		// pivotal entries: their rows of R, tile group by tile group
 		const bool piv = v != 0 && cid < (uint32_t) d.r;
-		const uint32_t ay = piv ? montmul(v, F.r2, F) : 0u;
+		const uint32_t ay = piv ? (PLAIN ? v : montmul(v, F.r2, F)) : 0u;
 		todo = __ballot(piv);
 		while (todo != 0) {
 			const int s0 = __builtin_ctzll(todo);
@@ -681,9 +696,9 @@ template <bool PACKED> __global__ __launch_bounds__(64 * AW_NW) void bs_apply_wi
 			}
 #pragma unroll
 			for (int u = 0; u < AP_TU; u++) {
-				acc[u] = w_submul<PACKED>(acc[u], x0[u], y0, F);
+				acc[u] = w_submul<PACKED, PLAIN>(acc[u], x0[u], y0, F, bm);
 				if (s1 >= 0)
-					acc[u] = w_submul<PACKED>(acc[u], x1[u], y1, F);
+					acc[u] = w_submul<PACKED, PLAIN>(acc[u], x1[u], y1, F, bm);
 			}
 		}
 	}
@@ -729,28 +744,28 @@ template <bool PACKED> __global__ __launch_bounds__(64 * AW_NW) void bs_apply_wi
 	}
 }
 
-template <bool PACKED, int LPR, int NW> void launch_backsolve_variant(const BsArgs &b, int Sm, hipStream_t stream)
+template <bool PACKED, bool PLAIN, int LPR, int NW> void launch_backsolve_variant(const BsArgs &b, int Sm, hipStream_t stream)
 {
 	using G = BsGeom<PACKED, LPR, NW>;
 	static bool configured = false;
 	if (!configured) {
-		HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(&backsolve_kernel<PACKED, LPR, NW>),
+		HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(&backsolve_kernel<PACKED, PLAIN, LPR, NW>),
 		                              hipFuncAttributeMaxDynamicSharedMemorySize, (int) G::LDS_BYTES));
 		configured = true;
 	}
-	hipLaunchKernelGGL((backsolve_kernel<PACKED, LPR, NW>), dim3((unsigned) ((Sm + G::CW - 1) / G::CW)), dim3(64 * NW), G::LDS_BYTES,
+	hipLaunchKernelGGL((backsolve_kernel<PACKED, PLAIN, LPR, NW>), dim3((unsigned) ((Sm + G::CW - 1) / G::CW)), dim3(64 * NW), G::LDS_BYTES,
 	                   stream, b);
 }
 
-template <bool PACKED> void launch_apply_variant(const ApplyArgs &d, int blocks, size_t lds, hipStream_t stream)
+template <bool PACKED, bool PLAIN> void launch_apply_variant(const ApplyArgs &d, int blocks, size_t lds, hipStream_t stream)
 {
 	static size_t configured = 0;
 	if (lds > configured) {
-		HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(&bs_apply_kernel<PACKED>), hipFuncAttributeMaxDynamicSharedMemorySize,
-		                              (int) lds));
+		HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(&bs_apply_kernel<PACKED, PLAIN>),
+		                              hipFuncAttributeMaxDynamicSharedMemorySize, (int) lds));
 		configured = lds;
 	}
-	hipLaunchKernelGGL((bs_apply_kernel<PACKED>), dim3(blocks), dim3(64 * d.waves), lds, stream, d);
+	hipLaunchKernelGGL((bs_apply_kernel<PACKED, PLAIN>), dim3(blocks), dim3(64 * d.waves), lds, stream, d);
 }
 
 }  // namespace
@@ -805,6 +820,26 @@ void backsolve_plan(const FactPlan &P, spasm_hip_dfact *F, hipStream_t stream)
 	for (int j = 0; j < m; j++)
 		colmap[j] = (P.lab[j] < (uint32_t) rpad) ? cid[P.lab[j]] : r + (int) (P.lab[j] - (uint32_t) rpad);
 
+	// p < 2^16: coefficients are kept as plain residues (the kernels multiply with 24-bit products + Barrett)
+	B.plain = P.prime < 65536;
+	uint64_t unmont = 1;                 // 2^-32 mod p
+	if (B.plain) {
+		const uint64_t R1 = (uint64_t) ((1ull << 32) % (uint64_t) P.prime);
+		// inverse by Fermat (p is prime in every use; for a composite odd modulus the extended Euclid below still works)
+		int64_t t0 = 0, t1 = 1, r0 = P.prime, r1 = (int64_t) R1;
+		while (r1 != 0) {
+			const int64_t qq = r0 / r1;
+			const int64_t t2 = t0 - qq * t1, r2 = r0 - qq * r1;
+			t0 = t1;
+			t1 = t2;
+			r0 = r1;
+			r1 = r2;
+		}
+		if (r0 != 1)
+			die("backsolve_plan: 2^32 is not invertible mod %lld", (long long) P.prime);
+		unmont = (uint64_t) ((t0 % P.prime + P.prime) % P.prime);
+	}
+	auto coeff = [&](uint32_t y_mont) -> uint32_t { return B.plain ? (uint32_t) (((uint64_t) y_mont * unmont) % (uint64_t) P.prime) : y_mont; };
 	// split every row into pivotal dependencies (compact ids) and non-pivotal entries
 	std::vector<uint64_t> dep_rp((size_t) r + 1, 0), np_rp((size_t) r + 1, 0);
 	std::vector<uint2> dep, np;
@@ -816,9 +851,9 @@ void backsolve_plan(const FactPlan &P, spasm_hip_dfact *F, hipStream_t stream)
 		for (uint64_t e = P.rp[c]; e < P.rp[c + 1]; e++) {
 			const uint2 en = P.ent[e];
 			if (en.x < (uint32_t) rpad) {
-				dep.push_back(uint2{(uint32_t) cid[en.x], en.y});
+				dep.push_back(uint2{(uint32_t) cid[en.x], coeff(en.y)});
 			} else {
-				np.push_back(uint2{en.x - (uint32_t) rpad, en.y});
+				np.push_back(uint2{en.x - (uint32_t) rpad, coeff(en.y)});
 				np_row.push_back(n);
 			}
 		}
@@ -1035,6 +1070,7 @@ void backsolve_build(const spasm_hip_dfact *F, hipStream_t stream)
 	b.np = B.d_np;
 	b.np_row = B.d_np_row;
 	b.r = B.r;
+	b.plain = B.plain ? 1 : 0;
 	b.F = to_dev(F->mont);
 	b.dbg = env_bs("SPASM_HIP_BS_DEBUG", 0);
 	// few non-pivotal entries per row of U (mk13.b5: 0.08): the kernel scatters them into its LDS ring itself and R is
@@ -1063,22 +1099,27 @@ void backsolve_build(const spasm_hip_dfact *F, hipStream_t stream)
 	}
 	const int slabs_small = packed ? (B.Sm + 31) / 32 : (B.Sm + 15) / 16;
 	const int shape = env_bs("SPASM_HIP_BS_SHAPE", slabs_small <= (packed ? 2 * cus : cus) ? 2 : 0);
-	snprintf(B.kernel_build, sizeof(B.kernel_build), "backsolve_kernel<%s,%d,%d>", packed ? "true" : "false", shape == 2 ? 16 : 32,
-	         shape == 0 ? 16 : 8);
+	snprintf(B.kernel_build, sizeof(B.kernel_build), "backsolve_kernel<%s,%s,%d,%d>", packed ? "true" : "false", B.plain ? "true" : "false",
+	         shape == 2 ? 16 : 32, (shape == 0 || (!packed && B.plain && shape == 1)) ? 16 : 8);
 	if (packed) {
 		if (shape == 1)
-			launch_backsolve_variant<true, 32, 8>(b, B.Sm, stream);
+			launch_backsolve_variant<true, true, 32, 8>(b, B.Sm, stream);
 		else if (shape == 2)
-			launch_backsolve_variant<true, 16, 8>(b, B.Sm, stream);
+			launch_backsolve_variant<true, true, 16, 8>(b, B.Sm, stream);
 		else
-			launch_backsolve_variant<true, 32, 16>(b, B.Sm, stream);
+			launch_backsolve_variant<true, true, 32, 16>(b, B.Sm, stream);
+	} else if (B.plain) {          // (p < 2^16 with 32-bit entries of R: the SPASM_HIP_BS_PACKED=0 knob)
+		if (shape == 2)
+			launch_backsolve_variant<false, true, 16, 8>(b, B.Sm, stream);
+		else
+			launch_backsolve_variant<false, true, 32, 16>(b, B.Sm, stream);
 	} else {
 		if (shape == 1)
-			launch_backsolve_variant<false, 32, 8>(b, B.Sm, stream);
+			launch_backsolve_variant<false, false, 32, 8>(b, B.Sm, stream);
 		else if (shape == 2)
-			launch_backsolve_variant<false, 16, 8>(b, B.Sm, stream);
+			launch_backsolve_variant<false, false, 16, 8>(b, B.Sm, stream);
 		else
-			launch_backsolve_variant<false, 32, 16>(b, B.Sm, stream);
+			launch_backsolve_variant<false, false, 32, 16>(b, B.Sm, stream);
 	}
 	HIP_CHECK(hipGetLastError());
 	HIP_CHECK(hipEventRecord(B.ev1, stream));
@@ -1097,9 +1138,11 @@ void backsolve_build(const spasm_hip_dfact *F, hipStream_t stream)
 		else
 			hipLaunchKernelGGL(bs_init_kernel<uint32_t>, dim3((B.r + 255) / 256), dim3(256), 0, stream, c);
 		if (packed)
-			launch_backsolve_variant<true, 32, 16>(c, B.Sm, stream);
+			launch_backsolve_variant<true, true, 32, 16>(c, B.Sm, stream);
+		else if (B.plain)
+			launch_backsolve_variant<false, true, 32, 16>(c, B.Sm, stream);
 		else
-			launch_backsolve_variant<false, 32, 16>(c, B.Sm, stream);
+			launch_backsolve_variant<false, false, 32, 16>(c, B.Sm, stream);
 		std::vector<unsigned char> h1(bytes), h2(bytes);
 		HIP_CHECK(hipMemcpyAsync(h1.data(), B.d_R, bytes, hipMemcpyDeviceToHost, stream));
 		HIP_CHECK(hipMemcpyAsync(h2.data(), R2, bytes, hipMemcpyDeviceToHost, stream));
@@ -1158,9 +1201,11 @@ void launch_backsolve_apply(const SchurArgs &a, const spasm_hip_dfact *F, uint32
 		const int nwords = d.Smpad / (packed ? 2 : 1);
 		const dim3 grid((unsigned) ((nwords + 64 * AP_TU - 1) / (64 * AP_TU)), (unsigned) a.nrows);
 		if (packed)
-			hipLaunchKernelGGL(bs_apply_wide_kernel<true>, grid, dim3(64 * AW_NW), 0, stream, d);
+			hipLaunchKernelGGL((bs_apply_wide_kernel<true, true>), grid, dim3(64 * AW_NW), 0, stream, d);
+		else if (B.plain)
+			hipLaunchKernelGGL((bs_apply_wide_kernel<false, true>), grid, dim3(64 * AW_NW), 0, stream, d);
 		else
-			hipLaunchKernelGGL(bs_apply_wide_kernel<false>, grid, dim3(64 * AW_NW), 0, stream, d);
+			hipLaunchKernelGGL((bs_apply_wide_kernel<false, false>), grid, dim3(64 * AW_NW), 0, stream, d);
 		HIP_CHECK(hipGetLastError());
 		return;
 	}
@@ -1174,9 +1219,11 @@ void launch_backsolve_apply(const SchurArgs &a, const spasm_hip_dfact *F, uint32
 	const size_t lds = per_wave * (size_t) waves;
 	const int blocks = std::max(1, std::min((a.nrows + waves - 1) / waves, prop.multiProcessorCount * 8));
 	if (packed)
-		launch_apply_variant<true>(d, blocks, lds, stream);
+		launch_apply_variant<true, true>(d, blocks, lds, stream);
+	else if (B.plain)
+		launch_apply_variant<false, true>(d, blocks, lds, stream);
 	else
-		launch_apply_variant<false>(d, blocks, lds, stream);
+		launch_apply_variant<false, false>(d, blocks, lds, stream);
 	HIP_CHECK(hipGetLastError());
 }
 

@@ -141,6 +141,7 @@ struct BsImage {
 	int64_t nfar = 0, nnear = 0, nnp = 0, ndeps = 0;
 	void *d_R = nullptr;              // r x ldR entries of elem_bytes each (uint16_t when p < 2^16, else uint32_t)
 	int elem_bytes = 4;
+	bool plain = false;               // coefficients of the plan are plain residues (p < 2^16) instead of Montgomery form
 	int *d_col = nullptr;             // column -> compact row id of its pivot, or r + index among the non-pivotal columns
 	BsChunk *d_chunk = nullptr;
 	int2 *d_step = nullptr;           // [first, last) into d_brow

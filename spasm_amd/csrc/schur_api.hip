@@ -923,7 +923,7 @@ eliminated:
 			// one row of R per pivotal entry of the reduced rows, the entries in and out, 20 B per row
 			stats->bytes_apply = (i64) ctr64[C64_ELIM] * (i64) B.Sm * B.elem_bytes + 8 * ((i64) ctr64[C64_INPUT] + total) + 20 * (i64) nrows;
 			char apply_name[32];
-			snprintf(apply_name, sizeof(apply_name), "bs_apply_kernel<%s>", B.elem_bytes == 2 ? "true" : "false");
+			snprintf(apply_name, sizeof(apply_name), "bs_apply_kernel<%s,%s>", B.elem_bytes == 2 ? "true" : "false", B.plain ? "true" : "false");
 			const bool build_dominates = stats->ms_backsolve > stats->ms_apply;
 			snprintf(stats->kernel, sizeof(stats->kernel), "%s", build_dominates ? B.kernel_build : apply_name);
 			snprintf(stats->kernel_other, sizeof(stats->kernel_other), "%s", build_dominates ? apply_name : B.kernel_build);

@@ -153,6 +153,31 @@ def test_echelonize_with_L_dense_finish(oracle, name, complete):
         assert not np.any(diff[F.Lp])
 
 
+@pytest.mark.parametrize("finish", ["device", "host-loop"])
+@pytest.mark.parametrize("p", [4294967291, 2147483659])
+@pytest.mark.parametrize("seed", [3, 4])
+def test_low_rank_finish_with_primes_above_2_31(oracle, p, seed, finish, monkeypatch):
+    """random combinations of rows are packed into CSR on the device: their residues must be stored as balanced
+    representatives (a residue >= 2^31 kept as a plain int reads back shifted by p -- found by tools/stress_gpu.py:
+    ranks came out too high in the low-rank mode with p = 4294967291)."""
+    if finish == "host-loop":
+        monkeypatch.setenv("SPASM_HIP_DEVICE_FINISH", "0")
+    en, em, eper = 892, 1412, 2
+    rng = np.random.default_rng(seed)
+    ti = np.repeat(np.arange(en, dtype=np.int32), eper)
+    tj = rng.integers(0, em, size=en * eper).astype(np.int32)
+    tx = rng.integers(1, p, size=en * eper).astype(np.int64)
+    A = oracle.compress(p, en, em, ti, tj, tx)
+    want = oracle.echelonize(A).U.n
+    o = spasm_amd.default_opts()
+    o.sparsity_threshold = -1.0
+    o.tall_and_skinny_ratio = 0.0
+    o.dense_block_size = 37
+    F = spasm_amd.echelonize(_as_product(A), o)
+    assert F.U.n == want
+    _check_echelon(oracle, A, F)
+
+
 @pytest.mark.parametrize("p", [257, 42013, 4294967291])
 @pytest.mark.parametrize("shape", [(900, 300, 4, 64), (2500, 700, 3, 100), (1200, 1200, 5, 1000)])
 def test_device_finish_on_random_matrices(oracle, shape, p):

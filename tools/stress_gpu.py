@@ -47,6 +47,20 @@ while time.time() < t_end:
                 print("MISMATCH schur n=%d m=%d per_row=%d p=%d waves=%s" % (n, m, per_row, p, waves), flush=True)
         os.environ.pop("SPASM_HIP_GROUP", None)
         os.environ.pop("SPASM_HIP_GROUP_WAVES", None)
+        # the back-substituted image: every workgroup shape, 16- and 32-bit entries, both ways of starting the rows and of
+        # writing the result
+        bs_env = {"SPASM_HIP_BACKSOLVE": "1", "SPASM_HIP_BS_SHAPE": str(int(rng.integers(0, 3))),
+                  "SPASM_HIP_BS_PACKED": str(int(rng.integers(0, 2))), "SPASM_HIP_BS_SPARSE_INIT": str(int(rng.integers(0, 2))),
+                  "SPASM_HIP_BS_DIRECT": str(int(rng.integers(0, 2)))}
+        os.environ.update(bs_env)
+        S, p_out = spasm_amd.schur(as_product(A), rows, spasm_amd.Fact(as_product(F.U), F.qinv))
+        ok = orc.same_matrix(orc.CSR(S.n, S.m, S.p, S.j, S.x, p), want) and np.array_equal(np.asarray(p_out), np.asarray(p_out_want))
+        cases += 1
+        if not ok:
+            fails += 1
+            print("MISMATCH backsolve n=%d m=%d per_row=%d p=%d %s" % (n, m, per_row, p, bs_env), flush=True)
+        for key in bs_env:
+            os.environ.pop(key, None)
     # ---- dense RREF of a rank-deficient block
     dn, dm = int(rng.integers(1, 1500)), int(rng.integers(1, 700))
     k = int(rng.integers(0, min(dn, dm) + 1))
@@ -68,10 +82,19 @@ while time.time() < t_end:
         tx = rng.integers(1, p, size=en * eper).astype(np.int64)
         E = orc.compress(p, en, em, ti, tj, tx)
         want_rank = orc.echelonize(E).U.n
-        got = spasm_amd.echelonize(as_product(E)).U.n
-        cases += 1
-        if got != want_rank:
-            fails += 1
-            print("MISMATCH echelonize %dx%d per_row=%d p=%d: rank %d, oracle %d" % (en, em, eper, p, got, want_rank), flush=True)
+        for finish in ("1", "0"):            # device-resident dense finish / the host loop
+            os.environ["SPASM_HIP_DEVICE_FINISH"] = finish
+            o = spasm_amd.default_opts()
+            if rng.integers(0, 2):
+                o.sparsity_threshold = -1.0          # dense finish straight away
+                o.dense_block_size = int(rng.integers(16, 400))
+                if rng.integers(0, 2):
+                    o.tall_and_skinny_ratio = 0.0    # ... in low-rank mode
+            got = spasm_amd.echelonize(as_product(E), o).U.n
+            cases += 1
+            if got != want_rank:
+                fails += 1
+                print("MISMATCH echelonize %dx%d per_row=%d p=%d finish=%s: rank %d, oracle %d" % (en, em, eper, p, finish, got, want_rank), flush=True)
+        os.environ.pop("SPASM_HIP_DEVICE_FINISH", None)
 print("stress: %d cases, %d mismatches" % (cases, fails))
 sys.exit(1 if fails else 0)
