@@ -182,7 +182,8 @@ void spasm_hip_echelonize_init_opts(struct echelonize_opts *opts);
 struct spasm_lu *spasm_hip_echelonize(const struct spasm_csr *A, struct echelonize_opts *opts);
 /* seconds the last spasm_hip_echelonize call spent in: [0] the whole call, [1] the host pivot search, [2] density
  * estimates, [3] sparse Schur complements, [4] the dense / low-rank finish, [5] number of sparse Schur rounds,
- * [6] the structural-rounds finish that replaces GPLU, [7] unused.  out has 8 doubles. */
+ * [6] the structural-rounds finish that replaces GPLU, [7] host matrices uploaded to the device by this process so far
+ * (inside the driver a matrix goes up at most once and Schur complements stay where they were computed).  8 doubles. */
 void spasm_hip_echelonize_profile(double *out);
 struct spasm_csr *spasm_hip_rref(const struct spasm_lu *fact, int *Rqinv);
 struct spasm_csr *spasm_hip_kernel(const struct spasm_lu *fact);

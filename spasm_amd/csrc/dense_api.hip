@@ -295,17 +295,10 @@ bool finish_on_device(const struct spasm_csr *A, const int *p, int n, struct spa
 	const int Sn_test = (int) std::ceil(128.0 / std::log2((double) prime));
 	const double start = wtime();
 	const i64 annz = A->p[A->n];
-	i64 *dAp = dalloc<i64>((i64) A->n + 1);
-	int *dAj = dalloc<int>(annz);
-	int *dAx = dalloc<int>(annz);
+	DeviceMatrix devA(A, stream);
 	int *drows = dalloc<int>(n);
-	HIP_CHECK(hipMemcpy(dAp, A->p, ((size_t) A->n + 1) * sizeof(i64), hipMemcpyHostToDevice));
-	if (annz > 0) {
-		HIP_CHECK(hipMemcpy(dAj, A->j, (size_t) annz * sizeof(int), hipMemcpyHostToDevice));
-		HIP_CHECK(hipMemcpy(dAx, A->x, (size_t) annz * sizeof(int), hipMemcpyHostToDevice));
-	}
 	HIP_CHECK(hipMemcpy(drows, p, (size_t) n * sizeof(int), hipMemcpyHostToDevice));
-	spasm_hip_dcsr dA{A->n, m, annz, dAp, dAj, dAx};
+	spasm_hip_dcsr dA{A->n, m, annz, devA.p, devA.j, devA.x};
 	const int maxblock = std::max(block, Sn_test);
 	spasm_hip_dwork *W = spasm_hip_dwork_create(maxblock, m, 64);
 	const i64 ld = Sm0;
@@ -421,9 +414,6 @@ bool finish_on_device(const struct spasm_csr *A, const int *p, int n, struct spa
 	(void) hipFree(dM);
 	(void) hipFree(dpiv);
 	spasm_hip_dwork_destroy(W);
-	(void) hipFree(dAp);
-	(void) hipFree(dAj);
-	(void) hipFree(dAx);
 	(void) hipFree(drows);
 	logmsg("[echelonize/dense/device] completed in %.2fs (dense rows %.2fs, RREF %.2fs). %d new pivots found\n", wtime() - start,
 	       t_rows, t_rref, U->n - old_un);
@@ -460,17 +450,10 @@ void spasm_hip_schur_dense(const struct spasm_csr *A, const int *p, int n, const
 		p_out[k] = (p_in != nullptr) ? p_in[p[k]] : p[k];
 	if (n > 0 && Sm > 0) {
 		const i64 annz = A->p[A->n];
-		i64 *dAp = dalloc<i64>((i64) A->n + 1);
-		int *dAj = dalloc<int>(annz);
-		int *dAx = dalloc<int>(annz);
+		DeviceMatrix devA(A, stream);
 		int *drows = dalloc<int>(n);
-		HIP_CHECK(hipMemcpy(dAp, A->p, ((size_t) A->n + 1) * sizeof(i64), hipMemcpyHostToDevice));
-		if (annz > 0) {
-			HIP_CHECK(hipMemcpy(dAj, A->j, (size_t) annz * sizeof(int), hipMemcpyHostToDevice));
-			HIP_CHECK(hipMemcpy(dAx, A->x, (size_t) annz * sizeof(int), hipMemcpyHostToDevice));
-		}
 		HIP_CHECK(hipMemcpy(drows, p, (size_t) n * sizeof(int), hipMemcpyHostToDevice));
-		spasm_hip_dcsr dA{A->n, m, annz, dAp, dAj, dAx};
+		spasm_hip_dcsr dA{A->n, m, annz, devA.p, devA.j, devA.x};
 		spasm_hip_dwork *W = spasm_hip_dwork_create(n, m, 64);
 		u32 *dS = dalloc<u32>((i64) n * Sm);
 		struct spasm_triplet *L = fact->Ltmp;
@@ -534,9 +517,6 @@ void spasm_hip_schur_dense(const struct spasm_csr *A, const int *p, int n, const
 		}
 		(void) hipFree(dS);
 		spasm_hip_dwork_destroy(W);
-		(void) hipFree(dAp);
-		(void) hipFree(dAj);
-		(void) hipFree(dAx);
 		(void) hipFree(drows);
 	}
 	logmsg("[schur/dense/hip] %d x %d dense rows in %.1fs\n", n, Sm, wtime() - t0);
@@ -564,17 +544,10 @@ void spasm_hip_schur_dense_randomized(const struct spasm_csr *A, const int *p, i
 		q[l] = F->h_q[l];
 	if (N > 0 && Sm > 0) {
 		const i64 annz = A->p[A->n];
-		i64 *dAp = dalloc<i64>((i64) A->n + 1);
-		int *dAj = dalloc<int>(annz);
-		int *dAx = dalloc<int>(annz);
+		DeviceMatrix devA(A, stream);
 		int *drows = dalloc<int>(n);
-		HIP_CHECK(hipMemcpy(dAp, A->p, ((size_t) A->n + 1) * sizeof(i64), hipMemcpyHostToDevice));
-		if (annz > 0) {
-			HIP_CHECK(hipMemcpy(dAj, A->j, (size_t) annz * sizeof(int), hipMemcpyHostToDevice));
-			HIP_CHECK(hipMemcpy(dAx, A->x, (size_t) annz * sizeof(int), hipMemcpyHostToDevice));
-		}
 		HIP_CHECK(hipMemcpy(drows, p, (size_t) n * sizeof(int), hipMemcpyHostToDevice));
-		spasm_hip_dcsr dA{A->n, m, annz, dAp, dAj, dAx};
+		spasm_hip_dcsr dA{A->n, m, annz, devA.p, devA.j, devA.x};
 		spasm_hip_dwork *W = spasm_hip_dwork_create(N, m, 64);
 		u32 *dS = dalloc<u32>((i64) N * Sm);
 		device_random_dense_rows(dA, drows, n, F, N, w, call_id * 0x9E3779B97F4A7C15ULL, dS, Sm, W, stream);
@@ -591,9 +564,6 @@ void spasm_hip_schur_dense_randomized(const struct spasm_csr *A, const int *p, i
 		}
 		(void) hipFree(dS);
 		spasm_hip_dwork_destroy(W);
-		(void) hipFree(dAp);
-		(void) hipFree(dAj);
-		(void) hipFree(dAx);
 		(void) hipFree(drows);
 	}
 	logmsg("[schur/dense/random/hip] %d combinations (weight %d) of %d rows, %d columns, %.1fs\n", N, w, n, Sm, wtime() - t0);

@@ -160,6 +160,23 @@ struct BsImage {
 	char kernel_build[48] = "backsolve_kernel";      // variant launched by the last build, as rocprofv3 prints it
 };
 
+// device copy of a host CSR matrix for the duration of a call (schur_api.hip: resident between the calls of a driver)
+struct DeviceMatrix {
+	int64_t *p = nullptr;
+	int *j = nullptr, *x = nullptr;
+	int64_t nnz = 0;
+	bool owned = false;
+	DeviceMatrix(const struct spasm_csr *A, hipStream_t stream);
+	~DeviceMatrix();
+	DeviceMatrix(const DeviceMatrix &) = delete;
+	DeviceMatrix &operator=(const DeviceMatrix &) = delete;
+};
+void resident_begin();
+void resident_end();
+void resident_forget(const struct spasm_csr *A);
+bool resident_enabled();
+void resident_counters(int64_t *uploads, int64_t *hits);
+
 // where bs_apply_kernel writes a sparse result directly in its final place (rows in order, offsets by look-back)
 struct BsDirectOut {
 	unsigned long long *status;   // nrows words, zeroed before the launch

@@ -9,7 +9,7 @@
 #include <cmath>
 #include <vector>
 
-#include "common.h"
+#include "device_types.h"
 #include "sha256.h"
 
 namespace sh {
@@ -365,6 +365,7 @@ extern "C" struct spasm_lu *spasm_hip_echelonize(const struct spasm_csr *A0, str
 {
 	for (int k = 0; k < 8; k++)
 		g_prof[k] = 0.0;
+	resident_begin();          // A, and every Schur complement after it, stays in HBM between the calls below
 	if (spasm_hip_device_count() == 0)
 		die("spasm_hip_echelonize: no HIP device (this library has no CPU path)");
 	struct echelonize_opts dflt;
@@ -440,8 +441,10 @@ extern "C" struct spasm_lu *spasm_hip_echelonize(const struct spasm_csr *A0, str
 			S = spasm_hip_schur(A, p + npiv, n - npiv, fact, density, fact->Ltmp, p_in, p_out);
 		}
 		g_prof[5] += 1.0;
-		if (A != A0)
+		if (A != A0) {
+			resident_forget(A);
 			spasm_hip_csr_free((struct spasm_csr *) A);
+		}
 		A = S;
 		n = n - npiv;
 		std::free(p_in);
@@ -490,8 +493,10 @@ extern "C" struct spasm_lu *spasm_hip_echelonize(const struct spasm_csr *A0, str
 				}
 				int *p_out = (int *) xmalloc((i64) (n - npiv) * sizeof(int));
 				struct spasm_csr *S = spasm_hip_schur(A, p + npiv, n - npiv, fact, density, fact->Ltmp, p_in, p_out);
-				if (A != A0)
+				if (A != A0) {
+					resident_forget(A);
 					spasm_hip_csr_free((struct spasm_csr *) A);
+				}
 				A = S;
 				n = n - npiv;
 				std::free(p_in);
@@ -505,6 +510,14 @@ extern "C" struct spasm_lu *spasm_hip_echelonize(const struct spasm_csr *A0, str
 	}
 	std::free(p);
 	std::free(p_in);
+	{
+		int64_t uploads = 0, hits = 0;
+		resident_counters(&uploads, &hits);
+		g_prof[7] = (double) uploads;
+		logmsg("[echelonize] matrices uploaded to the device so far in this process: %lld (reused in place %lld times)\n",
+		       (long long) uploads, (long long) hits);
+	}
+	resident_end();
 	g_prof[0] = wtime() - start;
 	logmsg("[echelonize] done in %.1fs. Rank %d, %" PRId64 " nz in basis\n", wtime() - start, U->n, U->p[U->n]);
 	spasm_hip_csr_resize(U, U->n, m);

@@ -103,6 +103,101 @@ int cu_count()
 
 }  // namespace
 
+// ---- device copies of host matrices -----------------------------------------------------------------
+// A host-pointer entry point needs its matrix in HBM for the duration of the call.  Inside spasm_hip_echelonize the
+// same matrices come back call after call (density estimate, Schur complement, dense finish of round k all read the A
+// of round k, and the S that round k produced is the A of round k + 1): the driver switches residency on, and then a
+// matrix is uploaded at most once, a Schur complement is kept where it was computed (all-gathered, with several
+// GPUs) and never uploaded at all.  Entries are keyed by the address of the host struct; the driver forgets an entry
+// before it frees the matrix, so an address is never reused behind the table's back.  Outside the driver every call
+// uploads and frees its own copy, as before.
+namespace sh {
+struct ResidentEntry {
+	const struct spasm_csr *host;
+	i64 *p;
+	int *j, *x;
+	i64 nnz;
+};
+static std::vector<ResidentEntry> g_resident;
+static bool g_resident_on = false;
+static i64 g_resident_uploads = 0, g_resident_hits = 0;
+
+void resident_begin() { g_resident_on = true; }
+
+void resident_forget(const struct spasm_csr *A)
+{
+	for (size_t t = 0; t < g_resident.size(); t++)
+		if (g_resident[t].host == A) {
+			(void) hipFree(g_resident[t].p);
+			(void) hipFree(g_resident[t].j);
+			(void) hipFree(g_resident[t].x);
+			g_resident.erase(g_resident.begin() + (long) t);
+			return;
+		}
+}
+
+void resident_end()
+{
+	while (!g_resident.empty())
+		resident_forget(g_resident.back().host);
+	g_resident_on = false;
+}
+
+void resident_counters(i64 *uploads, i64 *hits)
+{
+	*uploads = g_resident_uploads;
+	*hits = g_resident_hits;
+}
+
+// takes ownership of device arrays that hold the matrix `host` describes (a fresh Schur complement)
+void resident_adopt(const struct spasm_csr *host, i64 *dp, int *dj, int *dx)
+{
+	resident_forget(host);
+	g_resident.push_back(ResidentEntry{host, dp, dj, dx, host->p[host->n]});
+}
+
+bool resident_enabled() { return g_resident_on; }
+
+DeviceMatrix::DeviceMatrix(const struct spasm_csr *A, hipStream_t stream)
+{
+	nnz = A->p[A->n];
+	for (const ResidentEntry &e : g_resident)
+		if (e.host == A && e.nnz == nnz) {
+			p = e.p;
+			j = e.j;
+			x = e.x;
+			owned = false;
+			g_resident_hits += 1;
+			return;
+		}
+	HIP_CHECK(hipMalloc((void **) &p, ((size_t) A->n + 1) * sizeof(i64)));
+	HIP_CHECK(hipMalloc((void **) &j, (size_t) (nnz > 0 ? nnz : 1) * sizeof(int)));
+	HIP_CHECK(hipMalloc((void **) &x, (size_t) (nnz > 0 ? nnz : 1) * sizeof(int)));
+	HIP_CHECK(hipMemcpyAsync(p, A->p, ((size_t) A->n + 1) * sizeof(i64), hipMemcpyHostToDevice, stream));
+	if (nnz > 0) {
+		HIP_CHECK(hipMemcpyAsync(j, A->j, (size_t) nnz * sizeof(int), hipMemcpyHostToDevice, stream));
+		HIP_CHECK(hipMemcpyAsync(x, A->x, (size_t) nnz * sizeof(int), hipMemcpyHostToDevice, stream));
+	}
+	HIP_CHECK(hipStreamSynchronize(stream));
+	g_resident_uploads += 1;
+	if (g_resident_on) {
+		g_resident.push_back(ResidentEntry{A, p, j, x, nnz});
+		owned = false;
+	} else {
+		owned = true;
+	}
+}
+
+DeviceMatrix::~DeviceMatrix()
+{
+	if (owned) {
+		(void) hipFree(p);
+		(void) hipFree(j);
+		(void) hipFree(x);
+	}
+}
+}  // namespace sh
+
 // ---- one-entry cache of the factor image for the host-pointer wrappers -------------------------
 // A round of the driver calls spasm_hip_schur_estimate_density, spasm_hip_schur and the dense-row
 // functions on the same (U, qinv): planning + uploading the image once is enough.  The key is the
@@ -985,9 +1080,7 @@ struct spasm_csr *spasm_hip_schur(const struct spasm_csr *A, const int *p, int n
 	const double t_fact = wtime() - t0;
 	// device image of A and of the row list
 	const i64 annz = A->p[A->n];
-	i64 *dAp = dalloc<i64>((i64) A->n + 1);
-	int *dAj = dalloc<int>(annz);
-	int *dAx = dalloc<int>(annz);
+	DeviceMatrix devA(A, stream);
 	// one process per GPU with a communicator installed (dist_api.hip): this rank reduces rows [lo, hi) of the list, the
 	// slices are reassembled on the devices.  Small batches (density samples) and calls that record L are not sharded:
 	// every rank computes them whole, which keeps the ranks in step without a collective.
@@ -1002,11 +1095,8 @@ struct spasm_csr *spasm_hip_schur(const struct spasm_csr *A, const int *p, int n
 	p += lo;
 	n = hi - lo;
 	int *drows = dalloc<int>(n);
-	upload(dAp, A->p, (i64) A->n + 1, stream);
-	upload(dAj, A->j, annz, stream);
-	upload(dAx, A->x, annz, stream);
 	upload(drows, p, n, stream);
-	spasm_hip_dcsr dA{A->n, m, annz, dAp, dAj, dAx};
+	spasm_hip_dcsr dA{A->n, m, annz, devA.p, devA.j, devA.x};
 
 	if (est_density < 0)
 		est_density = 0.0;     // the pool below is grown on demand instead of being estimated
@@ -1116,15 +1206,32 @@ struct spasm_csr *spasm_hip_schur(const struct spasm_csr *A, const int *p, int n
 			HIP_CHECK(hipMemcpy(S->j, gSj, (size_t) total * sizeof(int), hipMemcpyDeviceToHost));
 			HIP_CHECK(hipMemcpy(S->x, gSx, (size_t) total * sizeof(int), hipMemcpyDeviceToHost));
 		}
-		(void) hipFree(gSp);
-		(void) hipFree(gSj);
-		(void) hipFree(gSx);
+		if (resident_enabled() && n_all >= 1024) {
+			resident_adopt(S, gSp, gSj, gSx);          // the next round's A is already on every device
+		} else {
+			(void) hipFree(gSp);
+			(void) hipFree(gSj);
+			(void) hipFree(gSx);
+		}
 	} else {
 		S = spasm_hip_csr_alloc(n, m, st.nnz, prime, true);
 		HIP_CHECK(hipMemcpy(S->p, W->d_Sp, ((size_t) n + 1) * sizeof(i64), hipMemcpyDeviceToHost));
 		if (st.nnz > 0) {
 			HIP_CHECK(hipMemcpy(S->j, W->d_Sj, (size_t) st.nnz * sizeof(int), hipMemcpyDeviceToHost));
 			HIP_CHECK(hipMemcpy(S->x, W->d_Sx, (size_t) st.nnz * sizeof(int), hipMemcpyDeviceToHost));
+		}
+		if (resident_enabled() && n >= 1024) {
+			// keep the result where it was computed (a device-to-device copy out of the workspace, which is sized for the
+			// estimate, not for the result): it is the A of the next round
+			i64 *kp = dalloc<i64>((i64) n + 1);
+			int *kj = dalloc<int>(st.nnz), *kx = dalloc<int>(st.nnz);
+			HIP_CHECK(hipMemcpyAsync(kp, W->d_Sp, ((size_t) n + 1) * sizeof(i64), hipMemcpyDeviceToDevice, stream));
+			if (st.nnz > 0) {
+				HIP_CHECK(hipMemcpyAsync(kj, W->d_Sj, (size_t) st.nnz * sizeof(int), hipMemcpyDeviceToDevice, stream));
+				HIP_CHECK(hipMemcpyAsync(kx, W->d_Sx, (size_t) st.nnz * sizeof(int), hipMemcpyDeviceToDevice, stream));
+			}
+			HIP_CHECK(hipStreamSynchronize(stream));
+			resident_adopt(S, kp, kj, kx);
 		}
 	}
 	if (p_out != nullptr)
@@ -1134,9 +1241,6 @@ struct spasm_csr *spasm_hip_schur(const struct spasm_csr *A, const int *p, int n
 	const double t3 = wtime();
 	scratch_park(W);
 	spasm_hip_dwork_destroy(W);
-	(void) hipFree(dAp);
-	(void) hipFree(dAj);
-	(void) hipFree(dAx);
 	(void) hipFree(drows);
 	const double density = (S->n > 0 && m > 0) ? (double) S->p[S->n] / ((double) m * S->n) : 0.0;
 	logmsg("Schur complement: %d * %d [%" PRId64 " nz / density= %.3f], %.1fs (GPU kernels %.1f ms; tiers %d/%d/%d; "

@@ -200,7 +200,7 @@ def echelonize_profile():
     out = (C.c_double * 8)()
     lib().spasm_hip_echelonize_profile(out)
     return {"total": out[0], "pivot_search": out[1], "density_estimates": out[2], "sparse_schur": out[3],
-            "dense_finish": out[4], "sparse_rounds": int(out[5]), "structural_finish": out[6]}
+            "dense_finish": out[4], "sparse_rounds": int(out[5]), "structural_finish": out[6], "uploads_so_far": int(out[7])}
 
 
 def rref(F):
