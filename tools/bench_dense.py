@@ -15,6 +15,7 @@ ap = argparse.ArgumentParser()
 ap.add_argument("--n", type=int, default=4096)
 ap.add_argument("--m", type=int, default=32768)
 ap.add_argument("--prime", type=int, default=42013)
+ap.add_argument("--mfma-only", action="store_true", help="skip the VALU comparison run (profiling)")
 args = ap.parse_args()
 
 import torch
@@ -27,7 +28,7 @@ g.manual_seed(1)
 A0 = torch.randint(0, args.prime, (args.n, args.m), dtype=torch.int64, device=dev, generator=g).to(torch.int32)
 out = {}
 results = []
-for name, use in (("mfma_i8", 1), ("valu_u64", 0)):
+for name, use in ((("mfma_i8", 1),) if args.mfma_only else (("mfma_i8", 1), ("valu_u64", 0))):
     A = A0.clone()
     piv = torch.zeros(args.m, dtype=torch.int32, device=dev)
     ms = C.c_float(0)
@@ -61,7 +62,7 @@ for _ in range(2):
     ev1.record()
     torch.cuda.synchronize()
 out["ms_total_untimed"] = ev0.elapsed_time(ev1)
-out["same_matrix"] = bool(torch.equal(results[0], results[1])) and bool(torch.equal(results[0], A[:r]))
+out["same_matrix"] = (len(results) < 2 or bool(torch.equal(results[0], results[1]))) and bool(torch.equal(results[0], A[:r]))
 out["shape"] = [args.n, args.m]
 out["i8_TOPs_equiv_mfma"] = (8 * out["mfma_i8"]["update_Tmacs_per_s"]) if out["mfma_i8"]["update_Tmacs_per_s"] else None
 print(json.dumps(out))

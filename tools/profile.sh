@@ -18,6 +18,8 @@ for MODE in default rows; do
 	rocprofv3 --kernel-trace --stats --output-format csv -d $D/trace -- python3 $ARGS > $D/bench_trace.json 2> $D/trace.log
 	rocprofv3 --pmc FETCH_SIZE --output-format csv -d $D/pmc_fetch -- python3 $ARGS > /dev/null 2> $D/pmc_fetch.log
 	rocprofv3 --pmc WRITE_SIZE --output-format csv -d $D/pmc_write -- python3 $ARGS > /dev/null 2> $D/pmc_write.log
+	# no-return atomics that reach the memory side (round 1's row-group kernel is bound by them; the back-substituted path has none)
+	rocprofv3 --pmc TCC_ATOMIC_sum --output-format csv -d $D/pmc_atomic -- python3 $ARGS > /dev/null 2> $D/pmc_atomic.log
 	python3 tools/summarize_profile.py $D > $OUT/summary_$MODE.txt 2>&1
 	cat $OUT/summary_$MODE.txt
 done

@@ -49,19 +49,19 @@ def main():
     for k, v in sorted(rows.items(), key=lambda kv: -sum(kv[1])):
         print("%-62s %8d %12.1f %12.1f %12.1f" % (k, len(v), sum(v), sum(v) / len(v), max(v)))
     per = {}
-    for ctr, sub in (("FETCH_SIZE", "pmc_fetch"), ("WRITE_SIZE", "pmc_write")):
+    for ctr, sub in (("FETCH_SIZE", "pmc_fetch"), ("WRITE_SIZE", "pmc_write"), ("TCC_ATOMIC_sum", "pmc_atomic")):
         acc = defaultdict(list)
         for f in glob.glob(os.path.join(out, sub, "**", "*counter_collection.csv"), recursive=True):
             for r in csv.DictReader(open(f)):
                 if r.get("Counter_Name") == ctr:
                     acc[short(r["Kernel_Name"])].append(float(r["Counter_Value"]))
-        print("\n== %s per launch (counter units: KiB) ==" % ctr)
+        print("\n== %s per launch (%s) ==" % (ctr, "64-byte atomic requests" if ctr.startswith("TCC") else "counter units: KiB"))
         for k, v in sorted(acc.items(), key=lambda kv: -sum(kv[1])):
             # bench.py sizes its row pool by probing: launches that ran out of pool stop early and move fewer bytes.
             # The per-launch figure is the mean over the full-size launches (within 10 % of the largest).
             full = [x for x in v if x >= 0.9 * max(v)]
             print("%-62s launches %5d  avg %16.1f  max %16.1f  full-size %5d  avg %16.1f" % (k, len(v), sum(v) / len(v), max(v), len(full), sum(full) / len(full)))
-            per.setdefault(k, {})[ctr] = sum(full) / len(full) * 1024.0
+            per.setdefault(k, {})[ctr] = sum(full) / len(full) * (1.0 if ctr.startswith("TCC") else 1024.0)
             per[k]["launches_" + ctr] = len(full)
     bench = {}
     try:
@@ -81,7 +81,7 @@ def main():
             traffic["kernels"][k] = {"fetch_bytes_raw": v["FETCH_SIZE"], "write_bytes_raw": v["WRITE_SIZE"],
                                      "bytes_per_launch": v["FETCH_SIZE"] + v["WRITE_SIZE"],
                                      "bytes_per_launch_fetch_doubled": 2 * v["FETCH_SIZE"] + v["WRITE_SIZE"],
-                                     "launches": v["launches_FETCH_SIZE"],
+                                     "launches": v["launches_FETCH_SIZE"], "atomic_requests_per_launch": v.get("TCC_ATOMIC_sum"),
                                      "avg_us_in_trace_full_size": (lambda t: sum(t) / len(t))([x for x in rows[k] if x >= 0.9 * max(rows[k])]) if k in rows else None}
     json.dump(traffic, open(os.path.join(out, "traffic.json"), "w"), indent=1)
 
