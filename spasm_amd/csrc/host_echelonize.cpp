@@ -482,6 +482,15 @@ extern "C" struct spasm_lu *spasm_hip_echelonize(const struct spasm_csr *A0, str
 					npiv = spasm_hip_pivots_extract_structural(A, p_in, fact, p, opts);
 					if (npiv == 0)
 						die("structural pivot search found nothing on a non-zero matrix");
+					// a round is only guaranteed one pivot, and every round re-plans the whole factor: once the search
+					// brings in less than 1 % of what is left, the remainder goes to the dense code whatever its density
+					// (the reference's one-pass GPLU would take it here)
+					if (opts->enable_dense && n - npiv > 0 && (double) npiv < 0.01 * (double) std::min(n, m - (U->n - npiv))) {
+						logmsg("[echelonize/rounds] only %d pivots in extra round %d: dense finish for the remaining %d rows\n", npiv, extra, n - npiv);
+						if (!finish_on_device(A, p + npiv, n - npiv, fact, opts, false))
+							finish_dense(A, p + npiv, n - npiv, p_in, fact, opts);
+						break;
+					}
 				}
 				if (n - npiv == 0)
 					break;

@@ -280,3 +280,36 @@ def test_schur_records_L(oracle, name, p, group, monkeypatch):
     assert _triplet_set(L_got, p) == _triplet_set(L_want, p)
     P = p
     assert np.all(L_got[2] <= P // 2) and np.all(L_got[2] >= -(P // 2))
+
+
+def test_wide_matrix_with_a_small_scratch_budget_takes_the_per_row_kernels(oracle, monkeypatch):
+    """2 M columns: a row-group slice (one 256-byte line per label) is 512 MB, so a 1 GB scratch budget holds two -- far
+    fewer than there are compute units.  The library must fall back to the per-row kernels (4 bytes per label and wave)
+    instead of idling the chip or failing to allocate; same matrix as the oracle's."""
+    import torch
+    monkeypatch.setenv("SPASM_HIP_SCRATCH_GB", "1")
+    p = 42013
+    n, m, per_row = 9000, 2_000_000, 3
+    rng = np.random.default_rng(77)
+    ti = np.repeat(np.arange(n, dtype=np.int32), per_row)
+    # every entry inside the first 4,000 columns (so at most 4,000 pivots and thousands of rows to reduce), one of them
+    # moved far out for a few rows so that the 2 M columns are really addressed; the label space is 2 M wide either way
+    tj = rng.integers(0, 4000, size=(n, per_row))
+    far = rng.random(n) < 0.05
+    tj[far, 2] = rng.integers(4000, m, size=int(far.sum()))
+    tj = tj.reshape(-1).astype(np.int32)
+    tx = rng.integers(1, p, size=n * per_row).astype(np.int64)
+    A = oracle.compress(p, n, m, ti, tj, tx)
+    npiv, perm, F = oracle.pivots_extract_structural(A, oracle.empty_fact(A.n, A.m, p))
+    rows = perm[npiv:]
+    assert len(rows) >= 2048
+    want, _, _ = oracle.schur(A, rows, F)
+    dA = spasm_amd.DeviceCsr.from_host(_as_product(A))
+    dF = spasm_amd.DeviceFact(_fact(F))
+    W = spasm_amd.SchurWorkspace(len(rows), A.m, 4 * want.nnz + (1 << 22))
+    drows = torch.from_numpy(np.ascontiguousarray(rows, np.int32)).cuda()
+    S, st = spasm_amd.dschur(dA, drows, dF, W)
+    assert st.status == 0 and st.used_backsolve == 0 and st.used_group_kernel == 0
+    assert st.rows_lds + st.rows_lds_big + st.rows_dense == len(rows)
+    H = S.to_host()
+    assert oracle.same_matrix(oracle.CSR(H.n, H.m, H.p, H.j, H.x, p), want)
