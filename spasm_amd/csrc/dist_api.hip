@@ -2,8 +2,8 @@
 //
 // What shards is what the reference hands to OpenMP threads: the rows of a Schur complement (spasm_schur.c:86-171).
 // Every rank holds A and the factor, reduces a contiguous slice of the row list on its GPU, and the slices are
-// reassembled ON THE DEVICES with an all-gatherv -- one ncclAllGather for the sizes, then one grouped round of
-// ncclBroadcast per rank and array with the exact counts (no padding, no host staging).  The host pivot search runs
+// reassembled ON THE DEVICES with an all-gatherv -- one ncclAllGather for the sizes, then one grouped round of direct
+// sends and receives between every pair of ranks with the exact counts (no padding, no host staging).  The host pivot search runs
 // once, on rank 0 (it is threaded and timing dependent), and its outcome is broadcast.  With a communicator installed
 // (spasm_hip_set_comm) the ordinary entry points -- spasm_hip_pivots_extract_structural, spasm_hip_schur and with them
 // spasm_hip_echelonize -- do all this by themselves; every rank must make the same calls in the same order.
@@ -153,18 +153,52 @@ int spasm_hip_dschur_allgatherv(spasm_hip_comm *c, const spasm_hip_dwork *W, i64
 		*total_nnz = nz_base[world];
 	if (cap < 0 || nz_base[world] > cap)
 		return 1;
-	// exact counts: one broadcast per rank and array, all in one group (they run concurrently over the links)
+	// exact counts, no padding.  xGMI is point-to-point (every GPU has a link to every other one): each rank SENDS its
+	// slice straight to every peer and receives theirs, all in one group, so that all the links carry payload at once
+	// (a ring all-gather or a broadcast tree would push the whole of S through single links).  The local slice is a
+	// device-to-device copy.  SPASM_HIP_ALLGATHERV=bcast: one ncclBroadcast per rank and array instead.
+	const char *how = std::getenv("SPASM_HIP_ALLGATHERV");
+	const bool use_bcast = how != nullptr && std::strcmp(how, "bcast") == 0;
+	const int me = c->rank;
 	NCCL_CHECK(ncclGroupStart());
 	for (int r = 0; r < world; r++) {
 		const int64_t nr = sizes[2 * r], nz = sizes[2 * r + 1];
+		if (use_bcast) {
+			if (nr > 0)
+				NCCL_CHECK(ncclBroadcast(W->d_Sp, d_Sp + row_base[r], (size_t) nr, ncclInt64, r, c->comm, stream));
+			if (nz > 0) {
+				NCCL_CHECK(ncclBroadcast(W->d_Sj, d_Sj + nz_base[r], (size_t) nz, ncclInt32, r, c->comm, stream));
+				NCCL_CHECK(ncclBroadcast(W->d_Sx, d_Sx + nz_base[r], (size_t) nz, ncclInt32, r, c->comm, stream));
+			}
+			continue;
+		}
+		if (r == me)
+			continue;
+		// to peer r: my slice; from peer r: its slice (sends and receives between two ranks match in issue order)
+		const int64_t my_nr = sizes[2 * me], my_nz = sizes[2 * me + 1];
+		if (my_nr > 0)
+			NCCL_CHECK(ncclSend(W->d_Sp, (size_t) my_nr, ncclInt64, r, c->comm, stream));
 		if (nr > 0)
-			NCCL_CHECK(ncclBroadcast(W->d_Sp, d_Sp + row_base[r], (size_t) nr, ncclInt64, r, c->comm, stream));
+			NCCL_CHECK(ncclRecv(d_Sp + row_base[r], (size_t) nr, ncclInt64, r, c->comm, stream));
+		if (my_nz > 0) {
+			NCCL_CHECK(ncclSend(W->d_Sj, (size_t) my_nz, ncclInt32, r, c->comm, stream));
+			NCCL_CHECK(ncclSend(W->d_Sx, (size_t) my_nz, ncclInt32, r, c->comm, stream));
+		}
 		if (nz > 0) {
-			NCCL_CHECK(ncclBroadcast(W->d_Sj, d_Sj + nz_base[r], (size_t) nz, ncclInt32, r, c->comm, stream));
-			NCCL_CHECK(ncclBroadcast(W->d_Sx, d_Sx + nz_base[r], (size_t) nz, ncclInt32, r, c->comm, stream));
+			NCCL_CHECK(ncclRecv(d_Sj + nz_base[r], (size_t) nz, ncclInt32, r, c->comm, stream));
+			NCCL_CHECK(ncclRecv(d_Sx + nz_base[r], (size_t) nz, ncclInt32, r, c->comm, stream));
 		}
 	}
 	NCCL_CHECK(ncclGroupEnd());
+	if (!use_bcast) {
+		const int64_t my_nr = sizes[2 * me], my_nz = sizes[2 * me + 1];
+		if (my_nr > 0)
+			HIP_CHECK(hipMemcpyAsync(d_Sp + row_base[me], W->d_Sp, (size_t) my_nr * sizeof(int64_t), hipMemcpyDeviceToDevice, stream));
+		if (my_nz > 0) {
+			HIP_CHECK(hipMemcpyAsync(d_Sj + nz_base[me], W->d_Sj, (size_t) my_nz * sizeof(int), hipMemcpyDeviceToDevice, stream));
+			HIP_CHECK(hipMemcpyAsync(d_Sx + nz_base[me], W->d_Sx, (size_t) my_nz * sizeof(int), hipMemcpyDeviceToDevice, stream));
+		}
+	}
 	// the row pointers of a slice start at 0: shift them to where the slice went
 	for (int r = 0; r < world; r++) {
 		const int nr = (int) sizes[2 * r];

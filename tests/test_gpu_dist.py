@@ -28,9 +28,11 @@ def comm():
     c.close()
 
 
+@pytest.mark.parametrize("how", ["p2p", "bcast"])
 @pytest.mark.parametrize("name", ["mat364.sms", "medium.sms", "trefethen_500.sms", "void.sms"])
-def test_allgatherv_of_a_world_of_one_is_the_identity(oracle, comm, name):
+def test_allgatherv_of_a_world_of_one_is_the_identity(oracle, comm, name, how, monkeypatch):
     import torch
+    monkeypatch.setenv("SPASM_HIP_ALLGATHERV", how)
     p = 42013
     A = oracle.load_sms(matrix_path(name), p)
     npiv, perm, F = oracle.pivots_extract_structural(A, oracle.empty_fact(A.n, A.m, p))
