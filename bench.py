@@ -147,7 +147,9 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--workload", default="mk13.b5")
+    ap.add_argument("--workload", default=None,
+                    help="BASELINE config to run (default: GL7d19 -- the matrix BASELINE.json quotes its metric on -- when "
+                         "$SPASM_DATA/GL7d19.sms[.gz] exists, else mk13.b5, the config that can be regenerated offline)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true",
                     help="skip the row-by-row comparison, the dense-tail probe and the end-to-end runs")
@@ -156,6 +158,13 @@ def main():
     import torch
     import spasm_amd
     import workloads
+    why = "asked for"
+    if args.workload is None:
+        if workloads.find_data(workloads.config("GL7d19")["file"]) is not None:
+            args.workload, why = "GL7d19", "BASELINE.json quotes its metric on GL7d19 and its data file is present"
+        else:
+            args.workload, why = "mk13.b5", ("GL7d19.sms (the matrix BASELINE.json quotes its metric on) is absent under %s: "
+                                            "configs[1], the config that can be regenerated offline" % workloads.data_dir())
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
@@ -325,6 +334,7 @@ def main():
                        "rows_per_step": total_rows, "pivots": int(F.U.n), "levels": dF.levels,
                        "non_pivotal_columns": int(A.m - F.U.n), "schur_nnz": int(st.nnz),
                        "path": "back-substituted factor image" if st.used_backsolve else "row-by-row elimination",
+                       "why_this_workload": why,
                        "sharding": "rows over %d rank(s)%s" % (world, ", all-gatherv of S" if use_dist else "")},
             "roofline": roof,
         }
@@ -359,14 +369,22 @@ def main():
             # the other half of the headline metric: wall-clock time of the whole rank computation (host I/O excluded:
             # the matrix is already in memory), default options of tools/rank, five calls
             os.environ.pop("SPASM_HIP_THREADS", None)
+            # (the tools/rank options of the config: --dense-threshold x, --no-greedy-pivot-search)
+            opts = spasm_amd.default_opts()
+            rank_args = (workloads.config(args.workload) or {"rank_args": []})["rank_args"]
+            for t, a in enumerate(rank_args):
+                if a == "--dense-threshold":
+                    opts.sparsity_threshold = float(rank_args[t + 1])
+                if a == "--no-greedy-pivot-search":
+                    opts.enable_greedy_pivot_search = False
             runs = []
             for _ in range(5):
                 t0 = time.perf_counter()
-                fact = spasm_amd.echelonize(A)
+                fact = spasm_amd.echelonize(A, opts)
                 runs.append((time.perf_counter() - t0, spasm_amd.echelonize_profile(), int(fact.U.n)))
             secs = [r[0] for r in runs]
             med = sorted(runs, key=lambda r: r[0])[len(runs) // 2]
-            out["end_to_end"] = {"what": "spasm_hip_echelonize on the same matrix, default options, 5 calls",
+            out["end_to_end"] = {"what": "spasm_hip_echelonize on the same matrix, options of the config (%s), 5 calls" % (" ".join(rank_args) or "defaults"),
                                  "rank": med[2], "ranks_agree": len({r[2] for r in runs}) == 1,
                                  "seconds_min": min(secs), "seconds_median": statistics.median(secs), "seconds_all": secs,
                                  "split_of_median_call": med[1]}
