@@ -70,6 +70,22 @@ def test_echelonize_dist_shards_every_round(oracle, comm, name, p, monkeypatch):
         seen.add(int(jj[0]))
 
 
+def test_sharded_driver_with_a_sparse_round_at_scale(comm, monkeypatch):
+    """mk13.b4 (159,093 x 23,958 Schur complement, 4.4 % dense) with its sparse round forced and every Schur complement
+    sharded: the slice is reduced by the row-group kernel, all-gathered on the device, kept there as the next round's
+    A (never uploaded) and downloaded once for the host pivot search.  Rank = the CPU oracle's."""
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import workloads
+    monkeypatch.setenv("SPASM_HIP_SHARD_FORCE", "1")
+    A, _ = workloads.load_matrix("mk13.b4")
+    o = spasm_amd.default_opts()
+    o.sparsity_threshold = 0.1
+    F = echelonize_dist(A, comm, o)
+    prof = spasm_amd.echelonize_profile()
+    assert F.U.n == 111463
+    assert prof["sparse_rounds"] >= 1
+
+
 def test_bench_runs_its_rccl_path_on_one_gpu():
     """bench.py with the all-gatherv of the C ABI forced on (world of one), on a small sibling of the bench matrix."""
     env = dict(os.environ, SPASM_BENCH_FORCE_DIST="1", SPASM_HIP_VERBOSE="0", MASTER_ADDR="127.0.0.1", MASTER_PORT="29871",
