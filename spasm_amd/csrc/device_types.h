@@ -120,6 +120,7 @@ struct FactPlan {
 	std::vector<uint2> ent;
 	std::vector<uint2> head;                // 4 entries per label: the first entries of the row, 0xFFFFFFFF-padded
 	std::vector<uint32_t> comp;             // per label: smallest label of its connected component in the pivot graph
+	std::vector<int> lvl_first;             // first label of every level (levels of >= 32 rows start on a multiple of 32)
 };
 
 // ---- back-substituted factor ("R image", backsolve.hip) ------------------------------------------
@@ -205,6 +206,9 @@ struct spasm_hip_dfact {
 	uint32_t *d_lvl_end = nullptr;
 	uint32_t *d_lvl_end_w = nullptr;
 	int *d_kof = nullptr;          // label -> row of U (-1: padding label)
+	uint64_t *d_cp = nullptr;      // U' by TARGET label (schur_pull.hip): rpad + Sm + 1 offsets into d_cent
+	uint2 *d_cent = nullptr;       // (source label, value * 2^32 mod p)
+	int2 *d_lvl = nullptr;         // [first label, last label + 1) of every level
 	std::vector<int> h_q;          // host copy of q
 	std::vector<int> h_kof;
 	mutable sh::BsImage bs;        // back-substituted image, built on first use when the factor is eligible

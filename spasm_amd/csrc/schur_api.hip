@@ -21,6 +21,10 @@ void launch_schur_wave_dense(const SchurArgs &a, unsigned char *scratch, int64_t
                              bool wide, uint32_t *dense_out, int64_t ldS, int blocks, hipStream_t stream);
 void launch_all_rows_to_list(int *list, int *count, int *row_len, int nrows, hipStream_t stream);
 void schur_group_variant_name(int r, bool wide, int waves, char *out, size_t cap);
+size_t pull_lds_bytes(int rpad, int Sm);
+int64_t pull_slot_bytes(int rpad, int Sm);
+void launch_schur_pull(const SchurArgs &a, unsigned char *scratch, int64_t slot_bytes, const uint64_t *cp, const uint2 *cent,
+                       const int2 *lvl, int nlev, int blocks, hipStream_t stream);
 bool backsolve_eligible(int r, int Sm, int64_t nnz_u, int64_t *bytes);
 void backsolve_plan(const FactPlan &P, spasm_hip_dfact *F, hipStream_t stream);
 void backsolve_free(spasm_hip_dfact *F);
@@ -415,6 +419,7 @@ static void plan_factor(const struct spasm_csr *U, const int *qinv, FactPlan &P)
 	}
 	const int rpad = (lvl_start[nlev] + 31) / 32 * 32;
 	P.rpad = rpad;
+	P.lvl_first.assign(lvl_start.begin(), lvl_start.begin() + nlev);
 	P.label_of_row.assign((size_t) (r > 0 ? r : 1), 0);
 	{
 		std::vector<int> cursor(lvl_start.begin(), lvl_start.end());
@@ -598,6 +603,28 @@ spasm_hip_dfact *spasm_hip_dfact_create(const struct spasm_csr *U, const int *qi
 	upload(F->d_lvl_end, P.lvl_end.data(), rpad, stream);
 	upload(F->d_lvl_end_w, P.lvl_end_w.data(), rpad / 32, stream);
 	upload(F->d_kof, P.kof.data(), rpad, stream);
+	// U' by target label and the label range of every level: what the pull variant of the row-group kernel reads
+	std::vector<uint64_t> cp((size_t) rpad + (size_t) (m - r) + 1, 0);
+	std::vector<uint2> cent((size_t) (F->nnz > 0 ? F->nnz : 1));
+	std::vector<int2> lvl((size_t) (P.nlevels > 0 ? P.nlevels : 1));
+	{
+		for (i64 e = 0; e < F->nnz; e++)
+			cp[(size_t) P.ent[e].x + 1] += 1;
+		for (size_t t = 0; t + 1 < cp.size(); t++)
+			cp[t + 1] += cp[t];
+		std::vector<uint64_t> cursor(cp.begin(), cp.end() - 1);
+		for (int c = 0; c < rpad; c++)
+			for (uint64_t e = P.rp[c]; e < P.rp[c + 1]; e++)
+				cent[cursor[P.ent[e].x]++] = uint2{(uint32_t) c, P.ent[e].y};
+		for (int l = 0; l < P.nlevels; l++)
+			lvl[l] = int2{P.lvl_first[l], P.lvl_first[l] + P.lvl_count[l]};
+	}
+	F->d_cp = dalloc<uint64_t>((i64) cp.size());
+	F->d_cent = dalloc<uint2>((i64) cent.size());
+	F->d_lvl = dalloc<int2>((i64) lvl.size());
+	upload(F->d_cp, cp.data(), (i64) cp.size(), stream);
+	upload(F->d_cent, cent.data(), (i64) cent.size(), stream);
+	upload(F->d_lvl, lvl.data(), (i64) lvl.size(), stream);
 	HIP_CHECK(hipStreamSynchronize(stream));    // the host vectors die here
 	// back-substituted image (backsolve.hip): planned when the non-pivotal columns are few enough for dense rows
 	// of R; R itself is computed by the first Schur complement that wants it
@@ -621,6 +648,9 @@ void spasm_hip_dfact_destroy(spasm_hip_dfact *F)
 	(void) hipFree(F->d_lvl_end);
 	(void) hipFree(F->d_lvl_end_w);
 	(void) hipFree(F->d_kof);
+	(void) hipFree(F->d_cp);
+	(void) hipFree(F->d_cent);
+	(void) hipFree(F->d_lvl);
 	delete F;
 }
 
@@ -834,7 +864,7 @@ int dschur_impl(const spasm_hip_dcsr *A, const int *d_rows, int nrows, const spa
 		a.row_orig = Lout->row_orig;
 	}
 
-	bool used_bs = false, built_bs = false, bs_direct = false;
+	bool used_bs = false, built_bs = false, bs_direct = false, use_pull = false;
 	if (want_bs) {
 		// R is built on first use
 		used_bs = true;
@@ -907,6 +937,15 @@ int dschur_impl(const spasm_hip_dcsr *A, const int *d_rows, int nrows, const spa
 				regroup();
 				a.order = W->d_order;
 			}
+			use_pull = Lout == nullptr && env_int("SPASM_HIP_PULL", 0) != 0 && pull_lds_bytes(F->rpad, F->Sm) <= (size_t) 150 * 1024;
+			if (use_pull) {
+				// left-looking numeric pass, no atomics (schur_pull.hip); its slices are the row-group kernel's without the bitmap
+				const int per_cu = (int) std::max<size_t>(1, std::min<size_t>(8, (size_t) (160 * 1024) / (pull_lds_bytes(F->rpad, F->Sm) + 5 * 1024)));
+				const int pull_slots = (int) std::max<i64>(1, std::min<i64>(std::min<i64>((nrows + 63) / 64, (i64) cus * per_cu),
+				                                                          W->scratch_bytes / pull_slot_bytes(F->rpad, F->Sm)));
+				probe = false;
+				launch_schur_pull(a, W->d_scratch, pull_slot_bytes(F->rpad, F->Sm), F->d_cp, F->d_cent, F->d_lvl, F->nlevels, pull_slots, stream);
+			} else
 			launch_schur_group(a, W->d_scratch, group_slot_bytes, group_off_bm, wide_dense, nullptr, 0, group_slots, stream,
 			                   probe ? 1 : 0, min_eff, min_w, group_waves);
 			a.order = nullptr;
@@ -1022,6 +1061,8 @@ eliminated:
 			const bool build_dominates = stats->ms_backsolve > stats->ms_apply;
 			snprintf(stats->kernel, sizeof(stats->kernel), "%s", build_dominates ? B.kernel_build : apply_name);
 			snprintf(stats->kernel_other, sizeof(stats->kernel_other), "%s", build_dominates ? apply_name : B.kernel_build);
+		} else if (group_mode && use_pull) {
+			snprintf(stats->kernel, sizeof(stats->kernel), "schur_pull_kernel");
 		} else if (group_mode && !stats->group_aborted) {
 			schur_group_variant_name(F->rpad, wide_dense, group_waves, stats->kernel, sizeof(stats->kernel));
 		} else {

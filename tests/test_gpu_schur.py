@@ -142,12 +142,17 @@ def test_empty_row_list(oracle):
     assert S.n == 0 and S.nnz == 0
 
 
+@pytest.mark.parametrize("variant", ["push", "pull"])
 @pytest.mark.parametrize("name", ["mat364.sms", "medium.sms", "trefethen_500.sms", "singular.sms", "rectangular_l.sms",
                                   "BIOMD0000000424.int.mpl.sms", "void.sms", "empty.sms", "m1.sms", "small.sms"])
 @pytest.mark.parametrize("p", [3, 42013, 65537, 4294967291])
-def test_schur_row_group_kernel(oracle, name, p, monkeypatch):
-    """the 64-rows-per-wave kernel (label-major accumulators) gives the same matrix."""
+def test_schur_row_group_kernel(oracle, name, p, variant, monkeypatch):
+    """the 64-rows-per-workgroup kernels (label-major accumulators) give the same matrix: push = schur_group_kernel (one
+    no-return atomic per update), pull = schur_pull_kernel (symbolic sweep, then a left-looking numeric sweep with plain
+    loads and one store per touched line: no atomics; SPASM_HIP_PULL=1)."""
     monkeypatch.setenv("SPASM_HIP_GROUP", "1")
+    if variant == "pull":
+        monkeypatch.setenv("SPASM_HIP_PULL", "1")
     A, npiv, perm, F = _round0(oracle, name, p)
     rows = perm[npiv:]
     want, p_out_want, _ = oracle.schur(A, rows, F)
@@ -173,9 +178,12 @@ def test_schur_row_group_kernel_waves_per_group(oracle, name, p, waves, touched_
     _check(oracle, S, p_out, want, p_out_want)
 
 
+@pytest.mark.parametrize("variant", ["push", "pull"])
 @pytest.mark.parametrize("p", [42013, 4294967291])
-def test_schur_row_group_kernel_random(oracle, p, monkeypatch):
+def test_schur_row_group_kernel_random(oracle, p, variant, monkeypatch):
     monkeypatch.setenv("SPASM_HIP_GROUP", "1")
+    if variant == "pull":
+        monkeypatch.setenv("SPASM_HIP_PULL", "1")
     n, m, per_row = 3000, 2000, 3
     rng = np.random.default_rng(99)
     ti, tj, tx = _random_sparse(rng, n, m, per_row, p)
@@ -187,12 +195,15 @@ def test_schur_row_group_kernel_random(oracle, p, monkeypatch):
     _check(oracle, S, p_out, want, p_out_want)
 
 
+@pytest.mark.parametrize("variant", ["push", "pull"])
 @pytest.mark.parametrize("p", [42013, 4294967291])
 @pytest.mark.parametrize("row_len", [5, 9, 68, 69, 150, 300])
-def test_schur_row_group_kernel_long_pivot_rows(oracle, p, row_len, monkeypatch):
+def test_schur_row_group_kernel_long_pivot_rows(oracle, p, row_len, variant, monkeypatch):
     """pivot rows beyond the four-entry head: entries 4.. are fetched 64 per instruction (lane = entry), rows
     over 68 entries in several chunks.  Upper-trapezoidal pivot block with long rows + rows to reduce."""
     monkeypatch.setenv("SPASM_HIP_GROUP", "1")
+    if variant == "pull":
+        monkeypatch.setenv("SPASM_HIP_PULL", "1")
     rng = np.random.default_rng(row_len)
     npiv_rows, m, nred = 400, 900, 200
     ti, tj, tx = [], [], []
