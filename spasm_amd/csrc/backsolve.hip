@@ -339,7 +339,7 @@ __global__ __launch_bounds__(64 * NW) void backsolve_kernel(BsArgs b)
 // S = A_n - A_p R, one wave per row.  The row of S is accumulated in LDS (one word per lane and tile), the pivotal
 // entries of the input row are collected in a small LDS list and applied tile by tile.
 // --------------------------------------------------------------------------
-constexpr int AP_LIST = 256;       // pivotal entries applied per pass
+constexpr int AP_LIST = 64;        // pivotal entries applied per pass (one batch of input entries)
 constexpr int AP_TU = 4;           // 64-word tiles per inner step
 
 struct ApplyArgs {
