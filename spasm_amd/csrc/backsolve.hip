@@ -365,7 +365,7 @@ struct ApplyArgs {
 };
 
 constexpr unsigned long long LB_FLAG_LEN = 1ull << 62, LB_FLAG_END = 2ull << 62, LB_VALUE = (1ull << 62) - 1;
-constexpr int LB_PER_LANE = 4;             // predecessors inspected per lane and poll (256 per wave)
+constexpr int LB_PER_LANE = 1;             // predecessors inspected per lane and poll (64 per wave: 8 -> 4.23, 4 -> 3.93, 2 -> 3.69, 1 -> 3.50 ms)
 
 template <bool PACKED, bool PLAIN> __global__ __launch_bounds__(512) void bs_apply_kernel(ApplyArgs d)
 {
