@@ -58,6 +58,64 @@ template <typename T> void upload(T *dst, const std::vector<T> &src, hipStream_t
 		HIP_CHECK(hipMemcpyAsync(dst, src.data(), src.size() * sizeof(T), hipMemcpyHostToDevice, s));
 }
 
+// ---- signed 16-bit entries with deferred reduction (SGN) -------------------------------------------
+// For small primes an entry of R is a signed 16-bit representative v, |v| <= B = p/2 + p/64 + 1, and a coefficient c
+// is the NEGATED balanced residue, |c| <= p/2.  x - sum c_i v_i then costs ONE v_mad_i32_i16 per term and component
+// (op_sel picks the half of the packed word: nothing to unpack), and up to four terms are added to an entry before it
+// is reduced: 4 B^2 + B < 2^31.  The reduction goes through fp32: q = rint(float(t) / p) is the nearest multiple up to an
+// error of 3 * 2^-24 |t| / p < 1/64 (t < 2^31, p < 2^16), so |t - q p| <= p/2 + p/64: the slack B allows.  Zero is
+// exact (|r| < p), and whoever hands values out brings them into [-p/2, p/2].  p <= 44934 qualifies (42013 does).
+struct SgnDev {
+	int p, negp, half;
+	float invp;
+};
+
+inline bool sgn_eligible(int64_t prime)
+{
+	const int64_t B = prime / 2 + prime / 64 + 1;
+	return prime >= 3 && B <= 32767 && 4 * B * B + B <= 0x7FFFFFFFll;
+}
+
+inline SgnDev sgn_setup(int64_t prime)
+{
+	return SgnDev{(int) prime, -(int) prime, (int) (prime / 2), 1.0f / (float) prime};
+}
+
+__device__ __forceinline__ void sgn_unpack(uint32_t w, int &lo, int &hi)
+{
+	lo = (int) (short) (w & 0xFFFFu);
+	hi = (int) w >> 16;
+}
+
+// lo += low half of w * c, hi += high half of w * c (16-bit signed factors, 32-bit sums)
+__device__ __forceinline__ void sgn_mad(uint32_t w, int c, int &lo, int &hi)
+{
+	asm("v_mad_i32_i16 %0, %1, %2, %0" : "+v"(lo) : "v"(w), "v"(c));
+	asm("v_mad_i32_i16 %0, %1, %2, %0 op_sel:[1,0,0,0]" : "+v"(hi) : "v"(w), "v"(c));
+}
+
+__device__ __forceinline__ int sgn_reduce(int t, const SgnDev &G)
+{
+	const int q = (int) __builtin_rintf((float) t * G.invp);
+	return t + __mul24(q, G.negp);
+}
+
+__device__ __forceinline__ uint32_t sgn_pack(int lo, int hi)
+{
+	return __builtin_amdgcn_perm((uint32_t) hi, (uint32_t) lo, 0x05040100u);       // (lo & 0xFFFF) | (hi << 16)
+}
+
+__device__ __forceinline__ int sgn_canonical(int v, const SgnDev &G)          // into [-p/2, p/2]
+{
+	v = (v > G.half) ? v - G.p : v;
+	return (v < -G.half) ? v + G.p : v;
+}
+
+__device__ __forceinline__ int sgn_from_residue(uint32_t v, const SgnDev &G)   // 0 <= v < p
+{
+	return ((int) v > G.half) ? (int) v - G.p : (int) v;
+}
+
 struct BsArgs {
 	void *R;                      // r x ldR elements of T (uint16_t when p < 2^16, else uint32_t)
 	int64_t ldR;
@@ -77,7 +135,9 @@ struct BsArgs {
 	int sparse_init;              // 1: the kernel scatters U_n itself (few entries); 0: R was pre-filled by bs_init_kernel
 	int r;
 	int dbg;                      // timing experiments only (SPASM_HIP_BS_DEBUG): bit 0/1/2 = skip phase A/B/C (wrong results)
+	int sgn;                      // signed 16-bit entries (the SGN kernels); coefficients are negated balanced residues
 	MontDev F;
+	SgnDev G;
 };
 
 // ---- storage of R ---------------------------------------------------------------------------------
@@ -122,7 +182,7 @@ template <typename T> __global__ __launch_bounds__(256) void bs_init_kernel(BsAr
 	T *row = static_cast<T *>(b.R) + (int64_t) c * b.ldR;
 	for (uint64_t e = b.np_rp[c]; e < b.np_rp[c + 1]; e++) {
 		const uint2 en = b.np[e];
-		row[en.x] = (T) (b.plain ? en.y : montmul(en.y, 1u, b.F));
+		row[en.x] = b.sgn ? (T) (uint16_t) (int16_t) sgn_from_residue(en.y, b.G) : (T) (b.plain ? en.y : montmul(en.y, 1u, b.F));
 	}
 }
 
@@ -135,7 +195,9 @@ template <bool PACKED, int LPR, int NW> struct BsGeom {
 	static constexpr int CW = LPR * Word<PACKED>::CPL;     // columns per slab
 	static constexpr int ROWS_PER_ITER = RS * NW;
 	static constexpr int ITERS = BS_RING / ROWS_PER_ITER;
-	static constexpr int UNR = (ITERS % 12 == 0) ? 12 : 8;  // rows in flight per lane in phase A
+	// rows in flight per lane in phase A.  Eight waves (two per SIMD: 256 registers each) take a whole chunk in ONE pass --
+	// a pass is a round trip to memory, and a chunk has little else to hide it behind
+	static constexpr int UNR = (NW == 8 && ITERS == 24) ? 24 : (ITERS % 12 == 0) ? 12 : 8;
 	static_assert(BS_RING % ROWS_PER_ITER == 0 && ITERS % UNR == 0, "phase A is unrolled in passes of UNR rows");
 	static constexpr int N_NEAR = (BS_NEARCAP + THREADS - 1) / THREADS;      // metadata words a thread carries for the next chunk
 	static constexpr int N_ROW = (BS_RING + THREADS - 1) / THREADS;
@@ -145,15 +207,17 @@ template <bool PACKED, int LPR, int NW> struct BsGeom {
 	                                    (size_t) BS_STEPCAP * sizeof(int2) + (size_t) BS_RING * LPR * 4;
 };
 
-template <bool PACKED, bool PLAIN, int LPR, int NW>
+template <bool PACKED, bool PLAIN, int LPR, int NW, bool SGN = false>
 __global__ __launch_bounds__(64 * NW) void backsolve_kernel(BsArgs b)
 {
+	static_assert(!SGN || (PACKED && PLAIN), "signed entries are packed 16-bit entries");
 	const uint32_t bm = PLAIN ? (uint32_t) (0x100000000ull / b.F.p) : 0u;
-	using G = BsGeom<PACKED, LPR, NW>;
+	const SgnDev G = b.G;
+	using Geo = BsGeom<PACKED, LPR, NW>;
 	using Elem = typename Word<PACKED>::Elem;
 	extern __shared__ __attribute__((aligned(16))) unsigned char bs_lds[];
 	uint4 *fh = reinterpret_cast<uint4 *>(bs_lds);                          // first two outside dependencies of every row
-	uint2 *near = reinterpret_cast<uint2 *>(bs_lds + G::FH_BYTES);
+	uint2 *near = reinterpret_cast<uint2 *>(bs_lds + Geo::FH_BYTES);
 	uint2 *brow = near + BS_NEARCAP;
 	int2 *step = reinterpret_cast<int2 *>(brow + BS_RING);
 	uint32_t *ring = reinterpret_cast<uint32_t *>(step + BS_STEPCAP);
@@ -163,24 +227,24 @@ __global__ __launch_bounds__(64 * NW) void backsolve_kernel(BsArgs b)
 	const MontDev F = b.F;
 	const int64_t ldw = b.ldR / Word<PACKED>::CPL;       // row stride of R in words
 	uint32_t *Rs = static_cast<uint32_t *>(b.R) + (int64_t) blockIdx.x * LPR + wl;
-	const int slot0 = wave * G::RS + rs;          // this lane's row slot within an iteration
-	const int col_lo = blockIdx.x * G::CW;        // columns [col_lo, col_lo + CW) belong to this workgroup
+	const int slot0 = wave * Geo::RS + rs;          // this lane's row slot within an iteration
+	const int col_lo = blockIdx.x * Geo::CW;        // columns [col_lo, col_lo + CW) belong to this workgroup
 
 	// metadata of a chunk (the same for every slab: served by the L2) travels through registers: the loads for chunk
 	// k + 1 are issued when chunk k starts and land in LDS when it is done
-	uint2 m_near[G::N_NEAR], m_brow[G::N_ROW];
-	uint4 m_fh[G::N_ROW];
+	uint2 m_near[Geo::N_NEAR], m_brow[Geo::N_ROW];
+	uint4 m_fh[Geo::N_ROW];
 	int2 m_step;
 	auto load_meta = [&](int k) {
 		const BsChunk c = b.chunk[k];
 #pragma unroll
-		for (int q = 0; q < G::N_NEAR; q++) {
-			const int t = tid + q * G::THREADS;
+		for (int q = 0; q < Geo::N_NEAR; q++) {
+			const int t = tid + q * Geo::THREADS;
 			m_near[q] = (t < c.nnear) ? b.near[c.near0 + t] : uint2{0u, 0u};
 		}
 #pragma unroll
-		for (int q = 0; q < G::N_ROW; q++) {
-			const int t = tid + q * G::THREADS;
+		for (int q = 0; q < Geo::N_ROW; q++) {
+			const int t = tid + q * Geo::THREADS;
 			m_brow[q] = (t < c.nbrow) ? b.brow[c.brow0 + t] : uint2{0u, 0u};
 			m_fh[q] = (t < c.hi - c.lo) ? b.far_head[c.lo + t] : uint4{BS_NONE, 0u, BS_NONE, 0u};
 		}
@@ -188,14 +252,14 @@ __global__ __launch_bounds__(64 * NW) void backsolve_kernel(BsArgs b)
 	};
 	auto store_meta = [&]() {
 #pragma unroll
-		for (int q = 0; q < G::N_NEAR; q++)
-			if (tid + q * G::THREADS < BS_NEARCAP)
-				near[tid + q * G::THREADS] = m_near[q];
+		for (int q = 0; q < Geo::N_NEAR; q++)
+			if (tid + q * Geo::THREADS < BS_NEARCAP)
+				near[tid + q * Geo::THREADS] = m_near[q];
 #pragma unroll
-		for (int q = 0; q < G::N_ROW; q++)
-			if (tid + q * G::THREADS < BS_RING) {
-				brow[tid + q * G::THREADS] = m_brow[q];
-				fh[tid + q * G::THREADS] = m_fh[q];
+		for (int q = 0; q < Geo::N_ROW; q++)
+			if (tid + q * Geo::THREADS < BS_RING) {
+				brow[tid + q * Geo::THREADS] = m_brow[q];
+				fh[tid + q * Geo::THREADS] = m_fh[q];
 			}
 		if (tid < BS_STEPCAP)
 			step[tid] = m_step;
@@ -214,27 +278,28 @@ __global__ __launch_bounds__(64 * NW) void backsolve_kernel(BsArgs b)
 
 		if (b.sparse_init) {
 			// the rows start as U_n: few entries, scattered from the list (R itself is never read for them)
-			for (int t = tid; t < nrows * LPR; t += G::THREADS)
+			for (int t = tid; t < nrows * LPR; t += Geo::THREADS)
 				ring[t] = 0;
 			__syncthreads();
 			const uint64_t e0 = b.np_rp[ch.lo], e1 = b.np_rp[ch.hi];
-			for (uint64_t e = e0 + tid; e < e1; e += G::THREADS) {
+			for (uint64_t e = e0 + tid; e < e1; e += Geo::THREADS) {
 				const uint2 en = b.np[e];
 				const int cc = (int) en.x - col_lo;
-				if (cc >= 0 && cc < G::CW)
-					reinterpret_cast<Elem *>(ring)[(b.np_row[e] - ch.lo) * G::CW + cc] = (Elem) (PLAIN ? en.y : montmul(en.y, 1u, F));
+				if (cc >= 0 && cc < Geo::CW)
+					reinterpret_cast<Elem *>(ring)[(b.np_row[e] - ch.lo) * Geo::CW + cc] =
+						SGN ? (Elem) (uint16_t) (int16_t) sgn_from_residue(en.y, G) : (Elem) (PLAIN ? en.y : montmul(en.y, 1u, F));
 			}
 			__syncthreads();
 		}
 
 		// ---- phase A: own row + dependencies outside the chunk, up to 3 * UNR loads in flight per lane ----
-		for (int pass = 0; pass < G::ITERS / G::UNR; pass++) {
-			if (pass * G::UNR * G::ROWS_PER_ITER >= nrows || (b.dbg & 1))
+		for (int pass = 0; pass < Geo::ITERS / Geo::UNR; pass++) {
+			if (pass * Geo::UNR * Geo::ROWS_PER_ITER >= nrows || (b.dbg & 1))
 				break;
-			uint32_t acc[G::UNR], v0[G::UNR], v1[G::UNR];
+			uint32_t acc[Geo::UNR], v0[Geo::UNR], v1[Geo::UNR];
 #pragma unroll
-			for (int u = 0; u < G::UNR; u++) {
-				const int s = (pass * G::UNR + u) * G::ROWS_PER_ITER + slot0;
+			for (int u = 0; u < Geo::UNR; u++) {
+				const int s = (pass * Geo::UNR + u) * Geo::ROWS_PER_ITER + slot0;
 				const bool ok = s < nrows;
 				const uint4 h = fh[ok ? s : 0];
 				const int c = ch.lo + (ok ? s : 0);
@@ -243,15 +308,26 @@ __global__ __launch_bounds__(64 * NW) void backsolve_kernel(BsArgs b)
 				v1[u] = (ok && h.z != BS_NONE) ? Rs[(int64_t) h.z * ldw] : 0u;
 			}
 #pragma unroll
-			for (int u = 0; u < G::UNR; u++) {
-				const int s = (pass * G::UNR + u) * G::ROWS_PER_ITER + slot0;
+			for (int u = 0; u < Geo::UNR; u++) {
+				const int s = (pass * Geo::UNR + u) * Geo::ROWS_PER_ITER + slot0;
 				if (s < nrows) {
 					const uint4 h = fh[s];
 					uint32_t x = b.sparse_init ? ring[s * LPR + wl] : acc[u];
-					if (h.x != BS_NONE)
-						x = w_submul<PACKED, PLAIN>(x, v0[u], h.y, F, bm);
-					if (h.z != BS_NONE)
-						x = w_submul<PACKED, PLAIN>(x, v1[u], h.w, F, bm);
+					if constexpr (SGN) {
+						// (an absent dependency was loaded as 0: its term vanishes whatever the coefficient slot holds)
+						if (h.x != BS_NONE) {
+							int lo, hi;
+							sgn_unpack(x, lo, hi);
+							sgn_mad(v0[u], (int) h.y, lo, hi);
+							sgn_mad(v1[u], (int) h.w, lo, hi);
+							x = sgn_pack(sgn_reduce(lo, G), sgn_reduce(hi, G));
+						}
+					} else {
+						if (h.x != BS_NONE)
+							x = w_submul<PACKED, PLAIN>(x, v0[u], h.y, F, bm);
+						if (h.z != BS_NONE)
+							x = w_submul<PACKED, PLAIN>(x, v1[u], h.w, F, bm);
+					}
 					ring[s * LPR + wl] = x;
 				}
 			}
@@ -259,15 +335,30 @@ __global__ __launch_bounds__(64 * NW) void backsolve_kernel(BsArgs b)
 		__syncthreads();
 		if (b.chunk_extra[k]) {
 			// rows with more than two outside dependencies (long rows of U): the rest of their lists
-			for (int s = slot0; s < nrows; s += G::ROWS_PER_ITER) {
+			for (int s = slot0; s < nrows; s += Geo::ROWS_PER_ITER) {
 				const int c = ch.lo + s;
 				const uint64_t e0 = b.far_rp[c], e1 = b.far_rp[c + 1];
 				if (e0 == e1)
 					continue;
 				uint32_t x = ring[s * LPR + wl];
-				for (uint64_t e = e0; e < e1; e++) {
-					const uint2 en = b.far[e];
-					x = w_submul<PACKED, PLAIN>(x, Rs[(int64_t) en.x * ldw], en.y, F, bm);
+				if constexpr (SGN) {
+					int lo, hi;
+					sgn_unpack(x, lo, hi);
+					for (uint64_t e = e0; e < e1; e += 4) {          // four terms per reduction
+#pragma unroll
+						for (int t = 0; t < 4; t++) {
+							const uint2 en = (e + t < e1) ? b.far[e + t] : uint2{0u, 0u};
+							sgn_mad((e + t < e1) ? Rs[(int64_t) en.x * ldw] : 0u, (int) en.y, lo, hi);
+						}
+						lo = sgn_reduce(lo, G);
+						hi = sgn_reduce(hi, G);
+					}
+					x = sgn_pack(lo, hi);
+				} else {
+					for (uint64_t e = e0; e < e1; e++) {
+						const uint2 en = b.far[e];
+						x = w_submul<PACKED, PLAIN>(x, Rs[(int64_t) en.x * ldw], en.y, F, bm);
+					}
 				}
 				ring[s * LPR + wl] = x;
 			}
@@ -297,21 +388,78 @@ __global__ __launch_bounds__(64 * NW) void backsolve_kernel(BsArgs b)
 				const uint2 B2 = rd_brow(S2);
 				const int2 S3 = rd_step(st + 3);
 				if (cnt != 0) {
-					x = w_submul<PACKED, PLAIN>(x, v, D0.y, F, bm);
-					for (int j = 1; j < cnt; j++) {
-						const uint2 en = near[B0.y + j];
-						x = w_submul<PACKED, PLAIN>(x, ring[en.x * LPR + wl], en.y, F, bm);
+					if constexpr (SGN) {
+						// one reduction per four dependencies: their list entries are read together, then their rows
+						int lo, hi;
+						sgn_unpack(x, lo, hi);
+						sgn_mad(v, (int) D0.y, lo, hi);
+						if (cnt > 1) {
+							uint2 en[3];
+							uint32_t w[3];
+#pragma unroll
+							for (int t = 0; t < 3; t++)
+								en[t] = (1 + t < cnt) ? near[B0.y + 1 + t] : uint2{D0.x, 0u};
+#pragma unroll
+							for (int t = 0; t < 3; t++)
+								w[t] = ring[en[t].x * LPR + wl];
+#pragma unroll
+							for (int t = 0; t < 3; t++)
+								sgn_mad(w[t], (int) en[t].y, lo, hi);
+							for (int j = 4; j < cnt; j += 4) {
+								lo = sgn_reduce(lo, G);
+								hi = sgn_reduce(hi, G);
+								uint2 em[4];
+								uint32_t wm[4];
+#pragma unroll
+								for (int t = 0; t < 4; t++)
+									em[t] = (j + t < cnt) ? near[B0.y + j + t] : uint2{D0.x, 0u};
+#pragma unroll
+								for (int t = 0; t < 4; t++)
+									wm[t] = ring[em[t].x * LPR + wl];
+#pragma unroll
+								for (int t = 0; t < 4; t++)
+									sgn_mad(wm[t], (int) em[t].y, lo, hi);
+							}
+						}
+						x = sgn_pack(sgn_reduce(lo, G), sgn_reduce(hi, G));
+					} else {
+						x = w_submul<PACKED, PLAIN>(x, v, D0.y, F, bm);
+						for (int j = 1; j < cnt; j++) {
+							const uint2 en = near[B0.y + j];
+							x = w_submul<PACKED, PLAIN>(x, ring[en.x * LPR + wl], en.y, F, bm);
+						}
 					}
 					ring[slot * LPR + wl] = x;
 				}
 				// levels wider than one pass of the workgroup
-				for (int q = S0.x + slot0 + G::ROWS_PER_ITER; q < S0.y; q += G::ROWS_PER_ITER) {
+				for (int q = S0.x + slot0 + Geo::ROWS_PER_ITER; q < S0.y; q += Geo::ROWS_PER_ITER) {
 					const uint2 bq = brow[q];
 					const int sq = (int) (bq.x & 0xFFFFu), cq = (int) (bq.x >> 16);
 					uint32_t y = ring[sq * LPR + wl];
-					for (int j = 0; j < cq; j++) {
-						const uint2 en = near[bq.y + j];
-						y = w_submul<PACKED, PLAIN>(y, ring[en.x * LPR + wl], en.y, F, bm);
+					if constexpr (SGN) {
+						int lo, hi;
+						sgn_unpack(y, lo, hi);
+						for (int j = 0; j < cq; j += 4) {
+							uint2 em[4];
+							uint32_t wm[4];
+#pragma unroll
+							for (int t = 0; t < 4; t++)
+								em[t] = (j + t < cq) ? near[bq.y + j + t] : uint2{(uint32_t) sq, 0u};
+#pragma unroll
+							for (int t = 0; t < 4; t++)
+								wm[t] = ring[em[t].x * LPR + wl];
+#pragma unroll
+							for (int t = 0; t < 4; t++)
+								sgn_mad(wm[t], (int) em[t].y, lo, hi);
+							lo = sgn_reduce(lo, G);
+							hi = sgn_reduce(hi, G);
+						}
+						y = sgn_pack(lo, hi);
+					} else {
+						for (int j = 0; j < cq; j++) {
+							const uint2 en = near[bq.y + j];
+							y = w_submul<PACKED, PLAIN>(y, ring[en.x * LPR + wl], en.y, F, bm);
+						}
 					}
 					ring[sq * LPR + wl] = y;
 				}
@@ -326,7 +474,7 @@ __global__ __launch_bounds__(64 * NW) void backsolve_kernel(BsArgs b)
 		}
 
 		// ---- phase C: write the chunk back ----
-		for (int s = slot0; s < ((b.dbg & 4) ? 0 : nrows); s += G::ROWS_PER_ITER)
+		for (int s = slot0; s < ((b.dbg & 4) ? 0 : nrows); s += Geo::ROWS_PER_ITER)
 			Rs[(int64_t) (ch.lo + s) * ldw] = ring[s * LPR + wl];
 		__syncthreads();          // (workgroup-scope release/acquire: later chunks read these rows; LDS metadata is free)
 		if (k + 1 < b.nchunks)
@@ -357,15 +505,105 @@ struct ApplyArgs {
 	// publishes its length and finds its offset by looking back over the rows before it (single-pass chained scan)
 	int direct;
 	unsigned long long *status;   // per row: flag << 62 | value; flag 1: value = length of the row, 2: = offset past the row
-	int *ticket;
+	int *ticket;                  // LB_TICKETS counters, LB_TICKET_STRIDE ints apart, zeroed before the launch
+	int ntickets;                 // counters in use (<= LB_TICKETS, <= workgroups)
 	int64_t *Sp;
 	int *Sj;
 	int *Sx;
 	int64_t cap;
+	int dbg;                      // timing experiments only (SPASM_HIP_BS_DEBUG): bit 3 = no loads of R, 4 = no look-back, 5 = no output stores
+	int sgn;                      // R holds signed 16-bit entries (SgnDev)
+	SgnDev G;
+	unsigned long long *block_sum; // staged output: sum of the lengths of every block of SCAN_BLOCK rows (zeroed before the launch)
+	uint32_t *stage;              // staged output (bs_apply_s16_kernel): the packed row of S, Smpad / 2 words per row, and its
+	                              // number of entries in a.row_len; bs_expand_s16_kernel writes the sparse rows afterwards
 };
 
 constexpr unsigned long long LB_FLAG_LEN = 1ull << 62, LB_FLAG_END = 2ull << 62, LB_VALUE = (1ull << 62) - 1;
 constexpr int LB_PER_LANE = 1;             // predecessors inspected per lane and poll (64 per wave: 8 -> 4.23, 4 -> 3.93, 2 -> 3.69, 1 -> 3.50 ms)
+
+
+// Rows are handed out in (nearly) increasing order, each to a wave that starts it at once: whoever waits for a row in the
+// look-back below knows a running wave holds it.  One counter would serve every wave of the chip -- returning atomics on
+// one address are served one after the other at the memory side, and a wave waited ~20 us for its row (0.9 ms of a
+// 3.5 ms kernel on mk13.b5).  LB_TICKETS counters on separate cache lines each hand out the rows of one residue class;
+// the classes advance at the same pace (every class is served by workgroups spread over the whole chip).
+constexpr int LB_TICKETS = 16, LB_TICKET_STRIDE = 32;          // (ints: one 128-byte line per counter)
+
+__device__ __forceinline__ int next_ticket(const ApplyArgs &d, int lane)
+{
+	const int c = (int) (blockIdx.x % (unsigned) d.ntickets);
+	int t = 0;
+	if (lane == 0)
+		t = atomicAdd(d.ticket + c * LB_TICKET_STRIDE, 1);
+	t = __builtin_amdgcn_readfirstlane(t);
+	const long long k = (long long) t * d.ntickets + c;
+	return (k < (long long) d.a.nrows) ? (int) k : d.a.nrows;
+}
+
+// Ordered output without a second pass (single-pass chained scan): row k publishes its length, adds up the lengths of
+// the rows before it, back to the nearest row that already knows where it ends, and publishes its own end.  Rows are
+// handed out by next_ticket().  Returns the offset of row k.
+__device__ __forceinline__ unsigned long long lookback_offset(const ApplyArgs &d, int k, int count, int lane, bool &lost)
+{
+	if (lane == 0)
+		__hip_atomic_store(&d.status[k], LB_FLAG_LEN | (unsigned long long) count, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+	unsigned long long prior = 0;
+	long long polls = 0;
+	if (d.dbg & 16)
+		prior = (unsigned long long) k * 3600ull;
+	for (int j = (d.dbg & 16) ? -1 : k - 1; j >= 0;) {
+		unsigned long long val[LB_PER_LANE];
+#pragma unroll
+		for (int u = 0; u < LB_PER_LANE; u++) {
+			const int idx = j - (u * 64 + lane);
+			val[u] = (idx >= 0) ? __hip_atomic_load(&d.status[idx], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : LB_FLAG_END;
+		}
+		// position (in look-back order) of the nearest row that knows its end; every row nearer must have a length
+		int first_end = 64 * LB_PER_LANE;
+		bool hole = false;
+		unsigned long long sum = 0;
+#pragma unroll
+		for (int u = LB_PER_LANE - 1; u >= 0; u--) {
+			const uint64_t m_end = __ballot((val[u] >> 62) == 2);
+			if (m_end != 0)
+				first_end = u * 64 + __builtin_ctzll(m_end);
+		}
+#pragma unroll
+		for (int u = 0; u < LB_PER_LANE; u++) {
+			const int pos = u * 64 + lane;
+			const bool counts = pos <= first_end;
+			hole = hole || (counts && (val[u] >> 62) == 0);
+			sum += counts ? (val[u] & LB_VALUE) : 0ull;
+		}
+		if (__ballot(hole) != 0) {          // a row in between has not published its length yet: look again
+			if (++polls > (1ll << 24)) {
+				lost = true;
+				break;
+			}
+			__builtin_amdgcn_s_sleep(2);
+			continue;
+		}
+		// wave-wide sum (64-bit, two halves through DPP-free shuffles)
+		for (int sft = 32; sft >= 1; sft >>= 1) {
+			const uint32_t lo32 = (uint32_t) __shfl_xor((int) (uint32_t) sum, sft);
+			const uint32_t hi32 = (uint32_t) __shfl_xor((int) (uint32_t) (sum >> 32), sft);
+			sum += ((unsigned long long) hi32 << 32) | lo32;
+		}
+		prior += sum;
+		if (first_end < 64 * LB_PER_LANE)
+			break;
+		j -= 64 * LB_PER_LANE;
+	}
+	if (lane == 0) {
+		__hip_atomic_store(&d.status[k], LB_FLAG_END | ((prior + (unsigned long long) count) & LB_VALUE), __ATOMIC_RELAXED,
+		                   __HIP_MEMORY_SCOPE_AGENT);
+		d.Sp[k] = (int64_t) prior;
+		if (k == d.a.nrows - 1)
+			d.Sp[d.a.nrows] = (int64_t) (prior + (unsigned long long) count);
+	}
+	return prior;
+}
 
 template <bool PACKED, bool PLAIN> __global__ __launch_bounds__(512) void bs_apply_kernel(ApplyArgs d)
 {
@@ -387,12 +625,8 @@ template <bool PACKED, bool PLAIN> __global__ __launch_bounds__(512) void bs_app
 	int st_done = 0;
 
 	for (int k = blockIdx.x * d.waves + wave;; k += gridDim.x * d.waves) {
-		if (d.direct) {                      // rows in ticket order: whoever waits for a row knows a running wave holds it
-			int t = 0;
-			if (lane == 0)
-				t = atomicAdd(d.ticket, 1);
-			k = __builtin_amdgcn_readfirstlane(t);
-		}
+		if (d.direct)
+			k = next_ticket(d, lane);
 		if (k >= a.nrows)
 			break;
 		const int i = a.rows[k];
@@ -442,7 +676,7 @@ template <bool PACKED, bool PLAIN> __global__ __launch_bounds__(512) void bs_app
 							const uint32_t *rq = R + (int64_t) pe[q].x * ldw + t0 + lane;
 #pragma unroll
 							for (int u = 0; u < AP_TU; u++)
-								w[q][u] = (e + q < npl && t0 + u * 64 < nwords) ? rq[u * 64] : 0u;
+								w[q][u] = (d.dbg & 8) ? (uint32_t) (lane + u) : (e + q < npl && t0 + u * 64 < nwords) ? rq[u * 64] : 0u;
 						}
 #pragma unroll
 						for (int q = 0; q < 4; q++)
@@ -484,65 +718,10 @@ template <bool PACKED, bool PLAIN> __global__ __launch_bounds__(512) void bs_app
 		int *out_j = a.pool_j, *out_x = a.pool_x;
 		bool fits;
 		if (d.direct) {
-			// publish the length, then add up the lengths of the rows before this one, back to the nearest row that
-			// already knows where it ends
-			if (lane == 0)
-				__hip_atomic_store(&d.status[k], LB_FLAG_LEN | (unsigned long long) count, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-			unsigned long long prior = 0;
 			bool lost = false;
-			long long polls = 0;
-			for (int j = k - 1; j >= 0;) {
-				unsigned long long val[LB_PER_LANE];
-#pragma unroll
-				for (int u = 0; u < LB_PER_LANE; u++) {
-					const int idx = j - (u * 64 + lane);
-					val[u] = (idx >= 0) ? __hip_atomic_load(&d.status[idx], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : LB_FLAG_END;
-				}
-				// position (in look-back order) of the nearest row that knows its end; every row nearer must have a length
-				int first_end = 64 * LB_PER_LANE;
-				bool hole = false;
-				unsigned long long sum = 0;
-#pragma unroll
-				for (int u = LB_PER_LANE - 1; u >= 0; u--) {
-					const uint64_t m_end = __ballot((val[u] >> 62) == 2);
-					if (m_end != 0)
-						first_end = u * 64 + __builtin_ctzll(m_end);
-				}
-#pragma unroll
-				for (int u = 0; u < LB_PER_LANE; u++) {
-					const int pos = u * 64 + lane;
-					const bool counts = pos <= first_end;
-					hole = hole || (counts && (val[u] >> 62) == 0);
-					sum += counts ? (val[u] & LB_VALUE) : 0ull;
-				}
-				if (__ballot(hole) != 0) {          // a row in between has not published its length yet: look again
-					if (++polls > (1ll << 24)) {
-						lost = true;
-						break;
-					}
-					__builtin_amdgcn_s_sleep(2);
-					continue;
-				}
-				// wave-wide sum (64-bit, two halves through DPP-free shuffles)
-				for (int sft = 32; sft >= 1; sft >>= 1) {
-					const uint32_t lo32 = (uint32_t) __shfl_xor((int) (uint32_t) sum, sft);
-					const uint32_t hi32 = (uint32_t) __shfl_xor((int) (uint32_t) (sum >> 32), sft);
-					sum += ((unsigned long long) hi32 << 32) | lo32;
-				}
-				prior += sum;
-				if (first_end < 64 * LB_PER_LANE)
-					break;
-				j -= 64 * LB_PER_LANE;
-			}
-			if (lane == 0) {
-				__hip_atomic_store(&d.status[k], LB_FLAG_END | ((prior + (unsigned long long) count) & LB_VALUE), __ATOMIC_RELAXED,
-				                   __HIP_MEMORY_SCOPE_AGENT);
-				d.Sp[k] = (int64_t) prior;
-				if (k == a.nrows - 1)
-					d.Sp[a.nrows] = (int64_t) (prior + (unsigned long long) count);
-				if (lost)
-					atomicOr(&a.ctr[CTR_STATUS], 4);
-			}
+			const unsigned long long prior = lookback_offset(d, k, count, lane, lost);
+			if (lane == 0 && lost)
+				atomicOr(&a.ctr[CTR_STATUS], 4);
 			off = (int64_t) prior;
 			out_j = d.Sj;
 			out_x = d.Sx;
@@ -556,7 +735,7 @@ template <bool PACKED, bool PLAIN> __global__ __launch_bounds__(512) void bs_app
 			off = (int64_t) (((uint64_t) g_hi << 32) | g_lo);
 			fits = off + count <= a.pool_cap;
 		}
-		if (fits) {
+		if (fits && !(d.dbg & 32)) {
 			int64_t wpos = off;
 			const uint64_t below = (1ull << lane) - 1ull;
 			for (int t0 = 0; t0 < nwords; t0 += 64) {
@@ -605,6 +784,366 @@ template <bool PACKED, bool PLAIN> __global__ __launch_bounds__(512) void bs_app
 		atomicAdd(&a.ctr64[C64_INPUT], st_input);
 		atomicAdd(&a.ctr64[C64_ELIM], st_piv);          // rows of R combined (not the reference's count of eliminations)
 		atomicAdd(&a.ctr[a.done_ctr], st_done);
+	}
+}
+
+// The same with signed 16-bit entries (SgnDev):
+//   * one v_mad_i32_i16 per term and component, one reduction per four rows of R;
+//   * the rows of R of the next tile group are in flight while the current one is multiplied;
+//   * the entries are counted while the last batch is applied (no separate pass over the row), the output loop works on
+//     32-bit offsets from a uniform base.
+__global__ __launch_bounds__(512) void bs_apply_s16_kernel(ApplyArgs d)
+{
+	extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
+	const SchurArgs &a = d.a;
+	const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+	const MontDev F = a.F;
+	const SgnDev G = d.G;
+	const int Sm = a.Sm;
+	const int nwords = d.Smpad / 2;                       // a multiple of 64 * AP_TU
+	uint2 *plist = reinterpret_cast<uint2 *>(lds_raw + (size_t) wave * d.wave_bytes);
+	uint32_t *xw = reinterpret_cast<uint32_t *>(plist + AP_LIST);
+	short *xe = reinterpret_cast<short *>(xw);
+	const uint32_t *R = static_cast<const uint32_t *>(d.R);
+	const int64_t ldw = d.ldR / 2;
+	const int2 *q2 = reinterpret_cast<const int2 *>(a.q);          // (the array is padded to whole tile groups)
+	unsigned long long st_input = 0, st_piv = 0;
+	int st_done = 0;
+
+	for (int k = blockIdx.x * d.waves + wave;; k += gridDim.x * d.waves) {
+		if (d.direct) {
+			k = next_ticket(d, lane);
+		}
+		if (k >= a.nrows)
+			break;
+		const int i = a.rows[k];
+		const int64_t lo = a.Ap[i], hi = a.Ap[i + 1];
+		st_input += (unsigned long long) (hi - lo);
+		for (int t = lane; t < nwords; t += 64)
+			xw[t] = 0;
+		int npl = 0;                         // entries waiting in plist (wave-uniform)
+		int count = -1;                      // entries of the finished row, once known
+		for (int64_t base = lo;; base += 64) {
+			bool piv = false;
+			uint32_t cid = 0;
+			int bal = 0;
+			if (base + lane < hi) {
+				cid = (uint32_t) d.col[a.Aj[base + lane]];
+				bal = sgn_from_residue(reduce_sum(from_balanced(a.Ax[base + lane], F), F), G);
+				if (cid >= (uint32_t) d.r) {
+					const uint32_t t = cid - (uint32_t) d.r;
+					xe[t] = (short) sgn_canonical((int) xe[t] + bal, G);
+				} else {
+					piv = bal != 0;
+				}
+			}
+			const uint64_t mk = __ballot(piv);
+			if (piv)
+				plist[npl + __popcll(mk & ((1ull << lane) - 1ull))] = uint2{cid, (uint32_t) (-bal)};
+			npl += __popcll(mk);
+			st_piv += (unsigned long long) __popcll(mk);
+			const bool last = base + 64 >= hi;
+			if (npl > 0 && (last || npl + 64 > AP_LIST)) {
+				// apply the queued pivotal entries: x[tile group] += sum_e (-a_e) R[e][tile group], four rows of R at a
+				// time.  A unit = (tile group, four entries of the list); the loads of unit u + 1 are issued before unit
+				// u is multiplied.
+				const int ne = (npl + 3) >> 2;
+				const int nunits = (nwords / (64 * AP_TU)) * ne;
+				int cnt = 0;
+				int alo[AP_TU], ahi[AP_TU];
+				uint32_t wa[4][AP_TU], wb[4][AP_TU];
+				int ca[4], cb[4];
+				int pf_t0 = 0, pf_e = 0;                 // unit the next issue() will load
+				// (no branch in here: the wait counts of the multiplications are static, and a path that skips an issue
+				//  would force them all to the count of that path.  Past the last unit the last tile group is read again.)
+				const int t0_last = nwords - 64 * AP_TU;
+				const int64_t row_mask = (d.dbg & 8) ? 0 : -1;
+				auto issue = [&](uint32_t (&w)[4][AP_TU], int (&cf)[4]) {
+					const int t0c = (pf_t0 < t0_last) ? pf_t0 : t0_last;
+#pragma unroll
+					for (int q = 0; q < 4; q++) {
+						const int idx = (pf_e + q < npl) ? pf_e + q : npl - 1;
+						const uint2 pe = plist[idx];
+						cf[q] = (pf_e + q < npl) ? (int) pe.y : 0;          // (coefficient 0: no effect)
+						const uint32_t *rq = R + ((int64_t) pe.x & row_mask) * ldw + t0c + lane;
+#pragma unroll
+						for (int u = 0; u < AP_TU; u++)
+							w[q][u] = rq[u * 64];          // (rows are padded to whole tile groups)
+					}
+					pf_e += 4;
+					const bool wrap = pf_e >= npl;
+					pf_e = wrap ? 0 : pf_e;
+					pf_t0 += wrap ? 64 * AP_TU : 0;
+				};
+				int t0 = 0, e = 0;                       // unit being multiplied
+				auto multiply = [&](const uint32_t (&w)[4][AP_TU], const int (&cf)[4]) {
+					if (e == 0) {
+#pragma unroll
+						for (int u = 0; u < AP_TU; u++)
+							sgn_unpack(xw[t0 + u * 64 + lane], alo[u], ahi[u]);
+					} else {                 // four terms were added already
+#pragma unroll
+						for (int u = 0; u < AP_TU; u++) {
+							alo[u] = sgn_reduce(alo[u], G);
+							ahi[u] = sgn_reduce(ahi[u], G);
+						}
+					}
+#pragma unroll
+					for (int q = 0; q < 4; q++)
+#pragma unroll
+						for (int u = 0; u < AP_TU; u++)
+							sgn_mad(w[q][u], cf[q], alo[u], ahi[u]);
+					e += 4;
+					if (e >= npl) {
+#pragma unroll
+						for (int u = 0; u < AP_TU; u++) {
+							const int rl = sgn_reduce(alo[u], G), rh = sgn_reduce(ahi[u], G);
+							xw[t0 + u * 64 + lane] = sgn_pack(rl, rh);
+							cnt += __popcll(__ballot(rl != 0)) + __popcll(__ballot(rh != 0));
+						}
+						e = 0;
+						t0 += 64 * AP_TU;
+					}
+				};
+				issue(wa, ca);
+				for (int u = 0; u < nunits; u += 2) {
+					issue(wb, cb);
+					multiply(wa, ca);
+					issue(wa, ca);
+					if (u + 1 < nunits)
+						multiply(wb, cb);
+				}
+				if (last)
+					count = cnt;
+				npl = 0;
+			}
+			if (last)
+				break;
+		}
+
+		// ---- output ----
+		if (d.dense_out != nullptr) {
+			uint32_t *out = d.dense_out + (int64_t) k * d.ldS;
+			for (int t = lane; t < Sm; t += 64) {
+				const int v = (int) xe[t];
+				out[t] = (uint32_t) (v < 0 ? v + G.p : v);
+			}
+			if (lane == 0)
+				a.row_len[k] = Sm;
+			st_done += 1;
+			continue;
+		}
+		if (count < 0) {                     // no pivotal entry in the last batch: the row was not swept
+			count = 0;
+			for (int t0 = 0; t0 < nwords; t0 += 64) {
+				const uint32_t w = xw[t0 + lane];
+				count += __popcll(__ballot((w & 0xFFFFu) != 0)) + __popcll(__ballot((w >> 16) != 0));
+			}
+		}
+		if (d.stage != nullptr) {
+			uint32_t *out = d.stage + (int64_t) k * nwords;
+			for (int t = lane; t < nwords; t += 64)
+				out[t] = xw[t];
+			if (lane == 0) {
+				a.row_len[k] = count;
+				atomicAdd(&d.block_sum[k / 1024], (unsigned long long) count);          // (SCAN_BLOCK rows per block)
+			}
+			st_done += 1;
+			continue;
+		}
+		int64_t off = 0;
+		int *out_j = a.pool_j, *out_x = a.pool_x;
+		bool fits;
+		if (d.direct) {
+			bool lost = false;
+			const unsigned long long prior = lookback_offset(d, k, count, lane, lost);
+			if (lane == 0 && lost)
+				atomicOr(&a.ctr[CTR_STATUS], 4);
+			off = (int64_t) prior;
+			out_j = d.Sj;
+			out_x = d.Sx;
+			fits = !lost && off + count <= d.cap;
+		} else {
+			unsigned long long got = 0;
+			if (lane == 0)
+				got = atomicAdd(&a.ctr64[C64_POOL], (unsigned long long) count);
+			const uint32_t g_lo = __builtin_amdgcn_readfirstlane((uint32_t) got);
+			const uint32_t g_hi = __builtin_amdgcn_readfirstlane((uint32_t) (got >> 32));
+			off = (int64_t) (((uint64_t) g_hi << 32) | g_lo);
+			fits = off + count <= a.pool_cap;
+		}
+		if (fits && !(d.dbg & 32)) {
+			// lane l of a tile holds columns 2 (t0 + l) and 2 (t0 + l) + 1: entries come out sorted by column
+			int *oj = out_j + off, *ox = out_x + off;
+			uint32_t wpos = 0;
+			for (int t0 = 0; t0 < nwords; t0 += 64) {
+				int v0, v1;
+				sgn_unpack(xw[t0 + lane], v0, v1);
+				v0 = sgn_canonical(v0, G);
+				v1 = sgn_canonical(v1, G);
+				const uint64_t m0 = __ballot(v0 != 0), m1 = __ballot(v1 != 0);
+				const int2 qq = q2[t0 + lane];
+				uint32_t dst = wpos;
+				dst = __builtin_amdgcn_mbcnt_hi((uint32_t) (m0 >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t) m0, dst));
+				dst = __builtin_amdgcn_mbcnt_hi((uint32_t) (m1 >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t) m1, dst));
+				if (v0 != 0) {
+					oj[dst] = qq.x;
+					ox[dst] = v0;
+					dst += 1;
+				}
+				if (v1 != 0) {
+					oj[dst] = qq.y;
+					ox[dst] = v1;
+				}
+				wpos += (uint32_t) (__popcll(m0) + __popcll(m1));
+			}
+		}
+		if (lane == 0) {
+			if (fits) {
+				if (!d.direct) {
+					a.row_off[k] = off | (1LL << 62);       // sorted by column already
+					a.row_len[k] = count;
+				}
+			} else {
+				atomicOr(&a.ctr[CTR_STATUS], 1);
+				if (!d.direct)
+					a.row_len[k] = -1;
+			}
+		}
+		st_done += fits ? 1 : 0;
+	}
+	if (lane == 0) {
+		atomicAdd(&a.ctr64[C64_INPUT], st_input);
+		atomicAdd(&a.ctr64[C64_ELIM], st_piv);
+		atomicAdd(&a.ctr[a.done_ctr], st_done);
+	}
+}
+
+// ---- staged sparse output (signed 16-bit entries) --------------------------------------------------
+// Writing the rows of S in order from ONE kernel makes every row wait for the lengths of the rows before it -- with
+// 3584 rows in flight a row waits for the slowest of its several hundred running predecessors, a third of its own time
+// on mk13.b5 -- and the waiting rows keep their LDS.  Two kernels instead: bs_apply_s16_kernel leaves the packed row
+// (2 bytes per column) and its length, one small scan turns lengths into offsets, bs_expand_s16_kernel streams the
+// packed rows out as (column, value) pairs.  Nobody waits for anybody; the price is one write and one read of the
+// packed rows (a third of the bytes of the result).
+// offsets from lengths.  The apply kernel has added every length to the sum of its block of SCAN_BLOCK rows
+// (block_sum); workgroup g adds up the sums of the blocks before it and scans its own block.
+constexpr int SCAN_BLOCK = 1024;
+
+__global__ __launch_bounds__(SCAN_BLOCK) void bs_scan_lengths_kernel(const int *len, int n, const unsigned long long *block_sum, int64_t *Sp, int64_t cap,
+                                                                      int *ctr)
+{
+	__shared__ long long part[SCAN_BLOCK / 64];
+	__shared__ long long s_base;
+	const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+	const int g = blockIdx.x;
+	auto wave_sum = [](long long v) -> long long {
+		for (int sft = 32; sft >= 1; sft >>= 1) {
+			const uint32_t lo32 = (uint32_t) __shfl_xor((int) (uint32_t) v, sft);
+			const uint32_t hi32 = (uint32_t) __shfl_xor((int) (uint32_t) ((unsigned long long) v >> 32), sft);
+			v += (long long) (((unsigned long long) hi32 << 32) | lo32);
+		}
+		return v;
+	};
+	// blocks before this one
+	long long before = 0;
+	for (int b = tid; b < g; b += SCAN_BLOCK)
+		before += (long long) block_sum[b];
+	before = wave_sum(before);
+	if (lane == 0)
+		part[wave] = before;
+	__syncthreads();
+	if (tid == 0) {
+		long long t = Sp[0];                 // (where this slice of rows starts)
+		for (int w = 0; w < SCAN_BLOCK / 64; w++)
+			t += part[w];
+		s_base = t;
+	}
+	__syncthreads();
+	const long long base = s_base;
+	__syncthreads();
+	// inclusive scan of the block: inside a wave, then over the waves
+	const int k = g * SCAN_BLOCK + tid;
+	const long long mine = (k < n) ? (long long) len[k] : 0;
+	long long incl = mine;
+	for (int sft = 1; sft < 64; sft <<= 1) {
+		const uint32_t lo32 = (uint32_t) __shfl_up((int) (uint32_t) incl, sft);
+		const uint32_t hi32 = (uint32_t) __shfl_up((int) (uint32_t) ((unsigned long long) incl >> 32), sft);
+		if (lane >= sft)
+			incl += (long long) (((unsigned long long) hi32 << 32) | lo32);
+	}
+	if (lane == 63)
+		part[wave] = incl;
+	__syncthreads();
+	long long waves_before = 0;
+	for (int w = 0; w < wave; w++)
+		waves_before += part[w];
+	const long long end = base + waves_before + incl;
+	if (k < n) {
+		Sp[k + 1] = end;
+		if (k == n - 1 && end > cap)
+			atomicOr(&ctr[CTR_STATUS], 1);
+	}
+}
+
+struct ExpandArgs {
+	const uint32_t *stage;
+	int nwords, nrows;
+	const int64_t *Sp;
+	int *Sj, *Sx;
+	int64_t cap;
+	const int *q;
+	SgnDev G;
+};
+
+__global__ __launch_bounds__(256) void bs_expand_s16_kernel(ExpandArgs e)
+{
+	constexpr int TU = 4;                // tiles per trip (rows are padded to whole groups of four tiles): four loads in flight per lane
+	const int lane = threadIdx.x & 63;
+	const int wave = (int) ((blockIdx.x * blockDim.x + threadIdx.x) >> 6), nwaves = (int) ((gridDim.x * blockDim.x) >> 6);
+	const int2 *q2 = reinterpret_cast<const int2 *>(e.q);
+	const SgnDev G = e.G;
+	for (int k = wave; k < e.nrows; k += nwaves) {
+		const int64_t off = e.Sp[k], end = e.Sp[k + 1];
+		if (end > e.cap || end == off)
+			continue;                    // (the scan has raised the overflow flag) / empty row
+		const uint32_t *row = e.stage + (int64_t) k * e.nwords + lane;
+		int *oj = e.Sj + off, *ox = e.Sx + off;
+		uint32_t wpos = 0;
+		// lane l of a tile holds columns 2 (t0 + l) and 2 (t0 + l) + 1: entries come out sorted by column
+		for (int t0 = 0; t0 < e.nwords; t0 += 64 * TU) {
+			uint32_t w[TU];
+			int2 qq[TU];
+#pragma unroll
+			for (int u = 0; u < TU; u++)
+				w[u] = __builtin_nontemporal_load(row + t0 + 64 * u);
+#pragma unroll
+			for (int u = 0; u < TU; u++)
+				qq[u] = q2[t0 + 64 * u + lane];
+#pragma unroll
+			for (int u = 0; u < TU; u++) {
+				int v0, v1;
+				sgn_unpack(w[u], v0, v1);
+				v0 = sgn_canonical(v0, G);
+				v1 = sgn_canonical(v1, G);
+				const uint64_t m0 = __ballot(v0 != 0), m1 = __ballot(v1 != 0);
+				uint32_t dst = wpos;
+				dst = __builtin_amdgcn_mbcnt_hi((uint32_t) (m0 >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t) m0, dst));
+				dst = __builtin_amdgcn_mbcnt_hi((uint32_t) (m1 >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t) m1, dst));
+				// (plain stores: the two halves of a line come from different instructions and meet in the L2 -- non-temporal
+				//  stores of this pattern ran at half the speed)
+				if (v0 != 0) {
+					oj[dst] = qq[u].x;
+					ox[dst] = v0;
+					dst += 1;
+				}
+				if (v1 != 0) {
+					oj[dst] = qq[u].y;
+					ox[dst] = v1;
+				}
+				wpos += (uint32_t) (__popcll(m0) + __popcll(m1));
+			}
+		}
 	}
 }
 
@@ -682,9 +1221,22 @@ template <bool PACKED, bool PLAIN> __global__ __launch_bounds__(64 * AW_NW) void
 			const uint32_t c0 = (uint32_t) __shfl((int) cid, s0), y0 = (uint32_t) __shfl((int) ay, s0);
 			const uint32_t *r0 = R + (int64_t) c0 * ldw + w0 + lane;
 			uint32_t x0[AP_TU], x1[AP_TU];
+			// (signed 16-bit entries are brought back to residues: this kernel runs for a handful of rows)
+			auto residues = [&](uint32_t w) -> uint32_t {
+				if constexpr (PACKED) {
+					if (d.sgn) {
+						int l, h;
+						sgn_unpack(w, l, h);
+						l = (l < 0) ? l + d.G.p : l;
+						h = (h < 0) ? h + d.G.p : h;
+						return (uint32_t) l | ((uint32_t) h << 16);
+					}
+				}
+				return w;
+			};
 #pragma unroll
 			for (int u = 0; u < AP_TU; u++)
-				x0[u] = (w0 + u * 64 < nwords) ? r0[u * 64] : 0u;
+				x0[u] = (w0 + u * 64 < nwords) ? residues(r0[u * 64]) : 0u;
 			uint32_t y1 = 0;
 			if (s1 >= 0) {
 				const uint32_t c1 = (uint32_t) __shfl((int) cid, s1);
@@ -692,7 +1244,7 @@ template <bool PACKED, bool PLAIN> __global__ __launch_bounds__(64 * AW_NW) void
 				const uint32_t *r1 = R + (int64_t) c1 * ldw + w0 + lane;
 #pragma unroll
 				for (int u = 0; u < AP_TU; u++)
-					x1[u] = (w0 + u * 64 < nwords) ? r1[u * 64] : 0u;
+					x1[u] = (w0 + u * 64 < nwords) ? residues(r1[u * 64]) : 0u;
 			}
 #pragma unroll
 			for (int u = 0; u < AP_TU; u++) {
@@ -744,16 +1296,16 @@ template <bool PACKED, bool PLAIN> __global__ __launch_bounds__(64 * AW_NW) void
 	}
 }
 
-template <bool PACKED, bool PLAIN, int LPR, int NW> void launch_backsolve_variant(const BsArgs &b, int Sm, hipStream_t stream)
+template <bool PACKED, bool PLAIN, int LPR, int NW, bool SGN = false> void launch_backsolve_variant(const BsArgs &b, int Sm, hipStream_t stream)
 {
 	using G = BsGeom<PACKED, LPR, NW>;
 	static bool configured = false;
 	if (!configured) {
-		HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(&backsolve_kernel<PACKED, PLAIN, LPR, NW>),
+		HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(&backsolve_kernel<PACKED, PLAIN, LPR, NW, SGN>),
 		                              hipFuncAttributeMaxDynamicSharedMemorySize, (int) G::LDS_BYTES));
 		configured = true;
 	}
-	hipLaunchKernelGGL((backsolve_kernel<PACKED, PLAIN, LPR, NW>), dim3((unsigned) ((Sm + G::CW - 1) / G::CW)), dim3(64 * NW), G::LDS_BYTES,
+	hipLaunchKernelGGL((backsolve_kernel<PACKED, PLAIN, LPR, NW, SGN>), dim3((unsigned) ((Sm + G::CW - 1) / G::CW)), dim3(64 * NW), G::LDS_BYTES,
 	                   stream, b);
 }
 
@@ -776,7 +1328,7 @@ template <bool PACKED, bool PLAIN> void launch_apply_variant(const ApplyArgs &d,
 // Is the back-substituted image worth having for this factor?  Memory: r x Sm words.  Work: nnz(U') * Sm.
 bool backsolve_eligible(int r, int Sm, int64_t nnz_u, int64_t *bytes)
 {
-	const int64_t ldR = ((int64_t) Sm + 255) / 256 * 256;
+	const int64_t ldR = ((int64_t) Sm + 511) / 512 * 512;
 	*bytes = (int64_t) r * ldR * 4;          // (2 bytes per entry when p < 2^16)
 	if (r <= 0 || Sm <= 0)
 		return false;
@@ -793,7 +1345,7 @@ void backsolve_plan(const FactPlan &P, spasm_hip_dfact *F, hipStream_t stream)
 	const int r = P.r, rpad = P.rpad, m = P.m;
 	B.r = r;
 	B.Sm = m - r;
-	B.ldR = ((int64_t) B.Sm + 255) / 256 * 256;          // whole tiles of the apply kernel (64 * AP_TU columns): the padding stays zero
+	B.ldR = ((int64_t) B.Sm + 511) / 512 * 512;          // whole tile groups of the apply kernels (64 * AP_TU words of two entries): the padding stays zero
 	// compact ids: labels that hold a row, in label (= level) order
 	std::vector<int> cid((size_t) (rpad > 0 ? rpad : 1), -1);
 	std::vector<int> label_of((size_t) (r > 0 ? r : 1), 0);
@@ -840,6 +1392,15 @@ void backsolve_plan(const FactPlan &P, spasm_hip_dfact *F, hipStream_t stream)
 		unmont = (uint64_t) ((t0 % P.prime + P.prime) % P.prime);
 	}
 	auto coeff = [&](uint32_t y_mont) -> uint32_t { return B.plain ? (uint32_t) (((uint64_t) y_mont * unmont) % (uint64_t) P.prime) : y_mont; };
+	// small p: signed 16-bit entries of R, coefficients of the dependencies are NEGATED balanced residues (SgnDev above)
+	B.sgn = B.plain && sgn_eligible(P.prime) && env_bs("SPASM_HIP_BS_SIGNED", 1) != 0 && env_bs("SPASM_HIP_BS_PACKED", 1) != 0;
+	auto dep_coeff = [&](uint32_t y_mont) -> uint32_t {
+		const uint32_t c = coeff(y_mont);
+		if (!B.sgn)
+			return c;
+		const int64_t bal = ((int64_t) c > P.prime / 2) ? (int64_t) c - P.prime : (int64_t) c;
+		return (uint32_t) (int32_t) (-bal);
+	};
 	// split every row into pivotal dependencies (compact ids) and non-pivotal entries
 	std::vector<uint64_t> dep_rp((size_t) r + 1, 0), np_rp((size_t) r + 1, 0);
 	std::vector<uint2> dep, np;
@@ -851,7 +1412,7 @@ void backsolve_plan(const FactPlan &P, spasm_hip_dfact *F, hipStream_t stream)
 		for (uint64_t e = P.rp[c]; e < P.rp[c + 1]; e++) {
 			const uint2 en = P.ent[e];
 			if (en.x < (uint32_t) rpad) {
-				dep.push_back(uint2{(uint32_t) cid[en.x], coeff(en.y)});
+				dep.push_back(uint2{(uint32_t) cid[en.x], dep_coeff(en.y)});
 			} else {
 				np.push_back(uint2{en.x - (uint32_t) rpad, coeff(en.y)});
 				np_row.push_back(n);
@@ -1037,7 +1598,7 @@ void backsolve_build(const spasm_hip_dfact *F, hipStream_t stream)
 	if (!B.planned)
 		die("backsolve_build: the factor has no back-substitution plan");
 	// R is stored in 16 bits when the prime allows (42013, the reference's default, does): half the traffic, half the LDS
-	const bool packed = F->prime < 65536 && env_bs("SPASM_HIP_BS_PACKED", 1) != 0;
+	const bool packed = B.sgn || (F->prime < 65536 && env_bs("SPASM_HIP_BS_PACKED", 1) != 0);
 	const int elem = packed ? 2 : 4;
 	const size_t bytes = (size_t) B.r * (size_t) B.ldR * (size_t) elem;
 	if (B.d_R != nullptr && B.elem_bytes != elem) {
@@ -1071,6 +1632,8 @@ void backsolve_build(const spasm_hip_dfact *F, hipStream_t stream)
 	b.np_row = B.d_np_row;
 	b.r = B.r;
 	b.plain = B.plain ? 1 : 0;
+	b.sgn = B.sgn ? 1 : 0;
+	b.G = sgn_setup(F->prime);
 	b.F = to_dev(F->mont);
 	b.dbg = env_bs("SPASM_HIP_BS_DEBUG", 0);
 	// few non-pivotal entries per row of U (mk13.b5: 0.08): the kernel scatters them into its LDS ring itself and R is
@@ -1099,9 +1662,16 @@ void backsolve_build(const spasm_hip_dfact *F, hipStream_t stream)
 	}
 	const int slabs_small = packed ? (B.Sm + 31) / 32 : (B.Sm + 15) / 16;
 	const int shape = env_bs("SPASM_HIP_BS_SHAPE", slabs_small <= (packed ? 2 * cus : cus) ? 2 : 0);
-	snprintf(B.kernel_build, sizeof(B.kernel_build), "backsolve_kernel<%s,%s,%d,%d>", packed ? "true" : "false", B.plain ? "true" : "false",
-	         shape == 2 ? 16 : 32, (shape == 0 || (!packed && B.plain && shape == 1)) ? 16 : 8);
-	if (packed) {
+	snprintf(B.kernel_build, sizeof(B.kernel_build), "backsolve_kernel<%s,%s,%d,%d,%s>", packed ? "true" : "false", B.plain ? "true" : "false",
+	         shape == 2 ? 16 : 32, (shape == 0 || (!packed && B.plain && shape == 1)) ? 16 : 8, B.sgn ? "true" : "false");
+	if (B.sgn) {
+		if (shape == 1)
+			launch_backsolve_variant<true, true, 32, 8, true>(b, B.Sm, stream);
+		else if (shape == 2)
+			launch_backsolve_variant<true, true, 16, 8, true>(b, B.Sm, stream);
+		else
+			launch_backsolve_variant<true, true, 32, 16, true>(b, B.Sm, stream);
+	} else if (packed) {
 		if (shape == 1)
 			launch_backsolve_variant<true, true, 32, 8>(b, B.Sm, stream);
 		else if (shape == 2)
@@ -1137,7 +1707,9 @@ void backsolve_build(const spasm_hip_dfact *F, hipStream_t stream)
 			hipLaunchKernelGGL(bs_init_kernel<uint16_t>, dim3((B.r + 255) / 256), dim3(256), 0, stream, c);
 		else
 			hipLaunchKernelGGL(bs_init_kernel<uint32_t>, dim3((B.r + 255) / 256), dim3(256), 0, stream, c);
-		if (packed)
+		if (B.sgn)
+			launch_backsolve_variant<true, true, 32, 16, true>(c, B.Sm, stream);
+		else if (packed)
 			launch_backsolve_variant<true, true, 32, 16>(c, B.Sm, stream);
 		else if (B.plain)
 			launch_backsolve_variant<false, true, 32, 16>(c, B.Sm, stream);
@@ -1164,6 +1736,14 @@ void backsolve_build(const spasm_hip_dfact *F, hipStream_t stream)
 	}
 }
 
+// staged sparse output available for this factor?  *row_bytes = size of one packed row of the staging buffer
+bool backsolve_stages_output(const spasm_hip_dfact *F, int64_t *row_bytes)
+{
+	const BsImage &B = F->bs;
+	*row_bytes = B.ldR * 2;
+	return B.planned && B.sgn && env_bs("SPASM_HIP_BS_STAGED", 1) != 0;
+}
+
 // S rows from R: sparse rows into the pool of `a` (dense_out == nullptr) or dense rows.
 void launch_backsolve_apply(const SchurArgs &a, const spasm_hip_dfact *F, uint32_t *dense_out, int64_t ldS, hipStream_t stream,
                             const BsDirectOut *direct)
@@ -1177,10 +1757,13 @@ void launch_backsolve_apply(const SchurArgs &a, const spasm_hip_dfact *F, uint32
 	d.ldR = B.ldR;
 	d.col = B.d_col;
 	d.r = B.r;
-	static_assert(64 * AP_TU == 256, "ldR is padded to whole tiles of the apply kernel");
+	static_assert(2 * 64 * AP_TU == 512, "ldR is padded to whole tile groups of the apply kernels");
 	d.Smpad = (int) B.ldR;
 	d.dense_out = dense_out;
 	d.ldS = ldS;
+	d.dbg = env_bs("SPASM_HIP_BS_DEBUG", 0);
+	d.sgn = B.sgn ? 1 : 0;
+	d.G = sgn_setup(F->prime);
 	if (direct != nullptr && dense_out == nullptr) {
 		d.direct = 1;
 		d.status = direct->status;
@@ -1218,7 +1801,41 @@ void launch_backsolve_apply(const SchurArgs &a, const spasm_hip_dfact *F, uint32
 	d.wave_bytes = per_wave;
 	const size_t lds = per_wave * (size_t) waves;
 	const int blocks = std::max(1, std::min((a.nrows + waves - 1) / waves, prop.multiProcessorCount * 8));
-	if (packed)
+	d.ntickets = std::min(LB_TICKETS, blocks);
+	if (B.sgn) {
+		static size_t configured = 0;
+		if (lds > configured) {
+			HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(&bs_apply_s16_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int) lds));
+			configured = lds;
+		}
+		if (direct != nullptr && direct->stage != nullptr && dense_out == nullptr) {
+			// staged output: packed rows + lengths, offsets by a scan, sparse rows by a streaming kernel; slices of
+			// stage_rows rows when the staging buffer is smaller than the batch
+			const int nwords = d.Smpad / 2;
+			HIP_CHECK(hipMemsetAsync(direct->Sp, 0, sizeof(int64_t), stream));
+			for (int64_t r0 = 0; r0 < a.nrows; r0 += direct->stage_rows) {
+				const int n = (int) std::min<int64_t>(direct->stage_rows, a.nrows - r0);
+				ApplyArgs d2 = d;
+				d2.direct = 0;
+				d2.stage = direct->stage;
+				d2.a.rows = a.rows + r0;
+				d2.a.row_len = a.row_len + r0;
+				d2.a.nrows = n;
+				const int blocks2 = std::max(1, std::min((n + waves - 1) / waves, prop.multiProcessorCount * 8));
+				const int nblocks = (n + SCAN_BLOCK - 1) / SCAN_BLOCK;
+				d2.block_sum = direct->status;          // (the look-back words are not used by the staged output)
+				HIP_CHECK(hipMemsetAsync(d2.block_sum, 0, (size_t) nblocks * sizeof(unsigned long long), stream));
+				hipLaunchKernelGGL(bs_apply_s16_kernel, dim3(blocks2), dim3(64 * d.waves), lds, stream, d2);
+				hipLaunchKernelGGL(bs_scan_lengths_kernel, dim3(nblocks), dim3(SCAN_BLOCK), 0, stream, a.row_len + r0, n, d2.block_sum, direct->Sp + r0,
+				                   direct->cap, a.ctr);
+				ExpandArgs e{direct->stage, nwords, n, direct->Sp + r0, direct->Sj, direct->Sx, direct->cap, a.q, d.G};
+				const int blocks3 = std::max(1, std::min((n + 3) / 4, prop.multiProcessorCount * 8));
+				hipLaunchKernelGGL(bs_expand_s16_kernel, dim3(blocks3), dim3(256), 0, stream, e);
+			}
+		} else {
+			hipLaunchKernelGGL(bs_apply_s16_kernel, dim3(blocks), dim3(64 * d.waves), lds, stream, d);
+		}
+	} else if (packed)
 		launch_apply_variant<true, true>(d, blocks, lds, stream);
 	else if (B.plain)
 		launch_apply_variant<false, true>(d, blocks, lds, stream);

@@ -143,6 +143,7 @@ struct BsImage {
 	void *d_R = nullptr;              // r x ldR entries of elem_bytes each (uint16_t when p < 2^16, else uint32_t)
 	int elem_bytes = 4;
 	bool plain = false;               // coefficients of the plan are plain residues (p < 2^16) instead of Montgomery form
+	bool sgn = false;                 // ... negated balanced residues, and R holds signed 16-bit entries (small p: backsolve.hip, SgnDev)
 	int *d_col = nullptr;             // column -> compact row id of its pivot, or r + index among the non-pivotal columns
 	BsChunk *d_chunk = nullptr;
 	int2 *d_step = nullptr;           // [first, last) into d_brow
@@ -181,10 +182,13 @@ void resident_counters(int64_t *uploads, int64_t *hits);
 // where bs_apply_kernel writes a sparse result directly in its final place (rows in order, offsets by look-back)
 struct BsDirectOut {
 	unsigned long long *status;   // nrows words, zeroed before the launch
-	int *ticket;                  // zeroed before the launch
+	int *ticket;                  // ticket counters (backsolve.hip: next_ticket), zeroed before the launch
 	int64_t *Sp;                  // nrows + 1
 	int *Sj, *Sx;
 	int64_t cap;                  // capacity of Sj / Sx
+	// staged output (signed 16-bit entries, backsolve.hip): room for stage_rows packed rows; nullptr: look-back output
+	uint32_t *stage = nullptr;
+	int64_t stage_rows = 0;
 };
 
 }  // namespace sh
@@ -228,7 +232,9 @@ struct spasm_hip_dwork {
 	int *d_order = nullptr, *d_sortbuf = nullptr;   // rows regrouped by connected component of the pivot graph
 	int64_t sortbuf_ints = 0;
 	int *d_Sj = nullptr, *d_Sx = nullptr;
-	unsigned long long *d_lb_status = nullptr;   // look-back words of the direct sparse output (max_rows + 1: the last one is the ticket)
+	uint32_t *d_stage = nullptr;                  // packed rows of the staged sparse output (backsolve.hip)
+	int64_t stage_bytes = 0;
+	unsigned long long *d_lb_status = nullptr;   // look-back words of the direct sparse output (one per row, then the ticket counters: schur_api.hip)
 	unsigned char *d_scratch = nullptr;   // per-wave dense accumulators (all zero between calls)
 	int64_t scratch_bytes = 0;
 	int64_t scratch_budget = 0;           // 0: up to half of the free HBM; else a cap in bytes

@@ -29,6 +29,7 @@ bool backsolve_eligible(int r, int Sm, int64_t nnz_u, int64_t *bytes);
 void backsolve_plan(const FactPlan &P, spasm_hip_dfact *F, hipStream_t stream);
 void backsolve_free(spasm_hip_dfact *F);
 void backsolve_build(const spasm_hip_dfact *F, hipStream_t stream);
+bool backsolve_stages_output(const spasm_hip_dfact *F, int64_t *row_bytes);
 void launch_backsolve_apply(const SchurArgs &a, const spasm_hip_dfact *F, uint32_t *dense_out, int64_t ldS, hipStream_t stream,
                             const BsDirectOut *direct);
 bool backsolve_wanted(const spasm_hip_dfact *F, bool other_path_forced);
@@ -586,7 +587,7 @@ spasm_hip_dfact *spasm_hip_dfact_create(const struct spasm_csr *U, const int *qi
 	F->h_q = P.q;
 	F->h_kof = P.kof;
 	F->d_lab = dalloc<uint32_t>(m);
-	F->d_q = dalloc<int>(m - r);
+	F->d_q = dalloc<int>(m - r + 514);          // (padded: bs_apply_s16_kernel reads pairs over whole tiles of the padded row)
 	F->d_rp = dalloc<uint64_t>(rpad + 1);
 	F->d_ent = dalloc<uint2>(F->nnz);
 	F->d_head = dalloc<uint2>((i64) rpad * 4);
@@ -712,6 +713,8 @@ void spasm_hip_dwork_destroy(spasm_hip_dwork *W)
 	(void) hipFree(W->d_blocksum);
 	if (W->d_lb_status != nullptr)
 		(void) hipFree(W->d_lb_status);
+	if (W->d_stage != nullptr)
+		(void) hipFree(W->d_stage);
 	if (W->d_order != nullptr)
 		(void) hipFree(W->d_order);
 	if (W->d_sortbuf != nullptr)
@@ -881,9 +884,28 @@ int dschur_impl(const spasm_hip_dcsr *A, const int *d_rows, int nrows, const spa
 		bs_direct = env_int("SPASM_HIP_BS_DIRECT", 1) != 0;
 		if (bs_direct) {
 			if (W->d_lb_status == nullptr)
-				W->d_lb_status = dalloc<unsigned long long>((i64) W->max_rows + 2);
-			HIP_CHECK(hipMemsetAsync(W->d_lb_status, 0, ((size_t) nrows + 2) * sizeof(unsigned long long), stream));
-			BsDirectOut out{W->d_lb_status, reinterpret_cast<int *>(W->d_lb_status + nrows + 1), W->d_Sp, W->d_Sj, W->d_Sx, W->pool_cap};
+				W->d_lb_status = dalloc<unsigned long long>((i64) W->max_rows + 16 + 16 * 16);
+			// status words of the rows, then (on a fresh 128-byte line) the 16 ticket counters, one line each
+			const size_t ticket_at = ((size_t) nrows + 16) / 16 * 16;
+			HIP_CHECK(hipMemsetAsync(W->d_lb_status, 0, (ticket_at + 16 * 16) * sizeof(unsigned long long), stream));
+			BsDirectOut out{W->d_lb_status, reinterpret_cast<int *>(W->d_lb_status + ticket_at), W->d_Sp, W->d_Sj, W->d_Sx, W->pool_cap};
+			int64_t stage_row_bytes = 0;
+			if (backsolve_stages_output(F, &stage_row_bytes) && nrows > 0) {
+				// packed rows of the staged output: the whole batch when it fits SPASM_HIP_STAGE_GB (default 8), else slices
+				const int64_t budget = (int64_t) env_int("SPASM_HIP_STAGE_GB", 8) << 30;
+				int64_t rows_fit = std::max<int64_t>(1024, budget / stage_row_bytes);
+				if (env_int("SPASM_HIP_STAGE_ROWS", 0) > 0)          // (tests: slices on small inputs)
+					rows_fit = env_int("SPASM_HIP_STAGE_ROWS", 0);
+				out.stage_rows = std::min<int64_t>(nrows, rows_fit);
+				const int64_t need = out.stage_rows * stage_row_bytes;
+				if (W->stage_bytes < need) {
+					if (W->d_stage != nullptr)
+						(void) hipFree(W->d_stage);
+					W->d_stage = dalloc<uint32_t>(need / 4);
+					W->stage_bytes = need;
+				}
+				out.stage = W->d_stage;
+			}
 			launch_backsolve_apply(a, F, nullptr, 0, stream, &out);
 		} else {
 			launch_backsolve_apply(a, F, nullptr, 0, stream, nullptr);
@@ -1057,7 +1079,10 @@ eliminated:
 			// one row of R per pivotal entry of the reduced rows, the entries in and out, 20 B per row
 			stats->bytes_apply = (i64) ctr64[C64_ELIM] * (i64) B.Sm * B.elem_bytes + 8 * ((i64) ctr64[C64_INPUT] + total) + 20 * (i64) nrows;
 			char apply_name[32];
-			snprintf(apply_name, sizeof(apply_name), "bs_apply_kernel<%s,%s>", B.elem_bytes == 2 ? "true" : "false", B.plain ? "true" : "false");
+			if (B.sgn)
+				snprintf(apply_name, sizeof(apply_name), "bs_apply_s16_kernel");
+			else
+				snprintf(apply_name, sizeof(apply_name), "bs_apply_kernel<%s,%s>", B.elem_bytes == 2 ? "true" : "false", B.plain ? "true" : "false");
 			const bool build_dominates = stats->ms_backsolve > stats->ms_apply;
 			snprintf(stats->kernel, sizeof(stats->kernel), "%s", build_dominates ? B.kernel_build : apply_name);
 			snprintf(stats->kernel_other, sizeof(stats->kernel_other), "%s", build_dominates ? apply_name : B.kernel_build);

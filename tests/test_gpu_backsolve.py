@@ -3,13 +3,19 @@ R = U_pp^-1 U_pn must be the matrix spasm_schur computes (spasm_schur.c:64-193),
 
 The shapes below aim at the kernel's own seams: chains longer than a chunk (768 rows), levels wider than a
 workgroup pass, rows with more than two dependencies outside their chunk, dependencies that straddle chunk
-boundaries, column counts around the 16-column slabs and 64-column tiles, 32-bit primes."""
+boundaries, column counts around the 16-column slabs and 64-column tiles, and every arithmetic of the kernels:
+signed 16-bit entries with deferred reduction (p <= 44927, the largest prime whose four-term sums fit 32 bits),
+unsigned 16-bit entries (p < 2^16, or SPASM_HIP_BS_SIGNED=0), 32-bit Montgomery entries."""
 import numpy as np
 import pytest
 
 import spasm_amd
 
 pytestmark = pytest.mark.gpu
+
+# (prime, SPASM_HIP_BS_SIGNED)
+SMALL = [(42013, "1"), (42013, "0"), (44927, "1"), (65521, "1")]
+ARITH = [(3, "1"), (257, "1"), (257, "0")] + SMALL + [(4294967291, "1")]
 
 
 def _as_product(A):
@@ -44,8 +50,9 @@ def _triangular_system(rng, p, npiv, nnon, nred, deps, reach, np_per_row, red_en
     return npiv + nred, m, np.array(ti, np.int32), np.array(tj, np.int32), np.array(tx, np.int64)
 
 
-def _run(oracle, monkeypatch, p, n, m, ti, tj, tx, min_pivots, dense=False):
+def _run(oracle, monkeypatch, p, n, m, ti, tj, tx, min_pivots, signed="1"):
     monkeypatch.setenv("SPASM_HIP_BACKSOLVE", "1")
+    monkeypatch.setenv("SPASM_HIP_BS_SIGNED", signed)
     A = oracle.compress(p, n, m, ti, tj, tx)
     npiv, perm, F = oracle.pivots_extract_structural(A, oracle.empty_fact(A.n, A.m, p))
     assert npiv >= min_pivots
@@ -60,52 +67,78 @@ def _run(oracle, monkeypatch, p, n, m, ti, tj, tx, min_pivots, dense=False):
     return A, rows, F, want
 
 
-@pytest.mark.parametrize("p", [3, 42013, 4294967291])
-@pytest.mark.parametrize("nnon", [1, 15, 16, 17, 63, 64, 65, 300])
-def test_backsolve_column_counts(oracle, monkeypatch, p, nnon):
+@pytest.mark.parametrize("p,signed", ARITH)
+@pytest.mark.parametrize("nnon", [1, 15, 16, 17, 63, 64, 65, 300, 513])
+def test_backsolve_column_counts(oracle, monkeypatch, p, signed, nnon):
     rng = np.random.default_rng(nnon)
     sysm = _triangular_system(rng, p, npiv=500, nnon=nnon, nred=300, deps=lambda k: 2, reach=40, np_per_row=3, red_entries=5)
-    _run(oracle, monkeypatch, p, *sysm, min_pivots=400)
+    _run(oracle, monkeypatch, p, *sysm, min_pivots=400, signed=signed)
 
 
-@pytest.mark.parametrize("p", [42013, 4294967291])
-def test_backsolve_chain_longer_than_a_chunk(oracle, monkeypatch, p):
+@pytest.mark.parametrize("p,signed", SMALL + [(4294967291, "1")])
+def test_backsolve_chain_longer_than_a_chunk(oracle, monkeypatch, p, signed):
     """one dependency on the next row: 2500 levels of one row each -- every chunk is a pure chain."""
     rng = np.random.default_rng(5)
     sysm = _triangular_system(rng, p, npiv=2500, nnon=40, nred=400, deps=lambda k: 1, reach=1, np_per_row=2, red_entries=4)
-    _run(oracle, monkeypatch, p, *sysm, min_pivots=2000)
+    _run(oracle, monkeypatch, p, *sysm, min_pivots=2000, signed=signed)
 
 
-@pytest.mark.parametrize("p", [257, 42013, 4294967291])
+@pytest.mark.parametrize("p,signed", ARITH[1:])
 @pytest.mark.parametrize("ndeps,reach", [(3, 3000), (8, 3000), (40, 3000), (6, 100), (150, 800)])
-def test_backsolve_many_dependencies(oracle, monkeypatch, p, ndeps, reach):
+def test_backsolve_many_dependencies(oracle, monkeypatch, p, signed, ndeps, reach):
     """rows of U with many pivotal entries, near (inside the chunk) and far (beyond the two inline ones)."""
     rng = np.random.default_rng(ndeps + reach)
     sysm = _triangular_system(rng, p, npiv=3000, nnon=100, nred=500, deps=lambda k: ndeps, reach=reach, np_per_row=4, red_entries=6)
-    _run(oracle, monkeypatch, p, *sysm, min_pivots=1500)
+    _run(oracle, monkeypatch, p, *sysm, min_pivots=1500, signed=signed)
 
 
-def test_backsolve_wide_levels(oracle, monkeypatch):
+@pytest.mark.parametrize("signed", ["1", "0"])
+def test_backsolve_wide_levels(oracle, monkeypatch, signed):
     """no dependencies between most pivot rows: a few levels of thousands of rows (levels wider than a chunk)."""
     p = 42013
     rng = np.random.default_rng(8)
     sysm = _triangular_system(rng, p, npiv=4000, nnon=200, nred=600, deps=lambda k: 1 if k % 7 == 0 else 0, reach=3000,
                               np_per_row=5, red_entries=8)
-    _run(oracle, monkeypatch, p, *sysm, min_pivots=3000)
+    _run(oracle, monkeypatch, p, *sysm, min_pivots=3000, signed=signed)
 
 
-def test_backsolve_long_input_rows(oracle, monkeypatch):
+@pytest.mark.parametrize("p,signed", SMALL)
+def test_backsolve_extreme_values(oracle, monkeypatch, p, signed):
+    """every entry is (p - 1) / 2 or (p + 1) / 2 -- the balanced representatives of largest magnitude: sums of four
+    products come as close to 2^31 as the data can push them."""
+    rng = np.random.default_rng(77)
+    n, m, ti, tj, tx = _triangular_system(rng, p, npiv=1500, nnon=70, nred=400, deps=lambda k: 4, reach=30, np_per_row=3, red_entries=8)
+    tx = np.where(tx == 1, 1, np.where(rng.integers(0, 2, size=len(tx)) == 0, (p - 1) // 2, (p + 1) // 2)).astype(np.int64)
+    _run(oracle, monkeypatch, p, n, m, ti, tj, tx, min_pivots=1000, signed=signed)
+
+
+@pytest.mark.parametrize("env", [{"SPASM_HIP_BS_STAGED": "0"}, {"SPASM_HIP_STAGE_ROWS": "100"}, {"SPASM_HIP_STAGE_ROWS": "1"},
+                                 {"SPASM_HIP_BS_DIRECT": "0"}])
+@pytest.mark.parametrize("p", [257, 42013])
+def test_backsolve_output_modes(oracle, monkeypatch, p, env):
+    """signed 16-bit entries: look-back output instead of the staged one, staged output in slices of 100 rows and of
+    one row, rows through the pool + gather pass."""
+    for k, v in env.items():
+        monkeypatch.setenv(k, v)
+    rng = np.random.default_rng(61)
+    sysm = _triangular_system(rng, p, npiv=1500, nnon=333, nred=777, deps=lambda k: 3, reach=40, np_per_row=3, red_entries=7)
+    _run(oracle, monkeypatch, p, *sysm, min_pivots=1000)
+
+
+@pytest.mark.parametrize("signed", ["1", "0"])
+def test_backsolve_long_input_rows(oracle, monkeypatch, signed):
     """rows to reduce with hundreds of pivotal entries (more than one pass of the apply kernel's list)."""
     p = 42013
     rng = np.random.default_rng(9)
     sysm = _triangular_system(rng, p, npiv=2000, nnon=130, nred=200, deps=lambda k: 2, reach=50, np_per_row=3, red_entries=900)
-    _run(oracle, monkeypatch, p, *sysm, min_pivots=1500)
+    _run(oracle, monkeypatch, p, *sysm, min_pivots=1500, signed=signed)
 
 
-@pytest.mark.parametrize("p", [42013, 4294967291])
-def test_backsolve_dense_rows(oracle, monkeypatch, p):
+@pytest.mark.parametrize("p,signed", SMALL + [(4294967291, "1")])
+def test_backsolve_dense_rows(oracle, monkeypatch, p, signed):
     """spasm_schur_dense (spasm_schur.c:258-343) through the same image."""
     monkeypatch.setenv("SPASM_HIP_BACKSOLVE", "1")
+    monkeypatch.setenv("SPASM_HIP_BS_SIGNED", signed)
     rng = np.random.default_rng(21)
     n, m, ti, tj, tx = _triangular_system(rng, p, npiv=1200, nnon=90, nred=300, deps=lambda k: 2, reach=60, np_per_row=3, red_entries=6)
     A = oracle.compress(p, n, m, ti, tj, tx)
@@ -117,10 +150,12 @@ def test_backsolve_dense_rows(oracle, monkeypatch, p):
     assert np.array_equal(np.asarray(got, np.int64) % p, np.asarray(want, np.int64) % p)
 
 
-def test_backsolve_is_rebuilt_after_forget(oracle, monkeypatch):
+@pytest.mark.parametrize("signed", ["1", "0"])
+def test_backsolve_is_rebuilt_after_forget(oracle, monkeypatch, signed):
     """device API: the image is built by the first call, reused by the second, rebuilt after forget()."""
     import torch
     monkeypatch.setenv("SPASM_HIP_BACKSOLVE", "1")
+    monkeypatch.setenv("SPASM_HIP_BS_SIGNED", signed)
     p = 42013
     rng = np.random.default_rng(33)
     n, m, ti, tj, tx = _triangular_system(rng, p, npiv=1500, nnon=70, nred=400, deps=lambda k: 2, reach=30, np_per_row=3, red_entries=5)
@@ -138,7 +173,7 @@ def test_backsolve_is_rebuilt_after_forget(oracle, monkeypatch):
             dF.forget()
         S, st = spasm_amd.dschur(dA, drows, dF, W)
         assert st.status == 0 and st.used_backsolve == 1 and st.nnz == want.nnz
-        assert {st.kernel.decode().split("<")[0], st.kernel_other.decode().split("<")[0]} == {"backsolve_kernel", "bs_apply_kernel"}
+        assert {st.kernel.decode().split("<")[0], st.kernel_other.decode().split("<")[0]} == {"backsolve_kernel", "bs_apply_s16_kernel" if signed == "1" else "bs_apply_kernel"}
         built.append(st.backsolve_built)
         H = S.to_host()
         assert oracle.same_matrix(oracle.CSR(H.n, H.m, H.p, H.j, H.x, p), want)
