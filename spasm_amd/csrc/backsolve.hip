@@ -35,8 +35,9 @@ namespace sh {
 namespace {
 
 constexpr int BS_RING = 768;       // rows per chunk (the LDS ring holds RING rows of one slab)
-constexpr int BS_NEARCAP = 1024;   // dependencies inside a chunk
-constexpr int BS_STEPCAP = 128;    // levels with such dependencies inside a chunk
+constexpr int BS_NEARCAP = 1024;   // dependencies inside a chunk that do not fit the pass table (rows with more than two)
+constexpr int BS_PASSCAP = 80;     // phase-B passes of a chunk (32 rows of one level each)
+constexpr int BS_PASSROWS = 32;
 constexpr uint32_t BS_NONE = 0xFFFFFFFFu;
 
 int env_bs(const char *name, int dflt)
@@ -122,8 +123,7 @@ struct BsArgs {
 	int nchunks;
 	const BsChunk *chunk;
 	const int *chunk_extra;       // per chunk: 1 when some row has more than two dependencies outside the chunk
-	const int2 *step;
-	const uint2 *brow;
+	const uint4 *ptab;
 	const uint2 *near;
 	const uint4 *far_head;
 	const uint64_t *far_rp;
@@ -201,10 +201,12 @@ template <bool PACKED, int LPR, int NW> struct BsGeom {
 	static_assert(BS_RING % ROWS_PER_ITER == 0 && ITERS % UNR == 0, "phase A is unrolled in passes of UNR rows");
 	static constexpr int N_NEAR = (BS_NEARCAP + THREADS - 1) / THREADS;      // metadata words a thread carries for the next chunk
 	static constexpr int N_ROW = (BS_RING + THREADS - 1) / THREADS;
-	static_assert(BS_STEPCAP <= THREADS, "one step descriptor per thread");
+	static constexpr int N_PTAB = (BS_PASSCAP * BS_PASSROWS + THREADS - 1) / THREADS;
 	static constexpr size_t FH_BYTES = (size_t) BS_RING * sizeof(uint4);
-	static constexpr size_t LDS_BYTES = FH_BYTES + (size_t) BS_NEARCAP * sizeof(uint2) + (size_t) BS_RING * sizeof(uint2) +
-	                                    (size_t) BS_STEPCAP * sizeof(int2) + (size_t) BS_RING * LPR * 4;
+	static constexpr size_t PTAB_BYTES = (size_t) BS_PASSCAP * BS_PASSROWS * sizeof(uint4);
+	static constexpr int RSTR = LPR + 1;                    // row stride of the ring in words: odd, so that a wave instruction over
+	                                                        // consecutive rows AND one over consecutive words both spread over the banks
+	static constexpr size_t LDS_BYTES = FH_BYTES + PTAB_BYTES + (size_t) BS_NEARCAP * sizeof(uint2) + (size_t) BS_RING * RSTR * 4;
 };
 
 template <bool PACKED, bool PLAIN, int LPR, int NW, bool SGN = false>
@@ -217,13 +219,17 @@ __global__ __launch_bounds__(64 * NW) void backsolve_kernel(BsArgs b)
 	using Elem = typename Word<PACKED>::Elem;
 	extern __shared__ __attribute__((aligned(16))) unsigned char bs_lds[];
 	uint4 *fh = reinterpret_cast<uint4 *>(bs_lds);                          // first two outside dependencies of every row
-	uint2 *near = reinterpret_cast<uint2 *>(bs_lds + Geo::FH_BYTES);
-	uint2 *brow = near + BS_NEARCAP;
-	int2 *step = reinterpret_cast<int2 *>(brow + BS_RING);
-	uint32_t *ring = reinterpret_cast<uint32_t *>(step + BS_STEPCAP);
+	uint4 *ptab = reinterpret_cast<uint4 *>(bs_lds + Geo::FH_BYTES);       // phase-B passes
+	uint2 *near = reinterpret_cast<uint2 *>(bs_lds + Geo::FH_BYTES + Geo::PTAB_BYTES);
+	uint32_t *ring = reinterpret_cast<uint32_t *>(near + BS_NEARCAP);
 	const int tid = threadIdx.x;
 	const int lane = tid & 63, wave = tid >> 6;
-	const int rs = lane / LPR, wl = lane % LPR;           // row slot of the lane, its word inside the row
+	const int rs = lane / LPR, wl = lane % LPR;           // row slot of the lane, its word inside the row (phases A and C)
+	constexpr int RSTR = Geo::RSTR;                        // words between two rows of the ring
+	// phase B splits the COLUMNS among the waves: a wave owns WPW words of every row, a wave instruction covers RSB rows
+	constexpr int WPW = LPR / NW, RSB = 64 / WPW;
+	static_assert(WPW >= 1 && RSB == Geo::ROWS_PER_ITER, "phase B walks the rows of a step as the other phases do");
+	const int rsb = lane / WPW, wlb = wave * WPW + lane % WPW;
 	const MontDev F = b.F;
 	const int64_t ldw = b.ldR / Word<PACKED>::CPL;       // row stride of R in words
 	uint32_t *Rs = static_cast<uint32_t *>(b.R) + (int64_t) blockIdx.x * LPR + wl;
@@ -232,9 +238,8 @@ __global__ __launch_bounds__(64 * NW) void backsolve_kernel(BsArgs b)
 
 	// metadata of a chunk (the same for every slab: served by the L2) travels through registers: the loads for chunk
 	// k + 1 are issued when chunk k starts and land in LDS when it is done
-	uint2 m_near[Geo::N_NEAR], m_brow[Geo::N_ROW];
-	uint4 m_fh[Geo::N_ROW];
-	int2 m_step;
+	uint2 m_near[Geo::N_NEAR];
+	uint4 m_fh[Geo::N_ROW], m_ptab[Geo::N_PTAB];
 	auto load_meta = [&](int k) {
 		const BsChunk c = b.chunk[k];
 #pragma unroll
@@ -245,10 +250,13 @@ __global__ __launch_bounds__(64 * NW) void backsolve_kernel(BsArgs b)
 #pragma unroll
 		for (int q = 0; q < Geo::N_ROW; q++) {
 			const int t = tid + q * Geo::THREADS;
-			m_brow[q] = (t < c.nbrow) ? b.brow[c.brow0 + t] : uint2{0u, 0u};
 			m_fh[q] = (t < c.hi - c.lo) ? b.far_head[c.lo + t] : uint4{BS_NONE, 0u, BS_NONE, 0u};
 		}
-		m_step = (tid < c.nsteps) ? b.step[c.step0 + tid] : int2{0, 0};
+#pragma unroll
+		for (int q = 0; q < Geo::N_PTAB; q++) {
+			const int t = tid + q * Geo::THREADS;
+			m_ptab[q] = (t < c.npass * BS_PASSROWS) ? b.ptab[(int64_t) c.pass0 * BS_PASSROWS + t] : uint4{0u, 0u, 0u, 0u};
+		}
 	};
 	auto store_meta = [&]() {
 #pragma unroll
@@ -257,12 +265,12 @@ __global__ __launch_bounds__(64 * NW) void backsolve_kernel(BsArgs b)
 				near[tid + q * Geo::THREADS] = m_near[q];
 #pragma unroll
 		for (int q = 0; q < Geo::N_ROW; q++)
-			if (tid + q * Geo::THREADS < BS_RING) {
-				brow[tid + q * Geo::THREADS] = m_brow[q];
+			if (tid + q * Geo::THREADS < BS_RING)
 				fh[tid + q * Geo::THREADS] = m_fh[q];
-			}
-		if (tid < BS_STEPCAP)
-			step[tid] = m_step;
+#pragma unroll
+		for (int q = 0; q < Geo::N_PTAB; q++)
+			if (tid + q * Geo::THREADS < BS_PASSCAP * BS_PASSROWS)
+				ptab[tid + q * Geo::THREADS] = m_ptab[q];
 	};
 	if (b.nchunks > 0) {
 		load_meta(0);
@@ -278,7 +286,7 @@ __global__ __launch_bounds__(64 * NW) void backsolve_kernel(BsArgs b)
 
 		if (b.sparse_init) {
 			// the rows start as U_n: few entries, scattered from the list (R itself is never read for them)
-			for (int t = tid; t < nrows * LPR; t += Geo::THREADS)
+			for (int t = tid; t < nrows * RSTR; t += Geo::THREADS)
 				ring[t] = 0;
 			__syncthreads();
 			const uint64_t e0 = b.np_rp[ch.lo], e1 = b.np_rp[ch.hi];
@@ -286,7 +294,7 @@ __global__ __launch_bounds__(64 * NW) void backsolve_kernel(BsArgs b)
 				const uint2 en = b.np[e];
 				const int cc = (int) en.x - col_lo;
 				if (cc >= 0 && cc < Geo::CW)
-					reinterpret_cast<Elem *>(ring)[(b.np_row[e] - ch.lo) * Geo::CW + cc] =
+					reinterpret_cast<Elem *>(ring)[(b.np_row[e] - ch.lo) * (RSTR * Word<PACKED>::CPL) + cc] =
 						SGN ? (Elem) (uint16_t) (int16_t) sgn_from_residue(en.y, G) : (Elem) (PLAIN ? en.y : montmul(en.y, 1u, F));
 			}
 			__syncthreads();
@@ -312,7 +320,7 @@ __global__ __launch_bounds__(64 * NW) void backsolve_kernel(BsArgs b)
 				const int s = (pass * Geo::UNR + u) * Geo::ROWS_PER_ITER + slot0;
 				if (s < nrows) {
 					const uint4 h = fh[s];
-					uint32_t x = b.sparse_init ? ring[s * LPR + wl] : acc[u];
+					uint32_t x = b.sparse_init ? ring[s * RSTR + wl] : acc[u];
 					if constexpr (SGN) {
 						// (an absent dependency was loaded as 0: its term vanishes whatever the coefficient slot holds)
 						if (h.x != BS_NONE) {
@@ -328,7 +336,7 @@ __global__ __launch_bounds__(64 * NW) void backsolve_kernel(BsArgs b)
 						if (h.z != BS_NONE)
 							x = w_submul<PACKED, PLAIN>(x, v1[u], h.w, F, bm);
 					}
-					ring[s * LPR + wl] = x;
+					ring[s * RSTR + wl] = x;
 				}
 			}
 		}
@@ -340,7 +348,7 @@ __global__ __launch_bounds__(64 * NW) void backsolve_kernel(BsArgs b)
 				const uint64_t e0 = b.far_rp[c], e1 = b.far_rp[c + 1];
 				if (e0 == e1)
 					continue;
-				uint32_t x = ring[s * LPR + wl];
+				uint32_t x = ring[s * RSTR + wl];
 				if constexpr (SGN) {
 					int lo, hi;
 					sgn_unpack(x, lo, hi);
@@ -360,122 +368,81 @@ __global__ __launch_bounds__(64 * NW) void backsolve_kernel(BsArgs b)
 						x = w_submul<PACKED, PLAIN>(x, Rs[(int64_t) en.x * ldw], en.y, F, bm);
 					}
 				}
-				ring[s * LPR + wl] = x;
+				ring[s * RSTR + wl] = x;
 			}
 			__syncthreads();
 		}
 
 		// ---- phase B: the chain of levels, in LDS ----
-		// What a row needs besides the values -- the rows of its step, its slot and list of dependencies, the first of
-		// them: a chain of three dependent LDS reads -- does not depend on the values.  It is fetched ahead, one link
-		// per step, so that a step is ONE round of independent LDS reads -> multiply -> ring write -> barrier.
+		// Columns never meet in a triangular solve, so every wave takes ITS columns (WPW words of every row) through all the
+		// levels of the chunk on its own: no barrier between the levels -- the LDS serves a wave's reads and writes in
+		// order.  The rows come as a flat table of passes (32 rows of one level each, levels in order): one 16-byte entry
+		// holds everything a row with one or two dependencies inside the chunk needs, and the entry of the next trip is
+		// in flight during the arithmetic of this one.  (Every wave decodes every entry: the table is what keeps that cheap.)
 		{
-			const int nsteps = (b.dbg & 2) ? 0 : ch.nsteps;
-			auto rd_step = [&](int i) { return (i < nsteps) ? step[i] : int2{0, 0}; };
-			auto rd_brow = [&](int2 sp) { return (sp.x + slot0 < sp.y) ? brow[sp.x + slot0] : uint2{0u, 0u}; };
-			auto rd_near = [&](uint2 br) { return ((br.x >> 16) != 0) ? near[br.y] : uint2{0u, 0u}; };
-			int2 S0 = rd_step(0), S1 = rd_step(1), S2 = rd_step(2);
-			uint2 B0 = rd_brow(S0), B1 = rd_brow(S1);
-			uint2 D0 = rd_near(B0);
-			for (int st = 0; st < nsteps; st++) {
-				const int slot = (int) (B0.x & 0xFFFFu), cnt = (int) (B0.x >> 16);      // cnt != 0: this lane has a row in the step
-				uint32_t x = 0, v = 0;
+			const int niter = ((b.dbg & 2) ? 0 : ch.npass) * (BS_PASSROWS / RSB);
+			uint4 e = (niter > 0) ? ptab[rsb] : uint4{0u, 0u, 0u, 0u};
+			for (int it = 0; it < niter; it++) {
+				const uint4 e_next = (it + 1 < niter) ? ptab[(it + 1) * RSB + rsb] : uint4{0u, 0u, 0u, 0u};
+				const int cnt = (int) (e.x >> 16);                    // cnt != 0: this lane has a row in the pass
 				if (cnt != 0) {
-					x = ring[slot * LPR + wl];
-					v = ring[D0.x * LPR + wl];
-				}
-				const uint2 D1 = rd_near(B1);
-				const uint2 B2 = rd_brow(S2);
-				const int2 S3 = rd_step(st + 3);
-				if (cnt != 0) {
-					if constexpr (SGN) {
-						// one reduction per four dependencies: their list entries are read together, then their rows
-						int lo, hi;
-						sgn_unpack(x, lo, hi);
-						sgn_mad(v, (int) D0.y, lo, hi);
-						if (cnt > 1) {
-							uint2 en[3];
-							uint32_t w[3];
-#pragma unroll
-							for (int t = 0; t < 3; t++)
-								en[t] = (1 + t < cnt) ? near[B0.y + 1 + t] : uint2{D0.x, 0u};
-#pragma unroll
-							for (int t = 0; t < 3; t++)
-								w[t] = ring[en[t].x * LPR + wl];
-#pragma unroll
-							for (int t = 0; t < 3; t++)
-								sgn_mad(w[t], (int) en[t].y, lo, hi);
-							for (int j = 4; j < cnt; j += 4) {
-								lo = sgn_reduce(lo, G);
-								hi = sgn_reduce(hi, G);
+					const int slot = (int) (e.x & 0xFFFFu);
+					uint32_t x = ring[slot * RSTR + wlb];
+					const uint32_t v0 = ring[(e.y & 0xFFFFu) * RSTR + wlb];
+					if (cnt <= 2) {
+						const uint32_t v1 = ring[(e.y >> 16) * RSTR + wlb];          // (one dependency: the same row again, coefficient 0)
+						if constexpr (SGN) {
+							int lo, hi;
+							sgn_unpack(x, lo, hi);
+							sgn_mad(v0, (int) e.z, lo, hi);
+							sgn_mad(v1, (int) e.w, lo, hi);
+							x = sgn_pack(sgn_reduce(lo, G), sgn_reduce(hi, G));
+						} else {
+							x = w_submul<PACKED, PLAIN>(x, v0, e.z, F, bm);
+							if (cnt == 2)
+								x = w_submul<PACKED, PLAIN>(x, v1, e.w, F, bm);
+						}
+					} else {
+						// the first dependency inline, the others in the list
+						const int rest = cnt - 1;
+						if constexpr (SGN) {
+							int lo, hi;
+							sgn_unpack(x, lo, hi);
+							sgn_mad(v0, (int) e.z, lo, hi);
+							for (int j = 0; j < rest; j += 4) {
 								uint2 em[4];
 								uint32_t wm[4];
 #pragma unroll
 								for (int t = 0; t < 4; t++)
-									em[t] = (j + t < cnt) ? near[B0.y + j + t] : uint2{D0.x, 0u};
+									em[t] = (j + t < rest) ? near[e.w + j + t] : uint2{(uint32_t) slot, 0u};
 #pragma unroll
 								for (int t = 0; t < 4; t++)
-									wm[t] = ring[em[t].x * LPR + wl];
+									wm[t] = ring[em[t].x * RSTR + wlb];
+								lo = sgn_reduce(lo, G);          // (one term or four are in already: four more need a fresh start)
+								hi = sgn_reduce(hi, G);
 #pragma unroll
 								for (int t = 0; t < 4; t++)
 									sgn_mad(wm[t], (int) em[t].y, lo, hi);
 							}
-						}
-						x = sgn_pack(sgn_reduce(lo, G), sgn_reduce(hi, G));
-					} else {
-						x = w_submul<PACKED, PLAIN>(x, v, D0.y, F, bm);
-						for (int j = 1; j < cnt; j++) {
-							const uint2 en = near[B0.y + j];
-							x = w_submul<PACKED, PLAIN>(x, ring[en.x * LPR + wl], en.y, F, bm);
-						}
-					}
-					ring[slot * LPR + wl] = x;
-				}
-				// levels wider than one pass of the workgroup
-				for (int q = S0.x + slot0 + Geo::ROWS_PER_ITER; q < S0.y; q += Geo::ROWS_PER_ITER) {
-					const uint2 bq = brow[q];
-					const int sq = (int) (bq.x & 0xFFFFu), cq = (int) (bq.x >> 16);
-					uint32_t y = ring[sq * LPR + wl];
-					if constexpr (SGN) {
-						int lo, hi;
-						sgn_unpack(y, lo, hi);
-						for (int j = 0; j < cq; j += 4) {
-							uint2 em[4];
-							uint32_t wm[4];
-#pragma unroll
-							for (int t = 0; t < 4; t++)
-								em[t] = (j + t < cq) ? near[bq.y + j + t] : uint2{(uint32_t) sq, 0u};
-#pragma unroll
-							for (int t = 0; t < 4; t++)
-								wm[t] = ring[em[t].x * LPR + wl];
-#pragma unroll
-							for (int t = 0; t < 4; t++)
-								sgn_mad(wm[t], (int) em[t].y, lo, hi);
-							lo = sgn_reduce(lo, G);
-							hi = sgn_reduce(hi, G);
-						}
-						y = sgn_pack(lo, hi);
-					} else {
-						for (int j = 0; j < cq; j++) {
-							const uint2 en = near[bq.y + j];
-							y = w_submul<PACKED, PLAIN>(y, ring[en.x * LPR + wl], en.y, F, bm);
+							x = sgn_pack(sgn_reduce(lo, G), sgn_reduce(hi, G));
+						} else {
+							x = w_submul<PACKED, PLAIN>(x, v0, e.z, F, bm);
+							for (int j = 0; j < rest; j++) {
+								const uint2 en = near[e.w + j];
+								x = w_submul<PACKED, PLAIN>(x, ring[en.x * RSTR + wlb], en.y, F, bm);
+							}
 						}
 					}
-					ring[sq * LPR + wl] = y;
+					ring[slot * RSTR + wlb] = x;
 				}
-				__syncthreads();
-				S0 = S1;
-				S1 = S2;
-				S2 = S3;
-				B0 = B1;
-				B1 = B2;
-				D0 = D1;
+				e = e_next;
 			}
 		}
+		__syncthreads();
 
 		// ---- phase C: write the chunk back ----
 		for (int s = slot0; s < ((b.dbg & 4) ? 0 : nrows); s += Geo::ROWS_PER_ITER)
-			Rs[(int64_t) (ch.lo + s) * ldw] = ring[s * LPR + wl];
+			Rs[(int64_t) (ch.lo + s) * ldw] = ring[s * RSTR + wl];
 		__syncthreads();          // (workgroup-scope release/acquire: later chunks read these rows; LDS metadata is free)
 		if (k + 1 < b.nchunks)
 			store_meta();
@@ -1094,15 +1061,22 @@ struct ExpandArgs {
 	int64_t cap;
 	const int *q;
 	SgnDev G;
+	int dbg;
 };
 
 __global__ __launch_bounds__(256) void bs_expand_s16_kernel(ExpandArgs e)
 {
-	constexpr int TU = 4;                // tiles per trip (rows are padded to whole groups of four tiles): four loads in flight per lane
-	const int lane = threadIdx.x & 63;
+	constexpr int TU = 4;                // tiles per group (rows are padded to whole groups of four tiles)
+	// The entries of a group are compacted in LDS and leave as dense, contiguous stores (64 consecutive entries per
+	// instruction).  Written straight from the lanes that hold them, an instruction covers every other slot of a
+	// 512-byte span and the holes are filled by the next one: the same bytes took 1.74 ms instead of 1.1.
+	__shared__ int stage_j[4][128 * TU], stage_x[4][128 * TU];
+	const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
 	const int wave = (int) ((blockIdx.x * blockDim.x + threadIdx.x) >> 6), nwaves = (int) ((gridDim.x * blockDim.x) >> 6);
-	const int2 *q2 = reinterpret_cast<const int2 *>(e.q);
+	const int2 *q2 = reinterpret_cast<const int2 *>(e.q) + lane;
 	const SgnDev G = e.G;
+	const int last = e.nwords - 64 * TU;
+	int *sj = stage_j[wv], *sx = stage_x[wv];
 	for (int k = wave; k < e.nrows; k += nwaves) {
 		const int64_t off = e.Sp[k], end = e.Sp[k + 1];
 		if (end > e.cap || end == off)
@@ -1110,16 +1084,32 @@ __global__ __launch_bounds__(256) void bs_expand_s16_kernel(ExpandArgs e)
 		const uint32_t *row = e.stage + (int64_t) k * e.nwords + lane;
 		int *oj = e.Sj + off, *ox = e.Sx + off;
 		uint32_t wpos = 0;
+		if (e.dbg & 128) {          // timing experiment: the same bytes as dense, contiguous stores (wrong results)
+			uint32_t acc = 0;
+			for (int t0 = 0; t0 < e.nwords; t0 += 64)
+				acc += row[t0];
+			for (int64_t t = lane; t < end - off; t += 64) {
+				oj[t] = (int) acc;
+				ox[t] = (int) acc;
+			}
+			continue;
+		}
+		// The loads of the next group are issued BEFORE the stores of this one: stores and loads share one in-order
+		// counter.  (No branch around the issue -- the wait counts are static; past the end the last group is read again.)
+		uint32_t wa[TU], wb[TU];
+		int2 qa[TU], qb[TU];
+		auto issue = [&](int t0, uint32_t (&w)[TU], int2 (&qq)[TU]) {
+			const int t = (t0 < last) ? t0 : last;
+#pragma unroll
+			for (int u = 0; u < TU; u++)
+				w[u] = __builtin_nontemporal_load(row + t + 64 * u);
+#pragma unroll
+			for (int u = 0; u < TU; u++)
+				qq[u] = q2[t + 64 * u];
+		};
 		// lane l of a tile holds columns 2 (t0 + l) and 2 (t0 + l) + 1: entries come out sorted by column
-		for (int t0 = 0; t0 < e.nwords; t0 += 64 * TU) {
-			uint32_t w[TU];
-			int2 qq[TU];
-#pragma unroll
-			for (int u = 0; u < TU; u++)
-				w[u] = __builtin_nontemporal_load(row + t0 + 64 * u);
-#pragma unroll
-			for (int u = 0; u < TU; u++)
-				qq[u] = q2[t0 + 64 * u + lane];
+		auto emit = [&](const uint32_t (&w)[TU], const int2 (&qq)[TU]) {
+			uint32_t gpos = 0;
 #pragma unroll
 			for (int u = 0; u < TU; u++) {
 				int v0, v1;
@@ -1127,22 +1117,33 @@ __global__ __launch_bounds__(256) void bs_expand_s16_kernel(ExpandArgs e)
 				v0 = sgn_canonical(v0, G);
 				v1 = sgn_canonical(v1, G);
 				const uint64_t m0 = __ballot(v0 != 0), m1 = __ballot(v1 != 0);
-				uint32_t dst = wpos;
+				uint32_t dst = gpos;
 				dst = __builtin_amdgcn_mbcnt_hi((uint32_t) (m0 >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t) m0, dst));
 				dst = __builtin_amdgcn_mbcnt_hi((uint32_t) (m1 >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t) m1, dst));
-				// (plain stores: the two halves of a line come from different instructions and meet in the L2 -- non-temporal
-				//  stores of this pattern ran at half the speed)
 				if (v0 != 0) {
-					oj[dst] = qq[u].x;
-					ox[dst] = v0;
+					sj[dst] = qq[u].x;
+					sx[dst] = v0;
 					dst += 1;
 				}
 				if (v1 != 0) {
-					oj[dst] = qq[u].y;
-					ox[dst] = v1;
+					sj[dst] = qq[u].y;
+					sx[dst] = v1;
 				}
-				wpos += (uint32_t) (__popcll(m0) + __popcll(m1));
+				gpos += (uint32_t) (__popcll(m0) + __popcll(m1));
 			}
+			for (uint32_t t = lane; t < gpos; t += 64) {
+				oj[wpos + t] = sj[t];
+				ox[wpos + t] = sx[t];
+			}
+			wpos += gpos;
+		};
+		issue(0, wa, qa);
+		for (int t0 = 0; t0 < e.nwords; t0 += 2 * 64 * TU) {
+			issue(t0 + 64 * TU, wb, qb);
+			emit(wa, qa);
+			issue(t0 + 2 * 64 * TU, wa, qa);
+			if (t0 + 64 * TU < e.nwords)
+				emit(wb, qb);
 		}
 	}
 }
@@ -1425,51 +1426,53 @@ void backsolve_plan(const FactPlan &P, spasm_hip_dfact *F, hipStream_t stream)
 	// chunks, from the last row to the first
 	std::vector<BsChunk> chunks;
 	std::vector<int> chunk_extra;
-	std::vector<int2> steps;
-	std::vector<uint2> brow, near;
+	std::vector<uint4> ptab;
+	std::vector<uint2> near;
 	std::vector<uint4> far_head((size_t) (r > 0 ? r : 1), uint4{BS_NONE, 0u, BS_NONE, 0u});
 	std::vector<uint64_t> far_rp((size_t) r + 1, 0);
 	std::vector<uint2> far;
 	std::vector<uint64_t> far_cnt((size_t) (r > 0 ? r : 1), 0);
-	// first pass: chunk boundaries (a chunk grows downwards while its rows, the dependencies they have inside the
-	// chunk and the levels holding such rows fit the LDS arrays of the kernel)
+	// first pass: chunk boundaries (a chunk grows downwards while its rows, the passes of its rows that have
+	// dependencies inside the chunk -- 32 rows of one level each -- and the dependencies beyond the second fit the LDS
+	// arrays of the kernel)
 	int hi = r;
 	while (hi > 0) {
 		BsChunk ch{};
 		ch.hi = hi;
-		int lo = hi, nnear = 0, nsteps = 0, nbrow = 0, last_level = -1;
+		int lo = hi, nnear = 0, npass = 0, in_level = 0, last_level = -1;
 		while (lo > 0 && hi - lo < BS_RING) {
 			const int c = lo - 1;
 			int nc = 0;
 			for (uint64_t e = dep_rp[c]; e < dep_rp[c + 1]; e++)
 				nc += dep[e].x < (uint32_t) hi;
-			const bool new_step = nc > 0 && level[c] != last_level;
-			if (nnear + nc > BS_NEARCAP || nc > 65535 || (new_step && nsteps + 1 > BS_STEPCAP))
+			const bool new_pass = nc > 0 && (level[c] != last_level || in_level % BS_PASSROWS == 0);
+			const int extra = nc > 2 ? nc - 1 : 0;
+			if (nnear + extra > BS_NEARCAP || nc > 65535 || (new_pass && npass + 1 > BS_PASSCAP))
 				break;                           // (the first row of a chunk never has dependencies inside it)
 			if (nc > 0) {
-				nsteps += new_step ? 1 : 0;
+				if (level[c] != last_level)
+					in_level = 0;
+				npass += new_pass ? 1 : 0;
+				in_level += 1;
 				last_level = level[c];
-				nbrow += 1;
-				nnear += nc;
+				nnear += extra;
 			}
 			lo = c;
 		}
 		ch.lo = lo;
-		ch.nsteps = nsteps;
+		ch.npass = npass;
 		ch.nnear = nnear;
-		ch.nbrow = nbrow;
 		chunks.push_back(ch);
 		chunk_extra.push_back(0);
 		hi = lo;
 	}
-	// second pass: the lists of every chunk, slots relative to its first row
+	// second pass: the tables of every chunk, slots relative to its first row
 	{
 		for (size_t k = 0; k < chunks.size(); k++) {
 			BsChunk &ch = chunks[k];
-			ch.step0 = (int) steps.size();
+			ch.pass0 = (int) (ptab.size() / BS_PASSROWS);
 			ch.near0 = (int) near.size();
-			ch.brow0 = (int) brow.size();
-			int last_level = -1, extra = 0;
+			int last_level = -1, extra = 0, in_level = 0;
 			for (int c = ch.hi - 1; c >= ch.lo; c--) {
 				int nc = 0, nf = 0;
 				for (uint64_t e = dep_rp[c]; e < dep_rp[c + 1]; e++) {
@@ -1491,22 +1494,41 @@ void backsolve_plan(const FactPlan &P, spasm_hip_dfact *F, hipStream_t stream)
 				}
 				if (nc == 0)
 					continue;
-				if (level[c] != last_level) {
-					if (last_level >= 0)
-						steps.back().y = (int) brow.size() - ch.brow0;
-					steps.push_back(int2{(int) brow.size() - ch.brow0, 0});
+				if (level[c] != last_level || in_level % BS_PASSROWS == 0) {
+					// a new pass: the previous one is padded with empty entries
+					while (ptab.size() % BS_PASSROWS != 0)
+						ptab.push_back(uint4{0u, 0u, 0u, 0u});
+					if (level[c] != last_level)
+						in_level = 0;
 					last_level = level[c];
 				}
-				brow.push_back(uint2{(uint32_t) (c - ch.lo) | ((uint32_t) nc << 16), (uint32_t) ((int) near.size() - ch.near0)});
-				for (uint64_t e = dep_rp[c]; e < dep_rp[c + 1]; e++)
-					if (dep[e].x < (uint32_t) ch.hi)
-						near.push_back(uint2{dep[e].x - (uint32_t) ch.lo, dep[e].y});
+				in_level += 1;
+				uint4 en{(uint32_t) (c - ch.lo) | ((uint32_t) nc << 16), 0u, 0u, 0u};
+				int seen = 0;
+				for (uint64_t e = dep_rp[c]; e < dep_rp[c + 1]; e++) {
+					if (dep[e].x >= (uint32_t) ch.hi)
+						continue;
+					const uint32_t slot = dep[e].x - (uint32_t) ch.lo;
+					if (seen == 0) {
+						en.y = slot | (slot << 16);          // (one dependency: the second slot repeats it with coefficient 0)
+						en.z = dep[e].y;
+						if (nc > 2)
+							en.w = (uint32_t) ((int) near.size() - ch.near0);
+					} else if (nc == 2) {
+						en.y = (en.y & 0xFFFFu) | (slot << 16);
+						en.w = dep[e].y;
+					} else {
+						near.push_back(uint2{slot, dep[e].y});
+					}
+					seen += 1;
+				}
+				ptab.push_back(en);
 			}
-			if (last_level >= 0)
-				steps.back().y = (int) brow.size() - ch.brow0;
-			if ((int) steps.size() - ch.step0 != ch.nsteps || (int) near.size() - ch.near0 != ch.nnear ||
-			    (int) brow.size() - ch.brow0 != ch.nbrow)
-				die("backsolve_plan: chunk %zu was counted differently on the second pass", k);
+			while (ptab.size() % BS_PASSROWS != 0)
+				ptab.push_back(uint4{0u, 0u, 0u, 0u});
+			if ((int) (ptab.size() / BS_PASSROWS) - ch.pass0 != ch.npass || (int) near.size() - ch.near0 != ch.nnear)
+				die("backsolve_plan: chunk %zu was counted differently on the second pass (%d passes against %d, %d list entries against %d)", k,
+				    (int) (ptab.size() / BS_PASSROWS) - ch.pass0, ch.npass, (int) near.size() - ch.near0, ch.nnear);
 			chunk_extra[k] = extra;
 		}
 	}
@@ -1534,6 +1556,24 @@ void backsolve_plan(const FactPlan &P, spasm_hip_dfact *F, hipStream_t stream)
 		}
 	}
 
+	if (env_bs("SPASM_HIP_BS_STATS", 0)) {
+		// shape of the plan (tuning aid)
+		int64_t cnt_hist[6] = {0, 0, 0, 0, 0, 0}, empty = 0;
+		for (size_t t = 0; t < ptab.size(); t++) {
+			const int c = (int) (ptab[t].x >> 16);
+			cnt_hist[c < 5 ? c : 5] += 1;
+			empty += c == 0;
+		}
+		int64_t far2 = 0, far1 = 0;
+		for (int c = 0; c < r; c++) {
+			far1 += far_head[c].x != BS_NONE;
+			far2 += far_head[c].z != BS_NONE;
+		}
+		fprintf(stderr, "[bs plan] r %d, Sm %d, levels %d, chunks %zu, passes of 32 rows %zu (%lld empty slots), rows with dependencies inside their chunk: 1: %lld, 2: %lld, 3: %lld, "
+		        "4: %lld, 5+: %lld; list %zu, far heads %lld + %lld, far rest %llu, np %zu\n",
+		        r, B.Sm, P.nlevels, chunks.size(), ptab.size() / BS_PASSROWS, (long long) empty, (long long) cnt_hist[1], (long long) cnt_hist[2], (long long) cnt_hist[3],
+		        (long long) cnt_hist[4], (long long) cnt_hist[5], near.size(), (long long) far1, (long long) far2, (unsigned long long) far_rp[r], np.size());
+	}
 	B.nchunks = (int) chunks.size();
 	B.nnear = (int64_t) near.size();
 	B.nfar = (int64_t) far_rp[r];
@@ -1541,8 +1581,7 @@ void backsolve_plan(const FactPlan &P, spasm_hip_dfact *F, hipStream_t stream)
 	B.ndeps = (int64_t) dep.size();
 	B.d_col = dalloc<int>(m);
 	B.d_chunk = dalloc<BsChunk>((int64_t) chunks.size());
-	B.d_step = dalloc<int2>((int64_t) steps.size());
-	B.d_brow = dalloc<uint2>((int64_t) brow.size());
+	B.d_ptab = dalloc<uint4>((int64_t) ptab.size());
 	B.d_near = dalloc<uint2>((int64_t) near.size());
 	B.d_far_head = dalloc<uint4>(r);
 	B.d_far_rp = dalloc<uint64_t>((int64_t) r + 1);
@@ -1554,8 +1593,7 @@ void backsolve_plan(const FactPlan &P, spasm_hip_dfact *F, hipStream_t stream)
 	upload(B.d_col, colmap, stream);
 	upload(B.d_chunk, chunks, stream);
 	upload(B.d_chunk_extra, chunk_extra, stream);
-	upload(B.d_step, steps, stream);
-	upload(B.d_brow, brow, stream);
+	upload(B.d_ptab, ptab, stream);
 	upload(B.d_near, near, stream);
 	upload(B.d_far_head, far_head, stream);
 	upload(B.d_far_rp, far_rp, stream);
@@ -1575,8 +1613,7 @@ void backsolve_free(spasm_hip_dfact *F)
 	(void) hipFree(B.d_col);
 	(void) hipFree(B.d_chunk);
 	(void) hipFree(B.d_chunk_extra);
-	(void) hipFree(B.d_step);
-	(void) hipFree(B.d_brow);
+	(void) hipFree(B.d_ptab);
 	(void) hipFree(B.d_near);
 	(void) hipFree(B.d_far_head);
 	(void) hipFree(B.d_far_rp);
@@ -1621,8 +1658,7 @@ void backsolve_build(const spasm_hip_dfact *F, hipStream_t stream)
 	b.nchunks = B.nchunks;
 	b.chunk = B.d_chunk;
 	b.chunk_extra = B.d_chunk_extra;
-	b.step = B.d_step;
-	b.brow = B.d_brow;
+	b.ptab = B.d_ptab;
 	b.near = B.d_near;
 	b.far_head = B.d_far_head;
 	b.far_rp = B.d_far_rp;
@@ -1828,7 +1864,7 @@ void launch_backsolve_apply(const SchurArgs &a, const spasm_hip_dfact *F, uint32
 				hipLaunchKernelGGL(bs_apply_s16_kernel, dim3(blocks2), dim3(64 * d.waves), lds, stream, d2);
 				hipLaunchKernelGGL(bs_scan_lengths_kernel, dim3(nblocks), dim3(SCAN_BLOCK), 0, stream, a.row_len + r0, n, d2.block_sum, direct->Sp + r0,
 				                   direct->cap, a.ctr);
-				ExpandArgs e{direct->stage, nwords, n, direct->Sp + r0, direct->Sj, direct->Sx, direct->cap, a.q, d.G};
+				ExpandArgs e{direct->stage, nwords, n, direct->Sp + r0, direct->Sj, direct->Sx, direct->cap, a.q, d.G, d.dbg};
 				const int blocks3 = std::max(1, std::min((n + 3) / 4, prop.multiProcessorCount * 8));
 				hipLaunchKernelGGL(bs_expand_s16_kernel, dim3(blocks3), dim3(256), 0, stream, e);
 			}

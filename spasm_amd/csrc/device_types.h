@@ -129,9 +129,9 @@ struct FactPlan {
 // Rows are numbered by COMPACT id = rank of their label among the labels that hold a row (so level order).
 struct BsChunk {              // a run of consecutive compact rows solved inside LDS by one workgroup per column slab
 	int lo, hi;               // compact rows [lo, hi)
-	int step0, nsteps;        // phase-B steps (one per level that has rows with dependencies inside the chunk)
-	int near0, nnear;         // their entries: (slot of the dependency, value * 2^32 mod p)
-	int brow0, nbrow;         // rows with dependencies inside the chunk: (slot | count << 16, first entry - near0)
+	int pass0, npass;         // phase-B passes of 32 rows (rows of one level that have dependencies inside the chunk)
+	int near0, nnear;         // dependencies of the rows that have more than two of them inside the chunk
+	int pad0, pad1;
 };
 
 struct BsImage {
@@ -146,9 +146,9 @@ struct BsImage {
 	bool sgn = false;                 // ... negated balanced residues, and R holds signed 16-bit entries (small p: backsolve.hip, SgnDev)
 	int *d_col = nullptr;             // column -> compact row id of its pivot, or r + index among the non-pivotal columns
 	BsChunk *d_chunk = nullptr;
-	int2 *d_step = nullptr;           // [first, last) into d_brow
-	uint2 *d_brow = nullptr;
-	uint2 *d_near = nullptr;
+	uint4 *d_ptab = nullptr;          // 32 entries per pass: (slot | count << 16, dep0 | dep1 << 16, coefficient 0, coefficient 1); a row
+	                                  // with more than two dependencies keeps the first inline, (offset into d_near - near0) in .w, the others there
+	uint2 *d_near = nullptr;          // (slot of the dependency, coefficient)
 	uint4 *d_far_head = nullptr;      // per compact row: its first two dependencies outside the chunk (t0, y0, t1, y1); t = ~0: none
 	uint64_t *d_far_rp = nullptr;     // per compact row: the others, [r + 1] offsets into d_far
 	uint2 *d_far = nullptr;
