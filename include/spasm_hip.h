@@ -251,11 +251,16 @@ typedef struct {
 	int used_backsolve;     /* 1: the rows were computed from the back-substituted factor image (S = A_n - A_p R) */
 	int backsolve_built;    /* 1: ... and R was (re)built by this call (ms_backsolve, bytes_backsolve say at what cost) */
 	float ms_backsolve;     /* device time of building R = U_pp^-1 U_pn (memset + init + backsolve_kernel) */
-	float ms_apply;         /* device time of bs_apply_kernel (S rows from R) */
+	float ms_apply;         /* device time of the apply kernel (S rows from R): bs_apply_kernel, or bs_apply_s16_kernel */
 	i64 bytes_backsolve;    /* algorithmic bytes of that build */
 	i64 bytes_apply;        /* ... of the apply kernel */
 	char kernel[64];        /* name of the dominant elimination kernel this call launched, as rocprofv3 shows it */
 	char kernel_other[64];  /* back-substituted path: the other of its two kernels (build of R / apply) */
+	float ms_expand;        /* staged output (small primes): device time of bs_expand_s16_kernel, not part of ms_apply; else 0 */
+	float ms_pad;
+	i64 bytes_expand;       /* ... its algorithmic bytes (the entries of S written); they are then not part of bytes_apply */
+	i64 bytes_staged;       /* ... bytes of the packed rows in between (written by the apply kernel, read by the expansion) */
+	char kernel_expand[64]; /* ... its name, or "" */
 } spasm_hip_schur_stats;
 
 /* S = Schur complement of rows d_rows[0..nrows) of A w.r.t. F, left in the

@@ -1782,7 +1782,7 @@ bool backsolve_stages_output(const spasm_hip_dfact *F, int64_t *row_bytes)
 
 // S rows from R: sparse rows into the pool of `a` (dense_out == nullptr) or dense rows.
 void launch_backsolve_apply(const SchurArgs &a, const spasm_hip_dfact *F, uint32_t *dense_out, int64_t ldS, hipStream_t stream,
-                            const BsDirectOut *direct)
+                            BsDirectOut *direct)
 {
 	const BsImage &B = F->bs;
 	if (!B.valid)
@@ -1866,7 +1866,11 @@ void launch_backsolve_apply(const SchurArgs &a, const spasm_hip_dfact *F, uint32
 				                   direct->cap, a.ctr);
 				ExpandArgs e{direct->stage, nwords, n, direct->Sp + r0, direct->Sj, direct->Sx, direct->cap, a.q, d.G, d.dbg};
 				const int blocks3 = std::max(1, std::min((n + 3) / 4, prop.multiProcessorCount * 8));
+				if (direct->ev_expand != nullptr)
+					HIP_CHECK(hipEventRecord(direct->ev_expand, stream));
 				hipLaunchKernelGGL(bs_expand_s16_kernel, dim3(blocks3), dim3(256), 0, stream, e);
+				direct->staged = true;
+				direct->slices += 1;
 			}
 		} else {
 			hipLaunchKernelGGL(bs_apply_s16_kernel, dim3(blocks), dim3(64 * d.waves), lds, stream, d);

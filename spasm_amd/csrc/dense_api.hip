@@ -30,7 +30,7 @@ void launch_schur_wave_dense(const SchurArgs &a, unsigned char *scratch, int64_t
                              bool wide, uint32_t *dense_out, int64_t ldS, int blocks, hipStream_t stream);
 void backsolve_build(const spasm_hip_dfact *F, hipStream_t stream);
 void launch_backsolve_apply(const SchurArgs &a, const spasm_hip_dfact *F, uint32_t *dense_out, int64_t ldS, hipStream_t stream,
-                            const BsDirectOut *direct);
+                            BsDirectOut *direct);
 bool backsolve_wanted(const spasm_hip_dfact *F, bool other_path_forced);
 }  // namespace sh
 

@@ -189,6 +189,9 @@ struct BsDirectOut {
 	// staged output (signed 16-bit entries, backsolve.hip): room for stage_rows packed rows; nullptr: look-back output
 	uint32_t *stage = nullptr;
 	int64_t stage_rows = 0;
+	hipEvent_t ev_expand = nullptr;   // recorded before the (last) expansion kernel
+	bool staged = false;              // set by the launch: the staged output ran
+	int slices = 0;
 };
 
 }  // namespace sh
@@ -240,7 +243,7 @@ struct spasm_hip_dwork {
 	int64_t scratch_budget = 0;           // 0: up to half of the free HBM; else a cap in bytes
 	int scratch_slots = 0;
 	int64_t slot_bytes = 0, off_bm = 0, off_xn = 0;
-	hipEvent_t ev[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+	hipEvent_t ev[7] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
 	int last_rows = 0;
 	int64_t last_nnz = 0;
 };

@@ -31,7 +31,7 @@ void backsolve_free(spasm_hip_dfact *F);
 void backsolve_build(const spasm_hip_dfact *F, hipStream_t stream);
 bool backsolve_stages_output(const spasm_hip_dfact *F, int64_t *row_bytes);
 void launch_backsolve_apply(const SchurArgs &a, const spasm_hip_dfact *F, uint32_t *dense_out, int64_t ldS, hipStream_t stream,
-                            const BsDirectOut *direct);
+                            BsDirectOut *direct);
 bool backsolve_wanted(const spasm_hip_dfact *F, bool other_path_forced);
 // multi-GPU layer (dist_api.hip)
 spasm_hip_comm *current_comm();
@@ -692,7 +692,7 @@ spasm_hip_dwork *spasm_hip_dwork_create(int max_rows, int m, i64 pool_entries)
 	W->d_blocksum = dalloc<int64_t>((max_rows + 1023) / 1024 + 1);
 	W->d_ctr = dalloc<int>(CTR_COUNT);
 	W->d_ctr64 = dalloc<unsigned long long>(C64_COUNT);
-	for (int e = 0; e < 6; e++)
+	for (int e = 0; e < 7; e++)
 		HIP_CHECK(hipEventCreate(&W->ev[e]));
 	return W;
 }
@@ -722,7 +722,7 @@ void spasm_hip_dwork_destroy(spasm_hip_dwork *W)
 	(void) hipFree(W->d_ctr);
 	(void) hipFree(W->d_ctr64);
 	(void) hipFree(W->d_scratch);
-	for (int e = 0; e < 6; e++)
+	for (int e = 0; e < 7; e++)
 		if (W->ev[e] != nullptr)
 			(void) hipEventDestroy(W->ev[e]);
 	delete W;
@@ -868,6 +868,7 @@ int dschur_impl(const spasm_hip_dcsr *A, const int *d_rows, int nrows, const spa
 	}
 
 	bool used_bs = false, built_bs = false, bs_direct = false, use_pull = false;
+	int bs_staged_slices = 0;          // staged output of the back-substituted path: slices it ran in (0: not used)
 	if (want_bs) {
 		// R is built on first use
 		used_bs = true;
@@ -905,8 +906,10 @@ int dschur_impl(const spasm_hip_dcsr *A, const int *d_rows, int nrows, const spa
 					W->stage_bytes = need;
 				}
 				out.stage = W->d_stage;
+				out.ev_expand = W->ev[6];
 			}
 			launch_backsolve_apply(a, F, nullptr, 0, stream, &out);
+			bs_staged_slices = out.staged ? out.slices : 0;
 		} else {
 			launch_backsolve_apply(a, F, nullptr, 0, stream, nullptr);
 		}
@@ -1068,6 +1071,9 @@ eliminated:
 		stats->bytes_backsolve = stats->bytes_apply = 0;
 		stats->kernel[0] = 0;
 		stats->kernel_other[0] = 0;
+		stats->kernel_expand[0] = 0;
+		stats->ms_expand = stats->ms_pad = 0.0f;
+		stats->bytes_expand = stats->bytes_staged = 0;
 		if (used_bs) {
 			const BsImage &B = F->bs;
 			if (built_bs) {
@@ -1078,6 +1084,17 @@ eliminated:
 			HIP_CHECK(hipEventElapsedTime(&stats->ms_apply, W->ev[5], W->ev[1]));
 			// one row of R per pivotal entry of the reduced rows, the entries in and out, 20 B per row
 			stats->bytes_apply = (i64) ctr64[C64_ELIM] * (i64) B.Sm * B.elem_bytes + 8 * ((i64) ctr64[C64_INPUT] + total) + 20 * (i64) nrows;
+			if (bs_staged_slices > 0) {
+				// staged output: the entries of S leave through bs_expand_s16_kernel; with one slice the two kernels are timed apart
+				stats->bytes_apply -= 8 * total;
+				stats->bytes_expand = 8 * total;
+				stats->bytes_staged = (i64) nrows * B.ldR * 2;
+				snprintf(stats->kernel_expand, sizeof(stats->kernel_expand), "bs_expand_s16_kernel");
+				if (bs_staged_slices == 1) {
+					HIP_CHECK(hipEventElapsedTime(&stats->ms_apply, W->ev[5], W->ev[6]));
+					HIP_CHECK(hipEventElapsedTime(&stats->ms_expand, W->ev[6], W->ev[1]));
+				}
+			}
 			char apply_name[32];
 			if (B.sgn)
 				snprintf(apply_name, sizeof(apply_name), "bs_apply_s16_kernel");

@@ -83,7 +83,8 @@ class CSchurStats(C.Structure):    # spasm_hip_schur_stats
                 ("ms_tier2", C.c_float), ("ms_finalize", C.c_float), ("ms_total", C.c_float),
                 ("used_backsolve", C.c_int), ("backsolve_built", C.c_int), ("ms_backsolve", C.c_float), ("ms_apply", C.c_float),
                 ("bytes_backsolve", C.c_int64), ("bytes_apply", C.c_int64), ("kernel", C.c_char * 64),
-                ("kernel_other", C.c_char * 64)]
+                ("kernel_other", C.c_char * 64), ("ms_expand", C.c_float), ("ms_pad", C.c_float), ("bytes_expand", C.c_int64),
+                ("bytes_staged", C.c_int64), ("kernel_expand", C.c_char * 64)]
 
 
 def field_of(prime):
