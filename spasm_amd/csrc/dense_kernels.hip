@@ -586,6 +586,14 @@ struct BlockGjArgs {
 	const int *try_rows, *try_count;
 	int *gj_done, *try_state;
 	int panel_index;
+	// optimistic super-panels (driver): the panel steps are enqueued without the selection kernels; a try that cannot
+	// finish its panel raises *abort (1 + abort_value) and every later kernel of the super-panel returns at once
+	int *abort;
+	int abort_value;
+	// ... and rref_try_inverse finds the first free rows itself (what rref_first_free does in its own launch otherwise):
+	// ff_flags != null: scan from *ff_hint, write try_rows / *try_count through ff_out / ff_count
+	const int *ff_flags;
+	int *ff_hint, *ff_out, *ff_count;
 	MontDev F;
 };
 
@@ -824,10 +832,36 @@ __global__ __launch_bounds__(256) void rref_try_inverse(BlockGjArgs g)
 	__shared__ int prow[NB], sigma[NB], prow_of[NB], s_rows[NB];
 	const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
 	const MontDev F = g.F;
-	const bool skip = g.try_state[0] >= 2 && (g.panel_index & 7) != 0;
+	if (g.abort != nullptr && *g.abort != 0)
+		return;
+	if (g.ff_flags != nullptr) {
+		if (w == 0) {
+			int found = 0, first = -1;
+			for (int base = *g.ff_hint; base < g.n && found < NB; base += 64) {
+				const int i = base + lane;
+				const bool fr = i < g.n && g.ff_flags[i] == 0;
+				const unsigned long long mk = __ballot(fr);
+				const int pos = found + __popcll(mk & ((1ull << lane) - 1ull));
+				if (fr && pos < NB)
+					g.ff_out[pos] = i;
+				if (first < 0 && mk != 0)
+					first = base + __builtin_ctzll(mk);
+				found += __popcll(mk);
+			}
+			if (lane == 0) {
+				*g.ff_count = min(found, NB);
+				*g.ff_hint = (first >= 0) ? first : g.n;
+			}
+		}
+		__syncthreads();
+	}
+	const bool skip = g.abort == nullptr && g.try_state[0] >= 2 && (g.panel_index & 7) != 0;
 	if (skip || *g.try_count < NB || g.width < NB) {
-		if (tid == 0)
+		if (tid == 0) {
 			*g.gj_done = 0;
+			if (g.abort != nullptr)
+				*g.abort = 1 + g.abort_value;
+		}
 		return;
 	}
 	{
@@ -873,6 +907,8 @@ __global__ __launch_bounds__(256) void rref_try_inverse(BlockGjArgs g)
 				if (tid == 0) {
 					*g.gj_done = 0;
 					g.try_state[0] = g.try_state[0] + 1;
+					if (g.abort != nullptr)
+						*g.abort = 1 + g.abort_value;
 				}
 				return;
 			}
@@ -952,12 +988,34 @@ __device__ __forceinline__ void split_digits(uint32_t v, const MontDev &F, int &
 }
 
 // SMALL16 (p < 2^16): plain 24-bit products summed in 64 bits, one reduction per multiplier.
-template <bool SMALL16>
-__global__ __launch_bounds__(256) void rref_multipliers(const uint32_t *A, int64_t ld, int n, int m, int c0, const uint32_t *Ginv,
-                                                        const int *gamma, const int *knew, uint32_t *P, MontDev F,
-                                                        const int *rho, const int *cand_pivot, signed char *Mh, signed char *Ml,
-                                                        uint32_t *Zblk = nullptr, int64_t ldz = 0)          // Zblk: M as 64 columns of Z (residues)
+struct MultArgs {
+	const uint32_t *A;
+	int64_t ld;
+	int n, m, c0;
+	const uint32_t *Ginv;
+	const int *gamma, *knew;
+	uint32_t *P;
+	MontDev F;
+	const int *rho, *cand_pivot;
+	signed char *Mh, *Ml;
+	uint32_t *Zblk;               // M as 64 columns of Z (residues), or null
+	int64_t ldz;
+	const int *abort;
+};
+
+template <bool SMALL16> __device__ __forceinline__ void multipliers_body(const int bx, const MultArgs &g)
 {
+	const uint32_t *A = g.A;
+	const int64_t ld = g.ld;
+	const int n = g.n, m = g.m, c0 = g.c0;
+	const uint32_t *Ginv = g.Ginv;
+	const int *gamma = g.gamma, *knew = g.knew, *rho = g.rho, *cand_pivot = g.cand_pivot;
+	uint32_t *P = g.P, *Zblk = g.Zblk;
+	const MontDev F = g.F;
+	signed char *Mh = g.Mh, *Ml = g.Ml;
+	const int64_t ldz = g.ldz;
+	if (g.abort != nullptr && *g.abort != 0)
+		return;
 	__shared__ uint32_t sG[NB][NB + 1];
 	__shared__ int sgam[NB], srho[NB], spiv[NB];
 	const int k = *knew;
@@ -965,7 +1023,7 @@ __global__ __launch_bounds__(256) void rref_multipliers(const uint32_t *A, int64
 	if (k == 0) {
 		// no pivot in this panel: all-zero digit planes (the update kernels multiply every set)
 		if (Mh != nullptr) {
-			const int i = blockIdx.x * 64 + (tid & 63), q = tid >> 6;
+			const int i = bx * 64 + (tid & 63), q = tid >> 6;
 			if (i < n) {
 				*reinterpret_cast<int4 *>(Mh + (int64_t) i * 64 + q * 16) = make_int4(0, 0, 0, 0);
 				*reinterpret_cast<int4 *>(Ml + (int64_t) i * 64 + q * 16) = make_int4(0, 0, 0, 0);
@@ -988,12 +1046,12 @@ __global__ __launch_bounds__(256) void rref_multipliers(const uint32_t *A, int64
 	__shared__ uint32_t tile[64][NB + 1];
 	for (int t = tid; t < 64 * NB; t += 256) {
 		const int rr = t / NB, cc = t % NB;
-		const int irow = blockIdx.x * 64 + rr;
+		const int irow = bx * 64 + rr;
 		tile[rr][cc] = (irow < n && c0 + cc < m) ? A[(int64_t) irow * ld + c0 + cc] : 0u;
 	}
 	__syncthreads();
 	// 64 rows per workgroup: thread (tid & 63) = row, (tid >> 6) = quarter of the r range
-	const int i = blockIdx.x * 64 + (tid & 63);
+	const int i = bx * 64 + (tid & 63);
 	const int q = tid >> 6;
 	if (i >= n)
 		return;
@@ -1058,6 +1116,11 @@ __global__ __launch_bounds__(256) void rref_multipliers(const uint32_t *A, int64
 		*reinterpret_cast<int4 *>(Mh + (int64_t) i * 64 + q * 16) = make_int4((int) wh[0], (int) wh[1], (int) wh[2], (int) wh[3]);
 		*reinterpret_cast<int4 *>(Ml + (int64_t) i * 64 + q * 16) = make_int4((int) wl[0], (int) wl[1], (int) wl[2], (int) wl[3]);
 	}
+}
+
+template <bool SMALL16> __global__ __launch_bounds__(256) void rref_multipliers(MultArgs g)
+{
+	multipliers_body<SMALL16>((int) blockIdx.x, g);
 }
 
 
@@ -1245,21 +1308,43 @@ struct UpdSets {
 	uint32_t *Z2;
 	int64_t ld2;
 	int tiles1, mr2;
+	const int *abort;               // optimistic super-panels: not null and raised -> the launch does nothing
 };
 
 
 // B[t, :] = A[rho[t], c1 : c1 + mr] (old values of the new pivot rows) as digit planes, one thread per column; the
 // 32-bit copy is written too when B is not null (VALU update)
-__global__ __launch_bounds__(256) void rref_gather_split_B(const uint32_t *A, int64_t ld, int c1, int mr, const int *rho, const int *knew,
-                                                           signed char *Bh, signed char *Bl, uint32_t *B, MontDev F,
-                                                           const uint32_t *Z2 = nullptr, int64_t ld2 = 0, int tiles1 = 0, int mr2 = 0)
+struct GatherArgs {
+	const uint32_t *A;
+	int64_t ld;
+	int c1, mr;
+	const int *rho, *knew;
+	signed char *Bh, *Bl;
+	uint32_t *B;
+	MontDev F;
+	const uint32_t *Z2;
+	int64_t ld2;
+	int tiles1, mr2;
+	const int *abort;
+};
+
+__device__ __forceinline__ void gather_split_body(const int bx, const GatherArgs &g)
 {
 	__shared__ int srho[NB];
+	const uint32_t *A = g.A, *Z2 = g.Z2;
+	const int64_t ld = g.ld, ld2 = g.ld2;
+	const int c1 = g.c1, mr = g.mr, tiles1 = g.tiles1, mr2 = g.mr2;
+	const int *rho = g.rho, *knew = g.knew;
+	signed char *Bh = g.Bh, *Bl = g.Bl;
+	uint32_t *B = g.B;
+	const MontDev F = g.F;
+	if (g.abort != nullptr && *g.abort != 0)
+		return;
 	const int k = *knew;
 	if (threadIdx.x < NB)
 		srho[threadIdx.x] = (threadIdx.x < k) ? rho[threadIdx.x] : 0;
 	__syncthreads();
-	int col = blockIdx.x * 256 + threadIdx.x;
+	int col = bx * 256 + threadIdx.x;
 	const uint32_t *src = A + c1;
 	int64_t lds = ld;
 	int plane_col = col;
@@ -1290,6 +1375,41 @@ __global__ __launch_bounds__(256) void rref_gather_split_B(const uint32_t *A, in
 		dh[part] = make_int4((int) wh[0], (int) wh[1], (int) wh[2], (int) wh[3]);
 		dl[part] = make_int4((int) wl[0], (int) wl[1], (int) wl[2], (int) wl[3]);
 	}
+}
+
+__global__ __launch_bounds__(256) void rref_gather_split_B(GatherArgs g)
+{
+	gather_split_body((int) blockIdx.x, g);
+}
+
+// the same for every set of a super-panel in one launch (blockIdx.y = set)
+struct GatherSets {
+	const int *rho[MAXSETS], *knew[MAXSETS];
+	signed char *Bh[MAXSETS], *Bl[MAXSETS];
+};
+
+__global__ __launch_bounds__(256) void rref_gather_split_sets(const uint32_t *A, int64_t ld, int c1, int mr, GatherSets gs, MontDev F)
+{
+	GatherArgs g{A, ld, c1, mr, nullptr, nullptr, nullptr, nullptr, nullptr, F, nullptr, 0, 0, 0, nullptr};
+#pragma unroll
+	for (int s = 0; s < MAXSETS; s++)          // (static indices into the kernel arguments)
+		if (s == (int) blockIdx.y) {
+			g.rho = gs.rho[s];
+			g.knew = gs.knew[s];
+			g.Bh = gs.Bh[s];
+			g.Bl = gs.Bl[s];
+		}
+	gather_split_body((int) blockIdx.x, g);
+}
+
+// both in one launch (they depend on the same Gauss-Jordan block and not on each other; a launch in a chain of dependent
+// launches costs ~8 us of idle device): workgroups 0 .. nmult - 1 compute multipliers, the others gather
+template <bool SMALL16> __global__ __launch_bounds__(256) void rref_mult_gather(MultArgs a, GatherArgs b, int nmult)
+{
+	if ((int) blockIdx.x < nmult)
+		multipliers_body<SMALL16>((int) blockIdx.x, a);
+	else
+		gather_split_body((int) blockIdx.x - nmult, b);
 }
 
 // digit planes of the accumulated multipliers Z[:, 64 s .. 64 s + 63] (set s), one thread per (row, 16 columns)
@@ -1391,6 +1511,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
 {
 	__shared__ __attribute__((aligned(16))) signed char Mhi[64][64 + 16], Mlo[64][64 + 16];   // [row][k]
 	__shared__ __attribute__((aligned(16))) signed char Bhi[64][64 + 16], Blo[64][64 + 16];   // [col][k]  (transposed)
+	if (S.abort != nullptr && *S.abort != 0)
+		return;
 	const int tid = threadIdx.x;
 	const int row0 = blockIdx.y * 64;
 	int col0 = blockIdx.x * 64;
@@ -1612,6 +1734,9 @@ int device_rref(int64_t prime, int n, int m, uint32_t *dA, int64_t ld, int *d_pi
 		const int64_t ldz = (int64_t) MAXSETS * NB;
 		signed char *Bown_h = B8 + (size_t) MAXSETS * 2 * (size_t) m * 64, *Bown_l = Bown_h + (size_t) (2 * MAXSETS * NB + 64) * 64;
 		bool far_pending = false;
+		const bool optimistic_enabled = std::getenv("SPASM_HIP_RREF_OPTIMISTIC") == nullptr || std::atoi(std::getenv("SPASM_HIP_RREF_OPTIMISTIC")) != 0;
+		bool optimistic_ok = optimistic_enabled;
+		int optimistic_skip = 0;
 		uint32_t *set_P[MAXSETS] = {};
 		int *set_rho[MAXSETS] = {}, *set_knew[MAXSETS] = {};
 		signed char *set_Mh[MAXSETS] = {}, *set_Ml[MAXSETS] = {};
@@ -1633,15 +1758,17 @@ int device_rref(int64_t prime, int n, int m, uint32_t *dA, int64_t ld, int *d_pi
 			const int sp_end = std::min(m, sp0 + SPW * NB);
 			const int mrT = m - sp_end;              // columns beyond the super-panel
 			UpdSets S{};
-			int nsets = 0;
-			for (int c0 = sp0; c0 < sp_end; c0 += NB, nsets++) {
+			int *abort_d = full_flag + 12;          // optimistic super-panels: raised by a try that cannot finish its panel
+			auto run_panel = [&](int c0, int nsets, bool optimistic) {
+				const int *abort_c = optimistic ? abort_d : nullptr;
 				const int width = std::min(NB, m - c0);
 				// (sets alternate between two halves by super-panel: the far update of the previous super-panel may
 				//  still be reading its multipliers on the second stream)
 				const int slot = (spi & 1) * MAXSETS + nsets;
 				uint32_t *P_s = P4 + (size_t) slot * (size_t) n * PW;
 				int *rho_s = rho4 + slot * NB, *knew_s = knew4 + slot * 16;
-				hipLaunchKernelGGL(rref_first_free, dim3(1), dim3(64), 0, stream, flags, n, free_count + 4, first64, free_count + 2);
+				if (!optimistic)
+					hipLaunchKernelGGL(rref_first_free, dim3(1), dim3(64), 0, stream, flags, n, free_count + 4, first64, free_count + 2);
 				// Gauss-Jordan straight on the first 64 free rows (try mode): when they give a pivot in every column of the
 				// panel (the usual case while the block is not exhausted) everything up to the regular call returns at once
 				BlockGjArgs bg;
@@ -1670,6 +1797,12 @@ int device_rref(int64_t prime, int n, int m, uint32_t *dA, int64_t ld, int *d_pi
 				bg.gj_done = full_flag + 4;
 				bg.try_state = full_flag + 8;
 				bg.panel_index = c0 / NB;
+				bg.abort = optimistic ? abort_d : nullptr;
+				bg.abort_value = nsets;
+				bg.ff_flags = optimistic ? flags : nullptr;
+				bg.ff_hint = free_count + 4;
+				bg.ff_out = first64;
+				bg.ff_count = free_count + 2;
 				if (try_first) {
 					if (fast_try)
 						hipLaunchKernelGGL(rref_try_inverse, dim3(1), dim3(256), invtab_bytes, stream, bg);
@@ -1678,6 +1811,7 @@ int device_rref(int64_t prime, int n, int m, uint32_t *dA, int64_t ld, int *d_pi
 					else
 						hipLaunchKernelGGL((rref_block_gj<false, 8>), dim3(1), dim3(1024), 0, stream, bg);
 				}
+				if (!optimistic) {
 				// the first 64 free rows alone, by selection (when the try was skipped or failed)
 				if (small_prime)
 					hipLaunchKernelGGL(rref_select_first<true>, dim3(1), dim3(256), 0, stream, dA, ld, c0, width, first64, free_count + 2,
@@ -1711,17 +1845,11 @@ int device_rref(int64_t prime, int n, int m, uint32_t *dA, int64_t ld, int *d_pi
 					hipLaunchKernelGGL((rref_block_gj<true, 8>), dim3(1), dim3(1024), invtab_bytes, stream, bg);
 				else
 					hipLaunchKernelGGL((rref_block_gj<false, 8>), dim3(1), dim3(1024), 0, stream, bg);
-				signed char *Mh_s = M8 + (size_t) slot * 2 * (size_t) n * 64, *Ml_s = Mh_s + (size_t) n * 64;
-				{
-					signed char *mh = mfma_ok ? Mh_s : nullptr, *ml = mfma_ok ? Ml_s : nullptr;
-					uint32_t *zb = mfma_ok ? Zacc + (size_t) nsets * NB : nullptr;          // M_s becomes block `nsets` of Z
-					if (small16)
-						hipLaunchKernelGGL(rref_multipliers<true>, dim3((n + 63) / 64), dim3(256), 0, stream, dA, ld, n, m, c0, Ginv, gamma, knew_s,
-						                   P_s, F, rho_s, cand_pivot, mh, ml, zb, ldz);
-					else
-						hipLaunchKernelGGL(rref_multipliers<false>, dim3((n + 63) / 64), dim3(256), 0, stream, dA, ld, n, m, c0, Ginv, gamma, knew_s,
-						                   P_s, F, rho_s, cand_pivot, mh, ml, zb, ldz);
 				}
+				signed char *Mh_s = M8 + (size_t) slot * 2 * (size_t) n * 64, *Ml_s = Mh_s + (size_t) n * 64;
+				MultArgs ma{dA, ld, n, m, c0, Ginv, gamma, knew_s, P_s, F, rho_s, cand_pivot, mfma_ok ? Mh_s : nullptr, mfma_ok ? Ml_s : nullptr,
+				            mfma_ok ? Zacc + (size_t) nsets * NB : nullptr /* M_s becomes block `nsets` of Z */, ldz, abort_c};
+				const int nmult = (n + 63) / 64;
 				// the columns of the super-panel, from this panel on, and (matrix cores) the multipliers of its earlier
 				// panels, blocks 0 .. nsets - 1 of Z: K = 64 update now
 				const int mr_sp = sp_end - c0;
@@ -1730,13 +1858,17 @@ int device_rref(int64_t prime, int n, int m, uint32_t *dA, int64_t ld, int *d_pi
 				one.B[0] = B;
 				one.knew[0] = knew_s;
 				one.nsets = 1;
-				if (!mfma_ok)
-					hipLaunchKernelGGL(rref_gather_pivot_rows, dim3(512), dim3(256), 0, stream, dA, ld, c0, mr_sp, rho_s, knew_s, B);
+				one.abort = abort_c;
 				int tiles = (mr_sp + 63) / 64;
 				if (mfma_ok) {
+					// multipliers and the digit planes of the pivot rows in one launch
 					const int tiles1 = (mr_sp + 63) / 64, mr2 = nsets * NB;
-					hipLaunchKernelGGL(rref_gather_split_B, dim3((tiles1 * 64 + mr2 + 255) / 256), dim3(256), 0, stream, dA, ld, c0, mr_sp, rho_s, knew_s,
-					                   Bown_h, Bown_l, (uint32_t *) nullptr, F, (const uint32_t *) Zacc, ldz, tiles1, mr2);
+					GatherArgs ga{dA, ld, c0, mr_sp, rho_s, knew_s, Bown_h, Bown_l, nullptr, F, Zacc, ldz, tiles1, mr2, abort_c};
+					const int ngather = (tiles1 * 64 + mr2 + 255) / 256;
+					if (small16)
+						hipLaunchKernelGGL(rref_mult_gather<true>, dim3(nmult + ngather), dim3(256), 0, stream, ma, ga, nmult);
+					else
+						hipLaunchKernelGGL(rref_mult_gather<false>, dim3(nmult + ngather), dim3(256), 0, stream, ma, ga, nmult);
 					one.Mh[0] = Mh_s;
 					one.Ml[0] = Ml_s;
 					one.Bh[0] = Bown_h;
@@ -1748,6 +1880,12 @@ int device_rref(int64_t prime, int n, int m, uint32_t *dA, int64_t ld, int *d_pi
 						one.mr2 = mr2;
 						tiles = tiles1 + mr2 / 64;
 					}
+				} else {
+					if (small16)
+						hipLaunchKernelGGL(rref_multipliers<true>, dim3(nmult), dim3(256), 0, stream, ma);
+					else
+						hipLaunchKernelGGL(rref_multipliers<false>, dim3(nmult), dim3(256), 0, stream, ma);
+					hipLaunchKernelGGL(rref_gather_pivot_rows, dim3(512), dim3(256), 0, stream, dA, ld, c0, mr_sp, rho_s, knew_s, B);
 				}
 				timed([&]() {
 					dim3 grid(tiles, (n + 63) / 64);
@@ -1762,7 +1900,30 @@ int device_rref(int64_t prime, int n, int m, uint32_t *dA, int64_t ld, int *d_pi
 				set_Mh[nsets] = Mh_s;
 				set_Ml[nsets] = Ml_s;
 				HIP_CHECK(hipGetLastError());
+			};
+			// Optimistic pass: first-free rows, try, multipliers, update -- five launches per panel instead of twelve, none of
+			// the selection kernels (they return at once when the try succeeds, but a launch is a launch: 30 us per panel).
+			// The host looks at the flag once per super-panel; the panels from the one that raised it on are redone the
+			// regular way, and the next super-panel is not attempted optimistically.
+			const int npanels = (sp_end - sp0 + NB - 1) / NB;
+			int first_regular = 0;
+			if (optimistic_ok && fast_try && mfma_ok && try_first && ms_update == nullptr) {
+				HIP_CHECK(hipMemsetAsync(abort_d, 0, sizeof(int), stream));
+				for (int i = 0; i < npanels; i++)
+					run_panel(sp0 + i * NB, i, true);
+				int raised = 0;
+				HIP_CHECK(hipMemcpyAsync(&raised, abort_d, sizeof(int), hipMemcpyDeviceToHost, stream));
+				HIP_CHECK(hipStreamSynchronize(stream));
+				first_regular = raised != 0 ? raised - 1 : npanels;
+				if (raised != 0)
+					optimistic_skip = 2;
 			}
+			if (optimistic_skip > 0)
+				optimistic_skip -= 1;
+			optimistic_ok = optimistic_enabled && optimistic_skip == 0;
+			for (int i = first_regular; i < npanels; i++)
+				run_panel(sp0 + i * NB, i, false);
+			const int nsets = npanels;
 			if (mrT > 0) {
 				// beyond the super-panel.  What is read here -- the rows rho_i beyond the super-panel -- is written by the far
 				// update of the previous super-panel on the second stream: wait for it here, not earlier -- the panel steps
@@ -1773,16 +1934,20 @@ int device_rref(int64_t prime, int n, int m, uint32_t *dA, int64_t ld, int *d_pi
 					// C += sum_i M'_i C[rho_i]: M'_i = block i of Z (digit planes), C[rho_i] = the rows as they stand
 					signed char *MZ = M8 + (size_t) (2 * MAXSETS + (spi & 1) * MAXSETS) * 2 * (size_t) n * 64;
 					hipLaunchKernelGGL(rref_split_Z, dim3((n + 63) / 64, nsets), dim3(256), 0, stream, Zacc, ldz, n, nsets, MZ, (int64_t) 2 * n * 64, F);
+					GatherSets gs{};
 					for (int s = 0; s < nsets; s++) {
 						signed char *Bh_s = B8 + (size_t) s * 2 * (size_t) m * 64, *Bl_s = Bh_s + (size_t) m * 64;
-						hipLaunchKernelGGL(rref_gather_split_B, dim3((mrT + 255) / 256), dim3(256), 0, stream, dA, ld, sp_end, mrT, set_rho[s], set_knew[s],
-						                   Bh_s, Bl_s, (uint32_t *) nullptr, F, (const uint32_t *) nullptr, (int64_t) 0, 0, 0);
+						gs.rho[s] = set_rho[s];
+						gs.knew[s] = set_knew[s];
+						gs.Bh[s] = Bh_s;
+						gs.Bl[s] = Bl_s;
 						S.knew[s] = set_knew[s];
 						S.Mh[s] = MZ + (size_t) s * 2 * (size_t) n * 64;
 						S.Ml[s] = S.Mh[s] + (size_t) n * 64;
 						S.Bh[s] = Bh_s;
 						S.Bl[s] = Bl_s;
 					}
+					hipLaunchKernelGGL(rref_gather_split_sets, dim3((mrT + 255) / 256, nsets), dim3(256), 0, stream, dA, ld, sp_end, mrT, gs, F);
 				} else {
 					for (int s = 0; s < nsets; s++) {
 						S.nsets = s;          // the sets before this one
