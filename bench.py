@@ -251,7 +251,7 @@ def main():
             st = step()
             if st.used_backsolve:
                 names = (st.kernel.decode(), st.kernel_other.decode())
-                build_name = [x for x in names if x.startswith("backsolve_kernel")][0]
+                build_name = [x for x in names if x.startswith("backsolve")][0]
                 apply_name = [x for x in names if x.startswith("bs_apply")][0]
                 parts = ((build_name, st.ms_backsolve, st.bytes_backsolve), (apply_name, st.ms_apply, st.bytes_apply))
                 if st.ms_expand > 0:          # staged output (small primes): the entries of S are written by a third kernel
