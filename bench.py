@@ -305,6 +305,12 @@ def main():
         traffic, traffic_hi, traffic_src = (None, None, None)
         if world == 1:
             traffic, traffic_hi, traffic_src = quoted_traffic(kernel_id, args.workload, total_rows)
+        if world == 1:          # HBM bytes of the other kernels of the step, from the same counter passes
+            for kname, kd in kernels.items():
+                tr = quoted_traffic(kname.split(" ")[0], args.workload, total_rows)
+                if tr[0]:
+                    kd["traffic"] = tr[0]
+                    kd["hbm_frac"] = tr[0] / (kd["ms"] * 1e-3) / 1e9 / HBM_PEAK_GBS
         step_bytes = sum(k["algorithmic_bytes"] for k in kernels.values())
         roof = {"bound": "hbm", "achieved": dom["GB_per_s"], "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": dom["GB_per_s"] / HBM_PEAK_GBS, "traffic": traffic,
