@@ -291,7 +291,11 @@ bool finish_on_device(const struct spasm_csr *A, const int *p, int n, struct spa
 	if (Sm0 <= 0 || !backsolve_wanted(F, env_int("SPASM_HIP_FORCE_TIER", 0) != 0 || env_int("SPASM_HIP_GROUP", -1) >= 0))
 		return false;
 	const i64 prime = A->field->p;
-	const int block = std::max(1, opts->dense_block_size);
+	// The reference's block size (1000 rows by default) is sized for FFPACK on a CPU; here every block costs one dense RREF of
+	// [E; Y] on top of the echelon rows found so far, so blocks of at least 4096 rows are taken (SPASM_HIP_DENSE_BLOCK=0:
+	// exactly opts->dense_block_size, > 0: that many).  Rank and row space do not depend on it.
+	const int block_env = env_int("SPASM_HIP_DENSE_BLOCK", -1);
+	const int block = std::max(1, block_env > 0 ? block_env : block_env == 0 ? opts->dense_block_size : std::max(opts->dense_block_size, 4096));
 	const int Sn_test = (int) std::ceil(128.0 / std::log2((double) prime));
 	const double start = wtime();
 	const i64 annz = A->p[A->n];

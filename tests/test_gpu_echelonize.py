@@ -11,6 +11,16 @@ pytestmark = pytest.mark.gpu
 SMALL_SET = [m for m in ALL_TEST_MATRICES if m not in ("mat364.sms", "trefethen_500.sms", "medium.sms", "m1.sms")]
 
 
+@pytest.fixture(autouse=True, params=["0", None], ids=["blocks_of_opts", "device_blocks"])
+def dense_block(request, monkeypatch):
+    """the device-resident dense finish takes blocks of >= 4096 rows by default; the small dense_block_size values the
+    tests below pass (several rounds on small matrices) only count with SPASM_HIP_DENSE_BLOCK=0: both ways."""
+    if request.param is None:
+        monkeypatch.delenv("SPASM_HIP_DENSE_BLOCK", raising=False)
+    else:
+        monkeypatch.setenv("SPASM_HIP_DENSE_BLOCK", request.param)
+
+
 def _as_product(A):
     return spasm_amd.Csr(A.n, A.m, A.p, A.j, A.x, A.prime)
 
