@@ -10,18 +10,19 @@
 // produce, spasm_rref.c:25).  R is dense, r x Sm (Sm = number of non-pivotal columns).  When Sm is small
 // -- a Schur complement that is going to be dense anyway -- building R costs nnz(U') * Sm multiply-adds,
 // streaming and free of atomics, and every reduced row is then a combination of the few rows of R its
-// pivotal entries select.  mk13.b5: 130183 x 4952 (2.6 GB) against 3.97e9 (row, pivot) eliminations.
+// pivotal entries select.  mk13.b5: 130183 x 4952 (1.3 GB in 16-bit entries) against 3.97e9 (row, pivot) eliminations.
 // Arithmetic mod p is exact, so the result is the same matrix, bit for bit.
 //
 // R[c] = U_n[c] - sum_{t pivotal in U'[c]} u_ct R[t], and t always lies in a later elimination level
-// than c.  The columns of R are independent: one workgroup owns a slab of 16 columns and walks the rows
-// from the last level to the first, with no communication between workgroups at all.  Inside a
+// than c.  The columns of R are independent: one workgroup owns a slab of 32 or 64 columns and walks the
+// rows from the last level to the first, with no communication between workgroups at all.  Inside a
 // workgroup the chain of levels runs in LDS: rows are cut into chunks of <= RING consecutive rows;
-//   phase A (throughput): every row of the chunk gathers what it needs from outside the chunk
-//            (rows of R that are final, in HBM) into an LDS ring,
-//   phase B (latency): level by level, rows pick up their dependencies inside the chunk from the ring
-//            (one LDS round trip + one workgroup barrier per level),
+//   phase A: every row of the chunk gathers what it needs from outside the chunk (rows of R that are
+//            final, in HBM) into an LDS ring,
+//   phase B: level by level, rows pick up their dependencies inside the chunk from the ring -- every WAVE
+//            on its own columns of every row, so that the levels need no barrier,
 //   phase C: the ring is written back to R.
+// The rows of S then come from bs_apply_*: one wave per row, a few rows of R each.
 #include <algorithm>
 #include <cinttypes>
 #include <type_traits>
