@@ -16,7 +16,7 @@ from oracle import oracle as orc
 budget = float(sys.argv[1]) if len(sys.argv) > 1 else 120.0
 t_end = time.time() + budget
 rng = np.random.default_rng(int(time.time()))
-primes = [3, 257, 42013, 46349, 65521, 4294967291]
+primes = [3, 257, 8191, 42013, 44927, 44939, 46349, 65521, 4294967291]          # (44927: the largest prime with signed 16-bit entries)
 cases = fails = 0
 
 
@@ -51,7 +51,8 @@ while time.time() < t_end:
         # writing the result
         bs_env = {"SPASM_HIP_BACKSOLVE": "1", "SPASM_HIP_BS_SHAPE": str(int(rng.integers(0, 3))),
                   "SPASM_HIP_BS_PACKED": str(int(rng.integers(0, 2))), "SPASM_HIP_BS_SPARSE_INIT": str(int(rng.integers(0, 2))),
-                  "SPASM_HIP_BS_DIRECT": str(int(rng.integers(0, 2)))}
+                  "SPASM_HIP_BS_DIRECT": str(int(rng.integers(0, 2))), "SPASM_HIP_BS_SIGNED": str(int(rng.integers(0, 2))),
+                  "SPASM_HIP_BS_STAGED": str(int(rng.integers(0, 2))), "SPASM_HIP_STAGE_ROWS": str(int(rng.choice([0, 1, 37, 1000])))}
         os.environ.update(bs_env)
         S, p_out = spasm_amd.schur(as_product(A), rows, spasm_amd.Fact(as_product(F.U), F.qinv))
         ok = orc.same_matrix(orc.CSR(S.n, S.m, S.p, S.j, S.x, p), want) and np.array_equal(np.asarray(p_out), np.asarray(p_out_want))
