@@ -273,3 +273,28 @@ def test_reference_tool_bound_to_the_hip_library_dies_loudly_without_a_gpu():
     with open(matrix_path("small.sms")) as f:
         out = subprocess.run([DROPIN["ref_echelonize_shim"]], stdin=f, capture_output=True, text=True, timeout=120)
     assert out.returncode != 0 and "no HIP device" in out.stderr
+
+
+def test_fp32_reduction_of_the_signed_16_bit_path_stays_inside_its_slack():
+    """backsolve.hip (SgnDev): an entry is reduced by q = rint(float(t) * float(1 / p)), r = t - q p; the kernels rely on
+    |r| <= B = p/2 + p/64 + 1 for every |t| <= 4 B^2 + B < 2^31 (four products of such values on top of one).  Replayed in
+    numpy float32 on the extreme sums, on values around the multiples of p/2 (where the quotient is least certain) and on
+    random sums, for the primes at both ends of the eligible range."""
+    rng = np.random.default_rng(5)
+    for p in (3, 5, 257, 8191, 32003, 42013, 44927):
+        B = p // 2 + p // 64 + 1
+        T = 4 * B * B + B
+        assert B <= 32767 and T <= 2 ** 31 - 1                       # sgn_eligible()
+        invp = np.float32(1.0) / np.float32(p)
+        k = np.arange(0, T // p + 2, max(1, (T // p) // 200000), dtype=np.int64)
+        near_half = np.concatenate([k * p + p // 2 + d for d in (-1, 0, 1, 2)])
+        t = np.concatenate([np.array([T, T - 1, -T, -T + 1, 0, 1, -1], np.int64), near_half, -near_half,
+                            rng.integers(-T, T + 1, size=400000)])
+        t = t[np.abs(t) <= T]
+        q = np.rint(t.astype(np.float32) * invp).astype(np.int64)        # (numpy rounds half to even, as v_rndne_f32 does)
+        r = t - q * p
+        assert np.all(np.abs(r) <= B), (p, int(np.abs(r).max()), B)
+        assert np.all((r - t) % p == 0)
+    # the next prime is out: four-term sums would not fit 32 bits
+    Bn = 44939 // 2 + 44939 // 64 + 1
+    assert 4 * Bn * Bn + Bn > 2 ** 31 - 1
