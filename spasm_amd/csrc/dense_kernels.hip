@@ -2286,9 +2286,10 @@ void launch_dense_pack(const unsigned long long *Y, int N, int m, uint32_t p, co
 //   row i of the packed matrix corresponds to original row P[i], column j to original column Qinv[j];
 //   M[i][j], j < min(i+1, r)  : L (lower trapezoid, pivots on its diagonal);
 //   M[i][j], i < r, j > i     : U (unit diagonal implied);      A == L * U in original coordinates.
-// Right-looking elimination, one pivot per step, rows and columns physically swapped; a column
-// with no non-zero below the current step is swapped to the end.  O(r) small launches: this is
-// the L-recording variant of the dense tail, not the fast path (that is device_rref above).
+// Right-looking elimination, rows and columns physically swapped; a column with no non-zero below the
+// current step is swapped to the end.  For p <= 65279: 64 pivots per round whenever the 64 x 64 block on
+// the diagonal is non-singular (blocked steps below, trailing update on the matrix cores), one pivot per step
+// otherwise.  This is the L-recording variant of the dense tail; the fast path is device_rref above.
 // --------------------------------------------------------------------------
 namespace sh {
 
@@ -2370,6 +2371,215 @@ __global__ __launch_bounds__(256) void lu_rank1_update(uint32_t *A, int64_t ld, 
 	}
 }
 
+// ---- blocked steps (p <= 65279): 64 pivots per round, the trailing update on the matrix cores ----
+// The 64 x 64 block on the diagonal is factored by one workgroup in LDS with row pivoting INSIDE the block (the usual
+// case: it is non-singular); then L21 = A21 U11^-1 row by row, the block's row order applied to the other columns,
+// U12 = L11^-1 A12 column by column (both emit the signed base-256 digit planes of their result), and
+// A22 -= L21 U12 through rref_update_mfma_multi.  A block with a column without pivot writes nothing: the caller takes
+// one step of the one-pivot-at-a-time code (any row may hold the pivot, a dead column moves to the end) and tries again.
+
+// v * w mod p for p < 2^16 (plain residues)
+__device__ __forceinline__ uint32_t lu_mul16(uint32_t v, uint32_t w, uint32_t p, uint32_t bm)
+{
+	const uint32_t t = __umul24(v, w);
+	const uint32_t q = __umulhi(t, bm);
+	uint32_t rem = t - __umul24(q, p);
+	rem = (rem >= p) ? rem - p : rem;
+	rem = (rem >= p) ? rem - p : rem;
+	return rem;
+}
+
+// info[0] = 1: factored in place, perm[r] = row of the block (0 .. 63) that went to position r; P updated.  0: untouched.
+__global__ __launch_bounds__(256) void lu_block_kernel(uint32_t *A, int64_t ld, int t, int *P, int *perm, int *info, MontDev F)
+{
+	__shared__ uint32_t B[NB][NB + 1];
+	__shared__ int s_perm[NB], s_P[NB];
+	__shared__ int s_pr;
+	__shared__ uint32_t s_inv;
+	const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+	const uint32_t p = F.p, bm = (uint32_t) (0x100000000ull / F.p);
+	for (int e = tid; e < NB * NB; e += 256)
+		B[e >> 6][e & 63] = A[(int64_t) (t + (e >> 6)) * ld + t + (e & 63)];
+	if (tid < NB) {
+		s_perm[tid] = tid;
+		s_P[tid] = P[t + tid];
+	}
+	__syncthreads();
+	for (int k = 0; k < NB; k++) {
+		if (w == 0) {
+			const unsigned long long nz = __ballot(lane >= k && B[lane][k] != 0);
+			if (lane == 0) {
+				s_pr = (nz != 0) ? (int) __builtin_ctzll(nz) : -1;
+				if (nz != 0)
+					s_inv = invmod(B[__builtin_ctzll(nz)][k], F);
+			}
+		}
+		__syncthreads();
+		const int pr = s_pr;
+		if (pr < 0) {
+			if (tid == 0)
+				info[0] = 0;
+			return;
+		}
+		if (pr != k && tid < NB) {          // swap rows k and pr of the block
+			const uint32_t x = B[k][tid];
+			B[k][tid] = B[pr][tid];
+			B[pr][tid] = x;
+			if (tid == 0) {
+				const int a = s_perm[k], b = s_P[k];
+				s_perm[k] = s_perm[pr];
+				s_perm[pr] = a;
+				s_P[k] = s_P[pr];
+				s_P[pr] = b;
+			}
+		}
+		__syncthreads();
+		if (tid > k && tid < NB)             // the row of U: divided by the pivot (the pivot itself stays, on the diagonal of L)
+			B[k][tid] = lu_mul16(B[k][tid], s_inv, p, bm);
+		__syncthreads();
+		// rows below, columns to the right
+		for (int e = tid; e < (NB - 1 - k) * (NB - 1 - k); e += 256) {
+			const int i = k + 1 + e / (NB - 1 - k), j = k + 1 + e % (NB - 1 - k);
+			const uint32_t l = B[i][k];
+			if (l != 0) {
+				const uint32_t sub = lu_mul16(l, B[k][j], p, bm);
+				B[i][j] = (B[i][j] >= sub) ? B[i][j] - sub : B[i][j] + p - sub;
+			}
+		}
+		__syncthreads();
+	}
+	for (int e = tid; e < NB * NB; e += 256)
+		A[(int64_t) (t + (e >> 6)) * ld + t + (e & 63)] = B[e >> 6][e & 63];
+	if (tid < NB) {
+		perm[tid] = s_perm[tid];
+		P[t + tid] = s_P[tid];
+	}
+	if (tid == 0)
+		info[0] = 1;
+}
+
+// the row order of the block for the columns outside it: row t + r <- old row t + perm[r]
+__global__ __launch_bounds__(256) void lu_permute_rows(uint32_t *A, int64_t ld, int m, int t, const int *perm)
+{
+	__shared__ int sp[NB];
+	if (threadIdx.x < NB)
+		sp[threadIdx.x] = perm[threadIdx.x];
+	__syncthreads();
+	const int j = blockIdx.x * 256 + threadIdx.x;
+	if (j >= m || (j >= t && j < t + NB))
+		return;
+	uint32_t v[NB];
+#pragma unroll
+	for (int r = 0; r < NB; r++)
+		v[r] = A[(int64_t) (t + sp[r]) * ld + j];
+#pragma unroll
+	for (int r = 0; r < NB; r++)
+		A[(int64_t) (t + r) * ld + j] = v[r];
+}
+
+// L21 = A21 U11^-1 (U11 unit upper triangular): one thread per row below the block, 64 entries in registers; also the
+// digit planes of -L21 for the trailing update (row i - (t + 64) of Mh / Ml)
+__global__ __launch_bounds__(256) void lu_L21_kernel(uint32_t *A, int64_t ld, int n, int t, signed char *Mh, signed char *Ml, MontDev F)
+{
+	__shared__ uint32_t U[NB][NB];
+	const uint32_t p = F.p, bm = (uint32_t) (0x100000000ull / F.p);
+	for (int e = threadIdx.x; e < NB * NB; e += 256)
+		U[e >> 6][e & 63] = A[(int64_t) (t + (e >> 6)) * ld + t + (e & 63)];
+	__syncthreads();
+	const int i = t + NB + blockIdx.x * 256 + threadIdx.x;
+	if (i >= n)
+		return;
+	uint32_t *row = A + (int64_t) i * ld + t;
+	uint32_t x[NB];
+#pragma unroll
+	for (int q = 0; q < NB / 4; q++) {
+		const uint4 v = *reinterpret_cast<const uint4 *>(row + 4 * q);          // (t and ld are multiples of 4 on this path)
+		x[4 * q] = v.x;
+		x[4 * q + 1] = v.y;
+		x[4 * q + 2] = v.z;
+		x[4 * q + 3] = v.w;
+	}
+#pragma unroll
+	for (int s = 0; s < NB; s++) {
+		const uint32_t neg = (x[s] == 0) ? 0u : p - x[s];
+#pragma unroll
+		for (int j = s + 1; j < NB; j++) {
+			uint32_t v = x[j] + lu_mul16(neg, U[s][j], p, bm);
+			x[j] = (v >= p) ? v - p : v;
+		}
+	}
+	unsigned int wh[NB / 4], wl[NB / 4];
+#pragma unroll
+	for (int q = 0; q < NB / 4; q++) {
+		*reinterpret_cast<uint4 *>(row + 4 * q) = make_uint4(x[4 * q], x[4 * q + 1], x[4 * q + 2], x[4 * q + 3]);
+		wh[q] = wl[q] = 0;
+#pragma unroll
+		for (int b = 0; b < 4; b++) {
+			int hi, lo;
+			split_digits((x[4 * q + b] == 0) ? 0u : p - x[4 * q + b], F, hi, lo);
+			wh[q] |= (unsigned int) (hi & 255) << (8 * b);
+			wl[q] |= (unsigned int) (lo & 255) << (8 * b);
+		}
+	}
+	int4 *dh = reinterpret_cast<int4 *>(Mh + (int64_t) (i - t - NB) * 64), *dl = reinterpret_cast<int4 *>(Ml + (int64_t) (i - t - NB) * 64);
+#pragma unroll
+	for (int q = 0; q < 4; q++) {
+		dh[q] = make_int4((int) wh[4 * q], (int) wh[4 * q + 1], (int) wh[4 * q + 2], (int) wh[4 * q + 3]);
+		dl[q] = make_int4((int) wl[4 * q], (int) wl[4 * q + 1], (int) wl[4 * q + 2], (int) wl[4 * q + 3]);
+	}
+}
+
+// U12 = L11^-1 A12 (L11 lower triangular with the pivots on its diagonal): one thread per column right of the block;
+// also its digit planes (column j - (t + 64) of Bh / Bl)
+__global__ __launch_bounds__(256) void lu_U12_kernel(uint32_t *A, int64_t ld, int m, int t, signed char *Bh, signed char *Bl, MontDev F)
+{
+	__shared__ uint32_t L[NB][NB + 1];
+	__shared__ uint32_t dinv[NB];
+	const uint32_t p = F.p, bm = (uint32_t) (0x100000000ull / F.p);
+	for (int e = threadIdx.x; e < NB * NB; e += 256)
+		L[e >> 6][e & 63] = A[(int64_t) (t + (e >> 6)) * ld + t + (e & 63)];
+	__syncthreads();
+	if (threadIdx.x < NB)
+		dinv[threadIdx.x] = invmod(L[threadIdx.x][threadIdx.x], F);
+	__syncthreads();
+	const int j = t + NB + blockIdx.x * 256 + threadIdx.x;
+	if (j >= m)
+		return;
+	uint32_t u[NB];
+#pragma unroll
+	for (int s = 0; s < NB; s++)
+		u[s] = A[(int64_t) (t + s) * ld + j];
+#pragma unroll
+	for (int q = 0; q < NB; q++) {
+		u[q] = lu_mul16(u[q], dinv[q], p, bm);
+		const uint32_t neg = (u[q] == 0) ? 0u : p - u[q];
+#pragma unroll
+		for (int s = q + 1; s < NB; s++) {
+			uint32_t v = u[s] + lu_mul16(L[s][q], neg, p, bm);
+			u[s] = (v >= p) ? v - p : v;
+		}
+	}
+	unsigned int wh[NB / 4], wl[NB / 4];
+#pragma unroll
+	for (int q = 0; q < NB / 4; q++) {
+		wh[q] = wl[q] = 0;
+#pragma unroll
+		for (int b = 0; b < 4; b++) {
+			A[(int64_t) (t + 4 * q + b) * ld + j] = u[4 * q + b];
+			int hi, lo;
+			split_digits(u[4 * q + b], F, hi, lo);
+			wh[q] |= (unsigned int) (hi & 255) << (8 * b);
+			wl[q] |= (unsigned int) (lo & 255) << (8 * b);
+		}
+	}
+	int4 *dh = reinterpret_cast<int4 *>(Bh + (int64_t) (j - t - NB) * 64), *dl = reinterpret_cast<int4 *>(Bl + (int64_t) (j - t - NB) * 64);
+#pragma unroll
+	for (int q = 0; q < 4; q++) {
+		dh[q] = make_int4((int) wh[4 * q], (int) wh[4 * q + 1], (int) wh[4 * q + 2], (int) wh[4 * q + 3]);
+		dl[q] = make_int4((int) wl[4 * q], (int) wl[4 * q + 1], (int) wl[4 * q + 2], (int) wl[4 * q + 3]);
+	}
+}
+
 int device_lu(int64_t prime, int n, int m, uint32_t *dA, int64_t ld, int *dP, int *dQ, hipStream_t stream)
 {
 	const Mont M = mont_setup(prime);
@@ -2379,7 +2589,49 @@ int device_lu(int64_t prime, int n, int m, uint32_t *dA, int64_t ld, int *dP, in
 	int t = 0;
 	int mlast = m;                   // columns [mlast, m) are known to be zero below the diagonal block
 	const int rmax = (n < m) ? n : m;
+	// blocked steps: the matrix cores need two signed base-256 digits (p <= 65279), the row kernels 16-byte rows
+	bool blocked = prime <= 65279 && ld % 4 == 0 && (reinterpret_cast<uintptr_t>(dA) % 16) == 0;
+	if (const char *e = std::getenv("SPASM_HIP_LU_BLOCKED"))
+		blocked = blocked && std::atoi(e) != 0;
+	signed char *lu_M8 = nullptr, *lu_B8 = nullptr;
+	int *lu_perm = nullptr;
+	if (blocked) {
+		HIP_CHECK(hipMalloc((void **) &lu_M8, (size_t) 2 * (size_t) n * 64));
+		HIP_CHECK(hipMalloc((void **) &lu_B8, (size_t) 2 * (size_t) m * 64));
+		HIP_CHECK(hipMalloc((void **) &lu_perm, NB * sizeof(int)));
+	}
+	int block_cooldown = 0;          // after a block that could not be factored: single steps before the next attempt
 	while (t < rmax && t < mlast) {
+		if (blocked && block_cooldown == 0 && t % 4 == 0 && t + NB <= n && t + NB <= mlast) {
+			int ok = 0;
+			hipLaunchKernelGGL(lu_block_kernel, dim3(1), dim3(256), 0, stream, dA, ld, t, dP, lu_perm, d_piv + 4, F);
+			HIP_CHECK(hipMemcpyAsync(&ok, d_piv + 4, sizeof(int), hipMemcpyDeviceToHost, stream));
+			HIP_CHECK(hipStreamSynchronize(stream));
+			if (ok) {
+				const int nb = n - t - NB, mb = m - t - NB;          // rows below, columns right of the block
+				hipLaunchKernelGGL(lu_permute_rows, dim3((m + 255) / 256), dim3(256), 0, stream, dA, ld, m, t, lu_perm);
+				if (nb > 0)
+					hipLaunchKernelGGL(lu_L21_kernel, dim3((nb + 255) / 256), dim3(256), 0, stream, dA, ld, n, t, lu_M8, lu_M8 + (size_t) n * 64, F);
+				if (mb > 0)
+					hipLaunchKernelGGL(lu_U12_kernel, dim3((mb + 255) / 256), dim3(256), 0, stream, dA, ld, m, t, lu_B8, lu_B8 + (size_t) m * 64, F);
+				if (nb > 0 && mb > 0) {
+					UpdSets one{};
+					one.nsets = 1;
+					one.Mh[0] = lu_M8;
+					one.Ml[0] = lu_M8 + (size_t) n * 64;
+					one.Bh[0] = lu_B8;
+					one.Bl[0] = lu_B8 + (size_t) m * 64;
+					dim3 grid((mb + 63) / 64, (nb + 63) / 64);
+					hipLaunchKernelGGL(rref_update_mfma_multi, grid, dim3(256), 0, stream, dA + (int64_t) (t + NB) * ld, ld, nb, t + NB, mb, one, F);
+				}
+				HIP_CHECK(hipGetLastError());
+				t += NB;
+				continue;
+			}
+			block_cooldown = 8;
+		}
+		if (block_cooldown > 0)
+			block_cooldown -= 1;
 		hipLaunchKernelGGL(lu_find_pivot, dim3(1), dim3(1024), 0, stream, dA, ld, n, t, d_piv);
 		int row = -1;
 		HIP_CHECK(hipMemcpyAsync(&row, d_piv, sizeof(int), hipMemcpyDeviceToHost, stream));
@@ -2403,6 +2655,9 @@ int device_lu(int64_t prime, int n, int m, uint32_t *dA, int64_t ld, int *dP, in
 	}
 	HIP_CHECK(hipStreamSynchronize(stream));
 	(void) hipFree(d_piv);
+	(void) hipFree(lu_M8);
+	(void) hipFree(lu_B8);
+	(void) hipFree(lu_perm);
 	return t;
 }
 

@@ -180,6 +180,44 @@ def _check_LU(oracle, p, M):
     assert not np.any((Lm.dot(Um) - A) % p)
 
 
+def _check_LU_small_prime(p, M, rank_want):
+    """the same check with int64 products (p < 2^16: sums of a few thousand products fit), for blocks large enough to
+    take the blocked steps (64 pivots per round, trailing update on the matrix cores)."""
+    n, m = M.shape
+    r, R, P, Q = spasm_amd.ffpack_LU(p, M)
+    assert r == rank_want
+    assert sorted(P.tolist()) == list(range(n)) and sorted(Q.tolist()) == list(range(m))
+    R = np.asarray(R, np.int64)
+    Lm = np.zeros((n, r), np.int64)
+    Um = np.zeros((r, m), np.int64)
+    tri = np.tril(np.ones((n, r), bool))                       # j < min(i + 1, r)
+    Lm[P] = np.where(tri, R[:, :r], 0)
+    Upacked = np.where(np.triu(np.ones((r, m), bool), 1), R[:r, :], 0) + np.eye(r, m, dtype=np.int64)
+    Um[:, Q] = Upacked
+    assert not np.any((Lm @ Um - np.asarray(M, np.int64)) % p)
+
+
+@pytest.mark.parametrize("blocked", ["1", "0"])
+@pytest.mark.parametrize("p", [257, 42013, 65269])
+@pytest.mark.parametrize("shape,rank", [((64, 64), 64), ((65, 200), 65), ((200, 65), 65), ((300, 500), 300), ((700, 400), 400),
+                                        ((512, 512), 512), ((400, 600), 150), ((260, 260), 259)])
+def test_LU_blocked_steps(monkeypatch, blocked, p, shape, rank):
+    """full-rank blocks take 64 pivots per round; rank-deficient ones fall back to single steps where a 64 x 64 diagonal
+    block is singular (and dead columns move to the end) and come back to blocked steps afterwards."""
+    monkeypatch.setenv("SPASM_HIP_LU_BLOCKED", blocked)
+    n, m = shape
+    rng = np.random.default_rng(n * 7 + m + p)
+    if rank == min(n, m):
+        M = rng.integers(0, p, size=(n, m), dtype=np.int64)
+    else:
+        Lf = rng.integers(0, p, size=(n, rank), dtype=np.int64)
+        Rf = rng.integers(0, p, size=(rank, m), dtype=np.int64)
+        M = (Lf @ Rf) % p
+        M[:, 70:75] = 0                          # dead columns inside the second block
+    r_want = spasm_amd.ffpack_rref(p, M)[0]          # the rank by the dense RREF (checked against the oracle elsewhere)
+    _check_LU_small_prime(p, M, r_want)
+
+
 @pytest.mark.parametrize("name", SMALL_SET)
 @pytest.mark.parametrize("p", [3, 257, 42013, 4294967291])
 def test_LU_reference_matrices(oracle, name, p):
