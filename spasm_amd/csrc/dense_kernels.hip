@@ -2477,106 +2477,112 @@ __global__ __launch_bounds__(256) void lu_permute_rows(uint32_t *A, int64_t ld, 
 		A[(int64_t) (t + r) * ld + j] = v[r];
 }
 
-// L21 = A21 U11^-1 (U11 unit upper triangular): one thread per row below the block, 64 entries in registers; also the
-// digit planes of -L21 for the trailing update (row i - (t + 64) of Mh / Ml)
+// L21 = A21 U11^-1 (U11 unit upper triangular): one thread per row below the block, its 64 entries in LDS (entry-major:
+// no bank conflicts, and plain loops -- the fully unrolled register version took minutes to compile); also the digit
+// planes of -L21 for the trailing update (row i - (t + 64) of Mh / Ml)
 __global__ __launch_bounds__(256) void lu_L21_kernel(uint32_t *A, int64_t ld, int n, int t, signed char *Mh, signed char *Ml, MontDev F)
 {
 	__shared__ uint32_t U[NB][NB];
+	__shared__ uint32_t xs[NB][256];
 	const uint32_t p = F.p, bm = (uint32_t) (0x100000000ull / F.p);
-	for (int e = threadIdx.x; e < NB * NB; e += 256)
+	const int tid = threadIdx.x;
+	for (int e = tid; e < NB * NB; e += 256)
 		U[e >> 6][e & 63] = A[(int64_t) (t + (e >> 6)) * ld + t + (e & 63)];
+	const int i = t + NB + blockIdx.x * 256 + tid;
+	uint32_t *row = A + (int64_t) (i < n ? i : t) * ld + t;
+	if (i < n)
+		for (int q = 0; q < NB / 4; q++) {
+			const uint4 v = *reinterpret_cast<const uint4 *>(row + 4 * q);          // (t and ld are multiples of 4 on this path)
+			xs[4 * q][tid] = v.x;
+			xs[4 * q + 1][tid] = v.y;
+			xs[4 * q + 2][tid] = v.z;
+			xs[4 * q + 3][tid] = v.w;
+		}
 	__syncthreads();
-	const int i = t + NB + blockIdx.x * 256 + threadIdx.x;
 	if (i >= n)
 		return;
-	uint32_t *row = A + (int64_t) i * ld + t;
-	uint32_t x[NB];
-#pragma unroll
-	for (int q = 0; q < NB / 4; q++) {
-		const uint4 v = *reinterpret_cast<const uint4 *>(row + 4 * q);          // (t and ld are multiples of 4 on this path)
-		x[4 * q] = v.x;
-		x[4 * q + 1] = v.y;
-		x[4 * q + 2] = v.z;
-		x[4 * q + 3] = v.w;
-	}
-#pragma unroll
 	for (int s = 0; s < NB; s++) {
-		const uint32_t neg = (x[s] == 0) ? 0u : p - x[s];
-#pragma unroll
+		const uint32_t xv = xs[s][tid];
+		if (xv == 0)
+			continue;
+		const uint32_t neg = p - xv;
+#pragma unroll 4
 		for (int j = s + 1; j < NB; j++) {
-			uint32_t v = x[j] + lu_mul16(neg, U[s][j], p, bm);
-			x[j] = (v >= p) ? v - p : v;
-		}
-	}
-	unsigned int wh[NB / 4], wl[NB / 4];
-#pragma unroll
-	for (int q = 0; q < NB / 4; q++) {
-		*reinterpret_cast<uint4 *>(row + 4 * q) = make_uint4(x[4 * q], x[4 * q + 1], x[4 * q + 2], x[4 * q + 3]);
-		wh[q] = wl[q] = 0;
-#pragma unroll
-		for (int b = 0; b < 4; b++) {
-			int hi, lo;
-			split_digits((x[4 * q + b] == 0) ? 0u : p - x[4 * q + b], F, hi, lo);
-			wh[q] |= (unsigned int) (hi & 255) << (8 * b);
-			wl[q] |= (unsigned int) (lo & 255) << (8 * b);
+			const uint32_t v = xs[j][tid] + lu_mul16(neg, U[s][j], p, bm);
+			xs[j][tid] = (v >= p) ? v - p : v;
 		}
 	}
 	int4 *dh = reinterpret_cast<int4 *>(Mh + (int64_t) (i - t - NB) * 64), *dl = reinterpret_cast<int4 *>(Ml + (int64_t) (i - t - NB) * 64);
+	for (int q4 = 0; q4 < 4; q4++) {
+		unsigned int wh[4] = {0, 0, 0, 0}, wl[4] = {0, 0, 0, 0};
 #pragma unroll
-	for (int q = 0; q < 4; q++) {
-		dh[q] = make_int4((int) wh[4 * q], (int) wh[4 * q + 1], (int) wh[4 * q + 2], (int) wh[4 * q + 3]);
-		dl[q] = make_int4((int) wl[4 * q], (int) wl[4 * q + 1], (int) wl[4 * q + 2], (int) wl[4 * q + 3]);
+		for (int q = 0; q < 4; q++) {
+			const int c = 16 * q4 + 4 * q;
+			const uint4 v = make_uint4(xs[c][tid], xs[c + 1][tid], xs[c + 2][tid], xs[c + 3][tid]);
+			*reinterpret_cast<uint4 *>(row + c) = v;
+			const uint32_t e4[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+			for (int b = 0; b < 4; b++) {
+				int hi, lo;
+				split_digits((e4[b] == 0) ? 0u : p - e4[b], F, hi, lo);
+				wh[q] |= (unsigned int) (hi & 255) << (8 * b);
+				wl[q] |= (unsigned int) (lo & 255) << (8 * b);
+			}
+		}
+		dh[q4] = make_int4((int) wh[0], (int) wh[1], (int) wh[2], (int) wh[3]);
+		dl[q4] = make_int4((int) wl[0], (int) wl[1], (int) wl[2], (int) wl[3]);
 	}
 }
 
-// U12 = L11^-1 A12 (L11 lower triangular with the pivots on its diagonal): one thread per column right of the block;
-// also its digit planes (column j - (t + 64) of Bh / Bl)
+// U12 = L11^-1 A12 (L11 lower triangular with the pivots on its diagonal): one thread per column right of the block, its
+// 64 entries in LDS; also its digit planes (column j - (t + 64) of Bh / Bl)
 __global__ __launch_bounds__(256) void lu_U12_kernel(uint32_t *A, int64_t ld, int m, int t, signed char *Bh, signed char *Bl, MontDev F)
 {
 	__shared__ uint32_t L[NB][NB + 1];
 	__shared__ uint32_t dinv[NB];
+	__shared__ uint32_t us[NB][256];
 	const uint32_t p = F.p, bm = (uint32_t) (0x100000000ull / F.p);
-	for (int e = threadIdx.x; e < NB * NB; e += 256)
+	const int tid = threadIdx.x;
+	for (int e = tid; e < NB * NB; e += 256)
 		L[e >> 6][e & 63] = A[(int64_t) (t + (e >> 6)) * ld + t + (e & 63)];
 	__syncthreads();
-	if (threadIdx.x < NB)
-		dinv[threadIdx.x] = invmod(L[threadIdx.x][threadIdx.x], F);
+	if (tid < NB)
+		dinv[tid] = invmod(L[tid][tid], F);
 	__syncthreads();
-	const int j = t + NB + blockIdx.x * 256 + threadIdx.x;
+	const int j = t + NB + blockIdx.x * 256 + tid;
 	if (j >= m)
 		return;
-	uint32_t u[NB];
-#pragma unroll
 	for (int s = 0; s < NB; s++)
-		u[s] = A[(int64_t) (t + s) * ld + j];
-#pragma unroll
+		us[s][tid] = A[(int64_t) (t + s) * ld + j];
 	for (int q = 0; q < NB; q++) {
-		u[q] = lu_mul16(u[q], dinv[q], p, bm);
-		const uint32_t neg = (u[q] == 0) ? 0u : p - u[q];
-#pragma unroll
+		const uint32_t uq = lu_mul16(us[q][tid], dinv[q], p, bm);
+		us[q][tid] = uq;
+		if (uq == 0)
+			continue;
+		const uint32_t neg = p - uq;
+#pragma unroll 4
 		for (int s = q + 1; s < NB; s++) {
-			uint32_t v = u[s] + lu_mul16(L[s][q], neg, p, bm);
-			u[s] = (v >= p) ? v - p : v;
-		}
-	}
-	unsigned int wh[NB / 4], wl[NB / 4];
-#pragma unroll
-	for (int q = 0; q < NB / 4; q++) {
-		wh[q] = wl[q] = 0;
-#pragma unroll
-		for (int b = 0; b < 4; b++) {
-			A[(int64_t) (t + 4 * q + b) * ld + j] = u[4 * q + b];
-			int hi, lo;
-			split_digits(u[4 * q + b], F, hi, lo);
-			wh[q] |= (unsigned int) (hi & 255) << (8 * b);
-			wl[q] |= (unsigned int) (lo & 255) << (8 * b);
+			const uint32_t v = us[s][tid] + lu_mul16(L[s][q], neg, p, bm);
+			us[s][tid] = (v >= p) ? v - p : v;
 		}
 	}
 	int4 *dh = reinterpret_cast<int4 *>(Bh + (int64_t) (j - t - NB) * 64), *dl = reinterpret_cast<int4 *>(Bl + (int64_t) (j - t - NB) * 64);
+	for (int q4 = 0; q4 < 4; q4++) {
+		unsigned int wh[4] = {0, 0, 0, 0}, wl[4] = {0, 0, 0, 0};
 #pragma unroll
-	for (int q = 0; q < 4; q++) {
-		dh[q] = make_int4((int) wh[4 * q], (int) wh[4 * q + 1], (int) wh[4 * q + 2], (int) wh[4 * q + 3]);
-		dl[q] = make_int4((int) wl[4 * q], (int) wl[4 * q + 1], (int) wl[4 * q + 2], (int) wl[4 * q + 3]);
+		for (int q = 0; q < 4; q++)
+#pragma unroll
+			for (int b = 0; b < 4; b++) {
+				const int srow = 16 * q4 + 4 * q + b;
+				const uint32_t v = us[srow][tid];
+				A[(int64_t) (t + srow) * ld + j] = v;
+				int hi, lo;
+				split_digits(v, F, hi, lo);
+				wh[q] |= (unsigned int) (hi & 255) << (8 * b);
+				wl[q] |= (unsigned int) (lo & 255) << (8 * b);
+			}
+		dh[q4] = make_int4((int) wh[0], (int) wh[1], (int) wh[2], (int) wh[3]);
+		dl[q4] = make_int4((int) wl[0], (int) wl[1], (int) wl[2], (int) wl[3]);
 	}
 }
 
