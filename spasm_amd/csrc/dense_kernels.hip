@@ -1048,16 +1048,34 @@ template <bool SMALL16> __device__ __forceinline__ void multipliers_body(const i
 		srho[tid] = (tid < k) ? rho[tid] : -1;
 		spiv[tid] = (tid < k) ? cand_pivot[tid] : -1;
 	}
-	for (int t = tid; t < NB * NB; t += 256)
-		sG[t / NB][t % NB] = (t / NB < k && t % NB < k) ? (SMALL16 ? montmul(Ginv[t], 1u, F) : Ginv[t]) : 0u;   // (plain / Montgomery form)
 	if (tid < NB)
 		sgam[tid] = (tid < k) ? gamma[tid] : 0;
-	// the panel entries of the workgroup's 64 rows, read row by row (256 contiguous bytes each)
+	// Ginv and the panel entries of the workgroup's 64 rows (read row by row, 256 contiguous bytes each): all 32 loads of a
+	// thread are issued before the first store to LDS (written as two plain copy loops, every load was waited for on its own)
 	__shared__ uint32_t tile[64][NB + 1];
-	for (int t = tid; t < 64 * NB; t += 256) {
-		const int rr = t / NB, cc = t % NB;
-		const int irow = bx * 64 + rr;
-		tile[rr][cc] = (irow < n && c0 + cc < m) ? A[(int64_t) irow * ld + c0 + cc] : 0u;
+	{
+		uint32_t gv[NB * NB / 256], tv[64 * NB / 256];
+#pragma unroll
+		for (int u = 0; u < NB * NB / 256; u++) {
+			const int t = tid + 256 * u;
+			gv[u] = (t / NB < k && t % NB < k) ? Ginv[t] : 0u;
+		}
+#pragma unroll
+		for (int u = 0; u < 64 * NB / 256; u++) {
+			const int t = tid + 256 * u;
+			const int irow = bx * 64 + t / NB, cc = t % NB;
+			tv[u] = (irow < n && c0 + cc < m) ? A[(int64_t) irow * ld + c0 + cc] : 0u;
+		}
+#pragma unroll
+		for (int u = 0; u < NB * NB / 256; u++) {
+			const int t = tid + 256 * u;
+			sG[t / NB][t % NB] = (SMALL16 && gv[u] != 0) ? montmul(gv[u], 1u, F) : gv[u];   // (plain / Montgomery form)
+		}
+#pragma unroll
+		for (int u = 0; u < 64 * NB / 256; u++) {
+			const int t = tid + 256 * u;
+			tile[t / NB][t % NB] = tv[u];
+		}
 	}
 	__syncthreads();
 	// 64 rows per workgroup: thread (tid & 63) = row, (tid >> 6) = quarter of the r range
