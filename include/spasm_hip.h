@@ -256,7 +256,7 @@ typedef struct {
 	i64 bytes_apply;        /* ... of the apply kernel */
 	char kernel[64];        /* name of the dominant elimination kernel this call launched, as rocprofv3 shows it */
 	char kernel_other[64];  /* back-substituted path: the other of its two kernels (build of R / apply) */
-	float ms_expand;        /* staged output (small primes): device time of bs_expand_s16_kernel, not part of ms_apply; else 0 */
+	float ms_expand;        /* staged output (the default): device time of bs_expand_kernel, not part of ms_apply; else 0 */
 	float ms_pad;
 	i64 bytes_expand;       /* ... its algorithmic bytes (the entries of S written); they are then not part of bytes_apply */
 	i64 bytes_staged;       /* ... bytes of the packed rows in between (written by the apply kernel, read by the expansion) */

@@ -484,7 +484,7 @@ struct ApplyArgs {
 	SgnDev G;
 	unsigned long long *block_sum; // staged output: sum of the lengths of every block of SCAN_BLOCK rows (zeroed before the launch)
 	uint32_t *stage;              // staged output (bs_apply_s16_kernel): the packed row of S, Smpad / 2 words per row, and its
-	                              // number of entries in a.row_len; bs_expand_s16_kernel writes the sparse rows afterwards
+	                              // number of entries in a.row_len; bs_expand_kernel writes the sparse rows afterwards
 };
 
 constexpr unsigned long long LB_FLAG_LEN = 1ull << 62, LB_FLAG_END = 2ull << 62, LB_VALUE = (1ull << 62) - 1;
@@ -681,6 +681,17 @@ template <bool PACKED, bool PLAIN> __global__ __launch_bounds__(512) void bs_app
 				count += __popcll(__ballot((w & 0xFFFFu) != 0)) + __popcll(__ballot((w >> 16) != 0));
 			else
 				count += __popcll(__ballot(w != 0));
+		}
+		if (d.stage != nullptr) {          // staged output: the row as it stands + its length (see bs_expand_kernel)
+			uint32_t *out = d.stage + (int64_t) k * nwords;
+			for (int t = lane; t < nwords; t += 64)
+				out[t] = xw[t];
+			if (lane == 0) {
+				a.row_len[k] = count;
+				atomicAdd(&d.block_sum[k / 1024], (unsigned long long) count);          // (SCAN_BLOCK rows per block)
+			}
+			st_done += 1;
+			continue;
 		}
 		int64_t off = 0;
 		int *out_j = a.pool_j, *out_x = a.pool_x;
@@ -991,7 +1002,7 @@ __global__ __launch_bounds__(512) void bs_apply_s16_kernel(ApplyArgs d)
 // Writing the rows of S in order from ONE kernel makes every row wait for the lengths of the rows before it -- with
 // 3584 rows in flight a row waits for the slowest of its several hundred running predecessors, a third of its own time
 // on mk13.b5 -- and the waiting rows keep their LDS.  Two kernels instead: bs_apply_s16_kernel leaves the packed row
-// (2 bytes per column) and its length, one small scan turns lengths into offsets, bs_expand_s16_kernel streams the
+// (2 bytes per column) and its length, one small scan turns lengths into offsets, bs_expand_kernel streams the
 // packed rows out as (column, value) pairs.  Nobody waits for anybody; the price is one write and one read of the
 // packed rows (a third of the bytes of the result).
 // offsets from lengths.  The apply kernel has added every length to the sum of its block of SCAN_BLOCK rows
@@ -1061,11 +1072,13 @@ struct ExpandArgs {
 	int *Sj, *Sx;
 	int64_t cap;
 	const int *q;
-	SgnDev G;
+	SgnDev G;                     // (p, -p, p / 2: every format uses them)
 	int dbg;
 };
 
-__global__ __launch_bounds__(256) void bs_expand_s16_kernel(ExpandArgs e)
+// FMT 0: signed 16-bit entries, two per word; 1: residues in 16 bits, two per word; 2: residues, one per word
+
+template <int FMT> __global__ __launch_bounds__(256) void bs_expand_kernel(ExpandArgs e)
 {
 	constexpr int TU = 4;                // tiles per group (rows are padded to whole groups of four tiles)
 	// The entries of a group are compacted in LDS and leave as dense, contiguous stores (64 consecutive entries per
@@ -1074,8 +1087,11 @@ __global__ __launch_bounds__(256) void bs_expand_s16_kernel(ExpandArgs e)
 	__shared__ int stage_j[4][128 * TU], stage_x[4][128 * TU];
 	const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
 	const int wave = (int) ((blockIdx.x * blockDim.x + threadIdx.x) >> 6), nwaves = (int) ((gridDim.x * blockDim.x) >> 6);
-	const int2 *q2 = reinterpret_cast<const int2 *>(e.q) + lane;
+	const int2 *q2 = reinterpret_cast<const int2 *>(e.q) + lane;          // (two columns per word)
+	const int *q1 = e.q + lane;                                             // (one column per word: FMT 2)
 	const SgnDev G = e.G;
+	const uint32_t pu = (uint32_t) G.p, halfu = (uint32_t) G.half;
+	auto balanced = [&](uint32_t v) -> int { return (v > halfu) ? (int) (v - pu) : (int) v; };          // residue -> [-p/2, p/2]
 	const int last = e.nwords - 64 * TU;
 	int *sj = stage_j[wv], *sx = stage_x[wv];
 	for (int k = wave; k < e.nrows; k += nwaves) {
@@ -1106,7 +1122,7 @@ __global__ __launch_bounds__(256) void bs_expand_s16_kernel(ExpandArgs e)
 				w[u] = __builtin_nontemporal_load(row + t + 64 * u);
 #pragma unroll
 			for (int u = 0; u < TU; u++)
-				qq[u] = q2[t + 64 * u];
+				qq[u] = (FMT == 2) ? int2{q1[t + 64 * u], 0} : q2[t + 64 * u];
 		};
 		// lane l of a tile holds columns 2 (t0 + l) and 2 (t0 + l) + 1: entries come out sorted by column
 		auto emit = [&](const uint32_t (&w)[TU], const int2 (&qq)[TU]) {
@@ -1114,9 +1130,17 @@ __global__ __launch_bounds__(256) void bs_expand_s16_kernel(ExpandArgs e)
 #pragma unroll
 			for (int u = 0; u < TU; u++) {
 				int v0, v1;
-				sgn_unpack(w[u], v0, v1);
-				v0 = sgn_canonical(v0, G);
-				v1 = sgn_canonical(v1, G);
+				if constexpr (FMT == 0) {
+					sgn_unpack(w[u], v0, v1);
+					v0 = sgn_canonical(v0, G);
+					v1 = sgn_canonical(v1, G);
+				} else if constexpr (FMT == 1) {
+					v0 = balanced(w[u] & 0xFFFFu);
+					v1 = balanced(w[u] >> 16);
+				} else {
+					v0 = balanced(w[u]);
+					v1 = 0;
+				}
 				const uint64_t m0 = __ballot(v0 != 0), m1 = __ballot(v1 != 0);
 				uint32_t dst = gpos;
 				dst = __builtin_amdgcn_mbcnt_hi((uint32_t) (m0 >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t) m0, dst));
@@ -1777,8 +1801,8 @@ void backsolve_build(const spasm_hip_dfact *F, hipStream_t stream)
 bool backsolve_stages_output(const spasm_hip_dfact *F, int64_t *row_bytes)
 {
 	const BsImage &B = F->bs;
-	*row_bytes = B.ldR * 2;
-	return B.planned && B.sgn && env_bs("SPASM_HIP_BS_STAGED", 1) != 0;
+	*row_bytes = B.ldR * (B.valid ? B.elem_bytes : 4);          // (asked after the build: the entry size is known)
+	return B.planned && env_bs("SPASM_HIP_BS_STAGED", 1) != 0;
 }
 
 // S rows from R: sparse rows into the pool of `a` (dense_out == nullptr) or dense rows.
@@ -1839,49 +1863,59 @@ void launch_backsolve_apply(const SchurArgs &a, const spasm_hip_dfact *F, uint32
 	const size_t lds = per_wave * (size_t) waves;
 	const int blocks = std::max(1, std::min((a.nrows + waves - 1) / waves, prop.multiProcessorCount * 8));
 	d.ntickets = std::min(LB_TICKETS, blocks);
-	if (B.sgn) {
-		static size_t configured = 0;
-		if (lds > configured) {
-			HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(&bs_apply_s16_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int) lds));
-			configured = lds;
-		}
-		if (direct != nullptr && direct->stage != nullptr && dense_out == nullptr) {
-			// staged output: packed rows + lengths, offsets by a scan, sparse rows by a streaming kernel; slices of
-			// stage_rows rows when the staging buffer is smaller than the batch
-			const int nwords = d.Smpad / 2;
-			HIP_CHECK(hipMemsetAsync(direct->Sp, 0, sizeof(int64_t), stream));
-			for (int64_t r0 = 0; r0 < a.nrows; r0 += direct->stage_rows) {
-				const int n = (int) std::min<int64_t>(direct->stage_rows, a.nrows - r0);
-				ApplyArgs d2 = d;
-				d2.direct = 0;
-				d2.stage = direct->stage;
-				d2.a.rows = a.rows + r0;
-				d2.a.row_len = a.row_len + r0;
-				d2.a.nrows = n;
-				const int blocks2 = std::max(1, std::min((n + waves - 1) / waves, prop.multiProcessorCount * 8));
-				const int nblocks = (n + SCAN_BLOCK - 1) / SCAN_BLOCK;
-				d2.block_sum = direct->status;          // (the look-back words are not used by the staged output)
-				HIP_CHECK(hipMemsetAsync(d2.block_sum, 0, (size_t) nblocks * sizeof(unsigned long long), stream));
-				hipLaunchKernelGGL(bs_apply_s16_kernel, dim3(blocks2), dim3(64 * d.waves), lds, stream, d2);
-				hipLaunchKernelGGL(bs_scan_lengths_kernel, dim3(nblocks), dim3(SCAN_BLOCK), 0, stream, a.row_len + r0, n, d2.block_sum, direct->Sp + r0,
-				                   direct->cap, a.ctr);
-				ExpandArgs e{direct->stage, nwords, n, direct->Sp + r0, direct->Sj, direct->Sx, direct->cap, a.q, d.G, d.dbg};
-				const int blocks3 = std::max(1, std::min((n + 3) / 4, prop.multiProcessorCount * 8));
-				if (direct->ev_expand != nullptr)
-					HIP_CHECK(hipEventRecord(direct->ev_expand, stream));
-				hipLaunchKernelGGL(bs_expand_s16_kernel, dim3(blocks3), dim3(256), 0, stream, e);
-				direct->staged = true;
-				direct->slices += 1;
+	// one launch of the apply kernel that fits the arithmetic of R
+	auto launch_apply = [&](const ApplyArgs &dd, int nblocks_apply) {
+		if (B.sgn) {
+			static size_t configured = 0;
+			if (lds > configured) {
+				HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(&bs_apply_s16_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int) lds));
+				configured = lds;
 			}
+			hipLaunchKernelGGL(bs_apply_s16_kernel, dim3(nblocks_apply), dim3(64 * dd.waves), lds, stream, dd);
+		} else if (packed) {
+			launch_apply_variant<true, true>(dd, nblocks_apply, lds, stream);
+		} else if (B.plain) {
+			launch_apply_variant<false, true>(dd, nblocks_apply, lds, stream);
 		} else {
-			hipLaunchKernelGGL(bs_apply_s16_kernel, dim3(blocks), dim3(64 * d.waves), lds, stream, d);
+			launch_apply_variant<false, false>(dd, nblocks_apply, lds, stream);
 		}
-	} else if (packed)
-		launch_apply_variant<true, true>(d, blocks, lds, stream);
-	else if (B.plain)
-		launch_apply_variant<false, true>(d, blocks, lds, stream);
-	else
-		launch_apply_variant<false, false>(d, blocks, lds, stream);
+	};
+	if (direct != nullptr && direct->stage != nullptr && dense_out == nullptr) {
+		// staged output: rows as they stand + lengths, offsets by a scan, sparse rows by a streaming kernel; slices of
+		// stage_rows rows when the staging buffer is smaller than the batch
+		const int nwords = d.Smpad / (packed ? 2 : 1);
+		HIP_CHECK(hipMemsetAsync(direct->Sp, 0, sizeof(int64_t), stream));
+		for (int64_t r0 = 0; r0 < a.nrows; r0 += direct->stage_rows) {
+			const int n = (int) std::min<int64_t>(direct->stage_rows, a.nrows - r0);
+			ApplyArgs d2 = d;
+			d2.direct = 0;
+			d2.stage = direct->stage;
+			d2.a.rows = a.rows + r0;
+			d2.a.row_len = a.row_len + r0;
+			d2.a.nrows = n;
+			const int blocks2 = std::max(1, std::min((n + waves - 1) / waves, prop.multiProcessorCount * 8));
+			const int nblocks = (n + SCAN_BLOCK - 1) / SCAN_BLOCK;
+			d2.block_sum = direct->status;          // (the look-back words are not used by the staged output)
+			HIP_CHECK(hipMemsetAsync(d2.block_sum, 0, (size_t) nblocks * sizeof(unsigned long long), stream));
+			launch_apply(d2, blocks2);
+			hipLaunchKernelGGL(bs_scan_lengths_kernel, dim3(nblocks), dim3(SCAN_BLOCK), 0, stream, a.row_len + r0, n, d2.block_sum, direct->Sp + r0,
+			                   direct->cap, a.ctr);
+			ExpandArgs e{direct->stage, nwords, n, direct->Sp + r0, direct->Sj, direct->Sx, direct->cap, a.q, d.G, d.dbg};
+			const int blocks3 = std::max(1, std::min((n + 3) / 4, prop.multiProcessorCount * 8));
+			if (direct->ev_expand != nullptr)
+				HIP_CHECK(hipEventRecord(direct->ev_expand, stream));
+			if (B.sgn)
+				hipLaunchKernelGGL(bs_expand_kernel<0>, dim3(blocks3), dim3(256), 0, stream, e);
+			else if (packed)
+				hipLaunchKernelGGL(bs_expand_kernel<1>, dim3(blocks3), dim3(256), 0, stream, e);
+			else
+				hipLaunchKernelGGL(bs_expand_kernel<2>, dim3(blocks3), dim3(256), 0, stream, e);
+			direct->staged = true;
+			direct->slices += 1;
+		}
+	} else {
+		launch_apply(d, blocks);
+	}
 	HIP_CHECK(hipGetLastError());
 }
 

@@ -186,7 +186,7 @@ struct BsDirectOut {
 	int64_t *Sp;                  // nrows + 1
 	int *Sj, *Sx;
 	int64_t cap;                  // capacity of Sj / Sx
-	// staged output (signed 16-bit entries, backsolve.hip): room for stage_rows packed rows; nullptr: look-back output
+	// staged output (backsolve.hip): room for stage_rows rows of R's width; nullptr: look-back output
 	uint32_t *stage = nullptr;
 	int64_t stage_rows = 0;
 	hipEvent_t ev_expand = nullptr;   // recorded before the (last) expansion kernel

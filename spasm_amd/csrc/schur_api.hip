@@ -1088,8 +1088,8 @@ eliminated:
 				// staged output: the entries of S leave through bs_expand_s16_kernel; with one slice the two kernels are timed apart
 				stats->bytes_apply -= 8 * total;
 				stats->bytes_expand = 8 * total;
-				stats->bytes_staged = (i64) nrows * B.ldR * 2;
-				snprintf(stats->kernel_expand, sizeof(stats->kernel_expand), "bs_expand_s16_kernel");
+				stats->bytes_staged = (i64) nrows * B.ldR * B.elem_bytes;
+				snprintf(stats->kernel_expand, sizeof(stats->kernel_expand), "bs_expand_kernel<%d>", B.sgn ? 0 : B.elem_bytes == 2 ? 1 : 2);
 				if (bs_staged_slices == 1) {
 					HIP_CHECK(hipEventElapsedTime(&stats->ms_apply, W->ev[5], W->ev[6]));
 					HIP_CHECK(hipEventElapsedTime(&stats->ms_expand, W->ev[6], W->ev[1]));

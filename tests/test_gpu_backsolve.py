@@ -114,9 +114,9 @@ def test_backsolve_extreme_values(oracle, monkeypatch, p, signed):
 
 @pytest.mark.parametrize("env", [{"SPASM_HIP_BS_STAGED": "0"}, {"SPASM_HIP_STAGE_ROWS": "100"}, {"SPASM_HIP_STAGE_ROWS": "1"},
                                  {"SPASM_HIP_BS_DIRECT": "0"}, {"SPASM_HIP_BS_SPARSE_INIT": "0"}, {"SPASM_HIP_BS_SHAPE": "0"}, {"SPASM_HIP_BS_SHAPE": "1"}])
-@pytest.mark.parametrize("p", [257, 42013])
+@pytest.mark.parametrize("p", [257, 42013, 65521, 4294967291])
 def test_backsolve_output_modes(oracle, monkeypatch, p, env):
-    """signed 16-bit entries: look-back output instead of the staged one, staged output in slices of 100 rows and of
+    """every arithmetic: look-back output instead of the staged one, staged output in slices of 100 rows and of
     one row, rows through the pool + gather pass; the build of R from a pre-filled R, in the other workgroup shapes."""
     for k, v in env.items():
         monkeypatch.setenv(k, v)
