@@ -912,7 +912,8 @@ __global__ __launch_bounds__(256) void rref_try_inverse(BlockGjArgs g)
 				}
 			}
 			__syncthreads();
-			const int pr = s_pr[par];
+			// (everything the owner published, in one round of LDS reads)
+			const int pr = s_pr[par], pv = s_pv[par], inv = s_inv[par], fmine = fcol[par][lane];
 			if (pr < 0) {                    // no pivot in this column: the regular path takes the panel
 				if (tid == 0) {
 					*g.gj_done = 0;
@@ -922,7 +923,6 @@ __global__ __launch_bounds__(256) void rref_try_inverse(BlockGjArgs g)
 				}
 				return;
 			}
-			const int pv = s_pv[par], inv = s_inv[par];
 			if (w == o)
 				x[jc] = (lane == pr) ? 1 : 0;          // in place: this column becomes the column of the inverse that row pr stands for
 			// my sixteen entries of the pivot row, normalised (lanes 0 .. 15), back through LDS for everybody's update
@@ -936,7 +936,7 @@ __global__ __launch_bounds__(256) void rref_try_inverse(BlockGjArgs g)
 				t = gj_reduce(__mul24(t, inv), negp, invp);
 				prow[16 * w + lane] = t;
 			}
-			const int fneg = (lane == pr) ? 1 - pv : -fcol[par][lane];          // (row pr: x = pv * prow, so x + (1 - pv) prow = prow)
+			const int fneg = (lane == pr) ? 1 - pv : -fmine;          // (row pr: x = pv * prow, so x + (1 - pv) prow = prow)
 #pragma unroll
 			for (int j = 0; j < 16; j++)
 				x[j] += __mul24(fneg, prow[16 * w + j]);
