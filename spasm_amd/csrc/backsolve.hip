@@ -784,7 +784,8 @@ __global__ __launch_bounds__(512) void bs_apply_s16_kernel(ApplyArgs d)
 	uint32_t *xw = reinterpret_cast<uint32_t *>(plist + AP_LIST);
 	short *xe = reinterpret_cast<short *>(xw);
 	const uint32_t *R = static_cast<const uint32_t *>(d.R);
-	const int64_t ldw = d.ldR / 2;
+	const uint32_t ldw256 = (uint32_t) (d.ldR / 2 / 256);          // row stride of R in units of 256 words (rows are padded to 512 columns):
+	                                                               // the offset of a row in these units fits 32 bits for any R below 4 TB
 	const int2 *q2 = reinterpret_cast<const int2 *>(a.q);          // (the array is padded to whole tile groups)
 	unsigned long long st_input = 0, st_piv = 0;
 	int st_done = 0;
@@ -818,7 +819,7 @@ __global__ __launch_bounds__(512) void bs_apply_s16_kernel(ApplyArgs d)
 			}
 			const uint64_t mk = __ballot(piv);
 			if (piv)
-				plist[npl + __popcll(mk & ((1ull << lane) - 1ull))] = uint2{cid, (uint32_t) (-bal)};
+				plist[npl + __popcll(mk & ((1ull << lane) - 1ull))] = uint2{cid * ldw256, (uint32_t) (-bal)};          // (where the row of R starts, in units of 256 words)
 			npl += __popcll(mk);
 			st_piv += (unsigned long long) __popcll(mk);
 			const bool last = base + 64 >= hi;
@@ -844,7 +845,7 @@ __global__ __launch_bounds__(512) void bs_apply_s16_kernel(ApplyArgs d)
 						const int idx = (pf_e + q < npl) ? pf_e + q : npl - 1;
 						const uint2 pe = plist[idx];
 						cf[q] = (pf_e + q < npl) ? (int) pe.y : 0;          // (coefficient 0: no effect)
-						const uint32_t *rq = R + ((int64_t) pe.x & row_mask) * ldw + t0c + lane;
+						const uint32_t *rq = R + ((((uint64_t) pe.x) << 8) & (uint64_t) row_mask) + t0c + lane;
 #pragma unroll
 						for (int u = 0; u < AP_TU; u++)
 							w[q][u] = rq[u * 64];          // (rows are padded to whole tile groups)
