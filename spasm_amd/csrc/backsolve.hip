@@ -234,6 +234,10 @@ __global__ __launch_bounds__(64 * NW) void backsolve_kernel(BsArgs b)
 	const MontDev F = b.F;
 	const int64_t ldw = b.ldR / Word<PACKED>::CPL;       // row stride of R in words
 	uint32_t *Rs = static_cast<uint32_t *>(b.R) + (int64_t) blockIdx.x * LPR + wl;
+	// a row of R starts at row * ldw words; ldw is a multiple of 256 (rows are padded to 512 columns), and row * (ldw / 256)
+	// fits 32 bits for any R below 4 TB: one 32-bit multiply and a shift instead of a 64-bit multiply per load
+	const uint32_t ldw256 = (uint32_t) (ldw >> 8);
+	auto row_at = [&](uint32_t row) -> uint32_t * { return Rs + ((uint64_t) (row * ldw256) << 8); };
 	const int slot0 = wave * Geo::RS + rs;          // this lane's row slot within an iteration
 	const int col_lo = blockIdx.x * Geo::CW;        // columns [col_lo, col_lo + CW) belong to this workgroup
 
@@ -312,9 +316,9 @@ __global__ __launch_bounds__(64 * NW) void backsolve_kernel(BsArgs b)
 				const bool ok = s < nrows;
 				const uint4 h = fh[ok ? s : 0];
 				const int c = ch.lo + (ok ? s : 0);
-				acc[u] = b.sparse_init ? 0u : Rs[(int64_t) c * ldw];
-				v0[u] = (ok && h.x != BS_NONE) ? Rs[(int64_t) h.x * ldw] : 0u;
-				v1[u] = (ok && h.z != BS_NONE) ? Rs[(int64_t) h.z * ldw] : 0u;
+				acc[u] = b.sparse_init ? 0u : *row_at((uint32_t) c);
+				v0[u] = (ok && h.x != BS_NONE) ? *row_at(h.x) : 0u;
+				v1[u] = (ok && h.z != BS_NONE) ? *row_at(h.z) : 0u;
 			}
 #pragma unroll
 			for (int u = 0; u < Geo::UNR; u++) {
@@ -357,7 +361,7 @@ __global__ __launch_bounds__(64 * NW) void backsolve_kernel(BsArgs b)
 #pragma unroll
 						for (int t = 0; t < 4; t++) {
 							const uint2 en = (e + t < e1) ? b.far[e + t] : uint2{0u, 0u};
-							sgn_mad((e + t < e1) ? Rs[(int64_t) en.x * ldw] : 0u, (int) en.y, lo, hi);
+							sgn_mad((e + t < e1) ? *row_at(en.x) : 0u, (int) en.y, lo, hi);
 						}
 						lo = sgn_reduce(lo, G);
 						hi = sgn_reduce(hi, G);
@@ -366,7 +370,7 @@ __global__ __launch_bounds__(64 * NW) void backsolve_kernel(BsArgs b)
 				} else {
 					for (uint64_t e = e0; e < e1; e++) {
 						const uint2 en = b.far[e];
-						x = w_submul<PACKED, PLAIN>(x, Rs[(int64_t) en.x * ldw], en.y, F, bm);
+						x = w_submul<PACKED, PLAIN>(x, *row_at(en.x), en.y, F, bm);
 					}
 				}
 				ring[s * RSTR + wl] = x;
@@ -443,7 +447,7 @@ __global__ __launch_bounds__(64 * NW) void backsolve_kernel(BsArgs b)
 
 		// ---- phase C: write the chunk back ----
 		for (int s = slot0; s < ((b.dbg & 4) ? 0 : nrows); s += Geo::ROWS_PER_ITER)
-			Rs[(int64_t) (ch.lo + s) * ldw] = ring[s * RSTR + wl];
+			*row_at((uint32_t) (ch.lo + s)) = ring[s * RSTR + wl];
 		__syncthreads();          // (workgroup-scope release/acquire: later chunks read these rows; LDS metadata is free)
 		if (k + 1 < b.nchunks)
 			store_meta();
