@@ -39,6 +39,9 @@ constexpr int BS_RING = 768;       // rows per chunk (the LDS ring holds RING ro
 constexpr int BS_NEARCAP = 1024;   // dependencies inside a chunk that do not fit the pass table (rows with more than two)
 constexpr int BS_PASSCAP = 80;     // phase-B passes of a chunk (32 rows of one level each)
 constexpr int BS_PASSROWS = 32;
+// an empty slot of the pass table points at a spare row of the ring (index BS_RING) with coefficient 0: the signed kernels
+// run every lane through the same reads, multiply-adds and write, without a branch
+#define BS_EMPTY_ENTRY uint4{(uint32_t) BS_RING, (uint32_t) BS_RING | ((uint32_t) BS_RING << 16), 0u, 0u}
 constexpr uint32_t BS_NONE = 0xFFFFFFFFu;
 
 int env_bs(const char *name, int dflt)
@@ -207,7 +210,7 @@ template <bool PACKED, int LPR, int NW> struct BsGeom {
 	static constexpr size_t PTAB_BYTES = (size_t) BS_PASSCAP * BS_PASSROWS * sizeof(uint4);
 	static constexpr int RSTR = LPR + 1;                    // row stride of the ring in words: odd, so that a wave instruction over
 	                                                        // consecutive rows AND one over consecutive words both spread over the banks
-	static constexpr size_t LDS_BYTES = FH_BYTES + PTAB_BYTES + (size_t) BS_NEARCAP * sizeof(uint2) + (size_t) BS_RING * RSTR * 4;
+	static constexpr size_t LDS_BYTES = FH_BYTES + PTAB_BYTES + (size_t) BS_NEARCAP * sizeof(uint2) + (size_t) (BS_RING + 1) * RSTR * 4;          // (+ the spare row)
 };
 
 template <bool PACKED, bool PLAIN, int LPR, int NW, bool SGN = false>
@@ -260,7 +263,7 @@ __global__ __launch_bounds__(64 * NW) void backsolve_kernel(BsArgs b)
 #pragma unroll
 		for (int q = 0; q < Geo::N_PTAB; q++) {
 			const int t = tid + q * Geo::THREADS;
-			m_ptab[q] = (t < c.npass * BS_PASSROWS) ? b.ptab[(int64_t) c.pass0 * BS_PASSROWS + t] : uint4{0u, 0u, 0u, 0u};
+			m_ptab[q] = (t < c.npass * BS_PASSROWS) ? b.ptab[(int64_t) c.pass0 * BS_PASSROWS + t] : BS_EMPTY_ENTRY;
 		}
 	};
 	auto store_meta = [&]() {
@@ -394,11 +397,43 @@ __global__ __launch_bounds__(64 * NW) void backsolve_kernel(BsArgs b)
 		// in flight during the arithmetic of this one.  (Every wave decodes every entry: the table is what keeps that cheap.)
 		{
 			const int niter = ((b.dbg & 2) ? 0 : ch.npass) * (BS_PASSROWS / RSB);
-			uint4 e = (niter > 0) ? ptab[rsb] : uint4{0u, 0u, 0u, 0u};
+			uint4 e = (niter > 0) ? ptab[rsb] : BS_EMPTY_ENTRY;
 			for (int it = 0; it < niter; it++) {
-				const uint4 e_next = (it + 1 < niter) ? ptab[(it + 1) * RSB + rsb] : uint4{0u, 0u, 0u, 0u};
+				const uint4 e_next = (it + 1 < niter) ? ptab[(it + 1) * RSB + rsb] : BS_EMPTY_ENTRY;
 				const int cnt = (int) (e.x >> 16);                    // cnt != 0: this lane has a row in the pass
-				if (cnt != 0) {
+				if constexpr (SGN) {
+					// no branch: an empty slot reads and writes the spare row.  (With a branch around the reads the compiler has
+					// to wait for the write of a pass before it may look at the next table entry.)
+					const int slot = (int) (e.x & 0xFFFFu);
+					const uint32_t x0 = ring[slot * RSTR + wlb];
+					const uint32_t v0 = ring[(e.y & 0xFFFFu) * RSTR + wlb];
+					const uint32_t v1 = ring[(e.y >> 16) * RSTR + wlb];          // (one dependency: the same row again, coefficient 0)
+					int lo, hi;
+					sgn_unpack(x0, lo, hi);
+					sgn_mad(v0, (int) e.z, lo, hi);
+					sgn_mad(v1, (cnt > 2) ? 0 : (int) e.w, lo, hi);          // (more than two: .w is the offset of the others in the list)
+					if (__ballot(cnt > 2) != 0) {
+						if (cnt > 2) {
+							const int rest = cnt - 1;
+							for (int j = 0; j < rest; j += 4) {
+								uint2 em[4];
+								uint32_t wm[4];
+#pragma unroll
+								for (int t = 0; t < 4; t++)
+									em[t] = (j + t < rest) ? near[e.w + j + t] : uint2{(uint32_t) slot, 0u};
+#pragma unroll
+								for (int t = 0; t < 4; t++)
+									wm[t] = ring[em[t].x * RSTR + wlb];
+								lo = sgn_reduce(lo, G);          // (one term or four are in already: four more need a fresh start)
+								hi = sgn_reduce(hi, G);
+#pragma unroll
+								for (int t = 0; t < 4; t++)
+									sgn_mad(wm[t], (int) em[t].y, lo, hi);
+							}
+						}
+					}
+					ring[slot * RSTR + wlb] = sgn_pack(sgn_reduce(lo, G), sgn_reduce(hi, G));
+				} else if (cnt != 0) {
 					const int slot = (int) (e.x & 0xFFFFu);
 					uint32_t x = ring[slot * RSTR + wlb];
 					const uint32_t v0 = ring[(e.y & 0xFFFFu) * RSTR + wlb];
@@ -1535,7 +1570,7 @@ void backsolve_plan(const FactPlan &P, spasm_hip_dfact *F, hipStream_t stream)
 				if (level[c] != last_level || in_level % BS_PASSROWS == 0) {
 					// a new pass: the previous one is padded with empty entries
 					while (ptab.size() % BS_PASSROWS != 0)
-						ptab.push_back(uint4{0u, 0u, 0u, 0u});
+						ptab.push_back(BS_EMPTY_ENTRY);
 					if (level[c] != last_level)
 						in_level = 0;
 					last_level = level[c];
@@ -1563,7 +1598,7 @@ void backsolve_plan(const FactPlan &P, spasm_hip_dfact *F, hipStream_t stream)
 				ptab.push_back(en);
 			}
 			while (ptab.size() % BS_PASSROWS != 0)
-				ptab.push_back(uint4{0u, 0u, 0u, 0u});
+				ptab.push_back(BS_EMPTY_ENTRY);
 			if ((int) (ptab.size() / BS_PASSROWS) - ch.pass0 != ch.npass || (int) near.size() - ch.near0 != ch.nnear)
 				die("backsolve_plan: chunk %zu was counted differently on the second pass (%d passes against %d, %d list entries against %d)", k,
 				    (int) (ptab.size() / BS_PASSROWS) - ch.pass0, ch.npass, (int) near.size() - ch.near0, ch.nnear);
