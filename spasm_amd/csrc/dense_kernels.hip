@@ -1669,18 +1669,64 @@ int device_rref(int64_t prime, int n, int m, uint32_t *dA, int64_t ld, int *d_pi
 {
 	if (n == 0 || m == 0)
 		return 0;
+	const double t_entry = wtime();
+	// work buffers are kept between calls (per host thread; SPASM_HIP_RREF_CACHE=0: allocated and freed every time): 28
+	// hipMalloc / hipFree pairs and the half-gigabyte row buffer of the final permutation were 2 of the 11 ms of a
+	// 4096 x 32768 block, and the dense finish calls this several times in a row
+	struct Cache {
+		int dev = -1;
+		std::vector<std::pair<void *, size_t>> slots;
+	};
+	static thread_local Cache cache;
+	const bool use_cache = std::getenv("SPASM_HIP_RREF_CACHE") == nullptr || std::atoi(std::getenv("SPASM_HIP_RREF_CACHE")) != 0;
+	size_t next_slot = 0;
+	{
+		int dev = 0;
+		HIP_CHECK(hipGetDevice(&dev));
+		if (cache.dev != dev) {
+			for (auto &sl : cache.slots)
+				(void) hipFree(sl.first);
+			cache.slots.clear();
+			cache.dev = dev;
+		}
+	}
+	std::vector<void *> owned;
+	auto ws_malloc = [&](void **ptr, size_t bytes) {
+		if (!use_cache || bytes > ((size_t) 4 << 30)) {
+			HIP_CHECK(hipMalloc(ptr, bytes));
+			owned.push_back(*ptr);
+			return;
+		}
+		if (next_slot == cache.slots.size())
+			cache.slots.push_back({nullptr, 0});
+		auto &sl = cache.slots[next_slot++];
+		if (sl.second < bytes) {
+			(void) hipFree(sl.first);
+			sl.second = bytes + bytes / 4;
+			HIP_CHECK(hipMalloc(&sl.first, sl.second));
+		}
+		*ptr = sl.first;
+	};
+	auto ws_free = [&](void *ptr) {
+		for (size_t t = 0; t < owned.size(); t++)
+			if (owned[t] == ptr) {
+				(void) hipFree(ptr);
+				owned[t] = nullptr;
+				return;
+			}
+	};
 	const Mont M = mont_setup(prime);
 	const MontDev F = to_dev(M);
 	uint32_t *P = nullptr, *B = nullptr;
 	int *flags = nullptr, *pivrow = nullptr, *rank_d = nullptr, *knew = nullptr, *rho = nullptr;
 	const int rmax = (n < m) ? n : m;
-	HIP_CHECK(hipMalloc((void **) &P, (size_t) n * PW * sizeof(uint32_t)));
-	HIP_CHECK(hipMalloc((void **) &B, (size_t) NB * (size_t) m * sizeof(uint32_t)));
-	HIP_CHECK(hipMalloc((void **) &flags, (size_t) n * sizeof(int)));
-	HIP_CHECK(hipMalloc((void **) &pivrow, (size_t) rmax * sizeof(int) + 64));
-	HIP_CHECK(hipMalloc((void **) &rank_d, 64));
-	HIP_CHECK(hipMalloc((void **) &knew, 64));
-	HIP_CHECK(hipMalloc((void **) &rho, NB * sizeof(int)));
+	ws_malloc((void **) &P, (size_t) n * PW * sizeof(uint32_t));
+	ws_malloc((void **) &B, (size_t) NB * (size_t) m * sizeof(uint32_t));
+	ws_malloc((void **) &flags, (size_t) n * sizeof(int));
+	ws_malloc((void **) &pivrow, (size_t) rmax * sizeof(int) + 64);
+	ws_malloc((void **) &rank_d, 64);
+	ws_malloc((void **) &knew, 64);
+	ws_malloc((void **) &rho, NB * sizeof(int));
 	HIP_CHECK(hipMemsetAsync(flags, 0, (size_t) n * sizeof(int), stream));
 	HIP_CHECK(hipMemsetAsync(rank_d, 0, 64, stream));
 	// tall blocks: the panel step is spread over several workgroups (SPASM_HIP_COOP_ROWS rows and up)
@@ -1700,20 +1746,20 @@ int device_rref(int64_t prime, int n, int m, uint32_t *dA, int64_t ld, int *d_pi
 	size_t invtab_bytes = 0;
 	if (tournament) {
 		const size_t cand_len = (size_t) std::max(n, ((n + SEL_ROWS - 1) / SEL_ROWS) * NB) + NB;
-		HIP_CHECK(hipMalloc((void **) &candA, cand_len * sizeof(int)));
-		HIP_CHECK(hipMalloc((void **) &candB, cand_len * sizeof(int)));
-		HIP_CHECK(hipMalloc((void **) &free_count, 64));
-		HIP_CHECK(hipMalloc((void **) &gamma, NB * sizeof(int)));
-		HIP_CHECK(hipMalloc((void **) &cand_first, NB * sizeof(int)));
-		HIP_CHECK(hipMalloc((void **) &first64, NB * sizeof(int)));
-		HIP_CHECK(hipMalloc((void **) &cand_pivot, NB * sizeof(int)));
+		ws_malloc((void **) &candA, cand_len * sizeof(int));
+		ws_malloc((void **) &candB, cand_len * sizeof(int));
+		ws_malloc((void **) &free_count, 64);
+		ws_malloc((void **) &gamma, NB * sizeof(int));
+		ws_malloc((void **) &cand_first, NB * sizeof(int));
+		ws_malloc((void **) &first64, NB * sizeof(int));
+		ws_malloc((void **) &cand_pivot, NB * sizeof(int));
 		HIP_CHECK(hipMemsetAsync(free_count, 0, 64, stream));          // [4]: scan hint of rref_first_free
-		HIP_CHECK(hipMalloc((void **) &P4, (size_t) 2 * MAXSETS * (size_t) n * PW * sizeof(uint32_t)));
-		HIP_CHECK(hipMalloc((void **) &Bt4, (size_t) 4 * (size_t) NB * (size_t) m * sizeof(uint32_t)));
-		HIP_CHECK(hipMalloc((void **) &rho4, 2 * MAXSETS * NB * sizeof(int)));
+		ws_malloc((void **) &P4, (size_t) 2 * MAXSETS * (size_t) n * PW * sizeof(uint32_t));
+		ws_malloc((void **) &Bt4, (size_t) 4 * (size_t) NB * (size_t) m * sizeof(uint32_t));
+		ws_malloc((void **) &rho4, 2 * MAXSETS * NB * sizeof(int));
 		if (small_prime) {
 			invtab_bytes = ((size_t) prime * 2 + 15) / 16 * 16;
-			HIP_CHECK(hipMalloc((void **) &invtab, invtab_bytes + 64));
+			ws_malloc((void **) &invtab, invtab_bytes + 64);
 			hipLaunchKernelGGL(rref_inverse_table, dim3(((unsigned) prime + 255) / 256), dim3(256), 0, stream, invtab, F);
 			static bool configured = false;
 			if (!configured) {
@@ -1728,19 +1774,19 @@ int device_rref(int64_t prime, int n, int m, uint32_t *dA, int64_t ld, int *d_pi
 		// (M planes: one per panel of two super-panels -- the far update of the previous one may still read its own -- and
 		//  as many again for the accumulated multipliers Z; B planes: one per set, one more for a panel's own update, which
 		//  covers the rest of the super-panel and the Z columns)
-		HIP_CHECK(hipMalloc((void **) &M8, (size_t) 4 * MAXSETS * 2 * (size_t) n * 64));
-		HIP_CHECK(hipMalloc((void **) &B8, (size_t) MAXSETS * 2 * (size_t) m * 64 + (size_t) 2 * (2 * MAXSETS * NB + 64) * 64));
-		HIP_CHECK(hipMalloc((void **) &Zacc, (size_t) n * (size_t) (MAXSETS * NB) * sizeof(uint32_t)));
-		HIP_CHECK(hipMalloc((void **) &knew4, 2 * MAXSETS * 16 * sizeof(int)));
-		HIP_CHECK(hipMalloc((void **) &full_flag, 64));
+		ws_malloc((void **) &M8, (size_t) 4 * MAXSETS * 2 * (size_t) n * 64);
+		ws_malloc((void **) &B8, (size_t) MAXSETS * 2 * (size_t) m * 64 + (size_t) 2 * (2 * MAXSETS * NB + 64) * 64);
+		ws_malloc((void **) &Zacc, (size_t) n * (size_t) (MAXSETS * NB) * sizeof(uint32_t));
+		ws_malloc((void **) &knew4, 2 * MAXSETS * 16 * sizeof(int));
+		ws_malloc((void **) &full_flag, 64);
 		HIP_CHECK(hipMemsetAsync(full_flag, 0, 64, stream));          // [0] full, [4] gj_done, [8] try_state
-		HIP_CHECK(hipMalloc((void **) &Ginv, NB * NB * sizeof(uint32_t)));
+		ws_malloc((void **) &Ginv, NB * NB * sizeof(uint32_t));
 	}
 	unsigned int *coop_barrier = nullptr;
 	int *coop_cand = nullptr, *coop_err = nullptr;
-	HIP_CHECK(hipMalloc((void **) &coop_barrier, 64));
-	HIP_CHECK(hipMalloc((void **) &coop_cand, NB * sizeof(int)));
-	HIP_CHECK(hipMalloc((void **) &coop_err, 64));
+	ws_malloc((void **) &coop_barrier, 64);
+	ws_malloc((void **) &coop_cand, NB * sizeof(int));
+	ws_malloc((void **) &coop_err, 64);
 	HIP_CHECK(hipMemsetAsync(coop_err, 0, 64, stream));
 	hipEvent_t e0 = nullptr, e1 = nullptr;
 	if (ms_update != nullptr) {
@@ -1768,6 +1814,10 @@ int device_rref(int64_t prime, int n, int m, uint32_t *dA, int64_t ld, int *d_pi
 			total_update += ms;
 		}
 	};
+	if (std::getenv("SPASM_HIP_RREF_TIMING")) {
+		HIP_CHECK(hipStreamSynchronize(stream));
+		fprintf(stderr, "[rref timing] allocations + setup: %.3f ms\n", 1e3 * (wtime() - t_entry));
+	}
 	if (tournament) {
 		const bool small16 = prime < 65536;
 		const bool try_first = std::getenv("SPASM_HIP_RREF_TRY") == nullptr || std::atoi(std::getenv("SPASM_HIP_RREF_TRY")) != 0;
@@ -2109,6 +2159,14 @@ int device_rref(int64_t prime, int n, int m, uint32_t *dA, int64_t ld, int *d_pi
 			HIP_CHECK(hipGetLastError());
 		}
 	}
+	double t_loop = 0.0;
+	if (std::getenv("SPASM_HIP_RREF_TIMING")) {
+		HIP_CHECK(hipStreamSynchronize(stream));
+		if (stream2 != nullptr)
+			HIP_CHECK(hipStreamSynchronize(stream2));
+		t_loop = wtime();
+		fprintf(stderr, "[rref timing] up to the end of the panels: %.3f ms\n", 1e3 * (t_loop - t_entry));
+	}
 	int rank = 0, coop_failed = 0;
 	HIP_CHECK(hipMemcpyAsync(&rank, rank_d, sizeof(int), hipMemcpyDeviceToHost, stream));
 	if (stream2 != nullptr) {
@@ -2120,49 +2178,51 @@ int device_rref(int64_t prime, int n, int m, uint32_t *dA, int64_t ld, int *d_pi
 	HIP_CHECK(hipMemcpyAsync(&coop_failed, coop_err, sizeof(int), hipMemcpyDeviceToHost, stream));
 	HIP_CHECK(hipStreamSynchronize(stream));
 	if (tournament) {
-		(void) hipFree(candA);
-		(void) hipFree(candB);
-		(void) hipFree(free_count);
-		(void) hipFree(gamma);
-		(void) hipFree(cand_first);
-		(void) hipFree(first64);
-		(void) hipFree(cand_pivot);
-		(void) hipFree(P4);
-		(void) hipFree(Bt4);
-		(void) hipFree(Zacc);
-		(void) hipFree(rho4);
-		(void) hipFree(M8);
-		(void) hipFree(invtab);
-		(void) hipFree(B8);
-		(void) hipFree(knew4);
-		(void) hipFree(full_flag);
-		(void) hipFree(Ginv);
+		ws_free(candA);
+		ws_free(candB);
+		ws_free(free_count);
+		ws_free(gamma);
+		ws_free(cand_first);
+		ws_free(first64);
+		ws_free(cand_pivot);
+		ws_free(P4);
+		ws_free(Bt4);
+		ws_free(Zacc);
+		ws_free(rho4);
+		ws_free(M8);
+		ws_free(invtab);
+		ws_free(B8);
+		ws_free(knew4);
+		ws_free(full_flag);
+		ws_free(Ginv);
 	}
-	(void) hipFree(coop_barrier);
-	(void) hipFree(coop_cand);
-	(void) hipFree(coop_err);
+	ws_free(coop_barrier);
+	ws_free(coop_cand);
+	ws_free(coop_err);
 	if (coop_failed)
 		die("dense RREF: a grid-wide barrier timed out (cooperative panel kernel)");
 	if (rank > 0) {
 		uint32_t *tmp = nullptr;
-		HIP_CHECK(hipMalloc((void **) &tmp, (size_t) rank * (size_t) m * sizeof(uint32_t)));
+		ws_malloc((void **) &tmp, (size_t) rank * (size_t) m * sizeof(uint32_t));
 		hipLaunchKernelGGL(rref_rows_to_tmp, dim3(std::min(rank, 4096)), dim3(256), 0, stream, dA, ld, m, pivrow, rank, tmp);
 		hipLaunchKernelGGL(rref_tmp_to_rows, dim3(std::min(n, 4096)), dim3(256), 0, stream, dA, ld, n, m, rank, tmp);
 		HIP_CHECK(hipStreamSynchronize(stream));
-		(void) hipFree(tmp);
+		ws_free(tmp);
 	}
 	if (ms_update != nullptr) {
 		*ms_update = total_update;
 		(void) hipEventDestroy(e0);
 		(void) hipEventDestroy(e1);
 	}
-	(void) hipFree(P);
-	(void) hipFree(B);
-	(void) hipFree(flags);
-	(void) hipFree(pivrow);
-	(void) hipFree(rank_d);
-	(void) hipFree(knew);
-	(void) hipFree(rho);
+	ws_free(P);
+	ws_free(B);
+	ws_free(flags);
+	ws_free(pivrow);
+	ws_free(rank_d);
+	ws_free(knew);
+	ws_free(rho);
+	if (std::getenv("SPASM_HIP_RREF_TIMING"))
+		fprintf(stderr, "[rref timing] whole call: %.3f ms\n", 1e3 * (wtime() - t_entry));
 	return rank;
 }
 
