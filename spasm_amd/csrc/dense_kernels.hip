@@ -1650,16 +1650,20 @@ __device__ __forceinline__ void copy_row(uint32_t *dst, const uint32_t *src, int
 	}
 }
 
+// (a row that is already in its place -- the usual case: the first free row is the pivot row of its column with probability
+//  1 - 1/p -- is neither copied out nor back)
 __global__ __launch_bounds__(256) void rref_rows_to_tmp(const uint32_t *A, int64_t ld, int m, const int *pivrow, int rank, uint32_t *tmp)
 {
 	for (int t = blockIdx.x; t < rank; t += gridDim.x)
-		copy_row(tmp + (int64_t) t * m, A + (int64_t) pivrow[t] * ld, m, false);
+		if (pivrow[t] != t)
+			copy_row(tmp + (int64_t) t * m, A + (int64_t) pivrow[t] * ld, m, false);
 }
 
-__global__ __launch_bounds__(256) void rref_tmp_to_rows(uint32_t *A, int64_t ld, int n, int m, int rank, const uint32_t *tmp)
+__global__ __launch_bounds__(256) void rref_tmp_to_rows(uint32_t *A, int64_t ld, int n, int m, int rank, const uint32_t *tmp, const int *pivrow)
 {
 	for (int i = blockIdx.x; i < n; i += gridDim.x)
-		copy_row(A + (int64_t) i * ld, tmp + (int64_t) (i < rank ? i : 0) * m, m, i >= rank);
+		if (i >= rank || pivrow[i] != i)
+			copy_row(A + (int64_t) i * ld, tmp + (int64_t) (i < rank ? i : 0) * m, m, i >= rank);
 }
 
 // ---- driver: everything resident on the device.  On return rows 0..rank-1 of A are the reduced
@@ -2205,7 +2209,7 @@ int device_rref(int64_t prime, int n, int m, uint32_t *dA, int64_t ld, int *d_pi
 		uint32_t *tmp = nullptr;
 		ws_malloc((void **) &tmp, (size_t) rank * (size_t) m * sizeof(uint32_t));
 		hipLaunchKernelGGL(rref_rows_to_tmp, dim3(std::min(rank, 4096)), dim3(256), 0, stream, dA, ld, m, pivrow, rank, tmp);
-		hipLaunchKernelGGL(rref_tmp_to_rows, dim3(std::min(n, 4096)), dim3(256), 0, stream, dA, ld, n, m, rank, tmp);
+		hipLaunchKernelGGL(rref_tmp_to_rows, dim3(std::min(n, 4096)), dim3(256), 0, stream, dA, ld, n, m, rank, tmp, pivrow);
 		HIP_CHECK(hipStreamSynchronize(stream));
 		ws_free(tmp);
 	}
