@@ -288,7 +288,15 @@ bool finish_on_device(const struct spasm_csr *A, const int *p, int n, struct spa
 	spasm_hip_dfact *F = cached_dfact(fact->U, fact->qinv, stream);
 	const int Sm0 = F->Sm, m = A->m;
 	F->bs.density_hint = 1.0;            // (this is the finish of a Schur complement that was found dense)
-	if (Sm0 <= 0 || !backsolve_wanted(F, env_int("SPASM_HIP_FORCE_TIER", 0) != 0 || env_int("SPASM_HIP_GROUP", -1) >= 0))
+	if (Sm0 <= 0)
+		return false;
+	// With the back-substituted image R the blocks are a_n - a_p R; without it (Sm too wide for R, or another path forced)
+	// they come from the row-by-row kernels.  Either way they are reduced by the ORIGINAL factor only: what the host loops
+	// would do instead -- append every block's dense echelon rows to U, re-plan and re-upload the grown factor, reduce the
+	// next block by it -- costs seconds per block on a wide remainder (ch8-8.b5: 0.4 -> 2.7 s per 1000 combinations).
+	// SPASM_HIP_DEVICE_FINISH=2 keeps the round-2 rule (device finish only with R).
+	const bool have_R = backsolve_wanted(F, env_int("SPASM_HIP_FORCE_TIER", 0) != 0 || env_int("SPASM_HIP_GROUP", -1) >= 0);
+	if (!have_R && env_int("SPASM_HIP_DEVICE_FINISH", 1) == 2)
 		return false;
 	const i64 prime = A->field->p;
 	// The reference's block size (1000 rows by default) is sized for FFPACK on a CPU; here every block costs one dense RREF of
@@ -306,9 +314,39 @@ bool finish_on_device(const struct spasm_csr *A, const int *p, int n, struct spa
 	const int maxblock = std::max(block, Sn_test);
 	spasm_hip_dwork *W = spasm_hip_dwork_create(maxblock, m, 64);
 	const i64 ld = Sm0;
-	const i64 cap_rows = (i64) std::min(n, Sm0) + maxblock;
+	// the stack [E; Y]: room for the echelon rows found so far plus one block, grown on demand (the rank is only
+	// bounded by min(n, Sm0), and a worst-case allocation would be Sm0^2 words: 45 GB on ch8-8.b5 for 3,900 rows used)
+	i64 cap_rows = std::min<i64>((i64) std::min(n, Sm0) + maxblock, (i64) 3 * maxblock);
+	{
+		size_t free_b = 0, total_b = 0;
+		HIP_CHECK(hipMemGetInfo(&free_b, &total_b));
+		if ((size_t) cap_rows * (size_t) ld * sizeof(u32) > free_b / 2) {
+			spasm_hip_dwork_destroy(W);
+			(void) hipFree(drows);
+			return false;                    // the blocked host loops work in dense_block_size x Sm pieces
+		}
+	}
 	u32 *dM = dalloc<u32>(cap_rows * ld);
 	int *dpiv = dalloc<int>(Sm0);
+	bool out_of_memory = false;
+	auto room_for = [&](int rows_added, int k_now) {
+		if ((i64) k_now + rows_added <= cap_rows)
+			return true;
+		const i64 want = std::min<i64>((i64) std::min(n, Sm0) + maxblock, std::max<i64>(2 * cap_rows, (i64) k_now + rows_added));
+		size_t free_b = 0, total_b = 0;
+		HIP_CHECK(hipMemGetInfo(&free_b, &total_b));
+		if ((size_t) want * (size_t) ld * sizeof(u32) > free_b - free_b / 8) {
+			out_of_memory = true;
+			return false;
+		}
+		u32 *bigger = dalloc<u32>(want * ld);
+		HIP_CHECK(hipMemcpyAsync(bigger, dM, (size_t) k_now * ld * sizeof(u32), hipMemcpyDeviceToDevice, stream));
+		HIP_CHECK(hipStreamSynchronize(stream));
+		(void) hipFree(dM);
+		dM = bigger;
+		cap_rows = want;
+		return true;
+	};
 	static uint64_t salt = 0x5DEECE66DULL;
 	int k = 0;                           // echelon rows found so far: rows [0, k) of dM, in reduced form
 	int rank_ub = std::min(n, Sm0);
@@ -328,9 +366,11 @@ bool finish_on_device(const struct spasm_csr *A, const int *p, int n, struct spa
 		logmsg("[echelonize/dense/device] dense schur complement of dimension %d x %d; block size=%d\n", n, Sm0, block);
 		for (;;) {
 			const int Sn = std::min(block, n - processed);
-			if (Sn <= 0 || k >= Sm0)
+			if (Sn <= 0 || k >= Sm0 || !room_for(Sn, k))
 				break;
+			const double tr0 = wtime();
 			dschur_dense_impl(&dA, drows + processed, Sn, F, W, dM + (i64) k * ld, ld, stream, nullptr);
+			t_rows += wtime() - tr0;
 			const int rr = stack_and_reduce(Sn);
 			logmsg("[echelonize/dense/device] round %d: S[%d:%d], %d new pivots (%d in all)\n", round, processed, processed + Sn, rr, k);
 			round += 1;
@@ -356,7 +396,7 @@ bool finish_on_device(const struct spasm_csr *A, const int *p, int n, struct spa
 		logmsg("[echelonize/dense/low-rank/device] dense schur complement of dimension %d x %d; block size=%d\n", nleft, Sm0 - k, block);
 		for (;;) {
 			const int Sn = std::min(rank_ub, block);
-			if (Sn <= 0)
+			if (Sn <= 0 || !room_for(std::max(Sn, Sn_test), k))
 				break;
 			salt += 0x9E3779B97F4A7C15ULL;
 			const double tr0 = wtime();
@@ -440,9 +480,11 @@ bool finish_on_device(const struct spasm_csr *A, const int *p, int n, struct spa
 	(void) hipFree(dpiv);
 	spasm_hip_dwork_destroy(W);
 	(void) hipFree(drows);
-	logmsg("[echelonize/dense/device] completed in %.2fs (dense rows %.2fs, RREF %.2fs). %d new pivots found\n", wtime() - start,
-	       t_rows, t_rref, U->n - old_un);
-	return true;
+	logmsg("[echelonize/dense/device] completed in %.2fs (dense rows %.2fs, RREF %.2fs; %s). %d new pivots found\n", wtime() - start,
+	       t_rows, t_rref, have_R ? "blocks from the back-substituted image" : "blocks from the row-by-row kernels", U->n - old_un);
+	if (out_of_memory)
+		logmsg("[echelonize/dense/device] the stack of echelon rows no longer fits in HBM: the host loops take over\n");
+	return !out_of_memory;          // (the echelon rows found so far are in U either way)
 }
 
 }  // namespace sh

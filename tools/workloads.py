@@ -112,10 +112,54 @@ def mk_boundary(nv, K):
     return len(big), len(small), np.array(ti, np.int32), np.array(tj, np.int32), np.array(tx, np.int64)
 
 
+# --------------------------------------------------------------------------
+# chessboard complexes (STAND-INS, never BASELINE configs)
+# --------------------------------------------------------------------------
+def _rook_placements(nr, nc, size):
+    """non-attacking placements of `size` rooks on an nr x nc board, each as a tuple of (row, column) cells sorted
+    by row; the list is in lexicographic order."""
+    out = []
+    for rows in itertools.combinations(range(nr), size):
+        for cols in itertools.permutations(range(nc), size):
+            out.append(tuple(zip(rows, cols)))
+    return out
+
+
+def ch_boundary(nr, nc, K):
+    """ch<nr>-<nc>.b<K> (hpac "Homology/ch"): rows = placements of K+1 non-attacking rooks on an nr x nc board,
+    columns = placements of K rooks, entry (-1)^t for the face that drops the t-th rook.  Checked against the
+    published sizes: ch7-8.b5 141120 x 141120 (846720 nnz), ch8-8.b5 564480 x 376320 (3386880 nnz)."""
+    big = _rook_placements(nr, nc, K + 1)
+    small = _rook_placements(nr, nc, K)
+    index = {s: i for i, s in enumerate(small)}
+    n = len(big)
+    ti = np.repeat(np.arange(n, dtype=np.int32), K + 1)
+    tj = np.empty(n * (K + 1), np.int32)
+    tx = np.tile(np.array([1 if t % 2 == 0 else -1 for t in range(K + 1)], np.int64), n)
+    pos = 0
+    for s in big:
+        for t in range(K + 1):
+            tj[pos] = index[s[:t] + s[t + 1:]]
+            pos += 1
+    return n, len(small), ti, tj, tx
+
+
+# Stand-ins for the BASELINE matrices whose files cannot be fetched: same hpac "Homology" collection, closed-form,
+# and -- unlike the matching complexes -- their Schur complements stay sparse for several elimination rounds, which
+# is the flow GL7d19 takes (spasm_echelonize.c:525-580, then the dense tail at --dense-threshold 0.01).
+STAND_INS = {
+    "ch7-8.b5": {"for": "GL7d19", "rank_args": ["--dense-threshold", "0.01"], "shape": (141120, 141120), "nnz": 846720},
+    "ch8-8.b5": {"for": "GL7d19", "rank_args": ["--dense-threshold", "0.01"], "shape": (564480, 376320), "nnz": 3386880},
+}
+
+
 def _triplets_of(name):
     kind = name.split(".")[0]
     if kind.startswith("mk") and ".b" in name:
         return mk_boundary(int(kind[2:]), int(name.split(".b")[1]))
+    if kind.startswith("ch") and "-" in kind and ".b" in name:
+        nr, nc = kind[2:].split("-")
+        return ch_boundary(int(nr), int(nc), int(name.split(".b")[1]))
     raise ValueError("no generator for %s" % name)
 
 
