@@ -7,6 +7,10 @@
 // Then the pivotal rows are ordered topologically and appended to U, scaled so
 // that every pivot is 1 and stored first in its row.
 #include <atomic>
+#include <cstdint>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
 #include <mutex>
 #include <thread>
 #include <algorithm>
@@ -22,6 +26,44 @@ spasm_hip_comm *current_comm();
 int comm_rank(const spasm_hip_comm *c);
 int comm_world(const spasm_hip_comm *c);
 void comm_bcast_host(spasm_hip_comm *c, void *buf, size_t bytes, int root);
+}  // namespace sh
+
+namespace sh {
+// CPUs this process may really use: the hardware threads, cut down to the CPU quota of its control group when there is
+// one (cgroup v2 cpu.max, v1 cfs_quota_us).  The MI355X boxes of this pool report 256 hardware threads and grant 16 CPUs
+// (cpu.max = "1600000 100000"; tools/cpu_scaling.cpp: 16 threads run in the time of one, 32 take twice as long) --
+// which is why the threaded pivot search stopped scaling at 16 threads in round 2, not its commit lock.
+int usable_cpus()
+{
+	int hw = (int) std::thread::hardware_concurrency();
+	if (hw <= 0)
+		hw = 1;
+	double quota = 0.0;
+	if (FILE *f = std::fopen("/sys/fs/cgroup/cpu.max", "r")) {
+		char a[64] = {0};
+		long long period = 0;
+		if (std::fscanf(f, "%63s %lld", a, &period) == 2 && std::strcmp(a, "max") != 0 && period > 0)
+			quota = std::atof(a) / (double) period;
+		std::fclose(f);
+	} else {
+		long long q = -1, period = 0;
+		if (FILE *g = std::fopen("/sys/fs/cgroup/cpu/cpu.cfs_quota_us", "r")) {
+			if (std::fscanf(g, "%lld", &q) != 1)
+				q = -1;
+			std::fclose(g);
+		}
+		if (FILE *g = std::fopen("/sys/fs/cgroup/cpu/cpu.cfs_period_us", "r")) {
+			if (std::fscanf(g, "%lld", &period) != 1)
+				period = 0;
+			std::fclose(g);
+		}
+		if (q > 0 && period > 0)
+			quota = (double) q / (double) period;
+	}
+	if (quota >= 1.0 && quota < (double) hw)
+		hw = (int) (quota + 0.5);
+	return hw;
+}
 }  // namespace sh
 
 namespace {
@@ -157,7 +199,10 @@ struct Search {
 		std::atomic<int> npiv{0};
 		std::atomic<int> next_row{0};
 		std::mutex commit;
+		const bool prefetch = std::getenv("SPASM_HIP_PIVOT_PREFETCH") == nullptr || std::atoi(std::getenv("SPASM_HIP_PIVOT_PREFETCH")) != 0;
+		std::atomic<unsigned long long> total_visits{0}, total_retries{0};
 		auto worker = [&]() {
+			unsigned long long visits = 0, retries = 0;
 			std::vector<signed char> mark((size_t) (m > 0 ? m : 1), 0);
 			std::vector<int> fifo((size_t) (m > 0 ? m : 1));
 			for (;;) {
@@ -184,11 +229,42 @@ struct Search {
 							push(j);
 						}
 					}
+					// a pivot that appeared behind our back only matters when its column is one we marked: a candidate of
+					// ours that became pivotal, or a column of a row we reached (whose new row must then be explored).
+					// Pivots on untouched columns cannot be reached from our row and leave the search as it stands.
+					auto absorb = [&](int jn) {
+						if (mark[jn] == 0)
+							return false;
+						if (mark[jn] == 1) {
+							push(jn);
+						} else {
+							const int row = q[jn].load(std::memory_order_relaxed);
+							for (i64 px = A->p[row]; px < A->p[row + 1]; px++) {
+								const int j = A->j[px];
+								if (mark[j] >= 0)
+									push(j);
+							}
+						}
+						return true;
+					};
 					for (;;) {
 						while (head < tail && candidates > 0) {
+							// the search is a chain of dependent random reads (column -> pivot row -> extent -> entries ->
+							// marks): ask for the rows of the columns a few places further down the queue now
+							if (prefetch && head + 6 < tail) {
+								const int r6 = q[fifo[head + 6]].load(std::memory_order_relaxed);
+								if (r6 >= 0)
+									__builtin_prefetch(&A->p[r6]);
+							}
+							if (prefetch && head + 3 < tail) {
+								const int r3 = q[fifo[head + 3]].load(std::memory_order_relaxed);
+								if (r3 >= 0)
+									__builtin_prefetch(&A->j[A->p[r3]]);
+							}
 							const int row = q[fifo[head++]].load(std::memory_order_relaxed);
 							if (row == -1)
 								continue;
+							visits += 1;
 							for (i64 px = A->p[row]; px < A->p[row + 1]; px++) {
 								const int j = A->j[px];
 								if (mark[j] >= 0)
@@ -197,42 +273,44 @@ struct Search {
 						}
 						if (candidates == 0)
 							break;
+						retries += 1;
+						// catch up with the journal WITHOUT the lock; go back to the search if any of it touched us
+						bool touched = false;
+						for (const int target = npiv.load(std::memory_order_acquire); seen < target; seen++)
+							touched |= absorb(journal[seen]);
+						if (touched)
+							continue;
 						int chosen = -1;
 						for (i64 px = A->p[i]; px < A->p[i + 1]; px++) {
 							chosen = A->j[px];
 							if (mark[chosen] == 1)
 								break;
 						}
-						int target = -1;
+						// commit: under the lock only the few pivots that arrived since the catch-up are looked at, and
+						// the commit goes through unless one of THEM touches this search (the reference retries whenever
+						// anything at all was committed meanwhile -- spasm_pivots.c:262-290 -- which is what stopped the
+						// threaded search from scaling past 16 threads: with T searches in flight nearly every attempt
+						// finds the counter moved)
+						bool done = false;
 						{
 							std::lock_guard<std::mutex> lock(commit);
 							const int now = npiv.load(std::memory_order_relaxed);
-							if (now == seen) {
+							bool clean = true;
+							for (int t = seen; t < now; t++)
+								if (mark[journal[t]] != 0) {
+									clean = false;
+									break;
+								}
+							if (clean) {
 								q[chosen].store(i, std::memory_order_relaxed);
 								pinv[i] = chosen;
 								journal[now] = chosen;
 								npiv.store(now + 1, std::memory_order_release);
-							} else {
-								target = now;
+								done = true;
 							}
 						}
-						if (target < 0)
-							break;                    // committed
-						for (; seen < target; seen++) {   // pivots that appeared behind our back
-							const int jn = journal[seen];
-							if (mark[jn] == 0)
-								continue;
-							if (mark[jn] == 1) {
-								push(jn);             // a candidate became pivotal
-							} else {
-								const int row = q[jn].load(std::memory_order_relaxed);
-								for (i64 px = A->p[row]; px < A->p[row + 1]; px++) {
-									const int j = A->j[px];
-									if (mark[j] >= 0)
-										push(j);
-								}
-							}
-						}
+						if (done)
+							break;
 					}
 					for (i64 px = A->p[i]; px < A->p[i + 1]; px++)
 						mark[A->j[px]] = 0;
@@ -240,12 +318,17 @@ struct Search {
 						mark[fifo[t]] = 0;
 				}
 			}
+			total_visits += visits;
+			total_retries += retries;
 		};
 		std::vector<std::thread> pool;
 		for (int t = 0; t < T; t++)
 			pool.emplace_back(worker);
 		for (auto &th : pool)
 			th.join();
+		if (std::getenv("SPASM_HIP_PIVOT_STATS"))
+			logmsg("[pivots] %d threads: %llu pivot rows visited, %llu commit attempts for %d pivots\n", T,
+			       total_visits.load(), total_retries.load(), npiv.load());
 		for (int j = 0; j < m; j++)
 			qinv[j] = q[j].load(std::memory_order_relaxed);
 		return npiv.load();
@@ -337,11 +420,8 @@ extern "C" int spasm_hip_pivots_extract_structural(const struct spasm_csr *A, co
 			int threads = 0;
 			if (const char *e = std::getenv("SPASM_HIP_THREADS"))
 				threads = std::atoi(e);
-			if (threads <= 0) {
-				threads = (int) std::thread::hardware_concurrency();
-				if (threads > 16)          // (commits serialise the searches: 16 threads 0.57 s, 32: 0.63 s, 128: 1.0 s on mk13.b5)
-					threads = 16;
-			}
+			if (threads <= 0)
+				threads = usable_cpus();
 			if (A->n < 20000)
 				threads = 1;                  // small inputs: the sequential search (deterministic) is as fast
 			extra = (threads > 1) ? S.acyclic_greedy_threads(threads) : S.acyclic_greedy();
