@@ -139,7 +139,8 @@ static int dschur_dense_impl(const spasm_hip_dcsr *A, const int *d_rows, int nro
 			group_mode = 0;
 	}
 	if (group_mode) {
-		gwaves = env_int("SPASM_HIP_GROUP_WAVES", (nrows + 63) / 64 <= cus * 3 ? 4 : (nrows + 63) / 64 <= cus * 12 ? 2 : 1);
+		const i64 in_flight = std::min<i64>((nrows + 63) / 64, budget / gslot);          // (groups, or what the budget holds: schur_api.hip)
+		gwaves = env_int("SPASM_HIP_GROUP_WAVES", in_flight <= cus * 3 ? 4 : in_flight <= cus * 12 ? 2 : 1);
 		gslots = (int) std::max<i64>(1, std::min<i64>((nrows + 63) / 64, std::min<i64>(gwaves >= 4 ? cus * 2 : gwaves >= 2 ? cus * 4 : cus * 8, budget / gslot)));
 		need = gslot * gslots;
 	}

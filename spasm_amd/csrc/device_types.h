@@ -178,6 +178,9 @@ void resident_end();
 void resident_forget(const struct spasm_csr *A);
 bool resident_enabled();
 void resident_counters(int64_t *uploads, int64_t *hits);
+void resident_lazy_downloads(bool on);
+void resident_materialize(const struct spasm_csr *A);
+int resident_fl_census(const struct spasm_csr *A);
 
 // where bs_apply_kernel writes a sparse result directly in its final place (rows in order, offsets by look-back)
 struct BsDirectOut {

@@ -20,6 +20,12 @@ bool finish_on_device(const struct spasm_csr *A, const int *p, int n, struct spa
 
 using namespace sh;
 
+static int env_int_host(const char *name, int dflt)
+{
+	const char *e = std::getenv(name);
+	return (e == nullptr || *e == 0) ? dflt : std::atoi(e);
+}
+
 // --------------------------------------------------------------------------
 // SHA-256 counter-mode generator (same stream as spasm_prng.c, so that seeded
 // runs draw the same coefficients as the reference)
@@ -409,6 +415,7 @@ extern "C" struct spasm_lu *spasm_hip_echelonize(const struct spasm_csr *A0, str
 	double density = (n > 0 && m > 0) ? (double) A->p[A->n] / n / m : 0.0;
 	int npiv = 0, status = 0, round;
 	// status 0: round limit reached / 1: nothing left / 2: pivots found, Schur complement not computed
+	// 3: a Schur complement was computed and the census says no further round (its entries may still be on the device only)
 	for (round = 0; round < opts->max_round; round++) {
 		if (A->p[A->n] == 0) {
 			status = 1;
@@ -438,7 +445,10 @@ extern "C" struct spasm_lu *spasm_hip_echelonize(const struct spasm_csr *A0, str
 		struct spasm_csr *S;
 		{
 			Stopwatch sw(3);
+			// the entries of S stay on the device until somebody needs them on the host (see below)
+			resident_lazy_downloads(round + 1 < opts->max_round && env_int_host("SPASM_HIP_LAZY_DOWNLOAD", 1) != 0);
 			S = spasm_hip_schur(A, p + npiv, n - npiv, fact, density, fact->Ltmp, p_in, p_out);
+			resident_lazy_downloads(false);
 		}
 		g_prof[5] += 1.0;
 		if (A != A0) {
@@ -449,6 +459,26 @@ extern "C" struct spasm_lu *spasm_hip_echelonize(const struct spasm_csr *A0, str
 		n = n - npiv;
 		std::free(p_in);
 		p_in = p_out;
+		// Is another structural round worth bringing S to the host for (8 bytes per entry over PCIe, then a search whose
+		// graph walks grow with the density of S)?  The first step of the search -- one pivot per distinct leftmost column,
+		// spasm_pivots.c:35-80 -- is counted on the device, where S already is: in every search logged so far the later
+		// steps (columns, greedy) added less than that again, so when even EIGHT times the count would fall short of
+		// min_pivot_proportion the round would end in "not enough pivots" and is skipped (mk14.b4: 89 leftmost pivots on a
+		// 673,000 x 42,000 complement with 1.06e9 entries; the search found 299 in 1.4 s after a 0.7 s download and stopped).
+		// The remainder goes to the finishing code as it would have, with no pivots of its own: same row space.
+		const int census = (round + 1 < opts->max_round) ? resident_fl_census(A) : -1;
+		if (census >= 0 && 8.0 * census < opts->min_pivot_proportion * std::min(n, m - U->n)) {
+			logmsg("[echelonize] %d leftmost-entry pivots in the Schur complement (counted on the device): not enough for another round\n", census);
+			npiv = 0;
+			for (int i = 0; i < n; i++)
+				p[i] = i;
+			status = 3;
+			break;
+		}
+		{
+			Stopwatch sw(3);
+			resident_materialize(A);
+		}
 	}
 	if (status == 0) {
 		npiv = 0;
@@ -458,16 +488,23 @@ extern "C" struct spasm_lu *spasm_hip_echelonize(const struct spasm_csr *A0, str
 	if (status != 1) {
 		const double aspect = (m - U->n > 0) ? (double) (n - npiv) / (m - U->n) : 0.0;
 		logmsg("[echelonize] finishing; density = %.3f; aspect ratio = %.1f\n", density, aspect);
+		// (status 3: the entries of A may be on the device only; the device finish never reads them on the host, everything
+		// else gets them first)
 		if (opts->enable_tall_and_skinny && aspect > opts->tall_and_skinny_ratio) {
 			Stopwatch sw(4);
-			if (!finish_on_device(A, p + npiv, n - npiv, fact, opts, true))
+			if (!finish_on_device(A, p + npiv, n - npiv, fact, opts, true)) {
+				resident_materialize(A);
 				finish_lowrank(A, p + npiv, n - npiv, fact, opts);
+			}
 		} else if (opts->enable_dense && density > opts->sparsity_threshold) {
 			Stopwatch sw(4);
-			if (!finish_on_device(A, p + npiv, n - npiv, fact, opts, false))
+			if (!finish_on_device(A, p + npiv, n - npiv, fact, opts, false)) {
+				resident_materialize(A);
 				finish_dense(A, p + npiv, n - npiv, p_in, fact, opts);
+			}
 		} else if (opts->enable_GPLU) {
 			Stopwatch sw(6);
+			resident_materialize(A);
 			// The reference reduces the remaining rows one by one (GPLU, a sequential loop).  Here the
 			// remainder keeps going through structural rounds on the GPU: each one finds at least one
 			// pivot while the remainder is non-zero, so this terminates with the same row space.

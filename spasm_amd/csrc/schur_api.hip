@@ -122,9 +122,11 @@ struct ResidentEntry {
 	i64 *p;
 	int *j, *x;
 	i64 nnz;
+	bool host_stale;          // the host struct has its row pointers only: j and x were never downloaded (resident_materialize)
 };
 static std::vector<ResidentEntry> g_resident;
 static bool g_resident_on = false;
+static bool g_lazy_download = false;
 static i64 g_resident_uploads = 0, g_resident_hits = 0;
 
 void resident_begin() { g_resident_on = true; }
@@ -155,10 +157,77 @@ void resident_counters(i64 *uploads, i64 *hits)
 }
 
 // takes ownership of device arrays that hold the matrix `host` describes (a fresh Schur complement)
-void resident_adopt(const struct spasm_csr *host, i64 *dp, int *dj, int *dx)
+void resident_adopt(const struct spasm_csr *host, i64 *dp, int *dj, int *dx, bool host_stale)
 {
 	resident_forget(host);
-	g_resident.push_back(ResidentEntry{host, dp, dj, dx, host->p[host->n]});
+	g_resident.push_back(ResidentEntry{host, dp, dj, dx, host->p[host->n], host_stale});
+}
+
+// The driver may ask spasm_hip_schur to leave the entries of S on the device (the host struct gets its row pointers only):
+// whether the next round needs them on the host at all is decided by a census on the device first (resident_fl_census).
+void resident_lazy_downloads(bool on) { g_lazy_download = on; }
+
+// brings the entries of a lazily returned Schur complement to its host struct (no-op when they are there)
+void resident_materialize(const struct spasm_csr *A)
+{
+	for (ResidentEntry &e : g_resident)
+		if (e.host == A && e.host_stale) {
+			if (e.nnz > 0) {
+				HIP_CHECK(hipMemcpy(A->j, e.j, (size_t) e.nnz * sizeof(int), hipMemcpyDeviceToHost));
+				HIP_CHECK(hipMemcpy(A->x, e.x, (size_t) e.nnz * sizeof(int), hipMemcpyDeviceToHost));
+			}
+			e.host_stale = false;
+			return;
+		}
+}
+
+__global__ __launch_bounds__(256) void fl_census_kernel(const i64 *Ap, const int *Aj, int n, uint32_t *bitmap)
+{
+	// one wave per row: the smallest column of the row (rows need not be sorted), one bit per distinct column
+	const int row = (int) ((blockIdx.x * 256 + threadIdx.x) >> 6), lane = threadIdx.x & 63;
+	if (row >= n)
+		return;
+	int best = 0x7FFFFFFF;
+	for (i64 px = Ap[row] + lane; px < Ap[row + 1]; px += 64)
+		best = min(best, Aj[px]);
+	for (int d = 32; d >= 1; d >>= 1)
+		best = min(best, __shfl_xor(best, d));
+	if (lane == 0 && best != 0x7FFFFFFF)
+		atomicOr(&bitmap[best >> 5], 1u << (best & 31));
+}
+
+__global__ __launch_bounds__(256) void popcount_kernel(const uint32_t *bitmap, int nwords, int *out)
+{
+	int c = 0;
+	for (int w = blockIdx.x * 256 + threadIdx.x; w < nwords; w += gridDim.x * 256)
+		c += __popc(bitmap[w]);
+	for (int d = 32; d >= 1; d >>= 1)
+		c += __shfl_xor(c, d);
+	if ((threadIdx.x & 63) == 0 && c != 0)
+		atomicAdd(out, c);
+}
+
+// How many pivots would the first step of the structural search (Faugere-Lachartre: the leftmost entry of every row, one
+// row per column -- spasm_pivots.c:35-80, host_pivots.cpp leftmost_entries) find on this device-resident matrix?  = the
+// number of distinct leftmost columns.  -1 when the matrix is not resident.
+int resident_fl_census(const struct spasm_csr *A)
+{
+	for (const ResidentEntry &e : g_resident)
+		if (e.host == A) {
+			const int n = A->n, m = A->m;
+			const int nwords = (m + 31) / 32 + 1;
+			uint32_t *bm = nullptr;
+			HIP_CHECK(hipMalloc((void **) &bm, ((size_t) nwords + 1) * sizeof(uint32_t)));
+			HIP_CHECK(hipMemset(bm, 0, ((size_t) nwords + 1) * sizeof(uint32_t)));
+			if (n > 0)
+				hipLaunchKernelGGL(fl_census_kernel, dim3((unsigned) (((i64) n * 64 + 255) / 256)), dim3(256), 0, nullptr, e.p, e.j, n, bm);
+			hipLaunchKernelGGL(popcount_kernel, dim3(64), dim3(256), 0, nullptr, bm, nwords, reinterpret_cast<int *>(bm + nwords));
+			int count = 0;
+			HIP_CHECK(hipMemcpy(&count, bm + nwords, sizeof(int), hipMemcpyDeviceToHost));
+			(void) hipFree(bm);
+			return count;
+		}
+	return -1;
 }
 
 bool resident_enabled() { return g_resident_on; }
@@ -807,7 +876,11 @@ int dschur_impl(const spasm_hip_dcsr *A, const int *d_rows, int nrows, const spa
 			// the chain of level rounds of one group, which the waves split between them (tools/probe_groups.py)
 			// (slots = workgroups = accumulator slices: as many as are resident at two waves per SIMD; the others
 			//  would only wait for a CU and find the queue of groups empty)
-			group_waves = env_int("SPASM_HIP_GROUP_WAVES", ngroups <= cus * 3 ? 4 : ngroups <= cus * 12 ? 2 : 1);
+			// ... and the same when it is the BUDGET that keeps the groups in flight few (wide factors: a slice of mk14.b4 is
+			// 80 MB, 297 of them fit the 24 GB of a one-shot call -- one wave each would leave the chip at one wave per CU:
+			// 641 ms against 334 ms with four waves per group)
+			const i64 in_flight = std::min<i64>(ngroups, budget / group_slot_bytes);
+			group_waves = env_int("SPASM_HIP_GROUP_WAVES", in_flight <= cus * 3 ? 4 : in_flight <= cus * 12 ? 2 : 1);
 			group_slots = (int) std::min<i64>(env_int("SPASM_HIP_GROUP_SLOTS", group_waves >= 4 ? cus * 2 : group_waves >= 2 ? cus * 4 : cus * 8),
 			                                  budget / group_slot_bytes);
 			group_slots = std::max(1, std::min(group_slots, ngroups));
@@ -939,7 +1012,11 @@ int dschur_impl(const spasm_hip_dcsr *A, const int *d_rows, int nrows, const spa
 			// Abandoned rows keep row_len == -1 and go to the per-row tiers.
 			HIP_CHECK(hipMemsetAsync(W->d_row_len, 0xFF, (size_t) nrows * sizeof(int), stream));
 			const float min_eff = (float) env_int("SPASM_HIP_GROUP_MIN_EFF_PCT", 4) / 100.0f;
-			const long long min_w = env_int("SPASM_HIP_GROUP_MIN_PIVOTS", 500000);
+			// (... per group in flight: the judgement used to fall after 500,000 pivots whatever the number of groups, i.e. after
+			// 1,700 pivots of each of the 297 groups of a mk14.b4 call -- all of them still in the cheap private start of their
+			// rows -- and sent a batch whose final efficiency is 0.60 to the per-row tier: 1.68 s instead of 0.35 s)
+			const long long min_w = std::max<long long>(env_int("SPASM_HIP_GROUP_MIN_PIVOTS", 500000),
+			                                            (long long) env_int("SPASM_HIP_GROUP_MIN_PIVOTS_PER_GROUP", 8192) * group_slots);
 			// several connected components in the pivot graph: rows of different components share nothing, so the
 			// rows are grouped by component from the start (the order of the list is kept inside a component; with a
 			// single or a dominant component -- mk13.b5: 109,966 of its 111,177 pivots -- nothing is done)
@@ -1193,6 +1270,7 @@ struct spasm_csr *spasm_hip_schur(const struct spasm_csr *A, const int *p, int n
 	spasm_hip_schur_stats st{};
 	spasm_hip_dwork *W = nullptr;
 	const double t1 = wtime();
+	double t_wcreate = 0.0;
 	// L requested: pools for the elimination coefficients, grown on demand
 	LOut lout;
 	i64 lcap = (L != nullptr) ? std::max<i64>(16 * in_nnz, (i64) 1 << 24) : 0;
@@ -1214,7 +1292,9 @@ struct spasm_csr *spasm_hip_schur(const struct spasm_csr *A, const int *p, int n
 			lout.Lx = dalloc<int>(lcap);
 			HIP_CHECK(hipMemsetAsync(lout.Li, 0xFF, (size_t) lcap * sizeof(int), stream));
 		}
+		const double tw0 = wtime();
 		W = spasm_hip_dwork_create(n, m, pool);
+		t_wcreate += wtime() - tw0;
 		// one-shot call: allocating tens of GB costs more than the kernel gains from having every
 		// row group resident at once (hipMalloc is ~30 ms per GB); the device-level API keeps its
 		// workspace and takes the large budget
@@ -1271,6 +1351,7 @@ struct spasm_csr *spasm_hip_schur(const struct spasm_csr *A, const int *p, int n
 	const double t_run = wtime() - t1;
 	const double t2 = wtime();
 	struct spasm_csr *S = nullptr;
+	bool lazy = false;
 	if (shard) {
 		// all-gatherv of the slices (sizes first, then exact-count broadcasts), then one download of the whole
 		i64 total = 0;
@@ -1290,7 +1371,7 @@ struct spasm_csr *spasm_hip_schur(const struct spasm_csr *A, const int *p, int n
 			HIP_CHECK(hipMemcpy(S->x, gSx, (size_t) total * sizeof(int), hipMemcpyDeviceToHost));
 		}
 		if (resident_enabled() && n_all >= 1024) {
-			resident_adopt(S, gSp, gSj, gSx);          // the next round's A is already on every device
+			resident_adopt(S, gSp, gSj, gSx, false);          // the next round's A is already on every device
 		} else {
 			(void) hipFree(gSp);
 			(void) hipFree(gSj);
@@ -1299,22 +1380,19 @@ struct spasm_csr *spasm_hip_schur(const struct spasm_csr *A, const int *p, int n
 	} else {
 		S = spasm_hip_csr_alloc(n, m, st.nnz, prime, true);
 		HIP_CHECK(hipMemcpy(S->p, W->d_Sp, ((size_t) n + 1) * sizeof(i64), hipMemcpyDeviceToHost));
-		if (st.nnz > 0) {
+		const bool keep = resident_enabled() && n >= 1024;
+		lazy = keep && g_lazy_download && L == nullptr;
+		if (st.nnz > 0 && !lazy) {
 			HIP_CHECK(hipMemcpy(S->j, W->d_Sj, (size_t) st.nnz * sizeof(int), hipMemcpyDeviceToHost));
 			HIP_CHECK(hipMemcpy(S->x, W->d_Sx, (size_t) st.nnz * sizeof(int), hipMemcpyDeviceToHost));
 		}
-		if (resident_enabled() && n >= 1024) {
-			// keep the result where it was computed (a device-to-device copy out of the workspace, which is sized for the
-			// estimate, not for the result): it is the A of the next round
-			i64 *kp = dalloc<i64>((i64) n + 1);
-			int *kj = dalloc<int>(st.nnz), *kx = dalloc<int>(st.nnz);
-			HIP_CHECK(hipMemcpyAsync(kp, W->d_Sp, ((size_t) n + 1) * sizeof(i64), hipMemcpyDeviceToDevice, stream));
-			if (st.nnz > 0) {
-				HIP_CHECK(hipMemcpyAsync(kj, W->d_Sj, (size_t) st.nnz * sizeof(int), hipMemcpyDeviceToDevice, stream));
-				HIP_CHECK(hipMemcpyAsync(kx, W->d_Sx, (size_t) st.nnz * sizeof(int), hipMemcpyDeviceToDevice, stream));
-			}
-			HIP_CHECK(hipStreamSynchronize(stream));
-			resident_adopt(S, kp, kj, kx);
+		if (keep) {
+			// keep the result where it was computed -- it is the A of the next round: the table takes the workspace's arrays
+			// over (no copy; they are sized for the estimate, a little more than the result)
+			resident_adopt(S, W->d_Sp, W->d_Sj, W->d_Sx, lazy);
+			W->d_Sp = nullptr;
+			W->d_Sj = nullptr;
+			W->d_Sx = nullptr;
 		}
 	}
 	if (p_out != nullptr)
@@ -1326,9 +1404,13 @@ struct spasm_csr *spasm_hip_schur(const struct spasm_csr *A, const int *p, int n
 	spasm_hip_dwork_destroy(W);
 	(void) hipFree(drows);
 	const double density = (S->n > 0 && m > 0) ? (double) S->p[S->n] / ((double) m * S->n) : 0.0;
-	logmsg("Schur complement: %d * %d [%" PRId64 " nz / density= %.3f], %.1fs (GPU kernels %.1f ms; tiers %d/%d/%d; "
-	       "factor image %.2fs, alloc+run %.2fs, download %.2fs, free %.2fs)\n", S->n, m, S->p[S->n], density, wtime() - t0,
-	       st.ms_total, st.rows_lds, st.rows_lds_big, st.rows_dense, t_fact, t_run, t_down, wtime() - t3);
+	logmsg("Schur complement: %d * %d [%" PRId64 " nz / density= %.3f], %.1fs (GPU kernels %.1f ms, %s%s; tiers %d/%d/%d; "
+	       "factor image %.2fs, alloc+run %.2fs, download %.2fs%s, free %.2fs)\n", S->n, m, S->p[S->n], density, wtime() - t0,
+	       st.ms_total, st.kernel, st.group_aborted ? " after the row-group kernel gave up" : "", st.rows_lds, st.rows_lds_big, st.rows_dense,
+	       t_fact, t_run, t_down, lazy ? " (row pointers only: the entries stay on the device)" : "", wtime() - t3);
+	if (verbose() >= 2)
+		logmsg("[schur/hip] of alloc+run: %.2fs allocating the workspace (%" PRId64 " pool entries), scratch %.1f GB\n", t_wcreate, pool,
+		       (double) g_scratch_cache.bytes / 1073741824.0);
 	return S;
 }
 

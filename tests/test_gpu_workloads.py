@@ -31,11 +31,15 @@ pytestmark = pytest.mark.gpu
 PRIME = 42013
 # mk13.b4 is not a BASELINE config: it is the sibling round 1 benchmarked by mistake, kept because its Schur complement
 # is SPARSE (4.4 %, 169 M entries) where mk13.b5's is dense -- the two matrices take the two elimination paths.
-EXTRA = ["mk13.b4"]
+# ch7-8.b5 (chessboard complex, 141,120 x 141,120): a STAND-IN of the GL7d19 class, never a BASELINE config -- 49,000 non-
+# pivotal columns (too wide for the back-substituted image: row-group kernel), Schur complement 18 % dense.
+EXTRA = ["mk13.b4", "ch7-8.b5"]
 NAMES = [c["name"] for c in workloads.CONFIGS] + EXTRA
 # mk13.b4: the CPU oracle's single-thread orc_echelonize (243 s, round 1).  mk13.b5: every path combination of this
 # library agrees on 134211; the CPU oracle had not finished it within the round.
-RANKS = {"mk13.b5": 134211, "mk13.b4": 111463}
+# ch7-8.b5 / ch8-8.b5: 92959 is the published rank of ch7-8.b5 (hpac table); both are what every flow of this library
+# returns (device finish, host loops).  mk14.b4: see test_multi_round_stand_in.
+RANKS = {"mk13.b5": 134211, "mk13.b4": 111463, "ch7-8.b5": 92959, "ch8-8.b5": 276031, "mk14.b4": 273183}
 
 
 def _available(name):
@@ -144,7 +148,7 @@ def test_rank_tool_on_baseline_workload(name, tmp_path):
     """tools/rank with the options of the BASELINE config; rank against the CPU value where one is recorded."""
     if not _available(name):
         pytest.skip("%s: data file absent (SPASM_DATA=%s)" % (name, workloads.data_dir()))
-    c = workloads.config(name) or {"file": name + ".sms", "rank_args": []}
+    c = workloads.config(name) or {"file": name + ".sms", "rank_args": workloads.STAND_INS.get(name, {}).get("rank_args", [])}
     path = workloads.find_data(c["file"])
     if path is None:
         A, _ = workloads.load_matrix(name, PRIME, tall=False)
@@ -164,3 +168,39 @@ def test_rank_tool_on_baseline_workload(name, tmp_path):
         assert rank == RANKS[name]
     else:
         assert rank > 0
+
+
+def test_generated_stand_ins_have_the_published_shapes():
+    """the chessboard complexes are closed-form: sizes against the published ones (tools/workloads.py)"""
+    for name, info in workloads.STAND_INS.items():
+        if name == "ch8-8.b5":
+            continue                      # (3.4 M entries through the Python generator: covered by the rank test below)
+        n, m, ti, tj, tx = workloads._triplets_of(name)
+        assert (n, m) == info["shape"] and len(ti) == info["nnz"]
+
+
+@pytest.mark.parametrize("name,threshold,min_sparse_rounds", [("ch7-8.b5", 0.01, 0), ("ch8-8.b5", 0.01, 0), ("mk14.b4", 0.05, 1)])
+def test_multi_round_stand_in(name, threshold, min_sparse_rounds):
+    """spasm_hip_echelonize end to end on the GL7d19-class stand-ins, with the options of the GL7d19 config for the chessboard
+    complexes (--dense-threshold 0.01: their first Schur complement is 18 % dense, so the call is pivot search + the dense
+    finish on 49,000 / 104,000 columns -- no back-substituted image) and the defaults for mk14.b4, whose first Schur
+    complement (673,000 x 42,000, 3.7 % dense, 1.06e9 entries) IS computed sparse before the low-rank finish.  The rank must
+    be the same on every call (the threaded pivot search picks different pivots each time) and equal to the recorded one;
+    the factor must be a valid echelon form of the right shape."""
+    A, _ = workloads.load_matrix(name, PRIME)
+    o = spasm_amd.default_opts()
+    o.sparsity_threshold = threshold
+    ranks = []
+    for _ in range(2):
+        F = spasm_amd.echelonize(A, o)
+        prof = spasm_amd.echelonize_profile()
+        ranks.append(F.U.n)
+        assert prof["sparse_rounds"] >= min_sparse_rounds
+        # echelon form: one pivot per row, on distinct columns, first in its row with value 1
+        piv = F.U.j[F.U.p[:-1]]
+        assert len(np.unique(piv)) == F.U.n and np.all(F.U.x[F.U.p[:-1]] == 1)
+        assert np.array_equal(F.qinv[piv], np.arange(F.U.n))
+    assert ranks[0] == ranks[1] == RANKS[name]
+    # rank(A) = rank(A^T): the transposed matrix is wide, its pivots, Schur complements and finishing blocks are all different
+    Ft = spasm_amd.echelonize(spasm_amd.transpose(A), o)
+    assert Ft.U.n == RANKS[name]
