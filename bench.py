@@ -38,6 +38,8 @@ os.environ.setdefault("SPASM_HIP_VERBOSE", "0")
 PRIME = 42013
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8 TB/s
 MFMA_I8_PEAK_TOPS = 5000.0     # dense i8 (the guide's ~5 P op/s class; AMD's sparsity figures are not used)
+# rocprofv3 PMC passes (tools/profile.sh): newest first; a file only counts for the workload, row count and kernel it names
+TRAFFIC_FILES = ["profiles/r03_traffic.json", "profiles/r03_sparse_traffic.json", "profiles/r02_traffic.json"]
 
 
 # --------------------------------------------------------------------------
@@ -48,7 +50,9 @@ def cpu_baseline(A, rows, F, budget_s=20.0):
     from oracle import oracle as orc
     Ao = orc.CSR(A.n, A.m, A.p, A.j, A.x, A.prime)
     Fo = orc.Fact(orc.CSR(F.U.n, F.U.m, F.U.p, F.U.j, F.U.x, A.prime), F.qinv)
-    cores = os.cpu_count() or 1
+    # the CPUs this process may really use (a box of this pool reports 256 hardware threads and grants 16: cgroup cpu.max)
+    import spasm_amd
+    cores = spasm_amd.usable_cpus()
     if orc.ref_available():
         kind, threads = "reference", cores
         run = lambda sub: orc.ref_schur(Ao, sub, Fo, threads=threads)
@@ -72,25 +76,29 @@ def cpu_baseline(A, rows, F, budget_s=20.0):
         t = time.perf_counter() - t0
         count = final
     return {"value": count / t, "unit": "rows/s", "cores": threads, "kind": kind,
-            "sample": "first %d of %d non-pivotal rows, spasm_schur, %.1f s" % (count, len(rows), t)}
+            "hardware_threads": os.cpu_count(),
+            "sample": "first %d of %d non-pivotal rows, spasm_schur, %.1f s, %d OpenMP threads = the CPU quota of the box"
+                      % (count, len(rows), t, threads)}
 
 
 def quoted_traffic(kernel, workload, rows):
     """HBM bytes per launch of `kernel` from the rocprofv3 PMC passes of this round, if they were recorded on
     this workload.  (value, fetch_doubled_upper_bound, source) or (None, None, None)."""
-    path = os.path.join(ROOT, "profiles", "r02_traffic.json")
-    if not os.path.exists(path):
-        return None, None, None
-    try:
-        t = json.load(open(path))
-    except ValueError:
-        return None, None, None
-    if t.get("workload") != workload or t.get("rows") != rows:
-        return None, None, None
-    k = t.get("kernels", {}).get(kernel)
-    if not k:
-        return None, None, None
-    return k.get("bytes_per_launch"), k.get("bytes_per_launch_fetch_doubled"), "profiles/r02_traffic.json"
+    for rel in TRAFFIC_FILES:
+        path = os.path.join(ROOT, rel)
+        if not os.path.exists(path):
+            continue
+        try:
+            t = json.load(open(path))
+        except ValueError:
+            continue
+        if t.get("workload") != workload or t.get("rows") != rows:
+            continue
+        k = t.get("kernels", {}).get(kernel)
+        if not k:
+            continue
+        return k.get("bytes_per_launch"), k.get("bytes_per_launch_fetch_doubled"), rel
+    return None, None, None
 
 
 def dense_tail_probe(torch, spasm_amd, dev, n=4096, m=32768):
@@ -138,6 +146,96 @@ def dense_tail_probe(torch, spasm_amd, dev, n=4096, m=32768):
                 out["mfma_busy_source"] = "profiles/r02_dense_tail.json"
         except ValueError:
             pass
+    return out
+
+
+def sparse_path_probe(torch, spasm_amd, workloads, dev, name="mk14.b4", steps=3):
+    """The flow GL7d19 takes (sparse rounds on a Schur complement too wide for the back-substituted image, then the dense
+    tail), on a matrix of the same collection that can be generated offline: mk14.b4, 945,945 x 315,315 -- a STAND-IN, not
+    a BASELINE config.  Its first Schur complement (673,000 rows x 42,000 columns, 3.7 % dense, 1.06e9 entries) is computed
+    sparse with default options.  Reports that Schur complement on the device-level API (the way the headline step is
+    measured) and the whole spasm_hip_echelonize call with its time split."""
+    t0 = time.perf_counter()
+    A, rows, F, source = workloads.round0(name, PRIME, threads=0)
+    t_prep = time.perf_counter() - t0
+    dA = spasm_amd.DeviceCsr.from_host(A, dev)
+    t0 = time.perf_counter()
+    dF = spasm_amd.DeviceFact(F)
+    torch.cuda.synchronize()
+    image_ms = 1e3 * (time.perf_counter() - t0)
+    drows = torch.from_numpy(np.ascontiguousarray(rows)).to(dev)
+    # one-shot budget of the host-pointer entry point (24 GB of accumulator slices), so that the numbers are those of a
+    # round inside spasm_hip_echelonize
+    os.environ["SPASM_HIP_SCRATCH_GB"] = "24"
+    try:
+        pool = 1 << 30
+        while True:
+            W = spasm_amd.SchurWorkspace(len(rows), A.m, pool)
+            _, st = spasm_amd.dschur(dA, drows, dF, W, fetch=False)
+            if st.status == 0:
+                break
+            W.close()
+            pool *= 2
+        best = None
+        for _ in range(steps):
+            _, st = spasm_amd.dschur(dA, drows, dF, W, fetch=False)
+            if best is None or st.ms_total < best.ms_total:
+                best = st
+        st = best
+    finally:
+        os.environ.pop("SPASM_HIP_SCRATCH_GB", None)
+    kernel = st.kernel.decode()
+    k_ms = st.ms_group if st.used_group_kernel and not st.group_aborted else st.ms_tier2
+    algo = 16 * st.entries_streamed + 8 * (st.input_entries + st.nnz) + 20 * st.eliminations + 20 * st.rows
+    out = {"what": "%s (%dx%d, %d nnz), STAND-IN for the GL7d19 class: round-0 Schur complement of %d rows w.r.t. %d pivots, "
+                   "%d non-pivotal columns, device-level API, 24 GB of accumulator slices" % (name, A.n, A.m, A.nnz, len(rows), F.U.n, A.m - F.U.n),
+           "rows": len(rows), "ms_per_step": st.ms_total, "rows_per_s": len(rows) / (st.ms_total * 1e-3),
+           "kernel": kernel, "kernel_ms": k_ms, "gather_ms": st.ms_finalize, "gave_up": bool(st.group_aborted),
+           "levels": dF.levels, "schur_nnz": int(st.nnz), "schur_density": st.nnz / (len(rows) * float(A.m - F.U.n)),
+           "eliminations": int(st.eliminations), "entries_streamed": int(st.entries_streamed), "group_pivots": int(st.group_pivots),
+           "lane_efficiency": (st.eliminations / (64.0 * st.group_pivots)) if st.group_pivots else None,
+           # one 256-byte no-return atomic instruction per (applied pivot, entry of its row) = 4 requests of 64 B
+           "atomic_requests_per_s": (4.0 * st.entries_streamed / 64.0 / max(st.eliminations / (64.0 * st.group_pivots), 1e-9) / (k_ms * 1e-3))
+           if st.group_pivots else None,
+           "slices_in_flight": st.group_slots, "slices_wanted": st.group_slots_wanted, "waves_per_group": st.group_waves,
+           "slice_bytes": int(st.group_slot_bytes),
+           "effective_bytes": int(algo), "effective_frac": algo / (k_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+           "effective_note": "bytes the reference's algorithm moves on its dense x (DESIGN.md section 4); the row-group kernel shares a 256-B "
+                             "line among the 64 rows of a group, so this is not HBM traffic",
+           "factor_image_ms": image_ms, "prepare_s": t_prep}
+    tr = quoted_traffic(kernel, name, len(rows))
+    if tr[0]:
+        out.update({"traffic": tr[0], "hbm_frac": tr[0] / (k_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, "traffic_source": tr[2]})
+    W.close()
+    dF.close()
+    del dA, drows
+    torch.cuda.empty_cache()
+    os.environ.pop("SPASM_HIP_THREADS", None)
+    runs = []
+    for _ in range(2):
+        t0 = time.perf_counter()
+        fact = spasm_amd.echelonize(A)
+        runs.append((time.perf_counter() - t0, spasm_amd.echelonize_profile(), int(fact.U.n)))
+    best = min(runs, key=lambda r: r[0])
+    out["end_to_end"] = {"what": "spasm_hip_echelonize, default options, 2 calls", "rank": best[2], "ranks_agree": len({r[2] for r in runs}) == 1,
+                         "seconds_all": [r[0] for r in runs], "split_of_best_call": best[1]}
+    return out
+
+
+def stand_in_runs(spasm_amd, workloads):
+    """the chessboard complexes with the options of the GL7d19 config (--dense-threshold 0.01): their first Schur complement
+    is 18 % dense, so a call is pivot search + the device-resident low-rank finish on 49,000 / 104,000 columns."""
+    out = []
+    for name, info in workloads.STAND_INS.items():
+        A, _ = workloads.load_matrix(name, PRIME)
+        opts = spasm_amd.default_opts()
+        for t, a in enumerate(info["rank_args"]):
+            if a == "--dense-threshold":
+                opts.sparsity_threshold = float(info["rank_args"][t + 1])
+        t0 = time.perf_counter()
+        fact = spasm_amd.echelonize(A, opts)
+        out.append({"name": name, "stand_in_for": info["for"], "shape": [A.n, A.m], "nnz": int(A.nnz), "options": " ".join(info["rank_args"]),
+                    "rank": int(fact.U.n), "seconds": time.perf_counter() - t0, "split": spasm_amd.echelonize_profile()})
     return out
 
 
@@ -217,7 +315,16 @@ def main():
     from spasm_amd.dist import shard_rows
     my_rows = shard_rows(rows, rank, world)
     dA = spasm_amd.DeviceCsr.from_host(A, dev)
-    dF = spasm_amd.DeviceFact(F)
+    # the factor image (host: level schedule, pass tables, chunk plans; then the upload) is built once per factor, outside
+    # the timed steps: its cost is measured here and reported next to the step (`factor_image_ms`, `rows_per_s_cold`)
+    image_ms = []
+    for _ in range(3):
+        t0 = time.perf_counter()
+        dF = spasm_amd.DeviceFact(F)
+        torch.cuda.synchronize()
+        image_ms.append(1e3 * (time.perf_counter() - t0))
+        if len(image_ms) < 3:
+            dF.close()
     drows = torch.from_numpy(np.ascontiguousarray(my_rows)).to(dev)
     stream = torch.cuda.Stream(device=dev)
 
@@ -350,6 +457,10 @@ def main():
                        "why_this_workload": why,
                        "sharding": "rows over %d rank(s)%s" % (world, ", all-gatherv of S" if use_dist else "")},
             "roofline": roof,
+            "factor_image_ms": statistics.median(image_ms),
+            "factor_image_note": "host planning + upload of the factor image (spasm_hip_dfact_create), once per factor, NOT in a step; "
+                                 "median of 3 builds",
+            "rows_per_s_cold": total_rows / (elapsed / args.steps + 1e-3 * statistics.median(image_ms)),
         }
         extras = world == 1 and not args.no_extras
         if extras and st.used_backsolve:
@@ -401,6 +512,9 @@ def main():
                                  "rank": med[2], "ranks_agree": len({r[2] for r in runs}) == 1,
                                  "seconds_min": min(secs), "seconds_median": statistics.median(secs), "seconds_all": secs,
                                  "split_of_median_call": med[1]}
+        if extras and args.workload == "mk13.b5":
+            out["sparse_path"] = sparse_path_probe(torch, spasm_amd, workloads, dev)
+            out["stand_ins"] = stand_in_runs(spasm_amd, workloads)
         out["configs"] = [{"name": c["name"], "status": status, "what": c["what"],
                            "bench": "python bench.py --workload %s" % c["name"],
                            "rank": "./tools/rank --matrix $SPASM_DATA/%s --modulus %d %s" % (c["file"], PRIME, " ".join(c["rank_args"]))}

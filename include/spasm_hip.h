@@ -107,6 +107,9 @@ typedef enum {SPASM_DOUBLE, SPASM_FLOAT, SPASM_I64} spasm_datatype;   /* spasm.h
 
 /* library / device probe.  Returns the number of usable gfx950 devices (0 if none). */
 int spasm_hip_device_count(void);
+/* CPUs this process may really use: hardware threads cut down to the CPU quota of its control group (the pivot search
+ * takes that many threads; a box of this pool reports 256 hardware threads and grants 16 CPUs) */
+int spasm_hip_usable_cpus(void);
 const char *spasm_hip_version(void);
 
 /* --- containers and field (replace spasm_util.c:85-191, spasm_ZZp.c) --- */
@@ -261,6 +264,10 @@ typedef struct {
 	i64 bytes_expand;       /* ... its algorithmic bytes (the entries of S written); they are then not part of bytes_apply */
 	i64 bytes_staged;       /* ... bytes of the packed rows in between (written by the apply kernel, read by the expansion) */
 	char kernel_expand[64]; /* ... its name, or "" */
+	/* row-group kernel: accumulator slices (= groups in flight) the launch ran with, the number that would fill the chip at
+	 * its wave count (8 waves per CU), waves per group, bytes of one slice ((rpad + Sm) * 256 B) */
+	int group_slots, group_slots_wanted, group_waves;
+	i64 group_slot_bytes;
 } spasm_hip_schur_stats;
 
 /* S = Schur complement of rows d_rows[0..nrows) of A w.r.t. F, left in the

@@ -31,6 +31,7 @@ def lib():
     pint = C.POINTER(C.c_int)
     sig = {
         "spasm_hip_device_count": (ci, []),
+        "spasm_hip_usable_cpus": (ci, []),
         "spasm_hip_version": (C.c_char_p, []),
         "spasm_hip_csr_alloc": (pcsr, [ci, ci, i64, i64, C.c_bool]),
         "spasm_hip_csr_free": (None, [pcsr]),
@@ -90,6 +91,11 @@ def lib():
 
 def device_count():
     return lib().spasm_hip_device_count()
+
+
+def usable_cpus():
+    """hardware threads cut down to the CPU quota of the control group (what the threaded host stages use)"""
+    return lib().spasm_hip_usable_cpus()
 
 
 def require_gpu(what):

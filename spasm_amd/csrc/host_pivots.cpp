@@ -393,6 +393,8 @@ struct Search {
 
 }  // namespace
 
+extern "C" int spasm_hip_usable_cpus(void) { return usable_cpus(); }
+
 extern "C" int spasm_hip_pivots_extract_structural(const struct spasm_csr *A, const int *p_in, struct spasm_lu *fact,
                                                    int *p, struct echelonize_opts *opts)
 {

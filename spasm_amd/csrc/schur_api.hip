@@ -1134,6 +1134,10 @@ eliminated:
 		stats->input_entries = (i64) ctr64[C64_INPUT];
 		stats->group_pivots = (i64) ctr64[C64_WAVEPIV];
 		stats->used_group_kernel = group_mode ? 1 : 0;
+		stats->group_slots = group_mode ? group_slots : 0;
+		stats->group_waves = group_mode ? group_waves : 0;
+		stats->group_slot_bytes = group_mode ? group_slot_bytes : 0;
+		stats->group_slots_wanted = group_mode ? (int) std::min<i64>((nrows + 63) / 64, (i64) cus * 8 / std::max(1, group_waves)) : 0;
 		stats->rows = nrows;
 		stats->rows_lds = ctr[CTR_DONE0];
 		stats->rows_lds_big = ctr[CTR_DONE1];

@@ -84,7 +84,8 @@ class CSchurStats(C.Structure):    # spasm_hip_schur_stats
                 ("used_backsolve", C.c_int), ("backsolve_built", C.c_int), ("ms_backsolve", C.c_float), ("ms_apply", C.c_float),
                 ("bytes_backsolve", C.c_int64), ("bytes_apply", C.c_int64), ("kernel", C.c_char * 64),
                 ("kernel_other", C.c_char * 64), ("ms_expand", C.c_float), ("ms_pad", C.c_float), ("bytes_expand", C.c_int64),
-                ("bytes_staged", C.c_int64), ("kernel_expand", C.c_char * 64)]
+                ("bytes_staged", C.c_int64), ("kernel_expand", C.c_char * 64),
+                ("group_slots", C.c_int), ("group_slots_wanted", C.c_int), ("group_waves", C.c_int), ("group_slot_bytes", C.c_int64)]
 
 
 def field_of(prime):

@@ -105,7 +105,7 @@ def test_round0_schur_of_baseline_workload(oracle, name, path):
     count = min(len(rows), 2048)
     ks = np.unique(np.linspace(0, len(rows) - 1, count).astype(np.int64))
     if oracle.ref_available():
-        want, p_out = oracle.ref_schur(Ao, rows[ks], Fo, threads=os.cpu_count() or 1)
+        want, p_out = oracle.ref_schur(Ao, rows[ks], Fo, threads=spasm_amd.usable_cpus())
         order = {int(r): t for t, r in enumerate(p_out)}          # the reference emits rows in thread-arrival order
     else:
         want, p_out, _ = oracle.schur(Ao, rows[ks], Fo)
@@ -119,7 +119,7 @@ def test_round0_schur_of_baseline_workload(oracle, name, path):
         assert np.all(np.diff(gj) > 0)
     assert int(Sp[-1]) == st.nnz
     if oracle.ref_available() and len(rows) <= 400000:
-        full, _ = oracle.ref_schur(Ao, rows, Fo, threads=os.cpu_count() or 1)
+        full, _ = oracle.ref_schur(Ao, rows, Fo, threads=spasm_amd.usable_cpus())
         assert full.nnz == st.nnz
     W.close()
     dF.close()

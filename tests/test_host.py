@@ -298,3 +298,24 @@ def test_fp32_reduction_of_the_signed_16_bit_path_stays_inside_its_slack():
     # the next prime is out: four-term sums would not fit 32 bits
     Bn = 44939 // 2 + 44939 // 64 + 1
     assert 4 * Bn * Bn + Bn > 2 ** 31 - 1
+
+
+def test_generated_workloads_are_built_like_spasm_compress():
+    """tools/workloads.py builds the CSR of a generated matrix with numpy (five million add_entry calls through ctypes take
+    longer than the elimination): same arrays as spasm_hip_compress on the same triplets, in both orientations; and the
+    chessboard generator has the published shape on a small member of the family."""
+    import sys
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import workloads
+    for name in ("mk10.b3", "ch6-6.b3"):
+        n, m, ti, tj, tx = workloads._triplets_of(name)
+        for a, b, N, M in ((ti, tj, n, m), (tj, ti, m, n)):
+            want = spasm_amd.compress(42013, N, M, a, b, tx)
+            got = workloads._csr_of_triplets(42013, N, M, a, b, tx)
+            assert np.array_equal(want.p, got.p) and np.array_equal(want.j, got.j) and np.array_equal(want.x, got.x)
+    n, m, ti, tj, tx = workloads._triplets_of("ch6-6.b3")          # 4-rook / 3-rook placements on a 6 x 6 board
+    assert (n, m, len(ti)) == (15 * 15 * 24, 20 * 20 * 6, 15 * 15 * 24 * 4)
+
+
+def test_usable_cpus_is_positive_and_within_the_hardware():
+    assert 1 <= spasm_amd.usable_cpus() <= (os.cpu_count() or 1)

@@ -195,14 +195,29 @@ def load_matrix(name, prime=PRIME, tall=True):
     if tall and n < m:
         ti, tj = tj, ti
         n, m = m, n
-    return spasm_amd.compress(prime, n, m, ti, tj, tx), "generated"
+    return _csr_of_triplets(prime, n, m, ti, tj, tx), "generated"
 
 
-def round0(name, prime=PRIME, cache=True):
-    """(A, rows, F, source): the matrix, its structural pivots (single-threaded search: the same pivots on
-    every rank and in every run) and the non-pivotal rows -- the input of the first Schur complement."""
+def _csr_of_triplets(prime, n, m, ti, tj, tx):
+    """what spasm_compress (spasm_triplet.c:97) makes of triplets without duplicates or zeros -- rows in order, entries of
+    a row in triplet order -- without five million calls through ctypes (checked against spasm_hip_compress in
+    tests/test_host.py)."""
     import spasm_amd
-    path = os.path.join(tempfile.gettempdir(), "spasm_amd_r0_v3_%s_%d.npz" % (name.replace("/", "_"), prime))
+    ti = np.asarray(ti)
+    order = np.argsort(ti, kind="stable")
+    p = np.zeros(n + 1, np.int64)
+    np.cumsum(np.bincount(ti, minlength=n), out=p[1:])
+    x = np.asarray(tx, np.int64)[order] % prime
+    x = np.where(x > prime // 2, x - prime, x).astype(np.int32)
+    return spasm_amd.Csr(n, m, p, np.ascontiguousarray(np.asarray(tj)[order], np.int32), x, prime)
+
+
+def round0(name, prime=PRIME, cache=True, threads=1):
+    """(A, rows, F, source): the matrix, its structural pivots (single-threaded search by default: the same pivots on
+    every rank and in every run; threads=0: the library's default thread count -- the pivots then depend on timing, which
+    is fine for a timing run on one process) and the non-pivotal rows -- the input of the first Schur complement."""
+    import spasm_amd
+    path = os.path.join(tempfile.gettempdir(), "spasm_amd_r0_v3_%s_%d%s.npz" % (name.replace("/", "_"), prime, "" if threads == 1 else "_mt"))
     if cache and os.path.exists(path):
         z = np.load(path, allow_pickle=False)
         A = spasm_amd.Csr(int(z["n"]), int(z["m"]), z["Ap"], z["Aj"], z["Ax"], prime)
@@ -210,7 +225,10 @@ def round0(name, prime=PRIME, cache=True):
         return A, z["rows"], F, str(z["source"])
     A, source = load_matrix(name, prime)
     saved = os.environ.get("SPASM_HIP_THREADS")
-    os.environ["SPASM_HIP_THREADS"] = "1"
+    if threads > 0:
+        os.environ["SPASM_HIP_THREADS"] = str(threads)
+    else:
+        os.environ.pop("SPASM_HIP_THREADS", None)
     try:
         npiv, perm, F = spasm_amd.pivots_extract_structural(A, spasm_amd.empty_fact(A.m, prime))
     finally:
