@@ -112,7 +112,12 @@ int spasm_hip_device_count(void);
 int spasm_hip_usable_cpus(void);
 const char *spasm_hip_version(void);
 
-/* --- containers and field (replace spasm_util.c:85-191, spasm_ZZp.c) --- */
+/* --- containers and field (replace spasm_util.c:85-191, spasm_ZZp.c) ---
+ * Moduli: the host-side field functions and containers take any 2 <= p <= 0xfffffffb, as the reference does
+ * (spasm_ZZp.c:5-15).  The GPU entry points (everything that eliminates: spasm_hip_schur*, _echelonize, _rref, _kernel,
+ * _ffpack_*, the spasm_hip_d* layer) take ODD p only and die with "modulus ... unsupported on the GPU path" otherwise:
+ * their arithmetic is Montgomery form mod 2^32 (and signed 16-bit / Barrett forms for small p), which needs p coprime
+ * to 2.  p = 2 -- which the reference accepts -- is therefore REFUSED, not emulated. */
 void spasm_hip_field_init(i64 p, spasm_field F);                                   /* spasm_ZZp.c:5-15 */
 spasm_ZZp spasm_hip_ZZp_init(const spasm_field F, i64 x);                          /* spasm_ZZp.c:26 */
 spasm_ZZp spasm_hip_ZZp_add(const spasm_field F, spasm_ZZp a, spasm_ZZp b);        /* spasm_ZZp.c:32 */

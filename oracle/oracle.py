@@ -529,6 +529,31 @@ def ref_compress(prime, n, m, ti, tj, tx):
     return out
 
 
+def ref_load(path, prime):
+    """spasm_triplet_load + spasm_compress of the real reference (spasm_io.c:60-160: SMS and MatrixMarket files)."""
+    R = ref()
+    libc = C.CDLL(None)
+    libc.fopen.restype = C.c_void_p
+    libc.fopen.argtypes = [C.c_char_p, C.c_char_p]
+    libc.fclose.argtypes = [C.c_void_p]
+    R.spasm_triplet_load.restype = C.POINTER(_RefTriplet)
+    R.spasm_triplet_load.argtypes = [C.c_void_p, C.c_int64, C.c_void_p]
+    f = libc.fopen(path.encode(), b"r")
+    if not f:
+        raise OSError("cannot open %s" % path)
+    saved = _silence()
+    try:
+        T = R.spasm_triplet_load(f, prime, None)
+        Cp = R.spasm_compress(T)
+        out = _ref_from(Cp)
+        R.spasm_csr_free(Cp)
+        R.spasm_triplet_free(T)
+    finally:
+        _unsilence(saved)
+        libc.fclose(f)
+    return out
+
+
 def _silence():
     """the reference chats on stderr; park fd 2 on /dev/null around its calls."""
     import sys

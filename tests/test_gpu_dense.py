@@ -117,6 +117,102 @@ def test_rref_super_panels_and_streams(oracle, shape, rank, env, monkeypatch):
     _check_rref(oracle, p, np.array((L.dot(R)) % p, dtype=np.int64))
 
 
+def _mod_product(L, R, p):
+    """(L @ R) mod p for int64 matrices with entries in [0, p), p < 2^16, exact in float64 (64 p^2 < 2^53 per chunk)"""
+    out = np.zeros((L.shape[0], R.shape[1]), np.int64)
+    Lf, Rf = L.astype(np.float64), R.astype(np.float64)
+    for c in range(0, L.shape[1], 64):
+        out = (out + (Lf[:, c:c + 64] @ Rf[c:c + 64]).astype(np.int64)) % p
+    return out
+
+
+_BIG_RREF = {}
+
+
+def _big_rref_case(oracle, which):
+    """matrices whose rank spans more than two full super-panels (8 panels of 64 columns each) on every route of the dense
+    RREF, with the oracle's answer (tens of seconds on the CPU: computed once per shape)"""
+    if which not in _BIG_RREF:
+        p = 42013
+        rng = np.random.default_rng(len(which))
+        if which == "deficient":          # 1536 x 3000, rank 1100, leading zero columns
+            n, m, k = 1536, 3000, 1100
+            M = _mod_product(rng.integers(0, p, size=(n, k)), rng.integers(0, p, size=(k, m)), p)
+            M[:, :m // 9] = 0
+        else:                             # 1100 x 2304, full rank
+            n, m = 1100, 2304
+            M = rng.integers(0, p, size=(n, m), dtype=np.int64)
+        _BIG_RREF[which] = (p, M) + tuple(oracle.dense_rref(p, M))
+    return _BIG_RREF[which]
+
+
+@pytest.mark.parametrize("env", [{}, {"SPASM_HIP_RREF_MFMA": "0"}, {"SPASM_HIP_RREF_ONE_STREAM": "1"}, {"SPASM_HIP_RREF_CACHE": "0"}])
+@pytest.mark.parametrize("which", ["deficient", "full"])
+def test_rref_more_than_two_super_panels(oracle, which, env, monkeypatch):
+    """no test compared a dense RREF of rank > 400 with the oracle -- the optimistic super-panels, the
+    second stream and the cached work buffers at several super-panels were only covered through ranks.  Rank 1100 = two
+    full super-panels and a part of a third, on the matrix-core route, the VALU route, one stream, fresh buffers; twice in
+    a row (the second call runs on the buffers the first one left)."""
+    for key, val in env.items():
+        monkeypatch.setenv(key, val)
+    p, M, r_want, R_want, q_want = _big_rref_case(oracle, which)
+    for _ in range(2):
+        r, R, q = spasm_amd.ffpack_rref(p, M)
+        assert r == r_want and r >= 1100
+        assert np.array_equal(q, q_want)
+        assert np.array_equal(R[:r], R_want[:r])
+        assert not np.any(R[r:])
+
+
+@pytest.mark.parametrize("shape,rank", [((4096, 32768), 4096), ((4096, 32768), 2500)])
+def test_rref_at_the_benchmarked_size(shape, rank):
+    """The size bench.py times (4096 x 32768 mod 42013) is beyond what the CPU oracle finishes in a test, so the result of
+    spasm_hip_drref is checked through what pins a reduced row echelon form down: (1) the pivot columns hold an identity,
+    pivots move right from row to row, rows beyond the rank are zero; (2) M = M[:, J] * R exactly (every row of M is the
+    combination of the echelon rows its own entries on the pivot columns J dictate) -- a 4096 x rank x 32768 product mod p,
+    done in float64 on the GPU in exact chunks; (3) the matrix-core route and the VALU route return the same rank, pivots
+    and rows.  (1) + (2) + rank(M) = rank by construction say R is THE echelon form of M."""
+    import ctypes as C
+    import torch
+    n, m = shape
+    p = 42013
+    dev = torch.device("cuda:0")
+    g = torch.Generator(device=dev)
+    g.manual_seed(n + rank)
+    if rank == n:
+        M = torch.randint(0, p, (n, m), dtype=torch.int64, device=dev, generator=g)
+    else:
+        Lh = torch.randint(0, p, (n, rank), dtype=torch.int64, device=dev, generator=g).to(torch.float64)
+        Rh = torch.randint(0, p, (rank, m), dtype=torch.int64, device=dev, generator=g).to(torch.float64)
+        M = torch.zeros((n, m), dtype=torch.int64, device=dev)
+        for c in range(0, rank, 64):
+            M = (M + (Lh[:, c:c + 64] @ Rh[c:c + 64]).to(torch.int64)) % p
+        M[:, :1000] = 0
+    L = spasm_amd.lib()
+    results = []
+    for mfma in (1, 0):
+        A = M.to(torch.int32).contiguous()
+        piv = torch.zeros(m, dtype=torch.int32, device=dev)
+        ms = C.c_float(0)
+        r = L.spasm_hip_drref_timed(p, n, m, A.data_ptr(), m, piv.data_ptr(), 0, mfma, C.byref(ms))
+        torch.cuda.synchronize()
+        results.append((r, piv[:r].clone(), A))
+    (r, J, R), (r2, J2, R2) = results
+    assert r == rank and r2 == rank and torch.equal(J, J2) and torch.equal(R, R2)
+    J = J.to(torch.int64)
+    assert bool(torch.all(J[1:] > J[:-1]))
+    assert not bool(torch.any(R[r:]))
+    eye = R[:r][:, J]
+    assert torch.equal(eye, torch.eye(r, dtype=torch.int32, device=dev))
+    # M == M[:, J] @ R[:r]  (mod p)
+    MJ = M[:, J].to(torch.float64)
+    Rf = R[:r].to(torch.float64)
+    acc = torch.zeros((n, m), dtype=torch.int64, device=dev)
+    for c in range(0, r, 64):
+        acc = (acc + (MJ[:, c:c + 64] @ Rf[c:c + 64]).to(torch.int64)) % p
+    assert torch.equal(acc, M)
+
+
 def test_rref_mfma_and_valu_agree(oracle, monkeypatch):
     p = 42013
     rng = np.random.default_rng(5)

@@ -1,4 +1,5 @@
-"""The drop-in command line tools (tools/rank, tools/echelonize) against the oracle."""
+"""The command line tools against the oracle: tools/rank (this repository's), and the reference's own tools/rank.c,
+tools/echelonize.c and tools/kernel.c compiled unmodified against the library (oracle/Makefile `dropin`)."""
 import os
 import subprocess
 
@@ -10,11 +11,20 @@ from conftest import ROOT, matrix_path
 pytestmark = pytest.mark.gpu
 
 RANK = os.path.join(ROOT, "tools", "rank")
-ECHELONIZE = os.path.join(ROOT, "tools", "echelonize")
+
+
+REF_BIN = os.path.join(ROOT, "oracle", "_ref")
+
+
+def _ref_tool(name):
+    path = os.path.join(REF_BIN, name)
+    if not os.path.exists(path):
+        pytest.skip("%s was not built (needs the reference tree at build time)" % name)
+    return path
 
 
 def _need_tools():
-    if not (os.path.exists(RANK) and os.path.exists(ECHELONIZE)):
+    if not os.path.exists(RANK):
         subprocess.run(["make", "-C", os.path.join(ROOT, "tools")], check=True)
 
 
@@ -35,8 +45,9 @@ def test_rank_tool(oracle, name, args):
 
 @pytest.mark.parametrize("name", ["mat364.sms", "singular2.sms", "rectangular_l.sms"])
 def test_echelonize_tool_outputs_sms(oracle, name):
-    """stdin -> stdout, SMS in, SMS out (U, or the RREF with --rref); the output spans the same row space."""
-    _need_tools()
+    """the reference's tools/echelonize.c (through the shim header): stdin -> stdout, SMS in, SMS out (U, or the RREF with
+    --rref); the output spans the same row space."""
+    ECHELONIZE = _ref_tool("ref_echelonize_shim")
     p = 42013
     A = oracle.load_sms(matrix_path(name), p)
     want = oracle.echelonize(A).U.n
@@ -69,16 +80,6 @@ def test_echelonize_tool_outputs_sms(oracle, name):
 # --------------------------------------------------------------------------
 # the reference's own tool sources, unmodified, bound to the HIP library (oracle/Makefile `dropin`)
 # --------------------------------------------------------------------------
-REF_BIN = os.path.join(ROOT, "oracle", "_ref")
-
-
-def _ref_tool(name):
-    path = os.path.join(REF_BIN, name)
-    if not os.path.exists(path):
-        pytest.skip("%s was not built (needs the reference tree at build time)" % name)
-    return path
-
-
 @pytest.mark.parametrize("name", ["mat364.sms", "medium.sms", "rectangular_h.sms", "singular.sms"])
 def test_reference_rank_c_linked_against_the_facade(oracle, name):
     """tools/rank.c of the reference, unmodified: its spasm_echelonize is the GPU one."""

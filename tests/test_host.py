@@ -319,3 +319,51 @@ def test_generated_workloads_are_built_like_spasm_compress():
 
 def test_usable_cpus_is_positive_and_within_the_hardware():
     assert 1 <= spasm_amd.usable_cpus() <= (os.cpu_count() or 1)
+
+
+def _write_mtx(A, path, comments=True):
+    with open(path, "w") as f:
+        f.write("%%MatrixMarket matrix coordinate integer general\n")
+        if comments:
+            f.write("% written by tests/test_host.py\n%\n")
+        f.write("%d %d %d\n" % (A.n, A.m, A.nnz))
+        for i in range(A.n):
+            for px in range(A.p[i], A.p[i + 1]):
+                f.write("%d %d %d\n" % (i + 1, A.j[px] + 1, A.x[px]))
+
+
+@pytest.mark.parametrize("name", ["small.sms", "rectangular_h.sms", "singular.sms", "medium.sms"])
+@pytest.mark.parametrize("p", [257, 42013])
+def test_matrix_market_files_load_like_the_reference(oracle, name, p, tmp_path):
+    """spasm_triplet_load reads MatrixMarket coordinate/integer/general files as well as SMS (spasm_io.c:76-97, 127-139): the
+    same matrix written as .mtx (with comment lines) loads to the same CSR as its .sms, and to what the compiled reference
+    makes of the very same .mtx file."""
+    A = spasm_amd.load(matrix_path(name), p)
+    path = str(tmp_path / (name.replace(".sms", "") + ".mtx"))
+    _write_mtx(A, path)
+    B = spasm_amd.load(path, p)
+    assert (A.n, A.m) == (B.n, B.m)
+    assert np.array_equal(A.p, B.p) and np.array_equal(A.j, B.j) and np.array_equal(A.x, B.x)
+    T = spasm_amd.load(path, p, transpose_if_wide=True)
+    assert T.n >= T.m
+    if oracle.ref_available():
+        R = oracle.ref_load(path, p)
+        assert (R.n, R.m) == (B.n, B.m)
+        assert np.array_equal(R.p, B.p) and np.array_equal(R.j, B.j) and np.array_equal(R.x, B.x)
+
+
+def test_matrix_market_header_is_validated(tmp_path):
+    """the reference refuses anything but `matrix coordinate integer general` (spasm_io.c:31-53): so does the loader
+    (it dies: checked in a child process)."""
+    import subprocess
+    import sys
+    bad = tmp_path / "bad.mtx"
+    bad.write_text("%%MatrixMarket matrix coordinate real general\n2 2 1\n1 1 1\n")
+    code = "import spasm_amd; spasm_amd.load(%r, 257)" % str(bad)
+    out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, cwd=ROOT)
+    assert out.returncode != 0 and "unsupported MatrixMarket data type" in out.stderr
+    end = tmp_path / "end.mtx"
+    end.write_text("%%MatrixMarket matrix coordinate integer general\n2 2 2\n1 1 1\n0 0 0\n")
+    code = "import spasm_amd; spasm_amd.load(%r, 257)" % str(end)
+    out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, cwd=ROOT)
+    assert out.returncode != 0 and "SMS end marker" in out.stderr
