@@ -11,9 +11,11 @@ forgotten before every step, so a step pays for all of spasm_schur.  There is no
 regenerated from its definition (tools/workloads.py) unless $SPASM_DATA/mk13.b5.sms exists; `data` says which.
 The other BASELINE configs are data files; `configs` in the output says which are present.
 
-Prints ONE JSON line (rank 0).  N > 1 (launched by torch.distributed.run): the row batch is sharded over
-the ranks, each rank reduces its slice, the slices are reassembled on every rank with an all-gatherv over
-RCCL (strong scaling: the matrix is fixed).
+Prints ONE JSON line (rank 0).  N > 1 (launched by torch.distributed.run), strong scaling (the matrix is fixed), two
+splits (--split): `columns` -- the default when the factor takes the back-substituted path, whose columns never meet --
+gives every rank a slab of the non-pivotal columns of ALL rows (spasm_hip_column_slab: nothing replicated but the few
+pivotal entries of U, no gather; the ranks exchange the row lengths); `rows` shards the row list and reassembles S on
+every rank with an all-gatherv over RCCL (the row-by-row kernels, whose rows never meet).
 
 Everything in the `roofline` object is measured in this run (HIP events of the library on the launch
 stream, the kernels' own work counters) except `traffic`, which rocprofv3 has to collect in separate
@@ -248,6 +250,11 @@ def main():
     ap.add_argument("--workload", default=None,
                     help="BASELINE config to run (default: GL7d19 -- the matrix BASELINE.json quotes its metric on -- when "
                          "$SPASM_DATA/GL7d19.sms[.gz] exists, else mk13.b5, the config that can be regenerated offline)")
+    ap.add_argument("--split", choices=["auto", "rows", "columns"], default="auto",
+                    help="how N > 1 ranks share a step: `rows` = contiguous slices of the row list, S reassembled on every rank with "
+                         "an all-gatherv over RCCL; `columns` = every rank owns a slab of the non-pivotal columns of ALL rows "
+                         "(spasm_hip_column_slab: no replicated factor image, only the row lengths are exchanged); auto = columns "
+                         "when the factor takes the back-substituted path (its columns never meet), rows otherwise")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true",
                     help="skip the row-by-row comparison, the dense-tail probe and the end-to-end runs")
@@ -312,8 +319,20 @@ def main():
                               "unit": "rows/s", "n_gpus": world, "data": "absent", "config": {"workload": args.workload},
                               "error": str(e)}))
         return
-    from spasm_amd.dist import shard_rows
-    my_rows = shard_rows(rows, rank, world)
+    from spasm_amd.dist import shard_rows, column_slab
+    split = args.split
+    if split == "auto":
+        # the back-substituted image is eligible up to 24,576 non-pivotal columns; one rank: nothing to split
+        split = "columns" if (world > 1 and A.m - F.U.n <= 24576) else "rows"
+    if world == 1 and os.environ.get("SPASM_BENCH_FORCE_DIST") != "1":
+        split = "rows"
+    A_full, F_full = A, F
+    if split == "columns":
+        # this rank's problem: (A, U) without the non-pivotal columns of the other ranks -- all rows, a slab of the columns
+        A, F, slab_cols = column_slab(A_full, F_full, rank, world)
+        my_rows = rows
+    else:
+        my_rows = shard_rows(rows, rank, world)
     dA = spasm_amd.DeviceCsr.from_host(A, dev)
     # the factor image (host: level schedule, pass tables, chunk plans; then the upload) is built once per factor, outside
     # the timed steps: its cost is measured here and reported next to the step (`factor_image_ms`, `rows_per_s_cold`)
@@ -339,11 +358,21 @@ def main():
         W.close()
         pool *= 2
 
+    if split == "columns":
+        my_Sp = torch.zeros(len(my_rows) + 1, dtype=torch.int64, device=dev)
+        my_len = torch.zeros(len(my_rows), dtype=torch.int64, device=dev)
+        all_len = torch.zeros(world * len(my_rows), dtype=torch.int64, device=dev)
+
     def step():
         dF.forget()          # a step is the whole of spasm_schur: derived factor state (the back-substituted rows) is rebuilt
         with torch.cuda.stream(stream):
             S, st = spasm_amd.dschur(dA, drows, dF, W, stream=stream.cuda_stream, fetch=False)
-            if use_dist:
+            if use_dist and split == "columns":
+                # the slabs stay where they are; what every rank needs to address whole rows later is their lengths
+                spasm_amd.lib().spasm_hip_dschur_row_pointers(W._h, my_Sp.data_ptr(), stream.cuda_stream)
+                torch.sub(my_Sp[1:], my_Sp[:-1], out=my_len)
+                dist.all_gather_into_tensor(all_len, my_len)
+            elif use_dist:
                 full = comm.allgatherv(W, A.m, PRIME, stream=stream.cuda_stream)      # all-gatherv of S on the devices
                 assert full.n == len(rows)
         return st
@@ -396,6 +425,9 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 
+    total_nnz_all = int(st.nnz)
+    if use_dist and split == "columns":
+        total_nnz_all = int(all_len.sum().item())          # entries of the whole Schur complement, from the exchanged lengths
     if rank == 0:
         total_rows = len(rows)
         ms_per_step = 1e3 * elapsed / args.steps
@@ -449,13 +481,16 @@ def main():
             "data": ("synthetic (%s regenerated from the definition of the matching complex; no network)" % args.workload)
             if source == "generated" else source,
             "config": {"workload": "%s (%dx%d, %d nnz) mod %d, round-0 Schur complement of %d non-pivotal rows "
-                                   "w.r.t. %d structural pivots" % (args.workload, A.n, A.m, A.nnz, PRIME,
+                                   "w.r.t. %d structural pivots" % (args.workload, A_full.n, A_full.m, A_full.nnz, PRIME,
                                                                    total_rows, F.U.n),
                        "rows_per_step": total_rows, "pivots": int(F.U.n), "levels": dF.levels,
-                       "non_pivotal_columns": int(A.m - F.U.n), "schur_nnz": int(st.nnz),
+                       "non_pivotal_columns": int(A_full.m - F_full.U.n), "schur_nnz": total_nnz_all,
                        "path": "back-substituted factor image" if st.used_backsolve else "row-by-row elimination",
                        "why_this_workload": why,
-                       "sharding": "rows over %d rank(s)%s" % (world, ", all-gatherv of S" if use_dist else "")},
+                       "sharding": ("columns: each of %d rank(s) reduces ALL rows on its slab of the non-pivotal columns (%d of %d here), no "
+                                    "replicated image, row lengths all-gathered (whole Schur complement: %d entries)"
+                                    % (world, A.m - F.U.n, A_full.m - F_full.U.n, total_nnz_all)) if split == "columns"
+                       else "rows over %d rank(s)%s" % (world, ", all-gatherv of S" if use_dist else "")},
             "roofline": roof,
             "factor_image_ms": statistics.median(image_ms),
             "factor_image_note": "host planning + upload of the factor image (spasm_hip_dfact_create), once per factor, NOT in a step; "
@@ -504,7 +539,7 @@ def main():
             runs = []
             for _ in range(5):
                 t0 = time.perf_counter()
-                fact = spasm_amd.echelonize(A, opts)
+                fact = spasm_amd.echelonize(A_full, opts)
                 runs.append((time.perf_counter() - t0, spasm_amd.echelonize_profile(), int(fact.U.n)))
             secs = [r[0] for r in runs]
             med = sorted(runs, key=lambda r: r[0])[len(runs) // 2]
@@ -520,7 +555,7 @@ def main():
                            "rank": "./tools/rank --matrix $SPASM_DATA/%s --modulus %d %s" % (c["file"], PRIME, " ".join(c["rank_args"]))}
                           for c, status, _ in workloads.discover()]
         if world == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(A, rows, F)
+            out["cpu_baseline"] = cpu_baseline(A_full, rows, F_full)
         print(json.dumps(out))
     if comm is not None:
         comm.close()

@@ -285,6 +285,8 @@ int spasm_hip_dschur(const spasm_hip_dcsr *A, const int *d_rows, int nrows, cons
 /* copies the result of the last spasm_hip_dschur into caller-provided device
  * buffers (Sp: nrows+1 int64; Sj, Sx: stats.nnz int32 each). */
 void spasm_hip_dschur_fetch(const spasm_hip_dwork *W, i64 *d_Sp, int *d_Sj, spasm_ZZp *d_Sx, void *stream);
+/* ... only its row pointers (rows + 1 int64; enqueued on `stream`, not synchronised) */
+void spasm_hip_dschur_row_pointers(const spasm_hip_dwork *W, i64 *d_Sp, void *stream);
 
 /* dense rows of the Schur complement, left on the device: d_S is nrows x Sm
  * (Sm = m - rank), row-major with leading dimension ldS, values in [0, p). */
@@ -318,6 +320,28 @@ void spasm_hip_shard(int n, int rank, int world, int *lo, int *hi);             
  * cap is too small -- call it with cap = -1 to learn the sizes. */
 int spasm_hip_dschur_allgatherv(spasm_hip_comm *c, const spasm_hip_dwork *W, i64 *d_Sp, int *d_Sj, spasm_ZZp *d_Sx, i64 cap,
                                 int *total_rows, i64 *total_nnz, void *stream);
+
+/* The exchange plan of spasm_hip_dschur_allgatherv as a pure host function (spasm_amd/csrc/host_dist.cpp; no GPU, no
+ * RCCL): the steps rank `me` issues, in order, for slices of sizes[2r] rows and sizes[2r + 1] entries.  The collective
+ * executes exactly this list; tests/test_dist_cpu.py checks it for worlds of 2 to 8 (every pair's send sequence equals the
+ * peer's receive sequence, receives + local copy tile the output). */
+enum {SPASM_HIP_XFER_SEND = 0, SPASM_HIP_XFER_RECV = 1, SPASM_HIP_XFER_COPY = 2};
+typedef struct {
+	int kind;       /* SPASM_HIP_XFER_* */
+	int peer;       /* the other rank (this rank for a local copy) */
+	int array;      /* 0: row pointers (int64), 1: column indices, 2: values (int32) */
+	i64 src;        /* send, copy: offset in this rank's own array */
+	i64 dst;        /* receive, copy: offset in the gathered array */
+	i64 count;      /* elements */
+} spasm_hip_xfer;
+int spasm_hip_allgatherv_plan(int world, int me, const i64 *sizes, spasm_hip_xfer *out, int cap, i64 *row_base, i64 *nz_base);
+
+/* The split that fits the back-substituted path: rank `part` of `parts` owns a contiguous range of the non-pivotal columns
+ * (in increasing column order) and works on (A, U) with the other non-pivotal columns deleted -- no replicated image, no
+ * exchange until somebody needs whole rows.  cols (room for A->m ints) maps the columns of the slab problem back; returns
+ * their number.  Pure host function (spasm_amd/csrc/host_dist.cpp).  Reference loop being split: spasm_schur.c:86-171. */
+int spasm_hip_column_slab(const struct spasm_csr *A, const struct spasm_lu *fact, int part, int parts, struct spasm_csr **A_slab,
+                          struct spasm_lu **fact_slab, int *cols);
 
 /* spasm_echelonize (spasm_echelonize.c:478) with every round's Schur complement sharded over the ranks of c; the pivot
  * search runs on rank 0 and is broadcast.  Collective; same rank of the matrix on every rank. */

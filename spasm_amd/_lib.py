@@ -57,6 +57,7 @@ def lib():
         "spasm_hip_dwork_destroy": (None, [vp]),
         "spasm_hip_dschur": (ci, [C.POINTER(CDcsr), vp, ci, vp, vp, vp, C.POINTER(CSchurStats)]),
         "spasm_hip_dschur_fetch": (None, [vp, vp, vp, vp, vp]),
+        "spasm_hip_dschur_row_pointers": (None, [vp, vp, vp]),
         "spasm_hip_echelonize_init_opts": (None, [C.POINTER(EchelonizeOpts)]),
         "spasm_hip_echelonize": (plu, [pcsr, C.POINTER(EchelonizeOpts)]),
         "spasm_hip_echelonize_profile": (None, [C.POINTER(C.c_double)]),
@@ -80,6 +81,8 @@ def lib():
         "spasm_hip_shard": (None, [ci, ci, ci, pint, pint]),
         "spasm_hip_dschur_allgatherv": (ci, [vp, vp, vp, vp, vp, i64, pint, C.POINTER(i64), vp]),
         "spasm_hip_echelonize_dist": (plu, [pcsr, C.POINTER(EchelonizeOpts), vp]),
+        "spasm_hip_allgatherv_plan": (ci, [ci, ci, C.POINTER(i64), vp, ci, C.POINTER(i64), C.POINTER(i64)]),
+        "spasm_hip_column_slab": (ci, [pcsr, plu, ci, ci, C.POINTER(pcsr), C.POINTER(plu), pint]),
     }
     for name, (res, args) in sig.items():
         fn = getattr(L, name)

@@ -142,63 +142,53 @@ int spasm_hip_dschur_allgatherv(spasm_hip_comm *c, const spasm_hip_dwork *W, i64
 	std::vector<int64_t> sizes((size_t) 2 * world);
 	HIP_CHECK(hipMemcpyAsync(sizes.data(), c->d_sizes, sizes.size() * sizeof(int64_t), hipMemcpyDeviceToHost, stream));
 	HIP_CHECK(hipStreamSynchronize(stream));
+	// who sends what to whom, in which order, at which offsets: spasm_hip_allgatherv_plan (host_dist.cpp, a pure host
+	// function that the CPU tests check for worlds of 2 to 8) -- this loop only executes its list
 	std::vector<int64_t> row_base((size_t) world + 1, 0), nz_base((size_t) world + 1, 0);
-	for (int r = 0; r < world; r++) {
-		row_base[r + 1] = row_base[r] + sizes[2 * r];
-		nz_base[r + 1] = nz_base[r] + sizes[2 * r + 1];
-	}
+	const int nsteps = spasm_hip_allgatherv_plan(world, c->rank, sizes.data(), nullptr, 0, row_base.data(), nz_base.data());
 	if (total_rows != nullptr)
 		*total_rows = (int) row_base[world];
 	if (total_nnz != nullptr)
 		*total_nnz = nz_base[world];
 	if (cap < 0 || nz_base[world] > cap)
 		return 1;
+	std::vector<spasm_hip_xfer> plan((size_t) (nsteps > 0 ? nsteps : 1));
+	(void) spasm_hip_allgatherv_plan(world, c->rank, sizes.data(), plan.data(), nsteps, nullptr, nullptr);
 	// exact counts, no padding.  xGMI is point-to-point (every GPU has a link to every other one): each rank SENDS its
 	// slice straight to every peer and receives theirs, all in one group, so that all the links carry payload at once
 	// (a ring all-gather or a broadcast tree would push the whole of S through single links).  The local slice is a
 	// device-to-device copy.  SPASM_HIP_ALLGATHERV=bcast: one ncclBroadcast per rank and array instead.
 	const char *how = std::getenv("SPASM_HIP_ALLGATHERV");
 	const bool use_bcast = how != nullptr && std::strcmp(how, "bcast") == 0;
-	const int me = c->rank;
+	const void *own[3] = {W->d_Sp, W->d_Sj, W->d_Sx};
+	void *all[3] = {d_Sp, d_Sj, d_Sx};
+	const size_t width[3] = {sizeof(int64_t), sizeof(int), sizeof(int)};
+	const ncclDataType_t type[3] = {ncclInt64, ncclInt32, ncclInt32};
 	NCCL_CHECK(ncclGroupStart());
-	for (int r = 0; r < world; r++) {
-		const int64_t nr = sizes[2 * r], nz = sizes[2 * r + 1];
-		if (use_bcast) {
+	if (use_bcast) {
+		for (int r = 0; r < world; r++) {
+			const int64_t nr = sizes[2 * r], nz = sizes[2 * r + 1];
 			if (nr > 0)
 				NCCL_CHECK(ncclBroadcast(W->d_Sp, d_Sp + row_base[r], (size_t) nr, ncclInt64, r, c->comm, stream));
 			if (nz > 0) {
 				NCCL_CHECK(ncclBroadcast(W->d_Sj, d_Sj + nz_base[r], (size_t) nz, ncclInt32, r, c->comm, stream));
 				NCCL_CHECK(ncclBroadcast(W->d_Sx, d_Sx + nz_base[r], (size_t) nz, ncclInt32, r, c->comm, stream));
 			}
-			continue;
 		}
-		if (r == me)
-			continue;
-		// to peer r: my slice; from peer r: its slice (sends and receives between two ranks match in issue order)
-		const int64_t my_nr = sizes[2 * me], my_nz = sizes[2 * me + 1];
-		if (my_nr > 0)
-			NCCL_CHECK(ncclSend(W->d_Sp, (size_t) my_nr, ncclInt64, r, c->comm, stream));
-		if (nr > 0)
-			NCCL_CHECK(ncclRecv(d_Sp + row_base[r], (size_t) nr, ncclInt64, r, c->comm, stream));
-		if (my_nz > 0) {
-			NCCL_CHECK(ncclSend(W->d_Sj, (size_t) my_nz, ncclInt32, r, c->comm, stream));
-			NCCL_CHECK(ncclSend(W->d_Sx, (size_t) my_nz, ncclInt32, r, c->comm, stream));
-		}
-		if (nz > 0) {
-			NCCL_CHECK(ncclRecv(d_Sj + nz_base[r], (size_t) nz, ncclInt32, r, c->comm, stream));
-			NCCL_CHECK(ncclRecv(d_Sx + nz_base[r], (size_t) nz, ncclInt32, r, c->comm, stream));
+	} else {
+		for (const spasm_hip_xfer &x : plan) {
+			if (x.kind == SPASM_HIP_XFER_SEND)
+				NCCL_CHECK(ncclSend((const char *) own[x.array] + (size_t) x.src * width[x.array], (size_t) x.count, type[x.array], x.peer, c->comm, stream));
+			else if (x.kind == SPASM_HIP_XFER_RECV)
+				NCCL_CHECK(ncclRecv((char *) all[x.array] + (size_t) x.dst * width[x.array], (size_t) x.count, type[x.array], x.peer, c->comm, stream));
 		}
 	}
 	NCCL_CHECK(ncclGroupEnd());
-	if (!use_bcast) {
-		const int64_t my_nr = sizes[2 * me], my_nz = sizes[2 * me + 1];
-		if (my_nr > 0)
-			HIP_CHECK(hipMemcpyAsync(d_Sp + row_base[me], W->d_Sp, (size_t) my_nr * sizeof(int64_t), hipMemcpyDeviceToDevice, stream));
-		if (my_nz > 0) {
-			HIP_CHECK(hipMemcpyAsync(d_Sj + nz_base[me], W->d_Sj, (size_t) my_nz * sizeof(int), hipMemcpyDeviceToDevice, stream));
-			HIP_CHECK(hipMemcpyAsync(d_Sx + nz_base[me], W->d_Sx, (size_t) my_nz * sizeof(int), hipMemcpyDeviceToDevice, stream));
-		}
-	}
+	if (!use_bcast)
+		for (const spasm_hip_xfer &x : plan)
+			if (x.kind == SPASM_HIP_XFER_COPY)
+				HIP_CHECK(hipMemcpyAsync((char *) all[x.array] + (size_t) x.dst * width[x.array], (const char *) own[x.array] + (size_t) x.src * width[x.array],
+				                         (size_t) x.count * width[x.array], hipMemcpyDeviceToDevice, stream));
 	// the row pointers of a slice start at 0: shift them to where the slice went
 	for (int r = 0; r < world; r++) {
 		const int nr = (int) sizes[2 * r];

@@ -1213,6 +1213,13 @@ int spasm_hip_dschur(const spasm_hip_dcsr *A, const int *d_rows, int nrows, cons
 	return dschur_impl(A, d_rows, nrows, F, W, stream, stats, nullptr);
 }
 
+// only the row pointers of the last result (rows + 1 int64): what the ranks of a column split exchange (lengths)
+void spasm_hip_dschur_row_pointers(const spasm_hip_dwork *W, i64 *d_Sp, void *stream_)
+{
+	hipStream_t stream = (hipStream_t) stream_;
+	HIP_CHECK(hipMemcpyAsync(d_Sp, W->d_Sp, ((size_t) W->last_rows + 1) * sizeof(i64), hipMemcpyDefault, stream));
+}
+
 void spasm_hip_dschur_fetch(const spasm_hip_dwork *W, i64 *d_Sp, int *d_Sj, spasm_ZZp *d_Sx, void *stream_)
 {
 	hipStream_t stream = (hipStream_t) stream_;

@@ -142,3 +142,76 @@ def sharded_schur(A, rows, F, W, dist, reduce_rows, stream=0, group=None):
     mine = shard_rows(rows, rank, world)
     S = reduce_rows(mine)
     return allgatherv_csr(S, dist, group=group)
+
+
+class CXfer(C.Structure):          # spasm_hip_xfer
+    _fields_ = [("kind", C.c_int), ("peer", C.c_int), ("array", C.c_int), ("src", C.c_int64), ("dst", C.c_int64), ("count", C.c_int64)]
+
+
+XFER_SEND, XFER_RECV, XFER_COPY = 0, 1, 2
+
+
+def allgatherv_plan(world, me, sizes):
+    """spasm_hip_allgatherv_plan: the steps rank `me` issues in spasm_hip_dschur_allgatherv, in order, as tuples
+    (kind, peer, array, src, dst, count); plus the row / entry offsets of the slices.  Pure host function (no GPU)."""
+    from ._lib import lib
+    L = lib()
+    flat = (C.c_int64 * (2 * world))(*[int(v) for pair in sizes for v in pair])
+    rb, zb = (C.c_int64 * (world + 1))(), (C.c_int64 * (world + 1))()
+    n = L.spasm_hip_allgatherv_plan(world, me, flat, None, 0, rb, zb)
+    buf = (CXfer * max(n, 1))()
+    L.spasm_hip_allgatherv_plan(world, me, flat, C.cast(buf, C.c_void_p), n, None, None)
+    return [(x.kind, x.peer, x.array, x.src, x.dst, x.count) for x in buf[:n]], list(rb), list(zb)
+
+
+def column_slab(A, F, part, parts):
+    """spasm_hip_column_slab: (A', F', cols) -- the problem of the rank that owns range `part` of `parts` of the non-pivotal
+    columns; cols[c'] = original column of column c' of A'.  Pure host function (no GPU)."""
+    from ._lib import lib
+    from .matrix import CCsr, CLu, view_csr, copy_csr, Fact
+    L = lib()
+    a = view_csr(A)
+    u = view_csr(F.U)
+    qinv = np.ascontiguousarray(F.qinv, np.int32)
+    lu = CLu()
+    lu.r = F.U.n
+    lu.complete = False
+    lu.L = None
+    lu.U = C.pointer(u)
+    lu.qinv = qinv.ctypes.data_as(C.POINTER(C.c_int))
+    lu.p = None
+    lu.Ltmp = None
+    cols = np.zeros(max(A.m, 1), np.int32)
+    pa, pf = C.POINTER(CCsr)(), C.POINTER(CLu)()
+    mm = L.spasm_hip_column_slab(C.byref(a), C.byref(lu), part, parts, C.byref(pa), C.byref(pf), cols.ctypes.data_as(C.POINTER(C.c_int)))
+    As = copy_csr(pa)
+    Us = copy_csr(pf.contents.U)
+    q2 = np.ctypeslib.as_array(pf.contents.qinv, shape=(max(mm, 1),))[:mm].copy()
+    L.spasm_hip_csr_free(pa)
+    L.spasm_hip_lu_free(pf)
+    return As, Fact(Us, q2), cols[:mm].copy()
+
+
+def stitch_column_slabs(parts, cols_of, n, m, prime):
+    """rows of the full Schur complement from those of its column slabs: parts[k] = Csr-like (p, j, x) of slab k on all n
+    rows, cols_of[k] = its column map.  Slabs are ranges of increasing columns, so a row is the concatenation of its
+    pieces in slab order.  Host arrays (numpy): this is what a rank does once it has been sent the other slabs."""
+    from .matrix import Csr
+    lens = np.zeros(n, np.int64)
+    for S in parts:
+        lens += np.diff(S.p)
+    p = np.zeros(n + 1, np.int64)
+    np.cumsum(lens, out=p[1:])
+    j = np.zeros(int(p[n]), np.int32)
+    x = np.zeros(int(p[n]), np.int32)
+    at = p[:-1].copy()
+    for S, cols in zip(parts, cols_of):
+        ln = np.diff(S.p)
+        # destination of every entry of the slab: start of its row + position inside the piece
+        row_of = np.repeat(np.arange(n), ln)
+        inside = np.arange(int(S.p[n])) - np.repeat(S.p[:-1], ln)
+        dst = at[row_of] + inside
+        j[dst] = cols[S.j[:int(S.p[n])]]
+        x[dst] = S.x[:int(S.p[n])]
+        at += ln
+    return Csr(n, m, p, j, x, prime)

@@ -58,3 +58,93 @@ def test_shard_bounds_cover():
             cuts = [shard_bounds(n, r, world) for r in range(world)]
             assert cuts[0][0] == 0 and cuts[-1][1] == n
             assert all(cuts[i][1] == cuts[i + 1][0] for i in range(world - 1))
+
+
+# --------------------------------------------------------------------------
+# the exchange plan of the RCCL all-gatherv (spasm_hip_allgatherv_plan: what dist_api.hip executes), for worlds 2 .. 8
+# --------------------------------------------------------------------------
+@pytest.mark.parametrize("world", [1, 2, 3, 4, 5, 6, 7, 8])
+def test_allgatherv_plan_is_consistent_between_every_pair_of_ranks(world):
+    """RCCL matches the k-th send of a to b with the k-th receive b posts for a (same group): for every ordered pair the
+    sequence of (array, count) sent must equal the sequence received; the receives of a rank plus its local copy must tile
+    the gathered arrays exactly; nothing of size zero is posted (by either side)."""
+    from spasm_amd.dist import allgatherv_plan, XFER_SEND, XFER_RECV, XFER_COPY
+    rng = np.random.default_rng(world)
+    for trial in range(12):
+        sizes = [(int(rng.integers(0, 50)), int(rng.integers(0, 5000))) for _ in range(world)]
+        if trial == 0:
+            sizes = [(0, 0)] * world                       # nothing anywhere
+        if trial == 1:
+            sizes = [(0, 0) if r % 2 else (7, 0) for r in range(world)]        # rows without entries, empty ranks
+        sizes = [(n, z if n > 0 else 0) for n, z in sizes]
+        plans = [allgatherv_plan(world, me, sizes) for me in range(world)]
+        total_rows, total_nz = sum(s[0] for s in sizes), sum(s[1] for s in sizes)
+        for me, (steps, rb, zb) in enumerate(plans):
+            assert rb[-1] == total_rows and zb[-1] == total_nz
+            assert all(rb[r + 1] - rb[r] == sizes[r][0] and zb[r + 1] - zb[r] == sizes[r][1] for r in range(world))
+            assert all(count > 0 for (_, _, _, _, _, count) in steps)
+            # the gathered arrays are written exactly once
+            for array, total in ((0, total_rows), (1, total_nz), (2, total_nz)):
+                covered = np.zeros(total, np.int32)
+                for kind, peer, arr, src, dst, count in steps:
+                    if arr == array and kind in (XFER_RECV, XFER_COPY):
+                        covered[dst:dst + count] += 1
+                        base = (rb if array == 0 else zb)[peer]
+                        assert dst == base and count == sizes[peer][0 if array == 0 else 1]
+                assert np.all(covered == 1)
+            # sends read this rank's own slice from its start, whole
+            for kind, peer, arr, src, dst, count in steps:
+                if kind == XFER_SEND:
+                    assert src == 0 and count == sizes[me][0 if arr == 0 else 1] and peer != me
+        for a in range(world):
+            for b in range(world):
+                if a == b:
+                    continue
+                sent = [(arr, count) for kind, peer, arr, _, _, count in plans[a][0] if kind == XFER_SEND and peer == b]
+                received = [(arr, count) for kind, peer, arr, _, _, count in plans[b][0] if kind == XFER_RECV and peer == a]
+                assert sent == received, (world, a, b, sent, received)
+
+
+# --------------------------------------------------------------------------
+# the column split (spasm_hip_column_slab): the Schur complement of a slab problem is the slab of the Schur complement
+# --------------------------------------------------------------------------
+@pytest.mark.parametrize("name", ["mat364.sms", "medium.sms", "rectangular_h.sms", "singular.sms", "trefethen_500.sms", "void.sms"])
+@pytest.mark.parametrize("parts", [1, 2, 3, 8])
+def test_column_slabs_stitch_to_the_full_schur_complement(oracle, name, parts):
+    """every rank works on (A, U) with the non-pivotal columns of the other ranks deleted; mapped back and concatenated, the
+    rows are those of the reference algorithm on the whole matrix (computed by the oracle on both sides: the function under
+    test is the host-side split, spasm_hip_column_slab + stitch_column_slabs)."""
+    import spasm_amd
+    from spasm_amd.dist import column_slab, stitch_column_slabs
+    p = 42013
+    A = oracle.load_sms(matrix_path(name), p)
+    npiv, perm, F = oracle.pivots_extract_structural(A, oracle.empty_fact(A.n, A.m, p))
+    rows = perm[npiv:]
+    want, _, _ = oracle.schur(A, rows, F)
+    Ap = spasm_amd.Csr(A.n, A.m, A.p, A.j, A.x, p)
+    Fp = spasm_amd.Fact(spasm_amd.Csr(F.U.n, F.U.m, F.U.p, F.U.j, F.U.x, p), F.qinv)
+    pieces, maps, widths = [], [], []
+    for k in range(parts):
+        As, Fs, cols = column_slab(Ap, Fp, k, parts)
+        assert As.n == A.n and As.m == len(cols) == Fs.U.m and Fs.U.n == F.U.n
+        assert np.all(np.diff(cols) > 0)
+        widths.append(len(cols) - F.U.n)
+        Ao = oracle.CSR(As.n, As.m, As.p, As.j, As.x, p)
+        Fo = oracle.Fact(oracle.CSR(Fs.U.n, Fs.U.m, Fs.U.p, Fs.U.j, Fs.U.x, p), Fs.qinv)
+        S, _, _ = oracle.schur(Ao, rows, Fo)
+        # (the library emits rows sorted by column; the oracle, like the reference, in the order of its elimination)
+        for i in range(S.n):
+            lo, hi = S.p[i], S.p[i + 1]
+            o = np.argsort(S.j[lo:hi])
+            S.j[lo:hi] = S.j[lo:hi][o]
+            S.x[lo:hi] = S.x[lo:hi][o]
+        pieces.append(S)
+        maps.append(cols)
+    assert sum(widths) == A.m - F.U.n and max(widths) - min(widths) <= 1
+    full = stitch_column_slabs(pieces, maps, len(rows), A.m, p)
+    assert full.nnz == want.nnz
+    for k in range(len(rows)):
+        wj, wx = want.row(k)
+        o = np.argsort(wj)
+        lo, hi = full.p[k], full.p[k + 1]
+        assert np.array_equal(full.j[lo:hi], wj[o]) and np.array_equal(full.x[lo:hi], wx[o])

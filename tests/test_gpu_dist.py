@@ -97,3 +97,60 @@ def test_bench_runs_its_rccl_path_on_one_gpu():
     line = [x for x in out.stdout.splitlines() if x.startswith("{")][-1]
     d = json.loads(line)
     assert d["value"] > 0 and "all-gatherv" in d["config"]["sharding"]
+
+
+def test_bench_runs_its_column_split_on_one_gpu():
+    """bench.py --split columns with the distributed path forced on (world of one): the slab problem of rank 0 of 1 is the
+    whole problem; the row lengths go through the RCCL all-gather."""
+    env = dict(os.environ, SPASM_BENCH_FORCE_DIST="1", SPASM_HIP_VERBOSE="0", MASTER_ADDR="127.0.0.1", MASTER_PORT="29873",
+               RANK="0", WORLD_SIZE="1", LOCAL_RANK="0")
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--workload", "mk11.b4", "--steps", "2", "--warmup", "1",
+                          "--no-extras", "--no-cpu-baseline", "--split", "columns"], capture_output=True, text=True, env=env, timeout=600)
+    assert out.returncode == 0, out.stderr[-3000:]
+    import json
+    line = [x for x in out.stdout.splitlines() if x.startswith("{")][-1]
+    d = json.loads(line)
+    assert d["value"] > 0 and d["config"]["sharding"].startswith("columns") and d["config"]["schur_nnz"] > 0
+
+
+@pytest.mark.parametrize("name,parts", [("mk12.b4", 4), ("mk11.b4", 8), ("mk12.b3", 3)])
+def test_column_slabs_on_the_gpu_stitch_to_the_full_schur_complement(name, parts):
+    """The split that fits the back-substituted path, in a world of one: the slab problems of all `parts` ranks
+    (spasm_hip_column_slab) are reduced one after the other by the HIP kernels -- each builds only ITS columns of R -- and
+    their rows, mapped back and concatenated, must be the Schur complement of the whole problem entry for entry (values
+    included: arithmetic mod p is exact).  What N ranks would each hold is exactly one of these pieces."""
+    import torch
+    from spasm_amd.dist import column_slab, stitch_column_slabs
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import workloads
+    p = 42013
+    A, rows, F, _ = workloads.round0(name, p)
+    os.environ["SPASM_HIP_BACKSOLVE"] = "1"
+    try:
+        def reduce(Ax, Fx):
+            dA = spasm_amd.DeviceCsr.from_host(Ax)
+            dF = spasm_amd.DeviceFact(Fx)
+            drows = torch.from_numpy(np.ascontiguousarray(rows, np.int32)).cuda()
+            pool = 1 << 24
+            while True:
+                W = spasm_amd.SchurWorkspace(len(rows), Ax.m, pool)
+                S, st = spasm_amd.dschur(dA, drows, dF, W, fetch=True)
+                if st.status == 0:
+                    break
+                W.close()
+                pool *= 4
+            assert st.used_backsolve == 1
+            H = S.to_host()
+            W.close()
+            dF.close()
+            return H
+        want = reduce(A, F)
+        pieces, maps = [], []
+        for k in range(parts):
+            As, Fs, cols = column_slab(A, F, k, parts)
+            pieces.append(reduce(As, Fs))
+            maps.append(cols)
+        full = stitch_column_slabs(pieces, maps, len(rows), A.m, p)
+    finally:
+        os.environ.pop("SPASM_HIP_BACKSOLVE", None)
+    assert np.array_equal(full.p, want.p) and np.array_equal(full.j, want.j) and np.array_equal(full.x, want.x)
