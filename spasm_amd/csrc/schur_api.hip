@@ -638,8 +638,10 @@ spasm_hip_dfact *spasm_hip_dfact_create(const struct spasm_csr *U, const int *qi
 	hipStream_t stream = (hipStream_t) stream_;
 	if (spasm_hip_device_count() == 0)
 		die("spasm_hip_dfact_create: no HIP device (this library has no CPU path)");
+	const double t_begin = wtime();
 	FactPlan P;
 	plan_factor(U, qinv, P);
+	const double t_planned = wtime();
 	const int r = P.r, m = P.m, rpad = P.rpad;
 	spasm_hip_dfact *F = new spasm_hip_dfact();
 	F->m = m;
@@ -673,11 +675,14 @@ spasm_hip_dfact *spasm_hip_dfact_create(const struct spasm_csr *U, const int *qi
 	upload(F->d_lvl_end, P.lvl_end.data(), rpad, stream);
 	upload(F->d_lvl_end_w, P.lvl_end_w.data(), rpad / 32, stream);
 	upload(F->d_kof, P.kof.data(), rpad, stream);
-	// U' by target label and the label range of every level: what the pull variant of the row-group kernel reads
-	std::vector<uint64_t> cp((size_t) rpad + (size_t) (m - r) + 1, 0);
-	std::vector<uint2> cent((size_t) (F->nnz > 0 ? F->nnz : 1));
-	std::vector<int2> lvl((size_t) (P.nlevels > 0 ? P.nlevels : 1));
-	{
+	// U' by target label and the label range of every level: what the pull variant of the row-group kernel reads (an
+	// experiment, SPASM_HIP_PULL=1: the tables are only built for it -- a counting sort of U' on the host, 15 % of the
+	// image's build time on mk13.b5)
+	const bool want_pull = env_int("SPASM_HIP_PULL", 0) != 0;
+	std::vector<uint64_t> cp(want_pull ? (size_t) rpad + (size_t) (m - r) + 1 : 1, 0);
+	std::vector<uint2> cent((size_t) (want_pull && F->nnz > 0 ? F->nnz : 1));
+	std::vector<int2> lvl((size_t) (want_pull && P.nlevels > 0 ? P.nlevels : 1));
+	if (want_pull) {
 		for (i64 e = 0; e < F->nnz; e++)
 			cp[(size_t) P.ent[e].x + 1] += 1;
 		for (size_t t = 0; t + 1 < cp.size(); t++)
@@ -696,11 +701,15 @@ spasm_hip_dfact *spasm_hip_dfact_create(const struct spasm_csr *U, const int *qi
 	upload(F->d_cent, cent.data(), (i64) cent.size(), stream);
 	upload(F->d_lvl, lvl.data(), (i64) lvl.size(), stream);
 	HIP_CHECK(hipStreamSynchronize(stream));    // the host vectors die here
+	const double t_uploaded = wtime();
 	// back-substituted image (backsolve.hip): planned when the non-pivotal columns are few enough for dense rows
 	// of R; R itself is computed by the first Schur complement that wants it
 	int64_t bs_bytes = 0;
 	if (env_int("SPASM_HIP_BACKSOLVE", -1) != 0 && backsolve_eligible(r, m - r, F->nnz, &bs_bytes))
 		backsolve_plan(P, F, stream);
+	if (verbose() >= 2)
+		logmsg("[factor image] %d rows, %d levels: level schedule + relabelling %.1f ms, tables + upload %.1f ms, plan of the back-substitution %.1f ms\n",
+		       r, P.nlevels, 1e3 * (t_planned - t_begin), 1e3 * (t_uploaded - t_planned), 1e3 * (wtime() - t_uploaded));
 	return F;
 }
 
