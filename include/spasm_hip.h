@@ -187,6 +187,9 @@ const char *spasm_hip_datatype_name(spasm_datatype datatype);
 
 /* --- drivers (replace spasm_echelonize.c:9-28, :478-616; spasm_rref.c:25; spasm_kernel.c:9) --- */
 void spasm_hip_echelonize_init_opts(struct echelonize_opts *opts);
+/* Threads: the driver keeps process-wide state between its stages (device-resident matrices, the cached factor image, the
+ * profile below); concurrent calls are taken one at a time (a mutex inside).  The other host-pointer entry points share the
+ * one-entry factor cache (serialised too); the spasm_hip_d* layer keeps its state in the handles it is given. */
 struct spasm_lu *spasm_hip_echelonize(const struct spasm_csr *A, struct echelonize_opts *opts);
 /* seconds the last spasm_hip_echelonize call spent in: [0] the whole call, [1] the host pivot search, [2] density
  * estimates, [3] sparse Schur complements, [4] the dense / low-rank finish, [5] number of sparse Schur rounds,

@@ -1909,7 +1909,14 @@ void launch_backsolve_apply(const SchurArgs &a, const spasm_hip_dfact *F, uint32
 	d.waves = waves;
 	d.wave_bytes = per_wave;
 	const size_t lds = per_wave * (size_t) waves;
-	const int blocks = std::max(1, std::min((a.nrows + waves - 1) / waves, prop.multiProcessorCount * 8));
+	int blocks = std::max(1, std::min((a.nrows + waves - 1) / waves, prop.multiProcessorCount * 8));
+	if (d.direct) {
+		// look-back output: a row waits for rows held by OTHER workgroups, so every workgroup of the grid must be resident
+		// (a workgroup that has not started cannot publish the lengths its ticket class owes): at most what the LDS of the
+		// chip holds at once
+		const int per_cu = (int) std::max<size_t>(1, (size_t) (160 * 1024) / std::max<size_t>(lds, 1));
+		blocks = std::min(blocks, prop.multiProcessorCount * per_cu);
+	}
 	d.ntickets = std::min(LB_TICKETS, blocks);
 	// one launch of the apply kernel that fits the arithmetic of R
 	auto launch_apply = [&](const ApplyArgs &dd, int nblocks_apply) {

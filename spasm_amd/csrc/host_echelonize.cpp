@@ -7,6 +7,7 @@
 //   rounds on the GPU until the remainder is empty.
 #include <cinttypes>
 #include <cmath>
+#include <mutex>
 #include <vector>
 
 #include "device_types.h"
@@ -367,8 +368,14 @@ struct Stopwatch {          // adds the time of its scope to a slot of g_prof
 };
 }  // namespace
 
+// The driver keeps process-wide state between its stages (the table of device-resident matrices, the cached factor image,
+// the profile above): calls from several threads are taken one at a time.  (The device-level entry points -- spasm_hip_d* --
+// keep their state in the handles they are given and may run concurrently on different handles.)
+static std::mutex g_driver_mutex;
+
 extern "C" struct spasm_lu *spasm_hip_echelonize(const struct spasm_csr *A0, struct echelonize_opts *opts)
 {
+	std::lock_guard<std::mutex> one_at_a_time(g_driver_mutex);
 	for (int k = 0; k < 8; k++)
 		g_prof[k] = 0.0;
 	resident_begin();          // A, and every Schur complement after it, stays in HBM between the calls below
