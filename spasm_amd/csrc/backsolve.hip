@@ -139,6 +139,7 @@ struct BsArgs {
 	int sparse_init;              // 1: the kernel scatters U_n itself (few entries); 0: R was pre-filled by bs_init_kernel
 	int r;
 	int dbg;                      // timing experiments only (SPASM_HIP_BS_DEBUG): bit 0/1/2 = skip phase A/B/C (wrong results)
+	unsigned long long *prof;     // SPASM_HIP_BS_PROFILE=1: 8 counters, shader-clock cycles of workgroup 0 per stage of a chunk, summed over the chunks
 	int sgn;                      // signed 16-bit entries (the SGN kernels); coefficients are negated balanced residues
 	MontDev F;
 	SgnDev G;
@@ -190,36 +191,68 @@ template <typename T> __global__ __launch_bounds__(256) void bs_init_kernel(BsAr
 	}
 }
 
+// A fixed number of values that must stay in REGISTERS across a long stretch of code.  A local array would do in
+// principle, but an array of more than 16 dwords is not turned into registers by the compiler (it becomes scratch memory,
+// i.e. global memory behind the cache: measured on the metadata of backsolve_kernel, whose 20-dword table part went
+// through scratch_store / scratch_load and cost two memory round trips per chunk); members of a struct, reached with
+// compile-time indices, always are.
+template <typename T, int N> struct RegFile {
+	T head;
+	RegFile<T, N - 1> tail;
+	template <int I> __device__ __forceinline__ T &at()
+	{
+		if constexpr (I == 0)
+			return head;
+		else
+			return tail.template at<I - 1>();
+	}
+};
+template <typename T> struct RegFile<T, 0> {
+};
+
+template <int I, int N, typename Fn> __device__ __forceinline__ void bs_static_for(Fn &&f)
+{
+	if constexpr (I < N) {
+		f(std::integral_constant<int, I>{});
+		bs_static_for<I + 1, N>(f);
+	}
+}
+
 // LPR lanes (words) per row of a slab: a row of a slab is LPR * 4 bytes (128 B with LPR = 32: whole cache lines, half
 // as many requests as 64-byte segments -- the kernel is bound by the rate of such requests).
 // NW waves per workgroup; a wave instruction covers 64 / LPR rows.
-template <bool PACKED, int LPR, int NW> struct BsGeom {
+// RING / PASSROWS / PASSCAP: rows per chunk, rows per phase-B pass, passes per chunk -- the plan (backsolve_plan) is built
+// for the values of the kernel that will run it (BsImage::ring, passrows, passcap).
+template <bool PACKED, int LPR, int NW, int RING = BS_RING, int PASSROWS = BS_PASSROWS, int PASSCAP = BS_PASSCAP> struct BsGeom {
+	static constexpr int RING_ = RING, PASSROWS_ = PASSROWS, PASSCAP_ = PASSCAP;
 	static constexpr int THREADS = 64 * NW;
 	static constexpr int RS = 64 / LPR;
 	static constexpr int CW = LPR * Word<PACKED>::CPL;     // columns per slab
 	static constexpr int ROWS_PER_ITER = RS * NW;
-	static constexpr int ITERS = BS_RING / ROWS_PER_ITER;
+	static constexpr int ITERS = RING / ROWS_PER_ITER;
 	// rows in flight per lane in phase A.  Eight waves (two per SIMD: 256 registers each) take a whole chunk in ONE pass --
 	// a pass is a round trip to memory, and a chunk has little else to hide it behind
 	static constexpr int UNR = (NW == 8 && ITERS == 24) ? 24 : (ITERS % 12 == 0) ? 12 : 8;
-	static_assert(BS_RING % ROWS_PER_ITER == 0 && ITERS % UNR == 0, "phase A is unrolled in passes of UNR rows");
+	static_assert(RING % ROWS_PER_ITER == 0 && ITERS % UNR == 0, "phase A is unrolled in passes of UNR rows");
 	static constexpr int N_NEAR = (BS_NEARCAP + THREADS - 1) / THREADS;      // metadata words a thread carries for the next chunk
-	static constexpr int N_ROW = (BS_RING + THREADS - 1) / THREADS;
-	static constexpr int N_PTAB = (BS_PASSCAP * BS_PASSROWS + THREADS - 1) / THREADS;
-	static constexpr size_t FH_BYTES = (size_t) BS_RING * sizeof(uint4);
-	static constexpr size_t PTAB_BYTES = (size_t) BS_PASSCAP * BS_PASSROWS * sizeof(uint4);
+	static constexpr int N_ROW = (RING + THREADS - 1) / THREADS;
+	static constexpr int N_PTAB = (PASSCAP * PASSROWS + THREADS - 1) / THREADS;
+	static constexpr size_t FH_BYTES = (size_t) RING * sizeof(uint4);
+	static constexpr size_t PTAB_BYTES = (size_t) PASSCAP * PASSROWS * sizeof(uint4);
 	static constexpr int RSTR = LPR + 1;                    // row stride of the ring in words: odd, so that a wave instruction over
 	                                                        // consecutive rows AND one over consecutive words both spread over the banks
-	static constexpr size_t LDS_BYTES = FH_BYTES + PTAB_BYTES + (size_t) BS_NEARCAP * sizeof(uint2) + (size_t) (BS_RING + 1) * RSTR * 4;          // (+ the spare row)
+	static constexpr size_t LDS_BYTES = FH_BYTES + PTAB_BYTES + (size_t) BS_NEARCAP * sizeof(uint2) + (size_t) (RING + 1) * RSTR * 4;          // (+ the spare row)
 };
 
-template <bool PACKED, bool PLAIN, int LPR, int NW, bool SGN = false>
-__global__ __launch_bounds__(64 * NW) void backsolve_kernel(BsArgs b)
+template <bool PACKED, bool PLAIN, int LPR, int NW, bool SGN = false, int RING = BS_RING, int PASSROWS = BS_PASSROWS, int PASSCAP = BS_PASSCAP, int WGS_PER_CU = 1>
+__global__ __launch_bounds__(64 * NW, WGS_PER_CU) void backsolve_kernel(BsArgs b)
 {
+	// an empty slot of the pass table points at the spare row of the ring (index RING) with coefficient 0
+	const uint4 EMPTY_ENTRY = uint4{(uint32_t) RING, (uint32_t) RING | ((uint32_t) RING << 16), 0u, 0u};
 	static_assert(!SGN || (PACKED && PLAIN), "signed entries are packed 16-bit entries");
 	const uint32_t bm = PLAIN ? (uint32_t) (0x100000000ull / b.F.p) : 0u;
 	const SgnDev G = b.G;
-	using Geo = BsGeom<PACKED, LPR, NW>;
+	using Geo = BsGeom<PACKED, LPR, NW, RING, PASSROWS, PASSCAP>;
 	using Elem = typename Word<PACKED>::Elem;
 	extern __shared__ __attribute__((aligned(16))) unsigned char bs_lds[];
 	uint4 *fh = reinterpret_cast<uint4 *>(bs_lds);                          // first two outside dependencies of every row
@@ -228,11 +261,18 @@ __global__ __launch_bounds__(64 * NW) void backsolve_kernel(BsArgs b)
 	uint32_t *ring = reinterpret_cast<uint32_t *>(near + BS_NEARCAP);
 	const int tid = threadIdx.x;
 	const int lane = tid & 63, wave = tid >> 6;
+	// workgroup barrier that waits for this wave's LDS traffic only.  __syncthreads() also drains the vector-memory counter,
+	// i.e. the metadata of the NEXT chunk that was asked for at the top of this one: the first barrier of every chunk then
+	// costs a round trip to memory (170 chunks x ~1 us on mk13.b5).  Between the phases only the ring (LDS) is handed
+	// from wave to wave; the one place where global stores must be visible to other waves (after phase C) keeps
+	// __syncthreads().
+	auto lds_barrier = [&]() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); };
 	const int rs = lane / LPR, wl = lane % LPR;           // row slot of the lane, its word inside the row (phases A and C)
 	constexpr int RSTR = Geo::RSTR;                        // words between two rows of the ring
 	// phase B splits the COLUMNS among the waves: a wave owns WPW words of every row, a wave instruction covers RSB rows
 	constexpr int WPW = LPR / NW, RSB = 64 / WPW;
 	static_assert(WPW >= 1 && RSB == Geo::ROWS_PER_ITER, "phase B walks the rows of a step as the other phases do");
+	static_assert(PASSROWS % RSB == 0, "a pass is a whole number of wave instructions");
 	const int rsb = lane / WPW, wlb = wave * WPW + lane % WPW;
 	const MontDev F = b.F;
 	const int64_t ldw = b.ldR / Word<PACKED>::CPL;       // row stride of R in words
@@ -246,57 +286,87 @@ __global__ __launch_bounds__(64 * NW) void backsolve_kernel(BsArgs b)
 
 	// metadata of a chunk (the same for every slab: served by the L2) travels through registers: the loads for chunk
 	// k + 1 are issued when chunk k starts and land in LDS when it is done
-	uint2 m_near[Geo::N_NEAR];
-	uint4 m_fh[Geo::N_ROW], m_ptab[Geo::N_PTAB];
-	auto load_meta = [&](int k) {
-		const BsChunk c = b.chunk[k];
-#pragma unroll
-		for (int q = 0; q < Geo::N_NEAR; q++) {
+	RegFile<uint2, Geo::N_NEAR> m_near;
+	RegFile<uint4, Geo::N_ROW> m_fh;
+	RegFile<uint4, Geo::N_PTAB> m_ptab;
+	auto load_meta = [&](const BsChunk &c) {
+		bs_static_for<0, Geo::N_NEAR>([&](auto qq) {
+			constexpr int q = decltype(qq)::value;
 			const int t = tid + q * Geo::THREADS;
-			m_near[q] = (t < c.nnear) ? b.near[c.near0 + t] : uint2{0u, 0u};
-		}
-#pragma unroll
-		for (int q = 0; q < Geo::N_ROW; q++) {
+			// (the load is unconditional, from a valid address, and the VALUE is selected: `cond ? *p : constant` makes the
+			//  compiler select between p and the address of the constant, which then has to live in scratch memory, and turns
+			//  the load into a FLAT one)
+			const uint2 v = b.near[(t < c.nnear) ? c.near0 + t : 0];
+			m_near.template at<q>() = (t < c.nnear) ? v : uint2{0u, 0u};
+		});
+		bs_static_for<0, Geo::N_ROW>([&](auto qq) {
+			constexpr int q = decltype(qq)::value;
 			const int t = tid + q * Geo::THREADS;
-			m_fh[q] = (t < c.hi - c.lo) ? b.far_head[c.lo + t] : uint4{BS_NONE, 0u, BS_NONE, 0u};
-		}
-#pragma unroll
-		for (int q = 0; q < Geo::N_PTAB; q++) {
+			const uint4 v = b.far_head[(t < c.hi - c.lo) ? c.lo + t : 0];
+			m_fh.template at<q>() = (t < c.hi - c.lo) ? v : uint4{BS_NONE, 0u, BS_NONE, 0u};
+		});
+		bs_static_for<0, Geo::N_PTAB>([&](auto qq) {
+			constexpr int q = decltype(qq)::value;
 			const int t = tid + q * Geo::THREADS;
-			m_ptab[q] = (t < c.npass * BS_PASSROWS) ? b.ptab[(int64_t) c.pass0 * BS_PASSROWS + t] : BS_EMPTY_ENTRY;
-		}
+			const uint4 v = b.ptab[(t < c.npass * PASSROWS) ? (int64_t) c.pass0 * PASSROWS + t : 0];
+			m_ptab.template at<q>() = (t < c.npass * PASSROWS) ? v : uint4{(uint32_t) RING, (uint32_t) RING | ((uint32_t) RING << 16), 0u, 0u};
+		});
 	};
 	auto store_meta = [&]() {
-#pragma unroll
-		for (int q = 0; q < Geo::N_NEAR; q++)
+		bs_static_for<0, Geo::N_NEAR>([&](auto qq) {
+			constexpr int q = decltype(qq)::value;
 			if (tid + q * Geo::THREADS < BS_NEARCAP)
-				near[tid + q * Geo::THREADS] = m_near[q];
-#pragma unroll
-		for (int q = 0; q < Geo::N_ROW; q++)
-			if (tid + q * Geo::THREADS < BS_RING)
-				fh[tid + q * Geo::THREADS] = m_fh[q];
-#pragma unroll
-		for (int q = 0; q < Geo::N_PTAB; q++)
-			if (tid + q * Geo::THREADS < BS_PASSCAP * BS_PASSROWS)
-				ptab[tid + q * Geo::THREADS] = m_ptab[q];
+				near[tid + q * Geo::THREADS] = m_near.template at<q>();
+		});
+		bs_static_for<0, Geo::N_ROW>([&](auto qq) {
+			constexpr int q = decltype(qq)::value;
+			if (tid + q * Geo::THREADS < RING)
+				fh[tid + q * Geo::THREADS] = m_fh.template at<q>();
+		});
+		bs_static_for<0, Geo::N_PTAB>([&](auto qq) {
+			constexpr int q = decltype(qq)::value;
+			if (tid + q * Geo::THREADS < PASSCAP * PASSROWS)
+				ptab[tid + q * Geo::THREADS] = m_ptab.template at<q>();
+		});
 	};
+	// chunk descriptors travel one chunk ahead too: the descriptor of chunk k + 1 is in registers when chunk k starts, so
+	// that the loads of its metadata (whose addresses it holds) can be issued at once instead of after a round trip
+	BsChunk ch_next = (b.nchunks > 0) ? b.chunk[0] : BsChunk{};
 	if (b.nchunks > 0) {
-		load_meta(0);
+		load_meta(ch_next);
 		store_meta();
 	}
+	BsChunk ch_after = (b.nchunks > 1) ? b.chunk[1] : BsChunk{};
 	__syncthreads();
 
+	// stage timer (SPASM_HIP_BS_PROFILE): thread 0 of workgroup 0 reads the shader clock at every stage boundary
+	unsigned long long pt[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+	unsigned long long t_last = 0;
+	const bool profiling = b.prof != nullptr && blockIdx.x == 0 && tid == 0;
+	auto tick = [&](int q) {
+		if (profiling) {
+			const unsigned long long now = __builtin_readcyclecounter();
+			pt[q] += now - t_last;
+			t_last = now;
+		}
+	};
+	if (profiling)
+		t_last = __builtin_readcyclecounter();
 	for (int k = 0; k < b.nchunks; k++) {
-		const BsChunk ch = b.chunk[k];
+		const BsChunk ch = ch_next;
+		ch_next = ch_after;
 		const int nrows = ch.hi - ch.lo;
 		if (k + 1 < b.nchunks)
-			load_meta(k + 1);
+			load_meta(ch_next);
+		if (k + 2 < b.nchunks)
+			ch_after = b.chunk[k + 2];
+		tick(0);          // descriptor + issue of the next chunk's metadata
 
 		if (b.sparse_init) {
 			// the rows start as U_n: few entries, scattered from the list (R itself is never read for them)
 			for (int t = tid; t < nrows * RSTR; t += Geo::THREADS)
 				ring[t] = 0;
-			__syncthreads();
+			lds_barrier();
 			const uint64_t e0 = b.np_rp[ch.lo], e1 = b.np_rp[ch.hi];
 			for (uint64_t e = e0 + tid; e < e1; e += Geo::THREADS) {
 				const uint2 en = b.np[e];
@@ -305,8 +375,9 @@ __global__ __launch_bounds__(64 * NW) void backsolve_kernel(BsArgs b)
 					reinterpret_cast<Elem *>(ring)[(b.np_row[e] - ch.lo) * (RSTR * Word<PACKED>::CPL) + cc] =
 						SGN ? (Elem) (uint16_t) (int16_t) sgn_from_residue(en.y, G) : (Elem) (PLAIN ? en.y : montmul(en.y, 1u, F));
 			}
-			__syncthreads();
+			lds_barrier();
 		}
+		tick(1);          // start of the rows (zero + scatter of the non-pivotal entries)
 
 		// ---- phase A: own row + dependencies outside the chunk, up to 3 * UNR loads in flight per lane ----
 		for (int pass = 0; pass < Geo::ITERS / Geo::UNR; pass++) {
@@ -356,7 +427,8 @@ __global__ __launch_bounds__(64 * NW) void backsolve_kernel(BsArgs b)
 				}
 			}
 		}
-		__syncthreads();
+		lds_barrier();
+		tick(2);          // phase A
 		if (b.chunk_extra[k]) {
 			// rows with more than two outside dependencies (long rows of U): the rest of their lists
 			for (int s = slot0; s < nrows; s += Geo::ROWS_PER_ITER) {
@@ -386,9 +458,10 @@ __global__ __launch_bounds__(64 * NW) void backsolve_kernel(BsArgs b)
 				}
 				ring[s * RSTR + wl] = x;
 			}
-			__syncthreads();
+			lds_barrier();
 		}
 
+		tick(3);          // long lists of outside dependencies
 		// ---- phase B: the chain of levels, in LDS ----
 		// Columns never meet in a triangular solve, so every wave takes ITS columns (WPW words of every row) through all the
 		// levels of the chunk on its own: no barrier between the levels -- the LDS serves a wave's reads and writes in
@@ -396,10 +469,10 @@ __global__ __launch_bounds__(64 * NW) void backsolve_kernel(BsArgs b)
 		// holds everything a row with one or two dependencies inside the chunk needs, and the entry of the next trip is
 		// in flight during the arithmetic of this one.  (Every wave decodes every entry: the table is what keeps that cheap.)
 		{
-			const int niter = ((b.dbg & 2) ? 0 : ch.npass) * (BS_PASSROWS / RSB);
-			uint4 e = (niter > 0) ? ptab[rsb] : BS_EMPTY_ENTRY;
+			const int niter = ((b.dbg & 2) ? 0 : ch.npass) * (PASSROWS / RSB);
+			uint4 e = (niter > 0) ? ptab[rsb] : EMPTY_ENTRY;
 			for (int it = 0; it < niter; it++) {
-				const uint4 e_next = (it + 1 < niter) ? ptab[(it + 1) * RSB + rsb] : BS_EMPTY_ENTRY;
+				const uint4 e_next = (it + 1 < niter) ? ptab[(it + 1) * RSB + rsb] : EMPTY_ENTRY;
 				const int cnt = (int) (e.x >> 16);                    // cnt != 0: this lane has a row in the pass
 				if constexpr (SGN) {
 					// no branch: an empty slot reads and writes the spare row.  (With a branch around the reads the compiler has
@@ -486,16 +559,22 @@ __global__ __launch_bounds__(64 * NW) void backsolve_kernel(BsArgs b)
 				e = e_next;
 			}
 		}
-		__syncthreads();
+		lds_barrier();
+		tick(4);          // phase B
 
 		// ---- phase C: write the chunk back ----
 		for (int s = slot0; s < ((b.dbg & 4) ? 0 : nrows); s += Geo::ROWS_PER_ITER)
 			*row_at((uint32_t) (ch.lo + s)) = ring[s * RSTR + wl];
 		__syncthreads();          // (workgroup-scope release/acquire: later chunks read these rows; LDS metadata is free)
+		tick(5);          // phase C
 		if (k + 1 < b.nchunks)
 			store_meta();
 		__syncthreads();
+		tick(6);          // metadata of the next chunk into LDS
 	}
+	if (profiling)
+		for (int q = 0; q < 8; q++)
+			b.prof[q] = pt[q];
 }
 
 // --------------------------------------------------------------------------
@@ -1370,17 +1449,21 @@ template <bool PACKED, bool PLAIN> __global__ __launch_bounds__(64 * AW_NW) void
 	}
 }
 
-template <bool PACKED, bool PLAIN, int LPR, int NW, bool SGN = false> void launch_backsolve_variant(const BsArgs &b, int Sm, hipStream_t stream)
+template <bool PACKED, bool PLAIN, int LPR, int NW, bool SGN = false, int RING = BS_RING, int PASSROWS = BS_PASSROWS, int PASSCAP = BS_PASSCAP, int WGS_PER_CU = 1>
+void launch_backsolve_variant(const BsArgs &b, int Sm, hipStream_t stream, const BsImage &B)
 {
-	using G = BsGeom<PACKED, LPR, NW>;
+	using G = BsGeom<PACKED, LPR, NW, RING, PASSROWS, PASSCAP>;
+	if (B.ring != RING || B.passrows != PASSROWS || B.passcap != PASSCAP)
+		die("backsolve: the plan was built for chunks of %d rows, passes of %d rows, %d passes; this kernel takes %d / %d / %d", B.ring, B.passrows,
+		    B.passcap, RING, PASSROWS, PASSCAP);
 	static bool configured = false;
 	if (!configured) {
-		HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(&backsolve_kernel<PACKED, PLAIN, LPR, NW, SGN>),
+		HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(&backsolve_kernel<PACKED, PLAIN, LPR, NW, SGN, RING, PASSROWS, PASSCAP, WGS_PER_CU>),
 		                              hipFuncAttributeMaxDynamicSharedMemorySize, (int) G::LDS_BYTES));
 		configured = true;
 	}
-	hipLaunchKernelGGL((backsolve_kernel<PACKED, PLAIN, LPR, NW, SGN>), dim3((unsigned) ((Sm + G::CW - 1) / G::CW)), dim3(64 * NW), G::LDS_BYTES,
-	                   stream, b);
+	hipLaunchKernelGGL((backsolve_kernel<PACKED, PLAIN, LPR, NW, SGN, RING, PASSROWS, PASSCAP, WGS_PER_CU>), dim3((unsigned) ((Sm + G::CW - 1) / G::CW)),
+	                   dim3(64 * NW), G::LDS_BYTES, stream, b);
 }
 
 template <bool PACKED, bool PLAIN> void launch_apply_variant(const ApplyArgs &d, int blocks, size_t lds, hipStream_t stream)
@@ -1420,6 +1503,38 @@ void backsolve_plan(const FactPlan &P, spasm_hip_dfact *F, hipStream_t stream)
 	B.r = r;
 	B.Sm = m - r;
 	B.ldR = ((int64_t) B.Sm + 511) / 512 * 512;          // whole tile groups of the apply kernels (64 * AP_TU words of two entries): the padding stays zero
+	// p < 2^16: coefficients are kept as plain residues (the kernels multiply with 24-bit products + Barrett); small p: signed
+	// 16-bit entries of R, coefficients of the dependencies are NEGATED balanced residues (SgnDev above)
+	B.plain = P.prime < 65536;
+	B.sgn = B.plain && sgn_eligible(P.prime) && env_bs("SPASM_HIP_BS_SIGNED", 1) != 0 && env_bs("SPASM_HIP_BS_PACKED", 1) != 0;
+	// Shape of the build kernel (the plan is cut for it).  0 = 128-byte slab rows, 16 waves; 1 = 128 B, 8 waves; 2 = 64 B, 8
+	// waves; 3 = 32-byte slab rows (16 columns), 8 waves, passes of 64 rows, TWO workgroups per CU.  The build is a chain
+	// (DESIGN.md section 5): a workgroup takes the same time whatever the width of its slab, phase A being bound by the
+	// instruction issue of ONE CU and phase B by LDS latency; so narrower slabs -- half the phase-A instructions per
+	// workgroup, a whole level of up to 64 rows per pass -- and two workgroups sharing a CU, one in its issue-bound phase
+	// while the other waits on the LDS, use the chip better as long as all of them are resident at once.
+	{
+		int cus = 0, dev = 0;
+		HIP_CHECK(hipGetDevice(&dev));
+		hipDeviceProp_t prop;
+		HIP_CHECK(hipGetDeviceProperties(&prop, dev));
+		cus = prop.multiProcessorCount;
+		const bool packed = B.sgn || (P.prime < 65536 && env_bs("SPASM_HIP_BS_PACKED", 1) != 0);
+		const int slabs_small = packed ? (B.Sm + 31) / 32 : (B.Sm + 15) / 16;
+		const int slabs_narrow = (B.Sm + 15) / 16;
+		int shape = slabs_small <= (packed ? 2 * cus : cus) ? 2 : 0;
+		if (B.sgn && slabs_narrow <= 2 * cus && env_bs("SPASM_HIP_BS_NARROW", 0) != 0)
+			shape = 3;
+		shape = env_bs("SPASM_HIP_BS_SHAPE", shape);
+		if (shape == 3 && !B.sgn)
+			shape = 2;
+		B.shape = shape;
+		B.ring = BS_RING;
+		B.passrows = (shape == 3) ? 64 : BS_PASSROWS;
+		B.passcap = (shape == 3) ? 31 : BS_PASSCAP;
+	}
+	const int PLAN_RING = B.ring, PLAN_PASSROWS = B.passrows, PLAN_PASSCAP = B.passcap;
+	const uint4 PLAN_EMPTY = uint4{(uint32_t) PLAN_RING, (uint32_t) PLAN_RING | ((uint32_t) PLAN_RING << 16), 0u, 0u};
 	// compact ids: labels that hold a row, in label (= level) order
 	std::vector<int> cid((size_t) (rpad > 0 ? rpad : 1), -1);
 	std::vector<int> label_of((size_t) (r > 0 ? r : 1), 0);
@@ -1446,8 +1561,6 @@ void backsolve_plan(const FactPlan &P, spasm_hip_dfact *F, hipStream_t stream)
 	for (int j = 0; j < m; j++)
 		colmap[j] = (P.lab[j] < (uint32_t) rpad) ? cid[P.lab[j]] : r + (int) (P.lab[j] - (uint32_t) rpad);
 
-	// p < 2^16: coefficients are kept as plain residues (the kernels multiply with 24-bit products + Barrett)
-	B.plain = P.prime < 65536;
 	uint64_t unmont = 1;                 // 2^-32 mod p
 	if (B.plain) {
 		const uint64_t R1 = (uint64_t) ((1ull << 32) % (uint64_t) P.prime);
@@ -1466,8 +1579,6 @@ void backsolve_plan(const FactPlan &P, spasm_hip_dfact *F, hipStream_t stream)
 		unmont = (uint64_t) ((t0 % P.prime + P.prime) % P.prime);
 	}
 	auto coeff = [&](uint32_t y_mont) -> uint32_t { return B.plain ? (uint32_t) (((uint64_t) y_mont * unmont) % (uint64_t) P.prime) : y_mont; };
-	// small p: signed 16-bit entries of R, coefficients of the dependencies are NEGATED balanced residues (SgnDev above)
-	B.sgn = B.plain && sgn_eligible(P.prime) && env_bs("SPASM_HIP_BS_SIGNED", 1) != 0 && env_bs("SPASM_HIP_BS_PACKED", 1) != 0;
 	auto dep_coeff = [&](uint32_t y_mont) -> uint32_t {
 		const uint32_t c = coeff(y_mont);
 		if (!B.sgn)
@@ -1513,14 +1624,14 @@ void backsolve_plan(const FactPlan &P, spasm_hip_dfact *F, hipStream_t stream)
 		BsChunk ch{};
 		ch.hi = hi;
 		int lo = hi, nnear = 0, npass = 0, in_level = 0, last_level = -1;
-		while (lo > 0 && hi - lo < BS_RING) {
+		while (lo > 0 && hi - lo < PLAN_RING) {
 			const int c = lo - 1;
 			int nc = 0;
 			for (uint64_t e = dep_rp[c]; e < dep_rp[c + 1]; e++)
 				nc += dep[e].x < (uint32_t) hi;
-			const bool new_pass = nc > 0 && (level[c] != last_level || in_level % BS_PASSROWS == 0);
+			const bool new_pass = nc > 0 && (level[c] != last_level || in_level % PLAN_PASSROWS == 0);
 			const int extra = nc > 2 ? nc - 1 : 0;
-			if (nnear + extra > BS_NEARCAP || nc > 65535 || (new_pass && npass + 1 > BS_PASSCAP))
+			if (nnear + extra > BS_NEARCAP || nc > 65535 || (new_pass && npass + 1 > PLAN_PASSCAP))
 				break;                           // (the first row of a chunk never has dependencies inside it)
 			if (nc > 0) {
 				if (level[c] != last_level)
@@ -1543,7 +1654,7 @@ void backsolve_plan(const FactPlan &P, spasm_hip_dfact *F, hipStream_t stream)
 	{
 		for (size_t k = 0; k < chunks.size(); k++) {
 			BsChunk &ch = chunks[k];
-			ch.pass0 = (int) (ptab.size() / BS_PASSROWS);
+			ch.pass0 = (int) (ptab.size() / PLAN_PASSROWS);
 			ch.near0 = (int) near.size();
 			int last_level = -1, extra = 0, in_level = 0;
 			for (int c = ch.hi - 1; c >= ch.lo; c--) {
@@ -1567,10 +1678,10 @@ void backsolve_plan(const FactPlan &P, spasm_hip_dfact *F, hipStream_t stream)
 				}
 				if (nc == 0)
 					continue;
-				if (level[c] != last_level || in_level % BS_PASSROWS == 0) {
+				if (level[c] != last_level || in_level % PLAN_PASSROWS == 0) {
 					// a new pass: the previous one is padded with empty entries
-					while (ptab.size() % BS_PASSROWS != 0)
-						ptab.push_back(BS_EMPTY_ENTRY);
+					while (ptab.size() % PLAN_PASSROWS != 0)
+						ptab.push_back(PLAN_EMPTY);
 					if (level[c] != last_level)
 						in_level = 0;
 					last_level = level[c];
@@ -1597,11 +1708,11 @@ void backsolve_plan(const FactPlan &P, spasm_hip_dfact *F, hipStream_t stream)
 				}
 				ptab.push_back(en);
 			}
-			while (ptab.size() % BS_PASSROWS != 0)
-				ptab.push_back(BS_EMPTY_ENTRY);
-			if ((int) (ptab.size() / BS_PASSROWS) - ch.pass0 != ch.npass || (int) near.size() - ch.near0 != ch.nnear)
+			while (ptab.size() % PLAN_PASSROWS != 0)
+				ptab.push_back(PLAN_EMPTY);
+			if ((int) (ptab.size() / PLAN_PASSROWS) - ch.pass0 != ch.npass || (int) near.size() - ch.near0 != ch.nnear)
 				die("backsolve_plan: chunk %zu was counted differently on the second pass (%d passes against %d, %d list entries against %d)", k,
-				    (int) (ptab.size() / BS_PASSROWS) - ch.pass0, ch.npass, (int) near.size() - ch.near0, ch.nnear);
+				    (int) (ptab.size() / PLAN_PASSROWS) - ch.pass0, ch.npass, (int) near.size() - ch.near0, ch.nnear);
 			chunk_extra[k] = extra;
 		}
 	}
@@ -1642,9 +1753,9 @@ void backsolve_plan(const FactPlan &P, spasm_hip_dfact *F, hipStream_t stream)
 			far1 += far_head[c].x != BS_NONE;
 			far2 += far_head[c].z != BS_NONE;
 		}
-		fprintf(stderr, "[bs plan] r %d, Sm %d, levels %d, chunks %zu, passes of 32 rows %zu (%lld empty slots), rows with dependencies inside their chunk: 1: %lld, 2: %lld, 3: %lld, "
+		fprintf(stderr, "[bs plan] r %d, Sm %d, levels %d, chunks %zu, passes %zu (%lld empty slots), rows with dependencies inside their chunk: 1: %lld, 2: %lld, 3: %lld, "
 		        "4: %lld, 5+: %lld; list %zu, far heads %lld + %lld, far rest %llu, np %zu\n",
-		        r, B.Sm, P.nlevels, chunks.size(), ptab.size() / BS_PASSROWS, (long long) empty, (long long) cnt_hist[1], (long long) cnt_hist[2], (long long) cnt_hist[3],
+		        r, B.Sm, P.nlevels, chunks.size(), ptab.size() / PLAN_PASSROWS, (long long) empty, (long long) cnt_hist[1], (long long) cnt_hist[2], (long long) cnt_hist[3],
 		        (long long) cnt_hist[4], (long long) cnt_hist[5], near.size(), (long long) far1, (long long) far2, (unsigned long long) far_rp[r], np.size());
 	}
 	B.nchunks = (int) chunks.size();
@@ -1745,6 +1856,11 @@ void backsolve_build(const spasm_hip_dfact *F, hipStream_t stream)
 	b.G = sgn_setup(F->prime);
 	b.F = to_dev(F->mont);
 	b.dbg = env_bs("SPASM_HIP_BS_DEBUG", 0);
+	b.prof = nullptr;
+	if (env_bs("SPASM_HIP_BS_PROFILE", 0)) {
+		b.prof = dalloc<unsigned long long>(8);
+		HIP_CHECK(hipMemsetAsync(b.prof, 0, 8 * sizeof(unsigned long long), stream));
+	}
 	// few non-pivotal entries per row of U (mk13.b5: 0.08): the kernel scatters them into its LDS ring itself and R is
 	// neither zeroed nor read for them; many (factors that already hold dense rows): R is pre-filled instead
 	b.sparse_init = (B.nnp <= 4 * (int64_t) B.r && env_bs("SPASM_HIP_BS_SPARSE_INIT", 1) != 0) ? 1 : 0;
@@ -1761,49 +1877,60 @@ void backsolve_build(const spasm_hip_dfact *F, hipStream_t stream)
 	// (phase B) is bound by instruction issue -- every wave runs every step -- so the small workgroup wins while all its
 	// slabs are resident at once (mk13.b5: 4.4 against 4.9 ms); with more slabs than that, whole cache lines per request
 	// matter more (phase A is bound by the rate of memory requests)
-	int cus = 0;
-	{
-		int dev = 0;
-		HIP_CHECK(hipGetDevice(&dev));
-		hipDeviceProp_t prop;
-		HIP_CHECK(hipGetDeviceProperties(&prop, dev));
-		cus = prop.multiProcessorCount;
-	}
-	const int slabs_small = packed ? (B.Sm + 31) / 32 : (B.Sm + 15) / 16;
-	const int shape = env_bs("SPASM_HIP_BS_SHAPE", slabs_small <= (packed ? 2 * cus : cus) ? 2 : 0);
-	snprintf(B.kernel_build, sizeof(B.kernel_build), "backsolve_kernel<%s,%s,%d,%d,%s>", packed ? "true" : "false", B.plain ? "true" : "false",
-	         shape == 2 ? 16 : 32, (shape == 0 || (!packed && B.plain && shape == 1)) ? 16 : 8, B.sgn ? "true" : "false");
+	const int shape = B.shape;
+	if (shape == 3)
+		snprintf(B.kernel_build, sizeof(B.kernel_build), "backsolve_kernel<true,true,8,8,true,768,64,31,2>");
+	else
+		snprintf(B.kernel_build, sizeof(B.kernel_build), "backsolve_kernel<%s,%s,%d,%d,%s>", packed ? "true" : "false", B.plain ? "true" : "false",
+		         shape == 2 ? 16 : 32, (shape == 0 || (!packed && B.plain && shape == 1)) ? 16 : 8, B.sgn ? "true" : "false");
 	if (B.sgn) {
-		if (shape == 1)
-			launch_backsolve_variant<true, true, 32, 8, true>(b, B.Sm, stream);
+		if (shape == 3)
+			launch_backsolve_variant<true, true, 8, 8, true, 768, 64, 31, 2>(b, B.Sm, stream, B);
+		else if (shape == 1)
+			launch_backsolve_variant<true, true, 32, 8, true>(b, B.Sm, stream, B);
 		else if (shape == 2)
-			launch_backsolve_variant<true, true, 16, 8, true>(b, B.Sm, stream);
+			launch_backsolve_variant<true, true, 16, 8, true>(b, B.Sm, stream, B);
 		else
-			launch_backsolve_variant<true, true, 32, 16, true>(b, B.Sm, stream);
+			launch_backsolve_variant<true, true, 32, 16, true>(b, B.Sm, stream, B);
 	} else if (packed) {
 		if (shape == 1)
-			launch_backsolve_variant<true, true, 32, 8>(b, B.Sm, stream);
+			launch_backsolve_variant<true, true, 32, 8>(b, B.Sm, stream, B);
 		else if (shape == 2)
-			launch_backsolve_variant<true, true, 16, 8>(b, B.Sm, stream);
+			launch_backsolve_variant<true, true, 16, 8>(b, B.Sm, stream, B);
 		else
-			launch_backsolve_variant<true, true, 32, 16>(b, B.Sm, stream);
+			launch_backsolve_variant<true, true, 32, 16>(b, B.Sm, stream, B);
 	} else if (B.plain) {          // (p < 2^16 with 32-bit entries of R: the SPASM_HIP_BS_PACKED=0 knob)
 		if (shape == 2)
-			launch_backsolve_variant<false, true, 16, 8>(b, B.Sm, stream);
+			launch_backsolve_variant<false, true, 16, 8>(b, B.Sm, stream, B);
 		else
-			launch_backsolve_variant<false, true, 32, 16>(b, B.Sm, stream);
+			launch_backsolve_variant<false, true, 32, 16>(b, B.Sm, stream, B);
 	} else {
 		if (shape == 1)
-			launch_backsolve_variant<false, false, 32, 8>(b, B.Sm, stream);
+			launch_backsolve_variant<false, false, 32, 8>(b, B.Sm, stream, B);
 		else if (shape == 2)
-			launch_backsolve_variant<false, false, 16, 8>(b, B.Sm, stream);
+			launch_backsolve_variant<false, false, 16, 8>(b, B.Sm, stream, B);
 		else
-			launch_backsolve_variant<false, false, 32, 16>(b, B.Sm, stream);
+			launch_backsolve_variant<false, false, 32, 16>(b, B.Sm, stream, B);
 	}
 	HIP_CHECK(hipGetLastError());
 	HIP_CHECK(hipEventRecord(B.ev1, stream));
 	B.valid = true;
 	B.builds += 1;
+	if (b.prof != nullptr) {
+		unsigned long long h[8];
+		HIP_CHECK(hipMemcpyAsync(h, b.prof, sizeof(h), hipMemcpyDeviceToHost, stream));
+		HIP_CHECK(hipStreamSynchronize(stream));
+		static const char *const stage[7] = {"descriptor + metadata issue", "row start (zero + scatter)", "phase A", "long outside lists", "phase B", "phase C",
+		                                     "metadata into LDS"};
+		unsigned long long tot = 0;
+		for (int q = 0; q < 7; q++)
+			tot += h[q];
+		fprintf(stderr, "[bs profile] %s, %d chunks, workgroup 0, shader-clock cycles per chunk:", B.kernel_build, B.nchunks);
+		for (int q = 0; q < 7; q++)
+			fprintf(stderr, " %s %.0f (%.0f%%);", stage[q], (double) h[q] / B.nchunks, 100.0 * (double) h[q] / (double) (tot ? tot : 1));
+		fprintf(stderr, " total %.0f\n", (double) tot / B.nchunks);
+		(void) hipFree(b.prof);
+	}
 	if (env_bs("SPASM_HIP_BS_CHECK", 0) && b.sparse_init && bytes < ((size_t) 1 << 30)) {
 		// debugging aid: the same build with R pre-filled (the other way of starting the rows), compared entry by entry
 		void *R2 = nullptr;
@@ -1817,13 +1944,13 @@ void backsolve_build(const spasm_hip_dfact *F, hipStream_t stream)
 		else
 			hipLaunchKernelGGL(bs_init_kernel<uint32_t>, dim3((B.r + 255) / 256), dim3(256), 0, stream, c);
 		if (B.sgn)
-			launch_backsolve_variant<true, true, 32, 16, true>(c, B.Sm, stream);
+			launch_backsolve_variant<true, true, 32, 16, true>(c, B.Sm, stream, B);
 		else if (packed)
-			launch_backsolve_variant<true, true, 32, 16>(c, B.Sm, stream);
+			launch_backsolve_variant<true, true, 32, 16>(c, B.Sm, stream, B);
 		else if (B.plain)
-			launch_backsolve_variant<false, true, 32, 16>(c, B.Sm, stream);
+			launch_backsolve_variant<false, true, 32, 16>(c, B.Sm, stream, B);
 		else
-			launch_backsolve_variant<false, false, 32, 16>(c, B.Sm, stream);
+			launch_backsolve_variant<false, false, 32, 16>(c, B.Sm, stream, B);
 		std::vector<unsigned char> h1(bytes), h2(bytes);
 		HIP_CHECK(hipMemcpyAsync(h1.data(), B.d_R, bytes, hipMemcpyDeviceToHost, stream));
 		HIP_CHECK(hipMemcpyAsync(h2.data(), R2, bytes, hipMemcpyDeviceToHost, stream));

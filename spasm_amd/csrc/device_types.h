@@ -159,7 +159,9 @@ struct BsImage {
 	hipEvent_t ev0 = nullptr, ev1 = nullptr;     // around the last build (memset + init + backsolve kernel)
 	int builds = 0;
 	double density_hint = -1.0;       // expected density of the Schur complements of this factor (< 0: unknown)
-	char kernel_build[48] = "backsolve_kernel";      // variant launched by the last build, as rocprofv3 prints it
+	char kernel_build[64] = "backsolve_kernel";      // variant launched by the last build, as rocprofv3 prints it
+	int shape = 2;                    // workgroup shape of the build kernel the plan was cut for (backsolve_plan)
+	int ring = 768, passrows = 32, passcap = 80;      // rows per chunk, rows per phase-B pass, passes per chunk of that plan
 };
 
 // device copy of a host CSR matrix for the duration of a call (schur_api.hip: resident between the calls of a driver)
