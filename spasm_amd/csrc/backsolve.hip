@@ -289,7 +289,18 @@ __global__ __launch_bounds__(64 * NW, WGS_PER_CU) void backsolve_kernel(BsArgs b
 	RegFile<uint2, Geo::N_NEAR> m_near;
 	RegFile<uint4, Geo::N_ROW> m_fh;
 	RegFile<uint4, Geo::N_PTAB> m_ptab;
+	// the first THREADS non-pivotal entries of the next chunk (mk13.b5: 61 per chunk), one per thread; the rest -- if any --
+	// is read when the chunk starts
+	uint2 m_np = uint2{0u, 0u};
+	int m_np_row = 0;
 	auto load_meta = [&](const BsChunk &c) {
+		{
+			const int cnt = c.npn & 0x7FFFFFFF;
+			const uint2 v = b.np[(tid < cnt) ? c.np0 + tid : 0];
+			const int vr = b.np_row[(tid < cnt) ? c.np0 + tid : 0];
+			m_np = v;
+			m_np_row = vr;
+		}
 		bs_static_for<0, Geo::N_NEAR>([&](auto qq) {
 			constexpr int q = decltype(qq)::value;
 			const int t = tid + q * Geo::THREADS;
@@ -331,12 +342,40 @@ __global__ __launch_bounds__(64 * NW, WGS_PER_CU) void backsolve_kernel(BsArgs b
 	};
 	// chunk descriptors travel one chunk ahead too: the descriptor of chunk k + 1 is in registers when chunk k starts, so
 	// that the loads of its metadata (whose addresses it holds) can be issued at once instead of after a round trip
-	BsChunk ch_next = (b.nchunks > 0) ? b.chunk[0] : BsChunk{};
+	// (read with VECTOR loads -- every lane the same 32 bytes: a scalar load shares its counter with the LDS, and the first
+	//  LDS access after it would wait for the round trip)
+	static_assert(sizeof(BsChunk) == 32, "a chunk descriptor is two 16-byte loads");
+	int vzero;
+	asm volatile("v_mov_b32 %0, 0" : "=v"(vzero));          // (a zero the compiler cannot see through: keeps the address in a VGPR)
+	uint4 raw_a = uint4{0u, 0u, 0u, 0u}, raw_b = uint4{0u, 0u, 0u, 0u};
+	auto fetch_chunk = [&](int k) {
+		const uint4 *src = reinterpret_cast<const uint4 *>(b.chunk + k) + vzero;
+		raw_a = src[0];
+		raw_b = src[1];
+	};
+	auto fetched_chunk = [&]() {
+		BsChunk c;
+		c.lo = __builtin_amdgcn_readfirstlane((int) raw_a.x);
+		c.hi = __builtin_amdgcn_readfirstlane((int) raw_a.y);
+		c.pass0 = __builtin_amdgcn_readfirstlane((int) raw_a.z);
+		c.npass = __builtin_amdgcn_readfirstlane((int) raw_a.w);
+		c.near0 = __builtin_amdgcn_readfirstlane((int) raw_b.x);
+		c.nnear = __builtin_amdgcn_readfirstlane((int) raw_b.y);
+		c.np0 = __builtin_amdgcn_readfirstlane((int) raw_b.z);
+		c.npn = __builtin_amdgcn_readfirstlane((int) raw_b.w);
+		return c;
+	};
+	BsChunk ch_next{};
 	if (b.nchunks > 0) {
+		fetch_chunk(0);
+		ch_next = fetched_chunk();
 		load_meta(ch_next);
 		store_meta();
 	}
-	BsChunk ch_after = (b.nchunks > 1) ? b.chunk[1] : BsChunk{};
+	uint2 c_np = m_np;            // (chunk 0's own first entries)
+	int c_np_row = m_np_row;
+	if (b.nchunks > 1)
+		fetch_chunk(1);
 	__syncthreads();
 
 	// stage timer (SPASM_HIP_BS_PROFILE): thread 0 of workgroup 0 reads the shader clock at every stage boundary
@@ -354,12 +393,17 @@ __global__ __launch_bounds__(64 * NW, WGS_PER_CU) void backsolve_kernel(BsArgs b
 		t_last = __builtin_readcyclecounter();
 	for (int k = 0; k < b.nchunks; k++) {
 		const BsChunk ch = ch_next;
-		ch_next = ch_after;
 		const int nrows = ch.hi - ch.lo;
-		if (k + 1 < b.nchunks)
+		if (k > 0) {
+			c_np = m_np;
+			c_np_row = m_np_row;
+		}
+		if (k + 1 < b.nchunks) {
+			ch_next = fetched_chunk();
 			load_meta(ch_next);
+		}
 		if (k + 2 < b.nchunks)
-			ch_after = b.chunk[k + 2];
+			fetch_chunk(k + 2);
 		tick(0);          // descriptor + issue of the next chunk's metadata
 
 		if (b.sparse_init) {
@@ -367,14 +411,17 @@ __global__ __launch_bounds__(64 * NW, WGS_PER_CU) void backsolve_kernel(BsArgs b
 			for (int t = tid; t < nrows * RSTR; t += Geo::THREADS)
 				ring[t] = 0;
 			lds_barrier();
-			const uint64_t e0 = b.np_rp[ch.lo], e1 = b.np_rp[ch.hi];
-			for (uint64_t e = e0 + tid; e < e1; e += Geo::THREADS) {
-				const uint2 en = b.np[e];
+			const int np_count = ch.npn & 0x7FFFFFFF;
+			auto put = [&](const uint2 en, int row) {
 				const int cc = (int) en.x - col_lo;
 				if (cc >= 0 && cc < Geo::CW)
-					reinterpret_cast<Elem *>(ring)[(b.np_row[e] - ch.lo) * (RSTR * Word<PACKED>::CPL) + cc] =
+					reinterpret_cast<Elem *>(ring)[(row - ch.lo) * (RSTR * Word<PACKED>::CPL) + cc] =
 						SGN ? (Elem) (uint16_t) (int16_t) sgn_from_residue(en.y, G) : (Elem) (PLAIN ? en.y : montmul(en.y, 1u, F));
-			}
+			};
+			if (tid < np_count)
+				put(c_np, c_np_row);
+			for (int e = Geo::THREADS + tid; e < np_count; e += Geo::THREADS)
+				put(b.np[ch.np0 + e], b.np_row[ch.np0 + e]);
 			lds_barrier();
 		}
 		tick(1);          // start of the rows (zero + scatter of the non-pivotal entries)
@@ -429,7 +476,7 @@ __global__ __launch_bounds__(64 * NW, WGS_PER_CU) void backsolve_kernel(BsArgs b
 		}
 		lds_barrier();
 		tick(2);          // phase A
-		if (b.chunk_extra[k]) {
+		if (ch.npn < 0) {          // (bit 31 of the descriptor)
 			// rows with more than two outside dependencies (long rows of U): the rest of their lists
 			for (int s = slot0; s < nrows; s += Geo::ROWS_PER_ITER) {
 				const int c = ch.lo + s;
@@ -1714,8 +1761,13 @@ void backsolve_plan(const FactPlan &P, spasm_hip_dfact *F, hipStream_t stream)
 				die("backsolve_plan: chunk %zu was counted differently on the second pass (%d passes against %d, %d list entries against %d)", k,
 				    (int) (ptab.size() / PLAN_PASSROWS) - ch.pass0, ch.npass, (int) near.size() - ch.near0, ch.nnear);
 			chunk_extra[k] = extra;
+			// everything the kernel needs to start a chunk sits in its descriptor (no dependent loads at the top of a chunk)
+			ch.np0 = (int) std::min<uint64_t>(np_rp[ch.lo], 0x7FFFFFFFull);
+			ch.npn = (int) std::min<uint64_t>(np_rp[ch.hi] - np_rp[ch.lo], 0x7FFFFFFFull) | (extra ? (int) 0x80000000u : 0);
 		}
 	}
+	if (np.size() >= 0x7FFFFFFFull)
+		die("backsolve_plan: %zu non-pivotal entries in the factor (the chunk descriptors index them with 31 bits)", np.size());
 	// dependencies beyond the first two outside the chunk, CSR by row
 	for (int c = 0; c < r; c++)
 		far_rp[c + 1] = far_rp[c] + far_cnt[c];

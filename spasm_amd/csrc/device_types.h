@@ -131,7 +131,8 @@ struct BsChunk {              // a run of consecutive compact rows solved inside
 	int lo, hi;               // compact rows [lo, hi)
 	int pass0, npass;         // phase-B passes of 32 rows (rows of one level that have dependencies inside the chunk)
 	int near0, nnear;         // dependencies of the rows that have more than two of them inside the chunk
-	int pad0, pad1;
+	int np0;                  // first non-pivotal entry (index into d_np) of the rows of the chunk ...
+	int npn;                  // ... their number (bits 0-30); bit 31: some row has more than two dependencies outside the chunk
 };
 
 struct BsImage {
