@@ -225,9 +225,12 @@ void spasm_hip_dfact_destroy(spasm_hip_dfact *F);
 /* forgets derived state cached in the image (the back-substituted rows R): the next Schur call rebuilds it.
  * bench.py calls this before every step so that a step is the whole of spasm_schur. */
 void spasm_hip_dfact_forget(spasm_hip_dfact *F);
-/* expected density (entries / (rows * non-pivotal columns)) of the Schur complements computed with this factor; < 0:
- * unknown.  Dense results (>= 0.25) go through the back-substituted image even when its rows are long. */
+/* Hints for the choice between the two elimination paths (a cost model): the expected density
+ * (entries / (rows * non-pivotal columns)) of the Schur complements computed with this factor, and the number of (row,
+ * pivot) eliminations a reduced row takes (what the row-by-row kernels count; spasm_hip_schur records it from the driver's
+ * density sample by itself).  < 0: unknown (5 % density, 5 % of the pivots per row are assumed). */
 void spasm_hip_dfact_hint_density(spasm_hip_dfact *F, double density);
+void spasm_hip_dfact_hint_eliminations(spasm_hip_dfact *F, double per_row);
 int spasm_hip_dfact_rank(const spasm_hip_dfact *F);
 int spasm_hip_dfact_levels(const spasm_hip_dfact *F);
 i64 spasm_hip_dfact_nnz(const spasm_hip_dfact *F);

@@ -50,6 +50,7 @@ def lib():
         "spasm_hip_dfact_destroy": (None, [vp]),
         "spasm_hip_dfact_forget": (None, [vp]),
         "spasm_hip_dfact_hint_density": (None, [vp, C.c_double]),
+        "spasm_hip_dfact_hint_eliminations": (None, [vp, C.c_double]),
         "spasm_hip_dfact_rank": (ci, [vp]),
         "spasm_hip_dfact_levels": (ci, [vp]),
         "spasm_hip_dfact_nnz": (i64, [vp]),

@@ -31,7 +31,7 @@ void launch_schur_wave_dense(const SchurArgs &a, unsigned char *scratch, int64_t
 void backsolve_build(const spasm_hip_dfact *F, hipStream_t stream);
 void launch_backsolve_apply(const SchurArgs &a, const spasm_hip_dfact *F, uint32_t *dense_out, int64_t ldS, hipStream_t stream,
                             BsDirectOut *direct);
-bool backsolve_wanted(const spasm_hip_dfact *F, bool other_path_forced);
+bool backsolve_wanted(const spasm_hip_dfact *F, bool other_path_forced, int nrows);
 }  // namespace sh
 
 using namespace sh;
@@ -85,7 +85,7 @@ static int dschur_dense_impl(const spasm_hip_dcsr *A, const int *d_rows, int nro
 		die("spasm_hip_dschur_dense: leading dimension %" PRId64 " below the %d non-pivotal columns", ldS, F->Sm);
 	if (nrows == 0)
 		return 0;
-	if (Lout == nullptr && backsolve_wanted(F, env_int("SPASM_HIP_FORCE_TIER", 0) != 0 || env_int("SPASM_HIP_GROUP", -1) >= 0)) {
+	if (Lout == nullptr && backsolve_wanted(F, env_int("SPASM_HIP_FORCE_TIER", 0) != 0 || env_int("SPASM_HIP_GROUP", -1) >= 0, nrows)) {
 		// dense rows straight from the back-substituted image (backsolve.hip)
 		if (!F->bs.valid)
 			backsolve_build(F, stream);
@@ -296,9 +296,12 @@ bool finish_on_device(const struct spasm_csr *A, const int *p, int n, struct spa
 	// would do instead -- append every block's dense echelon rows to U, re-plan and re-upload the grown factor, reduce the
 	// next block by it -- costs seconds per block on a wide remainder (ch8-8.b5: 0.4 -> 2.7 s per 1000 combinations).
 	// SPASM_HIP_DEVICE_FINISH=2 keeps the round-2 rule (device finish only with R).
-	const bool have_R = backsolve_wanted(F, env_int("SPASM_HIP_FORCE_TIER", 0) != 0 || env_int("SPASM_HIP_GROUP", -1) >= 0);
+	// (the finish reduces all n rows in the end -- as blocks, or inside random combinations: R is judged on that)
+	const bool have_R = backsolve_wanted(F, env_int("SPASM_HIP_FORCE_TIER", 0) != 0 || env_int("SPASM_HIP_GROUP", -1) >= 0, std::max(n, 1024));
 	if (!have_R && env_int("SPASM_HIP_DEVICE_FINISH", 1) == 2)
 		return false;
+	if (have_R && !F->bs.valid)
+		backsolve_build(F, stream);          // (the blocks below are small batches: they use R when it is there, they do not ask for it)
 	const i64 prime = A->field->p;
 	// The reference's block size (1000 rows by default) is sized for FFPACK on a CPU; here every block costs one dense RREF of
 	// [E; Y] on top of the echelon rows found so far, so blocks of at least 4096 rows are taken (SPASM_HIP_DENSE_BLOCK=0:

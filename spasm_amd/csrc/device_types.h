@@ -160,6 +160,7 @@ struct BsImage {
 	hipEvent_t ev0 = nullptr, ev1 = nullptr;     // around the last build (memset + init + backsolve kernel)
 	int builds = 0;
 	double density_hint = -1.0;       // expected density of the Schur complements of this factor (< 0: unknown)
+	double elim_hint = -1.0;          // (row, pivot) eliminations per reduced row, as the row-by-row kernels measured them on a sample (< 0: unknown)
 	char kernel_build[64] = "backsolve_kernel";      // variant launched by the last build, as rocprofv3 prints it
 	int shape = 2;                    // workgroup shape of the build kernel the plan was cut for (backsolve_plan)
 	int ring = 768, passrows = 32, passcap = 80;      // rows per chunk, rows per phase-B pass, passes per chunk of that plan

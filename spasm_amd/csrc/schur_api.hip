@@ -32,7 +32,7 @@ void backsolve_build(const spasm_hip_dfact *F, hipStream_t stream);
 bool backsolve_stages_output(const spasm_hip_dfact *F, int64_t *row_bytes);
 void launch_backsolve_apply(const SchurArgs &a, const spasm_hip_dfact *F, uint32_t *dense_out, int64_t ldS, hipStream_t stream,
                             BsDirectOut *direct);
-bool backsolve_wanted(const spasm_hip_dfact *F, bool other_path_forced);
+bool backsolve_wanted(const spasm_hip_dfact *F, bool other_path_forced, int nrows);
 // multi-GPU layer (dist_api.hip)
 spasm_hip_comm *current_comm();
 int comm_rank(const spasm_hip_comm *c);
@@ -346,14 +346,18 @@ spasm_hip_dfact *cached_dfact(const struct spasm_csr *U, const int *qinv, hipStr
 }  // namespace sh
 
 namespace sh {
-// Should this Schur complement go through the back-substituted image?  Its cost per reduced row is a few rows of R
-// (Sm entries each) whatever the result looks like; the row-by-row kernels pay for the actual fill-in.  Measured
-// (DESIGN.md section 5): mk13.b5, Sm = 4,952, S 72 % dense: 8.5 ms against 52.6 ms; mk13.b4, Sm = 23,958, S 4.4 % dense:
-// 53 ms against 26 ms.  So: SPASM_HIP_BACKSOLVE=0 never, =1 whenever the factor has a plan; otherwise, when no other path
-// was forced (tests force tiers / the row-group kernel through their own knobs) and R fits comfortably in the free HBM:
-// yes when R is already there, when its rows are short (Sm <= 8192: at worst a small loss), or when the caller expects
-// a dense result (density hint >= 0.25: spasm_hip_schur's est_density, spasm_hip_dfact_hint_density, the dense finish).
-bool backsolve_wanted(const spasm_hip_dfact *F, bool other_path_forced)
+// Should this batch of `nrows` rows go through the back-substituted image?  A cost model fitted on thirteen generated
+// factors (tools/sweep_cost.py, table in DESIGN.md section 3; 650 <= Sm <= 23,958, densities 0.4 % - 72 %), seconds:
+//   build of R (only if it is not there yet)   max(15 us per chunk of 768 rows, (r + D) Sm e / 2.1 TB/s)      D = pivotal entries of U'
+//   apply + expansion                          (P Sm e + 2 nrows ldR e + 8 nnz(S)) / 4.5 TB/s + 0.4 ms        P = pivotal entries of the rows
+//   row by row                                 0.3 ms + 27 ps per (row, pivot) elimination
+// The number of eliminations is what the row-by-row kernels measure on the density sample of the driver
+// (spasm_hip_schur on 100 rows: bs.elim_hint); without a sample, 5 % of the pivots per row (the family: 1.6 % - 22 %).
+// On full batches the image won on all thirteen (1.05x on mk13.b4 ... 11x on mk13.b5), so the rule of round 2 (Sm <= 8192
+// or density >= 0.25) lost up to 1.7x on the four widest; a one-off batch of a few thousand rows does not pay for the build.
+// SPASM_HIP_BACKSOLVE=0 never, =1 whenever the factor has a plan; tests that force a tier or the row-group kernel
+// switch the image off; batches under 1024 rows (density samples, completion tests) never trigger a build.
+bool backsolve_wanted(const spasm_hip_dfact *F, bool other_path_forced, int nrows)
 {
 	const char *e = std::getenv("SPASM_HIP_BACKSOLVE");
 	const int mode = (e == nullptr || *e == 0) ? -1 : std::atoi(e);
@@ -369,7 +373,20 @@ bool backsolve_wanted(const spasm_hip_dfact *F, bool other_path_forced)
 		return true;
 	if (other_path_forced)
 		return false;
-	return F->bs.valid || F->bs.Sm <= 8192 || F->bs.density_hint >= 0.25;
+	if (F->bs.valid)
+		return true;                      // R is there: a few of its rows per reduced row always beat an elimination
+	if (nrows < 1024)
+		return false;
+	const BsImage &B = F->bs;
+	const double eb = (F->prime < 65536) ? 2.0 : 4.0;
+	const double r = (double) B.r, Sm = (double) B.Sm, n = (double) nrows;
+	const double t_build = std::max(15e-6 * std::ceil(r / 768.0), (r + (double) B.ndeps) * Sm * eb / 2.1e12);
+	const double density = (B.density_hint >= 0.0) ? std::min(1.0, B.density_hint) : 0.05;
+	const double pivotal_per_row = 3.0;          // (entries of a row of A on pivotal columns: 2.9 - 5.1 in the family)
+	const double t_apply = (pivotal_per_row * n * Sm * eb + 2.0 * n * (double) B.ldR * eb + 8.0 * density * n * Sm) / 4.5e12 + 0.4e-3;
+	const double elim_per_row = (B.elim_hint >= 0.0) ? B.elim_hint : 0.05 * r;
+	const double t_rows = 0.3e-3 + 27e-12 * elim_per_row * n;
+	return t_build + t_apply <= t_rows;
 }
 }  // namespace sh
 
@@ -739,6 +756,12 @@ void spasm_hip_dfact_hint_density(spasm_hip_dfact *F, double density)
 		F->bs.density_hint = density;
 }
 
+void spasm_hip_dfact_hint_eliminations(spasm_hip_dfact *F, double per_row)
+{
+	if (F != nullptr)
+		F->bs.elim_hint = per_row;
+}
+
 void spasm_hip_dfact_forget(spasm_hip_dfact *F)
 {
 	if (F != nullptr)
@@ -849,7 +872,7 @@ int dschur_impl(const spasm_hip_dcsr *A, const int *d_rows, int nrows, const spa
 	i64 group_slot_bytes = 0, group_off_bm = 0;
 	// S = A_n - A_p R from the back-substituted image (backsolve.hip) when the factor has one: no accumulator scratch
 	const bool want_bs = nrows > 0 && Lout == nullptr &&
-	                     backsolve_wanted(F, env_int("SPASM_HIP_FORCE_TIER", 0) != 0 || env_int("SPASM_HIP_GROUP", -1) >= 0);
+	                     backsolve_wanted(F, env_int("SPASM_HIP_FORCE_TIER", 0) != 0 || env_int("SPASM_HIP_GROUP", -1) >= 0, nrows);
 	// per-wave dense scratch, (re)allocated when the factor geometry needs more
 	if (!want_bs) {
 		i64 slot_bytes, off_bm, off_xn;
@@ -1321,8 +1344,12 @@ struct spasm_csr *spasm_hip_schur(const struct spasm_csr *A, const int *p, int n
 		W->scratch_budget = (i64) 24 << 30;
 		scratch_adopt(W);
 		const int rc = dschur_impl(&dA, drows, n, F, W, stream, &st, (L != nullptr) ? &lout : nullptr);
-		if (rc == 0)
+		if (rc == 0) {
+			// what the row-by-row kernels measured feeds the path choice of the next, larger batch on the same factor
+			if (!st.used_backsolve && n >= 64 && st.eliminations > 0)
+				F->bs.elim_hint = (double) st.eliminations / (double) n;
 			break;
+		}
 		scratch_park(W);
 		spasm_hip_dwork_destroy(W);
 		if (L != nullptr) {

@@ -67,6 +67,10 @@ class DeviceFact:
         """expected density of the Schur complements of this factor (dense ones go through the back-substituted image)"""
         lib().spasm_hip_dfact_hint_density(self._h, float(density))
 
+    def hint_eliminations(self, per_row):
+        """(row, pivot) eliminations a reduced row takes on the row-by-row path (the other input of the path choice)"""
+        lib().spasm_hip_dfact_hint_eliminations(self._h, float(per_row))
+
     def forget(self):
         """drops derived state (the back-substituted rows): the next dschur pays for it again."""
         lib().spasm_hip_dfact_forget(self._h)

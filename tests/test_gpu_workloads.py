@@ -125,20 +125,30 @@ def test_round0_schur_of_baseline_workload(oracle, name, path):
     dF.close()
 
 
-def test_default_path_follows_the_density(oracle):
-    """no path forced: mk13.b5 (short rows of R) takes the back-substituted image, mk13.b4 (23,958 non-pivotal columns, sparse
-    result) the row-group kernel, and takes the image once the caller says the result will be dense."""
+def test_default_path_follows_the_cost_model(oracle):
+    """no path forced (fitted on tools/sweep_cost.py): a FULL batch of mk13.b5 (Sm = 4,952) and of mk13.b4
+    (Sm = 23,958: round 2's rule sent it row by row and lost) builds the back-substituted image; a one-off batch of 4,096
+    rows does not pay for the build and goes row by row -- unless R is already there; a factor whose rows take few
+    eliminations (hint: 50 per row instead of the ~5,000 measured) stays row by row even on the full batch."""
     import torch
-    for name, hint, want_bs in (("mk13.b5", None, 1), ("mk13.b4", None, 0), ("mk13.b4", 0.9, 1)):
+    for name in ("mk13.b5", "mk13.b4"):
         A, rows, F, _ = workloads.round0(name, PRIME)
         dA = spasm_amd.DeviceCsr.from_host(A)
+        drows = torch.from_numpy(np.ascontiguousarray(rows, np.int32)).cuda()
+        sub = drows[:4096].contiguous()
         dF = spasm_amd.DeviceFact(F)
-        if hint is not None:
-            dF.hint_density(hint)
-        sub = np.ascontiguousarray(rows[:4096], np.int32)
-        W = spasm_amd.SchurWorkspace(len(sub), A.m, 1 << 27)
-        S, st = spasm_amd.dschur(dA, torch.from_numpy(sub).cuda(), dF, W, fetch=False)
-        assert st.status == 0 and st.used_backsolve == want_bs, (name, hint, st.used_backsolve)
+        W = spasm_amd.SchurWorkspace(len(rows), A.m, 1 << 30)
+        S, st = spasm_amd.dschur(dA, sub, dF, W, fetch=False)
+        assert st.status == 0 and st.used_backsolve == 0, (name, "one-off sub-batch")
+        S, st = spasm_amd.dschur(dA, drows, dF, W, fetch=False)
+        assert st.status == 0 and st.used_backsolve == 1, (name, "full batch")
+        full_nnz = st.nnz
+        S, st = spasm_amd.dschur(dA, sub, dF, W, fetch=False)
+        assert st.status == 0 and st.used_backsolve == 1, (name, "sub-batch once R is there")
+        dF.forget()
+        dF.hint_eliminations(50.0)
+        S, st = spasm_amd.dschur(dA, drows, dF, W, fetch=False)
+        assert st.status == 0 and st.used_backsolve == 0 and st.nnz == full_nnz, (name, "few eliminations per row")
         W.close()
         dF.close()
 
