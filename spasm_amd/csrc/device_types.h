@@ -223,6 +223,7 @@ struct spasm_hip_dfact {
 	uint64_t *d_cp = nullptr;      // U' by TARGET label (schur_pull.hip): rpad + Sm + 1 offsets into d_cent
 	uint2 *d_cent = nullptr;       // (source label, value * 2^32 mod p)
 	int2 *d_lvl = nullptr;         // [first label, last label + 1) of every level
+	bool has_pull = false;         // d_cp / d_cent / d_lvl were filled (SPASM_HIP_PULL=1 when the image was created)
 	std::vector<int> h_q;          // host copy of q
 	std::vector<int> h_kof;
 	mutable sh::BsImage bs;        // back-substituted image, built on first use when the factor is eligible

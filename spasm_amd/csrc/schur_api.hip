@@ -335,7 +335,8 @@ spasm_hip_dfact *cached_dfact(const struct spasm_csr *U, const int *qinv, hipStr
 	h = hash_words(h, U->j, (size_t) key.nnz * sizeof(int));
 	h = hash_words(h, U->x, (size_t) key.nnz * sizeof(spasm_ZZp));
 	key.sum = h;
-	if (g_fact != nullptr && key == g_fact_key)
+	// (an image built without the tables of the pull experiment does not serve a call that asks for that kernel)
+	if (g_fact != nullptr && key == g_fact_key && (g_fact->has_pull || env_int("SPASM_HIP_PULL", 0) == 0))
 		return g_fact;
 	if (g_fact != nullptr)
 		spasm_hip_dfact_destroy(g_fact);
@@ -696,6 +697,7 @@ spasm_hip_dfact *spasm_hip_dfact_create(const struct spasm_csr *U, const int *qi
 	// experiment, SPASM_HIP_PULL=1: the tables are only built for it -- a counting sort of U' on the host, 15 % of the
 	// image's build time on mk13.b5)
 	const bool want_pull = env_int("SPASM_HIP_PULL", 0) != 0;
+	F->has_pull = want_pull;
 	std::vector<uint64_t> cp(want_pull ? (size_t) rpad + (size_t) (m - r) + 1 : 1, 0);
 	std::vector<uint2> cent((size_t) (want_pull && F->nnz > 0 ? F->nnz : 1));
 	std::vector<int2> lvl((size_t) (want_pull && P.nlevels > 0 ? P.nlevels : 1));
@@ -1071,7 +1073,7 @@ int dschur_impl(const spasm_hip_dcsr *A, const int *d_rows, int nrows, const spa
 				regroup();
 				a.order = W->d_order;
 			}
-			use_pull = Lout == nullptr && env_int("SPASM_HIP_PULL", 0) != 0 && pull_lds_bytes(F->rpad, F->Sm) <= (size_t) 150 * 1024;
+			use_pull = Lout == nullptr && env_int("SPASM_HIP_PULL", 0) != 0 && F->has_pull && pull_lds_bytes(F->rpad, F->Sm) <= (size_t) 150 * 1024;
 			if (use_pull) {
 				// left-looking numeric pass, no atomics (schur_pull.hip); its slices are the row-group kernel's without the bitmap
 				const int per_cu = (int) std::max<size_t>(1, std::min<size_t>(8, (size_t) (160 * 1024) / (pull_lds_bytes(F->rpad, F->Sm) + 5 * 1024)));
