@@ -94,7 +94,10 @@ def quoted_traffic(kernel, workload, rows):
             t = json.load(open(path))
         except ValueError:
             continue
-        if t.get("workload") != workload or t.get("rows") != rows:
+        if t.get("workload") != workload or not t.get("rows"):
+            continue
+        # (the stand-in's pivots come from the threaded search: the batch differs by a few rows in 670,000 from run to run)
+        if t.get("rows") != rows and not (workload.startswith("mk14") and abs(t["rows"] - rows) <= 0.002 * rows):
             continue
         k = t.get("kernels", {}).get(kernel)
         if not k:
@@ -139,13 +142,16 @@ def dense_tail_probe(torch, spasm_amd, dev, n=4096, m=32768):
            "update_kernels_ms_serialised": ms_upd.value, "update_kernels_Tmacs_per_s": tmacs_upd,
            # 4 int8 digit products per useful multiply-add (two base-256 digits each side), 2 ops per product
            "mfma_i8_frac_of_peak": (8 * tmacs_upd / MFMA_I8_PEAK_TOPS) if tmacs_upd else None}
-    path = os.path.join(ROOT, "profiles", "r02_dense_tail.json")
-    if os.path.exists(path):
+    for rel in ("profiles/r03_dense_tail.json", "profiles/r02_dense_tail.json"):
+        path = os.path.join(ROOT, rel)
+        if not os.path.exists(path):
+            continue
         try:
             q = json.load(open(path))
             if q.get("shape") == [n, m]:
                 out["mfma_busy_pct"] = q.get("mfma_busy_pct")
-                out["mfma_busy_source"] = "profiles/r02_dense_tail.json"
+                out["mfma_busy_source"] = rel
+                break
         except ValueError:
             pass
     return out

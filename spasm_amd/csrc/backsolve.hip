@@ -1933,8 +1933,9 @@ void backsolve_build(const spasm_hip_dfact *F, hipStream_t stream)
 	if (shape == 3)
 		snprintf(B.kernel_build, sizeof(B.kernel_build), "backsolve_kernel<true,true,8,8,true,768,64,31,2>");
 	else
-		snprintf(B.kernel_build, sizeof(B.kernel_build), "backsolve_kernel<%s,%s,%d,%d,%s>", packed ? "true" : "false", B.plain ? "true" : "false",
-		         shape == 2 ? 16 : 32, (shape == 0 || (!packed && B.plain && shape == 1)) ? 16 : 8, B.sgn ? "true" : "false");
+		snprintf(B.kernel_build, sizeof(B.kernel_build), "backsolve_kernel<%s,%s,%d,%d,%s,%d,%d,%d,1>", packed ? "true" : "false", B.plain ? "true" : "false",
+		         shape == 2 ? 16 : 32, (shape == 0 || (!packed && B.plain && shape == 1)) ? 16 : 8, B.sgn ? "true" : "false", BS_RING, BS_PASSROWS,
+		         BS_PASSCAP);          // (as rocprofv3 prints it: bench.py looks the counters of the profile passes up by this name)
 	if (B.sgn) {
 		if (shape == 3)
 			launch_backsolve_variant<true, true, 8, 8, true, 768, 64, 31, 2>(b, B.Sm, stream, B);

@@ -22,7 +22,7 @@ import spasm_amd
 import workloads
 
 for name in args.workloads:
-    A, rows, F, source = workloads.round0(name, 42013)
+    A, rows, F, source = workloads.round0(name, 42013, threads=0 if name.startswith("mk14") else 1)
     if args.rows:
         rows = rows[:args.rows]
     print("%s: %d x %d, %d nnz; %d pivots, %d rows to reduce, %d non-pivotal columns" % (name, A.n, A.m, A.nnz, F.U.n, len(rows), A.m - F.U.n), flush=True)
