@@ -304,6 +304,14 @@ int spasm_hip_dschur_dense(const spasm_hip_dcsr *A, const int *d_rows, int nrows
  * holds the pivot column of each echelon row.  Returns the rank. */
 int spasm_hip_drref(i64 prime, int n, int m, u32 *d_A, i64 ld, int *d_pivcol, void *stream);
 
+/* Extends k reduced echelon rows (rows [0, k) of d_M, identity on their pivot columns d_piv[0..k)) by the Sn rows below
+ * them: these are reduced by the echelon rows and by each other, the non-zero ones join the echelon rows (which stay
+ * reduced).  Pivots are taken where the rows have their leftmost entries, 64 rows at a time -- an echelon basis of the row
+ * space, not the column rank profile spasm_hip_drref returns: made for wide stacks of low rank (the dense / low-rank finish
+ * on tens of thousands of columns).  Values in [0, p), p <= 65279.  Returns the new number of echelon rows k'; d_piv[0..k')
+ * are their pivot columns.  Rows beyond k' are left undefined. */
+int spasm_hip_dechelon_extend(i64 prime, int m, u32 *d_M, i64 ld, int k, int Sn, int *d_piv, void *stream);
+
 /* ======================================================================
  * (M) multi-GPU: one process per GPU, RCCL over xGMI (spasm_amd/csrc/dist_api.hip)
  *

@@ -71,6 +71,7 @@ def lib():
         "spasm_hip_ffpack_LU": (ci, [i64, ci, ci, vp, ci, ci, C.POINTER(C.c_size_t), C.POINTER(C.c_size_t)]),
         "spasm_hip_dschur_dense": (ci, [C.POINTER(CDcsr), vp, ci, vp, vp, vp, i64, vp]),
         "spasm_hip_drref": (ci, [i64, ci, ci, vp, i64, vp, vp]),
+        "spasm_hip_dechelon_extend": (ci, [i64, ci, vp, i64, ci, ci, vp, vp]),
         "spasm_hip_drref_timed": (ci, [i64, ci, ci, vp, i64, vp, vp, ci, C.POINTER(C.c_float)]),
         "spasm_hip_comm_id_bytes": (ci, []),
         "spasm_hip_comm_new_id": (None, [vp]),

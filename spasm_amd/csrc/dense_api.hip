@@ -12,6 +12,7 @@ namespace sh {
 int device_rref(int64_t prime, int n, int m, uint32_t *dA, int64_t ld, int *d_pivcol, hipStream_t stream, int use_mfma,
                 float *ms_update);
 int device_lu(int64_t prime, int n, int m, uint32_t *dA, int64_t ld, int *dP, int *dQ, hipStream_t stream);
+int device_echelon_extend(int64_t prime, int m, uint32_t *dM, int64_t ld, int k, int Sn, int *d_piv, hipStream_t stream);
 spasm_hip_dfact *cached_dfact(const struct spasm_csr *U, const int *qinv, hipStream_t stream);
 void launch_combine(const int64_t *Ap, const int *Aj, const int *Ax, const int *rows, int nrows, int N, int w, int m,
                     uint64_t salt, unsigned long long *Y, const Mont &M, hipStream_t stream);
@@ -60,6 +61,16 @@ int spasm_hip_drref(i64 prime, int n, int m, u32 *d_A, i64 ld, int *d_pivcol, vo
 	if (spasm_hip_device_count() == 0)
 		die("spasm_hip_drref: no HIP device (this library has no CPU path)");
 	return device_rref(prime, n, m, d_A, ld, d_pivcol, (hipStream_t) stream, env_int("SPASM_HIP_RREF_MFMA", 1), nullptr);
+}
+
+// Rows [0, k) of d_M are reduced echelon rows with pivot columns d_piv[0..k) (identity on them); the Sn rows below are
+// reduced by them and by each other (row panels, any pivots: dense_kernels.hip) and the non-zero ones appended: on return
+// rows [0, k') are reduced echelon rows, d_piv[0..k') their pivot columns.  Returns k'.  p <= 65279.
+int spasm_hip_dechelon_extend(i64 prime, int m, u32 *d_M, i64 ld, int k, int Sn, int *d_piv, void *stream)
+{
+	if (spasm_hip_device_count() == 0)
+		die("spasm_hip_dechelon_extend: no HIP device (this library has no CPU path)");
+	return device_echelon_extend(prime, m, d_M, ld, k, Sn, d_piv, (hipStream_t) stream);
 }
 
 // timing variant used by bench/profiles: ms of the trailing-update kernels only

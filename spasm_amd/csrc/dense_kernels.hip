@@ -2233,6 +2233,343 @@ int device_rref(int64_t prime, int n, int m, uint32_t *dA, int64_t ld, int *d_pi
 }  // namespace sh
 
 // --------------------------------------------------------------------------
+// Echelon rows by ROW panels: extends k reduced echelon rows E (rows [0, k) of M, pivot columns piv[0..k), identity on
+// them) by the Sn rows below them.  This is what the dense / low-rank finish needs on a WIDE remainder (ch8-8.b5: stacks of
+// 8,000 rows x 104,000 columns of rank ~4,000): device_rref above walks the 1,635 column panels of such a stack, finds two
+// or three pivots in each and pays a pass over the trailing matrix per super-panel of 512 COLUMNS (0.35 - 0.5 s per
+// stack, 2.5 pivots per panel).  Here a panel is 64 ROWS; its pivots are taken wherever its rows have their leftmost
+// entries (any pivot will do for an echelon basis -- the column rank profile is not asked for), so a panel yields up to 64
+// pivots and the matrix is passed over once per 64 PIVOTS:
+//   A. Y -= Y[:, piv(E)] E                                     (matrix cores, K = k)
+//   B. for every panel of 64 rows of Y, until none of its rows is left without a pivot or non-zero:
+//        leftmost non-zero column of the rows still waiting -> a window of 256 columns starting at the smallest one;
+//        Gauss-Jordan of the 64 x 256 window in LDS (one workgroup) -> T (64 x 64) and the new pivot columns J;
+//        every row of the matrix, in ONE launch on the matrix cores:  C_i += sum_u M'[i][u] P_u  with the OLD panel rows P_u,
+//          M' = T - I on the panel's own rows, M'[i] = -C_i[J] T_J elsewhere (E and the earlier panels included: they stay reduced)
+//   C. the rows that hold a pivot move up behind E, in panel order.
+// p <= 65279 (two signed base-256 digits per operand, as rref_update_mfma_multi).  Returns the new number of echelon rows.
+// --------------------------------------------------------------------------
+namespace sh {
+
+namespace {
+constexpr int RP_ROWS = 64;
+constexpr int RP_WIN = 256;
+
+// leftmost non-zero column of every waiting row of the panel: one wave per (row, chunk of 1024 columns)
+__global__ __launch_bounds__(64) void rowpanel_leftmost(const uint32_t *P, int64_t ld, int m, const int *state, int *left)
+{
+	const int row = blockIdx.y, lane = threadIdx.x;
+	if (state[row] != -1)
+		return;                              // has a pivot (>= 0) or is known to be zero (-2)
+	const int c0 = blockIdx.x * 1024;
+	if (c0 >= atomicMin(&left[row], 0x7FFFFFFF))
+		return;                              // (a chunk further left already holds a non-zero entry)
+	int best = 0x7FFFFFFF;
+	for (int q = 0; q < 16; q++) {
+		const int c = c0 + q * 64 + lane;
+		const uint32_t v = (c < m) ? P[(int64_t) row * ld + c] : 0u;
+		const uint64_t mask = __ballot(v != 0);
+		if (mask != 0) {
+			best = c0 + q * 64 + __builtin_ctzll(mask);
+			break;
+		}
+	}
+	if (lane == 0 && best != 0x7FFFFFFF)
+		atomicMin(&left[row], best);
+}
+
+// Gauss-Jordan of the window P[:, w0 : w0 + RP_WIN) over the waiting rows, in row order, with the row transformation
+// accumulated in T (64 x 64, starts as the identity).  state[t] becomes the pivot column of row t when it finds one here.
+// newpiv[t] = that column for the rows that found a pivot in THIS call, -1 for the others.
+__global__ __launch_bounds__(256) void rowpanel_window(const uint32_t *P, int64_t ld, int m, int rows, int w0, int *state, int *newpiv, uint32_t *T_out, MontDev F)
+{
+	extern __shared__ uint32_t rp_lds[];
+	uint32_t(*W)[RP_WIN + 1] = reinterpret_cast<uint32_t(*)[RP_WIN + 1]>(rp_lds);
+	uint32_t(*T)[RP_ROWS + 1] = reinterpret_cast<uint32_t(*)[RP_ROWS + 1]>(rp_lds + RP_ROWS * (RP_WIN + 1));
+	__shared__ int s_col[4];
+	__shared__ int s_state[RP_ROWS];
+	const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+	for (int t = 0; t < RP_ROWS; t++) {
+		const int c = w0 + tid;
+		W[t][tid] = (c < m && t < rows) ? P[(int64_t) t * ld + c] : 0u;          // (the last panel may be short: its missing rows are zero, state -2)
+	}
+	for (int e = tid; e < RP_ROWS * RP_ROWS; e += 256)
+		T[e / RP_ROWS][e % RP_ROWS] = (e / RP_ROWS == e % RP_ROWS) ? 1u : 0u;
+	if (tid < RP_ROWS) {
+		s_state[tid] = state[tid];
+		newpiv[tid] = -1;
+	}
+	__syncthreads();
+	for (int t = 0; t < RP_ROWS; t++) {
+		if (s_state[t] != -1)
+			continue;                        // (uniform: shared)
+		// first non-zero entry of row t inside the window
+		const uint64_t mask = __ballot(W[t][tid] != 0);
+		if (lane == 0)
+			s_col[wave] = (mask != 0) ? wave * 64 + __builtin_ctzll(mask) : 0x7FFFFFFF;
+		__syncthreads();
+		const int c = min(min(s_col[0], s_col[1]), min(s_col[2], s_col[3]));
+		__syncthreads();
+		if (c == 0x7FFFFFFF)
+			continue;                        // nothing here: the row waits for a window further right
+		const uint32_t inv = invmod(W[t][c], F);
+		// the factors of the other rows, before anything moves
+		__shared__ uint32_t fac[RP_ROWS];
+		if (tid < RP_ROWS)
+			fac[tid] = (tid == t) ? 0u : W[tid][c];
+		__syncthreads();
+		// scale row t ( window | T )
+		const uint32_t wt = mulmod(W[t][tid], inv, F);
+		W[t][tid] = wt;
+		uint32_t tt = 0;
+		if (tid < RP_ROWS) {
+			tt = mulmod(T[t][tid], inv, F);
+			T[t][tid] = tt;
+		}
+		__syncthreads();
+		for (int s2 = 0; s2 < RP_ROWS; s2++) {
+			const uint32_t f = fac[s2];
+			if (f == 0)
+				continue;                    // (uniform)
+			W[s2][tid] = submod(W[s2][tid], mulmod(f, wt, F), F);
+			if (tid < RP_ROWS)
+				T[s2][tid] = submod(T[s2][tid], mulmod(f, tt, F), F);
+		}
+		if (tid == 0) {
+			s_state[t] = w0 + c;
+			newpiv[t] = w0 + c;
+		}
+		__syncthreads();
+	}
+	if (tid < RP_ROWS)
+		state[tid] = s_state[tid];
+	for (int e = tid; e < RP_ROWS * RP_ROWS; e += 256)
+		T_out[e] = T[e / RP_ROWS][e % RP_ROWS];
+}
+
+// digit planes of the multipliers of one panel step, for every row i of the matrix (n rows):
+//   rows of the panel (i in [r0, r0 + 64)):  M'[i] = T[i - r0] - e_{i - r0}
+//   other rows:                              M'[i][u] = - sum_{t new} C[i][J_t] T[t][u]
+__global__ __launch_bounds__(256) void rowpanel_multipliers(const uint32_t *C, int64_t ld, int n, int r0, const int *newpiv, const uint32_t *T,
+                                                            signed char *Mh, signed char *Ml, MontDev F)
+{
+	__shared__ uint32_t sT[RP_ROWS][RP_ROWS + 1];
+	__shared__ int sJ[RP_ROWS];
+	const int tid = threadIdx.x;
+	for (int e = tid; e < RP_ROWS * RP_ROWS; e += 256)
+		sT[e / RP_ROWS][e % RP_ROWS] = T[e];
+	if (tid < RP_ROWS)
+		sJ[tid] = newpiv[tid];
+	__syncthreads();
+	const int i = blockIdx.x * 64 + (tid & 63), q = tid >> 6;          // row, quarter of the 64 multipliers
+	if (i >= n)
+		return;
+	uint32_t out[16];
+	if (i >= r0 && i < r0 + RP_ROWS) {
+		for (int u = 0; u < 16; u++) {
+			const uint32_t v = sT[i - r0][q * 16 + u];
+			out[u] = (i - r0 == q * 16 + u) ? submod(v, 1u, F) : v;
+		}
+	} else {
+		unsigned long long acc[16];
+		for (int u = 0; u < 16; u++)
+			acc[u] = 0;
+		for (int t = 0; t < RP_ROWS; t++) {
+			const int j = sJ[t];
+			if (j < 0)
+				continue;                    // (uniform)
+			const uint32_t c = C[(int64_t) i * ld + j];
+			if (c == 0)
+				continue;
+			const uint32_t neg = F.p - c;
+			for (int u = 0; u < 16; u++)
+				acc[u] += (unsigned long long) neg * sT[t][q * 16 + u];          // < 64 * 2^32: fits
+		}
+		for (int u = 0; u < 16; u++)
+			out[u] = (uint32_t) (acc[u] % F.p);
+	}
+	unsigned int wh[4] = {0, 0, 0, 0}, wl[4] = {0, 0, 0, 0};
+	for (int u = 0; u < 16; u++) {
+		int hi, lo;
+		split_digits(out[u], F, hi, lo);
+		wh[u >> 2] |= (unsigned int) (hi & 255) << (8 * (u & 3));
+		wl[u >> 2] |= (unsigned int) (lo & 255) << (8 * (u & 3));
+	}
+	*reinterpret_cast<int4 *>(Mh + (int64_t) i * 64 + q * 16) = make_int4((int) wh[0], (int) wh[1], (int) wh[2], (int) wh[3]);
+	*reinterpret_cast<int4 *>(Ml + (int64_t) i * 64 + q * 16) = make_int4((int) wl[0], (int) wl[1], (int) wl[2], (int) wl[3]);
+}
+
+// Z[i][t] = - Y[i][piv[t0 + t]]  for the rows of Y and a run of echelon pivots (step A), 0 beyond the run
+__global__ __launch_bounds__(256) void rowpanel_gather_neg(const uint32_t *Y, int64_t ld, int n, const int *piv, int t0, int count, uint32_t *Z, int64_t ldz, MontDev F)
+{
+	const int i = blockIdx.x * 4 + (threadIdx.x >> 6), t = blockIdx.y * 64 + (threadIdx.x & 63);
+	if (i >= n || t >= (int) ldz)
+		return;
+	uint32_t v = 0;
+	if (t < count) {
+		const uint32_t y = Y[(int64_t) i * ld + piv[t0 + t]];
+		v = (y == 0) ? 0u : F.p - y;
+	}
+	Z[(int64_t) i * ldz + t] = v;
+}
+
+__global__ __launch_bounds__(256) void rowpanel_copy_rows(uint32_t *dst, int64_t ldd, const uint32_t *src, int64_t lds, int m, const int *src_row, int count)
+{
+	for (int t = blockIdx.x; t < count; t += gridDim.x)
+		copy_row(dst + (int64_t) t * ldd, src + (int64_t) src_row[t] * lds, m, false);
+}
+}  // namespace
+
+int device_echelon_extend(int64_t prime, int m, uint32_t *dM, int64_t ld, int k, int Sn, int *d_piv, hipStream_t stream)
+{
+	if (Sn <= 0 || m <= 0)
+		return k;
+	if (prime > 65279)
+		die("device_echelon_extend: p = %lld (the row-panel echelon form runs on the matrix cores: p <= 65279)", (long long) prime);
+	const MontDev F = to_dev(mont_setup(prime));
+	const int n = k + Sn;
+	uint32_t *Y = dM + (int64_t) k * ld;
+	std::vector<void *> owned;
+	auto dal = [&](size_t bytes) {
+		void *ptr = nullptr;
+		HIP_CHECK(hipMalloc(&ptr, bytes > 0 ? bytes : 1));
+		owned.push_back(ptr);
+		return ptr;
+	};
+	const int SETS = MAXSETS;
+	signed char *Mplanes = (signed char *) dal((size_t) SETS * 2 * n * 64);               // per set: Mh [n][64] | Ml [n][64]
+	signed char *Bplanes = (signed char *) dal((size_t) SETS * 2 * (size_t) m * 64);       // per set: Bh [m][64] | Bl [m][64]
+	uint32_t *Z = (uint32_t *) dal((size_t) Sn * 64 * SETS * sizeof(uint32_t));
+	int *d_cnt = (int *) dal(SETS * sizeof(int));
+	int *d_state = (int *) dal(RP_ROWS * sizeof(int));
+	int *d_left = (int *) dal(RP_ROWS * sizeof(int));
+	int *d_newpiv = (int *) dal(RP_ROWS * sizeof(int));
+	uint32_t *d_T = (uint32_t *) dal(RP_ROWS * RP_ROWS * sizeof(uint32_t));
+	const size_t win_lds = ((size_t) RP_ROWS * (RP_WIN + 1) + (size_t) RP_ROWS * (RP_ROWS + 1)) * sizeof(uint32_t);
+	static bool configured = false;
+	if (!configured) {
+		HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(&rowpanel_window), hipFuncAttributeMaxDynamicSharedMemorySize, (int) win_lds));
+		configured = true;
+	}
+	auto planes_of_set = [&](int s, signed char *&Mh, signed char *&Ml, signed char *&Bh, signed char *&Bl) {
+		Mh = Mplanes + (size_t) s * 2 * n * 64;
+		Ml = Mh + (size_t) n * 64;
+		Bh = Bplanes + (size_t) s * 2 * (size_t) m * 64;
+		Bl = Bh + (size_t) m * 64;
+	};
+
+	// ---- A. the rows of Y lose the pivot columns of E ----
+	for (int t0 = 0; t0 < k; t0 += 64 * SETS) {
+		const int count = std::min(k - t0, 64 * SETS);
+		const int nsets = (count + 63) / 64;
+		const int64_t ldz = (int64_t) 64 * nsets;
+		hipLaunchKernelGGL(rowpanel_gather_neg, dim3((Sn + 3) / 4, nsets), dim3(256), 0, stream, Y, ld, Sn, d_piv, t0, count, Z, ldz, F);
+		UpdSets S{};
+		std::vector<int> cnt((size_t) SETS, 0);
+		for (int s = 0; s < nsets; s++)
+			cnt[s] = std::min(64, count - 64 * s);
+		HIP_CHECK(hipMemcpyAsync(d_cnt, cnt.data(), SETS * sizeof(int), hipMemcpyHostToDevice, stream));
+		// (the planes of M for n = Sn rows: the first Sn * 64 bytes of each half)
+		hipLaunchKernelGGL(rref_split_Z, dim3((Sn + 63) / 64, nsets), dim3(256), 0, stream, Z, ldz, Sn, nsets, Mplanes, (int64_t) 2 * Sn * 64, F);
+		for (int s = 0; s < nsets; s++) {
+			signed char *Bh = Bplanes + (size_t) s * 2 * (size_t) m * 64, *Bl = Bh + (size_t) m * 64;
+			hipLaunchKernelGGL(rref_split_B, dim3((m + 255) / 256), dim3(256), 0, stream, dM + (int64_t) (t0 + 64 * s) * ld, (int) ld, d_cnt + s, Bh, Bl, F);
+			S.Mh[s] = Mplanes + (size_t) s * 2 * Sn * 64;
+			S.Ml[s] = S.Mh[s] + (size_t) Sn * 64;
+			S.Bh[s] = Bh;
+			S.Bl[s] = Bl;
+		}
+		S.nsets = nsets;
+		hipLaunchKernelGGL(rref_update_mfma_multi, dim3((m + 63) / 64, (Sn + 63) / 64), dim3(256), 0, stream, Y, ld, Sn, 0, m, S, F);
+		HIP_CHECK(hipStreamSynchronize(stream));          // (cnt dies here)
+	}
+
+	// ---- B. panels of 64 rows of Y ----
+	std::vector<int> pivot_of((size_t) Sn, -1);          // pivot column of every row of Y, -1: none (the row became zero)
+	const int panel_rows[2] = {64, Sn % RP_ROWS};          // d_cnt[0]: a full panel, d_cnt[1]: the last, short one
+	HIP_CHECK(hipMemcpyAsync(d_cnt, panel_rows, sizeof(panel_rows), hipMemcpyHostToDevice, stream));
+	HIP_CHECK(hipStreamSynchronize(stream));
+	for (int r0 = 0; r0 < Sn; r0 += RP_ROWS) {
+		const int rows_here = std::min(RP_ROWS, Sn - r0);
+		uint32_t *P = Y + (int64_t) r0 * ld;
+		int state[RP_ROWS];
+		for (int t = 0; t < RP_ROWS; t++)
+			state[t] = (t < rows_here) ? -1 : -2;
+		HIP_CHECK(hipMemcpyAsync(d_state, state, sizeof(state), hipMemcpyHostToDevice, stream));
+		for (int iter = 0;; iter++) {
+			HIP_CHECK(hipMemsetAsync(d_left, 0x7F, RP_ROWS * sizeof(int), stream));          // 0x7F7F7F7F: larger than any column
+			hipLaunchKernelGGL(rowpanel_leftmost, dim3((m + 1023) / 1024, rows_here), dim3(64), 0, stream, P, ld, m, d_state, d_left);
+			int left[RP_ROWS];
+			HIP_CHECK(hipMemcpyAsync(left, d_left, sizeof(left), hipMemcpyDeviceToHost, stream));
+			HIP_CHECK(hipStreamSynchronize(stream));
+			int w0 = 0x7FFFFFFF;
+			bool changed = false;
+			for (int t = 0; t < rows_here; t++) {
+				if (state[t] != -1)
+					continue;
+				if (left[t] >= m) {
+					state[t] = -2;           // the row is zero: it depended on the rows before it
+					changed = true;
+				} else {
+					w0 = std::min(w0, left[t]);
+				}
+			}
+			if (w0 == 0x7FFFFFFF)
+				break;                       // every row of the panel has a pivot or is zero
+			if (changed)
+				HIP_CHECK(hipMemcpyAsync(d_state, state, sizeof(state), hipMemcpyHostToDevice, stream));
+			if (iter > RP_ROWS + 2)
+				die("device_echelon_extend: a panel did not finish in %d window steps", iter);
+			// the OLD rows of the panel as digit planes, then T and the new pivots, then one update of every row
+			signed char *Mh, *Ml, *Bh, *Bl;
+			planes_of_set(0, Mh, Ml, Bh, Bl);
+			hipLaunchKernelGGL(rref_split_B, dim3((m + 255) / 256), dim3(256), 0, stream, P, (int) ld, d_cnt + (rows_here == RP_ROWS ? 0 : 1), Bh, Bl, F);
+			hipLaunchKernelGGL(rowpanel_window, dim3(1), dim3(256), win_lds, stream, P, ld, m, rows_here, w0, d_state, d_newpiv, d_T, F);
+			hipLaunchKernelGGL(rowpanel_multipliers, dim3((n + 63) / 64), dim3(256), 0, stream, dM, ld, n, k + r0, d_newpiv, d_T, Mh, Ml, F);
+			UpdSets S{};
+			S.Mh[0] = Mh;
+			S.Ml[0] = Ml;
+			S.Bh[0] = Bh;
+			S.Bl[0] = Bl;
+			S.nsets = 1;
+			hipLaunchKernelGGL(rref_update_mfma_multi, dim3((m + 63) / 64, (n + 63) / 64), dim3(256), 0, stream, dM, ld, n, 0, m, S, F);
+			HIP_CHECK(hipMemcpyAsync(state, d_state, sizeof(state), hipMemcpyDeviceToHost, stream));
+			HIP_CHECK(hipStreamSynchronize(stream));
+		}
+		for (int t = 0; t < rows_here; t++)
+			pivot_of[(size_t) r0 + t] = (state[t] >= 0) ? state[t] : -1;
+	}
+
+	// ---- C. the rows with a pivot move up behind E ----
+	std::vector<int> src, piv_new;
+	for (int i = 0; i < Sn; i++)
+		if (pivot_of[i] >= 0) {
+			src.push_back(i);
+			piv_new.push_back(pivot_of[i]);
+		}
+	const int rr = (int) src.size();
+	bool in_place = true;
+	for (int t = 0; t < rr; t++)
+		in_place = in_place && src[t] == t;
+	if (rr > 0 && !in_place) {
+		uint32_t *tmp = (uint32_t *) dal((size_t) rr * m * sizeof(uint32_t));
+		int *d_src = (int *) dal((size_t) rr * sizeof(int));
+		HIP_CHECK(hipMemcpyAsync(d_src, src.data(), (size_t) rr * sizeof(int), hipMemcpyHostToDevice, stream));
+		hipLaunchKernelGGL(rowpanel_copy_rows, dim3(std::min(rr, 4096)), dim3(256), 0, stream, tmp, (int64_t) m, Y, ld, m, d_src, rr);
+		HIP_CHECK(hipMemcpy2DAsync(Y, (size_t) ld * sizeof(uint32_t), tmp, (size_t) m * sizeof(uint32_t), (size_t) m * sizeof(uint32_t), (size_t) rr,
+		                           hipMemcpyDeviceToDevice, stream));
+	}
+	if (rr > 0)
+		HIP_CHECK(hipMemcpyAsync(d_piv + k, piv_new.data(), (size_t) rr * sizeof(int), hipMemcpyHostToDevice, stream));
+	HIP_CHECK(hipStreamSynchronize(stream));
+	for (void *ptr : owned)
+		(void) hipFree(ptr);
+	return k + rr;
+}
+
+}  // namespace sh
+
+// --------------------------------------------------------------------------
 // Random linear combinations of sparse rows, formed on the device (the first
 // half of spasm_schur_dense_randomized, spasm_schur.c:380-400): Y[k, :] =
 // sum_t c(k,t) A[rows(k,t), :] into a dense 64-bit accumulator, then packed

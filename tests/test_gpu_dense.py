@@ -334,3 +334,97 @@ def test_LU_random_low_rank(oracle, shape, rank, p):
     M = np.array((Lf.dot(Rf)) % p, dtype=np.int64)
     M[:, 2:5] = 0                            # dead columns in the leading block
     _check_LU(oracle, p, M)
+
+
+# --------------------------------------------------------------------------
+# echelon rows by ROW panels (spasm_hip_dechelon_extend): what the dense / low-rank finish uses on wide remainders
+# --------------------------------------------------------------------------
+def _rref_rows(p, M):
+    """the unique reduced row echelon form of the row space of M (device tensor of int32 rows), non-zero rows only"""
+    import torch
+    A = M.clone().contiguous()
+    n, m = A.shape
+    piv = torch.zeros(max(m, 1), dtype=torch.int32, device=A.device)
+    r = spasm_amd.lib().spasm_hip_drref(p, n, m, A.data_ptr(), m, piv.data_ptr(), 0)
+    torch.cuda.synchronize()
+    return r, A[:r].clone(), piv[:r].clone()
+
+
+def _extend_and_check(p, blocks, m):
+    """feeds the blocks one after the other to spasm_hip_dechelon_extend; after every block: the echelon rows are reduced
+    (identity on their pivot columns, distinct pivots, no zero row) and span exactly the row space of everything fed so far
+    (same unique RREF as the stack of the inputs, computed by spasm_hip_drref)."""
+    import torch
+    dev = torch.device("cuda:0")
+    total = sum(b.shape[0] for b in blocks)
+    M = torch.zeros((total + 64, m), dtype=torch.int32, device=dev)
+    piv = torch.zeros(total + 64, dtype=torch.int32, device=dev)
+    L = spasm_amd.lib()
+    k, fed = 0, []
+    for b in blocks:
+        Sn = b.shape[0]
+        M[k:k + Sn] = b
+        fed.append(b)
+        k2 = L.spasm_hip_dechelon_extend(p, m, M.data_ptr(), m, k, Sn, piv.data_ptr(), 0)
+        torch.cuda.synchronize()
+        assert k <= k2 <= k + Sn
+        k = k2
+        E = M[:k]
+        J = piv[:k].to(torch.int64)
+        assert len(torch.unique(J)) == k
+        if k:
+            assert torch.equal(E[:, J], torch.eye(k, dtype=torch.int32, device=dev))
+            assert bool(torch.all(E.ge(0) & E.lt(p)))
+        stack = torch.cat(fed, 0)
+        r_want, R_want, J_want = _rref_rows(p, stack)
+        assert k == r_want, (k, r_want)
+        if k:
+            r_got, R_got, J_got = _rref_rows(p, E)
+            assert r_got == k and torch.equal(J_got, J_want) and torch.equal(R_got, R_want)
+    return k
+
+
+def _low_rank(torch, gen, p, n, m, rank, density=1.0, dev="cuda:0"):
+    Lh = torch.randint(0, p, (n, rank), dtype=torch.int64, device=dev, generator=gen)
+    Rh = torch.randint(0, p, (rank, m), dtype=torch.int64, device=dev, generator=gen)
+    if density < 1.0:
+        Rh = Rh * (torch.rand((rank, m), device=dev, generator=gen) < density)
+    out = torch.zeros((n, m), dtype=torch.int64, device=dev)
+    for c in range(0, rank, 32):
+        out = (out + Lh[:, c:c + 32] @ Rh[c:c + 32]) % p          # (int64 matmul: exact)
+    return out.to(torch.int32)
+
+
+@pytest.mark.parametrize("p", [42013, 257, 65267])
+@pytest.mark.parametrize("case", ["two_blocks", "ragged", "dependent_on_E", "zeros", "sparse_wide", "many_windows"])
+def test_echelon_extend_by_row_panels(case, p):
+    import torch
+    dev = torch.device("cuda:0")
+    g = torch.Generator(device=dev)
+    g.manual_seed(len(case) * 1000 + p)
+    if case == "two_blocks":          # 256 rows of rank 150, then 320 rows of rank 200 sharing nothing in particular
+        m = 1500
+        blocks = [_low_rank(torch, g, p, 256, m, 150), _low_rank(torch, g, p, 320, m, 200)]
+    elif case == "ragged":            # row counts that are not multiples of 64; a single row; full-rank block
+        m = 700
+        blocks = [_low_rank(torch, g, p, 70, m, 70), _low_rank(torch, g, p, 1, m, 1), _low_rank(torch, g, p, 129, m, 40)]
+    elif case == "dependent_on_E":    # the second block lies in the row space of the first: nothing new
+        m = 900
+        B = _low_rank(torch, g, p, 200, m, 90)
+        C = torch.randint(0, p, (130, 200), dtype=torch.int64, device=dev, generator=g)
+        blocks = [B, ((C @ B.to(torch.int64)) % p).to(torch.int32)]
+    elif case == "zeros":
+        m = 300
+        blocks = [torch.zeros((100, m), dtype=torch.int32, device=dev), _low_rank(torch, g, p, 64, m, 10),
+                  torch.zeros((5, m), dtype=torch.int32, device=dev)]
+    elif case == "sparse_wide":       # wide and sparse: leftmost entries far apart, several windows per panel
+        m = 20000
+        blocks = [_low_rank(torch, g, p, 192, m, 120, density=0.02), _low_rank(torch, g, p, 192, m, 150, density=0.02)]
+    else:                             # many_windows: row i starts at column 300 * (i % 40): a panel needs ~40 windows
+        m = 13000
+        B = torch.zeros((128, m), dtype=torch.int32, device=dev)
+        for i in range(128):
+            c = 300 * (i % 40)
+            B[i, c:c + 200] = torch.randint(1, p, (200,), dtype=torch.int32, device=dev, generator=g)
+        blocks = [B]
+    _extend_and_check(p, blocks, m)
