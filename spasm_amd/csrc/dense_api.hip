@@ -244,7 +244,7 @@ void device_random_dense_rows(const spasm_hip_dcsr &dA, const int *d_rows, int n
 	const int m = dA.m;
 	const double t0 = wtime();
 	// Y = C * A[p, :], dense 64-bit accumulators, then CSR
-	unsigned long long *dY = dalloc<unsigned long long>((i64) N * m);
+	unsigned long long *dY = (unsigned long long *) big_alloc((size_t) N * (size_t) m * sizeof(unsigned long long));
 	HIP_CHECK(hipMemsetAsync(dY, 0, (size_t) N * m * sizeof(unsigned long long), stream));
 	launch_combine(dA.p, dA.j, dA.x, d_rows, n, N, w, m, salt, dY, F->mont, stream);
 	launch_dense_count(dY, N, m, (uint32_t) F->prime, W->d_row_len, stream);
@@ -252,8 +252,8 @@ void device_random_dense_rows(const spasm_hip_dcsr &dA, const int *d_rows, int n
 	i64 ynnz = 0;
 	HIP_CHECK(hipMemcpyAsync(&ynnz, W->d_Sp + N, sizeof(i64), hipMemcpyDeviceToHost, stream));
 	HIP_CHECK(hipStreamSynchronize(stream));
-	int *dYj = dalloc<int>(ynnz);
-	int *dYx = dalloc<int>(ynnz);
+	int *dYj = (int *) big_alloc((size_t) (ynnz > 0 ? ynnz : 1) * sizeof(int));
+	int *dYx = (int *) big_alloc((size_t) (ynnz > 0 ? ynnz : 1) * sizeof(int));
 	launch_dense_pack(dY, N, m, (uint32_t) F->prime, W->d_Sp, dYj, dYx, stream);
 	i64 *dYp = dalloc<i64>((i64) N + 1);
 	HIP_CHECK(hipMemcpyAsync(dYp, W->d_Sp, ((size_t) N + 1) * sizeof(i64), hipMemcpyDeviceToDevice, stream));
@@ -264,15 +264,15 @@ void device_random_dense_rows(const spasm_hip_dcsr &dA, const int *d_rows, int n
 	HIP_CHECK(hipMemcpyAsync(dident, ident.data(), (size_t) N * sizeof(int), hipMemcpyHostToDevice, stream));
 	HIP_CHECK(hipStreamSynchronize(stream));
 	const double t1 = wtime();
-	(void) hipFree(dY);
+	big_free(dY);
 	spasm_hip_dcsr dYcsr{N, m, ynnz, dYp, dYj, dYx};
 	dschur_dense_impl(&dYcsr, dident, N, F, W, d_S, ldS, stream, nullptr);
 	if (verbose() >= 2)
 		logmsg("[dense rows] %d combinations: combine + pack %.3fs (%" PRId64 " entries), reduction %.3fs\n", N, t1 - t0, ynnz, wtime() - t1);
 	(void) hipFree(dident);
 	(void) hipFree(dYp);
-	(void) hipFree(dYj);
-	(void) hipFree(dYx);
+	big_free(dYj);
+	big_free(dYx);
 }
 }  // namespace sh
 
@@ -341,7 +341,7 @@ bool finish_on_device(const struct spasm_csr *A, const int *p, int n, struct spa
 			return false;                    // the blocked host loops work in dense_block_size x Sm pieces
 		}
 	}
-	u32 *dM = dalloc<u32>(cap_rows * ld);
+	u32 *dM = (u32 *) big_alloc((size_t) cap_rows * (size_t) ld * sizeof(u32));
 	int *dpiv = dalloc<int>(Sm0);
 	bool out_of_memory = false;
 	auto room_for = [&](int rows_added, int k_now) {
@@ -354,10 +354,10 @@ bool finish_on_device(const struct spasm_csr *A, const int *p, int n, struct spa
 			out_of_memory = true;
 			return false;
 		}
-		u32 *bigger = dalloc<u32>(want * ld);
+		u32 *bigger = (u32 *) big_alloc((size_t) want * (size_t) ld * sizeof(u32));
 		HIP_CHECK(hipMemcpyAsync(bigger, dM, (size_t) k_now * ld * sizeof(u32), hipMemcpyDeviceToDevice, stream));
 		HIP_CHECK(hipStreamSynchronize(stream));
-		(void) hipFree(dM);
+		big_free(dM);
 		dM = bigger;
 		cap_rows = want;
 		return true;
@@ -368,9 +368,15 @@ bool finish_on_device(const struct spasm_csr *A, const int *p, int n, struct spa
 	int processed = 0, round = 0;
 	bool lowrank = lowrank_first;
 	double t_rows = 0.0, t_rref = 0.0;
+	// Wide remainders (tens of thousands of columns, rank a few thousand): the rows are added by ROW panels
+	// (device_echelon_extend: one pass over the stack per 64 pivots, E is not factored again); narrow ones go through the
+	// column-panel RREF of the whole stack [E; Y], which is at its best there.  SPASM_HIP_ROW_PANELS=0/1 forces the choice.
+	const int rp_env = env_int("SPASM_HIP_ROW_PANELS", -1);
+	const bool row_panels = prime <= 65279 && (rp_env > 0 || (rp_env < 0 && Sm0 >= env_int("SPASM_HIP_ROW_PANELS_MIN_COLS", 16384)));
 	auto stack_and_reduce = [&](int rows_added) {
 		const double t0 = wtime();
-		const int rk = spasm_hip_drref(prime, k + rows_added, Sm0, dM, ld, dpiv, stream);
+		const int rk = row_panels ? device_echelon_extend(prime, Sm0, dM, ld, k, rows_added, dpiv, stream)
+		                          : spasm_hip_drref(prime, k + rows_added, Sm0, dM, ld, dpiv, stream);
 		t_rref += wtime() - t0;
 		const int rr = rk - k;
 		k = rk;
@@ -491,12 +497,13 @@ bool finish_on_device(const struct spasm_csr *A, const int *p, int n, struct spa
 	for (int i = 0; i < k; i++)
 		fact->qinv[q0[piv[i]]] = old_un + i;
 	U->n = old_un + k;
-	(void) hipFree(dM);
+	big_free(dM);
 	(void) hipFree(dpiv);
 	spasm_hip_dwork_destroy(W);
 	(void) hipFree(drows);
-	logmsg("[echelonize/dense/device] completed in %.2fs (dense rows %.2fs, RREF %.2fs; %s). %d new pivots found\n", wtime() - start,
-	       t_rows, t_rref, have_R ? "blocks from the back-substituted image" : "blocks from the row-by-row kernels", U->n - old_un);
+	logmsg("[echelonize/dense/device] completed in %.2fs (dense rows %.2fs, %s %.2fs; %s). %d new pivots found\n", wtime() - start,
+	       t_rows, row_panels ? "echelon rows by row panels" : "RREF", t_rref,
+	       have_R ? "blocks from the back-substituted image" : "blocks from the row-by-row kernels", U->n - old_un);
 	if (out_of_memory)
 		logmsg("[echelonize/dense/device] the stack of echelon rows no longer fits in HBM: the host loops take over\n");
 	return !out_of_memory;          // (the echelon rows found so far are in U either way)

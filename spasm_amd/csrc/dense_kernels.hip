@@ -2431,8 +2431,7 @@ int device_echelon_extend(int64_t prime, int m, uint32_t *dM, int64_t ld, int k,
 	uint32_t *Y = dM + (int64_t) k * ld;
 	std::vector<void *> owned;
 	auto dal = [&](size_t bytes) {
-		void *ptr = nullptr;
-		HIP_CHECK(hipMalloc(&ptr, bytes > 0 ? bytes : 1));
+		void *ptr = big_alloc(bytes);
 		owned.push_back(ptr);
 		return ptr;
 	};
@@ -2563,7 +2562,7 @@ int device_echelon_extend(int64_t prime, int m, uint32_t *dM, int64_t ld, int k,
 		HIP_CHECK(hipMemcpyAsync(d_piv + k, piv_new.data(), (size_t) rr * sizeof(int), hipMemcpyHostToDevice, stream));
 	HIP_CHECK(hipStreamSynchronize(stream));
 	for (void *ptr : owned)
-		(void) hipFree(ptr);
+		big_free(ptr);
 	return k + rr;
 }
 

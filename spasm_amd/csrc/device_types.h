@@ -177,6 +177,13 @@ struct DeviceMatrix {
 	DeviceMatrix(const DeviceMatrix &) = delete;
 	DeviceMatrix &operator=(const DeviceMatrix &) = delete;
 };
+// Large device buffers of the host-level entry points (row pools, dense accumulators, stacks of echelon rows) come from a
+// small cache of freed blocks: hipMalloc of tens of GB costs up to 40 ms per GB on these boxes (tools/probe_alloc.py) and
+// the driver asks for the same sizes round after round.  big_free takes any device pointer (blocks it does not know go to
+// hipFree); big_trim releases everything cached (the driver calls it on exit).
+void *big_alloc(size_t bytes);
+void big_free(void *ptr);
+void big_trim();
 void resident_begin();
 void resident_end();
 void resident_forget(const struct spasm_csr *A);

@@ -62,6 +62,89 @@ template <typename T> void upload(T *dst, const T *src, int64_t count, hipStream
 		HIP_CHECK(hipMemcpyAsync(dst, src, (size_t) count * sizeof(T), hipMemcpyHostToDevice, s));
 }
 
+}  // namespace
+
+namespace sh {
+namespace {
+struct BigPool {
+	std::mutex mutex;
+	std::vector<std::pair<void *, size_t>> free_blocks;          // cached, not in use
+	std::vector<std::pair<void *, size_t>> live;                 // handed out by big_alloc
+	size_t cached = 0;
+};
+BigPool g_big;
+constexpr size_t BIG_MIN = (size_t) 32 << 20;                    // smaller requests go straight to hipMalloc
+constexpr size_t BIG_CACHE_CAP = (size_t) 96 << 30;
+}  // namespace
+
+void *big_alloc(size_t bytes)
+{
+	if (bytes == 0)
+		bytes = 1;
+	void *ptr = nullptr;
+	if (bytes >= BIG_MIN) {
+		std::lock_guard<std::mutex> guard(g_big.mutex);
+		int best = -1;
+		for (size_t t = 0; t < g_big.free_blocks.size(); t++) {
+			const size_t have = g_big.free_blocks[t].second;
+			if (have >= bytes && have <= bytes + bytes / 2 && (best < 0 || have < g_big.free_blocks[(size_t) best].second))
+				best = (int) t;
+		}
+		if (best >= 0) {
+			const auto blk = g_big.free_blocks[(size_t) best];
+			g_big.free_blocks.erase(g_big.free_blocks.begin() + best);
+			g_big.cached -= blk.second;
+			g_big.live.push_back(blk);
+			return blk.first;
+		}
+	}
+	if (hipMalloc(&ptr, bytes) != hipSuccess) {
+		(void) hipGetLastError();
+		big_trim();                          // cached blocks may be what is in the way
+		HIP_CHECK(hipMalloc(&ptr, bytes));
+	}
+	if (bytes >= BIG_MIN) {
+		std::lock_guard<std::mutex> guard(g_big.mutex);
+		g_big.live.push_back({ptr, bytes});
+	}
+	return ptr;
+}
+
+void big_free(void *ptr)
+{
+	if (ptr == nullptr)
+		return;
+	{
+		std::lock_guard<std::mutex> guard(g_big.mutex);
+		for (size_t t = 0; t < g_big.live.size(); t++)
+			if (g_big.live[t].first == ptr) {
+				const auto blk = g_big.live[t];
+				g_big.live.erase(g_big.live.begin() + (long) t);
+				if (g_big.cached + blk.second <= BIG_CACHE_CAP) {
+					g_big.free_blocks.push_back(blk);
+					g_big.cached += blk.second;
+					return;
+				}
+				break;
+			}
+	}
+	(void) hipFree(ptr);
+}
+
+void big_trim()
+{
+	std::vector<std::pair<void *, size_t>> blocks;
+	{
+		std::lock_guard<std::mutex> guard(g_big.mutex);
+		blocks.swap(g_big.free_blocks);
+		g_big.cached = 0;
+	}
+	for (auto &b : blocks)
+		(void) hipFree(b.first);
+}
+}  // namespace sh
+
+namespace {
 // The dense accumulator scratch is large (tens of GB on big inputs) and expensive to allocate;
 // host-level entry points park it here between calls instead of freeing it (it is all zero
 // whenever no kernel is running).
@@ -136,8 +219,8 @@ void resident_forget(const struct spasm_csr *A)
 	for (size_t t = 0; t < g_resident.size(); t++)
 		if (g_resident[t].host == A) {
 			(void) hipFree(g_resident[t].p);
-			(void) hipFree(g_resident[t].j);
-			(void) hipFree(g_resident[t].x);
+			big_free(g_resident[t].j);          // (may be the output arrays of a workspace, which come from the block cache)
+			big_free(g_resident[t].x);
 			g_resident.erase(g_resident.begin() + (long) t);
 			return;
 		}
@@ -148,6 +231,8 @@ void resident_end()
 	while (!g_resident.empty())
 		resident_forget(g_resident.back().host);
 	g_resident_on = false;
+	if (env_int("SPASM_HIP_KEEP_BLOCKS", 0) == 0)
+		big_trim();                          // the driver is done: cached blocks go back to the device
 }
 
 void resident_counters(i64 *uploads, i64 *hits)
@@ -783,10 +868,11 @@ spasm_hip_dwork *spasm_hip_dwork_create(int max_rows, int m, i64 pool_entries)
 	W->max_rows = max_rows;
 	W->m = m;
 	W->pool_cap = pool_entries;
-	W->d_pool_j = dalloc<int>(pool_entries);
-	W->d_pool_x = dalloc<int>(pool_entries);
-	W->d_Sj = dalloc<int>(pool_entries);
-	W->d_Sx = dalloc<int>(pool_entries);
+	const size_t pool_bytes = (size_t) (pool_entries > 0 ? pool_entries : 1) * sizeof(int);
+	W->d_pool_j = (int *) big_alloc(pool_bytes);
+	W->d_pool_x = (int *) big_alloc(pool_bytes);
+	W->d_Sj = (int *) big_alloc(pool_bytes);
+	W->d_Sx = (int *) big_alloc(pool_bytes);
 	W->d_row_off = dalloc<int64_t>(max_rows);
 	W->d_row_len = dalloc<int>(max_rows);
 	W->d_ovf1 = dalloc<int>(max_rows);
@@ -804,10 +890,10 @@ void spasm_hip_dwork_destroy(spasm_hip_dwork *W)
 {
 	if (W == nullptr)
 		return;
-	(void) hipFree(W->d_pool_j);
-	(void) hipFree(W->d_pool_x);
-	(void) hipFree(W->d_Sj);
-	(void) hipFree(W->d_Sx);
+	big_free(W->d_pool_j);
+	big_free(W->d_pool_x);
+	big_free(W->d_Sj);
+	big_free(W->d_Sx);
 	(void) hipFree(W->d_row_off);
 	(void) hipFree(W->d_row_len);
 	(void) hipFree(W->d_ovf1);

@@ -389,10 +389,16 @@ def _low_rank(torch, gen, p, n, m, rank, density=1.0, dev="cuda:0"):
     Rh = torch.randint(0, p, (rank, m), dtype=torch.int64, device=dev, generator=gen)
     if density < 1.0:
         Rh = Rh * (torch.rand((rank, m), device=dev, generator=gen) < density)
-    out = torch.zeros((n, m), dtype=torch.int64, device=dev)
-    for c in range(0, rank, 32):
-        out = (out + Lh[:, c:c + 32] @ Rh[c:c + 32]) % p          # (int64 matmul: exact)
-    return out.to(torch.int32)
+    return _mod_matmul(torch, Lh, Rh, p).to(torch.int32)
+
+
+def _mod_matmul(torch, A, B, p):
+    """(A @ B) mod p on the device, exact: float64 products of entries below 2^16, 64 terms per partial sum"""
+    out = torch.zeros((A.shape[0], B.shape[1]), dtype=torch.int64, device=A.device)
+    Af, Bf = A.to(torch.float64), B.to(torch.float64)
+    for c in range(0, A.shape[1], 64):
+        out = (out + (Af[:, c:c + 64] @ Bf[c:c + 64]).to(torch.int64)) % p
+    return out
 
 
 @pytest.mark.parametrize("p", [42013, 257, 65267])
@@ -412,7 +418,7 @@ def test_echelon_extend_by_row_panels(case, p):
         m = 900
         B = _low_rank(torch, g, p, 200, m, 90)
         C = torch.randint(0, p, (130, 200), dtype=torch.int64, device=dev, generator=g)
-        blocks = [B, ((C @ B.to(torch.int64)) % p).to(torch.int32)]
+        blocks = [B, _mod_matmul(torch, C, B.to(torch.int64), p).to(torch.int32)]
     elif case == "zeros":
         m = 300
         blocks = [torch.zeros((100, m), dtype=torch.int32, device=dev), _low_rank(torch, g, p, 64, m, 10),
