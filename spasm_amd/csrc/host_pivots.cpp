@@ -195,11 +195,44 @@ struct Search {
 		std::vector<std::atomic<int>> q((size_t) (m > 0 ? m : 1));
 		for (int j = 0; j < m; j++)
 			q[j].store(qinv[j], std::memory_order_relaxed);
+		// What a search visits is "the other columns of the pivot row of column c".  Going through q[c] -> A->p[row] ->
+		// A->j[...] is three dependent cache misses per visit; the rows of these matrices are short (a boundary matrix has
+		// K + 1 entries per row), so every pivotal column keeps its row -- minus itself -- in a 32-byte record: one miss.
+		// A column becomes pivotal once and stays so: the writer fills the entries, then publishes the length (release);
+		// len 0 = no pivot, len < 0 = row too long for a record (its index is in ent[0]).
+		struct alignas(32) PivRec {
+			std::atomic<int> len;
+			int ent[7];
+		};
+		std::vector<PivRec> rec((size_t) (m > 0 ? m : 1));
+		auto publish = [&](int col, int row) {
+			PivRec &R = rec[col];
+			const i64 lo = A->p[row], hi = A->p[row + 1];
+			if (hi - lo - 1 > 7) {
+				R.ent[0] = row;
+				R.len.store(-1, std::memory_order_release);
+				return;
+			}
+			int k = 0;
+			for (i64 px = lo; px < hi; px++)
+				if (A->j[px] != col)
+					R.ent[k++] = A->j[px];
+			if (k == 0) {                    // (a row with nothing but its pivot: nothing to visit, but the column IS pivotal)
+				R.ent[0] = row;
+				R.len.store(-1, std::memory_order_release);
+				return;
+			}
+			R.len.store(k, std::memory_order_release);
+		};
+		for (int j = 0; j < m; j++) {
+			rec[j].len.store(0, std::memory_order_relaxed);
+			if (qinv[j] >= 0)
+				publish(j, qinv[j]);
+		}
 		std::vector<int> journal((size_t) (n > 0 ? n : 1));
 		std::atomic<int> npiv{0};
 		std::atomic<int> next_row{0};
 		std::mutex commit;
-		const bool prefetch = std::getenv("SPASM_HIP_PIVOT_PREFETCH") == nullptr || std::atoi(std::getenv("SPASM_HIP_PIVOT_PREFETCH")) != 0;
 		std::atomic<unsigned long long> total_visits{0}, total_retries{0};
 		auto worker = [&]() {
 			unsigned long long visits = 0, retries = 0;
@@ -222,54 +255,52 @@ struct Search {
 					};
 					for (i64 px = A->p[i]; px < A->p[i + 1]; px++) {
 						const int j = A->j[px];
-						if (q[j].load(std::memory_order_relaxed) < 0) {
+						if (rec[j].len.load(std::memory_order_acquire) == 0) {
 							mark[j] = 1;
 							candidates += 1;
 						} else {
 							push(j);
 						}
 					}
-					// a pivot that appeared behind our back only matters when its column is one we marked: a candidate of
-					// ours that became pivotal, or a column of a row we reached (whose new row must then be explored).
-					// Pivots on untouched columns cannot be reached from our row and leave the search as it stands.
-					auto absorb = [&](int jn) {
-						if (mark[jn] == 0)
-							return false;
-						if (mark[jn] == 1) {
-							push(jn);
+					// the other columns of the pivot row of column c become reached
+					auto expand = [&](int c) {
+						const PivRec &R = rec[c];
+						const int len = R.len.load(std::memory_order_acquire);
+						if (len == 0)
+							return;                  // not a pivot (a reached non-pivotal column)
+						visits += 1;
+						if (len > 0) {
+							for (int e = 0; e < len; e++) {
+								const int j = R.ent[e];
+								if (mark[j] >= 0)
+									push(j);
+							}
 						} else {
-							const int row = q[jn].load(std::memory_order_relaxed);
+							const int row = R.ent[0];
 							for (i64 px = A->p[row]; px < A->p[row + 1]; px++) {
 								const int j = A->j[px];
 								if (mark[j] >= 0)
 									push(j);
 							}
 						}
+					};
+					// a pivot that appeared behind our back only matters when its column is one we marked: a candidate of
+					// ours that became pivotal, or a column of a row we reached (whose new row must then be explored).
+					// Pivots on untouched columns cannot be reached from our row and leave the search as it stands.
+					auto absorb = [&](int jn) {
+						if (mark[jn] == 0)
+							return false;
+						if (mark[jn] == 1)
+							push(jn);
+						else
+							expand(jn);
 						return true;
 					};
 					for (;;) {
 						while (head < tail && candidates > 0) {
-							// the search is a chain of dependent random reads (column -> pivot row -> extent -> entries ->
-							// marks): ask for the rows of the columns a few places further down the queue now
-							if (prefetch && head + 6 < tail) {
-								const int r6 = q[fifo[head + 6]].load(std::memory_order_relaxed);
-								if (r6 >= 0)
-									__builtin_prefetch(&A->p[r6]);
-							}
-							if (prefetch && head + 3 < tail) {
-								const int r3 = q[fifo[head + 3]].load(std::memory_order_relaxed);
-								if (r3 >= 0)
-									__builtin_prefetch(&A->j[A->p[r3]]);
-							}
-							const int row = q[fifo[head++]].load(std::memory_order_relaxed);
-							if (row == -1)
-								continue;
-							visits += 1;
-							for (i64 px = A->p[row]; px < A->p[row + 1]; px++) {
-								const int j = A->j[px];
-								if (mark[j] >= 0)
-									push(j);
-							}
+							if (head + 4 < tail)
+								__builtin_prefetch(&rec[fifo[head + 4]]);
+							expand(fifo[head++]);
 						}
 						if (candidates == 0)
 							break;
@@ -286,11 +317,9 @@ struct Search {
 							if (mark[chosen] == 1)
 								break;
 						}
-						// commit: under the lock only the few pivots that arrived since the catch-up are looked at, and
-						// the commit goes through unless one of THEM touches this search (the reference retries whenever
-						// anything at all was committed meanwhile -- spasm_pivots.c:262-290 -- which is what stopped the
-						// threaded search from scaling past 16 threads: with T searches in flight nearly every attempt
-						// finds the counter moved)
+						// commit: under the lock only the few pivots that arrived since the catch-up are looked at, and the
+						// commit goes through unless one of THEM touches this search (the reference retries whenever
+						// anything at all was committed meanwhile, spasm_pivots.c:262-290)
 						bool done = false;
 						{
 							std::lock_guard<std::mutex> lock(commit);
@@ -304,6 +333,7 @@ struct Search {
 							if (clean) {
 								q[chosen].store(i, std::memory_order_relaxed);
 								pinv[i] = chosen;
+								publish(chosen, i);
 								journal[now] = chosen;
 								npiv.store(now + 1, std::memory_order_release);
 								done = true;
