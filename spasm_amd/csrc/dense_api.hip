@@ -20,6 +20,9 @@ void launch_dense_count(const unsigned long long *Y, int N, int m, uint32_t p, i
 void launch_dense_pack(const unsigned long long *Y, int N, int m, uint32_t p, const int64_t *Sp, int *Sj, int *Sx,
                        hipStream_t stream);
 void launch_row_scan(const int *row_len, int n, int64_t *blocksum, int64_t *Sp, hipStream_t stream);
+void launch_echelon_count(const uint32_t *M, int64_t ld, int m, int k, int *row_len, hipStream_t stream);
+void launch_echelon_pack(const uint32_t *M, int64_t ld, int m, int k, const int *piv, const int *q, uint32_t p, const int64_t *Sp, int *Uj,
+                         int *Ux, hipStream_t stream);
 void wave_dense_geometry(int rpad, int Sm, bool wide, int64_t *slot_bytes, int64_t *off_bm, int64_t *off_xn);
 void group_geometry(int rpad, int Sm, bool wide, int64_t *slot_bytes, int64_t *off_bm);
 void launch_schur_group(const SchurArgs &a, unsigned char *scratch, int64_t slot_bytes, int64_t off_bm, bool wide,
@@ -441,62 +444,47 @@ bool finish_on_device(const struct spasm_csr *A, const int *p, int n, struct spa
 			round += 1;
 		}
 	}
-	// the echelon rows join U: pivot first (value 1), then the other entries, on the original columns
-	std::vector<u32> E((size_t) std::max<i64>(1, (i64) k * ld));
+	// the echelon rows join U: pivot first (value 1), then the other entries, on the original columns.  They are packed
+	// on the device (count, scan, pack: the stack is k x Sm words of which a tenth is non-zero -- 1.9 GB for 54 M entries on
+	// ch8-8.b5, 0.44 s through a pageable copy and two host passes) and land in U's own arrays.
+	const double t_tail0 = wtime();
+	struct spasm_csr *U = fact->U;
+	const int old_un = U->n;
 	std::vector<int> piv((size_t) std::max(1, k));
 	if (k > 0) {
-		HIP_CHECK(hipMemcpy(E.data(), dM, (size_t) k * ld * sizeof(u32), hipMemcpyDeviceToHost));
-		HIP_CHECK(hipMemcpy(piv.data(), dpiv, (size_t) k * sizeof(int), hipMemcpyDeviceToHost));
-	}
-	struct spasm_csr *U = fact->U;
-	const std::vector<int> &q0 = F->h_q;
-	// (threads: the block is k x Sm words, mostly zeros -- the pivot columns -- and two passes over it took 40 ms on mk13.b5)
-	const int T = (int) std::max(1u, std::min(16u, std::thread::hardware_concurrency()));
-	std::vector<i64> row_nz((size_t) k + 1, 0);
-	auto in_parallel = [&](auto &&body) {
-		std::vector<std::thread> pool;
-		for (int t = 0; t < T; t++)
-			pool.emplace_back([&, t]() {
-				for (int i = t; i < k; i += T)
-					body(i);
-			});
-		for (auto &th : pool)
-			th.join();
-	};
-	in_parallel([&](int i) {
-		const u32 *row = E.data() + (size_t) i * ld;
-		if (row[piv[i]] != 1)
-			die("finish_on_device: echelon row %d does not have a unit pivot on column %d", i, piv[i]);
-		i64 c = 0;
-		for (int j = 0; j < Sm0; j++)
-			c += row[j] != 0;
-		row_nz[(size_t) i + 1] = c;                   // (the pivot included)
-	});
-	for (int i = 0; i < k; i++)
-		row_nz[(size_t) i + 1] += row_nz[(size_t) i];
-	const i64 unz0 = U->p[U->n];
-	spasm_hip_csr_realloc(U, unz0 + row_nz[(size_t) k]);
-	const u32 half = (u32) (prime / 2);
-	const int old_un = U->n;
-	in_parallel([&](int i) {
-		const u32 *row = E.data() + (size_t) i * ld;
-		const int jp = piv[i];
-		i64 unz = unz0 + row_nz[(size_t) i];
-		U->j[unz] = q0[jp];
-		U->x[unz] = 1;
-		unz += 1;
-		for (int j = 0; j < Sm0; j++) {
-			if (j == jp || row[j] == 0)
-				continue;
-			U->j[unz] = q0[j];
-			U->x[unz] = (row[j] > half) ? (spasm_ZZp) ((i64) row[j] - prime) : (spasm_ZZp) row[j];
-			unz += 1;
+		int *d_len = dalloc<int>(k);
+		i64 *d_Up = dalloc<i64>((i64) k + 1);
+		i64 *d_bsum = dalloc<i64>((k + 1023) / 1024 + 2);
+		launch_echelon_count(dM, ld, Sm0, k, d_len, stream);
+		launch_row_scan(d_len, k, d_bsum, d_Up, stream);
+		std::vector<i64> Up((size_t) k + 1);
+		HIP_CHECK(hipMemcpyAsync(Up.data(), d_Up, ((size_t) k + 1) * sizeof(i64), hipMemcpyDeviceToHost, stream));
+		HIP_CHECK(hipMemcpyAsync(piv.data(), dpiv, (size_t) k * sizeof(int), hipMemcpyDeviceToHost, stream));
+		HIP_CHECK(hipStreamSynchronize(stream));
+		const i64 add = Up[(size_t) k];
+		int *d_Uj = (int *) big_alloc((size_t) std::max<i64>(add, 1) * sizeof(int));
+		int *d_Ux = (int *) big_alloc((size_t) std::max<i64>(add, 1) * sizeof(int));
+		launch_echelon_pack(dM, ld, Sm0, k, dpiv, F->d_q, (uint32_t) prime, d_Up, d_Uj, d_Ux, stream);
+		const i64 unz0 = U->p[U->n];
+		spasm_hip_csr_realloc(U, unz0 + add);
+		HIP_CHECK(hipMemcpyAsync(U->j + unz0, d_Uj, (size_t) add * sizeof(int), hipMemcpyDeviceToHost, stream));
+		HIP_CHECK(hipMemcpyAsync(U->x + unz0, d_Ux, (size_t) add * sizeof(int), hipMemcpyDeviceToHost, stream));
+		HIP_CHECK(hipStreamSynchronize(stream));
+		const std::vector<int> &q0 = F->h_q;
+		for (int i = 0; i < k; i++) {
+			U->p[old_un + i + 1] = unz0 + Up[(size_t) i + 1];
+			if (U->j[unz0 + Up[(size_t) i]] != q0[piv[i]] || U->x[unz0 + Up[(size_t) i]] != 1)
+				die("finish_on_device: echelon row %d does not start with a unit pivot on column %d", i, q0[piv[i]]);
+			fact->qinv[q0[piv[i]]] = old_un + i;
 		}
-		U->p[old_un + i + 1] = unz;
-	});
-	for (int i = 0; i < k; i++)
-		fact->qinv[q0[piv[i]]] = old_un + i;
-	U->n = old_un + k;
+		U->n = old_un + k;
+		big_free(d_Uj);
+		big_free(d_Ux);
+		(void) hipFree(d_len);
+		(void) hipFree(d_Up);
+		(void) hipFree(d_bsum);
+	}
+	const double t_tail1 = wtime();
 	big_free(dM);
 	(void) hipFree(dpiv);
 	spasm_hip_dwork_destroy(W);
@@ -504,6 +492,8 @@ bool finish_on_device(const struct spasm_csr *A, const int *p, int n, struct spa
 	logmsg("[echelonize/dense/device] completed in %.2fs (dense rows %.2fs, %s %.2fs; %s). %d new pivots found\n", wtime() - start,
 	       t_rows, row_panels ? "echelon rows by row panels" : "RREF", t_rref,
 	       have_R ? "blocks from the back-substituted image" : "blocks from the row-by-row kernels", U->n - old_un);
+	if (verbose() >= 2)
+		logmsg("[echelonize/dense/device] of that: %.2fs packing the %d echelon rows on the device and appending them to U\n", t_tail1 - t_tail0, k);
 	if (out_of_memory)
 		logmsg("[echelonize/dense/device] the stack of echelon rows no longer fits in HBM: the host loops take over\n");
 	return !out_of_memory;          // (the echelon rows found so far are in U either way)

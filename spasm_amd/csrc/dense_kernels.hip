@@ -2681,6 +2681,77 @@ __global__ __launch_bounds__(256) void dense_pack_kernel(const unsigned long lon
 	}
 }
 
+// ---- echelon rows (k x m words, values in [0, p), pivot of row t on column piv[t] with value 1) as rows of U ----
+// entries of row t: the pivot first, then the others in increasing column; columns go through q (index among the non-
+// pivotal columns of the factor the rows were reduced by -> column of the matrix); balanced representatives.
+__global__ __launch_bounds__(256) void echelon_count_kernel(const uint32_t *M, int64_t ld, int m, int k, int *row_len)
+{
+	__shared__ int part[256];
+	const int t = blockIdx.x;
+	int c = 0;
+	for (int j = threadIdx.x; j < m; j += 256)
+		c += M[(int64_t) t * ld + j] != 0;
+	part[threadIdx.x] = c;
+	__syncthreads();
+	for (int d = 128; d > 0; d >>= 1) {
+		if ((int) threadIdx.x < d)
+			part[threadIdx.x] += part[threadIdx.x + d];
+		__syncthreads();
+	}
+	if (threadIdx.x == 0)
+		row_len[t] = part[0];
+}
+
+__global__ __launch_bounds__(256) void echelon_pack_kernel(const uint32_t *M, int64_t ld, int m, int k, const int *piv, const int *q, uint32_t p,
+                                                           const int64_t *Sp, int *Uj, int *Ux)
+{
+	__shared__ int wave_tot[4];
+	const int t = blockIdx.x;
+	const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+	const int jp = piv[t];
+	int64_t wpos = Sp[t];
+	if (threadIdx.x == 0) {
+		Uj[wpos] = q[jp];
+		Ux[wpos] = 1;
+	}
+	wpos += 1;
+	for (int base = 0; base < m; base += 256) {
+		const int j = base + threadIdx.x;
+		const uint32_t v = (j < m && j != jp) ? M[(int64_t) t * ld + j] : 0u;
+		const bool keep = v != 0;
+		const uint64_t mk = __ballot(keep);
+		if (lane == 0)
+			wave_tot[wave] = __popcll(mk);
+		__syncthreads();
+		int before = 0, all = 0;
+		for (int wv = 0; wv < 4; wv++) {
+			if (wv < wave)
+				before += wave_tot[wv];
+			all += wave_tot[wv];
+		}
+		if (keep) {
+			const int64_t dst = wpos + before + __popcll(mk & ((1ull << lane) - 1ull));
+			Uj[dst] = q[j];
+			Ux[dst] = (v > p / 2) ? (int) (v - p) : (int) v;
+		}
+		wpos += all;
+		__syncthreads();
+	}
+}
+
+void launch_echelon_count(const uint32_t *M, int64_t ld, int m, int k, int *row_len, hipStream_t stream)
+{
+	if (k > 0)
+		hipLaunchKernelGGL(echelon_count_kernel, dim3(k), dim3(256), 0, stream, M, ld, m, k, row_len);
+}
+
+void launch_echelon_pack(const uint32_t *M, int64_t ld, int m, int k, const int *piv, const int *q, uint32_t p, const int64_t *Sp, int *Uj,
+                         int *Ux, hipStream_t stream)
+{
+	if (k > 0)
+		hipLaunchKernelGGL(echelon_pack_kernel, dim3(k), dim3(256), 0, stream, M, ld, m, k, piv, q, p, Sp, Uj, Ux);
+}
+
 void launch_combine(const int64_t *Ap, const int *Aj, const int *Ax, const int *rows, int nrows, int N, int w, int m,
                     uint64_t salt, unsigned long long *Y, const Mont &M, hipStream_t stream)
 {
