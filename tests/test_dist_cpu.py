@@ -148,3 +148,50 @@ def test_column_slabs_stitch_to_the_full_schur_complement(oracle, name, parts):
         o = np.argsort(wj)
         lo, hi = full.p[k], full.p[k + 1]
         assert np.array_equal(full.j[lo:hi], wj[o]) and np.array_equal(full.x[lo:hi], wx[o])
+
+
+# --------------------------------------------------------------------------
+# the column split under gloo: every rank its slab, only the row lengths are exchanged
+# --------------------------------------------------------------------------
+def _column_worker(rank, world, port, name, prime, result_dir):
+    sys.path.insert(0, ROOT)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from oracle import oracle as orc
+    import spasm_amd
+    from spasm_amd.dist import column_slab
+    A = orc.load_sms(matrix_path(name), prime)
+    npiv, perm, F = orc.pivots_extract_structural(A, orc.empty_fact(A.n, A.m, prime))
+    rows = perm[npiv:]
+    Ap = spasm_amd.Csr(A.n, A.m, A.p, A.j, A.x, prime)
+    Fp = spasm_amd.Fact(spasm_amd.Csr(F.U.n, F.U.m, F.U.p, F.U.j, F.U.x, prime), F.qinv)
+    As, Fs, cols = column_slab(Ap, Fp, rank, world)
+    S, _, _ = orc.schur(orc.CSR(As.n, As.m, As.p, As.j, As.x, prime), rows,
+                        orc.Fact(orc.CSR(Fs.U.n, Fs.U.m, Fs.U.p, Fs.U.j, Fs.U.x, prime), Fs.qinv))
+    # what bench.py --split columns exchanges: the lengths of this rank's pieces of every row
+    mine = torch.from_numpy(np.diff(S.p).astype(np.int64)) if len(rows) else torch.zeros(0, dtype=torch.int64)
+    everybody = [torch.zeros_like(mine) for _ in range(world)]
+    dist.all_gather(everybody, mine)
+    lengths = torch.stack(everybody).sum(0).numpy() if len(rows) else np.zeros(0, np.int64)
+    want, _, _ = orc.schur(A, rows, F)
+    ok = np.array_equal(lengths, np.diff(want.p))
+    # and the pieces themselves are the entries of the whole rows on this rank's columns
+    lo_col, hi_col = (int(cols[F.U.n:].min()), int(cols[F.U.n:].max())) if len(cols) > F.U.n else (0, -1)
+    mycols = set(int(c) for c in cols)
+    for k in range(len(rows)):
+        wj, wx = want.row(k)
+        keep = np.array([int(c) in mycols for c in wj], bool)
+        gj, gx = S.row(k)
+        o1, o2 = np.argsort(cols[gj]), np.argsort(wj[keep])
+        ok = ok and np.array_equal(cols[gj][o1], wj[keep][o2]) and np.array_equal(gx[o1], wx[keep][o2])
+    open(os.path.join(result_dir, "rank%d" % rank), "w").write("ok" if ok else "FAIL")
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("name,world", [("mat364.sms", 2), ("medium.sms", 3), ("rectangular_h.sms", 2)])
+def test_column_split_gloo(tmp_path, name, world):
+    port = 31500 + (os.getpid() + hash(name)) % 2000
+    mp.spawn(_column_worker, args=(world, port, name, 42013, str(tmp_path)), nprocs=world, join=True)
+    for r in range(world):
+        assert open(os.path.join(str(tmp_path), "rank%d" % r)).read() == "ok"
