@@ -232,7 +232,8 @@ template <bool PACKED, int LPR, int NW, int RING = BS_RING, int PASSROWS = BS_PA
 	static constexpr int ITERS = RING / ROWS_PER_ITER;
 	// rows in flight per lane in phase A.  Eight waves (two per SIMD: 256 registers each) take a whole chunk in ONE pass --
 	// a pass is a round trip to memory, and a chunk has little else to hide it behind
-	static constexpr int UNR = (NW == 8 && ITERS == 24) ? 24 : (ITERS % 12 == 0) ? 12 : 8;
+	static constexpr int UNR = (NW >= 8 && ITERS <= 24) ? ITERS : (ITERS % 12 == 0) ? 12 : 8;
+	static constexpr int LANES_USED = RS * LPR;            // (LPR need not divide 64: the lanes beyond RS whole rows idle in phases A and C)
 	static_assert(RING % ROWS_PER_ITER == 0 && ITERS % UNR == 0, "phase A is unrolled in passes of UNR rows");
 	static constexpr int N_NEAR = (BS_NEARCAP + THREADS - 1) / THREADS;      // metadata words a thread carries for the next chunk
 	static constexpr int N_ROW = (RING + THREADS - 1) / THREADS;
@@ -271,7 +272,7 @@ __global__ __launch_bounds__(64 * NW, WGS_PER_CU) void backsolve_kernel(BsArgs b
 	constexpr int RSTR = Geo::RSTR;                        // words between two rows of the ring
 	// phase B splits the COLUMNS among the waves: a wave owns WPW words of every row, a wave instruction covers RSB rows
 	constexpr int WPW = LPR / NW, RSB = 64 / WPW;
-	static_assert(WPW >= 1 && RSB == Geo::ROWS_PER_ITER, "phase B walks the rows of a step as the other phases do");
+	static_assert(WPW >= 1 && LPR % NW == 0 && 64 % WPW == 0, "every wave takes the same number of words of a row through phase B");
 	static_assert(PASSROWS % RSB == 0, "a pass is a whole number of wave instructions");
 	const int rsb = lane / WPW, wlb = wave * WPW + lane % WPW;
 	const MontDev F = b.F;
@@ -282,6 +283,9 @@ __global__ __launch_bounds__(64 * NW, WGS_PER_CU) void backsolve_kernel(BsArgs b
 	const uint32_t ldw256 = (uint32_t) (ldw >> 8);
 	auto row_at = [&](uint32_t row) -> uint32_t * { return Rs + ((uint64_t) (row * ldw256) << 8); };
 	const int slot0 = wave * Geo::RS + rs;          // this lane's row slot within an iteration
+	// lanes that hold a word of a row in phases A and C: all of them when LPR divides 64; and the word must exist (the last
+	// slab of a row may reach beyond the padded row when LPR does not divide its length)
+	const bool lane_ok = lane < Geo::LANES_USED && (int64_t) blockIdx.x * LPR + wl < ldw;
 	const int col_lo = blockIdx.x * Geo::CW;        // columns [col_lo, col_lo + CW) belong to this workgroup
 
 	// metadata of a chunk (the same for every slab: served by the L2) travels through registers: the loads for chunk
@@ -434,11 +438,11 @@ __global__ __launch_bounds__(64 * NW, WGS_PER_CU) void backsolve_kernel(BsArgs b
 #pragma unroll
 			for (int u = 0; u < Geo::UNR; u++) {
 				const int s = (pass * Geo::UNR + u) * Geo::ROWS_PER_ITER + slot0;
-				const bool ok = s < nrows;
+				const bool ok = s < nrows && lane_ok;
 				const uint4 h = fh[ok ? s : 0];
 				const int c = ch.lo + (ok ? s : 0);
-				acc[u] = b.sparse_init ? 0u : *row_at((uint32_t) c);
-				if constexpr (LPR <= 16) {
+				acc[u] = (b.sparse_init || !ok) ? 0u : *row_at((uint32_t) c);
+				if constexpr (LPR <= 16 && 64 % LPR == 0) {
 					// no branch around the loads: an absent dependency reads the chunk's own first row -- a valid address -- and
 					// is multiplied by the coefficient 0 of its slot, or skipped, below (64-byte rows: 2.84 -> 2.75 ms on mk13.b5,
 					// 9.2 -> 6.1 ms with 32-bit entries; with 128-byte rows the wasted lines cost more than the branches)
@@ -452,7 +456,7 @@ __global__ __launch_bounds__(64 * NW, WGS_PER_CU) void backsolve_kernel(BsArgs b
 #pragma unroll
 			for (int u = 0; u < Geo::UNR; u++) {
 				const int s = (pass * Geo::UNR + u) * Geo::ROWS_PER_ITER + slot0;
-				if (s < nrows) {
+				if (s < nrows && lane_ok) {
 					const uint4 h = fh[s];
 					uint32_t x = b.sparse_init ? ring[s * RSTR + wl] : acc[u];
 					if constexpr (SGN) {
@@ -481,7 +485,7 @@ __global__ __launch_bounds__(64 * NW, WGS_PER_CU) void backsolve_kernel(BsArgs b
 			for (int s = slot0; s < nrows; s += Geo::ROWS_PER_ITER) {
 				const int c = ch.lo + s;
 				const uint64_t e0 = b.far_rp[c], e1 = b.far_rp[c + 1];
-				if (e0 == e1)
+				if (e0 == e1 || !lane_ok)
 					continue;
 				uint32_t x = ring[s * RSTR + wl];
 				if constexpr (SGN) {
@@ -611,7 +615,8 @@ __global__ __launch_bounds__(64 * NW, WGS_PER_CU) void backsolve_kernel(BsArgs b
 
 		// ---- phase C: write the chunk back ----
 		for (int s = slot0; s < ((b.dbg & 4) ? 0 : nrows); s += Geo::ROWS_PER_ITER)
-			*row_at((uint32_t) (ch.lo + s)) = ring[s * RSTR + wl];
+			if (lane_ok)
+				*row_at((uint32_t) (ch.lo + s)) = ring[s * RSTR + wl];
 		__syncthreads();          // (workgroup-scope release/acquire: later chunks read these rows; LDS metadata is free)
 		tick(5);          // phase C
 		if (k + 1 < b.nchunks)
@@ -1572,13 +1577,24 @@ void backsolve_plan(const FactPlan &P, spasm_hip_dfact *F, hipStream_t stream)
 		int shape = slabs_small <= (packed ? 2 * cus : cus) ? 2 : 0;
 		if (B.sgn && slabs_narrow <= 2 * cus && env_bs("SPASM_HIP_BS_NARROW", 0) != 0)
 			shape = 3;
+		// 4 / 5 = slabs of 10 / 12 words, as many waves as words (every wave ONE word of every row through phase B: passes of 64
+		// rows), chunks of 1,260 / 1,200 rows.  A workgroup's time is the vector work of its slab on ONE CU (phases A and B are
+		// ~61 and ~45 instructions per row and word) plus ~8,000 cycles of latency per chunk: narrower
+		// slabs mean less work per workgroup and more workgroups (207 instead of 155 on mk13.b5, on a chip of 256 CUs), thinner
+		// rows put more of them into the same LDS (fewer chunks), and the slab must stay wide enough for every workgroup to
+		// have a CU of its own -- 8 words would be 310 workgroups.
+		const int words = (B.Sm + 1) / 2;
+		// (twelve waves = three per SIMD on all four; ten leave two SIMDs with three and two with two, and the fuller ones set
+		//  the pace: 2.18 against 2.26 ms on mk13.b5, 2.66 for the 64-byte slabs of round 2)
+		if (B.sgn && env_bs("SPASM_HIP_BS_BALANCED", 1) != 0 && (words + 11) / 12 <= cus)
+			shape = 5;
 		shape = env_bs("SPASM_HIP_BS_SHAPE", shape);
-		if (shape == 3 && !B.sgn)
+		if (shape >= 3 && !B.sgn)
 			shape = 2;
 		B.shape = shape;
-		B.ring = BS_RING;
-		B.passrows = (shape == 3) ? 64 : BS_PASSROWS;
-		B.passcap = (shape == 3) ? 31 : BS_PASSCAP;
+		B.ring = (shape == 4) ? 1260 : (shape == 5) ? 1200 : BS_RING;
+		B.passrows = (shape >= 3) ? 64 : BS_PASSROWS;
+		B.passcap = (shape == 3) ? 31 : (shape == 4) ? 48 : (shape == 5) ? 44 : BS_PASSCAP;
 	}
 	const int PLAN_RING = B.ring, PLAN_PASSROWS = B.passrows, PLAN_PASSCAP = B.passcap;
 	const uint4 PLAN_EMPTY = uint4{(uint32_t) PLAN_RING, (uint32_t) PLAN_RING | ((uint32_t) PLAN_RING << 16), 0u, 0u};
@@ -1932,6 +1948,10 @@ void backsolve_build(const spasm_hip_dfact *F, hipStream_t stream)
 	const int shape = B.shape;
 	if (shape == 3)
 		snprintf(B.kernel_build, sizeof(B.kernel_build), "backsolve_kernel<true,true,8,8,true,768,64,31,2>");
+	else if (shape == 4)
+		snprintf(B.kernel_build, sizeof(B.kernel_build), "backsolve_kernel<true,true,10,10,true,1260,64,48,1>");
+	else if (shape == 5)
+		snprintf(B.kernel_build, sizeof(B.kernel_build), "backsolve_kernel<true,true,12,12,true,1200,64,44,1>");
 	else
 		snprintf(B.kernel_build, sizeof(B.kernel_build), "backsolve_kernel<%s,%s,%d,%d,%s,%d,%d,%d,1>", packed ? "true" : "false", B.plain ? "true" : "false",
 		         shape == 2 ? 16 : 32, (shape == 0 || (!packed && B.plain && shape == 1)) ? 16 : 8, B.sgn ? "true" : "false", BS_RING, BS_PASSROWS,
@@ -1939,6 +1959,10 @@ void backsolve_build(const spasm_hip_dfact *F, hipStream_t stream)
 	if (B.sgn) {
 		if (shape == 3)
 			launch_backsolve_variant<true, true, 8, 8, true, 768, 64, 31, 2>(b, B.Sm, stream, B);
+		else if (shape == 4)
+			launch_backsolve_variant<true, true, 10, 10, true, 1260, 64, 48, 1>(b, B.Sm, stream, B);
+		else if (shape == 5)
+			launch_backsolve_variant<true, true, 12, 12, true, 1200, 64, 44, 1>(b, B.Sm, stream, B);
 		else if (shape == 1)
 			launch_backsolve_variant<true, true, 32, 8, true>(b, B.Sm, stream, B);
 		else if (shape == 2)
