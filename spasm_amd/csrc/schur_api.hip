@@ -442,7 +442,7 @@ namespace sh {
 // On full batches the image won on all thirteen (1.05x on mk13.b4 ... 11x on mk13.b5), so the rule of round 2 (Sm <= 8192
 // or density >= 0.25) lost up to 1.7x on the four widest; a one-off batch of a few thousand rows does not pay for the build.
 // SPASM_HIP_BACKSOLVE=0 never, =1 whenever the factor has a plan; tests that force a tier or the row-group kernel
-// switch the image off; batches under 1024 rows (density samples, completion tests) never trigger a build.
+// switch the image off; batches under 1024 rows (density samples, completion tests) only trigger a build when Sm <= 8192.
 bool backsolve_wanted(const spasm_hip_dfact *F, bool other_path_forced, int nrows)
 {
 	const char *e = std::getenv("SPASM_HIP_BACKSOLVE");
@@ -461,9 +461,12 @@ bool backsolve_wanted(const spasm_hip_dfact *F, bool other_path_forced, int nrow
 		return false;
 	if (F->bs.valid)
 		return true;                      // R is there: a few of its rows per reduced row always beat an elimination
-	if (nrows < 1024)
-		return false;
 	const BsImage &B = F->bs;
+	// small batches (the driver's density sample of 100 rows, completion tests): rows of R of at most 8,192 entries are
+	// built at once -- at worst a small loss, and what follows on such a factor (the Schur complement, the dense finish)
+	// will want R anyway; wider factors are sampled row by row, which is also what measures their eliminations per row
+	if (nrows < 1024)
+		return B.Sm <= 8192;
 	const double eb = (F->prime < 65536) ? 2.0 : 4.0;
 	const double r = (double) B.r, Sm = (double) B.Sm, n = (double) nrows;
 	const double t_build = std::max(15e-6 * std::ceil(r / 768.0), (r + (double) B.ndeps) * Sm * eb / 2.1e12);

@@ -140,6 +140,11 @@ def test_default_path_follows_the_cost_model(oracle):
         W = spasm_amd.SchurWorkspace(len(rows), A.m, 1 << 30)
         S, st = spasm_amd.dschur(dA, sub, dF, W, fetch=False)
         assert st.status == 0 and st.used_backsolve == 0, (name, "one-off sub-batch")
+        # (a batch under 1,024 rows -- the driver's density sample -- builds R at once only when its rows are short)
+        tiny = drows[:100].contiguous()
+        S, st = spasm_amd.dschur(dA, tiny, dF, W, fetch=False)
+        assert st.status == 0 and st.used_backsolve == (1 if A.m - F.U.n <= 8192 else 0), (name, "density sample")
+        dF.forget()
         S, st = spasm_amd.dschur(dA, drows, dF, W, fetch=False)
         assert st.status == 0 and st.used_backsolve == 1, (name, "full batch")
         full_nnz = st.nnz
