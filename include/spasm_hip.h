@@ -315,6 +315,10 @@ int spasm_hip_dechelon_extend(i64 prime, int m, u32 *d_M, i64 ld, int k, int Sn,
 /* ======================================================================
  * (M) multi-GPU: one process per GPU, RCCL over xGMI (spasm_amd/csrc/dist_api.hip)
  *
+ * EXPERIMENTAL: this section has never run on more than one GPU (the test pool grants one per call).  What can be
+ * checked without a second GPU is: the exchange plan and the column split are pure host functions tested for every world
+ * size (tests/test_dist_cpu.py), the RCCL code runs in a world of one (tests/test_gpu_dist.py).
+ *
  * What shards is what the reference hands to its OpenMP threads: the rows of a Schur complement
  * (spasm_schur.c:86-171).  Every rank holds A and the factor and reduces a contiguous slice of the row list; the
  * slices are reassembled on the devices with an all-gatherv.  With a communicator installed, the entry points of
