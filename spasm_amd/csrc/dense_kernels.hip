@@ -2242,8 +2242,9 @@ int device_rref(int64_t prime, int n, int m, uint32_t *dA, int64_t ld, int *d_pi
 // pivots and the matrix is passed over once per 64 PIVOTS:
 //   A. Y -= Y[:, piv(E)] E                                     (matrix cores, K = k)
 //   B. for every panel of 64 rows of Y, until none of its rows is left without a pivot or non-zero:
-//        leftmost non-zero column of the rows still waiting -> a window of 256 columns starting at the smallest one;
-//        Gauss-Jordan of the 64 x 256 window in LDS (one workgroup) -> T (64 x 64) and the new pivot columns J;
+//        leftmost non-zero column of every row still waiting -> the first 256 pivot-free columns from the smallest one on,
+//        plus those 64 columns themselves; Gauss-Jordan of the 64 x 320 block in LDS (one workgroup) -> T (64 x 64) and
+//        the new pivot columns J;
 //        every row of the matrix, in ONE launch on the matrix cores:  C_i += sum_u M'[i][u] P_u  with the OLD panel rows P_u,
 //          M' = T - I on the panel's own rows, M'[i] = -C_i[J] T_J elsewhere (E and the earlier panels included: they stay reduced)
 //   C. the rows that hold a pivot move up behind E, in panel order.
@@ -2278,66 +2279,122 @@ __global__ __launch_bounds__(64) void rowpanel_leftmost(const uint32_t *P, int64
 		atomicMin(&left[row], best);
 }
 
-// Gauss-Jordan of the window P[:, w0 : w0 + RP_WIN) over the waiting rows, in row order, with the row transformation
-// accumulated in T (64 x 64, starts as the identity).  state[t] becomes the pivot column of row t when it finds one here.
-// newpiv[t] = that column for the rows that found a pivot in THIS call, -1 for the others.
-__global__ __launch_bounds__(256) void rowpanel_window(const uint32_t *P, int64_t ld, int m, int rows, int w0, int *state, int *newpiv, uint32_t *T_out, MontDev F)
+// Gauss-Jordan of the panel restricted to RP_COLS = 320 of its columns, in row order, with the row transformation
+// accumulated in T (64 x 64, starts as the identity).  The columns: the first 256 that hold no pivot yet from the smallest
+// leftmost entry of the waiting rows on -- dense rows (random combinations reduced by the echelon rows) have their first
+// entries there and get up to 64 pivots out of it; the pivot columns of the echelon rows and of the earlier panels, zero
+// in every waiting row, are skipped --, and the leftmost entry of EVERY waiting row (left[t]) -- sparse rows (the rows of a
+// sparse Schur complement themselves) have theirs far apart: the window alone caught one row in four on a ch8-8.b5 block
+// (288 steps for its 64 panels, each a pass over the whole stack; 155 with their own columns added); the leftmost entries
+// alone collapse to one or two distinct columns on dense rows (3,082 steps), five columns per row from its leftmost entry
+// on are no better than the window (272).  A row takes the first of these columns where it is still non-zero once the rows
+// before it have been eliminated; a row that is zero on all of them waits for the next step.
+// state[t] becomes the pivot column of row t when it finds one here; newpiv[t] = that column for the rows that found a
+// pivot in THIS call, -1 for the others.
+constexpr int RP_COLS = RP_WIN + RP_ROWS;
+
+__global__ __launch_bounds__(256) void rowpanel_window(const uint32_t *P, int64_t ld, int m, int rows, const int *left, int *state, int *newpiv,
+                                                       uint32_t *T_out, unsigned char *is_piv, MontDev F)
 {
 	extern __shared__ uint32_t rp_lds[];
-	uint32_t(*W)[RP_WIN + 1] = reinterpret_cast<uint32_t(*)[RP_WIN + 1]>(rp_lds);
-	uint32_t(*T)[RP_ROWS + 1] = reinterpret_cast<uint32_t(*)[RP_ROWS + 1]>(rp_lds + RP_ROWS * (RP_WIN + 1));
-	__shared__ int s_col[4];
-	__shared__ int s_state[RP_ROWS];
+	uint32_t(*W)[RP_COLS + 1] = reinterpret_cast<uint32_t(*)[RP_COLS + 1]>(rp_lds);
+	uint32_t(*T)[RP_ROWS + 1] = reinterpret_cast<uint32_t(*)[RP_ROWS + 1]>(rp_lds + RP_ROWS * (RP_COLS + 1));
+	__shared__ int cols[RP_COLS], s_state[RP_ROWS], s_pick[5], s_w0, s_count, wcnt[4];
+	__shared__ uint32_t fac[RP_ROWS];
 	const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-	for (int t = 0; t < RP_ROWS; t++) {
-		const int c = w0 + tid;
-		W[t][tid] = (c < m && t < rows) ? P[(int64_t) t * ld + c] : 0u;          // (the last panel may be short: its missing rows are zero, state -2)
-	}
-	for (int e = tid; e < RP_ROWS * RP_ROWS; e += 256)
-		T[e / RP_ROWS][e % RP_ROWS] = (e / RP_ROWS == e % RP_ROWS) ? 1u : 0u;
 	if (tid < RP_ROWS) {
-		s_state[tid] = state[tid];
+		const int st = state[tid];
+		s_state[tid] = st;
+		const int c = (st == -1 && tid < rows) ? left[tid] : 0x7FFFFFFF;
+		cols[RP_WIN + tid] = (c < m) ? c : -1;
 		newpiv[tid] = -1;
+		int w0 = (c < m) ? c : 0x7FFFFFFF;          // the smallest leftmost entry (wave 0 holds the 64 rows)
+		for (int d = 32; d >= 1; d >>= 1)
+			w0 = min(w0, __shfl_xor(w0, d));
+		if (tid == 0) {
+			s_w0 = w0;
+			s_count = 0;
+		}
+	}
+	cols[tid] = -1;
+	__syncthreads();
+	for (int base = s_w0, chunk = 0; base < m && chunk < 128; base += 256, chunk++) {
+		const int have = s_count;
+		if (have >= RP_WIN)
+			break;                           // (uniform: shared, read after a barrier)
+		const int c = base + tid;
+		const bool free_col = c < m && is_piv[c] == 0;
+		const uint64_t mask = __ballot(free_col);
+		if (lane == 0)
+			wcnt[wave] = __popcll(mask);
+		__syncthreads();
+		int before = have, all = 0;
+		for (int w2 = 0; w2 < 4; w2++) {
+			if (w2 < wave)
+				before += wcnt[w2];
+			all += wcnt[w2];
+		}
+		const int pos = before + __popcll(mask & ((1ull << lane) - 1ull));
+		if (free_col && pos < RP_WIN)
+			cols[pos] = c;
+		__syncthreads();
+		if (tid == 0)
+			s_count = have + all;
+		__syncthreads();
+	}
+	__syncthreads();
+	for (int t = 0; t < RP_ROWS; t++) {
+		for (int u = tid; u < RP_COLS; u += 256)
+			W[t][u] = (cols[u] >= 0 && t < rows) ? P[(int64_t) t * ld + cols[u]] : 0u;          // (the last panel may be short: its missing rows are zero, state -2)
+		if (tid < RP_ROWS)
+			T[t][tid] = (t == tid) ? 1u : 0u;
 	}
 	__syncthreads();
 	for (int t = 0; t < RP_ROWS; t++) {
 		if (s_state[t] != -1)
 			continue;                        // (uniform: shared)
-		// first non-zero entry of row t inside the window
-		const uint64_t mask = __ballot(W[t][tid] != 0);
-		if (lane == 0)
-			s_col[wave] = (mask != 0) ? wave * 64 + __builtin_ctzll(mask) : 0x7FFFFFFF;
+		// first non-zero entry of row t among the columns: the 256 of the window (one per thread), then the 64 leftmost entries (wave 0)
+		{
+			const uint64_t mask = __ballot(W[t][tid] != 0);
+			if (lane == 0)
+				s_pick[wave] = (mask != 0) ? wave * 64 + __builtin_ctzll(mask) : 0x7FFFFFFF;
+			if (wave == 0) {
+				const uint64_t mask2 = __ballot(W[t][RP_WIN + lane] != 0);
+				if (lane == 0)
+					s_pick[4] = (mask2 != 0) ? RP_WIN + __builtin_ctzll(mask2) : 0x7FFFFFFF;
+			}
+		}
 		__syncthreads();
-		const int c = min(min(s_col[0], s_col[1]), min(s_col[2], s_col[3]));
-		__syncthreads();
-		if (c == 0x7FFFFFFF)
-			continue;                        // nothing here: the row waits for a window further right
+		const int c = min(min(min(s_pick[0], s_pick[1]), min(s_pick[2], s_pick[3])), s_pick[4]);
+		if (c == 0x7FFFFFFF) {
+			__syncthreads();
+			continue;                        // zero on every column looked at: the row waits for the next step
+		}
 		const uint32_t inv = invmod(W[t][c], F);
-		// the factors of the other rows, before anything moves
-		__shared__ uint32_t fac[RP_ROWS];
+		const uint32_t wt = mulmod(W[t][tid], inv, F);
+		const uint32_t wt2 = (tid < RP_ROWS) ? mulmod(W[t][RP_WIN + tid], inv, F) : 0u, tt = (tid < RP_ROWS) ? mulmod(T[t][tid], inv, F) : 0u;
 		if (tid < RP_ROWS)
 			fac[tid] = (tid == t) ? 0u : W[tid][c];
 		__syncthreads();
-		// scale row t ( window | T )
-		const uint32_t wt = mulmod(W[t][tid], inv, F);
 		W[t][tid] = wt;
-		uint32_t tt = 0;
 		if (tid < RP_ROWS) {
-			tt = mulmod(T[t][tid], inv, F);
+			W[t][RP_WIN + tid] = wt2;
 			T[t][tid] = tt;
 		}
-		__syncthreads();
 		for (int s2 = 0; s2 < RP_ROWS; s2++) {
 			const uint32_t f = fac[s2];
 			if (f == 0)
 				continue;                    // (uniform)
 			W[s2][tid] = submod(W[s2][tid], mulmod(f, wt, F), F);
-			if (tid < RP_ROWS)
+			if (tid < RP_ROWS) {
+				W[s2][RP_WIN + tid] = submod(W[s2][RP_WIN + tid], mulmod(f, wt2, F), F);
 				T[s2][tid] = submod(T[s2][tid], mulmod(f, tt, F), F);
+			}
 		}
 		if (tid == 0) {
-			s_state[t] = w0 + c;
-			newpiv[t] = w0 + c;
+			s_state[t] = cols[c];
+			newpiv[t] = cols[c];
+			is_piv[cols[c]] = 1;
 		}
 		__syncthreads();
 	}
@@ -2345,6 +2402,13 @@ __global__ __launch_bounds__(256) void rowpanel_window(const uint32_t *P, int64_
 		state[tid] = s_state[tid];
 	for (int e = tid; e < RP_ROWS * RP_ROWS; e += 256)
 		T_out[e] = T[e / RP_ROWS][e % RP_ROWS];
+}
+
+__global__ __launch_bounds__(256) void rowpanel_mark_pivots(const int *piv, int k, unsigned char *is_piv)
+{
+	const int t = blockIdx.x * 256 + threadIdx.x;
+	if (t < k)
+		is_piv[piv[t]] = 1;
 }
 
 // digit planes of the multipliers of one panel step, for every row i of the matrix (n rows):
@@ -2444,7 +2508,11 @@ int device_echelon_extend(int64_t prime, int m, uint32_t *dM, int64_t ld, int k,
 	int *d_left = (int *) dal(RP_ROWS * sizeof(int));
 	int *d_newpiv = (int *) dal(RP_ROWS * sizeof(int));
 	uint32_t *d_T = (uint32_t *) dal(RP_ROWS * RP_ROWS * sizeof(uint32_t));
-	const size_t win_lds = ((size_t) RP_ROWS * (RP_WIN + 1) + (size_t) RP_ROWS * (RP_ROWS + 1)) * sizeof(uint32_t);
+	unsigned char *d_ispiv = (unsigned char *) dal((size_t) m);
+	HIP_CHECK(hipMemsetAsync(d_ispiv, 0, (size_t) m, stream));
+	if (k > 0)
+		hipLaunchKernelGGL(rowpanel_mark_pivots, dim3((k + 255) / 256), dim3(256), 0, stream, d_piv, k, d_ispiv);
+	const size_t win_lds = ((size_t) RP_ROWS * (RP_COLS + 1) + (size_t) RP_ROWS * (RP_ROWS + 1)) * sizeof(uint32_t);
 	static bool configured = false;
 	if (!configured) {
 		HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(&rowpanel_window), hipFuncAttributeMaxDynamicSharedMemorySize, (int) win_lds));
@@ -2457,6 +2525,8 @@ int device_echelon_extend(int64_t prime, int m, uint32_t *dM, int64_t ld, int k,
 		Bl = Bh + (size_t) m * 64;
 	};
 
+	const double t_start = wtime();
+	int total_iters = 0;
 	// ---- A. the rows of Y lose the pivot columns of E ----
 	for (int t0 = 0; t0 < k; t0 += 64 * SETS) {
 		const int count = std::min(k - t0, 64 * SETS);
@@ -2483,6 +2553,7 @@ int device_echelon_extend(int64_t prime, int m, uint32_t *dM, int64_t ld, int k,
 		HIP_CHECK(hipStreamSynchronize(stream));          // (cnt dies here)
 	}
 
+	const double t_A = wtime();
 	// ---- B. panels of 64 rows of Y ----
 	std::vector<int> pivot_of((size_t) Sn, -1);          // pivot column of every row of Y, -1: none (the row became zero)
 	const int panel_rows[2] = {64, Sn % RP_ROWS};          // d_cnt[0]: a full panel, d_cnt[1]: the last, short one
@@ -2501,8 +2572,7 @@ int device_echelon_extend(int64_t prime, int m, uint32_t *dM, int64_t ld, int k,
 			int left[RP_ROWS];
 			HIP_CHECK(hipMemcpyAsync(left, d_left, sizeof(left), hipMemcpyDeviceToHost, stream));
 			HIP_CHECK(hipStreamSynchronize(stream));
-			int w0 = 0x7FFFFFFF;
-			bool changed = false;
+			bool changed = false, waiting = false;
 			for (int t = 0; t < rows_here; t++) {
 				if (state[t] != -1)
 					continue;
@@ -2510,10 +2580,10 @@ int device_echelon_extend(int64_t prime, int m, uint32_t *dM, int64_t ld, int k,
 					state[t] = -2;           // the row is zero: it depended on the rows before it
 					changed = true;
 				} else {
-					w0 = std::min(w0, left[t]);
+					waiting = true;
 				}
 			}
-			if (w0 == 0x7FFFFFFF)
+			if (!waiting)
 				break;                       // every row of the panel has a pivot or is zero
 			if (changed)
 				HIP_CHECK(hipMemcpyAsync(d_state, state, sizeof(state), hipMemcpyHostToDevice, stream));
@@ -2523,7 +2593,8 @@ int device_echelon_extend(int64_t prime, int m, uint32_t *dM, int64_t ld, int k,
 			signed char *Mh, *Ml, *Bh, *Bl;
 			planes_of_set(0, Mh, Ml, Bh, Bl);
 			hipLaunchKernelGGL(rref_split_B, dim3((m + 255) / 256), dim3(256), 0, stream, P, (int) ld, d_cnt + (rows_here == RP_ROWS ? 0 : 1), Bh, Bl, F);
-			hipLaunchKernelGGL(rowpanel_window, dim3(1), dim3(256), win_lds, stream, P, ld, m, rows_here, w0, d_state, d_newpiv, d_T, F);
+			hipLaunchKernelGGL(rowpanel_window, dim3(1), dim3(256), win_lds, stream, P, ld, m, rows_here, d_left, d_state, d_newpiv, d_T, d_ispiv, F);
+			total_iters += 1;
 			hipLaunchKernelGGL(rowpanel_multipliers, dim3((n + 63) / 64), dim3(256), 0, stream, dM, ld, n, k + r0, d_newpiv, d_T, Mh, Ml, F);
 			UpdSets S{};
 			S.Mh[0] = Mh;
@@ -2539,6 +2610,7 @@ int device_echelon_extend(int64_t prime, int m, uint32_t *dM, int64_t ld, int k,
 			pivot_of[(size_t) r0 + t] = (state[t] >= 0) ? state[t] : -1;
 	}
 
+	const double t_B = wtime();
 	// ---- C. the rows with a pivot move up behind E ----
 	std::vector<int> src, piv_new;
 	for (int i = 0; i < Sn; i++)
@@ -2563,6 +2635,9 @@ int device_echelon_extend(int64_t prime, int m, uint32_t *dM, int64_t ld, int k,
 	HIP_CHECK(hipStreamSynchronize(stream));
 	for (void *ptr : owned)
 		big_free(ptr);
+	if (verbose() >= 2)
+		logmsg("[echelon rows] %d + %d rows x %d: reduction by the echelon rows %.1f ms, %d panels in %d steps %.1f ms, compaction %.1f ms; %d new\n", k, Sn, m,
+		       1e3 * (t_A - t_start), (Sn + RP_ROWS - 1) / RP_ROWS, total_iters, 1e3 * (t_B - t_A), 1e3 * (wtime() - t_B), rr);
 	return k + rr;
 }
 
