@@ -2463,6 +2463,34 @@ __global__ __launch_bounds__(256) void rowpanel_multipliers(const uint32_t *C, i
 	*reinterpret_cast<int4 *>(Ml + (int64_t) i * 64 + q * 16) = make_int4((int) wl[0], (int) wl[1], (int) wl[2], (int) wl[3]);
 }
 
+// digit planes of M'[i][u] = - C[i][piv[u]]  (0 where piv[u] < 0 and on the rows [skip_lo, skip_hi)): what clears the pivot
+// columns of up to 64 rows that are reduced among themselves from the rows of C.  blockIdx.y = set (its pivots: piv + 64 * set).
+__global__ __launch_bounds__(256) void rowpanel_neg_columns(const uint32_t *C, int64_t ld, int n, int skip_lo, int skip_hi, const int *piv, signed char *Mplanes,
+                                                            int64_t set_stride, int64_t low_offset, MontDev F)
+{
+	__shared__ int sJ[RP_ROWS];
+	const int tid = threadIdx.x;
+	if (tid < RP_ROWS)
+		sJ[tid] = piv[blockIdx.y * RP_ROWS + tid];
+	__syncthreads();
+	const int i = blockIdx.x * 64 + (tid & 63), q = tid >> 6;          // row, quarter of the 64 multipliers
+	if (i >= n)
+		return;
+	const bool skip = i >= skip_lo && i < skip_hi;
+	unsigned int wh[4] = {0, 0, 0, 0}, wl[4] = {0, 0, 0, 0};
+	for (int u = 0; u < 16; u++) {
+		const int j = sJ[q * 16 + u];
+		const uint32_t c = (skip || j < 0) ? 0u : C[(int64_t) i * ld + j];
+		int hi, lo;
+		split_digits(c == 0 ? 0u : F.p - c, F, hi, lo);
+		wh[u >> 2] |= (unsigned int) (hi & 255) << (8 * (u & 3));
+		wl[u >> 2] |= (unsigned int) (lo & 255) << (8 * (u & 3));
+	}
+	signed char *Mh = Mplanes + blockIdx.y * set_stride, *Ml = Mh + low_offset;
+	*reinterpret_cast<int4 *>(Mh + (int64_t) i * 64 + q * 16) = make_int4((int) wh[0], (int) wh[1], (int) wh[2], (int) wh[3]);
+	*reinterpret_cast<int4 *>(Ml + (int64_t) i * 64 + q * 16) = make_int4((int) wl[0], (int) wl[1], (int) wl[2], (int) wl[3]);
+}
+
 // Z[i][t] = - Y[i][piv[t0 + t]]  for the rows of Y and a run of echelon pivots (step A), 0 beyond the run
 __global__ __launch_bounds__(256) void rowpanel_gather_neg(const uint32_t *Y, int64_t ld, int n, const int *piv, int t0, int count, uint32_t *Z, int64_t ldz, MontDev F)
 {
@@ -2555,18 +2583,59 @@ int device_echelon_extend(int64_t prime, int m, uint32_t *dM, int64_t ld, int k,
 
 	const double t_A = wtime();
 	// ---- B. panels of 64 rows of Y ----
+	// A panel in progress only touches its own 64 rows; the rows of a finished panel are reduced among themselves, so its
+	// pivot columns leave every other row with the entries of these columns as multipliers, in one pass.  Finished panels
+	// wait (at most SETS of them: rows [pend_base, pend_base + 64 npend) of Y, pivots in d_pend) and are kept reduced by
+	// one another -- (i) and (iii) below, on 64 (npend) rows --; the pass over the whole stack, which is what costs, is
+	// made once for SETS panels, with SETS x 64 multipliers a row.
 	std::vector<int> pivot_of((size_t) Sn, -1);          // pivot column of every row of Y, -1: none (the row became zero)
 	const int panel_rows[2] = {64, Sn % RP_ROWS};          // d_cnt[0]: a full panel, d_cnt[1]: the last, short one
 	HIP_CHECK(hipMemcpyAsync(d_cnt, panel_rows, sizeof(panel_rows), hipMemcpyHostToDevice, stream));
 	HIP_CHECK(hipStreamSynchronize(stream));
+	int *d_pend = (int *) dal((size_t) SETS * RP_ROWS * sizeof(int));
+	int npend = 0, pend_base = 0, passes = 0;
+	auto split_panel = [&](int row0, int set) {          // the rows [row0, row0 + 64) of Y as the B planes of `set`
+		signed char *Mh, *Ml, *Bh, *Bl;
+		planes_of_set(set, Mh, Ml, Bh, Bl);
+		hipLaunchKernelGGL(rref_split_B, dim3((m + 255) / 256), dim3(256), 0, stream, Y + (int64_t) row0 * ld, (int) ld, d_cnt + (Sn - row0 >= RP_ROWS ? 0 : 1), Bh, Bl, F);
+	};
+	auto clear_columns = [&](uint32_t *C, int rows, int skip_lo, int skip_hi, const int *piv, int nsets) {          // C -= C[:, piv] * (B planes of the sets)
+		hipLaunchKernelGGL(rowpanel_neg_columns, dim3((rows + 63) / 64, nsets), dim3(256), 0, stream, C, ld, rows, skip_lo, skip_hi, piv, Mplanes, (int64_t) 2 * n * 64,
+		                   (int64_t) n * 64, F);
+		UpdSets S{};
+		for (int s = 0; s < nsets; s++) {
+			signed char *Mh, *Ml, *Bh, *Bl;
+			planes_of_set(s, Mh, Ml, Bh, Bl);
+			S.Mh[s] = Mh;
+			S.Ml[s] = Ml;
+			S.Bh[s] = Bh;
+			S.Bl[s] = Bl;
+		}
+		S.nsets = nsets;
+		hipLaunchKernelGGL(rref_update_mfma_multi, dim3((m + 63) / 64, (rows + 63) / 64), dim3(256), 0, stream, C, ld, rows, 0, m, S, F);
+	};
+	auto flush = [&]() {          // the pivots of the waiting panels leave every other row of the stack
+		if (npend == 0)
+			return;
+		for (int s = 0; s < npend; s++)
+			split_panel(pend_base + RP_ROWS * s, s);
+		clear_columns(dM, n, k + pend_base, k + pend_base + RP_ROWS * npend, d_pend, npend);
+		passes += 1;
+		npend = 0;
+	};
 	for (int r0 = 0; r0 < Sn; r0 += RP_ROWS) {
 		const int rows_here = std::min(RP_ROWS, Sn - r0);
 		uint32_t *P = Y + (int64_t) r0 * ld;
+		if (npend > 0) {          // (i) the panel loses the pivot columns of the waiting panels
+			for (int s = 0; s < npend; s++)
+				split_panel(pend_base + RP_ROWS * s, s);
+			clear_columns(P, rows_here, -1, -1, d_pend, npend);
+		}
 		int state[RP_ROWS];
 		for (int t = 0; t < RP_ROWS; t++)
 			state[t] = (t < rows_here) ? -1 : -2;
 		HIP_CHECK(hipMemcpyAsync(d_state, state, sizeof(state), hipMemcpyHostToDevice, stream));
-		for (int iter = 0;; iter++) {
+		for (int iter = 0;; iter++) {          // (ii) its rows find their pivots
 			HIP_CHECK(hipMemsetAsync(d_left, 0x7F, RP_ROWS * sizeof(int), stream));          // 0x7F7F7F7F: larger than any column
 			hipLaunchKernelGGL(rowpanel_leftmost, dim3((m + 1023) / 1024, rows_here), dim3(64), 0, stream, P, ld, m, d_state, d_left);
 			int left[RP_ROWS];
@@ -2583,32 +2652,50 @@ int device_echelon_extend(int64_t prime, int m, uint32_t *dM, int64_t ld, int k,
 					waiting = true;
 				}
 			}
-			if (!waiting)
-				break;                       // every row of the panel has a pivot or is zero
 			if (changed)
 				HIP_CHECK(hipMemcpyAsync(d_state, state, sizeof(state), hipMemcpyHostToDevice, stream));
+			if (!waiting)
+				break;                       // every row of the panel has a pivot or is zero
 			if (iter > RP_ROWS + 2)
 				die("device_echelon_extend: a panel did not finish in %d window steps", iter);
-			// the OLD rows of the panel as digit planes, then T and the new pivots, then one update of every row
+			// the OLD rows of the panel as digit planes, then T and the new pivots, then P <- T P
 			signed char *Mh, *Ml, *Bh, *Bl;
 			planes_of_set(0, Mh, Ml, Bh, Bl);
-			hipLaunchKernelGGL(rref_split_B, dim3((m + 255) / 256), dim3(256), 0, stream, P, (int) ld, d_cnt + (rows_here == RP_ROWS ? 0 : 1), Bh, Bl, F);
+			split_panel(r0, 0);
 			hipLaunchKernelGGL(rowpanel_window, dim3(1), dim3(256), win_lds, stream, P, ld, m, rows_here, d_left, d_state, d_newpiv, d_T, d_ispiv, F);
 			total_iters += 1;
-			hipLaunchKernelGGL(rowpanel_multipliers, dim3((n + 63) / 64), dim3(256), 0, stream, dM, ld, n, k + r0, d_newpiv, d_T, Mh, Ml, F);
+			hipLaunchKernelGGL(rowpanel_multipliers, dim3(1), dim3(256), 0, stream, P, ld, rows_here, 0, d_newpiv, d_T, Mh, Ml, F);
 			UpdSets S{};
 			S.Mh[0] = Mh;
 			S.Ml[0] = Ml;
 			S.Bh[0] = Bh;
 			S.Bl[0] = Bl;
 			S.nsets = 1;
-			hipLaunchKernelGGL(rref_update_mfma_multi, dim3((m + 63) / 64, (n + 63) / 64), dim3(256), 0, stream, dM, ld, n, 0, m, S, F);
+			hipLaunchKernelGGL(rref_update_mfma_multi, dim3((m + 63) / 64, 1), dim3(256), 0, stream, P, ld, rows_here, 0, m, S, F);
 			HIP_CHECK(hipMemcpyAsync(state, d_state, sizeof(state), hipMemcpyDeviceToHost, stream));
 			HIP_CHECK(hipStreamSynchronize(stream));
 		}
+		HIP_CHECK(hipStreamSynchronize(stream));          // (state may have just gone up)
 		for (int t = 0; t < rows_here; t++)
 			pivot_of[(size_t) r0 + t] = (state[t] >= 0) ? state[t] : -1;
+		bool any = false;
+		for (int t = 0; t < rows_here; t++)
+			any = any || state[t] >= 0;
+		if (!any && npend == 0)
+			continue;                        // nothing but zero rows, and no panel waits: nothing to pass on
+		if (npend > 0) {          // (iii) the waiting panels lose its pivot columns
+			split_panel(r0, 0);
+			clear_columns(Y + (int64_t) pend_base * ld, RP_ROWS * npend, -1, -1, d_state, 1);
+		} else {
+			pend_base = r0;
+		}
+		HIP_CHECK(hipMemcpyAsync(d_pend + (size_t) npend * RP_ROWS, d_state, RP_ROWS * sizeof(int), hipMemcpyDeviceToDevice, stream));
+		npend += 1;
+		if (npend == SETS)
+			flush();
 	}
+	flush();
+	HIP_CHECK(hipStreamSynchronize(stream));
 
 	const double t_B = wtime();
 	// ---- C. the rows with a pivot move up behind E ----
@@ -2636,8 +2723,8 @@ int device_echelon_extend(int64_t prime, int m, uint32_t *dM, int64_t ld, int k,
 	for (void *ptr : owned)
 		big_free(ptr);
 	if (verbose() >= 2)
-		logmsg("[echelon rows] %d + %d rows x %d: reduction by the echelon rows %.1f ms, %d panels in %d steps %.1f ms, compaction %.1f ms; %d new\n", k, Sn, m,
-		       1e3 * (t_A - t_start), (Sn + RP_ROWS - 1) / RP_ROWS, total_iters, 1e3 * (t_B - t_A), 1e3 * (wtime() - t_B), rr);
+		logmsg("[echelon rows] %d + %d rows x %d: reduction by the echelon rows %.1f ms, %d panels in %d steps and %d passes %.1f ms, compaction %.1f ms; %d new\n",
+		       k, Sn, m, 1e3 * (t_A - t_start), (Sn + RP_ROWS - 1) / RP_ROWS, total_iters, passes, 1e3 * (t_B - t_A), 1e3 * (wtime() - t_B), rr);
 	return k + rr;
 }
 
