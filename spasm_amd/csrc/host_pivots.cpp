@@ -26,6 +26,8 @@ spasm_hip_comm *current_comm();
 int comm_rank(const spasm_hip_comm *c);
 int comm_world(const spasm_hip_comm *c);
 void comm_bcast_host(spasm_hip_comm *c, void *buf, size_t bytes, int root);
+// pivots_device.hip: the greedy search on the device; -1 = does not apply here (no device, too many columns, switched off)
+int device_acyclic_greedy(const struct spasm_csr *A, int *pinv, int *qinv);
 }  // namespace sh
 
 namespace sh {
@@ -456,7 +458,13 @@ extern "C" int spasm_hip_pivots_extract_structural(const struct spasm_csr *A, co
 				threads = usable_cpus();
 			if (A->n < 20000)
 				threads = 1;                  // small inputs: the sequential search (deterministic) is as fast
-			extra = (threads > 1) ? S.acyclic_greedy_threads(threads) : S.acyclic_greedy();
+			extra = (threads > 1) ? device_acyclic_greedy(A, S.pinv.data(), S.qinv.data()) : -1;
+			if (extra < 0) {
+				const char *where = std::getenv("SPASM_HIP_PIVOT_SEARCH");
+				if (threads > 1 && where != nullptr && std::strcmp(where, "device") == 0)
+					die("SPASM_HIP_PIVOT_SEARCH=device: the search on the device does not apply to this %d x %d matrix here", n, m);
+				extra = (threads > 1) ? S.acyclic_greedy_threads(threads) : S.acyclic_greedy();
+			}
 			npiv += extra;
 			logmsg("[pivots] greedy alternating cycle-free search: %d pivots found [%.1fs]\n", extra, wtime() - t1);
 		}

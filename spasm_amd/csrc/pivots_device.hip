@@ -1,0 +1,466 @@
+// The greedy cycle-free pivot search (spasm_pivots.c:147-305, step 3 of host_pivots.cpp) on the device.
+//
+// The search is a breadth-first walk per candidate row through "the other columns of the pivot row of column c"; the host
+// version spends 11-21 ns per visited pivot row and thread, 16 threads at most on these boxes (cgroup quota), and it is
+// 65-80 % of an echelonization of the stand-in matrices.  Here one WAVEFRONT searches one row, 64 frontier columns per
+// step, with the set of reached columns as one bit per column in LDS (m / 8 bytes: 47 KB for the 376,320 columns of
+// ch8-8.b5, three searches per CU) and hundreds of searches in flight.  The transactions are those of the threaded host
+// search (acyclic_greedy_threads): a wave explores against the pivots it can see, replays the journal of pivots committed
+// meanwhile on its own marks, and commits -- but not under a lock, nor by a compare-and-swap on the length of the journal
+// (the first version: with 2,048 searches in flight every commit sent hundreds of waiting waves back to replay one entry
+// and fail their swap again, 720 attempts per pivot on mk13.b5, 20 us per commit).  A wave that has a pivot draws a
+// TICKET (one atomic add, never refused), writes its proposal there, and looks at the tickets drawn between its last replay
+// and its own: if one of them -- accepted, or still undecided -- falls on a column this search has marked, it withdraws
+// (ABORTED), replays and goes on; otherwise its pivot is ACCEPTED.  Serialized by ticket number this is the sequential
+// algorithm: an accepted ticket has seen every accepted ticket before it, either in a replay or as one that does not touch
+// it.  Nobody waits for a chain: a ticket is decided a few loads after it was drawn, whatever the tickets before it do.
+// As with threads, the set of pivots depends on timing; it is always cycle-free.
+//
+// What waves hand to each other inside the launch -- the pivot records, the journal, the counter -- is written and read
+// with agent-scope atomic stores and loads (write-through `sc1` stores, L1-bypassing `sc1` loads); a committer drains its
+// record stores (s_waitcnt vmcnt(0)) before it stores the journal entry that announces them.  Everything else a wave
+// touches in global memory is either read-only in the launch (A, the rows that had a pivot before) or its own (its FIFO).
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cstdint>
+#include <cstdlib>
+#include <cstring>
+#include <vector>
+
+#include "common.h"
+#include "device_types.h"
+
+namespace sh {
+namespace {
+
+typedef int64_t i64;
+typedef unsigned long long u64;
+
+// record of a pivotal column, four 8-byte words: {len, e0} {e1, e2} {e3, e4} {e5, e6}.  len 0: not pivotal; len > 0: the
+// other columns of its row; len < 0: the row is too long (or has nothing else) and e0 is its index in A.
+constexpr int REC_WORDS = 4, REC_ENTS = 7;
+
+struct PsCtrl {
+	int tickets;         // tickets drawn = length of the journal
+	int prefix;          // every ticket below is decided (a lower bound, raised by whoever replays)
+	int next_row;
+	int status;          // 0 ok, 1: a bounded spin gave up (the host search takes over)
+	int overflowed;      // rows given up because their FIFO was full
+	u64 visits, attempts;
+};
+
+#define RLX_AGENT __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT
+
+int env_int(const char *name, int dflt)
+{
+	const char *e = std::getenv(name);
+	return (e == nullptr || *e == 0) ? dflt : std::atoi(e);
+}
+
+__device__ __forceinline__ int ld_i32(const int *p) { return __hip_atomic_load(p, RLX_AGENT); }
+__device__ __forceinline__ u64 ld_u64(const u64 *p) { return __hip_atomic_load(p, RLX_AGENT); }
+__device__ __forceinline__ void st_i32(int *p, int v) { __hip_atomic_store(p, v, RLX_AGENT); }
+__device__ __forceinline__ void st_u64(u64 *p, u64 v) { __hip_atomic_store(p, v, RLX_AGENT); }
+__device__ __forceinline__ void drain() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
+__device__ __forceinline__ u64 pack2(int lo, int hi) { return (u64) (uint32_t) lo | ((u64) (uint32_t) hi << 32); }
+
+// records of the pivots the host found (Faugere-Lachartre), one thread per column
+__global__ __launch_bounds__(256) void pivot_records_kernel(const i64 *Ap, const int *Aj, const int *qinv, int m, u64 *rec)
+{
+	const int col = blockIdx.x * 256 + threadIdx.x;
+	if (col >= m)
+		return;
+	const int row = qinv[col];
+	int len = 0, ent[REC_ENTS] = {0, 0, 0, 0, 0, 0, 0};
+	if (row >= 0) {
+		const i64 lo = Ap[row], hi = Ap[row + 1];
+		if (hi - lo - 1 > REC_ENTS || hi - lo - 1 <= 0) {
+			len = -1;
+			ent[0] = row;
+		} else {
+			for (i64 px = lo; px < hi; px++) {
+				const int j = Aj[px];
+				if (j != col)
+					ent[len++] = j;
+			}
+			if (len == 0) {
+				len = -1;
+				ent[0] = row;
+			}
+		}
+	}
+	u64 *R = rec + (size_t) col * REC_WORDS;
+	R[0] = pack2(len, ent[0]);
+	R[1] = pack2(ent[1], ent[2]);
+	R[2] = pack2(ent[3], ent[4]);
+	R[3] = pack2(ent[5], ent[6]);
+}
+
+// journal entry of a ticket, ONE 8-byte word: column | state << 32; 0 = not written yet
+constexpr u64 PS_PENDING = 1, PS_ACCEPTED = 2, PS_ABORTED = 3;
+__device__ __forceinline__ u64 entry(int col, u64 state) { return (u64) (uint32_t) col | (state << 32); }
+
+constexpr int PS_ROWS_PER_GRAB = 8;
+constexpr unsigned PS_SPIN_LIMIT = 1u << 24;
+
+// one wavefront per workgroup; LDS: the reached-bit of every column, then the candidate columns of the row (one per lane)
+__global__ __launch_bounds__(64) void pivot_search_kernel(const i64 *Ap, const int *Aj, const int *pinv, int n, int m, int words, u64 *rec, u64 *jent, int *jrow,
+                                                          PsCtrl *ctrl, int *fifo_all, int fifo_cap, int jcap)
+{
+	extern __shared__ __attribute__((aligned(16))) uint32_t ps_lds[];
+	uint32_t *bits = ps_lds;
+	int *cand = reinterpret_cast<int *>(ps_lds + words);
+	int *tmp = cand + 64;
+	const int lane = threadIdx.x;
+	const u64 below = (1ull << lane) - 1ull;
+	int *fifo = fifo_all + (size_t) blockIdx.x * fifo_cap;
+	u64 visits = 0, attempts = 0;
+	bool dead = false;          // a bounded spin gave up somewhere: leave
+
+	for (;;) {
+		int first = 0;
+		if (lane == 0)
+			first = atomicAdd(&ctrl->next_row, PS_ROWS_PER_GRAB);
+		first = __shfl(first, 0);
+		if (first >= n || dead)
+			break;
+		for (int i = first; i < min(n, first + PS_ROWS_PER_GRAB) && !dead; i++) {
+			if (pinv[i] >= 0)
+				continue;
+			if (ld_i32(&ctrl->status) != 0) {
+				dead = true;
+				break;
+			}
+			for (int w = lane * 4; w < words; w += 256)
+				*reinterpret_cast<uint4 *>(bits + w) = make_uint4(0, 0, 0, 0);
+			// every ticket below `seen` is decided, and the records of the accepted ones are complete
+			int seen = ld_i32(&ctrl->prefix);
+			__builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+			int head = 0, tail = 0, ncand = 0;
+			bool overflow = false;
+			auto push = [&](bool pred, int j) {
+				const u64 mask = __ballot(pred);
+				if (mask == 0)
+					return;
+				const int pos = tail + __popcll(mask & below);
+				if (pred && pos < fifo_cap)
+					fifo[pos] = j;
+				tail += __popcll(mask);
+				if (tail > fifo_cap) {
+					tail = fifo_cap;
+					overflow = true;
+				}
+			};
+			auto reach = [&](bool valid, int j) {          // the column becomes reached; queued if it was not
+				bool fresh = false;
+				if (valid) {
+					const uint32_t bit = 1u << (j & 31);
+					fresh = (atomicOr(&bits[j >> 5], bit) & bit) == 0;
+				}
+				push(fresh, j);
+			};
+			const i64 row_lo = Ap[i], row_hi = Ap[i + 1];
+			for (i64 px0 = row_lo; px0 < row_hi; px0 += 64) {
+				const bool valid = px0 + lane < row_hi;
+				const int j = valid ? Aj[px0 + lane] : 0;
+				const int len = valid ? (int) (uint32_t) ld_u64(rec + (size_t) j * REC_WORDS) : 0;
+				reach(valid && len != 0, j);
+				const bool is_cand = valid && len == 0;
+				const u64 mask = __ballot(is_cand);
+				const int pos = ncand + __popcll(mask & below);
+				if (is_cand && pos < 64)
+					cand[pos] = j;
+				// a row with more than 64 columns without a pivot: the others are not eligible, but they ARE entries of this row --
+				// marked reached, so that a pivot committed on one of them meanwhile is explored like any pivotal entry
+				if (is_cand && pos >= 64)
+					atomicOr(&bits[j >> 5], 1u << (j & 31));
+				ncand = min(64, ncand + __popcll(mask));
+			}
+			// candidates still unreached (one per lane)
+			auto alive = [&]() -> u64 {
+				bool a = false;
+				if (lane < ncand) {
+					const int j = cand[lane];
+					a = (bits[j >> 5] & (1u << (j & 31))) == 0;
+				}
+				return __ballot(a);
+			};
+			bool committed = false;
+			for (;;) {
+				u64 live = alive();
+				while (head < tail && live != 0 && !overflow) {
+					drain();                     // (the FIFO entries pushed by the step before are in memory)
+					const int cnt = min(64, tail - head);
+					const int c = (lane < cnt) ? fifo[head + lane] : -1;
+					head += cnt;
+					int len = 0, e[REC_ENTS] = {0, 0, 0, 0, 0, 0, 0};
+					if (c >= 0) {
+						const u64 *R = rec + (size_t) c * REC_WORDS;
+						const u64 r0 = ld_u64(R);
+						len = (int) (uint32_t) r0;
+						e[0] = (int) (r0 >> 32);
+						if (len > 1) {
+							const u64 r1 = ld_u64(R + 1);
+							e[1] = (int) (uint32_t) r1;
+							e[2] = (int) (r1 >> 32);
+							if (len > 3) {
+								const u64 r2 = ld_u64(R + 2);
+								e[3] = (int) (uint32_t) r2;
+								e[4] = (int) (r2 >> 32);
+								if (len > 5) {
+									const u64 r3 = ld_u64(R + 3);
+									e[5] = (int) (uint32_t) r3;
+									e[6] = (int) (r3 >> 32);
+								}
+							}
+						}
+					}
+					visits += (u64) __popcll(__ballot(len != 0));
+#pragma unroll
+					for (int t = 0; t < REC_ENTS; t++)
+						reach(t < len, e[t]);
+					// pivot rows too long for a record: the wave walks them one by one
+					for (u64 longs = __ballot(len < 0); longs != 0; longs &= longs - 1) {
+						const int row = __shfl(e[0], __builtin_ctzll(longs));
+						const i64 lo = Ap[row], hi = Ap[row + 1];
+						for (i64 px0 = lo; px0 < hi; px0 += 64) {
+							const bool valid = px0 + lane < hi;
+							reach(valid, valid ? Aj[px0 + lane] : 0);
+						}
+					}
+					live = alive();
+				}
+				if (live == 0 || overflow)
+					break;                       // every candidate is reached: no pivot on this row
+				// does column j of another search's pivot fall on our marks?  (a reached column, or a candidate of ours)
+				auto touches = [&](int j, bool &was_reached) {
+					const uint32_t bit = 1u << (j & 31);
+					was_reached = (bits[j >> 5] & bit) != 0;
+					if (was_reached)
+						return true;
+					for (int k = 0; k < ncand; k++)
+						if (cand[k] == j)
+							return true;
+					return false;
+				};
+				// replay the tickets decided since the last look on our marks: an accepted pivot that fell on a candidate of ours
+				// makes it reached, one on a reached column has a row we must explore; the others cannot be reached from this row
+				const int target = min(jcap, ld_i32(&ctrl->tickets));
+				const int seen_before = seen;
+				bool touched = false;
+				while (seen < target && !dead) {
+					const int t = seen + lane;
+					const bool valid = t < target;
+					u64 g = 0;
+					unsigned spins = 0;
+					for (;;) {
+						if (valid && (g >> 32) < PS_ACCEPTED)
+							g = ld_u64(jent + t);
+						if (__ballot(valid && (g >> 32) < PS_ACCEPTED) == 0)
+							break;
+						if (++spins > PS_SPIN_LIMIT) {
+							dead = true;
+							break;
+						}
+					}
+					if (dead)
+						break;
+					__builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+					const int j = (int) (uint32_t) g;
+					bool hit = false;
+					if (valid && (g >> 32) == PS_ACCEPTED) {
+						bool was_reached;
+						hit = touches(j, was_reached);
+						if (hit && !was_reached)
+							atomicOr(&bits[j >> 5], 1u << (j & 31));
+					}
+					push(hit, j);
+					touched = touched || __ballot(hit) != 0;
+					seen = min(target, seen + 64);
+				}
+				if (dead)
+					break;
+				if (seen > seen_before && lane == 0)
+					atomicMax(&ctrl->prefix, seen);
+				if (touched)
+					continue;
+				// the first candidate of the row that is still unreached goes on a ticket
+				const int chosen = cand[__builtin_ctzll(live)];
+				attempts += 1;
+				int ticket = 0;
+				if (lane == 0) {
+					ticket = atomicAdd(&ctrl->tickets, 1);
+					if (ticket < jcap) {
+						st_i32(jrow + ticket, i);
+						st_u64(jent + ticket, entry(chosen, PS_PENDING));
+					}
+				}
+				ticket = __shfl(ticket, 0);
+				if (ticket >= jcap) {                // (the journal is full: more withdrawals than anyone planned for)
+					dead = true;
+					break;
+				}
+				// the tickets drawn since the replay: written a few cycles after they were drawn, decided or not
+				bool conflict = false;
+				for (int t0 = seen; t0 < ticket && !dead; t0 += 64) {
+					const int t = t0 + lane;
+					const bool valid = t < ticket;
+					u64 g = 0;
+					unsigned spins = 0;
+					for (;;) {
+						if (valid && g == 0)
+							g = ld_u64(jent + t);
+						if (__ballot(valid && g == 0) == 0)
+							break;
+						if (++spins > PS_SPIN_LIMIT) {
+							dead = true;
+							break;
+						}
+					}
+					bool hit = false;
+					if (valid && !dead && (g >> 32) != PS_ABORTED) {
+						bool was_reached;
+						hit = touches((int) (uint32_t) g, was_reached);
+					}
+					conflict = conflict || __ballot(hit) != 0;
+				}
+				if (dead)
+					break;
+				if (conflict) {
+					if (lane == 0)
+						st_u64(jent + ticket, entry(chosen, PS_ABORTED));
+					continue;
+				}
+				// accepted: its record, then the journal entry that announces it
+				{
+					const i64 others = row_hi - row_lo - 1;
+					u64 *R = rec + (size_t) chosen * REC_WORDS;
+					if (others > REC_ENTS || others <= 0) {
+						if (lane == 0)
+							st_u64(R, pack2(-1, i));
+					} else {
+						const bool valid = row_lo + lane < row_hi;
+						const int j = valid ? Aj[row_lo + lane] : 0;
+						const bool other = valid && j != chosen;
+						const u64 mask = __ballot(other);
+						if (lane < REC_ENTS)
+							tmp[lane] = 0;
+						if (other)
+							tmp[__popcll(mask & below)] = j;
+						const int len = __popcll(mask);
+						if (lane == 0) {
+							st_u64(R + 1, pack2(tmp[1], tmp[2]));
+							st_u64(R + 2, pack2(tmp[3], tmp[4]));
+							st_u64(R + 3, pack2(tmp[5], tmp[6]));
+							drain();
+							st_u64(R, len > 0 ? pack2(len, tmp[0]) : pack2(-1, i));
+						}
+					}
+					if (lane == 0) {
+						drain();
+						st_u64(jent + ticket, entry(chosen, PS_ACCEPTED));
+					}
+				}
+				committed = true;
+				break;
+			}
+			(void) committed;
+			if (overflow && lane == 0)
+				atomicAdd(&ctrl->overflowed, 1);
+		}
+	}
+	if (dead && lane == 0)
+		st_i32(&ctrl->status, 1);
+	if (lane == 0) {
+		atomicAdd(&ctrl->visits, visits);
+		atomicAdd(&ctrl->attempts, attempts);
+	}
+}
+
+}  // namespace
+
+// The search on the device.  pinv / qinv: the pivots found so far (row -> column, column -> row, -1 = none), extended in
+// place.  Returns the number of new pivots, or -1 when the search does not apply here -- no device, the switch
+// SPASM_HIP_PIVOT_SEARCH=host, more columns than one bit per column in 64 KB of LDS covers -- or gave up; the caller then
+// runs the host search (which is the same algorithm: this is a matter of speed, the result is a valid set either way).
+int device_acyclic_greedy(const struct spasm_csr *A, int *pinv, int *qinv)
+{
+	const int n = A->n, m = A->m;
+	if (const char *e = std::getenv("SPASM_HIP_PIVOT_SEARCH"))
+		if (std::strcmp(e, "host") == 0)
+			return -1;
+	int ndev = 0;
+	if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) {
+		(void) hipGetLastError();
+		return -1;
+	}
+	const int words = ((m + 31) / 32 + 255) / 256 * 256;          // (cleared 256 words at a time)
+	const size_t lds = (size_t) words * 4 + (64 + 8) * sizeof(int);
+	if (n <= 0 || m <= 0 || lds > 64 * 1024)
+		return -1;
+	const double t0 = wtime();
+	hipStream_t stream = nullptr;
+	DeviceMatrix dA(A, stream);
+	int dev = 0, cus = 256;
+	HIP_CHECK(hipGetDevice(&dev));
+	HIP_CHECK(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev));
+	const int per_cu = std::max(1, std::min(env_int("SPASM_HIP_PIVOT_WAVES_PER_CU", 8), (int) ((160 * 1024) / lds)));
+	const int grid = cus * per_cu;
+	const int fifo_cap = m + 4096;
+	std::vector<void *> owned;
+	auto dal = [&](size_t bytes) {
+		void *ptr = big_alloc(bytes);
+		owned.push_back(ptr);
+		return ptr;
+	};
+	u64 *rec = (u64 *) dal((size_t) m * REC_WORDS * sizeof(u64));
+	int *d_pinv = (int *) dal((size_t) n * sizeof(int));
+	int *d_qinv = (int *) dal((size_t) m * sizeof(int));
+	const size_t jcap = (size_t) 8 * n + 65536;          // tickets: one per accepted pivot (<= n) and one per withdrawal
+	u64 *jent = (u64 *) dal(jcap * sizeof(u64));
+	int *jrow = (int *) dal(jcap * sizeof(int));
+	PsCtrl *ctrl = (PsCtrl *) dal(sizeof(PsCtrl));
+	int *fifo = (int *) dal((size_t) grid * fifo_cap * sizeof(int));
+	HIP_CHECK(hipMemcpyAsync(d_pinv, pinv, (size_t) n * sizeof(int), hipMemcpyHostToDevice, stream));
+	HIP_CHECK(hipMemcpyAsync(d_qinv, qinv, (size_t) m * sizeof(int), hipMemcpyHostToDevice, stream));
+	HIP_CHECK(hipMemsetAsync(jent, 0, jcap * sizeof(u64), stream));
+	HIP_CHECK(hipMemsetAsync(ctrl, 0, sizeof(PsCtrl), stream));
+	hipLaunchKernelGGL(pivot_records_kernel, dim3((m + 255) / 256), dim3(256), 0, stream, dA.p, dA.j, d_qinv, m, rec);
+	hipLaunchKernelGGL(pivot_search_kernel, dim3(grid), dim3(64), lds, stream, dA.p, dA.j, d_pinv, n, m, words, rec, jent, jrow, ctrl, fifo, fifo_cap, (int) jcap);
+	PsCtrl c;
+	HIP_CHECK(hipMemcpyAsync(&c, ctrl, sizeof(PsCtrl), hipMemcpyDeviceToHost, stream));
+	HIP_CHECK(hipStreamSynchronize(stream));
+	int found = -1;
+	if (c.status == 0) {
+		const int tickets = std::min(c.tickets, (int) jcap);
+		std::vector<u64> ent((size_t) std::max(tickets, 1));
+		std::vector<int> rows((size_t) std::max(tickets, 1));
+		if (tickets > 0) {
+			HIP_CHECK(hipMemcpy(ent.data(), jent, (size_t) tickets * sizeof(u64), hipMemcpyDeviceToHost));
+			HIP_CHECK(hipMemcpy(rows.data(), jrow, (size_t) tickets * sizeof(int), hipMemcpyDeviceToHost));
+		}
+		found = 0;
+		for (int t = 0; t < tickets; t++) {
+			const u64 state = ent[t] >> 32;
+			const int col = (int) (uint32_t) ent[t];
+			if (state == PS_ABORTED)
+				continue;
+			if (state != PS_ACCEPTED || rows[t] < 0 || rows[t] >= n || col < 0 || col >= m || pinv[rows[t]] != -1 || qinv[col] != -1)
+				die("device pivot search: ticket %d = (row %d, column %d, state %llu) is not a new pivot", t, rows[t], col, state);
+			pinv[rows[t]] = col;
+			qinv[col] = rows[t];
+			found += 1;
+		}
+		if (std::getenv("SPASM_HIP_PIVOT_STATS"))
+			logmsg("[pivots] device: %d searches in flight (%d per CU, %zu bytes of LDS each), %llu pivot rows visited, %d tickets for %d pivots, "
+			       "%d rows given up (FIFO full) [%.3fs]\n", grid, per_cu, lds, c.visits, c.tickets, found, c.overflowed, wtime() - t0);
+	} else {
+		logmsg("[pivots] device search gave up (a wait ran out): the host search takes over\n");
+	}
+	for (void *ptr : owned)
+		big_free(ptr);
+	return found;
+}
+
+}  // namespace sh

@@ -1,0 +1,89 @@
+"""The greedy cycle-free pivot search on the device (spasm_amd/csrc/pivots_device.hip) against the properties the
+reference's own search guarantees (spasm_pivots.c:147-305): every pivot is an entry of its row, rows and columns are
+used once, and the pivot graph -- pivotal column -> the other pivotal columns of its row -- has no cycle, which is what
+makes the rows of U triangular up to a permutation.  The set of pivots itself depends on timing, in the reference
+(OpenMP) as here, so it is compared in size with the host search, and in rank at the end of an echelonization."""
+import os
+import sys
+
+import numpy as np
+import pytest
+import scipy.sparse as sp
+from scipy.sparse.csgraph import connected_components
+
+import spasm_amd
+from spasm_amd.matrix import Csr
+
+sys.path.insert(0, os.path.join(os.path.dirname(__file__), "..", "tools"))
+import workloads  # noqa: E402
+
+pytestmark = pytest.mark.gpu
+
+
+def _random_matrix(n, m, seed, max_len, prime):
+    rng = np.random.default_rng(seed)
+    lens = rng.integers(1, max_len + 1, size=n)
+    lens[rng.integers(0, n, size=n // 50)] = rng.integers(65, 200, size=n // 50)          # some rows longer than a wavefront
+    p = np.zeros(n + 1, np.int64)
+    np.cumsum(lens, out=p[1:])
+    j = np.zeros(int(p[n]), np.int32)
+    for i in range(n):
+        j[p[i]:p[i + 1]] = rng.choice(m, size=int(lens[i]), replace=False)
+    x = rng.integers(1, prime, size=int(p[n])).astype(np.int32)
+    return Csr(n, m, p, j, x, prime)
+
+
+def _search(A, where):
+    old = os.environ.get("SPASM_HIP_PIVOT_SEARCH")
+    os.environ["SPASM_HIP_PIVOT_SEARCH"] = where
+    try:
+        return spasm_amd.pivots_extract_structural(A, spasm_amd.empty_fact(A.m, A.prime))
+    finally:
+        if old is None:
+            del os.environ["SPASM_HIP_PIVOT_SEARCH"]
+        else:
+            os.environ["SPASM_HIP_PIVOT_SEARCH"] = old
+
+
+def _check(A, npiv, perm, F):
+    U = F.U
+    assert U.n == npiv
+    piv_col = U.j[U.p[:npiv]]
+    assert len(np.unique(piv_col)) == npiv                        # one pivot per column
+    assert len(np.unique(perm[:npiv])) == npiv                    # ... and per row
+    assert np.all(U.x[U.p[:npiv]] == 1)
+    assert np.array_equal(F.qinv[piv_col], np.arange(npiv))
+    # the pivotal rows are rows of A, scaled: same columns
+    for t in np.random.default_rng(1).integers(0, npiv, size=200):
+        i = perm[t]
+        assert sorted(U.j[U.p[t]:U.p[t + 1]]) == sorted(A.j[A.p[i]:A.p[i + 1]])
+    # pivot graph: row t -> the rows whose pivot column it touches
+    lens = np.diff(U.p[:npiv + 1])
+    src = np.repeat(np.arange(npiv), lens)
+    dst = F.qinv[U.j[:U.p[npiv]]]
+    keep = (dst >= 0) & (dst != src)
+    G = sp.csr_matrix((np.ones(int(keep.sum()), np.int8), (src[keep], dst[keep])), shape=(npiv, npiv))
+    ncomp, _ = connected_components(G, directed=True, connection="strong")
+    assert ncomp == npiv                                          # no cycle
+    # the reference's order: a row only touches pivot columns of rows that come later (spasm_pivots.c:307-372)
+    assert np.all(dst[keep] > src[keep])
+
+
+@pytest.mark.parametrize("shape", [(30000, 20000, 6), (40000, 60000, 12), (25000, 9000, 3)])
+def test_device_search_on_random_matrices(shape):
+    n, m, max_len = shape
+    A = _random_matrix(n, m, seed=n + m, max_len=max_len, prime=65521)
+    npiv, perm, F = _search(A, "device")
+    _check(A, npiv, perm, F)
+    npiv_h, perm_h, F_h = _search(A, "host")
+    _check(A, npiv_h, perm_h, F_h)
+    assert abs(npiv - npiv_h) <= 0.03 * npiv_h
+
+
+@pytest.mark.parametrize("name", ["mk13.b5", "ch7-8.b5"])
+def test_device_search_on_stand_ins(name):
+    A, _ = workloads.load_matrix(name)
+    npiv, perm, F = _search(A, "device")
+    _check(A, npiv, perm, F)
+    npiv_h, _, _ = _search(A, "host")
+    assert abs(npiv - npiv_h) <= 0.03 * npiv_h
