@@ -366,6 +366,27 @@ struct Search {
 		return npiv.load();
 	}
 
+	// is the order p of the pivotal rows triangular: does every pivotal row only touch pivot columns of rows after it?
+	bool triangular(int npiv, const int *p) const
+	{
+		std::vector<int> when((size_t) (A->n > 0 ? A->n : 1), -1);
+		for (int t = 0; t < npiv; t++)
+			when[p[t]] = t;
+		for (int t = 0; t < npiv; t++) {
+			const int i = p[t];
+			if (pinv[i] < 0)
+				return false;
+			for (i64 px = A->p[i]; px < A->p[i + 1]; px++) {
+				const int j = A->j[px];
+				if (j == pinv[i] || qinv[j] < 0)
+					continue;
+				if (when[qinv[j]] <= t)
+					return false;
+			}
+		}
+		return true;
+	}
+
 	// reverse post-order of the pivot graph: a pivotal column precedes all
 	// the pivotal columns its row touches
 	void topological_rows(int npiv, int *p) const
@@ -443,6 +464,7 @@ extern "C" int spasm_hip_pivots_extract_structural(const struct spasm_csr *A, co
 	const bool dist = comm != nullptr && comm_world(comm) > 1;
 	int npiv = 0;
 	if (!dist || comm_rank(comm) == 0) {
+		bool ordered = false;
 		npiv = S.leftmost_entries();
 		logmsg("[pivots] Faugere-Lachartre: %d pivots found [%.1fs]\n", npiv, wtime() - t0);
 		double t1 = wtime();
@@ -458,7 +480,25 @@ extern "C" int spasm_hip_pivots_extract_structural(const struct spasm_csr *A, co
 				threads = usable_cpus();
 			if (A->n < 20000)
 				threads = 1;                  // small inputs: the sequential search (deterministic) is as fast
+			// on the device when there is one (pivots_device.hip); what comes back is checked -- the order below must be
+			// triangular -- before anything is built on it
+			std::vector<int> pinv0, qinv0;
+			if (threads > 1) {
+				pinv0 = S.pinv;
+				qinv0 = S.qinv;
+			}
 			extra = (threads > 1) ? device_acyclic_greedy(A, S.pinv.data(), S.qinv.data()) : -1;
+			if (extra >= 0) {
+				S.topological_rows(npiv + extra, p);
+				if (!S.triangular(npiv + extra, p)) {
+					std::fprintf(stderr, "[pivots] the pivots of the device search are NOT cycle-free (a bug: please report); discarded, searching on the host\n");
+					S.pinv = pinv0;
+					S.qinv = qinv0;
+					extra = -1;
+				} else {
+					ordered = true;
+				}
+			}
 			if (extra < 0) {
 				const char *where = std::getenv("SPASM_HIP_PIVOT_SEARCH");
 				if (threads > 1 && where != nullptr && std::strcmp(where, "device") == 0)
@@ -469,7 +509,8 @@ extern "C" int spasm_hip_pivots_extract_structural(const struct spasm_csr *A, co
 			logmsg("[pivots] greedy alternating cycle-free search: %d pivots found [%.1fs]\n", extra, wtime() - t1);
 		}
 		logmsg("[pivots] %d pivots found\n", npiv);
-		S.topological_rows(npiv, p);
+		if (!ordered)
+			S.topological_rows(npiv, p);
 
 	}
 	if (dist) {

@@ -422,6 +422,7 @@ int device_acyclic_greedy(const struct spasm_csr *A, int *pinv, int *qinv)
 	int *jrow = (int *) dal(jcap * sizeof(int));
 	PsCtrl *ctrl = (PsCtrl *) dal(sizeof(PsCtrl));
 	int *fifo = (int *) dal((size_t) grid * fifo_cap * sizeof(int));
+	const double t_alloc = wtime();
 	HIP_CHECK(hipMemcpyAsync(d_pinv, pinv, (size_t) n * sizeof(int), hipMemcpyHostToDevice, stream));
 	HIP_CHECK(hipMemcpyAsync(d_qinv, qinv, (size_t) m * sizeof(int), hipMemcpyHostToDevice, stream));
 	HIP_CHECK(hipMemsetAsync(jent, 0, jcap * sizeof(u64), stream));
@@ -431,6 +432,7 @@ int device_acyclic_greedy(const struct spasm_csr *A, int *pinv, int *qinv)
 	PsCtrl c;
 	HIP_CHECK(hipMemcpyAsync(&c, ctrl, sizeof(PsCtrl), hipMemcpyDeviceToHost, stream));
 	HIP_CHECK(hipStreamSynchronize(stream));
+	const double t_run = wtime();
 	int found = -1;
 	if (c.status == 0) {
 		const int tickets = std::min(c.tickets, (int) jcap);
@@ -454,7 +456,8 @@ int device_acyclic_greedy(const struct spasm_csr *A, int *pinv, int *qinv)
 		}
 		if (std::getenv("SPASM_HIP_PIVOT_STATS"))
 			logmsg("[pivots] device: %d searches in flight (%d per CU, %zu bytes of LDS each), %llu pivot rows visited, %d tickets for %d pivots, "
-			       "%d rows given up (FIFO full) [%.3fs]\n", grid, per_cu, lds, c.visits, c.tickets, found, c.overflowed, wtime() - t0);
+			       "%d rows given up (FIFO full) [%.3fs: %.3f upload of A + allocations, %.3f kernels, %.3f journal]\n", grid, per_cu, lds, c.visits, c.tickets, found,
+			       c.overflowed, wtime() - t0, t_alloc - t0, t_run - t_alloc, wtime() - t_run);
 	} else {
 		logmsg("[pivots] device search gave up (a wait ran out): the host search takes over\n");
 	}
