@@ -14,6 +14,8 @@ int device_rref(int64_t prime, int n, int m, uint32_t *dA, int64_t ld, int *d_pi
 int device_lu(int64_t prime, int n, int m, uint32_t *dA, int64_t ld, int *dP, int *dQ, hipStream_t stream);
 int device_echelon_extend(int64_t prime, int m, uint32_t *dM, int64_t ld, int k, int Sn, int *d_piv, hipStream_t stream);
 spasm_hip_dfact *cached_dfact(const struct spasm_csr *U, const int *qinv, hipStream_t stream);
+void launch_split_rows(const int64_t *Sp, int N, int pieces, int64_t *out, hipStream_t stream);
+void launch_sum_pieces(const uint32_t *parts, int64_t ldp, int N, int pieces, int m, uint32_t p, uint32_t *out, int64_t ldo, hipStream_t stream);
 void launch_combine(const int64_t *Ap, const int *Aj, const int *Ax, const int *rows, int nrows, int N, int w, int m,
                     uint64_t salt, unsigned long long *Y, const Mont &M, hipStream_t stream);
 void launch_dense_count(const unsigned long long *Y, int N, int m, uint32_t p, int *row_len, hipStream_t stream);
@@ -268,8 +270,32 @@ void device_random_dense_rows(const spasm_hip_dcsr &dA, const int *d_rows, int n
 	HIP_CHECK(hipStreamSynchronize(stream));
 	const double t1 = wtime();
 	big_free(dY);
-	spasm_hip_dcsr dYcsr{N, m, ynnz, dYp, dYj, dYx};
-	dschur_dense_impl(&dYcsr, dident, N, F, W, d_S, ldS, stream, nullptr);
+	// a few very long rows: cut into pieces that are reduced side by side and added up (launch_split_rows)
+	const int Sm = F->Sm;
+	int pieces = 1;
+	if (N <= 64 && ynnz / N >= 8192 && env_int("SPASM_HIP_SPLIT_LONG_ROWS", 1) != 0)
+		pieces = (int) std::min<i64>(std::min<i64>(64, W->max_rows / N), (ynnz / N + 2047) / 2048);
+	if (pieces > 1) {
+		const int NP = N * pieces;
+		i64 *dYp2 = dalloc<i64>((i64) NP + 1);
+		launch_split_rows(dYp, N, pieces, dYp2, stream);
+		std::vector<int> ident2((size_t) NP);
+		for (int k = 0; k < NP; k++)
+			ident2[k] = k;
+		int *dident2 = dalloc<int>(NP);
+		HIP_CHECK(hipMemcpyAsync(dident2, ident2.data(), (size_t) NP * sizeof(int), hipMemcpyHostToDevice, stream));
+		u32 *parts = (u32 *) big_alloc((size_t) NP * (size_t) Sm * sizeof(u32));
+		spasm_hip_dcsr dYcsr{NP, m, ynnz, dYp2, dYj, dYx};
+		dschur_dense_impl(&dYcsr, dident2, NP, F, W, parts, Sm, stream, nullptr);
+		launch_sum_pieces(parts, Sm, N, pieces, Sm, (uint32_t) F->prime, d_S, ldS, stream);
+		HIP_CHECK(hipStreamSynchronize(stream));
+		big_free(parts);
+		(void) hipFree(dident2);
+		(void) hipFree(dYp2);
+	} else {
+		spasm_hip_dcsr dYcsr{N, m, ynnz, dYp, dYj, dYx};
+		dschur_dense_impl(&dYcsr, dident, N, F, W, d_S, ldS, stream, nullptr);
+	}
 	if (verbose() >= 2)
 		logmsg("[dense rows] %d combinations: combine + pack %.3fs (%" PRId64 " entries), reduction %.3fs\n", N, t1 - t0, ynnz, wtime() - t1);
 	(void) hipFree(dident);
@@ -376,9 +402,10 @@ bool finish_on_device(const struct spasm_csr *A, const int *p, int n, struct spa
 	// column-panel RREF of the whole stack [E; Y], which is at its best there.  SPASM_HIP_ROW_PANELS=0/1 forces the choice.
 	const int rp_env = env_int("SPASM_HIP_ROW_PANELS", -1);
 	const bool row_panels = prime <= 65279 && (rp_env > 0 || (rp_env < 0 && Sm0 >= env_int("SPASM_HIP_ROW_PANELS_MIN_COLS", 16384)));
+	const bool row_panels_later = prime <= 65279 && rp_env != 0 && env_int("SPASM_HIP_ROW_PANELS_LATER", 1) != 0;
 	auto stack_and_reduce = [&](int rows_added) {
 		const double t0 = wtime();
-		const int rk = row_panels ? device_echelon_extend(prime, Sm0, dM, ld, k, rows_added, dpiv, stream)
+		const int rk = (row_panels || (row_panels_later && k > 0)) ? device_echelon_extend(prime, Sm0, dM, ld, k, rows_added, dpiv, stream)
 		                          : spasm_hip_drref(prime, k + rows_added, Sm0, dM, ld, dpiv, stream);
 		t_rref += wtime() - t0;
 		const int rr = rk - k;

@@ -2931,6 +2931,47 @@ void launch_dense_count(const unsigned long long *Y, int N, int m, uint32_t p, i
 	HIP_CHECK(hipGetLastError());
 }
 
+// A sparse row is reduced by one wavefront, entry after entry, and the reduction is linear in the row: a FEW very long rows
+// (the handful of combinations of ALL the rows that ends a low-rank finish: 9 rows of 133,000 entries on mk13.b5, 28 ms
+// on nine waves) are cut into `pieces` consecutive runs each -- the same entries under more row pointers --, every run is
+// reduced as a row of its own and the dense results are added up.
+__global__ __launch_bounds__(256) void split_rows_kernel(const int64_t *Sp, int N, int pieces, int64_t *out)
+{
+	const int idx = blockIdx.x * 256 + threadIdx.x;
+	if (idx > N * pieces)
+		return;
+	if (idx == N * pieces) {
+		out[idx] = Sp[N];
+		return;
+	}
+	const int k = idx / pieces, s = idx % pieces;
+	const int64_t lo = Sp[k], len = Sp[k + 1] - lo;
+	out[idx] = lo + len * s / pieces;
+}
+
+__global__ __launch_bounds__(256) void sum_pieces_kernel(const uint32_t *parts, int64_t ldp, int pieces, int m, uint32_t p, uint32_t *out, int64_t ldo)
+{
+	const int k = blockIdx.y;
+	for (int c = blockIdx.x * 256 + threadIdx.x; c < m; c += gridDim.x * 256) {
+		unsigned long long acc = 0;
+		for (int s = 0; s < pieces; s++)
+			acc += parts[((int64_t) k * pieces + s) * ldp + c];
+		out[(int64_t) k * ldo + c] = (uint32_t) (acc % p);
+	}
+}
+
+void launch_split_rows(const int64_t *Sp, int N, int pieces, int64_t *out, hipStream_t stream)
+{
+	hipLaunchKernelGGL(split_rows_kernel, dim3((N * pieces + 1 + 255) / 256), dim3(256), 0, stream, Sp, N, pieces, out);
+	HIP_CHECK(hipGetLastError());
+}
+
+void launch_sum_pieces(const uint32_t *parts, int64_t ldp, int N, int pieces, int m, uint32_t p, uint32_t *out, int64_t ldo, hipStream_t stream)
+{
+	hipLaunchKernelGGL(sum_pieces_kernel, dim3((m + 255) / 256, N), dim3(256), 0, stream, parts, ldp, pieces, m, p, out, ldo);
+	HIP_CHECK(hipGetLastError());
+}
+
 void launch_dense_pack(const unsigned long long *Y, int N, int m, uint32_t p, const int64_t *Sp, int *Sj, int *Sx,
                        hipStream_t stream)
 {
