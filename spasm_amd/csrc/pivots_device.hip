@@ -37,9 +37,37 @@ namespace {
 typedef int64_t i64;
 typedef unsigned long long u64;
 
-// record of a pivotal column, four 8-byte words: {len, e0} {e1, e2} {e3, e4} {e5, e6}.  len 0: not pivotal; len > 0: the
-// other columns of its row; len < 0: the row is too long (or has nothing else) and e0 is its index in A.
-constexpr int REC_WORDS = 4, REC_ENTS = 7;
+// record of a pivotal column, 16 bytes = ONE load per visited pivot row (the search is bound by the rate of these requests:
+// with four 8-byte words per record 512 searches in flight were as fast as 2,048).  Bits [0, 3): 0 = not pivotal, 1..6 =
+// that many other columns of its row follow, 20 bits each (this search is for m <= 2^19: one bit per column in 64 KB of LDS);
+// 7 = the row is too long for that (or has nothing else) and bits [3, 35) are its index in A.
+constexpr int REC_WORDS = 2, REC_ENTS = 6, REC_LONG = 7, REC_BITS = 20;
+
+__host__ __device__ inline void rec_put(unsigned long long &lo, unsigned long long &hi, int k, unsigned long long v)
+{
+	const int off = 3 + REC_BITS * k;
+	if (off < 64) {
+		lo |= v << off;
+		if (off + REC_BITS > 64)
+			hi |= v >> (64 - off);
+	} else {
+		hi |= v << (off - 64);
+	}
+}
+
+__host__ __device__ inline int rec_get(unsigned long long lo, unsigned long long hi, int k)
+{
+	const int off = 3 + REC_BITS * k;
+	unsigned long long v;
+	if (off < 64) {
+		v = lo >> off;
+		if (off + REC_BITS > 64)
+			v |= hi << (64 - off);
+	} else {
+		v = hi >> (off - 64);
+	}
+	return (int) (v & ((1ull << REC_BITS) - 1ull));
+}
 
 struct PsCtrl {
 	int tickets;         // tickets drawn = length of the journal
@@ -47,7 +75,10 @@ struct PsCtrl {
 	int next_row;
 	int status;          // 0 ok, 1: a bounded spin gave up (the host search takes over)
 	int overflowed;      // rows given up because their FIFO was full
-	u64 visits, attempts;
+	u64 visits, attempts, steps;
+	u64 c_search, c_commit, c_total;                 // wave-cycles (s_memtime): in the walk, in replay + ticket, in all
+	u64 t_start, t_first_exit, t_last_exit;          // wall_clock64() (100 MHz): first wave in, first wave out of rows, last wave out
+	u64 longest_search;                              // ... and the longest time one row took
 };
 
 #define RLX_AGENT __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT
@@ -62,8 +93,16 @@ __device__ __forceinline__ int ld_i32(const int *p) { return __hip_atomic_load(p
 __device__ __forceinline__ u64 ld_u64(const u64 *p) { return __hip_atomic_load(p, RLX_AGENT); }
 __device__ __forceinline__ void st_i32(int *p, int v) { __hip_atomic_store(p, v, RLX_AGENT); }
 __device__ __forceinline__ void st_u64(u64 *p, u64 v) { __hip_atomic_store(p, v, RLX_AGENT); }
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+// one 16-byte L1-bypassing load (global_load_dwordx4 sc1), waited for on the spot
+__device__ __forceinline__ void ld_rec(const u64 *p, u64 &lo, u64 &hi)
+{
+	u32x4 r;
+	asm volatile("global_load_dwordx4 %0, %1, off sc1\n\ts_waitcnt vmcnt(0)" : "=v"(r) : "v"(p) : "memory");
+	lo = (u64) r.x | ((u64) r.y << 32);
+	hi = (u64) r.z | ((u64) r.w << 32);
+}
 __device__ __forceinline__ void drain() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
-__device__ __forceinline__ u64 pack2(int lo, int hi) { return (u64) (uint32_t) lo | ((u64) (uint32_t) hi << 32); }
 
 // records of the pivots the host found (Faugere-Lachartre), one thread per column
 __global__ __launch_bounds__(256) void pivot_records_kernel(const i64 *Ap, const int *Aj, const int *qinv, int m, u64 *rec)
@@ -72,29 +111,25 @@ __global__ __launch_bounds__(256) void pivot_records_kernel(const i64 *Ap, const
 	if (col >= m)
 		return;
 	const int row = qinv[col];
-	int len = 0, ent[REC_ENTS] = {0, 0, 0, 0, 0, 0, 0};
+	u64 lo = 0, hi = 0;
 	if (row >= 0) {
-		const i64 lo = Ap[row], hi = Ap[row + 1];
-		if (hi - lo - 1 > REC_ENTS || hi - lo - 1 <= 0) {
-			len = -1;
-			ent[0] = row;
+		const i64 first = Ap[row], last = Ap[row + 1];
+		const i64 others = last - first - 1;
+		if (others > REC_ENTS || others <= 0) {
+			lo = (u64) REC_LONG | ((u64) (uint32_t) row << 3);
 		} else {
-			for (i64 px = lo; px < hi; px++) {
+			int len = 0;
+			for (i64 px = first; px < last; px++) {
 				const int j = Aj[px];
-				if (j != col)
-					ent[len++] = j;
+				if (j != col && len < REC_ENTS)
+					rec_put(lo, hi, len++, (u64) j);
 			}
-			if (len == 0) {
-				len = -1;
-				ent[0] = row;
-			}
+			lo |= (len > 0) ? (u64) len : (u64) REC_LONG | ((u64) (uint32_t) row << 3);
 		}
 	}
 	u64 *R = rec + (size_t) col * REC_WORDS;
-	R[0] = pack2(len, ent[0]);
-	R[1] = pack2(ent[1], ent[2]);
-	R[2] = pack2(ent[3], ent[4]);
-	R[3] = pack2(ent[5], ent[6]);
+	R[0] = lo;
+	R[1] = hi;
 }
 
 // journal entry of a ticket, ONE 8-byte word: column | state << 32; 0 = not written yet
@@ -113,10 +148,14 @@ __global__ __launch_bounds__(64) void pivot_search_kernel(const i64 *Ap, const i
 	int *cand = reinterpret_cast<int *>(ps_lds + words);
 	int *tmp = cand + 64;
 	const int lane = threadIdx.x;
+	const int spare = words + 64 + 8 + lane;          // a word of LDS of this lane's own, for atomics that must do nothing
 	const u64 below = (1ull << lane) - 1ull;
 	int *fifo = fifo_all + (size_t) blockIdx.x * fifo_cap;
-	u64 visits = 0, attempts = 0;
+	u64 visits = 0, attempts = 0, longest = 0, steps = 0, c_search = 0, c_commit = 0;
+	const u64 c_begin = clock64();
 	bool dead = false;          // a bounded spin gave up somewhere: leave
+	if (lane == 0)
+		atomicMin(&ctrl->t_start, wall_clock64());
 
 	for (;;) {
 		int first = 0;
@@ -132,6 +171,7 @@ __global__ __launch_bounds__(64) void pivot_search_kernel(const i64 *Ap, const i
 				dead = true;
 				break;
 			}
+			const u64 t_row = wall_clock64();
 			for (int w = lane * 4; w < words; w += 256)
 				*reinterpret_cast<uint4 *>(bits + w) = make_uint4(0, 0, 0, 0);
 			// every ticket below `seen` is decided, and the records of the accepted ones are complete
@@ -164,7 +204,7 @@ __global__ __launch_bounds__(64) void pivot_search_kernel(const i64 *Ap, const i
 			for (i64 px0 = row_lo; px0 < row_hi; px0 += 64) {
 				const bool valid = px0 + lane < row_hi;
 				const int j = valid ? Aj[px0 + lane] : 0;
-				const int len = valid ? (int) (uint32_t) ld_u64(rec + (size_t) j * REC_WORDS) : 0;
+				const int len = valid ? (int) (ld_u64(rec + (size_t) j * REC_WORDS) & 7ull) : 0;
 				reach(valid && len != 0, j);
 				const bool is_cand = valid && len == 0;
 				const u64 mask = __ballot(is_cand);
@@ -189,40 +229,48 @@ __global__ __launch_bounds__(64) void pivot_search_kernel(const i64 *Ap, const i
 			bool committed = false;
 			for (;;) {
 				u64 live = alive();
+				const u64 c0 = clock64();
 				while (head < tail && live != 0 && !overflow) {
+					if (tail + (REC_ENTS + 1) * 64 > fifo_cap) {
+						overflow = true;
+						break;
+					}
 					drain();                     // (the FIFO entries pushed by the step before are in memory)
 					const int cnt = min(64, tail - head);
 					const int c = (lane < cnt) ? fifo[head + lane] : -1;
 					head += cnt;
-					int len = 0, e[REC_ENTS] = {0, 0, 0, 0, 0, 0, 0};
-					if (c >= 0) {
-						const u64 *R = rec + (size_t) c * REC_WORDS;
-						const u64 r0 = ld_u64(R);
-						len = (int) (uint32_t) r0;
-						e[0] = (int) (r0 >> 32);
-						if (len > 1) {
-							const u64 r1 = ld_u64(R + 1);
-							e[1] = (int) (uint32_t) r1;
-							e[2] = (int) (r1 >> 32);
-							if (len > 3) {
-								const u64 r2 = ld_u64(R + 2);
-								e[3] = (int) (uint32_t) r2;
-								e[4] = (int) (r2 >> 32);
-								if (len > 5) {
-									const u64 r3 = ld_u64(R + 3);
-									e[5] = (int) (uint32_t) r3;
-									e[6] = (int) (r3 >> 32);
-								}
-							}
-						}
-					}
+					u64 lo = 0, hi = 0;
+					if (c >= 0)
+						ld_rec(rec + (size_t) c * REC_WORDS, lo, hi);
+					const int len = (int) (lo & 7ull);
+					const int long_row = (int) (uint32_t) (lo >> 3);
 					visits += (u64) __popcll(__ballot(len != 0));
+					steps += 1;
+					// The step is bound by instruction issue, not by memory (512 searches in flight are as fast as 2,048, cached record
+					// loads change nothing): the six columns of the records are marked by six LDS atomics issued back to back -- a lane
+					// with no column there ORs nothing into a word of its own --, then queued with one prefix sum.
+					int e[REC_ENTS];
+					uint32_t bit[REC_ENTS], old[REC_ENTS];
 #pragma unroll
-					for (int t = 0; t < REC_ENTS; t++)
-						reach(t < len, e[t]);
+					for (int t = 0; t < REC_ENTS; t++) {
+						e[t] = rec_get(lo, hi, t);
+						const bool ok = len != REC_LONG && t < len && e[t] < m;          // (e[t] < m: a record caught half written)
+						bit[t] = ok ? 1u << (e[t] & 31) : 0u;
+						old[t] = atomicOr(&bits[ok ? (e[t] >> 5) : spare], bit[t]);
+					}
+					int base = tail;
+#pragma unroll
+					for (int t = 0; t < REC_ENTS; t++) {
+						const bool fresh = (bit[t] & ~old[t]) != 0;
+						const u64 mask = __ballot(fresh);
+						if (fresh)
+							fifo[base + __popcll(mask & below)] = e[t];
+						base += __popcll(mask);
+					}
+					tail = base;
 					// pivot rows too long for a record: the wave walks them one by one
-					for (u64 longs = __ballot(len < 0); longs != 0; longs &= longs - 1) {
-						const int row = __shfl(e[0], __builtin_ctzll(longs));
+					for (u64 longs = __ballot(len == REC_LONG && long_row < n); longs != 0; longs &= longs - 1) {
+						const int row = __shfl(long_row, __builtin_ctzll(longs));
 						const i64 lo = Ap[row], hi = Ap[row + 1];
 						for (i64 px0 = lo; px0 < hi; px0 += 64) {
 							const bool valid = px0 + lane < hi;
@@ -231,6 +279,12 @@ __global__ __launch_bounds__(64) void pivot_search_kernel(const i64 *Ap, const i
 					}
 					live = alive();
 				}
+				const u64 c1 = clock64();
+				c_search += c1 - c0;
+				struct Tally {
+					u64 &acc, from;
+					__device__ ~Tally() { acc += clock64() - from; }
+				} tally{c_commit, c1};
 				if (live == 0 || overflow)
 					break;                       // every candidate is reached: no pivot on this row
 				// does column j of another search's pivot fall on our marks?  (a reached column, or a candidate of ours)
@@ -336,25 +390,25 @@ __global__ __launch_bounds__(64) void pivot_search_kernel(const i64 *Ap, const i
 				{
 					const i64 others = row_hi - row_lo - 1;
 					u64 *R = rec + (size_t) chosen * REC_WORDS;
+					const u64 as_long = (u64) REC_LONG | ((u64) (uint32_t) i << 3);
 					if (others > REC_ENTS || others <= 0) {
 						if (lane == 0)
-							st_u64(R, pack2(-1, i));
+							st_u64(R, as_long);
 					} else {
 						const bool valid = row_lo + lane < row_hi;
 						const int j = valid ? Aj[row_lo + lane] : 0;
 						const bool other = valid && j != chosen;
 						const u64 mask = __ballot(other);
-						if (lane < REC_ENTS)
-							tmp[lane] = 0;
 						if (other)
 							tmp[__popcll(mask & below)] = j;
 						const int len = __popcll(mask);
 						if (lane == 0) {
-							st_u64(R + 1, pack2(tmp[1], tmp[2]));
-							st_u64(R + 2, pack2(tmp[3], tmp[4]));
-							st_u64(R + 3, pack2(tmp[5], tmp[6]));
+							u64 lo = 0, hi = 0;
+							for (int t = 0; t < len; t++)
+								rec_put(lo, hi, t, (u64) tmp[t]);
+							st_u64(R + 1, hi);
 							drain();
-							st_u64(R, len > 0 ? pack2(len, tmp[0]) : pack2(-1, i));
+							st_u64(R, len > 0 ? (lo | (u64) len) : as_long);
 						}
 					}
 					if (lane == 0) {
@@ -368,12 +422,21 @@ __global__ __launch_bounds__(64) void pivot_search_kernel(const i64 *Ap, const i
 			(void) committed;
 			if (overflow && lane == 0)
 				atomicAdd(&ctrl->overflowed, 1);
+			longest = max(longest, (u64) (wall_clock64() - t_row));
 		}
 	}
 	if (dead && lane == 0)
 		st_i32(&ctrl->status, 1);
 	if (lane == 0) {
+		const u64 now = wall_clock64();
+		atomicMin(&ctrl->t_first_exit, now);
+		atomicMax(&ctrl->t_last_exit, now);
+		atomicMax(&ctrl->longest_search, longest);
 		atomicAdd(&ctrl->visits, visits);
+		atomicAdd(&ctrl->steps, steps);
+		atomicAdd(&ctrl->c_search, c_search);
+		atomicAdd(&ctrl->c_commit, c_commit);
+		atomicAdd(&ctrl->c_total, (u64) (clock64() - c_begin));
 		atomicAdd(&ctrl->attempts, attempts);
 	}
 }
@@ -396,8 +459,8 @@ int device_acyclic_greedy(const struct spasm_csr *A, int *pinv, int *qinv)
 		return -1;
 	}
 	const int words = ((m + 31) / 32 + 255) / 256 * 256;          // (cleared 256 words at a time)
-	const size_t lds = (size_t) words * 4 + (64 + 8) * sizeof(int);
-	if (n <= 0 || m <= 0 || lds > 64 * 1024)
+	const size_t lds = (size_t) words * 4 + (64 + 8 + 64) * sizeof(int);
+	if (n <= 0 || m <= 0 || lds > 64 * 1024 || m > (1 << REC_BITS))
 		return -1;
 	const double t0 = wtime();
 	hipStream_t stream = nullptr;
@@ -405,7 +468,7 @@ int device_acyclic_greedy(const struct spasm_csr *A, int *pinv, int *qinv)
 	int dev = 0, cus = 256;
 	HIP_CHECK(hipGetDevice(&dev));
 	HIP_CHECK(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev));
-	const int per_cu = std::max(1, std::min(env_int("SPASM_HIP_PIVOT_WAVES_PER_CU", 8), (int) ((160 * 1024) / lds)));
+	const int per_cu = std::max(1, std::min(env_int("SPASM_HIP_PIVOT_WAVES_PER_CU", 4), (int) ((160 * 1024) / lds)));
 	const int grid = cus * per_cu;
 	const int fifo_cap = m + 4096;
 	std::vector<void *> owned;
@@ -426,7 +489,13 @@ int device_acyclic_greedy(const struct spasm_csr *A, int *pinv, int *qinv)
 	HIP_CHECK(hipMemcpyAsync(d_pinv, pinv, (size_t) n * sizeof(int), hipMemcpyHostToDevice, stream));
 	HIP_CHECK(hipMemcpyAsync(d_qinv, qinv, (size_t) m * sizeof(int), hipMemcpyHostToDevice, stream));
 	HIP_CHECK(hipMemsetAsync(jent, 0, jcap * sizeof(u64), stream));
-	HIP_CHECK(hipMemsetAsync(ctrl, 0, sizeof(PsCtrl), stream));
+	{
+		PsCtrl init;
+		std::memset(&init, 0, sizeof(init));
+		init.t_start = init.t_first_exit = ~0ull;
+		HIP_CHECK(hipMemcpyAsync(ctrl, &init, sizeof(PsCtrl), hipMemcpyHostToDevice, stream));
+		HIP_CHECK(hipStreamSynchronize(stream));
+	}
 	hipLaunchKernelGGL(pivot_records_kernel, dim3((m + 255) / 256), dim3(256), 0, stream, dA.p, dA.j, d_qinv, m, rec);
 	hipLaunchKernelGGL(pivot_search_kernel, dim3(grid), dim3(64), lds, stream, dA.p, dA.j, d_pinv, n, m, words, rec, jent, jrow, ctrl, fifo, fifo_cap, (int) jcap);
 	PsCtrl c;
@@ -455,9 +524,13 @@ int device_acyclic_greedy(const struct spasm_csr *A, int *pinv, int *qinv)
 			found += 1;
 		}
 		if (std::getenv("SPASM_HIP_PIVOT_STATS"))
-			logmsg("[pivots] device: %d searches in flight (%d per CU, %zu bytes of LDS each), %llu pivot rows visited, %d tickets for %d pivots, "
-			       "%d rows given up (FIFO full) [%.3fs: %.3f upload of A + allocations, %.3f kernels, %.3f journal]\n", grid, per_cu, lds, c.visits, c.tickets, found,
-			       c.overflowed, wtime() - t0, t_alloc - t0, t_run - t_alloc, wtime() - t_run);
+			logmsg("[pivots] device: %d searches in flight (%d per CU, %zu bytes of LDS each), %llu pivot rows visited in %llu steps, %d tickets for %d pivots, "
+			       "%d rows given up (FIFO full) [%.3fs: %.3f upload of A + allocations, %.3f kernels, %.3f journal; in the search kernel the first wave "
+			       "ran out of rows after %.1f ms, the last one left after %.1f ms, the longest search of one row took %.1f ms; "
+			       "of the waves' time %.0f %% in the walk, %.0f %% in replays and tickets]\n", grid, per_cu, lds, c.visits, c.steps,
+			       c.tickets, found, c.overflowed, wtime() - t0, t_alloc - t0, t_run - t_alloc, wtime() - t_run, 1e-5 * (double) (c.t_first_exit - c.t_start),
+			       1e-5 * (double) (c.t_last_exit - c.t_start), 1e-5 * (double) c.longest_search, 100.0 * (double) c.c_search / (double) std::max<u64>(c.c_total, 1),
+			       100.0 * (double) c.c_commit / (double) std::max<u64>(c.c_total, 1));
 	} else {
 		logmsg("[pivots] device search gave up (a wait ran out): the host search takes over\n");
 	}
