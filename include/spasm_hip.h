@@ -149,7 +149,13 @@ struct spasm_triplet *spasm_hip_triplet_load(FILE *f, i64 prime, u8 *hash);     
 void spasm_hip_triplet_save(const struct spasm_triplet *A, FILE *f);               /* spasm_io.c:183 */
 void spasm_hip_csr_save(const struct spasm_csr *A, FILE *f);                       /* spasm_io.c:163 */
 
-/* --- host-side structural pivot search (stays on the CPU by design) --- */
+/* --- structural pivot search (replaces spasm_pivots.c:374) ---
+ * The Faugere-Lachartre steps, the topological order and the rows of U are host work.  The greedy cycle-free search
+ * (spasm_pivots.c:147-305) of a matrix with at least 20,000 rows runs ON THE DEVICE when the process has one and the matrix has
+ * at most 524,288 columns (spasm_amd/csrc/pivots_device.hip: one wavefront per candidate row; SPASM_HIP_PIVOT_SEARCH=host
+ * keeps it on the host threads, =device refuses to fall back); without a device -- the CPU tests, hosts that only plan --
+ * the host search of host_pivots.cpp runs: same transactions, same guarantees (a cycle-free set; which one depends on
+ * timing, as it does in the reference under OpenMP; one thread = the reference's sequential outcome). */
 int spasm_hip_pivots_extract_structural(const struct spasm_csr *A, const int *p_in, struct spasm_lu *fact,
                                         int *p, struct echelonize_opts *opts);     /* spasm_pivots.c:374 */
 

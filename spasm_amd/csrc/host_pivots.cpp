@@ -1,9 +1,9 @@
-// Structural pivot search on the host (replaces spasm_pivots.c).  By design
-// this stage stays on the CPU: it is a graph search with no arithmetic.
+// Structural pivot search (replaces spasm_pivots.c).
 //   1. Faugere-Lachartre: leftmost entry of each row, sparsest row wins;
 //   2. the same idea on columns not touched by a pivotal row;
-//   3. greedy search for pivots that keep the pivot graph acyclic (PASCO'17),
-//      executed in row order (the outcome of the reference with one thread).
+//   3. greedy search for pivots that keep the pivot graph acyclic (PASCO'17): on the device when there is one
+//      (pivots_device.hip), else here -- with threads and optimistic transactions, or in row order (one thread: the
+//      outcome of the reference with one thread).
 // Then the pivotal rows are ordered topologically and appended to U, scaled so
 // that every pivot is 1 and stored first in its row.
 #include <atomic>
