@@ -151,8 +151,8 @@ void spasm_hip_csr_save(const struct spasm_csr *A, FILE *f);                    
 
 /* --- structural pivot search (replaces spasm_pivots.c:374) ---
  * The Faugere-Lachartre steps, the topological order and the rows of U are host work.  The greedy cycle-free search
- * (spasm_pivots.c:147-305) of a matrix with at least 20,000 rows runs ON THE DEVICE when the process has one and the matrix has
- * at most 524,288 columns (spasm_amd/csrc/pivots_device.hip: one wavefront per candidate row; SPASM_HIP_PIVOT_SEARCH=host
+ * (spasm_pivots.c:147-305) of a matrix with at least 20,000 rows runs ON THE DEVICE when the process has one
+ * (spasm_amd/csrc/pivots_device.hip: one wavefront per candidate row; up to 2^25 columns; SPASM_HIP_PIVOT_SEARCH=host
  * keeps it on the host threads, =device refuses to fall back); without a device -- the CPU tests, hosts that only plan --
  * the host search of host_pivots.cpp runs: same transactions, same guarantees (a cycle-free set; which one depends on
  * timing, as it does in the reference under OpenMP; one thread = the reference's sequential outcome). */

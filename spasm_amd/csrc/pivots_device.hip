@@ -37,36 +37,35 @@ namespace {
 typedef int64_t i64;
 typedef unsigned long long u64;
 
-// record of a pivotal column, 16 bytes = ONE load per visited pivot row (the search is bound by the rate of these requests:
-// with four 8-byte words per record 512 searches in flight were as fast as 2,048).  Bits [0, 3): 0 = not pivotal, 1..6 =
-// that many other columns of its row follow, 20 bits each (this search is for m <= 2^19: one bit per column in 64 KB of LDS);
-// 7 = the row is too long for that (or has nothing else) and bits [3, 35) are its index in A.
-constexpr int REC_WORDS = 2, REC_ENTS = 6, REC_LONG = 7, REC_BITS = 20;
+// record of a pivotal column, 16 bytes = ONE load per visited pivot row.  Bits [0, 3): 0 = not pivotal, 1..ENTS = that many
+// other columns of its row follow, BITS bits each; 7 = the row is too long for that (or has nothing else) and bits [3, 35)
+// are its index in A.  Two formats: six columns of 20 bits (m <= 2^20; with the reached-bits in LDS: m <= 2^19), five of 25.
+constexpr int REC_WORDS = 2, REC_LONG = 7;
 
-__host__ __device__ inline void rec_put(unsigned long long &lo, unsigned long long &hi, int k, unsigned long long v)
+template <int BITS> __host__ __device__ inline void rec_put(unsigned long long &lo, unsigned long long &hi, int k, unsigned long long v)
 {
-	const int off = 3 + REC_BITS * k;
+	const int off = 3 + BITS * k;
 	if (off < 64) {
 		lo |= v << off;
-		if (off + REC_BITS > 64)
+		if (off + BITS > 64)
 			hi |= v >> (64 - off);
 	} else {
 		hi |= v << (off - 64);
 	}
 }
 
-__host__ __device__ inline int rec_get(unsigned long long lo, unsigned long long hi, int k)
+template <int BITS> __host__ __device__ inline int rec_get(unsigned long long lo, unsigned long long hi, int k)
 {
-	const int off = 3 + REC_BITS * k;
+	const int off = 3 + BITS * k;
 	unsigned long long v;
 	if (off < 64) {
 		v = lo >> off;
-		if (off + REC_BITS > 64)
+		if (off + BITS > 64)
 			v |= hi << (64 - off);
 	} else {
 		v = hi >> (off - 64);
 	}
-	return (int) (v & ((1ull << REC_BITS) - 1ull));
+	return (int) (v & ((1ull << BITS) - 1ull));
 }
 
 struct PsCtrl {
@@ -105,6 +104,7 @@ __device__ __forceinline__ void ld_rec(const u64 *p, u64 &lo, u64 &hi)
 __device__ __forceinline__ void drain() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
 
 // records of the pivots the host found (Faugere-Lachartre), one thread per column
+template <int REC_ENTS, int REC_BITS>
 __global__ __launch_bounds__(256) void pivot_records_kernel(const i64 *Ap, const int *Aj, const int *qinv, int m, u64 *rec)
 {
 	const int col = blockIdx.x * 256 + threadIdx.x;
@@ -122,7 +122,7 @@ __global__ __launch_bounds__(256) void pivot_records_kernel(const i64 *Ap, const
 			for (i64 px = first; px < last; px++) {
 				const int j = Aj[px];
 				if (j != col && len < REC_ENTS)
-					rec_put(lo, hi, len++, (u64) j);
+					rec_put<REC_BITS>(lo, hi, len++, (u64) j);
 			}
 			lo |= (len > 0) ? (u64) len : (u64) REC_LONG | ((u64) (uint32_t) row << 3);
 		}
@@ -139,16 +139,26 @@ __device__ __forceinline__ u64 entry(int col, u64 state) { return (u64) (uint32_
 constexpr int PS_ROWS_PER_GRAB = 8;
 constexpr unsigned PS_SPIN_LIMIT = 1u << 24;
 
-// one wavefront per workgroup; LDS: the reached-bit of every column, then the candidate columns of the row (one per lane)
+// one wavefront per workgroup.  The reached-bit of every column lives in LDS (GB = false: m / 8 bytes, cleared per row) or,
+// for matrices too wide for that, in a private stretch of HBM (GB = true: set and read through the L2 -- atomics and
+// L1-bypassing loads --, cleared after a row by walking its FIFO, which holds every column that was marked); then the
+// candidate columns of the row (one per lane) in LDS.
+template <bool GB, int REC_ENTS, int REC_BITS>
 __global__ __launch_bounds__(64) void pivot_search_kernel(const i64 *Ap, const int *Aj, const int *pinv, int n, int m, int words, u64 *rec, u64 *jent, int *jrow,
-                                                          PsCtrl *ctrl, int *fifo_all, int fifo_cap, int jcap)
+                                                          PsCtrl *ctrl, int *fifo_all, int fifo_cap, int jcap, uint32_t *gbits)
 {
 	extern __shared__ __attribute__((aligned(16))) uint32_t ps_lds[];
-	uint32_t *bits = ps_lds;
-	int *cand = reinterpret_cast<int *>(ps_lds + words);
+	uint32_t *bits = GB ? gbits + (size_t) blockIdx.x * (size_t) (words + 64) : ps_lds;
+	int *cand = reinterpret_cast<int *>(ps_lds + (GB ? 0 : words));
 	int *tmp = cand + 64;
 	const int lane = threadIdx.x;
-	const int spare = words + 64 + 8 + lane;          // a word of LDS of this lane's own, for atomics that must do nothing
+	const int spare = words + (GB ? 0 : 64 + 8) + lane;          // a word of this lane's own, for atomics that must do nothing
+	auto bits_at = [&](int w) -> uint32_t {                       // (GB: what the atomics left in the L2, not what the L1 remembers)
+		if constexpr (GB)
+			return (uint32_t) ld_i32(reinterpret_cast<const int *>(bits + w));
+		else
+			return bits[w];
+	};
 	const u64 below = (1ull << lane) - 1ull;
 	int *fifo = fifo_all + (size_t) blockIdx.x * fifo_cap;
 	u64 visits = 0, attempts = 0, longest = 0, steps = 0, c_search = 0, c_commit = 0;
@@ -172,8 +182,9 @@ __global__ __launch_bounds__(64) void pivot_search_kernel(const i64 *Ap, const i
 				break;
 			}
 			const u64 t_row = wall_clock64();
-			for (int w = lane * 4; w < words; w += 256)
-				*reinterpret_cast<uint4 *>(bits + w) = make_uint4(0, 0, 0, 0);
+			if constexpr (!GB)
+				for (int w = lane * 4; w < words; w += 256)
+					*reinterpret_cast<uint4 *>(bits + w) = make_uint4(0, 0, 0, 0);
 			// every ticket below `seen` is decided, and the records of the accepted ones are complete
 			int seen = ld_i32(&ctrl->prefix);
 			__builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
@@ -213,8 +224,9 @@ __global__ __launch_bounds__(64) void pivot_search_kernel(const i64 *Ap, const i
 					cand[pos] = j;
 				// a row with more than 64 columns without a pivot: the others are not eligible, but they ARE entries of this row --
 				// marked reached, so that a pivot committed on one of them meanwhile is explored like any pivotal entry
-				if (is_cand && pos >= 64)
-					atomicOr(&bits[j >> 5], 1u << (j & 31));
+				// (through the FIFO like any reached column: it has no record yet, so walking it does nothing, and the FIFO lists every
+				// marked column -- which is what the GB variant clears its bits by)
+				reach(is_cand && pos >= 64, j);
 				ncand = min(64, ncand + __popcll(mask));
 			}
 			// candidates still unreached (one per lane)
@@ -222,7 +234,7 @@ __global__ __launch_bounds__(64) void pivot_search_kernel(const i64 *Ap, const i
 				bool a = false;
 				if (lane < ncand) {
 					const int j = cand[lane];
-					a = (bits[j >> 5] & (1u << (j & 31))) == 0;
+					a = (bits_at(j >> 5) & (1u << (j & 31))) == 0;
 				}
 				return __ballot(a);
 			};
@@ -253,7 +265,7 @@ __global__ __launch_bounds__(64) void pivot_search_kernel(const i64 *Ap, const i
 					uint32_t bit[REC_ENTS], old[REC_ENTS];
 #pragma unroll
 					for (int t = 0; t < REC_ENTS; t++) {
-						e[t] = rec_get(lo, hi, t);
+						e[t] = rec_get<REC_BITS>(lo, hi, t);
 						const bool ok = len != REC_LONG && t < len && e[t] < m;          // (e[t] < m: a record caught half written)
 						bit[t] = ok ? 1u << (e[t] & 31) : 0u;
 						old[t] = atomicOr(&bits[ok ? (e[t] >> 5) : spare], bit[t]);
@@ -290,7 +302,7 @@ __global__ __launch_bounds__(64) void pivot_search_kernel(const i64 *Ap, const i
 				// does column j of another search's pivot fall on our marks?  (a reached column, or a candidate of ours)
 				auto touches = [&](int j, bool &was_reached) {
 					const uint32_t bit = 1u << (j & 31);
-					was_reached = (bits[j >> 5] & bit) != 0;
+					was_reached = (bits_at(j >> 5) & bit) != 0;
 					if (was_reached)
 						return true;
 					for (int k = 0; k < ncand; k++)
@@ -405,7 +417,7 @@ __global__ __launch_bounds__(64) void pivot_search_kernel(const i64 *Ap, const i
 						if (lane == 0) {
 							u64 lo = 0, hi = 0;
 							for (int t = 0; t < len; t++)
-								rec_put(lo, hi, t, (u64) tmp[t]);
+								rec_put<REC_BITS>(lo, hi, t, (u64) tmp[t]);
 							st_u64(R + 1, hi);
 							drain();
 							st_u64(R, len > 0 ? (lo | (u64) len) : as_long);
@@ -422,6 +434,18 @@ __global__ __launch_bounds__(64) void pivot_search_kernel(const i64 *Ap, const i
 			(void) committed;
 			if (overflow && lane == 0)
 				atomicAdd(&ctrl->overflowed, 1);
+			if constexpr (GB) {
+				// the marks of this row go: every marked column is in the FIFO (a FIFO that overflowed lists only some: all words then)
+				drain();
+				if (overflow) {
+					for (int w = lane; w < words; w += 64)
+						bits[w] = 0;
+				} else {
+					for (int t = lane; t < tail; t += 64)
+						bits[fifo[t] >> 5] = 0;
+				}
+				drain();
+			}
 			longest = max(longest, (u64) (wall_clock64() - t_row));
 		}
 	}
@@ -445,7 +469,7 @@ __global__ __launch_bounds__(64) void pivot_search_kernel(const i64 *Ap, const i
 
 // The search on the device.  pinv / qinv: the pivots found so far (row -> column, column -> row, -1 = none), extended in
 // place.  Returns the number of new pivots, or -1 when the search does not apply here -- no device, the switch
-// SPASM_HIP_PIVOT_SEARCH=host, more columns than one bit per column in 64 KB of LDS covers -- or gave up; the caller then
+// SPASM_HIP_PIVOT_SEARCH=host, more than 2^25 columns -- or gave up; the caller then
 // runs the host search (which is the same algorithm: this is a matter of speed, the result is a valid set either way).
 int device_acyclic_greedy(const struct spasm_csr *A, int *pinv, int *qinv)
 {
@@ -459,8 +483,12 @@ int device_acyclic_greedy(const struct spasm_csr *A, int *pinv, int *qinv)
 		return -1;
 	}
 	const int words = ((m + 31) / 32 + 255) / 256 * 256;          // (cleared 256 words at a time)
-	const size_t lds = (size_t) words * 4 + (64 + 8 + 64) * sizeof(int);
-	if (n <= 0 || m <= 0 || lds > 64 * 1024 || m > (1 << REC_BITS))
+	// the reached-bits in LDS when one bit per column fits 64 KB (and a column fits 20 bits), else in HBM
+	bool global_bits = (size_t) words * 4 + (64 + 8 + 64) * sizeof(int) > 64 * 1024 || m > (1 << 20);
+	if (const char *e = std::getenv("SPASM_HIP_PIVOT_BITS"))
+		global_bits = global_bits || std::strcmp(e, "global") == 0;
+	const size_t lds = global_bits ? (64 + 8) * sizeof(int) : (size_t) words * 4 + (64 + 8 + 64) * sizeof(int);
+	if (n <= 0 || m <= 0 || m > (1 << 25))
 		return -1;
 	const double t0 = wtime();
 	hipStream_t stream = nullptr;
@@ -468,9 +496,13 @@ int device_acyclic_greedy(const struct spasm_csr *A, int *pinv, int *qinv)
 	int dev = 0, cus = 256;
 	HIP_CHECK(hipGetDevice(&dev));
 	HIP_CHECK(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev));
-	const int per_cu = std::max(1, std::min(env_int("SPASM_HIP_PIVOT_WAVES_PER_CU", 4), (int) ((160 * 1024) / lds)));
-	const int grid = cus * per_cu;
 	const int fifo_cap = m + 4096;
+	int per_cu = std::max(1, std::min(env_int("SPASM_HIP_PIVOT_WAVES_PER_CU", 4), (int) ((160 * 1024) / lds)));
+	// (a search owns a FIFO of m + 4096 columns, and m / 8 bytes of marks with global_bits: at most 8 GB in all)
+	const size_t per_search = (size_t) fifo_cap * sizeof(int) + (global_bits ? ((size_t) words + 64) * sizeof(uint32_t) : 0);
+	while (per_cu > 1 && (size_t) cus * per_cu * per_search > ((size_t) 8 << 30))
+		per_cu -= 1;
+	const int grid = cus * per_cu;
 	std::vector<void *> owned;
 	auto dal = [&](size_t bytes) {
 		void *ptr = big_alloc(bytes);
@@ -485,6 +517,11 @@ int device_acyclic_greedy(const struct spasm_csr *A, int *pinv, int *qinv)
 	int *jrow = (int *) dal(jcap * sizeof(int));
 	PsCtrl *ctrl = (PsCtrl *) dal(sizeof(PsCtrl));
 	int *fifo = (int *) dal((size_t) grid * fifo_cap * sizeof(int));
+	uint32_t *gbits = nullptr;
+	if (global_bits) {
+		gbits = (uint32_t *) dal((size_t) grid * ((size_t) words + 64) * sizeof(uint32_t));
+		HIP_CHECK(hipMemsetAsync(gbits, 0, (size_t) grid * ((size_t) words + 64) * sizeof(uint32_t), stream));
+	}
 	const double t_alloc = wtime();
 	HIP_CHECK(hipMemcpyAsync(d_pinv, pinv, (size_t) n * sizeof(int), hipMemcpyHostToDevice, stream));
 	HIP_CHECK(hipMemcpyAsync(d_qinv, qinv, (size_t) m * sizeof(int), hipMemcpyHostToDevice, stream));
@@ -496,8 +533,16 @@ int device_acyclic_greedy(const struct spasm_csr *A, int *pinv, int *qinv)
 		HIP_CHECK(hipMemcpyAsync(ctrl, &init, sizeof(PsCtrl), hipMemcpyHostToDevice, stream));
 		HIP_CHECK(hipStreamSynchronize(stream));
 	}
-	hipLaunchKernelGGL(pivot_records_kernel, dim3((m + 255) / 256), dim3(256), 0, stream, dA.p, dA.j, d_qinv, m, rec);
-	hipLaunchKernelGGL(pivot_search_kernel, dim3(grid), dim3(64), lds, stream, dA.p, dA.j, d_pinv, n, m, words, rec, jent, jrow, ctrl, fifo, fifo_cap, (int) jcap);
+	if (global_bits) {
+		hipLaunchKernelGGL((pivot_records_kernel<5, 25>), dim3((m + 255) / 256), dim3(256), 0, stream, dA.p, dA.j, d_qinv, m, rec);
+		hipLaunchKernelGGL((pivot_search_kernel<true, 5, 25>), dim3(grid), dim3(64), lds, stream, dA.p, dA.j, d_pinv, n, m, words, rec, jent, jrow, ctrl, fifo,
+		                   fifo_cap, (int) jcap, gbits);
+	} else {
+		hipLaunchKernelGGL((pivot_records_kernel<6, 20>), dim3((m + 255) / 256), dim3(256), 0, stream, dA.p, dA.j, d_qinv, m, rec);
+		hipLaunchKernelGGL((pivot_search_kernel<false, 6, 20>), dim3(grid), dim3(64), lds, stream, dA.p, dA.j, d_pinv, n, m, words, rec, jent, jrow, ctrl, fifo,
+		                   fifo_cap, (int) jcap, gbits);
+	}
+	HIP_CHECK(hipGetLastError());
 	PsCtrl c;
 	HIP_CHECK(hipMemcpyAsync(&c, ctrl, sizeof(PsCtrl), hipMemcpyDeviceToHost, stream));
 	HIP_CHECK(hipStreamSynchronize(stream));
@@ -524,10 +569,10 @@ int device_acyclic_greedy(const struct spasm_csr *A, int *pinv, int *qinv)
 			found += 1;
 		}
 		if (std::getenv("SPASM_HIP_PIVOT_STATS"))
-			logmsg("[pivots] device: %d searches in flight (%d per CU, %zu bytes of LDS each), %llu pivot rows visited in %llu steps, %d tickets for %d pivots, "
+			logmsg("[pivots] device: %d searches in flight (%d per CU, %zu bytes of LDS each%s), %llu pivot rows visited in %llu steps, %d tickets for %d pivots, "
 			       "%d rows given up (FIFO full) [%.3fs: %.3f upload of A + allocations, %.3f kernels, %.3f journal; in the search kernel the first wave "
 			       "ran out of rows after %.1f ms, the last one left after %.1f ms, the longest search of one row took %.1f ms; "
-			       "of the waves' time %.0f %% in the walk, %.0f %% in replays and tickets]\n", grid, per_cu, lds, c.visits, c.steps,
+			       "of the waves' time %.0f %% in the walk, %.0f %% in replays and tickets]\n", grid, per_cu, lds, global_bits ? "; reached-bits in HBM" : "", c.visits, c.steps,
 			       c.tickets, found, c.overflowed, wtime() - t0, t_alloc - t0, t_run - t_alloc, wtime() - t_run, 1e-5 * (double) (c.t_first_exit - c.t_start),
 			       1e-5 * (double) (c.t_last_exit - c.t_start), 1e-5 * (double) c.longest_search, 100.0 * (double) c.c_search / (double) std::max<u64>(c.c_total, 1),
 			       100.0 * (double) c.c_commit / (double) std::max<u64>(c.c_total, 1));

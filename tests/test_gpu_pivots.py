@@ -33,16 +33,36 @@ def _random_matrix(n, m, seed, max_len, prime):
     return Csr(n, m, p, j, x, prime)
 
 
-def _search(A, where):
-    old = os.environ.get("SPASM_HIP_PIVOT_SEARCH")
+def _search(A, where, bits=None):
+    """where: "device" (refuses to fall back) / "host"; bits: "global" = the reached-bits in HBM even when they fit the LDS"""
+    saved = {k: os.environ.get(k) for k in ("SPASM_HIP_PIVOT_SEARCH", "SPASM_HIP_PIVOT_BITS")}
     os.environ["SPASM_HIP_PIVOT_SEARCH"] = where
+    if bits is not None:
+        os.environ["SPASM_HIP_PIVOT_BITS"] = bits
     try:
         return spasm_amd.pivots_extract_structural(A, spasm_amd.empty_fact(A.m, A.prime))
     finally:
-        if old is None:
-            del os.environ["SPASM_HIP_PIVOT_SEARCH"]
-        else:
-            os.environ["SPASM_HIP_PIVOT_SEARCH"] = old
+        for k, v in saved.items():
+            if v is None:
+                os.environ.pop(k, None)
+            else:
+                os.environ[k] = v
+
+
+def _wide_matrix(n, m, seed, prime):
+    """rows of 2..7 distinct columns (arithmetic progressions mod m), built without a Python loop: for matrices too wide
+    for one bit per column in LDS"""
+    rng = np.random.default_rng(seed)
+    lens = rng.integers(2, 8, size=n)
+    base = rng.integers(0, m, size=n)
+    stride = rng.integers(1, m // 8, size=n)
+    p = np.zeros(n + 1, np.int64)
+    np.cumsum(lens, out=p[1:])
+    row = np.repeat(np.arange(n), lens)
+    k = np.arange(int(p[n])) - np.repeat(p[:-1], lens)
+    j = ((base[row] + k * stride[row]) % m).astype(np.int32)
+    x = rng.integers(1, prime, size=int(p[n])).astype(np.int32)
+    return Csr(n, m, p, j, x, prime)
 
 
 def _check(A, npiv, perm, F):
@@ -69,21 +89,33 @@ def _check(A, npiv, perm, F):
     assert np.all(dst[keep] > src[keep])
 
 
+@pytest.mark.parametrize("bits", [None, "global"])
 @pytest.mark.parametrize("shape", [(30000, 20000, 6), (40000, 60000, 12), (25000, 9000, 3)])
-def test_device_search_on_random_matrices(shape):
+def test_device_search_on_random_matrices(shape, bits):
     n, m, max_len = shape
     A = _random_matrix(n, m, seed=n + m, max_len=max_len, prime=65521)
-    npiv, perm, F = _search(A, "device")
+    npiv, perm, F = _search(A, "device", bits)
     _check(A, npiv, perm, F)
     npiv_h, perm_h, F_h = _search(A, "host")
     _check(A, npiv_h, perm_h, F_h)
     assert abs(npiv - npiv_h) <= 0.03 * npiv_h
 
 
+@pytest.mark.parametrize("bits", [None, "global"])
 @pytest.mark.parametrize("name", ["mk13.b5", "ch7-8.b5"])
-def test_device_search_on_stand_ins(name):
+def test_device_search_on_stand_ins(name, bits):
     A, _ = workloads.load_matrix(name)
-    npiv, perm, F = _search(A, "device")
+    npiv, perm, F = _search(A, "device", bits)
     _check(A, npiv, perm, F)
     npiv_h, _, _ = _search(A, "host")
+    assert abs(npiv - npiv_h) <= 0.03 * npiv_h
+
+
+def test_device_search_on_a_matrix_too_wide_for_the_lds():
+    """1.3 M columns: the reached-bits live in HBM and a column takes 25 bits of a record (the GL7d19 class: 1.9 M columns)"""
+    A = _wide_matrix(400000, 1300000, seed=7, prime=42013)
+    npiv, perm, F = _search(A, "device")
+    _check(A, npiv, perm, F)
+    npiv_h, perm_h, F_h = _search(A, "host")
+    _check(A, npiv_h, perm_h, F_h)
     assert abs(npiv - npiv_h) <= 0.03 * npiv_h
