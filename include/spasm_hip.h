@@ -110,6 +110,10 @@ int spasm_hip_device_count(void);
 /* CPUs this process may really use: hardware threads cut down to the CPU quota of its control group (the pivot search
  * takes that many threads; a box of this pool reports 256 hardware threads and grants 16 CPUs) */
 int spasm_hip_usable_cpus(void);
+/* Between host-level calls the library parks device memory it would otherwise allocate again -- the accumulator scratch of
+ * the row-by-row kernels, and the blocks of its buffer cache up to SPASM_HIP_KEEP_GB (default 96 = all of them; 0 = none:
+ * multi-GB blocks take 0.1 to 1 s apiece to free and allocate again, erratically).  This gives all of it back. */
+void spasm_hip_release_cached_memory(void);
 const char *spasm_hip_version(void);
 
 /* --- containers and field (replace spasm_util.c:85-191, spasm_ZZp.c) ---

@@ -7,7 +7,7 @@ a GPU (so that symbols can be inspected), but every compute entry point dies
 loudly when no HIP device is present.
 """
 from .matrix import Csr, Fact, EchelonizeOpts                     # noqa: F401
-from ._lib import lib, device_count, usable_cpus, LIB_PATH                      # noqa: F401
+from ._lib import lib, device_count, usable_cpus, release_cached_memory, LIB_PATH                      # noqa: F401
 from .host import (load, compress, transpose, pivots_extract_structural, schur,       # noqa: F401
                    empty_fact, schur_dense, ffpack_rref, ffpack_LU, echelonize, echelonize_profile, rref, kernel,
                    default_opts)

@@ -32,6 +32,7 @@ def lib():
     sig = {
         "spasm_hip_device_count": (ci, []),
         "spasm_hip_usable_cpus": (ci, []),
+        "spasm_hip_release_cached_memory": (None, []),
         "spasm_hip_version": (C.c_char_p, []),
         "spasm_hip_csr_alloc": (pcsr, [ci, ci, i64, i64, C.c_bool]),
         "spasm_hip_csr_free": (None, [pcsr]),
@@ -106,6 +107,11 @@ def device_count():
 def usable_cpus():
     """hardware threads cut down to the CPU quota of the control group (what the threaded host stages use)"""
     return lib().spasm_hip_usable_cpus()
+
+
+def release_cached_memory():
+    """spasm_hip_release_cached_memory: the device memory the library parks between calls goes back to the device"""
+    lib().spasm_hip_release_cached_memory()
 
 
 def require_gpu(what):

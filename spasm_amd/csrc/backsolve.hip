@@ -643,6 +643,7 @@ struct ApplyArgs {
 	const int *col;               // column -> compact id
 	int r;                        // rows of R
 	int Smpad;                    // Sm rounded up to whole tile groups (= ldR)
+	int seg_words;                // bs_apply_s16_kernel: words of a row a wave holds in LDS at a time (a multiple of 64 * AP_TU; >= the row: one segment)
 	int waves;                    // waves per workgroup
 	size_t wave_bytes;            // LDS per wave: row buffer + list
 	uint32_t *dense_out;
@@ -957,7 +958,12 @@ __global__ __launch_bounds__(512) void bs_apply_s16_kernel(ApplyArgs d)
 	const MontDev F = a.F;
 	const SgnDev G = d.G;
 	const int Sm = a.Sm;
-	const int nwords = d.Smpad / 2;                       // a multiple of 64 * AP_TU
+	const int nwords_row = d.Smpad / 2;                   // a multiple of 64 * AP_TU
+	// A row wider than the LDS a wave may have (mk14.b4: 42,356 non-pivotal columns = 85 KB) is produced in SEGMENTS of
+	// seg_words words: the few entries of the input row are walked once per segment, the rows of R are read segment by
+	// segment -- every byte of R once, as before.  Staged and dense output only (the offset of a sparse row is known once
+	// its last segment is).
+	const int nseg = (nwords_row + d.seg_words - 1) / d.seg_words;
 	uint2 *plist = reinterpret_cast<uint2 *>(lds_raw + (size_t) wave * d.wave_bytes);
 	uint32_t *xw = reinterpret_cast<uint32_t *>(plist + AP_LIST);
 	short *xe = reinterpret_cast<short *>(xw);
@@ -977,10 +983,13 @@ __global__ __launch_bounds__(512) void bs_apply_s16_kernel(ApplyArgs d)
 		const int i = a.rows[k];
 		const int64_t lo = a.Ap[i], hi = a.Ap[i + 1];
 		st_input += (unsigned long long) (hi - lo);
+		int total = 0;                       // entries of the segments done so far
+	  for (int seg = 0; seg < nseg; seg++) {
+		const int w0 = seg * d.seg_words, nwords = min(d.seg_words, nwords_row - w0);
 		for (int t = lane; t < nwords; t += 64)
 			xw[t] = 0;
 		int npl = 0;                         // entries waiting in plist (wave-uniform)
-		int count = -1;                      // entries of the finished row, once known
+		int count = -1;                      // entries of the finished segment, once known
 		for (int64_t base = lo;; base += 64) {
 			bool piv = false;
 			uint32_t cid = 0;
@@ -989,8 +998,9 @@ __global__ __launch_bounds__(512) void bs_apply_s16_kernel(ApplyArgs d)
 				cid = (uint32_t) d.col[a.Aj[base + lane]];
 				bal = sgn_from_residue(reduce_sum(from_balanced(a.Ax[base + lane], F), F), G);
 				if (cid >= (uint32_t) d.r) {
-					const uint32_t t = cid - (uint32_t) d.r;
-					xe[t] = (short) sgn_canonical((int) xe[t] + bal, G);
+					const uint32_t t = cid - (uint32_t) d.r - 2u * (uint32_t) w0;          // (unsigned: columns before the segment wrap around)
+					if (t < 2u * (uint32_t) nwords)
+						xe[t] = (short) sgn_canonical((int) xe[t] + bal, G);
 				} else {
 					piv = bal != 0;
 				}
@@ -999,7 +1009,7 @@ __global__ __launch_bounds__(512) void bs_apply_s16_kernel(ApplyArgs d)
 			if (piv)
 				plist[npl + __popcll(mk & ((1ull << lane) - 1ull))] = uint2{cid * ldw256, (uint32_t) (-bal)};          // (where the row of R starts, in units of 256 words)
 			npl += __popcll(mk);
-			st_piv += (unsigned long long) __popcll(mk);
+			st_piv += (seg == 0) ? (unsigned long long) __popcll(mk) : 0ull;
 			const bool last = base + 64 >= hi;
 			if (npl > 0 && (last || npl + 64 > AP_LIST)) {
 				// apply the queued pivotal entries: x[tile group] += sum_e (-a_e) R[e][tile group], four rows of R at a
@@ -1023,7 +1033,7 @@ __global__ __launch_bounds__(512) void bs_apply_s16_kernel(ApplyArgs d)
 						const int idx = (pf_e + q < npl) ? pf_e + q : npl - 1;
 						const uint2 pe = plist[idx];
 						cf[q] = (pf_e + q < npl) ? (int) pe.y : 0;          // (coefficient 0: no effect)
-						const uint32_t *rq = R + ((((uint64_t) pe.x) << 8) & (uint64_t) row_mask) + t0c + lane;
+						const uint32_t *rq = R + ((((uint64_t) pe.x) << 8) & (uint64_t) row_mask) + w0 + t0c + lane;
 #pragma unroll
 						for (int u = 0; u < AP_TU; u++)
 							w[q][u] = rq[u * 64];          // (rows are padded to whole tile groups)
@@ -1081,34 +1091,40 @@ __global__ __launch_bounds__(512) void bs_apply_s16_kernel(ApplyArgs d)
 
 		// ---- output ----
 		if (d.dense_out != nullptr) {
-			uint32_t *out = d.dense_out + (int64_t) k * d.ldS;
-			for (int t = lane; t < Sm; t += 64) {
+			uint32_t *out = d.dense_out + (int64_t) k * d.ldS + 2 * w0;
+			for (int t = lane; t < min(2 * nwords, Sm - 2 * w0); t += 64) {
 				const int v = (int) xe[t];
 				out[t] = (uint32_t) (v < 0 ? v + G.p : v);
 			}
+			if (seg + 1 < nseg)
+				continue;
 			if (lane == 0)
 				a.row_len[k] = Sm;
 			st_done += 1;
 			continue;
 		}
-		if (count < 0) {                     // no pivotal entry in the last batch: the row was not swept
+		if (count < 0) {                     // no pivotal entry in the last batch: the segment was not swept
 			count = 0;
 			for (int t0 = 0; t0 < nwords; t0 += 64) {
 				const uint32_t w = xw[t0 + lane];
 				count += __popcll(__ballot((w & 0xFFFFu) != 0)) + __popcll(__ballot((w >> 16) != 0));
 			}
 		}
+		total += count;
 		if (d.stage != nullptr) {
-			uint32_t *out = d.stage + (int64_t) k * nwords;
+			uint32_t *out = d.stage + (int64_t) k * nwords_row + w0;
 			for (int t = lane; t < nwords; t += 64)
 				out[t] = xw[t];
+			if (seg + 1 < nseg)
+				continue;
 			if (lane == 0) {
-				a.row_len[k] = count;
-				atomicAdd(&d.block_sum[k / 1024], (unsigned long long) count);          // (SCAN_BLOCK rows per block)
+				a.row_len[k] = total;
+				atomicAdd(&d.block_sum[k / 1024], (unsigned long long) total);          // (SCAN_BLOCK rows per block)
 			}
 			st_done += 1;
 			continue;
 		}
+		// (sparse rows straight from the LDS: one segment, the launcher sees to it)
 		int64_t off = 0;
 		int *out_j = a.pool_j, *out_x = a.pool_x;
 		bool fits;
@@ -1169,6 +1185,7 @@ __global__ __launch_bounds__(512) void bs_apply_s16_kernel(ApplyArgs d)
 			}
 		}
 		st_done += fits ? 1 : 0;
+	  }          // segments
 	}
 	if (lane == 0) {
 		atomicAdd(&a.ctr64[C64_INPUT], st_input);
@@ -1535,13 +1552,17 @@ template <bool PACKED, bool PLAIN> void launch_apply_variant(const ApplyArgs &d,
 // host plan
 // --------------------------------------------------------------------------
 // Is the back-substituted image worth having for this factor?  Memory: r x Sm words.  Work: nnz(U') * Sm.
-bool backsolve_eligible(int r, int Sm, int64_t nnz_u, int64_t *bytes)
+bool backsolve_eligible(int r, int Sm, int64_t nnz_u, int64_t *bytes, int64_t prime)
 {
 	const int64_t ldR = ((int64_t) Sm + 511) / 512 * 512;
 	*bytes = (int64_t) r * ldR * 4;          // (2 bytes per entry when p < 2^16)
 	if (r <= 0 || Sm <= 0)
 		return false;
-	if (Sm > 24576)                       // the apply kernel keeps one row of S in LDS (96 KB)
+	// the apply kernels keep one row of S in LDS (96 KB); the one for signed 16-bit entries (p <= 44,927) goes through wider
+	// rows in segments
+	const bool segments = prime < 65536 && sgn_eligible(prime) && env_bs("SPASM_HIP_BS_SIGNED", 1) != 0 && env_bs("SPASM_HIP_BS_PACKED", 1) != 0 &&
+	                      env_bs("SPASM_HIP_BS_STAGED", 1) != 0 && env_bs("SPASM_HIP_BS_SEGMENTS", 1) != 0;
+	if (Sm > (segments ? 131072 : 24576))
 		return false;
 	if ((double) (nnz_u + r) * (double) Sm > 1.5e11)
 		return false;
@@ -1861,7 +1882,7 @@ void backsolve_plan(const FactPlan &P, spasm_hip_dfact *F, hipStream_t stream)
 void backsolve_free(spasm_hip_dfact *F)
 {
 	BsImage &B = F->bs;
-	(void) hipFree(B.d_R);
+	big_free(B.d_R);
 	(void) hipFree(B.d_col);
 	(void) hipFree(B.d_chunk);
 	(void) hipFree(B.d_chunk_extra);
@@ -1891,12 +1912,12 @@ void backsolve_build(const spasm_hip_dfact *F, hipStream_t stream)
 	const int elem = packed ? 2 : 4;
 	const size_t bytes = (size_t) B.r * (size_t) B.ldR * (size_t) elem;
 	if (B.d_R != nullptr && B.elem_bytes != elem) {
-		(void) hipFree(B.d_R);
+		big_free(B.d_R);
 		B.d_R = nullptr;
 	}
 	bool fresh = false;
 	if (B.d_R == nullptr) {
-		HIP_CHECK(hipMalloc(&B.d_R, bytes));
+		B.d_R = big_alloc(bytes);          // (from the block cache: tens of GB on a wide factor)
 		B.elem_bytes = elem;
 		fresh = true;
 	}
@@ -2105,7 +2126,14 @@ void launch_backsolve_apply(const SchurArgs &a, const spasm_hip_dfact *F, uint32
 		HIP_CHECK(hipGetLastError());
 		return;
 	}
-	const size_t per_wave = ((size_t) d.Smpad * (size_t) B.elem_bytes + (size_t) AP_LIST * sizeof(uint2) + 15) / 16 * 16;
+	// rows of more than 24,576 columns are produced in segments of 8,192 columns (signed 16-bit entries, staged or dense
+	// output): 16.5 KB of LDS per wave, eight waves per CU, where the whole row would leave one wave per CU
+	const bool staged_call = direct != nullptr && direct->stage != nullptr && dense_out == nullptr;
+	int seg_cols = d.Smpad;
+	if (B.sgn && d.Smpad > 24576 && (staged_call || dense_out != nullptr))
+		seg_cols = 8192;
+	d.seg_words = seg_cols / 2;
+	const size_t per_wave = ((size_t) seg_cols * (size_t) B.elem_bytes + (size_t) AP_LIST * sizeof(uint2) + 15) / 16 * 16;
 	if (per_wave > 150 * 1024)
 		die("launch_backsolve_apply: %d non-pivotal columns do not fit the LDS row buffer", B.Sm);
 	// as many waves as fit half of a CU's LDS (two workgroups per CU), at most 8, at least 1

@@ -183,7 +183,7 @@ struct DeviceMatrix {
 // hipFree); big_trim releases everything cached (the driver calls it on exit).
 void *big_alloc(size_t bytes);
 void big_free(void *ptr);
-void big_trim();
+void big_trim(size_t keep_bytes = 0);
 void resident_begin();
 void resident_end();
 void resident_forget(const struct spasm_csr *A);

@@ -25,7 +25,7 @@ size_t pull_lds_bytes(int rpad, int Sm);
 int64_t pull_slot_bytes(int rpad, int Sm);
 void launch_schur_pull(const SchurArgs &a, unsigned char *scratch, int64_t slot_bytes, const uint64_t *cp, const uint2 *cent,
                        const int2 *lvl, int nlev, int blocks, hipStream_t stream);
-bool backsolve_eligible(int r, int Sm, int64_t nnz_u, int64_t *bytes);
+bool backsolve_eligible(int r, int Sm, int64_t nnz_u, int64_t *bytes, int64_t prime);
 void backsolve_plan(const FactPlan &P, spasm_hip_dfact *F, hipStream_t stream);
 void backsolve_free(spasm_hip_dfact *F);
 void backsolve_build(const spasm_hip_dfact *F, hipStream_t stream);
@@ -100,7 +100,7 @@ void *big_alloc(size_t bytes)
 	}
 	if (hipMalloc(&ptr, bytes) != hipSuccess) {
 		(void) hipGetLastError();
-		big_trim();                          // cached blocks may be what is in the way
+		big_trim(0);                         // cached blocks may be what is in the way
 		HIP_CHECK(hipMalloc(&ptr, bytes));
 	}
 	if (bytes >= BIG_MIN) {
@@ -131,13 +131,30 @@ void big_free(void *ptr)
 	(void) hipFree(ptr);
 }
 
-void big_trim()
+void big_trim(size_t keep_bytes)
 {
 	std::vector<std::pair<void *, size_t>> blocks;
 	{
 		std::lock_guard<std::mutex> guard(g_big.mutex);
-		blocks.swap(g_big.free_blocks);
-		g_big.cached = 0;
+		if (keep_bytes == 0) {
+			blocks.swap(g_big.free_blocks);
+			g_big.cached = 0;
+		} else {
+			// the largest blocks stay (they are the ones that cost: up to 40 ms per GB to get back, seconds at times)
+			std::sort(g_big.free_blocks.begin(), g_big.free_blocks.end(), [](const auto &x, const auto &y) { return x.second > y.second; });
+			size_t kept = 0;
+			std::vector<std::pair<void *, size_t>> stay;
+			for (auto &b : g_big.free_blocks) {
+				if (kept + b.second <= keep_bytes) {
+					kept += b.second;
+					stay.push_back(b);
+				} else {
+					blocks.push_back(b);
+				}
+			}
+			g_big.free_blocks.swap(stay);
+			g_big.cached = kept;
+		}
 	}
 	for (auto &b : blocks)
 		(void) hipFree(b.first);
@@ -231,8 +248,13 @@ void resident_end()
 	while (!g_resident.empty())
 		resident_forget(g_resident.back().host);
 	g_resident_on = false;
+	// The driver is done.  Its large blocks (images, row pools, accumulators, FIFOs: 60-90 GB on mk14.b4) STAY in the cache, up
+	// to SPASM_HIP_KEEP_GB (default: the cap of the cache, 96; 0: everything goes back): allocating and freeing multi-GB blocks
+	// is erratic on these boxes -- 0.1 to 1 s apiece, now and then -- and made five of eight consecutive mk14.b4 calls take
+	// 1.0-2.3 s instead of 0.55 (keeping 32 or 64 GB did not help: whatever is handed back comes back slowly).
+	// spasm_hip_release_cached_memory() gives everything back; a failed hipMalloc of the library's own does too (big_alloc).
 	if (env_int("SPASM_HIP_KEEP_BLOCKS", 0) == 0)
-		big_trim();                          // the driver is done: cached blocks go back to the device
+		big_trim((size_t) std::max(0, env_int("SPASM_HIP_KEEP_GB", 96)) << 30);
 }
 
 void resident_counters(i64 *uploads, i64 *hits)
@@ -487,6 +509,17 @@ int spasm_hip_dschur_allgatherv(spasm_hip_comm *c, const spasm_hip_dwork *W, i64
 
 int spasm_hip_debug_plan(const struct spasm_csr *U, const int *qinv, int *label_of_row, int *lvl_end_of_row, int *lab,
                          int *info);
+
+// everything the library parks on the device between calls goes back to it: the block cache, the accumulator scratch
+void spasm_hip_release_cached_memory(void)
+{
+	big_trim(0);
+	if (g_scratch_cache.ptr != nullptr) {
+		(void) hipFree(g_scratch_cache.ptr);
+		g_scratch_cache.ptr = nullptr;
+		g_scratch_cache.bytes = 0;
+	}
+}
 
 int spasm_hip_device_count(void)
 {
@@ -812,7 +845,7 @@ spasm_hip_dfact *spasm_hip_dfact_create(const struct spasm_csr *U, const int *qi
 	// back-substituted image (backsolve.hip): planned when the non-pivotal columns are few enough for dense rows
 	// of R; R itself is computed by the first Schur complement that wants it
 	int64_t bs_bytes = 0;
-	if (env_int("SPASM_HIP_BACKSOLVE", -1) != 0 && backsolve_eligible(r, m - r, F->nnz, &bs_bytes))
+	if (env_int("SPASM_HIP_BACKSOLVE", -1) != 0 && backsolve_eligible(r, m - r, F->nnz, &bs_bytes, F->prime))
 		backsolve_plan(P, F, stream);
 	if (verbose() >= 2)
 		logmsg("[factor image] %d rows, %d levels: level schedule + relabelling %.1f ms, tables + upload %.1f ms, plan of the back-substitution %.1f ms\n",

@@ -150,6 +150,52 @@ def test_backsolve_dense_rows(oracle, monkeypatch, p, signed):
     assert np.array_equal(np.asarray(got, np.int64) % p, np.asarray(want, np.int64) % p)
 
 
+@pytest.mark.parametrize("p", [42013, 257])
+@pytest.mark.parametrize("nnon", [24577, 32768, 33000, 41000])
+def test_backsolve_rows_wider_than_the_lds(oracle, monkeypatch, p, nnon):
+    """more than 24,576 non-pivotal columns (mk14.b4 has 42,356): the apply kernel produces a row in segments of 8,192
+    columns -- whole segments, a last partial one, entries of the input row in every segment; sparse rows (staged output,
+    also in slices) and dense rows.  With that many free columns every row of the matrix finds a structural pivot, so the
+    factor is taken from the pivot rows alone and the other rows are reduced by it (spasm_schur takes any list of rows)."""
+    import torch
+    monkeypatch.setenv("SPASM_HIP_BACKSOLVE", "1")
+    rng = np.random.default_rng(nnon)
+    npiv, nred = 1200, 150
+    n, m, ti, tj, tx = _triangular_system(rng, p, npiv=npiv, nnon=nnon, nred=nred, deps=lambda k: 3, reach=50, np_per_row=40, red_entries=60)
+    A = oracle.compress(p, n, m, ti, tj, tx)
+    top = ti < npiv
+    P = oracle.compress(p, npiv, m, ti[top], tj[top], tx[top])
+    found, perm, F = oracle.pivots_extract_structural(P, oracle.empty_fact(P.n, P.m, p))
+    assert found == npiv
+    rows = np.arange(npiv, n, dtype=np.int32)
+    want, p_out_want, _ = oracle.schur(A, rows, F)
+    assert want.nnz > nred * nnon // 4               # (the rows fill in: every segment holds entries)
+    for stage_rows in (None, "37"):
+        if stage_rows:
+            monkeypatch.setenv("SPASM_HIP_STAGE_ROWS", stage_rows)
+        S, p_out = spasm_amd.schur(_as_product(A), rows, _fact(F))
+        assert np.array_equal(p_out, p_out_want)
+        assert oracle.same_matrix(oracle.CSR(S.n, S.m, S.p, S.j, S.x, p), want)
+        for i in range(S.n):
+            jj, _ = S.row(i)
+            assert np.all(np.diff(jj) > 0)
+    monkeypatch.delenv("SPASM_HIP_STAGE_ROWS")
+    dense_want, q_want, p_out_want = oracle.schur_dense(A, rows, F)
+    got, q, p_out = spasm_amd.schur_dense(_as_product(A), rows, _fact(F))
+    assert np.array_equal(q, q_want) and np.array_equal(p_out, p_out_want)
+    assert np.array_equal(np.asarray(got, np.int64) % p, np.asarray(dense_want, np.int64) % p)
+    # ... and it IS the image that produced them (device API: the statistics say which path ran)
+    dA = spasm_amd.DeviceCsr.from_host(_as_product(A))
+    dF = spasm_amd.DeviceFact(_fact(F))
+    W = spasm_amd.SchurWorkspace(len(rows), A.m, 2 * want.nnz + (1 << 20))
+    drows = torch.from_numpy(np.ascontiguousarray(rows, np.int32)).cuda()
+    S, st = spasm_amd.dschur(dA, drows, dF, W)
+    assert st.status == 0 and st.used_backsolve == 1 and st.nnz == want.nnz
+    assert st.kernel_other.decode().split("<")[0] == "bs_apply_s16_kernel" or st.kernel.decode().split("<")[0] == "bs_apply_s16_kernel"
+    H = S.to_host()
+    assert oracle.same_matrix(oracle.CSR(H.n, H.m, H.p, H.j, H.x, p), want)
+
+
 @pytest.mark.parametrize("signed", ["1", "0"])
 def test_backsolve_is_rebuilt_after_forget(oracle, monkeypatch, signed):
     """device API: the image is built by the first call, reused by the second, rebuilt after forget()."""
