@@ -158,74 +158,98 @@ def dense_tail_probe(torch, spasm_amd, dev, n=4096, m=32768):
 
 
 def sparse_path_probe(torch, spasm_amd, workloads, dev, name="mk14.b4", steps=3):
-    """The flow GL7d19 takes (sparse rounds on a Schur complement too wide for the back-substituted image, then the dense
-    tail), on a matrix of the same collection that can be generated offline: mk14.b4, 945,945 x 315,315 -- a STAND-IN, not
-    a BASELINE config.  Its first Schur complement (673,000 rows x 42,000 columns, 3.7 % dense, 1.06e9 entries) is computed
-    sparse with default options.  Reports that Schur complement on the device-level API (the way the headline step is
-    measured) and the whole spasm_hip_echelonize call with its time split."""
+    """The flow GL7d19 takes (a sparse round on a wide Schur complement, then the dense tail), on a matrix of the same
+    collection that can be generated offline: mk14.b4, 945,945 x 315,315 -- a STAND-IN, not a BASELINE config.  Its first
+    Schur complement (673,000 rows x 42,000 columns, 3.7 % dense, 1.06e9 entries) is computed sparse with default options.
+    Reports that Schur complement on the device-level API (the way the headline step is measured) through the path the
+    library takes by default -- since round 3 the back-substituted image, whose apply kernel goes through rows wider than
+    the LDS in segments -- and through the row-by-row kernels (what a factor too wide for an image gets: the row-group
+    kernel and its counters), then the whole spasm_hip_echelonize call with its time split."""
     t0 = time.perf_counter()
     A, rows, F, source = workloads.round0(name, PRIME, threads=0)
     t_prep = time.perf_counter() - t0
     dA = spasm_amd.DeviceCsr.from_host(A, dev)
-    t0 = time.perf_counter()
-    dF = spasm_amd.DeviceFact(F)
-    torch.cuda.synchronize()
-    image_ms = 1e3 * (time.perf_counter() - t0)
     drows = torch.from_numpy(np.ascontiguousarray(rows)).to(dev)
-    # one-shot budget of the host-pointer entry point (24 GB of accumulator slices), so that the numbers are those of a
-    # round inside spasm_hip_echelonize
-    os.environ["SPASM_HIP_SCRATCH_GB"] = "24"
-    try:
-        pool = 1 << 30
-        while True:
-            W = spasm_amd.SchurWorkspace(len(rows), A.m, pool)
-            _, st = spasm_amd.dschur(dA, drows, dF, W, fetch=False)
-            if st.status == 0:
-                break
+
+    def measure(env):
+        os.environ.update(env)
+        try:
+            t0 = time.perf_counter()
+            dF = spasm_amd.DeviceFact(F)
+            torch.cuda.synchronize()
+            image_ms = 1e3 * (time.perf_counter() - t0)
+            pool = 1 << 30
+            while True:
+                W = spasm_amd.SchurWorkspace(len(rows), A.m, pool)
+                _, st = spasm_amd.dschur(dA, drows, dF, W, fetch=False)
+                if st.status == 0:
+                    break
+                W.close()
+                pool *= 2
+            best = None
+            for _ in range(steps):
+                dF.forget()                      # (a step builds what it needs: the image R is part of it)
+                _, st = spasm_amd.dschur(dA, drows, dF, W, fetch=False)
+                if best is None or st.ms_total < best.ms_total:
+                    best = st
+            levels = dF.levels
             W.close()
-            pool *= 2
-        best = None
-        for _ in range(steps):
-            _, st = spasm_amd.dschur(dA, drows, dF, W, fetch=False)
-            if best is None or st.ms_total < best.ms_total:
-                best = st
-        st = best
-    finally:
-        os.environ.pop("SPASM_HIP_SCRATCH_GB", None)
+            dF.close()
+            return best, image_ms, levels
+        finally:
+            for k in env:
+                os.environ.pop(k, None)
+
+    st, image_ms, levels = measure({})
+    out = {"what": "%s (%dx%d, %d nnz), STAND-IN for the GL7d19 class: round-0 Schur complement of %d rows w.r.t. %d pivots, "
+                   "%d non-pivotal columns, device-level API, default path" % (name, A.n, A.m, A.nnz, len(rows), F.U.n, A.m - F.U.n),
+           "rows": len(rows), "ms_per_step": st.ms_total, "rows_per_s": len(rows) / (st.ms_total * 1e-3),
+           "path": "back-substituted factor image" if st.used_backsolve else "row by row",
+           "levels": levels, "schur_nnz": int(st.nnz), "schur_density": st.nnz / (len(rows) * float(A.m - F.U.n)),
+           "factor_image_ms": image_ms, "prepare_s": t_prep}
+    if st.used_backsolve:
+        kern = {st.kernel.decode(): {"ms": st.ms_backsolve, "algorithmic_bytes": int(st.bytes_backsolve)},
+                st.kernel_other.decode(): {"ms": st.ms_apply, "algorithmic_bytes": int(st.bytes_apply)},
+                st.kernel_expand.decode(): {"ms": st.ms_expand, "algorithmic_bytes": int(st.bytes_expand)}}
+        for k in kern.values():
+            if not k["ms"] > 0:                  # (staged output in several slices: the expansions run between the slices of the apply
+                k["ms"] = None                   #  kernel and are inside its time)
+            k["GB_per_s"] = k["algorithmic_bytes"] / (k["ms"] * 1e-3) / 1e9 if k["ms"] else None
+            k["frac"] = k["GB_per_s"] / HBM_PEAK_GBS if k["GB_per_s"] else None
+        out["kernels"] = kern
+    # the row-by-row kernels on the same batch, with the one-shot budget of the host-pointer entry point (24 GB of accumulator
+    # slices), so that the numbers are those of a round inside spasm_hip_echelonize
+    st, _, _ = measure({"SPASM_HIP_BACKSOLVE": "0", "SPASM_HIP_SCRATCH_GB": "24"})
     kernel = st.kernel.decode()
     k_ms = st.ms_group if st.used_group_kernel and not st.group_aborted else st.ms_tier2
     algo = 16 * st.entries_streamed + 8 * (st.input_entries + st.nnz) + 20 * st.eliminations + 20 * st.rows
-    out = {"what": "%s (%dx%d, %d nnz), STAND-IN for the GL7d19 class: round-0 Schur complement of %d rows w.r.t. %d pivots, "
-                   "%d non-pivotal columns, device-level API, 24 GB of accumulator slices" % (name, A.n, A.m, A.nnz, len(rows), F.U.n, A.m - F.U.n),
-           "rows": len(rows), "ms_per_step": st.ms_total, "rows_per_s": len(rows) / (st.ms_total * 1e-3),
-           "kernel": kernel, "kernel_ms": k_ms, "gather_ms": st.ms_finalize, "gave_up": bool(st.group_aborted),
-           "levels": dF.levels, "schur_nnz": int(st.nnz), "schur_density": st.nnz / (len(rows) * float(A.m - F.U.n)),
-           "eliminations": int(st.eliminations), "entries_streamed": int(st.entries_streamed), "group_pivots": int(st.group_pivots),
-           "lane_efficiency": (st.eliminations / (64.0 * st.group_pivots)) if st.group_pivots else None,
-           # one 256-byte no-return atomic instruction per (applied pivot, entry of its row) = 4 requests of 64 B
-           "atomic_requests_per_s": (4.0 * st.entries_streamed / 64.0 / max(st.eliminations / (64.0 * st.group_pivots), 1e-9) / (k_ms * 1e-3))
-           if st.group_pivots else None,
-           "slices_in_flight": st.group_slots, "slices_wanted": st.group_slots_wanted, "waves_per_group": st.group_waves,
-           "slice_bytes": int(st.group_slot_bytes),
-           "effective_bytes": int(algo), "effective_frac": algo / (k_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
-           "effective_note": "bytes the reference's algorithm moves on its dense x (DESIGN.md section 4); the row-group kernel shares a 256-B "
-                             "line among the 64 rows of a group, so this is not HBM traffic",
-           "factor_image_ms": image_ms, "prepare_s": t_prep}
+    rb = {"what": "same batch with SPASM_HIP_BACKSOLVE=0, 24 GB of accumulator slices", "ms_per_step": st.ms_total,
+          "rows_per_s": len(rows) / (st.ms_total * 1e-3), "same_nnz": int(st.nnz) == out["schur_nnz"],
+          "kernel": kernel, "kernel_ms": k_ms, "gather_ms": st.ms_finalize, "gave_up": bool(st.group_aborted),
+          "eliminations": int(st.eliminations), "entries_streamed": int(st.entries_streamed), "group_pivots": int(st.group_pivots),
+          "lane_efficiency": (st.eliminations / (64.0 * st.group_pivots)) if st.group_pivots else None,
+          # one 256-byte no-return atomic instruction per (applied pivot, entry of its row) = 4 requests of 64 B
+          "atomic_requests_per_s": (4.0 * st.entries_streamed / 64.0 / max(st.eliminations / (64.0 * st.group_pivots), 1e-9) / (k_ms * 1e-3))
+          if st.group_pivots else None,
+          "slices_in_flight": st.group_slots, "slices_wanted": st.group_slots_wanted, "waves_per_group": st.group_waves,
+          "slice_bytes": int(st.group_slot_bytes),
+          "effective_bytes": int(algo), "effective_frac": algo / (k_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+          "effective_note": "bytes the reference's algorithm moves on its dense x (DESIGN.md section 4); the row-group kernel shares a 256-B "
+                            "line among the 64 rows of a group, so this is not HBM traffic"}
     tr = quoted_traffic(kernel, name, len(rows))
     if tr[0]:
-        out.update({"traffic": tr[0], "hbm_frac": tr[0] / (k_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, "traffic_source": tr[2]})
-    W.close()
-    dF.close()
+        rb.update({"traffic": tr[0], "hbm_frac": tr[0] / (k_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, "traffic_source": tr[2]})
+    out["row_by_row"] = rb
     del dA, drows
     torch.cuda.empty_cache()
     os.environ.pop("SPASM_HIP_THREADS", None)
     runs = []
-    for _ in range(2):
+    for _ in range(3):
         t0 = time.perf_counter()
         fact = spasm_amd.echelonize(A)
         runs.append((time.perf_counter() - t0, spasm_amd.echelonize_profile(), int(fact.U.n)))
     best = min(runs, key=lambda r: r[0])
-    out["end_to_end"] = {"what": "spasm_hip_echelonize, default options, 2 calls", "rank": best[2], "ranks_agree": len({r[2] for r in runs}) == 1,
+    out["end_to_end"] = {"what": "spasm_hip_echelonize, default options, 3 calls", "rank": best[2], "ranks_agree": len({r[2] for r in runs}) == 1,
                          "seconds_all": [r[0] for r in runs], "split_of_best_call": best[1]}
     return out
 
@@ -240,10 +264,15 @@ def stand_in_runs(spasm_amd, workloads):
         for t, a in enumerate(info["rank_args"]):
             if a == "--dense-threshold":
                 opts.sparsity_threshold = float(info["rank_args"][t + 1])
-        t0 = time.perf_counter()
-        fact = spasm_amd.echelonize(A, opts)
+        runs = []
+        for _ in range(3):
+            t0 = time.perf_counter()
+            fact = spasm_amd.echelonize(A, opts)
+            runs.append((time.perf_counter() - t0, spasm_amd.echelonize_profile(), int(fact.U.n)))
+        best = min(runs, key=lambda r: r[0])
         out.append({"name": name, "stand_in_for": info["for"], "shape": [A.n, A.m], "nnz": int(A.nnz), "options": " ".join(info["rank_args"]),
-                    "rank": int(fact.U.n), "seconds": time.perf_counter() - t0, "split": spasm_amd.echelonize_profile()})
+                    "rank": best[2], "ranks_agree": len({r[2] for r in runs}) == 1, "seconds": best[0], "seconds_all": [r[0] for r in runs],
+                    "split": best[1]})
     return out
 
 
