@@ -2791,6 +2791,40 @@ __global__ __launch_bounds__(64) void combine_rows_kernel(const int64_t *Ap, con
 	}
 }
 
+// The few combinations of ALL the rows that end a low-rank finish (w == 0, N <= 16: spasm_echelonize_test_completion takes
+// nine), over a large input -- the 673,000 rows and 1.06e9 entries of mk14.b4's Schur complement: one wave per (combination,
+// row) reads every row N times and sends N atomic requests per entry, 6.3e9 of them, 0.16-0.19 s at the rate the memory
+// side takes them.  Here a wave takes a row ONCE, sixteen lanes per entry -- one per combination -- and the accumulator is
+// laid out [column][16]: the sixteen adds of an entry fall into one 128-byte line and travel as one or two requests.
+// transpose_combinations_kernel puts the result where the other kernels expect it ([combination][column]).
+__global__ __launch_bounds__(64) void combine_all_rows_kernel(const int64_t *Ap, const int *Aj, const int *Ax, const int *rows, int nrows, int N, uint64_t salt,
+                                                             unsigned long long *Yt, MontDev F)
+{
+	const int lane = threadIdx.x, k = lane & 15, e = lane >> 4;
+	for (int64_t t = blockIdx.x; t < nrows; t += gridDim.x) {
+		const uint64_t h = mix64(salt ^ mix64(((uint64_t) k << 32) ^ (uint64_t) t));          // (the generator of combine_rows_kernel)
+		const uint32_t coeff = (k < N) ? uniform_below(h, F.p) : 0u;
+		const uint32_t cm = montmul(coeff, F.r2, F);
+		const int i = rows[t];
+		for (int64_t px = Ap[i] + e; px < Ap[i + 1]; px += 4) {
+			const int a = Ax[px];
+			const uint32_t v = (a < 0) ? (uint32_t) a + F.p : (uint32_t) a;
+			if (coeff != 0)
+				atomicAdd(&Yt[(int64_t) Aj[px] * 16 + k], (unsigned long long) montmul(cm, v % F.p, F));
+		}
+	}
+}
+
+__global__ __launch_bounds__(256) void transpose_combinations_kernel(const unsigned long long *Yt, int N, int m, unsigned long long *Y)
+{
+	const int64_t idx = (int64_t) blockIdx.x * 256 + threadIdx.x;          // (column, combination): reads are contiguous
+	if (idx >= (int64_t) m * 16)
+		return;
+	const int j = (int) (idx >> 4), k = (int) (idx & 15);
+	if (k < N)
+		Y[(int64_t) k * m + j] = Yt[idx];
+}
+
 // per row of the dense accumulator: number of entries that are non-zero mod p
 __global__ __launch_bounds__(256) void dense_count_kernel(const unsigned long long *Y, int N, int m, uint32_t p, int *row_len)
 {
@@ -2919,6 +2953,18 @@ void launch_combine(const int64_t *Ap, const int *Aj, const int *Ax, const int *
 {
 	const int64_t terms = (w > 0) ? (int64_t) w : (int64_t) nrows;
 	const int64_t total = (int64_t) N * terms;
+	if (w <= 0 && N <= 16 && nrows >= 4096 && !std::getenv("SPASM_HIP_COMBINE_PER_PAIR")) {
+		// every row, few combinations: each row once, the combinations side by side (combine_all_rows_kernel); Y arrives zeroed
+		unsigned long long *Yt = (unsigned long long *) big_alloc((size_t) m * 16 * sizeof(unsigned long long));
+		HIP_CHECK(hipMemsetAsync(Yt, 0, (size_t) m * 16 * sizeof(unsigned long long), stream));
+		hipLaunchKernelGGL(combine_all_rows_kernel, dim3((unsigned) std::min<int64_t>(nrows, 65536)), dim3(64), 0, stream, Ap, Aj, Ax, rows, nrows, N, salt, Yt,
+		                   to_dev(M));
+		hipLaunchKernelGGL(transpose_combinations_kernel, dim3((unsigned) (((int64_t) m * 16 + 255) / 256)), dim3(256), 0, stream, Yt, N, m, Y);
+		HIP_CHECK(hipGetLastError());
+		HIP_CHECK(hipStreamSynchronize(stream));
+		big_free(Yt);
+		return;
+	}
 	const int blocks = (int) (total < 65536 ? (total > 0 ? total : 1) : 65536);
 	hipLaunchKernelGGL(combine_rows_kernel, dim3(blocks), dim3(64), 0, stream, Ap, Aj, Ax, rows, nrows, N, w, m, salt, Y,
 	                   to_dev(M));
