@@ -1662,13 +1662,27 @@ void backsolve_plan(const FactPlan &P, spasm_hip_dfact *F, hipStream_t stream)
 			die("backsolve_plan: 2^32 is not invertible mod %lld", (long long) P.prime);
 		unmont = (uint64_t) ((t0 % P.prime + P.prime) % P.prime);
 	}
-	auto coeff = [&](uint32_t y_mont) -> uint32_t { return B.plain ? (uint32_t) (((uint64_t) y_mont * unmont) % (uint64_t) P.prime) : y_mont; };
+	// (x mod p for x < 2^64 without a division per entry: q = floor(x * floor(2^64 / p) / 2^64) is the quotient or one less)
+	const uint64_t pu64 = (uint64_t) P.prime, barrett = ~0ull / pu64;
+	auto mod_p = [&](uint64_t x) -> uint32_t {
+		uint64_t rem = x - (uint64_t) (((unsigned __int128) x * barrett) >> 64) * pu64;
+		while (rem >= pu64)
+			rem -= pu64;
+		return (uint32_t) rem;
+	};
+	auto coeff = [&](uint32_t y_mont) -> uint32_t { return B.plain ? mod_p((uint64_t) y_mont * unmont) : y_mont; };
 	auto dep_coeff = [&](uint32_t y_mont) -> uint32_t {
 		const uint32_t c = coeff(y_mont);
 		if (!B.sgn)
 			return c;
 		const int64_t bal = ((int64_t) c > P.prime / 2) ? (int64_t) c - P.prime : (int64_t) c;
 		return (uint32_t) (int32_t) (-bal);
+	};
+	double t_mark = wtime();
+	auto lap = [&](const char *what) {
+		if (verbose() >= 3)
+			logmsg("[factor image/back-substitution plan] %s %.2f ms\n", what, 1e3 * (wtime() - t_mark));
+		t_mark = wtime();
 	};
 	// split every row into pivotal dependencies (compact ids) and non-pivotal entries
 	std::vector<uint64_t> dep_rp((size_t) r + 1, 0), np_rp((size_t) r + 1, 0);
@@ -1691,6 +1705,7 @@ void backsolve_plan(const FactPlan &P, spasm_hip_dfact *F, hipStream_t stream)
 		np_rp[n + 1] = np.size();
 	}
 
+	lap("dependencies / non-pivotal entries");
 	// chunks, from the last row to the first
 	std::vector<BsChunk> chunks;
 	std::vector<int> chunk_extra;
@@ -1863,6 +1878,7 @@ void backsolve_plan(const FactPlan &P, spasm_hip_dfact *F, hipStream_t stream)
 	B.d_np = dalloc<uint2>((int64_t) np.size());
 	B.d_np_row = dalloc<int>((int64_t) np_row.size());
 	B.d_chunk_extra = dalloc<int>((int64_t) chunk_extra.size());
+	lap("chunks, passes, near and far tables");
 	upload(B.d_col, colmap, stream);
 	upload(B.d_chunk, chunks, stream);
 	upload(B.d_chunk_extra, chunk_extra, stream);
@@ -1875,6 +1891,7 @@ void backsolve_plan(const FactPlan &P, spasm_hip_dfact *F, hipStream_t stream)
 	upload(B.d_np, np, stream);
 	upload(B.d_np_row, np_row, stream);
 	HIP_CHECK(hipStreamSynchronize(stream));      // the host vectors die here
+	lap("uploads");
 	B.planned = true;
 	B.valid = false;
 }

@@ -1,5 +1,6 @@
 // Launchers and C ABI of the sparse Schur complement (see include/spasm_hip.h).
 #include <algorithm>
+#include <thread>
 #include <cinttypes>
 #include <mutex>
 #include <vector>
@@ -33,6 +34,7 @@ bool backsolve_stages_output(const spasm_hip_dfact *F, int64_t *row_bytes);
 void launch_backsolve_apply(const SchurArgs &a, const spasm_hip_dfact *F, uint32_t *dense_out, int64_t ldS, hipStream_t stream,
                             BsDirectOut *direct);
 bool backsolve_wanted(const spasm_hip_dfact *F, bool other_path_forced, int nrows);
+int usable_cpus();          // host_pivots.cpp
 // multi-GPU layer (dist_api.hip)
 spasm_hip_comm *current_comm();
 int comm_rank(const spasm_hip_comm *c);
@@ -542,6 +544,12 @@ static void plan_factor(const struct spasm_csr *U, const int *qinv, FactPlan &P)
 	P.m = m;
 	P.r = r;
 	P.prime = prime;
+	double t_mark = wtime();
+	auto lap = [&](const char *what) {
+		if (verbose() >= 3)
+			logmsg("[factor image/plan] %s %.2f ms\n", what, 1e3 * (wtime() - t_mark));
+		t_mark = wtime();
+	};
 	for (int k = 0; k < r; k++) {
 		if (U->p[k + 1] == U->p[k])
 			die("row %d of U is empty", k);
@@ -564,7 +572,26 @@ static void plan_factor(const struct spasm_csr *U, const int *qinv, FactPlan &P)
 	// height of every pivot row in the dependency DAG (row k depends on the
 	// pivot rows of the pivotal columns it touches); iterative DFS
 	std::vector<int> height((size_t) (r > 0 ? r : 1), 0);
-	{
+	// The rows of a factor come in topological order as a rule (spasm_pivots.c:307-372 appends them that way, round after
+	// round: a row only touches pivot columns of rows after it): then one pass from the last row to the first gives the
+	// heights.  Any dependency on an earlier row sends the whole computation to the general search below.
+	bool forward_only = true;
+	for (int k = r - 1; k >= 0 && forward_only; k--) {
+		int h = 0;
+		for (i64 px = U->p[k] + 1; px < U->p[k + 1]; px++) {
+			const int k2 = qinv[U->j[px]];
+			if (k2 < 0)
+				continue;
+			if (k2 <= k) {
+				forward_only = false;
+				break;
+			}
+			h = std::max(h, height[k2] + 1);
+		}
+		height[k] = h;
+	}
+	if (!forward_only) {
+		std::fill(height.begin(), height.end(), 0);
 		std::vector<unsigned char> state((size_t) (r > 0 ? r : 1), 0);   // 0 new, 1 open, 2 done
 		std::vector<int> stk;
 		std::vector<i64> pos;
@@ -604,6 +631,7 @@ static void plan_factor(const struct spasm_csr *U, const int *qinv, FactPlan &P)
 			}
 		}
 	}
+	lap("checks + heights");
 	int hmax = 0;
 	for (int k = 0; k < r; k++)
 		hmax = std::max(hmax, height[k]);
@@ -685,42 +713,58 @@ static void plan_factor(const struct spasm_csr *U, const int *qinv, FactPlan &P)
 			}
 		}
 	}
+	lap("levels + labels");
 	// rows of U' in label order, pivot entry dropped, values * R mod p
 	const i64 nnz = U->p[r] - r;
+	// (v << 32) mod p without a 64-bit division per entry: q = floor(x * floor(2^64 / p) / 2^64) is the quotient or one less
+	const uint64_t pu64 = (uint64_t) prime, barrett = ~0ull / pu64;
+	auto shifted_mod = [&](uint64_t v) -> uint32_t {
+		const uint64_t x = v << 32;
+		const uint64_t qh = (uint64_t) (((unsigned __int128) x * barrett) >> 64);
+		uint64_t rem = x - qh * pu64;
+		while (rem >= pu64)
+			rem -= pu64;
+		return (uint32_t) rem;
+	};
 	P.rp.assign((size_t) rpad + 1, 0);
 	P.ent.assign((size_t) (nnz > 0 ? nnz : 1), uint2{0, 0});
-	std::vector<int> deg((size_t) (m > 0 ? m : 1), 0);
-	i64 w = 0;
-	for (int c = 0; c < rpad; c++) {
-		const int k = P.kof[c];
-		P.rp[c] = (uint64_t) w;
-		if (k < 0)
-			continue;
-		for (i64 px = U->p[k] + 1; px < U->p[k + 1]; px++) {
-			const uint64_t v = zp_unsigned(prime, U->x[px]);
-			uint2 e;
-			e.x = P.lab[U->j[px]];
-			e.y = (uint32_t) ((v << 32) % (uint64_t) prime);
-			P.ent[w++] = e;
-			deg[U->j[px]] += 1;
+	{
+		i64 w = 0;
+		for (int c = 0; c < rpad; c++) {
+			const int k = P.kof[c];
+			P.rp[c] = (uint64_t) w;
+			if (k >= 0)
+				w += U->p[k + 1] - U->p[k] - 1;
 		}
+		P.rp[rpad] = (uint64_t) w;
 	}
-	P.rp[rpad] = (uint64_t) w;
-	for (int j = 0; j < m; j++)
-		P.maxdeg = std::max(P.maxdeg, deg[j]);
 	// the first four entries of every row again, at a fixed place (label * 4): the row-group kernel
 	// fetches them together with the accumulator line, without waiting for the row extent
 	P.head.assign((size_t) (rpad > 0 ? rpad : 1) * 4, uint2{0xFFFFFFFFu, 0u});
-	for (int c = 0; c < rpad; c++) {
-		const uint64_t len = P.rp[c + 1] - P.rp[c];
-		for (uint64_t t = 0; t < len && t < 4; t++)
-			P.head[(size_t) c * 4 + t] = P.ent[P.rp[c] + t];
-	}
+	// The rows are gathered in label order -- a cache miss per row and per entry (the label of its column) -- by a few threads,
+	// each a range of labels; the connected components below only need the labels and run beside them.
+	auto fill = [&](int c0, int c1) {
+		for (int c = c0; c < c1; c++) {
+			const int k = P.kof[c];
+			if (k < 0)
+				continue;
+			uint64_t w = P.rp[c];
+			for (i64 px = U->p[k] + 1; px < U->p[k + 1]; px++) {
+				uint2 e;
+				e.x = P.lab[U->j[px]];
+				e.y = shifted_mod(zp_unsigned(prime, U->x[px]));
+				P.ent[w++] = e;
+			}
+			const uint64_t len = P.rp[c + 1] - P.rp[c];
+			for (uint64_t t = 0; t < len && t < 4; t++)
+				P.head[(size_t) c * 4 + t] = P.ent[P.rp[c] + t];
+		}
+	};
 	// connected components of the pivot graph (row c -- the pivots it touches): rows of the matrix whose pivotal
 	// entries lie in different components share no elimination at all; the row-group kernel regroups rows by
 	// component when the order of the row list turns out to be unrelated to the structure
 	P.comp.assign((size_t) (rpad > 0 ? rpad : 1), 0);
-	{
+	auto components = [&]() {
 		std::vector<uint32_t> parent((size_t) (rpad > 0 ? rpad : 1));
 		for (int c = 0; c < rpad; c++)
 			parent[c] = (uint32_t) c;
@@ -731,13 +775,17 @@ static void plan_factor(const struct spasm_csr *U, const int *qinv, FactPlan &P)
 			}
 			return x;
 		};
-		for (int c = 0; c < rpad; c++)
-			for (uint64_t e = P.rp[c]; e < P.rp[c + 1]; e++)
-				if (P.ent[e].x < (uint32_t) rpad) {
-					const uint32_t a = find((uint32_t) c), b = find(P.ent[e].x);
+		for (int k = 0; k < r; k++) {
+			const uint32_t c = (uint32_t) P.label_of_row[k];
+			for (i64 px = U->p[k] + 1; px < U->p[k + 1]; px++) {
+				const uint32_t t = P.lab[U->j[px]];
+				if (t < (uint32_t) rpad) {
+					const uint32_t a = find(c), b = find(t);
 					if (a != b)
 						parent[std::max(a, b)] = std::min(a, b);          // the root is the smallest label
 				}
+			}
+		}
 		std::vector<int> members((size_t) (rpad > 0 ? rpad : 1), 0);
 		for (int c = 0; c < rpad; c++) {
 			P.comp[c] = find((uint32_t) c);
@@ -749,7 +797,30 @@ static void plan_factor(const struct spasm_csr *U, const int *qinv, FactPlan &P)
 				P.ncomp += 1;
 				P.comp_largest = std::max(P.comp_largest, members[c]);
 			}
+	};
+	{
+		const int T = (r < 20000) ? 1 : std::max(1, std::min(8, usable_cpus() - 1));
+		std::vector<std::thread> pool;
+		if (T > 1)
+			pool.emplace_back(components);
+		for (int t = 1; t < T; t++)
+			pool.emplace_back(fill, (int) ((i64) rpad * t / T), (int) ((i64) rpad * (t + 1) / T));
+		fill(0, (int) ((i64) rpad / T));
+		if (T == 1)
+			components();
+		for (auto &th : pool)
+			th.join();
 	}
+	{
+		std::vector<int> deg((size_t) (m > 0 ? m : 1), 0);
+		for (int k = 0; k < r; k++)
+			for (i64 px = U->p[k] + 1; px < U->p[k + 1]; px++)
+				deg[U->j[px]] += 1;
+		for (int j = 0; j < m; j++)
+			P.maxdeg = std::max(P.maxdeg, deg[j]);
+	}
+	lap("entries + heads + components");
+
 }
 
 // CPU-only view of the plan, for tests: label of each row of U, end of the
