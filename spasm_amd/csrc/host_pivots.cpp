@@ -465,12 +465,14 @@ extern "C" int spasm_hip_pivots_extract_structural(const struct spasm_csr *A, co
 	int npiv = 0;
 	if (!dist || comm_rank(comm) == 0) {
 		bool ordered = false;
+		double t_fl = 0.0, t_greedy = 0.0, t_device = 0.0;
 		npiv = S.leftmost_entries();
 		logmsg("[pivots] Faugere-Lachartre: %d pivots found [%.1fs]\n", npiv, wtime() - t0);
 		double t1 = wtime();
 		int extra = S.free_columns();
 		npiv += extra;
 		logmsg("[pivots] Faugere-Lachartre on columns: %d pivots found [%.1fs]\n", extra, wtime() - t1);
+		t_fl = wtime() - t0;
 		if (opts == nullptr || opts->enable_greedy_pivot_search) {
 			t1 = wtime();
 			int threads = 0;
@@ -488,9 +490,15 @@ extern "C" int spasm_hip_pivots_extract_structural(const struct spasm_csr *A, co
 				qinv0 = S.qinv;
 			}
 			extra = (threads > 1) ? device_acyclic_greedy(A, S.pinv.data(), S.qinv.data()) : -1;
+			t_device = wtime() - t1;
 			if (extra >= 0) {
+				const double ta = wtime();
 				S.topological_rows(npiv + extra, p);
-				if (!S.triangular(npiv + extra, p)) {
+				const double tb = wtime();
+				const bool fine = S.triangular(npiv + extra, p);
+				if (verbose() >= 3)
+					logmsg("[pivots] order %.1f ms, check %.1f ms\n", 1e3 * (tb - ta), 1e3 * (wtime() - tb));
+				if (!fine) {
 					std::fprintf(stderr, "[pivots] the pivots of the device search are NOT cycle-free (a bug: please report); discarded, searching on the host\n");
 					S.pinv = pinv0;
 					S.qinv = qinv0;
@@ -506,11 +514,16 @@ extern "C" int spasm_hip_pivots_extract_structural(const struct spasm_csr *A, co
 				extra = (threads > 1) ? S.acyclic_greedy_threads(threads) : S.acyclic_greedy();
 			}
 			npiv += extra;
+			t_greedy = wtime() - t1;
 			logmsg("[pivots] greedy alternating cycle-free search: %d pivots found [%.1fs]\n", extra, wtime() - t1);
 		}
 		logmsg("[pivots] %d pivots found\n", npiv);
+		const double t_order = wtime();
 		if (!ordered)
 			S.topological_rows(npiv, p);
+		if (verbose() >= 2)
+			logmsg("[pivots] Faugere-Lachartre steps %.1f ms, greedy search %.1f ms (%.1f on the device, then order + check), order %.1f ms\n", 1e3 * t_fl, 1e3 * t_greedy, 1e3 * t_device,
+			       1e3 * (wtime() - t_order));
 
 	}
 	if (dist) {
@@ -519,6 +532,8 @@ extern "C" int spasm_hip_pivots_extract_structural(const struct spasm_csr *A, co
 		comm_bcast_host(comm, S.pinv.data(), (size_t) n * sizeof(int), 0);
 	}
 
+	const double t_searched = wtime();
+	const uint64_t pu64 = (uint64_t) prime, barrett = ~0ull / pu64;          // x mod p = x - floor(x * floor(2^64 / p) / 2^64) * p, or p more
 	struct spasm_csr *U = fact->U;
 	struct spasm_triplet *L = fact->Ltmp;
 	i64 unz = U->p[U->n];
@@ -544,7 +559,8 @@ extern "C" int spasm_hip_pivots_extract_structural(const struct spasm_csr *A, co
 			spasm_hip_add_entry(L, i_out, U->n, pivot);
 			fact->p[U->n] = i_out;
 		}
-		const spasm_ZZp scale = zp_inverse(prime, pivot);
+		// (boundary matrices have pivots +-1: no inverse, no product; otherwise one reduction per entry without a division)
+		const spasm_ZZp scale = (pivot == 1) ? 1 : (pivot == -1) ? -1 : zp_inverse(prime, pivot);
 		U->j[unz] = j;
 		U->x[unz] = 1;
 		unz += 1;
@@ -552,11 +568,29 @@ extern "C" int spasm_hip_pivots_extract_structural(const struct spasm_csr *A, co
 			if (A->j[px] == j)
 				continue;
 			U->j[unz] = A->j[px];
-			U->x[unz] = zp_mul(prime, scale, A->x[px]);
+			const spasm_ZZp a = A->x[px];
+			spasm_ZZp v;
+			if (scale == 1) {
+				v = a;
+			} else if (scale == -1 && a != -a) {
+				v = -a;
+			} else {
+				const int64_t t = (int64_t) scale * a;
+				const uint64_t u = (uint64_t) (t < 0 ? -t : t);
+				uint64_t rem = u - (uint64_t) (((unsigned __int128) u * barrett) >> 64) * pu64;
+				while (rem >= pu64)
+					rem -= pu64;
+				if (t < 0 && rem != 0)
+					rem = pu64 - rem;
+				v = zp_balance(prime, (int64_t) rem);
+			}
+			U->x[unz] = v;
 			unz += 1;
 		}
 		U->n += 1;
 		U->p[U->n] = unz;
 	}
+	if (verbose() >= 2)
+		logmsg("[pivots] search and order %.1f ms, rows of U %.1f ms\n", 1e3 * (t_searched - t0), 1e3 * (wtime() - t_searched));
 	return npiv;
 }
