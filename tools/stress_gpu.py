@@ -85,6 +85,7 @@ while time.time() < t_end:
         want_rank = orc.echelonize(E).U.n
         for finish in ("1", "0"):            # device-resident dense finish / the host loop
             os.environ["SPASM_HIP_DEVICE_FINISH"] = finish
+            os.environ["SPASM_HIP_ROW_PANELS"] = str(int(rng.choice([-1, 0, 1])))          # echelon rows: default rule / column panels / row panels
             o = spasm_amd.default_opts()
             if rng.integers(0, 2):
                 o.sparsity_threshold = -1.0          # dense finish straight away
@@ -97,5 +98,26 @@ while time.time() < t_end:
                 fails += 1
                 print("MISMATCH echelonize %dx%d per_row=%d p=%d finish=%s: rank %d, oracle %d" % (en, em, eper, p, finish, got, want_rank), flush=True)
         os.environ.pop("SPASM_HIP_DEVICE_FINISH", None)
+        os.environ.pop("SPASM_HIP_ROW_PANELS", None)
+    # ---- matrices large enough for the pivot search on the device (>= 20,000 rows): the rank must not depend on where the
+    # search runs (device with the reached-bits in LDS / in HBM, host threads) nor on transposition
+    if cases % 23 == 0:
+        en, em, eper = int(rng.integers(20000, 60000)), int(rng.integers(8000, 70000)), int(rng.integers(2, 6))
+        ti = np.repeat(np.arange(en, dtype=np.int32), eper)
+        tj = rng.integers(0, em, size=en * eper).astype(np.int32)
+        tx = rng.integers(1, p, size=en * eper).astype(np.int64)
+        E = as_product(orc.compress(p, en, em, ti, tj, tx))
+        ranks = {}
+        for where, bits in (("device", ""), ("device", "global"), ("host", "")):
+            os.environ["SPASM_HIP_PIVOT_SEARCH"] = where
+            os.environ["SPASM_HIP_PIVOT_BITS"] = bits
+            ranks[where + bits] = spasm_amd.echelonize(E).U.n
+        os.environ.pop("SPASM_HIP_PIVOT_SEARCH", None)
+        os.environ.pop("SPASM_HIP_PIVOT_BITS", None)
+        ranks["transpose"] = spasm_amd.echelonize(spasm_amd.transpose(E)).U.n
+        cases += 1
+        if len(set(ranks.values())) != 1:
+            fails += 1
+            print("MISMATCH ranks of a %dx%d matrix, %d per row, p=%d: %s" % (en, em, eper, p, ranks), flush=True)
 print("stress: %d cases, %d mismatches" % (cases, fails))
 sys.exit(1 if fails else 0)
