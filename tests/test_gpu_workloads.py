@@ -185,6 +185,38 @@ def test_rank_tool_on_baseline_workload(name, tmp_path):
         assert rank > 0
 
 
+def test_image_on_rows_wider_than_the_lds_at_full_size(oracle):
+    """mk14.b4, the GL7d19-class stand-in: 673,000 rows to reduce on 42,000 non-pivotal columns -- rows of S too wide for the
+    LDS of a wave, produced in segments by the apply kernel of the back-substituted image (a 23 GB image).  The whole
+    Schur complement, 1.06e9 entries, must be the one the row-by-row kernels compute, entry for entry; sampled rows are
+    checked against the compiled reference."""
+    import torch
+    A, rows, F, source = workloads.round0("mk14.b4", PRIME, threads=0)
+    S1, st1, W1, dF1 = _full_schur(A, rows, F, {"SPASM_HIP_BACKSOLVE": "1"})
+    assert st1.used_backsolve == 1 and st1.status == 0
+    S0, st0, W0, dF0 = _full_schur(A, rows, F, {"SPASM_HIP_BACKSOLVE": "0"})
+    assert st0.used_backsolve == 0 and st0.status == 0 and st0.nnz == st1.nnz
+    assert torch.equal(S1.p, S0.p)
+    assert torch.equal(S1.j[:st1.nnz], S0.j[:st0.nnz]) and torch.equal(S1.x[:st1.nnz], S0.x[:st0.nnz])
+    Ao = oracle.CSR(A.n, A.m, A.p, A.j, A.x, PRIME)
+    Fo = oracle.Fact(oracle.CSR(F.U.n, F.U.m, F.U.p, F.U.j, F.U.x, PRIME), F.qinv)
+    ks = np.unique(np.linspace(0, len(rows) - 1, 64).astype(np.int64))
+    if oracle.ref_available():
+        want, p_out = oracle.ref_schur(Ao, rows[ks], Fo, threads=spasm_amd.usable_cpus())
+    else:
+        want, p_out, _ = oracle.schur(Ao, rows[ks], Fo)
+    order = {int(r): t for t, r in enumerate(p_out)}
+    Sp, got = _device_rows(S1, ks)
+    for k, (gj, gx) in zip(ks, got):
+        wj, wx = want.row(order[int(rows[k])])
+        o = np.argsort(wj)
+        assert np.array_equal(gj, wj[o]) and np.array_equal(np.asarray(gx, np.int64) % PRIME, np.asarray(wx[o], np.int64) % PRIME), \
+            "row %d of the batch (row %d of A) differs" % (k, rows[k])
+    for W, dF in ((W1, dF1), (W0, dF0)):
+        W.close()
+        dF.close()
+
+
 def test_generated_stand_ins_have_the_published_shapes():
     """the chessboard complexes are closed-form: sizes against the published ones (tools/workloads.py)"""
     for name, info in workloads.STAND_INS.items():
