@@ -2815,6 +2815,84 @@ __global__ __launch_bounds__(64) void combine_all_rows_kernel(const int64_t *Ap,
 	}
 }
 
+// The same for p < 2^16 WITHOUT an atomic per term at the memory side (92 ms on mk14.b4: 1.4e9 atomic requests, the largest
+// kernel of the whole call).  A workgroup takes CB_ROWS rows and walks the columns in blocks of CB_COLS: rows are sorted by
+// column, so every row keeps a cursor; the terms of a block are added up in LDS -- 32-bit sums: a term is < 2^16 and a
+// workgroup adds at most CB_ROWS = 2,048 of them to a sum -- and only the sums that are not zero go to Y ([combination]
+// [column], 64-bit), one atomic each: 42,000 occupied columns x 9 per workgroup instead of a thousand entries x 9 per row.
+// Needs sorted rows (a row with a column out of order falls behind its cursor: the caller checks the flag and redoes the
+// batch with combine_all_rows_kernel).
+constexpr int CB_ROWS = 2048, CB_COLS = 1024, CB_THREADS = 256, CB_PER_THREAD = CB_ROWS / CB_THREADS;
+
+__global__ __launch_bounds__(CB_THREADS) void combine_all_rows_blocked_kernel(const int64_t *Ap, const int *Aj, const int *Ax, const int *rows, int nrows, int N, int m,
+                                                                              uint64_t salt, unsigned long long *Y, int *unsorted, MontDev F)
+{
+	extern __shared__ __attribute__((aligned(16))) uint32_t cb_lds[];
+	uint32_t *acc = cb_lds;                                                            // [CB_COLS][N]
+	unsigned short *coef = reinterpret_cast<unsigned short *>(cb_lds + CB_COLS * N);     // [CB_ROWS][N], Montgomery form
+	const int tid = threadIdx.x;
+	const int64_t base = (int64_t) blockIdx.x * CB_ROWS;
+	for (int e = tid; e < CB_ROWS * N; e += CB_THREADS) {
+		const int64_t t = base + e / N;
+		const int k = e % N;
+		uint32_t cm = 0;
+		if (t < nrows) {
+			const uint64_t h = mix64(salt ^ mix64(((uint64_t) k << 32) ^ (uint64_t) t));          // (the generator of combine_rows_kernel)
+			cm = montmul(uniform_below(h, F.p), F.r2, F);
+		}
+		coef[e] = (unsigned short) cm;
+	}
+	for (int e = tid; e < CB_COLS * N; e += CB_THREADS)
+		acc[e] = 0;
+	int64_t cur[CB_PER_THREAD], end[CB_PER_THREAD];
+	int prev[CB_PER_THREAD];
+#pragma unroll
+	for (int q = 0; q < CB_PER_THREAD; q++) {
+		const int64_t t = base + tid + (int64_t) q * CB_THREADS;
+		const int i = (t < nrows) ? rows[t] : 0;
+		cur[q] = (t < nrows) ? Ap[i] : 0;
+		end[q] = (t < nrows) ? Ap[i + 1] : 0;
+		prev[q] = -1;
+	}
+	__syncthreads();
+	bool bad = false;
+	for (int lo = 0; lo < m; lo += CB_COLS) {
+		const int hi = min(m, lo + CB_COLS);
+		bool any = false;
+#pragma unroll
+		for (int q = 0; q < CB_PER_THREAD; q++) {
+			const unsigned short *cf = coef + (size_t) (tid + q * CB_THREADS) * N;
+			while (cur[q] < end[q]) {
+				const int j = Aj[cur[q]];
+				if (j >= hi)
+					break;
+				bad = bad || j <= prev[q];
+				prev[q] = j;
+				const int a = Ax[cur[q]];
+				const uint32_t v = ((a < 0) ? (uint32_t) a + F.p : (uint32_t) a) % F.p;
+				if (j >= lo)
+					for (int k = 0; k < N; k++)
+						atomicAdd(&acc[(j - lo) * N + k], montmul((uint32_t) cf[k], v, F));
+				cur[q] += 1;
+				any = true;
+			}
+		}
+		// (a block nobody of this workgroup touched: nothing to flush, nothing to clear)
+		if (__syncthreads_or(any)) {
+			for (int e = tid; e < (hi - lo) * N; e += CB_THREADS) {
+				const uint32_t sum = acc[e];
+				if (sum != 0) {
+					atomicAdd(&Y[(int64_t) (e % N) * m + lo + e / N], (unsigned long long) sum);
+					acc[e] = 0;
+				}
+			}
+			__syncthreads();
+		}
+	}
+	if (bad)
+		atomicOr(unsorted, 1);
+}
+
 __global__ __launch_bounds__(256) void transpose_combinations_kernel(const unsigned long long *Yt, int N, int m, unsigned long long *Y)
 {
 	const int64_t idx = (int64_t) blockIdx.x * 256 + threadIdx.x;          // (column, combination): reads are contiguous
@@ -2953,6 +3031,54 @@ void launch_combine(const int64_t *Ap, const int *Aj, const int *Ax, const int *
 {
 	const int64_t terms = (w > 0) ? (int64_t) w : (int64_t) nrows;
 	const int64_t total = (int64_t) N * terms;
+	if (w <= 0 && N <= 16 && nrows >= 4096 && M.p < 65536 && !std::getenv("SPASM_HIP_COMBINE_PER_PAIR") && !std::getenv("SPASM_HIP_COMBINE_ATOMIC")) {
+		// every row, few combinations, p < 2^16: block sums in LDS, one atomic per occupied (column, combination) and workgroup
+		const size_t lds = (size_t) CB_COLS * N * sizeof(uint32_t) + (size_t) CB_ROWS * N * sizeof(unsigned short);
+		static size_t configured = 0;
+		if (lds > configured) {
+			HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(&combine_all_rows_blocked_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int) lds));
+			configured = lds;
+		}
+		int *d_flag = nullptr;
+		HIP_CHECK(hipMalloc((void **) &d_flag, sizeof(int)));
+		HIP_CHECK(hipMemsetAsync(d_flag, 0, sizeof(int), stream));
+		hipLaunchKernelGGL(combine_all_rows_blocked_kernel, dim3((unsigned) ((nrows + CB_ROWS - 1) / CB_ROWS)), dim3(CB_THREADS), lds, stream, Ap, Aj, Ax, rows, nrows,
+		                   N, m, salt, Y, d_flag, to_dev(M));
+		HIP_CHECK(hipGetLastError());
+		int flag = 0;
+		HIP_CHECK(hipMemcpyAsync(&flag, d_flag, sizeof(int), hipMemcpyDeviceToHost, stream));
+		HIP_CHECK(hipStreamSynchronize(stream));
+		(void) hipFree(d_flag);
+		if (flag == 0 && std::getenv("SPASM_HIP_COMBINE_CHECK")) {
+			// (tests) the same combinations by the kernel that sends an atomic per term: the sums must agree mod p
+			const size_t count = (size_t) N * m;
+			unsigned long long *Y2 = (unsigned long long *) big_alloc(count * sizeof(unsigned long long));
+			unsigned long long *Yt = (unsigned long long *) big_alloc((size_t) m * 16 * sizeof(unsigned long long));
+			HIP_CHECK(hipMemsetAsync(Y2, 0, count * sizeof(unsigned long long), stream));
+			HIP_CHECK(hipMemsetAsync(Yt, 0, (size_t) m * 16 * sizeof(unsigned long long), stream));
+			hipLaunchKernelGGL(combine_all_rows_kernel, dim3((unsigned) std::min<int64_t>(nrows, 65536)), dim3(64), 0, stream, Ap, Aj, Ax, rows, nrows, N, salt, Yt,
+			                   to_dev(M));
+			hipLaunchKernelGGL(transpose_combinations_kernel, dim3((unsigned) (((int64_t) m * 16 + 255) / 256)), dim3(256), 0, stream, Yt, N, m, Y2);
+			std::vector<unsigned long long> a(count), b(count);
+			HIP_CHECK(hipMemcpyAsync(a.data(), Y, count * sizeof(unsigned long long), hipMemcpyDeviceToHost, stream));
+			HIP_CHECK(hipMemcpyAsync(b.data(), Y2, count * sizeof(unsigned long long), hipMemcpyDeviceToHost, stream));
+			HIP_CHECK(hipStreamSynchronize(stream));
+			size_t differ = 0, nonzero = 0;
+			for (size_t t = 0; t < count; t++) {
+				differ += (a[t] % M.p) != (b[t] % M.p);
+				nonzero += (a[t] % M.p) != 0;
+			}
+			logmsg("[combine check] %d combinations of %d rows: %zu sums differ mod p (%zu non-zero)\n", N, nrows, differ, nonzero);
+			if (differ != 0)
+				die("combine_all_rows_blocked_kernel and combine_all_rows_kernel disagree on %zu sums", differ);
+			big_free(Y2);
+			big_free(Yt);
+		}
+		if (flag == 0)
+			return;
+		// (rows that are not sorted by column: Y holds part of the sums -- start again, the other way)
+		HIP_CHECK(hipMemsetAsync(Y, 0, (size_t) N * m * sizeof(unsigned long long), stream));
+	}
 	if (w <= 0 && N <= 16 && nrows >= 4096 && !std::getenv("SPASM_HIP_COMBINE_PER_PAIR")) {
 		// every row, few combinations: each row once, the combinations side by side (combine_all_rows_kernel); Y arrives zeroed
 		unsigned long long *Yt = (unsigned long long *) big_alloc((size_t) m * 16 * sizeof(unsigned long long));

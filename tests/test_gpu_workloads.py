@@ -227,7 +227,7 @@ def test_generated_stand_ins_have_the_published_shapes():
 
 
 @pytest.mark.parametrize("name,threshold,min_sparse_rounds", [("ch7-8.b5", 0.01, 0), ("ch8-8.b5", 0.01, 0), ("mk14.b4", 0.05, 1)])
-def test_multi_round_stand_in(name, threshold, min_sparse_rounds):
+def test_multi_round_stand_in(name, threshold, min_sparse_rounds, monkeypatch):
     """spasm_hip_echelonize end to end on the GL7d19-class stand-ins, with the options of the GL7d19 config for the chessboard
     complexes (--dense-threshold 0.01: their first Schur complement is 18 % dense, so the call is pivot search + the dense
     finish on 49,000 / 104,000 columns -- no back-substituted image) and the defaults for mk14.b4, whose first Schur
@@ -238,6 +238,9 @@ def test_multi_round_stand_in(name, threshold, min_sparse_rounds):
     o = spasm_amd.default_opts()
     o.sparsity_threshold = threshold
     ranks = []
+    # (the combinations of all rows that end the low-rank finish are formed twice -- block sums in LDS, and one atomic per
+    #  term -- and the library dies if the sums differ mod p: mk14.b4 is where the first kernel runs on 1e9 entries)
+    monkeypatch.setenv("SPASM_HIP_COMBINE_CHECK", "1")
     for _ in range(2):
         F = spasm_amd.echelonize(A, o)
         prof = spasm_amd.echelonize_profile()
