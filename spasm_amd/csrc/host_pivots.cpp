@@ -372,19 +372,29 @@ struct Search {
 		std::vector<int> when((size_t) (A->n > 0 ? A->n : 1), -1);
 		for (int t = 0; t < npiv; t++)
 			when[p[t]] = t;
-		for (int t = 0; t < npiv; t++) {
-			const int i = p[t];
-			if (pinv[i] < 0)
-				return false;
-			for (i64 px = A->p[i]; px < A->p[i + 1]; px++) {
-				const int j = A->j[px];
-				if (j == pinv[i] || qinv[j] < 0)
-					continue;
-				if (when[qinv[j]] <= t)
-					return false;
+		std::atomic<bool> fine{true};
+		auto check = [&](int t_lo, int t_hi) {
+			for (int t = t_lo; t < t_hi && fine.load(std::memory_order_relaxed); t++) {
+				const int i = p[t];
+				bool ok = pinv[i] >= 0;
+				for (i64 px = A->p[i]; ok && px < A->p[i + 1]; px++) {
+					const int j = A->j[px];
+					if (j == pinv[i] || qinv[j] < 0)
+						continue;
+					ok = when[qinv[j]] > t;
+				}
+				if (!ok)
+					fine.store(false, std::memory_order_relaxed);
 			}
-		}
-		return true;
+		};
+		const int T = (npiv < 20000) ? 1 : std::max(1, std::min(8, usable_cpus()));
+		std::vector<std::thread> pool;
+		for (int t = 1; t < T; t++)
+			pool.emplace_back(check, (int) ((i64) npiv * t / T), (int) ((i64) npiv * (t + 1) / T));
+		check(0, (int) ((i64) npiv / T));
+		for (auto &th : pool)
+			th.join();
+		return fine.load();
 	}
 
 	// reverse post-order of the pivot graph: a pivotal column precedes all
@@ -536,60 +546,79 @@ extern "C" int spasm_hip_pivots_extract_structural(const struct spasm_csr *A, co
 	const uint64_t pu64 = (uint64_t) prime, barrett = ~0ull / pu64;          // x mod p = x - floor(x * floor(2^64 / p) / 2^64) * p, or p more
 	struct spasm_csr *U = fact->U;
 	struct spasm_triplet *L = fact->Ltmp;
-	i64 unz = U->p[U->n];
+	const i64 unz = U->p[U->n];
 	i64 need = 0;
 	for (int t = 0; t < npiv; t++)
 		need += S.weight(p[t]);
 	if (unz + need > U->nzmax)
 		spasm_hip_csr_realloc(U, unz + need);
+	// where every new row goes, then the rows themselves -- by a few threads on large inputs: a row is a gather from A
+	const int n0 = U->n;
 	for (int t = 0; t < npiv; t++) {
 		const int i = p[t];
-		const int j = S.pinv[i];
-		fact->qinv[j] = U->n;
-		spasm_ZZp pivot = 0;
-		for (i64 px = A->p[i]; px < A->p[i + 1]; px++)
-			if (A->j[px] == j && A->x[px] != 0) {
-				pivot = A->x[px];
-				break;
-			}
-		if (pivot == 0)
-			die("structural pivot (%d, %d) has no value", i, j);
-		if (L != nullptr) {
-			int i_out = (p_in != nullptr) ? p_in[i] : i;
-			spasm_hip_add_entry(L, i_out, U->n, pivot);
-			fact->p[U->n] = i_out;
-		}
-		// (boundary matrices have pivots +-1: no inverse, no product; otherwise one reduction per entry without a division)
-		const spasm_ZZp scale = (pivot == 1) ? 1 : (pivot == -1) ? -1 : zp_inverse(prime, pivot);
-		U->j[unz] = j;
-		U->x[unz] = 1;
-		unz += 1;
-		for (i64 px = A->p[i]; px < A->p[i + 1]; px++) {
-			if (A->j[px] == j)
-				continue;
-			U->j[unz] = A->j[px];
-			const spasm_ZZp a = A->x[px];
-			spasm_ZZp v;
-			if (scale == 1) {
-				v = a;
-			} else if (scale == -1 && a != -a) {
-				v = -a;
-			} else {
-				const int64_t t = (int64_t) scale * a;
-				const uint64_t u = (uint64_t) (t < 0 ? -t : t);
-				uint64_t rem = u - (uint64_t) (((unsigned __int128) u * barrett) >> 64) * pu64;
-				while (rem >= pu64)
-					rem -= pu64;
-				if (t < 0 && rem != 0)
-					rem = pu64 - rem;
-				v = zp_balance(prime, (int64_t) rem);
-			}
-			U->x[unz] = v;
-			unz += 1;
-		}
-		U->n += 1;
-		U->p[U->n] = unz;
+		fact->qinv[S.pinv[i]] = n0 + t;
+		U->p[n0 + t + 1] = U->p[n0 + t] + S.weight(i);
 	}
+	auto pivot_of = [&](int i, int j) -> spasm_ZZp {
+		for (i64 px = A->p[i]; px < A->p[i + 1]; px++)
+			if (A->j[px] == j && A->x[px] != 0)
+				return A->x[px];
+		die("structural pivot (%d, %d) has no value", i, j);
+		return 0;
+	};
+	if (L != nullptr)
+		for (int t = 0; t < npiv; t++) {
+			const int i = p[t];
+			const int i_out = (p_in != nullptr) ? p_in[i] : i;
+			spasm_hip_add_entry(L, i_out, n0 + t, pivot_of(i, S.pinv[i]));
+			fact->p[n0 + t] = i_out;
+		}
+	auto fill_rows = [&](int t_lo, int t_hi) {
+		for (int t = t_lo; t < t_hi; t++) {
+			const int i = p[t];
+			const int j = S.pinv[i];
+			const spasm_ZZp pivot = pivot_of(i, j);
+			// (boundary matrices have pivots +-1: no inverse, no product; otherwise one reduction per entry without a division)
+			const spasm_ZZp scale = (pivot == 1) ? 1 : (pivot == -1) ? -1 : zp_inverse(prime, pivot);
+			i64 w = U->p[n0 + t];
+			U->j[w] = j;
+			U->x[w] = 1;
+			w += 1;
+			for (i64 px = A->p[i]; px < A->p[i + 1]; px++) {
+				if (A->j[px] == j)
+					continue;
+				U->j[w] = A->j[px];
+				const spasm_ZZp a = A->x[px];
+				spasm_ZZp v;
+				if (scale == 1) {
+					v = a;
+				} else if (scale == -1 && a != -a) {
+					v = -a;
+				} else {
+					const int64_t prod = (int64_t) scale * a;
+					const uint64_t u = (uint64_t) (prod < 0 ? -prod : prod);
+					uint64_t rem = u - (uint64_t) (((unsigned __int128) u * barrett) >> 64) * pu64;
+					while (rem >= pu64)
+						rem -= pu64;
+					if (prod < 0 && rem != 0)
+						rem = pu64 - rem;
+					v = zp_balance(prime, (int64_t) rem);
+				}
+				U->x[w] = v;
+				w += 1;
+			}
+		}
+	};
+	{
+		const int T = (npiv < 20000) ? 1 : std::max(1, std::min(8, usable_cpus()));
+		std::vector<std::thread> pool;
+		for (int t = 1; t < T; t++)
+			pool.emplace_back(fill_rows, (int) ((i64) npiv * t / T), (int) ((i64) npiv * (t + 1) / T));
+		fill_rows(0, (int) ((i64) npiv / T));
+		for (auto &th : pool)
+			th.join();
+	}
+	U->n = n0 + npiv;
 	if (verbose() >= 2)
 		logmsg("[pivots] search and order %.1f ms, rows of U %.1f ms\n", 1e3 * (t_searched - t0), 1e3 * (wtime() - t_searched));
 	return npiv;
