@@ -2293,8 +2293,12 @@ __global__ __launch_bounds__(64) void rowpanel_leftmost(const uint32_t *P, int64
 // pivot in THIS call, -1 for the others.
 constexpr int RP_COLS = RP_WIN + RP_ROWS;
 
-__global__ __launch_bounds__(256) void rowpanel_window(const uint32_t *P, int64_t ld, int m, int rows, const int *left, int *state, int *newpiv,
-                                                       uint32_t *T_out, unsigned char *is_piv, MontDev F)
+// (1,024 threads: a column of the block per thread of a group of 256, the 64 rows dealt out to the four groups -- the
+//  elimination of a pivot column from 63 rows is what a step costs, 64 pivots a call on dense rows: 1.08 ms with 256 threads)
+constexpr int RP_THREADS = 1024, RP_GROUPS = RP_THREADS / 256;
+
+__global__ __launch_bounds__(RP_THREADS) void rowpanel_window(const uint32_t *P, int64_t ld, int m, int rows, const int *left, int *state, int *newpiv,
+                                                              uint32_t *T_out, unsigned char *is_piv, MontDev F)
 {
 	extern __shared__ uint32_t rp_lds[];
 	uint32_t(*W)[RP_COLS + 1] = reinterpret_cast<uint32_t(*)[RP_COLS + 1]>(rp_lds);
@@ -2302,6 +2306,7 @@ __global__ __launch_bounds__(256) void rowpanel_window(const uint32_t *P, int64_
 	__shared__ int cols[RP_COLS], s_state[RP_ROWS], s_pick[5], s_w0, s_count, wcnt[4];
 	__shared__ uint32_t fac[RP_ROWS];
 	const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+	const int col = tid & 255, grp = tid >> 8;          // (a group is four whole waves: everything below that depends on grp is wave-uniform)
 	if (tid < RP_ROWS) {
 		const int st = state[tid];
 		s_state[tid] = st;
@@ -2316,16 +2321,17 @@ __global__ __launch_bounds__(256) void rowpanel_window(const uint32_t *P, int64_
 			s_count = 0;
 		}
 	}
-	cols[tid] = -1;
+	if (grp == 0)
+		cols[col] = -1;
 	__syncthreads();
 	for (int base = s_w0, chunk = 0; base < m && chunk < 128; base += 256, chunk++) {
 		const int have = s_count;
 		if (have >= RP_WIN)
 			break;                           // (uniform: shared, read after a barrier)
-		const int c = base + tid;
-		const bool free_col = c < m && is_piv[c] == 0;
+		const int c = base + col;
+		const bool free_col = grp == 0 && c < m && is_piv[c] == 0;
 		const uint64_t mask = __ballot(free_col);
-		if (lane == 0)
+		if (grp == 0 && lane == 0)
 			wcnt[wave] = __popcll(mask);
 		__syncthreads();
 		int before = have, all = 0;
@@ -2343,19 +2349,20 @@ __global__ __launch_bounds__(256) void rowpanel_window(const uint32_t *P, int64_
 		__syncthreads();
 	}
 	__syncthreads();
-	for (int t = 0; t < RP_ROWS; t++) {
-		for (int u = tid; u < RP_COLS; u += 256)
-			W[t][u] = (cols[u] >= 0 && t < rows) ? P[(int64_t) t * ld + cols[u]] : 0u;          // (the last panel may be short: its missing rows are zero, state -2)
-		if (tid < RP_ROWS)
-			T[t][tid] = (t == tid) ? 1u : 0u;
+	for (int t = grp; t < RP_ROWS; t += RP_GROUPS) {
+		W[t][col] = (cols[col] >= 0 && t < rows) ? P[(int64_t) t * ld + cols[col]] : 0u;          // (the last panel may be short: its missing rows are zero, state -2)
+		if (col < RP_ROWS) {
+			W[t][RP_WIN + col] = (cols[RP_WIN + col] >= 0 && t < rows) ? P[(int64_t) t * ld + cols[RP_WIN + col]] : 0u;
+			T[t][col] = (t == col) ? 1u : 0u;
+		}
 	}
 	__syncthreads();
 	for (int t = 0; t < RP_ROWS; t++) {
 		if (s_state[t] != -1)
 			continue;                        // (uniform: shared)
-		// first non-zero entry of row t among the columns: the 256 of the window (one per thread), then the 64 leftmost entries (wave 0)
-		{
-			const uint64_t mask = __ballot(W[t][tid] != 0);
+		// first non-zero entry of row t among the columns: the 256 of the window (one per thread of group 0), then the 64 leftmost entries (wave 0)
+		if (grp == 0) {
+			const uint64_t mask = __ballot(W[t][col] != 0);
 			if (lane == 0)
 				s_pick[wave] = (mask != 0) ? wave * 64 + __builtin_ctzll(mask) : 0x7FFFFFFF;
 			if (wave == 0) {
@@ -2371,24 +2378,26 @@ __global__ __launch_bounds__(256) void rowpanel_window(const uint32_t *P, int64_
 			continue;                        // zero on every column looked at: the row waits for the next step
 		}
 		const uint32_t inv = invmod(W[t][c], F);
-		const uint32_t wt = mulmod(W[t][tid], inv, F);
-		const uint32_t wt2 = (tid < RP_ROWS) ? mulmod(W[t][RP_WIN + tid], inv, F) : 0u, tt = (tid < RP_ROWS) ? mulmod(T[t][tid], inv, F) : 0u;
+		const uint32_t wt = mulmod(W[t][col], inv, F);
+		const uint32_t wt2 = (col < RP_ROWS) ? mulmod(W[t][RP_WIN + col], inv, F) : 0u, tt = (col < RP_ROWS) ? mulmod(T[t][col], inv, F) : 0u;
 		if (tid < RP_ROWS)
 			fac[tid] = (tid == t) ? 0u : W[tid][c];
 		__syncthreads();
-		W[t][tid] = wt;
-		if (tid < RP_ROWS) {
-			W[t][RP_WIN + tid] = wt2;
-			T[t][tid] = tt;
+		if (grp == 0) {
+			W[t][col] = wt;
+			if (col < RP_ROWS) {
+				W[t][RP_WIN + col] = wt2;
+				T[t][col] = tt;
+			}
 		}
-		for (int s2 = 0; s2 < RP_ROWS; s2++) {
+		for (int s2 = grp; s2 < RP_ROWS; s2 += RP_GROUPS) {
 			const uint32_t f = fac[s2];
 			if (f == 0)
-				continue;                    // (uniform)
-			W[s2][tid] = submod(W[s2][tid], mulmod(f, wt, F), F);
-			if (tid < RP_ROWS) {
-				W[s2][RP_WIN + tid] = submod(W[s2][RP_WIN + tid], mulmod(f, wt2, F), F);
-				T[s2][tid] = submod(T[s2][tid], mulmod(f, tt, F), F);
+				continue;                    // (uniform: a group is whole waves)
+			W[s2][col] = submod(W[s2][col], mulmod(f, wt, F), F);
+			if (col < RP_ROWS) {
+				W[s2][RP_WIN + col] = submod(W[s2][RP_WIN + col], mulmod(f, wt2, F), F);
+				T[s2][col] = submod(T[s2][col], mulmod(f, tt, F), F);
 			}
 		}
 		if (tid == 0) {
@@ -2400,7 +2409,7 @@ __global__ __launch_bounds__(256) void rowpanel_window(const uint32_t *P, int64_
 	}
 	if (tid < RP_ROWS)
 		state[tid] = s_state[tid];
-	for (int e = tid; e < RP_ROWS * RP_ROWS; e += 256)
+	for (int e = tid; e < RP_ROWS * RP_ROWS; e += RP_THREADS)
 		T_out[e] = T[e / RP_ROWS][e % RP_ROWS];
 }
 
@@ -2662,7 +2671,7 @@ int device_echelon_extend(int64_t prime, int m, uint32_t *dM, int64_t ld, int k,
 			signed char *Mh, *Ml, *Bh, *Bl;
 			planes_of_set(0, Mh, Ml, Bh, Bl);
 			split_panel(r0, 0);
-			hipLaunchKernelGGL(rowpanel_window, dim3(1), dim3(256), win_lds, stream, P, ld, m, rows_here, d_left, d_state, d_newpiv, d_T, d_ispiv, F);
+			hipLaunchKernelGGL(rowpanel_window, dim3(1), dim3(RP_THREADS), win_lds, stream, P, ld, m, rows_here, d_left, d_state, d_newpiv, d_T, d_ispiv, F);
 			total_iters += 1;
 			hipLaunchKernelGGL(rowpanel_multipliers, dim3(1), dim3(256), 0, stream, P, ld, rows_here, 0, d_newpiv, d_T, Mh, Ml, F);
 			UpdSets S{};
