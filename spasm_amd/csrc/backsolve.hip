@@ -52,9 +52,7 @@ int env_bs(const char *name, int dflt)
 
 template <typename T> T *dalloc(int64_t count)
 {
-	T *p = nullptr;
-	HIP_CHECK(hipMalloc((void **) &p, (size_t) (count > 0 ? count : 1) * sizeof(T)));
-	return p;
+	return static_cast<T *>(sh::big_alloc((size_t) (count > 0 ? count : 1) * sizeof(T)));
 }
 
 template <typename T> void upload(T *dst, const std::vector<T> &src, hipStream_t s)
@@ -1900,17 +1898,17 @@ void backsolve_free(spasm_hip_dfact *F)
 {
 	BsImage &B = F->bs;
 	big_free(B.d_R);
-	(void) hipFree(B.d_col);
-	(void) hipFree(B.d_chunk);
-	(void) hipFree(B.d_chunk_extra);
-	(void) hipFree(B.d_ptab);
-	(void) hipFree(B.d_near);
-	(void) hipFree(B.d_far_head);
-	(void) hipFree(B.d_far_rp);
-	(void) hipFree(B.d_far);
-	(void) hipFree(B.d_np_rp);
-	(void) hipFree(B.d_np);
-	(void) hipFree(B.d_np_row);
+	sh::big_free(B.d_col);
+	sh::big_free(B.d_chunk);
+	sh::big_free(B.d_chunk_extra);
+	sh::big_free(B.d_ptab);
+	sh::big_free(B.d_near);
+	sh::big_free(B.d_far_head);
+	sh::big_free(B.d_far_rp);
+	sh::big_free(B.d_far);
+	sh::big_free(B.d_np_rp);
+	sh::big_free(B.d_np);
+	sh::big_free(B.d_np_row);
 	if (B.ev0 != nullptr)
 		(void) hipEventDestroy(B.ev0);
 	if (B.ev1 != nullptr)
@@ -2044,7 +2042,7 @@ void backsolve_build(const spasm_hip_dfact *F, hipStream_t stream)
 		for (int q = 0; q < 7; q++)
 			fprintf(stderr, " %s %.0f (%.0f%%);", stage[q], (double) h[q] / B.nchunks, 100.0 * (double) h[q] / (double) (tot ? tot : 1));
 		fprintf(stderr, " total %.0f\n", (double) tot / B.nchunks);
-		(void) hipFree(b.prof);
+		sh::big_free(b.prof);
 	}
 	if (env_bs("SPASM_HIP_BS_CHECK", 0) && b.sparse_init && bytes < ((size_t) 1 << 30)) {
 		// debugging aid: the same build with R pre-filled (the other way of starting the rows), compared entry by entry
@@ -2083,7 +2081,7 @@ void backsolve_build(const spasm_hip_dfact *F, hipStream_t stream)
 			}
 		}
 		fprintf(stderr, "[bs check] %lld entries differ\n", (long long) bad);
-		(void) hipFree(R2);
+		sh::big_free(R2);
 	}
 }
 

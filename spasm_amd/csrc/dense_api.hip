@@ -52,9 +52,7 @@ int env_int(const char *name, int dflt)
 
 template <typename T> T *dalloc(int64_t count)
 {
-	T *p = nullptr;
-	HIP_CHECK(hipMalloc((void **) &p, (size_t) (count > 0 ? count : 1) * sizeof(T)));
-	return p;
+	return static_cast<T *>(sh::big_alloc((size_t) (count > 0 ? count : 1) * sizeof(T)));
 }
 
 }  // namespace
@@ -162,7 +160,7 @@ static int dschur_dense_impl(const spasm_hip_dcsr *A, const int *d_rows, int nro
 	}
 	if (need > W->scratch_bytes) {
 		if (W->d_scratch != nullptr)
-			(void) hipFree(W->d_scratch);
+			sh::big_free(W->d_scratch);
 		HIP_CHECK(hipMalloc((void **) &W->d_scratch, (size_t) need));
 		W->scratch_bytes = need;
 		HIP_CHECK(hipMemsetAsync(W->d_scratch, 0, (size_t) need, stream));
@@ -215,7 +213,7 @@ static int dschur_dense_impl(const spasm_hip_dcsr *A, const int *d_rows, int nro
 			const int64_t need = regroup_scratch_ints(nrows, F->rpad);
 			if (W->sortbuf_ints < need) {
 				if (W->d_sortbuf != nullptr)
-					(void) hipFree(W->d_sortbuf);
+					sh::big_free(W->d_sortbuf);
 				HIP_CHECK(hipMalloc((void **) &W->d_sortbuf, (size_t) need * sizeof(int)));
 				W->sortbuf_ints = need;
 			}
@@ -290,16 +288,16 @@ void device_random_dense_rows(const spasm_hip_dcsr &dA, const int *d_rows, int n
 		launch_sum_pieces(parts, Sm, N, pieces, Sm, (uint32_t) F->prime, d_S, ldS, stream);
 		HIP_CHECK(hipStreamSynchronize(stream));
 		big_free(parts);
-		(void) hipFree(dident2);
-		(void) hipFree(dYp2);
+		sh::big_free(dident2);
+		sh::big_free(dYp2);
 	} else {
 		spasm_hip_dcsr dYcsr{N, m, ynnz, dYp, dYj, dYx};
 		dschur_dense_impl(&dYcsr, dident, N, F, W, d_S, ldS, stream, nullptr);
 	}
 	if (verbose() >= 2)
 		logmsg("[dense rows] %d combinations: combine + pack %.3fs (%" PRId64 " entries), reduction %.3fs\n", N, t1 - t0, ynnz, wtime() - t1);
-	(void) hipFree(dident);
-	(void) hipFree(dYp);
+	sh::big_free(dident);
+	sh::big_free(dYp);
 	big_free(dYj);
 	big_free(dYx);
 }
@@ -366,7 +364,7 @@ bool finish_on_device(const struct spasm_csr *A, const int *p, int n, struct spa
 		HIP_CHECK(hipMemGetInfo(&free_b, &total_b));
 		if ((size_t) cap_rows * (size_t) ld * sizeof(u32) > free_b / 2) {
 			spasm_hip_dwork_destroy(W);
-			(void) hipFree(drows);
+			sh::big_free(drows);
 			return false;                    // the blocked host loops work in dense_block_size x Sm pieces
 		}
 	}
@@ -507,15 +505,15 @@ bool finish_on_device(const struct spasm_csr *A, const int *p, int n, struct spa
 		U->n = old_un + k;
 		big_free(d_Uj);
 		big_free(d_Ux);
-		(void) hipFree(d_len);
-		(void) hipFree(d_Up);
-		(void) hipFree(d_bsum);
+		sh::big_free(d_len);
+		sh::big_free(d_Up);
+		sh::big_free(d_bsum);
 	}
 	const double t_tail1 = wtime();
 	big_free(dM);
-	(void) hipFree(dpiv);
+	sh::big_free(dpiv);
 	spasm_hip_dwork_destroy(W);
-	(void) hipFree(drows);
+	sh::big_free(drows);
 	logmsg("[echelonize/dense/device] completed in %.2fs (dense rows %.2fs, %s %.2fs; %s). %d new pivots found\n", wtime() - start,
 	       t_rows, row_panels ? "echelon rows by row panels" : "RREF", t_rref,
 	       have_R ? "blocks from the back-substituted image" : "blocks from the row-by-row kernels", U->n - old_un);
@@ -601,14 +599,14 @@ void spasm_hip_schur_dense(const struct spasm_csr *A, const int *p, int n, const
 						L->nz += 1;
 					}
 				}
-				(void) hipFree(lout.Li);
-				(void) hipFree(lout.Lj);
-				(void) hipFree(lout.Lx);
+				sh::big_free(lout.Li);
+				sh::big_free(lout.Lj);
+				sh::big_free(lout.Lx);
 				if (rc == 0)
 					break;
 				lcap *= 4;
 			}
-			(void) hipFree(d_row_orig);
+			sh::big_free(d_row_orig);
 		}
 		std::vector<u32> h((size_t) n * Sm);
 		HIP_CHECK(hipMemcpy(h.data(), dS, (size_t) n * Sm * sizeof(u32), hipMemcpyDeviceToHost));
@@ -621,9 +619,9 @@ void spasm_hip_schur_dense(const struct spasm_csr *A, const int *p, int n, const
 			case SPASM_I64: ((i64 *) S)[t] = v; break;
 			}
 		}
-		(void) hipFree(dS);
+		sh::big_free(dS);
 		spasm_hip_dwork_destroy(W);
-		(void) hipFree(drows);
+		sh::big_free(drows);
 	}
 	logmsg("[schur/dense/hip] %d x %d dense rows in %.1fs\n", n, Sm, wtime() - t0);
 }
@@ -668,9 +666,9 @@ void spasm_hip_schur_dense_randomized(const struct spasm_csr *A, const int *p, i
 			case SPASM_I64: ((i64 *) S)[t] = v; break;
 			}
 		}
-		(void) hipFree(dS);
+		sh::big_free(dS);
 		spasm_hip_dwork_destroy(W);
-		(void) hipFree(drows);
+		sh::big_free(drows);
 	}
 	logmsg("[schur/dense/random/hip] %d combinations (weight %d) of %d rows, %d columns, %.1fs\n", N, w, n, Sm, wtime() - t0);
 }
@@ -730,8 +728,8 @@ int spasm_hip_ffpack_rref(i64 prime, int n, int m, void *A, int ldA, spasm_datat
 	std::vector<int> pivcol((size_t) (r > 0 ? r : 1));
 	if (r > 0)
 		HIP_CHECK(hipMemcpy(pivcol.data(), dpiv, (size_t) r * sizeof(int), hipMemcpyDeviceToHost));
-	(void) hipFree(dA);
-	(void) hipFree(dpiv);
+	sh::big_free(dA);
+	sh::big_free(dpiv);
 	std::vector<char> is_piv((size_t) m, 0);
 	for (int i = 0; i < r; i++) {
 		qinv[i] = (size_t) pivcol[i];
@@ -808,9 +806,9 @@ int spasm_hip_ffpack_LU(i64 prime, int n, int m, void *A, int ldA, spasm_datatyp
 	HIP_CHECK(hipMemcpy(h.data(), dA, (size_t) n * m * sizeof(u32), hipMemcpyDeviceToHost));
 	HIP_CHECK(hipMemcpy(hp.data(), dP, (size_t) n * sizeof(int), hipMemcpyDeviceToHost));
 	HIP_CHECK(hipMemcpy(hq.data(), dQ, (size_t) m * sizeof(int), hipMemcpyDeviceToHost));
-	(void) hipFree(dA);
-	(void) hipFree(dP);
-	(void) hipFree(dQ);
+	sh::big_free(dA);
+	sh::big_free(dP);
+	sh::big_free(dQ);
 	for (int i = 0; i < n; i++)
 		p[i] = (size_t) hp[i];
 	for (int j = 0; j < m; j++)

@@ -1689,7 +1689,7 @@ int device_rref(int64_t prime, int n, int m, uint32_t *dA, int64_t ld, int *d_pi
 		HIP_CHECK(hipGetDevice(&dev));
 		if (cache.dev != dev) {
 			for (auto &sl : cache.slots)
-				(void) hipFree(sl.first);
+				sh::big_free(sl.first);
 			cache.slots.clear();
 			cache.dev = dev;
 		}
@@ -1705,7 +1705,7 @@ int device_rref(int64_t prime, int n, int m, uint32_t *dA, int64_t ld, int *d_pi
 			cache.slots.push_back({nullptr, 0});
 		auto &sl = cache.slots[next_slot++];
 		if (sl.second < bytes) {
-			(void) hipFree(sl.first);
+			sh::big_free(sl.first);
 			sl.second = bytes + bytes / 4;
 			HIP_CHECK(hipMalloc(&sl.first, sl.second));
 		}
@@ -1714,7 +1714,7 @@ int device_rref(int64_t prime, int n, int m, uint32_t *dA, int64_t ld, int *d_pi
 	auto ws_free = [&](void *ptr) {
 		for (size_t t = 0; t < owned.size(); t++)
 			if (owned[t] == ptr) {
-				(void) hipFree(ptr);
+				sh::big_free(ptr);
 				owned[t] = nullptr;
 				return;
 			}
@@ -3057,7 +3057,7 @@ void launch_combine(const int64_t *Ap, const int *Aj, const int *Ax, const int *
 		int flag = 0;
 		HIP_CHECK(hipMemcpyAsync(&flag, d_flag, sizeof(int), hipMemcpyDeviceToHost, stream));
 		HIP_CHECK(hipStreamSynchronize(stream));
-		(void) hipFree(d_flag);
+		sh::big_free(d_flag);
 		if (flag == 0 && std::getenv("SPASM_HIP_COMBINE_CHECK")) {
 			// (tests) the same combinations by the kernel that sends an atomic per term: the sums must agree mod p
 			const size_t count = (size_t) N * m;
@@ -3543,10 +3543,10 @@ int device_lu(int64_t prime, int n, int m, uint32_t *dA, int64_t ld, int *dP, in
 		t += 1;
 	}
 	HIP_CHECK(hipStreamSynchronize(stream));
-	(void) hipFree(d_piv);
-	(void) hipFree(lu_M8);
-	(void) hipFree(lu_B8);
-	(void) hipFree(lu_perm);
+	sh::big_free(d_piv);
+	sh::big_free(lu_M8);
+	sh::big_free(lu_B8);
+	sh::big_free(lu_perm);
 	return t;
 }
 

@@ -1,5 +1,6 @@
 // Launchers and C ABI of the sparse Schur complement (see include/spasm_hip.h).
 #include <algorithm>
+#include <unordered_map>
 #include <thread>
 #include <cinttypes>
 #include <mutex>
@@ -53,9 +54,7 @@ int env_int(const char *name, int dflt)
 
 template <typename T> T *dalloc(int64_t count)
 {
-	T *p = nullptr;
-	HIP_CHECK(hipMalloc((void **) &p, (size_t) (count > 0 ? count : 1) * sizeof(T)));
-	return p;
+	return static_cast<T *>(sh::big_alloc((size_t) (count > 0 ? count : 1) * sizeof(T)));
 }
 
 template <typename T> void upload(T *dst, const T *src, int64_t count, hipStream_t s)
@@ -73,12 +72,28 @@ struct BigPool {
 	std::vector<std::pair<void *, size_t>> free_blocks;          // cached, not in use
 	std::vector<std::pair<void *, size_t>> live;                 // handed out by big_alloc
 	size_t cached = 0;
+	// small blocks (< BIG_MIN), rounded up to a power of two: free lists per size class, and who is out
+	std::vector<void *> small_free[32];
+	std::unordered_map<void *, int> small_live;
+	size_t small_cached = 0;
 };
 BigPool g_big;
-constexpr size_t BIG_MIN = (size_t) 32 << 20;                    // smaller requests go straight to hipMalloc
+constexpr size_t BIG_MIN = (size_t) 32 << 20;                    // from here on: whole blocks, best fit
 constexpr size_t BIG_CACHE_CAP = (size_t) 96 << 30;
+constexpr size_t SMALL_CACHE_CAP = (size_t) 8 << 30;
+inline int small_class(size_t bytes)
+{
+	int c = 8;                          // 256 bytes
+	while (((size_t) 1 << c) < bytes)
+		c += 1;
+	return c;
+}
 }  // namespace
 
+// Device buffers of every size come from here.  hipMalloc itself is cheap on these boxes (3-20 us: it maps nothing), but a
+// FRESH block is paid for on first touch -- erratically, up to seconds for tens of GB -- and hipFree takes 70-170 us for
+// anything from 1 MB up (it waits for the device): a call of the driver makes a few hundred small buffers.  So freed
+// blocks are parked and handed out again: small ones (< 32 MB) by size class, large ones by best fit.
 void *big_alloc(size_t bytes)
 {
 	if (bytes == 0)
@@ -99,16 +114,28 @@ void *big_alloc(size_t bytes)
 			g_big.live.push_back(blk);
 			return blk.first;
 		}
+	} else {
+		const int c = small_class(bytes);
+		bytes = (size_t) 1 << c;
+		std::lock_guard<std::mutex> guard(g_big.mutex);
+		if (!g_big.small_free[c].empty()) {
+			ptr = g_big.small_free[c].back();
+			g_big.small_free[c].pop_back();
+			g_big.small_cached -= bytes;
+			g_big.small_live[ptr] = c;
+			return ptr;
+		}
 	}
 	if (hipMalloc(&ptr, bytes) != hipSuccess) {
 		(void) hipGetLastError();
 		big_trim(0);                         // cached blocks may be what is in the way
 		HIP_CHECK(hipMalloc(&ptr, bytes));
 	}
-	if (bytes >= BIG_MIN) {
-		std::lock_guard<std::mutex> guard(g_big.mutex);
+	std::lock_guard<std::mutex> guard(g_big.mutex);
+	if (bytes >= BIG_MIN)
 		g_big.live.push_back({ptr, bytes});
-	}
+	else
+		g_big.small_live[ptr] = small_class(bytes);
 	return ptr;
 }
 
@@ -118,17 +145,28 @@ void big_free(void *ptr)
 		return;
 	{
 		std::lock_guard<std::mutex> guard(g_big.mutex);
-		for (size_t t = 0; t < g_big.live.size(); t++)
-			if (g_big.live[t].first == ptr) {
-				const auto blk = g_big.live[t];
-				g_big.live.erase(g_big.live.begin() + (long) t);
-				if (g_big.cached + blk.second <= BIG_CACHE_CAP) {
-					g_big.free_blocks.push_back(blk);
-					g_big.cached += blk.second;
-					return;
-				}
-				break;
+		auto it = g_big.small_live.find(ptr);
+		if (it != g_big.small_live.end()) {
+			const int c = it->second;
+			g_big.small_live.erase(it);
+			if (g_big.small_cached + ((size_t) 1 << c) <= SMALL_CACHE_CAP) {
+				g_big.small_free[c].push_back(ptr);
+				g_big.small_cached += (size_t) 1 << c;
+				return;
 			}
+		} else {
+			for (size_t t = 0; t < g_big.live.size(); t++)
+				if (g_big.live[t].first == ptr) {
+					const auto blk = g_big.live[t];
+					g_big.live.erase(g_big.live.begin() + (long) t);
+					if (g_big.cached + blk.second <= BIG_CACHE_CAP) {
+						g_big.free_blocks.push_back(blk);
+						g_big.cached += blk.second;
+						return;
+					}
+					break;
+				}
+		}
 	}
 	(void) hipFree(ptr);
 }
@@ -141,6 +179,12 @@ void big_trim(size_t keep_bytes)
 		if (keep_bytes == 0) {
 			blocks.swap(g_big.free_blocks);
 			g_big.cached = 0;
+			for (int c = 0; c < 32; c++) {
+				for (void *q : g_big.small_free[c])
+					blocks.push_back({q, (size_t) 1 << c});
+				g_big.small_free[c].clear();
+			}
+			g_big.small_cached = 0;
 		} else {
 			// the largest blocks stay (they are the ones that cost: up to 40 ms per GB to get back, seconds at times)
 			std::sort(g_big.free_blocks.begin(), g_big.free_blocks.end(), [](const auto &x, const auto &y) { return x.second > y.second; });
@@ -188,7 +232,7 @@ void scratch_park(spasm_hip_dwork *W)
 	if (W->d_scratch == nullptr)
 		return;
 	if (g_scratch_cache.ptr != nullptr)
-		(void) hipFree(g_scratch_cache.ptr);
+		sh::big_free(g_scratch_cache.ptr);
 	g_scratch_cache.ptr = W->d_scratch;
 	g_scratch_cache.bytes = W->scratch_bytes;
 	W->d_scratch = nullptr;
@@ -237,7 +281,7 @@ void resident_forget(const struct spasm_csr *A)
 {
 	for (size_t t = 0; t < g_resident.size(); t++)
 		if (g_resident[t].host == A) {
-			(void) hipFree(g_resident[t].p);
+			sh::big_free(g_resident[t].p);
 			big_free(g_resident[t].j);          // (may be the output arrays of a workspace, which come from the block cache)
 			big_free(g_resident[t].x);
 			g_resident.erase(g_resident.begin() + (long) t);
@@ -333,7 +377,7 @@ int resident_fl_census(const struct spasm_csr *A)
 			hipLaunchKernelGGL(popcount_kernel, dim3(64), dim3(256), 0, nullptr, bm, nwords, reinterpret_cast<int *>(bm + nwords));
 			int count = 0;
 			HIP_CHECK(hipMemcpy(&count, bm + nwords, sizeof(int), hipMemcpyDeviceToHost));
-			(void) hipFree(bm);
+			sh::big_free(bm);
 			return count;
 		}
 	return -1;
@@ -374,9 +418,9 @@ DeviceMatrix::DeviceMatrix(const struct spasm_csr *A, hipStream_t stream)
 DeviceMatrix::~DeviceMatrix()
 {
 	if (owned) {
-		(void) hipFree(p);
-		(void) hipFree(j);
-		(void) hipFree(x);
+		sh::big_free(p);
+		sh::big_free(j);
+		sh::big_free(x);
 	}
 }
 }  // namespace sh
@@ -517,7 +561,7 @@ void spasm_hip_release_cached_memory(void)
 {
 	big_trim(0);
 	if (g_scratch_cache.ptr != nullptr) {
-		(void) hipFree(g_scratch_cache.ptr);
+		sh::big_free(g_scratch_cache.ptr);
 		g_scratch_cache.ptr = nullptr;
 		g_scratch_cache.bytes = 0;
 	}
@@ -929,18 +973,18 @@ void spasm_hip_dfact_destroy(spasm_hip_dfact *F)
 	if (F == nullptr)
 		return;
 	backsolve_free(F);
-	(void) hipFree(F->d_lab);
-	(void) hipFree(F->d_q);
-	(void) hipFree(F->d_rp);
-	(void) hipFree(F->d_ent);
-	(void) hipFree(F->d_head);
-	(void) hipFree(F->d_comp);
-	(void) hipFree(F->d_lvl_end);
-	(void) hipFree(F->d_lvl_end_w);
-	(void) hipFree(F->d_kof);
-	(void) hipFree(F->d_cp);
-	(void) hipFree(F->d_cent);
-	(void) hipFree(F->d_lvl);
+	sh::big_free(F->d_lab);
+	sh::big_free(F->d_q);
+	sh::big_free(F->d_rp);
+	sh::big_free(F->d_ent);
+	sh::big_free(F->d_head);
+	sh::big_free(F->d_comp);
+	sh::big_free(F->d_lvl_end);
+	sh::big_free(F->d_lvl_end_w);
+	sh::big_free(F->d_kof);
+	sh::big_free(F->d_cp);
+	sh::big_free(F->d_cent);
+	sh::big_free(F->d_lvl);
 	delete F;
 }
 
@@ -1001,23 +1045,23 @@ void spasm_hip_dwork_destroy(spasm_hip_dwork *W)
 	big_free(W->d_pool_x);
 	big_free(W->d_Sj);
 	big_free(W->d_Sx);
-	(void) hipFree(W->d_row_off);
-	(void) hipFree(W->d_row_len);
-	(void) hipFree(W->d_ovf1);
-	(void) hipFree(W->d_ovf2);
-	(void) hipFree(W->d_Sp);
-	(void) hipFree(W->d_blocksum);
+	sh::big_free(W->d_row_off);
+	sh::big_free(W->d_row_len);
+	sh::big_free(W->d_ovf1);
+	sh::big_free(W->d_ovf2);
+	sh::big_free(W->d_Sp);
+	sh::big_free(W->d_blocksum);
 	if (W->d_lb_status != nullptr)
-		(void) hipFree(W->d_lb_status);
+		sh::big_free(W->d_lb_status);
 	if (W->d_stage != nullptr)
-		(void) hipFree(W->d_stage);
+		sh::big_free(W->d_stage);
 	if (W->d_order != nullptr)
-		(void) hipFree(W->d_order);
+		sh::big_free(W->d_order);
 	if (W->d_sortbuf != nullptr)
-		(void) hipFree(W->d_sortbuf);
-	(void) hipFree(W->d_ctr);
-	(void) hipFree(W->d_ctr64);
-	(void) hipFree(W->d_scratch);
+		sh::big_free(W->d_sortbuf);
+	sh::big_free(W->d_ctr);
+	sh::big_free(W->d_ctr64);
+	sh::big_free(W->d_scratch);
 	for (int e = 0; e < 7; e++)
 		if (W->ev[e] != nullptr)
 			(void) hipEventDestroy(W->ev[e]);
@@ -1116,7 +1160,7 @@ int dschur_impl(const spasm_hip_dcsr *A, const int *d_rows, int nrows, const spa
 		}
 		if (need > W->scratch_bytes) {
 			if (W->d_scratch != nullptr)
-				(void) hipFree(W->d_scratch);
+				sh::big_free(W->d_scratch);
 			HIP_CHECK(hipMalloc((void **) &W->d_scratch, (size_t) need));
 			W->scratch_bytes = need;
 			HIP_CHECK(hipMemsetAsync(W->d_scratch, 0, (size_t) need, stream));
@@ -1201,7 +1245,7 @@ int dschur_impl(const spasm_hip_dcsr *A, const int *d_rows, int nrows, const spa
 				const int64_t need = out.stage_rows * stage_row_bytes;
 				if (W->stage_bytes < need) {
 					if (W->d_stage != nullptr)
-						(void) hipFree(W->d_stage);
+						sh::big_free(W->d_stage);
 					W->d_stage = dalloc<uint32_t>(need / 4);
 					W->stage_bytes = need;
 				}
@@ -1252,7 +1296,7 @@ int dschur_impl(const spasm_hip_dcsr *A, const int *d_rows, int nrows, const spa
 				const int64_t need = regroup_scratch_ints(nrows, F->rpad);
 				if (W->sortbuf_ints < need) {
 					if (W->d_sortbuf != nullptr)
-						(void) hipFree(W->d_sortbuf);
+						sh::big_free(W->d_sortbuf);
 					W->d_sortbuf = dalloc<int>(need);
 					W->sortbuf_ints = need;
 				}
@@ -1548,9 +1592,9 @@ struct spasm_csr *spasm_hip_schur(const struct spasm_csr *A, const int *p, int n
 		scratch_park(W);
 		spasm_hip_dwork_destroy(W);
 		if (L != nullptr) {
-			(void) hipFree(lout.Li);
-			(void) hipFree(lout.Lj);
-			(void) hipFree(lout.Lx);
+			sh::big_free(lout.Li);
+			sh::big_free(lout.Lj);
+			sh::big_free(lout.Lx);
 		}
 		if (rc & 1) {
 			if (pool >= pool_max)
@@ -1585,10 +1629,10 @@ struct spasm_csr *spasm_hip_schur(const struct spasm_csr *A, const int *p, int n
 			L->x[L->nz] = hx[t];
 			L->nz += 1;
 		}
-		(void) hipFree(lout.Li);
-		(void) hipFree(lout.Lj);
-		(void) hipFree(lout.Lx);
-		(void) hipFree(d_row_orig);
+		sh::big_free(lout.Li);
+		sh::big_free(lout.Lj);
+		sh::big_free(lout.Lx);
+		sh::big_free(d_row_orig);
 	}
 	const double t_run = wtime() - t1;
 	const double t2 = wtime();
@@ -1615,9 +1659,9 @@ struct spasm_csr *spasm_hip_schur(const struct spasm_csr *A, const int *p, int n
 		if (resident_enabled() && n_all >= 1024) {
 			resident_adopt(S, gSp, gSj, gSx, false);          // the next round's A is already on every device
 		} else {
-			(void) hipFree(gSp);
-			(void) hipFree(gSj);
-			(void) hipFree(gSx);
+			sh::big_free(gSp);
+			sh::big_free(gSj);
+			sh::big_free(gSx);
 		}
 	} else {
 		S = spasm_hip_csr_alloc(n, m, st.nnz, prime, true);
@@ -1644,7 +1688,7 @@ struct spasm_csr *spasm_hip_schur(const struct spasm_csr *A, const int *p, int n
 	const double t3 = wtime();
 	scratch_park(W);
 	spasm_hip_dwork_destroy(W);
-	(void) hipFree(drows);
+	sh::big_free(drows);
 	const double density = (S->n > 0 && m > 0) ? (double) S->p[S->n] / ((double) m * S->n) : 0.0;
 	logmsg("Schur complement: %d * %d [%" PRId64 " nz / density= %.3f], %.1fs (GPU kernels %.1f ms, %s%s; tiers %d/%d/%d; "
 	       "factor image %.2fs, alloc+run %.2fs, download %.2fs%s, free %.2fs)\n", S->n, m, S->p[S->n], density, wtime() - t0,
