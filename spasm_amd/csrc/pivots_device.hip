@@ -263,12 +263,31 @@ __global__ __launch_bounds__(64) void pivot_search_kernel(const i64 *Ap, const i
 					// with no column there ORs nothing into a word of its own --, then queued with one prefix sum.
 					int e[REC_ENTS];
 					uint32_t bit[REC_ENTS], old[REC_ENTS];
+					if constexpr (GB) {
+						// (the marks are in HBM and the search is bound by the atomics the memory side takes, 30 G/s; five columns in
+						//  six are marked already: look first -- L1-bypassing loads, issued together --, set only what looks clear)
+						uint32_t seen_word[REC_ENTS];
 #pragma unroll
-					for (int t = 0; t < REC_ENTS; t++) {
-						e[t] = rec_get<REC_BITS>(lo, hi, t);
-						const bool ok = len != REC_LONG && t < len && e[t] < m;          // (e[t] < m: a record caught half written)
-						bit[t] = ok ? 1u << (e[t] & 31) : 0u;
-						old[t] = atomicOr(&bits[ok ? (e[t] >> 5) : spare], bit[t]);
+						for (int t = 0; t < REC_ENTS; t++) {
+							e[t] = rec_get<REC_BITS>(lo, hi, t);
+							const bool ok = len != REC_LONG && t < len && e[t] < m;          // (e[t] < m: a record caught half written)
+							bit[t] = ok ? 1u << (e[t] & 31) : 0u;
+							seen_word[t] = ok ? bits_at(e[t] >> 5) : ~0u;
+						}
+#pragma unroll
+						for (int t = 0; t < REC_ENTS; t++) {
+							old[t] = ~0u;
+							if ((bit[t] & ~seen_word[t]) != 0)
+								old[t] = atomicOr(&bits[e[t] >> 5], bit[t]);
+						}
+					} else {
+#pragma unroll
+						for (int t = 0; t < REC_ENTS; t++) {
+							e[t] = rec_get<REC_BITS>(lo, hi, t);
+							const bool ok = len != REC_LONG && t < len && e[t] < m;          // (e[t] < m: a record caught half written)
+							bit[t] = ok ? 1u << (e[t] & 31) : 0u;
+							old[t] = atomicOr(&bits[ok ? (e[t] >> 5) : spare], bit[t]);
+						}
 					}
 					int base = tail;
 #pragma unroll
@@ -497,10 +516,12 @@ int device_acyclic_greedy(const struct spasm_csr *A, int *pinv, int *qinv)
 	HIP_CHECK(hipGetDevice(&dev));
 	HIP_CHECK(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev));
 	const int fifo_cap = m + 4096;
-	int per_cu = std::max(1, std::min(env_int("SPASM_HIP_PIVOT_WAVES_PER_CU", 4), (int) ((160 * 1024) / lds)));
-	// (a search owns a FIFO of m + 4096 columns, and m / 8 bytes of marks with global_bits: at most 8 GB in all)
+	// searches in flight per CU: 4 with the marks in LDS (the step is bound by instruction issue: more only adds speculation),
+	// 8 with the marks in HBM (bound by memory latency: mk14.b5 6.4 s at 2, 4.2 at 4, 3.4 at 8)
+	int per_cu = std::max(1, std::min(env_int("SPASM_HIP_PIVOT_WAVES_PER_CU", global_bits ? 8 : 4), (int) ((160 * 1024) / lds)));
+	// (a search owns a FIFO of m + 4096 columns, and m / 8 bytes of marks with global_bits: at most 16 GB in all)
 	const size_t per_search = (size_t) fifo_cap * sizeof(int) + (global_bits ? ((size_t) words + 64) * sizeof(uint32_t) : 0);
-	while (per_cu > 1 && (size_t) cus * per_cu * per_search > ((size_t) 8 << 30))
+	while (per_cu > 1 && (size_t) cus * per_cu * per_search > ((size_t) 16 << 30))
 		per_cu -= 1;
 	const int grid = cus * per_cu;
 	std::vector<void *> owned;
