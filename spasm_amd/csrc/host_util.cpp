@@ -73,7 +73,7 @@ using namespace sh;
 
 extern "C" {
 
-const char *spasm_hip_version(void) { return "spasm-hip 0.2 (gfx950)"; }
+const char *spasm_hip_version(void) { return "spasm-hip 0.3 (gfx950)"; }
 
 // spasm_malloc / spasm_calloc / spasm_realloc (spasm_util.c:65-83): die instead of returning NULL
 void *spasm_hip_malloc(i64 size) { return xmalloc(size); }
