@@ -530,7 +530,7 @@ def main():
             "roofline": roof,
             "factor_image_ms": statistics.median(image_ms),
             "factor_image_note": "host planning + upload of the factor image (spasm_hip_dfact_create), once per factor, NOT in a step; "
-                                 "median of 3 builds",
+                                 "median of 3 builds after a first one that is not counted (it loads the code object and fills the buffer cache)",
             "rows_per_s_cold": total_rows / (elapsed / args.steps + 1e-3 * statistics.median(image_ms)),
         }
         extras = world == 1 and not args.no_extras
