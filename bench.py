@@ -583,6 +583,17 @@ def main():
                                  "rank": med[2], "ranks_agree": len({r[2] for r in runs}) == 1,
                                  "seconds_min": min(secs), "seconds_median": statistics.median(secs), "seconds_all": secs,
                                  "split_of_median_call": med[1]}
+            # north_star keeps the pivot selection on the host; the library runs its greedy search on the device when it has
+            # one.  The same call with the search where north_star puts it:
+            os.environ["SPASM_HIP_PIVOT_SEARCH"] = "host"
+            try:
+                t0 = time.perf_counter()
+                fact = spasm_amd.echelonize(A_full, opts)
+                out["end_to_end"]["with_the_pivot_search_on_the_host"] = {
+                    "what": "one more call with SPASM_HIP_PIVOT_SEARCH=host (%d threads)" % spasm_amd.usable_cpus(),
+                    "seconds": time.perf_counter() - t0, "rank": int(fact.U.n), "split": spasm_amd.echelonize_profile()}
+            finally:
+                os.environ.pop("SPASM_HIP_PIVOT_SEARCH", None)
         if extras and args.workload == "mk13.b5":
             out["sparse_path"] = sparse_path_probe(torch, spasm_amd, workloads, dev)
             out["stand_ins"] = stand_in_runs(spasm_amd, workloads)
