@@ -137,6 +137,7 @@ constexpr u64 PS_PENDING = 1, PS_ACCEPTED = 2, PS_ABORTED = 3;
 __device__ __forceinline__ u64 entry(int col, u64 state) { return (u64) (uint32_t) col | (state << 32); }
 
 constexpr int PS_ROWS_PER_GRAB = 8;
+constexpr int PS_LIST = 512;
 constexpr unsigned PS_SPIN_LIMIT = 1u << 24;
 
 // one wavefront per workgroup.  The reached-bit of every column lives in LDS (GB = false: m / 8 bytes, cleared per row) or,
@@ -145,14 +146,15 @@ constexpr unsigned PS_SPIN_LIMIT = 1u << 24;
 // candidate columns of the row (one per lane) in LDS.
 template <bool GB, int REC_ENTS, int REC_BITS>
 __global__ __launch_bounds__(64) void pivot_search_kernel(const i64 *Ap, const int *Aj, const int *pinv, int n, int m, int words, u64 *rec, u64 *jent, int *jrow,
-                                                          PsCtrl *ctrl, int *fifo_all, int fifo_cap, int jcap, uint32_t *gbits)
+                                                          PsCtrl *ctrl, int *fifo_all, int fifo_cap, int jcap, uint32_t *gbits, int list_cap)
 {
 	extern __shared__ __attribute__((aligned(16))) uint32_t ps_lds[];
 	uint32_t *bits = GB ? gbits + (size_t) blockIdx.x * (size_t) (words + 64) : ps_lds;
 	int *cand = reinterpret_cast<int *>(ps_lds + (GB ? 0 : words));
 	int *tmp = cand + 64;
+	uint32_t *list = reinterpret_cast<uint32_t *>(tmp + 8);          // PS_LIST (lane, entry) pairs of the long rows of a step
 	const int lane = threadIdx.x;
-	const int spare = words + (GB ? 0 : 64 + 8) + lane;          // a word of this lane's own, for atomics that must do nothing
+	const int spare = words + (GB ? 0 : 64 + 8 + list_cap) + lane;          // a word of this lane's own, for atomics that must do nothing
 	auto bits_at = [&](int w) -> uint32_t {                       // (GB: what the atomics left in the L2, not what the L1 remembers)
 		if constexpr (GB)
 			return (uint32_t) ld_i32(reinterpret_cast<const int *>(bits + w));
@@ -299,13 +301,92 @@ __global__ __launch_bounds__(64) void pivot_search_kernel(const i64 *Ap, const i
 						base += __popcll(mask);
 					}
 					tail = base;
-					// pivot rows too long for a record: the wave walks them one by one
-					for (u64 longs = __ballot(len == REC_LONG && long_row < n); longs != 0; longs &= longs - 1) {
-						const int row = __shfl(long_row, __builtin_ctzll(longs));
-						const i64 lo = Ap[row], hi = Ap[row + 1];
-						for (i64 px0 = lo; px0 < hi; px0 += 64) {
-							const bool valid = px0 + lane < hi;
-							reach(valid, valid ? Aj[px0 + lane] : 0);
+					// Pivot rows too long for a record (GL7d19 has ~19 entries per row: every one of them).  One row after the other with
+					// the whole wave -- 19 lanes of 64 at work, one round of marking per visited row -- left the search at 1.4 G visits/s
+					// on such a matrix; here the entries of all the long rows of the step are listed in LDS as (lane, entry) pairs, up
+					// to list_cap at a time (PS_LIST when the matrix has such rows: the list is LDS that matrices of short rows would rather
+					// spend on a fourth search per CU), and marked 64 per round whatever row they come from.
+					{
+						u64 longs = __ballot(len == REC_LONG && long_row < n);
+						i64 my_lo = 0;
+						int my_len = 0;
+						if ((longs >> lane) & 1) {
+							my_lo = Ap[long_row];
+							my_len = (int) min((i64) (1 << 30), Ap[long_row + 1] - my_lo);
+						}
+						while (longs != 0) {
+							const bool in = (longs >> lane) & 1;
+							int incl = in ? my_len : 0;          // entries of the waiting rows up to and including this lane's
+							for (int d = 1; d < 64; d <<= 1) {
+								const int v = __shfl_up(incl, d);
+								if (lane >= d)
+									incl += v;
+							}
+							const bool fits = in && incl <= list_cap;
+							const u64 batch = __ballot(fits);          // (a prefix of the waiting lanes: incl grows with the lane)
+							if (batch == 0) {
+								// the first waiting row alone is longer than the list: the whole wave walks it
+								const int l0 = __builtin_ctzll(longs);
+								const i64 lo0 = ((i64) __shfl((int) (my_lo >> 32), l0) << 32) | (uint32_t) __shfl((int) (uint32_t) my_lo, l0);
+								const i64 hi0 = lo0 + __shfl(my_len, l0);
+								for (i64 px0 = lo0; px0 < hi0; px0 += 64) {
+									const bool valid = px0 + lane < hi0;
+									reach(valid, valid ? Aj[px0 + lane] : 0);
+								}
+								longs &= longs - 1;
+								continue;
+							}
+							if (fits)
+								for (int t = 0; t < my_len; t++)
+									list[incl - my_len + t] = ((uint32_t) lane << 16) | (uint32_t) t;
+							const int total = __shfl(incl, 63 - __builtin_clzll(batch));
+							// four rounds of 64 entries at a time: their loads in flight together, their marks set back to back, one prefix
+							// sum for the queue (as for the columns of the records)
+							for (int g0 = 0; g0 < total && !overflow; g0 += 256) {
+								if (tail + 256 > fifo_cap) {
+									overflow = true;
+									break;
+								}
+								int jj[4];
+								uint32_t bt[4], od[4];
+#pragma unroll
+								for (int u = 0; u < 4; u++) {
+									const int g = g0 + 64 * u + lane;
+									const bool valid = g < total;
+									const uint32_t ent = valid ? list[g] : 0u;
+									const int owner = (int) (ent >> 16);
+									const i64 lo1 = ((i64) __shfl((int) (my_lo >> 32), owner) << 32) | (uint32_t) __shfl((int) (uint32_t) my_lo, owner);
+									jj[u] = valid ? Aj[lo1 + (ent & 0xFFFFu)] : 0;
+									bt[u] = valid ? 1u << (jj[u] & 31) : 0u;
+								}
+								if constexpr (GB) {
+									uint32_t sw[4];
+#pragma unroll
+									for (int u = 0; u < 4; u++)
+										sw[u] = (bt[u] != 0) ? bits_at(jj[u] >> 5) : ~0u;
+#pragma unroll
+									for (int u = 0; u < 4; u++) {
+										od[u] = ~0u;
+										if ((bt[u] & ~sw[u]) != 0)
+											od[u] = atomicOr(&bits[jj[u] >> 5], bt[u]);
+									}
+								} else {
+#pragma unroll
+									for (int u = 0; u < 4; u++)
+										od[u] = atomicOr(&bits[(bt[u] != 0) ? (jj[u] >> 5) : spare], bt[u]);
+								}
+								int base2 = tail;
+#pragma unroll
+								for (int u = 0; u < 4; u++) {
+									const bool fresh = (bt[u] & ~od[u]) != 0;
+									const u64 mask = __ballot(fresh);
+									if (fresh)
+										fifo[base2 + __popcll(mask & below)] = jj[u];
+									base2 += __popcll(mask);
+								}
+								tail = base2;
+							}
+							longs &= ~batch;
 						}
 					}
 					live = alive();
@@ -503,10 +584,15 @@ int device_acyclic_greedy(const struct spasm_csr *A, int *pinv, int *qinv)
 	}
 	const int words = ((m + 31) / 32 + 255) / 256 * 256;          // (cleared 256 words at a time)
 	// the reached-bits in LDS when one bit per column fits 64 KB (and a column fits 20 bits), else in HBM
-	bool global_bits = (size_t) words * 4 + (64 + 8 + 64) * sizeof(int) > 64 * 1024 || m > (1 << 20);
+	bool global_bits = (size_t) words * 4 + (64 + 8 + PS_LIST + 64) * sizeof(int) > 64 * 1024 || m > (1 << 20);          // (room for the list, needed or not)
 	if (const char *e = std::getenv("SPASM_HIP_PIVOT_BITS"))
 		global_bits = global_bits || std::strcmp(e, "global") == 0;
-	const size_t lds = global_bits ? (64 + 8) * sizeof(int) : (size_t) words * 4 + (64 + 8 + 64) * sizeof(int);
+	// rows with more than six other entries have no 16-byte record: their entries go through a list in LDS (if there are any)
+	int list_cap = 0;
+	for (int i = 0; i < n && list_cap == 0; i++)
+		if (A->p[i + 1] - A->p[i] > (global_bits ? 6 : 7))          // (the pivot and five or six others: what a record holds)
+			list_cap = PS_LIST;
+	const size_t lds = global_bits ? (size_t) (64 + 8 + list_cap) * sizeof(int) : (size_t) words * 4 + (size_t) (64 + 8 + list_cap + 64) * sizeof(int);
 	if (n <= 0 || m <= 0 || m > (1 << 25))
 		return -1;
 	const double t0 = wtime();
@@ -557,11 +643,11 @@ int device_acyclic_greedy(const struct spasm_csr *A, int *pinv, int *qinv)
 	if (global_bits) {
 		hipLaunchKernelGGL((pivot_records_kernel<5, 25>), dim3((m + 255) / 256), dim3(256), 0, stream, dA.p, dA.j, d_qinv, m, rec);
 		hipLaunchKernelGGL((pivot_search_kernel<true, 5, 25>), dim3(grid), dim3(64), lds, stream, dA.p, dA.j, d_pinv, n, m, words, rec, jent, jrow, ctrl, fifo,
-		                   fifo_cap, (int) jcap, gbits);
+		                   fifo_cap, (int) jcap, gbits, list_cap);
 	} else {
 		hipLaunchKernelGGL((pivot_records_kernel<6, 20>), dim3((m + 255) / 256), dim3(256), 0, stream, dA.p, dA.j, d_qinv, m, rec);
 		hipLaunchKernelGGL((pivot_search_kernel<false, 6, 20>), dim3(grid), dim3(64), lds, stream, dA.p, dA.j, d_pinv, n, m, words, rec, jent, jrow, ctrl, fifo,
-		                   fifo_cap, (int) jcap, gbits);
+		                   fifo_cap, (int) jcap, gbits, list_cap);
 	}
 	HIP_CHECK(hipGetLastError());
 	PsCtrl c;
