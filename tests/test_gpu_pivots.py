@@ -24,6 +24,7 @@ def _random_matrix(n, m, seed, max_len, prime):
     rng = np.random.default_rng(seed)
     lens = rng.integers(1, max_len + 1, size=n)
     lens[rng.integers(0, n, size=n // 50)] = rng.integers(65, 200, size=n // 50)          # some rows longer than a wavefront
+    lens[rng.integers(0, n, size=n // 400)] = rng.integers(520, 900, size=n // 400)       # ... a few longer than the list of the device search
     p = np.zeros(n + 1, np.int64)
     np.cumsum(lens, out=p[1:])
     j = np.zeros(int(p[n]), np.int32)
