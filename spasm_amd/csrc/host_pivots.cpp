@@ -406,21 +406,63 @@ struct Search {
 		order.reserve((size_t) m);
 		std::vector<char> seen((size_t) (m > 0 ? m : 1), 0);
 		std::vector<int> stack_col, stack_pos;
+		// The walk goes column -> its pivot row -> the columns of that row: qinv[j], A->p[i], A->j[...] are three dependent cache
+		// misses per node.  As in the search (PivRec), a pivotal column keeps the columns of its row -- all of them, in row order,
+		// the walk skips what it has seen -- in a 32-byte record when they are at most seven: one miss.  cnt -1: not pivotal;
+		// -2: the row is longer (its index is in ent[0]).  The records are filled row by row, by a few threads on large inputs.
+		struct alignas(32) Rec {
+			int cnt;
+			int ent[7];
+		};
+		std::vector<Rec> rec((size_t) (m > 0 ? m : 1));
+		for (int j = 0; j < m; j++)
+			rec[j].cnt = -1;
+		auto fill = [&](int i_lo, int i_hi) {
+			for (int i = i_lo; i < i_hi; i++) {
+				const int j = pinv[i];
+				if (j < 0)
+					continue;
+				Rec &R = rec[j];
+				const int w = weight(i);
+				if (w > 7) {
+					R.cnt = -2;
+					R.ent[0] = i;
+				} else {
+					for (int k = 0; k < w; k++)
+						R.ent[k] = A->j[A->p[i] + k];
+					R.cnt = w;
+				}
+			}
+		};
+		{
+			const int T = (npiv < 20000) ? 1 : std::max(1, std::min(8, usable_cpus()));
+			std::vector<std::thread> pool;
+			for (int t = 1; t < T; t++)
+				pool.emplace_back(fill, (int) ((i64) n * t / T), (int) ((i64) n * (t + 1) / T));
+			fill(0, (int) ((i64) n / T));
+			for (auto &th : pool)
+				th.join();
+		}
 		for (int j0 = 0; j0 < m; j0++) {
-			if (qinv[j0] == -1 || seen[j0])
+			if (rec[j0].cnt == -1 || seen[j0])
 				continue;
 			stack_col.assign(1, j0);
 			stack_pos.assign(1, 0);
 			seen[j0] = 1;
 			while (!stack_col.empty()) {
-				int j = stack_col.back();
-				int i = qinv[j];
+				const int j = stack_col.back();
+				const Rec &R = rec[j];
 				bool down = false;
-				if (i >= 0) {
-					i64 base = A->p[i];
-					int w = weight(i);
+				if (R.cnt != -1) {
+					const int *ents = R.ent;
+					int w = R.cnt;
+					if (w == -2) {
+						const int i = R.ent[0];
+						ents = A->j + A->p[i];
+						w = weight(i);
+					}
 					for (int k = stack_pos.back(); k < w; k++) {
-						int jj = A->j[base + k];
+						const int jj = ents[k];
 						if (seen[jj])
 							continue;
 						stack_pos.back() = k + 1;
