@@ -1079,6 +1079,7 @@ int dschur_impl(const spasm_hip_dcsr *A, const int *d_rows, int nrows, const spa
                 void *stream_, spasm_hip_schur_stats *stats, LOut *Lout)
 {
 	hipStream_t stream = (hipStream_t) stream_;
+	const double t_enter = wtime();
 	if (nrows > W->max_rows)
 		die("spasm_hip_dschur: %d rows but the workspace was sized for %d", nrows, W->max_rows);
 	if (A->m != F->m || W->m < F->m)
@@ -1382,7 +1383,11 @@ eliminated:
 	HIP_CHECK(hipMemcpyAsync(ctr, W->d_ctr, sizeof(ctr), hipMemcpyDeviceToHost, stream));
 	HIP_CHECK(hipMemcpyAsync(ctr64, W->d_ctr64, sizeof(ctr64), hipMemcpyDeviceToHost, stream));
 	HIP_CHECK(hipMemcpyAsync(&total, W->d_Sp + nrows, sizeof(i64), hipMemcpyDeviceToHost, stream));
+	const double t_enqueued = wtime();
 	HIP_CHECK(hipStreamSynchronize(stream));
+	if (verbose() >= 3)
+		logmsg("[schur/hip] %d rows: %.2f ms of host work up to the last launch, %.2f ms waiting for the device\n", nrows, 1e3 * (t_enqueued - t_enter),
+		       1e3 * (wtime() - t_enqueued));
 	W->last_rows = nrows;
 	W->last_nnz = total;
 	if (ctr[CTR_STATUS] & 4)
