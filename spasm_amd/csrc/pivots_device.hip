@@ -14,12 +14,18 @@
 // (ABORTED), replays and goes on; otherwise its pivot is ACCEPTED.  Serialized by ticket number this is the sequential
 // algorithm: an accepted ticket has seen every accepted ticket before it, either in a replay or as one that does not touch
 // it.  Nobody waits for a chain: a ticket is decided a few loads after it was drawn, whatever the tickets before it do.
-// As with threads, the set of pivots depends on timing; it is always cycle-free.
+// A replay only moves past DECIDED tickets (it polls the few that are not: they are a few loads from their decision), so the
+// record of an accepted pivot is complete before any search relies on it; a search that starts takes a lower bound of the
+// decided prefix (PsCtrl::prefix, raised by whoever replays) as the point its first replay starts from.
+// As with threads, the set of pivots depends on timing; it is always cycle-free -- and the host checks that the order it
+// derives from the result is triangular before anything is built on it (host_pivots.cpp, Search::triangular).
 //
 // What waves hand to each other inside the launch -- the pivot records, the journal, the counter -- is written and read
 // with agent-scope atomic stores and loads (write-through `sc1` stores, L1-bypassing `sc1` loads); a committer drains its
 // record stores (s_waitcnt vmcnt(0)) before it stores the journal entry that announces them.  Everything else a wave
-// touches in global memory is either read-only in the launch (A, the rows that had a pivot before) or its own (its FIFO).
+// touches in global memory is either read-only in the launch (A, the rows that had a pivot before) or its own (its FIFO;
+// its marks when the matrix is too wide for the LDS -- set by atomics and read by L1-bypassing loads, since an atomic
+// leaves the L1 as it was).
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
