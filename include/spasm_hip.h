@@ -241,6 +241,9 @@ void spasm_hip_dfact_forget(spasm_hip_dfact *F);
  * density sample by itself).  < 0: unknown (5 % density, 5 % of the pivots per row are assumed). */
 void spasm_hip_dfact_hint_density(spasm_hip_dfact *F, double density);
 void spasm_hip_dfact_hint_eliminations(spasm_hip_dfact *F, double per_row);
+/* fill of R = U_pp^-1 U_pn as the sparse image holds it: out[0] entries, out[1] occupied 64-column tiles, out[2] non-empty
+ * fragments, out[3] (row, segment) pairs.  Returns 1 when the factor holds a valid sparse image (else 0, out zeroed). */
+int spasm_hip_dfact_sparse_image_census(const spasm_hip_dfact *F, i64 *out, void *stream);
 int spasm_hip_dfact_rank(const spasm_hip_dfact *F);
 int spasm_hip_dfact_levels(const spasm_hip_dfact *F);
 i64 spasm_hip_dfact_nnz(const spasm_hip_dfact *F);
@@ -289,6 +292,21 @@ typedef struct {
 	 * its wave count (8 waves per CU), waves per group, bytes of one slice ((rpad + Sm) * 256 B) */
 	int group_slots, group_slots_wanted, group_waves;
 	i64 group_slot_bytes;
+	/* sparse image (S = A_n - A_p R with R kept as sparse fragments: spasm_amd/csrc/sparse_image.hip) */
+	int used_sparse_image;      /* 1: the rows were computed from the sparse image */
+	int sparse_image_built;     /* 1: ... and the image was (re)built by this call */
+	float ms_sparse_build;      /* device time of that build (sp_build_kernel, one launch per elimination level) */
+	float ms_sparse_apply;      /* ... of sp_apply_kernel (fragments of S) */
+	float ms_sparse_gather;     /* ... of the scan of the row lengths + sp_gather_kernel (rows in their final place) */
+	int sparse_image_levels;    /* elimination levels of the factor */
+	int sparse_image_launches;  /* kernels of the build (levels, + those redone after a pool extension) */
+	int sparse_image_pad;
+	i64 sparse_image_nnz;       /* entries of R */
+	i64 sparse_image_ops_build; /* multiply-adds of the build (entries of the fragments added up) */
+	i64 sparse_image_ops_apply; /* ... of the rows of S */
+	i64 bytes_sparse_build;     /* algorithmic bytes of the three kernels */
+	i64 bytes_sparse_apply;
+	i64 bytes_sparse_gather;
 } spasm_hip_schur_stats;
 
 /* S = Schur complement of rows d_rows[0..nrows) of A w.r.t. F, left in the

@@ -55,6 +55,7 @@ def lib():
         "spasm_hip_dfact_rank": (ci, [vp]),
         "spasm_hip_dfact_levels": (ci, [vp]),
         "spasm_hip_dfact_nnz": (i64, [vp]),
+        "spasm_hip_dfact_sparse_image_census": (ci, [vp, C.POINTER(i64), vp]),
         "spasm_hip_dwork_create": (vp, [ci, ci, i64]),
         "spasm_hip_dwork_destroy": (None, [vp]),
         "spasm_hip_dschur": (ci, [C.POINTER(CDcsr), vp, ci, vp, vp, vp, C.POINTER(CSchurStats)]),

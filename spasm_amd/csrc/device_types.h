@@ -166,6 +166,52 @@ struct BsImage {
 	int ring = 768, passrows = 32, passcap = 80;      // rows per chunk, rows per phase-B pass, passes per chunk of that plan
 };
 
+// ---- sparse back-substituted factor ("sparse image", sparse_image.hip) ----------------------------
+// The same R = U_pp^-1 U_pn as BsImage, for factors whose R is mostly zeros (a Schur complement that stays sparse): rows
+// of R are kept as FRAGMENTS -- the entries a row has in one segment of SP_SEG non-pivotal columns, 4 bytes each
+// (column inside the segment | signed 16-bit value << 16) -- in a bump-allocated pool; frag[c * nseg + g] says where the
+// fragment of row c (compact id) in segment g lies and how long it is.  Bytes and work scale with the fill of R, not with
+// r x Sm, and there is no limit on Sm.
+constexpr int SP_SEG = 8192;            // columns per segment: 16 KB of 16-bit accumulators per wave
+constexpr int SP_LEN_BITS = 14;         // a fragment holds at most SP_SEG entries
+constexpr int SP_OFF_BITS = 40;         // offset inside a pool chunk (entries)
+constexpr int SP_MAX_CHUNKS = 12;
+constexpr int SP_SHARDS = 256;          // allocation cursors of the build (one 128-byte line each)
+
+struct SpPools {
+	const uint32_t *base[SP_MAX_CHUNKS];
+};
+
+struct SpImage {
+	bool planned = false;     // the dependency tables below are on the device
+	bool valid = false;       // the fragments hold R
+	bool failed = false;      // the last build gave up (R is not sparse: the pool budget ran out)
+	int r = 0, Sm = 0, nseg = 0, nlevels = 0;
+	int64_t ndeps = 0, nnp = 0;
+	std::vector<int> lvl_lo;          // first compact row of every level (nlevels + 1 entries)
+	int *d_col = nullptr;             // column -> compact row id of its pivot, or r + index among the non-pivotal columns
+	uint64_t *d_dep_rp = nullptr;     // per compact row: its pivotal entries ...
+	uint2 *d_dep = nullptr;           // ... (compact row of the pivot, NEGATED balanced coefficient)
+	uint64_t *d_np_rp = nullptr;      // per compact row: its non-pivotal entries ...
+	uint2 *d_np = nullptr;            // ... (index among the non-pivotal columns, balanced value)
+	uint64_t *d_frag = nullptr;       // r * nseg words: chunk << 54 | offset << 14 | length
+	uint32_t *d_chunk[SP_MAX_CHUNKS] = {};
+	int64_t chunk_cap[SP_MAX_CHUNKS] = {};        // entries
+	int nchunks = 0;
+	unsigned long long *d_shard = nullptr;        // SP_SHARDS x 16 words: [0] cursor, [1] limit (entries inside the current chunk)
+	unsigned long long *d_stat = nullptr;         // 8 counters of the build (see sparse_image.hip)
+	hipEvent_t ev0 = nullptr, ev1 = nullptr;      // around the last build
+	int builds = 0;
+	int64_t nnz = 0;                  // entries of R (last build)
+	int64_t ops_build = 0;            // (entry of a fragment, row that uses it) pairs of the last build
+	int64_t pool_used = 0;            // entries handed out by the cursors
+	int launches = 0;                 // kernels of the last build (levels, + those redone after a pool extension)
+};
+
+struct SchurArgs;
+struct FactPlan;
+void launch_scan_lengths(const int *len, int n, const unsigned long long *block_sum, int64_t *Sp, int64_t cap, int *ctr, hipStream_t stream);
+
 // device copy of a host CSR matrix for the duration of a call (schur_api.hip: resident between the calls of a driver)
 struct DeviceMatrix {
 	int64_t *p = nullptr;
@@ -234,6 +280,7 @@ struct spasm_hip_dfact {
 	std::vector<int> h_q;          // host copy of q
 	std::vector<int> h_kof;
 	mutable sh::BsImage bs;        // back-substituted image, built on first use when the factor is eligible
+	mutable sh::SpImage sp;        // sparse back-substituted image (sparse_image.hip)
 };
 
 struct spasm_hip_dwork {
@@ -252,6 +299,8 @@ struct spasm_hip_dwork {
 	int *d_Sj = nullptr, *d_Sx = nullptr;
 	uint32_t *d_stage = nullptr;                  // packed rows of the staged sparse output (backsolve.hip)
 	int64_t stage_bytes = 0;
+	uint64_t *d_spT = nullptr;                    // sparse image: where the fragment of every (row, segment) of S lies (sparse_image.hip)
+	int64_t spT_words = 0;
 	unsigned long long *d_lb_status = nullptr;   // look-back words of the direct sparse output (one per row, then the ticket counters: schur_api.hip)
 	unsigned char *d_scratch = nullptr;   // per-wave dense accumulators (all zero between calls)
 	int64_t scratch_bytes = 0;

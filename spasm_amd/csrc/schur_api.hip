@@ -35,6 +35,15 @@ bool backsolve_stages_output(const spasm_hip_dfact *F, int64_t *row_bytes);
 void launch_backsolve_apply(const SchurArgs &a, const spasm_hip_dfact *F, uint32_t *dense_out, int64_t ldS, hipStream_t stream,
                             BsDirectOut *direct);
 bool backsolve_wanted(const spasm_hip_dfact *F, bool other_path_forced, int nrows);
+bool sparse_image_possible(int64_t prime);
+void sparse_image_plan(const FactPlan &P, spasm_hip_dfact *F, hipStream_t stream);
+void sparse_image_free(spasm_hip_dfact *F);
+bool sparse_image_build(const spasm_hip_dfact *F, hipStream_t stream);
+void launch_sparse_image_apply(const SchurArgs &a, const spasm_hip_dfact *F, uint32_t *dense_out, int64_t ldS, uint32_t *fpool, int64_t fcap,
+                               uint64_t *T, unsigned long long *block_sum, int64_t *Sp, int *Sj, int *Sx, int64_t cap, hipStream_t stream,
+                               hipEvent_t ev_gather);
+bool sparse_image_wanted(const spasm_hip_dfact *F, bool other_path_forced, int nrows);
+void sparse_image_census(const spasm_hip_dfact *F, int64_t *out, hipStream_t stream);
 int usable_cpus();          // host_pivots.cpp
 // multi-GPU layer (dist_api.hip)
 spasm_hip_comm *current_comm();
@@ -545,6 +554,40 @@ bool backsolve_wanted(const spasm_hip_dfact *F, bool other_path_forced, int nrow
 	const double t_rows = 0.3e-3 + 27e-12 * elim_per_row * n;
 	return t_build + t_apply <= t_rows;
 }
+
+// Should this batch go through the SPARSE image (sparse_image.hip)?  It is made for Schur complements that stay sparse on
+// many columns: R is then mostly zeros, and both the build and the rows of S cost what R and S hold, not r x Sm.
+// SPASM_HIP_SPARSE_IMAGE=0 never, =1 whenever the factor has the plan (tests); else: full batches (>= 1,024 rows) whose
+// expected density is under 12 % (the driver's estimate; unknown: 3 % assumed beyond 16,384 non-pivotal columns), when the
+// chain of level launches of the build (~10 us each) is small against what the other paths would take.
+bool sparse_image_wanted(const spasm_hip_dfact *F, bool other_path_forced, int nrows)
+{
+	const SpImage &S = F->sp;
+	const int mode = env_int("SPASM_HIP_SPARSE_IMAGE", -1);
+	if (mode == 0 || !S.planned || S.failed)
+		return false;
+	if (mode == 1)
+		return true;
+	if (other_path_forced || env_int("SPASM_HIP_BACKSOLVE", -1) >= 0)
+		return false;
+	if (S.valid)
+		return true;
+	if (nrows < 1024)
+		return false;
+	const BsImage &B = F->bs;
+	const double density = (B.density_hint >= 0.0) ? B.density_hint : (S.Sm > 16384 ? 0.03 : 1.0);
+	if (density >= 0.12)
+		return false;
+	const double r = (double) S.r, Sm = (double) S.Sm, n = (double) nrows;
+	const double eb = 2.0;
+	const double t_dense = std::max(15e-6 * std::ceil(r / 768.0), (r + (double) S.ndeps) * Sm * eb / 2.1e12) +
+	                       (3.0 * n * Sm * eb + 2.0 * n * Sm * eb + 8.0 * density * n * Sm) / 4.5e12 + 0.4e-3;
+	const double elim_per_row = (B.elim_hint >= 0.0) ? B.elim_hint : 0.05 * r;
+	const double t_rows = 0.3e-3 + 27e-12 * elim_per_row * n;
+	const double t_other = B.planned ? std::min(t_dense, t_rows) : t_rows;
+	const double t_sparse = 10e-6 * (double) S.nlevels + 6e-9 * n * (double) S.nseg + 16.0 * density * n * Sm / 3e12 + 0.5e-3;
+	return t_sparse < t_other;
+}
 }  // namespace sh
 
 extern "C" {
@@ -962,9 +1005,16 @@ spasm_hip_dfact *spasm_hip_dfact_create(const struct spasm_csr *U, const int *qi
 	int64_t bs_bytes = 0;
 	if (env_int("SPASM_HIP_BACKSOLVE", -1) != 0 && backsolve_eligible(r, m - r, F->nnz, &bs_bytes, F->prime))
 		backsolve_plan(P, F, stream);
+	// sparse image (sparse_image.hip): its dependency tables, for wide factors (R itself is built by the first batch that wants it)
+	const double t_bs = wtime();
+	if (sparse_image_possible(F->prime) && r > 0 && m - r > 0 &&
+	    (env_int("SPASM_HIP_SPARSE_IMAGE", -1) == 1 || (m - r >= 8192 && (double) r * (double) (m - r) >= 5e8)))
+		sparse_image_plan(P, F, stream);
+	if (verbose() >= 2 && F->sp.planned)
+		logmsg("[factor image] tables of the sparse image: %.1f ms\n", 1e3 * (wtime() - t_bs));
 	if (verbose() >= 2)
 		logmsg("[factor image] %d rows, %d levels: level schedule + relabelling %.1f ms, tables + upload %.1f ms, plan of the back-substitution %.1f ms\n",
-		       r, P.nlevels, 1e3 * (t_planned - t_begin), 1e3 * (t_uploaded - t_planned), 1e3 * (wtime() - t_uploaded));
+		       r, P.nlevels, 1e3 * (t_planned - t_begin), 1e3 * (t_uploaded - t_planned), 1e3 * (t_bs - t_uploaded));
 	return F;
 }
 
@@ -973,6 +1023,7 @@ void spasm_hip_dfact_destroy(spasm_hip_dfact *F)
 	if (F == nullptr)
 		return;
 	backsolve_free(F);
+	sparse_image_free(F);
 	sh::big_free(F->d_lab);
 	sh::big_free(F->d_q);
 	sh::big_free(F->d_rp);
@@ -1002,8 +1053,18 @@ void spasm_hip_dfact_hint_eliminations(spasm_hip_dfact *F, double per_row)
 
 void spasm_hip_dfact_forget(spasm_hip_dfact *F)
 {
-	if (F != nullptr)
+	if (F != nullptr) {
 		F->bs.valid = false;          // (the buffer stays: only the contents are forgotten)
+		F->sp.valid = false;
+	}
+}
+
+// fill of R as the sparse image holds it: out[0] entries, out[1] occupied 64-column tiles, out[2] non-empty
+// fragments, out[3] (row, segment) pairs.  Returns 1 when the factor holds a valid sparse image, else 0 (out zeroed).
+int spasm_hip_dfact_sparse_image_census(const spasm_hip_dfact *F, i64 *out, void *stream)
+{
+	sparse_image_census(F, out, (hipStream_t) stream);
+	return F->sp.valid ? 1 : 0;
 }
 
 int spasm_hip_dfact_rank(const spasm_hip_dfact *F) { return F->r; }
@@ -1055,6 +1116,8 @@ void spasm_hip_dwork_destroy(spasm_hip_dwork *W)
 		sh::big_free(W->d_lb_status);
 	if (W->d_stage != nullptr)
 		sh::big_free(W->d_stage);
+	if (W->d_spT != nullptr)
+		sh::big_free(W->d_spT);
 	if (W->d_order != nullptr)
 		sh::big_free(W->d_order);
 	if (W->d_sortbuf != nullptr)
@@ -1111,10 +1174,18 @@ int dschur_impl(const spasm_hip_dcsr *A, const int *d_rows, int nrows, const spa
 	int group_slots = 0, group_waves = 1;
 	i64 group_slot_bytes = 0, group_off_bm = 0;
 	// S = A_n - A_p R from the back-substituted image (backsolve.hip) when the factor has one: no accumulator scratch
-	const bool want_bs = nrows > 0 && Lout == nullptr &&
-	                     backsolve_wanted(F, env_int("SPASM_HIP_FORCE_TIER", 0) != 0 || env_int("SPASM_HIP_GROUP", -1) >= 0, nrows);
+	const bool other_forced = env_int("SPASM_HIP_FORCE_TIER", 0) != 0 || env_int("SPASM_HIP_GROUP", -1) >= 0;
+	// S = A_n - A_p R from the SPARSE image (sparse_image.hip) when the Schur complement is expected to stay sparse; the image
+	// is built on first use, and a build that finds R dense gives up: the other paths then take the batch
+	bool want_sp = nrows > 0 && Lout == nullptr && sparse_image_wanted(F, other_forced, nrows);
+	bool built_sp = false;
+	if (want_sp && !F->sp.valid) {
+		built_sp = sparse_image_build(F, stream);
+		want_sp = built_sp;
+	}
+	const bool want_bs = !want_sp && nrows > 0 && Lout == nullptr && backsolve_wanted(F, other_forced, nrows);
 	// per-wave dense scratch, (re)allocated when the factor geometry needs more
-	if (!want_bs) {
+	if (!want_bs && !want_sp) {
 		i64 slot_bytes, off_bm, off_xn;
 		wave_dense_geometry(F->rpad, F->Sm, wide_dense, &slot_bytes, &off_bm, &off_xn);
 		int slots = env_int("SPASM_HIP_WAVE_SLOTS", cus * 32);
@@ -1214,6 +1285,29 @@ int dschur_impl(const spasm_hip_dcsr *A, const int *d_rows, int nrows, const spa
 
 	bool used_bs = false, built_bs = false, bs_direct = false, use_pull = false;
 	int bs_staged_slices = 0;          // staged output of the back-substituted path: slices it ran in (0: not used)
+	if (want_sp) {
+		group_mode = 0;
+		HIP_CHECK(hipEventRecord(W->ev[5], stream));
+		a.list = nullptr;
+		a.list_count = nullptr;
+		a.done_ctr = CTR_DONE2;
+		bs_direct = true;          // rows land in W->d_Sj / d_Sx in their final order: no gather pass from the pool
+		const i64 twords = (i64) nrows * F->sp.nseg;
+		if (W->spT_words < twords) {
+			if (W->d_spT != nullptr)
+				sh::big_free(W->d_spT);
+			W->d_spT = dalloc<uint64_t>(twords);
+			W->spT_words = twords;
+		}
+		if (W->d_lb_status == nullptr)
+			W->d_lb_status = dalloc<unsigned long long>((i64) W->max_rows + 16 + 16 * 16);
+		// the fragments of S go to the row pool of the workspace (4 bytes an entry: pool_cap entries fit pool_j)
+		launch_sparse_image_apply(a, F, nullptr, 0, reinterpret_cast<uint32_t *>(W->d_pool_j), W->pool_cap, W->d_spT, W->d_lb_status, W->d_Sp, W->d_Sj,
+		                          W->d_Sx, W->pool_cap, stream, W->ev[6]);
+		HIP_CHECK(hipEventRecord(W->ev[3], stream));
+		HIP_CHECK(hipEventRecord(W->ev[4], stream));
+		goto eliminated;
+	}
 	if (want_bs) {
 		// R is built on first use
 		used_bs = true;
@@ -1431,7 +1525,36 @@ eliminated:
 		stats->kernel_expand[0] = 0;
 		stats->ms_expand = stats->ms_pad = 0.0f;
 		stats->bytes_expand = stats->bytes_staged = 0;
-		if (used_bs) {
+		stats->used_sparse_image = want_sp ? 1 : 0;
+		stats->sparse_image_built = built_sp ? 1 : 0;
+		stats->ms_sparse_build = stats->ms_sparse_apply = stats->ms_sparse_gather = 0.0f;
+		stats->sparse_image_nnz = stats->sparse_image_ops_build = stats->sparse_image_ops_apply = 0;
+		stats->sparse_image_levels = stats->sparse_image_launches = 0;
+		stats->bytes_sparse_build = stats->bytes_sparse_apply = stats->bytes_sparse_gather = 0;
+		if (want_sp) {
+			const SpImage &P = F->sp;
+			if (built_sp)
+				HIP_CHECK(hipEventElapsedTime(&stats->ms_sparse_build, P.ev0, P.ev1));
+			HIP_CHECK(hipEventElapsedTime(&stats->ms_sparse_apply, W->ev[5], W->ev[6]));
+			HIP_CHECK(hipEventElapsedTime(&stats->ms_sparse_gather, W->ev[6], W->ev[1]));
+			stats->sparse_image_nnz = P.nnz;
+			stats->sparse_image_ops_build = P.ops_build;
+			stats->sparse_image_ops_apply = (i64) ctr64[C64_STREAM];
+			stats->sparse_image_levels = P.nlevels;
+			stats->sparse_image_launches = P.launches;
+			// algorithmic bytes.  Build: every fragment entry read once per row that uses it and written
+			// once (4 B each), the fragment words (8 B per dependency and segment + 8 B per row and segment), the entries of U'.
+			// Rows of S: the fragment entries read (4 B), a fragment word per pivotal entry and segment, the entries in and the
+			// fragments of S out (4 B); gather: fragments in (4 B), pairs out (8 B), 8 B per (row, segment).
+			stats->bytes_sparse_build = 4 * (P.ops_build + P.nnz) + 8 * (P.ndeps + (i64) P.r) * P.nseg + 8 * F->nnz;
+			stats->bytes_sparse_apply = 4 * (i64) ctr64[C64_STREAM] + 8 * (i64) ctr64[C64_ELIM] * P.nseg + 8 * (i64) ctr64[C64_INPUT] + 4 * total +
+			                            8 * (i64) nrows * P.nseg;
+			stats->bytes_sparse_gather = 12 * total + 8 * (i64) nrows * P.nseg + 8 * (i64) nrows;
+			const bool build_dominates = stats->ms_sparse_build > stats->ms_sparse_apply;
+			snprintf(stats->kernel, sizeof(stats->kernel), "%s", build_dominates ? "sp_build_kernel" : "sp_apply_kernel");
+			snprintf(stats->kernel_other, sizeof(stats->kernel_other), "%s", build_dominates ? "sp_apply_kernel" : "sp_build_kernel");
+			snprintf(stats->kernel_expand, sizeof(stats->kernel_expand), "sp_gather_kernel");
+		} else if (used_bs) {
 			const BsImage &B = F->bs;
 			if (built_bs) {
 				HIP_CHECK(hipEventElapsedTime(&stats->ms_backsolve, B.ev0, B.ev1));
@@ -1467,7 +1590,7 @@ eliminated:
 		} else {
 			snprintf(stats->kernel, sizeof(stats->kernel), "schur_wave_dense_kernel<%s>", wide_dense ? "true" : "false");
 		}
-		if (nrows > 0 && !used_bs) {
+		if (nrows > 0 && !used_bs && !want_sp) {
 			if (group_mode)
 				HIP_CHECK(hipEventElapsedTime(&stats->ms_group, W->ev[0], W->ev[5]));
 			HIP_CHECK(hipEventElapsedTime(&stats->ms_tier0, group_mode ? W->ev[5] : W->ev[0], W->ev[3]));
@@ -1476,6 +1599,10 @@ eliminated:
 		}
 		HIP_CHECK(hipEventElapsedTime(&stats->ms_finalize, W->ev[1], W->ev[2]));
 		HIP_CHECK(hipEventElapsedTime(&stats->ms_total, W->ev[0], W->ev[2]));
+		if (built_sp) {          // (the sparse image is built before the events of the call start: its time belongs to the call)
+			stats->ms_total += stats->ms_sparse_build;
+			stats->ms_eliminate += stats->ms_sparse_build;
+		}
 	}
 	return status;
 }
@@ -1590,7 +1717,7 @@ struct spasm_csr *spasm_hip_schur(const struct spasm_csr *A, const int *p, int n
 		const int rc = dschur_impl(&dA, drows, n, F, W, stream, &st, (L != nullptr) ? &lout : nullptr);
 		if (rc == 0) {
 			// what the row-by-row kernels measured feeds the path choice of the next, larger batch on the same factor
-			if (!st.used_backsolve && n >= 64 && st.eliminations > 0)
+			if (!st.used_backsolve && !st.used_sparse_image && n >= 64 && st.eliminations > 0)
 				F->bs.elim_hint = (double) st.eliminations / (double) n;
 			break;
 		}

@@ -75,6 +75,14 @@ class DeviceFact:
         """drops derived state (the back-substituted rows): the next dschur pays for it again."""
         lib().spasm_hip_dfact_forget(self._h)
 
+    def sparse_image_census(self, stream=0):
+        """fill of R as the sparse image holds it, or None when the factor has no valid sparse image:
+        {entries, tiles64 (occupied 64-column tiles), fragments, pairs ((row, segment) pairs)}"""
+        out = (C.c_int64 * 4)()
+        if not lib().spasm_hip_dfact_sparse_image_census(self._h, out, stream):
+            return None
+        return {"entries": out[0], "tiles64": out[1], "fragments": out[2], "pairs": out[3]}
+
     def close(self):
         if self._h:
             lib().spasm_hip_dfact_destroy(self._h)

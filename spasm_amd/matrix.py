@@ -85,7 +85,11 @@ class CSchurStats(C.Structure):    # spasm_hip_schur_stats
                 ("bytes_backsolve", C.c_int64), ("bytes_apply", C.c_int64), ("kernel", C.c_char * 64),
                 ("kernel_other", C.c_char * 64), ("ms_expand", C.c_float), ("ms_pad", C.c_float), ("bytes_expand", C.c_int64),
                 ("bytes_staged", C.c_int64), ("kernel_expand", C.c_char * 64),
-                ("group_slots", C.c_int), ("group_slots_wanted", C.c_int), ("group_waves", C.c_int), ("group_slot_bytes", C.c_int64)]
+                ("group_slots", C.c_int), ("group_slots_wanted", C.c_int), ("group_waves", C.c_int), ("group_slot_bytes", C.c_int64),
+                ("used_sparse_image", C.c_int), ("sparse_image_built", C.c_int), ("ms_sparse_build", C.c_float), ("ms_sparse_apply", C.c_float),
+                ("ms_sparse_gather", C.c_float), ("sparse_image_levels", C.c_int), ("sparse_image_launches", C.c_int), ("sparse_image_pad", C.c_int),
+                ("sparse_image_nnz", C.c_int64), ("sparse_image_ops_build", C.c_int64), ("sparse_image_ops_apply", C.c_int64),
+                ("bytes_sparse_build", C.c_int64), ("bytes_sparse_apply", C.c_int64), ("bytes_sparse_gather", C.c_int64)]
 
 
 def field_of(prime):

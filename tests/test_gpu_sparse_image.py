@@ -1,0 +1,204 @@
+"""GPU parity of the SPARSE back-substituted image (spasm_amd/csrc/sparse_image.hip): S = A_n - A_p R with R = U_pp^-1 U_pn
+kept as sparse fragments must be the matrix spasm_schur computes (spasm_schur.c:64-193 -> spasm_triangular.c:110-146), bit
+for bit -- checked against the oracle (oracle/spasm_oracle.c, pinned on the compiled reference by tests/test_oracle.py).
+
+The shapes aim at the kernels' own seams: column counts around the 8,192-column segments, rows of U and of A with more
+than 64 entries (the batches of a wave), chains of one row per level (one launch each), wide levels, values at the bound of
+the signed 16-bit arithmetic (p = 44,927), a fragment pool that is extended in mid-build, an output pool that is too small."""
+import os
+
+import numpy as np
+import pytest
+
+from conftest import ALL_TEST_MATRICES, matrix_path
+
+import spasm_amd
+
+pytestmark = pytest.mark.gpu
+
+PRIMES = [3, 257, 42013, 44927]          # (the sparse image exists for p <= 44,927: signed 16-bit entries)
+
+
+def _as_product(A):
+    return spasm_amd.Csr(A.n, A.m, A.p, A.j, A.x, A.prime)
+
+
+def _fact(F):
+    return spasm_amd.Fact(_as_product(F.U), F.qinv)
+
+
+def _triangular_system(rng, p, npiv, nnon, nred, deps, reach, np_per_row, red_entries):
+    """npiv pivot rows (row k: pivot on column k, then `deps(k)` pivotal entries within `reach` columns to the right and
+    np_per_row entries on the nnon trailing non-pivotal columns), then nred rows to reduce."""
+    m = npiv + nnon
+    ti, tj, tx = [], [], []
+    for k in range(npiv):
+        cols = [k]
+        room = min(reach, npiv - k - 1)
+        d = min(deps(k), room)
+        if d > 0:
+            cols += list(k + 1 + rng.choice(room, size=d, replace=False))
+        if nnon > 0 and np_per_row > 0:
+            cols += list(npiv + rng.choice(nnon, size=min(np_per_row, nnon), replace=False))
+        ti += [k] * len(cols)
+        tj += [int(c) for c in cols]
+        tx += [1] + [int(v) for v in rng.integers(1, p, size=len(cols) - 1)]
+    for k in range(nred):
+        cols = rng.choice(m, size=min(red_entries, m), replace=False)
+        ti += [npiv + k] * len(cols)
+        tj += [int(c) for c in cols]
+        tx += [int(v) for v in rng.integers(1, p, size=len(cols))]
+    return npiv + nred, m, np.array(ti, np.int32), np.array(tj, np.int32), np.array(tx, np.int64)
+
+
+def _check(oracle, A, rows, F, want, p_out_want, p):
+    S, p_out = spasm_amd.schur(_as_product(A), rows, _fact(F))
+    assert np.array_equal(p_out, p_out_want)
+    assert oracle.same_matrix(oracle.CSR(S.n, S.m, S.p, S.j, S.x, p), want)
+    for i in range(S.n):
+        jj, _ = S.row(i)
+        assert np.all(np.diff(jj) > 0)
+    return S
+
+
+def _run(oracle, monkeypatch, p, n, m, ti, tj, tx, min_pivots, env=None):
+    monkeypatch.setenv("SPASM_HIP_SPARSE_IMAGE", "1")
+    for k, v in (env or {}).items():
+        monkeypatch.setenv(k, v)
+    A = oracle.compress(p, n, m, ti, tj, tx)
+    npiv, perm, F = oracle.pivots_extract_structural(A, oracle.empty_fact(A.n, A.m, p))
+    assert npiv >= min_pivots
+    rows = perm[npiv:]
+    want, p_out_want, _ = oracle.schur(A, rows, F)
+    _check(oracle, A, rows, F, want, p_out_want, p)
+    return A, rows, F, want
+
+
+def _stats_of_device_call(A, rows, F, pool):
+    import torch
+    dA = spasm_amd.DeviceCsr.from_host(_as_product(A))
+    dF = spasm_amd.DeviceFact(_fact(F))
+    drows = torch.from_numpy(np.ascontiguousarray(rows, np.int32)).cuda()
+    W = spasm_amd.SchurWorkspace(len(rows), A.m, pool)
+    S, st = spasm_amd.dschur(dA, drows, dF, W, fetch=True)
+    return S, st, W, dF, dA, drows
+
+
+@pytest.mark.parametrize("p", PRIMES)
+@pytest.mark.parametrize("name", ALL_TEST_MATRICES)
+def test_sparse_image_on_the_reference_matrices(oracle, monkeypatch, name, p):
+    """the reference's own 32 test matrices (tests/CMakeLists.txt:75-110): pivots by the oracle, every non-pivotal row reduced"""
+    monkeypatch.setenv("SPASM_HIP_SPARSE_IMAGE", "1")
+    A = oracle.load_sms(matrix_path(name), p)
+    npiv, perm, F = oracle.pivots_extract_structural(A, oracle.empty_fact(A.n, A.m, p))
+    rows = perm[npiv:]
+    if len(rows) == 0 or npiv == 0:
+        pytest.skip("nothing to reduce")
+    want, p_out_want, _ = oracle.schur(A, rows, F)
+    _check(oracle, A, rows, F, want, p_out_want, p)
+
+
+@pytest.mark.parametrize("p", PRIMES)
+@pytest.mark.parametrize("nnon", [1, 63, 8191, 8192, 8193, 16385, 20011])
+def test_sparse_image_column_counts(oracle, monkeypatch, p, nnon):
+    rng = np.random.default_rng(nnon)
+    sysm = _triangular_system(rng, p, npiv=500, nnon=nnon, nred=300, deps=lambda k: 2, reach=40, np_per_row=3, red_entries=5)
+    _run(oracle, monkeypatch, p, *sysm, min_pivots=400)
+
+
+@pytest.mark.parametrize("p", [257, 42013])
+def test_sparse_image_chain_of_single_row_levels(oracle, monkeypatch, p):
+    """one dependency on the next row: 1500 levels of one row each, one launch per level"""
+    rng = np.random.default_rng(5)
+    sysm = _triangular_system(rng, p, npiv=1500, nnon=9000, nred=400, deps=lambda k: 1, reach=1, np_per_row=2, red_entries=4)
+    _run(oracle, monkeypatch, p, *sysm, min_pivots=1200)
+
+
+@pytest.mark.parametrize("p", PRIMES[1:])
+@pytest.mark.parametrize("ndeps,reach", [(3, 3000), (40, 3000), (150, 800)])
+def test_sparse_image_many_dependencies(oracle, monkeypatch, p, ndeps, reach):
+    """rows of U with more pivotal entries than a wave has lanes (batches of 64), rows that fill up"""
+    rng = np.random.default_rng(ndeps + reach)
+    sysm = _triangular_system(rng, p, npiv=3000, nnon=300, nred=500, deps=lambda k: ndeps, reach=reach, np_per_row=4, red_entries=6)
+    _run(oracle, monkeypatch, p, *sysm, min_pivots=1500)
+
+
+@pytest.mark.parametrize("p", [257, 42013])
+def test_sparse_image_long_input_rows(oracle, monkeypatch, p):
+    """rows of A with 300 entries (what the second round of a flow sees): five batches of 64 per row and segment"""
+    rng = np.random.default_rng(11)
+    sysm = _triangular_system(rng, p, npiv=2000, nnon=9000, nred=300, deps=lambda k: 3, reach=500, np_per_row=6, red_entries=300)
+    _run(oracle, monkeypatch, p, *sysm, min_pivots=1500)
+
+
+def test_sparse_image_wide_levels(oracle, monkeypatch):
+    p = 42013
+    rng = np.random.default_rng(8)
+    sysm = _triangular_system(rng, p, npiv=4000, nnon=12000, nred=600, deps=lambda k: 1 if k % 7 == 0 else 0, reach=3000,
+                              np_per_row=5, red_entries=8)
+    _run(oracle, monkeypatch, p, *sysm, min_pivots=3000)
+
+
+@pytest.mark.parametrize("p", [42013, 44927])
+def test_sparse_image_extreme_values(oracle, monkeypatch, p):
+    """every entry is (p - 1) / 2 or (p + 1) / 2: accumulator + product as close to 2^31 as the data can push it"""
+    rng = np.random.default_rng(77)
+    n, m, ti, tj, tx = _triangular_system(rng, p, npiv=1500, nnon=70, nred=400, deps=lambda k: 4, reach=30, np_per_row=3, red_entries=8)
+    tx = np.where(tx == 1, 1, np.where(rng.integers(0, 2, size=len(tx)) == 0, (p - 1) // 2, (p + 1) // 2)).astype(np.int64)
+    _run(oracle, monkeypatch, p, n, m, ti, tj, tx, min_pivots=1000)
+
+
+@pytest.mark.parametrize("chunk", [1024, 4096, 65536])
+def test_sparse_image_pool_extended_in_mid_build(oracle, monkeypatch, chunk):
+    """a first chunk far too small: the build runs out of room in some level, takes the next chunk (twice the size) and redoes
+    the levels from there -- the fragments end up spread over several chunks, S is the same"""
+    p = 42013
+    rng = np.random.default_rng(chunk)
+    sysm = _triangular_system(rng, p, npiv=3000, nnon=9000, nred=500, deps=lambda k: 3, reach=200, np_per_row=4, red_entries=6)
+    _run(oracle, monkeypatch, p, *sysm, min_pivots=2000, env={"SPASM_HIP_SPARSE_IMAGE_CHUNK": str(chunk), "SPASM_HIP_SPARSE_IMAGE_GB": "1"})
+
+
+def test_sparse_image_device_call_statistics_rebuild_and_small_pool(oracle, monkeypatch):
+    """the device-level call: the statistics say which path ran; an output pool that is too small is reported (status 1) and a
+    larger one succeeds; forgetting the image and building it again (what bench.py does every step) gives the same S; a second
+    batch on the same factor reuses R"""
+    import torch
+    monkeypatch.setenv("SPASM_HIP_SPARSE_IMAGE", "1")
+    p = 42013
+    rng = np.random.default_rng(3)
+    n, m, ti, tj, tx = _triangular_system(rng, p, npiv=3000, nnon=9000, nred=800, deps=lambda k: 3, reach=300, np_per_row=4, red_entries=6)
+    A = oracle.compress(p, n, m, ti, tj, tx)
+    npiv, perm, F = oracle.pivots_extract_structural(A, oracle.empty_fact(A.n, A.m, p))
+    rows = perm[npiv:]
+    want, _, _ = oracle.schur(A, rows, F)
+    S, st, W, dF, dA, drows = _stats_of_device_call(A, rows, F, 64)
+    assert st.status == 1 and st.used_sparse_image == 1
+    W.close()
+    W = spasm_amd.SchurWorkspace(len(rows), A.m, want.nnz + 100)
+    S, st = spasm_amd.dschur(dA, drows, dF, W, fetch=True)
+    assert st.status == 0 and st.used_sparse_image == 1 and st.sparse_image_built == 0 and st.nnz == want.nnz
+    assert st.sparse_image_nnz > 0 and st.sparse_image_levels > 1
+    H = S.to_host()
+    assert oracle.same_matrix(oracle.CSR(H.n, H.m, H.p, H.j, H.x, p), want)
+    dF.forget()
+    S2, st2 = spasm_amd.dschur(dA, drows, dF, W, fetch=True)
+    assert st2.status == 0 and st2.sparse_image_built == 1 and st2.sparse_image_nnz == st.sparse_image_nnz
+    assert torch.equal(S2.p, S.p) and torch.equal(S2.j, S.j) and torch.equal(S2.x, S.x)
+    # a sub-batch, R being there
+    assert len(rows) >= 60
+    sub = drows[10:50].contiguous()
+    S3, st3 = spasm_amd.dschur(dA, sub, dF, W, fetch=True)
+    assert st3.status == 0 and st3.used_sparse_image == 1 and st3.sparse_image_built == 0
+    H3 = S3.to_host()
+    want3, _, _ = oracle.schur(A, rows[10:50], F)
+    assert oracle.same_matrix(oracle.CSR(H3.n, H3.m, H3.p, H3.j, H3.x, p), want3)
+    W.close()
+    dF.close()
+
+
+@pytest.mark.parametrize("p", [65521, 4294967291])
+def test_primes_beyond_the_signed_arithmetic_take_the_other_paths(oracle, monkeypatch, p):
+    """the sparse image only exists for p <= 44,927; asking for it on a larger prime must leave the result right"""
+    rng = np.random.default_rng(21)
+    sysm = _triangular_system(rng, p, npiv=800, nnon=300, nred=200, deps=lambda k: 2, reach=40, np_per_row=3, red_entries=5)
+    _run(oracle, monkeypatch, p, *sysm, min_pivots=600)
