@@ -172,7 +172,10 @@ struct BsImage {
 // (column inside the segment | signed 16-bit value << 16) -- in a bump-allocated pool; frag[c * nseg + g] says where the
 // fragment of row c (compact id) in segment g lies and how long it is.  Bytes and work scale with the fill of R, not with
 // r x Sm, and there is no limit on Sm.
-constexpr int SP_SEG = 8192;            // columns per segment: 16 KB of 16-bit accumulators per wave
+#ifndef SPASM_SP_SEG
+#define SPASM_SP_SEG 4096
+#endif
+constexpr int SP_SEG = SPASM_SP_SEG;    // columns per segment: 16 KB of 16-bit accumulators per wave (4,096: 8 KB)
 constexpr int SP_LEN_BITS = 14;         // a fragment holds at most SP_SEG entries
 constexpr int SP_OFF_BITS = 40;         // offset inside a pool chunk (entries)
 constexpr int SP_MAX_CHUNKS = 12;

@@ -1,3 +1,10 @@
+// Should this batch go through the SPARSE image (sparse_image.hip)?  It is made for Schur complements that stay sparse on
+// many columns: R is then mostly zeros, and both the build and the rows of S cost what R and S hold, not r x Sm.
+// SPASM_HIP_SPARSE_IMAGE=0 never, =1 whenever the factor has the plan (tests); else: full batches (>= 1,024 rows) whose
+// expected density is under 12 % (the driver's estimate; unknown: 3 % assumed beyond 16,384 non-pivotal columns), when
+//   build (if R is not there)   8 us per elimination level (the chain of hand-overs: measured 8.0 on mk14.b4, 2,000 levels)
+//   rows of S + gather          27 ps per expected entry of S + 3 ns per row + 0.5 ms      (mk14.b4: 6.4e8 entries in 20 ms)
+// is less than what the cost model of backsolve_wanted gives the dense image and the row-by-row kernels.
 // Launchers and C ABI of the sparse Schur complement (see include/spasm_hip.h).
 #include <algorithm>
 #include <unordered_map>
@@ -585,7 +592,7 @@ bool sparse_image_wanted(const spasm_hip_dfact *F, bool other_path_forced, int n
 	const double elim_per_row = (B.elim_hint >= 0.0) ? B.elim_hint : 0.05 * r;
 	const double t_rows = 0.3e-3 + 27e-12 * elim_per_row * n;
 	const double t_other = B.planned ? std::min(t_dense, t_rows) : t_rows;
-	const double t_sparse = 10e-6 * (double) S.nlevels + 6e-9 * n * (double) S.nseg + 16.0 * density * n * Sm / 3e12 + 0.5e-3;
+	const double t_sparse = 8e-6 * (double) S.nlevels + 27e-12 * density * n * Sm + 3e-9 * n + 0.5e-3;
 	return t_sparse < t_other;
 }
 }  // namespace sh

@@ -62,6 +62,17 @@ __device__ __forceinline__ const uint32_t *frag_ptr(const SpPools &P, uint64_t f
 	return P.base[(f >> (SP_LEN_BITS + SP_OFF_BITS)) & 15u] + ((f >> SP_LEN_BITS) & OFF_MASK);
 }
 
+// A value every lane holds alike, told to the compiler: branches on it are scalar branches.  (Without this the loop
+// of the single-launch driver -- whose exits hang on values loaded per lane from uniform addresses -- was compiled into
+// exec-masked loops in which lane 0, the lane that publishes, left on its own: tasks were redone for ever and nothing was
+// published.  Wave-uniform control flow must be visibly uniform.)
+__device__ __forceinline__ uint64_t sp_uniform(uint64_t v)
+{
+	const uint32_t lo = (uint32_t) __builtin_amdgcn_readfirstlane((int) (uint32_t) v);
+	const uint32_t hi = (uint32_t) __builtin_amdgcn_readfirstlane((int) (uint32_t) (v >> 32));
+	return ((uint64_t) hi << 32) | lo;
+}
+
 __device__ __forceinline__ uint64_t readlane64(uint64_t v, int src)
 {
 	const uint32_t lo = (uint32_t) __builtin_amdgcn_readlane((int) (uint32_t) v, src);
@@ -69,27 +80,164 @@ __device__ __forceinline__ uint64_t readlane64(uint64_t v, int src)
 	return ((uint64_t) hi << 32) | lo;
 }
 
-__device__ __forceinline__ void sp_zero(uint32_t *accw, int lane)
+// ---- operations of lane 0 that leave no divergent branch behind --------------------------------------
+// `if (lane == 0) store(...)` at the end of a loop body is a divergent branch whose join is the loop header; the compiler
+// (ROCm 7.2, structurizer) has turned that into a loop nest in which lane 0 leaves first and the other 63 lanes go round
+// again -- with readfirstlane / ballots that then see a wave without lane 0: the single-launch build re-ran its task for
+// ever and never published (found with the watchdog below: one ticket drawn per wave, every fragment pending).  So lane 0's
+// stores and atomics are single instructions under a temporary exec mask: the control flow stays uniform.  All 64 lanes
+// are active wherever these are called.
+__device__ __forceinline__ void l0_store_u64(uint64_t *p, uint64_t v)
 {
-	uint4 *a4 = reinterpret_cast<uint4 *>(accw);
+	uint64_t saved;
+	asm volatile("s_mov_b64 %0, exec\n\ts_mov_b64 exec, 1\n\tglobal_store_dwordx2 %1, %2, off\n\ts_mov_b64 exec, %0" : "=&s"(saved) : "v"(p), "v"(v) : "memory");
+}
+
+__device__ __forceinline__ void l0_store_u64_sc1(uint64_t *p, uint64_t v)
+{
+	uint64_t saved;
+	asm volatile("s_mov_b64 %0, exec\n\ts_mov_b64 exec, 1\n\tglobal_store_dwordx2 %1, %2, off sc1\n\ts_mov_b64 exec, %0" : "=&s"(saved) : "v"(p), "v"(v) : "memory");
+}
+
+__device__ __forceinline__ void l0_store_i32(int *p, int v)
+{
+	uint64_t saved;
+	asm volatile("s_mov_b64 %0, exec\n\ts_mov_b64 exec, 1\n\tglobal_store_dword %1, %2, off\n\ts_mov_b64 exec, %0" : "=&s"(saved) : "v"(p), "v"(v) : "memory");
+}
+
+__device__ __forceinline__ void l0_store_i32_sc1(int *p, int v)
+{
+	uint64_t saved;
+	asm volatile("s_mov_b64 %0, exec\n\ts_mov_b64 exec, 1\n\tglobal_store_dword %1, %2, off sc1\n\ts_mov_b64 exec, %0" : "=&s"(saved) : "v"(p), "v"(v) : "memory");
+}
+
+__device__ __forceinline__ void l0_atomic_add_u64(unsigned long long *p, unsigned long long v)
+{
+	uint64_t saved;
+	asm volatile("s_mov_b64 %0, exec\n\ts_mov_b64 exec, 1\n\tglobal_atomic_add_x2 %1, %2, off\n\ts_mov_b64 exec, %0" : "=&s"(saved) : "v"(p), "v"(v) : "memory");
+}
+
+__device__ __forceinline__ void l0_atomic_smax_i32(int *p, int v)
+{
+	uint64_t saved;
+	asm volatile("s_mov_b64 %0, exec\n\ts_mov_b64 exec, 1\n\tglobal_atomic_smax %1, %2, off\n\ts_mov_b64 exec, %0" : "=&s"(saved) : "v"(p), "v"(v) : "memory");
+}
+
+// returning forms: the value lane 0 got, in every lane
+__device__ __forceinline__ int l0_atomic_add_i32_ret(int *p, int v)
+{
+	uint64_t saved;
+	int r;
+	asm volatile("s_mov_b64 %0, exec\n\ts_mov_b64 exec, 1\n\tglobal_atomic_add %1, %2, %3, off sc0\n\ts_waitcnt vmcnt(0)\n\ts_mov_b64 exec, %0"
+	             : "=&s"(saved), "=&v"(r)
+	             : "v"(p), "v"(v)
+	             : "memory");
+	return __builtin_amdgcn_readfirstlane(r);
+}
+
+__device__ __forceinline__ unsigned long long l0_atomic_add_u64_ret(unsigned long long *p, unsigned long long v)
+{
+	uint64_t saved;
+	unsigned long long r;
+	asm volatile("s_mov_b64 %0, exec\n\ts_mov_b64 exec, 1\n\tglobal_atomic_add_x2 %1, %2, %3, off sc0\n\ts_waitcnt vmcnt(0)\n\ts_mov_b64 exec, %0"
+	             : "=&s"(saved), "=&v"(r)
+	             : "v"(p), "v"(v)
+	             : "memory");
+	return sp_uniform(r);
+}
+
+// SPASM_HIP_SPARSE_IMAGE_PROFILE=1: shader-clock cycles per stage, summed over the waves (the kernels take a null pointer otherwise)
+struct SpStamp {
+	unsigned long long *out;
+	unsigned long long last;
+	unsigned long long acc[8];
+	__device__ __forceinline__ void begin(unsigned long long *p)
+	{
+		out = p;
+		for (int q = 0; q < 8; q++)
+			acc[q] = 0;
+		last = (p != nullptr) ? __builtin_amdgcn_s_memtime() : 0;
+	}
+	__device__ __forceinline__ void mark(int slot)
+	{
+		if (out != nullptr) {
+			const unsigned long long t = __builtin_amdgcn_s_memtime();
+			acc[slot] += t - last;
+			last = t;
+		}
+	}
+	__device__ __forceinline__ void flush(int lane)
+	{
+		if (out != nullptr && lane == 0)
+			for (int q = 0; q < 8; q++)
+				atomicAdd(&out[q], acc[q]);
+	}
+};
+
+// ---- a wave's LDS: the accumulators of one segment + one bit per column that was touched ----------
+// Columns are stored SWIZZLED: the emit pass gives lane L the columns [128 L, 128 L + 128) (so that what the lanes write,
+// lane after lane, is sorted by column), and unswizzled those 64 chunks of 256 bytes would all start on the same bank; word
+// w = column / 2 of chunk L = w / 64 lives at position (w + L) mod 64 of its chunk.
+constexpr int BMW = SP_SEG / 32;          // bitmap words
+constexpr int WPL = BMW / 64;             // bitmap words per lane (2 or 4)
+constexpr int CW = SEGW / 64;             // accumulator words of the columns one lane owns in the lane-by-lane walk
+static_assert(WPL == 2 || WPL == 4, "segments of 4,096 or 8,192 columns");
+constexpr int LISTCAP = 1024;             // touched columns a segment may have for the balanced emit (more: the lane-by-lane one)
+struct __attribute__((aligned(16))) WaveLds {
+	uint32_t acc[SEGW];
+	uint32_t bm[BMW];
+	uint16_t list[LISTCAP];
+};
+
+__device__ __forceinline__ uint32_t sp_swz(uint32_t c)          // column of the segment -> index of its 16-bit accumulator
+{
+	const uint32_t w = c >> 1;
+	return ((((w & ~(uint32_t) (CW - 1)) | ((w + (w / CW)) & (uint32_t) (CW - 1))) << 1) | (c & 1u));
+}
+
+__device__ __forceinline__ void sp_lds_init(WaveLds &L, int lane)
+{
+	uint4 *a4 = reinterpret_cast<uint4 *>(L.acc);
 #pragma unroll
 	for (int t = 0; t < SEGW / 4 / 64; t++)
 		a4[t * 64 + lane] = uint4{0u, 0u, 0u, 0u};
+	for (int t = lane; t < BMW; t += 64)
+		L.bm[t] = 0;
 }
 
-// acc[column] += coef * value for one entry (column | value << 16); the sum is reduced at once
-__device__ __forceinline__ void sp_entry(short *acc, uint32_t e, int coef, const SgnDev &G)
+template <bool SC1> __device__ __forceinline__ uint32_t sp_ld(const uint32_t *p)
 {
-	short *a = acc + (e & 0xFFFFu);
+	if constexpr (SC1)
+		return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);          // (global_load_dword sc1: not from this CU's L1)
+	else
+		return *p;
+}
+
+template <bool SC1> __device__ __forceinline__ void sp_st(uint32_t *p, uint32_t v)
+{
+	if constexpr (SC1)
+		__hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);             // (write-through)
+	else
+		*p = v;
+}
+
+// acc[column] += coef * value for one entry (column | value << 16); the sum is reduced at once; the column is marked
+__device__ __forceinline__ void sp_entry(WaveLds &L, uint32_t e, int coef, const SgnDev &G)
+{
+	const uint32_t c = e & 0xFFFFu;
+	short *a = reinterpret_cast<short *>(L.acc) + sp_swz(c);
 	int t = (int) *a;
 	asm("v_mad_i32_i16 %0, %1, %2, %0 op_sel:[1,0,0,0]" : "+v"(t) : "v"(e), "v"(coef));
 	*a = (short) sgn_reduce(t, G);
+	atomicOr(&L.bm[c >> 5], 1u << (c & 31u));
 }
 
 // four entries of ONE fragment (distinct columns): the four reads are in flight together
-__device__ __forceinline__ void sp_entry4(short *acc, uint32_t e0, uint32_t e1, uint32_t e2, uint32_t e3, int coef, const SgnDev &G)
+__device__ __forceinline__ void sp_entry4(WaveLds &L, uint32_t e0, uint32_t e1, uint32_t e2, uint32_t e3, int coef, const SgnDev &G)
 {
-	short *a0 = acc + (e0 & 0xFFFFu), *a1 = acc + (e1 & 0xFFFFu), *a2 = acc + (e2 & 0xFFFFu), *a3 = acc + (e3 & 0xFFFFu);
+	short *acc = reinterpret_cast<short *>(L.acc);
+	const uint32_t c0 = e0 & 0xFFFFu, c1 = e1 & 0xFFFFu, c2 = e2 & 0xFFFFu, c3 = e3 & 0xFFFFu;
+	short *a0 = acc + sp_swz(c0), *a1 = acc + sp_swz(c1), *a2 = acc + sp_swz(c2), *a3 = acc + sp_swz(c3);
 	int t0 = (int) *a0, t1 = (int) *a1, t2 = (int) *a2, t3 = (int) *a3;
 	asm("v_mad_i32_i16 %0, %1, %2, %0 op_sel:[1,0,0,0]" : "+v"(t0) : "v"(e0), "v"(coef));
 	asm("v_mad_i32_i16 %0, %1, %2, %0 op_sel:[1,0,0,0]" : "+v"(t1) : "v"(e1), "v"(coef));
@@ -99,101 +247,279 @@ __device__ __forceinline__ void sp_entry4(short *acc, uint32_t e0, uint32_t e1, 
 	*a1 = (short) sgn_reduce(t1, G);
 	*a2 = (short) sgn_reduce(t2, G);
 	*a3 = (short) sgn_reduce(t3, G);
+	atomicOr(&L.bm[c0 >> 5], 1u << (c0 & 31u));
+	atomicOr(&L.bm[c1 >> 5], 1u << (c1 & 31u));
+	atomicOr(&L.bm[c2 >> 5], 1u << (c2 & 31u));
+	atomicOr(&L.bm[c3 >> 5], 1u << (c3 & 31u));
 }
 
-// acc += coef * fragment, for every lane whose fragment word f is not empty (wave-uniform loop over those lanes).  The
-// first 64 entries of the next fragment are in flight while the current one is added.
-__device__ __forceinline__ void sp_accumulate(short *acc, uint64_t f, int coef, const SpPools &pools, int lane, const SgnDev &G,
+// acc[column] += value (an entry of the row itself); value in [-p/2, p/2]
+__device__ __forceinline__ void sp_own_entry(WaveLds &L, uint32_t c, int val, const SgnDev &G)
+{
+	short *a = reinterpret_cast<short *>(L.acc) + sp_swz(c);
+	*a = (short) sgn_canonical((int) *a + val, G);
+	atomicOr(&L.bm[c >> 5], 1u << (c & 31u));
+}
+
+// acc += coef * fragment, for every lane whose fragment word f is not empty and for which `take` holds (wave-uniform loop
+// over those lanes).  Four fragments at a time: the first 64 entries of all four are in flight together (a reduced row
+// combines 3-5 rows of R per segment, each 1-3 batches long: the stage is the latency of these loads).
+template <bool SC1>
+__device__ __forceinline__ void sp_accumulate(WaveLds &L, uint64_t f, int coef, bool take, const SpPools &pools, int lane, const SgnDev &G,
                                               unsigned long long &ops)
 {
-	uint64_t live = __ballot((f & LEN_MASK) != 0);
-	if (live == 0)
+	uint64_t live = __ballot(take && (f & LEN_MASK) != 0);
+	while (live != 0) {
+		const uint32_t *src[4];
+		int len[4], cf[4];
+		uint32_t head[4];
+#pragma unroll
+		for (int u = 0; u < 4; u++) {
+			len[u] = 0;
+			cf[u] = 0;
+			src[u] = nullptr;
+			head[u] = 0;
+			if (live != 0) {
+				const int s = __builtin_ctzll(live);
+				live &= live - 1;
+				const uint64_t fc = readlane64(f, s);
+				cf[u] = __builtin_amdgcn_readlane(coef, s);
+				src[u] = frag_ptr(pools, fc);
+				len[u] = (int) (fc & LEN_MASK);
+				head[u] = (lane < len[u]) ? sp_ld<SC1>(src[u] + lane) : 0u;
+			}
+		}
+#pragma unroll
+		for (int u = 0; u < 4; u++) {
+			if (len[u] == 0)
+				continue;
+			ops += (unsigned long long) len[u];
+			if (lane < len[u])
+				sp_entry(L, head[u], cf[u], G);
+			int i = lane + 64;
+			for (; i + 192 < len[u]; i += 256) {
+				const uint32_t a0 = sp_ld<SC1>(src[u] + i), a1 = sp_ld<SC1>(src[u] + i + 64), a2 = sp_ld<SC1>(src[u] + i + 128),
+				               a3 = sp_ld<SC1>(src[u] + i + 192);
+				sp_entry4(L, a0, a1, a2, a3, cf[u], G);
+			}
+			for (; i < len[u]; i += 64)
+				sp_entry(L, sp_ld<SC1>(src[u] + i), cf[u], G);
+		}
+	}
+}
+
+// inclusive prefix sum over the 64 lanes (DPP: shifts inside the rows of 16 lanes, then the row totals handed on)
+__device__ __forceinline__ int wave_incl_scan(int x)
+{
+	x += __builtin_amdgcn_update_dpp(0, x, 0x111, 0xf, 0xf, false);          // row_shr:1
+	x += __builtin_amdgcn_update_dpp(0, x, 0x112, 0xf, 0xf, false);          // row_shr:2
+	x += __builtin_amdgcn_update_dpp(0, x, 0x114, 0xf, 0xf, false);          // row_shr:4
+	x += __builtin_amdgcn_update_dpp(0, x, 0x118, 0xf, 0xf, false);          // row_shr:8
+	x += __builtin_amdgcn_update_dpp(0, x, 0x142, 0xa, 0xf, false);          // row_bcast:15 into rows 1 and 3
+	x += __builtin_amdgcn_update_dpp(0, x, 0x143, 0xc, 0xf, false);          // row_bcast:31 into rows 2 and 3
+	return x;
+}
+
+// What a segment has touched, ready to be emitted.  The fill of these matrices is CLUSTERED (mk14.b4: 1.9 % of R's entries
+// but 16 % of its 64-column tiles): a lane that owns 128 consecutive columns walks 40-60 of them while most lanes walk none
+// (the emit pass was 52 % of sp_apply_kernel that way).  So: lane L takes the bitmap words L, L + 64, L + 128, L + 192
+// (a cluster of 128 columns is spread over four lanes), one packed scan gives every word its place in column order, the
+// lanes list their columns in LDS (a cheap loop), and the entries themselves are produced 64 at a time from the list,
+// whoever touched them.  Segments with more than LISTCAP touched columns (dense fragments: balanced by themselves) keep
+// the lane-by-lane walk.
+struct SpTouched {
+	int ub;                       // touched columns: an upper bound of the entries (a sum that came back to zero gives none)
+	bool listed;                  // their columns stand in L.list[0 .. ub), sorted
+	uint64_t lo64, hi64;          // else: the bits of the lane's 128 consecutive columns ...
+	uint32_t prefix;              // ... and the touched columns before them
+};
+
+__device__ __forceinline__ void sp_touched(WaveLds &L, int lane, SpTouched &T)
+{
+	const uint32_t w0 = L.bm[lane], w1 = L.bm[64 + lane], w2 = (WPL > 2) ? L.bm[(128 + lane) % BMW] : 0u, w3 = (WPL > 2) ? L.bm[(192 + lane) % BMW] : 0u;
+	const int c0 = __popc(w0), c1 = __popc(w1), c2 = __popc(w2), c3 = __popc(w3);
+	const int ia = wave_incl_scan(c0 | (c1 << 16)), ib = wave_incl_scan(c2 | (c3 << 16));          // (a field holds at most 64 * 32)
+	const int ta = __builtin_amdgcn_readlane(ia, 63), tb = __builtin_amdgcn_readlane(ib, 63);
+	const int t0 = ta & 0xFFFF, t1 = ta >> 16, t2 = tb & 0xFFFF, t3 = tb >> 16;
+	T.ub = t0 + t1 + t2 + t3;
+	T.listed = T.ub <= LISTCAP;
+	T.lo64 = T.hi64 = 0;
+	T.prefix = 0;
+	if (T.listed) {
+		L.bm[lane] = 0;
+		L.bm[64 + lane] = 0;
+		if (WPL > 2) {
+			L.bm[(128 + lane) % BMW] = 0;
+			L.bm[(192 + lane) % BMW] = 0;
+		}
+		// where the columns of word j go, minus the columns this lane lists before them
+		const int adj0 = (ia & 0xFFFF) - c0;
+		const int adj1 = t0 + (ia >> 16) - c1 - c0;
+		const int adj2 = t0 + t1 + (ib & 0xFFFF) - c2 - (c0 + c1);
+		const int adj3 = t0 + t1 + t2 + (ib >> 16) - c3 - (c0 + c1 + c2);
+		uint64_t lo = ((uint64_t) w1 << 32) | w0, hi = ((uint64_t) w3 << 32) | w2;
+		int n = 0;
+		while (__ballot((lo | hi) != 0) != 0) {
+			if ((lo | hi) != 0) {
+				int b;
+				if (lo != 0) {
+					b = __builtin_ctzll(lo);
+					lo &= lo - 1;
+				} else {
+					b = 64 + __builtin_ctzll(hi);
+					hi &= hi - 1;
+				}
+				const int j = b >> 5;
+				const int adj = (j == 0) ? adj0 : (j == 1) ? adj1 : (j == 2) ? adj2 : adj3;
+				L.list[adj + n] = (uint16_t) ((((uint32_t) j * 64u + (uint32_t) lane) << 5) | ((uint32_t) b & 31u));
+				n += 1;
+			}
+		}
 		return;
-	int s = __builtin_ctzll(live);
-	live &= live - 1;
-	uint64_t fc = readlane64(f, s);
-	int cc = __builtin_amdgcn_readlane(coef, s);
-	const uint32_t *src = frag_ptr(pools, fc);
-	int len = (int) (fc & LEN_MASK);
-	uint32_t e0 = (lane < len) ? src[lane] : 0u;
-	for (;;) {
-		// the next fragment's head
-		const bool more = live != 0;
-		uint64_t fn = 0;
-		int cn = 0, lenn = 0;
-		const uint32_t *srcn = src;
-		uint32_t en = 0;
-		if (more) {
-			s = __builtin_ctzll(live);
-			live &= live - 1;
-			fn = readlane64(f, s);
-			cn = __builtin_amdgcn_readlane(coef, s);
-			srcn = frag_ptr(pools, fn);
-			lenn = (int) (fn & LEN_MASK);
-			en = (lane < lenn) ? srcn[lane] : 0u;
+	}
+	// many columns: lane L owns the columns [32 WPL L, 32 WPL (L + 1))
+	uint32_t bw[4] = {0u, 0u, 0u, 0u};
+#pragma unroll
+	for (int t = 0; t < WPL; t++) {
+		bw[t] = L.bm[WPL * lane + t];
+		L.bm[WPL * lane + t] = 0;
+	}
+	T.lo64 = ((uint64_t) bw[1] << 32) | bw[0];
+	T.hi64 = ((uint64_t) bw[3] << 32) | bw[2];
+	const int mine = __popcll(T.lo64) + __popcll(T.hi64);
+	T.prefix = (uint32_t) (wave_incl_scan(mine) - mine);
+}
+
+// in-place compaction of out[0 .. ub) (zero words = columns whose sum came back to zero); returns what is left
+__device__ __forceinline__ int sp_compact(uint32_t *out, int ub, int lane)
+{
+	asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // (the words are read back, past the L1)
+	uint32_t w = 0;
+	for (int i0 = 0; i0 < ub; i0 += 64) {
+		const uint32_t e = (i0 + lane < ub) ? sp_ld<true>(out + i0 + lane) : 0u;
+		const uint64_t m = __ballot(e != 0);
+		const uint32_t dst = __builtin_amdgcn_mbcnt_hi((uint32_t) (m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t) m, w));
+		if (e != 0)
+			sp_st<true>(out + dst, e);
+		w += (uint32_t) __popcll(m);
+	}
+	return (int) w;
+}
+
+// The touched columns as (column | value << 16) entries at out[0 .. ub), sorted by column; their accumulators go back to
+// zero.  A column whose sum is zero leaves a zero word, and when there was one (rare: a cancellation mod p) the words are
+// compacted in place afterwards.  Returns the number of entries.
+// CANON: values brought into [-p/2, p/2].  SC1: write-through stores (the fragment is read by other CUs in this launch).
+template <bool CANON, bool SC1>
+__device__ __forceinline__ int sp_emit(WaveLds &L, const SpTouched &T, uint32_t *out, int lane, const SgnDev &G)
+{
+	short *acc = reinterpret_cast<short *>(L.acc);
+	const int ub = T.ub;
+	int holes = 0;
+	if (T.listed) {
+		// 64 columns of the list at a time (two such batches in flight): the non-zero ones are written one behind the other --
+		// sums that came back to zero are common in these matrices (boundary maps: the products cancel), and leave no holes
+		uint32_t w = 0;
+		for (int i0 = 0; i0 < ub; i0 += 128) {          // (a uniform loop: the lanes past the end idle)
+			const int i = i0 + lane;
+			const bool first = i < ub, second = i + 64 < ub;
+			const uint32_t c0 = first ? L.list[i] : 0u, c1 = second ? L.list[i + 64] : 0u;
+			short *a0 = acc + sp_swz(c0), *a1 = acc + sp_swz(c1);
+			int v0 = first ? (int) *a0 : 0, v1 = second ? (int) *a1 : 0;
+			if (first)
+				*a0 = 0;
+			if (second)
+				*a1 = 0;
+			if (CANON) {
+				v0 = sgn_canonical(v0, G);
+				v1 = sgn_canonical(v1, G);
+			}
+			const uint64_t m0 = __ballot(v0 != 0), m1 = __ballot(v1 != 0);
+			const uint32_t d0 = __builtin_amdgcn_mbcnt_hi((uint32_t) (m0 >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t) m0, w));
+			w += (uint32_t) __popcll(m0);
+			const uint32_t d1 = __builtin_amdgcn_mbcnt_hi((uint32_t) (m1 >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t) m1, w));
+			w += (uint32_t) __popcll(m1);
+			if (v0 != 0)
+				sp_st<SC1>(out + d0, c0 | ((uint32_t) v0 << 16));
+			if (v1 != 0)
+				sp_st<SC1>(out + d1, c1 | ((uint32_t) v1 << 16));
 		}
-		ops += (unsigned long long) len;
-		if (lane < len)
-			sp_entry(acc, e0, cc, G);
-		int i = lane + 64;
-		for (; i + 192 < len; i += 256) {
-			const uint32_t a0 = src[i], a1 = src[i + 64], a2 = src[i + 128], a3 = src[i + 192];
-			sp_entry4(acc, a0, a1, a2, a3, cc, G);
+		return (int) w;
+	} else {
+		uint64_t lo64 = T.lo64, hi64 = T.hi64;
+		uint32_t pos = T.prefix;
+		while (__ballot((lo64 | hi64) != 0) != 0) {
+			if ((lo64 | hi64) != 0) {
+				int j;
+				if (lo64 != 0) {
+					j = __builtin_ctzll(lo64);
+					lo64 &= lo64 - 1;
+				} else {
+					j = 64 + __builtin_ctzll(hi64);
+					hi64 &= hi64 - 1;
+				}
+				const uint32_t c = (uint32_t) lane * (32u * WPL) + (uint32_t) j;
+				short *a = acc + sp_swz(c);
+				int v = (int) *a;
+				*a = 0;
+				if (CANON)
+					v = sgn_canonical(v, G);
+				holes += (v == 0);
+				sp_st<SC1>(out + pos, (v != 0) ? (c | ((uint32_t) v << 16)) : 0u);
+				pos += 1;
+			}
 		}
-		for (; i < len; i += 64)
-			sp_entry(acc, src[i], cc, G);
-		if (!more)
-			break;
-		src = srcn;
-		len = lenn;
-		cc = cn;
-		e0 = en;
+		for (int sft = 32; sft >= 1; sft >>= 1)
+			holes += __shfl_xor(holes, sft);
+	}
+	if (holes == 0)
+		return ub;
+	return sp_compact(out, ub, lane);
+}
+
+// the same walk without output: a segment that cannot be written (no room) still leaves its accumulators at zero
+__device__ __forceinline__ void sp_discard(WaveLds &L, const SpTouched &T, int lane)
+{
+	short *acc = reinterpret_cast<short *>(L.acc);
+	if (T.listed) {
+		for (int i = lane; i < T.ub; i += 64)
+			acc[sp_swz(L.list[i])] = 0;
+		return;
+	}
+	uint64_t lo64 = T.lo64, hi64 = T.hi64;
+	while (__ballot((lo64 | hi64) != 0) != 0) {
+		if ((lo64 | hi64) != 0) {
+			int j;
+			if (lo64 != 0) {
+				j = __builtin_ctzll(lo64);
+				lo64 &= lo64 - 1;
+			} else {
+				j = 64 + __builtin_ctzll(hi64);
+				hi64 &= hi64 - 1;
+			}
+			acc[sp_swz((uint32_t) lane * (32u * WPL) + (uint32_t) j)] = 0;
+		}
 	}
 }
 
-// non-zero accumulators of the segment (the whole wave gets the sum)
-__device__ __forceinline__ int sp_count(const uint32_t *accw, int lane)
+// the whole segment as dense values in [0, p) (ncols of them), accumulators and bitmap back to zero
+__device__ __forceinline__ void sp_emit_dense(WaveLds &L, uint32_t *out, int ncols, int lane, const SgnDev &G)
 {
-	const uint4 *a4 = reinterpret_cast<const uint4 *>(accw);
-	int cnt = 0;
-#pragma unroll 4
-	for (int t = 0; t < SEGW / 4 / 64; t++) {
-		const uint4 w = a4[t * 64 + lane];
-		cnt += ((w.x & 0xFFFFu) != 0) + ((w.x >> 16) != 0) + ((w.y & 0xFFFFu) != 0) + ((w.y >> 16) != 0);
-		cnt += ((w.z & 0xFFFFu) != 0) + ((w.z >> 16) != 0) + ((w.w & 0xFFFFu) != 0) + ((w.w >> 16) != 0);
-	}
-	for (int sft = 32; sft >= 1; sft >>= 1)
-		cnt += __shfl_xor(cnt, sft);
-	return cnt;
-}
-
-// the non-zero accumulators as (column | value << 16) entries, sorted by column; CANON: values brought into [-p/2, p/2]
-template <bool CANON> __device__ __forceinline__ void sp_emit(const uint32_t *accw, uint32_t *out, int lane, const SgnDev &G)
-{
-	uint32_t wpos = 0;
-	for (int t0 = 0; t0 < SEGW; t0 += 64) {
-		const uint32_t w = accw[t0 + lane];
-		if (__ballot(w != 0) == 0)
-			continue;
+	for (int w = lane; w < SEGW; w += 64) {
+		const uint32_t pw = ((uint32_t) w & ~(uint32_t) (CW - 1)) | (((uint32_t) w + ((uint32_t) w / CW)) & (uint32_t) (CW - 1));
+		const uint32_t x = L.acc[pw];
+		L.acc[pw] = 0;
 		int v0, v1;
-		sgn_unpack(w, v0, v1);
-		if (CANON) {
-			v0 = sgn_canonical(v0, G);
-			v1 = sgn_canonical(v1, G);
-		}
-		const uint64_t m0 = __ballot(v0 != 0), m1 = __ballot(v1 != 0);
-		uint32_t dst = wpos;
-		dst = __builtin_amdgcn_mbcnt_hi((uint32_t) (m0 >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t) m0, dst));
-		dst = __builtin_amdgcn_mbcnt_hi((uint32_t) (m1 >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t) m1, dst));
-		const uint32_t c0 = 2u * (uint32_t) (t0 + lane);
-		if (v0 != 0) {
-			out[dst] = c0 | ((uint32_t) v0 << 16);
-			dst += 1;
-		}
-		if (v1 != 0)
-			out[dst] = (c0 + 1u) | ((uint32_t) v1 << 16);
-		wpos += (uint32_t) (__popcll(m0) + __popcll(m1));
+		sgn_unpack(x, v0, v1);
+		v0 = sgn_canonical(v0, G);
+		v1 = sgn_canonical(v1, G);
+		if (2 * w < ncols)
+			out[2 * w] = (uint32_t) (v0 < 0 ? v0 + G.p : v0);
+		if (2 * w + 1 < ncols)
+			out[2 * w + 1] = (uint32_t) (v1 < 0 ? v1 + G.p : v1);
 	}
+	for (int t = lane; t < BMW; t += 64)
+		L.bm[t] = 0;
 }
 
 __device__ __forceinline__ uint32_t sp_hash(uint32_t c, uint32_t g)
@@ -205,8 +531,23 @@ __device__ __forceinline__ uint32_t sp_hash(uint32_t c, uint32_t g)
 }
 
 // ---------------------------------------------------------------------------------------------------
-// build of R, one level per launch
+// build of R
 // ---------------------------------------------------------------------------------------------------
+// Two drivers for the same task -- (row c, segment g): R[c][g] = U_n[c][g] - sum_t u_ct R[t][g]:
+//   * sp_build_kernel<false>: one launch per elimination level, from the last level to the first (a launch boundary is what
+//     makes the fragments of the later levels visible);
+//   * sp_build_kernel<true> (default): ONE launch of as many waves as the chip holds at once.  Tasks are handed out in
+//     order -- rows from the last to the first, i.e. every row after the rows it depends on -- by ticket counters; a task
+//     whose dependencies are not there yet polls their fragment words.  Whoever waits, waits for a task with a smaller
+//     number, which a running wave holds or has finished: no deadlock as long as all waves of the grid are resident.  The
+//     chain of levels then costs a hand-over between two CUs per level (a few us) instead of a launch and the slowest task
+//     of the level (17-18 us measured), and rows of different levels overlap wherever the dependencies allow.
+//     Visibility: the entries of a fragment are written through (sc1), the wave drains its stores, then publishes the
+//     fragment word (sc1); readers poll the word (sc1) and read the entries past their L1 (sc1).
+constexpr uint64_t FRAG_PENDING = ~0ull;                 // not computed yet (length bits all ones: never a valid word)
+constexpr uint64_t FRAG_FAILED = ~0ull - 1;              // could not be computed in this launch (no room, or a dependency failed)
+constexpr int SP_TICKETS = 16, SP_TICKET_STRIDE = 32;    // ticket counters, one 128-byte line each
+
 struct SpBuildArgs {
 	const uint64_t *dep_rp;
 	const uint2 *dep;
@@ -214,12 +555,18 @@ struct SpBuildArgs {
 	const uint2 *np;
 	uint64_t *frag;
 	int nseg;
-	int row_lo, row_hi;           // compact rows of this level
+	int row_lo, row_hi;           // level-by-level: compact rows of this level; persistent: all rows (0, r)
 	int level, chunk;
 	SpPools pools;
 	uint32_t *chunk_base;         // the chunk fragments are written to
 	unsigned long long *shard;
-	int *ovf_level;               // largest level in which a reservation failed (-1: none)
+	int *ovf_level;               // level by level: largest level in which a reservation failed (-1: none); persistent: 1 when any task failed
+	unsigned long long shard_sub; // entries of a shard of the current chunk (shard s: [s, s + 1) * shard_sub)
+	int *ticket;                  // persistent: SP_TICKETS counters
+	int *abort_flag;              // persistent: a wave waited too long (the grid is not resident?): everybody gives up
+	long long poll_limit;         // ... polls of one batch of dependencies before that happens
+	unsigned long long *prof;     // SPASM_HIP_SPARSE_IMAGE_PROFILE=1: 8 cycle counters (ticket, metadata, polling, adding, reservation, emit, publication)
+	int *dbg;                     // SPASM_HIP_SPARSE_IMAGE_DEBUG=1: 4 ints per workgroup (stage, task, detail, polls), read by the host's watchdog
 	SgnDev G;
 };
 
@@ -237,20 +584,45 @@ __global__ __launch_bounds__(64) void sp_reset_shards_kernel(unsigned long long 
 	}
 }
 
-__global__ __launch_bounds__(64) void sp_build_kernel(SpBuildArgs b)
+// failed words back to pending (before the launch that retries them with more room)
+__global__ __launch_bounds__(256) void sp_reset_failed_kernel(uint64_t *frag, int64_t n)
 {
-	__shared__ __attribute__((aligned(16))) uint32_t accw[SEGW];
-	short *acc = reinterpret_cast<short *>(accw);
-	const int lane = threadIdx.x;
-	const int task = blockIdx.x;
-	const int c = b.row_lo + task / b.nseg;
-	const int g = task - (c - b.row_lo) * b.nseg;
+	for (int64_t t = (int64_t) blockIdx.x * blockDim.x + threadIdx.x; t < n; t += (int64_t) gridDim.x * blockDim.x)
+		if (frag[t] == FRAG_FAILED)
+			frag[t] = FRAG_PENDING;
+}
+
+__device__ __forceinline__ void sp_dbg(const SpBuildArgs &b, int lane, int stage, long long task, int detail)
+{
+#ifndef SP_NO_DBG
+	if (b.dbg != nullptr) {
+		int *d = b.dbg + 4 * (size_t) blockIdx.x;
+		l0_store_i32_sc1(d + 0, stage);
+		l0_store_i32_sc1(d + 1, (int) task);
+		l0_store_i32_sc1(d + 2, detail);
+	}
+#endif
+}
+
+template <bool PERSISTENT> __device__ __forceinline__ void sp_publish(uint64_t *fout, uint64_t word, int lane)
+{
+	if (PERSISTENT) {
+		asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // the entries of the fragment have left
+		l0_store_u64_sc1(fout, word);
+	} else {
+		l0_store_u64(fout, word);
+	}
+}
+
+// one task: the fragment of (row c, segment g).  One exit, one publication.
+template <bool PERSISTENT> __device__ __forceinline__ void sp_build_task(const SpBuildArgs &b, WaveLds &L, int c, int g, int lane, SpStamp &st)
+{
 	const uint32_t col0 = (uint32_t) g * SP_SEG;
 	const SgnDev G = b.G;
-	const uint64_t d0 = b.dep_rp[c], d1 = b.dep_rp[c + 1], n0 = b.np_rp[c], n1 = b.np_rp[c + 1];
+	const uint64_t d0 = sp_uniform(b.dep_rp[c]), d1 = sp_uniform(b.dep_rp[c + 1]), n0 = sp_uniform(b.np_rp[c]), n1 = sp_uniform(b.np_rp[c + 1]);
 	uint64_t *fout = b.frag + (uint64_t) c * b.nseg + g;
 	unsigned long long ops = 0;
-	bool zeroed = false;
+	bool touched = false, failed = false;          // (wave-uniform: they only ever change on ballots)
 	// the row's own non-pivotal entries that fall into this segment
 	for (uint64_t e = n0; e < n1; e += 64) {
 		uint32_t idx = 0xFFFFFFFFu;
@@ -261,66 +633,129 @@ __global__ __launch_bounds__(64) void sp_build_kernel(SpBuildArgs b)
 			val = (int) en.y;
 		}
 		const bool in = idx < (uint32_t) SP_SEG;
-		if (__ballot(in) == 0)
-			continue;
-		if (!zeroed) {
-			sp_zero(accw, lane);
-			zeroed = true;
+		if (__ballot(in) != 0) {
+			touched = true;
+			if (in)
+				sp_own_entry(L, idx, val, G);
 		}
-		if (in)
-			acc[idx] = (short) val;
 	}
 	// minus the rows of R its pivotal entries point at (coefficients are stored negated)
 	for (uint64_t e = d0; e < d1; e += 64) {
 		uint64_t f = 0;
 		int coef = 0;
-		if (e + lane < d1) {
+		const bool have = e + lane < d1;
+		const uint64_t *fin = b.frag;
+		if (have) {
 			const uint2 de = b.dep[e + lane];
-			f = b.frag[(uint64_t) de.x * b.nseg + g];
+			fin = b.frag + (uint64_t) de.x * b.nseg + g;
 			coef = (int) de.y;
 		}
-		if (__ballot((f & LEN_MASK) != 0) == 0)
-			continue;
-		if (!zeroed) {
-			sp_zero(accw, lane);
-			zeroed = true;
+		st.mark(1);
+		if (PERSISTENT) {
+			sp_dbg(b, lane, 2, (long long) c * b.nseg + g, (int) (e - d0));
+			f = have ? __hip_atomic_load(fin, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0;
+			long long polls = 0;
+			while (__ballot(f == FRAG_PENDING) != 0) {
+				polls += 1;
+				int gave_up = (polls > b.poll_limit) ? 1 : 0;
+				if ((polls & 255) == 0)
+					gave_up |= __builtin_amdgcn_readfirstlane(__hip_atomic_load(b.abort_flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+				if (gave_up != 0) {
+					l0_store_i32_sc1(b.abort_flag, 1);
+					f = (f == FRAG_PENDING) ? FRAG_FAILED : f;
+				} else {
+					__builtin_amdgcn_s_sleep(1);
+					if (f == FRAG_PENDING)
+						f = __hip_atomic_load(fin, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+				}
+			}
+			if (__ballot(f == FRAG_FAILED) != 0)
+				failed = true;
+		} else if (have) {
+			f = *fin;
 		}
-		sp_accumulate(acc, f, coef, b.pools, lane, G, ops);
-	}
-	if (!zeroed) {
-		if (lane == 0)
-			*fout = 0;
-		return;
-	}
-	const int cnt = sp_count(accw, lane);
-	const uint32_t sh = sp_hash((uint32_t) c, (uint32_t) g);
-	unsigned long long *S = b.shard + (size_t) sh * SHARD_STRIDE;
-	if (cnt == 0) {
-		if (lane == 0) {
-			*fout = 0;
-			atomicAdd(&S[2], ops);
+		st.mark(2);
+		if (!failed && __ballot((f & LEN_MASK) != 0) != 0) {
+			touched = true;
+			if (PERSISTENT)
+				sp_dbg(b, lane, 3, (long long) c * b.nseg + g, (int) (e - d0));
+			sp_accumulate<PERSISTENT>(L, f, coef, true, b.pools, lane, G, ops);
+			st.mark(3);
 		}
-		return;
 	}
-	unsigned long long off = 0;
-	if (lane == 0)
-		off = atomicAdd(&S[0], (unsigned long long) cnt);
-	off = readlane64(off, 0);
-	const unsigned long long limit = S[1];
-	if (off + (unsigned long long) cnt > limit) {
-		if (lane == 0) {
-			atomicMax(b.ovf_level, b.level);
-			*fout = 0;
+	st.mark(1);
+	uint64_t word = 0;
+	int cnt = 0;
+	if (touched) {
+		if (PERSISTENT)
+			sp_dbg(b, lane, 4, (long long) c * b.nseg + g, failed ? 1 : 0);
+		SpTouched T;
+		sp_touched(L, lane, T);
+		const int ub = T.ub;
+		const uint32_t sh = sp_hash((uint32_t) c, (uint32_t) g);
+		unsigned long long *S = b.shard + (size_t) sh * SHARD_STRIDE;
+		unsigned long long off = 0;
+		if (!failed && ub > 0) {
+			off = l0_atomic_add_u64_ret(&S[0], (unsigned long long) ub);
+			if (off + (unsigned long long) ub > (unsigned long long) (sh + 1) * b.shard_sub)
+				failed = true;
 		}
-		return;
+		st.mark(4);
+		if (failed) {
+			sp_discard(L, T, lane);
+		} else if (ub > 0) {
+			cnt = sp_emit<false, PERSISTENT>(L, T, b.chunk_base + off, lane, G);
+			if (cnt > 0)
+				word = ((uint64_t) b.chunk << (SP_LEN_BITS + SP_OFF_BITS)) | ((uint64_t) off << SP_LEN_BITS) | (uint64_t) cnt;
+		}
+		st.mark(5);
+		if (!failed) {
+			l0_atomic_add_u64(&S[2], ops);
+			l0_atomic_add_u64(&S[3], (unsigned long long) cnt);
+			l0_atomic_add_u64(&S[4], (cnt > 0) ? 1ull : 0ull);
+		}
 	}
-	sp_emit<false>(accw, b.chunk_base + off, lane, G);
-	if (lane == 0) {
-		*fout = ((uint64_t) b.chunk << (SP_LEN_BITS + SP_OFF_BITS)) | ((uint64_t) off << SP_LEN_BITS) | (uint64_t) cnt;
-		atomicAdd(&S[2], ops);
-		atomicAdd(&S[3], (unsigned long long) cnt);
-		atomicAdd(&S[4], 1ull);
+	if (failed) {
+		l0_atomic_smax_i32(b.ovf_level, PERSISTENT ? 1 : b.level);
+		word = PERSISTENT ? FRAG_FAILED : 0;
 	}
+	sp_publish<PERSISTENT>(fout, word, lane);
+	st.mark(6);
+}
+
+template <bool PERSISTENT> __global__ __launch_bounds__(64) void sp_build_kernel(SpBuildArgs b)
+{
+	__shared__ WaveLds L;
+	const int lane = threadIdx.x;
+	sp_lds_init(L, lane);
+	SpStamp st;
+	st.begin(b.prof);
+	if constexpr (!PERSISTENT) {
+		const int task = blockIdx.x;
+		const int c = b.row_lo + task / b.nseg;
+		sp_build_task<false>(b, L, c, task - (c - b.row_lo) * b.nseg, lane, st);
+	} else {
+		const int q = (int) (blockIdx.x % SP_TICKETS);
+		const long long ntasks = (long long) (b.row_hi - b.row_lo) * b.nseg;
+		for (;;) {
+			const int j = l0_atomic_add_i32_ret(b.ticket + q * SP_TICKET_STRIDE, 1);
+			const long long t = (long long) j * SP_TICKETS + q;
+			st.mark(0);
+			sp_dbg(b, lane, 1, t, j);
+			if (t >= ntasks)
+				break;
+			const int c = b.row_hi - 1 - (int) (t / b.nseg);          // rows from the last to the first
+			const int g = (int) (t % b.nseg);
+			// (a launch that retries after a pool extension finds most fragments done)
+			const uint64_t cur = sp_uniform(__hip_atomic_load(b.frag + (uint64_t) c * b.nseg + g, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+			if (cur == FRAG_PENDING) {
+				sp_build_task<true>(b, L, c, g, lane, st);
+				sp_dbg(b, lane, 5, t, 0);
+			}
+		}
+		sp_dbg(b, lane, 9, 0, 0);
+	}
+	st.flush(lane);
 }
 
 // entries of R: the lengths of all fragments (after a build that redid levels the counters of the shards count those twice)
@@ -382,121 +817,166 @@ struct SpApplyArgs {
 	uint64_t *T;                  // nrows x nseg: offset << SP_LEN_BITS | length of the fragment of (row, segment)
 	unsigned long long *block_sum;// sum of the lengths of every block of 1024 rows (zeroed before the launch)
 	int arena;                    // entries a wave reserves from the pool at a time (0: every fragment on its own)
+	int *ticket;                  // SP_TICKETS counters handing out the rows (zeroed before the launch)
+	unsigned long long *prof;     // SPASM_HIP_SPARSE_IMAGE_PROFILE=1: 8 cycle counters (row of A, fragment words, adding, reservation, emit, words out)
 	uint32_t *dense_out;          // dense rows instead (values in [0, p)), leading dimension ldS
 	int64_t ldS;
 };
 
+// One wave per row of the batch, segment after segment: the entries of the row of A are read and relabelled once (rows
+// of at most 64 entries -- longer ones go through them once per segment), the fragment words of segment g + 1 are in
+// flight while segment g is added up, and the row's fragments of S land one behind the other in the wave's arena.
 __global__ __launch_bounds__(64) void sp_apply_kernel(SpApplyArgs d)
 {
-	__shared__ __attribute__((aligned(16))) uint32_t accw[SEGW];
-	short *acc = reinterpret_cast<short *>(accw);
+	__shared__ WaveLds L;
 	const SchurArgs &a = d.a;
 	const int lane = threadIdx.x;
 	const SgnDev G = d.G;
 	const MontDev F = a.F;
-	const int nrows = a.nrows;
-	const long long ntasks = (long long) nrows * d.nseg;
+	const int nrows = a.nrows, nseg = d.nseg;
 	unsigned long long st_input = 0, ops = 0;
 	int st_done = 0, st_piv = 0;
 	long long ar_cur = 0, ar_end = 0;            // the wave's arena in the fragment pool
 	bool pool_full = false;
-	// segment-major: the waves of the chip work on the same segment of R at the same time (its fragments -- 1 / nseg of the
-	// image -- are what the caches then hold)
-	for (long long task = blockIdx.x; task < ntasks; task += gridDim.x) {
-		const int g = (int) (task / nrows);
-		const int k = (int) (task - (long long) g * nrows);
-		const uint32_t col0 = (uint32_t) g * SP_SEG;
-		const int i = a.rows[k];
-		const int64_t lo = a.Ap[i], hi = a.Ap[i + 1];
-		if (g == 0)
-			st_input += (unsigned long long) (hi - lo);
-		bool zeroed = false;
-		for (int64_t base = lo; base < hi; base += 64) {
-			uint64_t f = 0;
-			int coef = 0, bal = 0;
-			uint32_t idx = 0xFFFFFFFFu;
-			if (base + lane < hi) {
-				const uint32_t cid = (uint32_t) d.col[a.Aj[base + lane]];
-				bal = sgn_from_residue(reduce_sum(from_balanced(a.Ax[base + lane], F), F), G);
-				if (cid >= (uint32_t) d.r) {
-					idx = cid - (uint32_t) d.r - col0;
-				} else if (bal != 0) {
-					f = d.frag[(uint64_t) cid * d.nseg + g];
-					coef = -bal;
-					st_piv += (g == 0) ? 1 : 0;
-				}
-			}
-			const bool in = idx < (uint32_t) SP_SEG;
-			if ((__ballot(in) | __ballot((f & LEN_MASK) != 0)) == 0)
-				continue;
-			if (!zeroed) {
-				sp_zero(accw, lane);
-				zeroed = true;
-			}
-			if (in)
-				acc[idx] = (short) sgn_canonical((int) acc[idx] + bal, G);
-			sp_accumulate(acc, f, coef, d.pools, lane, G, ops);
-		}
+	sp_lds_init(L, lane);
+	SpStamp st;
+	st.begin(d.prof);
+	// what a (row, segment) leaves behind: its fragment in the pool and its word in T (or its dense values)
+	auto finish = [&](int k, int g, bool touched) -> int {
 		if (d.dense_out != nullptr) {
-			uint32_t *out = d.dense_out + (int64_t) k * d.ldS + col0;
-			const int ncols = min(SP_SEG, a.Sm - (int) col0);
-			for (int t = lane; t < ncols; t += 64) {
-				const int v = zeroed ? sgn_canonical((int) acc[t], G) : 0;
-				out[t] = (uint32_t) (v < 0 ? v + G.p : v);
+			uint32_t *out = d.dense_out + (int64_t) k * d.ldS + (int64_t) g * SP_SEG;
+			const int ncols = min(SP_SEG, a.Sm - g * SP_SEG);
+			if (touched) {
+				sp_emit_dense(L, out, ncols, lane, G);
+			} else {
+				for (int t = lane; t < ncols; t += 64)
+					out[t] = 0u;
 			}
-			if (g == 0) {
-				if (lane == 0)
-					a.row_len[k] = a.Sm;
-				st_done += 1;
-			}
-			continue;
+			return 0;
 		}
-		st_done += (g == 0) ? 1 : 0;
-		const int cnt = zeroed ? sp_count(accw, lane) : 0;
-		if (cnt == 0) {
-			if (lane == 0)
-				d.T[(uint64_t) k * d.nseg + g] = 0;
-			continue;
+		uint64_t *tout = d.T + (uint64_t) k * nseg + g;
+		if (!touched) {
+			l0_store_u64(tout, 0);
+			return 0;
 		}
-		if (ar_cur + cnt > ar_end) {
-			const long long want = (d.arena > cnt) ? d.arena : cnt;
-			unsigned long long got = 0;
-			if (lane == 0)
-				got = atomicAdd(&a.ctr64[C64_POOL], (unsigned long long) want);
-			got = readlane64(got, 0);
+		SpTouched T;
+		sp_touched(L, lane, T);
+		const int ub = T.ub;
+		if (ar_cur + ub > ar_end) {
+			const long long want = (d.arena > ub) ? d.arena : ub;
+			const unsigned long long got = l0_atomic_add_u64_ret(&a.ctr64[C64_POOL], (unsigned long long) want);
 			ar_cur = (long long) got;
 			ar_end = ar_cur + want;
 			if (ar_end > d.fcap) {
-				// the pool is exhausted: a smaller reservation may still fit for this fragment, the call fails anyway
 				pool_full = true;
 				ar_end = ar_cur;
 			}
 		}
-		if (ar_cur + cnt > ar_end) {
-			if (lane == 0)
-				d.T[(uint64_t) k * d.nseg + g] = 0;
-			continue;
+		if (ar_cur + ub > ar_end) {
+			sp_discard(L, T, lane);
+			l0_store_u64(tout, 0);
+			return 0;
 		}
-		sp_emit<true>(accw, d.fpool + ar_cur, lane, G);
-		if (lane == 0) {
-			d.T[(uint64_t) k * d.nseg + g] = ((uint64_t) ar_cur << SP_LEN_BITS) | (uint64_t) cnt;
-			atomicAdd(&a.row_len[k], cnt);
-			atomicAdd(&d.block_sum[k >> 10], (unsigned long long) cnt);
-		}
+		st.mark(3);
+		const int cnt = sp_emit<true, false>(L, T, d.fpool + ar_cur, lane, G);
+		st.mark(4);
+		l0_store_u64(tout, (cnt > 0) ? (((uint64_t) ar_cur << SP_LEN_BITS) | (uint64_t) cnt) : 0);
 		ar_cur += cnt;
+		return cnt;
+	};
+	// rows are handed out by ticket counters (their costs differ by orders of magnitude: with a fixed share per wave the
+	// kernel ran 1.6 times as long as its average wave)
+	const int q = (int) (blockIdx.x % SP_TICKETS);
+	for (;;) {
+		const long long kk = (long long) l0_atomic_add_i32_ret(d.ticket + q * SP_TICKET_STRIDE, 1) * SP_TICKETS + q;
+		if (kk >= nrows)
+			break;
+		const int k = (int) kk;
+		const int i = __builtin_amdgcn_readfirstlane(a.rows[k]);
+		const int64_t lo = (int64_t) sp_uniform((uint64_t) a.Ap[i]), hi = (int64_t) sp_uniform((uint64_t) a.Ap[i + 1]);
+		st_input += (unsigned long long) (hi - lo);
+		int total = 0;
+		if (hi - lo <= 64) {
+			// the row in registers: lane e holds entry e
+			uint32_t cid = 0xFFFFFFFFu;
+			int bal = 0;
+			if (lo + lane < hi) {
+				cid = (uint32_t) d.col[a.Aj[lo + lane]];
+				bal = sgn_from_residue(reduce_sum(from_balanced(a.Ax[lo + lane], F), F), G);
+			}
+			const bool piv = cid < (uint32_t) d.r && bal != 0;
+			const bool own = cid != 0xFFFFFFFFu && cid >= (uint32_t) d.r;
+			const uint32_t idx_all = cid - (uint32_t) d.r;          // (own entries: index among the non-pivotal columns)
+			const uint64_t *fin = d.frag + (piv ? (uint64_t) cid * nseg : 0);
+			st_piv += piv ? 1 : 0;
+			uint64_t f = piv ? fin[0] : 0;
+			st.mark(0);
+			for (int g = 0; g < nseg; g++) {
+				const uint64_t fnext = (piv && g + 1 < nseg) ? fin[g + 1] : 0;
+				const uint32_t idx = idx_all - (uint32_t) g * SP_SEG;
+				const bool in = own && idx < (uint32_t) SP_SEG;
+				const bool touched = (__ballot(in) | __ballot((f & LEN_MASK) != 0)) != 0;
+				st.mark(1);
+				if (touched) {
+					if (in)
+						sp_own_entry(L, idx, bal, G);
+					sp_accumulate<false>(L, f, -bal, piv, d.pools, lane, G, ops);
+				}
+				st.mark(2);
+				total += finish(k, g, touched);
+				st.mark(5);
+				f = fnext;
+			}
+		} else {
+			for (int g = 0; g < nseg; g++) {
+				const uint32_t col0 = (uint32_t) g * SP_SEG;
+				bool touched = false;
+				for (int64_t base = lo; base < hi; base += 64) {
+					uint64_t f = 0;
+					int bal = 0;
+					uint32_t idx = 0xFFFFFFFFu;
+					bool piv = false;
+					if (base + lane < hi) {
+						const uint32_t cid = (uint32_t) d.col[a.Aj[base + lane]];
+						bal = sgn_from_residue(reduce_sum(from_balanced(a.Ax[base + lane], F), F), G);
+						if (cid >= (uint32_t) d.r) {
+							idx = cid - (uint32_t) d.r - col0;
+						} else if (bal != 0) {
+							piv = true;
+							f = d.frag[(uint64_t) cid * nseg + g];
+							st_piv += (g == 0) ? 1 : 0;
+						}
+					}
+					const bool in = idx < (uint32_t) SP_SEG;
+					if ((__ballot(in) | __ballot((f & LEN_MASK) != 0)) == 0)
+						continue;
+					touched = true;
+					if (in)
+						sp_own_entry(L, idx, bal, G);
+					sp_accumulate<false>(L, f, -bal, piv, d.pools, lane, G, ops);
+				}
+				total += finish(k, g, touched);
+			}
+		}
+		st_done += 1;
+		if (d.dense_out != nullptr) {
+			l0_store_i32(a.row_len + k, a.Sm);
+		} else {
+			l0_store_i32(a.row_len + k, total);
+			l0_atomic_add_u64(&d.block_sum[k >> 10], (unsigned long long) total);
+		}
 	}
+	st.flush(lane);
+	for (int sft = 32; sft >= 1; sft >>= 1)
+		st_piv += __shfl_xor(st_piv, sft);
 	if (lane == 0) {
 		atomicAdd(&a.ctr64[C64_INPUT], st_input);
 		atomicAdd(&a.ctr64[C64_STREAM], ops);
+		atomicAdd(&a.ctr64[C64_ELIM], (unsigned long long) st_piv);
 		atomicAdd(&a.ctr[a.done_ctr], st_done);
 		if (pool_full)
 			atomicOr(&a.ctr[CTR_STATUS], 1);
 	}
-	// (pivotal entries are counted per lane)
-	for (int sft = 32; sft >= 1; sft >>= 1)
-		st_piv += __shfl_xor(st_piv, sft);
-	if (lane == 0)
-		atomicAdd(&a.ctr64[C64_ELIM], (unsigned long long) st_piv);
 }
 
 struct SpGatherArgs {
@@ -676,14 +1156,17 @@ bool sparse_image_build(const spasm_hip_dfact *F, hipStream_t stream)
 		HIP_CHECK(hipEventCreate(&S.ev0));
 		HIP_CHECK(hipEventCreate(&S.ev1));
 	}
+	const int64_t nfrag = (int64_t) S.r * S.nseg;
 	if (S.d_frag == nullptr)
-		S.d_frag = dalloc<uint64_t>((int64_t) S.r * S.nseg);
+		S.d_frag = dalloc<uint64_t>(nfrag);
 	if (S.d_shard == nullptr)
-		S.d_shard = dalloc<unsigned long long>((int64_t) SP_SHARDS * SHARD_STRIDE + 16);
-	int *d_ovf = reinterpret_cast<int *>(S.d_shard + (size_t) SP_SHARDS * SHARD_STRIDE);
-	// Room: the pool grows by chunks.  A build that runs out of room in some level allocates the next chunk (twice the size)
-	// and redoes the levels from that one on; what it may take in all is bounded -- an R that needs more than half the bytes
-	// of its dense form is not sparse, and the other paths are the better ones for it.
+		S.d_shard = dalloc<unsigned long long>((int64_t) SP_SHARDS * SHARD_STRIDE + 512);
+	// small words behind the shards: [0, 512) the ticket counters, 512 the abort flag, 513 the overflow word
+	int *d_sync = reinterpret_cast<int *>(S.d_shard + (size_t) SP_SHARDS * SHARD_STRIDE);
+	int *d_abort = d_sync + SP_TICKETS * SP_TICKET_STRIDE, *d_ovf = d_abort + 1;
+	// Room: the pool grows by chunks.  A build that runs out of room allocates the next chunk (twice the size) and redoes
+	// what failed; what it may take in all is bounded -- an R that needs more than half the bytes of its dense form is not
+	// sparse, and the other paths are the better ones for it.
 	size_t free_b = 0, total_b = 0;
 	HIP_CHECK(hipMemGetInfo(&free_b, &total_b));
 	int64_t held = 0;
@@ -717,60 +1200,200 @@ bool sparse_image_build(const spasm_hip_dfact *F, hipStream_t stream)
 	b.nseg = S.nseg;
 	b.shard = S.d_shard;
 	b.ovf_level = d_ovf;
+	b.ticket = d_sync;
+	b.abort_flag = d_abort;
+	b.poll_limit = (long long) env_sp("SPASM_HIP_SPARSE_IMAGE_POLLS", 1 << 21);
+	unsigned long long *d_prof = nullptr;
+	if (env_sp("SPASM_HIP_SPARSE_IMAGE_PROFILE", 0) != 0) {
+		d_prof = dalloc<unsigned long long>(8);
+		HIP_CHECK(hipMemsetAsync(d_prof, 0, 8 * sizeof(unsigned long long), stream));
+	}
+	b.prof = d_prof;
 	b.G = sgn_setup(F->prime);
+	// the persistent driver needs every wave of its grid resident at once
+	int dev = 0, cus = 0, per_cu = 0;
+	HIP_CHECK(hipGetDevice(&dev));
+	HIP_CHECK(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev));
+	HIP_CHECK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, sp_build_kernel<true>, 64, 0));
+	per_cu = std::min(per_cu, env_sp("SPASM_HIP_SPARSE_IMAGE_BUILD_WAVES", (int) std::min<size_t>(16, (size_t) (160 * 1024) / sizeof(WaveLds))));
+	bool persistent = env_sp("SPASM_HIP_SPARSE_IMAGE_PERSISTENT", 1) != 0 && per_cu >= 1;
 	HIP_CHECK(hipEventRecord(S.ev0, stream));
-	int chunk = 0, from_level = S.nlevels - 1;
-	S.launches = 0;
-	bool first = true;
-	for (;;) {
+	auto next_chunk = [&](int chunk) -> bool {          // room for another attempt?  (allocates chunk + 1 when it is not there)
+		int64_t total = 0;
+		for (int k = 0; k < S.nchunks; k++)
+			total += S.chunk_cap[k] * 4;
+		const int64_t cap = S.chunk_cap[S.nchunks - 1] * 2;
+		if (chunk + 1 < S.nchunks)
+			return true;
+		if (chunk + 1 >= SP_MAX_CHUNKS || total + cap * 4 > budget) {
+			if (verbose() >= 2)
+				logmsg("[sparse image] gave up: %.2f GB of fragments do not hold R (budget %.2f GB) -- R is not sparse\n", 1e-9 * (double) total,
+				       1e-9 * (double) budget);
+			return false;
+		}
+		S.d_chunk[S.nchunks] = dalloc<uint32_t>(cap);
+		S.chunk_cap[S.nchunks] = cap;
+		S.nchunks += 1;
+		return true;
+	};
+	auto set_chunk = [&](int chunk, bool first) {
 		for (int k = 0; k < SP_MAX_CHUNKS; k++)
 			b.pools.base[k] = S.d_chunk[k < S.nchunks ? k : 0];
 		b.chunk = chunk;
 		b.chunk_base = S.d_chunk[chunk];
+		b.shard_sub = (unsigned long long) (S.chunk_cap[chunk] / SP_SHARDS);
 		hipLaunchKernelGGL(sp_reset_shards_kernel, dim3(SP_SHARDS / 64), dim3(64), 0, stream, S.d_shard,
 		                   (unsigned long long) (S.chunk_cap[chunk] / SP_SHARDS), first ? 1 : 0);
-		HIP_CHECK(hipMemsetAsync(d_ovf, 0xFF, sizeof(int), stream));
-		first = false;
-		for (int l = from_level; l >= 0; l--) {
-			b.row_lo = S.lvl_lo[l];
-			b.row_hi = S.lvl_lo[l + 1];
-			b.level = l;
-			const int64_t ntasks = (int64_t) (b.row_hi - b.row_lo) * S.nseg;
-			if (ntasks <= 0)
-				continue;
-			if (ntasks > 0x7FFFFFFFll)
-				die("sparse_image_build: level %d has %lld (row, segment) pairs", l, (long long) ntasks);
-			hipLaunchKernelGGL(sp_build_kernel, dim3((unsigned) ntasks), dim3(64), 0, stream, b);
+	};
+	int chunk = 0;
+	S.launches = 0;
+	bool ok = true;
+	if (persistent) {
+		HIP_CHECK(hipMemsetAsync(S.d_frag, 0xFF, (size_t) nfrag * sizeof(uint64_t), stream));          // every fragment pending
+		b.row_lo = 0;
+		b.row_hi = S.r;
+		const int64_t ntasks = nfrag;
+		const int blocks = (int) std::max<int64_t>(1, std::min<int64_t>(ntasks, (int64_t) cus * per_cu));
+		for (bool first = true;; first = false) {
+			set_chunk(chunk, first);
+			HIP_CHECK(hipMemsetAsync(d_sync, 0, (size_t) (SP_TICKETS * SP_TICKET_STRIDE + 2) * sizeof(int), stream));
+			int *d_dbg = nullptr;
+			if (env_sp("SPASM_HIP_SPARSE_IMAGE_DEBUG", 0) != 0) {
+				d_dbg = dalloc<int>((int64_t) blocks * 4);
+				HIP_CHECK(hipMemsetAsync(d_dbg, 0, (size_t) blocks * 4 * sizeof(int), stream));
+			}
+			b.dbg = d_dbg;
+			hipLaunchKernelGGL(sp_build_kernel<true>, dim3(blocks), dim3(64), 0, stream, b);
+			HIP_CHECK(hipGetLastError());
 			S.launches += 1;
+			{
+				// watchdog: a launch that is still running after SPASM_HIP_SPARSE_IMAGE_WATCHDOG_S seconds (default 20) is told to
+				// give up (the abort flag, written from a stream of its own); what the ticket counters and the wave marks say
+				// goes to stderr
+				const double t_launch = wtime(), patience = (double) env_sp("SPASM_HIP_SPARSE_IMAGE_WATCHDOG_S", 20);
+				const int wd_mode = env_sp("SPASM_HIP_SPARSE_IMAGE_WD_MODE", 0);          // (experiment: 1 = no busy wait before the read-back, 2 = pinned read-back)
+				while (wd_mode == 0 && hipStreamQuery(stream) == hipErrorNotReady && wtime() - t_launch < patience) {
+				}
+				if (wd_mode == 2) {
+					int *pin = nullptr;
+					HIP_CHECK(hipHostMalloc((void **) &pin, 64, hipHostMallocDefault));
+					HIP_CHECK(hipMemcpyAsync(pin, d_abort, 8, hipMemcpyDeviceToHost, stream));
+					HIP_CHECK(hipStreamSynchronize(stream));
+					fprintf(stderr, "[wd_mode 2] pinned read-back done: %d %d\n", pin[0], pin[1]);
+					HIP_CHECK(hipHostFree(pin));
+				}
+				if (wd_mode == 3) {
+					HIP_CHECK(hipStreamSynchronize(stream));
+					fprintf(stderr, "[wd_mode 3] plain synchronize done\n");
+				}
+				if (wd_mode == 0 && hipStreamQuery(stream) == hipErrorNotReady) {
+					hipStream_t side;
+					HIP_CHECK(hipStreamCreateWithFlags(&side, hipStreamNonBlocking));
+					std::vector<int> hs((size_t) SP_TICKETS * SP_TICKET_STRIDE + 2);
+					HIP_CHECK(hipMemcpyAsync(hs.data(), d_sync, hs.size() * sizeof(int), hipMemcpyDeviceToHost, side));
+					HIP_CHECK(hipStreamSynchronize(side));
+					fprintf(stderr, "[sparse image] the build kernel is still running after %.0f s (%lld tasks, %d waves); tickets drawn per class:", patience,
+					        (long long) ntasks, blocks);
+					for (int q = 0; q < SP_TICKETS; q++)
+						fprintf(stderr, " %d", hs[(size_t) q * SP_TICKET_STRIDE]);
+					fprintf(stderr, "; abort %d, overflow %d\n", hs[(size_t) SP_TICKETS * SP_TICKET_STRIDE], hs[(size_t) SP_TICKETS * SP_TICKET_STRIDE + 1]);
+					if (d_dbg != nullptr) {
+						std::vector<int> hd((size_t) blocks * 4);
+						HIP_CHECK(hipMemcpyAsync(hd.data(), d_dbg, hd.size() * sizeof(int), hipMemcpyDeviceToHost, side));
+						HIP_CHECK(hipStreamSynchronize(side));
+						int hist[10] = {0};
+						for (int w = 0; w < blocks; w++)
+							hist[std::max(0, std::min(9, hd[(size_t) w * 4]))] += 1;
+						fprintf(stderr, "[sparse image/debug] waves by stage: not started %d, ticket %d, polling %d, adding %d, emit %d, task done %d, exited %d\n",
+						        hist[0], hist[1], hist[2], hist[3], hist[4], hist[5], hist[9]);
+						int shown = 0;
+						for (int w = 0; w < blocks && shown < 24; w++)
+							if (hd[(size_t) w * 4] != 9 && hd[(size_t) w * 4] != 0) {
+								fprintf(stderr, "[sparse image/debug]   wave %d: stage %d, task %d, detail %d\n", w, hd[(size_t) w * 4], hd[(size_t) w * 4 + 1], hd[(size_t) w * 4 + 2]);
+								shown += 1;
+							}
+					}
+					// a sample of the fragment words: how many are still pending?
+					{
+						const int64_t ns = std::min<int64_t>(nfrag, 1 << 20);
+						std::vector<uint64_t> hf((size_t) ns);
+						HIP_CHECK(hipMemcpyAsync(hf.data(), S.d_frag + (nfrag - ns), (size_t) ns * sizeof(uint64_t), hipMemcpyDeviceToHost, side));
+						HIP_CHECK(hipStreamSynchronize(side));
+						int64_t pend = 0, first_pending = -1;
+						for (int64_t t = ns - 1; t >= 0; t--)
+							if (hf[(size_t) t] == FRAG_PENDING) {
+								pend += 1;
+								if (first_pending < 0)
+									first_pending = (nfrag - 1) - ((nfrag - ns) + t);
+							}
+						fprintf(stderr, "[sparse image] of the first %lld tasks, %lld are pending; the first pending one is task %lld\n", (long long) ns, (long long) pend,
+						        (long long) first_pending);
+					}
+					const int one = 1;
+					HIP_CHECK(hipMemcpyAsync(d_abort, &one, sizeof(int), hipMemcpyHostToDevice, side));
+					HIP_CHECK(hipStreamSynchronize(side));
+					(void) hipStreamDestroy(side);
+				}
+			}
+			int flags[2] = {0, 0};          // abort, overflow
+			HIP_CHECK(hipMemcpyAsync(flags, d_abort, sizeof(flags), hipMemcpyDeviceToHost, stream));
+			HIP_CHECK(hipStreamSynchronize(stream));
+			if (verbose() >= 3)
+				logmsg("[sparse image] launch %d on chunk %d (%lld entries): abort %d, overflow %d\n", S.launches, chunk, (long long) S.chunk_cap[chunk], flags[0], flags[1]);
+			if (flags[0] != 0) {
+				// a wave waited for a dependency for seconds: the grid was not resident (something else holds the chip?).  The
+				// level-by-level driver needs no such thing.
+				logmsg("[sparse image] the single-launch build gave up waiting; building level by level\n");
+				persistent = false;
+				chunk = 0;
+				break;
+			}
+			if (flags[1] == 0)
+				break;
+			if (!next_chunk(chunk)) {
+				ok = false;
+				break;
+			}
+			chunk += 1;
+			hipLaunchKernelGGL(sp_reset_failed_kernel, dim3(1024), dim3(256), 0, stream, S.d_frag, nfrag);
 		}
-		HIP_CHECK(hipGetLastError());
-		int ovf = -1;
-		HIP_CHECK(hipMemcpyAsync(&ovf, d_ovf, sizeof(int), hipMemcpyDeviceToHost, stream));
-		HIP_CHECK(hipStreamSynchronize(stream));
-		if (ovf < 0)
-			break;
-		// out of room in level `ovf`: the next chunk, and again from there
-		int64_t total = 0;
-		for (int k = 0; k < S.nchunks; k++)
-			total += S.chunk_cap[k] * 4;
-		int64_t cap = S.chunk_cap[S.nchunks - 1] * 2;
-		if (chunk + 1 >= SP_MAX_CHUNKS || total + cap * 4 > budget) {
-			if (verbose() >= 2)
-				logmsg("[sparse image] gave up in level %d of %d: %.2f GB of fragments would not hold R (budget %.2f GB) -- R is not sparse\n", ovf,
-				       S.nlevels, 1e-9 * (double) total, 1e-9 * (double) budget);
-			S.failed = true;
-			HIP_CHECK(hipEventRecord(S.ev1, stream));
-			return false;
+	}
+	if (!persistent) {
+		int from_level = S.nlevels - 1;
+		for (bool first = true;; first = false) {
+			set_chunk(chunk, first);
+			HIP_CHECK(hipMemsetAsync(d_ovf, 0xFF, sizeof(int), stream));
+			for (int l = from_level; l >= 0; l--) {
+				b.row_lo = S.lvl_lo[l];
+				b.row_hi = S.lvl_lo[l + 1];
+				b.level = l;
+				const int64_t ntasks = (int64_t) (b.row_hi - b.row_lo) * S.nseg;
+				if (ntasks <= 0)
+					continue;
+				if (ntasks > 0x7FFFFFFFll)
+					die("sparse_image_build: level %d has %lld (row, segment) pairs", l, (long long) ntasks);
+				hipLaunchKernelGGL(sp_build_kernel<false>, dim3((unsigned) ntasks), dim3(64), 0, stream, b);
+				S.launches += 1;
+			}
+			HIP_CHECK(hipGetLastError());
+			int ovf = -1;
+			HIP_CHECK(hipMemcpyAsync(&ovf, d_ovf, sizeof(int), hipMemcpyDeviceToHost, stream));
+			HIP_CHECK(hipStreamSynchronize(stream));
+			if (ovf < 0)
+				break;
+			if (!next_chunk(chunk)) {          // out of room in level `ovf`
+				ok = false;
+				break;
+			}
+			chunk += 1;
+			from_level = ovf;
 		}
-		if (chunk + 1 >= S.nchunks) {
-			S.d_chunk[S.nchunks] = dalloc<uint32_t>(cap);
-			S.chunk_cap[S.nchunks] = cap;
-			S.nchunks += 1;
-		}
-		chunk += 1;
-		from_level = ovf;
 	}
 	HIP_CHECK(hipEventRecord(S.ev1, stream));
+	if (!ok) {
+		S.failed = true;
+		return false;
+	}
 	std::vector<unsigned long long> h((size_t) SP_SHARDS * SHARD_STRIDE);
 	HIP_CHECK(hipMemcpyAsync(h.data(), S.d_shard, h.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost, stream));
 	HIP_CHECK(hipStreamSynchronize(stream));
@@ -780,29 +1403,42 @@ bool sparse_image_build(const spasm_hip_dfact *F, hipStream_t stream)
 		S.ops_build += (int64_t) h[(size_t) s * SHARD_STRIDE + 2];
 		S.nnz += (int64_t) h[(size_t) s * SHARD_STRIDE + 3];
 	}
-	S.pool_used = S.nnz;          // (entries written, fragments of redone levels included: what a rebuild needs in one chunk)
-	if (chunk > 0) {
+	S.pool_used = S.nnz + S.nnz / 64;          // (what a rebuild needs in one chunk: the entries, and the few words cancellations strand)
+	if (chunk > 0 && !persistent) {
 		// levels were redone: their fragments were counted twice
 		HIP_CHECK(hipMemsetAsync(S.d_shard, 0, sizeof(unsigned long long), stream));
-		hipLaunchKernelGGL(sp_sum_frag_kernel, dim3(1024), dim3(256), 0, stream, S.d_frag, (int64_t) S.r * S.nseg, S.d_shard);
+		hipLaunchKernelGGL(sp_sum_frag_kernel, dim3(1024), dim3(256), 0, stream, S.d_frag, nfrag, S.d_shard);
 		unsigned long long exact = 0;
 		HIP_CHECK(hipMemcpyAsync(&exact, S.d_shard, sizeof(exact), hipMemcpyDeviceToHost, stream));
 		HIP_CHECK(hipStreamSynchronize(stream));
 		S.nnz = (int64_t) exact;
 	}
+	if (d_prof != nullptr) {
+		unsigned long long hp[8];
+		HIP_CHECK(hipMemcpyAsync(hp, d_prof, sizeof(hp), hipMemcpyDeviceToHost, stream));
+		HIP_CHECK(hipStreamSynchronize(stream));
+		static const char *const name[7] = {"ticket", "metadata", "polling", "adding", "reservation", "emit", "publication"};
+		double tot = 0;
+		for (int q = 0; q < 7; q++)
+			tot += (double) hp[q];
+		fprintf(stderr, "[sparse image/profile] build, wave cycles by stage:");
+		for (int q = 0; q < 7; q++)
+			fprintf(stderr, " %s %.1f %%;", name[q], 100.0 * (double) hp[q] / std::max(1.0, tot));
+		fprintf(stderr, " %.3g cycles in all\n", tot);
+		sh::big_free(d_prof);
+	}
 	S.valid = true;
 	S.failed = false;
 	S.builds += 1;
-	if (verbose() >= 2)
+	if (verbose() >= 2) {
+		double gb = 0;
+		for (int k = 0; k < S.nchunks; k++)
+			gb += 4e-9 * (double) S.chunk_cap[k];
 		logmsg("[sparse image] R: %d rows x %d columns in %d segments, %lld entries (%.3f %% of the dense form, %.1f per row), %lld multiply-adds, %d "
-		       "launches, %d pool chunk(s) of %.2f GB in all\n",
+		       "launch(es) (%s), %d pool chunk(s) of %.2f GB in all\n",
 		       S.r, S.Sm, S.nseg, (long long) S.nnz, 100.0 * (double) S.nnz / std::max(1.0, (double) S.r * (double) S.Sm),
-		       (double) S.nnz / std::max(1, S.r), (long long) S.ops_build, S.launches, S.nchunks, [&] {
-			       double t = 0;
-			       for (int k = 0; k < S.nchunks; k++)
-				       t += 4e-9 * (double) S.chunk_cap[k];
-			       return t;
-		       }());
+		       (double) S.nnz / std::max(1, S.r), (long long) S.ops_build, S.launches, persistent ? "tasks handed out in order" : "level by level", S.nchunks, gb);
+	}
 	return true;
 }
 
@@ -834,23 +1470,45 @@ void launch_sparse_image_apply(const SchurArgs &a, const spasm_hip_dfact *F, uin
 	d.block_sum = block_sum;
 	d.dense_out = dense_out;
 	d.ldS = ldS;
-	const int64_t ntasks = (int64_t) a.nrows * S.nseg;
+	const int64_t ntasks = (int64_t) a.nrows;          // (a wave takes a row through all its segments)
 	if (ntasks <= 0)
 		return;
-	// nine waves per CU (16 KB of LDS each), every wave a workgroup of its own
-	const int per_cu = std::max(1, std::min(16, env_sp("SPASM_HIP_SPARSE_IMAGE_WAVES", 9)));
+	// as many waves per CU as its LDS holds (19.5 KB each: eight), every wave a workgroup of its own
+	const int per_cu = std::max(1, std::min(16, env_sp("SPASM_HIP_SPARSE_IMAGE_WAVES", (int) std::min<size_t>(16, (size_t) (160 * 1024) / sizeof(WaveLds)))));
 	const int blocks = (int) std::min<int64_t>(ntasks, (int64_t) prop.multiProcessorCount * per_cu);
 	// a wave reserves the room of its fragments 32,768 entries at a time when the pool is large enough for every wave to
 	// strand one such arena; else fragment by fragment
 	d.arena = (fcap >= (int64_t) blocks * 32768 * 8) ? 32768 : 0;
+	// (block_sum: (nrows + 1023) / 1024 words rounded up to 16, then 256 words of ticket counters)
+	const int nblocks = (a.nrows + 1023) / 1024;
+	d.ticket = reinterpret_cast<int *>(block_sum + (size_t) (nblocks + 15) / 16 * 16);
+	HIP_CHECK(hipMemsetAsync(d.ticket, 0, (size_t) SP_TICKETS * SP_TICKET_STRIDE * sizeof(int), stream));
 	if (dense_out == nullptr) {
-		const int nblocks = (a.nrows + 1023) / 1024;
 		HIP_CHECK(hipMemsetAsync(block_sum, 0, (size_t) nblocks * sizeof(unsigned long long), stream));
-		HIP_CHECK(hipMemsetAsync(a.row_len, 0, (size_t) a.nrows * sizeof(int), stream));
 		HIP_CHECK(hipMemsetAsync(Sp, 0, sizeof(int64_t), stream));
 	}
+	unsigned long long *d_prof = nullptr;
+	if (env_sp("SPASM_HIP_SPARSE_IMAGE_PROFILE", 0) != 0) {
+		d_prof = dalloc<unsigned long long>(8);
+		HIP_CHECK(hipMemsetAsync(d_prof, 0, 8 * sizeof(unsigned long long), stream));
+	}
+	d.prof = d_prof;
 	hipLaunchKernelGGL(sp_apply_kernel, dim3(blocks), dim3(64), 0, stream, d);
 	HIP_CHECK(hipGetLastError());
+	if (d_prof != nullptr) {
+		unsigned long long hp[8];
+		HIP_CHECK(hipMemcpyAsync(hp, d_prof, sizeof(hp), hipMemcpyDeviceToHost, stream));
+		HIP_CHECK(hipStreamSynchronize(stream));
+		static const char *const name[6] = {"row of A", "fragment words", "adding", "reservation", "emit", "words out"};
+		double tot = 0;
+		for (int q = 0; q < 6; q++)
+			tot += (double) hp[q];
+		fprintf(stderr, "[sparse image/profile] rows of S (%d waves), wave cycles by stage:", blocks);
+		for (int q = 0; q < 6; q++)
+			fprintf(stderr, " %s %.1f %%;", name[q], 100.0 * (double) hp[q] / std::max(1.0, tot));
+		fprintf(stderr, " %.3g cycles in all\n", tot);
+		sh::big_free(d_prof);
+	}
 	if (dense_out != nullptr)
 		return;
 	if (ev_gather != nullptr)
