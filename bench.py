@@ -19,8 +19,15 @@ every rank with an all-gatherv over RCCL (the row-by-row kernels, whose rows nev
 
 Everything in the `roofline` object is measured in this run (HIP events of the library on the launch
 stream, the kernels' own work counters) except `traffic`, which rocprofv3 has to collect in separate
-passes: it is quoted from profiles/r02_traffic.json (written by tools/profile.sh) only when that file was
-recorded for the same kernel on the same workload, with its path in `traffic_source`; otherwise null.
+passes: it is quoted from profiles/r04_traffic.json (written by tools/profile.sh; older rounds' files are looked at
+next) only when that file was recorded for the same kernel on the same workload, with its path in
+`traffic_source`; otherwise null.
+
+Next to the step, on one GPU: the same batch through the row-by-row kernels, the dense tail, five end-to-end calls
+(first call, median and minimum are all reported), `sparse_path` -- the flow of the GL7d19 class on the generated
+stand-in mk14.b4: its Schur complement through the sparse image (the default there), the dense image and the
+row-by-row kernels --, `at_scale` -- mk15.b4, 2,837,835 x 675,675 with 14.2 M entries, the size of GL7d19 -- and the
+chessboard stand-ins.
 """
 import argparse
 import ctypes as C
@@ -41,7 +48,8 @@ PRIME = 42013
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8 TB/s
 MFMA_I8_PEAK_TOPS = 5000.0     # dense i8 (the guide's ~5 P op/s class; AMD's sparsity figures are not used)
 # rocprofv3 PMC passes (tools/profile.sh): newest first; a file only counts for the workload, row count and kernel it names
-TRAFFIC_FILES = ["profiles/r03_traffic.json", "profiles/r03_sparse_traffic.json", "profiles/r02_traffic.json"]
+TRAFFIC_FILES = ["profiles/r04_traffic.json", "profiles/r04_sparse_traffic.json", "profiles/r03_traffic.json", "profiles/r03_sparse_traffic.json",
+                 "profiles/r02_traffic.json"]
 
 
 # --------------------------------------------------------------------------
@@ -142,7 +150,7 @@ def dense_tail_probe(torch, spasm_amd, dev, n=4096, m=32768):
            "update_kernels_ms_serialised": ms_upd.value, "update_kernels_Tmacs_per_s": tmacs_upd,
            # 4 int8 digit products per useful multiply-add (two base-256 digits each side), 2 ops per product
            "mfma_i8_frac_of_peak": (8 * tmacs_upd / MFMA_I8_PEAK_TOPS) if tmacs_upd else None}
-    for rel in ("profiles/r03_dense_tail.json", "profiles/r02_dense_tail.json"):
+    for rel in ("profiles/r04_dense_tail.json", "profiles/r03_dense_tail.json", "profiles/r02_dense_tail.json"):
         path = os.path.join(ROOT, rel)
         if not os.path.exists(path):
             continue
@@ -157,19 +165,35 @@ def dense_tail_probe(torch, spasm_amd, dev, n=4096, m=32768):
     return out
 
 
-def sparse_path_probe(torch, spasm_amd, workloads, dev, name="mk14.b4", steps=3):
+def _calls(fn, count):
+    """`count` timed calls of fn() -> (profile, rank): first call, median, minimum, all of them"""
+    runs = []
+    for _ in range(count):
+        t0 = time.perf_counter()
+        prof, rank = fn()
+        runs.append((time.perf_counter() - t0, prof, rank))
+    secs = [r[0] for r in runs]
+    med = sorted(runs, key=lambda r: r[0])[len(runs) // 2]
+    return {"rank": med[2], "ranks_agree": len({r[2] for r in runs}) == 1, "seconds_first_call": secs[0],
+            "seconds_median": statistics.median(secs), "seconds_min": min(secs), "seconds_all": secs, "split_of_median_call": med[1]}
+
+
+def sparse_path_probe(torch, spasm_amd, workloads, dev, name="mk14.b4", steps=3, paths=("default", "dense image", "row by row"), calls=3):
     """The flow GL7d19 takes (a sparse round on a wide Schur complement, then the dense tail), on a matrix of the same
-    collection that can be generated offline: mk14.b4, 945,945 x 315,315 -- a STAND-IN, not a BASELINE config.  Its first
-    Schur complement (673,000 rows x 42,000 columns, 3.7 % dense, 1.06e9 entries) is computed sparse with default options.
-    Reports that Schur complement on the device-level API (the way the headline step is measured) through the path the
-    library takes by default -- since round 3 the back-substituted image, whose apply kernel goes through rows wider than
-    the LDS in segments -- and through the row-by-row kernels (what a factor too wide for an image gets: the row-group
-    kernel and its counters), then the whole spasm_hip_echelonize call with its time split."""
+    collection that can be generated offline -- a STAND-IN, not a BASELINE config: mk14.b4 (945,945 x 315,315; its first
+    Schur complement is 673,000 x 42,000, ~2 % dense, 5-7e8 entries depending on the pivots of the run) or, at the size of
+    GL7d19, mk15.b4 (2,837,835 x 675,675; 2.2 M x 71,000, 1.4-1.9e9 entries).  Reports that Schur complement on the
+    device-level API (the way the headline step is measured) through the path the library takes by itself -- since round 4
+    the SPARSE image: R = U_pp^-1 U_pn as sparse fragments, sparse_image.hip -- and, where they exist for the factor, through
+    the dense image and the row-by-row kernels; then whole spasm_hip_echelonize calls with their time split."""
     t0 = time.perf_counter()
     A, rows, F, source = workloads.round0(name, PRIME, threads=0)
     t_prep = time.perf_counter() - t0
     dA = spasm_amd.DeviceCsr.from_host(A, dev)
     drows = torch.from_numpy(np.ascontiguousarray(rows)).to(dev)
+    ENV = {"default": {}, "dense image": {"SPASM_HIP_SPARSE_IMAGE": "0", "SPASM_HIP_BACKSOLVE": "1"},
+           "row by row": {"SPASM_HIP_SPARSE_IMAGE": "0", "SPASM_HIP_BACKSOLVE": "0", "SPASM_HIP_SCRATCH_GB": "24"}}
+    pool_hint = [1 << 30]
 
     def measure(env):
         os.environ.update(env)
@@ -178,79 +202,92 @@ def sparse_path_probe(torch, spasm_amd, workloads, dev, name="mk14.b4", steps=3)
             dF = spasm_amd.DeviceFact(F)
             torch.cuda.synchronize()
             image_ms = 1e3 * (time.perf_counter() - t0)
-            pool = 1 << 30
             while True:
-                W = spasm_amd.SchurWorkspace(len(rows), A.m, pool)
+                W = spasm_amd.SchurWorkspace(len(rows), A.m, pool_hint[0])
                 _, st = spasm_amd.dschur(dA, drows, dF, W, fetch=False)
                 if st.status == 0:
                     break
                 W.close()
-                pool *= 2
+                pool_hint[0] *= 2
+            all_ms = []
             best = None
             for _ in range(steps):
                 dF.forget()                      # (a step builds what it needs: the image R is part of it)
                 _, st = spasm_amd.dschur(dA, drows, dF, W, fetch=False)
+                all_ms.append(st.ms_total)
                 if best is None or st.ms_total < best.ms_total:
-                    best = st
+                    best = type(st).from_buffer_copy(st)
+            census = dF.sparse_image_census() if best.used_sparse_image else None
             levels = dF.levels
             W.close()
             dF.close()
-            return best, image_ms, levels
+            return best, all_ms, image_ms, levels, census
         finally:
             for k in env:
                 os.environ.pop(k, None)
 
-    st, image_ms, levels = measure({})
+    r, Sm = int(F.U.n), int(A.m - F.U.n)
     out = {"what": "%s (%dx%d, %d nnz), STAND-IN for the GL7d19 class: round-0 Schur complement of %d rows w.r.t. %d pivots, "
-                   "%d non-pivotal columns, device-level API, default path" % (name, A.n, A.m, A.nnz, len(rows), F.U.n, A.m - F.U.n),
-           "rows": len(rows), "ms_per_step": st.ms_total, "rows_per_s": len(rows) / (st.ms_total * 1e-3),
-           "path": "back-substituted factor image" if st.used_backsolve else "row by row",
-           "levels": levels, "schur_nnz": int(st.nnz), "schur_density": st.nnz / (len(rows) * float(A.m - F.U.n)),
-           "factor_image_ms": image_ms, "prepare_s": t_prep}
-    if st.used_backsolve:
-        kern = {st.kernel.decode(): {"ms": st.ms_backsolve, "algorithmic_bytes": int(st.bytes_backsolve)},
-                st.kernel_other.decode(): {"ms": st.ms_apply, "algorithmic_bytes": int(st.bytes_apply)},
-                st.kernel_expand.decode(): {"ms": st.ms_expand, "algorithmic_bytes": int(st.bytes_expand)}}
-        for k in kern.values():
-            if not k["ms"] > 0:                  # (staged output in several slices: the expansions run between the slices of the apply
-                k["ms"] = None                   #  kernel and are inside its time)
-            k["GB_per_s"] = k["algorithmic_bytes"] / (k["ms"] * 1e-3) / 1e9 if k["ms"] else None
-            k["frac"] = k["GB_per_s"] / HBM_PEAK_GBS if k["GB_per_s"] else None
-        out["kernels"] = kern
-    # the row-by-row kernels on the same batch, with the one-shot budget of the host-pointer entry point (24 GB of accumulator
-    # slices), so that the numbers are those of a round inside spasm_hip_echelonize
-    st, _, _ = measure({"SPASM_HIP_BACKSOLVE": "0", "SPASM_HIP_SCRATCH_GB": "24"})
-    kernel = st.kernel.decode()
-    k_ms = st.ms_group if st.used_group_kernel and not st.group_aborted else st.ms_tier2
-    algo = 16 * st.entries_streamed + 8 * (st.input_entries + st.nnz) + 20 * st.eliminations + 20 * st.rows
-    rb = {"what": "same batch with SPASM_HIP_BACKSOLVE=0, 24 GB of accumulator slices", "ms_per_step": st.ms_total,
-          "rows_per_s": len(rows) / (st.ms_total * 1e-3), "same_nnz": int(st.nnz) == out["schur_nnz"],
-          "kernel": kernel, "kernel_ms": k_ms, "gather_ms": st.ms_finalize, "gave_up": bool(st.group_aborted),
-          "eliminations": int(st.eliminations), "entries_streamed": int(st.entries_streamed), "group_pivots": int(st.group_pivots),
-          "lane_efficiency": (st.eliminations / (64.0 * st.group_pivots)) if st.group_pivots else None,
-          # one 256-byte no-return atomic instruction per (applied pivot, entry of its row) = 4 requests of 64 B
-          "atomic_requests_per_s": (4.0 * st.entries_streamed / 64.0 / max(st.eliminations / (64.0 * st.group_pivots), 1e-9) / (k_ms * 1e-3))
-          if st.group_pivots else None,
-          "slices_in_flight": st.group_slots, "slices_wanted": st.group_slots_wanted, "waves_per_group": st.group_waves,
-          "slice_bytes": int(st.group_slot_bytes),
-          "effective_bytes": int(algo), "effective_frac": algo / (k_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
-          "effective_note": "bytes the reference's algorithm moves on its dense x (DESIGN.md section 4); the row-group kernel shares a 256-B "
-                            "line among the 64 rows of a group, so this is not HBM traffic"}
-    tr = quoted_traffic(kernel, name, len(rows))
-    if tr[0]:
-        rb.update({"traffic": tr[0], "hbm_frac": tr[0] / (k_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, "traffic_source": tr[2]})
-    out["row_by_row"] = rb
+                   "%d non-pivotal columns, device-level API" % (name, A.n, A.m, A.nnz, len(rows), r, Sm),
+           "rows": len(rows), "prepare_s": t_prep, "paths": {}}
+
+    def kernel_entry(ms, by):
+        gbs = by / (ms * 1e-3) / 1e9 if ms and ms > 0 else None
+        return {"ms": ms if ms and ms > 0 else None, "algorithmic_bytes": int(by), "GB_per_s": gbs, "frac": gbs / HBM_PEAK_GBS if gbs else None}
+
+    for path in paths:
+        st, all_ms, image_ms, levels, census = measure(ENV[path])
+        which = "sparse image" if st.used_sparse_image else "dense image" if st.used_backsolve else "row by row"
+        if path == "dense image" and not st.used_backsolve:
+            out["paths"][path] = {"status": "the factor is not eligible for the dense image (%d x %d entries)" % (r, Sm)}
+            continue
+        e = {"took": which, "ms_per_step": st.ms_total, "ms_all": all_ms, "rows_per_s": len(rows) / (st.ms_total * 1e-3), "schur_nnz": int(st.nnz),
+             "schur_density": st.nnz / (len(rows) * float(Sm)), "factor_image_ms": image_ms, "levels": levels}
+        if st.used_sparse_image:
+            e["kernels"] = {"sp_build_kernel": kernel_entry(st.ms_sparse_build, st.bytes_sparse_build),
+                            "sp_apply_kernel": kernel_entry(st.ms_sparse_apply, st.bytes_sparse_apply),
+                            "scan + sp_gather_kernel": kernel_entry(st.ms_sparse_gather, st.bytes_sparse_gather)}
+            e["multiply_adds"] = {"build": int(st.sparse_image_ops_build), "rows_of_S": int(st.sparse_image_ops_apply)}
+            e["build_us_per_level"] = 1e3 * st.ms_sparse_build / max(1, st.sparse_image_levels)
+            if census:
+                tiles = r * ((Sm + 63) // 64)
+                e["fill_of_R"] = {"entries": census["entries"], "fraction": census["entries"] / (float(r) * Sm),
+                                  "entries_per_row": census["entries"] / float(r), "occupied_64_column_tiles": census["tiles64"],
+                                  "tile_fraction": census["tiles64"] / float(tiles),
+                                  "non_empty_fragments": census["fragments"], "fragment_fraction": census["fragments"] / float(max(1, census["pairs"]))}
+        elif st.used_backsolve:
+            e["kernels"] = {st.kernel.decode(): kernel_entry(st.ms_backsolve, st.bytes_backsolve),
+                            st.kernel_other.decode(): kernel_entry(st.ms_apply, st.bytes_apply)}
+            if st.ms_expand > 0:
+                e["kernels"][st.kernel_expand.decode()] = kernel_entry(st.ms_expand, st.bytes_expand)
+        else:
+            kernel = st.kernel.decode()
+            k_ms = st.ms_group if st.used_group_kernel and not st.group_aborted else st.ms_tier2
+            algo = 16 * st.entries_streamed + 8 * (st.input_entries + st.nnz) + 20 * st.eliminations + 20 * st.rows
+            e.update({"kernel": kernel, "kernel_ms": k_ms, "gather_ms": st.ms_finalize, "gave_up": bool(st.group_aborted),
+                      "eliminations": int(st.eliminations), "entries_streamed": int(st.entries_streamed), "group_pivots": int(st.group_pivots),
+                      "lane_efficiency": (st.eliminations / (64.0 * st.group_pivots)) if st.group_pivots else None,
+                      "slices_in_flight": st.group_slots, "slices_wanted": st.group_slots_wanted, "waves_per_group": st.group_waves,
+                      "slice_bytes": int(st.group_slot_bytes), "effective_bytes": int(algo),
+                      "effective_frac": algo / (k_ms * 1e-3) / 1e9 / HBM_PEAK_GBS if k_ms > 0 else None,
+                      "effective_note": "bytes the reference's algorithm moves on its dense x (DESIGN.md section 4); the row-group kernel "
+                                        "shares a 256-B line among the 64 rows of a group, so this is not HBM traffic"})
+            tr = quoted_traffic(kernel, name, len(rows))
+            if tr[0] and k_ms > 0:
+                e.update({"traffic": tr[0], "hbm_frac": tr[0] / (k_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, "traffic_source": tr[2]})
+        out["paths"][path] = e
+    nnzs = {e["schur_nnz"] for e in out["paths"].values() if "schur_nnz" in e}
+    out["same_nnz_on_every_path"] = len(nnzs) == 1
+    dflt = out["paths"].get("default", {})
+    out.update({k: dflt.get(k) for k in ("ms_per_step", "rows_per_s", "schur_nnz", "schur_density", "took")})
     del dA, drows
     torch.cuda.empty_cache()
     os.environ.pop("SPASM_HIP_THREADS", None)
-    runs = []
-    for _ in range(3):
-        t0 = time.perf_counter()
+
+    def call():
         fact = spasm_amd.echelonize(A)
-        runs.append((time.perf_counter() - t0, spasm_amd.echelonize_profile(), int(fact.U.n)))
-    best = min(runs, key=lambda r: r[0])
-    out["end_to_end"] = {"what": "spasm_hip_echelonize, default options, 3 calls", "rank": best[2], "ranks_agree": len({r[2] for r in runs}) == 1,
-                         "seconds_all": [r[0] for r in runs], "split_of_best_call": best[1]}
+        return spasm_amd.echelonize_profile(), int(fact.U.n)
+    out["end_to_end"] = dict(_calls(call, calls), what="spasm_hip_echelonize, default options, %d calls" % calls)
     return out
 
 
@@ -264,15 +301,10 @@ def stand_in_runs(spasm_amd, workloads):
         for t, a in enumerate(info["rank_args"]):
             if a == "--dense-threshold":
                 opts.sparsity_threshold = float(info["rank_args"][t + 1])
-        runs = []
-        for _ in range(3):
-            t0 = time.perf_counter()
+        def call():
             fact = spasm_amd.echelonize(A, opts)
-            runs.append((time.perf_counter() - t0, spasm_amd.echelonize_profile(), int(fact.U.n)))
-        best = min(runs, key=lambda r: r[0])
-        out.append({"name": name, "stand_in_for": info["for"], "shape": [A.n, A.m], "nnz": int(A.nnz), "options": " ".join(info["rank_args"]),
-                    "rank": best[2], "ranks_agree": len({r[2] for r in runs}) == 1, "seconds": best[0], "seconds_all": [r[0] for r in runs],
-                    "split": best[1]})
+            return spasm_amd.echelonize_profile(), int(fact.U.n)
+        out.append(dict(_calls(call, 3), name=name, stand_in_for=info["for"], shape=[A.n, A.m], nnz=int(A.nnz), options=" ".join(info["rank_args"])))
     return out
 
 
@@ -421,7 +453,10 @@ def main():
         t0 = time.perf_counter()
         for _ in range(count):
             st = step()
-            if st.used_backsolve:
+            if st.used_sparse_image:
+                parts = (("sp_build_kernel", st.ms_sparse_build, st.bytes_sparse_build), ("sp_apply_kernel", st.ms_sparse_apply, st.bytes_sparse_apply),
+                         ("sp_gather_kernel", st.ms_sparse_gather, st.bytes_sparse_gather))
+            elif st.used_backsolve:
                 names = (st.kernel.decode(), st.kernel_other.decode())
                 build_name = [x for x in names if x.startswith("backsolve")][0]
                 apply_name = [x for x in names if x.startswith("bs_apply")][0]
@@ -436,7 +471,7 @@ def main():
                 name = st.kernel.decode()
                 parts = ((name, st.ms_group if st.used_group_kernel and not st.group_aborted else st.ms_tier2, algo),
                          ("schur_lds_kernel<1024>", st.ms_tier0, 0), ("schur_lds_kernel<8192>", st.ms_tier1, 0))
-            if st.ms_finalize > 0.05:          # (the back-substituted path writes S in its final place: no gather pass)
+            if st.ms_finalize > 0.05 and not st.used_sparse_image:          # (the image paths write S in its final place: no gather pass)
                 parts += (("scan_* + gather_rows_kernel", st.ms_finalize, 16 * st.nnz + 12 * st.rows),)
             for name, m_, b_ in parts:
                 ms[name] = ms.get(name, 0.0) + m_
@@ -521,7 +556,7 @@ def main():
                                                                    total_rows, F.U.n),
                        "rows_per_step": total_rows, "pivots": int(F.U.n), "levels": dF.levels,
                        "non_pivotal_columns": int(A_full.m - F_full.U.n), "schur_nnz": total_nnz_all,
-                       "path": "back-substituted factor image" if st.used_backsolve else "row-by-row elimination",
+                       "path": "sparse image" if st.used_sparse_image else "back-substituted factor image" if st.used_backsolve else "row-by-row elimination",
                        "why_this_workload": why,
                        "sharding": ("columns: each of %d rank(s) reduces ALL rows on its slab of the non-pivotal columns (%d of %d here), no "
                                     "replicated image, row lengths all-gathered (whole Schur complement: %d entries)"
@@ -572,17 +607,11 @@ def main():
                     opts.sparsity_threshold = float(rank_args[t + 1])
                 if a == "--no-greedy-pivot-search":
                     opts.enable_greedy_pivot_search = False
-            runs = []
-            for _ in range(5):
-                t0 = time.perf_counter()
+            def call():
                 fact = spasm_amd.echelonize(A_full, opts)
-                runs.append((time.perf_counter() - t0, spasm_amd.echelonize_profile(), int(fact.U.n)))
-            secs = [r[0] for r in runs]
-            med = sorted(runs, key=lambda r: r[0])[len(runs) // 2]
-            out["end_to_end"] = {"what": "spasm_hip_echelonize on the same matrix, options of the config (%s), 5 calls" % (" ".join(rank_args) or "defaults"),
-                                 "rank": med[2], "ranks_agree": len({r[2] for r in runs}) == 1,
-                                 "seconds_min": min(secs), "seconds_median": statistics.median(secs), "seconds_all": secs,
-                                 "split_of_median_call": med[1]}
+                return spasm_amd.echelonize_profile(), int(fact.U.n)
+            out["end_to_end"] = dict(_calls(call, 5), what="spasm_hip_echelonize on the same matrix, options of the config (%s), 5 calls"
+                                                           % (" ".join(rank_args) or "defaults"))
             # north_star keeps the pivot selection on the host; the library runs its greedy search on the device when it has
             # one.  The same call with the search where north_star puts it:
             os.environ["SPASM_HIP_PIVOT_SEARCH"] = "host"
@@ -596,6 +625,8 @@ def main():
                 os.environ.pop("SPASM_HIP_PIVOT_SEARCH", None)
         if extras and args.workload == "mk13.b5":
             out["sparse_path"] = sparse_path_probe(torch, spasm_amd, workloads, dev)
+            # the same at the size of GL7d19 (no dense image exists for this factor; the row-by-row kernels are left out: minutes)
+            out["at_scale"] = sparse_path_probe(torch, spasm_amd, workloads, dev, name="mk15.b4", steps=2, paths=("default",), calls=2)
             out["stand_ins"] = stand_in_runs(spasm_amd, workloads)
         out["configs"] = [{"name": c["name"], "status": status, "what": c["what"],
                            "bench": "python bench.py --workload %s" % c["name"],

@@ -324,6 +324,10 @@ void spasm_hip_dschur_row_pointers(const spasm_hip_dwork *W, i64 *d_Sp, void *st
 
 /* dense rows of the Schur complement, left on the device: d_S is nrows x Sm
  * (Sm = m - rank), row-major with leading dimension ldS, values in [0, p). */
+/* test hook: N pseudo-random combinations of rows of A (w > 0: of w random rows each; w <= 0: of all nrows rows), as the dense /
+ * low-rank finish forms them on the device, N x m residues in [0, p) written to the host array `out` */
+void spasm_hip_debug_combine(const struct spasm_csr *A, const int *rows, int nrows, int N, int w, uint64_t salt, u32 *out);
+
 int spasm_hip_dschur_dense(const spasm_hip_dcsr *A, const int *d_rows, int nrows, const spasm_hip_dfact *F,
                            spasm_hip_dwork *W, u32 *d_S, i64 ldS, void *stream);
 

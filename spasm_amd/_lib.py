@@ -71,6 +71,7 @@ def lib():
         "spasm_hip_schur_dense": (None, [pcsr, pint, ci, pint, plu, vp, ci, pint, pint]),
         "spasm_hip_ffpack_rref": (ci, [i64, ci, ci, vp, ci, ci, C.POINTER(C.c_size_t)]),
         "spasm_hip_ffpack_LU": (ci, [i64, ci, ci, vp, ci, ci, C.POINTER(C.c_size_t), C.POINTER(C.c_size_t)]),
+        "spasm_hip_debug_combine": (None, [pcsr, pint, ci, ci, ci, C.c_uint64, vp]),
         "spasm_hip_dschur_dense": (ci, [C.POINTER(CDcsr), vp, ci, vp, vp, vp, i64, vp]),
         "spasm_hip_drref": (ci, [i64, ci, ci, vp, i64, vp, vp]),
         "spasm_hip_dechelon_extend": (ci, [i64, ci, vp, i64, ci, ci, vp, vp]),

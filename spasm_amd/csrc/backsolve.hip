@@ -1998,7 +1998,7 @@ void backsolve_build(const spasm_hip_dfact *F, hipStream_t stream)
 	if (env_bs("SPASM_HIP_BS_CHECK", 0) && b.sparse_init && bytes < ((size_t) 1 << 30)) {
 		// debugging aid: the same build with R pre-filled (the other way of starting the rows), compared entry by entry
 		void *R2 = nullptr;
-		HIP_CHECK(hipMalloc(&R2, bytes));
+		HIP_CHECK(sh::malloc_or_trim(&R2, bytes));
 		BsArgs c = b;
 		c.R = R2;
 		c.sparse_init = 0;

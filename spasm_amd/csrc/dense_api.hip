@@ -161,7 +161,7 @@ static int dschur_dense_impl(const spasm_hip_dcsr *A, const int *d_rows, int nro
 	if (need > W->scratch_bytes) {
 		if (W->d_scratch != nullptr)
 			sh::big_free(W->d_scratch);
-		HIP_CHECK(hipMalloc((void **) &W->d_scratch, (size_t) need));
+		HIP_CHECK(sh::malloc_or_trim((void **) &W->d_scratch, (size_t) need));
 		W->scratch_bytes = need;
 		HIP_CHECK(hipMemsetAsync(W->d_scratch, 0, (size_t) need, stream));
 	}
@@ -214,11 +214,11 @@ static int dschur_dense_impl(const spasm_hip_dcsr *A, const int *d_rows, int nro
 			if (W->sortbuf_ints < need) {
 				if (W->d_sortbuf != nullptr)
 					sh::big_free(W->d_sortbuf);
-				HIP_CHECK(hipMalloc((void **) &W->d_sortbuf, (size_t) need * sizeof(int)));
+				HIP_CHECK(sh::malloc_or_trim((void **) &W->d_sortbuf, (size_t) need * sizeof(int)));
 				W->sortbuf_ints = need;
 			}
 			if (W->d_order == nullptr)
-				HIP_CHECK(hipMalloc((void **) &W->d_order, (size_t) W->max_rows * sizeof(int)));
+				HIP_CHECK(sh::malloc_or_trim((void **) &W->d_order, (size_t) W->max_rows * sizeof(int)));
 			launch_regroup_rows(a, W->d_sortbuf, W->d_order, stream);
 			a.order = W->d_order;
 		}
@@ -361,7 +361,7 @@ bool finish_on_device(const struct spasm_csr *A, const int *p, int n, struct spa
 	i64 cap_rows = std::min<i64>((i64) std::min(n, Sm0) + maxblock, (i64) 3 * maxblock);
 	{
 		size_t free_b = 0, total_b = 0;
-		HIP_CHECK(hipMemGetInfo(&free_b, &total_b));
+		sh::mem_info(&free_b, &total_b);
 		if ((size_t) cap_rows * (size_t) ld * sizeof(u32) > free_b / 2) {
 			spasm_hip_dwork_destroy(W);
 			sh::big_free(drows);
@@ -376,7 +376,7 @@ bool finish_on_device(const struct spasm_csr *A, const int *p, int n, struct spa
 			return true;
 		const i64 want = std::min<i64>((i64) std::min(n, Sm0) + maxblock, std::max<i64>(2 * cap_rows, (i64) k_now + rows_added));
 		size_t free_b = 0, total_b = 0;
-		HIP_CHECK(hipMemGetInfo(&free_b, &total_b));
+		sh::mem_info(&free_b, &total_b);
 		if ((size_t) want * (size_t) ld * sizeof(u32) > free_b - free_b / 8) {
 			out_of_memory = true;
 			return false;
@@ -827,6 +827,34 @@ int spasm_hip_ffpack_LU(i64 prime, int n, int m, void *A, int ldA, spasm_datatyp
 		}
 	logmsg("[LU/hip] %d x %d mod %" PRId64 ": rank %d [%.1fs]\n", n, m, prime, r, wtime() - t0);
 	return r;
+}
+
+
+// Test hook: the N combinations launch_combine forms of the rows rows[0..nrows) of the host matrix A (w > 0: of w random rows
+// each; w <= 0: of all the rows -- the kernels of the completion test of a low-rank finish), as N x m residues in [0, p) on the
+// host.  The coefficients come from the counter-based generator of dense_kernels.hip (splitmix64 of (salt, k, t)), which
+// tests/test_gpu_dense.py restates in numpy: the sums are checked against a product computed without this library.
+void spasm_hip_debug_combine(const struct spasm_csr *A, const int *rows, int nrows, int N, int w, uint64_t salt, u32 *out)
+{
+	if (spasm_hip_device_count() == 0)
+		die("spasm_hip_debug_combine: no HIP device (this library has no CPU path)");
+	hipStream_t stream = nullptr;
+	const int m = A->m;
+	DeviceMatrix dA(A, stream);
+	int *d_rows = static_cast<int *>(sh::big_alloc((size_t) (nrows > 0 ? nrows : 1) * sizeof(int)));
+	HIP_CHECK(hipMemcpyAsync(d_rows, rows, (size_t) nrows * sizeof(int), hipMemcpyHostToDevice, stream));
+	const size_t count = (size_t) N * (size_t) m;
+	unsigned long long *dY = static_cast<unsigned long long *>(sh::big_alloc(count * sizeof(unsigned long long)));
+	HIP_CHECK(hipMemsetAsync(dY, 0, count * sizeof(unsigned long long), stream));
+	launch_combine(dA.p, dA.j, dA.x, d_rows, nrows, N, w, m, salt, dY, mont_setup(A->field->p), stream);
+	std::vector<unsigned long long> h(count);
+	HIP_CHECK(hipMemcpyAsync(h.data(), dY, count * sizeof(unsigned long long), hipMemcpyDeviceToHost, stream));
+	HIP_CHECK(hipStreamSynchronize(stream));
+	const unsigned long long p = (unsigned long long) A->field->p;
+	for (size_t t = 0; t < count; t++)
+		out[t] = (u32) (h[t] % p);
+	sh::big_free(dY);
+	sh::big_free(d_rows);
 }
 
 }  // extern "C"

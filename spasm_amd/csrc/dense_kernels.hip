@@ -1697,7 +1697,7 @@ int device_rref(int64_t prime, int n, int m, uint32_t *dA, int64_t ld, int *d_pi
 	std::vector<void *> owned;
 	auto ws_malloc = [&](void **ptr, size_t bytes) {
 		if (!use_cache || bytes > ((size_t) 4 << 30)) {
-			HIP_CHECK(hipMalloc(ptr, bytes));
+			HIP_CHECK(sh::malloc_or_trim(ptr, bytes));
 			owned.push_back(*ptr);
 			return;
 		}
@@ -1707,7 +1707,7 @@ int device_rref(int64_t prime, int n, int m, uint32_t *dA, int64_t ld, int *d_pi
 		if (sl.second < bytes) {
 			sh::big_free(sl.first);
 			sl.second = bytes + bytes / 4;
-			HIP_CHECK(hipMalloc(&sl.first, sl.second));
+			HIP_CHECK(sh::malloc_or_trim(&sl.first, sl.second));
 		}
 		*ptr = sl.first;
 	};
@@ -3049,7 +3049,7 @@ void launch_combine(const int64_t *Ap, const int *Aj, const int *Ax, const int *
 			configured = lds;
 		}
 		int *d_flag = nullptr;
-		HIP_CHECK(hipMalloc((void **) &d_flag, sizeof(int)));
+		HIP_CHECK(sh::malloc_or_trim((void **) &d_flag, sizeof(int)));
 		HIP_CHECK(hipMemsetAsync(d_flag, 0, sizeof(int), stream));
 		hipLaunchKernelGGL(combine_all_rows_blocked_kernel, dim3((unsigned) ((nrows + CB_ROWS - 1) / CB_ROWS)), dim3(CB_THREADS), lds, stream, Ap, Aj, Ax, rows, nrows,
 		                   N, m, salt, Y, d_flag, to_dev(M));
@@ -3474,7 +3474,7 @@ int device_lu(int64_t prime, int n, int m, uint32_t *dA, int64_t ld, int *dP, in
 	const Mont M = mont_setup(prime);
 	const MontDev F = to_dev(M);
 	int *d_piv = nullptr;
-	HIP_CHECK(hipMalloc((void **) &d_piv, 64));
+	HIP_CHECK(sh::malloc_or_trim((void **) &d_piv, 64));
 	int t = 0;
 	int mlast = m;                   // columns [mlast, m) are known to be zero below the diagonal block
 	const int rmax = (n < m) ? n : m;
@@ -3485,9 +3485,9 @@ int device_lu(int64_t prime, int n, int m, uint32_t *dA, int64_t ld, int *dP, in
 	signed char *lu_M8 = nullptr, *lu_B8 = nullptr;
 	int *lu_perm = nullptr;
 	if (blocked) {
-		HIP_CHECK(hipMalloc((void **) &lu_M8, (size_t) 2 * (size_t) n * 64));
-		HIP_CHECK(hipMalloc((void **) &lu_B8, (size_t) 2 * (size_t) m * 64));
-		HIP_CHECK(hipMalloc((void **) &lu_perm, NB * sizeof(int)));
+		HIP_CHECK(sh::malloc_or_trim((void **) &lu_M8, (size_t) 2 * (size_t) n * 64));
+		HIP_CHECK(sh::malloc_or_trim((void **) &lu_B8, (size_t) 2 * (size_t) m * 64));
+		HIP_CHECK(sh::malloc_or_trim((void **) &lu_perm, NB * sizeof(int)));
 	}
 	int block_cooldown = 0;          // after a block that could not be factored: single steps before the next attempt
 	while (t < rmax && t < mlast) {

@@ -55,7 +55,7 @@ void comm_bcast_host(spasm_hip_comm *c, void *buf, size_t bytes, int root)
 	if (c->stage_bytes < bytes) {
 		if (c->d_stage != nullptr)
 			(void) hipFree(c->d_stage);
-		HIP_CHECK(hipMalloc(&c->d_stage, bytes));
+		HIP_CHECK(sh::malloc_or_trim(&c->d_stage, bytes));
 		c->stage_bytes = bytes;
 	}
 	if (c->rank == root)
@@ -95,7 +95,7 @@ spasm_hip_comm *spasm_hip_comm_create(const void *id, int rank, int world)
 	std::memcpy(&u, id, sizeof(u));
 	NCCL_CHECK(ncclCommInitRank(&c->comm, world, u, rank));
 	HIP_CHECK(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
-	HIP_CHECK(hipMalloc((void **) &c->d_sizes, (size_t) 2 * world * sizeof(int64_t)));
+	HIP_CHECK(sh::malloc_or_trim((void **) &c->d_sizes, (size_t) 2 * world * sizeof(int64_t)));
 	return c;
 }
 

@@ -675,13 +675,28 @@ int device_acyclic_greedy(const struct spasm_csr *A, int *pinv, int *qinv)
 			const int col = (int) (uint32_t) ent[t];
 			if (state == PS_ABORTED)
 				continue;
-			if (state != PS_ACCEPTED || rows[t] < 0 || rows[t] >= n || col < 0 || col >= m || pinv[rows[t]] != -1 || qinv[col] != -1)
-				die("device pivot search: ticket %d = (row %d, column %d, state %llu) is not a new pivot", t, rows[t], col, state);
+			if (state != PS_ACCEPTED || rows[t] < 0 || rows[t] >= n || col < 0 || col >= m || pinv[rows[t]] != -1 || qinv[col] != -1) {
+				// an inconsistent journal (a ticket left undecided, a row or a column taken twice): nothing of this search is
+				// kept -- the pivots applied so far are taken back and the host search runs (the caller sees -1)
+				std::fprintf(stderr, "[pivots] device search: ticket %d = (row %d, column %d, state %llu) is not a new pivot (a bug: please report); "
+				                     "the %d pivots of this search are discarded, searching on the host\n", t, rows[t], col, (unsigned long long) state, found);
+				for (int u = 0; u < t; u++) {
+					if ((ent[u] >> 32) != PS_ACCEPTED)
+						continue;
+					const int cu = (int) (uint32_t) ent[u];
+					if (rows[u] >= 0 && rows[u] < n && cu >= 0 && cu < m && pinv[rows[u]] == cu && qinv[cu] == rows[u]) {
+						pinv[rows[u]] = -1;
+						qinv[cu] = -1;
+					}
+				}
+				found = -1;
+				break;
+			}
 			pinv[rows[t]] = col;
 			qinv[col] = rows[t];
 			found += 1;
 		}
-		if (std::getenv("SPASM_HIP_PIVOT_STATS"))
+		if (found >= 0 && std::getenv("SPASM_HIP_PIVOT_STATS"))
 			logmsg("[pivots] device: %d searches in flight (%d per CU, %zu bytes of LDS each%s), %llu pivot rows visited in %llu steps, %d tickets for %d pivots, "
 			       "%d rows given up (FIFO full) [%.3fs: %.3f upload of A + allocations, %.3f kernels, %.3f journal; in the search kernel the first wave "
 			       "ran out of rows after %.1f ms, the last one left after %.1f ms, the longest search of one row took %.1f ms; "

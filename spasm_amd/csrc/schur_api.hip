@@ -155,6 +155,28 @@ void *big_alloc(size_t bytes)
 	return ptr;
 }
 
+// hipMalloc for the few buffers that do not go through the cache (they are freed with hipFree by their owners): a failure
+// first returns what the cache parks, then tries again
+hipError_t malloc_or_trim(void **ptr, size_t bytes)
+{
+	hipError_t e = hipMalloc(ptr, bytes);
+	if (e != hipSuccess) {
+		(void) hipGetLastError();
+		big_trim(0);
+		e = hipMalloc(ptr, bytes);
+	}
+	return e;
+}
+
+// free / total device memory as the decisions of this library should see them: what the block cache parks counts as free
+// (it is given back on demand)
+void mem_info(size_t *free_b, size_t *total_b)
+{
+	HIP_CHECK(hipMemGetInfo(free_b, total_b));
+	std::lock_guard<std::mutex> guard(g_big.mutex);
+	*free_b += g_big.cached + g_big.small_cached;
+}
+
 void big_free(void *ptr)
 {
 	if (ptr == nullptr)
@@ -316,7 +338,13 @@ void resident_end()
 	// 1.0-2.3 s instead of 0.55 (keeping 32 or 64 GB did not help: whatever is handed back comes back slowly).
 	// spasm_hip_release_cached_memory() gives everything back; a failed hipMalloc of the library's own does too (big_alloc).
 	if (env_int("SPASM_HIP_KEEP_BLOCKS", 0) == 0)
-		big_trim((size_t) std::max(0, env_int("SPASM_HIP_KEEP_GB", 96)) << 30);
+		{
+		// (default: a quarter of the device memory, at most the cap of the cache)
+		size_t free_b = 0, total_b = 0;
+		HIP_CHECK(hipMemGetInfo(&free_b, &total_b));
+		const int dflt = (int) std::min<size_t>(96, (total_b >> 30) / 4);
+		big_trim((size_t) std::max(0, env_int("SPASM_HIP_KEEP_GB", dflt)) << 30);
+	}
 }
 
 void resident_counters(i64 *uploads, i64 *hits)
@@ -386,7 +414,7 @@ int resident_fl_census(const struct spasm_csr *A)
 			const int n = A->n, m = A->m;
 			const int nwords = (m + 31) / 32 + 1;
 			uint32_t *bm = nullptr;
-			HIP_CHECK(hipMalloc((void **) &bm, ((size_t) nwords + 1) * sizeof(uint32_t)));
+			HIP_CHECK(sh::malloc_or_trim((void **) &bm, ((size_t) nwords + 1) * sizeof(uint32_t)));
 			HIP_CHECK(hipMemset(bm, 0, ((size_t) nwords + 1) * sizeof(uint32_t)));
 			if (n > 0)
 				hipLaunchKernelGGL(fl_census_kernel, dim3((unsigned) (((i64) n * 64 + 255) / 256)), dim3(256), 0, nullptr, e.p, e.j, n, bm);
@@ -413,9 +441,9 @@ DeviceMatrix::DeviceMatrix(const struct spasm_csr *A, hipStream_t stream)
 			g_resident_hits += 1;
 			return;
 		}
-	HIP_CHECK(hipMalloc((void **) &p, ((size_t) A->n + 1) * sizeof(i64)));
-	HIP_CHECK(hipMalloc((void **) &j, (size_t) (nnz > 0 ? nnz : 1) * sizeof(int)));
-	HIP_CHECK(hipMalloc((void **) &x, (size_t) (nnz > 0 ? nnz : 1) * sizeof(int)));
+	HIP_CHECK(sh::malloc_or_trim((void **) &p, ((size_t) A->n + 1) * sizeof(i64)));
+	HIP_CHECK(sh::malloc_or_trim((void **) &j, (size_t) (nnz > 0 ? nnz : 1) * sizeof(int)));
+	HIP_CHECK(sh::malloc_or_trim((void **) &x, (size_t) (nnz > 0 ? nnz : 1) * sizeof(int)));
 	HIP_CHECK(hipMemcpyAsync(p, A->p, ((size_t) A->n + 1) * sizeof(i64), hipMemcpyHostToDevice, stream));
 	if (nnz > 0) {
 		HIP_CHECK(hipMemcpyAsync(j, A->j, (size_t) nnz * sizeof(int), hipMemcpyHostToDevice, stream));
@@ -535,7 +563,7 @@ bool backsolve_wanted(const spasm_hip_dfact *F, bool other_path_forced, int nrow
 		return false;
 	if (F->bs.d_R == nullptr) {
 		size_t free_b = 0, total_b = 0;
-		HIP_CHECK(hipMemGetInfo(&free_b, &total_b));
+		sh::mem_info(&free_b, &total_b);
 		if ((size_t) F->bs.r * (size_t) F->bs.ldR * 4 > free_b / 2)
 			return false;
 	}
@@ -1199,7 +1227,7 @@ int dschur_impl(const spasm_hip_dcsr *A, const int *d_rows, int nrows, const spa
 		// accumulator slices may take up to half of the free HBM (288 GB parts: be generous), or what
 		// SPASM_HIP_SCRATCH_GB says
 		size_t free_b = 0, total_b = 0;
-		HIP_CHECK(hipMemGetInfo(&free_b, &total_b));
+		sh::mem_info(&free_b, &total_b);
 		i64 budget = (i64) ((free_b + (size_t) W->scratch_bytes) / 2);
 		if (W->scratch_budget > 0)
 			budget = std::min(budget, std::max(W->scratch_budget, W->scratch_bytes));
@@ -1240,7 +1268,7 @@ int dschur_impl(const spasm_hip_dcsr *A, const int *d_rows, int nrows, const spa
 		if (need > W->scratch_bytes) {
 			if (W->d_scratch != nullptr)
 				sh::big_free(W->d_scratch);
-			HIP_CHECK(hipMalloc((void **) &W->d_scratch, (size_t) need));
+			HIP_CHECK(sh::malloc_or_trim((void **) &W->d_scratch, (size_t) need));
 			W->scratch_bytes = need;
 			HIP_CHECK(hipMemsetAsync(W->d_scratch, 0, (size_t) need, stream));
 		} else if (slot_bytes != W->slot_bytes || off_bm != W->off_bm || off_xn != W->off_xn) {

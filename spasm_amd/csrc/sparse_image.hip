@@ -581,6 +581,7 @@ __global__ __launch_bounds__(64) void sp_reset_shards_kernel(unsigned long long 
 		shard[s * SHARD_STRIDE + 2] = 0;          // entries of fragments added up (the work of the build)
 		shard[s * SHARD_STRIDE + 3] = 0;          // entries written
 		shard[s * SHARD_STRIDE + 4] = 0;          // non-empty (row, segment) pairs
+		shard[s * SHARD_STRIDE + 5] = 0;          // entries reserved (touched columns: the fill plus what cancelled)
 	}
 }
 
@@ -713,6 +714,7 @@ template <bool PERSISTENT> __device__ __forceinline__ void sp_build_task(const S
 			l0_atomic_add_u64(&S[2], ops);
 			l0_atomic_add_u64(&S[3], (unsigned long long) cnt);
 			l0_atomic_add_u64(&S[4], (cnt > 0) ? 1ull : 0ull);
+			l0_atomic_add_u64(&S[5], (unsigned long long) ub);
 		}
 	}
 	if (failed) {
@@ -1168,7 +1170,7 @@ bool sparse_image_build(const spasm_hip_dfact *F, hipStream_t stream)
 	// what failed; what it may take in all is bounded -- an R that needs more than half the bytes of its dense form is not
 	// sparse, and the other paths are the better ones for it.
 	size_t free_b = 0, total_b = 0;
-	HIP_CHECK(hipMemGetInfo(&free_b, &total_b));
+	sh::mem_info(&free_b, &total_b);
 	int64_t held = 0;
 	for (int k = 0; k < S.nchunks; k++)
 		held += S.chunk_cap[k] * 4;
@@ -1182,7 +1184,9 @@ bool sparse_image_build(const spasm_hip_dfact *F, hipStream_t stream)
 	}
 	if (S.nchunks == 0) {
 		int64_t cap = (S.pool_used > 0) ? S.pool_used + S.pool_used / 4 + ((int64_t) SP_SHARDS << 14)
-		                                 : std::max<int64_t>((int64_t) 16 << 20, 64 * (F->nnz + S.r));
+		                                 : std::max<int64_t>((int64_t) 16 << 20, std::max<int64_t>(64 * (F->nnz + S.r), (int64_t) 1536 * S.r));
+		// (first guess: the rows of R of the generated families hold 550-870 entries on average, and a segment reserves room for
+		//  every column it touched, cancelled or not; a guess that is too small costs a second launch, one too large only address space)
 		if (env_sp("SPASM_HIP_SPARSE_IMAGE_CHUNK", 0) > 0)          // (tests: pool extensions on small inputs)
 			cap = env_sp("SPASM_HIP_SPARSE_IMAGE_CHUNK", 0);
 		cap = std::min<int64_t>(cap, std::max<int64_t>(budget / 4, (int64_t) SP_SHARDS * 64));
@@ -1399,11 +1403,13 @@ bool sparse_image_build(const spasm_hip_dfact *F, hipStream_t stream)
 	HIP_CHECK(hipStreamSynchronize(stream));
 	S.ops_build = 0;
 	S.nnz = 0;
+	int64_t reserved = 0;
 	for (int s = 0; s < SP_SHARDS; s++) {
 		S.ops_build += (int64_t) h[(size_t) s * SHARD_STRIDE + 2];
 		S.nnz += (int64_t) h[(size_t) s * SHARD_STRIDE + 3];
+		reserved += (int64_t) h[(size_t) s * SHARD_STRIDE + 5];
 	}
-	S.pool_used = S.nnz + S.nnz / 64;          // (what a rebuild needs in one chunk: the entries, and the few words cancellations strand)
+	S.pool_used = reserved;          // (what a rebuild needs in one chunk: a segment reserves room for every column it touched)
 	if (chunk > 0 && !persistent) {
 		// levels were redone: their fragments were counted twice
 		HIP_CHECK(hipMemsetAsync(S.d_shard, 0, sizeof(unsigned long long), stream));
@@ -1476,9 +1482,10 @@ void launch_sparse_image_apply(const SchurArgs &a, const spasm_hip_dfact *F, uin
 	// as many waves per CU as its LDS holds (19.5 KB each: eight), every wave a workgroup of its own
 	const int per_cu = std::max(1, std::min(16, env_sp("SPASM_HIP_SPARSE_IMAGE_WAVES", (int) std::min<size_t>(16, (size_t) (160 * 1024) / sizeof(WaveLds)))));
 	const int blocks = (int) std::min<int64_t>(ntasks, (int64_t) prop.multiProcessorCount * per_cu);
-	// a wave reserves the room of its fragments 32,768 entries at a time when the pool is large enough for every wave to
-	// strand one such arena; else fragment by fragment
-	d.arena = (fcap >= (int64_t) blocks * 32768 * 8) ? 32768 : 0;
+	// a wave reserves the room of its fragments 8,192 entries at a time (what the ~4,000 waves strand at the end must stay small
+	// against a pool sized from a density estimate: 32,768 apiece were 126 M entries, and a retry of the whole call); a pool
+	// too small even for that: fragment by fragment
+	d.arena = (fcap >= (int64_t) blocks * 8192 * 8) ? 8192 : 0;
 	// (block_sum: (nrows + 1023) / 1024 words rounded up to 16, then 256 words of ticket counters)
 	const int nblocks = (a.nrows + 1023) / 1024;
 	d.ticket = reinterpret_cast<int *>(block_sum + (size_t) (nblocks + 15) / 16 * 16);

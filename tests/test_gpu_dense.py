@@ -350,7 +350,7 @@ def _rref_rows(p, M):
     return r, A[:r].clone(), piv[:r].clone()
 
 
-def _extend_and_check(p, blocks, m):
+def _extend_and_check(p, blocks, m, oracle=None):
     """feeds the blocks one after the other to spasm_hip_dechelon_extend; after every block: the echelon rows are reduced
     (identity on their pivot columns, distinct pivots, no zero row) and span exactly the row space of everything fed so far
     (same unique RREF as the stack of the inputs, computed by spasm_hip_drref)."""
@@ -381,6 +381,20 @@ def _extend_and_check(p, blocks, m):
         if k:
             r_got, R_got, J_got = _rref_rows(p, E)
             assert r_got == k and torch.equal(J_got, J_want) and torch.equal(R_got, R_want)
+        # ... and directly against the oracle (oracle/spasm_oracle.c: orc_dense_rref, pinned on the reference's own dense_rref
+        # test): the echelon rows are reduced, so sorted by pivot column they ARE the unique RREF of the row space of the input
+        if oracle is not None:
+            r_o, R_o, qinv_o = oracle.dense_rref(p, stack.cpu().numpy().astype(np.int64))
+            assert r_o == k
+            if k:
+                order = torch.argsort(J)
+                got = E[order].cpu().numpy().astype(np.int64)
+                piv_o = np.flatnonzero(qinv_o >= 0)
+                piv_o = piv_o[np.argsort(qinv_o[piv_o])]          # pivot column of every row of the oracle's RREF
+                assert np.array_equal(np.sort(J.cpu().numpy()), np.sort(piv_o))
+                want = np.mod(R_o[:r_o], p)
+                want = want[np.argsort(piv_o)]
+                assert np.array_equal(got, want)
     return k
 
 
@@ -403,7 +417,7 @@ def _mod_matmul(torch, A, B, p):
 
 @pytest.mark.parametrize("p", [42013, 257, 65267])
 @pytest.mark.parametrize("case", ["two_blocks", "ragged", "dependent_on_E", "zeros", "sparse_wide", "many_windows"])
-def test_echelon_extend_by_row_panels(case, p):
+def test_echelon_extend_by_row_panels(oracle, case, p):
     import torch
     dev = torch.device("cuda:0")
     g = torch.Generator(device=dev)
@@ -433,4 +447,61 @@ def test_echelon_extend_by_row_panels(case, p):
             c = 300 * (i % 40)
             B[i, c:c + 200] = torch.randint(1, p, (200,), dtype=torch.int32, device=dev, generator=g)
         blocks = [B]
-    _extend_and_check(p, blocks, m)
+    _extend_and_check(p, blocks, m, oracle)
+
+
+# --------------------------------------------------------------------------
+# the combinations of rows the dense / low-rank finish forms on the device, against numpy
+# --------------------------------------------------------------------------
+def _mix64(z):
+    z = (z + np.uint64(0x9E3779B97F4A7C15)).astype(np.uint64)
+    z = ((z ^ (z >> np.uint64(30))) * np.uint64(0xBF58476D1CE4E5B9)).astype(np.uint64)
+    z = ((z ^ (z >> np.uint64(27))) * np.uint64(0x94D049BB133111EB)).astype(np.uint64)
+    return z ^ (z >> np.uint64(31))
+
+
+def _uniform_below(h, bound):
+    return ((h >> np.uint64(32)) * np.uint64(bound)) >> np.uint64(32)
+
+
+@pytest.mark.parametrize("p", [42013, 65521, 4294967291])
+@pytest.mark.parametrize("n,m,per_row,N", [(20000, 3000, 7, 9), (5000, 40000, 30, 16), (4096, 1500, 3, 1)])
+def test_combinations_of_all_rows_against_numpy(p, n, m, per_row, N):
+    """spasm_echelonize_test_completion combines EVERY remaining row into a few random rows (spasm_echelonize.c:389-420); on
+    the device that is combine_all_rows_blocked_kernel (p < 2^16: block sums in LDS) or combine_all_rows_kernel (an atomic per
+    term).  The coefficients are a counter-based generator (splitmix64 of (salt, combination, row)) restated here in numpy:
+    the N x m sums must equal C A mod p computed with scipy -- not another kernel of this library."""
+    import scipy.sparse as sp
+    rng = np.random.default_rng(n + m + N)
+    lens = rng.integers(1, 2 * per_row, size=n)
+    ptr = np.zeros(n + 1, np.int64)
+    np.cumsum(lens, out=ptr[1:])
+    j = np.zeros(int(ptr[n]), np.int32)
+    for i in range(n):
+        j[ptr[i]:ptr[i + 1]] = np.sort(rng.choice(m, size=int(lens[i]), replace=False))          # rows sorted by column (as Schur complements are)
+    vals = rng.integers(1, p, size=int(ptr[n]), dtype=np.int64)
+    x = np.where(vals > p // 2, vals - p, vals).astype(np.int32)
+    A = spasm_amd.Csr(n, m, ptr, j, x, p)
+    rows = rng.permutation(n).astype(np.int32)[: n - 17]                                        # a list of rows, not all of them, not in order
+    salt = 0x1234567890ABCDEF
+    out = np.zeros((N, m), np.uint32)
+    from spasm_amd.matrix import view_csr
+    import ctypes as C
+    spasm_amd.lib().spasm_hip_debug_combine(C.byref(view_csr(A)), rows.ctypes.data_as(C.POINTER(C.c_int)), len(rows), N, 0, C.c_uint64(salt),
+                                            out.ctypes.data_as(C.c_void_p))
+    with np.errstate(over="ignore"):
+        k = np.arange(N, dtype=np.uint64)[:, None]
+        t = np.arange(len(rows), dtype=np.uint64)[None, :]
+        h = _mix64(np.uint64(salt) ^ _mix64((k << np.uint64(32)) ^ t))
+        coeff = _uniform_below(h, p).astype(np.int64)                                            # N x len(rows)
+    # exact: every term is reduced mod p with Python integers, then the rows are added up in int64 (at most n terms below 2^32)
+    want = np.zeros((N, m), np.int64)
+    Mr = sp.csr_matrix((vals, j, ptr), shape=(n, m))[rows]
+    for kk in range(N):
+        c = coeff[kk]
+        scaled = Mr.copy()
+        rep = np.repeat(np.arange(len(rows)), np.diff(scaled.indptr))
+        d = scaled.data.astype(object) * c[rep].astype(object)
+        scaled.data = np.array([int(v) % p for v in d], np.int64)
+        want[kk] = np.asarray(scaled.sum(axis=0)).ravel() % p
+    assert np.array_equal(out.astype(np.int64), want)

@@ -50,13 +50,13 @@ def _search(A, where, bits=None):
                 os.environ[k] = v
 
 
-def _wide_matrix(n, m, seed, prime):
-    """rows of 2..7 distinct columns (arithmetic progressions mod m), built without a Python loop: for matrices too wide
+def _wide_matrix(n, m, seed, prime, lo=2, hi=8):
+    """rows of lo..hi-1 distinct columns (arithmetic progressions mod m), built without a Python loop: for matrices too wide
     for one bit per column in LDS"""
     rng = np.random.default_rng(seed)
-    lens = rng.integers(2, 8, size=n)
+    lens = rng.integers(lo, hi, size=n)
     base = rng.integers(0, m, size=n)
-    stride = rng.integers(1, m // 8, size=n)
+    stride = rng.integers(1, m // (hi + 1), size=n)
     p = np.zeros(n + 1, np.int64)
     np.cumsum(lens, out=p[1:])
     row = np.repeat(np.arange(n), lens)
@@ -120,3 +120,14 @@ def test_device_search_on_a_matrix_too_wide_for_the_lds():
     npiv_h, perm_h, F_h = _search(A, "host")
     _check(A, npiv_h, perm_h, F_h)
     assert abs(npiv - npiv_h) <= 0.03 * npiv_h
+
+
+def test_device_search_with_long_rows_on_a_matrix_too_wide_for_the_lds():
+    """both handicaps of GL7d19 at once (1.9 M columns, ~19 entries per row): rows too long for the 16-byte records of the
+    search (walked from A by the whole wave) AND more columns than the LDS has bits for (marks in HBM).  150,000 rows of
+    16-22 entries on 700,000 columns; the host search on this shape takes a minute, so the count is not compared: the
+    properties are what is checked (tools/probe_long_rows.py times the 300,000-row version)"""
+    A = _wide_matrix(150000, 700000, seed=11, prime=42013, lo=16, hi=23)
+    npiv, perm, F = _search(A, "device")
+    assert npiv > 0.5 * A.n
+    _check(A, npiv, perm, F)

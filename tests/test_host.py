@@ -300,6 +300,24 @@ def test_fp32_reduction_of_the_signed_16_bit_path_stays_inside_its_slack():
     assert 4 * Bn * Bn + Bn > 2 ** 31 - 1
 
 
+def test_vectorised_matching_complexes_equal_the_recursive_enumeration():
+    """tools/workloads.py enumerates the matchings level by level with numpy (mk15.b4 -- 2.8 M rows, the at-scale stand-in --
+    in seconds); the triplets must be those of the recursive enumeration, and the sizes the published ones"""
+    import sys
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import workloads
+    for nv, K in ((7, 1), (9, 1), (10, 2), (11, 3), (12, 3)):
+        a = workloads.mk_boundary(nv, K)
+        b = workloads.mk_boundary_reference(nv, K)
+        assert a[0] == b[0] and a[1] == b[1]
+        for x, y in zip(a[2:], b[2:]):
+            assert np.array_equal(x, y)
+    n, m, ti, tj, tx = workloads.mk_boundary(9, 1)
+    assert (n, m, len(ti)) == (378, 36, 756)
+    n, m, ti, tj, tx = workloads.mk_boundary(12, 3)
+    assert (n, m, len(ti)) == (51975, 13860, 207900)
+
+
 def test_generated_workloads_are_built_like_spasm_compress():
     """tools/workloads.py builds the CSR of a generated matrix with numpy (five million add_entry calls through ctypes take
     longer than the elimination): same arrays as spasm_hip_compress on the same triplets, in both orientations; and the
