@@ -264,6 +264,10 @@ __device__ __forceinline__ void sp_own_entry(WaveLds &L, uint32_t c, int val, co
 // acc += coef * fragment, for every lane whose fragment word f is not empty and for which `take` holds (wave-uniform loop
 // over those lanes).  Four fragments at a time: the first 64 entries of all four are in flight together (a reduced row
 // combines 3-5 rows of R per segment, each 1-3 batches long: the stage is the latency of these loads).
+// (A version that kept the four heads in a struct across calls -- to fetch the next segment's fragments before the current
+//  segment is emitted -- computed wrong sums on rows with more than four fragments (tests: mat364 mod 3) although it reads
+//  the same; it bought nothing measurable and is gone.  Loops with divergent tails followed by lane-crossing operations are
+//  kept in this one shape, which the tests pin.)
 template <bool SC1>
 __device__ __forceinline__ void sp_accumulate(WaveLds &L, uint64_t f, int coef, bool take, const SpPools &pools, int lane, const SgnDev &G,
                                               unsigned long long &ops)
@@ -304,6 +308,7 @@ __device__ __forceinline__ void sp_accumulate(WaveLds &L, uint64_t f, int coef, 
 			}
 			for (; i < len[u]; i += 64)
 				sp_entry(L, sp_ld<SC1>(src[u] + i), cf[u], G);
+			__builtin_amdgcn_wave_barrier();          // (the lanes meet again before the next fragment touches the same columns)
 		}
 	}
 }
@@ -562,6 +567,8 @@ struct SpBuildArgs {
 	unsigned long long *shard;
 	int *ovf_level;               // level by level: largest level in which a reservation failed (-1: none); persistent: 1 when any task failed
 	unsigned long long shard_sub; // entries of a shard of the current chunk (shard s: [s, s + 1) * shard_sub)
+	int arena;                    // persistent: entries a wave reserves at a time from the cursor of shard 0, which then serves the whole
+	                              // chunk (0: every fragment reserves its own room from the shard its hash picks)
 	int *ticket;                  // persistent: SP_TICKETS counters
 	int *abort_flag;              // persistent: a wave waited too long (the grid is not resident?): everybody gives up
 	long long poll_limit;         // ... polls of one batch of dependencies before that happens
@@ -605,6 +612,12 @@ __device__ __forceinline__ void sp_dbg(const SpBuildArgs &b, int lane, int stage
 #endif
 }
 
+// what a wave of the single-launch build carries from task to task: its arena in the pool, its share of the statistics
+struct SpWaveState {
+	long long ar_cur = 0, ar_end = 0;
+	unsigned long long ops = 0, nnz = 0, frags = 0, reserved = 0;
+};
+
 template <bool PERSISTENT> __device__ __forceinline__ void sp_publish(uint64_t *fout, uint64_t word, int lane)
 {
 	if (PERSISTENT) {
@@ -616,7 +629,8 @@ template <bool PERSISTENT> __device__ __forceinline__ void sp_publish(uint64_t *
 }
 
 // one task: the fragment of (row c, segment g).  One exit, one publication.
-template <bool PERSISTENT> __device__ __forceinline__ void sp_build_task(const SpBuildArgs &b, WaveLds &L, int c, int g, int lane, SpStamp &st)
+template <bool PERSISTENT>
+__device__ __forceinline__ void sp_build_task(const SpBuildArgs &b, WaveLds &L, int c, int g, int lane, SpStamp &st, SpWaveState &ws)
 {
 	const uint32_t col0 = (uint32_t) g * SP_SEG;
 	const SgnDev G = b.G;
@@ -696,10 +710,26 @@ template <bool PERSISTENT> __device__ __forceinline__ void sp_build_task(const S
 		const uint32_t sh = sp_hash((uint32_t) c, (uint32_t) g);
 		unsigned long long *S = b.shard + (size_t) sh * SHARD_STRIDE;
 		unsigned long long off = 0;
+		const bool arenas = PERSISTENT && b.arena > 0;
 		if (!failed && ub > 0) {
-			off = l0_atomic_add_u64_ret(&S[0], (unsigned long long) ub);
-			if (off + (unsigned long long) ub > (unsigned long long) (sh + 1) * b.shard_sub)
-				failed = true;
+			if (arenas) {
+				// room from the wave's own arena: no atomic on the path of a task (a new arena every few dozen fragments), and
+				// the arena moves on by what was WRITTEN -- columns whose sums cancelled strand nothing
+				if (ws.ar_cur + ub > ws.ar_end) {
+					const long long want = (b.arena > ub) ? b.arena : ub;
+					ws.ar_cur = (long long) l0_atomic_add_u64_ret(&b.shard[0], (unsigned long long) want);
+					ws.ar_end = ws.ar_cur + want;
+					if ((unsigned long long) ws.ar_end > (unsigned long long) SP_SHARDS * b.shard_sub) {
+						ws.ar_end = ws.ar_cur;          // (the chunk is full)
+						failed = true;
+					}
+				}
+				off = (unsigned long long) ws.ar_cur;
+			} else {
+				off = l0_atomic_add_u64_ret(&S[0], (unsigned long long) ub);
+				if (off + (unsigned long long) ub > (unsigned long long) (sh + 1) * b.shard_sub)
+					failed = true;
+			}
 		}
 		st.mark(4);
 		if (failed) {
@@ -708,13 +738,22 @@ template <bool PERSISTENT> __device__ __forceinline__ void sp_build_task(const S
 			cnt = sp_emit<false, PERSISTENT>(L, T, b.chunk_base + off, lane, G);
 			if (cnt > 0)
 				word = ((uint64_t) b.chunk << (SP_LEN_BITS + SP_OFF_BITS)) | ((uint64_t) off << SP_LEN_BITS) | (uint64_t) cnt;
+			if (arenas)
+				ws.ar_cur += cnt;
 		}
 		st.mark(5);
 		if (!failed) {
-			l0_atomic_add_u64(&S[2], ops);
-			l0_atomic_add_u64(&S[3], (unsigned long long) cnt);
-			l0_atomic_add_u64(&S[4], (cnt > 0) ? 1ull : 0ull);
-			l0_atomic_add_u64(&S[5], (unsigned long long) ub);
+			if (PERSISTENT) {
+				ws.ops += ops;
+				ws.nnz += (unsigned long long) cnt;
+				ws.frags += (cnt > 0) ? 1ull : 0ull;
+				ws.reserved += (unsigned long long) (arenas ? cnt : ub);
+			} else {
+				l0_atomic_add_u64(&S[2], ops);
+				l0_atomic_add_u64(&S[3], (unsigned long long) cnt);
+				l0_atomic_add_u64(&S[4], (cnt > 0) ? 1ull : 0ull);
+				l0_atomic_add_u64(&S[5], (unsigned long long) ub);
+			}
 		}
 	}
 	if (failed) {
@@ -735,10 +774,12 @@ template <bool PERSISTENT> __global__ __launch_bounds__(64) void sp_build_kernel
 	if constexpr (!PERSISTENT) {
 		const int task = blockIdx.x;
 		const int c = b.row_lo + task / b.nseg;
-		sp_build_task<false>(b, L, c, task - (c - b.row_lo) * b.nseg, lane, st);
+		SpWaveState ws;
+		sp_build_task<false>(b, L, c, task - (c - b.row_lo) * b.nseg, lane, st, ws);
 	} else {
 		const int q = (int) (blockIdx.x % SP_TICKETS);
 		const long long ntasks = (long long) (b.row_hi - b.row_lo) * b.nseg;
+		SpWaveState ws;
 		for (;;) {
 			const int j = l0_atomic_add_i32_ret(b.ticket + q * SP_TICKET_STRIDE, 1);
 			const long long t = (long long) j * SP_TICKETS + q;
@@ -751,11 +792,17 @@ template <bool PERSISTENT> __global__ __launch_bounds__(64) void sp_build_kernel
 			// (a launch that retries after a pool extension finds most fragments done)
 			const uint64_t cur = sp_uniform(__hip_atomic_load(b.frag + (uint64_t) c * b.nseg + g, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
 			if (cur == FRAG_PENDING) {
-				sp_build_task<true>(b, L, c, g, lane, st);
+				sp_build_task<true>(b, L, c, g, lane, st, ws);
 				sp_dbg(b, lane, 5, t, 0);
 			}
 		}
 		sp_dbg(b, lane, 9, 0, 0);
+		// the wave's share of the statistics (and what its last arena strands counts as reserved)
+		unsigned long long *S = b.shard + (size_t) (blockIdx.x % SP_SHARDS) * SHARD_STRIDE;
+		l0_atomic_add_u64(&S[2], ws.ops);
+		l0_atomic_add_u64(&S[3], ws.nnz);
+		l0_atomic_add_u64(&S[4], ws.frags);
+		l0_atomic_add_u64(&S[5], ws.reserved + (unsigned long long) (ws.ar_end - ws.ar_cur));
 	}
 	st.flush(lane);
 }
@@ -917,7 +964,7 @@ __global__ __launch_bounds__(64) void sp_apply_kernel(SpApplyArgs d)
 				const uint64_t fnext = (piv && g + 1 < nseg) ? fin[g + 1] : 0;
 				const uint32_t idx = idx_all - (uint32_t) g * SP_SEG;
 				const bool in = own && idx < (uint32_t) SP_SEG;
-				const bool touched = (__ballot(in) | __ballot((f & LEN_MASK) != 0)) != 0;
+				const bool touched = (__ballot(in) | __ballot(piv && (f & LEN_MASK) != 0)) != 0;
 				st.mark(1);
 				if (touched) {
 					if (in)
@@ -1260,6 +1307,8 @@ bool sparse_image_build(const spasm_hip_dfact *F, hipStream_t stream)
 		const int blocks = (int) std::max<int64_t>(1, std::min<int64_t>(ntasks, (int64_t) cus * per_cu));
 		for (bool first = true;; first = false) {
 			set_chunk(chunk, first);
+			// (arenas of 16,384 entries when the chunk is large enough for every wave to strand one; tests with tiny chunks: none)
+			b.arena = (S.chunk_cap[chunk] >= (int64_t) blocks * 16384 * 4 && env_sp("SPASM_HIP_SPARSE_IMAGE_ARENAS", 1) != 0) ? 16384 : 0;
 			HIP_CHECK(hipMemsetAsync(d_sync, 0, (size_t) (SP_TICKETS * SP_TICKET_STRIDE + 2) * sizeof(int), stream));
 			int *d_dbg = nullptr;
 			if (env_sp("SPASM_HIP_SPARSE_IMAGE_DEBUG", 0) != 0) {
