@@ -47,7 +47,7 @@ constexpr uint32_t BS_NONE = 0xFFFFFFFFu;
 
 int env_bs(const char *name, int dflt)
 {
-	const char *e = std::getenv(name);
+	const char *e = sh::env_get(name);
 	return (e == nullptr || *e == 0) ? dflt : std::atoi(e);
 }
 
@@ -1871,6 +1871,12 @@ void backsolve_free(spasm_hip_dfact *F)
 void backsolve_build(const spasm_hip_dfact *F, hipStream_t stream)
 {
 	BsImage &B = F->bs;
+	if (!B.planned && F->bs_deferred && F->host_plan) {
+		// (a factor with the tables of the sparse image: the plan of the dense one was left for the batch that wants it)
+		backsolve_plan(*F->host_plan, const_cast<spasm_hip_dfact *>(F), stream);
+		F->bs_deferred = false;
+		F->host_plan.reset();
+	}
 	if (!B.planned)
 		die("backsolve_build: the factor has no back-substitution plan");
 	// R is stored in 16 bits when the prime allows (42013, the reference's default, does): half the traffic, half the LDS

@@ -42,6 +42,11 @@ inline void *xrealloc(void *old, int64_t bytes)
 
 double wtime();
 
+// Environment switches.  The SUPPORTED ones (listed in include/spasm_hip.h) are read as they are; every other SPASM_HIP_* name
+// selects an experiment, a debugging aid or a code path kept for A/B runs and tests, and is only honoured when
+// SPASM_HIP_EXPERIMENT=1 is set as well (tests/conftest.py sets it).  Returns the value or nullptr.
+const char *env_get(const char *name);
+
 // verbosity of the progress messages on stderr (SPASM_HIP_VERBOSE=0 silences them)
 int verbose();
 void logmsg(const char *fmt, ...);

@@ -46,7 +46,7 @@ namespace {
 
 int env_int(const char *name, int dflt)
 {
-	const char *e = std::getenv(name);
+	const char *e = sh::env_get(name);
 	return (e == nullptr || *e == 0) ? dflt : std::atoi(e);
 }
 

@@ -1682,7 +1682,7 @@ int device_rref(int64_t prime, int n, int m, uint32_t *dA, int64_t ld, int *d_pi
 		std::vector<std::pair<void *, size_t>> slots;
 	};
 	static thread_local Cache cache;
-	const bool use_cache = std::getenv("SPASM_HIP_RREF_CACHE") == nullptr || std::atoi(std::getenv("SPASM_HIP_RREF_CACHE")) != 0;
+	const bool use_cache = sh::env_get("SPASM_HIP_RREF_CACHE") == nullptr || std::atoi(sh::env_get("SPASM_HIP_RREF_CACHE")) != 0;
 	size_t next_slot = 0;
 	{
 		int dev = 0;
@@ -1735,12 +1735,12 @@ int device_rref(int64_t prime, int n, int m, uint32_t *dA, int64_t ld, int *d_pi
 	HIP_CHECK(hipMemsetAsync(rank_d, 0, 64, stream));
 	// tall blocks: the panel step is spread over several workgroups (SPASM_HIP_COOP_ROWS rows and up)
 	int coop_min_rows = 2048;
-	if (const char *e = std::getenv("SPASM_HIP_COOP_ROWS"))
+	if (const char *e = sh::env_get("SPASM_HIP_COOP_ROWS"))
 		coop_min_rows = std::atoi(e);
 	// panel step: tournament (default) or the column-by-column kernels (SPASM_HIP_RREF_PANEL=columns)
 	bool tournament = true;
 	const bool small_prime = prime < 46341;          // 2 p^2 < 2^32: the panel kernels use 24-bit multiplies
-	if (const char *e = std::getenv("SPASM_HIP_RREF_PANEL"))
+	if (const char *e = sh::env_get("SPASM_HIP_RREF_PANEL"))
 		tournament = std::strcmp(e, "columns") != 0;
 	int *candA = nullptr, *candB = nullptr, *free_count = nullptr, *gamma = nullptr, *cand_first = nullptr, *full_flag = nullptr, *first64 = nullptr, *cand_pivot = nullptr;
 	uint32_t *Ginv = nullptr, *P4 = nullptr, *Bt4 = nullptr, *Zacc = nullptr;
@@ -1801,7 +1801,7 @@ int device_rref(int64_t prime, int n, int m, uint32_t *dA, int64_t ld, int *d_pi
 	const bool mfma_ok = use_mfma && prime <= 65279;      // two signed base-256 digits must fit int8
 	hipStream_t stream2 = nullptr;
 	hipEvent_t ev_near = nullptr, ev_far = nullptr;
-	if (tournament && mfma_ok && !std::getenv("SPASM_HIP_RREF_ONE_STREAM")) {
+	if (tournament && mfma_ok && !sh::env_get("SPASM_HIP_RREF_ONE_STREAM")) {
 		HIP_CHECK(hipStreamCreateWithFlags(&stream2, hipStreamNonBlocking));
 		HIP_CHECK(hipEventCreate(&ev_near));
 		HIP_CHECK(hipEventCreate(&ev_far));
@@ -1818,23 +1818,23 @@ int device_rref(int64_t prime, int n, int m, uint32_t *dA, int64_t ld, int *d_pi
 			total_update += ms;
 		}
 	};
-	if (std::getenv("SPASM_HIP_RREF_TIMING")) {
+	if (sh::env_get("SPASM_HIP_RREF_TIMING")) {
 		HIP_CHECK(hipStreamSynchronize(stream));
 		fprintf(stderr, "[rref timing] allocations + setup: %.3f ms\n", 1e3 * (wtime() - t_entry));
 	}
 	if (tournament) {
 		const bool small16 = prime < 65536;
-		const bool try_first = std::getenv("SPASM_HIP_RREF_TRY") == nullptr || std::atoi(std::getenv("SPASM_HIP_RREF_TRY")) != 0;
+		const bool try_first = sh::env_get("SPASM_HIP_RREF_TRY") == nullptr || std::atoi(sh::env_get("SPASM_HIP_RREF_TRY")) != 0;
 		// the 64 x 64 inversion kernel for the try: signed representatives with deferred reduction need 4 B^2 + B < 2^31, B = p/2 + p/64 + 1
 		bool fast_try = small_prime && (4 * (prime / 2 + prime / 64 + 1) * (prime / 2 + prime / 64 + 1) + (prime / 2 + prime / 64 + 1) <= 0x7FFFFFFFll);
-		if (const char *e = std::getenv("SPASM_HIP_RREF_FAST_TRY"))
+		if (const char *e = sh::env_get("SPASM_HIP_RREF_FAST_TRY"))
 			fast_try = fast_try && std::atoi(e) != 0;
 		// panels per super-panel: eight on the matrix cores (K = 512 per pass over the matrix), four with VALU updates
-		const int SPW = mfma_ok ? std::min(MAXSETS, std::max(1, std::getenv("SPASM_HIP_RREF_SPW") ? std::atoi(std::getenv("SPASM_HIP_RREF_SPW")) : MAXSETS)) : 4;
+		const int SPW = mfma_ok ? std::min(MAXSETS, std::max(1, sh::env_get("SPASM_HIP_RREF_SPW") ? std::atoi(sh::env_get("SPASM_HIP_RREF_SPW")) : MAXSETS)) : 4;
 		const int64_t ldz = (int64_t) MAXSETS * NB;
 		signed char *Bown_h = B8 + (size_t) MAXSETS * 2 * (size_t) m * 64, *Bown_l = Bown_h + (size_t) (2 * MAXSETS * NB + 64) * 64;
 		bool far_pending = false;
-		const bool optimistic_enabled = std::getenv("SPASM_HIP_RREF_OPTIMISTIC") == nullptr || std::atoi(std::getenv("SPASM_HIP_RREF_OPTIMISTIC")) != 0;
+		const bool optimistic_enabled = sh::env_get("SPASM_HIP_RREF_OPTIMISTIC") == nullptr || std::atoi(sh::env_get("SPASM_HIP_RREF_OPTIMISTIC")) != 0;
 		bool optimistic_ok = optimistic_enabled;
 		int optimistic_skip = 0;
 		uint32_t *set_P[MAXSETS] = {};
@@ -2164,7 +2164,7 @@ int device_rref(int64_t prime, int n, int m, uint32_t *dA, int64_t ld, int *d_pi
 		}
 	}
 	double t_loop = 0.0;
-	if (std::getenv("SPASM_HIP_RREF_TIMING")) {
+	if (sh::env_get("SPASM_HIP_RREF_TIMING")) {
 		HIP_CHECK(hipStreamSynchronize(stream));
 		if (stream2 != nullptr)
 			HIP_CHECK(hipStreamSynchronize(stream2));
@@ -2225,7 +2225,7 @@ int device_rref(int64_t prime, int n, int m, uint32_t *dA, int64_t ld, int *d_pi
 	ws_free(rank_d);
 	ws_free(knew);
 	ws_free(rho);
-	if (std::getenv("SPASM_HIP_RREF_TIMING"))
+	if (sh::env_get("SPASM_HIP_RREF_TIMING"))
 		fprintf(stderr, "[rref timing] whole call: %.3f ms\n", 1e3 * (wtime() - t_entry));
 	return rank;
 }
@@ -3040,7 +3040,7 @@ void launch_combine(const int64_t *Ap, const int *Aj, const int *Ax, const int *
 {
 	const int64_t terms = (w > 0) ? (int64_t) w : (int64_t) nrows;
 	const int64_t total = (int64_t) N * terms;
-	if (w <= 0 && N <= 16 && nrows >= 4096 && M.p < 65536 && !std::getenv("SPASM_HIP_COMBINE_PER_PAIR") && !std::getenv("SPASM_HIP_COMBINE_ATOMIC")) {
+	if (w <= 0 && N <= 16 && nrows >= 4096 && M.p < 65536 && !sh::env_get("SPASM_HIP_COMBINE_PER_PAIR") && !sh::env_get("SPASM_HIP_COMBINE_ATOMIC")) {
 		// every row, few combinations, p < 2^16: block sums in LDS, one atomic per occupied (column, combination) and workgroup
 		const size_t lds = (size_t) CB_COLS * N * sizeof(uint32_t) + (size_t) CB_ROWS * N * sizeof(unsigned short);
 		static size_t configured = 0;
@@ -3058,7 +3058,7 @@ void launch_combine(const int64_t *Ap, const int *Aj, const int *Ax, const int *
 		HIP_CHECK(hipMemcpyAsync(&flag, d_flag, sizeof(int), hipMemcpyDeviceToHost, stream));
 		HIP_CHECK(hipStreamSynchronize(stream));
 		sh::big_free(d_flag);
-		if (flag == 0 && std::getenv("SPASM_HIP_COMBINE_CHECK")) {
+		if (flag == 0 && sh::env_get("SPASM_HIP_COMBINE_CHECK")) {
 			// (tests) the same combinations by the kernel that sends an atomic per term: the sums must agree mod p
 			const size_t count = (size_t) N * m;
 			unsigned long long *Y2 = (unsigned long long *) big_alloc(count * sizeof(unsigned long long));
@@ -3088,7 +3088,7 @@ void launch_combine(const int64_t *Ap, const int *Aj, const int *Ax, const int *
 		// (rows that are not sorted by column: Y holds part of the sums -- start again, the other way)
 		HIP_CHECK(hipMemsetAsync(Y, 0, (size_t) N * m * sizeof(unsigned long long), stream));
 	}
-	if (w <= 0 && N <= 16 && nrows >= 4096 && !std::getenv("SPASM_HIP_COMBINE_PER_PAIR")) {
+	if (w <= 0 && N <= 16 && nrows >= 4096 && !sh::env_get("SPASM_HIP_COMBINE_PER_PAIR")) {
 		// every row, few combinations: each row once, the combinations side by side (combine_all_rows_kernel); Y arrives zeroed
 		unsigned long long *Yt = (unsigned long long *) big_alloc((size_t) m * 16 * sizeof(unsigned long long));
 		HIP_CHECK(hipMemsetAsync(Yt, 0, (size_t) m * 16 * sizeof(unsigned long long), stream));
@@ -3480,7 +3480,7 @@ int device_lu(int64_t prime, int n, int m, uint32_t *dA, int64_t ld, int *dP, in
 	const int rmax = (n < m) ? n : m;
 	// blocked steps: the matrix cores need two signed base-256 digits (p <= 65279), the row kernels 16-byte rows
 	bool blocked = prime <= 65279 && ld % 4 == 0 && (reinterpret_cast<uintptr_t>(dA) % 16) == 0;
-	if (const char *e = std::getenv("SPASM_HIP_LU_BLOCKED"))
+	if (const char *e = sh::env_get("SPASM_HIP_LU_BLOCKED"))
 		blocked = blocked && std::atoi(e) != 0;
 	signed char *lu_M8 = nullptr, *lu_B8 = nullptr;
 	int *lu_perm = nullptr;

@@ -4,6 +4,7 @@
 #include <hip/hip_runtime.h>
 
 #include <cstdint>
+#include <memory>
 #include <vector>
 
 #include "common.h"
@@ -286,6 +287,10 @@ struct spasm_hip_dfact {
 	std::vector<int> h_kof;
 	mutable sh::BsImage bs;        // back-substituted image, built on first use when the factor is eligible
 	mutable sh::SpImage sp;        // sparse back-substituted image (sparse_image.hip)
+	// a factor that has the tables of the sparse image plans its dense image only when a batch asks for it (the plan is 40 % of
+	// the image's cost and such factors seldom take the dense image): the host part of the image waits here until then
+	mutable bool bs_deferred = false;
+	mutable std::unique_ptr<sh::FactPlan> host_plan;
 };
 
 struct spasm_hip_dwork {

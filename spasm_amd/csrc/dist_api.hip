@@ -158,7 +158,7 @@ int spasm_hip_dschur_allgatherv(spasm_hip_comm *c, const spasm_hip_dwork *W, i64
 	// slice straight to every peer and receives theirs, all in one group, so that all the links carry payload at once
 	// (a ring all-gather or a broadcast tree would push the whole of S through single links).  The local slice is a
 	// device-to-device copy.  SPASM_HIP_ALLGATHERV=bcast: one ncclBroadcast per rank and array instead.
-	const char *how = std::getenv("SPASM_HIP_ALLGATHERV");
+	const char *how = sh::env_get("SPASM_HIP_ALLGATHERV");
 	const bool use_bcast = how != nullptr && std::strcmp(how, "bcast") == 0;
 	const void *own[3] = {W->d_Sp, W->d_Sj, W->d_Sx};
 	void *all[3] = {d_Sp, d_Sj, d_Sx};

@@ -23,7 +23,7 @@ using namespace sh;
 
 static int env_int_host(const char *name, int dflt)
 {
-	const char *e = std::getenv(name);
+	const char *e = sh::env_get(name);
 	return (e == nullptr || *e == 0) ? dflt : std::atoi(e);
 }
 

@@ -358,7 +358,7 @@ struct Search {
 			pool.emplace_back(worker);
 		for (auto &th : pool)
 			th.join();
-		if (std::getenv("SPASM_HIP_PIVOT_STATS"))
+		if (sh::env_get("SPASM_HIP_PIVOT_STATS"))
 			logmsg("[pivots] %d threads: %llu pivot rows visited, %llu commit attempts for %d pivots\n", T,
 			       total_visits.load(), total_retries.load(), npiv.load());
 		for (int j = 0; j < m; j++)
@@ -528,7 +528,7 @@ extern "C" int spasm_hip_pivots_extract_structural(const struct spasm_csr *A, co
 		if (opts == nullptr || opts->enable_greedy_pivot_search) {
 			t1 = wtime();
 			int threads = 0;
-			if (const char *e = std::getenv("SPASM_HIP_THREADS"))
+			if (const char *e = sh::env_get("SPASM_HIP_THREADS"))
 				threads = std::atoi(e);
 			if (threads <= 0)
 				threads = usable_cpus();
@@ -560,7 +560,7 @@ extern "C" int spasm_hip_pivots_extract_structural(const struct spasm_csr *A, co
 				}
 			}
 			if (extra < 0) {
-				const char *where = std::getenv("SPASM_HIP_PIVOT_SEARCH");
+				const char *where = sh::env_get("SPASM_HIP_PIVOT_SEARCH");
 				if (threads > 1 && where != nullptr && std::strcmp(where, "device") == 0)
 					die("SPASM_HIP_PIVOT_SEARCH=device: the search on the device does not apply to this %d x %d matrix here", n, m);
 				extra = (threads > 1) ? S.acyclic_greedy_threads(threads) : S.acyclic_greedy();

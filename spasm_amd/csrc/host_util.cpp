@@ -4,6 +4,7 @@
 // malloc-owned so the reference's own free functions can release them.
 #include <sys/time.h>
 
+#include <cstring>
 #include <vector>
 
 #include "common.h"
@@ -17,11 +18,40 @@ double wtime()
 	return (double) tv.tv_sec + 1e-6 * (double) tv.tv_usec;
 }
 
+// ---- environment switches --------------------------------------------------------------------
+const char *env_get(const char *name)
+{
+	// (the list of include/spasm_hip.h, section "Environment")
+	static const char *const supported[] = {"SPASM_HIP_VERBOSE", "SPASM_HIP_THREADS", "SPASM_HIP_PIVOT_SEARCH", "SPASM_HIP_BACKSOLVE", "SPASM_HIP_SPARSE_IMAGE",
+	                                        "SPASM_HIP_DEVICE_FINISH", "SPASM_HIP_KEEP_GB", "SPASM_HIP_SCRATCH_GB", "SPASM_HIP_STAGE_GB",
+	                                        "SPASM_HIP_SPARSE_IMAGE_GB", "SPASM_HIP_EXPERIMENT"};
+	const char *v = std::getenv(name);
+	if (v == nullptr)
+		return nullptr;
+	for (const char *s : supported)
+		if (std::strcmp(s, name) == 0)
+			return v;
+	static int experiment = -1;
+	if (experiment < 0) {
+		const char *e = std::getenv("SPASM_HIP_EXPERIMENT");
+		experiment = (e != nullptr && *e != 0 && std::strcmp(e, "0") != 0) ? 1 : 0;
+	}
+	if (experiment == 0) {
+		static bool warned = false;
+		if (!warned) {
+			warned = true;
+			std::fprintf(stderr, "[spasm-hip] %s is set but SPASM_HIP_EXPERIMENT is not: switches outside the supported list (include/spasm_hip.h) are ignored\n", name);
+		}
+		return nullptr;
+	}
+	return v;
+}
+
 int verbose()
 {
 	static int v = -1;
 	if (v < 0) {
-		const char *e = std::getenv("SPASM_HIP_VERBOSE");
+		const char *e = env_get("SPASM_HIP_VERBOSE");
 		v = (e == nullptr) ? 1 : std::atoi(e);
 	}
 	return v;

@@ -90,7 +90,7 @@ struct PsCtrl {
 
 int env_int(const char *name, int dflt)
 {
-	const char *e = std::getenv(name);
+	const char *e = sh::env_get(name);
 	return (e == nullptr || *e == 0) ? dflt : std::atoi(e);
 }
 
@@ -580,7 +580,7 @@ __global__ __launch_bounds__(64) void pivot_search_kernel(const i64 *Ap, const i
 int device_acyclic_greedy(const struct spasm_csr *A, int *pinv, int *qinv)
 {
 	const int n = A->n, m = A->m;
-	if (const char *e = std::getenv("SPASM_HIP_PIVOT_SEARCH"))
+	if (const char *e = sh::env_get("SPASM_HIP_PIVOT_SEARCH"))
 		if (std::strcmp(e, "host") == 0)
 			return -1;
 	int ndev = 0;
@@ -591,7 +591,7 @@ int device_acyclic_greedy(const struct spasm_csr *A, int *pinv, int *qinv)
 	const int words = ((m + 31) / 32 + 255) / 256 * 256;          // (cleared 256 words at a time)
 	// the reached-bits in LDS when one bit per column fits 64 KB (and a column fits 20 bits), else in HBM
 	bool global_bits = (size_t) words * 4 + (64 + 8 + PS_LIST + 64) * sizeof(int) > 64 * 1024 || m > (1 << 20);          // (room for the list, needed or not)
-	if (const char *e = std::getenv("SPASM_HIP_PIVOT_BITS"))
+	if (const char *e = sh::env_get("SPASM_HIP_PIVOT_BITS"))
 		global_bits = global_bits || std::strcmp(e, "global") == 0;
 	// rows with more than six other entries have no 16-byte record: their entries go through a list in LDS (if there are any)
 	int list_cap = 0;
@@ -696,7 +696,7 @@ int device_acyclic_greedy(const struct spasm_csr *A, int *pinv, int *qinv)
 			qinv[col] = rows[t];
 			found += 1;
 		}
-		if (found >= 0 && std::getenv("SPASM_HIP_PIVOT_STATS"))
+		if (found >= 0 && sh::env_get("SPASM_HIP_PIVOT_STATS"))
 			logmsg("[pivots] device: %d searches in flight (%d per CU, %zu bytes of LDS each%s), %llu pivot rows visited in %llu steps, %d tickets for %d pivots, "
 			       "%d rows given up (FIFO full) [%.3fs: %.3f upload of A + allocations, %.3f kernels, %.3f journal; in the search kernel the first wave "
 			       "ran out of rows after %.1f ms, the last one left after %.1f ms, the longest search of one row took %.1f ms; "

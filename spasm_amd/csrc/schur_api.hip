@@ -64,7 +64,7 @@ namespace {
 
 int env_int(const char *name, int dflt)
 {
-	const char *e = std::getenv(name);
+	const char *e = sh::env_get(name);
 	return (e == nullptr || *e == 0) ? dflt : std::atoi(e);
 }
 
@@ -557,9 +557,9 @@ namespace sh {
 // switch the image off; batches under 1024 rows (density samples, completion tests) only trigger a build when Sm <= 8192.
 bool backsolve_wanted(const spasm_hip_dfact *F, bool other_path_forced, int nrows)
 {
-	const char *e = std::getenv("SPASM_HIP_BACKSOLVE");
+	const char *e = sh::env_get("SPASM_HIP_BACKSOLVE");
 	const int mode = (e == nullptr || *e == 0) ? -1 : std::atoi(e);
-	if (mode == 0 || !F->bs.planned)
+	if (mode == 0 || !(F->bs.planned || F->bs_deferred))
 		return false;
 	if (F->bs.d_R == nullptr) {
 		size_t free_b = 0, total_b = 0;
@@ -619,7 +619,7 @@ bool sparse_image_wanted(const spasm_hip_dfact *F, bool other_path_forced, int n
 	                       (3.0 * n * Sm * eb + 2.0 * n * Sm * eb + 8.0 * density * n * Sm) / 4.5e12 + 0.4e-3;
 	const double elim_per_row = (B.elim_hint >= 0.0) ? B.elim_hint : 0.05 * r;
 	const double t_rows = 0.3e-3 + 27e-12 * elim_per_row * n;
-	const double t_other = B.planned ? std::min(t_dense, t_rows) : t_rows;
+	const double t_other = (B.planned || F->bs_deferred) ? std::min(t_dense, t_rows) : t_rows;
 	const double t_sparse = 8e-6 * (double) S.nlevels + 27e-12 * density * n * Sm + 3e-9 * n + 0.5e-3;
 	return t_sparse < t_other;
 }
@@ -1037,19 +1037,31 @@ spasm_hip_dfact *spasm_hip_dfact_create(const struct spasm_csr *U, const int *qi
 	const double t_uploaded = wtime();
 	// back-substituted image (backsolve.hip): planned when the non-pivotal columns are few enough for dense rows
 	// of R; R itself is computed by the first Schur complement that wants it
-	int64_t bs_bytes = 0;
-	if (env_int("SPASM_HIP_BACKSOLVE", -1) != 0 && backsolve_eligible(r, m - r, F->nnz, &bs_bytes, F->prime))
-		backsolve_plan(P, F, stream);
 	// sparse image (sparse_image.hip): its dependency tables, for wide factors (R itself is built by the first batch that wants it)
-	const double t_bs = wtime();
-	if (sparse_image_possible(F->prime) && r > 0 && m - r > 0 &&
-	    (env_int("SPASM_HIP_SPARSE_IMAGE", -1) == 1 || (m - r >= 8192 && (double) r * (double) (m - r) >= 5e8)))
+	const bool plan_sparse = sparse_image_possible(F->prime) && r > 0 && m - r > 0 &&
+	                         (env_int("SPASM_HIP_SPARSE_IMAGE", -1) == 1 || (m - r >= 8192 && (double) r * (double) (m - r) >= 5e8));
+	if (plan_sparse)
 		sparse_image_plan(P, F, stream);
+	const double t_bs = wtime();
 	if (verbose() >= 2 && F->sp.planned)
-		logmsg("[factor image] tables of the sparse image: %.1f ms\n", 1e3 * (wtime() - t_bs));
+		logmsg("[factor image] tables of the sparse image: %.1f ms\n", 1e3 * (t_bs - t_uploaded));
+	int64_t bs_bytes = 0;
+	if (env_int("SPASM_HIP_BACKSOLVE", -1) != 0 && backsolve_eligible(r, m - r, F->nnz, &bs_bytes, F->prime)) {
+		if (F->sp.planned && env_int("SPASM_HIP_BACKSOLVE", -1) != 1 && env_int("SPASM_HIP_BS_PLAN_EAGER", 0) == 0) {
+			// the plan of the dense image waits for a batch that wants it (backsolve_build); what the path choice reads is known now
+			F->bs.r = r;
+			F->bs.Sm = m - r;
+			F->bs.ldR = ((int64_t) (m - r) + 511) / 512 * 512;
+			F->bs.ndeps = F->sp.ndeps;
+			F->bs_deferred = true;
+			F->host_plan = std::make_unique<FactPlan>(std::move(P));
+		} else {
+			backsolve_plan(P, F, stream);
+		}
+	}
 	if (verbose() >= 2)
 		logmsg("[factor image] %d rows, %d levels: level schedule + relabelling %.1f ms, tables + upload %.1f ms, plan of the back-substitution %.1f ms\n",
-		       r, P.nlevels, 1e3 * (t_planned - t_begin), 1e3 * (t_uploaded - t_planned), 1e3 * (t_bs - t_uploaded));
+		       r, F->nlevels, 1e3 * (t_planned - t_begin), 1e3 * (t_uploaded - t_planned), 1e3 * (wtime() - t_bs));
 	return F;
 }
 

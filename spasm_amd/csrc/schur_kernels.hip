@@ -1941,7 +1941,7 @@ void launch_schur_group(const SchurArgs &a, unsigned char *scratch, int64_t slot
 	const size_t piv_bytes = ((size_t) a.r / 32 + 1) * 4;
 	const size_t all_bytes = (((size_t) a.r + (size_t) a.Sm) / 32 + 2) * 4;
 	const bool lbm = piv_bytes <= (size_t) GR_LBM_MAX_BYTES;
-	d.touched_lds = (lbm && all_bytes <= (size_t) GR_LBM_MAX_BYTES && getenv("SPASM_HIP_GROUP_TOUCHED_HBM") == nullptr) ? 1 : 0;     // (the knob: tests)
+	d.touched_lds = (lbm && all_bytes <= (size_t) GR_LBM_MAX_BYTES && sh::env_get("SPASM_HIP_GROUP_TOUCHED_HBM") == nullptr) ? 1 : 0;     // (the knob: tests)
 	const size_t bm_bytes = d.touched_lds ? all_bytes : piv_bytes;
 	const int nwv = waves >= 4 ? 4 : waves >= 2 ? 2 : 1;
 #define SPASM_LAUNCH_GROUP(WIDE_, LBM_, LDS_)                                                    \

@@ -42,7 +42,7 @@ constexpr int SHARD_STRIDE = 16;                        // 64-bit words per shar
 
 int env_sp(const char *name, int dflt)
 {
-	const char *e = std::getenv(name);
+	const char *e = sh::env_get(name);
 	return (e == nullptr || *e == 0) ? dflt : std::atoi(e);
 }
 

@@ -7,6 +7,9 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
+# the tests pick kernel variants and debugging aids by name: switches outside the supported list need this (spasm_hip.h, "Environment")
+os.environ.setdefault("SPASM_HIP_EXPERIMENT", "1")
+
 GOLDEN = os.path.join(ROOT, "tests", "golden")
 
 # moduli and matrices of the reference's own suite (tests/CMakeLists.txt:45-52, 75-110)

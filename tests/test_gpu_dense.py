@@ -384,16 +384,18 @@ def _extend_and_check(p, blocks, m, oracle=None):
         # ... and directly against the oracle (oracle/spasm_oracle.c: orc_dense_rref, pinned on the reference's own dense_rref
         # test): the echelon rows are reduced, so sorted by pivot column they ARE the unique RREF of the row space of the input
         if oracle is not None:
-            r_o, R_o, qinv_o = oracle.dense_rref(p, stack.cpu().numpy().astype(np.int64))
+            # (orc_dense_rref follows spasm_ffpack_rref, spasm_ffpack.cpp:23-66: the matrix comes back as [I | R'] in PERMUTED
+            #  columns -- q[0..rank) are the pivot columns of the rows, q[rank..m) the other columns in increasing order)
+            r_o, R_o, q_o = oracle.dense_rref(p, stack.cpu().numpy().astype(np.int64))
             assert r_o == k
             if k:
-                order = torch.argsort(J)
-                got = E[order].cpu().numpy().astype(np.int64)
-                piv_o = np.flatnonzero(qinv_o >= 0)
-                piv_o = piv_o[np.argsort(qinv_o[piv_o])]          # pivot column of every row of the oracle's RREF
-                assert np.array_equal(np.sort(J.cpu().numpy()), np.sort(piv_o))
-                want = np.mod(R_o[:r_o], p)
+                piv_o = np.asarray(q_o[:r_o], np.int64)
+                want = np.zeros((r_o, m), np.int64)
+                want[np.arange(r_o), piv_o] = 1
+                want[:, np.asarray(q_o[r_o:], np.int64)] = np.mod(R_o[:r_o, r_o:], p)
                 want = want[np.argsort(piv_o)]
+                got = E[torch.argsort(J)].cpu().numpy().astype(np.int64)
+                assert np.array_equal(np.sort(J.cpu().numpy()), np.sort(piv_o))
                 assert np.array_equal(got, want)
     return k
 

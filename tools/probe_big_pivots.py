@@ -1,5 +1,6 @@
 import os, sys, time
 sys.path.insert(0, "/root/repo"); sys.path.insert(0, "/root/repo/tools")
+os.environ.setdefault("SPASM_HIP_EXPERIMENT", "1")          # (this script names kernel variants and debugging aids)
 os.environ.setdefault("SPASM_HIP_VERBOSE", "1")
 import spasm_amd, workloads
 A, src = workloads.load_matrix("mk14.b5")

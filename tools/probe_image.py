@@ -1,5 +1,6 @@
 """how long does the factor image of a workload take to build (host plan + upload), and where?  SPASM_HIP_VERBOSE=2 prints the split."""
 import os
+os.environ.setdefault("SPASM_HIP_EXPERIMENT", "1")          # (this script names kernel variants and debugging aids)
 import sys
 import time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))

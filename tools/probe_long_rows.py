@@ -9,6 +9,7 @@ import numpy as np
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
+os.environ.setdefault("SPASM_HIP_EXPERIMENT", "1")          # (this script names kernel variants and debugging aids)
 os.environ.setdefault("SPASM_HIP_VERBOSE", "1")
 os.environ.setdefault("SPASM_HIP_PIVOT_STATS", "1")
 import spasm_amd

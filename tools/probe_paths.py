@@ -11,6 +11,7 @@ import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tools"))
+os.environ.setdefault("SPASM_HIP_EXPERIMENT", "1")          # (this script names kernel variants and debugging aids)
 os.environ.setdefault("SPASM_HIP_VERBOSE", "0")
 ap = argparse.ArgumentParser()
 ap.add_argument("--workload", default="mk13.b4")

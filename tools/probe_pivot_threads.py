@@ -1,5 +1,6 @@
 """host pivot search (spasm_hip_pivots_extract_structural) against the thread count, on the box's cores."""
 import os
+os.environ.setdefault("SPASM_HIP_EXPERIMENT", "1")          # (this script names kernel variants and debugging aids)
 import sys
 import time
 

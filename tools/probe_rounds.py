@@ -1,3 +1,5 @@
+import os
+os.environ.setdefault("SPASM_HIP_EXPERIMENT", "1")
 import sys, time, os
 sys.path.insert(0,'/root/repo'); sys.path.insert(0,'/root/repo/tools')
 os.environ["SPASM_HIP_VERBOSE"]="1"

@@ -8,6 +8,7 @@ mkdir -p $OUT
 rm -rf $OUT/trace
 export TMPDIR=/tmp
 export PROBE_CALLS=1
+export SPASM_HIP_EXPERIMENT=1
 export SPASM_HIP_RREF_TIMING=1
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -- python3 tools/probe_standins.py $NAME > $OUT/out.txt 2> $OUT/err.txt
 f=$(find $OUT/trace -name "*kernel_stats.csv" | head -1)
