@@ -20,6 +20,21 @@
  * Error behaviour: like the reference (spasm_util.c:62-83, err()/errx()), a
  * fatal condition -- no usable GPU, out of device memory, malformed input --
  * prints "[spasm-hip] ..." on stderr and exits.  There is NO CPU fallback.
+ *
+ * Environment.  These switches are supported (read at every call):
+ *   SPASM_HIP_VERBOSE=0..3        progress messages on stderr (default 1: what the reference prints)
+ *   SPASM_HIP_THREADS=n           host threads of the pivot search and the planning (default: the CPU quota of the cgroup)
+ *   SPASM_HIP_PIVOT_SEARCH=host|device   where the greedy cycle-free search runs (default: the device when there is one)
+ *   SPASM_HIP_SPARSE_IMAGE=0|1    never / always take the sparse image R = U_pp^-1 U_pn for a Schur complement (default: cost model)
+ *   SPASM_HIP_BACKSOLVE=0|1       never / always take the dense image (default: cost model); both 0: row-by-row kernels
+ *   SPASM_HIP_DEVICE_FINISH=0|1|2 dense / low-rank finish in the host loops / on the device / on the device only with the dense image
+ *   SPASM_HIP_KEEP_GB=n           device memory the block cache keeps between calls (default: a quarter of the HBM; 0: none)
+ *   SPASM_HIP_SCRATCH_GB=n        accumulator slices of the row-by-row kernels (default: up to half of the free HBM)
+ *   SPASM_HIP_STAGE_GB=n          staging buffer of the dense image's output (default 8)
+ *   SPASM_HIP_SPARSE_IMAGE_GB=n   cap of the fragment pool of the sparse image (default: a third of the free HBM, at most half
+ *                                 the bytes of the dense form)
+ * Every other SPASM_HIP_* name in the sources picks a kernel variant, a debugging aid or a code path kept for A/B runs and
+ * tests; they are ignored (with one warning) unless SPASM_HIP_EXPERIMENT=1 is set as well.
  */
 #ifndef SPASM_HIP_H
 #define SPASM_HIP_H
@@ -111,7 +126,7 @@ int spasm_hip_device_count(void);
  * takes that many threads; a box of this pool reports 256 hardware threads and grants 16 CPUs) */
 int spasm_hip_usable_cpus(void);
 /* Between host-level calls the library parks device memory it would otherwise allocate again -- the accumulator scratch of
- * the row-by-row kernels, and the blocks of its buffer cache up to SPASM_HIP_KEEP_GB (default 96 = all of them; 0 = none:
+ * the row-by-row kernels, and the blocks of its buffer cache up to SPASM_HIP_KEEP_GB (default: a quarter of the device memory; 0 = none:
  * multi-GB blocks take 0.1 to 1 s apiece to free and allocate again, erratically).  This gives all of it back. */
 void spasm_hip_release_cached_memory(void);
 const char *spasm_hip_version(void);

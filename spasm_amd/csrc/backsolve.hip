@@ -1875,7 +1875,6 @@ void backsolve_build(const spasm_hip_dfact *F, hipStream_t stream)
 		// (a factor with the tables of the sparse image: the plan of the dense one was left for the batch that wants it)
 		backsolve_plan(*F->host_plan, const_cast<spasm_hip_dfact *>(F), stream);
 		F->bs_deferred = false;
-		F->host_plan.reset();
 	}
 	if (!B.planned)
 		die("backsolve_build: the factor has no back-substitution plan");

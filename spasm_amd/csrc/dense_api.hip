@@ -125,6 +125,7 @@ static int dschur_dense_impl(const spasm_hip_dcsr *A, const int *d_rows, int nro
 		HIP_CHECK(hipStreamSynchronize(stream));
 		return 0;
 	}
+	ensure_row_tables(F, stream);
 	// a column receives at most maxdeg + 1 terms, each below 2p (the row-group kernel adds unreduced products)
 	const bool wide = (2.0 * (double) F->prime * ((double) F->maxdeg + 3.0) >= 4294967296.0);
 	int dev = 0;

@@ -240,6 +240,7 @@ void resident_begin();
 void resident_end();
 void resident_forget(const struct spasm_csr *A);
 bool resident_enabled();
+void ensure_row_tables(const struct ::spasm_hip_dfact *F, hipStream_t stream);
 void resident_counters(int64_t *uploads, int64_t *hits);
 void resident_lazy_downloads(bool on);
 void resident_materialize(const struct spasm_csr *A);
@@ -265,8 +266,11 @@ struct BsDirectOut {
 // opaque handles of the C ABI
 struct spasm_hip_dfact {
 	int m = 0, r = 0, Sm = 0, nlevels = 0;
-	int rpad = 0, maxdeg = 0;
-	int ncomp = 0, comp_largest = 0;   // connected components of the pivot graph, rows of the largest one
+	int rpad = 0;
+	// (filled by ensure_row_tables when a row-by-row path first runs)
+	mutable bool row_tables = false;
+	mutable int maxdeg = 0;
+	mutable int ncomp = 0, comp_largest = 0;   // connected components of the pivot graph, rows of the largest one
 	int64_t nnz = 0;
 	int64_t prime = 0;
 	sh::Mont mont{};
@@ -275,7 +279,7 @@ struct spasm_hip_dfact {
 	uint64_t *d_rp = nullptr;
 	uint2 *d_ent = nullptr;
 	uint2 *d_head = nullptr;
-	uint32_t *d_comp = nullptr;     // label -> smallest label of its connected component in the pivot graph
+	mutable uint32_t *d_comp = nullptr;     // label -> smallest label of its connected component in the pivot graph (ensure_row_tables)
 	uint32_t *d_lvl_end = nullptr;
 	uint32_t *d_lvl_end_w = nullptr;
 	int *d_kof = nullptr;          // label -> row of U (-1: padding label)

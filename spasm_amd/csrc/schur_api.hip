@@ -882,67 +882,68 @@ static void plan_factor(const struct spasm_csr *U, const int *qinv, FactPlan &P)
 				P.head[(size_t) c * 4 + t] = P.ent[P.rp[c] + t];
 		}
 	};
-	// connected components of the pivot graph (row c -- the pivots it touches): rows of the matrix whose pivotal
-	// entries lie in different components share no elimination at all; the row-group kernel regroups rows by
-	// component when the order of the row list turns out to be unrelated to the structure
-	P.comp.assign((size_t) (rpad > 0 ? rpad : 1), 0);
-	auto components = [&]() {
-		std::vector<uint32_t> parent((size_t) (rpad > 0 ? rpad : 1));
-		for (int c = 0; c < rpad; c++)
-			parent[c] = (uint32_t) c;
-		auto find = [&](uint32_t x) {
-			while (parent[x] != x) {
-				parent[x] = parent[parent[x]];
-				x = parent[x];
-			}
-			return x;
-		};
-		for (int k = 0; k < r; k++) {
-			const uint32_t c = (uint32_t) P.label_of_row[k];
-			for (i64 px = U->p[k] + 1; px < U->p[k + 1]; px++) {
-				const uint32_t t = P.lab[U->j[px]];
-				if (t < (uint32_t) rpad) {
-					const uint32_t a = find(c), b = find(t);
-					if (a != b)
-						parent[std::max(a, b)] = std::min(a, b);          // the root is the smallest label
-				}
-			}
-		}
-		std::vector<int> members((size_t) (rpad > 0 ? rpad : 1), 0);
-		for (int c = 0; c < rpad; c++) {
-			P.comp[c] = find((uint32_t) c);
-			if (P.kof[c] >= 0)
-				members[P.comp[c]] += 1;
-		}
-		for (int c = 0; c < rpad; c++)
-			if (members[c] > 0) {
-				P.ncomp += 1;
-				P.comp_largest = std::max(P.comp_largest, members[c]);
-			}
-	};
 	{
-		const int T = (r < 20000) ? 1 : std::max(1, std::min(8, usable_cpus() - 1));
+		const int T = (r < 20000) ? 1 : std::max(1, std::min(8, usable_cpus()));
 		std::vector<std::thread> pool;
-		if (T > 1)
-			pool.emplace_back(components);
 		for (int t = 1; t < T; t++)
 			pool.emplace_back(fill, (int) ((i64) rpad * t / T), (int) ((i64) rpad * (t + 1) / T));
 		fill(0, (int) ((i64) rpad / T));
-		if (T == 1)
-			components();
 		for (auto &th : pool)
 			th.join();
 	}
-	{
-		std::vector<int> deg((size_t) (m > 0 ? m : 1), 0);
-		for (int k = 0; k < r; k++)
-			for (i64 px = U->p[k] + 1; px < U->p[k + 1]; px++)
-				deg[U->j[px]] += 1;
-		for (int j = 0; j < m; j++)
-			P.maxdeg = std::max(P.maxdeg, deg[j]);
-	}
-	lap("entries + heads + components");
+	lap("entries + heads");
 
+}
+
+// What only the row-by-row kernels read, computed when they are first asked for (a quarter of the planning time, and the
+// image paths never look at it): the connected components of the pivot graph -- rows of the matrix whose pivotal entries
+// lie in different components share no elimination at all; the row-group kernel regroups rows by component when the order
+// of the row list turns out to be unrelated to the structure -- and the largest number of rows of U' that hold one label
+// (how many terms an accumulator may receive).  From the relabelled entries of the plan: no access to U.
+static void plan_row_tables(FactPlan &P)
+{
+	const int rpad = P.rpad;
+	P.comp.assign((size_t) (rpad > 0 ? rpad : 1), 0);
+	P.ncomp = 0;
+	P.comp_largest = 0;
+	P.maxdeg = 0;
+	std::vector<uint32_t> parent((size_t) (rpad > 0 ? rpad : 1));
+	for (int c = 0; c < rpad; c++)
+		parent[c] = (uint32_t) c;
+	auto find = [&](uint32_t x) {
+		while (parent[x] != x) {
+			parent[x] = parent[parent[x]];
+			x = parent[x];
+		}
+		return x;
+	};
+	std::vector<int> deg((size_t) rpad + (size_t) (P.m - P.r) + 1, 0);
+	for (int c = 0; c < rpad; c++) {
+		if (P.kof[c] < 0)
+			continue;
+		for (uint64_t e = P.rp[c]; e < P.rp[c + 1]; e++) {
+			const uint32_t t = P.ent[e].x;
+			deg[t] += 1;
+			if (t < (uint32_t) rpad) {
+				const uint32_t a = find((uint32_t) c), b = find(t);
+				if (a != b)
+					parent[std::max(a, b)] = std::min(a, b);          // the root is the smallest label
+			}
+		}
+	}
+	for (size_t t = 0; t < deg.size(); t++)
+		P.maxdeg = std::max(P.maxdeg, deg[t]);
+	std::vector<int> members((size_t) (rpad > 0 ? rpad : 1), 0);
+	for (int c = 0; c < rpad; c++) {
+		P.comp[c] = find((uint32_t) c);
+		if (P.kof[c] >= 0)
+			members[P.comp[c]] += 1;
+	}
+	for (int c = 0; c < rpad; c++)
+		if (members[c] > 0) {
+			P.ncomp += 1;
+			P.comp_largest = std::max(P.comp_largest, members[c]);
+		}
 }
 
 // CPU-only view of the plan, for tests: label of each row of U, end of the
@@ -961,6 +962,7 @@ int spasm_hip_debug_plan(const struct spasm_csr *U, const int *qinv, int *label_
 	for (int j = 0; j < P.m; j++)
 		lab[j] = (int) P.lab[j];
 	info[0] = P.rpad;
+	plan_row_tables(P);
 	info[1] = P.maxdeg;
 	return P.nlevels;
 }
@@ -979,9 +981,6 @@ spasm_hip_dfact *spasm_hip_dfact_create(const struct spasm_csr *U, const int *qi
 	F->m = m;
 	F->r = r;
 	F->rpad = rpad;
-	F->maxdeg = P.maxdeg;
-	F->ncomp = P.ncomp;
-	F->comp_largest = P.comp_largest;
 	F->Sm = m - r;
 	F->prime = P.prime;
 	F->mont = mont_setup(P.prime);
@@ -995,8 +994,6 @@ spasm_hip_dfact *spasm_hip_dfact_create(const struct spasm_csr *U, const int *qi
 	F->d_ent = dalloc<uint2>(F->nnz);
 	F->d_head = dalloc<uint2>((i64) rpad * 4);
 	upload(F->d_head, P.head.data(), (i64) rpad * 4, stream);
-	F->d_comp = dalloc<uint32_t>(rpad);
-	upload(F->d_comp, P.comp.data(), (i64) rpad, stream);
 	F->d_lvl_end = dalloc<uint32_t>(rpad);
 	F->d_lvl_end_w = dalloc<uint32_t>(rpad / 32);
 	F->d_kof = dalloc<int>(rpad);
@@ -1054,7 +1051,6 @@ spasm_hip_dfact *spasm_hip_dfact_create(const struct spasm_csr *U, const int *qi
 			F->bs.ldR = ((int64_t) (m - r) + 511) / 512 * 512;
 			F->bs.ndeps = F->sp.ndeps;
 			F->bs_deferred = true;
-			F->host_plan = std::make_unique<FactPlan>(std::move(P));
 		} else {
 			backsolve_plan(P, F, stream);
 		}
@@ -1062,8 +1058,40 @@ spasm_hip_dfact *spasm_hip_dfact_create(const struct spasm_csr *U, const int *qi
 	if (verbose() >= 2)
 		logmsg("[factor image] %d rows, %d levels: level schedule + relabelling %.1f ms, tables + upload %.1f ms, plan of the back-substitution %.1f ms\n",
 		       r, F->nlevels, 1e3 * (t_planned - t_begin), 1e3 * (t_uploaded - t_planned), 1e3 * (wtime() - t_bs));
+	// the host part of the image stays: the tables of the row-by-row kernels (ensure_row_tables) and a deferred plan of the dense
+	// image are made from it when somebody asks
+	F->host_plan = std::make_unique<FactPlan>(std::move(P));
 	return F;
 }
+
+}  // extern "C"
+
+namespace sh {
+// components of the pivot graph + largest column degree, on first use by a row-by-row path (plan_row_tables)
+void ensure_row_tables(const spasm_hip_dfact *F, hipStream_t stream)
+{
+	static std::mutex mutex;
+	std::lock_guard<std::mutex> guard(mutex);
+	if (F->row_tables)
+		return;
+	if (!F->host_plan)
+		die("ensure_row_tables: the factor image has lost its host plan");
+	const double t0 = wtime();
+	FactPlan &P = *F->host_plan;
+	plan_row_tables(P);
+	F->maxdeg = P.maxdeg;
+	F->ncomp = P.ncomp;
+	F->comp_largest = P.comp_largest;
+	F->d_comp = dalloc<uint32_t>(F->rpad);
+	upload(F->d_comp, P.comp.data(), (i64) F->rpad, stream);
+	HIP_CHECK(hipStreamSynchronize(stream));
+	F->row_tables = true;
+	if (verbose() >= 2)
+		logmsg("[factor image] tables of the row-by-row kernels (components of the pivot graph, column degrees): %.1f ms\n", 1e3 * (wtime() - t0));
+}
+}  // namespace sh
+
+extern "C" {
 
 void spasm_hip_dfact_destroy(spasm_hip_dfact *F)
 {
@@ -1198,7 +1226,7 @@ int dschur_impl(const spasm_hip_dcsr *A, const int *d_rows, int nrows, const spa
 	const bool wide_lds = ((double) F->prime * 6146.0 >= 4294967296.0);
 	// ... and in the dense accumulators: a column receives at most maxdeg + 1 terms, each below 2p (the
 	// row-group kernel adds unreduced products)
-	const bool wide_dense = (2.0 * (double) F->prime * ((double) F->maxdeg + 3.0) >= 4294967296.0);
+	bool wide_dense = false;          // (set below, once it is known that a row-by-row path runs: it needs the tables of ensure_row_tables)
 	const int sort_rows = env_int("SPASM_HIP_SORT_ROWS", 1);
 	const int small_table = 1024, big_table = 8192;
 	const int cus = cu_count();
@@ -1231,6 +1259,10 @@ int dschur_impl(const spasm_hip_dcsr *A, const int *d_rows, int nrows, const spa
 		want_sp = built_sp;
 	}
 	const bool want_bs = !want_sp && nrows > 0 && Lout == nullptr && backsolve_wanted(F, other_forced, nrows);
+	if (!want_bs && !want_sp) {
+		ensure_row_tables(F, stream);
+		wide_dense = (2.0 * (double) F->prime * ((double) F->maxdeg + 3.0) >= 4294967296.0);
+	}
 	// per-wave dense scratch, (re)allocated when the factor geometry needs more
 	if (!want_bs && !want_sp) {
 		i64 slot_bytes, off_bm, off_xn;
