@@ -321,7 +321,7 @@ def main():
                     help="how N > 1 ranks share a step: `rows` = contiguous slices of the row list, S reassembled on every rank with "
                          "an all-gatherv over RCCL; `columns` = every rank owns a slab of the non-pivotal columns of ALL rows "
                          "(spasm_hip_column_slab: no replicated factor image, only the row lengths are exchanged); auto = columns "
-                         "when the factor takes the back-substituted path (its columns never meet), rows otherwise")
+                         "(the columns of R and S never meet on either image path)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true",
                     help="skip the row-by-row comparison, the dense-tail probe and the end-to-end runs")
@@ -389,8 +389,9 @@ def main():
     from spasm_amd.dist import shard_rows, column_slab
     split = args.split
     if split == "auto":
-        # the back-substituted image is eligible up to 24,576 non-pivotal columns; one rank: nothing to split
-        split = "columns" if (world > 1 and A.m - F.U.n <= 24576) else "rows"
+        # both image paths -- the dense one and, since round 4, the sparse one (no limit on the width) -- compute the columns of
+        # S independently of each other: a slab of the non-pivotal columns per rank replicates nothing.  One rank: nothing to split
+        split = "columns" if world > 1 else "rows"
     if world == 1 and os.environ.get("SPASM_BENCH_FORCE_DIST") != "1":
         split = "rows"
     A_full, F_full = A, F
