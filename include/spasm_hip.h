@@ -386,6 +386,14 @@ void spasm_hip_shard(int n, int rank, int world, int *lo, int *hi);             
 int spasm_hip_dschur_allgatherv(spasm_hip_comm *c, const spasm_hip_dwork *W, i64 *d_Sp, int *d_Sj, spasm_ZZp *d_Sx, i64 cap,
                                 int *total_rows, i64 *total_nnz, void *stream);
 
+/* Column split (the image paths: the columns of R and of S never meet).  With a communicator installed spasm_hip_schur gives
+ * rank k the slab k of the non-pivotal columns (spasm_hip_column_slab below): it builds ITS columns of the image only, reduces
+ * ALL rows on them, and the slabs are stacked by the all-gatherv and stitched into whole rows on every device.  The stitching
+ * alone, for `parts` slabs of n rows stacked in device arrays (d_gSp: parts * n + 1 offsets): row i of the result is slab 0's
+ * row i, then slab 1's, ...  Returns 0, or 1 when cap (entries of d_Sj / d_Sx) is too small. */
+int spasm_hip_dstitch_slabs(const i64 *d_gSp, const int *d_gSj, const spasm_ZZp *d_gSx, int n, int parts, i64 *d_Sp, int *d_Sj, spasm_ZZp *d_Sx, i64 cap,
+                            void *stream);
+
 /* The exchange plan of spasm_hip_dschur_allgatherv as a pure host function (spasm_amd/csrc/host_dist.cpp; no GPU, no
  * RCCL): the steps rank `me` issues, in order, for slices of sizes[2r] rows and sizes[2r + 1] entries.  The collective
  * executes exactly this list; tests/test_dist_cpu.py checks it for worlds of 2 to 8 (every pair's send sequence equals the

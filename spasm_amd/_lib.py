@@ -85,6 +85,7 @@ def lib():
         "spasm_hip_set_comm": (None, [vp]),
         "spasm_hip_shard": (None, [ci, ci, ci, pint, pint]),
         "spasm_hip_dschur_allgatherv": (ci, [vp, vp, vp, vp, vp, i64, pint, C.POINTER(i64), vp]),
+        "spasm_hip_dstitch_slabs": (ci, [vp, vp, vp, ci, ci, vp, vp, vp, i64, vp]),
         "spasm_hip_echelonize_dist": (plu, [pcsr, C.POINTER(EchelonizeOpts), vp]),
         "spasm_hip_allgatherv_plan": (ci, [ci, ci, C.POINTER(i64), vp, ci, C.POINTER(i64), C.POINTER(i64)]),
         "spasm_hip_column_slab": (ci, [pcsr, plu, ci, ci, C.POINTER(pcsr), C.POINTER(plu), pint]),

@@ -214,6 +214,9 @@ struct SpImage {
 
 struct SchurArgs;
 struct FactPlan;
+void launch_map_columns(int *d_Sj, int64_t nnz, const int *d_cols, hipStream_t stream);
+void launch_stitch_slabs(const int64_t *gSp, const int *gSj, const int *gSx, int n, int parts, int64_t *Sp, int *Sj, int *Sx, int64_t cap, int *d_len,
+                         unsigned long long *d_block_sum, int *d_ctr, hipStream_t stream);
 void launch_scan_lengths(const int *len, int n, const unsigned long long *block_sum, int64_t *Sp, int64_t cap, int *ctr, hipStream_t stream);
 
 // device copy of a host CSR matrix for the duration of a call (schur_api.hip: resident between the calls of a driver)

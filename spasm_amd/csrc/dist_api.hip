@@ -47,6 +47,71 @@ __global__ void rebase_offsets_kernel(int64_t *Sp, int n, int64_t base)
 		Sp[t] += base;
 }
 
+// ---- column split: the slabs of a Schur complement, stacked by the all-gatherv, become whole rows ----------------
+// Rank k has reduced ALL n rows on its slab of the non-pivotal columns; the all-gatherv stacks the slabs (rows k n .. k n + n
+// of the stack are rank k's), and row i of S is the concatenation over k of row k n + i -- the slabs are ranges of columns
+// in increasing order, so the row comes out sorted.
+__global__ __launch_bounds__(256) void stitch_lengths_kernel(const int64_t *gSp, int n, int parts, int *len, unsigned long long *block_sum)
+{
+	const int i = blockIdx.x * blockDim.x + threadIdx.x;
+	if (i >= n)
+		return;
+	int64_t t = 0;
+	for (int k = 0; k < parts; k++)
+		t += gSp[(int64_t) k * n + i + 1] - gSp[(int64_t) k * n + i];
+	len[i] = (int) t;
+	atomicAdd(&block_sum[i >> 10], (unsigned long long) t);
+}
+
+__global__ __launch_bounds__(256) void stitch_rows_kernel(const int64_t *gSp, const int *gSj, const int *gSx, int n, int parts, const int64_t *Sp, int *Sj, int *Sx,
+                                                          int64_t cap)
+{
+	const int lane = threadIdx.x & 63;
+	const int wave = (int) ((blockIdx.x * blockDim.x + threadIdx.x) >> 6), nwaves = (int) ((gridDim.x * blockDim.x) >> 6);
+	for (int i = wave; i < n; i += nwaves) {
+		int64_t w = Sp[i];
+		if (Sp[i + 1] > cap)
+			continue;          // (the scan has raised the overflow flag)
+		for (int k = 0; k < parts; k++) {
+			const int64_t lo = gSp[(int64_t) k * n + i], hi = gSp[(int64_t) k * n + i + 1];
+			for (int64_t t = lo + lane; t < hi; t += 64) {
+				Sj[w + (t - lo)] = gSj[t];
+				Sx[w + (t - lo)] = gSx[t];
+			}
+			w += hi - lo;
+		}
+	}
+}
+
+// slab-local column numbers -> columns of the matrix
+__global__ __launch_bounds__(256) void map_columns_kernel(int *Sj, int64_t nnz, const int *cols)
+{
+	for (int64_t t = (int64_t) blockIdx.x * blockDim.x + threadIdx.x; t < nnz; t += (int64_t) gridDim.x * blockDim.x)
+		Sj[t] = cols[Sj[t]];
+}
+
+void launch_map_columns(int *d_Sj, int64_t nnz, const int *d_cols, hipStream_t stream)
+{
+	if (nnz > 0)
+		hipLaunchKernelGGL(map_columns_kernel, dim3((unsigned) std::min<int64_t>((nnz + 255) / 256, 65536)), dim3(256), 0, stream, d_Sj, nnz, d_cols);
+}
+
+// the stack of `parts` slabs of n rows each (gSp: parts * n + 1 offsets) -> S (Sp: n + 1; Sj, Sx: gSp[parts * n] entries);
+// d_len: n ints, d_block_sum: (n + 1023) / 1024 words of scratch
+void launch_stitch_slabs(const int64_t *gSp, const int *gSj, const int *gSx, int n, int parts, int64_t *Sp, int *Sj, int *Sx, int64_t cap, int *d_len,
+                         unsigned long long *d_block_sum, int *d_ctr, hipStream_t stream)
+{
+	if (n <= 0)
+		return;
+	const int nblocks = (n + 1023) / 1024;
+	HIP_CHECK(hipMemsetAsync(d_block_sum, 0, (size_t) nblocks * sizeof(unsigned long long), stream));
+	HIP_CHECK(hipMemsetAsync(Sp, 0, sizeof(int64_t), stream));
+	hipLaunchKernelGGL(stitch_lengths_kernel, dim3((n + 255) / 256), dim3(256), 0, stream, gSp, n, parts, d_len, d_block_sum);
+	launch_scan_lengths(d_len, n, d_block_sum, Sp, cap, d_ctr, stream);
+	hipLaunchKernelGGL(stitch_rows_kernel, dim3((unsigned) std::min(n / 4 + 1, 256 * 8)), dim3(256), 0, stream, gSp, gSj, gSx, n, parts, Sp, Sj, Sx, cap);
+	HIP_CHECK(hipGetLastError());
+}
+
 // broadcast of a host buffer from `root` (staged through device memory: RCCL moves device buffers)
 void comm_bcast_host(spasm_hip_comm *c, void *buf, size_t bytes, int root)
 {
@@ -198,6 +263,27 @@ int spasm_hip_dschur_allgatherv(spasm_hip_comm *c, const spasm_hip_dwork *W, i64
 	HIP_CHECK(hipMemcpyAsync(d_Sp + row_base[world], &nz_base[world], sizeof(int64_t), hipMemcpyHostToDevice, stream));
 	HIP_CHECK(hipStreamSynchronize(stream));        // (nz_base dies here)
 	return 0;
+}
+
+// Test hook (and building block of the column split): `parts` slabs of n rows each, stacked in device arrays (gSp: parts * n + 1
+// offsets into gSj / gSx), stitched into whole rows -- row i = slab 0's row i, then slab 1's, ... -- in d_Sp (n + 1) / d_Sj /
+// d_Sx (cap entries).  Returns 0, or 1 when cap is too small.  Everything on `stream`, synchronised before returning.
+int spasm_hip_dstitch_slabs(const int64_t *d_gSp, const int *d_gSj, const spasm_ZZp *d_gSx, int n, int parts, int64_t *d_Sp, int *d_Sj, spasm_ZZp *d_Sx,
+                            int64_t cap, void *stream_)
+{
+	hipStream_t stream = (hipStream_t) stream_;
+	int *d_len = static_cast<int *>(sh::big_alloc((size_t) (n > 0 ? n : 1) * sizeof(int)));
+	unsigned long long *d_bs = static_cast<unsigned long long *>(sh::big_alloc((size_t) ((n + 1023) / 1024 + 1) * sizeof(unsigned long long)));
+	int *d_ctr = static_cast<int *>(sh::big_alloc((size_t) sh::CTR_COUNT * sizeof(int)));
+	HIP_CHECK(hipMemsetAsync(d_ctr, 0, (size_t) sh::CTR_COUNT * sizeof(int), stream));
+	sh::launch_stitch_slabs(d_gSp, d_gSj, d_gSx, n, parts, d_Sp, d_Sj, d_Sx, cap, d_len, d_bs, d_ctr, stream);
+	int status = 0;
+	HIP_CHECK(hipMemcpyAsync(&status, d_ctr + sh::CTR_STATUS, sizeof(int), hipMemcpyDeviceToHost, stream));
+	HIP_CHECK(hipStreamSynchronize(stream));
+	sh::big_free(d_len);
+	sh::big_free(d_bs);
+	sh::big_free(d_ctr);
+	return status & 1;
 }
 
 // spasm_echelonize with the Schur complements of every round sharded over the ranks of `c` (one process per GPU).

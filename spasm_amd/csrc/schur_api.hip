@@ -630,6 +630,9 @@ extern "C" {
 void spasm_hip_shard(int n, int rank, int world, int *lo, int *hi);
 int spasm_hip_dschur_allgatherv(spasm_hip_comm *c, const spasm_hip_dwork *W, i64 *d_Sp, int *d_Sj, spasm_ZZp *d_Sx, i64 cap,
                                 int *total_rows, i64 *total_nnz, void *stream);
+int spasm_hip_column_slab(const struct spasm_csr *A, const struct spasm_lu *fact, int part, int parts, struct spasm_csr **A_slab,
+                          struct spasm_lu **fact_slab, int *cols);
+void spasm_hip_lu_free(struct spasm_lu *N);
 
 int spasm_hip_debug_plan(const struct spasm_csr *U, const int *qinv, int *label_of_row, int *lvl_end_of_row, int *lab,
                          int *info);
@@ -1714,6 +1717,101 @@ void spasm_hip_dschur_fetch(const spasm_hip_dwork *W, i64 *d_Sp, int *d_Sj, spas
 }
 
 // --------------------------------------------------------------------------
+// spasm_hip_schur over several GPUs, split by columns
+// --------------------------------------------------------------------------
+// Every rank: its slab problem (host: spasm_hip_column_slab -- A and U with the other ranks' non-pivotal columns deleted),
+// its image, ALL n rows reduced on it (the ordinary one-GPU call below, communicator set aside), columns mapped back,
+// all-gatherv of the slabs, stitched into whole rows on every device, then downloaded / kept resident like any result.
+static struct spasm_csr *schur_by_column_slabs(const struct spasm_csr *A, const int *p, int n, const struct spasm_lu *fact, double est_density,
+                                               const int *p_in, int *p_out, spasm_hip_comm *comm)
+{
+	const double t0 = wtime();
+	const int m = A->m, world = comm_world(comm), rank = comm_rank(comm);
+	const i64 prime = A->field->p;
+	hipStream_t stream = nullptr;
+	struct spasm_csr *A_slab = nullptr;
+	struct spasm_lu *F_slab = nullptr;
+	std::vector<int> cols((size_t) (m > 0 ? m : 1));
+	const int mm = spasm_hip_column_slab(A, fact, rank, world, &A_slab, &F_slab, cols.data());
+	const double t_slab = wtime() - t0;
+	// the slab's Schur complement, on this device only
+	spasm_hip_set_comm(nullptr);
+	const bool was_lazy = g_lazy_download;
+	g_lazy_download = false;
+	struct spasm_csr *S_slab = spasm_hip_schur(A_slab, p, n, F_slab, est_density, nullptr, nullptr, nullptr);
+	g_lazy_download = was_lazy;
+	spasm_hip_set_comm(comm);
+	// (the slab result came to the host with the call above: what travels between the devices is uploaded again -- the slab
+	//  is 1 / world of S; keeping it on the device needs the workspace of that call, which it has released)
+	const i64 snz = S_slab->p[n];
+	spasm_hip_dwork *W = spasm_hip_dwork_create(n, m, std::max<i64>(snz, 1));
+	HIP_CHECK(hipMemcpyAsync(W->d_Sp, S_slab->p, ((size_t) n + 1) * sizeof(i64), hipMemcpyHostToDevice, stream));
+	if (snz > 0) {
+		HIP_CHECK(hipMemcpyAsync(W->d_Sj, S_slab->j, (size_t) snz * sizeof(int), hipMemcpyHostToDevice, stream));
+		HIP_CHECK(hipMemcpyAsync(W->d_Sx, S_slab->x, (size_t) snz * sizeof(int), hipMemcpyHostToDevice, stream));
+	}
+	W->last_rows = n;
+	W->last_nnz = snz;
+	int *d_cols = dalloc<int>(mm);
+	upload(d_cols, cols.data(), mm, stream);
+	launch_map_columns(W->d_Sj, snz, d_cols, stream);
+	HIP_CHECK(hipStreamSynchronize(stream));
+	resident_forget(S_slab);
+	spasm_hip_csr_free(S_slab);
+	resident_forget(A_slab);
+	spasm_hip_csr_free(A_slab);
+	spasm_hip_lu_free(F_slab);
+	// stack of the slabs, then whole rows
+	i64 total = 0;
+	int rows_all = 0;
+	(void) spasm_hip_dschur_allgatherv(comm, W, nullptr, nullptr, nullptr, -1, &rows_all, &total, stream);
+	if (rows_all != n * world)
+		die("spasm_hip_schur (columns): the ranks hold %d slab rows in all, %d expected", rows_all, n * world);
+	i64 *gSp = dalloc<i64>((i64) rows_all + 1);
+	int *gSj = dalloc<int>(total);
+	int *gSx = dalloc<int>(total);
+	if (spasm_hip_dschur_allgatherv(comm, W, gSp, gSj, gSx, total, nullptr, nullptr, stream) != 0)
+		die("spasm_hip_schur (columns): all-gatherv of the slabs failed");
+	i64 *dSp = dalloc<i64>((i64) n + 1);
+	int *dSj = static_cast<int *>(big_alloc((size_t) std::max<i64>(total, 1) * sizeof(int)));
+	int *dSx = static_cast<int *>(big_alloc((size_t) std::max<i64>(total, 1) * sizeof(int)));
+	if (W->d_lb_status == nullptr)
+		W->d_lb_status = dalloc<unsigned long long>((i64) W->max_rows + 16 + 16 * 16);
+	HIP_CHECK(hipMemsetAsync(W->d_ctr, 0, CTR_COUNT * sizeof(int), stream));
+	launch_stitch_slabs(gSp, gSj, gSx, n, world, dSp, dSj, dSx, total, W->d_row_len, W->d_lb_status, W->d_ctr, stream);
+	struct spasm_csr *S = spasm_hip_csr_alloc(n, m, total, prime, true);
+	HIP_CHECK(hipMemcpyAsync(S->p, dSp, ((size_t) n + 1) * sizeof(i64), hipMemcpyDeviceToHost, stream));
+	HIP_CHECK(hipStreamSynchronize(stream));
+	if (S->p[n] != total)
+		die("spasm_hip_schur (columns): the stitched rows hold %lld entries, the slabs %lld", (long long) S->p[n], (long long) total);
+	const bool keep = resident_enabled() && n >= 1024;
+	const bool lazy = keep && g_lazy_download;
+	if (total > 0 && !lazy) {
+		HIP_CHECK(hipMemcpy(S->j, dSj, (size_t) total * sizeof(int), hipMemcpyDeviceToHost));
+		HIP_CHECK(hipMemcpy(S->x, dSx, (size_t) total * sizeof(int), hipMemcpyDeviceToHost));
+	}
+	if (keep) {
+		resident_adopt(S, dSp, dSj, dSx, lazy);          // the next round's A is already on every device
+	} else {
+		sh::big_free(dSp);
+		big_free(dSj);
+		big_free(dSx);
+	}
+	sh::big_free(gSp);
+	sh::big_free(gSj);
+	sh::big_free(gSx);
+	sh::big_free(d_cols);
+	spasm_hip_dwork_destroy(W);
+	if (p_out != nullptr)
+		for (int k = 0; k < n; k++)
+			p_out[k] = (p_in != nullptr) ? p_in[p[k]] : p[k];
+	const double density = (n > 0 && m > 0) ? (double) total / ((double) m * n) : 0.0;
+	logmsg("Schur complement: %d * %d [%" PRId64 " nz / density= %.3f], %.1fs (split by columns: rank %d of %d reduced every row on %d of the %d "
+	       "non-pivotal columns; slab problem %.2fs)\n", n, m, total, density, wtime() - t0, rank, world, mm - fact->U->n, m - fact->U->n, t_slab);
+	return S;
+}
+
+// --------------------------------------------------------------------------
 // host-pointer drop-in for spasm_schur
 // --------------------------------------------------------------------------
 struct spasm_csr *spasm_hip_schur(const struct spasm_csr *A, const int *p, int n, const struct spasm_lu *fact,
@@ -1741,6 +1839,21 @@ struct spasm_csr *spasm_hip_schur(const struct spasm_csr *A, const int *p, int n
 	int lo = 0, hi = n;
 	const bool shard = comm != nullptr && L == nullptr && (comm_world(comm) > 1 || env_int("SPASM_HIP_SHARD_FORCE", 0) != 0) &&
 	                   n >= env_int("SPASM_HIP_SHARD_MIN_ROWS", 2048) * comm_world(comm);
+	// Two ways to share a batch.  By COLUMNS when the factor takes an image path -- the sparse image or
+	// the dense one: the columns of R and of S never meet, so rank k builds only ITS slab of R and reduces all rows on it;
+	// nothing is replicated --, by ROWS otherwise (the row-by-row kernels: rows never meet; with an image every rank would
+	// rebuild all of R).  SPASM_HIP_SHARD=rows|columns forces one.
+	bool shard_cols = false;
+	if (shard) {
+		const char *how = sh::env_get("SPASM_HIP_SHARD");
+		if (how != nullptr && std::strcmp(how, "columns") == 0)
+			shard_cols = true;
+		else if (how == nullptr || std::strcmp(how, "rows") != 0)
+			shard_cols = (F->sp.planned && !F->sp.failed) || F->bs.planned || F->bs_deferred;
+		shard_cols = shard_cols && m - F->r >= comm_world(comm);
+	}
+	if (shard_cols)
+		return schur_by_column_slabs(A, p, n, fact, est_density, p_in, p_out, comm);
 	if (shard)
 		spasm_hip_shard(n, comm_rank(comm), comm_world(comm), &lo, &hi);
 	const int n_all = n;

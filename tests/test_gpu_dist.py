@@ -51,11 +51,15 @@ def test_allgatherv_of_a_world_of_one_is_the_identity(oracle, comm, name, how, m
 
 @pytest.mark.parametrize("name", ["mat364.sms", "medium.sms", "m1.sms", "singular.sms", "rectangular_l.sms"])
 @pytest.mark.parametrize("p", [42013, 4294967291])
-def test_echelonize_dist_shards_every_round(oracle, comm, name, p, monkeypatch):
-    """spasm_hip_echelonize_dist: every Schur complement goes through the sharded path (slice of the row list, all-gatherv
-    on the device, download) even in a world of one; same rank as the oracle, valid echelon form."""
+@pytest.mark.parametrize("split", ["rows", "columns"])
+def test_echelonize_dist_shards_every_round(oracle, comm, name, p, split, monkeypatch):
+    """spasm_hip_echelonize_dist: every Schur complement goes through the sharded path even in a world of one -- by rows (slice
+    of the row list, all-gatherv on the device, download) and by columns (the slab problem of rank 0 of 1 = the whole problem:
+    spasm_hip_column_slab, the one-GPU call on it, columns mapped back, all-gatherv of the slab, rows stitched on the device);
+    same rank as the oracle, valid echelon form."""
     monkeypatch.setenv("SPASM_HIP_SHARD_FORCE", "1")
     monkeypatch.setenv("SPASM_HIP_SHARD_MIN_ROWS", "1")
+    monkeypatch.setenv("SPASM_HIP_SHARD", split)
     A = oracle.load_sms(matrix_path(name), p)
     want = oracle.echelonize(A).U.n
     o = spasm_amd.default_opts()
@@ -70,13 +74,17 @@ def test_echelonize_dist_shards_every_round(oracle, comm, name, p, monkeypatch):
         seen.add(int(jj[0]))
 
 
-def test_sharded_driver_with_a_sparse_round_at_scale(comm, monkeypatch):
+@pytest.mark.parametrize("split", ["rows", "auto"])
+def test_sharded_driver_with_a_sparse_round_at_scale(comm, split, monkeypatch):
     """mk13.b4 (159,093 x 23,958 Schur complement, 4.4 % dense) with its sparse round forced and every Schur complement
-    sharded: the slice is reduced by the row-group kernel, all-gathered on the device, kept there as the next round's
-    A (never uploaded) and downloaded once for the host pivot search.  Rank = the CPU oracle's."""
+    sharded: by rows (the slice is all-gathered on the device, kept there as the next round's A and downloaded once for the
+    host pivot search) and the way the driver chooses by itself -- by COLUMNS, since this factor takes the sparse image: the
+    slab is reduced through it, stacked by the all-gatherv, stitched on the device.  Rank = the CPU oracle's."""
     sys.path.insert(0, os.path.join(ROOT, "tools"))
     import workloads
     monkeypatch.setenv("SPASM_HIP_SHARD_FORCE", "1")
+    if split != "auto":
+        monkeypatch.setenv("SPASM_HIP_SHARD", split)
     A, _ = workloads.load_matrix("mk13.b4")
     o = spasm_amd.default_opts()
     o.sparsity_threshold = 0.1
@@ -154,3 +162,56 @@ def test_column_slabs_on_the_gpu_stitch_to_the_full_schur_complement(name, parts
     finally:
         os.environ.pop("SPASM_HIP_BACKSOLVE", None)
     assert np.array_equal(full.p, want.p) and np.array_equal(full.j, want.j) and np.array_equal(full.x, want.x)
+
+
+@pytest.mark.parametrize("name,parts", [("mk12.b4", 4), ("mk12.b3", 3)])
+def test_slabs_stitched_on_the_device(name, parts):
+    """spasm_hip_dstitch_slabs -- what the column split of the driver runs after its all-gatherv: the slabs of all `parts` ranks,
+    computed here one after the other (sparse image or dense image, whatever the library takes), columns mapped back, STACKED
+    as the all-gatherv leaves them, stitched by the device kernel: entry for entry the Schur complement of the whole problem."""
+    import torch
+    from spasm_amd.dist import column_slab
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import workloads
+    p = 42013
+    A, rows, F, _ = workloads.round0(name, p)
+    drows = torch.from_numpy(np.ascontiguousarray(rows, np.int32)).cuda()
+
+    def reduce(Ax, Fx):
+        dA = spasm_amd.DeviceCsr.from_host(Ax)
+        dF = spasm_amd.DeviceFact(Fx)
+        pool = 1 << 24
+        while True:
+            W = spasm_amd.SchurWorkspace(len(rows), Ax.m, pool)
+            S, st = spasm_amd.dschur(dA, drows, dF, W, fetch=True)
+            if st.status == 0:
+                break
+            W.close()
+            pool *= 4
+        W.close()
+        dF.close()
+        return S, st
+    want, st = reduce(A, F)
+    n = len(rows)
+    sp, sj, sx = [], [], []
+    base = 0
+    for k in range(parts):
+        As, Fs, cols = column_slab(A, F, k, parts)
+        S, st = reduce(As, Fs)
+        cmap = torch.from_numpy(np.ascontiguousarray(cols, np.int32)).cuda()
+        sp.append(S.p[:-1] + base)
+        sj.append(cmap[S.j[:st.nnz].long()])
+        sx.append(S.x[:st.nnz])
+        base += int(st.nnz)
+    gSp = torch.cat(sp + [torch.tensor([base], dtype=torch.int64, device="cuda")])
+    gSj = torch.cat(sj).contiguous()
+    gSx = torch.cat(sx).contiguous()
+    assert base == int(want.p[-1].item())
+    Sp = torch.zeros(n + 1, dtype=torch.int64, device="cuda")
+    Sj = torch.zeros(max(base, 1), dtype=torch.int32, device="cuda")
+    Sx = torch.zeros(max(base, 1), dtype=torch.int32, device="cuda")
+    rc = spasm_amd.lib().spasm_hip_dstitch_slabs(gSp.data_ptr(), gSj.data_ptr(), gSx.data_ptr(), n, parts, Sp.data_ptr(), Sj.data_ptr(), Sx.data_ptr(), base, 0)
+    assert rc == 0
+    assert torch.equal(Sp, want.p) and torch.equal(Sj[:base], want.j[:base]) and torch.equal(Sx[:base], want.x[:base])
+    rc = spasm_amd.lib().spasm_hip_dstitch_slabs(gSp.data_ptr(), gSj.data_ptr(), gSx.data_ptr(), n, parts, Sp.data_ptr(), Sj.data_ptr(), Sx.data_ptr(), base - 1, 0)
+    assert rc == 1
