@@ -165,6 +165,37 @@ def dense_tail_probe(torch, spasm_amd, dev, n=4096, m=32768):
     return out
 
 
+def dense_tail_real_probe(torch, spasm_amd, dev, dA, drows, dF, Sm, nrows=4096):
+    """the dense tail on a block the flow really produces: the first `nrows` non-pivotal rows of the workload reduced to dense
+    rows by the factor (spasm_schur_dense, spasm_schur.c:258-343) -- for mk13.b5 a 4,096 x 4,952 block of rank ~4,130 in which
+    one column in seven depends on the columns before it -- then its RREF (spasm_hip_drref), timed like the random block."""
+    L = spasm_amd.lib()
+    n = min(nrows, int(drows.numel()))
+    ld = (Sm + 63) // 64 * 64
+    S0 = torch.zeros((n, ld), dtype=torch.int32, device=dev)
+    W = spasm_amd.SchurWorkspace(n, dA.m, 1 << 20)
+    a = dA.cstruct(nnz=-1)
+    sub = drows[:n].contiguous()
+    rc = L.spasm_hip_dschur_dense(C.byref(a), sub.data_ptr(), n, dF._h, W._h, S0.data_ptr(), ld, 0)
+    torch.cuda.synchronize()
+    W.close()
+    if rc != 0:
+        return {"status": "spasm_hip_dschur_dense returned %d" % rc}
+    piv = torch.zeros(ld, dtype=torch.int32, device=dev)
+    times, r = [], 0
+    for _ in range(4):
+        A = S0[:, :Sm].contiguous()
+        torch.cuda.synchronize()
+        ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        ev0.record()
+        r = L.spasm_hip_drref(PRIME, n, Sm, A.data_ptr(), Sm, piv.data_ptr(), 0)
+        ev1.record()
+        torch.cuda.synchronize()
+        times.append(ev0.elapsed_time(ev1))
+    return {"what": "spasm_hip_drref of the dense rows of the first %d non-pivotal rows of the workload (spasm_hip_dschur_dense), mod %d" % (n, PRIME),
+            "shape": [n, Sm], "rank": int(r), "ms_first": times[0], "ms_median_of_the_rest": statistics.median(times[1:]), "ms_all": times}
+
+
 def _calls(fn, count):
     """`count` timed calls of fn() -> (profile, rank): first call, median, minimum, all of them"""
     runs = []
@@ -597,6 +628,7 @@ def main():
                                                "traffic_source": tr2[2]})
         if extras:
             out["dense_tail"] = dense_tail_probe(torch, spasm_amd, dev)
+            out["dense_tail_real"] = dense_tail_real_probe(torch, spasm_amd, dev, dA, drows, dF, int(A_full.m - F_full.U.n))
             # the other half of the headline metric: wall-clock time of the whole rank computation (host I/O excluded:
             # the matrix is already in memory), default options of tools/rank, five calls
             os.environ.pop("SPASM_HIP_THREADS", None)
