@@ -1466,8 +1466,10 @@ __global__ __launch_bounds__(256) void rref_split_Z(const uint32_t *Z, int64_t l
 	*reinterpret_cast<int4 *>(Ml + (int64_t) i * 64 + q * 16) = make_int4((int) wl[0], (int) wl[1], (int) wl[2], (int) wl[3]);
 }
 
-// digits of B (k x mr, row-major): one thread per column
-__global__ __launch_bounds__(256) void rref_split_B(const uint32_t *B, int mr, const int *knew, signed char *Bh, signed char *Bl, MontDev F)
+// digits of B (k x mr, row-major with row stride ldb >= mr): one thread per column.  (The planes hold mr columns: with the
+// stride as the bound, the columns of the padding of a matrix with ld > m were written past the end of the plane -- into the
+// first columns of the next one, racing with their own writers.)
+__global__ __launch_bounds__(256) void rref_split_B(const uint32_t *B, int64_t ldb, int mr, const int *knew, signed char *Bh, signed char *Bl, MontDev F)
 {
 	const int col = blockIdx.x * 256 + threadIdx.x;
 	if (col >= mr)
@@ -1480,7 +1482,7 @@ __global__ __launch_bounds__(256) void rref_split_B(const uint32_t *B, int mr, c
 #pragma unroll
 		for (int b = 0; b < 16; b++) {
 			const int kk = part * 16 + b;
-			const uint32_t v = (kk < k) ? B[(int64_t) kk * mr + col] : 0u;
+			const uint32_t v = (kk < k) ? B[(int64_t) kk * ldb + col] : 0u;
 			int hi, lo;
 			split_digits(v, F, hi, lo);
 			wh[b >> 2] |= (unsigned int) (hi & 255) << (8 * (b & 3));
@@ -2579,7 +2581,7 @@ int device_echelon_extend(int64_t prime, int m, uint32_t *dM, int64_t ld, int k,
 		hipLaunchKernelGGL(rref_split_Z, dim3((Sn + 63) / 64, nsets), dim3(256), 0, stream, Z, ldz, Sn, nsets, Mplanes, (int64_t) 2 * Sn * 64, F);
 		for (int s = 0; s < nsets; s++) {
 			signed char *Bh = Bplanes + (size_t) s * 2 * (size_t) m * 64, *Bl = Bh + (size_t) m * 64;
-			hipLaunchKernelGGL(rref_split_B, dim3((m + 255) / 256), dim3(256), 0, stream, dM + (int64_t) (t0 + 64 * s) * ld, (int) ld, d_cnt + s, Bh, Bl, F);
+			hipLaunchKernelGGL(rref_split_B, dim3((m + 255) / 256), dim3(256), 0, stream, dM + (int64_t) (t0 + 64 * s) * ld, ld, m, d_cnt + s, Bh, Bl, F);
 			S.Mh[s] = Mplanes + (size_t) s * 2 * Sn * 64;
 			S.Ml[s] = S.Mh[s] + (size_t) Sn * 64;
 			S.Bh[s] = Bh;
@@ -2606,7 +2608,7 @@ int device_echelon_extend(int64_t prime, int m, uint32_t *dM, int64_t ld, int k,
 	auto split_panel = [&](int row0, int set) {          // the rows [row0, row0 + 64) of Y as the B planes of `set`
 		signed char *Mh, *Ml, *Bh, *Bl;
 		planes_of_set(set, Mh, Ml, Bh, Bl);
-		hipLaunchKernelGGL(rref_split_B, dim3((m + 255) / 256), dim3(256), 0, stream, Y + (int64_t) row0 * ld, (int) ld, d_cnt + (Sn - row0 >= RP_ROWS ? 0 : 1), Bh, Bl, F);
+		hipLaunchKernelGGL(rref_split_B, dim3((m + 255) / 256), dim3(256), 0, stream, Y + (int64_t) row0 * ld, ld, m, d_cnt + (Sn - row0 >= RP_ROWS ? 0 : 1), Bh, Bl, F);
 	};
 	auto clear_columns = [&](uint32_t *C, int rows, int skip_lo, int skip_hi, const int *piv, int nsets) {          // C -= C[:, piv] * (B planes of the sets)
 		hipLaunchKernelGGL(rowpanel_neg_columns, dim3((rows + 63) / 64, nsets), dim3(256), 0, stream, C, ld, rows, skip_lo, skip_hi, piv, Mplanes, (int64_t) 2 * n * 64,

@@ -350,26 +350,28 @@ def _rref_rows(p, M):
     return r, A[:r].clone(), piv[:r].clone()
 
 
-def _extend_and_check(p, blocks, m, oracle=None):
+def _extend_and_check(p, blocks, m, oracle=None, pad=0):
     """feeds the blocks one after the other to spasm_hip_dechelon_extend; after every block: the echelon rows are reduced
     (identity on their pivot columns, distinct pivots, no zero row) and span exactly the row space of everything fed so far
     (same unique RREF as the stack of the inputs, computed by spasm_hip_drref)."""
     import torch
     dev = torch.device("cuda:0")
     total = sum(b.shape[0] for b in blocks)
-    M = torch.zeros((total + 64, m), dtype=torch.int32, device=dev)
+    ld = m + pad                          # (pad > 0: a row stride larger than the number of columns; the padding stays zero)
+    M = torch.zeros((total + 64, ld), dtype=torch.int32, device=dev)
     piv = torch.zeros(total + 64, dtype=torch.int32, device=dev)
     L = spasm_amd.lib()
     k, fed = 0, []
     for b in blocks:
         Sn = b.shape[0]
-        M[k:k + Sn] = b
+        M[k:k + Sn, :m] = b
         fed.append(b)
-        k2 = L.spasm_hip_dechelon_extend(p, m, M.data_ptr(), m, k, Sn, piv.data_ptr(), 0)
+        k2 = L.spasm_hip_dechelon_extend(p, m, M.data_ptr(), ld, k, Sn, piv.data_ptr(), 0)
         torch.cuda.synchronize()
         assert k <= k2 <= k + Sn
         k = k2
-        E = M[:k]
+        E = M[:k, :m]
+        assert not bool(M[:, m:].any())
         J = piv[:k].to(torch.int64)
         assert len(torch.unique(J)) == k
         if k:
@@ -450,6 +452,22 @@ def test_echelon_extend_by_row_panels(oracle, case, p):
             B[i, c:c + 200] = torch.randint(1, p, (200,), dtype=torch.int32, device=dev, generator=g)
         blocks = [B]
     _extend_and_check(p, blocks, m, oracle)
+
+
+@pytest.mark.parametrize("pad", [40, 64, 3])
+def test_echelon_extend_with_a_row_stride_larger_than_the_width(oracle, pad):
+    """ld > m (a padded dense block, as spasm_hip_dschur_dense callers round the stride up to 64 words): the digit planes of the
+    panel rows hold m columns, and the kernel that writes them took the STRIDE as its bound until round 4 -- the columns of the
+    padding landed in the first columns of the next plane, racing with their writers: ranks above the true one, different on
+    every call (found on the first dense block of mk13.b5, 4,096 x 4,952 with ld = 4,992)."""
+    import torch
+    dev = torch.device("cuda:0")
+    g = torch.Generator(device=dev)
+    g.manual_seed(77 + pad)
+    p, m = 42013, 1000 - pad
+    blocks = [_low_rank(torch, g, p, 300, m, 120), _low_rank(torch, g, p, 200, m, 90)]
+    for _ in range(3):
+        _extend_and_check(p, blocks, m, oracle, pad=pad)
 
 
 # --------------------------------------------------------------------------

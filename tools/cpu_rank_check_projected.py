@@ -35,61 +35,93 @@ print("%s: %d x %d, %d structural pivots (compiled reference), %d rows left, %d 
 rng = np.random.default_rng(12345)
 Z = np.zeros((c, Sm), np.float64)
 BLOCK = 2048
+FOLD = 8                                  # every row of S is added, with random coefficients, to FOLD random rows of Z
 t0 = time.time()
 for lo in range(0, len(rows), BLOCK):
     sub = rows[lo:lo + BLOCK]
     S, q, p_out = orc.ref_schur_dense(A, sub, F)
     Y = np.mod(np.asarray(S, np.int64), p).astype(np.float64)
-    H = rng.integers(0, p, size=(c, Y.shape[0])).astype(np.float64)
-    for j0 in range(0, Sm, 8192):          # (tiles keep the temporaries small; 2,048 terms of < 2^32 each: exact)
-        Z[:, j0:j0 + 8192] = np.mod(Z[:, j0:j0 + 8192] + H @ Y[:, j0:j0 + 8192], p)
+    for f in range(FOLD):
+        dst = rng.integers(0, c, size=Y.shape[0])
+        coef = rng.integers(1, p, size=Y.shape[0]).astype(np.float64)
+        order = np.argsort(dst, kind="stable")
+        dsts, starts = np.unique(dst[order], return_index=True)
+        # (rows of Y that go to the same row of Z are added up first: products < 2^32, a few terms)
+        contrib = np.add.reduceat(np.mod(Y[order] * coef[order, None], p), starts, axis=0)
+        Z[dsts] = np.mod(Z[dsts] + contrib, p)
     if (lo // BLOCK) % 8 == 0:
         print("  rows %d / %d folded (%.0f s)" % (lo + len(sub), len(rows), time.time() - t0), flush=True)
-print("folded %d rows into %d combinations (%.0f s); eliminating" % (len(rows), c, time.time() - t0), flush=True)
+print("folded %d rows into %d combinations, %d per row (%.0f s); eliminating" % (len(rows), c, FOLD, time.time() - t0), flush=True)
 
-# exact blocked elimination of Z: panels of 256 columns
+# exact blocked elimination of Z: panels of 256 columns, the rows below and the columns to the right updated by ONE product
+# of rank <= 256 per panel (entries below p, 256 terms: far below 2^53)
 t0 = time.time()
 rank = 0
-row = 0                                   # rows [0, row) are finished pivot rows
+row = 0                                   # rows [0, row) are finished pivot rows (not kept reduced: only the rank is asked for)
 PANEL = 256
 for j0 in range(0, Sm, PANEL):
     j1 = min(Sm, j0 + PANEL)
-    P = Z[row:, j0:j1]
+    P = Z[row:, j0:j1].copy()
     if not P.any():
         continue
-    # Gauss-Jordan of the panel, recording the row operations as a matrix T (applied to the rest of Z by one product per panel)
-    k = Z.shape[0] - row
-    T = np.eye(k)
-    P = P.copy()
-    piv_rows = []
+    k = P.shape[0]
+    # Gaussian elimination of the panel by rows; the pivot rows are swapped to the top of the remaining rows
+    perm = np.arange(k)
+    piv_cols = []
+    npiv_here = 0
     for j in range(j1 - j0):
-        cand = np.flatnonzero(P[len(piv_rows):, j]) + len(piv_rows)
+        cand = np.flatnonzero(P[npiv_here:, j])
         if cand.size == 0:
             continue
-        r = int(cand[0])
-        t = len(piv_rows)
+        r = int(cand[0]) + npiv_here
+        t = npiv_here
         if r != t:
             P[[t, r]] = P[[r, t]]
-            T[[t, r]] = T[[r, t]]
+            perm[[t, r]] = perm[[r, t]]
         inv = pow(int(P[t, j]), p - 2, p)
         P[t] = np.mod(P[t] * inv, p)
-        T[t] = np.mod(T[t] * inv, p)
-        f = P[:, j].copy()
-        f[t] = 0
+        f = P[t + 1:, j].copy()
         nz = np.flatnonzero(f)
         if nz.size:
-            P[nz] = np.mod(P[nz] - np.outer(f[nz], P[t]), p)
-            T[nz] = np.mod(T[nz] - np.outer(f[nz], T[t]), p)
-        piv_rows.append(t)
-    if not piv_rows:
+            P[t + 1 + nz] = np.mod(P[t + 1 + nz] - np.outer(f[nz], P[t]), p)
+        piv_cols.append(j)
+        npiv_here += 1
+    if npiv_here == 0:
         continue
-    # apply T to the columns to the right (entries of T and Z below p, k <= 8192 terms: below 2^53)
+    # the same row operations on the columns to the right.  With Q = the rows in their new order, the pivot rows are
+    # W = L^-1 Q[:np] (unit-lower-triangular system solved through the panel itself) and every other row loses its multiples of
+    # them; both from the ORIGINAL panel: M = multipliers such that P_below_original = M @ (pivot rows of the panel)
+    Zr = Z[row:][perm]                        # (a copy, rows in the new order)
+    orig = Zr[:, j0:j1]
+    # pivot rows of the panel in echelon form (unit pivots): E (np x 256); solve X E[:, piv_cols] = orig[:, piv_cols] for the
+    # multipliers X of every row (triangular: E[:, piv_cols] is unit upper triangular)
+    E = P[:npiv_here]
+    U = E[:, piv_cols]                        # np x np, unit upper triangular
+    B = orig[:, piv_cols].copy()              # k x np
+    X = np.zeros_like(B)
+    for t in range(npiv_here):                # forward substitution column by column (np <= 256 steps of a k-vector update)
+        X[:, t] = B[:, t]
+        if t + 1 < npiv_here:
+            B[:, t + 1:] = np.mod(B[:, t + 1:] - np.outer(X[:, t], U[t, t + 1:]), p)
+    # rows: new pivot rows = X[:np] relates original pivot rows to echelon rows: orig[:np] = X[:np] @ E  ->  E = X[:np]^-1 orig[:np]
+    # apply to the right part: ER = X[:np]^-1 @ Zr[:np, right]; then rows below: Zr[np:, right] -= X[np:] @ ER
+    Xp = X[:npiv_here]                        # np x np, lower triangular with non-zero diagonal
     for c0 in range(j1, Sm, 8192):
-        Z[row:, c0:c0 + 8192] = np.mod(T @ Z[row:, c0:c0 + 8192], p)
-    Z[row:, j0:j1] = P
-    row += len(piv_rows)
-    rank += len(piv_rows)
-    if (j0 // PANEL) % 32 == 0:
+        R = Zr[:, c0:c0 + 8192]
+        ER = R[:npiv_here].copy()
+        for t in range(npiv_here):            # forward substitution with the lower-triangular Xp
+            inv = pow(int(Xp[t, t]), p - 2, p)
+            ER[t] = np.mod(ER[t] * inv, p)
+            if t + 1 < npiv_here:
+                ER[t + 1:] = np.mod(ER[t + 1:] - np.outer(Xp[t + 1:, t], ER[t]), p)
+        R[:npiv_here] = ER
+        R[npiv_here:] = np.mod(R[npiv_here:] - np.mod(X[npiv_here:] @ ER, p), p)
+        Zr[:, c0:c0 + 8192] = R
+    Zr[:, j0:j1] = P
+    Z[row:] = Zr
+    row += npiv_here
+    rank += npiv_here
+    if (j0 // PANEL) % 16 == 0:
         print("  columns %d / %d: rank so far %d (%.0f s)" % (j1, Sm, rank, time.time() - t0), flush=True)
     if row >= Z.shape[0]:
         break
