@@ -17,6 +17,12 @@
 // A replay only moves past DECIDED tickets (it polls the few that are not: they are a few loads from their decision), so the
 // record of an accepted pivot is complete before any search relies on it; a search that starts takes a lower bound of the
 // decided prefix (PsCtrl::prefix, raised by whoever replays) as the point its first replay starts from.
+// (Tried in round 4: one BACKWARD level -- the pivot rows that hold a candidate are known from the columns of A, so a candidate
+//  can count as reached as soon as one of their pivot columns is MARKED, a level of the walk earlier.  Four searches in five
+//  end without a pivot and make 70 % of the visits (mk15.b4: 4.3e9 of 5.9e9, 1,900 per row), so a level looked like a factor
+//  of the branching.  It is not: the visits did not move (5.75e9 against 5.46e9; 1.05e10 against 1.29e10 on 19-entry random
+//  rows) and the table look-ups cost 5-40 % -- the pivot graph of these matrices is thousands of levels deep and a walk is
+//  long and thin, so a level is a few dozen visits, not three quarters of them.)
 // As with threads, the set of pivots depends on timing; it is always cycle-free -- and the host checks that the order it
 // derives from the result is triangular before anything is built on it (host_pivots.cpp, Search::triangular).
 //
@@ -81,6 +87,7 @@ struct PsCtrl {
 	int status;          // 0 ok, 1: a bounded spin gave up (the host search takes over)
 	int overflowed;      // rows given up because their FIFO was full
 	u64 visits, attempts, steps;
+	u64 visits_won, rows_won, rows_lost;             // visits of the searches that ended with a pivot; rows with / without one
 	u64 c_search, c_commit, c_total;                 // wave-cycles (s_memtime): in the walk, in replay + ticket, in all
 	u64 t_start, t_first_exit, t_last_exit;          // wall_clock64() (100 MHz): first wave in, first wave out of rows, last wave out
 	u64 longest_search;                              // ... and the longest time one row took
@@ -106,6 +113,17 @@ __device__ __forceinline__ void ld_rec(const u64 *p, u64 &lo, u64 &hi)
 	asm volatile("global_load_dwordx4 %0, %1, off sc1\n\ts_waitcnt vmcnt(0)" : "=v"(r) : "v"(p) : "memory");
 	lo = (u64) r.x | ((u64) r.y << 32);
 	hi = (u64) r.z | ((u64) r.w << 32);
+}
+// the record of a column and one word of the reached-bits (HBM variant) in flight together, waited for on the spot: a step of
+// the walk is a chain of dependent round trips, and "are the candidates still unreached?" used to be one of its own
+__device__ __forceinline__ void ld_rec_and_word(const u64 *p, const uint32_t *q, u64 &lo, u64 &hi, uint32_t &word)
+{
+	u32x4 r;
+	uint32_t w;
+	asm volatile("global_load_dwordx4 %0, %2, off sc1\n\tglobal_load_dword %1, %3, off sc1\n\ts_waitcnt vmcnt(0)" : "=&v"(r), "=&v"(w) : "v"(p), "v"(q) : "memory");
+	lo = (u64) r.x | ((u64) r.y << 32);
+	hi = (u64) r.z | ((u64) r.w << 32);
+	word = w;
 }
 __device__ __forceinline__ void drain() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
 
@@ -145,6 +163,7 @@ __device__ __forceinline__ u64 entry(int col, u64 state) { return (u64) (uint32_
 constexpr int PS_ROWS_PER_GRAB = 8;
 constexpr int PS_LIST = 512;
 constexpr unsigned PS_SPIN_LIMIT = 1u << 24;
+constexpr int PS_RING = 512;          // the last entries of a search's FIFO, mirrored in LDS
 
 // one wavefront per workgroup.  The reached-bit of every column lives in LDS (GB = false: m / 8 bytes, cleared per row) or,
 // for matrices too wide for that, in a private stretch of HBM (GB = true: set and read through the L2 -- atomics and
@@ -159,6 +178,10 @@ __global__ __launch_bounds__(64) void pivot_search_kernel(const i64 *Ap, const i
 	int *cand = reinterpret_cast<int *>(ps_lds + (GB ? 0 : words));
 	int *tmp = cand + 64;
 	uint32_t *list = reinterpret_cast<uint32_t *>(tmp + 8);          // PS_LIST (lane, entry) pairs of the long rows of a step
+	// The walks of these matrices are long and thin (a few dozen columns per step, thousands of levels): the next step's columns
+	// are the ones just queued.  The last PS_RING entries of the FIFO are mirrored here, so that a step reads them without
+	// waiting for its own stores to reach memory and come back (a round trip per step).
+	int *ring = reinterpret_cast<int *>(list + list_cap + 64);          // (behind the 64 spare words)
 	const int lane = threadIdx.x;
 	const int spare = words + (GB ? 0 : 64 + 8 + list_cap) + lane;          // a word of this lane's own, for atomics that must do nothing
 	auto bits_at = [&](int w) -> uint32_t {                       // (GB: what the atomics left in the L2, not what the L1 remembers)
@@ -169,7 +192,7 @@ __global__ __launch_bounds__(64) void pivot_search_kernel(const i64 *Ap, const i
 	};
 	const u64 below = (1ull << lane) - 1ull;
 	int *fifo = fifo_all + (size_t) blockIdx.x * fifo_cap;
-	u64 visits = 0, attempts = 0, longest = 0, steps = 0, c_search = 0, c_commit = 0;
+	u64 visits = 0, attempts = 0, longest = 0, steps = 0, c_search = 0, c_commit = 0, visits_won = 0, rows_won = 0, rows_lost = 0;
 	const u64 c_begin = clock64();
 	bool dead = false;          // a bounded spin gave up somewhere: leave
 	if (lane == 0)
@@ -190,6 +213,7 @@ __global__ __launch_bounds__(64) void pivot_search_kernel(const i64 *Ap, const i
 				break;
 			}
 			const u64 t_row = wall_clock64();
+			const u64 visits_before = visits;
 			if constexpr (!GB)
 				for (int w = lane * 4; w < words; w += 256)
 					*reinterpret_cast<uint4 *>(bits + w) = make_uint4(0, 0, 0, 0);
@@ -203,8 +227,10 @@ __global__ __launch_bounds__(64) void pivot_search_kernel(const i64 *Ap, const i
 				if (mask == 0)
 					return;
 				const int pos = tail + __popcll(mask & below);
-				if (pred && pos < fifo_cap)
+				if (pred && pos < fifo_cap) {
 					fifo[pos] = j;
+					ring[pos & (PS_RING - 1)] = j;
+				}
 				tail += __popcll(mask);
 				if (tail > fifo_cap) {
 					tail = fifo_cap;
@@ -255,13 +281,30 @@ __global__ __launch_bounds__(64) void pivot_search_kernel(const i64 *Ap, const i
 						overflow = true;
 						break;
 					}
-					drain();                     // (the FIFO entries pushed by the step before are in memory)
 					const int cnt = min(64, tail - head);
-					const int c = (lane < cnt) ? fifo[head + lane] : -1;
+					int c;
+					if (tail - head <= PS_RING) {
+						c = (lane < cnt) ? ring[(head + lane) & (PS_RING - 1)] : -1;
+					} else {
+						drain();                 // (the FIFO entries pushed by the steps before are in memory)
+						c = (lane < cnt) ? fifo[head + lane] : -1;
+					}
 					head += cnt;
 					u64 lo = 0, hi = 0;
-					if (c >= 0)
-						ld_rec(rec + (size_t) c * REC_WORDS, lo, hi);
+					if constexpr (GB) {
+						// the records of the step and the candidates' reached-bits (as the step before left them) in one round trip
+						const int jc = (lane < ncand) ? cand[lane] : 0;
+						uint32_t word;
+						ld_rec_and_word(rec + (size_t) (c >= 0 ? c : 0) * REC_WORDS, bits + ((lane < ncand) ? (jc >> 5) : spare), lo, hi, word);
+						if (c < 0)
+							lo = hi = 0;
+						live = __ballot(lane < ncand && (word & (1u << (jc & 31))) == 0);
+						if (live == 0)
+							break;
+					} else {
+						if (c >= 0)
+							ld_rec(rec + (size_t) c * REC_WORDS, lo, hi);
+					}
 					const int len = (int) (lo & 7ull);
 					const int long_row = (int) (uint32_t) (lo >> 3);
 					visits += (u64) __popcll(__ballot(len != 0));
@@ -302,8 +345,11 @@ __global__ __launch_bounds__(64) void pivot_search_kernel(const i64 *Ap, const i
 					for (int t = 0; t < REC_ENTS; t++) {
 						const bool fresh = (bit[t] & ~old[t]) != 0;
 						const u64 mask = __ballot(fresh);
-						if (fresh)
-							fifo[base + __popcll(mask & below)] = e[t];
+						if (fresh) {
+							const int pos = base + __popcll(mask & below);
+							fifo[pos] = e[t];
+							ring[pos & (PS_RING - 1)] = e[t];
+						}
 						base += __popcll(mask);
 					}
 					tail = base;
@@ -386,8 +432,11 @@ __global__ __launch_bounds__(64) void pivot_search_kernel(const i64 *Ap, const i
 								for (int u = 0; u < 4; u++) {
 									const bool fresh = (bt[u] & ~od[u]) != 0;
 									const u64 mask = __ballot(fresh);
-									if (fresh)
-										fifo[base2 + __popcll(mask & below)] = jj[u];
+									if (fresh) {
+										const int pos = base2 + __popcll(mask & below);
+										fifo[pos] = jj[u];
+										ring[pos & (PS_RING - 1)] = jj[u];
+									}
 									base2 += __popcll(mask);
 								}
 								tail = base2;
@@ -395,8 +444,12 @@ __global__ __launch_bounds__(64) void pivot_search_kernel(const i64 *Ap, const i
 							longs &= ~batch;
 						}
 					}
-					live = alive();
+					if constexpr (!GB)
+						live = alive();
 				}
+				if constexpr (GB)
+					if (live != 0)
+						live = alive();          // (the marks of the last step)
 				const u64 c1 = clock64();
 				c_search += c1 - c0;
 				struct Tally {
@@ -537,7 +590,12 @@ __global__ __launch_bounds__(64) void pivot_search_kernel(const i64 *Ap, const i
 				committed = true;
 				break;
 			}
-			(void) committed;
+			if (committed) {
+				visits_won += visits - visits_before;
+				rows_won += 1;
+			} else {
+				rows_lost += 1;
+			}
 			if (overflow && lane == 0)
 				atomicAdd(&ctrl->overflowed, 1);
 			if constexpr (GB) {
@@ -563,6 +621,9 @@ __global__ __launch_bounds__(64) void pivot_search_kernel(const i64 *Ap, const i
 		atomicMax(&ctrl->t_last_exit, now);
 		atomicMax(&ctrl->longest_search, longest);
 		atomicAdd(&ctrl->visits, visits);
+		atomicAdd(&ctrl->visits_won, visits_won);
+		atomicAdd(&ctrl->rows_won, rows_won);
+		atomicAdd(&ctrl->rows_lost, rows_lost);
 		atomicAdd(&ctrl->steps, steps);
 		atomicAdd(&ctrl->c_search, c_search);
 		atomicAdd(&ctrl->c_commit, c_commit);
@@ -590,7 +651,7 @@ int device_acyclic_greedy(const struct spasm_csr *A, int *pinv, int *qinv)
 	}
 	const int words = ((m + 31) / 32 + 255) / 256 * 256;          // (cleared 256 words at a time)
 	// the reached-bits in LDS when one bit per column fits 64 KB (and a column fits 20 bits), else in HBM
-	bool global_bits = (size_t) words * 4 + (64 + 8 + PS_LIST + 64) * sizeof(int) > 64 * 1024 || m > (1 << 20);          // (room for the list, needed or not)
+	bool global_bits = (size_t) words * 4 + (64 + 8 + PS_LIST + 64 + PS_RING) * sizeof(int) > 64 * 1024 || m > (1 << 20);          // (room for the list, needed or not)
 	if (const char *e = sh::env_get("SPASM_HIP_PIVOT_BITS"))
 		global_bits = global_bits || std::strcmp(e, "global") == 0;
 	// rows with more than six other entries have no 16-byte record: their entries go through a list in LDS (if there are any)
@@ -598,7 +659,7 @@ int device_acyclic_greedy(const struct spasm_csr *A, int *pinv, int *qinv)
 	for (int i = 0; i < n && list_cap == 0; i++)
 		if (A->p[i + 1] - A->p[i] > (global_bits ? 6 : 7))          // (the pivot and five or six others: what a record holds)
 			list_cap = PS_LIST;
-	const size_t lds = global_bits ? (size_t) (64 + 8 + list_cap) * sizeof(int) : (size_t) words * 4 + (size_t) (64 + 8 + list_cap + 64) * sizeof(int);
+	const size_t lds = (global_bits ? (size_t) 0 : (size_t) words * 4) + (size_t) (64 + 8 + list_cap + 64 + PS_RING) * sizeof(int);
 	if (n <= 0 || m <= 0 || m > (1 << 25))
 		return -1;
 	const double t0 = wtime();
@@ -697,10 +758,10 @@ int device_acyclic_greedy(const struct spasm_csr *A, int *pinv, int *qinv)
 			found += 1;
 		}
 		if (found >= 0 && sh::env_get("SPASM_HIP_PIVOT_STATS"))
-			logmsg("[pivots] device: %d searches in flight (%d per CU, %zu bytes of LDS each%s), %llu pivot rows visited in %llu steps, %d tickets for %d pivots, "
+			logmsg("[pivots] device: %d searches in flight (%d per CU, %zu bytes of LDS each%s), %llu pivot rows visited in %llu steps (%llu of them by the %llu searches that ended with a pivot, the rest by %llu that did not), %d tickets for %d pivots, "
 			       "%d rows given up (FIFO full) [%.3fs: %.3f upload of A + allocations, %.3f kernels, %.3f journal; in the search kernel the first wave "
 			       "ran out of rows after %.1f ms, the last one left after %.1f ms, the longest search of one row took %.1f ms; "
-			       "of the waves' time %.0f %% in the walk, %.0f %% in replays and tickets]\n", grid, per_cu, lds, global_bits ? "; reached-bits in HBM" : "", c.visits, c.steps,
+			       "of the waves' time %.0f %% in the walk, %.0f %% in replays and tickets]\n", grid, per_cu, lds, global_bits ? "; reached-bits in HBM" : "", c.visits, c.steps, c.visits_won, c.rows_won, c.rows_lost,
 			       c.tickets, found, c.overflowed, wtime() - t0, t_alloc - t0, t_run - t_alloc, wtime() - t_run, 1e-5 * (double) (c.t_first_exit - c.t_start),
 			       1e-5 * (double) (c.t_last_exit - c.t_start), 1e-5 * (double) c.longest_search, 100.0 * (double) c.c_search / (double) std::max<u64>(c.c_total, 1),
 			       100.0 * (double) c.c_commit / (double) std::max<u64>(c.c_total, 1));

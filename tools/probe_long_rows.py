@@ -27,7 +27,7 @@ k = np.arange(int(p[n])) - np.repeat(p[:-1], lens)
 j = ((base[row] + k * stride[row]) % m).astype(np.int32)
 x = rng.integers(1, 42013, size=int(p[n])).astype(np.int32)
 A = Csr(n, m, p, j, x, 42013)
-for where in ("device", "host"):
+for where in (sys.argv[4].split(",") if len(sys.argv) > 4 else ("device", "host")):
     os.environ["SPASM_HIP_PIVOT_SEARCH"] = where
     t0 = time.time()
     npiv, perm, F = spasm_amd.pivots_extract_structural(A, spasm_amd.empty_fact(A.m, A.prime))
