@@ -23,6 +23,11 @@
 //  of the branching.  It is not: the visits did not move (5.75e9 against 5.46e9; 1.05e10 against 1.29e10 on 19-entry random
 //  rows) and the table look-ups cost 5-40 % -- the pivot graph of these matrices is thousands of levels deep and a walk is
 //  long and thin, so a level is a few dozen visits, not three quarters of them.)
+// (Also tried in round 4, HBM variant: the reached columns of a search in an LDS hash set -- 4,096 slots, open addressing --
+//  until they outgrow half of it, which four searches in five never do, so that their probes never leave the CU.  Same time
+//  (mk15.b4 0.50 s against 0.45; mk14.b4 with the bits forced to HBM 0.135 against 0.081 with one bit per column in LDS):
+//  the HBM variant is not slow because of where the marks are.  A step is a chain of round trips -- 6.8 us with eight
+//  searches per CU, 4 us with four -- and more searches in flight buy 15 %.)
 // As with threads, the set of pivots depends on timing; it is always cycle-free -- and the host checks that the order it
 // derives from the result is triangular before anything is built on it (host_pivots.cpp, Search::triangular).
 //
