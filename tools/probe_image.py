@@ -6,7 +6,7 @@ import time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tools"))
-os.environ["SPASM_HIP_VERBOSE"] = "2"
+os.environ.setdefault("SPASM_HIP_VERBOSE", "2")
 import torch
 import spasm_amd
 import workloads
