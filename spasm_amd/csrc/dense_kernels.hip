@@ -323,12 +323,31 @@ __global__ __launch_bounds__(COOP_THREADS) void rref_panel_coop_kernel(CoopPanel
 // --------------------------------------------------------------------------
 constexpr int SEL_ROWS = 256;
 
-// out[0 .. *count) = the first (at most 64) rows without pivot, found by one wave from *hint on; *hint moves up to
-// the first of them.
-__global__ __launch_bounds__(64) void rref_first_free(const int *flags, int n, int *hint, int *out, int *count)
+// The candidates of a try: at most 64 rows without pivot, picked by one wave.  Without a list of live rows: the first ones
+// from *hint on (*hint moves up to the first of them).  With one (rref_mark_dead below: the rows that are not zero from the
+// super-panel on, in no particular order): rows SPREAD over the list.  On a block the flow really produces -- the first
+// dense rows of mk13.b5's Schur complement: 4,096 x 4,952, rank 1,583 -- the first 64 free rows are soon all zero rows (they
+// depend on the pivots found so far and stay "free" for ever), and 64 CONSECUTIVE live rows have rank ~40 on a panel where 64
+// rows spread over the block have 64: the try failed on 58 of 64 panels and the tournament ran.
+__device__ __forceinline__ int pick_candidates(const int *flags, int n, int *hint, const int *live_list, const int *live_count, int *out, int lane)
 {
-	const int lane = threadIdx.x;
-	int found = 0, first = -1;
+	int found = 0;
+	const int cnt = (live_list != nullptr) ? *live_count : 0;
+	if (cnt >= NB) {
+		const int stride = cnt / NB;
+		for (int round = 0; round < stride && found < NB; round++) {
+			const int pos = lane * stride + round;
+			const int row = (pos < cnt) ? live_list[pos] : -1;
+			const bool fr = row >= 0 && flags[row] == 0;          // (a row of the list may have become a pivot row since)
+			const unsigned long long mk = __ballot(fr);
+			const int at = found + __popcll(mk & ((1ull << lane) - 1ull));
+			if (fr && at < NB)
+				out[at] = row;
+			found += __popcll(mk);
+		}
+		return min(found, NB);
+	}
+	int first = -1;
 	for (int base = *hint; base < n && found < NB; base += 64) {
 		const int i = base + lane;
 		const bool fr = i < n && flags[i] == 0;
@@ -340,9 +359,43 @@ __global__ __launch_bounds__(64) void rref_first_free(const int *flags, int n, i
 			first = base + __builtin_ctzll(mk);
 		found += __popcll(mk);
 	}
-	if (lane == 0) {
-		*count = min(found, NB);
+	if (lane == 0)
 		*hint = (first >= 0) ? first : n;
+	return min(found, NB);
+}
+
+__global__ __launch_bounds__(64) void rref_first_free(const int *flags, int n, int *hint, int *out, int *count, const int *live_list, const int *live_count)
+{
+	const int found = pick_candidates(flags, n, hint, live_list, live_count, out, (int) threadIdx.x);
+	if (threadIdx.x == 0)
+		*count = found;
+}
+
+// Rows without pivot that are zero from column c_from on can never hold one: they leave the free rows for good (flags = 2);
+// the others are listed (any order).  One wave per row; a live row usually says so in its first few hundred entries.
+__global__ __launch_bounds__(256) void rref_mark_dead(const uint32_t *A, int64_t ld, int n, int m, int c_from, int *flags, int *live_list, int *live_count)
+{
+	const int lane = threadIdx.x & 63;
+	const int wave = (blockIdx.x * 256 + threadIdx.x) >> 6, nwaves = (gridDim.x * 256) >> 6;
+	for (int i = wave; i < n; i += nwaves) {
+		if (flags[i] != 0)
+			continue;
+		bool live = false;
+		for (int j0 = c_from; j0 < m && !live; j0 += 256) {
+			bool nz = false;
+#pragma unroll
+			for (int u = 0; u < 4; u++) {
+				const int j = j0 + 64 * u + lane;
+				nz |= j < m && A[(int64_t) i * ld + j] != 0;
+			}
+			live = __ballot(nz) != 0;
+		}
+		if (lane == 0) {
+			if (live)
+				live_list[atomicAdd(live_count, 1)] = i;
+			else
+				flags[i] = 2;
+		}
 	}
 }
 
@@ -594,6 +647,12 @@ struct BlockGjArgs {
 	// ff_flags != null: scan from *ff_hint, write try_rows / *try_count through ff_out / ff_count
 	const int *ff_flags;
 	int *ff_hint, *ff_out, *ff_count;
+	const int *live_list, *live_count;          // rref_mark_dead's list of this super-panel, or null
+	// mode == 2 (SMALL only): a try that takes what its candidates give -- k <= 64 pivots, the other columns of the panel skipped
+	// as dependent -- and leaves the proof to the multiplier kernel (MultArgs::verify_flags): after the step every row without a
+	// pivot must be zero on the whole panel, which says that no skipped column could have had a pivot anywhere (then the
+	// pivot columns are the leftmost possible ones: the step is the regular step).  Only the candidates that got a pivot are
+	// passed on (knew = the number of pivots; knew[1] = the same = what rref_rollback takes back when the proof fails).
 	MontDev F;
 };
 
@@ -624,6 +683,25 @@ __global__ __launch_bounds__(128 * NPAR) void rref_block_gj(BlockGjArgs g)
 	const ElimArith<SMALL> E(F);
 	if (g.mode == 0 && *g.gj_done != 0)
 		return;                       // the try on the first free rows already did this panel
+	if (g.mode == 2) {
+		if (*g.abort != 0)
+			return;
+		if (tid < 64 && g.ff_flags != nullptr) {          // (null: the candidates were selected by the launch before)
+			const int found = pick_candidates(g.ff_flags, g.n, g.ff_hint, g.live_list, g.live_count, g.ff_out, tid);
+			if (tid == 0)
+				*g.ff_count = found;
+		}
+		if (tid == 0)
+			g.knew[1] = 0;
+		__syncthreads();
+		if (*g.try_count < 1 || g.width < NB) {
+			if (tid == 0) {
+				*g.gj_done = 0;
+				*g.abort = 1 + g.abort_value;
+			}
+			return;
+		}
+	}
 	if (g.mode == 1) {
 		const bool skip = g.try_state[0] >= 2 && (g.panel_index & 7) != 0;
 		if (skip || *g.try_count < g.width || g.width < NB) {
@@ -633,8 +711,8 @@ __global__ __launch_bounds__(128 * NPAR) void rref_block_gj(BlockGjArgs g)
 		}
 	}
 	if (tid < NB) {
-		const int *cand = (g.mode == 1) ? g.try_rows : (*g.full != 0) ? g.cand_first : g.cand;
-		const int c = (g.mode == 1 && tid >= *g.try_count) ? -1 : cand[tid];
+		const int *cand = (g.mode >= 1) ? g.try_rows : (*g.full != 0) ? g.cand_first : g.cand;
+		const int c = (g.mode >= 1 && tid >= *g.try_count) ? -1 : cand[tid];
 		const unsigned long long have = __ballot(c >= 0);
 		if (c >= 0)
 			s_rows[__popcll(have & ((1ull << tid) - 1ull))] = c;
@@ -764,13 +842,28 @@ __global__ __launch_bounds__(128 * NPAR) void rref_block_gj(BlockGjArgs g)
 		if (!ok)
 			return;                   // nothing written: the selection kernels and the regular call take over
 	}
+	if (g.mode == 2) {
+		if (tid == 0)
+			*g.gj_done = 1;
+		if (npiv == 0) {
+			// no pivot among the candidates: the multiplier kernel checks that NO free row has anything on this panel
+			if (tid == 0)
+				*g.knew = 0;
+			return;
+		}
+	}
+	const bool compact = g.mode == 2;          // pass on the candidates that hold a pivot, under their pivot index
 	if constexpr (SMALL) {
 		// pivot rows are normalised: the right half is Ginv
 #pragma unroll
 		for (int i = 0; i < RPT; i++) {
 			const int r = NPAR * i + par;
-			if (r < k && j >= NB && j - NB < k && s_prow_of[r] >= 0)
-				g.Ginv[s_prow_of[r] * NB + (j - NB)] = montmul(x[i], F.r2, F);          // Montgomery form
+			if (r < k && j >= NB && j - NB < k && s_prow_of[r] >= 0) {
+				// (compact: a pivot row is a combination of candidates that hold a pivot -- the others only ever RECEIVE)
+				const int col_of = compact ? s_prow_of[j - NB] : j - NB;
+				if (col_of >= 0)
+					g.Ginv[s_prow_of[r] * NB + col_of] = montmul(x[i], F.r2, F);          // Montgomery form
+			}
 		}
 	} else {
 		// scale: pivot row s has d at gamma_s, zeros at the other pivot columns; Ginv[s][r] = aug[s][r] / d
@@ -797,9 +890,14 @@ __global__ __launch_bounds__(128 * NPAR) void rref_block_gj(BlockGjArgs g)
 	if (tid < npiv)
 		g.gamma[tid] = s_gamma[tid];
 	if (tid < k) {
-		g.rho[tid] = s_rows[tid];
 		const int s = s_prow_of[tid];
-		g.cand_pivot[tid] = s;
+		if (!compact) {
+			g.rho[tid] = s_rows[tid];
+			g.cand_pivot[tid] = s;
+		} else if (s >= 0) {
+			g.rho[s] = s_rows[tid];
+			g.cand_pivot[s] = s;
+		}
 		if (s >= 0) {
 			g.is_pivot_row[s_rows[tid]] = 1;
 			g.pivrow[base + s] = s_rows[tid];
@@ -808,7 +906,22 @@ __global__ __launch_bounds__(128 * NPAR) void rref_block_gj(BlockGjArgs g)
 	}
 	if (tid == 0) {
 		*g.rank = base + npiv;
-		*g.knew = k;
+		*g.knew = compact ? npiv : k;
+		if (compact)
+			g.knew[1] = npiv;
+	}
+}
+
+// the pivots of a mode-2 try whose proof failed are taken back (the matrix itself was not touched: the update returned at once)
+__global__ __launch_bounds__(64) void rref_rollback(const int *rho, int *knew, int *flags, int *rank)
+{
+	const int committed = knew[1];
+	if ((int) threadIdx.x < committed)
+		flags[rho[threadIdx.x]] = 0;
+	__syncthreads();
+	if (threadIdx.x == 0) {
+		*rank -= committed;
+		knew[1] = 0;
 	}
 }
 
@@ -836,22 +949,9 @@ __global__ __launch_bounds__(256) void rref_try_inverse(BlockGjArgs g)
 		return;
 	if (g.ff_flags != nullptr) {
 		if (w == 0) {
-			int found = 0, first = -1;
-			for (int base = *g.ff_hint; base < g.n && found < NB; base += 64) {
-				const int i = base + lane;
-				const bool fr = i < g.n && g.ff_flags[i] == 0;
-				const unsigned long long mk = __ballot(fr);
-				const int pos = found + __popcll(mk & ((1ull << lane) - 1ull));
-				if (fr && pos < NB)
-					g.ff_out[pos] = i;
-				if (first < 0 && mk != 0)
-					first = base + __builtin_ctzll(mk);
-				found += __popcll(mk);
-			}
-			if (lane == 0) {
-				*g.ff_count = min(found, NB);
-				*g.ff_hint = (first >= 0) ? first : g.n;
-			}
+			const int found = pick_candidates(g.ff_flags, g.n, g.ff_hint, g.live_list, g.live_count, g.ff_out, lane);
+			if (lane == 0)
+				*g.ff_count = found;
 		}
 		__syncthreads();
 	}
@@ -1011,6 +1111,11 @@ struct MultArgs {
 	uint32_t *Zblk;               // M as 64 columns of Z (residues), or null
 	int64_t ldz;
 	const int *abort;
+	// the proof of a mode-2 try (BlockGjArgs): not null = the rows' flags (0 = no pivot, alive); after the step every such row
+	// must be zero on the 64 columns of the panel, else *abort_w = 1 + abort_value (SMALL16 only)
+	const int *verify_flags;
+	int *abort_w;
+	int abort_value;
 };
 
 template <bool SMALL16> __device__ __forceinline__ void multipliers_body(const int bx, const MultArgs &g)
@@ -1032,6 +1137,16 @@ template <bool SMALL16> __device__ __forceinline__ void multipliers_body(const i
 	const int tid = threadIdx.x;
 	if (k == 0) {
 		// no pivot in this panel: all-zero digit planes (the update kernels multiply every set)
+		if (SMALL16 && g.verify_flags != nullptr) {
+			// (a mode-2 try that found nothing: right if no row without a pivot has an entry on the panel)
+			const int i = bx * 64 + (tid & 63), q = tid >> 6;
+			bool bad = false;
+			if (i < n && g.verify_flags[i] == 0)
+				for (int u = 0; u < 16; u++)
+					bad = bad || (c0 + q * 16 + u < m && A[(int64_t) i * ld + c0 + q * 16 + u] != 0);
+			if (bad)
+				*g.abort_w = 1 + g.abort_value;
+		}
 		if (Mh != nullptr) {
 			const int i = bx * 64 + (tid & 63), q = tid >> 6;
 			if (i < n) {
@@ -1081,8 +1196,10 @@ template <bool SMALL16> __device__ __forceinline__ void multipliers_body(const i
 	// 64 rows per workgroup: thread (tid & 63) = row, (tid >> 6) = quarter of the r range
 	const int i = bx * 64 + (tid & 63);
 	const int q = tid >> 6;
-	if (i >= n)
+	const bool verify = SMALL16 && g.verify_flags != nullptr;          // (uniform)
+	if (i >= n && !verify)
 		return;
+	const bool active = i < n;
 	uint32_t acc[16];
 #pragma unroll
 	for (int u = 0; u < 16; u++)
@@ -1118,7 +1235,8 @@ template <bool SMALL16> __device__ __forceinline__ void multipliers_body(const i
 	// M = -acc; the row that became pivot s gets + Ginv[s][.] (see the definition of T above)
 	int my_pivot = -1;
 	for (int r = 0; r < k; r++)
-		my_pivot = (srho[r] == i) ? spiv[r] : my_pivot;
+		my_pivot = (active && srho[r] == i) ? spiv[r] : my_pivot;
+	uint32_t mine[16];
 	unsigned int wh[4] = {0, 0, 0, 0}, wl[4] = {0, 0, 0, 0};
 #pragma unroll
 	for (int u = 0; u < 16; u++) {
@@ -1129,20 +1247,50 @@ template <bool SMALL16> __device__ __forceinline__ void multipliers_body(const i
 			mval += g;
 			mval = (mval >= F.p || mval < g) ? mval - F.p : mval;
 		}
-		if (r < k)
+		if (r < k && active)
 			P[(int64_t) (NB + r) * n + i] = mval;
-		else
+		if (r >= k)
 			mval = 0;
-		if (Zblk != nullptr)
+		mine[u] = mval;
+		if (Zblk != nullptr && active)
 			Zblk[(int64_t) i * ldz + r] = SMALL16 ? mval : 0u;          // (only the matrix-core path, p < 2^16, keeps Z)
 		int hi, lo;
 		split_digits(mval, F, hi, lo);
 		wh[u >> 2] |= (unsigned int) (hi & 255) << (8 * (u & 3));
 		wl[u >> 2] |= (unsigned int) (lo & 255) << (8 * (u & 3));
 	}
-	if (Mh != nullptr) {
+	if (Mh != nullptr && active) {
 		*reinterpret_cast<int4 *>(Mh + (int64_t) i * 64 + q * 16) = make_int4((int) wh[0], (int) wh[1], (int) wh[2], (int) wh[3]);
 		*reinterpret_cast<int4 *>(Ml + (int64_t) i * 64 + q * 16) = make_int4((int) wl[0], (int) wl[1], (int) wl[2], (int) wl[3]);
+	}
+	if constexpr (SMALL16) {
+		if (verify) {
+			// the proof of a mode-2 try: new row = old row + M[i] (old pivot rows), on the 64 columns of the panel; sG is done with
+			// and becomes the multipliers of the 64 rows, the old pivot rows of the panel come in beside it
+			__shared__ uint32_t sR[NB][NB + 1];
+			__syncthreads();
+#pragma unroll
+			for (int u = 0; u < 16; u++)
+				sG[tid & 63][q * 16 + u] = mine[u];
+			for (int t = tid; t < NB * NB; t += 256) {
+				const int tt = t / NB, cc = t % NB;
+				sR[tt][cc] = (tt < k && c0 + cc < m) ? A[(int64_t) srho[tt] * ld + c0 + cc] : 0u;
+			}
+			__syncthreads();
+			bool bad = false;
+			if (active && g.verify_flags[i] == 0) {
+#pragma unroll 4
+				for (int u = 0; u < 16; u++) {
+					const int cc = q * 16 + u;
+					unsigned long long w = tile[tid & 63][cc];
+					for (int t = 0; t < k; t++)
+						w += (unsigned long long) sG[tid & 63][t] * sR[t][cc];          // < 2^32 each, at most 64 of them
+					bad = bad || reduce_sum(w, F) != 0;
+				}
+			}
+			if (bad)
+				*g.abort_w = 1 + g.abort_value;
+		}
 	}
 }
 
@@ -1744,7 +1892,7 @@ int device_rref(int64_t prime, int n, int m, uint32_t *dA, int64_t ld, int *d_pi
 	const bool small_prime = prime < 46341;          // 2 p^2 < 2^32: the panel kernels use 24-bit multiplies
 	if (const char *e = sh::env_get("SPASM_HIP_RREF_PANEL"))
 		tournament = std::strcmp(e, "columns") != 0;
-	int *candA = nullptr, *candB = nullptr, *free_count = nullptr, *gamma = nullptr, *cand_first = nullptr, *full_flag = nullptr, *first64 = nullptr, *cand_pivot = nullptr;
+	int *candA = nullptr, *candB = nullptr, *free_count = nullptr, *gamma = nullptr, *cand_first = nullptr, *full_flag = nullptr, *first64 = nullptr, *cand_pivot = nullptr, *live_list = nullptr;
 	uint32_t *Ginv = nullptr, *P4 = nullptr, *Bt4 = nullptr, *Zacc = nullptr;
 	int *rho4 = nullptr, *knew4 = nullptr;
 	signed char *M8 = nullptr, *B8 = nullptr;
@@ -1758,6 +1906,7 @@ int device_rref(int64_t prime, int n, int m, uint32_t *dA, int64_t ld, int *d_pi
 		ws_malloc((void **) &gamma, NB * sizeof(int));
 		ws_malloc((void **) &cand_first, NB * sizeof(int));
 		ws_malloc((void **) &first64, NB * sizeof(int));
+		ws_malloc((void **) &live_list, (size_t) n * sizeof(int));
 		ws_malloc((void **) &cand_pivot, NB * sizeof(int));
 		HIP_CHECK(hipMemsetAsync(free_count, 0, 64, stream));          // [4]: scan hint of rref_first_free
 		ws_malloc((void **) &P4, (size_t) 2 * MAXSETS * (size_t) n * PW * sizeof(uint32_t));
@@ -1824,6 +1973,7 @@ int device_rref(int64_t prime, int n, int m, uint32_t *dA, int64_t ld, int *d_pi
 		HIP_CHECK(hipStreamSynchronize(stream));
 		fprintf(stderr, "[rref timing] allocations + setup: %.3f ms\n", 1e3 * (wtime() - t_entry));
 	}
+	int stat_opt_ok = 0, stat_regular = 0, stat_aborts = 0, stat_marked = 0;          // panels done by the optimistic pass / the regular way; super-panels
 	if (tournament) {
 		const bool small16 = prime < 65536;
 		const bool try_first = sh::env_get("SPASM_HIP_RREF_TRY") == nullptr || std::atoi(sh::env_get("SPASM_HIP_RREF_TRY")) != 0;
@@ -1839,6 +1989,10 @@ int device_rref(int64_t prime, int n, int m, uint32_t *dA, int64_t ld, int *d_pi
 		const bool optimistic_enabled = sh::env_get("SPASM_HIP_RREF_OPTIMISTIC") == nullptr || std::atoi(sh::env_get("SPASM_HIP_RREF_OPTIMISTIC")) != 0;
 		bool optimistic_ok = optimistic_enabled;
 		int optimistic_skip = 0;
+		// a try has failed in this call: from the next super-panel on the zero rows are retired and the candidates of the tries
+		// are spread over the live ones (rref_mark_dead, pick_candidates)
+		bool deficient = false;
+		const bool retire_rows = sh::env_get("SPASM_HIP_RREF_RETIRE") == nullptr || std::atoi(sh::env_get("SPASM_HIP_RREF_RETIRE")) != 0;
 		uint32_t *set_P[MAXSETS] = {};
 		int *set_rho[MAXSETS] = {}, *set_knew[MAXSETS] = {};
 		signed char *set_Mh[MAXSETS] = {}, *set_Ml[MAXSETS] = {};
@@ -1857,6 +2011,24 @@ int device_rref(int64_t prime, int n, int m, uint32_t *dA, int64_t ld, int *d_pi
 				if (rk_nz[0] >= n || rk_nz[1] == 0)
 					break;
 			}
+			bool have_live = false;
+			int live_rows = -1;
+			auto retire = [&]() {
+				// (reads the columns from sp0 on: the far update of the previous super-panel must have landed -- the overlap of that
+				//  update with the panel steps is given up here, on blocks whose panel steps are the slow part anyway)
+				if (far_pending)
+					HIP_CHECK(hipStreamWaitEvent(stream, ev_far, 0));
+				HIP_CHECK(hipMemsetAsync(free_count + 10, 0, sizeof(int), stream));
+				hipLaunchKernelGGL(rref_mark_dead, dim3(512), dim3(256), 0, stream, dA, ld, n, m, sp0, flags, live_list, free_count + 10);
+				HIP_CHECK(hipMemcpyAsync(&live_rows, free_count + 10, sizeof(int), hipMemcpyDeviceToHost, stream));
+				HIP_CHECK(hipStreamSynchronize(stream));
+				have_live = true;
+			};
+			if (deficient && retire_rows) {
+				retire();
+				if (live_rows == 0)
+					break;                           // every row holds a pivot or is zero from here on
+			}
 			const int sp_end = std::min(m, sp0 + SPW * NB);
 			const int mrT = m - sp_end;              // columns beyond the super-panel
 			UpdSets S{};
@@ -1870,7 +2042,8 @@ int device_rref(int64_t prime, int n, int m, uint32_t *dA, int64_t ld, int *d_pi
 				uint32_t *P_s = P4 + (size_t) slot * (size_t) n * PW;
 				int *rho_s = rho4 + slot * NB, *knew_s = knew4 + slot * 16;
 				if (!optimistic)
-					hipLaunchKernelGGL(rref_first_free, dim3(1), dim3(64), 0, stream, flags, n, free_count + 4, first64, free_count + 2);
+					hipLaunchKernelGGL(rref_first_free, dim3(1), dim3(64), 0, stream, flags, n, free_count + 4, first64, free_count + 2, have_live ? live_list : nullptr,
+					                   free_count + 10);
 				// Gauss-Jordan straight on the first 64 free rows (try mode): when they give a pivot in every column of the
 				// panel (the usual case while the block is not exhausted) everything up to the regular call returns at once
 				BlockGjArgs bg;
@@ -1905,7 +2078,16 @@ int device_rref(int64_t prime, int n, int m, uint32_t *dA, int64_t ld, int *d_pi
 				bg.ff_hint = free_count + 4;
 				bg.ff_out = first64;
 				bg.ff_count = free_count + 2;
-				if (try_first) {
+				bg.live_list = have_live ? live_list : nullptr;
+				bg.live_count = free_count + 10;
+				// (a block on which tries fail -- dependent columns, or rows that depend on each other --: the try that takes what its
+				//  candidates give, with the proof in the multiplier kernel; see BlockGjArgs)
+				const bool take_what_comes = optimistic && have_live && small_prime && small16 && mfma_ok && width == NB;
+				if (take_what_comes) {
+					bg.mode = 2;
+					hipLaunchKernelGGL((rref_block_gj<true, 8>), dim3(1), dim3(1024), invtab_bytes, stream, bg);
+					bg.mode = 1;
+				} else if (try_first) {
 					if (fast_try)
 						hipLaunchKernelGGL(rref_try_inverse, dim3(1), dim3(256), invtab_bytes, stream, bg);
 					else if (small_prime)
@@ -1923,7 +2105,7 @@ int device_rref(int64_t prime, int n, int m, uint32_t *dA, int64_t ld, int *d_pi
 					                   cand_first, F, full_flag, full_flag + 4);
 				// (everything from here to the Gauss-Jordan block returns at once when that was enough)
 				hipLaunchKernelGGL(rref_free_list, dim3(1), dim3(1024), 0, stream, flags, n, candA, free_count, full_flag);
-				int n_in = n;
+				int n_in = have_live ? std::max(live_rows, 1) : n;          // (the free rows are among the live ones: fewer levels on a block that is running out)
 				const int *count_dev = free_count;
 				int *src = candA, *dst = candB;
 				for (;;) {
@@ -1950,7 +2132,8 @@ int device_rref(int64_t prime, int n, int m, uint32_t *dA, int64_t ld, int *d_pi
 				}
 				signed char *Mh_s = M8 + (size_t) slot * 2 * (size_t) n * 64, *Ml_s = Mh_s + (size_t) n * 64;
 				MultArgs ma{dA, ld, n, m, c0, Ginv, gamma, knew_s, P_s, F, rho_s, cand_pivot, mfma_ok ? Mh_s : nullptr, mfma_ok ? Ml_s : nullptr,
-				            mfma_ok ? Zacc + (size_t) nsets * NB : nullptr /* M_s becomes block `nsets` of Z */, ldz, abort_c};
+				            mfma_ok ? Zacc + (size_t) nsets * NB : nullptr /* M_s becomes block `nsets` of Z */, ldz, abort_c,
+				            take_what_comes ? flags : nullptr, abort_d, nsets};
 				const int nmult = (n + 63) / 64;
 				// the columns of the super-panel, from this panel on, and (matrix cores) the multipliers of its earlier
 				// panels, blocks 0 .. nsets - 1 of Z: K = 64 update now
@@ -2010,21 +2193,60 @@ int device_rref(int64_t prime, int n, int m, uint32_t *dA, int64_t ld, int *d_pi
 			const int npanels = (sp_end - sp0 + NB - 1) / NB;
 			int first_regular = 0;
 			if (optimistic_ok && fast_try && mfma_ok && try_first && ms_update == nullptr) {
-				HIP_CHECK(hipMemsetAsync(abort_d, 0, sizeof(int), stream));
-				for (int i = 0; i < npanels; i++)
-					run_panel(sp0 + i * NB, i, true);
-				int raised = 0;
-				HIP_CHECK(hipMemcpyAsync(&raised, abort_d, sizeof(int), hipMemcpyDeviceToHost, stream));
-				HIP_CHECK(hipStreamSynchronize(stream));
-				first_regular = raised != 0 ? raised - 1 : npanels;
-				if (raised != 0)
-					optimistic_skip = 2;
+				// passes of optimistic panel steps from `start` on; a pass ends at the panel whose try (or proof) failed.  The first
+				// failure of a call switches to the tries that take what comes (rows retired, candidates spread: BlockGjArgs mode 2)
+				// and the pass is taken up again at that panel; a failure in that mode sends the one panel the regular way.
+				int start = 0, fallbacks = 0;
+				while (start < npanels) {
+					HIP_CHECK(hipMemsetAsync(abort_d, 0, sizeof(int), stream));
+					// (knew[1] of a slot = the pivots a mode-2 try has taken, for rref_rollback: nothing yet)
+					HIP_CHECK(hipMemset2DAsync(knew4 + (size_t) (spi & 1) * MAXSETS * 16 + 1, 16 * sizeof(int), 0, sizeof(int), MAXSETS, stream));
+					for (int i = start; i < npanels; i++)
+						run_panel(sp0 + i * NB, i, true);
+					int raised = 0;
+					HIP_CHECK(hipMemcpyAsync(&raised, abort_d, sizeof(int), hipMemcpyDeviceToHost, stream));
+					HIP_CHECK(hipStreamSynchronize(stream));
+					const int stop = raised != 0 ? raised - 1 : npanels;
+					stat_opt_ok += stop - start;
+					start = stop;
+					if (raised == 0)
+						break;
+					stat_aborts += 1;
+					if (have_live) {
+						// (a mode-2 try whose proof failed has taken its pivots already: they go back before the panel is redone)
+						const int slot = (spi & 1) * MAXSETS + stop;
+						if (sh::env_get("SPASM_HIP_RREF_TIMING")) {
+							int took = 0, tc = 0;
+							HIP_CHECK(hipMemcpy(&took, knew4 + slot * 16 + 1, sizeof(int), hipMemcpyDeviceToHost));
+							HIP_CHECK(hipMemcpy(&tc, free_count + 2, sizeof(int), hipMemcpyDeviceToHost));
+							fprintf(stderr, "[rref timing] super-panel %d: the try of panel %d took %d pivots from %d candidates (%d live rows) and the proof failed\n", spi, stop, took, tc,
+							        live_rows);
+						}
+						hipLaunchKernelGGL(rref_rollback, dim3(1), dim3(64), 0, stream, rho4 + slot * NB, knew4 + slot * 16, flags, rank_d);
+						run_panel(sp0 + stop * NB, stop, false);
+						stat_regular += 1;
+						start = stop + 1;
+						fallbacks += 1;
+						if (fallbacks >= 3)
+							break;                   // (the rest of the super-panel the regular way)
+					} else if (retire_rows && small_prime && small16) {
+						deficient = true;
+						retire();
+					} else {
+						break;
+					}
+				}
+				first_regular = start;
+				if (start < npanels)
+					optimistic_skip = (deficient && retire_rows) ? 0 : 2;          // (2: the next super-panel is not attempted)
 			}
 			if (optimistic_skip > 0)
 				optimistic_skip -= 1;
 			optimistic_ok = optimistic_enabled && optimistic_skip == 0;
 			for (int i = first_regular; i < npanels; i++)
 				run_panel(sp0 + i * NB, i, false);
+			stat_regular += npanels - first_regular;
+			stat_marked += have_live;
 			const int nsets = npanels;
 			if (mrT > 0) {
 				// beyond the super-panel.  What is read here -- the rows rho_i beyond the super-panel -- is written by the far
@@ -2171,7 +2393,8 @@ int device_rref(int64_t prime, int n, int m, uint32_t *dA, int64_t ld, int *d_pi
 		if (stream2 != nullptr)
 			HIP_CHECK(hipStreamSynchronize(stream2));
 		t_loop = wtime();
-		fprintf(stderr, "[rref timing] up to the end of the panels: %.3f ms\n", 1e3 * (t_loop - t_entry));
+		fprintf(stderr, "[rref timing] up to the end of the panels: %.3f ms (%d panels by the optimistic passes, %d the regular way, %d super-panels gave up, %d with retired rows)\n",
+		        1e3 * (t_loop - t_entry), stat_opt_ok, stat_regular, stat_aborts, stat_marked);
 	}
 	int rank = 0, coop_failed = 0;
 	HIP_CHECK(hipMemcpyAsync(&rank, rank_d, sizeof(int), hipMemcpyDeviceToHost, stream));
@@ -2190,6 +2413,7 @@ int device_rref(int64_t prime, int n, int m, uint32_t *dA, int64_t ld, int *d_pi
 		ws_free(gamma);
 		ws_free(cand_first);
 		ws_free(first64);
+		ws_free(live_list);
 		ws_free(cand_pivot);
 		ws_free(P4);
 		ws_free(Bt4);

@@ -55,8 +55,9 @@ typedef int64_t i64;
 typedef unsigned long long u64;
 
 // record of a pivotal column, 16 bytes = ONE load per visited pivot row.  Bits [0, 3): 0 = not pivotal, 1..ENTS = that many
-// other columns of its row follow, BITS bits each; 7 = the row is too long for that (or has nothing else) and bits [3, 35)
-// are its index in A.  Two formats: six columns of 20 bits (m <= 2^20; with the reached-bits in LDS: m <= 2^19), five of 25.
+// other columns of its row follow, BITS bits each; 7 = the row is too long for that (or has nothing else): bits [3, 64) are
+// where its entries start in A and the second word is their number (until round 4: the index of the row, and the walk paid
+// a round trip for Ap[row] before it could ask for the entries -- one of three per step on a matrix of long rows).  Two formats: six columns of 20 bits (m <= 2^20; with the reached-bits in LDS: m <= 2^19), five of 25.
 constexpr int REC_WORDS = 2, REC_LONG = 7;
 
 template <int BITS> __host__ __device__ inline void rec_put(unsigned long long &lo, unsigned long long &hi, int k, unsigned long long v)
@@ -145,7 +146,8 @@ __global__ __launch_bounds__(256) void pivot_records_kernel(const i64 *Ap, const
 		const i64 first = Ap[row], last = Ap[row + 1];
 		const i64 others = last - first - 1;
 		if (others > REC_ENTS || others <= 0) {
-			lo = (u64) REC_LONG | ((u64) (uint32_t) row << 3);
+			lo = (u64) REC_LONG | ((u64) first << 3);
+			hi = (u64) (last - first);
 		} else {
 			int len = 0;
 			for (i64 px = first; px < last; px++) {
@@ -153,7 +155,12 @@ __global__ __launch_bounds__(256) void pivot_records_kernel(const i64 *Ap, const
 				if (j != col && len < REC_ENTS)
 					rec_put<REC_BITS>(lo, hi, len++, (u64) j);
 			}
-			lo |= (len > 0) ? (u64) len : (u64) REC_LONG | ((u64) (uint32_t) row << 3);
+			if (len > 0) {
+				lo |= (u64) len;
+			} else {
+				lo = (u64) REC_LONG | ((u64) first << 3);
+				hi = (u64) (last - first);
+			}
 		}
 	}
 	u64 *R = rec + (size_t) col * REC_WORDS;
@@ -176,7 +183,7 @@ constexpr int PS_RING = 512;          // the last entries of a search's FIFO, mi
 // candidate columns of the row (one per lane) in LDS.
 template <bool GB, int REC_ENTS, int REC_BITS>
 __global__ __launch_bounds__(64) void pivot_search_kernel(const i64 *Ap, const int *Aj, const int *pinv, int n, int m, int words, u64 *rec, u64 *jent, int *jrow,
-                                                          PsCtrl *ctrl, int *fifo_all, int fifo_cap, int jcap, uint32_t *gbits, int list_cap)
+                                                          PsCtrl *ctrl, int *fifo_all, int fifo_cap, int jcap, uint32_t *gbits, int list_cap, i64 annz)
 {
 	extern __shared__ __attribute__((aligned(16))) uint32_t ps_lds[];
 	uint32_t *bits = GB ? gbits + (size_t) blockIdx.x * (size_t) (words + 64) : ps_lds;
@@ -311,7 +318,8 @@ __global__ __launch_bounds__(64) void pivot_search_kernel(const i64 *Ap, const i
 							ld_rec(rec + (size_t) c * REC_WORDS, lo, hi);
 					}
 					const int len = (int) (lo & 7ull);
-					const int long_row = (int) (uint32_t) (lo >> 3);
+					const i64 long_off = (i64) (lo >> 3);
+					const int long_len = (int) min((u64) (1 << 30), hi);
 					visits += (u64) __popcll(__ballot(len != 0));
 					steps += 1;
 					// The step is bound by instruction issue, not by memory (512 searches in flight are as fast as 2,048, cached record
@@ -364,12 +372,12 @@ __global__ __launch_bounds__(64) void pivot_search_kernel(const i64 *Ap, const i
 					// to list_cap at a time (PS_LIST when the matrix has such rows: the list is LDS that matrices of short rows would rather
 					// spend on a fourth search per CU), and marked 64 per round whatever row they come from.
 					{
-						u64 longs = __ballot(len == REC_LONG && long_row < n);
+						u64 longs = __ballot(len == REC_LONG && long_off + long_len <= annz);          // (beyond A: a record caught half written)
 						i64 my_lo = 0;
 						int my_len = 0;
 						if ((longs >> lane) & 1) {
-							my_lo = Ap[long_row];
-							my_len = (int) min((i64) (1 << 30), Ap[long_row + 1] - my_lo);
+							my_lo = long_off;
+							my_len = long_len;
 						}
 						while (longs != 0) {
 							const bool in = (longs >> lane) & 1;
@@ -566,10 +574,13 @@ __global__ __launch_bounds__(64) void pivot_search_kernel(const i64 *Ap, const i
 				{
 					const i64 others = row_hi - row_lo - 1;
 					u64 *R = rec + (size_t) chosen * REC_WORDS;
-					const u64 as_long = (u64) REC_LONG | ((u64) (uint32_t) i << 3);
+					const u64 as_long = (u64) REC_LONG | ((u64) row_lo << 3), all_of_it = (u64) (row_hi - row_lo);
 					if (others > REC_ENTS || others <= 0) {
-						if (lane == 0)
+						if (lane == 0) {
+							st_u64(R + 1, all_of_it);
+							drain();
 							st_u64(R, as_long);
+						}
 					} else {
 						const bool valid = row_lo + lane < row_hi;
 						const int j = valid ? Aj[row_lo + lane] : 0;
@@ -582,7 +593,7 @@ __global__ __launch_bounds__(64) void pivot_search_kernel(const i64 *Ap, const i
 							u64 lo = 0, hi = 0;
 							for (int t = 0; t < len; t++)
 								rec_put<REC_BITS>(lo, hi, t, (u64) tmp[t]);
-							st_u64(R + 1, hi);
+							st_u64(R + 1, len > 0 ? hi : all_of_it);
 							drain();
 							st_u64(R, len > 0 ? (lo | (u64) len) : as_long);
 						}
@@ -715,11 +726,11 @@ int device_acyclic_greedy(const struct spasm_csr *A, int *pinv, int *qinv)
 	if (global_bits) {
 		hipLaunchKernelGGL((pivot_records_kernel<5, 25>), dim3((m + 255) / 256), dim3(256), 0, stream, dA.p, dA.j, d_qinv, m, rec);
 		hipLaunchKernelGGL((pivot_search_kernel<true, 5, 25>), dim3(grid), dim3(64), lds, stream, dA.p, dA.j, d_pinv, n, m, words, rec, jent, jrow, ctrl, fifo,
-		                   fifo_cap, (int) jcap, gbits, list_cap);
+		                   fifo_cap, (int) jcap, gbits, list_cap, (i64) A->p[n]);
 	} else {
 		hipLaunchKernelGGL((pivot_records_kernel<6, 20>), dim3((m + 255) / 256), dim3(256), 0, stream, dA.p, dA.j, d_qinv, m, rec);
 		hipLaunchKernelGGL((pivot_search_kernel<false, 6, 20>), dim3(grid), dim3(64), lds, stream, dA.p, dA.j, d_pinv, n, m, words, rec, jent, jrow, ctrl, fifo,
-		                   fifo_cap, (int) jcap, gbits, list_cap);
+		                   fifo_cap, (int) jcap, gbits, list_cap, (i64) A->p[n]);
 	}
 	HIP_CHECK(hipGetLastError());
 	PsCtrl c;

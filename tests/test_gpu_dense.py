@@ -410,6 +410,48 @@ def _low_rank(torch, gen, p, n, m, rank, density=1.0, dev="cuda:0"):
     return _mod_matmul(torch, Lh, Rh, p).to(torch.int32)
 
 
+@pytest.mark.parametrize("case", ["dependent_columns", "dependent_rows", "dead_rows_and_empty_panels"])
+def test_rref_blocks_on_which_the_tries_fail(oracle, case):
+    """The panel steps of a block whose tries fail (round 4): zero rows are retired, the candidates of a try are spread over the
+    live rows, a try takes the pivots its candidates give and the multiplier kernel PROVES that the skipped columns had none
+    (else the pivots are taken back and the panel goes the regular way).  Three shapes of trouble, three super-panels and more
+    each, exact reduced echelon form against the oracle, twice (the second call runs on the cached buffers):
+    dependent_columns: one column in three independent, generic rows (every try gives ~21 pivots, every proof holds);
+    dependent_rows: runs of 64 rows that span 40 dimensions (tries come up short: proofs fail, pivots go back);
+    dead_rows_and_empty_panels: rank 300 in 1,400 rows, then 600 columns that depend on the first ones."""
+    p = 42013
+    rng = np.random.default_rng(len(case))
+    if case == "dependent_columns":
+        n, m, k = 1280, 2112, 600
+        gen = rng.integers(0, p, size=(k, (m + 2) // 3))
+        R = np.zeros((k, m), np.int64)
+        R[:, ::3] = gen[:, : len(range(0, m, 3))]
+        for off in (1, 2):
+            cols = np.arange(off, m, 3)
+            src = cols // 3
+            R[:, cols] = (gen[:, src] * rng.integers(1, p, size=len(cols)) + gen[:, np.maximum(src - 1, 0)] * rng.integers(0, p, size=len(cols))) % p
+        M = _mod_product(rng.integers(0, p, size=(n, k)), R, p)
+    elif case == "dependent_rows":
+        n, m = 1536, 1800
+        M = np.zeros((n, m), np.int64)
+        for g0 in range(0, n, 64):
+            basis = rng.integers(0, p, size=(40, m))
+            M[g0:g0 + 64] = _mod_product(rng.integers(0, p, size=(64, 40)), basis, p)
+    else:
+        n, m, k = 1400, 2200, 300
+        R = rng.integers(0, p, size=(k, m))
+        R[:, 1600:] = _mod_product(R[:, :k], rng.integers(0, p, size=(k, m - 1600)), p)          # columns that depend on the first ones
+        M = _mod_product(rng.integers(0, p, size=(n, k)), R, p)
+        M[::3] = 0                                                                               # zero rows among the others
+    r_want, R_want, q_want = oracle.dense_rref(p, M)
+    for _ in range(2):
+        r, R, q = spasm_amd.ffpack_rref(p, M)
+        assert r == r_want
+        assert np.array_equal(q, q_want)
+        assert np.array_equal(R[:r], R_want[:r])
+        assert not np.any(R[r:])
+
+
 def _mod_matmul(torch, A, B, p):
     """(A @ B) mod p on the device, exact: float64 products of entries below 2^16, 64 terms per partial sum"""
     out = torch.zeros((A.shape[0], B.shape[1]), dtype=torch.int64, device=A.device)
