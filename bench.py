@@ -167,8 +167,10 @@ def dense_tail_probe(torch, spasm_amd, dev, n=4096, m=32768):
 
 def dense_tail_real_probe(torch, spasm_amd, dev, dA, drows, dF, Sm, nrows=4096):
     """the dense tail on a block the flow really produces: the first `nrows` non-pivotal rows of the workload reduced to dense
-    rows by the factor (spasm_schur_dense, spasm_schur.c:258-343) -- for mk13.b5 a 4,096 x 4,952 block of rank ~4,130 in which
-    one column in seven depends on the columns before it -- then its RREF (spasm_hip_drref), timed like the random block."""
+    rows by the factor (spasm_schur_dense, spasm_schur.c:258-343) -- for mk13.b5 a 4,096 x 4,952 block of rank ~1,600 (the
+    pivots of the run decide): its first 25 panels of 64 columns are full, then a few hundred live rows face panels with no
+    pivot at all, 64 consecutive rows have rank ~40 on a panel, and rows that have become zero stay among the free ones --
+    then its RREF (spasm_hip_drref), timed like the random block."""
     L = spasm_amd.lib()
     n = min(nrows, int(drows.numel()))
     ld = (Sm + 63) // 64 * 64
