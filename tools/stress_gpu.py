@@ -63,6 +63,18 @@ while time.time() < t_end:
             print("MISMATCH backsolve n=%d m=%d per_row=%d p=%d %s" % (n, m, per_row, p, bs_env), flush=True)
         for key in bs_env:
             os.environ.pop(key, None)
+        # the sparse image (round 4): forced, with a random segment size and a pool small enough to be outgrown now and then
+        sp_env = {"SPASM_HIP_SPARSE_IMAGE": "1", "SPASM_HIP_BACKSOLVE": "0", "SPASM_HIP_SPARSE_IMAGE_PERSISTENT": str(int(rng.integers(0, 2))),
+                  "SPASM_HIP_SPARSE_IMAGE_CHUNK": str(int(rng.choice([0, 4096, 100000]))), "SPASM_HIP_SPARSE_IMAGE_ARENAS": str(int(rng.integers(0, 2)))}
+        os.environ.update(sp_env)
+        S, p_out = spasm_amd.schur(as_product(A), rows, spasm_amd.Fact(as_product(F.U), F.qinv))
+        ok = orc.same_matrix(orc.CSR(S.n, S.m, S.p, S.j, S.x, p), want) and np.array_equal(np.asarray(p_out), np.asarray(p_out_want))
+        cases += 1
+        if not ok:
+            fails += 1
+            print("MISMATCH sparse image n=%d m=%d per_row=%d p=%d %s" % (n, m, per_row, p, sp_env), flush=True)
+        for key in sp_env:
+            os.environ.pop(key, None)
     # ---- dense RREF of a rank-deficient block
     dn, dm = int(rng.integers(1, 1500)), int(rng.integers(1, 700))
     k = int(rng.integers(0, min(dn, dm) + 1))
@@ -76,6 +88,31 @@ while time.time() < t_end:
     if r != r0 or not np.array_equal(np.asarray(q)[:r], np.asarray(q0)[:r]) or not np.array_equal(np.asarray(Rm)[:r], np.asarray(R0)[:r]):
         fails += 1
         print("MISMATCH rref %dx%d rank %d p=%d (got rank %d)" % (dn, dm, r0, p, r), flush=True)
+    # ---- dense RREF of blocks on which the tries of the panel steps fail (round 4: retired rows, tries that take what comes,
+    # proofs and rollbacks): dependent columns among independent ones, runs of dependent rows, zero rows
+    if cases % 5 == 0:
+        dn, dm = int(rng.integers(600, 1800)), int(rng.integers(1100, 2400))
+        every = int(rng.integers(2, 5))
+        kk = int(rng.integers(50, min(dn, dm // every)))
+        gen = rng.integers(0, p, size=(kk, dm), dtype=np.int64)
+        for j in range(dm):
+            if j % every != 0 and j >= every:
+                gen[:, j] = (gen[:, j - (j % every)] * int(rng.integers(1, p)) + gen[:, (j - (j % every)) - every] * int(rng.integers(0, p))) % p
+        L = rng.integers(0, p, size=(dn, kk), dtype=np.int64)
+        if rng.integers(0, 2):
+            for g0 in range(0, dn, 64):          # runs of 64 rows that only involve 30 of the kk directions
+                keep = rng.choice(kk, size=min(kk, 30), replace=False)
+                mask = np.zeros(kk, bool)
+                mask[keep] = True
+                L[g0:g0 + 64, ~mask] = 0
+        M = np.array((L.astype(object).dot(gen.astype(object))) % p, dtype=np.int64)
+        M[rng.integers(0, dn, size=dn // 4)] = 0
+        r, Rm, q = spasm_amd.ffpack_rref(p, M)
+        r0, R0, q0 = orc.dense_rref(p, M)
+        cases += 1
+        if r != r0 or not np.array_equal(np.asarray(q)[:r], np.asarray(q0)[:r]) or not np.array_equal(np.asarray(Rm)[:r], np.asarray(R0)[:r]):
+            fails += 1
+            print("MISMATCH rref (dependent columns) %dx%d rank %d p=%d every=%d (got rank %d)" % (dn, dm, r0, p, every, r), flush=True)
     # ---- the whole driver on a random sparse matrix: rank against the oracle's driver
     if cases % 7 == 0:
         en, em, eper = int(rng.integers(50, 1500)), int(rng.integers(50, 1500)), int(rng.integers(1, 6))
