@@ -400,10 +400,19 @@ __global__ __launch_bounds__(256) void rref_mark_dead(const uint32_t *A, int64_t
 }
 
 // list[0 .. count) = rows i with flags[i] == 0, increasing.  One workgroup.  (skip: see rref_select_kernel)
-__global__ __launch_bounds__(1024) void rref_free_list(const int *flags, int n, int *list, int *count, const int *skip)
+__global__ __launch_bounds__(1024) void rref_free_list(const int *flags, int n, int *list, int *count, const int *skip, int *reset = nullptr)
 {
 	__shared__ int part[1024];
 	const int tid = threadIdx.x;
+	if (reset != nullptr) {
+		// (a panel step that starts here -- the try and the selection on the first rows were not even launched: they fail on
+		//  this block --: "not done yet" for the kernels that follow; reset[0] = *full = *skip, reset[4] = *gj_done)
+		if (tid == 0) {
+			reset[0] = 0;
+			reset[4] = 0;
+		}
+		__syncthreads();
+	}
 	if (skip != nullptr && *skip != 0)
 		return;
 	const int per = (n + 1023) / 1024;
@@ -2041,7 +2050,9 @@ int device_rref(int64_t prime, int n, int m, uint32_t *dA, int64_t ld, int *d_pi
 				const int slot = (spi & 1) * MAXSETS + nsets;
 				uint32_t *P_s = P4 + (size_t) slot * (size_t) n * PW;
 				int *rho_s = rho4 + slot * NB, *knew_s = knew4 + slot * 16;
-				if (!optimistic)
+				// (regular panel of a block on which the tries fail: straight to the tournament, three launches fewer)
+				const bool straight = !optimistic && have_live;
+				if (!optimistic && !straight)
 					hipLaunchKernelGGL(rref_first_free, dim3(1), dim3(64), 0, stream, flags, n, free_count + 4, first64, free_count + 2, have_live ? live_list : nullptr,
 					                   free_count + 10);
 				// Gauss-Jordan straight on the first 64 free rows (try mode): when they give a pivot in every column of the
@@ -2087,7 +2098,7 @@ int device_rref(int64_t prime, int n, int m, uint32_t *dA, int64_t ld, int *d_pi
 					bg.mode = 2;
 					hipLaunchKernelGGL((rref_block_gj<true, 8>), dim3(1), dim3(1024), invtab_bytes, stream, bg);
 					bg.mode = 1;
-				} else if (try_first) {
+				} else if (try_first && !straight) {
 					if (fast_try)
 						hipLaunchKernelGGL(rref_try_inverse, dim3(1), dim3(256), invtab_bytes, stream, bg);
 					else if (small_prime)
@@ -2097,14 +2108,16 @@ int device_rref(int64_t prime, int n, int m, uint32_t *dA, int64_t ld, int *d_pi
 				}
 				if (!optimistic) {
 				// the first 64 free rows alone, by selection (when the try was skipped or failed)
-				if (small_prime)
+				if (straight)
+					;
+				else if (small_prime)
 					hipLaunchKernelGGL(rref_select_first<true>, dim3(1), dim3(256), 0, stream, dA, ld, c0, width, first64, free_count + 2,
 					                   cand_first, F, full_flag, full_flag + 4);
 				else
 					hipLaunchKernelGGL(rref_select_first<false>, dim3(1), dim3(256), 0, stream, dA, ld, c0, width, first64, free_count + 2,
 					                   cand_first, F, full_flag, full_flag + 4);
 				// (everything from here to the Gauss-Jordan block returns at once when that was enough)
-				hipLaunchKernelGGL(rref_free_list, dim3(1), dim3(1024), 0, stream, flags, n, candA, free_count, full_flag);
+				hipLaunchKernelGGL(rref_free_list, dim3(1), dim3(1024), 0, stream, flags, n, candA, free_count, full_flag, straight ? full_flag : nullptr);
 				int n_in = have_live ? std::max(live_rows, 1) : n;          // (the free rows are among the live ones: fewer levels on a block that is running out)
 				const int *count_dev = free_count;
 				int *src = candA, *dst = candB;
