@@ -317,6 +317,18 @@ __global__ __launch_bounds__(64) void pivot_search_kernel(const i64 *Ap, const i
 						if (c >= 0)
 							ld_rec(rec + (size_t) c * REC_WORDS, lo, hi);
 					}
+					// (a record of a long row is published second word first -- its length, never 0 -- then, drained, the first word;
+					//  should a 16-byte load ever see the new first word beside the old second one, it is read again)
+					for (unsigned spins = 0; __ballot((lo & 7ull) == (u64) REC_LONG && hi == 0) != 0; spins++) {
+						if ((lo & 7ull) == (u64) REC_LONG && hi == 0)
+							ld_rec(rec + (size_t) c * REC_WORDS, lo, hi);
+						if (spins > 64) {
+							dead = true;
+							break;
+						}
+					}
+					if (dead)
+						break;
 					const int len = (int) (lo & 7ull);
 					const i64 long_off = (i64) (lo >> 3);
 					const int long_len = (int) min((u64) (1 << 30), hi);
