@@ -659,15 +659,13 @@ def main():
             finally:
                 os.environ.pop("SPASM_HIP_PIVOT_SEARCH", None)
         if extras and args.workload == "mk13.b5":
-            # (every object below starts from an empty cache of device blocks, as a process of its own would: after the three
-            #  paths of mk14.b4 -- 23 GB of dense R, 24 GB of accumulator scratch -- the first mk15.b4 call of one run spent
-            #  1.7 s of its pivot stage giving cached blocks back to the device; in a process of its own it takes 1.15 s)
-            spasm_amd.release_cached_memory()
-            out["sparse_path"] = sparse_path_probe(torch, spasm_amd, workloads, dev)
-            spasm_amd.release_cached_memory()
-            # the same at the size of GL7d19 (no dense image exists for this factor; the row-by-row kernels are left out: minutes)
+            # (the largest object first: what the three paths of mk14.b4 park in the cache of device blocks -- 23 GB of dense R, 24 GB
+            #  of accumulator scratch -- had to be given back to the device in the middle of the first mk15.b4 call of one run,
+            #  2.6 s instead of 0.9-1.2; emptying the cache between the objects is worse: blocks that come back from the driver
+            #  are paid for on first touch, 1.1 s for the pools of one sparse round)
+            # the flow of GL7d19 at its size (no dense image exists for this factor; the row-by-row kernels are left out: minutes)
             out["at_scale"] = sparse_path_probe(torch, spasm_amd, workloads, dev, name="mk15.b4", steps=2, paths=("default",), calls=2)
-            spasm_amd.release_cached_memory()
+            out["sparse_path"] = sparse_path_probe(torch, spasm_amd, workloads, dev)
             out["stand_ins"] = stand_in_runs(spasm_amd, workloads)
         out["configs"] = [{"name": c["name"], "status": status, "what": c["what"],
                            "bench": "python bench.py --workload %s" % c["name"],

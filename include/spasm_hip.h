@@ -28,7 +28,8 @@
  *   SPASM_HIP_SPARSE_IMAGE=0|1    never / always take the sparse image R = U_pp^-1 U_pn for a Schur complement (default: cost model)
  *   SPASM_HIP_BACKSOLVE=0|1       never / always take the dense image (default: cost model); both 0: row-by-row kernels
  *   SPASM_HIP_DEVICE_FINISH=0|1|2 dense / low-rank finish in the host loops / on the device / on the device only with the dense image
- *   SPASM_HIP_KEEP_GB=n           device memory the block cache keeps between calls (default: a quarter of the HBM; 0: none)
+ *   SPASM_HIP_KEEP_GB=n           device memory the block cache keeps between calls (default: a third of the HBM, at most 96 GB; 0: none;
+ *                                 a cached block that two driver calls in a row did not use goes back whatever the total)
  *   SPASM_HIP_SCRATCH_GB=n        accumulator slices of the row-by-row kernels (default: up to half of the free HBM)
  *   SPASM_HIP_STAGE_GB=n          staging buffer of the dense image's output (default 8)
  *   SPASM_HIP_SPARSE_IMAGE_GB=n   cap of the fragment pool of the sparse image (default: a third of the free HBM, at most half
@@ -126,7 +127,7 @@ int spasm_hip_device_count(void);
  * takes that many threads; a box of this pool reports 256 hardware threads and grants 16 CPUs) */
 int spasm_hip_usable_cpus(void);
 /* Between host-level calls the library parks device memory it would otherwise allocate again -- the accumulator scratch of
- * the row-by-row kernels, and the blocks of its buffer cache up to SPASM_HIP_KEEP_GB (default: a quarter of the device memory; 0 = none:
+ * the row-by-row kernels, and the blocks of its buffer cache up to SPASM_HIP_KEEP_GB (default: a third of the device memory, and nothing that two calls in a row did not use; 0 = none:
  * multi-GB blocks take 0.1 to 1 s apiece to free and allocate again, erratically).  This gives all of it back. */
 void spasm_hip_release_cached_memory(void);
 const char *spasm_hip_version(void);

@@ -237,6 +237,7 @@ struct DeviceMatrix {
 void *big_alloc(size_t bytes);
 void big_free(void *ptr);
 void big_trim(size_t keep_bytes = 0);
+void big_age(int max_idle);          // cached blocks unused through more than max_idle driver calls go back to the device
 hipError_t malloc_or_trim(void **ptr, size_t bytes);          // hipMalloc; on failure the cache is emptied and it is tried again
 void mem_info(size_t *free_b, size_t *total_b);                // hipMemGetInfo + what the cache parks (given back on demand)
 void resident_begin();

@@ -88,6 +88,7 @@ struct BigPool {
 	std::vector<std::pair<void *, size_t>> free_blocks;          // cached, not in use
 	std::vector<std::pair<void *, size_t>> live;                 // handed out by big_alloc
 	size_t cached = 0;
+	std::unordered_map<void *, int> idle;                        // driver calls a cached block has sat through unused (big_age)
 	// small blocks (< BIG_MIN), rounded up to a power of two: free lists per size class, and who is out
 	std::vector<void *> small_free[32];
 	std::unordered_map<void *, int> small_live;
@@ -127,6 +128,7 @@ void *big_alloc(size_t bytes)
 			const auto blk = g_big.free_blocks[(size_t) best];
 			g_big.free_blocks.erase(g_big.free_blocks.begin() + best);
 			g_big.cached -= blk.second;
+			g_big.idle.erase(blk.first);
 			g_big.live.push_back(blk);
 			return blk.first;
 		}
@@ -240,6 +242,36 @@ void big_trim(size_t keep_bytes)
 			g_big.cached = kept;
 		}
 	}
+	{
+		std::lock_guard<std::mutex> guard(g_big.mutex);
+		for (auto &b : blocks)
+			g_big.idle.erase(b.first);
+	}
+	for (auto &b : blocks)
+		(void) hipFree(b.first);
+}
+
+// End of a driver call: a cached block that nobody took during the last `max_idle` calls goes back to the device (the working
+// set of a process that calls the driver again and again stays -- mk15.b4 parks 80 GB: row pools, the Schur complement, 22 GB of
+// accumulators of the low-rank finish, the FIFOs of the pivot search --, what a one-off large call left behind does not).
+void big_age(int max_idle)
+{
+	std::vector<std::pair<void *, size_t>> blocks;
+	{
+		std::lock_guard<std::mutex> guard(g_big.mutex);
+		std::vector<std::pair<void *, size_t>> stay;
+		for (auto &b : g_big.free_blocks) {
+			const int age = ++g_big.idle[b.first];
+			if (age > max_idle) {
+				blocks.push_back(b);
+				g_big.cached -= b.second;
+				g_big.idle.erase(b.first);
+			} else {
+				stay.push_back(b);
+			}
+		}
+		g_big.free_blocks.swap(stay);
+	}
 	for (auto &b : blocks)
 		(void) hipFree(b.first);
 }
@@ -337,12 +369,14 @@ void resident_end()
 	// is erratic on these boxes -- 0.1 to 1 s apiece, now and then -- and made five of eight consecutive mk14.b4 calls take
 	// 1.0-2.3 s instead of 0.55 (keeping 32 or 64 GB did not help: whatever is handed back comes back slowly).
 	// spasm_hip_release_cached_memory() gives everything back; a failed hipMalloc of the library's own does too (big_alloc).
-	if (env_int("SPASM_HIP_KEEP_BLOCKS", 0) == 0)
-		{
-		// (default: a quarter of the device memory, at most the cap of the cache)
+	if (env_int("SPASM_HIP_KEEP_BLOCKS", 0) == 0) {
+		// (default: a third of the device memory, at most the cap of the cache -- a quarter, 72 GB here, was tried in round 4 and is
+		//  less than one mk15.b4 call parks: every call then gave 10-20 GB back and paid 1-2 s to get them again, in whichever
+		//  stage asked first --; and whatever sat unused through two calls in a row goes back whatever the total)
 		size_t free_b = 0, total_b = 0;
 		HIP_CHECK(hipMemGetInfo(&free_b, &total_b));
-		const int dflt = (int) std::min<size_t>(96, (total_b >> 30) / 4);
+		const int dflt = (int) std::min<size_t>(96, (total_b >> 30) / 3);
+		big_age(env_int("SPASM_HIP_KEEP_CALLS", 2));
 		big_trim((size_t) std::max(0, env_int("SPASM_HIP_KEEP_GB", dflt)) << 30);
 	}
 }
