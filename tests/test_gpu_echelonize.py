@@ -211,3 +211,36 @@ def test_device_finish_on_random_matrices(oracle, shape, p):
         F = spasm_amd.echelonize(_as_product(A), o)
         assert F.U.n == want
         _check_echelon(oracle, A, F)
+
+
+def test_cached_device_blocks_age_out_and_can_be_released(oracle):
+    """The library parks large device blocks between driver calls (fresh ones are paid for on first touch).  What two driver
+    calls in a row did not use goes back to the device (big_age, round 4), and spasm_hip_release_cached_memory() gives
+    everything back: after a call on a large matrix, three calls on a small one leave less of the device taken than the large
+    call did, and a release leaves (almost) nothing."""
+    import torch
+    import sys
+    import os
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools"))
+    import workloads
+    p = 42013
+    spasm_amd.release_cached_memory()
+    torch.cuda.synchronize()
+    free0 = torch.cuda.mem_get_info()[0]
+    big, _ = workloads.load_matrix("ch7-8.b5", p)
+    o = spasm_amd.default_opts()
+    o.sparsity_threshold = 0.01
+    assert spasm_amd.echelonize(big, o).U.n == 92959
+    torch.cuda.synchronize()
+    taken_big = free0 - torch.cuda.mem_get_info()[0]
+    assert taken_big > (1 << 30)                          # (the blocks of that call are parked: gigabytes)
+    A = oracle.load_sms(matrix_path("mat364.sms"), p)
+    small = spasm_amd.Csr(A.n, A.m, A.p, A.j, A.x, A.prime)
+    for _ in range(4):
+        spasm_amd.echelonize(small)
+    torch.cuda.synchronize()
+    taken_later = free0 - torch.cuda.mem_get_info()[0]
+    assert taken_later < taken_big // 2, (taken_big, taken_later)
+    spasm_amd.release_cached_memory()
+    torch.cuda.synchronize()
+    assert free0 - torch.cuda.mem_get_info()[0] < (1 << 30)
