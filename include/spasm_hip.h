@@ -229,6 +229,13 @@ struct spasm_csr *spasm_hip_kernel(const struct spasm_lu *fact);
  * (D) device-resident entry points
  * ====================================================================== */
 
+/* Streams.  Every entry point below enqueues its work on the stream it is given and may return before it is done (the
+ * ones that return a count -- ranks, sizes -- synchronise that stream first).  The objects (spasm_hip_dfact,
+ * spasm_hip_dwork) and their buffers come from a cache of device blocks that is NOT stream-aware: destroying an object
+ * while work that uses it is still queued, or using one object from two streams without an event between them, hands a
+ * block that is still being written to the next allocation.  One stream per object, synchronised before
+ * spasm_hip_d*_destroy: that is the contract (the host-level entry points use the null stream throughout). */
+
 /* A CSR matrix whose arrays live in HBM.  Same layout and value convention
  * (balanced int32) as struct spasm_csr: p has n+1 int64, j/x have p[n] int32. */
 typedef struct {
