@@ -207,11 +207,13 @@ def _calls(fn, count):
         runs.append((time.perf_counter() - t0, prof, rank))
     secs = [r[0] for r in runs]
     med = sorted(runs, key=lambda r: r[0])[len(runs) // 2]
+    stages = ("pivot_search", "density_estimates", "sparse_schur", "dense_finish")
     return {"rank": med[2], "ranks_agree": len({r[2] for r in runs}) == 1, "seconds_first_call": secs[0],
-            "seconds_median": statistics.median(secs), "seconds_min": min(secs), "seconds_all": secs, "split_of_median_call": med[1]}
+            "seconds_median": statistics.median(secs), "seconds_min": min(secs), "seconds_all": secs, "split_of_median_call": med[1],
+            "stages_of_every_call": [{k: round(r[1].get(k, 0.0), 3) for k in stages} for r in runs]}
 
 
-def sparse_path_probe(torch, spasm_amd, workloads, dev, name="mk14.b4", steps=3, paths=("default", "dense image", "row by row"), calls=3):
+def sparse_path_probe(torch, spasm_amd, workloads, dev, name="mk14.b4", steps=3, paths=("default", "dense image", "row by row"), calls=5):
     """The flow GL7d19 takes (a sparse round on a wide Schur complement, then the dense tail), on a matrix of the same
     collection that can be generated offline -- a STAND-IN, not a BASELINE config: mk14.b4 (945,945 x 315,315; its first
     Schur complement is 673,000 x 42,000, ~2 % dense, 5-7e8 entries depending on the pivots of the run) or, at the size of
@@ -662,9 +664,10 @@ def main():
             # (the largest object first: what the three paths of mk14.b4 park in the cache of device blocks -- 23 GB of dense R, 24 GB
             #  of accumulator scratch -- had to be given back to the device in the middle of the first mk15.b4 call of one run,
             #  2.6 s instead of 0.9-1.2; emptying the cache between the objects is worse: blocks that come back from the driver
-            #  are paid for on first touch, 1.1 s for the pools of one sparse round)
+            #  are paid for on first touch, 1.1 s for the pools of one sparse round.  Single calls still take 1-2 s longer now and
+            #  then, in whichever stage asks for a large block first -- five calls per object, so that the median does not hang on one)
             # the flow of GL7d19 at its size (no dense image exists for this factor; the row-by-row kernels are left out: minutes)
-            out["at_scale"] = sparse_path_probe(torch, spasm_amd, workloads, dev, name="mk15.b4", steps=2, paths=("default",), calls=2)
+            out["at_scale"] = sparse_path_probe(torch, spasm_amd, workloads, dev, name="mk15.b4", steps=2, paths=("default",), calls=5)
             out["sparse_path"] = sparse_path_probe(torch, spasm_amd, workloads, dev)
             out["stand_ins"] = stand_in_runs(spasm_amd, workloads)
         out["configs"] = [{"name": c["name"], "status": status, "what": c["what"],
