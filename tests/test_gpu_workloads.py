@@ -37,8 +37,9 @@ EXTRA = ["mk13.b4", "ch7-8.b5"]
 NAMES = [c["name"] for c in workloads.CONFIGS] + EXTRA
 # mk13.b4: the CPU oracle's single-thread orc_echelonize (243 s, round 1).  mk13.b5: every path combination of this
 # library agrees on 134211; the CPU oracle had not finished it within the round.
-# ch7-8.b5 / ch8-8.b5: 92959 is the published rank of ch7-8.b5 (hpac table); both are what every flow of this library
-# returns (device finish, host loops).  mk14.b4: see test_multi_round_stand_in.
+# ch7-8.b5 / ch8-8.b5: 92959 is the published rank of ch7-8.b5 (hpac table); 276031 was recomputed on the CPU with the compiled
+# reference and numpy (tools/cpu_rank_check_projected.py: 271,552 structural pivots + 4,479, profiles/r04_cpu_rank_check_ch8-8.b5.log).
+# mk14.b4: 272,862 + 321 by tools/cpu_rank_check.py (profiles/r04_cpu_rank_check_mk14.b4.log).
 # mk15.b4 (2,837,835 x 675,675, 14.2 M entries: the at-scale stand-in) and mk14.b5 (945,945 x 945,945): what every flow of this
 # library returns, equal to the rank of the transpose -- no independent value exists.
 RANKS = {"mk13.b5": 134211, "mk13.b4": 111463, "ch7-8.b5": 92959, "ch8-8.b5": 276031, "mk14.b4": 273183, "mk15.b4": 604591,

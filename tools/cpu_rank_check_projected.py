@@ -4,9 +4,11 @@ tools/cpu_rank_check.py (ch8-8.b5: 292,000 rows x 104,000 columns of rank ~4,350
 take days).  None of this repository's elimination code: structural pivots and dense rows of the Schur complement come from
 the COMPILED REFERENCE (oracle/_ref: spasm_pivots_extract_structural, spasm_schur_dense); the rows are then folded into
 Z = H S mod p with a random c x n matrix H (c = 8,192 > rank), block by block (float64 products of residues < 2^16 summed over
-2,048 terms stay below 2^53), and Z is eliminated exactly (blocked Gauss-Jordan, same bound).  rowspace(Z) is inside
-rowspace(S), so pivots + rank(Z) is a PROVEN lower bound of the rank; it is the rank itself unless H is unlucky
-(probability ~ 1/p per missing dimension).   python tools/cpu_rank_check_projected.py ch8-8.b5 [c]"""
+2,048 terms stay below 2^53), Z is projected once more on the column side (W = Z G, 8,192 x 5,120) and W is eliminated
+exactly (blocked, same bound).  rowspace(Z) is inside rowspace(S) and rank(Z G) <= rank(Z), so pivots + rank(W) is a PROVEN
+lower bound of the rank; it is the rank itself unless H or G is unlucky (probability ~ 1/p per missing dimension).
+Six hours on eight cores for ch8-8.b5, nearly all of it in the reference's spasm_schur_dense.
+python tools/cpu_rank_check_projected.py ch8-8.b5 [rows of H] [columns of G]"""
 import os
 import sys
 import time
@@ -53,28 +55,46 @@ for lo in range(0, len(rows), BLOCK):
         print("  rows %d / %d folded (%.0f s)" % (lo + len(sub), len(rows), time.time() - t0), flush=True)
 print("folded %d rows into %d combinations, %d per row (%.0f s); eliminating" % (len(rows), c, FOLD, time.time() - t0), flush=True)
 
-# exact blocked elimination of Z: panels of 256 columns, the rows below and the columns to the right updated by ONE product
-# of rank <= 256 per panel (entries below p, 256 terms: far below 2^53)
+np.save(os.environ.get("RANK_CHECK_Z", "/tmp/rank_check_Z_%s.npy" % name), Z)          # (six hours of folding on ch8-8.b5: kept)
+
+# Second projection, on the column side: W = Z G with G a random Sm x w matrix (w = 5,120 > rank): rank(W) <= rank(Z) always,
+# equal unless G is unlucky.  An exact elimination of the 8,192 x 104,768 matrix Z itself in numpy takes 160 s per panel of 256
+# columns (409 panels: the first version of this script); W is 8,192 x 5,120.
+w = int(sys.argv[3]) if len(sys.argv) > 3 else 5120
+t0 = time.time()
+W = np.zeros((c, w), np.float64)
+CH = 2048                                   # 2,048 products of residues: below 2^53
+for k0 in range(0, Sm, CH):
+    k1 = min(Sm, k0 + CH)
+    G = rng.integers(0, p, size=(k1 - k0, w)).astype(np.float64)
+    W = np.mod(W + np.mod(Z[:, k0:k1] @ G, p), p)
+print("projected onto %d random combinations of the columns (%.0f s)" % (w, time.time() - t0), flush=True)
+
+# exact blocked elimination of W: panels of 128 columns, the rows below and the columns to the right updated by ONE product
+# of rank <= 128 per panel (entries below p, 128 terms: far below 2^53)
+Z = W
+Sm = w
 t0 = time.time()
 rank = 0
 row = 0                                   # rows [0, row) are finished pivot rows (not kept reduced: only the rank is asked for)
-PANEL = 256
+PANEL = 128
 for j0 in range(0, Sm, PANEL):
     j1 = min(Sm, j0 + PANEL)
+    if row >= Z.shape[0]:
+        break
     P = Z[row:, j0:j1].copy()
     if not P.any():
         continue
     k = P.shape[0]
-    # Gaussian elimination of the panel by rows; the pivot rows are swapped to the top of the remaining rows
     perm = np.arange(k)
     piv_cols = []
-    npiv_here = 0
+    npv = 0
     for j in range(j1 - j0):
-        cand = np.flatnonzero(P[npiv_here:, j])
+        cand = np.flatnonzero(P[npv:, j])
         if cand.size == 0:
             continue
-        r = int(cand[0]) + npiv_here
-        t = npiv_here
+        r = int(cand[0]) + npv
+        t = npv
         if r != t:
             P[[t, r]] = P[[r, t]]
             perm[[t, r]] = perm[[r, t]]
@@ -85,45 +105,34 @@ for j0 in range(0, Sm, PANEL):
         if nz.size:
             P[t + 1 + nz] = np.mod(P[t + 1 + nz] - np.outer(f[nz], P[t]), p)
         piv_cols.append(j)
-        npiv_here += 1
-    if npiv_here == 0:
+        npv += 1
+    if npv == 0:
         continue
-    # the same row operations on the columns to the right.  With Q = the rows in their new order, the pivot rows are
-    # W = L^-1 Q[:np] (unit-lower-triangular system solved through the panel itself) and every other row loses its multiples of
-    # them; both from the ORIGINAL panel: M = multipliers such that P_below_original = M @ (pivot rows of the panel)
-    Zr = Z[row:][perm]                        # (a copy, rows in the new order)
-    orig = Zr[:, j0:j1]
-    # pivot rows of the panel in echelon form (unit pivots): E (np x 256); solve X E[:, piv_cols] = orig[:, piv_cols] for the
-    # multipliers X of every row (triangular: E[:, piv_cols] is unit upper triangular)
-    E = P[:npiv_here]
-    U = E[:, piv_cols]                        # np x np, unit upper triangular
-    B = orig[:, piv_cols].copy()              # k x np
+    # the same row operations on the columns to the right: with the rows in their new order, orig[:, piv_cols] = X U (U unit upper
+    # triangular: the pivot rows of the panel in echelon form) gives the multipliers X of every row; the pivot rows are
+    # Xp^-1 (old pivot rows), every other row loses X[row] times them
+    Zr = Z[row:][perm]
+    U = P[:npv][:, piv_cols]
+    B = Zr[:, j0:j1][:, piv_cols].copy()
     X = np.zeros_like(B)
-    for t in range(npiv_here):                # forward substitution column by column (np <= 256 steps of a k-vector update)
+    for t in range(npv):
         X[:, t] = B[:, t]
-        if t + 1 < npiv_here:
+        if t + 1 < npv:
             B[:, t + 1:] = np.mod(B[:, t + 1:] - np.outer(X[:, t], U[t, t + 1:]), p)
-    # rows: new pivot rows = X[:np] relates original pivot rows to echelon rows: orig[:np] = X[:np] @ E  ->  E = X[:np]^-1 orig[:np]
-    # apply to the right part: ER = X[:np]^-1 @ Zr[:np, right]; then rows below: Zr[np:, right] -= X[np:] @ ER
-    Xp = X[:npiv_here]                        # np x np, lower triangular with non-zero diagonal
-    for c0 in range(j1, Sm, 8192):
-        R = Zr[:, c0:c0 + 8192]
-        ER = R[:npiv_here].copy()
-        for t in range(npiv_here):            # forward substitution with the lower-triangular Xp
-            inv = pow(int(Xp[t, t]), p - 2, p)
-            ER[t] = np.mod(ER[t] * inv, p)
-            if t + 1 < npiv_here:
-                ER[t + 1:] = np.mod(ER[t + 1:] - np.outer(Xp[t + 1:, t], ER[t]), p)
-        R[:npiv_here] = ER
-        R[npiv_here:] = np.mod(R[npiv_here:] - np.mod(X[npiv_here:] @ ER, p), p)
-        Zr[:, c0:c0 + 8192] = R
+    Xp = X[:npv]
+    R = Zr[:, j1:]
+    ER = R[:npv].copy()
+    for t in range(npv):
+        inv = pow(int(Xp[t, t]), p - 2, p)
+        ER[t] = np.mod(ER[t] * inv, p)
+        if t + 1 < npv:
+            ER[t + 1:] = np.mod(ER[t + 1:] - np.outer(Xp[t + 1:, t], ER[t]), p)
+    R[:npv] = ER
+    R[npv:] = np.mod(R[npv:] - np.mod(X[npv:] @ ER, p), p)
+    Zr[:, j1:] = R
     Zr[:, j0:j1] = P
     Z[row:] = Zr
-    row += npiv_here
-    rank += npiv_here
-    if (j0 // PANEL) % 16 == 0:
-        print("  columns %d / %d: rank so far %d (%.0f s)" % (j1, Sm, rank, time.time() - t0), flush=True)
-    if row >= Z.shape[0]:
-        break
-print("%s: rank >= %d pivots + %d = %d (equal unless the random combinations are unlucky; c = %d%s) (%.0f s)" %
-      (name, npiv, rank, npiv + rank, c, "" if rank < c else ": c is NOT above the rank, raise it", time.time() - t0), flush=True)
+    row += npv
+    rank += npv
+print("%s: rank >= %d pivots + %d = %d (equal unless the random combinations are unlucky; %d combinations of the rows, %d of the columns%s) (%.0f s)" %
+      (name, npiv, rank, npiv + rank, c, w, "" if rank < min(c, w) else ": NOT above the rank, raise them", time.time() - t0), flush=True)
