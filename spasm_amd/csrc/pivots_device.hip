@@ -183,7 +183,7 @@ constexpr int PS_RING = 512;          // the last entries of a search's FIFO, mi
 // candidate columns of the row (one per lane) in LDS.
 template <bool GB, int REC_ENTS, int REC_BITS>
 __global__ __launch_bounds__(64) void pivot_search_kernel(const i64 *Ap, const int *Aj, const int *pinv, int n, int m, int words, u64 *rec, u64 *jent, int *jrow,
-                                                          PsCtrl *ctrl, int *fifo_all, int fifo_cap, int jcap, uint32_t *gbits, int list_cap, i64 annz)
+                                                          PsCtrl *ctrl, int *fifo_all, int fifo_cap, int jcap, uint32_t *gbits, int list_cap, i64 annz, const int *rowlist)
 {
 	extern __shared__ __attribute__((aligned(16))) uint32_t ps_lds[];
 	uint32_t *bits = GB ? gbits + (size_t) blockIdx.x * (size_t) (words + 64) : ps_lds;
@@ -217,7 +217,9 @@ __global__ __launch_bounds__(64) void pivot_search_kernel(const i64 *Ap, const i
 		first = __shfl(first, 0);
 		if (first >= n || dead)
 			break;
-		for (int i = first; i < min(n, first + PS_ROWS_PER_GRAB) && !dead; i++) {
+		for (int i0 = first; i0 < min(n, first + PS_ROWS_PER_GRAB) && !dead; i0++) {
+			// (n counts the entries of the row list when there is one: the second pass of the labelled search below)
+			const int i = (rowlist != nullptr) ? rowlist[i0] : i0;
 			if (pinv[i] >= 0)
 				continue;
 			if (ld_i32(&ctrl->status) != 0) {
@@ -660,6 +662,618 @@ __global__ __launch_bounds__(64) void pivot_search_kernel(const i64 *Ap, const i
 	}
 }
 
+
+// ------------------------------------------------------------------------------------------------------------------------------
+// Round 5: the search with DEPTH LABELS -- fewer visits, not cheaper ones.
+//
+// Every column e carries a label D[e] (30 bits) and a state (2 bits: leaf / claimed / pivotal) in ONE 32-bit word, and the
+// labels keep, at every instant, the invariant
+//     (I)   for every pivotal column c and every other entry e of its pivot row:   D[e] > D[c].
+// Labels only ever grow.  (I) makes the pivot graph acyclic by itself -- labels strictly increase along every edge -- and it
+// answers most reachability questions of the greedy search (spasm_pivots.c:147-305) without a walk:
+//   * column j can only be reached from pivotal column c when D[j] > D[c]: a candidate j of row i whose label does not exceed
+//     the label of any pivotal entry of the row is unreachable -- accepted without visiting anything ("free");
+//   * otherwise the walk only expands pivot rows whose label is below the largest label of a candidate that is still
+//     unreached: everything else cannot lead to one (mk14.b4: 1.04e9 visited pivot rows -> 2.3e7; mk15.b4: 5.9e9 -> 7.3e7 in
+//     the sequential simulation of this scheme).
+// A pivot (i, j) is ADDED by restoring (I) for its row first: every entry of row i -- and, transitively, whatever hangs below
+// it -- is raised above D[j] (the "cascade": a breadth-first list of (column, new label) items, children = parent + 1, built
+// without touching anything and then applied from the largest value down, so that a column is never raised before the columns
+// its row holds: (I) holds between any two stores); meeting j itself on the way means j IS reachable (a pivot published
+// meanwhile, or a pruned walk that was wrong about stale labels): nothing was written, the candidate is dropped.  Then ONE
+// compare-and-swap on j's word -- same label, leaf -> claimed -- decides: it fails when anybody raised j or took it meanwhile
+// (the row is searched again), and when it succeeds (I) holds for the new row at that instant.  The record of the row is
+// written, drained, and the state becomes pivotal.  Nobody relies on anybody's marks: what the walk believes only decides
+// which cascades are attempted, never whether the pivot set is cycle-free -- that is (I), kept by single-word atomics.
+// A leaf is raised by compare-and-swap on (label, leaf): a raise can never slip past the moment a column becomes pivotal;
+// a raiser that finds its leaf pivotal gives up its attempt (what it raised so far is harmless: labels may be too large,
+// never too small) and searches the row again.
+// Cascades are mostly tiny (half of the accepted pivots need none beyond the leaves of their row) but heavy-tailed (3.5e6
+// items in the sequential simulation of mk15.b4): a row whose candidate sits more than `gap_max` above its lowest pivotal
+// entry, or whose cascade outgrows `casc_cap` items, is DEFERRED -- a second pass gives the deferred rows (a percent of the
+// rows that end with a pivot) to the ticket search above, against the pivots of this pass.
+struct PlCtrl {
+	int next_row, status, ndeferred, pad;
+	u64 visits, visits_won, rows_won, rows_lost, steps;
+	u64 free_accepts, walk_accepts, casc_items, casc_steps, casc_wasted;
+	u64 deferred_gap, deferred_cap, deferred_retry, restarts, cycles;
+	u64 t_start, t_first_exit, t_last_exit, longest_search;
+};
+
+constexpr int PL_HASH = 1024;                  // pending values of a cascade (direct-mapped, lossy: a miss costs a duplicate item)
+constexpr uint32_t PL_CLAIMED = 1u, PL_PIVOTAL = 3u;
+constexpr int PL_EXPANDED = 1 << 30, PL_NOOP = 1 << 29, PL_VALUE = (1 << 29) - 1;
+constexpr int PL_MAX_LABEL = (1 << 29) - (1 << 21);          // (room above for the values of a cascade: casc_cap <= 2^20 items)
+
+__device__ __forceinline__ uint32_t ld_u32(const uint32_t *p) { return __hip_atomic_load(p, RLX_AGENT); }
+__device__ __forceinline__ int wave_min(int v)
+{
+	for (int d = 32; d > 0; d >>= 1)
+		v = min(v, __shfl_xor(v, d));
+	return v;
+}
+__device__ __forceinline__ int wave_max(int v)
+{
+	for (int d = 32; d > 0; d >>= 1)
+		v = max(v, __shfl_xor(v, d));
+	return v;
+}
+
+// labels of the pivots the host found: state from qinv, then sweeps of D[e] = max(D[e], D[c] + 1) over the pivot rows until
+// nothing moves (the Faugere-Lachartre pivots of these matrices are 5-6 levels deep)
+__global__ __launch_bounds__(256) void pivot_labels_init_kernel(const int *qinv, int m, uint32_t *lab)
+{
+	const int col = blockIdx.x * 256 + threadIdx.x;
+	if (col < m)
+		lab[col] = (qinv[col] >= 0) ? PL_PIVOTAL : 0u;
+}
+
+__global__ __launch_bounds__(256) void pivot_labels_relax_kernel(const i64 *Ap, const int *Aj, const int *qinv, int m, uint32_t *lab, int *changed)
+{
+	const int col = blockIdx.x * 256 + threadIdx.x;
+	if (col >= m)
+		return;
+	const int row = qinv[col];
+	if (row < 0)
+		return;
+	const uint32_t need = (ld_u32(lab + col) >> 2) + 1u;
+	bool moved = false;
+	for (i64 px = Ap[row]; px < Ap[row + 1]; px++) {
+		const int e = Aj[px];
+		if (e == col)
+			continue;
+		const uint32_t word = (need << 2) | ((qinv[e] >= 0) ? PL_PIVOTAL : 0u);
+		if (ld_u32(lab + e) < word)
+			moved = atomicMax(lab + e, word) < word || moved;
+	}
+	if (moved)
+		*changed = 1;
+}
+
+template <bool GB, int REC_ENTS, int REC_BITS>
+__global__ __launch_bounds__(64) void pivot_label_search_kernel(const i64 *Ap, const int *Aj, int *pinv, int n, int m, int words, u64 *rec, uint32_t *lab, PlCtrl *ctrl,
+                                                                int *fifo_all, int fifo_cap, uint32_t *gbits, int *deferred, i64 annz, int gap_max, int casc_cap)
+{
+	extern __shared__ __attribute__((aligned(16))) uint32_t ps_lds[];
+	uint32_t *bits = GB ? gbits + (size_t) blockIdx.x * (size_t) (words + 64) : ps_lds;
+	int *cand = reinterpret_cast<int *>(ps_lds + (GB ? 0 : words));
+	int *clab = cand + 64;           // the labels of the candidates, as read when the row was
+	int *tmp = clab + 64;
+	int *ring = tmp + 8;             // the last PS_RING entries of the FIFO / of the cascade list (column ...
+	int *ringv = ring + PS_RING;     // ... and value)
+	int *hk = ringv + PS_RING;       // pending values of the cascade: column, value
+	int *hv = hk + PL_HASH;
+	const int lane = threadIdx.x;
+	auto bits_at = [&](int w) -> uint32_t {
+		if constexpr (GB)
+			return ld_u32(bits + w);
+		else
+			return bits[w];
+	};
+	const u64 below = (1ull << lane) - 1ull;
+	int *fifo = fifo_all + (size_t) blockIdx.x * fifo_cap;
+	u64 visits = 0, visits_won = 0, rows_won = 0, rows_lost = 0, steps = 0, longest = 0;
+	u64 free_accepts = 0, walk_accepts = 0, casc_items = 0, casc_steps = 0, casc_wasted = 0, deferred_gap = 0, deferred_cap = 0, deferred_retry = 0, restarts = 0, cycles = 0;
+	bool dead = false;
+	if (lane == 0)
+		atomicMin(&ctrl->t_start, wall_clock64());
+	if constexpr (!GB)
+		for (int w = lane * 4; w < words; w += 256)
+			*reinterpret_cast<uint4 *>(bits + w) = make_uint4(0, 0, 0, 0);
+
+	for (;;) {
+		int first = 0;
+		if (lane == 0)
+			first = atomicAdd(&ctrl->next_row, PS_ROWS_PER_GRAB);
+		first = __shfl(first, 0);
+		if (first >= n || dead)
+			break;
+		for (int i = first; i < min(n, first + PS_ROWS_PER_GRAB) && !dead; i++) {
+			if (pinv[i] >= 0)
+				continue;
+			if (ld_i32(&ctrl->status) != 0) {
+				dead = true;
+				break;
+			}
+			const u64 t_row = wall_clock64();
+			const u64 visits_before = visits;
+			const i64 row_lo = Ap[i], row_hi = Ap[i + 1];
+			int outcome = -1;          // 0: no pivot on this row, 1: pivot, 2: deferred to the second pass
+			bool was_free = false;
+			for (int attempt = 0; outcome < 0; attempt++) {
+				// (the reached-bits are all clear here)
+				int head = 0, tail = 0, ncand = 0;
+				bool overflow = false;
+				auto push = [&](bool pred, int j) {
+					const u64 mask = __ballot(pred);
+					if (mask == 0)
+						return;
+					const int pos = tail + __popcll(mask & below);
+					if (pred && pos < fifo_cap) {
+						fifo[pos] = j;
+						ring[pos & (PS_RING - 1)] = j;
+					}
+					tail += __popcll(mask);
+					if (tail > fifo_cap) {
+						tail = fifo_cap;
+						overflow = true;
+					}
+				};
+				auto reach = [&](bool valid, int j) {          // the column becomes reached; queued if it was not
+					bool fresh = false;
+					if (valid) {
+						const uint32_t bit = 1u << (j & 31);
+						fresh = (atomicOr(&bits[j >> 5], bit) & bit) == 0;
+					}
+					push(fresh, j);
+				};
+				// the entries of the row: pivotal (or being committed) ones start the walk, the others are candidates
+				int hi_lab = 0x7fffffff;
+				for (i64 px0 = row_lo; px0 < row_hi; px0 += 64) {
+					const bool valid = px0 + lane < row_hi;
+					const int j = valid ? Aj[px0 + lane] : 0;
+					const uint32_t w = valid ? ld_u32(lab + j) : 0u;
+					const bool piv = valid && (w & 3u) != 0;
+					if (piv)
+						hi_lab = min(hi_lab, (int) (w >> 2));
+					reach(piv, j);
+					const bool is_cand = valid && !piv;
+					const u64 mask = __ballot(is_cand);
+					const int pos = ncand + __popcll(mask & below);
+					if (is_cand && pos < 64) {
+						cand[pos] = j;
+						clab[pos] = (int) (w >> 2);
+					}
+					reach(is_cand && pos >= 64, j);          // (beyond 64 candidates: entries of the row, not eligible)
+					ncand = min(64, ncand + __popcll(mask));
+				}
+				hi_lab = wave_min(hi_lab);
+				auto alive = [&]() -> u64 {
+					bool a = false;
+					if (lane < ncand) {
+						const int j = cand[lane];
+						a = (bits_at(j >> 5) & (1u << (j & 31))) == 0;
+					}
+					return __ballot(a);
+				};
+				bool again = false;          // this attempt failed on somebody else's progress: search the row again
+				while (outcome < 0 && !again && !dead) {
+					u64 live = alive();
+					if (live == 0) {
+						outcome = 0;
+						break;
+					}
+					int mine = ((live >> lane) & 1) ? clab[lane] : 0x7fffffff;
+					int lmin = wave_min(mine);
+					int lmax = wave_max(((live >> lane) & 1) ? clab[lane] : -1);
+					was_free = lmin <= hi_lab;
+					// the walk, pruned: a pivot row at or above the largest label of a live candidate cannot lead to one
+					while (!was_free && head < tail && live != 0 && !overflow) {
+						if (tail + (REC_ENTS + 1) * 64 > fifo_cap) {
+							overflow = true;
+							break;
+						}
+						const int cnt = min(64, tail - head);
+						int c;
+						if (tail - head <= PS_RING) {
+							c = (lane < cnt) ? ring[(head + lane) & (PS_RING - 1)] : -1;
+						} else {
+							drain();
+							c = (lane < cnt) ? fifo[head + lane] : -1;
+						}
+						head += cnt;
+						u64 lo = 0, hi = 0;
+						uint32_t w = 0;
+						ld_rec_and_word(rec + (size_t) (c >= 0 ? c : 0) * REC_WORDS, lab + (c >= 0 ? c : 0), lo, hi, w);
+						bool open = c >= 0 && (w & 3u) == PL_PIVOTAL && (int) (w >> 2) < lmax;
+						// (the record is in memory before the state says pivotal; the two loads are not ordered: read it again)
+						for (unsigned spins = 0; __ballot(open && ((lo & 7ull) == 0 || ((lo & 7ull) == (u64) REC_LONG && hi == 0))) != 0; spins++) {
+							if (open && ((lo & 7ull) == 0 || ((lo & 7ull) == (u64) REC_LONG && hi == 0)))
+								ld_rec(rec + (size_t) c * REC_WORDS, lo, hi);
+							if (spins > 4096) {
+								dead = true;
+								break;
+							}
+						}
+						if (dead)
+							break;
+						const int len = open ? (int) (lo & 7ull) : 0;
+						const i64 long_off = (i64) (lo >> 3);
+						const int long_len = (int) min((u64) (1 << 30), hi);
+						visits += (u64) __popcll(__ballot(len != 0));
+						steps += 1;
+						int e[REC_ENTS];
+						uint32_t bit[REC_ENTS], old[REC_ENTS];
+						if constexpr (GB) {
+							uint32_t seen_word[REC_ENTS];
+#pragma unroll
+							for (int t = 0; t < REC_ENTS; t++) {
+								e[t] = rec_get<REC_BITS>(lo, hi, t);
+								const bool ok = len != 0 && len != REC_LONG && t < len && e[t] < m;
+								bit[t] = ok ? 1u << (e[t] & 31) : 0u;
+								seen_word[t] = ok ? bits_at(e[t] >> 5) : ~0u;
+							}
+#pragma unroll
+							for (int t = 0; t < REC_ENTS; t++) {
+								old[t] = ~0u;
+								if ((bit[t] & ~seen_word[t]) != 0)
+									old[t] = atomicOr(&bits[e[t] >> 5], bit[t]);
+							}
+						} else {
+#pragma unroll
+							for (int t = 0; t < REC_ENTS; t++) {
+								e[t] = rec_get<REC_BITS>(lo, hi, t);
+								const bool ok = len != 0 && len != REC_LONG && t < len && e[t] < m;
+								bit[t] = ok ? 1u << (e[t] & 31) : 0u;
+								old[t] = ~0u;
+								if (ok)
+									old[t] = atomicOr(&bits[e[t] >> 5], bit[t]);
+							}
+						}
+						int base = tail;
+#pragma unroll
+						for (int t = 0; t < REC_ENTS; t++) {
+							const bool fresh = (bit[t] & ~old[t]) != 0;
+							const u64 mask = __ballot(fresh);
+							if (fresh) {
+								const int pos = base + __popcll(mask & below);
+								fifo[pos] = e[t];
+								ring[pos & (PS_RING - 1)] = e[t];
+							}
+							base += __popcll(mask);
+						}
+						tail = base;
+						// rows too long for a record: the whole wave walks them, one after the other
+						for (u64 longs = __ballot(len == REC_LONG && long_off + long_len <= annz); longs != 0 && !overflow; longs &= longs - 1) {
+							const int l0 = __builtin_ctzll(longs);
+							const i64 lo0 = ((i64) __shfl((int) (long_off >> 32), l0) << 32) | (uint32_t) __shfl((int) (uint32_t) long_off, l0);
+							const i64 hi0 = lo0 + __shfl(long_len, l0);
+							for (i64 px0 = lo0; px0 < hi0 && !overflow; px0 += 64) {
+								const bool valid = px0 + lane < hi0;
+								reach(valid, valid ? Aj[px0 + lane] : 0);
+							}
+						}
+						const u64 now_live = alive();
+						if (now_live != live) {
+							live = now_live;
+							mine = ((live >> lane) & 1) ? clab[lane] : 0x7fffffff;
+							lmin = wave_min(mine);
+							lmax = wave_max(((live >> lane) & 1) ? clab[lane] : -1);
+						}
+					}
+					if (dead)
+						break;
+					if (overflow) {
+						outcome = 2;
+						deferred_cap += 1;
+						break;
+					}
+					if (live == 0) {
+						outcome = 0;
+						break;
+					}
+					// the live candidate with the smallest label: the least to raise
+					const int chosen_lane = __builtin_ctzll(__ballot(((live >> lane) & 1) && mine == lmin));
+					const int chosen = cand[chosen_lane], dj = lmin;
+					if ((hi_lab != 0x7fffffff && dj - hi_lab > gap_max) || dj >= PL_MAX_LABEL) {
+						outcome = 2;
+						deferred_gap += 1;
+						break;
+					}
+					// ---- the cascade: (column, value) items, breadth first; the list is sorted by value (children = parent + 1 and
+					//      a step only takes items of one value), kept behind the FIFO of the walk
+					for (int t = lane; t < PL_HASH; t += 64)
+						hk[t] = -1;
+					const int lbase = (tail + 63) & ~63;
+					const int lroom = min(casc_cap, (fifo_cap - lbase) / 2 - 64);
+					int lhead = 0, ltail = 0;
+					bool cyc = false, capped = lroom < 64;
+					auto lpush = [&](bool pred, int x, int v) {
+						const u64 mask = __ballot(pred);
+						if (mask == 0)
+							return;
+						const int pos = ltail + __popcll(mask & below);
+						if (pred && pos < lroom) {
+							fifo[lbase + 2 * pos] = x;
+							fifo[lbase + 2 * pos + 1] = v;
+							ring[pos & (PS_RING - 1)] = x;
+							ringv[pos & (PS_RING - 1)] = v;
+						}
+						ltail += __popcll(mask);
+						if (ltail > lroom) {
+							ltail = lroom;
+							capped = true;
+						}
+					};
+					// does (e, v) still have to be listed?  not when an item of e with at least that value is pending
+					auto want = [&](int e, int v) -> bool {
+						const int slot = (int) (((uint32_t) e * 2654435761u) >> 22);
+						if (hk[slot] == e && hv[slot] >= v)
+							return false;
+						hk[slot] = e;
+						hv[slot] = v;
+						return true;
+					};
+					for (i64 px0 = row_lo; px0 < row_hi && !capped; px0 += 64) {
+						const bool valid = px0 + lane < row_hi;
+						const int x = valid ? Aj[px0 + lane] : 0;
+						const uint32_t w = valid ? ld_u32(lab + x) : ~0u;
+						lpush(valid && x != chosen && (int) (w >> 2) <= dj, x, dj + 1);
+					}
+					while (lhead < ltail && !cyc && !capped && !dead) {
+						int cnt = min(64, ltail - lhead);
+						int x = -1, v = 0;
+						if (ltail - lhead <= PS_RING) {
+							if (lane < cnt) {
+								x = ring[(lhead + lane) & (PS_RING - 1)];
+								v = ringv[(lhead + lane) & (PS_RING - 1)];
+							}
+						} else {
+							drain();
+							if (lane < cnt) {
+								x = fifo[lbase + 2 * (lhead + lane)];
+								v = fifo[lbase + 2 * (lhead + lane) + 1];
+							}
+						}
+						const int v0 = __shfl(v, 0);
+						cnt = __popcll(__ballot(lane < cnt && v == v0));          // (a prefix: the list is sorted)
+						const bool active = lane < cnt;
+						const int my_index = lhead + lane;
+						lhead += cnt;
+						casc_steps += 1;
+						u64 lo = 0, hi = 0;
+						uint32_t w = 0;
+						ld_rec_and_word(rec + (size_t) (active ? x : 0) * REC_WORDS, lab + (active ? x : 0), lo, hi, w);
+						const bool pivotal = active && (w & 3u) == PL_PIVOTAL;
+						bool expand = pivotal && (int) (w >> 2) < v0;
+						if (pivotal)
+							fifo[lbase + 2 * my_index + 1] = v0 | (expand ? PL_EXPANDED : PL_NOOP);
+						// (a later item of the same column carries more: that one looks at the row)
+						if (expand) {
+							const int slot = (int) (((uint32_t) x * 2654435761u) >> 22);
+							if (hk[slot] == x && hv[slot] > v0)
+								expand = false;
+						}
+						for (unsigned spins = 0; __ballot(expand && ((lo & 7ull) == 0 || ((lo & 7ull) == (u64) REC_LONG && hi == 0))) != 0; spins++) {
+							if (expand && ((lo & 7ull) == 0 || ((lo & 7ull) == (u64) REC_LONG && hi == 0)))
+								ld_rec(rec + (size_t) x * REC_WORDS, lo, hi);
+							if (spins > 4096) {
+								dead = true;
+								break;
+							}
+						}
+						if (dead)
+							break;
+						const int len = expand ? (int) (lo & 7ull) : 0;
+						const i64 long_off = (i64) (lo >> 3);
+						const int long_len = (int) min((u64) (1 << 30), hi);
+						int e[REC_ENTS];
+						uint32_t ew[REC_ENTS];
+#pragma unroll
+						for (int t = 0; t < REC_ENTS; t++) {
+							e[t] = rec_get<REC_BITS>(lo, hi, t);
+							const bool ok = len != 0 && len != REC_LONG && t < len && e[t] < m;
+							ew[t] = ok ? ld_u32(lab + e[t]) : ~0u;
+						}
+#pragma unroll
+						for (int t = 0; t < REC_ENTS; t++) {
+							bool need = ew[t] != ~0u && (int) (ew[t] >> 2) <= v0;
+							cyc = cyc || __ballot(need && e[t] == chosen) != 0;
+							need = need && want(e[t], v0 + 1);
+							lpush(need, e[t], v0 + 1);
+						}
+						for (u64 longs = __ballot(len == REC_LONG && long_off + long_len <= annz); longs != 0 && !capped; longs &= longs - 1) {
+							const int l0 = __builtin_ctzll(longs);
+							const i64 lo0 = ((i64) __shfl((int) (long_off >> 32), l0) << 32) | (uint32_t) __shfl((int) (uint32_t) long_off, l0);
+							const i64 hi0 = lo0 + __shfl(long_len, l0);
+							const int self = __shfl(x, l0);
+							for (i64 px0 = lo0; px0 < hi0 && !capped; px0 += 64) {
+								const bool valid = px0 + lane < hi0;
+								const int ee = valid ? Aj[px0 + lane] : 0;
+								const uint32_t eww = (valid && ee != self) ? ld_u32(lab + ee) : ~0u;
+								bool need = eww != ~0u && (int) (eww >> 2) <= v0;
+								cyc = cyc || __ballot(need && ee == chosen) != 0;
+								need = need && want(ee, v0 + 1);
+								lpush(need, ee, v0 + 1);
+							}
+						}
+					}
+					if (dead)
+						break;
+					casc_items += (u64) ltail;
+					if (cyc) {
+						// the candidate IS reachable (through a pivot published meanwhile): nothing was written; it counts as reached
+						cycles += 1;
+						casc_wasted += (u64) ltail;
+						reach(lane == 0, chosen);
+						continue;
+					}
+					if (capped) {
+						casc_wasted += (u64) ltail;
+						outcome = 2;
+						deferred_cap += 1;
+						break;
+					}
+					// ---- applied from the largest value down: all items of one value, then -- once they are in memory -- the next
+					drain();
+					bool conflict = false;
+					for (int pos = ltail; pos > 0 && !conflict;) {
+						const int lo_idx = max(0, pos - 64);
+						const int k = lo_idx + lane;
+						const bool valid = k < pos;
+						const int x = valid ? fifo[lbase + 2 * k] : 0;
+						const int vv = valid ? fifo[lbase + 2 * k + 1] : 0;
+						const int vtop = __shfl(vv, pos - 1 - lo_idx) & PL_VALUE;
+						const u64 group = __ballot(valid && (vv & PL_VALUE) == vtop);          // (a suffix: the list is sorted)
+						const bool mine_now = (group >> lane) & 1;
+						bool bad = false;
+						if (mine_now && (vv & PL_NOOP) == 0) {
+							if (vv & PL_EXPANDED) {
+								atomicMax(lab + x, ((uint32_t) vtop << 2) | PL_PIVOTAL);
+							} else {
+								uint32_t w = ld_u32(lab + x);
+								for (unsigned spins = 0;;) {
+									const uint32_t st = w & 3u;
+									if (st == PL_PIVOTAL) {          // it got a row meanwhile, which must rise first: give up the attempt
+										bad = true;
+										break;
+									}
+									if (st == PL_CLAIMED) {
+										if (++spins > (1u << 20)) {
+											bad = true;
+											break;
+										}
+										w = ld_u32(lab + x);
+										continue;
+									}
+									if ((int) (w >> 2) >= vtop)
+										break;
+									const uint32_t old = atomicCAS(lab + x, w, (uint32_t) vtop << 2);
+									if (old == w)
+										break;
+									w = old;
+								}
+							}
+						}
+						drain();
+						conflict = __ballot(bad) != 0;
+						pos = lo_idx + __builtin_ctzll(group);
+					}
+					if (conflict) {
+						again = true;
+						break;
+					}
+					// ---- the commit: j's word from (dj, leaf) to (dj, claimed), or not at all
+					int ok = 0;
+					if (lane == 0)
+						ok = atomicCAS(lab + chosen, (uint32_t) dj << 2, ((uint32_t) dj << 2) | PL_CLAIMED) == ((uint32_t) dj << 2);
+					ok = __shfl(ok, 0);
+					if (!ok) {
+						again = true;
+						break;
+					}
+					{
+						const i64 others = row_hi - row_lo - 1;
+						u64 *R = rec + (size_t) chosen * REC_WORDS;
+						const u64 as_long = (u64) REC_LONG | ((u64) row_lo << 3), all_of_it = (u64) (row_hi - row_lo);
+						if (others > REC_ENTS || others <= 0) {
+							if (lane == 0) {
+								st_u64(R + 1, all_of_it);
+								drain();
+								st_u64(R, as_long);
+							}
+						} else {
+							const bool valid = row_lo + lane < row_hi;
+							const int j = valid ? Aj[row_lo + lane] : 0;
+							const bool other = valid && j != chosen;
+							const u64 mask = __ballot(other);
+							if (other)
+								tmp[__popcll(mask & below)] = j;
+							const int len = __popcll(mask);
+							if (lane == 0) {
+								u64 lo = 0, hi = 0;
+								for (int t = 0; t < len; t++)
+									rec_put<REC_BITS>(lo, hi, t, (u64) tmp[t]);
+								st_u64(R + 1, len > 0 ? hi : all_of_it);
+								drain();          // (second word first: a reader that sees the new first word sees all of the record)
+								st_u64(R, len > 0 ? (lo | (u64) len) : as_long);
+							}
+						}
+						if (lane == 0) {
+							drain();
+							atomicOr(lab + chosen, 2u);
+							st_i32(pinv + i, chosen);
+						}
+					}
+					outcome = 1;
+				}
+				// the marks of this attempt go: every marked column is in the FIFO
+				drain();
+				if (overflow || (!GB && tail > words / 2)) {
+					if constexpr (GB) {
+						for (int w = lane; w < words; w += 64)
+							bits[w] = 0;
+					} else {
+						for (int w = lane * 4; w < words; w += 256)
+							*reinterpret_cast<uint4 *>(bits + w) = make_uint4(0, 0, 0, 0);
+					}
+				} else {
+					for (int t = lane; t < tail; t += 64)
+						bits[fifo[t] >> 5] = 0;
+				}
+				drain();
+				if (dead)
+					break;
+				if (again) {
+					restarts += 1;
+					if (attempt >= 6) {
+						outcome = 2;
+						deferred_retry += 1;
+					}
+				}
+			}
+			if (dead)
+				break;
+			if (outcome == 1) {
+				rows_won += 1;
+				visits_won += visits - visits_before;
+				if (was_free)
+					free_accepts += 1;
+				else
+					walk_accepts += 1;
+			} else if (outcome == 0) {
+				rows_lost += 1;
+			} else if (lane == 0) {
+				deferred[atomicAdd(&ctrl->ndeferred, 1)] = i;
+			}
+			longest = max(longest, (u64) (wall_clock64() - t_row));
+		}
+	}
+	if (dead && lane == 0)
+		st_i32(&ctrl->status, 1);
+	if (lane == 0) {
+		const u64 now = wall_clock64();
+		atomicMin(&ctrl->t_first_exit, now);
+		atomicMax(&ctrl->t_last_exit, now);
+		atomicMax(&ctrl->longest_search, longest);
+		atomicAdd(&ctrl->visits, visits);
+		atomicAdd(&ctrl->visits_won, visits_won);
+		atomicAdd(&ctrl->rows_won, rows_won);
+		atomicAdd(&ctrl->rows_lost, rows_lost);
+		atomicAdd(&ctrl->steps, steps);
+		atomicAdd(&ctrl->free_accepts, free_accepts);
+		atomicAdd(&ctrl->walk_accepts, walk_accepts);
+		atomicAdd(&ctrl->casc_items, casc_items);
+		atomicAdd(&ctrl->casc_steps, casc_steps);
+		atomicAdd(&ctrl->casc_wasted, casc_wasted);
+		atomicAdd(&ctrl->deferred_gap, deferred_gap);
+		atomicAdd(&ctrl->deferred_cap, deferred_cap);
+		atomicAdd(&ctrl->deferred_retry, deferred_retry);
+		atomicAdd(&ctrl->restarts, restarts);
+		atomicAdd(&ctrl->cycles, cycles);
+	}
+}
+
 }  // namespace
 
 // The search on the device.  pinv / qinv: the pivots found so far (row -> column, column -> row, -1 = none), extended in
@@ -677,9 +1291,18 @@ int device_acyclic_greedy(const struct spasm_csr *A, int *pinv, int *qinv)
 		(void) hipGetLastError();
 		return -1;
 	}
+	if (n <= 0 || m <= 0 || m > (1 << 25))
+		return -1;
+	// the labelled search (round 5) first, the ticket search for the rows it defers; SPASM_HIP_PIVOT_LABELS=0: the ticket search alone
+	bool labels = env_int("SPASM_HIP_PIVOT_LABELS", 1) != 0;
+	const int gap_max = std::max(0, env_int("SPASM_HIP_PIVOT_GAP", 64));
+	const int casc_cap = std::max(64, std::min(1 << 20, env_int("SPASM_HIP_PIVOT_CASCADE", 8192)));
 	const int words = ((m + 31) / 32 + 255) / 256 * 256;          // (cleared 256 words at a time)
+	const size_t lds_labels_extra = (size_t) (64 + 64 + 8 + 2 * PS_RING + 2 * PL_HASH) * sizeof(int);
 	// the reached-bits in LDS when one bit per column fits 64 KB (and a column fits 20 bits), else in HBM
 	bool global_bits = (size_t) words * 4 + (64 + 8 + PS_LIST + 64 + PS_RING) * sizeof(int) > 64 * 1024 || m > (1 << 20);          // (room for the list, needed or not)
+	if (labels && (size_t) words * 4 + lds_labels_extra > 64 * 1024)
+		global_bits = true;
 	if (const char *e = sh::env_get("SPASM_HIP_PIVOT_BITS"))
 		global_bits = global_bits || std::strcmp(e, "global") == 0;
 	// rows with more than six other entries have no 16-byte record: their entries go through a list in LDS (if there are any)
@@ -688,116 +1311,234 @@ int device_acyclic_greedy(const struct spasm_csr *A, int *pinv, int *qinv)
 		if (A->p[i + 1] - A->p[i] > (global_bits ? 6 : 7))          // (the pivot and five or six others: what a record holds)
 			list_cap = PS_LIST;
 	const size_t lds = (global_bits ? (size_t) 0 : (size_t) words * 4) + (size_t) (64 + 8 + list_cap + 64 + PS_RING) * sizeof(int);
-	if (n <= 0 || m <= 0 || m > (1 << 25))
-		return -1;
+	const size_t lds_labels = (global_bits ? (size_t) 0 : (size_t) words * 4) + lds_labels_extra;
 	const double t0 = wtime();
 	hipStream_t stream = nullptr;
 	DeviceMatrix dA(A, stream);
 	int dev = 0, cus = 256;
 	HIP_CHECK(hipGetDevice(&dev));
 	HIP_CHECK(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev));
-	const int fifo_cap = m + 4096;
+	const int fifo_cap = m + 4096 + (labels ? 2 * casc_cap + 256 : 0);          // (the cascade list of the labelled search lies behind its FIFO)
 	// searches in flight per CU: 4 with the marks in LDS (the step is bound by instruction issue: more only adds speculation),
 	// 8 with the marks in HBM (bound by memory latency: mk14.b5 6.4 s at 2, 4.2 at 4, 3.4 at 8)
-	int per_cu = std::max(1, std::min(env_int("SPASM_HIP_PIVOT_WAVES_PER_CU", global_bits ? 8 : 4), (int) ((160 * 1024) / lds)));
+	const int per_cu_wanted = env_int("SPASM_HIP_PIVOT_WAVES_PER_CU", global_bits ? 8 : 4);
+	int per_cu = std::max(1, std::min(per_cu_wanted, (int) ((160 * 1024) / lds)));
+	int per_cu_labels = std::max(1, std::min(per_cu_wanted, (int) ((160 * 1024) / lds_labels)));
 	// (a search owns a FIFO of m + 4096 columns, and m / 8 bytes of marks with global_bits: at most 16 GB in all)
 	const size_t per_search = (size_t) fifo_cap * sizeof(int) + (global_bits ? ((size_t) words + 64) * sizeof(uint32_t) : 0);
 	while (per_cu > 1 && (size_t) cus * per_cu * per_search > ((size_t) 16 << 30))
 		per_cu -= 1;
-	const int grid = cus * per_cu;
+	per_cu_labels = std::min(per_cu_labels, std::max(per_cu, 1));
+	while (per_cu_labels > 1 && (size_t) cus * per_cu_labels * per_search > ((size_t) 16 << 30))
+		per_cu_labels -= 1;
+	const int grid = cus * per_cu, grid_labels = cus * per_cu_labels, grid_max = std::max(grid, grid_labels);
 	std::vector<void *> owned;
 	auto dal = [&](size_t bytes) {
 		void *ptr = big_alloc(bytes);
 		owned.push_back(ptr);
 		return ptr;
 	};
+	auto release = [&]() {
+		for (void *ptr : owned)
+			big_free(ptr);
+		owned.clear();
+	};
 	u64 *rec = (u64 *) dal((size_t) m * REC_WORDS * sizeof(u64));
 	int *d_pinv = (int *) dal((size_t) n * sizeof(int));
 	int *d_qinv = (int *) dal((size_t) m * sizeof(int));
-	const size_t jcap = (size_t) 8 * n + 65536;          // tickets: one per accepted pivot (<= n) and one per withdrawal
-	u64 *jent = (u64 *) dal(jcap * sizeof(u64));
-	int *jrow = (int *) dal(jcap * sizeof(int));
-	PsCtrl *ctrl = (PsCtrl *) dal(sizeof(PsCtrl));
-	int *fifo = (int *) dal((size_t) grid * fifo_cap * sizeof(int));
+	int *fifo = (int *) dal((size_t) grid_max * fifo_cap * sizeof(int));
 	uint32_t *gbits = nullptr;
 	if (global_bits) {
-		gbits = (uint32_t *) dal((size_t) grid * ((size_t) words + 64) * sizeof(uint32_t));
-		HIP_CHECK(hipMemsetAsync(gbits, 0, (size_t) grid * ((size_t) words + 64) * sizeof(uint32_t), stream));
+		gbits = (uint32_t *) dal((size_t) grid_max * ((size_t) words + 64) * sizeof(uint32_t));
+		HIP_CHECK(hipMemsetAsync(gbits, 0, (size_t) grid_max * ((size_t) words + 64) * sizeof(uint32_t), stream));
 	}
 	const double t_alloc = wtime();
 	HIP_CHECK(hipMemcpyAsync(d_pinv, pinv, (size_t) n * sizeof(int), hipMemcpyHostToDevice, stream));
 	HIP_CHECK(hipMemcpyAsync(d_qinv, qinv, (size_t) m * sizeof(int), hipMemcpyHostToDevice, stream));
-	HIP_CHECK(hipMemsetAsync(jent, 0, jcap * sizeof(u64), stream));
-	{
-		PsCtrl init;
-		std::memset(&init, 0, sizeof(init));
-		init.t_start = init.t_first_exit = ~0ull;
-		HIP_CHECK(hipMemcpyAsync(ctrl, &init, sizeof(PsCtrl), hipMemcpyHostToDevice, stream));
-		HIP_CHECK(hipStreamSynchronize(stream));
-	}
-	if (global_bits) {
+	if (global_bits)
 		hipLaunchKernelGGL((pivot_records_kernel<5, 25>), dim3((m + 255) / 256), dim3(256), 0, stream, dA.p, dA.j, d_qinv, m, rec);
-		hipLaunchKernelGGL((pivot_search_kernel<true, 5, 25>), dim3(grid), dim3(64), lds, stream, dA.p, dA.j, d_pinv, n, m, words, rec, jent, jrow, ctrl, fifo,
-		                   fifo_cap, (int) jcap, gbits, list_cap, (i64) A->p[n]);
-	} else {
+	else
 		hipLaunchKernelGGL((pivot_records_kernel<6, 20>), dim3((m + 255) / 256), dim3(256), 0, stream, dA.p, dA.j, d_qinv, m, rec);
-		hipLaunchKernelGGL((pivot_search_kernel<false, 6, 20>), dim3(grid), dim3(64), lds, stream, dA.p, dA.j, d_pinv, n, m, words, rec, jent, jrow, ctrl, fifo,
-		                   fifo_cap, (int) jcap, gbits, list_cap, (i64) A->p[n]);
-	}
 	HIP_CHECK(hipGetLastError());
-	PsCtrl c;
-	HIP_CHECK(hipMemcpyAsync(&c, ctrl, sizeof(PsCtrl), hipMemcpyDeviceToHost, stream));
-	HIP_CHECK(hipStreamSynchronize(stream));
-	const double t_run = wtime();
-	int found = -1;
-	if (c.status == 0) {
-		const int tickets = std::min(c.tickets, (int) jcap);
-		std::vector<u64> ent((size_t) std::max(tickets, 1));
-		std::vector<int> rows((size_t) std::max(tickets, 1));
-		if (tickets > 0) {
-			HIP_CHECK(hipMemcpy(ent.data(), jent, (size_t) tickets * sizeof(u64), hipMemcpyDeviceToHost));
-			HIP_CHECK(hipMemcpy(rows.data(), jrow, (size_t) tickets * sizeof(int), hipMemcpyDeviceToHost));
+	const bool stats = sh::env_get("SPASM_HIP_PIVOT_STATS") != nullptr;
+	int found = 0;
+
+	// ---- first pass: the labelled search
+	int *d_deferred = nullptr;
+	int ndeferred = 0;
+	double t_labels_init = 0.0, t_labels = 0.0;
+	std::vector<int> mine;          // the rows that got their pivot in the first pass
+	if (labels) {
+		const double ta = wtime();
+		uint32_t *lab = (uint32_t *) dal((size_t) m * sizeof(uint32_t));
+		d_deferred = (int *) dal((size_t) n * sizeof(int));
+		PlCtrl *pctrl = (PlCtrl *) dal(sizeof(PlCtrl) + 64);
+		int *d_changed = reinterpret_cast<int *>(reinterpret_cast<char *>(pctrl) + sizeof(PlCtrl));
+		hipLaunchKernelGGL(pivot_labels_init_kernel, dim3((m + 255) / 256), dim3(256), 0, stream, d_qinv, m, lab);
+		// (sweeps until nothing moves, looked at every fourth; the pivots of the Faugere-Lachartre steps are a few levels deep on
+		//  boundary matrices -- a matrix on which they are thousands deep goes to the ticket search alone)
+		int sweeps = 0;
+		for (bool moving = true; moving && labels;) {
+			HIP_CHECK(hipMemsetAsync(d_changed, 0, sizeof(int), stream));
+			for (int t = 0; t < 4; t++)
+				hipLaunchKernelGGL(pivot_labels_relax_kernel, dim3((m + 255) / 256), dim3(256), 0, stream, dA.p, dA.j, d_qinv, m, lab, d_changed);
+			sweeps += 4;
+			int changed = 0;
+			HIP_CHECK(hipMemcpyAsync(&changed, d_changed, sizeof(int), hipMemcpyDeviceToHost, stream));
+			HIP_CHECK(hipStreamSynchronize(stream));
+			moving = changed != 0;
+			if (moving && sweeps >= 8192)
+				labels = false;
 		}
-		found = 0;
-		for (int t = 0; t < tickets; t++) {
-			const u64 state = ent[t] >> 32;
-			const int col = (int) (uint32_t) ent[t];
-			if (state == PS_ABORTED)
-				continue;
-			if (state != PS_ACCEPTED || rows[t] < 0 || rows[t] >= n || col < 0 || col >= m || pinv[rows[t]] != -1 || qinv[col] != -1) {
-				// an inconsistent journal (a ticket left undecided, a row or a column taken twice): nothing of this search is
-				// kept -- the pivots applied so far are taken back and the host search runs (the caller sees -1)
-				std::fprintf(stderr, "[pivots] device search: ticket %d = (row %d, column %d, state %llu) is not a new pivot (a bug: please report); "
-				                     "the %d pivots of this search are discarded, searching on the host\n", t, rows[t], col, (unsigned long long) state, found);
-				for (int u = 0; u < t; u++) {
-					if ((ent[u] >> 32) != PS_ACCEPTED)
-						continue;
-					const int cu = (int) (uint32_t) ent[u];
-					if (rows[u] >= 0 && rows[u] < n && cu >= 0 && cu < m && pinv[rows[u]] == cu && qinv[cu] == rows[u]) {
-						pinv[rows[u]] = -1;
-						qinv[cu] = -1;
-					}
-				}
-				found = -1;
-				break;
+		t_labels_init = wtime() - ta;
+		if (labels) {
+			PlCtrl init;
+			std::memset(&init, 0, sizeof(init));
+			init.t_start = init.t_first_exit = ~0ull;
+			HIP_CHECK(hipMemcpyAsync(pctrl, &init, sizeof(PlCtrl), hipMemcpyHostToDevice, stream));
+			if (global_bits)
+				hipLaunchKernelGGL((pivot_label_search_kernel<true, 5, 25>), dim3(grid_labels), dim3(64), lds_labels, stream, dA.p, dA.j, d_pinv, n, m, words, rec, lab, pctrl,
+				                   fifo, fifo_cap, gbits, d_deferred, (i64) A->p[n], gap_max, casc_cap);
+			else
+				hipLaunchKernelGGL((pivot_label_search_kernel<false, 6, 20>), dim3(grid_labels), dim3(64), lds_labels, stream, dA.p, dA.j, d_pinv, n, m, words, rec, lab, pctrl,
+				                   fifo, fifo_cap, gbits, d_deferred, (i64) A->p[n], gap_max, casc_cap);
+			HIP_CHECK(hipGetLastError());
+			PlCtrl c;
+			HIP_CHECK(hipMemcpyAsync(&c, pctrl, sizeof(PlCtrl), hipMemcpyDeviceToHost, stream));
+			HIP_CHECK(hipStreamSynchronize(stream));
+			t_labels = wtime() - ta - t_labels_init;
+			if (c.status != 0) {
+				logmsg("[pivots] labelled device search gave up (a wait ran out): the host search takes over\n");
+				release();
+				return -1;
 			}
-			pinv[rows[t]] = col;
-			qinv[col] = rows[t];
-			found += 1;
+			// its pivots: the rows whose entry of pinv it filled
+			std::vector<int> got((size_t) n);
+			HIP_CHECK(hipMemcpy(got.data(), d_pinv, (size_t) n * sizeof(int), hipMemcpyDeviceToHost));
+			bool fine = true;
+			for (int i = 0; i < n && fine; i++) {
+				if (pinv[i] >= 0 || got[i] < 0)
+					continue;
+				const int col = got[i];
+				if (col >= m || qinv[col] != -1) {
+					std::fprintf(stderr, "[pivots] labelled device search: (row %d, column %d) is not a new pivot (a bug: please report); its pivots are discarded, searching on the host\n", i, col);
+					fine = false;
+					break;
+				}
+				pinv[i] = col;
+				qinv[col] = i;
+				mine.push_back(i);
+			}
+			if (!fine) {
+				for (int i : mine) {
+					qinv[pinv[i]] = -1;
+					pinv[i] = -1;
+				}
+				release();
+				return -1;
+			}
+			found = (int) mine.size();
+			ndeferred = c.ndeferred;
+			if (stats)
+				logmsg("[pivots] device, labelled search: %d searches in flight (%d per CU, %zu bytes of LDS each%s), %llu pivot rows visited in %llu steps (%llu of them on the %llu rows that ended with a pivot: "
+				       "%llu accepted on their labels alone, %llu after a walk; %llu rows without one), cascades: %llu items in %llu steps (%llu of them thrown away: %llu candidates found reachable, "
+				       "%llu attempts repeated), %d rows deferred (%llu label gap > %d, %llu cascade > %d items, %llu retries) [%.3fs: %.3f upload of A + allocations, %.3f initial labels (%d sweeps), %.3f search; "
+				       "first wave out of rows after %.1f ms, last one after %.1f ms, longest row %.1f ms]\n",
+				       grid_labels, per_cu_labels, lds_labels, global_bits ? "; reached-bits in HBM" : "", c.visits, c.steps, c.visits_won, c.rows_won, c.free_accepts, c.walk_accepts, c.rows_lost,
+				       c.casc_items, c.casc_steps, c.casc_wasted, c.cycles, c.restarts, ndeferred, c.deferred_gap, gap_max, c.deferred_cap, casc_cap, c.deferred_retry, wtime() - t0, t_alloc - t0,
+				       t_labels_init, sweeps, t_labels, 1e-5 * (double) (c.t_first_exit - c.t_start), 1e-5 * (double) (c.t_last_exit - c.t_start), 1e-5 * (double) c.longest_search);
 		}
-		if (found >= 0 && sh::env_get("SPASM_HIP_PIVOT_STATS"))
-			logmsg("[pivots] device: %d searches in flight (%d per CU, %zu bytes of LDS each%s), %llu pivot rows visited in %llu steps (%llu of them by the %llu searches that ended with a pivot, the rest by %llu that did not), %d tickets for %d pivots, "
-			       "%d rows given up (FIFO full) [%.3fs: %.3f upload of A + allocations, %.3f kernels, %.3f journal; in the search kernel the first wave "
-			       "ran out of rows after %.1f ms, the last one left after %.1f ms, the longest search of one row took %.1f ms; "
-			       "of the waves' time %.0f %% in the walk, %.0f %% in replays and tickets]\n", grid, per_cu, lds, global_bits ? "; reached-bits in HBM" : "", c.visits, c.steps, c.visits_won, c.rows_won, c.rows_lost,
-			       c.tickets, found, c.overflowed, wtime() - t0, t_alloc - t0, t_run - t_alloc, wtime() - t_run, 1e-5 * (double) (c.t_first_exit - c.t_start),
-			       1e-5 * (double) (c.t_last_exit - c.t_start), 1e-5 * (double) c.longest_search, 100.0 * (double) c.c_search / (double) std::max<u64>(c.c_total, 1),
-			       100.0 * (double) c.c_commit / (double) std::max<u64>(c.c_total, 1));
-	} else {
-		logmsg("[pivots] device search gave up (a wait ran out): the host search takes over\n");
 	}
-	for (void *ptr : owned)
-		big_free(ptr);
+
+	// ---- the ticket search: on the rows the first pass deferred, or on all of them
+	if (!labels || ndeferred > 0) {
+		const double tb = wtime();
+		const int nrows = labels ? ndeferred : n;
+		const int *rowlist = labels ? d_deferred : nullptr;
+		const size_t jcap = (size_t) 8 * nrows + 65536;          // tickets: one per accepted pivot (<= n) and one per withdrawal
+		u64 *jent = (u64 *) dal(jcap * sizeof(u64));
+		int *jrow = (int *) dal(jcap * sizeof(int));
+		PsCtrl *ctrl = (PsCtrl *) dal(sizeof(PsCtrl));
+		HIP_CHECK(hipMemsetAsync(jent, 0, jcap * sizeof(u64), stream));
+		{
+			PsCtrl init;
+			std::memset(&init, 0, sizeof(init));
+			init.t_start = init.t_first_exit = ~0ull;
+			HIP_CHECK(hipMemcpyAsync(ctrl, &init, sizeof(PsCtrl), hipMemcpyHostToDevice, stream));
+			HIP_CHECK(hipStreamSynchronize(stream));
+		}
+		const int grid2 = std::max(1, std::min(grid, (nrows + PS_ROWS_PER_GRAB - 1) / PS_ROWS_PER_GRAB));
+		if (global_bits)
+			hipLaunchKernelGGL((pivot_search_kernel<true, 5, 25>), dim3(grid2), dim3(64), lds, stream, dA.p, dA.j, d_pinv, nrows, m, words, rec, jent, jrow, ctrl, fifo,
+			                   fifo_cap, (int) jcap, gbits, list_cap, (i64) A->p[n], rowlist);
+		else
+			hipLaunchKernelGGL((pivot_search_kernel<false, 6, 20>), dim3(grid2), dim3(64), lds, stream, dA.p, dA.j, d_pinv, nrows, m, words, rec, jent, jrow, ctrl, fifo,
+			                   fifo_cap, (int) jcap, gbits, list_cap, (i64) A->p[n], rowlist);
+		HIP_CHECK(hipGetLastError());
+		PsCtrl c;
+		HIP_CHECK(hipMemcpyAsync(&c, ctrl, sizeof(PsCtrl), hipMemcpyDeviceToHost, stream));
+		HIP_CHECK(hipStreamSynchronize(stream));
+		const double t_run = wtime();
+		int found2 = -1;
+		if (c.status == 0) {
+			const int tickets = std::min(c.tickets, (int) jcap);
+			std::vector<u64> ent((size_t) std::max(tickets, 1));
+			std::vector<int> rows((size_t) std::max(tickets, 1));
+			if (tickets > 0) {
+				HIP_CHECK(hipMemcpy(ent.data(), jent, (size_t) tickets * sizeof(u64), hipMemcpyDeviceToHost));
+				HIP_CHECK(hipMemcpy(rows.data(), jrow, (size_t) tickets * sizeof(int), hipMemcpyDeviceToHost));
+			}
+			found2 = 0;
+			for (int t = 0; t < tickets; t++) {
+				const u64 state = ent[t] >> 32;
+				const int col = (int) (uint32_t) ent[t];
+				if (state == PS_ABORTED)
+					continue;
+				if (state != PS_ACCEPTED || rows[t] < 0 || rows[t] >= n || col < 0 || col >= m || pinv[rows[t]] != -1 || qinv[col] != -1) {
+					// an inconsistent journal (a ticket left undecided, a row or a column taken twice): nothing of this search is
+					// kept -- the pivots applied so far are taken back and the host search runs (the caller sees -1)
+					std::fprintf(stderr, "[pivots] device search: ticket %d = (row %d, column %d, state %llu) is not a new pivot (a bug: please report); "
+					                     "the %d pivots of this search are discarded, searching on the host\n", t, rows[t], col, (unsigned long long) state, found2);
+					for (int u = 0; u < t; u++) {
+						if ((ent[u] >> 32) != PS_ACCEPTED)
+							continue;
+						const int cu = (int) (uint32_t) ent[u];
+						if (rows[u] >= 0 && rows[u] < n && cu >= 0 && cu < m && pinv[rows[u]] == cu && qinv[cu] == rows[u]) {
+							pinv[rows[u]] = -1;
+							qinv[cu] = -1;
+						}
+					}
+					found2 = -1;
+					break;
+				}
+				pinv[rows[t]] = col;
+				qinv[col] = rows[t];
+				found2 += 1;
+			}
+			if (found2 >= 0 && stats)
+				logmsg("[pivots] device%s: %d searches in flight (%d per CU, %zu bytes of LDS each%s), %llu pivot rows visited in %llu steps (%llu of them by the %llu searches that ended with a pivot, the rest by %llu that did not), %d tickets for %d pivots, "
+				       "%d rows given up (FIFO full) [%.3fs: %.3f kernels, %.3f journal; in the search kernel the first wave "
+				       "ran out of rows after %.1f ms, the last one left after %.1f ms, the longest search of one row took %.1f ms; "
+				       "of the waves' time %.0f %% in the walk, %.0f %% in replays and tickets]\n", labels ? ", ticket search on the deferred rows" : "", grid2, per_cu, lds, global_bits ? "; reached-bits in HBM" : "", c.visits, c.steps, c.visits_won, c.rows_won, c.rows_lost,
+				       c.tickets, found2, c.overflowed, wtime() - tb, t_run - tb, wtime() - t_run, 1e-5 * (double) (c.t_first_exit - c.t_start),
+				       1e-5 * (double) (c.t_last_exit - c.t_start), 1e-5 * (double) c.longest_search, 100.0 * (double) c.c_search / (double) std::max<u64>(c.c_total, 1),
+				       100.0 * (double) c.c_commit / (double) std::max<u64>(c.c_total, 1));
+		} else {
+			logmsg("[pivots] device search gave up (a wait ran out): the host search takes over\n");
+		}
+		if (found2 < 0) {
+			// (the pivots of the first pass stand on their own -- they are cycle-free by their labels -- but the caller's contract
+			//  is all or nothing: they are taken back too)
+			for (int i : mine) {
+				qinv[pinv[i]] = -1;
+				pinv[i] = -1;
+			}
+			found = -1;
+		} else {
+			found += found2;
+		}
+	}
+	release();
 	return found;
 }
 
