@@ -1318,7 +1318,12 @@ int device_acyclic_greedy(const struct spasm_csr *A, int *pinv, int *qinv)
 	int dev = 0, cus = 256;
 	HIP_CHECK(hipGetDevice(&dev));
 	HIP_CHECK(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev));
-	const int fifo_cap = m + 4096 + (labels ? 2 * casc_cap + 256 : 0);          // (the cascade list of the labelled search lies behind its FIFO)
+	// A search of the ticket kernel may reach every column: a FIFO of m + 4096.  The walks of the labelled search are short (a few
+	// dozen visits per row, pruned): 32,768 columns, then the cascade list behind them; a row that outgrows that is deferred to
+	// the ticket search, which then runs few searches at a time (its rows are a percent of all).  What this saves is device
+	// memory that a driver call has to get first: 5.8 GB of FIFOs on mk15.b4 were 0.1-0.3 s of hipMalloc per call.
+	const int fifo_cap = m + 4096;
+	const int fifo_cap_labels = std::min(m + 4096, env_int("SPASM_HIP_PIVOT_LABEL_FIFO", 32768)) + 2 * casc_cap + 256;
 	// searches in flight per CU: 4 with the marks in LDS (the step is bound by instruction issue: more only adds speculation),
 	// 8 with the marks in HBM (bound by memory latency: mk14.b5 6.4 s at 2, 4.2 at 4, 3.4 at 8)
 	const int per_cu_wanted = env_int("SPASM_HIP_PIVOT_WAVES_PER_CU", global_bits ? 8 : 4);
@@ -1328,10 +1333,12 @@ int device_acyclic_greedy(const struct spasm_csr *A, int *pinv, int *qinv)
 	const size_t per_search = (size_t) fifo_cap * sizeof(int) + (global_bits ? ((size_t) words + 64) * sizeof(uint32_t) : 0);
 	while (per_cu > 1 && (size_t) cus * per_cu * per_search > ((size_t) 16 << 30))
 		per_cu -= 1;
-	per_cu_labels = std::min(per_cu_labels, std::max(per_cu, 1));
-	while (per_cu_labels > 1 && (size_t) cus * per_cu_labels * per_search > ((size_t) 16 << 30))
+	const size_t per_search_labels = (size_t) fifo_cap_labels * sizeof(int) + (global_bits ? ((size_t) words + 64) * sizeof(uint32_t) : 0);
+	while (per_cu_labels > 1 && (size_t) cus * per_cu_labels * per_search_labels > ((size_t) 16 << 30))
 		per_cu_labels -= 1;
-	const int grid = cus * per_cu, grid_labels = cus * per_cu_labels, grid_max = std::max(grid, grid_labels);
+	// (behind the labelled search the ticket search gets a fraction of the rows: 512 searches at a time are plenty)
+	const int grid = labels ? std::min(cus * per_cu, std::max(64, env_int("SPASM_HIP_PIVOT_SECOND_PASS_SEARCHES", 512))) : cus * per_cu;
+	const int grid_labels = cus * per_cu_labels, grid_max = std::max(grid, labels ? grid_labels : 0);
 	std::vector<void *> owned;
 	auto dal = [&](size_t bytes) {
 		void *ptr = big_alloc(bytes);
@@ -1346,7 +1353,7 @@ int device_acyclic_greedy(const struct spasm_csr *A, int *pinv, int *qinv)
 	u64 *rec = (u64 *) dal((size_t) m * REC_WORDS * sizeof(u64));
 	int *d_pinv = (int *) dal((size_t) n * sizeof(int));
 	int *d_qinv = (int *) dal((size_t) m * sizeof(int));
-	int *fifo = (int *) dal((size_t) grid_max * fifo_cap * sizeof(int));
+	int *fifo = labels ? (int *) dal((size_t) grid_labels * fifo_cap_labels * sizeof(int)) : nullptr;          // (the ticket search allocates its own when it runs)
 	uint32_t *gbits = nullptr;
 	if (global_bits) {
 		gbits = (uint32_t *) dal((size_t) grid_max * ((size_t) words + 64) * sizeof(uint32_t));
@@ -1398,10 +1405,10 @@ int device_acyclic_greedy(const struct spasm_csr *A, int *pinv, int *qinv)
 			HIP_CHECK(hipMemcpyAsync(pctrl, &init, sizeof(PlCtrl), hipMemcpyHostToDevice, stream));
 			if (global_bits)
 				hipLaunchKernelGGL((pivot_label_search_kernel<true, 5, 25>), dim3(grid_labels), dim3(64), lds_labels, stream, dA.p, dA.j, d_pinv, n, m, words, rec, lab, pctrl,
-				                   fifo, fifo_cap, gbits, d_deferred, (i64) A->p[n], gap_max, casc_cap);
+				                   fifo, fifo_cap_labels, gbits, d_deferred, (i64) A->p[n], gap_max, casc_cap);
 			else
 				hipLaunchKernelGGL((pivot_label_search_kernel<false, 6, 20>), dim3(grid_labels), dim3(64), lds_labels, stream, dA.p, dA.j, d_pinv, n, m, words, rec, lab, pctrl,
-				                   fifo, fifo_cap, gbits, d_deferred, (i64) A->p[n], gap_max, casc_cap);
+				                   fifo, fifo_cap_labels, gbits, d_deferred, (i64) A->p[n], gap_max, casc_cap);
 			HIP_CHECK(hipGetLastError());
 			PlCtrl c;
 			HIP_CHECK(hipMemcpyAsync(&c, pctrl, sizeof(PlCtrl), hipMemcpyDeviceToHost, stream));
@@ -1468,6 +1475,8 @@ int device_acyclic_greedy(const struct spasm_csr *A, int *pinv, int *qinv)
 			HIP_CHECK(hipStreamSynchronize(stream));
 		}
 		const int grid2 = std::max(1, std::min(grid, (nrows + PS_ROWS_PER_GRAB - 1) / PS_ROWS_PER_GRAB));
+		if (fifo == nullptr || (size_t) grid2 * fifo_cap > (size_t) grid_labels * fifo_cap_labels)
+			fifo = (int *) dal((size_t) grid2 * fifo_cap * sizeof(int));
 		if (global_bits)
 			hipLaunchKernelGGL((pivot_search_kernel<true, 5, 25>), dim3(grid2), dim3(64), lds, stream, dA.p, dA.j, d_pinv, nrows, m, words, rec, jent, jrow, ctrl, fifo,
 			                   fifo_cap, (int) jcap, gbits, list_cap, (i64) A->p[n], rowlist);
