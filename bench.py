@@ -201,16 +201,18 @@ def dense_tail_real_probe(torch, spasm_amd, dev, dA, drows, dF, Sm, nrows=4096):
 def _calls(fn, count):
     """`count` timed calls of fn() -> (profile, rank): first call, median, minimum, all of them"""
     runs = []
+    import spasm_amd
     for _ in range(count):
         t0 = time.perf_counter()
         prof, rank = fn()
+        prof = dict(prof, events=spasm_amd.echelonize_counters())
         runs.append((time.perf_counter() - t0, prof, rank))
     secs = [r[0] for r in runs]
     med = sorted(runs, key=lambda r: r[0])[len(runs) // 2]
     stages = ("pivot_search", "density_estimates", "sparse_schur", "dense_finish")
     return {"rank": med[2], "ranks_agree": len({r[2] for r in runs}) == 1, "seconds_first_call": secs[0],
             "seconds_median": statistics.median(secs), "seconds_min": min(secs), "seconds_all": secs, "split_of_median_call": med[1],
-            "stages_of_every_call": [{k: round(r[1].get(k, 0.0), 3) for k in stages} for r in runs]}
+            "stages_of_every_call": [dict({k: round(r[1].get(k, 0.0), 3) for k in stages}, events=r[1]["events"]) for r in runs]}
 
 
 def sparse_path_probe(torch, spasm_amd, workloads, dev, name="mk14.b4", steps=3, paths=("default", "dense image", "row by row"), calls=5):
@@ -340,6 +342,20 @@ def stand_in_runs(spasm_amd, workloads):
             fact = spasm_amd.echelonize(A, opts)
             return spasm_amd.echelonize_profile(), int(fact.U.n)
         out.append(dict(_calls(call, 3), name=name, stand_in_for=info["for"], shape=[A.n, A.m], nnz=int(A.nnz), options=" ".join(info["rank_args"])))
+    # the flow of BASELINE configs[4] (M0,6-D9: --no-greedy-pivot-search, tools/echelonize.c:36, spasm_pivots.c:315) on the generated
+    # matrices: Faugere-Lachartre pivots only, so the first Schur complement is larger and the call runs two or three sparse
+    # rounds, each with a factor image of its own, before the dense finish
+    for name, thr in (("mk13.b4", 0.05), ("mk13.b5", 0.05), ("mk14.b4", 0.05)):
+        A, _ = workloads.load_matrix(name, PRIME)
+        opts = spasm_amd.default_opts()
+        opts.enable_greedy_pivot_search = 0
+        opts.sparsity_threshold = thr
+        def call():
+            fact = spasm_amd.echelonize(A, opts)
+            return spasm_amd.echelonize_profile(), int(fact.U.n)
+        runs = _calls(call, 3)
+        out.append(dict(runs, name=name, stand_in_for="M0,6-D9 (the no-greedy flow)", shape=[A.n, A.m], nnz=int(A.nnz), options="--no-greedy-pivot-search",
+                        sparse_rounds=runs["split_of_median_call"].get("sparse_rounds")))
     return out
 
 

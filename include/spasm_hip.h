@@ -222,6 +222,14 @@ struct spasm_lu *spasm_hip_echelonize(const struct spasm_csr *A, struct echeloni
  * [6] the structural-rounds finish that replaces GPLU, [7] host matrices uploaded to the device by this process so far
  * (inside the driver a matrix goes up at most once and Schur complements stay where they were computed).  8 doubles. */
 void spasm_hip_echelonize_profile(double *out);
+/* events since the last spasm_hip_echelonize call started, that its time split does not show -- out[k] for k < count:
+ * [0] spasm_hip_schur calls redone because the pool of S was too small, [1] pools sized from a sampled run of the sparse
+ * image, [2] chunks added to the pool of the sparse image R during a build, [3] persistent builds of R aborted and redone
+ * level by level, [4] device blocks the block cache did not have and [5] their bytes, [6] factor images planned on the
+ * host, [7] pivot rows visited by the device pivot searches, [8] of them by searches that ended with a pivot, [9] items of
+ * the label cascades, [10] rows that got / [11] did not get a pivot in the greedy search, [12] pivots accepted on their
+ * labels alone, [13] rows the labelled search deferred to the ticket search.  Returns how many there are (14). */
+int spasm_hip_echelonize_counters(long long *out, int count);
 struct spasm_csr *spasm_hip_rref(const struct spasm_lu *fact, int *Rqinv);
 struct spasm_csr *spasm_hip_kernel(const struct spasm_lu *fact);
 

@@ -64,6 +64,7 @@ def lib():
         "spasm_hip_echelonize_init_opts": (None, [C.POINTER(EchelonizeOpts)]),
         "spasm_hip_echelonize": (plu, [pcsr, C.POINTER(EchelonizeOpts)]),
         "spasm_hip_echelonize_profile": (None, [C.POINTER(C.c_double)]),
+        "spasm_hip_echelonize_counters": (ci, [C.POINTER(C.c_longlong), ci]),
         "spasm_hip_rref": (pcsr, [plu, pint]),
         "spasm_hip_kernel": (pcsr, [plu]),
         "spasm_hip_lu_free": (None, [plu]),

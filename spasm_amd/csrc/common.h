@@ -51,6 +51,28 @@ const char *env_get(const char *name);
 int verbose();
 void logmsg(const char *fmt, ...);
 
+// Events of a driver call that its time split does not show (include/spasm_hip.h: spasm_hip_echelonize_counters): a stage that
+// took 2 s instead of 0.07 s in one call of five is a retry, an extension or memory that had to be fetched -- counted here,
+// reset when spasm_hip_echelonize starts, added to by whoever causes them (also outside the driver).
+enum {
+	CNT_POOL_RETRIES = 0,        // spasm_hip_schur calls redone because the row pool of S was too small
+	CNT_POOL_RESIZED,            // ... pools sized from a sampled run of the sparse image instead of the driver's 100-row estimate
+	CNT_SP_CHUNK_EXTENSIONS,     // chunks added to the pool of the sparse image R during a build
+	CNT_SP_BUILD_ABORTS,         // persistent builds of R that were aborted (watchdog / residency) and redone level by level
+	CNT_BIG_ALLOC_MISSES,        // device blocks >= 1 MB that the block cache did not have (hipMalloc)
+	CNT_BIG_ALLOC_MISS_BYTES,
+	CNT_FACTOR_PLANS,            // factor images planned on the host (level schedule + upload)
+	CNT_PIVOT_VISITS,            // pivot rows visited by the device searches (walks of both passes)
+	CNT_PIVOT_VISITS_WON,        // ... of them by searches that ended with a pivot
+	CNT_PIVOT_CASCADE_ITEMS,     // (column, label) items of the label cascades
+	CNT_PIVOT_ROWS_WON,
+	CNT_PIVOT_ROWS_LOST,
+	CNT_PIVOT_FREE_ACCEPTS,      // pivots accepted on their labels alone (no walk)
+	CNT_PIVOT_DEFERRED,          // rows the labelled search handed to the ticket search
+	CNT_COUNT
+};
+long long *counters();
+
 // ---- GF(p), balanced representatives, exact 64-bit arithmetic ----
 inline spasm_ZZp zp_balance(int64_t p, int64_t r)
 {

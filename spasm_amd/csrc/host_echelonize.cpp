@@ -360,6 +360,13 @@ extern "C" void spasm_hip_echelonize_profile(double *out)
 }
 
 namespace {
+extern "C" int spasm_hip_echelonize_counters(long long *out, int count)
+{
+	for (int k = 0; k < count && k < CNT_COUNT; k++)
+		out[k] = counters()[k];
+	return CNT_COUNT;
+}
+
 struct Stopwatch {          // adds the time of its scope to a slot of g_prof
 	double t0;
 	int slot;
@@ -378,6 +385,8 @@ extern "C" struct spasm_lu *spasm_hip_echelonize(const struct spasm_csr *A0, str
 	std::lock_guard<std::mutex> one_at_a_time(g_driver_mutex);
 	for (int k = 0; k < 8; k++)
 		g_prof[k] = 0.0;
+	for (int k = 0; k < CNT_COUNT; k++)
+		counters()[k] = 0;
 	resident_begin();          // A, and every Schur complement after it, stays in HBM between the calls below
 	if (spasm_hip_device_count() == 0)
 		die("spasm_hip_echelonize: no HIP device (this library has no CPU path)");

@@ -18,6 +18,12 @@ double wtime()
 	return (double) tv.tv_sec + 1e-6 * (double) tv.tv_usec;
 }
 
+long long *counters()
+{
+	static long long c[CNT_COUNT];
+	return c;
+}
+
 // ---- environment switches --------------------------------------------------------------------
 const char *env_get(const char *name)
 {

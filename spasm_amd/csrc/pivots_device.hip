@@ -1446,6 +1446,13 @@ int device_acyclic_greedy(const struct spasm_csr *A, int *pinv, int *qinv)
 			}
 			found = (int) mine.size();
 			ndeferred = c.ndeferred;
+			counters()[CNT_PIVOT_VISITS] += (long long) c.visits;
+			counters()[CNT_PIVOT_VISITS_WON] += (long long) c.visits_won;
+			counters()[CNT_PIVOT_CASCADE_ITEMS] += (long long) c.casc_items;
+			counters()[CNT_PIVOT_ROWS_WON] += (long long) c.rows_won;
+			counters()[CNT_PIVOT_ROWS_LOST] += (long long) c.rows_lost;
+			counters()[CNT_PIVOT_FREE_ACCEPTS] += (long long) c.free_accepts;
+			counters()[CNT_PIVOT_DEFERRED] += (long long) c.ndeferred;
 			if (stats)
 				logmsg("[pivots] device, labelled search: %d searches in flight (%d per CU, %zu bytes of LDS each%s), %llu pivot rows visited in %llu steps (%llu of them on the %llu rows that ended with a pivot: "
 				       "%llu accepted on their labels alone, %llu after a walk; %llu rows without one), cascades: %llu items in %llu steps (%llu of them thrown away: %llu candidates found reachable, "
@@ -1523,6 +1530,12 @@ int device_acyclic_greedy(const struct spasm_csr *A, int *pinv, int *qinv)
 				pinv[rows[t]] = col;
 				qinv[col] = rows[t];
 				found2 += 1;
+			}
+			if (found2 >= 0) {
+				counters()[CNT_PIVOT_VISITS] += (long long) c.visits;
+				counters()[CNT_PIVOT_VISITS_WON] += (long long) c.visits_won;
+				counters()[CNT_PIVOT_ROWS_WON] += (long long) c.rows_won;
+				counters()[CNT_PIVOT_ROWS_LOST] += (long long) c.rows_lost;
 			}
 			if (found2 >= 0 && stats)
 				logmsg("[pivots] device%s: %d searches in flight (%d per CU, %zu bytes of LDS each%s), %llu pivot rows visited in %llu steps (%llu of them by the %llu searches that ended with a pivot, the rest by %llu that did not), %d tickets for %d pivots, "

@@ -150,6 +150,10 @@ void *big_alloc(size_t bytes)
 		HIP_CHECK(hipMalloc(&ptr, bytes));
 	}
 	std::lock_guard<std::mutex> guard(g_big.mutex);
+	if (bytes >= BIG_MIN) {
+		counters()[CNT_BIG_ALLOC_MISSES] += 1;
+		counters()[CNT_BIG_ALLOC_MISS_BYTES] += (long long) bytes;
+	}
 	if (bytes >= BIG_MIN)
 		g_big.live.push_back({ptr, bytes});
 	else
@@ -572,6 +576,7 @@ spasm_hip_dfact *cached_dfact(const struct spasm_csr *U, const int *qinv, hipStr
 	if (g_fact != nullptr)
 		spasm_hip_dfact_destroy(g_fact);
 	g_fact = spasm_hip_dfact_create(U, qinv, stream);
+	counters()[CNT_FACTOR_PLANS] += 1;
 	g_fact_key = key;
 	return g_fact;
 }
@@ -1911,6 +1916,47 @@ struct spasm_csr *spasm_hip_schur(const struct spasm_csr *A, const int *p, int n
 	spasm_hip_dwork *W = nullptr;
 	const double t1 = wtime();
 	double t_wcreate = 0.0;
+	// A full batch through the sparse image: the pool of S is sized from the image itself.  The driver's estimate comes from
+	// 100 rows (spasm_schur_estimate_density) and the rows of these Schur complements differ by orders of magnitude: mk15.b4
+	// was given 2.54e9 entries for 1.86e9 in one call and too few in another -- and a pool that is too small means the whole
+	// call again on a fresh block of twice the size (tens of GB that the device has to map: the 2.2 s sparse round in one
+	// call of five of round 4's bench, where the others took 0.07).  Here R is built first and 8,192 rows spread over the
+	// batch go through it (half a millisecond): their entries, scaled, + 12 % + what the waves strand in their arenas.
+	double ms_sample = 0.0;
+	if (L == nullptr && !shard && n >= 65536 && env_int("SPASM_HIP_POOL_SAMPLE", 1) != 0 &&
+	    sparse_image_wanted(F, env_int("SPASM_HIP_FORCE_TIER", 0) != 0 || env_int("SPASM_HIP_GROUP", -1) >= 0, n) &&
+	    (F->sp.valid || sparse_image_build(F, stream))) {
+		const int ns = 8192;
+		std::vector<int> sample((size_t) ns);
+		for (int k = 0; k < ns; k++)
+			sample[(size_t) k] = p[(i64) k * n / ns];
+		int *d_sample = dalloc<int>(ns);
+		upload(d_sample, sample.data(), ns, stream);
+		const i64 spool_max = (i64) ns * (i64) (m - F->r) + (i64) 4096 * 4096;
+		i64 spool = std::min(spool_max, std::max<i64>((i64) (4.0 * est_density * ns * (double) (m - F->r)), (i64) 1 << 24) + (i64) 4096 * 4096);
+		for (;;) {
+			spasm_hip_dwork *Ws = spasm_hip_dwork_create(ns, m, spool);
+			spasm_hip_schur_stats sts{};
+			const int rc = dschur_impl(&dA, d_sample, ns, F, Ws, stream, &sts, nullptr);
+			spasm_hip_dwork_destroy(Ws);
+			if (rc == 0) {
+				ms_sample = sts.ms_total;
+				if (sts.used_sparse_image && sts.nnz > 0) {
+					const i64 sized = (i64) (1.12 * (double) sts.nnz / (double) ns * (double) n) + (i64) 48 * 1024 * 1024;
+					if (verbose() >= 2)
+						logmsg("[schur/hip] pool of S: %" PRId64 " entries from %d sampled rows through the sparse image (%.1f per row), %" PRId64 " from the driver's estimate\n",
+						       sized, ns, (double) sts.nnz / ns, pool);
+					pool = std::min(pool_max, sized);
+					counters()[CNT_POOL_RESIZED] += 1;
+				}
+				break;
+			}
+			if (spool >= spool_max)
+				break;
+			spool = std::min(spool_max, 2 * spool);
+		}
+		sh::big_free(d_sample);
+	}
 	// L requested: pools for the elimination coefficients, grown on demand
 	LOut lout;
 	i64 lcap = (L != nullptr) ? std::max<i64>(16 * in_nnz, (i64) 1 << 24) : 0;
@@ -1958,6 +2004,7 @@ struct spasm_csr *spasm_hip_schur(const struct spasm_csr *A, const int *p, int n
 			if (pool >= pool_max)
 				die("spasm_hip_schur: pool of %" PRId64 " entries still too small", pool);
 			pool = std::min(pool_max, 2 * pool + m);
+			counters()[CNT_POOL_RETRIES] += 1;
 			logmsg("[schur/hip] pool too small, retrying with %" PRId64 " entries\n", pool);
 		}
 		if (rc & 2) {
@@ -2050,7 +2097,7 @@ struct spasm_csr *spasm_hip_schur(const struct spasm_csr *A, const int *p, int n
 	const double density = (S->n > 0 && m > 0) ? (double) S->p[S->n] / ((double) m * S->n) : 0.0;
 	logmsg("Schur complement: %d * %d [%" PRId64 " nz / density= %.3f], %.1fs (GPU kernels %.1f ms, %s%s; tiers %d/%d/%d; "
 	       "factor image %.2fs, alloc+run %.2fs, download %.2fs%s, free %.2fs)\n", S->n, m, S->p[S->n], density, wtime() - t0,
-	       st.ms_total, st.kernel, st.group_aborted ? " after the row-group kernel gave up" : "", st.rows_lds, st.rows_lds_big, st.rows_dense,
+	       st.ms_total + ms_sample, st.kernel, st.group_aborted ? " after the row-group kernel gave up" : "", st.rows_lds, st.rows_lds_big, st.rows_dense,
 	       t_fact, t_run, t_down, lazy ? " (row pointers only: the entries stay on the device)" : "", wtime() - t3);
 	if (verbose() >= 2)
 		logmsg("[schur/hip] of alloc+run: %.2fs allocating the workspace (%" PRId64 " pool entries), scratch %.1f GB\n", t_wcreate, pool,

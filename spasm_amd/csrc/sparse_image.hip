@@ -7,24 +7,31 @@
 // and what that costs on a GPU is the random read-modify-write traffic of the row-group kernel.
 // Here R is formed once per factor, like in backsolve.hip, but as sparse rows:
 //
-//   * the non-pivotal columns are cut into SEGMENTS of SP_SEG = 8,192 columns;
+//   * the non-pivotal columns are cut into SEGMENTS of SP_SEG = 4,096 columns;
 //   * a row of R is a set of FRAGMENTS, one per segment it has entries in: 4-byte entries (column inside the segment |
-//     signed 16-bit value << 16, sorted by column) in a bump-allocated pool; frag[c * nseg + g] = where and how long;
-//   * sp_build_kernel, one launch per elimination level from the last to the first (what spasm_reach's depth-first search
-//     orders for one row, the level schedule orders for all of them): one WAVE per (row c, segment g) adds up
-//     U_n[c] - sum_t u_ct R[t] in 16 KB of LDS (16-bit accumulators, one read-modify-write per entry of a fragment: the
-//     entries of a fragment have distinct columns and a wave's LDS accesses are served in order, so no atomics), counts,
-//     reserves its room and writes the fragment.  Work = sum over the pivotal entries of U of the fill of the rows they
-//     point at -- it scales with nnz(R), not with r x Sm;
-//   * sp_apply_kernel: one wave per (reduced row k, segment g), the same accumulation over the pivotal entries of the row
-//     of A, fragments of S into a pool; a scan of the row lengths and sp_gather_kernel put the rows in their final place
-//     (W->d_Sp / d_Sj / d_Sx, columns sorted).
+//     signed 16-bit value << 16, sorted by column) in a bump-allocated pool of 1-12 chunks; frag[c * nseg + g] = where and
+//     how long;
+//   * sp_build_kernel<true>: ONE cooperative launch of as many waves as the chip holds (10.5 KB of LDS each).  A task =
+//     (row c, segment g): R[c][g] = U_n[c][g] - sum_t u_ct R[t][g]; tasks are handed out in order -- rows from the last to
+//     the first, i.e. after the rows they depend on: what spasm_reach's depth-first search orders for one row, the level
+//     schedule orders for all of them -- by ticket counters, and a task whose dependencies are not there yet polls their
+//     fragment words.  The sum is formed in 8 KB of LDS (16-bit accumulators, one read-modify-write per entry of a fragment:
+//     the entries of a fragment have distinct columns and a wave's LDS accesses are served in order, so no atomics), the
+//     touched columns are listed from a bitmap, the non-zero sums go to the wave's arena of the pool, the fragment word is
+//     published.  Work = sum over the pivotal entries of U of the fill of the rows they point at -- it scales with nnz(R),
+//     not with r x Sm.  sp_build_kernel<false> is the same task per launch of one elimination level (the fall-back when the
+//     cooperative launch is refused or the watchdog fires);
+//   * sp_apply_kernel: one wave per reduced row k, through all its segments: the same accumulation over the pivotal entries
+//     of the row of A, fragments of S into a pool; a scan of the row lengths and sp_gather_kernel put the rows in their final
+//     place (W->d_Sp / d_Sj / d_Sx, columns sorted).
 //
 // Arithmetic: signed 16-bit representatives with the fp32 reduction of sgn_dev.h (p <= 44,927; 42013 -- the reference's
 // default -- qualifies); every multiply-add is reduced at once (|x| <= B, |c v| <= (p/2) B: the sum fits 31 bits).
 // Exact mod p, so S is the matrix the other paths compute, bit for bit (tests/test_gpu_sparse_image.py).
 #include <algorithm>
 #include <cinttypes>
+#include <chrono>
+#include <thread>
 #include <vector>
 
 #include "device_types.h"
@@ -1285,6 +1292,7 @@ bool sparse_image_build(const spasm_hip_dfact *F, hipStream_t stream)
 		S.d_chunk[S.nchunks] = dalloc<uint32_t>(cap);
 		S.chunk_cap[S.nchunks] = cap;
 		S.nchunks += 1;
+		counters()[CNT_SP_CHUNK_EXTENSIONS] += 1;
 		return true;
 	};
 	auto set_chunk = [&](int chunk, bool first) {
@@ -1316,30 +1324,33 @@ bool sparse_image_build(const spasm_hip_dfact *F, hipStream_t stream)
 				HIP_CHECK(hipMemsetAsync(d_dbg, 0, (size_t) blocks * 4 * sizeof(int), stream));
 			}
 			b.dbg = d_dbg;
-			hipLaunchKernelGGL(sp_build_kernel<true>, dim3(blocks), dim3(64), 0, stream, b);
-			HIP_CHECK(hipGetLastError());
+			// A COOPERATIVE launch: the tasks of this kernel wait for each other, which only ends when every wave of the grid is
+			// resident -- the runtime then refuses a grid that is not (an error at launch time instead of a stall), and does not
+			// start it beside work that holds part of the chip.
+			{
+				void *kargs[1] = {(void *) &b};
+				const hipError_t le = hipLaunchCooperativeKernel(reinterpret_cast<void *>(sp_build_kernel<true>), dim3(blocks), dim3(64), kargs, 0, stream);
+				if (le != hipSuccess) {
+					(void) hipGetLastError();
+					logmsg("[sparse image] the single-launch build cannot be resident here (%s); building level by level\n", hipGetErrorString(le));
+					counters()[CNT_SP_BUILD_ABORTS] += 1;
+					if (d_dbg != nullptr)
+						sh::big_free(d_dbg);
+					persistent = false;
+					chunk = 0;
+					break;
+				}
+			}
 			S.launches += 1;
 			{
-				// watchdog: a launch that is still running after SPASM_HIP_SPARSE_IMAGE_WATCHDOG_S seconds (default 20) is told to
-				// give up (the abort flag, written from a stream of its own); what the ticket counters and the wave marks say
-				// goes to stderr
-				const double t_launch = wtime(), patience = (double) env_sp("SPASM_HIP_SPARSE_IMAGE_WATCHDOG_S", 20);
-				const int wd_mode = env_sp("SPASM_HIP_SPARSE_IMAGE_WD_MODE", 0);          // (experiment: 1 = no busy wait before the read-back, 2 = pinned read-back)
-				while (wd_mode == 0 && hipStreamQuery(stream) == hipErrorNotReady && wtime() - t_launch < patience) {
-				}
-				if (wd_mode == 2) {
-					int *pin = nullptr;
-					HIP_CHECK(hipHostMalloc((void **) &pin, 64, hipHostMallocDefault));
-					HIP_CHECK(hipMemcpyAsync(pin, d_abort, 8, hipMemcpyDeviceToHost, stream));
-					HIP_CHECK(hipStreamSynchronize(stream));
-					fprintf(stderr, "[wd_mode 2] pinned read-back done: %d %d\n", pin[0], pin[1]);
-					HIP_CHECK(hipHostFree(pin));
-				}
-				if (wd_mode == 3) {
-					HIP_CHECK(hipStreamSynchronize(stream));
-					fprintf(stderr, "[wd_mode 3] plain synchronize done\n");
-				}
-				if (wd_mode == 0 && hipStreamQuery(stream) == hipErrorNotReady) {
+				// second line of defence, a watchdog: a launch that is still running after SPASM_HIP_SPARSE_IMAGE_WATCHDOG_S seconds
+				// (default 5: a hundred times what the longest build measured takes) is told to give up (the abort flag, written
+				// from a stream of its own); what the ticket counters and the wave marks say goes to stderr.  The host sleeps
+				// between its looks at the stream.
+				const double t_launch = wtime(), patience = (double) env_sp("SPASM_HIP_SPARSE_IMAGE_WATCHDOG_S", 5);
+				while (hipStreamQuery(stream) == hipErrorNotReady && wtime() - t_launch < patience)
+					std::this_thread::sleep_for(std::chrono::microseconds(wtime() - t_launch < 2e-3 ? 5 : 50));
+				if (hipStreamQuery(stream) == hipErrorNotReady) {
 					hipStream_t side;
 					HIP_CHECK(hipStreamCreateWithFlags(&side, hipStreamNonBlocking));
 					std::vector<int> hs((size_t) SP_TICKETS * SP_TICKET_STRIDE + 2);
@@ -1391,12 +1402,15 @@ bool sparse_image_build(const spasm_hip_dfact *F, hipStream_t stream)
 			int flags[2] = {0, 0};          // abort, overflow
 			HIP_CHECK(hipMemcpyAsync(flags, d_abort, sizeof(flags), hipMemcpyDeviceToHost, stream));
 			HIP_CHECK(hipStreamSynchronize(stream));
+			if (d_dbg != nullptr)
+				sh::big_free(d_dbg);
 			if (verbose() >= 3)
 				logmsg("[sparse image] launch %d on chunk %d (%lld entries): abort %d, overflow %d\n", S.launches, chunk, (long long) S.chunk_cap[chunk], flags[0], flags[1]);
 			if (flags[0] != 0) {
 				// a wave waited for a dependency for seconds: the grid was not resident (something else holds the chip?).  The
 				// level-by-level driver needs no such thing.
 				logmsg("[sparse image] the single-launch build gave up waiting; building level by level\n");
+				counters()[CNT_SP_BUILD_ABORTS] += 1;
 				persistent = false;
 				chunk = 0;
 				break;
@@ -1444,7 +1458,18 @@ bool sparse_image_build(const spasm_hip_dfact *F, hipStream_t stream)
 	}
 	HIP_CHECK(hipEventRecord(S.ev1, stream));
 	if (!ok) {
+		// R is not sparse: the other paths take the batch -- on this very call, and they size themselves by the memory that is
+		// free: everything the attempt holds goes back first (the pool chunks: up to a third of the HBM; the fragment words).
+		// `failed` is for good on this factor, so nothing here is needed again.
 		S.failed = true;
+		HIP_CHECK(hipStreamSynchronize(stream));
+		sparse_image_drop_chunks(S);
+		for (void **ptr : {(void **) &S.d_frag, (void **) &S.d_shard, (void **) &S.d_col, (void **) &S.d_dep_rp, (void **) &S.d_dep, (void **) &S.d_np_rp, (void **) &S.d_np}) {
+			sh::big_free(*ptr);          // (the tables of the plan too: the dependencies and the non-pivotal entries of every row)
+			*ptr = nullptr;
+		}
+		if (d_prof != nullptr)
+			sh::big_free(d_prof);
 		return false;
 	}
 	std::vector<unsigned long long> h((size_t) SP_SHARDS * SHARD_STRIDE);

@@ -203,6 +203,20 @@ def echelonize_profile():
             "dense_finish": out[4], "sparse_rounds": int(out[5]), "structural_finish": out[6], "uploads_so_far": int(out[7])}
 
 
+COUNTER_NAMES = ("pool_retries", "pools_sized_from_a_sample", "sparse_image_chunk_extensions", "sparse_image_build_aborts",
+                 "block_cache_misses", "block_cache_miss_bytes", "factor_plans", "pivot_visits", "pivot_visits_of_searches_with_a_pivot",
+                 "pivot_cascade_items", "pivot_rows_with_a_pivot", "pivot_rows_without", "pivots_accepted_on_labels_alone",
+                 "pivot_rows_deferred_to_the_ticket_search")
+
+
+def echelonize_counters():
+    """events since the last echelonize() call started that its time split does not show (spasm_hip_echelonize_counters):
+    pool retries, extensions of the sparse image, block-cache misses, factor plans, visits of the pivot search by outcome."""
+    out = (C.c_longlong * len(COUNTER_NAMES))()
+    lib().spasm_hip_echelonize_counters(out, len(COUNTER_NAMES))
+    return {k: int(out[t]) for t, k in enumerate(COUNTER_NAMES)}
+
+
 def rref(F):
     """spasm_rref (spasm_rref.c:25): returns (R, Rqinv)."""
     require_gpu("rref")

@@ -202,3 +202,46 @@ def test_primes_beyond_the_signed_arithmetic_take_the_other_paths(oracle, monkey
     rng = np.random.default_rng(21)
     sysm = _triangular_system(rng, p, npiv=800, nnon=300, nred=200, deps=lambda k: 2, reach=40, np_per_row=3, red_entries=5)
     _run(oracle, monkeypatch, p, *sysm, min_pivots=600)
+
+
+def test_a_build_that_finds_R_dense_gives_its_memory_back_and_the_other_paths_take_the_batch(oracle, monkeypatch):
+    """R of this factor is dense (every pivot row holds 300 of the 2,000 non-pivotal columns and the rows chain): with first
+    chunks of 1,024 entries the build runs out of chunks and gives up.  The same call must then come out right through
+    another path, and what the attempt allocated must be back (the advisor's finding of round 4: the fallback sized its
+    scratch by free memory with up to a third of the HBM still held by the failed attempt): the factor holds no more device
+    memory afterwards than one that never tried."""
+    import torch
+    monkeypatch.setenv("SPASM_HIP_SPARSE_IMAGE_CHUNK", "1024")
+    p = 42013
+    rng = np.random.default_rng(5)
+    n, m, ti, tj, tx = _triangular_system(rng, p, npiv=4000, nnon=2000, nred=300, deps=lambda k: 3, reach=60, np_per_row=300, red_entries=6)
+    A = oracle.compress(p, n, m, ti, tj, tx)
+    npiv, perm, F = oracle.pivots_extract_structural(A, oracle.empty_fact(A.n, A.m, p))
+    rows = perm[npiv:]
+    want, _, _ = oracle.schur(A, rows, F)
+
+    def held_by_the_factor(mode):
+        monkeypatch.setenv("SPASM_HIP_SPARSE_IMAGE", mode)
+        torch.cuda.synchronize()
+        spasm_amd.release_cached_memory()
+        free_before = torch.cuda.mem_get_info()[0]
+        S, st, W, dF, dA, drows = _stats_of_device_call(A, rows, F, want.nnz + 4096)
+        assert st.status == 0 and st.used_sparse_image == 0 and st.nnz == want.nnz
+        H = S.to_host()
+        assert oracle.same_matrix(oracle.CSR(H.n, H.m, H.p, H.j, H.x, p), want)
+        # a second batch on the same factor: the image is not tried again
+        S2, st2 = spasm_amd.dschur(dA, drows, dF, W, fetch=True)
+        assert st2.status == 0 and st2.used_sparse_image == 0 and st2.nnz == want.nnz
+        del S, S2
+        W.close()
+        spasm_amd.release_cached_memory()
+        torch.cuda.synchronize()
+        held = free_before - torch.cuda.mem_get_info()[0]
+        dF.close()
+        del dA, drows
+        return held
+
+    never_tried = held_by_the_factor("0")
+    tried_and_failed = held_by_the_factor("1")
+    # (the pool chunks of the failed attempt: 1,024 * (2^12 - 1) entries = 16 MB, and 4,000 fragment words)
+    assert tried_and_failed <= never_tried + (4 << 20), "the factor holds %.1f MB more after a failed sparse-image build" % ((tried_and_failed - never_tried) / 1048576.0)

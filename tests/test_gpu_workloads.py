@@ -63,7 +63,7 @@ def _device_rows(S, ks):
     return Sp, out
 
 
-def _full_schur(A, rows, F, env):
+def _full_schur(A, rows, F, env, pool=None):
     import torch
     saved = {k: os.environ.get(k) for k in env}
     os.environ.update(env)
@@ -71,7 +71,7 @@ def _full_schur(A, rows, F, env):
         dA = spasm_amd.DeviceCsr.from_host(A)
         dF = spasm_amd.DeviceFact(F)
         drows = torch.from_numpy(np.ascontiguousarray(rows, np.int32)).cuda()
-        pool = 4 * A.nnz + (1 << 24)
+        pool = pool or 4 * A.nnz + (1 << 24)
         while True:
             W = spasm_amd.SchurWorkspace(len(rows), A.m, pool)
             S, st = spasm_amd.dschur(dA, drows, dF, W, fetch=True)
@@ -129,6 +129,38 @@ def test_round0_schur_of_baseline_workload(oracle, name, path):
     if oracle.ref_available() and len(rows) <= 400000:
         full, _ = oracle.ref_schur(Ao, rows, Fo, threads=spasm_amd.usable_cpus())
         assert full.nnz == st.nnz
+    W.close()
+    dF.close()
+
+
+def test_round0_schur_at_the_size_of_GL7d19_against_the_compiled_reference(oracle):
+    """mk15.b4 (2,837,835 x 675,675: the at-scale stand-in): its round-0 Schur complement -- 2.2 M rows on 71,000 columns, 1.4-2.6e9
+    entries, 18 segments, ~2,600 elimination levels: the largest thing the sparse image ever produces -- against the compiled
+    reference's spasm_schur on 2,048 rows spread over the whole batch, entry for entry (the pivots come from the device search:
+    the sequential host search of round0() would take minutes on this matrix; S is checked against the reference on the SAME
+    factor, whatever pivots it holds)."""
+    name = "mk15.b4"
+    A, rows, F, source = workloads.round0(name, PRIME, threads=0)
+    S, st, W, dF = _full_schur(A, rows, F, {}, pool=3 << 30)
+    assert st.status == 0 and st.used_sparse_image == 1 and st.rows == len(rows)
+    Ao = oracle.CSR(A.n, A.m, A.p, A.j, A.x, PRIME)
+    Fo = oracle.Fact(oracle.CSR(F.U.n, F.U.m, F.U.p, F.U.j, F.U.x, PRIME), F.qinv)
+    ks = np.unique(np.linspace(0, len(rows) - 1, 2048).astype(np.int64))
+    if oracle.ref_available():
+        want, p_out = oracle.ref_schur(Ao, rows[ks], Fo, threads=spasm_amd.usable_cpus())
+    else:
+        want, p_out, _ = oracle.schur(Ao, rows[ks], Fo)
+    order = {int(r): t for t, r in enumerate(p_out)}
+    Sp, got = _device_rows(S, ks)
+    total = 0
+    for k, (gj, gx) in zip(ks, got):
+        wj, wx = want.row(order[int(rows[k])])
+        o = np.argsort(wj)
+        assert np.array_equal(gj, wj[o]) and np.array_equal(np.asarray(gx, np.int64) % PRIME, np.asarray(wx[o], np.int64) % PRIME), \
+            "row %d of the batch (row %d of A) differs" % (k, rows[k])
+        assert np.all(np.diff(gj) > 0)
+        total += len(gj)
+    assert total > 0 and int(Sp[-1]) == st.nnz
     W.close()
     dF.close()
 
@@ -314,3 +346,26 @@ def test_multi_round_stand_in(name, threshold, min_sparse_rounds, monkeypatch):
         return
     Ft = spasm_amd.echelonize(spasm_amd.transpose(A), o)
     assert Ft.U.n == RANKS[name]
+
+
+@pytest.mark.parametrize("name,threshold,min_sparse_rounds", [("mk13.b4", 0.05, 2), ("ch7-8.b5", 0.01, 1), ("mk13.b5", 0.05, 2), ("mk14.b4", 0.05, 2)])
+def test_flow_without_the_greedy_pivot_search(name, threshold, min_sparse_rounds):
+    """the option of BASELINE configs[4] (M0,6-D9, "greedy pivot search disabled": tools/echelonize.c:36 -> spasm_pivots.c:315;
+    the data file cannot be fetched, the FLOW runs on every generated matrix): with Faugere-Lachartre pivots only the first
+    Schur complement is larger and fills in, the driver runs several sparse rounds (spasm_echelonize.c:525-565) -- each with a
+    factor image planned for the U of that round -- before the dense finish.  Same rank as every other flow, twice, and a
+    valid echelon form."""
+    A, _ = workloads.load_matrix(name, PRIME)
+    o = spasm_amd.default_opts()
+    o.enable_greedy_pivot_search = 0
+    o.sparsity_threshold = threshold
+    for _ in range(2):
+        F = spasm_amd.echelonize(A, o)
+        prof = spasm_amd.echelonize_profile()
+        events = spasm_amd.echelonize_counters()
+        assert F.U.n == RANKS[name]
+        assert prof["sparse_rounds"] >= min_sparse_rounds
+        assert events["pivot_visits"] == 0 and events["pivot_rows_with_a_pivot"] == 0          # the greedy search never ran
+        piv = F.U.j[F.U.p[:-1]]
+        assert len(np.unique(piv)) == F.U.n and np.all(F.U.x[F.U.p[:-1]] == 1)
+        assert np.array_equal(F.qinv[piv], np.arange(F.U.n))
