@@ -91,6 +91,30 @@ def cpu_baseline(A, rows, F, budget_s=20.0):
                       % (count, len(rows), t, threads)}
 
 
+def cpu_baseline_sampled(A, rows, F, count=2000):
+    """the reference's spasm_schur on `count` rows spread evenly over the batch (the rows of a stand-in's Schur complement differ
+    by orders of magnitude from one end of the batch to the other: the first rows alone would not say much)"""
+    from oracle import oracle as orc
+    import spasm_amd
+    Ao = orc.CSR(A.n, A.m, A.p, A.j, A.x, A.prime)
+    Fo = orc.Fact(orc.CSR(F.U.n, F.U.m, F.U.p, F.U.j, F.U.x, A.prime), F.qinv)
+    cores = spasm_amd.usable_cpus()
+    ks = np.unique(np.linspace(0, len(rows) - 1, min(count, len(rows))).astype(np.int64))
+    sub = np.ascontiguousarray(rows[ks])
+    if orc.ref_available():
+        kind, threads = "reference", cores
+        run = lambda: orc.ref_schur(Ao, sub, Fo, threads=threads)
+    else:
+        kind, threads = "port", 1
+        run = lambda: orc.schur(Ao, sub, Fo)
+    t0 = time.perf_counter()
+    run()
+    t = time.perf_counter() - t0
+    return {"value": len(sub) / t, "unit": "rows/s", "cores": threads, "kind": kind, "hardware_threads": os.cpu_count(),
+            "sample": "%d of %d non-pivotal rows spread evenly over the batch, spasm_schur, %.1f s, %d OpenMP threads = the CPU quota of the box"
+                      % (len(sub), len(rows), t, threads)}
+
+
 def quoted_traffic(kernel, workload, rows):
     """HBM bytes per launch of `kernel` from the rocprofv3 PMC passes of this round, if they were recorded on
     this workload.  (value, fetch_doubled_upper_bound, source) or (None, None, None)."""
@@ -215,7 +239,7 @@ def _calls(fn, count):
             "stages_of_every_call": [dict({k: round(r[1].get(k, 0.0), 3) for k in stages}, events=r[1]["events"]) for r in runs]}
 
 
-def sparse_path_probe(torch, spasm_amd, workloads, dev, name="mk14.b4", steps=3, paths=("default", "dense image", "row by row"), calls=5):
+def sparse_path_probe(torch, spasm_amd, workloads, dev, name="mk14.b4", steps=3, paths=("default", "dense image", "row by row"), calls=5, cpu_rows=0):
     """The flow GL7d19 takes (a sparse round on a wide Schur complement, then the dense tail), on a matrix of the same
     collection that can be generated offline -- a STAND-IN, not a BASELINE config: mk14.b4 (945,945 x 315,315; its first
     Schur complement is 673,000 x 42,000, ~2 % dense, 5-7e8 entries depending on the pivots of the run) or, at the size of
@@ -317,6 +341,30 @@ def sparse_path_probe(torch, spasm_amd, workloads, dev, name="mk14.b4", steps=3,
     out["same_nnz_on_every_path"] = len(nnzs) == 1
     dflt = out["paths"].get("default", {})
     out.update({k: dflt.get(k) for k in ("ms_per_step", "rows_per_s", "schur_nnz", "schur_density", "took")})
+    if cpu_rows > 0:
+        out["cpu_baseline"] = cpu_baseline_sampled(A, rows, F, cpu_rows)
+    # the same step on a pivot set that does not depend on timing (the sequential search with depth labels, one thread): the
+    # device search above finds a different set in every run, and with it a Schur complement of another size
+    t0 = time.perf_counter()
+    A1, rows1, F1, _ = workloads.round0(name, PRIME, threads=1, labelled=True)
+    t_fixed = time.perf_counter() - t0
+    rows_keep, F_keep = rows, F
+    try:
+        rows, F = rows1, F1
+        drows_keep = drows
+        drows = torch.from_numpy(np.ascontiguousarray(rows)).to(dev)
+        st1, all_ms1, image_ms1, levels1, _ = measure(ENV["default"])
+        out["fixed_pivot_set"] = {"what": "the default path on the pivots of the sequential labelled search (SPASM_HIP_THREADS=1): the same workload in every run",
+                                  "pivots": int(F1.U.n), "rows": len(rows1), "non_pivotal_columns": int(A.m - F1.U.n), "prepare_s": t_fixed,
+                                  "took": "sparse image" if st1.used_sparse_image else "dense image" if st1.used_backsolve else "row by row",
+                                  "ms_per_step": st1.ms_total, "ms_all": all_ms1, "rows_per_s": len(rows1) / (st1.ms_total * 1e-3), "schur_nnz": int(st1.nnz),
+                                  "levels": levels1, "factor_image_ms": image_ms1}
+        if st1.used_sparse_image:
+            out["fixed_pivot_set"]["kernels_ms"] = {"sp_build_kernel": st1.ms_sparse_build, "sp_apply_kernel": st1.ms_sparse_apply, "scan + sp_gather_kernel": st1.ms_sparse_gather}
+            out["fixed_pivot_set"]["build_us_per_level"] = 1e3 * st1.ms_sparse_build / max(1, st1.sparse_image_levels)
+    finally:
+        rows, F, drows = rows_keep, F_keep, drows_keep
+        del A1
     del dA, drows
     torch.cuda.empty_cache()
     os.environ.pop("SPASM_HIP_THREADS", None)
@@ -683,7 +731,7 @@ def main():
             #  are paid for on first touch, 1.1 s for the pools of one sparse round.  Single calls still take 1-2 s longer now and
             #  then, in whichever stage asks for a large block first -- five calls per object, so that the median does not hang on one)
             # the flow of GL7d19 at its size (no dense image exists for this factor; the row-by-row kernels are left out: minutes)
-            out["at_scale"] = sparse_path_probe(torch, spasm_amd, workloads, dev, name="mk15.b4", steps=2, paths=("default",), calls=5)
+            out["at_scale"] = sparse_path_probe(torch, spasm_amd, workloads, dev, name="mk15.b4", steps=2, paths=("default",), calls=5, cpu_rows=2000)
             out["sparse_path"] = sparse_path_probe(torch, spasm_amd, workloads, dev)
             out["stand_ins"] = stand_in_runs(spasm_amd, workloads)
         out["configs"] = [{"name": c["name"], "status": status, "what": c["what"],

@@ -17,10 +17,11 @@ spasm_hip_dfact *cached_dfact(const struct spasm_csr *U, const int *qinv, hipStr
 void launch_split_rows(const int64_t *Sp, int N, int pieces, int64_t *out, hipStream_t stream);
 void launch_sum_pieces(const uint32_t *parts, int64_t ldp, int N, int pieces, int m, uint32_t p, uint32_t *out, int64_t ldo, hipStream_t stream);
 void launch_combine(const int64_t *Ap, const int *Aj, const int *Ax, const int *rows, int nrows, int N, int w, int m,
-                    uint64_t salt, unsigned long long *Y, const Mont &M, hipStream_t stream);
+                    uint64_t salt, unsigned long long *Y, const Mont &M, hipStream_t stream, const uint32_t *colmap = nullptr, uint32_t base = 0);
+bool rows_are_nonpivotal(const int64_t *Ap, const int *Aj, const int *rows, int nrows, const uint32_t *lab, uint32_t base, hipStream_t stream);
 void launch_dense_count(const unsigned long long *Y, int N, int m, uint32_t p, int *row_len, hipStream_t stream);
 void launch_dense_pack(const unsigned long long *Y, int N, int m, uint32_t p, const int64_t *Sp, int *Sj, int *Sx,
-                       hipStream_t stream);
+                       hipStream_t stream, const int *unmap = nullptr);
 void launch_row_scan(const int *row_len, int n, int64_t *blocksum, int64_t *Sp, hipStream_t stream);
 void launch_echelon_count(const uint32_t *M, int64_t ld, int m, int k, int *row_len, hipStream_t stream);
 void launch_echelon_pack(const uint32_t *M, int64_t ld, int m, int k, const int *piv, const int *q, uint32_t p, const int64_t *Sp, int *Uj,
@@ -242,15 +243,21 @@ namespace sh {
 // N random combinations of the rows d_rows[0..n) of A (w > 0: of w random rows each, first coefficient 1; w <= 0: of all
 // the rows), reduced by F, as dense rows on the non-pivotal columns: d_S is N x ldS, values in [0, p).  Everything on
 // `stream`, which is synchronised before returning.  W needs max_rows >= N.
+// `compact`: the rows only hold non-pivotal columns of F (rows of a Schur complement by this factor): the accumulators then
+// span those Sm columns instead of all m -- mk15.b4: 4,096 combinations x 675,675 columns x 8 bytes = 22 GB of which the
+// Schur complement occupies 71,000 columns, memory that every call had to get, clear and scan.
 void device_random_dense_rows(const spasm_hip_dcsr &dA, const int *d_rows, int n, const spasm_hip_dfact *F, int N, int w,
-                              uint64_t salt, u32 *d_S, i64 ldS, spasm_hip_dwork *W, hipStream_t stream)
+                              uint64_t salt, u32 *d_S, i64 ldS, spasm_hip_dwork *W, hipStream_t stream, bool compact)
 {
-	const int m = dA.m;
+	const int m_all = dA.m;
+	const int m = compact ? F->Sm : m_all;          // width of the accumulators
+	const uint32_t *colmap = compact ? F->d_lab : nullptr;
+	const uint32_t base = compact ? (uint32_t) F->rpad : 0u;
 	const double t0 = wtime();
 	// Y = C * A[p, :], dense 64-bit accumulators, then CSR
 	unsigned long long *dY = (unsigned long long *) big_alloc((size_t) N * (size_t) m * sizeof(unsigned long long));
 	HIP_CHECK(hipMemsetAsync(dY, 0, (size_t) N * m * sizeof(unsigned long long), stream));
-	launch_combine(dA.p, dA.j, dA.x, d_rows, n, N, w, m, salt, dY, F->mont, stream);
+	launch_combine(dA.p, dA.j, dA.x, d_rows, n, N, w, m, salt, dY, F->mont, stream, colmap, base);
 	launch_dense_count(dY, N, m, (uint32_t) F->prime, W->d_row_len, stream);
 	launch_row_scan(W->d_row_len, N, W->d_blocksum, W->d_Sp, stream);
 	i64 ynnz = 0;
@@ -258,7 +265,7 @@ void device_random_dense_rows(const spasm_hip_dcsr &dA, const int *d_rows, int n
 	HIP_CHECK(hipStreamSynchronize(stream));
 	int *dYj = (int *) big_alloc((size_t) (ynnz > 0 ? ynnz : 1) * sizeof(int));
 	int *dYx = (int *) big_alloc((size_t) (ynnz > 0 ? ynnz : 1) * sizeof(int));
-	launch_dense_pack(dY, N, m, (uint32_t) F->prime, W->d_Sp, dYj, dYx, stream);
+	launch_dense_pack(dY, N, m, (uint32_t) F->prime, W->d_Sp, dYj, dYx, stream, compact ? F->d_q : nullptr);
 	i64 *dYp = dalloc<i64>((i64) N + 1);
 	HIP_CHECK(hipMemcpyAsync(dYp, W->d_Sp, ((size_t) N + 1) * sizeof(i64), hipMemcpyDeviceToDevice, stream));
 	std::vector<int> ident((size_t) N);
@@ -284,7 +291,7 @@ void device_random_dense_rows(const spasm_hip_dcsr &dA, const int *d_rows, int n
 		int *dident2 = dalloc<int>(NP);
 		HIP_CHECK(hipMemcpyAsync(dident2, ident2.data(), (size_t) NP * sizeof(int), hipMemcpyHostToDevice, stream));
 		u32 *parts = (u32 *) big_alloc((size_t) NP * (size_t) Sm * sizeof(u32));
-		spasm_hip_dcsr dYcsr{NP, m, ynnz, dYp2, dYj, dYx};
+		spasm_hip_dcsr dYcsr{NP, m_all, ynnz, dYp2, dYj, dYx};
 		dschur_dense_impl(&dYcsr, dident2, NP, F, W, parts, Sm, stream, nullptr);
 		launch_sum_pieces(parts, Sm, N, pieces, Sm, (uint32_t) F->prime, d_S, ldS, stream);
 		HIP_CHECK(hipStreamSynchronize(stream));
@@ -292,7 +299,7 @@ void device_random_dense_rows(const spasm_hip_dcsr &dA, const int *d_rows, int n
 		sh::big_free(dident2);
 		sh::big_free(dYp2);
 	} else {
-		spasm_hip_dcsr dYcsr{N, m, ynnz, dYp, dYj, dYx};
+		spasm_hip_dcsr dYcsr{N, m_all, ynnz, dYp, dYj, dYx};
 		dschur_dense_impl(&dYcsr, dident, N, F, W, d_S, ldS, stream, nullptr);
 	}
 	if (verbose() >= 2)
@@ -440,6 +447,10 @@ bool finish_on_device(const struct spasm_csr *A, const int *p, int n, struct spa
 		// echelonize_dense_lowrank: random combinations of the remaining rows
 		const int nleft = n - processed;
 		const int *rows_left = drows + processed;
+		// (rows of a Schur complement by this very factor hold non-pivotal columns only -- checked, once: the accumulators of the
+		//  combinations then span Sm columns instead of m)
+		const bool compact = m > 2 * Sm0 && env_int("SPASM_HIP_COMPACT_COMBINATIONS", 1) != 0 &&
+		                     rows_are_nonpivotal(dA.p, dA.j, rows_left, nleft, F->d_lab, (uint32_t) F->rpad, stream);
 		rank_ub = std::min(nleft, Sm0 - k);
 		int w = (opts->low_rank_start_weight < 0) ? (int) std::ceil(-std::log(0.01) * nleft / (rank_ub > 0 ? rank_ub : 1))
 		                                          : (int) opts->low_rank_start_weight;
@@ -450,14 +461,14 @@ bool finish_on_device(const struct spasm_csr *A, const int *p, int n, struct spa
 				break;
 			salt += 0x9E3779B97F4A7C15ULL;
 			const double tr0 = wtime();
-			device_random_dense_rows(dA, rows_left, nleft, F, Sn, w, salt, dM + (i64) k * ld, ld, W, stream);
+			device_random_dense_rows(dA, rows_left, nleft, F, Sn, w, salt, dM + (i64) k * ld, ld, W, stream, compact);
 			t_rows += wtime() - tr0;
 			int rr = stack_and_reduce(Sn);
 			logmsg("[echelonize/dense/low-rank/device] round %d, weight %d, %d combinations: %d new pivots (%d in all)\n", round, w, Sn, rr, k);
 			if (rr == 0) {
 				// spasm_echelonize_test_completion (spasm_echelonize.c:30-52): a few combinations of ALL the rows
 				salt += 0x9E3779B97F4A7C15ULL;
-				device_random_dense_rows(dA, rows_left, nleft, F, Sn_test, 0, salt, dM + (i64) k * ld, ld, W, stream);
+				device_random_dense_rows(dA, rows_left, nleft, F, Sn_test, 0, salt, dM + (i64) k * ld, ld, W, stream, compact);
 				rr = stack_and_reduce(Sn_test);
 				if (rr == 0)
 					break;
@@ -655,7 +666,7 @@ void spasm_hip_schur_dense_randomized(const struct spasm_csr *A, const int *p, i
 		spasm_hip_dcsr dA{A->n, m, annz, devA.p, devA.j, devA.x};
 		spasm_hip_dwork *W = spasm_hip_dwork_create(N, m, 64);
 		u32 *dS = dalloc<u32>((i64) N * Sm);
-		device_random_dense_rows(dA, drows, n, F, N, w, call_id * 0x9E3779B97F4A7C15ULL, dS, Sm, W, stream);
+		device_random_dense_rows(dA, drows, n, F, N, w, call_id * 0x9E3779B97F4A7C15ULL, dS, Sm, W, stream, false);
 		std::vector<u32> h((size_t) N * Sm);
 		HIP_CHECK(hipMemcpy(h.data(), dS, (size_t) N * Sm * sizeof(u32), hipMemcpyDeviceToHost));
 		const u32 half = (u32) (prime / 2);

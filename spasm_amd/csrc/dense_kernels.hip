@@ -3007,9 +3007,11 @@ __device__ __forceinline__ uint32_t uniform_below(uint64_t h, uint32_t bound)
 
 // one wave per (combination k, term t).  w > 0: term t picks a random row of the list (coefficient 1
 // for t = 0); w == 0: term t is row t of the list, every row taken, random coefficient.
+// (colmap != nullptr: the accumulators only span the non-pivotal columns -- column j goes to colmap[j] - base; the caller has
+//  made sure that the rows hold no other column.  The same in the two kernels below.)
 __global__ __launch_bounds__(64) void combine_rows_kernel(const int64_t *Ap, const int *Aj, const int *Ax, const int *rows,
                                                          int nrows, int N, int w, int m, uint64_t salt,
-                                                         unsigned long long *Y, MontDev F)
+                                                         unsigned long long *Y, MontDev F, const uint32_t *colmap, uint32_t base)
 {
 	const int lane = threadIdx.x;
 	const int64_t terms = (w > 0) ? (int64_t) w : (int64_t) nrows;
@@ -3034,7 +3036,8 @@ __global__ __launch_bounds__(64) void combine_rows_kernel(const int64_t *Ap, con
 		for (int64_t px = Ap[i] + lane; px < Ap[i + 1]; px += 64) {
 			const int a = Ax[px];
 			const uint32_t v = (a < 0) ? (uint32_t) a + F.p : (uint32_t) a;
-			atomicAdd(&Yk[Aj[px]], (unsigned long long) montmul(cm, v % F.p, F));
+			const int j = Aj[px];
+			atomicAdd(&Yk[colmap != nullptr ? (int) (colmap[j] - base) : j], (unsigned long long) montmul(cm, v % F.p, F));
 		}
 	}
 }
@@ -3046,7 +3049,7 @@ __global__ __launch_bounds__(64) void combine_rows_kernel(const int64_t *Ap, con
 // laid out [column][16]: the sixteen adds of an entry fall into one 128-byte line and travel as one or two requests.
 // transpose_combinations_kernel puts the result where the other kernels expect it ([combination][column]).
 __global__ __launch_bounds__(64) void combine_all_rows_kernel(const int64_t *Ap, const int *Aj, const int *Ax, const int *rows, int nrows, int N, uint64_t salt,
-                                                             unsigned long long *Yt, MontDev F)
+                                                             unsigned long long *Yt, MontDev F, const uint32_t *colmap, uint32_t base)
 {
 	const int lane = threadIdx.x, k = lane & 15, e = lane >> 4;
 	for (int64_t t = blockIdx.x; t < nrows; t += gridDim.x) {
@@ -3057,8 +3060,9 @@ __global__ __launch_bounds__(64) void combine_all_rows_kernel(const int64_t *Ap,
 		for (int64_t px = Ap[i] + e; px < Ap[i + 1]; px += 4) {
 			const int a = Ax[px];
 			const uint32_t v = (a < 0) ? (uint32_t) a + F.p : (uint32_t) a;
+			const int j = Aj[px];
 			if (coeff != 0)
-				atomicAdd(&Yt[(int64_t) Aj[px] * 16 + k], (unsigned long long) montmul(cm, v % F.p, F));
+				atomicAdd(&Yt[(int64_t) (colmap != nullptr ? (int) (colmap[j] - base) : j) * 16 + k], (unsigned long long) montmul(cm, v % F.p, F));
 		}
 	}
 }
@@ -3073,7 +3077,8 @@ __global__ __launch_bounds__(64) void combine_all_rows_kernel(const int64_t *Ap,
 constexpr int CB_ROWS = 2048, CB_COLS = 1024, CB_THREADS = 256, CB_PER_THREAD = CB_ROWS / CB_THREADS;
 
 __global__ __launch_bounds__(CB_THREADS) void combine_all_rows_blocked_kernel(const int64_t *Ap, const int *Aj, const int *Ax, const int *rows, int nrows, int N, int m,
-                                                                              uint64_t salt, unsigned long long *Y, int *unsorted, MontDev F)
+                                                                              uint64_t salt, unsigned long long *Y, int *unsorted, MontDev F, const uint32_t *colmap,
+                                                                              uint32_t cbase)
 {
 	extern __shared__ __attribute__((aligned(16))) uint32_t cb_lds[];
 	uint32_t *acc = cb_lds;                                                            // [CB_COLS][N]
@@ -3111,7 +3116,8 @@ __global__ __launch_bounds__(CB_THREADS) void combine_all_rows_blocked_kernel(co
 		for (int q = 0; q < CB_PER_THREAD; q++) {
 			const unsigned short *cf = coef + (size_t) (tid + q * CB_THREADS) * N;
 			while (cur[q] < end[q]) {
-				const int j = Aj[cur[q]];
+				const int j0 = Aj[cur[q]];
+				const int j = colmap != nullptr ? (int) (colmap[j0] - cbase) : j0;          // (monotone in the column: rows stay sorted)
 				if (j >= hi)
 					break;
 				bad = bad || j <= prev[q];
@@ -3172,7 +3178,7 @@ __global__ __launch_bounds__(256) void dense_count_kernel(const unsigned long lo
 
 // pack row k (sorted by column); one workgroup per row
 __global__ __launch_bounds__(256) void dense_pack_kernel(const unsigned long long *Y, int N, int m, uint32_t p,
-                                                        const int64_t *Sp, int *Sj, int *Sx)
+                                                        const int64_t *Sp, int *Sj, int *Sx, const int *unmap)
 {
 	__shared__ int wave_tot[4];
 	const int k = blockIdx.x;
@@ -3275,7 +3281,7 @@ void launch_echelon_pack(const uint32_t *M, int64_t ld, int m, int k, const int 
 }
 
 void launch_combine(const int64_t *Ap, const int *Aj, const int *Ax, const int *rows, int nrows, int N, int w, int m,
-                    uint64_t salt, unsigned long long *Y, const Mont &M, hipStream_t stream)
+                    uint64_t salt, unsigned long long *Y, const Mont &M, hipStream_t stream, const uint32_t *colmap, uint32_t base)
 {
 	const int64_t terms = (w > 0) ? (int64_t) w : (int64_t) nrows;
 	const int64_t total = (int64_t) N * terms;
@@ -3291,7 +3297,7 @@ void launch_combine(const int64_t *Ap, const int *Aj, const int *Ax, const int *
 		HIP_CHECK(sh::malloc_or_trim((void **) &d_flag, sizeof(int)));
 		HIP_CHECK(hipMemsetAsync(d_flag, 0, sizeof(int), stream));
 		hipLaunchKernelGGL(combine_all_rows_blocked_kernel, dim3((unsigned) ((nrows + CB_ROWS - 1) / CB_ROWS)), dim3(CB_THREADS), lds, stream, Ap, Aj, Ax, rows, nrows,
-		                   N, m, salt, Y, d_flag, to_dev(M));
+		                   N, m, salt, Y, d_flag, to_dev(M), colmap, base);
 		HIP_CHECK(hipGetLastError());
 		int flag = 0;
 		HIP_CHECK(hipMemcpyAsync(&flag, d_flag, sizeof(int), hipMemcpyDeviceToHost, stream));
@@ -3305,7 +3311,7 @@ void launch_combine(const int64_t *Ap, const int *Aj, const int *Ax, const int *
 			HIP_CHECK(hipMemsetAsync(Y2, 0, count * sizeof(unsigned long long), stream));
 			HIP_CHECK(hipMemsetAsync(Yt, 0, (size_t) m * 16 * sizeof(unsigned long long), stream));
 			hipLaunchKernelGGL(combine_all_rows_kernel, dim3((unsigned) std::min<int64_t>(nrows, 65536)), dim3(64), 0, stream, Ap, Aj, Ax, rows, nrows, N, salt, Yt,
-			                   to_dev(M));
+			                   to_dev(M), colmap, base);
 			hipLaunchKernelGGL(transpose_combinations_kernel, dim3((unsigned) (((int64_t) m * 16 + 255) / 256)), dim3(256), 0, stream, Yt, N, m, Y2);
 			std::vector<unsigned long long> a(count), b(count);
 			HIP_CHECK(hipMemcpyAsync(a.data(), Y, count * sizeof(unsigned long long), hipMemcpyDeviceToHost, stream));
@@ -3332,7 +3338,7 @@ void launch_combine(const int64_t *Ap, const int *Aj, const int *Ax, const int *
 		unsigned long long *Yt = (unsigned long long *) big_alloc((size_t) m * 16 * sizeof(unsigned long long));
 		HIP_CHECK(hipMemsetAsync(Yt, 0, (size_t) m * 16 * sizeof(unsigned long long), stream));
 		hipLaunchKernelGGL(combine_all_rows_kernel, dim3((unsigned) std::min<int64_t>(nrows, 65536)), dim3(64), 0, stream, Ap, Aj, Ax, rows, nrows, N, salt, Yt,
-		                   to_dev(M));
+		                   to_dev(M), colmap, base);
 		hipLaunchKernelGGL(transpose_combinations_kernel, dim3((unsigned) (((int64_t) m * 16 + 255) / 256)), dim3(256), 0, stream, Yt, N, m, Y);
 		HIP_CHECK(hipGetLastError());
 		HIP_CHECK(hipStreamSynchronize(stream));
@@ -3341,8 +3347,36 @@ void launch_combine(const int64_t *Ap, const int *Aj, const int *Ax, const int *
 	}
 	const int blocks = (int) (total < 65536 ? (total > 0 ? total : 1) : 65536);
 	hipLaunchKernelGGL(combine_rows_kernel, dim3(blocks), dim3(64), 0, stream, Ap, Aj, Ax, rows, nrows, N, w, m, salt, Y,
-	                   to_dev(M));
+	                   to_dev(M), colmap, base);
 	HIP_CHECK(hipGetLastError());
+}
+
+// do the rows only hold columns whose label is >= base (non-pivotal columns of the factor)?  *flag is raised when one does not
+__global__ __launch_bounds__(256) void rows_nonpivotal_kernel(const int64_t *Ap, const int *Aj, const int *rows, int nrows, const uint32_t *lab, uint32_t base, int *flag)
+{
+	const int lane = threadIdx.x & 63;
+	bool bad = false;
+	for (int64_t t = (int64_t) blockIdx.x * 4 + (threadIdx.x >> 6); t < nrows; t += (int64_t) gridDim.x * 4) {
+		const int i = rows[t];
+		for (int64_t px = Ap[i] + lane; px < Ap[i + 1]; px += 64)
+			bad = bad || lab[Aj[px]] < base;
+	}
+	if (bad)
+		atomicOr(flag, 1);
+}
+
+bool rows_are_nonpivotal(const int64_t *Ap, const int *Aj, const int *rows, int nrows, const uint32_t *lab, uint32_t base, hipStream_t stream)
+{
+	int *d_flag = nullptr;
+	HIP_CHECK(sh::malloc_or_trim((void **) &d_flag, sizeof(int)));
+	HIP_CHECK(hipMemsetAsync(d_flag, 0, sizeof(int), stream));
+	hipLaunchKernelGGL(rows_nonpivotal_kernel, dim3((unsigned) std::max(1, std::min(nrows / 4 + 1, 16384))), dim3(256), 0, stream, Ap, Aj, rows, nrows, lab, base, d_flag);
+	HIP_CHECK(hipGetLastError());
+	int flag = 1;
+	HIP_CHECK(hipMemcpyAsync(&flag, d_flag, sizeof(int), hipMemcpyDeviceToHost, stream));
+	HIP_CHECK(hipStreamSynchronize(stream));
+	HIP_CHECK(hipFree(d_flag));
+	return flag == 0;
 }
 
 void launch_dense_count(const unsigned long long *Y, int N, int m, uint32_t p, int *row_len, hipStream_t stream)
@@ -3393,9 +3427,9 @@ void launch_sum_pieces(const uint32_t *parts, int64_t ldp, int N, int pieces, in
 }
 
 void launch_dense_pack(const unsigned long long *Y, int N, int m, uint32_t p, const int64_t *Sp, int *Sj, int *Sx,
-                       hipStream_t stream)
+                       hipStream_t stream, const int *unmap)
 {
-	hipLaunchKernelGGL(dense_pack_kernel, dim3(N), dim3(256), 0, stream, Y, N, m, p, Sp, Sj, Sx);
+	hipLaunchKernelGGL(dense_pack_kernel, dim3(N), dim3(256), 0, stream, Y, N, m, p, Sp, Sj, Sx, unmap);
 	HIP_CHECK(hipGetLastError());
 }
 

@@ -117,11 +117,20 @@ void *big_alloc(size_t bytes)
 		bytes = 1;
 	void *ptr = nullptr;
 	if (bytes >= BIG_MIN) {
+		// Sizes in steps of an eighth of their leading power of two, and any parked block of up to twice the size will do: the
+		// large buffers of a driver call -- row pools, the Schur complement, accumulators, echelon stacks -- follow the pivot set of
+		// the call, which depends on timing, and differ by tens of percent from one call to the next.  With exact sizes and a
+		// window of 1.5x the third mk15.b4 call of a process still fetched 62 GB from the device (3.5 s inside one sparse round;
+		// spasm_hip_echelonize_counters: block_cache_miss_bytes), the fourth 21 GB.
+		size_t step = (size_t) 1 << 20;
+		while ((step << 4) <= bytes)
+			step <<= 1;
+		bytes = (bytes + step - 1) / step * step;
 		std::lock_guard<std::mutex> guard(g_big.mutex);
 		int best = -1;
 		for (size_t t = 0; t < g_big.free_blocks.size(); t++) {
 			const size_t have = g_big.free_blocks[t].second;
-			if (have >= bytes && have <= bytes + bytes / 2 && (best < 0 || have < g_big.free_blocks[(size_t) best].second))
+			if (have >= bytes && have <= 2 * bytes && (best < 0 || have < g_big.free_blocks[(size_t) best].second))
 				best = (int) t;
 		}
 		if (best >= 0) {

@@ -262,30 +262,37 @@ def _csr_of_triplets(prime, n, m, ti, tj, tx):
     return spasm_amd.Csr(n, m, p, np.ascontiguousarray(np.asarray(tj)[order], np.int32), x, prime)
 
 
-def round0(name, prime=PRIME, cache=True, threads=1):
+def round0(name, prime=PRIME, cache=True, threads=1, labelled=False):
     """(A, rows, F, source): the matrix, its structural pivots (single-threaded search by default: the same pivots on
     every rank and in every run; threads=0: the library's default thread count -- the pivots then depend on timing, which
-    is fine for a timing run on one process) and the non-pivotal rows -- the input of the first Schur complement."""
+    is fine for a timing run on one process) and the non-pivotal rows -- the input of the first Schur complement.
+    threads=1: the row-order search whose outcome is the reference's with one thread (the pivot set of the headline step
+    since round 1: 140,087 rows on mk13.b5) -- or, labelled=True, the sequential search with depth labels (round 5: as
+    deterministic, another valid pivot set, 10-20x faster: what fixes the pivot set of the large stand-ins)."""
     import spasm_amd
-    path = os.path.join(tempfile.gettempdir(), "spasm_amd_r0_v3_%s_%d%s.npz" % (name.replace("/", "_"), prime, "" if threads == 1 else "_mt"))
+    path = os.path.join(tempfile.gettempdir(), "spasm_amd_r0_v3_%s_%d%s.npz" % (name.replace("/", "_"), prime, ("_lab" if labelled else "") if threads == 1 else "_mt"))
     if cache and os.path.exists(path):
         z = np.load(path, allow_pickle=False)
         A = spasm_amd.Csr(int(z["n"]), int(z["m"]), z["Ap"], z["Aj"], z["Ax"], prime)
         F = spasm_amd.Fact(spasm_amd.Csr(int(z["r"]), int(z["m"]), z["Up"], z["Uj"], z["Ux"], prime), z["qinv"])
         return A, z["rows"], F, str(z["source"])
     A, source = load_matrix(name, prime)
-    saved = os.environ.get("SPASM_HIP_THREADS")
+    saved = {k: os.environ.get(k) for k in ("SPASM_HIP_THREADS", "SPASM_HIP_PIVOT_LABELS", "SPASM_HIP_EXPERIMENT")}
     if threads > 0:
         os.environ["SPASM_HIP_THREADS"] = str(threads)
     else:
         os.environ.pop("SPASM_HIP_THREADS", None)
+    if threads == 1 and not labelled:
+        os.environ["SPASM_HIP_PIVOT_LABELS"] = "0"
+        os.environ["SPASM_HIP_EXPERIMENT"] = "1"
     try:
         npiv, perm, F = spasm_amd.pivots_extract_structural(A, spasm_amd.empty_fact(A.m, prime))
     finally:
-        if saved is None:
-            os.environ.pop("SPASM_HIP_THREADS", None)
-        else:
-            os.environ["SPASM_HIP_THREADS"] = saved
+        for k, v in saved.items():
+            if v is None:
+                os.environ.pop(k, None)
+            else:
+                os.environ[k] = v
     rows = np.ascontiguousarray(perm[npiv:], np.int32)
     if cache:
         tmp = "%s.%d.tmp.npz" % (path, os.getpid())          # ranks build concurrently: publish atomically
