@@ -3009,6 +3009,9 @@ __device__ __forceinline__ uint32_t uniform_below(uint64_t h, uint32_t bound)
 // for t = 0); w == 0: term t is row t of the list, every row taken, random coefficient.
 // (colmap != nullptr: the accumulators only span the non-pivotal columns -- column j goes to colmap[j] - base; the caller has
 //  made sure that the rows hold no other column.  The same in the two kernels below.)
+//  MAPPED is a template parameter, not a test of the pointer: with `colmap != nullptr ? colmap[j] - base : j` the compiler
+//  turned the choice into a select and loaded colmap[j] from a null pointer.)
+template <bool MAPPED>
 __global__ __launch_bounds__(64) void combine_rows_kernel(const int64_t *Ap, const int *Aj, const int *Ax, const int *rows,
                                                          int nrows, int N, int w, int m, uint64_t salt,
                                                          unsigned long long *Y, MontDev F, const uint32_t *colmap, uint32_t base)
@@ -3037,7 +3040,10 @@ __global__ __launch_bounds__(64) void combine_rows_kernel(const int64_t *Ap, con
 			const int a = Ax[px];
 			const uint32_t v = (a < 0) ? (uint32_t) a + F.p : (uint32_t) a;
 			const int j = Aj[px];
-			atomicAdd(&Yk[colmap != nullptr ? (int) (colmap[j] - base) : j], (unsigned long long) montmul(cm, v % F.p, F));
+			int jc = j;
+			if constexpr (MAPPED)
+				jc = (int) (colmap[j] - base);
+			atomicAdd(&Yk[jc], (unsigned long long) montmul(cm, v % F.p, F));
 		}
 	}
 }
@@ -3048,6 +3054,7 @@ __global__ __launch_bounds__(64) void combine_rows_kernel(const int64_t *Ap, con
 // side takes them.  Here a wave takes a row ONCE, sixteen lanes per entry -- one per combination -- and the accumulator is
 // laid out [column][16]: the sixteen adds of an entry fall into one 128-byte line and travel as one or two requests.
 // transpose_combinations_kernel puts the result where the other kernels expect it ([combination][column]).
+template <bool MAPPED>
 __global__ __launch_bounds__(64) void combine_all_rows_kernel(const int64_t *Ap, const int *Aj, const int *Ax, const int *rows, int nrows, int N, uint64_t salt,
                                                              unsigned long long *Yt, MontDev F, const uint32_t *colmap, uint32_t base)
 {
@@ -3060,9 +3067,11 @@ __global__ __launch_bounds__(64) void combine_all_rows_kernel(const int64_t *Ap,
 		for (int64_t px = Ap[i] + e; px < Ap[i + 1]; px += 4) {
 			const int a = Ax[px];
 			const uint32_t v = (a < 0) ? (uint32_t) a + F.p : (uint32_t) a;
-			const int j = Aj[px];
+			int j = Aj[px];
+			if constexpr (MAPPED)
+				j = (int) (colmap[j] - base);
 			if (coeff != 0)
-				atomicAdd(&Yt[(int64_t) (colmap != nullptr ? (int) (colmap[j] - base) : j) * 16 + k], (unsigned long long) montmul(cm, v % F.p, F));
+				atomicAdd(&Yt[(int64_t) j * 16 + k], (unsigned long long) montmul(cm, v % F.p, F));
 		}
 	}
 }
@@ -3076,6 +3085,7 @@ __global__ __launch_bounds__(64) void combine_all_rows_kernel(const int64_t *Ap,
 // batch with combine_all_rows_kernel).
 constexpr int CB_ROWS = 2048, CB_COLS = 1024, CB_THREADS = 256, CB_PER_THREAD = CB_ROWS / CB_THREADS;
 
+template <bool MAPPED>
 __global__ __launch_bounds__(CB_THREADS) void combine_all_rows_blocked_kernel(const int64_t *Ap, const int *Aj, const int *Ax, const int *rows, int nrows, int N, int m,
                                                                               uint64_t salt, unsigned long long *Y, int *unsorted, MontDev F, const uint32_t *colmap,
                                                                               uint32_t cbase)
@@ -3116,8 +3126,9 @@ __global__ __launch_bounds__(CB_THREADS) void combine_all_rows_blocked_kernel(co
 		for (int q = 0; q < CB_PER_THREAD; q++) {
 			const unsigned short *cf = coef + (size_t) (tid + q * CB_THREADS) * N;
 			while (cur[q] < end[q]) {
-				const int j0 = Aj[cur[q]];
-				const int j = colmap != nullptr ? (int) (colmap[j0] - cbase) : j0;          // (monotone in the column: rows stay sorted)
+				int j = Aj[cur[q]];
+				if constexpr (MAPPED)
+					j = (int) (colmap[j] - cbase);          // (monotone in the column: rows stay sorted)
 				if (j >= hi)
 					break;
 				bad = bad || j <= prev[q];
@@ -3177,6 +3188,7 @@ __global__ __launch_bounds__(256) void dense_count_kernel(const unsigned long lo
 }
 
 // pack row k (sorted by column); one workgroup per row
+template <bool MAPPED>
 __global__ __launch_bounds__(256) void dense_pack_kernel(const unsigned long long *Y, int N, int m, uint32_t p,
                                                         const int64_t *Sp, int *Sj, int *Sx, const int *unmap)
 {
@@ -3290,14 +3302,19 @@ void launch_combine(const int64_t *Ap, const int *Aj, const int *Ax, const int *
 		const size_t lds = (size_t) CB_COLS * N * sizeof(uint32_t) + (size_t) CB_ROWS * N * sizeof(unsigned short);
 		static size_t configured = 0;
 		if (lds > configured) {
-			HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(&combine_all_rows_blocked_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int) lds));
+			HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(&combine_all_rows_blocked_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int) lds));
+			HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(&combine_all_rows_blocked_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int) lds));
 			configured = lds;
 		}
 		int *d_flag = nullptr;
 		HIP_CHECK(sh::malloc_or_trim((void **) &d_flag, sizeof(int)));
 		HIP_CHECK(hipMemsetAsync(d_flag, 0, sizeof(int), stream));
-		hipLaunchKernelGGL(combine_all_rows_blocked_kernel, dim3((unsigned) ((nrows + CB_ROWS - 1) / CB_ROWS)), dim3(CB_THREADS), lds, stream, Ap, Aj, Ax, rows, nrows,
-		                   N, m, salt, Y, d_flag, to_dev(M), colmap, base);
+		if (colmap != nullptr)
+			hipLaunchKernelGGL(combine_all_rows_blocked_kernel<true>, dim3((unsigned) ((nrows + CB_ROWS - 1) / CB_ROWS)), dim3(CB_THREADS), lds, stream, Ap, Aj, Ax, rows, nrows,
+			                   N, m, salt, Y, d_flag, to_dev(M), colmap, base);
+		else
+			hipLaunchKernelGGL(combine_all_rows_blocked_kernel<false>, dim3((unsigned) ((nrows + CB_ROWS - 1) / CB_ROWS)), dim3(CB_THREADS), lds, stream, Ap, Aj, Ax, rows, nrows,
+			                   N, m, salt, Y, d_flag, to_dev(M), colmap, base);
 		HIP_CHECK(hipGetLastError());
 		int flag = 0;
 		HIP_CHECK(hipMemcpyAsync(&flag, d_flag, sizeof(int), hipMemcpyDeviceToHost, stream));
@@ -3310,8 +3327,12 @@ void launch_combine(const int64_t *Ap, const int *Aj, const int *Ax, const int *
 			unsigned long long *Yt = (unsigned long long *) big_alloc((size_t) m * 16 * sizeof(unsigned long long));
 			HIP_CHECK(hipMemsetAsync(Y2, 0, count * sizeof(unsigned long long), stream));
 			HIP_CHECK(hipMemsetAsync(Yt, 0, (size_t) m * 16 * sizeof(unsigned long long), stream));
-			hipLaunchKernelGGL(combine_all_rows_kernel, dim3((unsigned) std::min<int64_t>(nrows, 65536)), dim3(64), 0, stream, Ap, Aj, Ax, rows, nrows, N, salt, Yt,
-			                   to_dev(M), colmap, base);
+			if (colmap != nullptr)
+				hipLaunchKernelGGL(combine_all_rows_kernel<true>, dim3((unsigned) std::min<int64_t>(nrows, 65536)), dim3(64), 0, stream, Ap, Aj, Ax, rows, nrows, N, salt, Yt,
+				                   to_dev(M), colmap, base);
+			else
+				hipLaunchKernelGGL(combine_all_rows_kernel<false>, dim3((unsigned) std::min<int64_t>(nrows, 65536)), dim3(64), 0, stream, Ap, Aj, Ax, rows, nrows, N, salt, Yt,
+				                   to_dev(M), colmap, base);
 			hipLaunchKernelGGL(transpose_combinations_kernel, dim3((unsigned) (((int64_t) m * 16 + 255) / 256)), dim3(256), 0, stream, Yt, N, m, Y2);
 			std::vector<unsigned long long> a(count), b(count);
 			HIP_CHECK(hipMemcpyAsync(a.data(), Y, count * sizeof(unsigned long long), hipMemcpyDeviceToHost, stream));
@@ -3337,8 +3358,12 @@ void launch_combine(const int64_t *Ap, const int *Aj, const int *Ax, const int *
 		// every row, few combinations: each row once, the combinations side by side (combine_all_rows_kernel); Y arrives zeroed
 		unsigned long long *Yt = (unsigned long long *) big_alloc((size_t) m * 16 * sizeof(unsigned long long));
 		HIP_CHECK(hipMemsetAsync(Yt, 0, (size_t) m * 16 * sizeof(unsigned long long), stream));
-		hipLaunchKernelGGL(combine_all_rows_kernel, dim3((unsigned) std::min<int64_t>(nrows, 65536)), dim3(64), 0, stream, Ap, Aj, Ax, rows, nrows, N, salt, Yt,
-		                   to_dev(M), colmap, base);
+		if (colmap != nullptr)
+			hipLaunchKernelGGL(combine_all_rows_kernel<true>, dim3((unsigned) std::min<int64_t>(nrows, 65536)), dim3(64), 0, stream, Ap, Aj, Ax, rows, nrows, N, salt, Yt,
+			                   to_dev(M), colmap, base);
+		else
+			hipLaunchKernelGGL(combine_all_rows_kernel<false>, dim3((unsigned) std::min<int64_t>(nrows, 65536)), dim3(64), 0, stream, Ap, Aj, Ax, rows, nrows, N, salt, Yt,
+			                   to_dev(M), colmap, base);
 		hipLaunchKernelGGL(transpose_combinations_kernel, dim3((unsigned) (((int64_t) m * 16 + 255) / 256)), dim3(256), 0, stream, Yt, N, m, Y);
 		HIP_CHECK(hipGetLastError());
 		HIP_CHECK(hipStreamSynchronize(stream));
@@ -3346,8 +3371,12 @@ void launch_combine(const int64_t *Ap, const int *Aj, const int *Ax, const int *
 		return;
 	}
 	const int blocks = (int) (total < 65536 ? (total > 0 ? total : 1) : 65536);
-	hipLaunchKernelGGL(combine_rows_kernel, dim3(blocks), dim3(64), 0, stream, Ap, Aj, Ax, rows, nrows, N, w, m, salt, Y,
-	                   to_dev(M), colmap, base);
+	if (colmap != nullptr)
+		hipLaunchKernelGGL(combine_rows_kernel<true>, dim3(blocks), dim3(64), 0, stream, Ap, Aj, Ax, rows, nrows, N, w, m, salt, Y,
+		                   to_dev(M), colmap, base);
+	else
+		hipLaunchKernelGGL(combine_rows_kernel<false>, dim3(blocks), dim3(64), 0, stream, Ap, Aj, Ax, rows, nrows, N, w, m, salt, Y,
+		                   to_dev(M), colmap, base);
 	HIP_CHECK(hipGetLastError());
 }
 
@@ -3429,7 +3458,10 @@ void launch_sum_pieces(const uint32_t *parts, int64_t ldp, int N, int pieces, in
 void launch_dense_pack(const unsigned long long *Y, int N, int m, uint32_t p, const int64_t *Sp, int *Sj, int *Sx,
                        hipStream_t stream, const int *unmap)
 {
-	hipLaunchKernelGGL(dense_pack_kernel, dim3(N), dim3(256), 0, stream, Y, N, m, p, Sp, Sj, Sx, unmap);
+	if (unmap != nullptr)
+		hipLaunchKernelGGL(dense_pack_kernel<true>, dim3(N), dim3(256), 0, stream, Y, N, m, p, Sp, Sj, Sx, unmap);
+	else
+		hipLaunchKernelGGL(dense_pack_kernel<false>, dim3(N), dim3(256), 0, stream, Y, N, m, p, Sp, Sj, Sx, unmap);
 	HIP_CHECK(hipGetLastError());
 }
 

@@ -122,15 +122,17 @@ void *big_alloc(size_t bytes)
 		// the call, which depends on timing, and differ by tens of percent from one call to the next.  With exact sizes and a
 		// window of 1.5x the third mk15.b4 call of a process still fetched 62 GB from the device (3.5 s inside one sparse round;
 		// spasm_hip_echelonize_counters: block_cache_miss_bytes), the fourth 21 GB.
+		static const bool classes = env_int("SPASM_HIP_BLOCK_CLASSES", 1) != 0;
 		size_t step = (size_t) 1 << 20;
 		while ((step << 4) <= bytes)
 			step <<= 1;
-		bytes = (bytes + step - 1) / step * step;
+		if (classes)
+			bytes = (bytes + step - 1) / step * step;
 		std::lock_guard<std::mutex> guard(g_big.mutex);
 		int best = -1;
 		for (size_t t = 0; t < g_big.free_blocks.size(); t++) {
 			const size_t have = g_big.free_blocks[t].second;
-			if (have >= bytes && have <= 2 * bytes && (best < 0 || have < g_big.free_blocks[(size_t) best].second))
+			if (have >= bytes && have <= (classes ? 2 * bytes : bytes + bytes / 2) && (best < 0 || have < g_big.free_blocks[(size_t) best].second))
 				best = (int) t;
 		}
 		if (best >= 0) {
