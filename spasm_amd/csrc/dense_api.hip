@@ -302,6 +302,31 @@ void device_random_dense_rows(const spasm_hip_dcsr &dA, const int *d_rows, int n
 		spasm_hip_dcsr dYcsr{N, m_all, ynnz, dYp, dYj, dYx};
 		dschur_dense_impl(&dYcsr, dident, N, F, W, d_S, ldS, stream, nullptr);
 	}
+	if (compact && env_int("SPASM_HIP_COMPACT_CHECK", 0) != 0) {
+		// (tests) the same combinations with accumulators over all the columns: the dense rows must be the same
+		u32 *d_ref = (u32 *) big_alloc((size_t) N * (size_t) ldS * sizeof(u32));
+		device_random_dense_rows(dA, d_rows, n, F, N, w, salt, d_ref, ldS, W, stream, false);
+		std::vector<u32> x((size_t) N * (size_t) ldS), y((size_t) N * (size_t) ldS);
+		HIP_CHECK(hipMemcpy(x.data(), d_S, x.size() * sizeof(u32), hipMemcpyDeviceToHost));
+		HIP_CHECK(hipMemcpy(y.data(), d_ref, y.size() * sizeof(u32), hipMemcpyDeviceToHost));
+		size_t differ = 0, nzx = 0, nzy = 0, first = (size_t) -1;
+		for (size_t k = 0; k < (size_t) N; k++)
+			for (size_t j = 0; j < (size_t) F->Sm; j++) {
+				const size_t t = k * (size_t) ldS + j;
+				nzx += x[t] != 0;
+				nzy += y[t] != 0;
+				if (x[t] != y[t]) {
+					differ += 1;
+					if (first == (size_t) -1)
+						first = t;
+				}
+			}
+		logmsg("[dense rows/check] compact against full accumulators: %zu of %zu entries differ (non-zero: %zu / %zu; first at row %zu column %zu; %" PRId64 " packed entries)\n",
+		       differ, (size_t) N * (size_t) F->Sm, nzx, nzy, first == (size_t) -1 ? 0 : first / (size_t) ldS, first == (size_t) -1 ? 0 : first % (size_t) ldS, ynnz);
+		big_free(d_ref);
+		if (differ != 0)
+			die("combinations formed on the non-pivotal columns only differ from those formed on all columns (%zu entries)", differ);
+	}
 	if (verbose() >= 2)
 		logmsg("[dense rows] %d combinations: combine + pack %.3fs (%" PRId64 " entries), reduction %.3fs\n", N, t1 - t0, ynnz, wtime() - t1);
 	sh::big_free(dident);

@@ -3212,7 +3212,10 @@ __global__ __launch_bounds__(256) void dense_pack_kernel(const unsigned long lon
 		}
 		if (keep) {
 			const int64_t dst = wpos + before + __popcll(mk & ((1ull << lane) - 1ull));
-			Sj[dst] = j;
+			int col = j;
+			if constexpr (MAPPED)          // (accumulators over the non-pivotal columns only: back to the column of the matrix)
+				col = unmap[j];
+			Sj[dst] = col;
 			// balanced representative (for p > 2^31 a residue >= 2^31 would read back as a negative int and be shifted by p)
 			Sx[dst] = (v > p / 2) ? (int) (v - p) : (int) v;
 		}

@@ -328,7 +328,11 @@ def test_multi_round_stand_in(name, threshold, min_sparse_rounds, monkeypatch):
     ranks = []
     # (the combinations of all rows that end the low-rank finish are formed twice -- block sums in LDS, and one atomic per
     #  term -- and the library dies if the sums differ mod p: mk14.b4 is where the first kernel runs on 1e9 entries)
+    monkeypatch.setenv("SPASM_HIP_EXPERIMENT", "1")          # (the two checks below are switches outside the supported list)
     monkeypatch.setenv("SPASM_HIP_COMBINE_CHECK", "1")
+    # (... and the combinations of rows of a Schur complement are formed on its non-pivotal columns only: once more on all
+    #  columns, and the library dies if the dense rows differ)
+    monkeypatch.setenv("SPASM_HIP_COMPACT_CHECK", "1")
     for _ in range(2):
         F = spasm_amd.echelonize(A, o)
         prof = spasm_amd.echelonize_profile()
@@ -349,7 +353,7 @@ def test_multi_round_stand_in(name, threshold, min_sparse_rounds, monkeypatch):
 
 
 @pytest.mark.parametrize("name,threshold,min_sparse_rounds", [("mk13.b4", 0.05, 2), ("ch7-8.b5", 0.01, 1), ("mk13.b5", 0.05, 2), ("mk14.b4", 0.05, 2)])
-def test_flow_without_the_greedy_pivot_search(name, threshold, min_sparse_rounds):
+def test_flow_without_the_greedy_pivot_search(name, threshold, min_sparse_rounds, monkeypatch):
     """the option of BASELINE configs[4] (M0,6-D9, "greedy pivot search disabled": tools/echelonize.c:36 -> spasm_pivots.c:315;
     the data file cannot be fetched, the FLOW runs on every generated matrix): with Faugere-Lachartre pivots only the first
     Schur complement is larger and fills in, the driver runs several sparse rounds (spasm_echelonize.c:525-565) -- each with a
@@ -359,6 +363,11 @@ def test_flow_without_the_greedy_pivot_search(name, threshold, min_sparse_rounds
     o = spasm_amd.default_opts()
     o.enable_greedy_pivot_search = 0
     o.sparsity_threshold = threshold
+    # (mk13.b5 ends on the round limit with a Schur complement of 152,000 rows on 17,000 of 135,000 columns: the combinations of
+    #  the low-rank finish are formed on those columns only -- and, under this switch, once more on all columns: the library
+    #  dies if the dense rows differ)
+    monkeypatch.setenv("SPASM_HIP_EXPERIMENT", "1")
+    monkeypatch.setenv("SPASM_HIP_COMPACT_CHECK", "1")
     for _ in range(2):
         F = spasm_amd.echelonize(A, o)
         prof = spasm_amd.echelonize_profile()
