@@ -190,17 +190,18 @@ struct SpImage {
 	bool planned = false;     // the dependency tables below are on the device
 	bool valid = false;       // the fragments hold R
 	bool failed = false;      // the last build gave up (R is not sparse: the pool budget ran out)
+	bool wide = false;        // 8-byte entries (column, plain residue) and 32-bit accumulators: primes beyond the signed 16-bit arithmetic
 	int r = 0, Sm = 0, nseg = 0, nlevels = 0;
 	int64_t ndeps = 0, nnp = 0;
 	std::vector<int> lvl_lo;          // first compact row of every level (nlevels + 1 entries)
 	int *d_col = nullptr;             // column -> compact row id of its pivot, or r + index among the non-pivotal columns
 	uint64_t *d_dep_rp = nullptr;     // per compact row: its pivotal entries ...
-	uint2 *d_dep = nullptr;           // ... (compact row of the pivot, NEGATED balanced coefficient)
+	uint2 *d_dep = nullptr;           // ... (compact row of the pivot, NEGATED balanced coefficient; wide: Montgomery form of the negated coefficient)
 	uint64_t *d_np_rp = nullptr;      // per compact row: its non-pivotal entries ...
-	uint2 *d_np = nullptr;            // ... (index among the non-pivotal columns, balanced value)
+	uint2 *d_np = nullptr;            // ... (index among the non-pivotal columns, balanced value; wide: plain residue)
 	uint64_t *d_frag = nullptr;       // r * nseg words: chunk << 54 | offset << 14 | length
 	uint32_t *d_chunk[SP_MAX_CHUNKS] = {};
-	int64_t chunk_cap[SP_MAX_CHUNKS] = {};        // entries
+	int64_t chunk_cap[SP_MAX_CHUNKS] = {};        // entries (4 bytes each; wide: 8)
 	int nchunks = 0;
 	unsigned long long *d_shard = nullptr;        // SP_SHARDS x 16 words: [0] cursor, [1] limit (entries inside the current chunk)
 	unsigned long long *d_stat = nullptr;         // 8 counters of the build (see sparse_image.hip)

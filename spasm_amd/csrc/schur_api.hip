@@ -46,7 +46,7 @@ bool sparse_image_possible(int64_t prime);
 void sparse_image_plan(const FactPlan &P, spasm_hip_dfact *F, hipStream_t stream);
 void sparse_image_free(spasm_hip_dfact *F);
 bool sparse_image_build(const spasm_hip_dfact *F, hipStream_t stream);
-void launch_sparse_image_apply(const SchurArgs &a, const spasm_hip_dfact *F, uint32_t *dense_out, int64_t ldS, uint32_t *fpool, int64_t fcap,
+void launch_sparse_image_apply(const SchurArgs &a, const spasm_hip_dfact *F, uint32_t *fpool, uint32_t *fpool_v, int64_t fcap,
                                uint64_t *T, unsigned long long *block_sum, int64_t *Sp, int *Sj, int *Sx, int64_t cap, hipStream_t stream,
                                hipEvent_t ev_gather);
 bool sparse_image_wanted(const spasm_hip_dfact *F, bool other_path_forced, int nrows);
@@ -1434,7 +1434,7 @@ int dschur_impl(const spasm_hip_dcsr *A, const int *d_rows, int nrows, const spa
 		if (W->d_lb_status == nullptr)
 			W->d_lb_status = dalloc<unsigned long long>((i64) W->max_rows + 16 + 16 * 16);
 		// the fragments of S go to the row pool of the workspace (4 bytes an entry: pool_cap entries fit pool_j)
-		launch_sparse_image_apply(a, F, nullptr, 0, reinterpret_cast<uint32_t *>(W->d_pool_j), W->pool_cap, W->d_spT, W->d_lb_status, W->d_Sp, W->d_Sj,
+		launch_sparse_image_apply(a, F, reinterpret_cast<uint32_t *>(W->d_pool_j), reinterpret_cast<uint32_t *>(W->d_pool_x), W->pool_cap, W->d_spT, W->d_lb_status, W->d_Sp, W->d_Sj,
 		                          W->d_Sx, W->pool_cap, stream, W->ev[6]);
 		HIP_CHECK(hipEventRecord(W->ev[3], stream));
 		HIP_CHECK(hipEventRecord(W->ev[4], stream));

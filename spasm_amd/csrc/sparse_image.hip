@@ -32,6 +32,7 @@
 #include <cinttypes>
 #include <chrono>
 #include <thread>
+#include <type_traits>
 #include <vector>
 
 #include "device_types.h"
@@ -320,6 +321,121 @@ __device__ __forceinline__ void sp_accumulate(WaveLds &L, uint64_t f, int coef, 
 	}
 }
 
+// ---- the same for EVERY odd prime below 2^32 (round 5): 32-bit accumulators, 8-byte fragment entries -------------------------------
+// The signed 16-bit arithmetic above stops at p = 44,927; the reference takes every prime below 2^32 (spasm_ZZp.c:5-15; its own
+// tests run 65537, 67108859, 189812507, 4294967291), and a GL7d19-class factor with such a prime had no image at all (the dense
+// one is out of reach by size): minutes in the row-group kernel.  Same segments, same fragments, same drivers; what changes is
+// what an entry is: (column inside the segment, plain residue in [0, p)) in 8 bytes, accumulators of 32 bits (16 KB of LDS per
+// wave instead of 8: eight waves per CU instead of fourteen), coefficients in Montgomery form (c * 2^32 mod p: one montmul per
+// multiply-add, exact for every odd p < 2^32).  Fragments of S: columns and values in two arrays (the row pool of the workspace
+// is two arrays of 32-bit words).
+struct __attribute__((aligned(16))) WaveLds32 {
+	uint32_t acc[SP_SEG];
+	uint32_t bm[BMW];
+	uint16_t list[LISTCAP];
+};
+
+// column of the segment -> index of its accumulator: lane L of the lane-by-lane walk owns the 64 columns [64 L, 64 L + 64),
+// whose words would all start on the same bank: rotated by L inside the chunk
+__device__ __forceinline__ uint32_t sp_swz32(uint32_t c) { return (c & ~63u) | ((c + (c >> 6)) & 63u); }
+
+__device__ __forceinline__ void sp_lds_init(WaveLds32 &L, int lane)
+{
+	uint4 *a4 = reinterpret_cast<uint4 *>(L.acc);
+#pragma unroll
+	for (int t = 0; t < SP_SEG / 4 / 64; t++)
+		a4[t * 64 + lane] = uint4{0u, 0u, 0u, 0u};
+	for (int t = lane; t < BMW; t += 64)
+		L.bm[t] = 0;
+}
+
+template <bool SC1> __device__ __forceinline__ uint64_t sp_ld64(const uint64_t *p)
+{
+	if constexpr (SC1)
+		return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+	else
+		return *p;
+}
+
+template <bool SC1> __device__ __forceinline__ void sp_st64(uint64_t *p, uint64_t v)
+{
+	if constexpr (SC1)
+		__hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+	else
+		*p = v;
+}
+
+__device__ __forceinline__ uint32_t sp_addmod(uint32_t a, uint32_t b, uint32_t p)          // a, b in [0, p), any p < 2^32
+{
+	uint32_t s = a + b;
+	if (s < a || s >= p)
+		s -= p;
+	return s;
+}
+
+// acc[column] += coef * value for one entry (column | value << 32), coef in Montgomery form
+__device__ __forceinline__ void sp_entry(WaveLds32 &L, uint64_t e, uint32_t coef, const MontDev &F)
+{
+	const uint32_t c = (uint32_t) e & 0xFFFFu;
+	uint32_t *a = L.acc + sp_swz32(c);
+	*a = sp_addmod(*a, montmul(coef, (uint32_t) (e >> 32), F), F.p);
+	atomicOr(&L.bm[c >> 5], 1u << (c & 31u));
+}
+
+__device__ __forceinline__ void sp_own_entry(WaveLds32 &L, uint32_t c, uint32_t val, const MontDev &F)
+{
+	uint32_t *a = L.acc + sp_swz32(c);
+	*a = sp_addmod(*a, val, F.p);
+	atomicOr(&L.bm[c >> 5], 1u << (c & 31u));
+}
+
+__device__ __forceinline__ const uint64_t *frag_ptr64(const SpPools &P, uint64_t f)
+{
+	return reinterpret_cast<const uint64_t *>(P.base[(f >> (SP_LEN_BITS + SP_OFF_BITS)) & 15u]) + ((f >> SP_LEN_BITS) & OFF_MASK);
+}
+
+// acc += coef * fragment for every lane whose fragment word is not empty and for which `take` holds: the shape of
+// sp_accumulate above (four fragments' first 64 entries in flight together), 8-byte entries
+template <bool SC1>
+__device__ __forceinline__ void sp_accumulate(WaveLds32 &L, uint64_t f, uint32_t coef, bool take, const SpPools &pools, int lane, const MontDev &F,
+                                              unsigned long long &ops)
+{
+	uint64_t live = __ballot(take && (f & LEN_MASK) != 0);
+	while (live != 0) {
+		const uint64_t *src[4];
+		int len[4];
+		uint32_t cf[4];
+		uint64_t head[4];
+#pragma unroll
+		for (int u = 0; u < 4; u++) {
+			len[u] = 0;
+			cf[u] = 0;
+			src[u] = nullptr;
+			head[u] = 0;
+			if (live != 0) {
+				const int s = __builtin_ctzll(live);
+				live &= live - 1;
+				const uint64_t fc = readlane64(f, s);
+				cf[u] = (uint32_t) __builtin_amdgcn_readlane((int) coef, s);
+				src[u] = frag_ptr64(pools, fc);
+				len[u] = (int) (fc & LEN_MASK);
+				head[u] = (lane < len[u]) ? sp_ld64<SC1>(src[u] + lane) : 0ull;
+			}
+		}
+#pragma unroll
+		for (int u = 0; u < 4; u++) {
+			if (len[u] == 0)
+				continue;
+			ops += (unsigned long long) len[u];
+			if (lane < len[u])
+				sp_entry(L, head[u], cf[u], F);
+			for (int i = lane + 64; i < len[u]; i += 64)
+				sp_entry(L, sp_ld64<SC1>(src[u] + i), cf[u], F);
+			__builtin_amdgcn_wave_barrier();
+		}
+	}
+}
+
 // inclusive prefix sum over the 64 lanes (DPP: shifts inside the rows of 16 lanes, then the row totals handed on)
 __device__ __forceinline__ int wave_incl_scan(int x)
 {
@@ -346,7 +462,7 @@ struct SpTouched {
 	uint32_t prefix;              // ... and the touched columns before them
 };
 
-__device__ __forceinline__ void sp_touched(WaveLds &L, int lane, SpTouched &T)
+template <typename LDS> __device__ __forceinline__ void sp_touched(LDS &L, int lane, SpTouched &T)
 {
 	const uint32_t w0 = L.bm[lane], w1 = L.bm[64 + lane], w2 = (WPL > 2) ? L.bm[(128 + lane) % BMW] : 0u, w3 = (WPL > 2) ? L.bm[(192 + lane) % BMW] : 0u;
 	const int c0 = __popc(w0), c1 = __popc(w1), c2 = __popc(w2), c3 = __popc(w3);
@@ -514,24 +630,69 @@ __device__ __forceinline__ void sp_discard(WaveLds &L, const SpTouched &T, int l
 	}
 }
 
-// the whole segment as dense values in [0, p) (ncols of them), accumulators and bitmap back to zero
-__device__ __forceinline__ void sp_emit_dense(WaveLds &L, uint32_t *out, int ncols, int lane, const SgnDev &G)
+// 32-bit accumulators: the touched columns with a non-zero sum go to out(position, column, value), sorted by column; the
+// accumulators go back to zero.  Returns the number of entries.  No holes: the lane-by-lane walk (segments with more than
+// LISTCAP touched columns) counts its non-zero sums first.
+template <typename OUT>
+__device__ __forceinline__ int sp_emit32(WaveLds32 &L, const SpTouched &T, int lane, OUT out)
 {
-	for (int w = lane; w < SEGW; w += 64) {
-		const uint32_t pw = ((uint32_t) w & ~(uint32_t) (CW - 1)) | (((uint32_t) w + ((uint32_t) w / CW)) & (uint32_t) (CW - 1));
-		const uint32_t x = L.acc[pw];
-		L.acc[pw] = 0;
-		int v0, v1;
-		sgn_unpack(x, v0, v1);
-		v0 = sgn_canonical(v0, G);
-		v1 = sgn_canonical(v1, G);
-		if (2 * w < ncols)
-			out[2 * w] = (uint32_t) (v0 < 0 ? v0 + G.p : v0);
-		if (2 * w + 1 < ncols)
-			out[2 * w + 1] = (uint32_t) (v1 < 0 ? v1 + G.p : v1);
+	const int ub = T.ub;
+	if (T.listed) {
+		uint32_t w = 0;
+		for (int i0 = 0; i0 < ub; i0 += 128) {
+			const int i = i0 + lane;
+			const bool first = i < ub, second = i + 64 < ub;
+			const uint32_t c0 = first ? L.list[i] : 0u, c1 = second ? L.list[i + 64] : 0u;
+			uint32_t *a0 = L.acc + sp_swz32(c0), *a1 = L.acc + sp_swz32(c1);
+			const uint32_t v0 = first ? *a0 : 0u, v1 = second ? *a1 : 0u;
+			if (first)
+				*a0 = 0;
+			if (second)
+				*a1 = 0;
+			const uint64_t m0 = __ballot(v0 != 0), m1 = __ballot(v1 != 0);
+			const uint32_t d0 = __builtin_amdgcn_mbcnt_hi((uint32_t) (m0 >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t) m0, w));
+			w += (uint32_t) __popcll(m0);
+			const uint32_t d1 = __builtin_amdgcn_mbcnt_hi((uint32_t) (m1 >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t) m1, w));
+			w += (uint32_t) __popcll(m1);
+			if (v0 != 0)
+				out(d0, c0, v0);
+			if (v1 != 0)
+				out(d1, c1, v1);
+		}
+		return (int) w;
 	}
-	for (int t = lane; t < BMW; t += 64)
-		L.bm[t] = 0;
+	// lane L owns the columns [32 WPL L, 32 WPL (L + 1)): count, scan, write
+	const uint32_t col0 = (uint32_t) lane * (32u * WPL);
+	int mine = 0;
+	for (int half = 0; half < 2; half++)
+		for (uint64_t bits = half ? T.hi64 : T.lo64; bits != 0; bits &= bits - 1)
+			mine += L.acc[sp_swz32(col0 + 64u * half + (uint32_t) __builtin_ctzll(bits))] != 0;
+	const int incl = wave_incl_scan(mine);
+	uint32_t pos = (uint32_t) (incl - mine);
+	for (int half = 0; half < 2; half++)
+		for (uint64_t bits = half ? T.hi64 : T.lo64; bits != 0; bits &= bits - 1) {
+			const uint32_t c = col0 + 64u * half + (uint32_t) __builtin_ctzll(bits);
+			uint32_t *a = L.acc + sp_swz32(c);
+			const uint32_t v = *a;
+			*a = 0;
+			if (v != 0) {
+				out(pos, c, v);
+				pos += 1;
+			}
+		}
+	return __builtin_amdgcn_readlane(incl, 63);
+}
+
+__device__ __forceinline__ void sp_discard(WaveLds32 &L, const SpTouched &T, int lane)
+{
+	if (T.listed) {
+		for (int i = lane; i < T.ub; i += 64)
+			L.acc[sp_swz32(L.list[i])] = 0;
+		return;
+	}
+	for (int half = 0; half < 2; half++)
+		for (uint64_t bits = half ? T.hi64 : T.lo64; bits != 0; bits &= bits - 1)
+			L.acc[sp_swz32((uint32_t) lane * (32u * WPL) + 64u * half + (uint32_t) __builtin_ctzll(bits))] = 0;
 }
 
 __device__ __forceinline__ uint32_t sp_hash(uint32_t c, uint32_t g)
@@ -582,6 +743,7 @@ struct SpBuildArgs {
 	unsigned long long *prof;     // SPASM_HIP_SPARSE_IMAGE_PROFILE=1: 8 cycle counters (ticket, metadata, polling, adding, reservation, emit, publication)
 	int *dbg;                     // SPASM_HIP_SPARSE_IMAGE_DEBUG=1: 4 ints per workgroup (stage, task, detail, polls), read by the host's watchdog
 	SgnDev G;
+	MontDev M;                    // the 32-bit variant: coefficients in Montgomery form, values plain residues
 };
 
 __global__ __launch_bounds__(64) void sp_reset_shards_kernel(unsigned long long *shard, unsigned long long sub, int clear_stats)
@@ -636,11 +798,12 @@ template <bool PERSISTENT> __device__ __forceinline__ void sp_publish(uint64_t *
 }
 
 // one task: the fragment of (row c, segment g).  One exit, one publication.
-template <bool PERSISTENT>
-__device__ __forceinline__ void sp_build_task(const SpBuildArgs &b, WaveLds &L, int c, int g, int lane, SpStamp &st, SpWaveState &ws)
+template <bool PERSISTENT, bool W32, typename LDS>
+__device__ __forceinline__ void sp_build_task(const SpBuildArgs &b, LDS &L, int c, int g, int lane, SpStamp &st, SpWaveState &ws)
 {
 	const uint32_t col0 = (uint32_t) g * SP_SEG;
 	const SgnDev G = b.G;
+	const MontDev M = b.M;
 	const uint64_t d0 = sp_uniform(b.dep_rp[c]), d1 = sp_uniform(b.dep_rp[c + 1]), n0 = sp_uniform(b.np_rp[c]), n1 = sp_uniform(b.np_rp[c + 1]);
 	uint64_t *fout = b.frag + (uint64_t) c * b.nseg + g;
 	unsigned long long ops = 0;
@@ -657,8 +820,12 @@ __device__ __forceinline__ void sp_build_task(const SpBuildArgs &b, WaveLds &L, 
 		const bool in = idx < (uint32_t) SP_SEG;
 		if (__ballot(in) != 0) {
 			touched = true;
-			if (in)
-				sp_own_entry(L, idx, val, G);
+			if (in) {
+				if constexpr (W32)
+					sp_own_entry(L, idx, (uint32_t) val, M);
+				else
+					sp_own_entry(L, idx, val, G);
+			}
 		}
 	}
 	// minus the rows of R its pivotal entries point at (coefficients are stored negated)
@@ -701,7 +868,10 @@ __device__ __forceinline__ void sp_build_task(const SpBuildArgs &b, WaveLds &L, 
 			touched = true;
 			if (PERSISTENT)
 				sp_dbg(b, lane, 3, (long long) c * b.nseg + g, (int) (e - d0));
-			sp_accumulate<PERSISTENT>(L, f, coef, true, b.pools, lane, G, ops);
+			if constexpr (W32)
+				sp_accumulate<PERSISTENT>(L, f, (uint32_t) coef, true, b.pools, lane, M, ops);
+			else
+				sp_accumulate<PERSISTENT>(L, f, coef, true, b.pools, lane, G, ops);
 			st.mark(3);
 		}
 	}
@@ -742,7 +912,12 @@ __device__ __forceinline__ void sp_build_task(const SpBuildArgs &b, WaveLds &L, 
 		if (failed) {
 			sp_discard(L, T, lane);
 		} else if (ub > 0) {
-			cnt = sp_emit<false, PERSISTENT>(L, T, b.chunk_base + off, lane, G);
+			if constexpr (W32) {
+				uint64_t *dst = reinterpret_cast<uint64_t *>(b.chunk_base) + off;
+				cnt = sp_emit32(L, T, lane, [&](uint32_t pos, uint32_t col, uint32_t v) { sp_st64<PERSISTENT>(dst + pos, (uint64_t) col | ((uint64_t) v << 32)); });
+			} else {
+				cnt = sp_emit<false, PERSISTENT>(L, T, b.chunk_base + off, lane, G);
+			}
 			if (cnt > 0)
 				word = ((uint64_t) b.chunk << (SP_LEN_BITS + SP_OFF_BITS)) | ((uint64_t) off << SP_LEN_BITS) | (uint64_t) cnt;
 			if (arenas)
@@ -771,9 +946,9 @@ __device__ __forceinline__ void sp_build_task(const SpBuildArgs &b, WaveLds &L, 
 	st.mark(6);
 }
 
-template <bool PERSISTENT> __global__ __launch_bounds__(64) void sp_build_kernel(SpBuildArgs b)
+template <bool PERSISTENT, bool W32 = false> __global__ __launch_bounds__(64) void sp_build_kernel(SpBuildArgs b)
 {
-	__shared__ WaveLds L;
+	__shared__ typename std::conditional<W32, WaveLds32, WaveLds>::type L;
 	const int lane = threadIdx.x;
 	sp_lds_init(L, lane);
 	SpStamp st;
@@ -782,7 +957,7 @@ template <bool PERSISTENT> __global__ __launch_bounds__(64) void sp_build_kernel
 		const int task = blockIdx.x;
 		const int c = b.row_lo + task / b.nseg;
 		SpWaveState ws;
-		sp_build_task<false>(b, L, c, task - (c - b.row_lo) * b.nseg, lane, st, ws);
+		sp_build_task<false, W32>(b, L, c, task - (c - b.row_lo) * b.nseg, lane, st, ws);
 	} else {
 		const int q = (int) (blockIdx.x % SP_TICKETS);
 		const long long ntasks = (long long) (b.row_hi - b.row_lo) * b.nseg;
@@ -799,7 +974,7 @@ template <bool PERSISTENT> __global__ __launch_bounds__(64) void sp_build_kernel
 			// (a launch that retries after a pool extension finds most fragments done)
 			const uint64_t cur = sp_uniform(__hip_atomic_load(b.frag + (uint64_t) c * b.nseg + g, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
 			if (cur == FRAG_PENDING) {
-				sp_build_task<true>(b, L, c, g, lane, st, ws);
+				sp_build_task<true, W32>(b, L, c, g, lane, st, ws);
 				sp_dbg(b, lane, 5, t, 0);
 			}
 		}
@@ -827,7 +1002,7 @@ __global__ __launch_bounds__(256) void sp_sum_frag_kernel(const uint64_t *frag, 
 }
 
 // census of R for DESIGN.md: entries, occupied 64-column tiles (what a tile-sparse dense form would store), fragments
-__global__ __launch_bounds__(256) void sp_census_kernel(const uint64_t *frag, int64_t n, SpPools pools, unsigned long long *out)
+template <bool W32> __global__ __launch_bounds__(256) void sp_census_kernel(const uint64_t *frag, int64_t n, SpPools pools, unsigned long long *out)
 {
 	const int lane = threadIdx.x & 63;
 	const int64_t wave = ((int64_t) blockIdx.x * blockDim.x + threadIdx.x) >> 6, nwaves = ((int64_t) gridDim.x * blockDim.x) >> 6;
@@ -838,10 +1013,11 @@ __global__ __launch_bounds__(256) void sp_census_kernel(const uint64_t *frag, in
 		if (len == 0)
 			continue;
 		const uint32_t *src = frag_ptr(pools, f);
+		const uint64_t *src64 = frag_ptr64(pools, f);
 		frags += (lane == 0);
 		for (int i = lane; i < len; i += 64) {
-			const uint32_t c = src[i] & 0xFFFFu;
-			const uint32_t prev = (i > 0) ? (src[i - 1] & 0xFFFFu) : 0xFFFFFFFFu;
+			const uint32_t c = (W32 ? (uint32_t) src64[i] : src[i]) & 0xFFFFu;
+			const uint32_t prev = (i > 0) ? ((W32 ? (uint32_t) src64[i - 1] : src[i - 1]) & 0xFFFFu) : 0xFFFFFFFFu;
 			entries += 1;
 			tiles += (i == 0) || ((c >> 6) != (prev >> 6));
 		}
@@ -869,22 +1045,21 @@ struct SpApplyArgs {
 	SpPools pools;
 	SgnDev G;
 	uint32_t *fpool;              // fragments of S (column inside the segment | value << 16, values in [-p/2, p/2])
+	uint32_t *fpool_v;            // the 32-bit variant: fpool holds the columns, this the values in [0, p)
 	int64_t fcap;
 	uint64_t *T;                  // nrows x nseg: offset << SP_LEN_BITS | length of the fragment of (row, segment)
 	unsigned long long *block_sum;// sum of the lengths of every block of 1024 rows (zeroed before the launch)
 	int arena;                    // entries a wave reserves from the pool at a time (0: every fragment on its own)
 	int *ticket;                  // SP_TICKETS counters handing out the rows (zeroed before the launch)
 	unsigned long long *prof;     // SPASM_HIP_SPARSE_IMAGE_PROFILE=1: 8 cycle counters (row of A, fragment words, adding, reservation, emit, words out)
-	uint32_t *dense_out;          // dense rows instead (values in [0, p)), leading dimension ldS
-	int64_t ldS;
 };
 
 // One wave per row of the batch, segment after segment: the entries of the row of A are read and relabelled once (rows
 // of at most 64 entries -- longer ones go through them once per segment), the fragment words of segment g + 1 are in
 // flight while segment g is added up, and the row's fragments of S land one behind the other in the wave's arena.
-__global__ __launch_bounds__(64) void sp_apply_kernel(SpApplyArgs d)
+template <bool W32> __global__ __launch_bounds__(64) void sp_apply_kernel(SpApplyArgs d)
 {
-	__shared__ WaveLds L;
+	__shared__ typename std::conditional<W32, WaveLds32, WaveLds>::type L;
 	const SchurArgs &a = d.a;
 	const int lane = threadIdx.x;
 	const SgnDev G = d.G;
@@ -899,17 +1074,6 @@ __global__ __launch_bounds__(64) void sp_apply_kernel(SpApplyArgs d)
 	st.begin(d.prof);
 	// what a (row, segment) leaves behind: its fragment in the pool and its word in T (or its dense values)
 	auto finish = [&](int k, int g, bool touched) -> int {
-		if (d.dense_out != nullptr) {
-			uint32_t *out = d.dense_out + (int64_t) k * d.ldS + (int64_t) g * SP_SEG;
-			const int ncols = min(SP_SEG, a.Sm - g * SP_SEG);
-			if (touched) {
-				sp_emit_dense(L, out, ncols, lane, G);
-			} else {
-				for (int t = lane; t < ncols; t += 64)
-					out[t] = 0u;
-			}
-			return 0;
-		}
 		uint64_t *tout = d.T + (uint64_t) k * nseg + g;
 		if (!touched) {
 			l0_store_u64(tout, 0);
@@ -934,7 +1098,16 @@ __global__ __launch_bounds__(64) void sp_apply_kernel(SpApplyArgs d)
 			return 0;
 		}
 		st.mark(3);
-		const int cnt = sp_emit<true, false>(L, T, d.fpool + ar_cur, lane, G);
+		int cnt;
+		if constexpr (W32) {
+			uint32_t *oc = d.fpool + ar_cur, *ov = d.fpool_v + ar_cur;
+			cnt = sp_emit32(L, T, lane, [&](uint32_t pos, uint32_t col, uint32_t v) {
+				oc[pos] = col;
+				ov[pos] = v;
+			});
+		} else {
+			cnt = sp_emit<true, false>(L, T, d.fpool + ar_cur, lane, G);
+		}
 		st.mark(4);
 		l0_store_u64(tout, (cnt > 0) ? (((uint64_t) ar_cur << SP_LEN_BITS) | (uint64_t) cnt) : 0);
 		ar_cur += cnt;
@@ -955,10 +1128,18 @@ __global__ __launch_bounds__(64) void sp_apply_kernel(SpApplyArgs d)
 		if (hi - lo <= 64) {
 			// the row in registers: lane e holds entry e
 			uint32_t cid = 0xFFFFFFFFu;
-			int bal = 0;
+			int bal = 0;          // the entry: balanced (16-bit variant) / plain residue (32-bit variant)
+			int ncoef = 0;        // minus the entry, as the arithmetic wants a coefficient: negated balanced / Montgomery form of p - a
 			if (lo + lane < hi) {
 				cid = (uint32_t) d.col[a.Aj[lo + lane]];
-				bal = sgn_from_residue(reduce_sum(from_balanced(a.Ax[lo + lane], F), F), G);
+				const uint32_t av = reduce_sum(from_balanced(a.Ax[lo + lane], F), F);
+				if constexpr (W32) {
+					bal = (int) av;
+					ncoef = (int) montmul(av == 0 ? 0u : F.p - av, F.r2, F);
+				} else {
+					bal = sgn_from_residue(av, G);
+					ncoef = -bal;
+				}
 			}
 			const bool piv = cid < (uint32_t) d.r && bal != 0;
 			const bool own = cid != 0xFFFFFFFFu && cid >= (uint32_t) d.r;
@@ -974,9 +1155,15 @@ __global__ __launch_bounds__(64) void sp_apply_kernel(SpApplyArgs d)
 				const bool touched = (__ballot(in) | __ballot(piv && (f & LEN_MASK) != 0)) != 0;
 				st.mark(1);
 				if (touched) {
-					if (in)
-						sp_own_entry(L, idx, bal, G);
-					sp_accumulate<false>(L, f, -bal, piv, d.pools, lane, G, ops);
+					if constexpr (W32) {
+						if (in)
+							sp_own_entry(L, idx, (uint32_t) bal, F);
+						sp_accumulate<false>(L, f, (uint32_t) ncoef, piv, d.pools, lane, F, ops);
+					} else {
+						if (in)
+							sp_own_entry(L, idx, bal, G);
+						sp_accumulate<false>(L, f, ncoef, piv, d.pools, lane, G, ops);
+					}
 				}
 				st.mark(2);
 				total += finish(k, g, touched);
@@ -989,12 +1176,19 @@ __global__ __launch_bounds__(64) void sp_apply_kernel(SpApplyArgs d)
 				bool touched = false;
 				for (int64_t base = lo; base < hi; base += 64) {
 					uint64_t f = 0;
-					int bal = 0;
+					int bal = 0, ncoef = 0;
 					uint32_t idx = 0xFFFFFFFFu;
 					bool piv = false;
 					if (base + lane < hi) {
 						const uint32_t cid = (uint32_t) d.col[a.Aj[base + lane]];
-						bal = sgn_from_residue(reduce_sum(from_balanced(a.Ax[base + lane], F), F), G);
+						const uint32_t av = reduce_sum(from_balanced(a.Ax[base + lane], F), F);
+						if constexpr (W32) {
+							bal = (int) av;
+							ncoef = (int) montmul(av == 0 ? 0u : F.p - av, F.r2, F);
+						} else {
+							bal = sgn_from_residue(av, G);
+							ncoef = -bal;
+						}
 						if (cid >= (uint32_t) d.r) {
 							idx = cid - (uint32_t) d.r - col0;
 						} else if (bal != 0) {
@@ -1007,20 +1201,22 @@ __global__ __launch_bounds__(64) void sp_apply_kernel(SpApplyArgs d)
 					if ((__ballot(in) | __ballot((f & LEN_MASK) != 0)) == 0)
 						continue;
 					touched = true;
-					if (in)
-						sp_own_entry(L, idx, bal, G);
-					sp_accumulate<false>(L, f, -bal, piv, d.pools, lane, G, ops);
+					if constexpr (W32) {
+						if (in)
+							sp_own_entry(L, idx, (uint32_t) bal, F);
+						sp_accumulate<false>(L, f, (uint32_t) ncoef, piv, d.pools, lane, F, ops);
+					} else {
+						if (in)
+							sp_own_entry(L, idx, bal, G);
+						sp_accumulate<false>(L, f, ncoef, piv, d.pools, lane, G, ops);
+					}
 				}
 				total += finish(k, g, touched);
 			}
 		}
 		st_done += 1;
-		if (d.dense_out != nullptr) {
-			l0_store_i32(a.row_len + k, a.Sm);
-		} else {
-			l0_store_i32(a.row_len + k, total);
-			l0_atomic_add_u64(&d.block_sum[k >> 10], (unsigned long long) total);
-		}
+		l0_store_i32(a.row_len + k, total);
+		l0_atomic_add_u64(&d.block_sum[k >> 10], (unsigned long long) total);
 	}
 	st.flush(lane);
 	for (int sft = 32; sft >= 1; sft >>= 1)
@@ -1038,6 +1234,8 @@ __global__ __launch_bounds__(64) void sp_apply_kernel(SpApplyArgs d)
 struct SpGatherArgs {
 	const uint64_t *T;
 	const uint32_t *fpool;
+	const uint32_t *fpool_v;      // 32-bit variant: the values (fpool: the columns)
+	uint32_t p;
 	int nrows, nseg;
 	const int64_t *Sp;
 	int *Sj, *Sx;
@@ -1046,7 +1244,7 @@ struct SpGatherArgs {
 };
 
 // the fragments of a row, segment after segment, as (column, value) pairs at the row's final place
-__global__ __launch_bounds__(256) void sp_gather_kernel(SpGatherArgs e)
+template <bool W32> __global__ __launch_bounds__(256) void sp_gather_kernel(SpGatherArgs e)
 {
 	const int lane = threadIdx.x & 63;
 	const int wave = (int) ((blockIdx.x * blockDim.x + threadIdx.x) >> 6), nwaves = (int) ((gridDim.x * blockDim.x) >> 6);
@@ -1066,10 +1264,19 @@ __global__ __launch_bounds__(256) void sp_gather_kernel(SpGatherArgs e)
 				const uint32_t *src = e.fpool + (tt >> SP_LEN_BITS);
 				const int *q = e.q + (int64_t) (g0 + s) * SP_SEG;
 				int *oj = e.Sj + w, *ox = e.Sx + w;
-				for (int i = lane; i < len; i += 64) {
-					const uint32_t en = src[i];
-					oj[i] = q[en & 0xFFFFu];
-					ox[i] = (int) en >> 16;
+				if constexpr (W32) {
+					const uint32_t *sv = e.fpool_v + (tt >> SP_LEN_BITS);
+					for (int i = lane; i < len; i += 64) {
+						const uint32_t v = sv[i];
+						oj[i] = q[src[i] & 0xFFFFu];
+						ox[i] = (v > e.p / 2) ? (int) (v - e.p) : (int) v;          // balanced representative (spasm_ZZp)
+					}
+				} else {
+					for (int i = lane; i < len; i += 64) {
+						const uint32_t en = src[i];
+						oj[i] = q[en & 0xFFFFu];
+						ox[i] = (int) en >> 16;
+					}
 				}
 				w += len;
 			}
@@ -1082,9 +1289,11 @@ __global__ __launch_bounds__(256) void sp_gather_kernel(SpGatherArgs e)
 // ---------------------------------------------------------------------------------------------------
 // host side
 // ---------------------------------------------------------------------------------------------------
+// every odd prime below 2^32: signed 16-bit entries up to 44,927, (column, 32-bit residue) entries beyond
+// (SPASM_HIP_SPARSE_IMAGE_WIDE=1 takes the 32-bit variant for small primes too: tests)
 bool sparse_image_possible(int64_t prime)
 {
-	return sgn_eligible(prime) && env_sp("SPASM_HIP_SPARSE_IMAGE", -1) != 0;
+	return prime >= 3 && prime < ((int64_t) 1 << 32) && (prime & 1) != 0 && env_sp("SPASM_HIP_SPARSE_IMAGE", -1) != 0;
 }
 
 // dependency tables of the build: per compact row (level order) its pivotal entries (compact row, negated balanced
@@ -1098,6 +1307,7 @@ void sparse_image_plan(const FactPlan &P, spasm_hip_dfact *F, hipStream_t stream
 	S.Sm = m - r;
 	S.nseg = (S.Sm + SP_SEG - 1) / SP_SEG;
 	S.nlevels = P.nlevels;
+	S.wide = !sgn_eligible(prime) || env_sp("SPASM_HIP_SPARSE_IMAGE_WIDE", 0) != 0;
 	std::vector<int> cid((size_t) (rpad > 0 ? rpad : 1), -1), label_of((size_t) (r > 0 ? r : 1), 0);
 	{
 		int n = 0;
@@ -1145,6 +1355,14 @@ void sparse_image_plan(const FactPlan &P, spasm_hip_dfact *F, hipStream_t stream
 		const int c = label_of[n];
 		for (uint64_t e = P.rp[c]; e < P.rp[c + 1]; e++) {
 			const uint2 en = P.ent[e];
+			if (S.wide) {
+				// (the image's values ARE Montgomery forms: the negated coefficient as it stands, the non-pivotal value as a plain residue)
+				if (en.x < (uint32_t) rpad)
+					dep.push_back(uint2{(uint32_t) cid[en.x], en.y == 0 ? 0u : (uint32_t) ((uint64_t) prime - en.y)});
+				else
+					np.push_back(uint2{en.x - (uint32_t) rpad, (uint32_t) (((unsigned __int128) en.y * unmont) % (uint64_t) prime)});
+				continue;
+			}
 			const int32_t v = balanced(en.y);
 			if (en.x < (uint32_t) rpad)
 				dep.push_back(uint2{(uint32_t) cid[en.x], (uint32_t) (-v)});
@@ -1226,8 +1444,9 @@ bool sparse_image_build(const spasm_hip_dfact *F, hipStream_t stream)
 	size_t free_b = 0, total_b = 0;
 	sh::mem_info(&free_b, &total_b);
 	int64_t held = 0;
+	const int64_t esize = S.wide ? 8 : 4;          // bytes of a fragment entry
 	for (int k = 0; k < S.nchunks; k++)
-		held += S.chunk_cap[k] * 4;
+		held += S.chunk_cap[k] * esize;
 	int64_t budget = std::min<int64_t>((int64_t) ((free_b + (size_t) held) / 3), std::max<int64_t>((int64_t) S.r * (int64_t) S.Sm, (int64_t) 256 << 20));
 	if (env_sp("SPASM_HIP_SPARSE_IMAGE_GB", 0) > 0)
 		budget = (int64_t) env_sp("SPASM_HIP_SPARSE_IMAGE_GB", 0) << 30;
@@ -1243,9 +1462,9 @@ bool sparse_image_build(const spasm_hip_dfact *F, hipStream_t stream)
 		//  every column it touched, cancelled or not; a guess that is too small costs a second launch, one too large only address space)
 		if (env_sp("SPASM_HIP_SPARSE_IMAGE_CHUNK", 0) > 0)          // (tests: pool extensions on small inputs)
 			cap = env_sp("SPASM_HIP_SPARSE_IMAGE_CHUNK", 0);
-		cap = std::min<int64_t>(cap, std::max<int64_t>(budget / 4, (int64_t) SP_SHARDS * 64));
+		cap = std::min<int64_t>(cap, std::max<int64_t>(budget / esize, (int64_t) SP_SHARDS * 64));
 		cap = (cap + SP_SHARDS - 1) / SP_SHARDS * SP_SHARDS;
-		S.d_chunk[0] = dalloc<uint32_t>(cap);
+		S.d_chunk[0] = dalloc<uint32_t>(cap * (esize / 4));
 		S.chunk_cap[0] = cap;
 		S.nchunks = 1;
 	}
@@ -1267,29 +1486,33 @@ bool sparse_image_build(const spasm_hip_dfact *F, hipStream_t stream)
 		HIP_CHECK(hipMemsetAsync(d_prof, 0, 8 * sizeof(unsigned long long), stream));
 	}
 	b.prof = d_prof;
-	b.G = sgn_setup(F->prime);
+	b.G = sgn_setup(S.wide ? 3 : F->prime);
+	b.M = to_dev(F->mont);
 	// the persistent driver needs every wave of its grid resident at once
 	int dev = 0, cus = 0, per_cu = 0;
 	HIP_CHECK(hipGetDevice(&dev));
 	HIP_CHECK(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev));
-	HIP_CHECK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, sp_build_kernel<true>, 64, 0));
-	per_cu = std::min(per_cu, env_sp("SPASM_HIP_SPARSE_IMAGE_BUILD_WAVES", (int) std::min<size_t>(16, (size_t) (160 * 1024) / sizeof(WaveLds))));
+	if (S.wide)
+		HIP_CHECK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, sp_build_kernel<true, true>, 64, 0));
+	else
+		HIP_CHECK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, sp_build_kernel<true, false>, 64, 0));
+	per_cu = std::min(per_cu, env_sp("SPASM_HIP_SPARSE_IMAGE_BUILD_WAVES", (int) std::min<size_t>(16, (size_t) (160 * 1024) / (S.wide ? sizeof(WaveLds32) : sizeof(WaveLds)))));
 	bool persistent = env_sp("SPASM_HIP_SPARSE_IMAGE_PERSISTENT", 1) != 0 && per_cu >= 1;
 	HIP_CHECK(hipEventRecord(S.ev0, stream));
 	auto next_chunk = [&](int chunk) -> bool {          // room for another attempt?  (allocates chunk + 1 when it is not there)
 		int64_t total = 0;
 		for (int k = 0; k < S.nchunks; k++)
-			total += S.chunk_cap[k] * 4;
+			total += S.chunk_cap[k] * esize;
 		const int64_t cap = S.chunk_cap[S.nchunks - 1] * 2;
 		if (chunk + 1 < S.nchunks)
 			return true;
-		if (chunk + 1 >= SP_MAX_CHUNKS || total + cap * 4 > budget) {
+		if (chunk + 1 >= SP_MAX_CHUNKS || total + cap * esize > budget) {
 			if (verbose() >= 2)
 				logmsg("[sparse image] gave up: %.2f GB of fragments do not hold R (budget %.2f GB) -- R is not sparse\n", 1e-9 * (double) total,
 				       1e-9 * (double) budget);
 			return false;
 		}
-		S.d_chunk[S.nchunks] = dalloc<uint32_t>(cap);
+		S.d_chunk[S.nchunks] = dalloc<uint32_t>(cap * (esize / 4));
 		S.chunk_cap[S.nchunks] = cap;
 		S.nchunks += 1;
 		counters()[CNT_SP_CHUNK_EXTENSIONS] += 1;
@@ -1329,7 +1552,8 @@ bool sparse_image_build(const spasm_hip_dfact *F, hipStream_t stream)
 			// start it beside work that holds part of the chip.
 			{
 				void *kargs[1] = {(void *) &b};
-				const hipError_t le = hipLaunchCooperativeKernel(reinterpret_cast<void *>(sp_build_kernel<true>), dim3(blocks), dim3(64), kargs, 0, stream);
+				const hipError_t le = hipLaunchCooperativeKernel(S.wide ? reinterpret_cast<void *>(sp_build_kernel<true, true>) : reinterpret_cast<void *>(sp_build_kernel<true, false>),
+				                                                 dim3(blocks), dim3(64), kargs, 0, stream);
 				if (le != hipSuccess) {
 					(void) hipGetLastError();
 					logmsg("[sparse image] the single-launch build cannot be resident here (%s); building level by level\n", hipGetErrorString(le));
@@ -1439,7 +1663,10 @@ bool sparse_image_build(const spasm_hip_dfact *F, hipStream_t stream)
 					continue;
 				if (ntasks > 0x7FFFFFFFll)
 					die("sparse_image_build: level %d has %lld (row, segment) pairs", l, (long long) ntasks);
-				hipLaunchKernelGGL(sp_build_kernel<false>, dim3((unsigned) ntasks), dim3(64), 0, stream, b);
+				if (S.wide)
+					hipLaunchKernelGGL((sp_build_kernel<false, true>), dim3((unsigned) ntasks), dim3(64), 0, stream, b);
+				else
+					hipLaunchKernelGGL((sp_build_kernel<false, false>), dim3((unsigned) ntasks), dim3(64), 0, stream, b);
 				S.launches += 1;
 			}
 			HIP_CHECK(hipGetLastError());
@@ -1522,9 +1749,10 @@ bool sparse_image_build(const spasm_hip_dfact *F, hipStream_t stream)
 	return true;
 }
 
-// S rows from the sparse image: sparse rows in W's final arrays (dense_out == nullptr) or dense rows.
-//   fpool / fcap: room for the fragments of S (4-byte entries); T: nrows * nseg words; block_sum: (nrows + 1023) / 1024 words
-void launch_sparse_image_apply(const SchurArgs &a, const spasm_hip_dfact *F, uint32_t *dense_out, int64_t ldS, uint32_t *fpool, int64_t fcap,
+// S rows from the sparse image, as sparse rows in W's final arrays.
+//   fpool / fcap: room for the fragments of S (4-byte entries; the 32-bit variant: their columns, and fpool_v their values);
+//   T: nrows * nseg words; block_sum: (nrows + 1023) / 1024 words
+void launch_sparse_image_apply(const SchurArgs &a, const spasm_hip_dfact *F, uint32_t *fpool, uint32_t *fpool_v, int64_t fcap,
                                uint64_t *T, unsigned long long *block_sum, int64_t *Sp, int *Sj, int *Sx, int64_t cap, hipStream_t stream,
                                hipEvent_t ev_gather)
 {
@@ -1543,18 +1771,17 @@ void launch_sparse_image_apply(const SchurArgs &a, const spasm_hip_dfact *F, uin
 	d.frag = S.d_frag;
 	for (int k = 0; k < SP_MAX_CHUNKS; k++)
 		d.pools.base[k] = S.d_chunk[k < S.nchunks ? k : 0];
-	d.G = sgn_setup(F->prime);
+	d.G = sgn_setup(S.wide ? 3 : F->prime);
 	d.fpool = fpool;
+	d.fpool_v = fpool_v;
 	d.fcap = fcap;
 	d.T = T;
 	d.block_sum = block_sum;
-	d.dense_out = dense_out;
-	d.ldS = ldS;
 	const int64_t ntasks = (int64_t) a.nrows;          // (a wave takes a row through all its segments)
 	if (ntasks <= 0)
 		return;
 	// as many waves per CU as its LDS holds (19.5 KB each: eight), every wave a workgroup of its own
-	const int per_cu = std::max(1, std::min(16, env_sp("SPASM_HIP_SPARSE_IMAGE_WAVES", (int) std::min<size_t>(16, (size_t) (160 * 1024) / sizeof(WaveLds)))));
+	const int per_cu = std::max(1, std::min(16, env_sp("SPASM_HIP_SPARSE_IMAGE_WAVES", (int) std::min<size_t>(16, (size_t) (160 * 1024) / (S.wide ? sizeof(WaveLds32) : sizeof(WaveLds))))));
 	const int blocks = (int) std::min<int64_t>(ntasks, (int64_t) prop.multiProcessorCount * per_cu);
 	// a wave reserves the room of its fragments 8,192 entries at a time (what the ~4,000 waves strand at the end must stay small
 	// against a pool sized from a density estimate: 32,768 apiece were 126 M entries, and a retry of the whole call); a pool
@@ -1564,17 +1791,18 @@ void launch_sparse_image_apply(const SchurArgs &a, const spasm_hip_dfact *F, uin
 	const int nblocks = (a.nrows + 1023) / 1024;
 	d.ticket = reinterpret_cast<int *>(block_sum + (size_t) (nblocks + 15) / 16 * 16);
 	HIP_CHECK(hipMemsetAsync(d.ticket, 0, (size_t) SP_TICKETS * SP_TICKET_STRIDE * sizeof(int), stream));
-	if (dense_out == nullptr) {
-		HIP_CHECK(hipMemsetAsync(block_sum, 0, (size_t) nblocks * sizeof(unsigned long long), stream));
-		HIP_CHECK(hipMemsetAsync(Sp, 0, sizeof(int64_t), stream));
-	}
+	HIP_CHECK(hipMemsetAsync(block_sum, 0, (size_t) nblocks * sizeof(unsigned long long), stream));
+	HIP_CHECK(hipMemsetAsync(Sp, 0, sizeof(int64_t), stream));
 	unsigned long long *d_prof = nullptr;
 	if (env_sp("SPASM_HIP_SPARSE_IMAGE_PROFILE", 0) != 0) {
 		d_prof = dalloc<unsigned long long>(8);
 		HIP_CHECK(hipMemsetAsync(d_prof, 0, 8 * sizeof(unsigned long long), stream));
 	}
 	d.prof = d_prof;
-	hipLaunchKernelGGL(sp_apply_kernel, dim3(blocks), dim3(64), 0, stream, d);
+	if (S.wide)
+		hipLaunchKernelGGL(sp_apply_kernel<true>, dim3(blocks), dim3(64), 0, stream, d);
+	else
+		hipLaunchKernelGGL(sp_apply_kernel<false>, dim3(blocks), dim3(64), 0, stream, d);
 	HIP_CHECK(hipGetLastError());
 	if (d_prof != nullptr) {
 		unsigned long long hp[8];
@@ -1590,14 +1818,15 @@ void launch_sparse_image_apply(const SchurArgs &a, const spasm_hip_dfact *F, uin
 		fprintf(stderr, " %.3g cycles in all\n", tot);
 		sh::big_free(d_prof);
 	}
-	if (dense_out != nullptr)
-		return;
 	if (ev_gather != nullptr)
 		HIP_CHECK(hipEventRecord(ev_gather, stream));
 	launch_scan_lengths(a.row_len, a.nrows, block_sum, Sp, cap, a.ctr, stream);
-	SpGatherArgs e{T, fpool, a.nrows, S.nseg, Sp, Sj, Sx, cap, a.q};
+	SpGatherArgs e{T, fpool, fpool_v, (uint32_t) F->prime, a.nrows, S.nseg, Sp, Sj, Sx, cap, a.q};
 	const int gblocks = std::max(1, std::min((a.nrows + 3) / 4, prop.multiProcessorCount * 8));
-	hipLaunchKernelGGL(sp_gather_kernel, dim3(gblocks), dim3(256), 0, stream, e);
+	if (S.wide)
+		hipLaunchKernelGGL(sp_gather_kernel<true>, dim3(gblocks), dim3(256), 0, stream, e);
+	else
+		hipLaunchKernelGGL(sp_gather_kernel<false>, dim3(gblocks), dim3(256), 0, stream, e);
 	HIP_CHECK(hipGetLastError());
 }
 
@@ -1613,7 +1842,10 @@ void sparse_image_census(const spasm_hip_dfact *F, int64_t *out, hipStream_t str
 		pools.base[k] = S.d_chunk[k < S.nchunks ? k : 0];
 	unsigned long long *d = dalloc<unsigned long long>(4);
 	HIP_CHECK(hipMemsetAsync(d, 0, 4 * sizeof(unsigned long long), stream));
-	hipLaunchKernelGGL(sp_census_kernel, dim3(2048), dim3(256), 0, stream, S.d_frag, (int64_t) S.r * S.nseg, pools, d);
+	if (S.wide)
+		hipLaunchKernelGGL(sp_census_kernel<true>, dim3(2048), dim3(256), 0, stream, S.d_frag, (int64_t) S.r * S.nseg, pools, d);
+	else
+		hipLaunchKernelGGL(sp_census_kernel<false>, dim3(2048), dim3(256), 0, stream, S.d_frag, (int64_t) S.r * S.nseg, pools, d);
 	unsigned long long h[4] = {0, 0, 0, 0};
 	HIP_CHECK(hipMemcpyAsync(h, d, sizeof(h), hipMemcpyDeviceToHost, stream));
 	HIP_CHECK(hipStreamSynchronize(stream));

@@ -16,7 +16,9 @@ import spasm_amd
 
 pytestmark = pytest.mark.gpu
 
-PRIMES = [3, 257, 42013, 44927]          # (the sparse image exists for p <= 44,927: signed 16-bit entries)
+# signed 16-bit entries up to p = 44,927; beyond (round 5) 8-byte entries (column, residue) and 32-bit accumulators: every odd
+# prime below 2^32, as the reference takes them (spasm_ZZp.c:5-15; its own tests run 65537 ... 4294967291)
+PRIMES = [3, 257, 42013, 44927, 44939, 65537, 189812507, 4294967291]
 
 
 def _as_product(A):
@@ -196,12 +198,41 @@ def test_sparse_image_device_call_statistics_rebuild_and_small_pool(oracle, monk
     dF.close()
 
 
-@pytest.mark.parametrize("p", [65521, 4294967291])
-def test_primes_beyond_the_signed_arithmetic_take_the_other_paths(oracle, monkeypatch, p):
-    """the sparse image only exists for p <= 44,927; asking for it on a larger prime must leave the result right"""
+@pytest.mark.parametrize("p", [65521, 67108859, 4294967291])
+def test_primes_beyond_the_signed_arithmetic_take_the_wide_variant(oracle, monkeypatch, p):
+    """beyond p = 44,927 the image keeps (column, 32-bit residue) entries: the device call says the sparse image ran, S is the
+    oracle's; a second batch reuses R; extreme values (p - 1 everywhere) stay exact"""
+    import torch
     rng = np.random.default_rng(21)
-    sysm = _triangular_system(rng, p, npiv=800, nnon=300, nred=200, deps=lambda k: 2, reach=40, np_per_row=3, red_entries=5)
-    _run(oracle, monkeypatch, p, *sysm, min_pivots=600)
+    n, m, ti, tj, tx = _triangular_system(rng, p, npiv=3000, nnon=9000, nred=500, deps=lambda k: 3, reach=200, np_per_row=4, red_entries=6)
+    tx = np.where(tx == 1, 1, np.where(rng.integers(0, 3, size=len(tx)) == 0, p - 1, tx)).astype(np.int64)
+    # (R of this system is a quarter full: 8-byte entries need more than the 256 MB a small factor may take by default)
+    A, rows, F, want = _run(oracle, monkeypatch, p, n, m, ti, tj, tx, min_pivots=2000, env={"SPASM_HIP_SPARSE_IMAGE_GB": "2"})
+    S, st, W, dF, dA, drows = _stats_of_device_call(A, rows, F, want.nnz + 4096)
+    assert st.status == 0 and st.used_sparse_image == 1 and st.nnz == want.nnz
+    H = S.to_host()
+    assert oracle.same_matrix(oracle.CSR(H.n, H.m, H.p, H.j, H.x, p), want)
+    assert len(rows) >= 30
+    S2, st2 = spasm_amd.dschur(dA, drows[5:25].contiguous(), dF, W, fetch=True)
+    assert st2.status == 0 and st2.used_sparse_image == 1 and st2.sparse_image_built == 0
+    want2, _, _ = oracle.schur(A, rows[5:25], F)
+    H2 = S2.to_host()
+    assert oracle.same_matrix(oracle.CSR(H2.n, H2.m, H2.p, H2.j, H2.x, p), want2)
+    W.close()
+    dF.close()
+
+
+@pytest.mark.parametrize("chunk", [0, 2048])
+def test_the_wide_variant_on_a_small_prime_gives_the_same_schur_complement(oracle, monkeypatch, chunk):
+    """SPASM_HIP_SPARSE_IMAGE_WIDE=1: the 32-bit variant for p = 42013 -- the Schur complement of the 16-bit variant and of the
+    oracle, with levels of one row, wide levels, more than 64 dependencies per row, and a pool extended in mid-build"""
+    p = 42013
+    rng = np.random.default_rng(9 + chunk)
+    sysm = _triangular_system(rng, p, npiv=2500, nnon=9500, nred=400, deps=lambda k: 70 if k % 97 == 0 else 3, reach=400, np_per_row=5, red_entries=70)
+    env = {"SPASM_HIP_EXPERIMENT": "1", "SPASM_HIP_SPARSE_IMAGE_WIDE": "1", "SPASM_HIP_SPARSE_IMAGE_GB": "2"}
+    if chunk:
+        env.update({"SPASM_HIP_SPARSE_IMAGE_CHUNK": str(chunk)})
+    _run(oracle, monkeypatch, p, *sysm, min_pivots=1500, env=env)
 
 
 def test_a_build_that_finds_R_dense_gives_its_memory_back_and_the_other_paths_take_the_batch(oracle, monkeypatch):

@@ -165,6 +165,39 @@ def test_round0_schur_at_the_size_of_GL7d19_against_the_compiled_reference(oracl
     dF.close()
 
 
+def test_sparse_image_beyond_16_bit_primes_at_scale(oracle):
+    """mk14.b4 mod 65537 (673,000 rows on 42,000 columns: a GL7d19-class factor with a prime beyond the signed 16-bit arithmetic,
+    which until round 5 had no image at all -- minutes in the row-group kernel): the sparse image with 32-bit entries takes it by
+    itself, and its Schur complement is the one the row-by-row kernels compute, entry for entry; 64 rows against the compiled
+    reference."""
+    import torch
+    prime = 65537
+    A, rows, F, source = workloads.round0("mk14.b4", prime, threads=0)
+    S2, st2, W2, dF2 = _full_schur(A, rows, F, {}, pool=1 << 30)
+    assert st2.used_sparse_image == 1 and st2.status == 0
+    S0, st0, W0, dF0 = _full_schur(A, rows, F, {"SPASM_HIP_BACKSOLVE": "0", "SPASM_HIP_SPARSE_IMAGE": "0"}, pool=1 << 30)
+    assert st0.used_sparse_image == 0 and st0.used_backsolve == 0 and st0.status == 0 and st0.nnz == st2.nnz
+    assert torch.equal(S2.p, S0.p)
+    assert torch.equal(S2.j[:st2.nnz], S0.j[:st0.nnz]) and torch.equal(S2.x[:st2.nnz], S0.x[:st0.nnz])
+    Ao = oracle.CSR(A.n, A.m, A.p, A.j, A.x, prime)
+    Fo = oracle.Fact(oracle.CSR(F.U.n, F.U.m, F.U.p, F.U.j, F.U.x, prime), F.qinv)
+    ks = np.unique(np.linspace(0, len(rows) - 1, 64).astype(np.int64))
+    if oracle.ref_available():
+        want, p_out = oracle.ref_schur(Ao, rows[ks], Fo, threads=spasm_amd.usable_cpus())
+    else:
+        want, p_out, _ = oracle.schur(Ao, rows[ks], Fo)
+    order = {int(r): t for t, r in enumerate(p_out)}
+    Sp, got = _device_rows(S2, ks)
+    for k, (gj, gx) in zip(ks, got):
+        wj, wx = want.row(order[int(rows[k])])
+        o = np.argsort(wj)
+        assert np.array_equal(gj, wj[o]) and np.array_equal(np.asarray(gx, np.int64) % prime, np.asarray(wx[o], np.int64) % prime), \
+            "row %d of the batch (row %d of A) differs" % (k, rows[k])
+    for W, dF in ((W2, dF2), (W0, dF0)):
+        W.close()
+        dF.close()
+
+
 def test_default_path_follows_the_cost_model(oracle, monkeypatch):
     """no path forced (fitted on tools/sweep_cost.py): a FULL batch of mk13.b5 (Sm = 4,952) and of mk13.b4
     (Sm = 23,958: round 2's rule sent it row by row and lost) builds the back-substituted image; a one-off batch of 4,096
