@@ -422,7 +422,10 @@ bool finish_on_device(const struct spasm_csr *A, const int *p, int n, struct spa
 		cap_rows = want;
 		return true;
 	};
-	static uint64_t salt = 0x5DEECE66DULL;
+	// the generator of the random combinations is keyed by the problem, not by the history of the process: ranks of a sharded
+	// run that replicate this finish draw the same combinations whatever else they have computed before
+	uint64_t salt = 0x5DEECE66DULL ^ ((uint64_t) (uint32_t) n << 32) ^ (uint64_t) (uint32_t) Sm0 ^ ((uint64_t) prime * 0x9E3779B97F4A7C15ULL) ^
+	                ((uint64_t) A->p[A->n] << 17);
 	int k = 0;                           // echelon rows found so far: rows [0, k) of dM, in reduced form
 	int rank_ub = std::min(n, Sm0);
 	int processed = 0, round = 0;

@@ -287,8 +287,10 @@ int spasm_hip_dstitch_slabs(const int64_t *d_gSp, const int *d_gSj, const spasm_
 }
 
 // spasm_echelonize with the Schur complements of every round sharded over the ranks of `c` (one process per GPU).
-// Collective: every rank passes the same A and options and gets the same rank; the factorization returned on rank 0 is
-// the reference one (the random combinations of a dense finish are drawn per rank).
+// Collective: every rank passes the same A and options and gets the same factorization: the pivots come from rank 0 (broadcast),
+// the Schur complements are gathered on every rank, and the random combinations of the dense finish are drawn from a
+// generator keyed by what is combined (shape of the block, rows left, round: dense_api.hip) -- not by how many calls the
+// process has made --, so that the replicated finish takes the same pivots on every rank.
 struct spasm_lu *spasm_hip_echelonize_dist(const struct spasm_csr *A, struct echelonize_opts *opts, spasm_hip_comm *c)
 {
 	spasm_hip_comm *saved = g_comm;

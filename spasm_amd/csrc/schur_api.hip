@@ -953,13 +953,25 @@ static void plan_factor(const struct spasm_csr *U, const int *qinv, FactPlan &P)
 // lie in different components share no elimination at all; the row-group kernel regroups rows by component when the order
 // of the row list turns out to be unrelated to the structure -- and the largest number of rows of U' that hold one label
 // (how many terms an accumulator may receive).  From the relabelled entries of the plan: no access to U.
-static void plan_row_tables(FactPlan &P)
+// components = false: the column degrees only (what the per-row tiers need: the width of their sums) -- the connected components
+// of the pivot graph are what the row-group kernel regroups its rows by, and a factor that only ever sees a density sample of
+// 100 rows (every GL7d19-class round since the sparse image: mk15.b4) paid 10 ms of union-find for nothing
+static void plan_row_tables(FactPlan &P, bool components = true)
 {
 	const int rpad = P.rpad;
-	P.comp.assign((size_t) (rpad > 0 ? rpad : 1), 0);
 	P.ncomp = 0;
 	P.comp_largest = 0;
 	P.maxdeg = 0;
+	if (!components) {
+		std::vector<int> deg((size_t) rpad + (size_t) (P.m - P.r) + 1, 0);
+		const size_t count = (size_t) P.rp[rpad];
+		for (size_t e = 0; e < count; e++)
+			deg[P.ent[e].x] += 1;
+		for (size_t t = 0; t < deg.size(); t++)
+			P.maxdeg = std::max(P.maxdeg, deg[t]);
+		return;
+	}
+	P.comp.assign((size_t) (rpad > 0 ? rpad : 1), 0);
 	std::vector<uint32_t> parent((size_t) (rpad > 0 ? rpad : 1));
 	for (int c = 0; c < rpad; c++)
 		parent[c] = (uint32_t) c;
@@ -1121,16 +1133,23 @@ spasm_hip_dfact *spasm_hip_dfact_create(const struct spasm_csr *U, const int *qi
 
 namespace sh {
 // components of the pivot graph + largest column degree, on first use by a row-by-row path (plan_row_tables)
-void ensure_row_tables(const spasm_hip_dfact *F, hipStream_t stream)
+void ensure_row_tables(const spasm_hip_dfact *F, hipStream_t stream, bool components)
 {
 	static std::mutex mutex;
 	std::lock_guard<std::mutex> guard(mutex);
-	if (F->row_tables)
+	if (F->row_tables || (!components && F->maxdeg > 0))
 		return;
 	if (!F->host_plan)
 		die("ensure_row_tables: the factor image has lost its host plan");
 	const double t0 = wtime();
 	FactPlan &P = *F->host_plan;
+	if (!components) {
+		plan_row_tables(P, false);
+		F->maxdeg = std::max(P.maxdeg, 1);
+		if (verbose() >= 2)
+			logmsg("[factor image] column degrees for the per-row kernels: %.1f ms\n", 1e3 * (wtime() - t0));
+		return;
+	}
 	plan_row_tables(P);
 	F->maxdeg = P.maxdeg;
 	F->ncomp = P.ncomp;
@@ -1875,13 +1894,6 @@ struct spasm_csr *spasm_hip_schur(const struct spasm_csr *A, const int *p, int n
 	const i64 prime = A->field->p;
 	const double t0 = wtime();
 	hipStream_t stream = nullptr;
-	spasm_hip_dfact *F = cached_dfact(fact->U, fact->qinv, stream);
-	if (est_density >= 0)
-		F->bs.density_hint = est_density;      // (a dense result is cheaper through the back-substituted image)
-	const double t_fact = wtime() - t0;
-	// device image of A and of the row list
-	const i64 annz = A->p[A->n];
-	DeviceMatrix devA(A, stream);
 	// one process per GPU with a communicator installed (dist_api.hip): this rank reduces rows [lo, hi) of the list, the
 	// slices are reassembled on the devices.  Small batches (density samples) and calls that record L are not sharded:
 	// every rank computes them whole, which keeps the ranks in step without a collective.
@@ -1892,18 +1904,32 @@ struct spasm_csr *spasm_hip_schur(const struct spasm_csr *A, const int *p, int n
 	// Two ways to share a batch.  By COLUMNS when the factor takes an image path -- the sparse image or
 	// the dense one: the columns of R and of S never meet, so rank k builds only ITS slab of R and reduces all rows on it;
 	// nothing is replicated --, by ROWS otherwise (the row-by-row kernels: rows never meet; with an image every rank would
-	// rebuild all of R).  SPASM_HIP_SHARD=rows|columns forces one.
-	bool shard_cols = false;
+	// rebuild all of R).  SPASM_HIP_SHARD=rows|columns forces one.  The choice is made BEFORE the image of the whole factor is
+	// planned -- it hangs on the sizes alone (r, Sm, nnz(U), p: the rules of spasm_hip_dfact_create) --, so that a rank of a
+	// column split never plans, hashes or uploads more than its own slab (round 4 planned the full image on every rank first).
 	if (shard) {
+		const int r_all = fact->U->n, Sm_all = m - fact->U->n;
+		bool shard_cols = false;
 		const char *how = sh::env_get("SPASM_HIP_SHARD");
-		if (how != nullptr && std::strcmp(how, "columns") == 0)
+		if (how != nullptr && std::strcmp(how, "columns") == 0) {
 			shard_cols = true;
-		else if (how == nullptr || std::strcmp(how, "rows") != 0)
-			shard_cols = (F->sp.planned && !F->sp.failed) || F->bs.planned || F->bs_deferred;
-		shard_cols = shard_cols && m - F->r >= comm_world(comm);
+		} else if (how == nullptr || std::strcmp(how, "rows") != 0) {
+			int64_t bs_bytes = 0;
+			const bool has_sparse_plan = sparse_image_possible(prime) && r_all > 0 && Sm_all > 0 &&
+			                             (env_int("SPASM_HIP_SPARSE_IMAGE", -1) == 1 || (Sm_all >= 8192 && (double) r_all * (double) Sm_all >= 5e8));
+			const bool has_dense_plan = env_int("SPASM_HIP_BACKSOLVE", -1) != 0 && backsolve_eligible(r_all, Sm_all, fact->U->p[r_all] - r_all, &bs_bytes, prime);
+			shard_cols = has_sparse_plan || has_dense_plan;
+		}
+		if (shard_cols && Sm_all >= comm_world(comm))
+			return schur_by_column_slabs(A, p, n, fact, est_density, p_in, p_out, comm);
 	}
-	if (shard_cols)
-		return schur_by_column_slabs(A, p, n, fact, est_density, p_in, p_out, comm);
+	spasm_hip_dfact *F = cached_dfact(fact->U, fact->qinv, stream);
+	if (est_density >= 0)
+		F->bs.density_hint = est_density;      // (a dense result is cheaper through the back-substituted image)
+	const double t_fact = wtime() - t0;
+	// device image of A and of the row list
+	const i64 annz = A->p[A->n];
+	DeviceMatrix devA(A, stream);
 	if (shard)
 		spasm_hip_shard(n, comm_rank(comm), comm_world(comm), &lo, &hi);
 	const int n_all = n;
