@@ -752,7 +752,8 @@ __global__ __launch_bounds__(256) void pivot_labels_relax_kernel(const i64 *Ap, 
 
 template <bool GB, int REC_ENTS, int REC_BITS>
 __global__ __launch_bounds__(64) void pivot_label_search_kernel(const i64 *Ap, const int *Aj, int *pinv, int n, int m, int words, u64 *rec, uint32_t *lab, PlCtrl *ctrl,
-                                                                int *fifo_all, int fifo_cap, uint32_t *gbits, int *deferred, i64 annz, int gap_max, int casc_cap)
+                                                                int *fifo_all, int fifo_cap, uint32_t *gbits, int *deferred, i64 annz, int gap_max, int casc_cap,
+                                                                const int *rowlist)
 {
 	extern __shared__ __attribute__((aligned(16))) uint32_t ps_lds[];
 	uint32_t *bits = GB ? gbits + (size_t) blockIdx.x * (size_t) (words + 64) : ps_lds;
@@ -788,7 +789,9 @@ __global__ __launch_bounds__(64) void pivot_label_search_kernel(const i64 *Ap, c
 		first = __shfl(first, 0);
 		if (first >= n || dead)
 			break;
-		for (int i = first; i < min(n, first + PS_ROWS_PER_GRAB) && !dead; i++) {
+		for (int i0 = first; i0 < min(n, first + PS_ROWS_PER_GRAB) && !dead; i0++) {
+			// (n counts the entries of the row list when there is one: a later pass, on the rows an earlier one deferred)
+			const int i = (rowlist != nullptr) ? rowlist[i0] : i0;
 			if (pinv[i] >= 0)
 				continue;
 			if (ld_i32(&ctrl->status) != 0) {
@@ -798,7 +801,7 @@ __global__ __launch_bounds__(64) void pivot_label_search_kernel(const i64 *Ap, c
 			const u64 t_row = wall_clock64();
 			const u64 visits_before = visits;
 			const i64 row_lo = Ap[i], row_hi = Ap[i + 1];
-			int outcome = -1;          // 0: no pivot on this row, 1: pivot, 2: deferred to the second pass
+			int outcome = -1;          // 0: no pivot on this row, 1: pivot, 2: deferred to the next pass
 			bool was_free = false;
 			for (int attempt = 0; outcome < 0; attempt++) {
 				// (the reached-bits are all clear here)
@@ -1297,6 +1300,7 @@ int device_acyclic_greedy(const struct spasm_csr *A, int *pinv, int *qinv)
 	bool labels = env_int("SPASM_HIP_PIVOT_LABELS", 1) != 0;
 	const int gap_max = std::max(0, env_int("SPASM_HIP_PIVOT_GAP", 64));
 	const int casc_cap = std::max(64, std::min(1 << 20, env_int("SPASM_HIP_PIVOT_CASCADE", 8192)));
+	const int casc_cap_late = std::max(casc_cap, std::min(1 << 20, env_int("SPASM_HIP_PIVOT_CASCADE_LATE", 65536)));
 	const int words = ((m + 31) / 32 + 255) / 256 * 256;          // (cleared 256 words at a time)
 	const size_t lds_labels_extra = (size_t) (64 + 64 + 8 + 2 * PS_RING + 2 * PL_HASH) * sizeof(int);
 	// the reached-bits in LDS when one bit per column fits 64 KB (and a column fits 20 bits), else in HBM
@@ -1323,7 +1327,7 @@ int device_acyclic_greedy(const struct spasm_csr *A, int *pinv, int *qinv)
 	// the ticket search, which then runs few searches at a time (its rows are a percent of all).  What this saves is device
 	// memory that a driver call has to get first: 5.8 GB of FIFOs on mk15.b4 were 0.1-0.3 s of hipMalloc per call.
 	const int fifo_cap = m + 4096;
-	const int fifo_cap_labels = std::min(m + 4096, env_int("SPASM_HIP_PIVOT_LABEL_FIFO", 32768)) + 2 * casc_cap + 256;
+	const int fifo_cap_labels = std::min(m + 4096, env_int("SPASM_HIP_PIVOT_LABEL_FIFO", 32768)) + 2 * casc_cap_late + 256;
 	// searches in flight per CU: 4 with the marks in LDS (the step is bound by instruction issue: more only adds speculation),
 	// 8 with the marks in HBM (bound by memory latency: mk14.b5 6.4 s at 2, 4.2 at 4, 3.4 at 8)
 	const int per_cu_wanted = env_int("SPASM_HIP_PIVOT_WAVES_PER_CU", global_bits ? 8 : 4);
@@ -1378,7 +1382,6 @@ int device_acyclic_greedy(const struct spasm_csr *A, int *pinv, int *qinv)
 	if (labels) {
 		const double ta = wtime();
 		uint32_t *lab = (uint32_t *) dal((size_t) m * sizeof(uint32_t));
-		d_deferred = (int *) dal((size_t) n * sizeof(int));
 		PlCtrl *pctrl = (PlCtrl *) dal(sizeof(PlCtrl) + 64);
 		int *d_changed = reinterpret_cast<int *>(reinterpret_cast<char *>(pctrl) + sizeof(PlCtrl));
 		hipLaunchKernelGGL(pivot_labels_init_kernel, dim3((m + 255) / 256), dim3(256), 0, stream, d_qinv, m, lab);
@@ -1398,27 +1401,65 @@ int device_acyclic_greedy(const struct spasm_csr *A, int *pinv, int *qinv)
 				labels = false;
 		}
 		t_labels_init = wtime() - ta;
-		if (labels) {
+		// Two labelled passes.  The first one defers what would hang long chains under the rows in flight (gap) or costs a long
+		// cascade (cap); the second one takes the deferred rows again with the gap rule off and cascades of up to 65,536 items --
+		// nine in ten of them have lost their candidate meanwhile and end after a pruned walk of a few dozen visits (mk15.b5:
+		// 347,000 rows deferred, 33,000 of them end with a pivot; through the ticket search they cost 120,000 visits apiece:
+		// 6-9 s of a 10-12 s call).  What the second pass defers goes to the ticket search.
+		const int npasses = std::max(1, std::min(2, env_int("SPASM_HIP_PIVOT_LABEL_PASSES", 2)));
+		int nrows_pass = n;
+		const int *rowlist_pass = nullptr;
+		for (int pass = 0; pass < npasses && labels; pass++) {
+			const double tp = wtime();
+			const int gap_pass = (pass == 0) ? gap_max : (1 << 30);
+			const int cap_pass = (pass == 0) ? casc_cap : casc_cap_late;
+			int *d_out = (int *) dal((size_t) std::max(nrows_pass, 1) * sizeof(int));
 			PlCtrl init;
 			std::memset(&init, 0, sizeof(init));
 			init.t_start = init.t_first_exit = ~0ull;
 			HIP_CHECK(hipMemcpyAsync(pctrl, &init, sizeof(PlCtrl), hipMemcpyHostToDevice, stream));
+			const int grid_pass = std::max(1, std::min(grid_labels, (nrows_pass + PS_ROWS_PER_GRAB - 1) / PS_ROWS_PER_GRAB));
 			if (global_bits)
-				hipLaunchKernelGGL((pivot_label_search_kernel<true, 5, 25>), dim3(grid_labels), dim3(64), lds_labels, stream, dA.p, dA.j, d_pinv, n, m, words, rec, lab, pctrl,
-				                   fifo, fifo_cap_labels, gbits, d_deferred, (i64) A->p[n], gap_max, casc_cap);
+				hipLaunchKernelGGL((pivot_label_search_kernel<true, 5, 25>), dim3(grid_pass), dim3(64), lds_labels, stream, dA.p, dA.j, d_pinv, nrows_pass, m, words, rec, lab, pctrl,
+				                   fifo, fifo_cap_labels, gbits, d_out, (i64) A->p[n], gap_pass, cap_pass, rowlist_pass);
 			else
-				hipLaunchKernelGGL((pivot_label_search_kernel<false, 6, 20>), dim3(grid_labels), dim3(64), lds_labels, stream, dA.p, dA.j, d_pinv, n, m, words, rec, lab, pctrl,
-				                   fifo, fifo_cap_labels, gbits, d_deferred, (i64) A->p[n], gap_max, casc_cap);
+				hipLaunchKernelGGL((pivot_label_search_kernel<false, 6, 20>), dim3(grid_pass), dim3(64), lds_labels, stream, dA.p, dA.j, d_pinv, nrows_pass, m, words, rec, lab, pctrl,
+				                   fifo, fifo_cap_labels, gbits, d_out, (i64) A->p[n], gap_pass, cap_pass, rowlist_pass);
 			HIP_CHECK(hipGetLastError());
 			PlCtrl c;
 			HIP_CHECK(hipMemcpyAsync(&c, pctrl, sizeof(PlCtrl), hipMemcpyDeviceToHost, stream));
 			HIP_CHECK(hipStreamSynchronize(stream));
-			t_labels = wtime() - ta - t_labels_init;
+			t_labels += wtime() - tp;
 			if (c.status != 0) {
 				logmsg("[pivots] labelled device search gave up (a wait ran out): the host search takes over\n");
+				for (int i : mine) {
+					qinv[pinv[i]] = -1;
+					pinv[i] = -1;
+				}
 				release();
 				return -1;
 			}
+			counters()[CNT_PIVOT_VISITS] += (long long) c.visits;
+			counters()[CNT_PIVOT_VISITS_WON] += (long long) c.visits_won;
+			counters()[CNT_PIVOT_CASCADE_ITEMS] += (long long) c.casc_items;
+			counters()[CNT_PIVOT_ROWS_WON] += (long long) c.rows_won;
+			counters()[CNT_PIVOT_ROWS_LOST] += (long long) c.rows_lost;
+			counters()[CNT_PIVOT_FREE_ACCEPTS] += (long long) c.free_accepts;
+			if (stats)
+				logmsg("[pivots] device, labelled search, pass %d on %d rows: %d searches in flight (%d per CU, %zu bytes of LDS each%s), %llu pivot rows visited in %llu steps (%llu of them on the %llu rows that ended with a pivot: "
+				       "%llu accepted on their labels alone, %llu after a walk; %llu rows without one), cascades: %llu items in %llu steps (%llu of them thrown away: %llu candidates found reachable, "
+				       "%llu attempts repeated), %d rows deferred (%llu label gap > %d, %llu cascade > %d items, %llu retries) [%.3f s; first wave out of rows after %.1f ms, last one after %.1f ms, longest row %.1f ms]\n",
+				       pass + 1, nrows_pass, grid_pass, per_cu_labels, lds_labels, global_bits ? "; reached-bits in HBM" : "", c.visits, c.steps, c.visits_won, c.rows_won, c.free_accepts, c.walk_accepts, c.rows_lost,
+				       c.casc_items, c.casc_steps, c.casc_wasted, c.cycles, c.restarts, c.ndeferred, c.deferred_gap, gap_pass, c.deferred_cap, cap_pass, c.deferred_retry, wtime() - tp,
+				       1e-5 * (double) (c.t_first_exit - c.t_start), 1e-5 * (double) (c.t_last_exit - c.t_start), 1e-5 * (double) c.longest_search);
+			ndeferred = c.ndeferred;
+			d_deferred = d_out;
+			rowlist_pass = d_out;
+			nrows_pass = ndeferred;
+			if (ndeferred == 0)
+				break;
+		}
+		if (labels) {
 			// its pivots: the rows whose entry of pinv it filled
 			std::vector<int> got((size_t) n);
 			HIP_CHECK(hipMemcpy(got.data(), d_pinv, (size_t) n * sizeof(int), hipMemcpyDeviceToHost));
@@ -1445,22 +1486,10 @@ int device_acyclic_greedy(const struct spasm_csr *A, int *pinv, int *qinv)
 				return -1;
 			}
 			found = (int) mine.size();
-			ndeferred = c.ndeferred;
-			counters()[CNT_PIVOT_VISITS] += (long long) c.visits;
-			counters()[CNT_PIVOT_VISITS_WON] += (long long) c.visits_won;
-			counters()[CNT_PIVOT_CASCADE_ITEMS] += (long long) c.casc_items;
-			counters()[CNT_PIVOT_ROWS_WON] += (long long) c.rows_won;
-			counters()[CNT_PIVOT_ROWS_LOST] += (long long) c.rows_lost;
-			counters()[CNT_PIVOT_FREE_ACCEPTS] += (long long) c.free_accepts;
-			counters()[CNT_PIVOT_DEFERRED] += (long long) c.ndeferred;
+			counters()[CNT_PIVOT_DEFERRED] += (long long) ndeferred;
 			if (stats)
-				logmsg("[pivots] device, labelled search: %d searches in flight (%d per CU, %zu bytes of LDS each%s), %llu pivot rows visited in %llu steps (%llu of them on the %llu rows that ended with a pivot: "
-				       "%llu accepted on their labels alone, %llu after a walk; %llu rows without one), cascades: %llu items in %llu steps (%llu of them thrown away: %llu candidates found reachable, "
-				       "%llu attempts repeated), %d rows deferred (%llu label gap > %d, %llu cascade > %d items, %llu retries) [%.3fs: %.3f upload of A + allocations, %.3f initial labels (%d sweeps), %.3f search; "
-				       "first wave out of rows after %.1f ms, last one after %.1f ms, longest row %.1f ms]\n",
-				       grid_labels, per_cu_labels, lds_labels, global_bits ? "; reached-bits in HBM" : "", c.visits, c.steps, c.visits_won, c.rows_won, c.free_accepts, c.walk_accepts, c.rows_lost,
-				       c.casc_items, c.casc_steps, c.casc_wasted, c.cycles, c.restarts, ndeferred, c.deferred_gap, gap_max, c.deferred_cap, casc_cap, c.deferred_retry, wtime() - t0, t_alloc - t0,
-				       t_labels_init, sweeps, t_labels, 1e-5 * (double) (c.t_first_exit - c.t_start), 1e-5 * (double) (c.t_last_exit - c.t_start), 1e-5 * (double) c.longest_search);
+				logmsg("[pivots] device, labelled search: %d pivots, %d rows left to the ticket search [%.3fs: %.3f upload of A + allocations, %.3f initial labels (%d sweeps), %.3f search]\n", found, ndeferred,
+				       wtime() - t0, t_alloc - t0, t_labels_init, sweeps, t_labels);
 		}
 	}
 
