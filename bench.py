@@ -19,7 +19,7 @@ every rank with an all-gatherv over RCCL (the row-by-row kernels, whose rows nev
 
 Everything in the `roofline` object is measured in this run (HIP events of the library on the launch
 stream, the kernels' own work counters) except `traffic`, which rocprofv3 has to collect in separate
-passes: it is quoted from profiles/r04_traffic.json (written by tools/profile.sh; older rounds' files are looked at
+passes: it is quoted from profiles/r05_traffic.json (written by tools/profile.sh; older rounds' files are looked at
 next) only when that file was recorded for the same kernel on the same workload, with its path in
 `traffic_source`; otherwise null.
 
@@ -48,7 +48,7 @@ PRIME = 42013
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8 TB/s
 MFMA_I8_PEAK_TOPS = 5000.0     # dense i8 (the guide's ~5 P op/s class; AMD's sparsity figures are not used)
 # rocprofv3 PMC passes (tools/profile.sh): newest first; a file only counts for the workload, row count and kernel it names
-TRAFFIC_FILES = ["profiles/r04_traffic.json", "profiles/r04_sparse_traffic.json", "profiles/r03_traffic.json", "profiles/r03_sparse_traffic.json",
+TRAFFIC_FILES = ["profiles/r05_traffic.json", "profiles/r04_traffic.json", "profiles/r04_sparse_traffic.json", "profiles/r03_traffic.json", "profiles/r03_sparse_traffic.json",
                  "profiles/r02_traffic.json"]
 
 
@@ -174,7 +174,7 @@ def dense_tail_probe(torch, spasm_amd, dev, n=4096, m=32768):
            "update_kernels_ms_serialised": ms_upd.value, "update_kernels_Tmacs_per_s": tmacs_upd,
            # 4 int8 digit products per useful multiply-add (two base-256 digits each side), 2 ops per product
            "mfma_i8_frac_of_peak": (8 * tmacs_upd / MFMA_I8_PEAK_TOPS) if tmacs_upd else None}
-    for rel in ("profiles/r04_dense_tail.json", "profiles/r03_dense_tail.json", "profiles/r02_dense_tail.json"):
+    for rel in ("profiles/r05_dense_tail.json", "profiles/r04_dense_tail.json", "profiles/r03_dense_tail.json", "profiles/r02_dense_tail.json"):
         path = os.path.join(ROOT, rel)
         if not os.path.exists(path):
             continue
