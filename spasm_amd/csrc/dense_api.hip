@@ -17,7 +17,8 @@ spasm_hip_dfact *cached_dfact(const struct spasm_csr *U, const int *qinv, hipStr
 void launch_split_rows(const int64_t *Sp, int N, int pieces, int64_t *out, hipStream_t stream);
 void launch_sum_pieces(const uint32_t *parts, int64_t ldp, int N, int pieces, int m, uint32_t p, uint32_t *out, int64_t ldo, hipStream_t stream);
 void launch_combine(const int64_t *Ap, const int *Aj, const int *Ax, const int *rows, int nrows, int N, int w, int m,
-                    uint64_t salt, unsigned long long *Y, const Mont &M, hipStream_t stream, const uint32_t *colmap = nullptr, uint32_t base = 0);
+                    uint64_t salt, unsigned long long *Y, const Mont &M, hipStream_t stream, const uint32_t *colmap, uint32_t base, int64_t annz);
+void launch_dense_reduce_rows(const unsigned long long *Y, int N, int m, const Mont &M, uint32_t *S, int64_t ldS, hipStream_t stream);
 bool rows_are_nonpivotal(const int64_t *Ap, const int *Aj, const int *rows, int nrows, const uint32_t *lab, uint32_t base, hipStream_t stream);
 void launch_dense_count(const unsigned long long *Y, int N, int m, uint32_t p, int *row_len, hipStream_t stream);
 void launch_dense_pack(const unsigned long long *Y, int N, int m, uint32_t p, const int64_t *Sp, int *Sj, int *Sx,
@@ -257,7 +258,32 @@ void device_random_dense_rows(const spasm_hip_dcsr &dA, const int *d_rows, int n
 	// Y = C * A[p, :], dense 64-bit accumulators, then CSR
 	unsigned long long *dY = (unsigned long long *) big_alloc((size_t) N * (size_t) m * sizeof(unsigned long long));
 	HIP_CHECK(hipMemsetAsync(dY, 0, (size_t) N * m * sizeof(unsigned long long), stream));
-	launch_combine(dA.p, dA.j, dA.x, d_rows, n, N, w, m, salt, dY, F->mont, stream, colmap, base);
+	launch_combine(dA.p, dA.j, dA.x, d_rows, n, N, w, m, salt, dY, F->mont, stream, colmap, base, dA.nnz);
+	if (compact && env_int("SPASM_HIP_COMPACT_DIRECT", 1) != 0) {
+		// the rows combined hold non-pivotal columns only: their combinations, reduced mod p, ARE the dense rows on those columns
+		// (mk15.b4: 20-26 ms per 4,096 combinations through count / scan / pack / the elimination kernels, of a finish of 100)
+		launch_dense_reduce_rows(dY, N, m, F->mont, d_S, ldS, stream);
+		HIP_CHECK(hipStreamSynchronize(stream));
+		big_free(dY);
+		if (env_int("SPASM_HIP_COMPACT_CHECK", 0) != 0) {
+			u32 *d_ref = (u32 *) big_alloc((size_t) N * (size_t) ldS * sizeof(u32));
+			device_random_dense_rows(dA, d_rows, n, F, N, w, salt, d_ref, ldS, W, stream, false);
+			std::vector<u32> x((size_t) N * (size_t) ldS), y((size_t) N * (size_t) ldS);
+			HIP_CHECK(hipMemcpy(x.data(), d_S, x.size() * sizeof(u32), hipMemcpyDeviceToHost));
+			HIP_CHECK(hipMemcpy(y.data(), d_ref, y.size() * sizeof(u32), hipMemcpyDeviceToHost));
+			size_t differ = 0;
+			for (size_t k = 0; k < (size_t) N; k++)
+				for (size_t j = 0; j < (size_t) F->Sm; j++)
+					differ += x[k * (size_t) ldS + j] != y[k * (size_t) ldS + j];
+			logmsg("[dense rows/check] combinations on the non-pivotal columns, reduced directly, against the full path: %zu of %zu entries differ\n", differ, (size_t) N * (size_t) F->Sm);
+			big_free(d_ref);
+			if (differ != 0)
+				die("combinations formed on the non-pivotal columns only differ from those formed on all columns (%zu entries)", differ);
+		}
+		if (verbose() >= 2)
+			logmsg("[dense rows] %d combinations on the %d non-pivotal columns: %.3fs\n", N, m, wtime() - t0);
+		return;
+	}
 	launch_dense_count(dY, N, m, (uint32_t) F->prime, W->d_row_len, stream);
 	launch_row_scan(W->d_row_len, N, W->d_blocksum, W->d_Sp, stream);
 	i64 ynnz = 0;
@@ -886,7 +912,7 @@ void spasm_hip_debug_combine(const struct spasm_csr *A, const int *rows, int nro
 	const size_t count = (size_t) N * (size_t) m;
 	unsigned long long *dY = static_cast<unsigned long long *>(sh::big_alloc(count * sizeof(unsigned long long)));
 	HIP_CHECK(hipMemsetAsync(dY, 0, count * sizeof(unsigned long long), stream));
-	launch_combine(dA.p, dA.j, dA.x, d_rows, nrows, N, w, m, salt, dY, mont_setup(A->field->p), stream);
+	launch_combine(dA.p, dA.j, dA.x, d_rows, nrows, N, w, m, salt, dY, mont_setup(A->field->p), stream, nullptr, 0, (int64_t) A->p[A->n]);
 	std::vector<unsigned long long> h(count);
 	HIP_CHECK(hipMemcpyAsync(h.data(), dY, count * sizeof(unsigned long long), hipMemcpyDeviceToHost, stream));
 	HIP_CHECK(hipStreamSynchronize(stream));

@@ -3088,7 +3088,7 @@ constexpr int CB_ROWS = 2048, CB_COLS = 1024, CB_THREADS = 256, CB_PER_THREAD = 
 template <bool MAPPED>
 __global__ __launch_bounds__(CB_THREADS) void combine_all_rows_blocked_kernel(const int64_t *Ap, const int *Aj, const int *Ax, const int *rows, int nrows, int N, int m,
                                                                               uint64_t salt, unsigned long long *Y, int *unsorted, MontDev F, const uint32_t *colmap,
-                                                                              uint32_t cbase)
+                                                                              uint32_t cbase, int64_t annz)
 {
 	extern __shared__ __attribute__((aligned(16))) uint32_t cb_lds[];
 	uint32_t *acc = cb_lds;                                                            // [CB_COLS][N]
@@ -3109,6 +3109,21 @@ __global__ __launch_bounds__(CB_THREADS) void combine_all_rows_blocked_kernel(co
 		acc[e] = 0;
 	int64_t cur[CB_PER_THREAD], end[CB_PER_THREAD];
 	int prev[CB_PER_THREAD];
+	// A thread walks ITS rows: with one 4-byte load per entry every load instruction of a wave touched 64 different lines for
+	// 256 useful bytes, and the lines did not survive in the L1 until their next entry was wanted (2,048 rows x two arrays per
+	// workgroup) -- 48 ms for the 1e9 entries of mk15.b4's Schur complement, sixteen times the bytes.  The next four entries of
+	// every row are kept in registers, fetched by aligned 16-byte loads (a row's entries are contiguous).
+	int4 bj[CB_PER_THREAD], bx[CB_PER_THREAD];
+	auto refill = [&](int q) {
+		const int64_t b = cur[q] & ~(int64_t) 3;
+		if (b + 4 <= annz) {
+			bj[q] = *reinterpret_cast<const int4 *>(Aj + b);
+			bx[q] = *reinterpret_cast<const int4 *>(Ax + b);
+		} else {          // (the last entries of the arrays: one by one)
+			bj[q] = make_int4(b < annz ? Aj[b] : 0, b + 1 < annz ? Aj[b + 1] : 0, b + 2 < annz ? Aj[b + 2] : 0, 0);
+			bx[q] = make_int4(b < annz ? Ax[b] : 0, b + 1 < annz ? Ax[b + 1] : 0, b + 2 < annz ? Ax[b + 2] : 0, 0);
+		}
+	};
 #pragma unroll
 	for (int q = 0; q < CB_PER_THREAD; q++) {
 		const int64_t t = base + tid + (int64_t) q * CB_THREADS;
@@ -3116,6 +3131,9 @@ __global__ __launch_bounds__(CB_THREADS) void combine_all_rows_blocked_kernel(co
 		cur[q] = (t < nrows) ? Ap[i] : 0;
 		end[q] = (t < nrows) ? Ap[i + 1] : 0;
 		prev[q] = -1;
+		bj[q] = bx[q] = make_int4(0, 0, 0, 0);
+		if (cur[q] < end[q])
+			refill(q);
 	}
 	__syncthreads();
 	bool bad = false;
@@ -3126,20 +3144,23 @@ __global__ __launch_bounds__(CB_THREADS) void combine_all_rows_blocked_kernel(co
 		for (int q = 0; q < CB_PER_THREAD; q++) {
 			const unsigned short *cf = coef + (size_t) (tid + q * CB_THREADS) * N;
 			while (cur[q] < end[q]) {
-				int j = Aj[cur[q]];
+				const int sub = (int) (cur[q] & 3);
+				int j = (sub == 0) ? bj[q].x : (sub == 1) ? bj[q].y : (sub == 2) ? bj[q].z : bj[q].w;
 				if constexpr (MAPPED)
 					j = (int) (colmap[j] - cbase);          // (monotone in the column: rows stay sorted)
 				if (j >= hi)
 					break;
 				bad = bad || j <= prev[q];
 				prev[q] = j;
-				const int a = Ax[cur[q]];
+				const int a = (sub == 0) ? bx[q].x : (sub == 1) ? bx[q].y : (sub == 2) ? bx[q].z : bx[q].w;
 				const uint32_t v = ((a < 0) ? (uint32_t) a + F.p : (uint32_t) a) % F.p;
 				if (j >= lo)
 					for (int k = 0; k < N; k++)
 						atomicAdd(&acc[(j - lo) * N + k], montmul((uint32_t) cf[k], v, F));
 				cur[q] += 1;
 				any = true;
+				if (sub == 3 && cur[q] < end[q])
+					refill(q);
 			}
 		}
 		// (a block nobody of this workgroup touched: nothing to flush, nothing to clear)
@@ -3296,7 +3317,7 @@ void launch_echelon_pack(const uint32_t *M, int64_t ld, int m, int k, const int 
 }
 
 void launch_combine(const int64_t *Ap, const int *Aj, const int *Ax, const int *rows, int nrows, int N, int w, int m,
-                    uint64_t salt, unsigned long long *Y, const Mont &M, hipStream_t stream, const uint32_t *colmap, uint32_t base)
+                    uint64_t salt, unsigned long long *Y, const Mont &M, hipStream_t stream, const uint32_t *colmap, uint32_t base, int64_t annz)
 {
 	const int64_t terms = (w > 0) ? (int64_t) w : (int64_t) nrows;
 	const int64_t total = (int64_t) N * terms;
@@ -3314,10 +3335,10 @@ void launch_combine(const int64_t *Ap, const int *Aj, const int *Ax, const int *
 		HIP_CHECK(hipMemsetAsync(d_flag, 0, sizeof(int), stream));
 		if (colmap != nullptr)
 			hipLaunchKernelGGL(combine_all_rows_blocked_kernel<true>, dim3((unsigned) ((nrows + CB_ROWS - 1) / CB_ROWS)), dim3(CB_THREADS), lds, stream, Ap, Aj, Ax, rows, nrows,
-			                   N, m, salt, Y, d_flag, to_dev(M), colmap, base);
+			                   N, m, salt, Y, d_flag, to_dev(M), colmap, base, annz);
 		else
 			hipLaunchKernelGGL(combine_all_rows_blocked_kernel<false>, dim3((unsigned) ((nrows + CB_ROWS - 1) / CB_ROWS)), dim3(CB_THREADS), lds, stream, Ap, Aj, Ax, rows, nrows,
-			                   N, m, salt, Y, d_flag, to_dev(M), colmap, base);
+			                   N, m, salt, Y, d_flag, to_dev(M), colmap, base, annz);
 		HIP_CHECK(hipGetLastError());
 		int flag = 0;
 		HIP_CHECK(hipMemcpyAsync(&flag, d_flag, sizeof(int), hipMemcpyDeviceToHost, stream));
@@ -3409,6 +3430,25 @@ bool rows_are_nonpivotal(const int64_t *Ap, const int *Aj, const int *rows, int 
 	HIP_CHECK(hipStreamSynchronize(stream));
 	HIP_CHECK(hipFree(d_flag));
 	return flag == 0;
+}
+
+// S[k][j] = Y[k][j] mod p: accumulators that span exactly the non-pivotal columns ARE the dense rows (nothing to reduce: the rows
+// combined hold no pivotal column), no detour through CSR and the elimination kernels
+__global__ __launch_bounds__(256) void dense_reduce_rows_kernel(const unsigned long long *Y, int N, int m, MontDev F, uint32_t *S, int64_t ldS)
+{
+	const int k = blockIdx.y;
+	for (int j = blockIdx.x * 256 + threadIdx.x; j < m; j += gridDim.x * 256) {
+		const unsigned long long v = Y[(int64_t) k * m + j];
+		S[(int64_t) k * ldS + j] = (v == 0) ? 0u : reduce_sum(v, F);
+	}
+}
+
+void launch_dense_reduce_rows(const unsigned long long *Y, int N, int m, const Mont &M, uint32_t *S, int64_t ldS, hipStream_t stream)
+{
+	if (N <= 0 || m <= 0)
+		return;
+	hipLaunchKernelGGL(dense_reduce_rows_kernel, dim3((unsigned) std::min(1024, (m + 255) / 256), (unsigned) N), dim3(256), 0, stream, Y, N, m, to_dev(M), S, ldS);
+	HIP_CHECK(hipGetLastError());
 }
 
 void launch_dense_count(const unsigned long long *Y, int N, int m, uint32_t p, int *row_len, hipStream_t stream)
