@@ -36,8 +36,11 @@ def _random_matrix(n, m, seed, max_len, prime):
 
 def _search(A, where, bits=None):
     """where: "device" (refuses to fall back) / "host"; bits: "global" = the reached-bits in HBM even when they fit the LDS"""
-    saved = {k: os.environ.get(k) for k in ("SPASM_HIP_PIVOT_SEARCH", "SPASM_HIP_PIVOT_BITS")}
+    saved = {k: os.environ.get(k) for k in ("SPASM_HIP_PIVOT_SEARCH", "SPASM_HIP_PIVOT_BITS", "SPASM_HIP_PIVOT_CHECK")}
     os.environ["SPASM_HIP_PIVOT_SEARCH"] = where
+    # (the device hands back depth labels and the rows are ordered by them: here the host checks that order on top -- the
+    #  library dies if it is not triangular -- and _check() below checks it once more from the outside)
+    os.environ["SPASM_HIP_PIVOT_CHECK"] = "1"
     if bits is not None:
         os.environ["SPASM_HIP_PIVOT_BITS"] = bits
     try:
