@@ -94,8 +94,47 @@ struct Search {
 		return fresh;
 	}
 
+	// the same on large inputs, by threads: the pivot of a column is the row of smallest (weight, index) among the rows whose
+	// leftmost entry it is -- what the loop below arrives at, row after row -- found with one atomic minimum per row
+	int leftmost_entries_threads(int T)
+	{
+		const int n = A->n, m = A->m;
+		std::vector<std::atomic<uint64_t>> best((size_t) (m > 0 ? m : 1));
+		for (int j = 0; j < m; j++)
+			best[(size_t) j].store(~0ull, std::memory_order_relaxed);
+		auto scan = [&](int lo, int hi) {
+			for (int i = lo; i < hi; i++) {
+				int left = m + 1;
+				for (i64 px = A->p[i]; px < A->p[i + 1]; px++)
+					if (A->j[px] < left)
+						left = A->j[px];
+				if (left > m)
+					continue;
+				const uint64_t key = ((uint64_t) (uint32_t) weight(i) << 32) | (uint32_t) i;
+				uint64_t cur = best[(size_t) left].load(std::memory_order_relaxed);
+				while (key < cur && !best[(size_t) left].compare_exchange_weak(cur, key, std::memory_order_relaxed)) {
+				}
+			}
+		};
+		std::vector<std::thread> pool;
+		for (int t = 1; t < T; t++)
+			pool.emplace_back(scan, (int) ((i64) n * t / T), (int) ((i64) n * (t + 1) / T));
+		scan(0, (int) ((i64) n / T));
+		for (auto &th : pool)
+			th.join();
+		int found = 0;
+		for (int j = 0; j < m; j++) {
+			const uint64_t key = best[(size_t) j].load(std::memory_order_relaxed);
+			if (key != ~0ull)
+				found += take((int) (uint32_t) key, j);
+		}
+		return found;
+	}
+
 	int leftmost_entries()
 	{
+		if (A->n >= 200000 && usable_cpus() > 1)
+			return leftmost_entries_threads(std::min(16, usable_cpus()));
 		int found = 0;
 		for (int i = 0; i < A->n; i++) {
 			int best = A->m + 1;
@@ -819,7 +858,7 @@ extern "C" int spasm_hip_pivots_extract_structural(const struct spasm_csr *A, co
 		}
 	};
 	{
-		const int T = (npiv < 20000) ? 1 : std::max(1, std::min(8, usable_cpus()));
+		const int T = (npiv < 20000) ? 1 : std::max(1, std::min(16, usable_cpus()));
 		std::vector<std::thread> pool;
 		for (int t = 1; t < T; t++)
 			pool.emplace_back(fill_rows, (int) ((i64) npiv * t / T), (int) ((i64) npiv * (t + 1) / T));
