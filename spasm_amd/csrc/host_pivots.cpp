@@ -237,34 +237,64 @@ struct Search {
 	int acyclic_greedy_labels()
 	{
 		const int n = A->n, m = A->m;
-		std::vector<int> D((size_t) (m > 0 ? m : 1), 0), work;
-		auto cascade = [&](int i, int j) {          // row i got the pivot j
-			work.clear();
+		std::vector<int> D((size_t) (m > 0 ? m : 1), 0), pend((size_t) (m > 0 ? m : 1), 0);
+		std::vector<std::pair<int, int>> items;
+		// The cascade of the device search: a breadth-first list of (column, new label) items -- children = parent + 1 --, built
+		// without touching the labels and applied only when it is complete.  Returns 0 when row i may take the pivot j (labels
+		// raised), 1 when the cascade comes back to j itself (j IS reachable from the row, through pivots the walk did not look
+		// at: see `lag` below), 2 when it outgrows `cap` items; in both cases nothing was changed.
+		auto cascade = [&](int i, int j, size_t cap) -> int {          // row i gets the pivot j
+			items.clear();
+			const int dj = D[j];
+			int outcome = 0;
 			for (i64 px = A->p[i]; px < A->p[i + 1]; px++) {
 				const int x = A->j[px];
-				if (x != j && D[x] <= D[j]) {
-					D[x] = D[j] + 1;
-					if (qinv[x] >= 0)
-						work.push_back(x);
+				if (x != j && D[x] <= dj && pend[x] <= dj) {
+					items.push_back({x, dj + 1});
+					pend[x] = dj + 1;
 				}
 			}
-			while (!work.empty()) {
-				const int c = work.back();
-				work.pop_back();
-				const int r = qinv[c];
+			for (size_t h = 0; h < items.size() && outcome == 0; h++) {
+				const int x = items[h].first, v = items[h].second;
+				if (pend[x] > v || qinv[x] < 0)
+					continue;
+				const int r = qinv[x];
 				for (i64 px = A->p[r]; px < A->p[r + 1]; px++) {
 					const int e = A->j[px];
-					if (e != c && D[e] <= D[c]) {
-						D[e] = D[c] + 1;
-						if (qinv[e] >= 0)
-							work.push_back(e);
+					if (e == x)
+						continue;
+					if (e == j) {
+						outcome = 1;
+						break;
+					}
+					if (D[e] <= v && pend[e] <= v) {
+						items.push_back({e, v + 1});
+						pend[e] = v + 1;
 					}
 				}
+				if (items.size() > cap)
+					outcome = 2;
 			}
+			for (size_t h = items.size(); h-- > 0;) {
+				if (outcome == 0)
+					D[items[h].first] = std::max(D[items[h].first], items[h].second);
+				pend[items[h].first] = 0;
+			}
+			return outcome;
 		};
 		for (int i = 0; i < n; i++)
 			if (pinv[i] >= 0)
-				cascade(i, pinv[i]);
+				cascade(i, pinv[i], (size_t) -1);
+		// The device runs 2,048 searches at a time: a walk does not see the pivots committed since its row was picked up, and the
+		// pivots of rows that are in flight together do not chain off each other -- which is why the pivot graphs of the device
+		// are a fifth as deep as those of a strictly sequential search (mk15.b4: 450-650 elimination levels against 2,500-3,100)
+		// and the Schur complements that follow a quarter of the size.  To give the same kind of pivot set, deterministically, a
+		// walk here only expands pivots that are at least `lag` rows old (the cascade -- which sees everything -- rejects a
+		// candidate that the younger ones make reachable).
+		int lag = 8192;
+		if (const char *e = sh::env_get("SPASM_HIP_PIVOT_LAG"))
+			lag = std::max(0, std::atoi(e));
+		std::vector<int> born((size_t) (m > 0 ? m : 1), -0x40000000);          // row at which the pivot of a column was taken
 		std::vector<signed char> mark((size_t) (m > 0 ? m : 1), 0);
 		std::vector<int> fifo((size_t) (m > 0 ? m : 1));
 		int found = 0;
@@ -276,8 +306,15 @@ struct Search {
 		int gap = 64;
 		if (const char *e = sh::env_get("SPASM_HIP_PIVOT_GAP"))
 			gap = std::max(0, std::atoi(e));
-		std::vector<int> put_off;
-		for (int pass = 0; pass < 2; pass++)
+		// ... and, as on the device, a cascade that outgrows 8,192 items puts its row off as well (these are the pivots that
+		// make the graph deep: mk14.b4 has 1,900-2,150 elimination levels when every cascade is run as it comes, a few hundred
+		// when the long ones wait); the rows put off are taken again with cascades of up to 65,536 items, and what is left
+		// after that without a limit.
+		std::vector<int> put_off, later;
+		for (int pass = 0; pass < 3; pass++) {
+		const size_t cap = (pass == 0) ? 8192 : (pass == 1) ? 65536 : (size_t) -1;
+		if (pass == 2)
+			put_off.swap(later);
 		for (int i0 = 0; i0 < (pass == 0 ? n : (int) put_off.size()); i0++) {
 			const int i = (pass == 0) ? i0 : put_off[(size_t) i0];
 			if (pinv[i] >= 0)
@@ -313,7 +350,7 @@ struct Search {
 				while (head < tail && candidates > 0) {
 					const int c = fifo[head++];
 					const int row = qinv[c];
-					if (row == -1 || D[c] >= reach)
+					if (row == -1 || D[c] >= reach || (pass == 0 && born[c] + lag > i0))
 						continue;
 					visits += 1;
 					const int before = candidates;
@@ -338,13 +375,21 @@ struct Search {
 			if (chosen >= 0 && pass == 0 && lowest != 0x7fffffff && D[chosen] - lowest > gap) {
 				put_off.push_back(i);
 			} else if (chosen >= 0) {
-				found += take(i, chosen);
-				cascade(i, chosen);
+				const int outcome = cascade(i, chosen, cap);
+				if (outcome == 0) {
+					found += take(i, chosen);
+					born[chosen] = (pass == 0) ? i0 : -0x40000000;
+				} else if (pass == 0) {
+					put_off.push_back(i);          // (reachable through young pivots, or a long cascade: looked at again later, with everything in sight)
+				} else if (pass == 1 && outcome == 2) {
+					later.push_back(i);
+				}
 			}
 			for (i64 px = A->p[i]; px < A->p[i + 1]; px++)
 				mark[A->j[px]] = 0;
 			for (int t = 0; t < tail; t++)
 				mark[fifo[t]] = 0;
+		}
 		}
 		if (sh::env_get("SPASM_HIP_PIVOT_STATS"))
 			logmsg("[pivots] sequential search with labels: %llu pivot rows visited for %d pivots\n", visits, found);
