@@ -40,8 +40,12 @@ NAMES = [c["name"] for c in workloads.CONFIGS] + EXTRA
 # ch7-8.b5 / ch8-8.b5: 92959 is the published rank of ch7-8.b5 (hpac table); 276031 was recomputed on the CPU with the compiled
 # reference and numpy (tools/cpu_rank_check_projected.py: 271,552 structural pivots + 4,479, profiles/r04_cpu_rank_check_ch8-8.b5.log).
 # mk14.b4: 272,862 + 321 by tools/cpu_rank_check.py (profiles/r04_cpu_rank_check_mk14.b4.log).
-# mk15.b4 (2,837,835 x 675,675, 14.2 M entries: the at-scale stand-in) and mk14.b5 (945,945 x 945,945): what every flow of this
-# library returns, equal to the rank of the transpose -- no independent value exists.
+# mk15.b4 (2,837,835 x 675,675, 14.2 M entries: the at-scale stand-in): 604,176 structural pivots + 415 = 604,591 by
+# tools/cpu_rank_check_sparse.py -- pivots and all 2,233,659 rows of the Schur complement (3.8e9 entries) from the COMPILED
+# REFERENCE, folded into 2,048 random combinations and eliminated exactly in numpy, 2 h 21 min on six cores, run end to end by
+# the script (profiles/r05_cpu_rank_check_mk15.b4.log).  mk14.b5 (945,945 x 945,945): what every flow of this library
+# returns, equal to the rank of the transpose -- no independent value (its Schur complement, 22 % dense on 290,000 columns
+# with a rank of 17,000, is out of reach of the reference's spasm_schur on this container: see DESIGN.md section 5).
 RANKS = {"mk13.b5": 134211, "mk13.b4": 111463, "ch7-8.b5": 92959, "ch8-8.b5": 276031, "mk14.b4": 273183, "mk15.b4": 604591,
          "mk14.b5": 672762}
 
