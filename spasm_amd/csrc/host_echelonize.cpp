@@ -506,15 +506,28 @@ extern "C" struct spasm_lu *spasm_hip_echelonize(const struct spasm_csr *A0, str
 		logmsg("[echelonize] finishing; density = %.3f; aspect ratio = %.1f\n", density, aspect);
 		// (status 3: the entries of A may be on the device only; the device finish never reads them on the host, everything
 		// else gets them first)
+		// (a remainder that the device finish cannot hold -- its stack of echelon rows is rows x non-pivotal columns words -- goes
+		//  through the host loops of the reference: minutes to hours on a remainder of a million columns.  That is what the WIDE
+		//  orientation of a matrix leads to (the transpose of mk15.b4: 730 s where the tall orientation takes 0.3 s); tools/rank
+		//  transposes such a matrix first, a caller of this function is told)
+		auto leaving_the_device = [&]() {
+			const int cols_left = m - U->n;
+			if (cols_left > 1000000 || (A0->m > 2 * (i64) A0->n && cols_left > 200000))
+				std::fprintf(stderr, "[spasm-hip] warning: the dense finish of this %d x %d matrix (%d columns left) does not fit the device and runs in the host loops: "
+				                     "expect minutes to hours.%s\n", A0->n, A0->m, cols_left,
+				             A0->m > A0->n ? "  The matrix has more columns than rows: echelonize its transpose (same rank) as tools/rank does." : "");
+		};
 		if (opts->enable_tall_and_skinny && aspect > opts->tall_and_skinny_ratio) {
 			Stopwatch sw(4);
 			if (!finish_on_device(A, p + npiv, n - npiv, fact, opts, true)) {
+				leaving_the_device();
 				resident_materialize(A);
 				finish_lowrank(A, p + npiv, n - npiv, fact, opts);
 			}
 		} else if (opts->enable_dense && density > opts->sparsity_threshold) {
 			Stopwatch sw(4);
 			if (!finish_on_device(A, p + npiv, n - npiv, fact, opts, false)) {
+				leaving_the_device();
 				resident_materialize(A);
 				finish_dense(A, p + npiv, n - npiv, p_in, fact, opts);
 			}
