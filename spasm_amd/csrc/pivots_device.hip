@@ -1395,6 +1395,7 @@ int device_acyclic_greedy(const struct spasm_csr *A, int *pinv, int *qinv, std::
 	double t_labels_init = 0.0, t_labels = 0.0;
 	std::vector<int> mine;          // the rows that got their pivot in the first pass
 	uint32_t *lab = nullptr;        // the label words of the labelled search
+	int ticket_pivots = 0;          // pivots the ticket search added behind it
 	int *d_changed_final = nullptr;
 	if (labels) {
 		const double ta = wtime();
@@ -1425,12 +1426,12 @@ int device_acyclic_greedy(const struct spasm_csr *A, int *pinv, int *qinv, std::
 		// 347,000 rows deferred, 33,000 of them end with a pivot; through the ticket search they cost 120,000 visits apiece:
 		// 6-9 s of a 10-12 s call).  What the second pass defers goes to the ticket search.
 		const int npasses = std::max(1, std::min(2, env_int("SPASM_HIP_PIVOT_LABEL_PASSES", 2)));
-		int nrows_pass = n;
+		int nrows_pass = n, late_cap_now = casc_cap_late;
 		const int *rowlist_pass = nullptr;
 		for (int pass = 0; pass < npasses && labels; pass++) {
 			const double tp = wtime();
 			const int gap_pass = (pass == 0) ? gap_max : (1 << 30);
-			const int cap_pass = (pass == 0) ? casc_cap : casc_cap_late;
+			const int cap_pass = (pass == 0) ? casc_cap : late_cap_now;
 			int *d_out = (int *) dal((size_t) std::max(nrows_pass, 1) * sizeof(int));
 			PlCtrl init;
 			std::memset(&init, 0, sizeof(init));
@@ -1474,7 +1475,16 @@ int device_acyclic_greedy(const struct spasm_csr *A, int *pinv, int *qinv, std::
 			d_deferred = d_out;
 			rowlist_pass = d_out;
 			nrows_pass = ndeferred;
-			if (ndeferred == 0)
+			// Is a second labelled pass worth it?  Its long cascades are a latency tail (milliseconds per wave), the ticket search
+			// costs a closure per row; measured on five matrices (tools/probe_pivot_passes.sh): with MANY rows deferred (mk15.b5:
+			// 300,000) it is what makes the call (cascades up to 65,536 items: 8 s of ticket search -> 0.7); with few, cascades up
+			// to 16,384 items leave the ticket search a dozen pivots, few enough for the labels to settle afterwards and replace
+			// the host's depth-first search (mk15.b4 104 -> 79 ms, mk14.b4 58 -> 46) -- unless the rows were deferred by the gap
+			// rule rather than by the cap (mk13.b5 65 : 1, ch8-8.b5 4 : 1): those sit far above their rows, their cascades are the
+			// longest, and the ticket search takes them faster (mk13.b5 20 against 27-36 ms, ch8-8.b5 76 against 93-114).
+			const bool many = ndeferred >= env_int("SPASM_HIP_PIVOT_SECOND_PASS_MANY_ROWS", 32768);
+			late_cap_now = many ? casc_cap_late : std::min(casc_cap_late, std::max(casc_cap, 16384));
+			if (!many && c.deferred_gap > 3 * c.deferred_cap && env_int("SPASM_HIP_PIVOT_SECOND_PASS_ALWAYS", 0) == 0)
 				break;
 		}
 		if (labels) {
@@ -1605,10 +1615,14 @@ int device_acyclic_greedy(const struct spasm_csr *A, int *pinv, int *qinv, std::
 			found = -1;
 		} else {
 			found += found2;
+			ticket_pivots = found2;
 		}
 	}
 	// ---- the labels of the final pivot set (see the head of this function)
-	if (found >= 0 && labels && lab != nullptr && col_label != nullptr && env_int("SPASM_HIP_PIVOT_ORDER_BY_LABELS", 1) != 0) {
+	// (only when the ticket search added few pivots: every one of them hangs a long chain of sweeps under its row -- mk13.b5,
+	//  450 of them: not settled after 30 ms, which were then lost)
+	if (found >= 0 && labels && lab != nullptr && col_label != nullptr && ticket_pivots <= env_int("SPASM_HIP_PIVOT_ORDER_MAX_TICKET_PIVOTS", 64) &&
+	    env_int("SPASM_HIP_PIVOT_ORDER_BY_LABELS", 1) != 0) {
 		const double tl = wtime();
 		HIP_CHECK(hipMemcpyAsync(d_qinv, qinv, (size_t) m * sizeof(int), hipMemcpyHostToDevice, stream));
 		hipLaunchKernelGGL(pivot_labels_states_kernel, dim3((m + 255) / 256), dim3(256), 0, stream, d_qinv, m, lab);
