@@ -21,9 +21,11 @@
  * fatal condition -- no usable GPU, out of device memory, malformed input --
  * prints "[spasm-hip] ..." on stderr and exits.  There is NO CPU fallback.
  *
- * Environment.  These switches are supported (read at every call):
+ * Environment.  These switches are supported (read at every call -- SPASM_HIP_SPARSE_IMAGE and SPASM_HIP_BACKSOLVE also decide what
+ * the image of a factor plans when it is created: a cached image keeps the setting it was created under):
  *   SPASM_HIP_VERBOSE=0..3        progress messages on stderr (default 1: what the reference prints)
- *   SPASM_HIP_THREADS=n           host threads of the pivot search and the planning (default: the CPU quota of the cgroup)
+ *   SPASM_HIP_THREADS=n           host threads of the pivot search and the planning (default: the CPU quota of the cgroup; 1: a
+ *                                 sequential search on the host -- a pivot set that does not depend on timing)
  *   SPASM_HIP_PIVOT_SEARCH=host|device   where the greedy cycle-free search runs (default: the device when there is one)
  *   SPASM_HIP_SPARSE_IMAGE=0|1    never / always take the sparse image R = U_pp^-1 U_pn for a Schur complement (default: cost model)
  *   SPASM_HIP_BACKSOLVE=0|1       never / always take the dense image (default: cost model); both 0: row-by-row kernels
