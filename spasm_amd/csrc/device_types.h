@@ -199,6 +199,8 @@ struct SpImage {
 	uint2 *d_dep = nullptr;           // ... (compact row of the pivot, NEGATED balanced coefficient; wide: Montgomery form of the negated coefficient)
 	uint64_t *d_np_rp = nullptr;      // per compact row: its non-pivotal entries ...
 	uint2 *d_np = nullptr;            // ... (index among the non-pivotal columns, balanced value; wide: plain residue)
+	uint64_t *d_segmask = nullptr;    // per compact row: the segments in which its row of R CAN have entries (its own non-pivotal entries
+	                                  // and those of the rows it depends on: structural, an upper bound) -- nullptr beyond 64 segments
 	uint64_t *d_frag = nullptr;       // r * nseg words: chunk << 54 | offset << 14 | length
 	uint32_t *d_chunk[SP_MAX_CHUNKS] = {};
 	int64_t chunk_cap[SP_MAX_CHUNKS] = {};        // entries (4 bytes each; wide: 8)
