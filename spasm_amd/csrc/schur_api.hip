@@ -1957,13 +1957,14 @@ struct spasm_csr *spasm_hip_schur(const struct spasm_csr *A, const int *p, int n
 	// 100 rows (spasm_schur_estimate_density) and the rows of these Schur complements differ by orders of magnitude: mk15.b4
 	// was given 2.54e9 entries for 1.86e9 in one call and too few in another -- and a pool that is too small means the whole
 	// call again on a fresh block of twice the size (tens of GB that the device has to map: the 2.2 s sparse round in one
-	// call of five of round 4's bench, where the others took 0.07).  Here R is built first and 8,192 rows spread over the
-	// batch go through it (half a millisecond): their entries, scaled, + 12 % + what the waves strand in their arenas.
+	// call of five of round 4's bench, where the others took 0.07).  Here R is built first and 16,384 rows spread over the
+	// batch go through it (under a millisecond): their entries, scaled, + 15 % + what the waves strand in their arenas
+	// (8,192 rows + 12 % still fell short once in fifteen mk14.b4 calls).
 	double ms_sample = 0.0;
 	if (L == nullptr && !shard && n >= 65536 && env_int("SPASM_HIP_POOL_SAMPLE", 1) != 0 &&
 	    sparse_image_wanted(F, env_int("SPASM_HIP_FORCE_TIER", 0) != 0 || env_int("SPASM_HIP_GROUP", -1) >= 0, n) &&
 	    (F->sp.valid || sparse_image_build(F, stream))) {
-		const int ns = 8192;
+		const int ns = 16384;
 		std::vector<int> sample((size_t) ns);
 		for (int k = 0; k < ns; k++)
 			sample[(size_t) k] = p[(i64) k * n / ns];
@@ -1979,7 +1980,7 @@ struct spasm_csr *spasm_hip_schur(const struct spasm_csr *A, const int *p, int n
 			if (rc == 0) {
 				ms_sample = sts.ms_total;
 				if (sts.used_sparse_image && sts.nnz > 0) {
-					const i64 sized = (i64) (1.12 * (double) sts.nnz / (double) ns * (double) n) + (i64) 48 * 1024 * 1024;
+					const i64 sized = (i64) (1.15 * (double) sts.nnz / (double) ns * (double) n) + (i64) 48 * 1024 * 1024;
 					if (verbose() >= 2)
 						logmsg("[schur/hip] pool of S: %" PRId64 " entries from %d sampled rows through the sparse image (%.1f per row), %" PRId64 " from the driver's estimate\n",
 						       sized, ns, (double) sts.nnz / ns, pool);

@@ -134,3 +134,44 @@ def test_device_search_with_long_rows_on_a_matrix_too_wide_for_the_lds():
     npiv, perm, F = _search(A, "device")
     assert npiv > 0.5 * A.n
     _check(A, npiv, perm, F)
+
+
+@pytest.mark.parametrize("switches", [{"SPASM_HIP_PIVOT_CASCADE": "64", "SPASM_HIP_PIVOT_CASCADE_LATE": "64"},
+                                      {"SPASM_HIP_PIVOT_GAP": "0"},
+                                      {"SPASM_HIP_PIVOT_LABEL_FIFO": "256"},
+                                      {"SPASM_HIP_PIVOT_SECOND_PASS_ALWAYS": "1", "SPASM_HIP_PIVOT_SECOND_PASS_MANY_ROWS": "0"},
+                                      {"SPASM_HIP_PIVOT_LABEL_PASSES": "1"},
+                                      {"SPASM_HIP_PIVOT_ORDER_BY_LABELS": "0"},
+                                      {"SPASM_HIP_PIVOT_LABELS": "0"}])
+@pytest.mark.parametrize("name", ["mk13.b5", "ch7-8.b5"])
+def test_labelled_search_under_starved_limits(name, switches, monkeypatch):
+    """the passes of the labelled search with their limits pulled tight -- cascades of at most 64 items, a label gap of 0 (every
+    pivot that needs a walk is deferred), a FIFO of 256 columns (walks overflow and defer their row), the second pass always /
+    never, the host's depth-first order instead of the label order, the ticket search alone: whatever is deferred must reach
+    the next pass, and the pivot set that comes back is cycle-free, in triangular order (checked by the host inside the library
+    -- SPASM_HIP_PIVOT_CHECK -- and by _check from the outside), and within 5 % of the host's in size."""
+    for k, v in switches.items():
+        monkeypatch.setenv(k, v)
+    A, _ = workloads.load_matrix(name)
+    npiv, perm, F = _search(A, "device")
+    _check(A, npiv, perm, F)
+    npiv_h, _, _ = _search(A, "host")
+    assert npiv >= 0.95 * npiv_h
+
+
+def test_labelled_search_is_what_runs_by_default(monkeypatch):
+    """the counters of the driver say which search ran: visits of the labelled search are a small fraction of the rows times
+    the pivots, some pivots are accepted on their labels alone, and the ticket search alone (SPASM_HIP_PIVOT_LABELS=0) visits
+    at least ten times as many pivot rows for a pivot set of the same size (mk13.b5: 6e8 against 3e7)"""
+    A, _ = workloads.load_matrix("mk13.b5")
+    o = spasm_amd.default_opts()
+    F = spasm_amd.echelonize(A, o)
+    ev = spasm_amd.echelonize_counters()
+    assert F.U.n == 134211
+    assert ev["pivots_accepted_on_labels_alone"] > 1000 and ev["pivot_rows_with_a_pivot"] > 30000
+    labelled = ev["pivot_visits"]
+    monkeypatch.setenv("SPASM_HIP_PIVOT_LABELS", "0")
+    F = spasm_amd.echelonize(A, o)
+    ev = spasm_amd.echelonize_counters()
+    assert F.U.n == 134211
+    assert ev["pivots_accepted_on_labels_alone"] == 0 and ev["pivot_visits"] > 10 * labelled
