@@ -422,6 +422,9 @@ def main():
                          "(spasm_hip_column_slab: no replicated factor image, only the row lengths are exchanged); auto = columns "
                          "(the columns of R and S never meet on either image path)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--beyond-scale", action="store_true",
+                    help="also run spasm_hip_echelonize twice on mk15.b5 (4,729,725 x 2,837,835, 28.4 M entries: beyond the size of GL7d19; "
+                         "about a minute more, 40 GB of device memory) and report it as `beyond_scale`")
     ap.add_argument("--no-extras", action="store_true",
                     help="skip the row-by-row comparison, the dense-tail probe and the end-to-end runs")
     args = ap.parse_args()
@@ -734,6 +737,14 @@ def main():
             out["at_scale"] = sparse_path_probe(torch, spasm_amd, workloads, dev, name="mk15.b4", steps=2, paths=("default",), calls=5, cpu_rows=2000)
             out["sparse_path"] = sparse_path_probe(torch, spasm_amd, workloads, dev)
             out["stand_ins"] = stand_in_runs(spasm_amd, workloads)
+        if extras and args.beyond_scale:
+            Abig, _ = workloads.load_matrix("mk15.b5", PRIME)
+            def call_big():
+                fact = spasm_amd.echelonize(Abig)
+                return spasm_amd.echelonize_profile(), int(fact.U.n)
+            out["beyond_scale"] = dict(_calls(call_big, 2), what="spasm_hip_echelonize on mk15.b5 (%d x %d, %d entries: generated, beyond the size of GL7d19), defaults, 2 calls"
+                                                                   % (Abig.n, Abig.m, Abig.nnz))
+            del Abig
         out["configs"] = [{"name": c["name"], "status": status, "what": c["what"],
                            "bench": "python bench.py --workload %s" % c["name"],
                            "rank": "./tools/rank --matrix $SPASM_DATA/%s --modulus %d %s" % (c["file"], PRIME, " ".join(c["rank_args"]))}

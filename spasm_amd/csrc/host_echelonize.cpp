@@ -483,7 +483,11 @@ extern "C" struct spasm_lu *spasm_hip_echelonize(const struct spasm_csr *A0, str
 		// 673,000 x 42,000 complement with 1.06e9 entries; the search found 299 in 1.4 s after a 0.7 s download and stopped).
 		// The remainder goes to the finishing code as it would have, with no pivots of its own: same row space.
 		const int census = (round + 1 < opts->max_round) ? resident_fl_census(A) : -1;
-		if (census >= 0 && 8.0 * census < opts->min_pivot_proportion * std::min(n, m - U->n)) {
+		// (the factor 8 is the largest ratio (pivots of a whole search) / (its first step) seen on the generated families, where it is
+		//  1.1-1.5; a matrix whose greedy step finds ten times what its leftmost entries give would be cut short here:
+		//  SPASM_HIP_CENSUS_FACTOR raises it, 0 switches the short cut off -- the round then runs and decides by itself)
+		const double census_factor = (double) env_int_host("SPASM_HIP_CENSUS_FACTOR", 8);
+		if (census >= 0 && census_factor > 0 && census_factor * census < opts->min_pivot_proportion * std::min(n, m - U->n)) {
 			logmsg("[echelonize] %d leftmost-entry pivots in the Schur complement (counted on the device): not enough for another round\n", census);
 			npiv = 0;
 			for (int i = 0; i < n; i++)
