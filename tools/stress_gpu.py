@@ -65,7 +65,9 @@ while time.time() < t_end:
             os.environ.pop(key, None)
         # the sparse image (round 4): forced, with a random segment size and a pool small enough to be outgrown now and then
         sp_env = {"SPASM_HIP_SPARSE_IMAGE": "1", "SPASM_HIP_BACKSOLVE": "0", "SPASM_HIP_SPARSE_IMAGE_PERSISTENT": str(int(rng.integers(0, 2))),
-                  "SPASM_HIP_SPARSE_IMAGE_CHUNK": str(int(rng.choice([0, 4096, 100000]))), "SPASM_HIP_SPARSE_IMAGE_ARENAS": str(int(rng.integers(0, 2)))}
+                  "SPASM_HIP_SPARSE_IMAGE_CHUNK": str(int(rng.choice([0, 4096, 100000]))), "SPASM_HIP_SPARSE_IMAGE_ARENAS": str(int(rng.integers(0, 2))),
+                  # (round 5) 8-byte entries with 32-bit accumulators whatever the prime; structural masks of the segments on or off
+                  "SPASM_HIP_SPARSE_IMAGE_WIDE": str(int(rng.integers(0, 2))), "SPASM_HIP_SPARSE_IMAGE_MASKS": str(int(rng.integers(0, 2)))}
         os.environ.update(sp_env)
         S, p_out = spasm_amd.schur(as_product(A), rows, spasm_amd.Fact(as_product(F.U), F.qinv))
         ok = orc.same_matrix(orc.CSR(S.n, S.m, S.p, S.j, S.x, p), want) and np.array_equal(np.asarray(p_out), np.asarray(p_out_want))
@@ -146,13 +148,24 @@ while time.time() < t_end:
         tx = rng.integers(1, p, size=en * eper).astype(np.int64)
         E = as_product(orc.compress(p, en, em, ti, tj, tx))
         ranks = {}
-        for where, bits in (("device", ""), ("device", "global"), ("host", "")):
+        # (round 5) the labelled search under random limits (gap between labels, length of a cascade, work list), with the
+        # triangular check of the host on the ordering the labels gave, and the checks of the compact combinations
+        os.environ.update({"SPASM_HIP_PIVOT_CHECK": "1", "SPASM_HIP_COMBINE_CHECK": "1", "SPASM_HIP_COMPACT_CHECK": "1"})
+        for where, bits, labels in (("device", "", "1"), ("device", "", "0"), ("device", "global", "1"), ("host", "", "1"), ("host", "", "0")):
             os.environ["SPASM_HIP_PIVOT_SEARCH"] = where
             os.environ["SPASM_HIP_PIVOT_BITS"] = bits
-            ranks[where + bits] = spasm_amd.echelonize(E).U.n
-        os.environ.pop("SPASM_HIP_PIVOT_SEARCH", None)
-        os.environ.pop("SPASM_HIP_PIVOT_BITS", None)
+            os.environ["SPASM_HIP_PIVOT_LABELS"] = labels
+            os.environ["SPASM_HIP_PIVOT_GAP"] = str(int(rng.choice([1, 8, 64, 4096])))
+            os.environ["SPASM_HIP_PIVOT_CASCADE"] = str(int(rng.choice([16, 512, 8192])))
+            os.environ["SPASM_HIP_PIVOT_LABEL_FIFO"] = str(int(rng.choice([64, 4096, 32768])))
+            os.environ["SPASM_HIP_PIVOT_SECOND_PASS_ALWAYS"] = str(int(rng.integers(0, 2)))
+            ranks[where + bits + labels] = spasm_amd.echelonize(E).U.n
+        for key in ("SPASM_HIP_PIVOT_SEARCH", "SPASM_HIP_PIVOT_BITS", "SPASM_HIP_PIVOT_LABELS", "SPASM_HIP_PIVOT_GAP", "SPASM_HIP_PIVOT_CASCADE",
+                    "SPASM_HIP_PIVOT_LABEL_FIFO", "SPASM_HIP_PIVOT_SECOND_PASS_ALWAYS"):
+            os.environ.pop(key, None)
         ranks["transpose"] = spasm_amd.echelonize(spasm_amd.transpose(E)).U.n
+        for key in ("SPASM_HIP_PIVOT_CHECK", "SPASM_HIP_COMBINE_CHECK", "SPASM_HIP_COMPACT_CHECK"):
+            os.environ.pop(key, None)
         cases += 1
         if len(set(ranks.values())) != 1:
             fails += 1
