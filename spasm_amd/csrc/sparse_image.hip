@@ -192,12 +192,29 @@ constexpr int BMW = SP_SEG / 32;          // bitmap words
 constexpr int WPL = BMW / 64;             // bitmap words per lane (2 or 4)
 constexpr int CW = SEGW / 64;             // accumulator words of the columns one lane owns in the lane-by-lane walk
 static_assert(WPL == 2 || WPL == 4, "segments of 4,096 or 8,192 columns");
-constexpr int LISTCAP = 1024;             // touched columns a segment may have for the balanced emit (more: the lane-by-lane one)
+// The list of touched columns (sp_touched) stands IN the bitmap's words -- the bitmap is in registers by the time the list is
+// written, and is zeroed again once the list has been emitted -- plus LIST_EXTRA entries behind them (round 5: with a list of
+// its own, 2 KB, a wave took 10.75 KB and a CU held 14 of them; the kernels are bound by the waves in flight -- 10, 12, 14
+// waves per CU: 39.6, 34.3, 30.5 ms for the rows of S of mk15.b4).
+#ifndef SPASM_SP_LIST_EXTRA
+#define SPASM_SP_LIST_EXTRA 192
+#endif
+constexpr int LIST_EXTRA = SPASM_SP_LIST_EXTRA;
+constexpr int LISTCAP = 2 * BMW + LIST_EXTRA;          // touched columns a segment may have for the balanced emit (more: the lane-by-lane one)
 struct __attribute__((aligned(16))) WaveLds {
 	uint32_t acc[SEGW];
 	uint32_t bm[BMW];
-	uint16_t list[LISTCAP];
+	uint16_t list_extra[LIST_EXTRA > 0 ? LIST_EXTRA : 1];
 };
+
+template <typename LDS> __device__ __forceinline__ uint16_t *sp_list(LDS &L) { return reinterpret_cast<uint16_t *>(L.bm); }
+
+template <typename LDS> __device__ __forceinline__ void sp_bm_clear(LDS &L, int lane)
+{
+#pragma unroll
+	for (int t = 0; t < WPL; t++)
+		L.bm[64 * t + lane] = 0;
+}
 
 __device__ __forceinline__ uint32_t sp_swz(uint32_t c)          // column of the segment -> index of its 16-bit accumulator
 {
@@ -334,7 +351,7 @@ __device__ __forceinline__ void sp_accumulate(WaveLds &L, uint64_t f, int coef, 
 struct __attribute__((aligned(16))) WaveLds32 {
 	uint32_t acc[SP_SEG];
 	uint32_t bm[BMW];
-	uint16_t list[LISTCAP];
+	uint16_t list_extra[LIST_EXTRA > 0 ? LIST_EXTRA : 1];
 };
 
 // column of the segment -> index of its accumulator: lane L of the lane-by-lane walk owns the 64 columns [64 L, 64 L + 64),
@@ -459,7 +476,7 @@ __device__ __forceinline__ int wave_incl_scan(int x)
 // the lane-by-lane walk.
 struct SpTouched {
 	int ub;                       // touched columns: an upper bound of the entries (a sum that came back to zero gives none)
-	bool listed;                  // their columns stand in L.list[0 .. ub), sorted
+	bool listed;                  // their columns stand in sp_list(L)[0 .. ub), sorted
 	uint64_t lo64, hi64;          // else: the bits of the lane's 128 consecutive columns ...
 	uint32_t prefix;              // ... and the touched columns before them
 };
@@ -476,12 +493,9 @@ template <typename LDS> __device__ __forceinline__ void sp_touched(LDS &L, int l
 	T.lo64 = T.hi64 = 0;
 	T.prefix = 0;
 	if (T.listed) {
-		L.bm[lane] = 0;
-		L.bm[64 + lane] = 0;
-		if (WPL > 2) {
-			L.bm[(128 + lane) % BMW] = 0;
-			L.bm[(192 + lane) % BMW] = 0;
-		}
+		// (the list goes over the bitmap's words, which every lane has read by now; whoever consumes the list -- sp_emit,
+		//  sp_emit32, sp_discard -- leaves the bitmap zeroed)
+		uint16_t *list = sp_list(L);
 		// where the columns of word j go, minus the columns this lane lists before them
 		const int adj0 = (ia & 0xFFFF) - c0;
 		const int adj1 = t0 + (ia >> 16) - c1 - c0;
@@ -501,7 +515,7 @@ template <typename LDS> __device__ __forceinline__ void sp_touched(LDS &L, int l
 				}
 				const int j = b >> 5;
 				const int adj = (j == 0) ? adj0 : (j == 1) ? adj1 : (j == 2) ? adj2 : adj3;
-				L.list[adj + n] = (uint16_t) ((((uint32_t) j * 64u + (uint32_t) lane) << 5) | ((uint32_t) b & 31u));
+				list[adj + n] = (uint16_t) ((((uint32_t) j * 64u + (uint32_t) lane) << 5) | ((uint32_t) b & 31u));
 				n += 1;
 			}
 		}
@@ -550,10 +564,11 @@ __device__ __forceinline__ int sp_emit(WaveLds &L, const SpTouched &T, uint32_t 
 		// 64 columns of the list at a time (two such batches in flight): the non-zero ones are written one behind the other --
 		// sums that came back to zero are common in these matrices (boundary maps: the products cancel), and leave no holes
 		uint32_t w = 0;
+		const uint16_t *list = sp_list(L);
 		for (int i0 = 0; i0 < ub; i0 += 128) {          // (a uniform loop: the lanes past the end idle)
 			const int i = i0 + lane;
 			const bool first = i < ub, second = i + 64 < ub;
-			const uint32_t c0 = first ? L.list[i] : 0u, c1 = second ? L.list[i + 64] : 0u;
+			const uint32_t c0 = first ? list[i] : 0u, c1 = second ? list[i + 64] : 0u;
 			short *a0 = acc + sp_swz(c0), *a1 = acc + sp_swz(c1);
 			int v0 = first ? (int) *a0 : 0, v1 = second ? (int) *a1 : 0;
 			if (first)
@@ -574,6 +589,7 @@ __device__ __forceinline__ int sp_emit(WaveLds &L, const SpTouched &T, uint32_t 
 			if (v1 != 0)
 				sp_st<SC1>(out + d1, c1 | ((uint32_t) v1 << 16));
 		}
+		sp_bm_clear(L, lane);
 		return (int) w;
 	} else {
 		uint64_t lo64 = T.lo64, hi64 = T.hi64;
@@ -612,8 +628,10 @@ __device__ __forceinline__ void sp_discard(WaveLds &L, const SpTouched &T, int l
 {
 	short *acc = reinterpret_cast<short *>(L.acc);
 	if (T.listed) {
+		const uint16_t *list = sp_list(L);
 		for (int i = lane; i < T.ub; i += 64)
-			acc[sp_swz(L.list[i])] = 0;
+			acc[sp_swz(list[i])] = 0;
+		sp_bm_clear(L, lane);
 		return;
 	}
 	uint64_t lo64 = T.lo64, hi64 = T.hi64;
@@ -641,10 +659,11 @@ __device__ __forceinline__ int sp_emit32(WaveLds32 &L, const SpTouched &T, int l
 	const int ub = T.ub;
 	if (T.listed) {
 		uint32_t w = 0;
+		const uint16_t *list = sp_list(L);
 		for (int i0 = 0; i0 < ub; i0 += 128) {
 			const int i = i0 + lane;
 			const bool first = i < ub, second = i + 64 < ub;
-			const uint32_t c0 = first ? L.list[i] : 0u, c1 = second ? L.list[i + 64] : 0u;
+			const uint32_t c0 = first ? list[i] : 0u, c1 = second ? list[i + 64] : 0u;
 			uint32_t *a0 = L.acc + sp_swz32(c0), *a1 = L.acc + sp_swz32(c1);
 			const uint32_t v0 = first ? *a0 : 0u, v1 = second ? *a1 : 0u;
 			if (first)
@@ -661,6 +680,7 @@ __device__ __forceinline__ int sp_emit32(WaveLds32 &L, const SpTouched &T, int l
 			if (v1 != 0)
 				out(d1, c1, v1);
 		}
+		sp_bm_clear(L, lane);
 		return (int) w;
 	}
 	// lane L owns the columns [32 WPL L, 32 WPL (L + 1)): count, scan, write
@@ -688,8 +708,10 @@ __device__ __forceinline__ int sp_emit32(WaveLds32 &L, const SpTouched &T, int l
 __device__ __forceinline__ void sp_discard(WaveLds32 &L, const SpTouched &T, int lane)
 {
 	if (T.listed) {
+		const uint16_t *list = sp_list(L);
 		for (int i = lane; i < T.ub; i += 64)
-			L.acc[sp_swz32(L.list[i])] = 0;
+			L.acc[sp_swz32(list[i])] = 0;
+		sp_bm_clear(L, lane);
 		return;
 	}
 	for (int half = 0; half < 2; half++)
@@ -1557,7 +1579,7 @@ bool sparse_image_build(const spasm_hip_dfact *F, hipStream_t stream)
 		HIP_CHECK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, sp_build_kernel<true, true>, 64, 0));
 	else
 		HIP_CHECK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, sp_build_kernel<true, false>, 64, 0));
-	per_cu = std::min(per_cu, env_sp("SPASM_HIP_SPARSE_IMAGE_BUILD_WAVES", (int) std::min<size_t>(16, (size_t) (160 * 1024) / (S.wide ? sizeof(WaveLds32) : sizeof(WaveLds)))));
+	per_cu = std::min(per_cu, env_sp("SPASM_HIP_SPARSE_IMAGE_BUILD_WAVES", (int) std::min<size_t>(32, (size_t) (160 * 1024) / (S.wide ? sizeof(WaveLds32) : sizeof(WaveLds)))));
 	bool persistent = env_sp("SPASM_HIP_SPARSE_IMAGE_PERSISTENT", 1) != 0 && per_cu >= 1;
 	HIP_CHECK(hipEventRecord(S.ev0, stream));
 	auto next_chunk = [&](int chunk) -> bool {          // room for another attempt?  (allocates chunk + 1 when it is not there)
@@ -1845,7 +1867,7 @@ void launch_sparse_image_apply(const SchurArgs &a, const spasm_hip_dfact *F, uin
 	if (ntasks <= 0)
 		return;
 	// as many waves per CU as its LDS holds (19.5 KB each: eight), every wave a workgroup of its own
-	const int per_cu = std::max(1, std::min(16, env_sp("SPASM_HIP_SPARSE_IMAGE_WAVES", (int) std::min<size_t>(16, (size_t) (160 * 1024) / (S.wide ? sizeof(WaveLds32) : sizeof(WaveLds))))));
+	const int per_cu = std::max(1, std::min(32, env_sp("SPASM_HIP_SPARSE_IMAGE_WAVES", (int) std::min<size_t>(32, (size_t) (160 * 1024) / (S.wide ? sizeof(WaveLds32) : sizeof(WaveLds))))));
 	const int blocks = (int) std::min<int64_t>(ntasks, (int64_t) prop.multiProcessorCount * per_cu);
 	// a wave reserves the room of its fragments 8,192 entries at a time (what the ~4,000 waves strand at the end must stay small
 	// against a pool sized from a density estimate: 32,768 apiece were 126 M entries, and a retry of the whole call); a pool
