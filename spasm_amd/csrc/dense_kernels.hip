@@ -3184,11 +3184,24 @@ __global__ __launch_bounds__(64) void combine_all_rows_kernel(const int64_t *Ap,
 // The same for p < 2^16 WITHOUT an atomic per term at the memory side (92 ms on mk14.b4: 1.4e9 atomic requests, the largest
 // kernel of the whole call).  A workgroup takes CB_ROWS rows and walks the columns in blocks of CB_COLS: rows are sorted by
 // column, so every row keeps a cursor; the terms of a block are added up in LDS -- 32-bit sums: a term is < 2^16 and a
-// workgroup adds at most CB_ROWS = 2,048 of them to a sum -- and only the sums that are not zero go to Y ([combination]
+// workgroup adds at most CB_ROWS = 512 of them to a sum -- and only the sums that are not zero go to Y ([combination]
 // [column], 64-bit), one atomic each: 42,000 occupied columns x 9 per workgroup instead of a thousand entries x 9 per row.
 // Needs sorted rows (a row with a column out of order falls behind its cursor: the caller checks the flag and redoes the
 // batch with combine_all_rows_kernel).
-constexpr int CB_ROWS = 2048, CB_COLS = 1024, CB_THREADS = 256, CB_PER_THREAD = CB_ROWS / CB_THREADS;
+#ifndef SPASM_CB_ROWS
+#define SPASM_CB_ROWS 512
+#endif
+#ifndef SPASM_CB_COLS
+#define SPASM_CB_COLS 1024
+#endif
+#ifndef SPASM_CB_THREADS
+#define SPASM_CB_THREADS 512
+#endif
+// (round 5: 512 rows by 512 threads, one row per thread, three workgroups per CU.  With 2,048 rows by 256 threads -- eight rows per
+//  thread, 8 waves per CU -- the kernel took 31 ms on the 8.2e8 entries of mk15.b4's Schur complement and 13 on mk14.b4's; a thread's
+//  next entries stand in registers, so what counts is the waves in flight: 1,024 x 512: 15.4 / 7.2, 512 x 512: 13.7 / 4.0,
+//  1,024 x 1,024: 19.7 / 4.7, column blocks of 512 or 2,048: no better)
+constexpr int CB_ROWS = SPASM_CB_ROWS, CB_COLS = SPASM_CB_COLS, CB_THREADS = SPASM_CB_THREADS, CB_PER_THREAD = CB_ROWS / CB_THREADS;
 
 template <bool MAPPED>
 __global__ __launch_bounds__(CB_THREADS) void combine_all_rows_blocked_kernel(const int64_t *Ap, const int *Aj, const int *Ax, const int *rows, int nrows, int N, int m,

@@ -758,6 +758,69 @@ __global__ __launch_bounds__(256) void pivot_labels_relax_kernel(const i64 *Ap, 
 		*changed = 1;
 }
 
+// The same fixed point by WORK LISTS (round 5, at the end of the searches): the pivots of the ticket search hang chains of hundreds
+// of levels under their rows, and a sweep over all the pivot rows moves such a chain down by ONE level -- 424 sweeps of 600,000 rows,
+// 19 ms on mk15.b4, for 445,000 labels raised in all.  One sweep that also LISTS the pivotal columns whose label it raised, then
+// rounds that take the listed columns, relax their pivot rows again and list what THAT raised, until a list stays empty: every
+// pivot row has then been relaxed with the final label of its column (its last visit came after the last raise of its column,
+// which listed it).  q[0 .. cap) the list, qn[0 .. 3) the counters of three consecutive rounds, qn[3] = 1: a list overflowed (the
+// caller falls back to the sweeps / the host).
+__global__ __launch_bounds__(256) void pivot_labels_relax_list_kernel(const i64 *Ap, const int *Aj, const int *qinv, int m, uint32_t *lab, int *q, int cap, int *qn)
+{
+	const int col = blockIdx.x * 256 + threadIdx.x;
+	if (col >= m)
+		return;
+	const int row = qinv[col];
+	if (row < 0)
+		return;
+	const uint32_t need = (ld_u32(lab + col) >> 2) + 1u;
+	for (i64 px = Ap[row]; px < Ap[row + 1]; px++) {
+		const int e = Aj[px];
+		if (e == col)
+			continue;
+		const bool pivotal = qinv[e] >= 0;
+		const uint32_t word = (need << 2) | (pivotal ? PL_PIVOTAL : 0u);
+		if (ld_u32(lab + e) < word && atomicMax(lab + e, word) < word && pivotal) {
+			const int at = atomicAdd(&qn[0], 1);
+			if (at < cap)
+				q[at] = e;
+			else
+				qn[3] = 1;
+		}
+	}
+}
+
+// one round of the chase: the pivot rows of the columns listed by the round before (qin[0 .. cnt[k % 3])) are relaxed again, the
+// pivotal columns this raises are listed for the next round (qout, cnt[(k + 1) % 3]); the third counter is zeroed for the round
+// after.  No host in between: the rounds are launched in batches and the counters looked at after each batch.
+__global__ __launch_bounds__(256) void pivot_labels_round_kernel(const i64 *Ap, const int *Aj, const int *qinv, uint32_t *lab, const int *qin, int *qout, int cap, int *cnt,
+                                                                 int k)
+{
+	const int nin = min(cnt[k % 3], cap);
+	if (blockIdx.x == 0 && threadIdx.x == 0)
+		cnt[(k + 2) % 3] = 0;
+	int *nout = cnt + (k + 1) % 3;
+	for (int i = blockIdx.x * 256 + threadIdx.x; i < nin; i += gridDim.x * 256) {
+		const int col = qin[i];
+		const int row = qinv[col];
+		const uint32_t need = (ld_u32(lab + col) >> 2) + 1u;
+		for (i64 px = Ap[row]; px < Ap[row + 1]; px++) {
+			const int e = Aj[px];
+			if (e == col)
+				continue;
+			const bool pivotal = qinv[e] >= 0;
+			const uint32_t word = (need << 2) | (pivotal ? PL_PIVOTAL : 0u);
+			if (ld_u32(lab + e) < word && atomicMax(lab + e, word) < word && pivotal) {
+				const int at = atomicAdd(nout, 1);
+				if (at < cap)
+					qout[at] = e;
+				else
+					cnt[3] = 1;
+			}
+		}
+	}
+}
+
 template <bool GB, int REC_ENTS, int REC_BITS>
 __global__ __launch_bounds__(64) void pivot_label_search_kernel(const i64 *Ap, const int *Aj, int *pinv, int n, int m, int words, u64 *rec, uint32_t *lab, PlCtrl *ctrl,
                                                                 int *fifo_all, int fifo_cap, uint32_t *gbits, int *deferred, i64 annz, int gap_max, int casc_cap,
@@ -1628,12 +1691,38 @@ int device_acyclic_greedy(const struct spasm_csr *A, int *pinv, int *qinv, std::
 		hipLaunchKernelGGL(pivot_labels_states_kernel, dim3((m + 255) / 256), dim3(256), 0, stream, d_qinv, m, lab);
 		int sweeps = 0;
 		bool settled = false;
-		// (a sweep moves the labels one level down the chains that hang under the pivots of the ticket search: a dozen of them on
+		const double patience = 1e-3 * (double) env_int("SPASM_HIP_PIVOT_ORDER_MS", 30);
+		// one sweep that lists what it raised, then the rounds of the chase in batches of 64 launches (see the kernels)
+		if (env_int("SPASM_HIP_PIVOT_ORDER_CHASE", 1) != 0) {
+			const int qcap = 1 << 22;
+			int *d_q0 = (int *) dal((2 * (size_t) qcap + 4) * sizeof(int));
+			int *d_q1 = d_q0 + qcap, *d_cnt = d_q1 + qcap;
+			HIP_CHECK(hipMemsetAsync(d_cnt, 0, 4 * sizeof(int), stream));
+			hipLaunchKernelGGL(pivot_labels_relax_list_kernel, dim3((m + 255) / 256), dim3(256), 0, stream, dA.p, dA.j, d_qinv, m, lab, d_q0, qcap, d_cnt);
+			int k = 0, listed = 0;
+			const int max_rounds = env_int("SPASM_HIP_PIVOT_ORDER_ROUNDS", 1 << 16);
+			for (;;) {
+				for (int t = 0; t < 64; t++, k++)
+					hipLaunchKernelGGL(pivot_labels_round_kernel, dim3(256), dim3(256), 0, stream, dA.p, dA.j, d_qinv, lab, (k & 1) ? d_q1 : d_q0, (k & 1) ? d_q0 : d_q1, qcap, d_cnt, k);
+				int cnt[4] = {0, 0, 0, 1};
+				HIP_CHECK(hipMemcpyAsync(cnt, d_cnt, 4 * sizeof(int), hipMemcpyDeviceToHost, stream));
+				HIP_CHECK(hipStreamSynchronize(stream));
+				listed += cnt[k % 3];
+				if (cnt[3] != 0 || k >= max_rounds || wtime() - tl > patience)
+					break;
+				if (cnt[k % 3] == 0) {          // (nothing listed for the next round)
+					settled = true;
+					break;
+				}
+			}
+			sweeps = -k;          // (logged as minus the number of rounds)
+			(void) listed;
+		}
+		// (without the chase: a sweep moves the labels one level down the chains that hang under the pivots of the ticket search: a dozen of them on
 		//  mk15.b4 -- 64-330 sweeps, 4-15 ms, against 35 + 8 ms of depth-first search and check on the host --, three thousand
 		//  on mk15.b5 -- 6,700 sweeps, 0.87 s: given up after 30 ms, the host then orders as before)
 		const int limit = env_int("SPASM_HIP_PIVOT_ORDER_SWEEPS", 16384);
-		const double patience = 1e-3 * (double) env_int("SPASM_HIP_PIVOT_ORDER_MS", 30);
-		while (!settled && sweeps < limit && wtime() - tl < patience) {
+		while (!settled && sweeps >= 0 && sweeps < limit && wtime() - tl < patience) {
 			HIP_CHECK(hipMemsetAsync(d_changed_final, 0, sizeof(int), stream));
 			for (int t = 0; t < 8; t++)
 				hipLaunchKernelGGL(pivot_labels_relax_kernel, dim3((m + 255) / 256), dim3(256), 0, stream, dA.p, dA.j, d_qinv, m, lab, d_changed_final);
@@ -1651,7 +1740,7 @@ int device_acyclic_greedy(const struct spasm_csr *A, int *pinv, int *qinv, std::
 				(*col_label)[(size_t) j] = (int) (words[(size_t) j] >> 2);
 		}
 		if (stats || verbose() >= 3)
-			logmsg("[pivots] labels of the final pivot set: %d sweeps, %s [%.1f ms]\n", sweeps, settled ? "settled" : "NOT settled (the host orders and checks)", 1e3 * (wtime() - tl));
+			logmsg("[pivots] labels of the final pivot set: %d sweeps (< 0: rounds of the chase), %s [%.1f ms]\n", sweeps, settled ? "settled" : "NOT settled (the host orders and checks)", 1e3 * (wtime() - tl));
 	}
 	release();
 	return found;

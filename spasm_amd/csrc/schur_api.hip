@@ -903,16 +903,32 @@ static void plan_factor(const struct spasm_csr *U, const int *qinv, FactPlan &P)
 	};
 	P.rp.assign((size_t) rpad + 1, 0);
 	P.ent.assign((size_t) (nnz > 0 ? nnz : 1), uint2{0, 0});
+	const int T_fill = (r < 20000) ? 1 : std::max(1, std::min(16, usable_cpus()));
+	auto in_threads = [&](auto &&body) {          // body(c0, c1) over equal ranges of the labels
+		std::vector<std::thread> pool;
+		for (int t = 1; t < T_fill; t++)
+			pool.emplace_back(body, (int) ((i64) rpad * t / T_fill), (int) ((i64) rpad * (t + 1) / T_fill));
+		body(0, (int) ((i64) rpad / T_fill));
+		for (auto &th : pool)
+			th.join();
+	};
 	{
-		i64 w = 0;
+		// (the lengths first -- a cache miss per label, by the threads --, then their running sum)
+		in_threads([&](int c0, int c1) {
+			for (int c = c0; c < c1; c++) {
+				const int k = P.kof[c];
+				P.rp[(size_t) c + 1] = (k >= 0) ? (uint64_t) (U->p[k + 1] - U->p[k] - 1) : 0;
+			}
+		});
+		uint64_t w = 0;
 		for (int c = 0; c < rpad; c++) {
-			const int k = P.kof[c];
-			P.rp[c] = (uint64_t) w;
-			if (k >= 0)
-				w += U->p[k + 1] - U->p[k] - 1;
+			const uint64_t len = P.rp[(size_t) c + 1];
+			P.rp[c] = w;
+			w += len;
 		}
-		P.rp[rpad] = (uint64_t) w;
+		P.rp[rpad] = w;
 	}
+	lap("row pointers");
 	// the first four entries of every row again, at a fixed place (label * 4): the row-group kernel
 	// fetches them together with the accumulator line, without waiting for the row extent
 	P.head.assign((size_t) (rpad > 0 ? rpad : 1) * 4, uint2{0xFFFFFFFFu, 0u});
@@ -920,6 +936,15 @@ static void plan_factor(const struct spasm_csr *U, const int *qinv, FactPlan &P)
 	// each a range of labels; the connected components below only need the labels and run beside them.
 	auto fill = [&](int c0, int c1) {
 		for (int c = c0; c < c1; c++) {
+			// (a row of U per label: three cache misses a row -- its extent, its columns, its values -- and nothing else to do
+			//  meanwhile: the rows sixteen and eight labels ahead are asked for now)
+			if (c + 16 < c1 && P.kof[c + 16] >= 0)
+				__builtin_prefetch(&U->p[P.kof[c + 16]]);
+			if (c + 8 < c1 && P.kof[c + 8] >= 0) {
+				const i64 pf = U->p[P.kof[c + 8]];
+				__builtin_prefetch(&U->j[pf]);
+				__builtin_prefetch(&U->x[pf]);
+			}
 			const int k = P.kof[c];
 			if (k < 0)
 				continue;
@@ -935,15 +960,7 @@ static void plan_factor(const struct spasm_csr *U, const int *qinv, FactPlan &P)
 				P.head[(size_t) c * 4 + t] = P.ent[P.rp[c] + t];
 		}
 	};
-	{
-		const int T = (r < 20000) ? 1 : std::max(1, std::min(8, usable_cpus()));
-		std::vector<std::thread> pool;
-		for (int t = 1; t < T; t++)
-			pool.emplace_back(fill, (int) ((i64) rpad * t / T), (int) ((i64) rpad * (t + 1) / T));
-		fill(0, (int) ((i64) rpad / T));
-		for (auto &th : pool)
-			th.join();
-	}
+	in_threads(fill);
 	lap("entries + heads");
 
 }
@@ -1332,7 +1349,9 @@ int dschur_impl(const spasm_hip_dcsr *A, const int *d_rows, int nrows, const spa
 	}
 	const bool want_bs = !want_sp && nrows > 0 && Lout == nullptr && backsolve_wanted(F, other_forced, nrows);
 	if (!want_bs && !want_sp) {
-		ensure_row_tables(F, stream);
+		// (the components of the pivot graph are what the row-GROUP kernel regroups its rows by: a density sample of 100 rows on the
+		//  per-row tiers only needs the column degrees -- 10 ms of union-find on mk15.b4's factor that nothing ever read)
+		ensure_row_tables(F, stream, group_mode != 0 || env_int("SPASM_HIP_LAZY_COMPONENTS", 1) == 0);
 		wide_dense = (2.0 * (double) F->prime * ((double) F->maxdeg + 3.0) >= 4294967296.0);
 	}
 	// per-wave dense scratch, (re)allocated when the factor geometry needs more
