@@ -195,9 +195,11 @@ static_assert(WPL == 2 || WPL == 4, "segments of 4,096 or 8,192 columns");
 // The list of touched columns (sp_touched) stands IN the bitmap's words -- the bitmap is in registers by the time the list is
 // written, and is zeroed again once the list has been emitted -- plus LIST_EXTRA entries behind them (round 5: with a list of
 // its own, 2 KB, a wave took 10.75 KB and a CU held 14 of them; the kernels are bound by the waves in flight -- 10, 12, 14
-// waves per CU: 39.6, 34.3, 30.5 ms for the rows of S of mk15.b4).
+// waves per CU: 39.6, 34.3, 30.5 ms for the rows of S of mk15.b4).  448 extra entries: 9,600 bytes per wave, seventeen waves per CU
+// (192 -- eighteen by the arithmetic -- ran no faster, and the denser Schur complements of the sequential search's pivots, where
+// more segments outgrow the list, lost 5 %; 832 -- sixteen waves -- cost 10 % on mk15.b4).
 #ifndef SPASM_SP_LIST_EXTRA
-#define SPASM_SP_LIST_EXTRA 192
+#define SPASM_SP_LIST_EXTRA 448
 #endif
 constexpr int LIST_EXTRA = SPASM_SP_LIST_EXTRA;
 constexpr int LISTCAP = 2 * BMW + LIST_EXTRA;          // touched columns a segment may have for the balanced emit (more: the lane-by-lane one)

@@ -18,6 +18,7 @@ ap.add_argument("--workload", default="mk13.b4")
 ap.add_argument("--paths", default="sparse,dense,rows")
 ap.add_argument("--steps", type=int, default=3)
 ap.add_argument("--no-check", action="store_true")
+ap.add_argument("--fixed-pivots", action="store_true", help="the pivots of the sequential labelled search (the same workload in every run) instead of the device search's")
 ap.add_argument("--pool", type=float, default=0.0, help="entries of the output pool (default: grown on demand)")
 args = ap.parse_args()
 
@@ -26,7 +27,7 @@ import spasm_amd
 import workloads
 
 t0 = time.time()
-A, rows, F, source = workloads.round0(args.workload, 42013, threads=0)
+A, rows, F, source = workloads.round0(args.workload, 42013, threads=1, labelled=True) if args.fixed_pivots else workloads.round0(args.workload, 42013, threads=0)
 print("%s: %d x %d, %d entries; %d pivots, %d rows to reduce on %d non-pivotal columns (%.1f s)" %
       (args.workload, A.n, A.m, A.nnz, F.U.n, len(rows), A.m - F.U.n, time.time() - t0), flush=True)
 dev = torch.device("cuda:0")
