@@ -111,6 +111,7 @@ struct FactPlan {
 	int m = 0, r = 0, nlevels = 0;
 	int rpad = 0;                 // size of the label space of the pivots: every level starts on a multiple of 32
 	int maxdeg = 0;               // largest number of rows of U' that hold one given label
+	int64_t ndeps = 0;            // entries of U' on pivotal columns (the dependencies between the rows)
 	int ncomp = 0, comp_largest = 0;   // connected components of the pivot graph (labels that hold a row), size of the largest
 	int64_t prime = 0;
 	std::vector<uint32_t> lab, lvl_end;     // lvl_end is indexed by (padded) label
@@ -186,7 +187,10 @@ struct SpPools {
 	const uint32_t *base[SP_MAX_CHUNKS];
 };
 
+struct SpPending;          // (sparse_image.hip: the tables while a host thread is making them)
 struct SpImage {
+	std::shared_ptr<SpPending> pending;          // tables on their way (sparse_image_plan_start); sparse_image_planned() waits for them
+	int pending_m = 0;
 	bool planned = false;     // the dependency tables below are on the device
 	bool valid = false;       // the fragments hold R
 	bool failed = false;      // the last build gave up (R is not sparse: the pool budget ran out)

@@ -8,6 +8,7 @@
 // Launchers and C ABI of the sparse Schur complement (see include/spasm_hip.h).
 #include <algorithm>
 #include <unordered_map>
+#include <atomic>
 #include <thread>
 #include <cinttypes>
 #include <mutex>
@@ -44,6 +45,9 @@ void launch_backsolve_apply(const SchurArgs &a, const spasm_hip_dfact *F, uint32
 bool backsolve_wanted(const spasm_hip_dfact *F, bool other_path_forced, int nrows);
 bool sparse_image_possible(int64_t prime);
 void sparse_image_plan(const FactPlan &P, spasm_hip_dfact *F, hipStream_t stream);
+void sparse_image_plan_start(const FactPlan &P, spasm_hip_dfact *F);
+bool sparse_image_planned(const spasm_hip_dfact *F, hipStream_t stream);
+bool sparse_image_plan_expected(const spasm_hip_dfact *F);
 void sparse_image_free(spasm_hip_dfact *F);
 bool sparse_image_build(const spasm_hip_dfact *F, hipStream_t stream);
 void launch_sparse_image_apply(const SchurArgs &a, const spasm_hip_dfact *F, uint32_t *fpool, uint32_t *fpool_v, int64_t fcap,
@@ -649,16 +653,16 @@ bool sparse_image_wanted(const spasm_hip_dfact *F, bool other_path_forced, int n
 {
 	const SpImage &S = F->sp;
 	const int mode = env_int("SPASM_HIP_SPARSE_IMAGE", -1);
-	if (mode == 0 || !S.planned || S.failed)
+	if (mode == 0 || !sparse_image_plan_expected(F) || S.failed)
 		return false;
 	if (mode == 1)
-		return true;
+		return sparse_image_planned(F, nullptr);
 	if (other_path_forced || env_int("SPASM_HIP_BACKSOLVE", -1) >= 0)
 		return false;
 	if (S.valid)
 		return true;
 	if (nrows < 1024)
-		return false;
+		return false;          // (a density sample: the tables may still be on their way, and nobody waits for them here)
 	const BsImage &B = F->bs;
 	const double density = (B.density_hint >= 0.0) ? B.density_hint : (S.Sm > 16384 ? 0.03 : 1.0);
 	if (density >= 0.12)
@@ -671,7 +675,7 @@ bool sparse_image_wanted(const spasm_hip_dfact *F, bool other_path_forced, int n
 	const double t_rows = 0.3e-3 + 27e-12 * elim_per_row * n;
 	const double t_other = (B.planned || F->bs_deferred) ? std::min(t_dense, t_rows) : t_rows;
 	const double t_sparse = 8e-6 * (double) S.nlevels + 27e-12 * density * n * Sm + 3e-9 * n + 0.5e-3;
-	return t_sparse < t_other;
+	return t_sparse < t_other && sparse_image_planned(F, nullptr);
 }
 }  // namespace sh
 
@@ -934,7 +938,9 @@ static void plan_factor(const struct spasm_csr *U, const int *qinv, FactPlan &P)
 	P.head.assign((size_t) (rpad > 0 ? rpad : 1) * 4, uint2{0xFFFFFFFFu, 0u});
 	// The rows are gathered in label order -- a cache miss per row and per entry (the label of its column) -- by a few threads,
 	// each a range of labels; the connected components below only need the labels and run beside them.
+	std::atomic<int64_t> ndeps_all{0};
 	auto fill = [&](int c0, int c1) {
+		int64_t ndeps = 0;
 		for (int c = c0; c < c1; c++) {
 			// (a row of U per label: three cache misses a row -- its extent, its columns, its values -- and nothing else to do
 			//  meanwhile: the rows sixteen and eight labels ahead are asked for now)
@@ -953,14 +959,17 @@ static void plan_factor(const struct spasm_csr *U, const int *qinv, FactPlan &P)
 				uint2 e;
 				e.x = P.lab[U->j[px]];
 				e.y = shifted_mod(zp_unsigned(prime, U->x[px]));
+				ndeps += e.x < (uint32_t) rpad;
 				P.ent[w++] = e;
 			}
 			const uint64_t len = P.rp[c + 1] - P.rp[c];
 			for (uint64_t t = 0; t < len && t < 4; t++)
 				P.head[(size_t) c * 4 + t] = P.ent[P.rp[c] + t];
 		}
+		ndeps_all += ndeps;
 	};
 	in_threads(fill);
+	P.ndeps = ndeps_all.load();
 	lap("entries + heads");
 
 }
@@ -1119,19 +1128,21 @@ spasm_hip_dfact *spasm_hip_dfact_create(const struct spasm_csr *U, const int *qi
 	// sparse image (sparse_image.hip): its dependency tables, for wide factors (R itself is built by the first batch that wants it)
 	const bool plan_sparse = sparse_image_possible(F->prime) && r > 0 && m - r > 0 &&
 	                         (env_int("SPASM_HIP_SPARSE_IMAGE", -1) == 1 || (m - r >= 8192 && (double) r * (double) (m - r) >= 5e8));
-	if (plan_sparse)
+	// (large factors: by a thread of their own, started below once the plan stands where it will stay)
+	const bool plan_sparse_async = plan_sparse && r >= 100000 && env_int("SPASM_HIP_SPARSE_IMAGE_PLAN_ASYNC", 1) != 0;
+	if (plan_sparse && !plan_sparse_async)
 		sparse_image_plan(P, F, stream);
 	const double t_bs = wtime();
 	if (verbose() >= 2 && F->sp.planned)
 		logmsg("[factor image] tables of the sparse image: %.1f ms\n", 1e3 * (t_bs - t_uploaded));
 	int64_t bs_bytes = 0;
 	if (env_int("SPASM_HIP_BACKSOLVE", -1) != 0 && backsolve_eligible(r, m - r, F->nnz, &bs_bytes, F->prime)) {
-		if (F->sp.planned && env_int("SPASM_HIP_BACKSOLVE", -1) != 1 && env_int("SPASM_HIP_BS_PLAN_EAGER", 0) == 0) {
+		if (plan_sparse && env_int("SPASM_HIP_BACKSOLVE", -1) != 1 && env_int("SPASM_HIP_BS_PLAN_EAGER", 0) == 0) {
 			// the plan of the dense image waits for a batch that wants it (backsolve_build); what the path choice reads is known now
 			F->bs.r = r;
 			F->bs.Sm = m - r;
 			F->bs.ldR = ((int64_t) (m - r) + 511) / 512 * 512;
-			F->bs.ndeps = F->sp.ndeps;
+			F->bs.ndeps = P.ndeps;
 			F->bs_deferred = true;
 		} else {
 			backsolve_plan(P, F, stream);
@@ -1143,6 +1154,8 @@ spasm_hip_dfact *spasm_hip_dfact_create(const struct spasm_csr *U, const int *qi
 	// the host part of the image stays: the tables of the row-by-row kernels (ensure_row_tables) and a deferred plan of the dense
 	// image are made from it when somebody asks
 	F->host_plan = std::make_unique<FactPlan>(std::move(P));
+	if (plan_sparse_async)
+		sparse_image_plan_start(*F->host_plan, F);
 	return F;
 }
 

@@ -1334,16 +1334,39 @@ bool sparse_image_possible(int64_t prime)
 
 // dependency tables of the build: per compact row (level order) its pivotal entries (compact row, negated balanced
 // coefficient) and its non-pivotal entries (index among the non-pivotal columns, balanced value)
-void sparse_image_plan(const FactPlan &P, spasm_hip_dfact *F, hipStream_t stream)
+// The tables as the host makes them.  Round 5: on a large factor they are made by a thread of their own while the caller goes on
+// (sparse_image_plan_start) -- the driver's next step after planning a factor is the density sample of 100 rows, which never
+// looks at them: 15 ms of mk15.b4's call that nobody waited for -- and reach the device when somebody asks for the image
+// (sparse_image_planned).  The thread reads the FactPlan only (kof, lab, rp, ent, lvl_count: nothing ensure_row_tables or the
+// deferred plan of the dense image write) and makes no HIP call.
+struct SpPending {
+	std::thread worker;
+	double t_start = 0.0, t_done = 0.0;
+	std::vector<int> colmap;
+	std::vector<uint64_t> dep_rp, np_rp, segmask;
+	std::vector<uint2> dep, np;
+};
+
+// what the path choice reads: known at once
+void sparse_image_plan_sizes(const FactPlan &P, spasm_hip_dfact *F)
 {
 	SpImage &S = F->sp;
-	const int r = P.r, rpad = P.rpad, m = P.m;
-	const int64_t prime = P.prime;
-	S.r = r;
-	S.Sm = m - r;
+	S.r = P.r;
+	S.Sm = P.m - P.r;
 	S.nseg = (S.Sm + SP_SEG - 1) / SP_SEG;
 	S.nlevels = P.nlevels;
-	S.wide = !sgn_eligible(prime) || env_sp("SPASM_HIP_SPARSE_IMAGE_WIDE", 0) != 0;
+	S.wide = !sgn_eligible(P.prime) || env_sp("SPASM_HIP_SPARSE_IMAGE_WIDE", 0) != 0;
+	S.lvl_lo.assign((size_t) P.nlevels + 1, 0);
+	for (int l = 0; l < P.nlevels; l++)
+		S.lvl_lo[l + 1] = S.lvl_lo[l] + P.lvl_count[l];
+	S.ndeps = P.ndeps;
+	S.nnp = (int64_t) P.rp[P.rpad] - P.ndeps;
+}
+
+static void sparse_image_plan_host(const FactPlan &P, bool wide, SpPending &H)
+{
+	const int r = P.r, rpad = P.rpad, m = P.m;
+	const int64_t prime = P.prime;
 	std::vector<int> cid((size_t) (rpad > 0 ? rpad : 1), -1), label_of((size_t) (r > 0 ? r : 1), 0);
 	{
 		int n = 0;
@@ -1356,10 +1379,8 @@ void sparse_image_plan(const FactPlan &P, spasm_hip_dfact *F, hipStream_t stream
 		if (n != r)
 			die("sparse_image_plan: %d labelled rows, %d expected", n, r);
 	}
-	S.lvl_lo.assign((size_t) P.nlevels + 1, 0);
-	for (int l = 0; l < P.nlevels; l++)
-		S.lvl_lo[l + 1] = S.lvl_lo[l] + P.lvl_count[l];
-	std::vector<int> colmap((size_t) (m > 0 ? m : 1), 0);
+	std::vector<int> &colmap = H.colmap;
+	colmap.assign((size_t) (m > 0 ? m : 1), 0);
 	for (int j = 0; j < m; j++)
 		colmap[j] = (P.lab[j] < (uint32_t) rpad) ? cid[P.lab[j]] : r + (int) (P.lab[j] - (uint32_t) rpad);
 	// the image keeps values in Montgomery form (value * 2^32 mod p): back to plain residues, then balanced
@@ -1386,7 +1407,9 @@ void sparse_image_plan(const FactPlan &P, spasm_hip_dfact *F, hipStream_t stream
 	// two passes over the rows of U', by a few threads on large factors (604,000 rows and 3 M entries on mk15.b4: 16-20 ms with
 	// one thread and a push_back per entry, a 128-bit division per value): count, then fill.  The entries of boundary
 	// matrices are +-1: their Montgomery forms are recognised, no division.
-	std::vector<uint64_t> dep_rp((size_t) r + 1, 0), np_rp((size_t) r + 1, 0);
+	std::vector<uint64_t> &dep_rp = H.dep_rp, &np_rp = H.np_rp;
+	dep_rp.assign((size_t) r + 1, 0);
+	np_rp.assign((size_t) r + 1, 0);
 	const uint32_t mont_one = (uint32_t) ((1ull << 32) % (uint64_t) prime), mont_minus_one = (uint32_t) ((uint64_t) prime - mont_one);
 	const int T = (r < 50000) ? 1 : std::max(1, std::min(8, usable_cpus()));
 	auto for_rows = [&](auto &&body) {
@@ -1411,7 +1434,9 @@ void sparse_image_plan(const FactPlan &P, spasm_hip_dfact *F, hipStream_t stream
 		dep_rp[n + 1] += dep_rp[n];
 		np_rp[n + 1] += np_rp[n];
 	}
-	std::vector<uint2> dep((size_t) dep_rp[r]), np((size_t) np_rp[r]);
+	std::vector<uint2> &dep = H.dep, &np = H.np;
+	dep.resize((size_t) dep_rp[r]);
+	np.resize((size_t) np_rp[r]);
 	for_rows([&](int n_lo, int n_hi) {
 		for (int n = n_lo; n < n_hi; n++) {
 			const int c = label_of[n];
@@ -1419,7 +1444,7 @@ void sparse_image_plan(const FactPlan &P, spasm_hip_dfact *F, hipStream_t stream
 			for (uint64_t e = P.rp[c]; e < P.rp[c + 1]; e++) {
 				const uint2 en = P.ent[e];
 				const bool pivotal = en.x < (uint32_t) rpad;
-				if (S.wide) {
+				if (wide) {
 					// (the image's values ARE Montgomery forms: the negated coefficient as it stands, the non-pivotal value as a plain residue)
 					if (pivotal)
 						dep[wd++] = uint2{(uint32_t) cid[en.x], en.y == 0 ? 0u : (uint32_t) ((uint64_t) prime - en.y)};
@@ -1440,8 +1465,9 @@ void sparse_image_plan(const FactPlan &P, spasm_hip_dfact *F, hipStream_t stream
 	// on (rows with larger compact ids: one pass from the last row to the first).  Half of the pairs of the generated families
 	// are empty (mk15.b4: 47-49 %), and their tasks used to read the row's lists and poll its dependencies to find that out
 	// (metadata: 38 % of the build's wave-cycles): their fragment words are published as empty before the build starts.
-	std::vector<uint64_t> segmask;
-	if (S.nseg <= 64) {
+	std::vector<uint64_t> &segmask = H.segmask;
+	segmask.clear();
+	if ((m - r + SP_SEG - 1) / SP_SEG <= 64) {
 		segmask.assign((size_t) r, 0);
 		for (int n = r - 1; n >= 0; n--) {
 			uint64_t mk = 0;
@@ -1452,27 +1478,80 @@ void sparse_image_plan(const FactPlan &P, spasm_hip_dfact *F, hipStream_t stream
 			segmask[(size_t) n] = mk;
 		}
 	}
-	S.ndeps = (int64_t) dep.size();
-	S.nnp = (int64_t) np.size();
+}
+
+static void sparse_image_plan_device(SpImage &S, SpPending &H, int m, hipStream_t stream)
+{
+	const int r = S.r;
+	if ((int64_t) H.dep.size() != S.ndeps || (int64_t) H.np.size() != S.nnp)
+		die("sparse_image_plan: %zu + %zu entries in the tables, %lld + %lld counted by the plan of the factor", H.dep.size(), H.np.size(), (long long) S.ndeps, (long long) S.nnp);
 	S.d_col = dalloc<int>(m);
 	S.d_dep_rp = dalloc<uint64_t>((int64_t) r + 1);
-	S.d_dep = dalloc<uint2>((int64_t) dep.size());
+	S.d_dep = dalloc<uint2>((int64_t) H.dep.size());
 	S.d_np_rp = dalloc<uint64_t>((int64_t) r + 1);
-	S.d_np = dalloc<uint2>((int64_t) np.size());
-	upload(S.d_col, colmap, stream);
-	upload(S.d_dep_rp, dep_rp, stream);
-	upload(S.d_dep, dep, stream);
-	upload(S.d_np_rp, np_rp, stream);
-	upload(S.d_np, np, stream);
-	if (!segmask.empty()) {
+	S.d_np = dalloc<uint2>((int64_t) H.np.size());
+	upload(S.d_col, H.colmap, stream);
+	upload(S.d_dep_rp, H.dep_rp, stream);
+	upload(S.d_dep, H.dep, stream);
+	upload(S.d_np_rp, H.np_rp, stream);
+	upload(S.d_np, H.np, stream);
+	if (!H.segmask.empty()) {
 		S.d_segmask = dalloc<uint64_t>((int64_t) r);
-		upload(S.d_segmask, segmask, stream);
+		upload(S.d_segmask, H.segmask, stream);
 	}
 	HIP_CHECK(hipStreamSynchronize(stream));          // the host vectors die here
 	S.planned = true;
 	S.valid = false;
 	S.failed = false;
 }
+
+// the tables, here and now
+void sparse_image_plan(const FactPlan &P, spasm_hip_dfact *F, hipStream_t stream)
+{
+	sparse_image_plan_sizes(P, F);
+	SpPending H;
+	sparse_image_plan_host(P, F->sp.wide, H);
+	sparse_image_plan_device(F->sp, H, P.m, stream);
+}
+
+// ... or by a thread of their own: P must stay where it is until sparse_image_planned / sparse_image_free has been called
+void sparse_image_plan_start(const FactPlan &P, spasm_hip_dfact *F)
+{
+	sparse_image_plan_sizes(P, F);
+	auto H = std::make_shared<SpPending>();
+	const bool wide = F->sp.wide;
+	const FactPlan *plan = &P;
+	SpPending *raw = H.get();
+	H->t_start = wtime();
+	H->worker = std::thread([plan, wide, raw]() {
+		sparse_image_plan_host(*plan, wide, *raw);
+		raw->t_done = wtime();
+	});
+	F->sp.pending = H;
+	F->sp.pending_m = P.m;
+}
+
+// is there a plan?  (waits for the thread and sends its tables to the device the first time)
+bool sparse_image_planned(const spasm_hip_dfact *F, hipStream_t stream)
+{
+	SpImage &S = F->sp;
+	if (S.pending) {
+		std::shared_ptr<SpPending> H = S.pending;
+		const double t_ask = wtime();
+		if (H->worker.joinable())
+			H->worker.join();
+		const double t_joined = wtime();
+		S.pending.reset();
+		sparse_image_plan_device(S, *H, S.pending_m, stream);
+		if (verbose() >= 2)
+			logmsg("[factor image] tables of the sparse image: %.1f ms by a thread beside the caller, who waited %.1f ms for them; upload %.1f ms\n", 1e3 * (H->t_done - H->t_start),
+			       1e3 * (t_joined - t_ask), 1e3 * (wtime() - t_joined));
+	}
+	return S.planned;
+}
+
+// (a plan that is on its way counts for the decisions that only need to know whether there will be one)
+bool sparse_image_plan_expected(const spasm_hip_dfact *F) { return F->sp.planned || (bool) F->sp.pending; }
 
 static void sparse_image_drop_chunks(SpImage &S)
 {
@@ -1487,6 +1566,11 @@ static void sparse_image_drop_chunks(SpImage &S)
 void sparse_image_free(spasm_hip_dfact *F)
 {
 	SpImage &S = F->sp;
+	if (S.pending) {
+		if (S.pending->worker.joinable())
+			S.pending->worker.join();
+		S.pending.reset();
+	}
 	sparse_image_drop_chunks(S);
 	sh::big_free(S.d_col);
 	sh::big_free(S.d_dep_rp);
@@ -1508,7 +1592,7 @@ void sparse_image_free(spasm_hip_dfact *F)
 bool sparse_image_build(const spasm_hip_dfact *F, hipStream_t stream)
 {
 	SpImage &S = F->sp;
-	if (!S.planned)
+	if (!sparse_image_planned(F, stream))
 		die("sparse_image_build: the factor has no plan for the sparse image");
 	S.valid = false;
 	if (S.ev0 == nullptr) {
