@@ -152,13 +152,46 @@ struct Search {
 	int free_columns()
 	{
 		std::vector<char> open((size_t) (A->m > 0 ? A->m : 1), 1);
-		for (int i = 0; i < A->n; i++)
-			if (pinv[i] >= 0)
-				for (i64 px = A->p[i]; px < A->p[i + 1]; px++)
-					open[A->j[px]] = 0;
+		// (large inputs, round 5: the columns of the pivotal rows are closed by threads -- everybody writes the same zero --, and
+		//  so are the rows looked at that have no open column left at that point: the loop below only ever closes columns, such a
+		//  row cannot take one.  On the generated families that is every row: 8 ms of two serial passes over mk15.b4's 14 M entries)
+		const int T = (A->n >= 200000) ? std::max(1, std::min(16, usable_cpus())) : 1;
+		std::vector<char> hopeless;
+		if (T > 1) {
+			hopeless.assign((size_t) A->n, 0);
+			auto in_threads = [&](auto &&body) {
+				std::vector<std::thread> pool;
+				for (int t = 1; t < T; t++)
+					pool.emplace_back(body, (int) ((i64) A->n * t / T), (int) ((i64) A->n * (t + 1) / T));
+				body(0, (int) ((i64) A->n / T));
+				for (auto &th : pool)
+					th.join();
+			};
+			char *op = open.data();
+			in_threads([&](int lo, int hi) {
+				for (int i = lo; i < hi; i++)
+					if (pinv[i] >= 0)
+						for (i64 px = A->p[i]; px < A->p[i + 1]; px++)
+							op[A->j[px]] = 0;
+			});
+			in_threads([&](int lo, int hi) {
+				for (int i = lo; i < hi; i++) {
+					bool any = false;
+					if (pinv[i] < 0)
+						for (i64 px = A->p[i]; px < A->p[i + 1] && !any; px++)
+							any = op[A->j[px]] != 0 && qinv[A->j[px]] < 0;
+					hopeless[(size_t) i] = !any;
+				}
+			});
+		} else {
+			for (int i = 0; i < A->n; i++)
+				if (pinv[i] >= 0)
+					for (i64 px = A->p[i]; px < A->p[i + 1]; px++)
+						open[A->j[px]] = 0;
+		}
 		int found = 0;
 		for (int i = 0; i < A->n; i++) {
-			if (pinv[i] >= 0)
+			if (pinv[i] >= 0 || (T > 1 && hopeless[(size_t) i]))
 				continue;
 			for (i64 px = A->p[i]; px < A->p[i + 1]; px++) {
 				int j = A->j[px];
@@ -840,18 +873,35 @@ extern "C" int spasm_hip_pivots_extract_structural(const struct spasm_csr *A, co
 	struct spasm_csr *U = fact->U;
 	struct spasm_triplet *L = fact->Ltmp;
 	const i64 unz = U->p[U->n];
+	// where every new row goes, then the rows themselves -- by a few threads on large inputs: a row is a gather from A (its
+	// extent, its columns, its values: three cache misses, asked for a few rows ahead), and so are the lengths (round 5: the
+	// two serial passes over the pivots before the threaded one -- 600,000 random looks at A->p on mk15.b4 -- took as long as it)
+	const int n0 = U->n;
+	const int T_rows = (npiv < 20000) ? 1 : std::max(1, std::min(16, usable_cpus()));
+	auto in_threads = [&](auto &&body) {
+		std::vector<std::thread> pool;
+		for (int t = 1; t < T_rows; t++)
+			pool.emplace_back(body, (int) ((i64) npiv * t / T_rows), (int) ((i64) npiv * (t + 1) / T_rows));
+		body(0, (int) ((i64) npiv / T_rows));
+		for (auto &th : pool)
+			th.join();
+	};
+	in_threads([&](int t_lo, int t_hi) {
+		for (int t = t_lo; t < t_hi; t++) {
+			if (t + 8 < t_hi)
+				__builtin_prefetch(&A->p[p[t + 8]]);
+			const int i = p[t];
+			fact->qinv[S.pinv[i]] = n0 + t;
+			U->p[n0 + t + 1] = S.weight(i);          // (lengths for now)
+		}
+	});
 	i64 need = 0;
 	for (int t = 0; t < npiv; t++)
-		need += S.weight(p[t]);
+		need += U->p[n0 + t + 1];
 	if (unz + need > U->nzmax)
 		spasm_hip_csr_realloc(U, unz + need);
-	// where every new row goes, then the rows themselves -- by a few threads on large inputs: a row is a gather from A
-	const int n0 = U->n;
-	for (int t = 0; t < npiv; t++) {
-		const int i = p[t];
-		fact->qinv[S.pinv[i]] = n0 + t;
-		U->p[n0 + t + 1] = U->p[n0 + t] + S.weight(i);
-	}
+	for (int t = 0; t < npiv; t++)
+		U->p[n0 + t + 1] += U->p[n0 + t];
 	auto pivot_of = [&](int i, int j) -> spasm_ZZp {
 		for (i64 px = A->p[i]; px < A->p[i + 1]; px++)
 			if (A->j[px] == j && A->x[px] != 0)
@@ -868,6 +918,13 @@ extern "C" int spasm_hip_pivots_extract_structural(const struct spasm_csr *A, co
 		}
 	auto fill_rows = [&](int t_lo, int t_hi) {
 		for (int t = t_lo; t < t_hi; t++) {
+			if (t + 16 < t_hi)
+				__builtin_prefetch(&A->p[p[t + 16]]);
+			if (t + 8 < t_hi) {
+				const i64 pf = A->p[p[t + 8]];
+				__builtin_prefetch(&A->j[pf]);
+				__builtin_prefetch(&A->x[pf]);
+			}
 			const int i = p[t];
 			const int j = S.pinv[i];
 			const spasm_ZZp pivot = pivot_of(i, j);
@@ -902,15 +959,7 @@ extern "C" int spasm_hip_pivots_extract_structural(const struct spasm_csr *A, co
 			}
 		}
 	};
-	{
-		const int T = (npiv < 20000) ? 1 : std::max(1, std::min(16, usable_cpus()));
-		std::vector<std::thread> pool;
-		for (int t = 1; t < T; t++)
-			pool.emplace_back(fill_rows, (int) ((i64) npiv * t / T), (int) ((i64) npiv * (t + 1) / T));
-		fill_rows(0, (int) ((i64) npiv / T));
-		for (auto &th : pool)
-			th.join();
-	}
+	in_threads(fill_rows);
 	U->n = n0 + npiv;
 	if (verbose() >= 2)
 		logmsg("[pivots] search and order %.1f ms, rows of U %.1f ms\n", 1e3 * (t_searched - t0), 1e3 * (wtime() - t_searched));
