@@ -347,7 +347,7 @@ __device__ __forceinline__ void sp_accumulate(WaveLds &L, uint64_t f, int coef, 
 // tests run 65537, 67108859, 189812507, 4294967291), and a GL7d19-class factor with such a prime had no image at all (the dense
 // one is out of reach by size): minutes in the row-group kernel.  Same segments, same fragments, same drivers; what changes is
 // what an entry is: (column inside the segment, plain residue in [0, p)) in 8 bytes, accumulators of 32 bits (16 KB of LDS per
-// wave instead of 8: eight waves per CU instead of fourteen), coefficients in Montgomery form (c * 2^32 mod p: one montmul per
+// wave instead of 8: nine waves per CU instead of seventeen), coefficients in Montgomery form (c * 2^32 mod p: one montmul per
 // multiply-add, exact for every odd p < 2^32).  Fragments of S: columns and values in two arrays (the row pool of the workspace
 // is two arrays of 32-bit words).
 struct __attribute__((aligned(16))) WaveLds32 {
