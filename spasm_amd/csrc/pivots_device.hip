@@ -701,6 +701,8 @@ struct PlCtrl {
 };
 
 constexpr int PL_HASH = 1024;                  // pending values of a cascade (direct-mapped, lossy: a miss costs a duplicate item)
+constexpr int PL_SET_LOG = 11, PL_SET = 1 << PL_SET_LOG;          // the set of reached columns of the labelled search (HS): slots ...
+constexpr int PL_SET_LIMIT = PL_SET - 7 * 64 - 64;                  // ... and how many columns a row may reach before it is deferred (a step adds up to 6 x 64)
 constexpr uint32_t PL_CLAIMED = 1u, PL_PIVOTAL = 3u;
 constexpr int PL_EXPANDED = 1 << 30, PL_NOOP = 1 << 29, PL_VALUE = (1 << 29) - 1;
 constexpr int PL_MAX_LABEL = (1 << 29) - (1 << 21);          // (room above for the values of a cascade: casc_cap <= 2^20 items)
@@ -821,7 +823,7 @@ __global__ __launch_bounds__(256) void pivot_labels_round_kernel(const i64 *Ap, 
 	}
 }
 
-template <bool GB, int REC_ENTS, int REC_BITS>
+template <bool GB, int REC_ENTS, int REC_BITS, bool HS = false>
 __global__ __launch_bounds__(64) void pivot_label_search_kernel(const i64 *Ap, const int *Aj, int *pinv, int n, int m, int words, u64 *rec, uint32_t *lab, PlCtrl *ctrl,
                                                                 int *fifo_all, int fifo_cap, uint32_t *gbits, int *deferred, i64 annz, int gap_max, int casc_cap,
                                                                 const int *rowlist)
@@ -835,6 +837,13 @@ __global__ __launch_bounds__(64) void pivot_label_search_kernel(const i64 *Ap, c
 	int *ringv = ring + PS_RING;     // ... and value)
 	int *hk = ringv + PS_RING;       // pending values of the cascade: column, value
 	int *hv = hk + PL_HASH;
+	// HS: the reached columns of a row as a SET in LDS (open addressing, column + 1, 0 = free) instead of one bit per column in HBM.
+	// The walks of this kernel are pruned -- 14 pivot rows visited per row on mk15.b4 -- and with the marks in HBM every step of a
+	// walk was four dependent trips to memory (record, word of marks, atomic on it, marks of the candidates) where the LDS takes
+	// one; 2,048 searches x 84 KB of marks were also the one large randomly accessed footprint of the kernel.  A row that reaches more
+	// than PL_SET_LIMIT columns is deferred like one that outgrows its FIFO (the ticket search keeps its marks in HBM).
+	int *hs = hv + PL_HASH;
+	static_assert(!HS || GB, "the set replaces the marks in HBM");
 	const int lane = threadIdx.x;
 	auto bits_at = [&](int w) -> uint32_t {
 		if constexpr (GB)
@@ -852,6 +861,39 @@ __global__ __launch_bounds__(64) void pivot_label_search_kernel(const i64 *Ap, c
 	if constexpr (!GB)
 		for (int w = lane * 4; w < words; w += 256)
 			*reinterpret_cast<uint4 *>(bits + w) = make_uint4(0, 0, 0, 0);
+	if constexpr (HS)
+		for (int w = lane * 4; w < PL_SET; w += 256)
+			*reinterpret_cast<int4 *>(hs + w) = make_int4(0, 0, 0, 0);
+	// (HS) column j joins the set: true when it was not there.  The lanes of a call may hold the same column: one of them wins.
+	auto set_insert = [&](bool valid, int j) -> bool {
+		bool fresh = false;
+		if (valid) {
+			uint32_t slot = ((uint32_t) j * 2654435761u) >> (32 - PL_SET_LOG);
+			for (int probe = 0; probe < PL_SET; probe++) {
+				const int old = atomicCAS(&hs[slot], 0, j + 1);
+				if (old == 0) {
+					fresh = true;
+					break;
+				}
+				if (old == j + 1)
+					break;
+				slot = (slot + 1) & (PL_SET - 1);
+			}
+		}
+		return fresh;
+	};
+	auto set_has = [&](int j) -> bool {
+		uint32_t slot = ((uint32_t) j * 2654435761u) >> (32 - PL_SET_LOG);
+		for (int probe = 0; probe < PL_SET; probe++) {
+			const int old = hs[slot];
+			if (old == 0)
+				return false;
+			if (old == j + 1)
+				return true;
+			slot = (slot + 1) & (PL_SET - 1);
+		}
+		return true;
+	};
 
 	for (;;) {
 		int first = 0;
@@ -895,11 +937,15 @@ __global__ __launch_bounds__(64) void pivot_label_search_kernel(const i64 *Ap, c
 				};
 				auto reach = [&](bool valid, int j) {          // the column becomes reached; queued if it was not
 					bool fresh = false;
-					if (valid) {
+					if constexpr (HS) {
+						fresh = set_insert(valid, j);
+					} else if (valid) {
 						const uint32_t bit = 1u << (j & 31);
 						fresh = (atomicOr(&bits[j >> 5], bit) & bit) == 0;
 					}
 					push(fresh, j);
+					if constexpr (HS)
+						overflow = overflow || tail > PL_SET_LIMIT;
 				};
 				// the entries of the row: pivotal (or being committed) ones start the walk, the others are candidates
 				int hi_lab = 0x7fffffff;
@@ -926,7 +972,10 @@ __global__ __launch_bounds__(64) void pivot_label_search_kernel(const i64 *Ap, c
 					bool a = false;
 					if (lane < ncand) {
 						const int j = cand[lane];
-						a = (bits_at(j >> 5) & (1u << (j & 31))) == 0;
+						if constexpr (HS)
+							a = !set_has(j);
+						else
+							a = (bits_at(j >> 5) & (1u << (j & 31))) == 0;
 					}
 					return __ballot(a);
 				};
@@ -943,7 +992,7 @@ __global__ __launch_bounds__(64) void pivot_label_search_kernel(const i64 *Ap, c
 					was_free = lmin <= hi_lab;
 					// the walk, pruned: a pivot row at or above the largest label of a live candidate cannot lead to one
 					while (!was_free && head < tail && live != 0 && !overflow) {
-						if (tail + (REC_ENTS + 1) * 64 > fifo_cap) {
+						if (tail + (REC_ENTS + 1) * 64 > (HS ? min(fifo_cap, PL_SET_LIMIT) : fifo_cap)) {
 							overflow = true;
 							break;
 						}
@@ -978,7 +1027,15 @@ __global__ __launch_bounds__(64) void pivot_label_search_kernel(const i64 *Ap, c
 						steps += 1;
 						int e[REC_ENTS];
 						uint32_t bit[REC_ENTS], old[REC_ENTS];
-						if constexpr (GB) {
+						if constexpr (HS) {
+#pragma unroll
+							for (int t = 0; t < REC_ENTS; t++) {
+								e[t] = rec_get<REC_BITS>(lo, hi, t);
+								const bool ok = len != 0 && len != REC_LONG && t < len && e[t] < m;
+								bit[t] = set_insert(ok, e[t]) ? 1u : 0u;
+								old[t] = 0u;
+							}
+						} else if constexpr (GB) {
 							uint32_t seen_word[REC_ENTS];
 #pragma unroll
 							for (int t = 0; t < REC_ENTS; t++) {
@@ -1283,7 +1340,11 @@ __global__ __launch_bounds__(64) void pivot_label_search_kernel(const i64 *Ap, c
 				}
 				// the marks of this attempt go: every marked column is in the FIFO
 				drain();
-				if (overflow || (!GB && tail > words / 2)) {
+				if constexpr (HS) {
+					if (tail > 0)
+						for (int w = lane * 4; w < PL_SET; w += 256)
+							*reinterpret_cast<int4 *>(hs + w) = make_int4(0, 0, 0, 0);
+				} else if (overflow || (!GB && tail > words / 2)) {
 					if constexpr (GB) {
 						for (int w = lane; w < words; w += 64)
 							bits[w] = 0;
@@ -1393,7 +1454,12 @@ int device_acyclic_greedy(const struct spasm_csr *A, int *pinv, int *qinv, std::
 		if (A->p[i + 1] - A->p[i] > (global_bits ? 6 : 7))          // (the pivot and five or six others: what a record holds)
 			list_cap = PS_LIST;
 	const size_t lds = (global_bits ? (size_t) 0 : (size_t) words * 4) + (size_t) (64 + 8 + list_cap + 64 + PS_RING) * sizeof(int);
-	const size_t lds_labels = (global_bits ? (size_t) 0 : (size_t) words * 4) + lds_labels_extra;
+	// (round 5, late) with the marks in HBM the labelled search keeps the reached columns of a row as a set in LDS instead
+	// (SPASM_HIP_PIVOT_REACHED_SET: 0 never, 1 first pass only -- the second pass then takes what outgrew the set with its marks in HBM
+	//  instead of leaving it to the ticket search --, 2 both passes)
+	const int hash_set_mode = env_int("SPASM_HIP_PIVOT_REACHED_SET", 2);
+	const bool hash_set = labels && global_bits && hash_set_mode != 0;
+	const size_t lds_labels = (global_bits ? (size_t) 0 : (size_t) words * 4) + lds_labels_extra + (hash_set ? (size_t) PL_SET * sizeof(int) : 0);
 	const double t0 = wtime();
 	hipStream_t stream = nullptr;
 	DeviceMatrix dA(A, stream);
@@ -1501,7 +1567,10 @@ int device_acyclic_greedy(const struct spasm_csr *A, int *pinv, int *qinv, std::
 			init.t_start = init.t_first_exit = ~0ull;
 			HIP_CHECK(hipMemcpyAsync(pctrl, &init, sizeof(PlCtrl), hipMemcpyHostToDevice, stream));
 			const int grid_pass = std::max(1, std::min(grid_labels, (nrows_pass + PS_ROWS_PER_GRAB - 1) / PS_ROWS_PER_GRAB));
-			if (global_bits)
+			if (hash_set && (pass == 0 || hash_set_mode >= 2))
+				hipLaunchKernelGGL((pivot_label_search_kernel<true, 5, 25, true>), dim3(grid_pass), dim3(64), lds_labels, stream, dA.p, dA.j, d_pinv, nrows_pass, m, words, rec, lab, pctrl,
+				                   fifo, fifo_cap_labels, gbits, d_out, (i64) A->p[n], gap_pass, cap_pass, rowlist_pass);
+			else if (global_bits)
 				hipLaunchKernelGGL((pivot_label_search_kernel<true, 5, 25>), dim3(grid_pass), dim3(64), lds_labels, stream, dA.p, dA.j, d_pinv, nrows_pass, m, words, rec, lab, pctrl,
 				                   fifo, fifo_cap_labels, gbits, d_out, (i64) A->p[n], gap_pass, cap_pass, rowlist_pass);
 			else
@@ -1531,7 +1600,7 @@ int device_acyclic_greedy(const struct spasm_csr *A, int *pinv, int *qinv, std::
 				logmsg("[pivots] device, labelled search, pass %d on %d rows: %d searches in flight (%d per CU, %zu bytes of LDS each%s), %llu pivot rows visited in %llu steps (%llu of them on the %llu rows that ended with a pivot: "
 				       "%llu accepted on their labels alone, %llu after a walk; %llu rows without one), cascades: %llu items in %llu steps (%llu of them thrown away: %llu candidates found reachable, "
 				       "%llu attempts repeated), %d rows deferred (%llu label gap > %d, %llu cascade > %d items, %llu retries) [%.3f s; first wave out of rows after %.1f ms, last one after %.1f ms, longest row %.1f ms]\n",
-				       pass + 1, nrows_pass, grid_pass, per_cu_labels, lds_labels, global_bits ? "; reached-bits in HBM" : "", c.visits, c.steps, c.visits_won, c.rows_won, c.free_accepts, c.walk_accepts, c.rows_lost,
+				       pass + 1, nrows_pass, grid_pass, per_cu_labels, lds_labels, (hash_set && (pass == 0 || hash_set_mode >= 2)) ? "; reached columns as a set in LDS" : global_bits ? "; reached-bits in HBM" : "", c.visits, c.steps, c.visits_won, c.rows_won, c.free_accepts, c.walk_accepts, c.rows_lost,
 				       c.casc_items, c.casc_steps, c.casc_wasted, c.cycles, c.restarts, c.ndeferred, c.deferred_gap, gap_pass, c.deferred_cap, cap_pass, c.deferred_retry, wtime() - tp,
 				       1e-5 * (double) (c.t_first_exit - c.t_start), 1e-5 * (double) (c.t_last_exit - c.t_start), 1e-5 * (double) c.longest_search);
 			ndeferred = c.ndeferred;

@@ -142,12 +142,18 @@ def test_device_search_with_long_rows_on_a_matrix_too_wide_for_the_lds():
                                       {"SPASM_HIP_PIVOT_SECOND_PASS_ALWAYS": "1", "SPASM_HIP_PIVOT_SECOND_PASS_MANY_ROWS": "0"},
                                       {"SPASM_HIP_PIVOT_LABEL_PASSES": "1"},
                                       {"SPASM_HIP_PIVOT_ORDER_BY_LABELS": "0"},
+                                      {"SPASM_HIP_PIVOT_ORDER_CHASE": "0"},
+                                      {"SPASM_HIP_PIVOT_BITS": "global"},
+                                      {"SPASM_HIP_PIVOT_BITS": "global", "SPASM_HIP_PIVOT_REACHED_SET": "1"},
+                                      {"SPASM_HIP_PIVOT_BITS": "global", "SPASM_HIP_PIVOT_REACHED_SET": "0"},
                                       {"SPASM_HIP_PIVOT_LABELS": "0"}])
 @pytest.mark.parametrize("name", ["mk13.b5", "ch7-8.b5"])
 def test_labelled_search_under_starved_limits(name, switches, monkeypatch):
     """the passes of the labelled search with their limits pulled tight -- cascades of at most 64 items, a label gap of 0 (every
     pivot that needs a walk is deferred), a FIFO of 256 columns (walks overflow and defer their row), the second pass always /
-    never, the host's depth-first order instead of the label order, the ticket search alone: whatever is deferred must reach
+    never, the host's depth-first order instead of the label order, the final labels by sweeps instead of work lists, the marks
+    of the walks as a set in LDS (what a matrix too wide for one bit per column in LDS gets: in both passes, in the first one only,
+    not at all -- rows that reach more than 1,536 columns are deferred), the ticket search alone: whatever is deferred must reach
     the next pass, and the pivot set that comes back is cycle-free, in triangular order (checked by the host inside the library
     -- SPASM_HIP_PIVOT_CHECK -- and by _check from the outside), and within 5 % of the host's in size."""
     for k, v in switches.items():
