@@ -79,6 +79,48 @@ def test_pivot_search_matches_oracle(oracle, name, p):
     assert np.array_equal(F.U.p, F_o.U.p) and np.array_equal(F.U.j, F_o.U.j) and np.array_equal(F.U.x, F_o.U.x)
 
 
+def test_threaded_steps_of_the_pivot_search_on_a_large_matrix(oracle, monkeypatch):
+    """beyond 200,000 rows the Faugere-Lachartre steps run on threads (leftmost entries by atomic minima, the column step with
+    its first pass and a filter for its second on threads) and so do the lengths and the rows of U (round 5): the pivots, the
+    permutation and U must still be the oracle's, entry for entry.  210,000 rows of 1-3 entries whose leftmost columns fill a
+    third of the 260,000 columns, so that the column step has pivots to find; the row-order greedy search behind them
+    (SPASM_HIP_THREADS=1, no labels: the reference's pivot set) is cheap on this shape."""
+    monkeypatch.setenv("SPASM_HIP_THREADS", "1")
+    monkeypatch.setenv("SPASM_HIP_PIVOT_LABELS", "0")
+    monkeypatch.setenv("SPASM_HIP_PIVOT_SEARCH", "host")
+    rng = np.random.default_rng(7)
+    p, n, m = 42013, 210000, 260000
+    lens = rng.integers(1, 4, size=n)
+    ti = np.repeat(np.arange(n, dtype=np.int32), lens)
+    tj = rng.integers(m // 3, m, size=len(ti)).astype(np.int32)
+    tj[np.cumsum(lens) - lens] = rng.integers(0, m // 3, size=n)
+    tx = rng.integers(1, p, size=len(ti)).astype(np.int64)
+    A = oracle.compress(p, n, m, ti, tj, tx)
+    npiv_o, perm_o, F_o = oracle.pivots_extract_structural(A, oracle.empty_fact(A.n, A.m, p))
+    Ap = spasm_amd.Csr(A.n, A.m, A.p, A.j, A.x, p)
+    npiv, perm, F = spasm_amd.pivots_extract_structural(Ap, spasm_amd.empty_fact(A.m, p))
+    assert npiv == npiv_o and npiv > len(np.unique(tj[np.cumsum(lens) - lens]))          # (more than the leftmost entries alone give)
+    assert np.array_equal(perm, perm_o)
+    assert np.array_equal(F.qinv, F_o.qinv)
+    assert np.array_equal(F.U.p, F_o.U.p) and np.array_equal(F.U.j, F_o.U.j) and np.array_equal(F.U.x, F_o.U.x)
+    # ... and the plan of this factor (rows gathered by threads beyond 20,000 pivots): a label per row, the pivot column of a
+    # row carries the row's label, every other pivotal column of the row belongs to a strictly later level, the rest lies
+    # behind the pivots
+    nlev, label, lvl_end_row, lab, rpad = _plan(F)
+    U, qinv = F.U, np.asarray(F.qinv)
+    r = U.n
+    assert nlev >= 1 and len(np.unique(label)) == r and label.min() >= 0 and label.max() < rpad
+    Up, Uj = np.asarray(U.p), np.asarray(U.j)
+    row_of = np.repeat(np.arange(r), np.diff(Up))
+    first = np.zeros(len(Uj), bool)
+    first[Up[:-1]] = True
+    assert np.array_equal(lab[Uj[first]], label)
+    rest_lab, rest_row = lab[Uj[~first]], row_of[~first]
+    pivotal = qinv[Uj[~first]] >= 0
+    assert np.all(rest_lab[pivotal] >= lvl_end_row[rest_row[pivotal]])
+    assert np.all(rest_lab[~pivotal] >= rpad)
+
+
 def _plan(F):
     L = C.CDLL(spasm_amd.LIB_PATH)
     u = view_csr(F.U)
