@@ -2143,6 +2143,23 @@ void launch_backsolve_apply(const SchurArgs &a, const spasm_hip_dfact *F, uint32
 		// stage_rows rows when the staging buffer is smaller than the batch
 		const int nwords = d.Smpad / (packed ? 2 : 1);
 		HIP_CHECK(hipMemsetAsync(direct->Sp, 0, sizeof(int64_t), stream));
+		auto expand_slice = [&](int64_t r0, int n, const uint32_t *stage, const unsigned long long *block_sum, hipStream_t s2) {
+			const int nblocks = (n + SCAN_BLOCK - 1) / SCAN_BLOCK;
+			hipLaunchKernelGGL(bs_scan_lengths_kernel, dim3(nblocks), dim3(SCAN_BLOCK), 0, s2, a.row_len + r0, n, block_sum, direct->Sp + r0, direct->cap, a.ctr);
+			ExpandArgs e{stage, nwords, n, direct->Sp + r0, direct->Sj, direct->Sx, direct->cap, a.q, d.G, d.dbg};
+			const int blocks3 = std::max(1, std::min((n + 3) / 4, prop.multiProcessorCount * 8));
+			if (B.sgn)
+				hipLaunchKernelGGL(bs_expand_kernel<0>, dim3(blocks3), dim3(256), 0, s2, e);
+			else if (packed)
+				hipLaunchKernelGGL(bs_expand_kernel<1>, dim3(blocks3), dim3(256), 0, s2, e);
+			else
+				hipLaunchKernelGGL(bs_expand_kernel<2>, dim3(blocks3), dim3(256), 0, s2, e);
+		};
+		// (round 5, measured and dropped: the batch cut into 2 / 4 / 8 parts, each with its own part of the staging buffer, the parts
+		//  applied one after the other on the caller's stream while a second stream scanned and expanded each part as soon as it was
+		//  there -- expansion of part k beside the apply of part k + 1, two kernels bound by the memory at 4.5 and 4.1 TB/s of the
+		//  8 the device has.  The step of mk13.b5 went from 4.63 ms to 4.74 / 5.19 / 6.30: two workgroup shapes that both want
+		//  the LDS and the memory queues of the same CUs take more from each other than the overlap gives back.)
 		for (int64_t r0 = 0; r0 < a.nrows; r0 += direct->stage_rows) {
 			const int n = (int) std::min<int64_t>(direct->stage_rows, a.nrows - r0);
 			ApplyArgs d2 = d;
@@ -2156,18 +2173,9 @@ void launch_backsolve_apply(const SchurArgs &a, const spasm_hip_dfact *F, uint32
 			d2.block_sum = direct->status;          // (the look-back words are not used by the staged output)
 			HIP_CHECK(hipMemsetAsync(d2.block_sum, 0, (size_t) nblocks * sizeof(unsigned long long), stream));
 			launch_apply(d2, blocks2);
-			hipLaunchKernelGGL(bs_scan_lengths_kernel, dim3(nblocks), dim3(SCAN_BLOCK), 0, stream, a.row_len + r0, n, d2.block_sum, direct->Sp + r0,
-			                   direct->cap, a.ctr);
-			ExpandArgs e{direct->stage, nwords, n, direct->Sp + r0, direct->Sj, direct->Sx, direct->cap, a.q, d.G, d.dbg};
-			const int blocks3 = std::max(1, std::min((n + 3) / 4, prop.multiProcessorCount * 8));
 			if (direct->ev_expand != nullptr)
 				HIP_CHECK(hipEventRecord(direct->ev_expand, stream));
-			if (B.sgn)
-				hipLaunchKernelGGL(bs_expand_kernel<0>, dim3(blocks3), dim3(256), 0, stream, e);
-			else if (packed)
-				hipLaunchKernelGGL(bs_expand_kernel<1>, dim3(blocks3), dim3(256), 0, stream, e);
-			else
-				hipLaunchKernelGGL(bs_expand_kernel<2>, dim3(blocks3), dim3(256), 0, stream, e);
+			expand_slice(r0, n, direct->stage, d2.block_sum, stream);
 			direct->staged = true;
 			direct->slices += 1;
 		}

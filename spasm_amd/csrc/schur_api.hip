@@ -168,6 +168,9 @@ void *big_alloc(size_t bytes)
 	if (bytes >= BIG_MIN) {
 		counters()[CNT_BIG_ALLOC_MISSES] += 1;
 		counters()[CNT_BIG_ALLOC_MISS_BYTES] += (long long) bytes;
+		if (verbose() >= 3)
+			logmsg("[block cache] no parked block for %.1f MB: taken from the device (%.1f MB parked in %zu blocks)\n", 1e-6 * (double) bytes, 1e-6 * (double) g_big.cached,
+			       g_big.free_blocks.size());
 	}
 	if (bytes >= BIG_MIN)
 		g_big.live.push_back({ptr, bytes});
