@@ -120,7 +120,10 @@ void *big_alloc(size_t bytes)
 	if (bytes == 0)
 		bytes = 1;
 	void *ptr = nullptr;
-	if (bytes >= BIG_MIN) {
+	const bool big = bytes >= BIG_MIN;          // (decided BEFORE the rounding: a small request of 17-32 MB is rounded to BIG_MIN itself, was
+	                                            //  then booked as a big block, parked as one when freed, and never found again by the next
+	                                            //  small request of its class: five hipMallocs of 32 MB in every driver call on mk15.b4)
+	if (big) {
 		// Sizes in steps of an eighth of their leading power of two, and any parked block of up to twice the size will do: the
 		// large buffers of a driver call -- row pools, the Schur complement, accumulators, echelon stacks -- follow the pivot set of
 		// the call, which depends on timing, and differ by tens of percent from one call to the next.  With exact sizes and a
@@ -159,20 +162,34 @@ void *big_alloc(size_t bytes)
 			return ptr;
 		}
 	}
-	if (hipMalloc(&ptr, bytes) != hipSuccess) {
+	// A large block that has to come from the device is taken half again as large as asked: the pools of a driver call follow its
+	// pivot set, and the SECOND call of a process on mk15.b4 found its Schur complement 20-30 % larger than the first one's often
+	// enough -- 6 blocks, 11.7 GB taken fresh, 0.36 s of first touches inside one sparse round (the later calls then fit).  The
+	// part nobody asked for is never touched and costs nothing but address space of a 288 GB device.
+	size_t take = bytes;
+	if (big && bytes >= ((size_t) 256 << 20))
+		take = bytes + bytes / 100 * (size_t) std::max(0, std::min(100, env_int("SPASM_HIP_BLOCK_HEADROOM_PCT", 50)));
+	if (take > bytes && hipMalloc(&ptr, take) != hipSuccess) {
+		(void) hipGetLastError();
+		ptr = nullptr;
+		take = bytes;
+	}
+	if (ptr == nullptr && hipMalloc(&ptr, bytes) != hipSuccess) {
 		(void) hipGetLastError();
 		big_trim(0);                         // cached blocks may be what is in the way
 		HIP_CHECK(hipMalloc(&ptr, bytes));
 	}
+	if (ptr != nullptr && take > bytes)
+		bytes = take;
 	std::lock_guard<std::mutex> guard(g_big.mutex);
-	if (bytes >= BIG_MIN) {
+	if (big) {
 		counters()[CNT_BIG_ALLOC_MISSES] += 1;
 		counters()[CNT_BIG_ALLOC_MISS_BYTES] += (long long) bytes;
 		if (verbose() >= 3)
 			logmsg("[block cache] no parked block for %.1f MB: taken from the device (%.1f MB parked in %zu blocks)\n", 1e-6 * (double) bytes, 1e-6 * (double) g_big.cached,
 			       g_big.free_blocks.size());
 	}
-	if (bytes >= BIG_MIN)
+	if (big)
 		g_big.live.push_back({ptr, bytes});
 	else
 		g_big.small_live[ptr] = small_class(bytes);

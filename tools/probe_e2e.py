@@ -26,5 +26,6 @@ for k in range(calls):
     t0 = time.time()
     F = spasm_amd.echelonize(A, o)
     ranks.append(F.U.n)
-    print("== %s call %d: rank %d, %.2f s, %s" % (name, k, F.U.n, time.time() - t0, spasm_amd.echelonize_profile()), flush=True)
+    print("== %s call %d: rank %d, %.2f s, %s %s" % (name, k, F.U.n, time.time() - t0, spasm_amd.echelonize_profile(),
+                                                    {a: b for a, b in spasm_amd.echelonize_counters().items() if not a.startswith("pivot")}), flush=True)
 print("ranks agree:", len(set(ranks)) == 1, ranks)
