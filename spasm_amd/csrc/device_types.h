@@ -251,6 +251,7 @@ void resident_begin();
 void resident_end();
 void resident_forget(const struct spasm_csr *A);
 bool resident_enabled();
+void resident_prefetch(const struct spasm_csr *A);
 void ensure_row_tables(const struct ::spasm_hip_dfact *F, hipStream_t stream, bool components = true);
 void resident_counters(int64_t *uploads, int64_t *hits);
 void resident_lazy_downloads(bool on);

@@ -28,6 +28,9 @@ int comm_world(const spasm_hip_comm *c);
 void comm_bcast_host(spasm_hip_comm *c, void *buf, size_t bytes, int root);
 // pivots_device.hip: the greedy search on the device; -1 = does not apply here (no device, too many columns, switched off)
 int device_acyclic_greedy(const struct spasm_csr *A, int *pinv, int *qinv, std::vector<int> *col_label);
+bool resident_prefetch_possible();                              // schur_api.hip
+int resident_current_device();
+void resident_prefetch_matrix(const struct spasm_csr *A, int dev);
 }  // namespace sh
 
 namespace sh {
@@ -761,6 +764,29 @@ extern "C" int spasm_hip_pivots_extract_structural(const struct spasm_csr *A, co
 	if (!dist || comm_rank(comm) == 0) {
 		bool ordered = false;
 		double t_fl = 0.0, t_greedy = 0.0, t_device = 0.0;
+		// (round 5, late) the matrix starts for the device now, beside the Faugere-Lachartre steps: the greedy search on the device is
+		// the first stage that wants it there, and the copy from pageable host memory took 1-36 ms of its time
+		std::thread upload;
+		{
+			const char *where = sh::env_get("SPASM_HIP_PIVOT_SEARCH");
+			int threads = 0;
+			if (const char *e = sh::env_get("SPASM_HIP_THREADS"))
+				threads = std::atoi(e);
+			if ((opts == nullptr || opts->enable_greedy_pivot_search) && A->n >= 20000 && m <= (1 << 25) && threads != 1 && (where == nullptr || std::strcmp(where, "host") != 0) &&
+			    resident_prefetch_possible() && usable_cpus() > 1)
+			{
+				const int dev = resident_current_device();
+				upload = std::thread([A, dev]() { resident_prefetch_matrix(A, dev); });
+			}
+		}
+		struct Joiner {
+			std::thread &t;
+			~Joiner()
+			{
+				if (t.joinable())
+					t.join();
+			}
+		} joiner{upload};
 		npiv = S.leftmost_entries();
 		logmsg("[pivots] Faugere-Lachartre: %d pivots found [%.1fs]\n", npiv, wtime() - t0);
 		double t1 = wtime();
@@ -785,6 +811,8 @@ extern "C" int spasm_hip_pivots_extract_structural(const struct spasm_csr *A, co
 				qinv0 = S.qinv;
 			}
 			std::vector<int> col_label;
+			if (upload.joinable())
+				upload.join();
 			extra = (threads > 1) ? device_acyclic_greedy(A, S.pinv.data(), S.qinv.data(), &col_label) : -1;
 			t_device = wtime() - t1;
 			if (extra >= 0 && !col_label.empty()) {

@@ -502,6 +502,37 @@ int resident_fl_census(const struct spasm_csr *A)
 
 bool resident_enabled() { return g_resident_on; }
 
+// A on its way to the device while the host does something else (the Faugere-Lachartre steps of a round: host_pivots.cpp): the
+// matrix is resident by the time the first device stage of the round asks for it.  Only inside a driver call (resident_begin).
+void resident_prefetch(const struct spasm_csr *A)
+{
+	if (!g_resident_on)
+		return;
+	int ndev = 0;
+	if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) {
+		(void) hipGetLastError();
+		return;
+	}
+	DeviceMatrix up(A, nullptr);
+}
+// (for translation units that do not see device_types.h)
+bool resident_prefetch_possible() { return g_resident_on; }
+int resident_current_device()
+{
+	int dev = 0;
+	if (hipGetDevice(&dev) != hipSuccess)
+		(void) hipGetLastError();
+	return dev;
+}
+void resident_prefetch_matrix(const struct spasm_csr *A, int dev)          // (called on a thread of its own: the caller's device is not this thread's by default)
+{
+	if (hipSetDevice(dev) != hipSuccess) {
+		(void) hipGetLastError();
+		return;
+	}
+	resident_prefetch(A);
+}
+
 DeviceMatrix::DeviceMatrix(const struct spasm_csr *A, hipStream_t stream)
 {
 	nnz = A->p[A->n];
