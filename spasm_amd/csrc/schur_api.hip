@@ -115,6 +115,8 @@ inline int small_class(size_t bytes)
 // FRESH block is paid for on first touch -- erratically, up to seconds for tens of GB -- and hipFree takes 70-170 us for
 // anything from 1 MB up (it waits for the device): a call of the driver makes a few hundred small buffers.  So freed
 // blocks are parked and handed out again: small ones (< 32 MB) by size class, large ones by best fit.
+static std::atomic<long long> g_device_mallocs{0};          // requests that the cache could not serve (tests)
+
 void *big_alloc(size_t bytes)
 {
 	if (bytes == 0)
@@ -166,6 +168,7 @@ void *big_alloc(size_t bytes)
 	// pivot set, and the SECOND call of a process on mk15.b4 found its Schur complement 20-30 % larger than the first one's often
 	// enough -- 6 blocks, 11.7 GB taken fresh, 0.36 s of first touches inside one sparse round (the later calls then fit).  The
 	// part nobody asked for is never touched and costs nothing but address space of a 288 GB device.
+	g_device_mallocs += 1;
 	size_t take = bytes;
 	if (big && bytes >= ((size_t) 256 << 20))
 		take = bytes + bytes / 100 * (size_t) std::max(0, std::min(100, env_int("SPASM_HIP_BLOCK_HEADROOM_PCT", 50)));
@@ -741,6 +744,18 @@ void spasm_hip_lu_free(struct spasm_lu *N);
 
 int spasm_hip_debug_plan(const struct spasm_csr *U, const int *qinv, int *label_of_row, int *lvl_end_of_row, int *lab,
                          int *info);
+
+// (tests) a buffer of `bytes` bytes taken and given back twice: 1 when the second request was served by the cache, 0 when it went
+// to the device again
+int spasm_hip_debug_block_cache_roundtrip(size_t bytes)
+{
+	void *first = big_alloc(bytes);
+	sh::big_free(first);
+	const long long before = g_device_mallocs.load();
+	void *second = big_alloc(bytes);
+	sh::big_free(second);
+	return g_device_mallocs.load() == before ? 1 : 0;
+}
 
 // everything the library parks on the device between calls goes back to it: the block cache, the accumulator scratch
 void spasm_hip_release_cached_memory(void)

@@ -415,3 +415,35 @@ def test_flow_without_the_greedy_pivot_search(name, threshold, min_sparse_rounds
         piv = F.U.j[F.U.p[:-1]]
         assert len(np.unique(piv)) == F.U.n and np.all(F.U.x[F.U.p[:-1]] == 1)
         assert np.array_equal(F.qinv[piv], np.arange(F.U.n))
+
+
+@pytest.mark.gpu
+def test_block_cache_serves_the_second_call_of_the_same_work(monkeypatch):
+    """the cache of device blocks: a driver call that does exactly what the call before it did -- same matrix, the sequential
+    host search (SPASM_HIP_THREADS=1: the same pivot set every time), hence the same buffers of the same sizes -- must not take
+    a single large block fresh from the device (spasm_hip_echelonize_counters: block_cache_misses).  Round 5 found requests of
+    17-32 MB rounded up to the very threshold from which a block counts as large: booked as large, parked as large, and never
+    found again by the next small request -- five fresh blocks in every call."""
+    monkeypatch.setenv("SPASM_HIP_THREADS", "1")
+    A, _ = workloads.load_matrix("mk13.b5")
+    o = spasm_amd.default_opts()
+    ranks, misses = [], []
+    for _ in range(3):
+        F = spasm_amd.echelonize(A, o)
+        ev = spasm_amd.echelonize_counters()
+        ranks.append(F.U.n)
+        misses.append((ev["block_cache_misses"], ev["block_cache_miss_bytes"]))
+    assert ranks == [134211] * 3
+    assert misses[1] == (0, 0) and misses[2] == (0, 0), misses          # (the first call of a process fills the cache, the next ones live off it)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("mb", [0.5, 3, 17, 20, 31.9, 32, 33, 100, 300, 1500])
+def test_block_cache_gives_a_block_back_to_the_next_request_of_its_size(mb):
+    """a buffer taken, given back, and asked for again must come from the cache whatever its size -- in particular 17-32 MB,
+    which the power-of-two classes of the small blocks round to 32 MB, the threshold of the large ones (the defect above)"""
+    import ctypes as C
+    L = C.CDLL(spasm_amd.LIB_PATH)
+    L.spasm_hip_debug_block_cache_roundtrip.argtypes = [C.c_size_t]
+    L.spasm_hip_debug_block_cache_roundtrip.restype = C.c_int
+    assert L.spasm_hip_debug_block_cache_roundtrip(int(mb * (1 << 20))) == 1
