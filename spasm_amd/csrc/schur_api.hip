@@ -141,7 +141,12 @@ void *big_alloc(size_t bytes)
 		int best = -1;
 		for (size_t t = 0; t < g_big.free_blocks.size(); t++) {
 			const size_t have = g_big.free_blocks[t].second;
-			if (have >= bytes && have <= (classes ? 2 * bytes : bytes + bytes / 2) && (best < 0 || have < g_big.free_blocks[(size_t) best].second))
+			// (from 256 MB on a parked block of up to FOUR times the size will do: what the device charges for is a block taken
+			//  fresh -- its first touch, 0.2 s per GB when the driver has to clear new memory: a 2.5 s sparse round in one mk15.b4
+			//  call of ten, whose pools of 2.7 GB found only the 6.7 GB blocks of a call with a larger Schur complement parked --, not
+			//  the untouched tail of a block that is larger than asked)
+			const size_t most = !classes ? bytes + bytes / 2 : (bytes >= ((size_t) 256 << 20) ? 4 * bytes : 2 * bytes);
+			if (have >= bytes && have <= most && (best < 0 || have < g_big.free_blocks[(size_t) best].second))
 				best = (int) t;
 		}
 		if (best >= 0) {
