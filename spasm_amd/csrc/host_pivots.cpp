@@ -31,6 +31,7 @@ int device_acyclic_greedy(const struct spasm_csr *A, int *pinv, int *qinv, std::
 bool resident_prefetch_possible();                              // schur_api.hip
 int resident_current_device();
 void resident_prefetch_matrix(const struct spasm_csr *A, int dev);
+void level_hint_set(const struct spasm_csr *U, int rows, std::vector<int> &&height);          // schur_api.hip
 }  // namespace sh
 
 namespace sh {
@@ -761,6 +762,7 @@ extern "C" int spasm_hip_pivots_extract_structural(const struct spasm_csr *A, co
 	spasm_hip_comm *comm = current_comm();
 	const bool dist = comm != nullptr && comm_world(comm) > 1;
 	int npiv = 0;
+	std::vector<int> hint_height;          // heights of the new rows of U from the labels of the device search (see level_hint_set)
 	if (!dist || comm_rank(comm) == 0) {
 		bool ordered = false;
 		double t_fl = 0.0, t_greedy = 0.0, t_device = 0.0;
@@ -839,6 +841,9 @@ extern "C" int spasm_hip_pivots_extract_structural(const struct spasm_csr *A, co
 					}
 				if (placed != npiv + extra)
 					die("pivot ordering by labels lost pivots (%d != %d)", placed, npiv + extra);
+				hint_height.resize((size_t) placed);
+				for (int t = 0; t < placed; t++)
+					hint_height[(size_t) t] = top - col_label[(size_t) S.pinv[p[t]]];
 				for (int i = 0; i < n; i++)
 					if (S.pinv[i] == -1)
 						p[placed++] = i;
@@ -989,6 +994,8 @@ extern "C" int spasm_hip_pivots_extract_structural(const struct spasm_csr *A, co
 	};
 	in_threads(fill_rows);
 	U->n = n0 + npiv;
+	if (n0 == 0 && !dist && (int) hint_height.size() == npiv && npiv > 0)
+		level_hint_set(U, npiv, std::move(hint_height));
 	if (verbose() >= 2)
 		logmsg("[pivots] search and order %.1f ms, rows of U %.1f ms\n", 1e3 * (t_searched - t0), 1e3 * (wtime() - t_searched));
 	return npiv;

@@ -787,6 +787,86 @@ int spasm_hip_device_count(void)
 // Host part of the factor image (sh::FactPlan, device_types.h): checks U, computes the elimination levels,
 // the column labels and the relabelled rows.  No GPU involved (unit-tested on
 // the CPU through spasm_hip_debug_plan).
+// Levels that somebody else has computed already (round 5, late): the device pivot search ends with a depth label for every
+// column -- every other entry of a pivot row has a larger label than its pivot -- so "largest label minus the label of the
+// row's pivot" is a valid height for every row of a factor made of that search's pivots alone.  The search leaves them here
+// (spasm_hip_pivots_extract_structural: first round of a driver call); plan_factor takes them when they belong to the factor
+// it is given AND a threaded pass confirms, entry by entry, that they order it (so a stale or foreign hint costs a millisecond,
+// never a wrong schedule), and skips its own serial pass over the rows (8 ms on mk15.b4's 604,000).
+extern "C++" {
+namespace sh {
+struct LevelHint {
+	const void *U = nullptr;
+	int rows = 0;
+	std::vector<int> height;          // per row of U
+};
+static LevelHint g_level_hint;
+static std::mutex g_level_hint_mutex;
+
+void level_hint_set(const struct spasm_csr *U, int rows, std::vector<int> &&height)
+{
+	std::lock_guard<std::mutex> guard(g_level_hint_mutex);
+	g_level_hint.U = U;
+	g_level_hint.rows = rows;
+	g_level_hint.height = std::move(height);
+}
+}  // namespace sh
+}  // extern "C++"
+
+static bool heights_from_hint(const struct spasm_csr *U, const int *qinv, std::vector<int> &height)
+{
+	const int r = U->n;
+	{
+		std::lock_guard<std::mutex> guard(sh::g_level_hint_mutex);
+		if (sh::g_level_hint.U != (const void *) U || sh::g_level_hint.rows != r || (int) sh::g_level_hint.height.size() != r || r < 20000 ||
+		    env_int("SPASM_HIP_LEVEL_HINT", 1) == 0)
+			return false;
+		height = sh::g_level_hint.height;
+	}
+	const int T = std::max(1, std::min(16, usable_cpus()));
+	std::atomic<int> bad{0};
+	auto check = [&](int k0, int k1) {
+		for (int k = k0; k < k1 && bad.load(std::memory_order_relaxed) == 0; k++) {
+			const int h = height[k];
+			if (h < 0) {
+				bad.store(1);
+				return;
+			}
+			for (i64 px = U->p[k] + 1; px < U->p[k + 1]; px++) {
+				const int k2 = qinv[U->j[px]];
+				if (k2 >= 0 && (k2 == k || height[k2] >= h)) {
+					bad.store(1);
+					return;
+				}
+			}
+		}
+	};
+	std::vector<std::thread> pool;
+	for (int t = 1; t < T; t++)
+		pool.emplace_back(check, (int) ((i64) r * t / T), (int) ((i64) r * (t + 1) / T));
+	check(0, (int) ((i64) r / T));
+	for (auto &th : pool)
+		th.join();
+	if (bad.load() != 0)
+		return false;
+	// the labels of a search have gaps: heights without empty levels (same order)
+	int top = 0;
+	for (int k = 0; k < r; k++)
+		top = std::max(top, height[k]);
+	std::vector<int> rank_of((size_t) top + 1, 0);
+	for (int k = 0; k < r; k++)
+		rank_of[(size_t) height[k]] = 1;
+	int next = 0;
+	for (int h = 0; h <= top; h++)
+		if (rank_of[(size_t) h]) {
+			rank_of[(size_t) h] = next;
+			next += 1;
+		}
+	for (int k = 0; k < r; k++)
+		height[k] = rank_of[(size_t) height[k]];
+	return true;
+}
+
 static void plan_factor(const struct spasm_csr *U, const int *qinv, FactPlan &P)
 {
 	const int r = U->n, m = U->m;
@@ -826,7 +906,10 @@ static void plan_factor(const struct spasm_csr *U, const int *qinv, FactPlan &P)
 	// round: a row only touches pivot columns of rows after it): then one pass from the last row to the first gives the
 	// heights.  Any dependency on an earlier row sends the whole computation to the general search below.
 	bool forward_only = true;
-	for (int k = r - 1; k >= 0 && forward_only; k--) {
+	const bool hinted = heights_from_hint(U, qinv, height);
+	if (!hinted)
+		std::fill(height.begin(), height.end(), 0);
+	for (int k = r - 1; k >= 0 && forward_only && !hinted; k--) {
 		int h = 0;
 		for (i64 px = U->p[k] + 1; px < U->p[k + 1]; px++) {
 			const int k2 = qinv[U->j[px]];
@@ -840,7 +923,7 @@ static void plan_factor(const struct spasm_csr *U, const int *qinv, FactPlan &P)
 		}
 		height[k] = h;
 	}
-	if (!forward_only) {
+	if (!forward_only && !hinted) {
 		std::fill(height.begin(), height.end(), 0);
 		std::vector<unsigned char> state((size_t) (r > 0 ? r : 1), 0);   // 0 new, 1 open, 2 done
 		std::vector<int> stk;
@@ -881,7 +964,7 @@ static void plan_factor(const struct spasm_csr *U, const int *qinv, FactPlan &P)
 			}
 		}
 	}
-	lap("checks + heights");
+	lap(hinted ? "checks + heights (levels of the device pivot search, verified)" : "checks + heights");
 	int hmax = 0;
 	for (int k = 0; k < r; k++)
 		hmax = std::max(hmax, height[k]);
@@ -1106,6 +1189,13 @@ static void plan_row_tables(FactPlan &P, bool components = true)
 			P.ncomp += 1;
 			P.comp_largest = std::max(P.comp_largest, members[c]);
 		}
+}
+
+// (tests) levels offered to plan_factor for this factor, as the device pivot search offers them: heights[k] per row of U
+void spasm_hip_debug_level_hint(const struct spasm_csr *U, const int *heights)
+{
+	std::vector<int> h(heights, heights + U->n);
+	sh::level_hint_set(U, U->n, std::move(h));
 }
 
 // CPU-only view of the plan, for tests: label of each row of U, end of the

@@ -120,6 +120,35 @@ def test_threaded_steps_of_the_pivot_search_on_a_large_matrix(oracle, monkeypatc
     assert np.all(rest_lab[pivotal] >= lvl_end_row[rest_row[pivotal]])
     assert np.all(rest_lab[~pivotal] >= rpad)
 
+    # ... and with levels OFFERED to the plan, as the device pivot search offers its depth labels (round 5): valid ones are taken
+    # (checked entry by entry on threads first), wrong ones are refused and the plan computes its own -- either way the schedule
+    # that comes back must pass the same checks
+    def check(plan):
+        nlev2, label2, lvl_end2, lab2, rpad2 = plan
+        assert nlev2 >= 1 and len(np.unique(label2)) == r and label2.min() >= 0 and label2.max() < rpad2
+        assert np.array_equal(lab2[Uj[first]], label2)
+        rl = lab2[Uj[~first]]
+        assert np.all(rl[pivotal] >= lvl_end2[rest_row[pivotal]]) and np.all(rl[~pivotal] >= rpad2)
+        return nlev2
+
+    level_of_row = np.searchsorted(np.unique(lvl_end_row), lvl_end_row)          # 0 = the level eliminated first
+    L = C.CDLL(spasm_amd.LIB_PATH)
+    u = view_csr(F.U)
+
+    def offer(heights):
+        h = np.ascontiguousarray(heights, np.int32)
+        L.spasm_hip_debug_level_hint(C.byref(u), h.ctypes.data_as(C.POINTER(C.c_int)))
+        lab_out, lvl_out, lab_cols, info = np.zeros(r, np.int32), np.zeros(r, np.int32), np.zeros(F.U.m, np.int32), np.zeros(2, np.int32)
+        ip = lambda a: a.ctypes.data_as(C.POINTER(C.c_int))
+        q = np.ascontiguousarray(F.qinv, np.int32)
+        n_levels = L.spasm_hip_debug_plan(C.byref(u), ip(q), ip(lab_out), ip(lvl_out), ip(lab_cols), ip(info))
+        return n_levels, lab_out, lvl_out, lab_cols, int(info[0])
+
+    top = int(level_of_row.max())
+    assert check(offer(3 * (top - level_of_row))) == top + 1               # (valid, with gaps: taken, the gaps closed)
+    assert check(offer(np.zeros(r, np.int32))) == nlev                      # (every dependency violated: refused)
+    assert check(offer(level_of_row)) == nlev                               # (upside down: refused)
+
 
 def _plan(F):
     L = C.CDLL(spasm_amd.LIB_PATH)
