@@ -1508,8 +1508,8 @@ int device_acyclic_greedy(const struct spasm_csr *A, int *pinv, int *qinv, std::
 		HIP_CHECK(hipMemsetAsync(gbits, 0, (size_t) grid_max * ((size_t) words + 64) * sizeof(uint32_t), stream));
 	}
 	const double t_alloc = wtime();
-	HIP_CHECK(hipMemcpyAsync(d_pinv, pinv, (size_t) n * sizeof(int), hipMemcpyHostToDevice, stream));
-	HIP_CHECK(hipMemcpyAsync(d_qinv, qinv, (size_t) m * sizeof(int), hipMemcpyHostToDevice, stream));
+	sh::h2d(d_pinv, pinv, (size_t) n * sizeof(int), stream);
+	sh::h2d(d_qinv, qinv, (size_t) m * sizeof(int), stream);
 	if (global_bits)
 		hipLaunchKernelGGL((pivot_records_kernel<5, 25>), dim3((m + 255) / 256), dim3(256), 0, stream, dA.p, dA.j, d_qinv, m, rec);
 	else
@@ -1756,7 +1756,7 @@ int device_acyclic_greedy(const struct spasm_csr *A, int *pinv, int *qinv, std::
 	if (found >= 0 && labels && lab != nullptr && col_label != nullptr && ticket_pivots <= env_int("SPASM_HIP_PIVOT_ORDER_MAX_TICKET_PIVOTS", 64) &&
 	    env_int("SPASM_HIP_PIVOT_ORDER_BY_LABELS", 1) != 0) {
 		const double tl = wtime();
-		HIP_CHECK(hipMemcpyAsync(d_qinv, qinv, (size_t) m * sizeof(int), hipMemcpyHostToDevice, stream));
+		sh::h2d(d_qinv, qinv, (size_t) m * sizeof(int), stream);
 		hipLaunchKernelGGL(pivot_labels_states_kernel, dim3((m + 255) / 256), dim3(256), 0, stream, d_qinv, m, lab);
 		int sweeps = 0;
 		bool settled = false;

@@ -80,7 +80,7 @@ template <typename T> T *dalloc(int64_t count)
 template <typename T> void upload(T *dst, const T *src, int64_t count, hipStream_t s)
 {
 	if (count > 0)
-		HIP_CHECK(hipMemcpyAsync(dst, src, (size_t) count * sizeof(T), hipMemcpyHostToDevice, s));
+		sh::h2d(dst, src, (size_t) count * sizeof(T), s);
 }
 
 }  // namespace
@@ -388,6 +388,80 @@ struct ResidentEntry {
 	bool host_stale;          // the host struct has its row pointers only: j and x were never downloaded (resident_materialize)
 };
 static std::vector<ResidentEntry> g_resident;
+// ---- host -> device copies ---------------------------------------------------------------------------
+// hipMemcpyAsync from pageable memory pins the caller's pages for large copies, and what that costs depends on the history of
+// the process: the 136 MB of mk15.b4 went over in 1 to 36 ms from one driver call to the next, the 5 MB of tables of mk13.b5's
+// factor image in 0.7 or 19 ms (`factor_image_ms` 6.8 or 30 from one bench process to the next -- with the same library).  Copies of
+// 256 KB and more go through pinned buffers of the library instead: 8 MB pieces, filled by up to four threads (each with two
+// buffers of its own, so that a piece is on its way while the next one is filled), sent by hipMemcpyAsync on the caller's
+// stream.  The source is consumed when the call returns.  SPASM_HIP_STAGED_H2D=0: the runtime's own path.
+namespace {
+constexpr size_t H2D_PIECE = (size_t) 8 << 20;
+constexpr int H2D_THREADS = 4;
+struct H2dLane {
+	void *buf[2] = {nullptr, nullptr};
+	hipEvent_t ev[2] = {nullptr, nullptr};
+	bool busy[2] = {false, false};
+};
+struct H2dStage {
+	std::mutex mutex;
+	H2dLane lane[H2D_THREADS];
+	bool ready = false, broken = false;
+};
+H2dStage g_h2d;
+}  // namespace
+
+void h2d(void *dst, const void *src, size_t bytes, hipStream_t stream)
+{
+	if (bytes == 0)
+		return;
+	static const bool staged = env_int("SPASM_HIP_STAGED_H2D", 1) != 0;
+	if (!staged || bytes < ((size_t) 256 << 10)) {
+		HIP_CHECK(hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, stream));
+		return;
+	}
+	std::lock_guard<std::mutex> guard(g_h2d.mutex);
+	if (!g_h2d.ready && !g_h2d.broken) {
+		for (int t = 0; t < H2D_THREADS && !g_h2d.broken; t++)
+			for (int b = 0; b < 2 && !g_h2d.broken; b++)
+				if (hipHostMalloc(&g_h2d.lane[t].buf[b], H2D_PIECE, hipHostMallocDefault) != hipSuccess ||
+				    hipEventCreateWithFlags(&g_h2d.lane[t].ev[b], hipEventDisableTiming) != hipSuccess) {
+					(void) hipGetLastError();
+					g_h2d.broken = true;
+				}
+		g_h2d.ready = !g_h2d.broken;
+	}
+	if (g_h2d.broken) {
+		HIP_CHECK(hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, stream));
+		return;
+	}
+	const size_t pieces = (bytes + H2D_PIECE - 1) / H2D_PIECE;
+	const int T = (int) std::min<size_t>((size_t) std::max(1, std::min(H2D_THREADS, usable_cpus())), pieces);
+	int dev = 0;
+	HIP_CHECK(hipGetDevice(&dev));
+	auto work = [&](int t) {
+		if (t > 0 && hipSetDevice(dev) != hipSuccess)
+			die("h2d: hipSetDevice(%d) failed on a copy thread", dev);
+		H2dLane &L = g_h2d.lane[t];
+		int b = 0;
+		for (size_t k = (size_t) t; k < pieces; k += (size_t) T, b ^= 1) {
+			const size_t off = k * H2D_PIECE, n = std::min(H2D_PIECE, bytes - off);
+			if (L.busy[b])
+				HIP_CHECK(hipEventSynchronize(L.ev[b]));
+			std::memcpy(L.buf[b], static_cast<const char *>(src) + off, n);
+			HIP_CHECK(hipMemcpyAsync(static_cast<char *>(dst) + off, L.buf[b], n, hipMemcpyHostToDevice, stream));
+			HIP_CHECK(hipEventRecord(L.ev[b], stream));
+			L.busy[b] = true;
+		}
+	};
+	std::vector<std::thread> pool;
+	for (int t = 1; t < T; t++)
+		pool.emplace_back(work, t);
+	work(0);
+	for (auto &th : pool)
+		th.join();
+}
+
 static bool g_resident_on = false;
 static bool g_lazy_download = false;
 static i64 g_resident_uploads = 0, g_resident_hits = 0;
@@ -556,10 +630,10 @@ DeviceMatrix::DeviceMatrix(const struct spasm_csr *A, hipStream_t stream)
 	HIP_CHECK(sh::malloc_or_trim((void **) &p, ((size_t) A->n + 1) * sizeof(i64)));
 	HIP_CHECK(sh::malloc_or_trim((void **) &j, (size_t) (nnz > 0 ? nnz : 1) * sizeof(int)));
 	HIP_CHECK(sh::malloc_or_trim((void **) &x, (size_t) (nnz > 0 ? nnz : 1) * sizeof(int)));
-	HIP_CHECK(hipMemcpyAsync(p, A->p, ((size_t) A->n + 1) * sizeof(i64), hipMemcpyHostToDevice, stream));
+	h2d(p, A->p, ((size_t) A->n + 1) * sizeof(i64), stream);
 	if (nnz > 0) {
-		HIP_CHECK(hipMemcpyAsync(j, A->j, (size_t) nnz * sizeof(int), hipMemcpyHostToDevice, stream));
-		HIP_CHECK(hipMemcpyAsync(x, A->x, (size_t) nnz * sizeof(int), hipMemcpyHostToDevice, stream));
+		h2d(j, A->j, (size_t) nnz * sizeof(int), stream);
+		h2d(x, A->x, (size_t) nnz * sizeof(int), stream);
 	}
 	HIP_CHECK(hipStreamSynchronize(stream));
 	g_resident_uploads += 1;

@@ -64,7 +64,7 @@ template <typename T> T *dalloc(int64_t count)
 template <typename T> void upload(T *dst, const std::vector<T> &src, hipStream_t s)
 {
 	if (!src.empty())
-		HIP_CHECK(hipMemcpyAsync(dst, src.data(), src.size() * sizeof(T), hipMemcpyHostToDevice, s));
+		sh::h2d(dst, src.data(), src.size() * sizeof(T), s);
 }
 
 __device__ __forceinline__ const uint32_t *frag_ptr(const SpPools &P, uint64_t f)
