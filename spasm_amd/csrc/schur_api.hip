@@ -141,11 +141,14 @@ void *big_alloc(size_t bytes)
 		int best = -1;
 		for (size_t t = 0; t < g_big.free_blocks.size(); t++) {
 			const size_t have = g_big.free_blocks[t].second;
-			// (from 256 MB on a parked block of up to FOUR times the size will do: what the device charges for is a block taken
+			// (from 256 MB on a parked block of up to FOUR times the size would do -- see below --: what the device charges for is a block taken
 			//  fresh -- its first touch, 0.2 s per GB when the driver has to clear new memory: a 2.5 s sparse round in one mk15.b4
 			//  call of ten, whose pools of 2.7 GB found only the 6.7 GB blocks of a call with a larger Schur complement parked --, not
 			//  the untouched tail of a block that is larger than asked)
-			const size_t most = !classes ? bytes + bytes / 2 : (bytes >= ((size_t) 256 << 20) ? 4 * bytes : 2 * bytes);
+			// (... and in the end ANY parked block that is large enough, the smallest one first: the bench's first mk15.b4 call after
+			//  the phase with the 19 GB pools of the fixed pivot set found those parked, more than four times what it wanted, took 9 GB
+			//  fresh right after 100 GB had gone back to the device, and spent 2.9 s on their first touch)
+			const size_t most = !classes ? bytes + bytes / 2 : (bytes >= ((size_t) 256 << 20) ? ~(size_t) 0 : 2 * bytes);
 			if (have >= bytes && have <= most && (best < 0 || have < g_big.free_blocks[(size_t) best].second))
 				best = (int) t;
 		}
