@@ -246,6 +246,8 @@ void big_free(void *ptr);
 void big_trim(size_t keep_bytes = 0);
 // host -> device through pinned staging buffers of the library (schur_api.hip): the source is consumed when the call returns
 void h2d(void *dst, const void *src, size_t bytes, hipStream_t stream);
+// device -> host the same way; returns when dst holds the bytes (everything queued on the stream before it has run)
+void d2h(void *dst, const void *src, size_t bytes, hipStream_t stream);
 void big_age(int max_idle);          // cached blocks unused through more than max_idle driver calls go back to the device
 hipError_t malloc_or_trim(void **ptr, size_t bytes);          // hipMalloc; on failure the cache is emptied and it is tried again
 void mem_info(size_t *free_b, size_t *total_b);                // hipMemGetInfo + what the cache parks (given back on demand)

@@ -1622,7 +1622,7 @@ int device_acyclic_greedy(const struct spasm_csr *A, int *pinv, int *qinv, std::
 		if (labels) {
 			// its pivots: the rows whose entry of pinv it filled
 			std::vector<int> got((size_t) n);
-			HIP_CHECK(hipMemcpy(got.data(), d_pinv, (size_t) n * sizeof(int), hipMemcpyDeviceToHost));
+			sh::d2h(got.data(), d_pinv, (size_t) n * sizeof(int), stream);
 			bool fine = true;
 			for (int i = 0; i < n && fine; i++) {
 				if (pinv[i] >= 0 || got[i] < 0)
@@ -1803,7 +1803,7 @@ int device_acyclic_greedy(const struct spasm_csr *A, int *pinv, int *qinv, std::
 		}
 		if (settled) {
 			std::vector<uint32_t> words((size_t) m);
-			HIP_CHECK(hipMemcpy(words.data(), lab, (size_t) m * sizeof(uint32_t), hipMemcpyDeviceToHost));
+			sh::d2h(words.data(), lab, (size_t) m * sizeof(uint32_t), stream);
 			col_label->resize((size_t) m);
 			for (int j = 0; j < m; j++)
 				(*col_label)[(size_t) j] = (int) (words[(size_t) j] >> 2);

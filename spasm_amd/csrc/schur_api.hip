@@ -465,6 +465,64 @@ void h2d(void *dst, const void *src, size_t bytes, hipStream_t stream)
 		th.join();
 }
 
+// (the way back: 256 KB to 256 MB -- the pivots and labels of a search, the row pointers of a Schur complement -- through the same
+//  buffers; larger ones -- a whole Schur complement for a host round -- keep the runtime's path, which pins once and streams)
+void d2h(void *dst, const void *src, size_t bytes, hipStream_t stream)
+{
+	if (bytes == 0)
+		return;
+	static const bool staged = env_int("SPASM_HIP_STAGED_H2D", 1) != 0;
+	bool direct = !staged || bytes < ((size_t) 256 << 10) || bytes > ((size_t) 256 << 20);
+	std::unique_lock<std::mutex> guard(g_h2d.mutex, std::defer_lock);
+	if (!direct) {
+		guard.lock();
+		direct = !g_h2d.ready;          // (the buffers are made by the first staged copy to the device)
+	}
+	if (direct) {
+		HIP_CHECK(hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, stream));
+		HIP_CHECK(hipStreamSynchronize(stream));
+		return;
+	}
+	const size_t pieces = (bytes + H2D_PIECE - 1) / H2D_PIECE;
+	const int T = (int) std::min<size_t>((size_t) std::max(1, std::min(H2D_THREADS, usable_cpus())), pieces);
+	int dev = 0;
+	HIP_CHECK(hipGetDevice(&dev));
+	auto work = [&](int t) {
+		if (t > 0 && hipSetDevice(dev) != hipSuccess)
+			die("d2h: hipSetDevice(%d) failed on a copy thread", dev);
+		H2dLane &L = g_h2d.lane[t];
+		for (int b = 0; b < 2; b++)
+			if (L.busy[b]) {          // (a copy TO the device may still be reading the buffer)
+				HIP_CHECK(hipEventSynchronize(L.ev[b]));
+				L.busy[b] = false;
+			}
+		size_t pend_off = 0, pend_n = 0;
+		int pend_b = -1, b = 0;
+		for (size_t k = (size_t) t; k < pieces; k += (size_t) T, b ^= 1) {
+			const size_t off = k * H2D_PIECE, n = std::min(H2D_PIECE, bytes - off);
+			HIP_CHECK(hipMemcpyAsync(L.buf[b], static_cast<const char *>(src) + off, n, hipMemcpyDeviceToHost, stream));
+			HIP_CHECK(hipEventRecord(L.ev[b], stream));
+			if (pend_b >= 0) {
+				HIP_CHECK(hipEventSynchronize(L.ev[pend_b]));
+				std::memcpy(static_cast<char *>(dst) + pend_off, L.buf[pend_b], pend_n);
+			}
+			pend_off = off;
+			pend_n = n;
+			pend_b = b;
+		}
+		if (pend_b >= 0) {
+			HIP_CHECK(hipEventSynchronize(L.ev[pend_b]));
+			std::memcpy(static_cast<char *>(dst) + pend_off, L.buf[pend_b], pend_n);
+		}
+	};
+	std::vector<std::thread> pool;
+	for (int t = 1; t < T; t++)
+		pool.emplace_back(work, t);
+	work(0);
+	for (auto &th : pool)
+		th.join();
+}
+
 static bool g_resident_on = false;
 static bool g_lazy_download = false;
 static i64 g_resident_uploads = 0, g_resident_hits = 0;
@@ -2378,7 +2436,7 @@ struct spasm_csr *spasm_hip_schur(const struct spasm_csr *A, const int *p, int n
 		}
 	} else {
 		S = spasm_hip_csr_alloc(n, m, st.nnz, prime, true);
-		HIP_CHECK(hipMemcpy(S->p, W->d_Sp, ((size_t) n + 1) * sizeof(i64), hipMemcpyDeviceToHost));
+		sh::d2h(S->p, W->d_Sp, ((size_t) n + 1) * sizeof(i64), stream);
 		const bool keep = resident_enabled() && n >= 1024;
 		lazy = keep && g_lazy_download && L == nullptr;
 		if (st.nnz > 0 && !lazy) {
