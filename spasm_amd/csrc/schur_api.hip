@@ -465,6 +465,27 @@ void h2d(void *dst, const void *src, size_t bytes, hipStream_t stream)
 		th.join();
 }
 
+// the pinned buffers go back (spasm_hip_release_cached_memory); the next large copy makes new ones
+void h2d_release()
+{
+	std::lock_guard<std::mutex> guard(g_h2d.mutex);
+	for (int t = 0; t < H2D_THREADS; t++)
+		for (int b = 0; b < 2; b++) {
+			H2dLane &L = g_h2d.lane[t];
+			if (L.busy[b] && L.ev[b] != nullptr)
+				(void) hipEventSynchronize(L.ev[b]);
+			L.busy[b] = false;
+			if (L.buf[b] != nullptr)
+				(void) hipHostFree(L.buf[b]);
+			if (L.ev[b] != nullptr)
+				(void) hipEventDestroy(L.ev[b]);
+			L.buf[b] = nullptr;
+			L.ev[b] = nullptr;
+		}
+	g_h2d.ready = false;
+	g_h2d.broken = false;
+}
+
 // (the way back: 256 KB to 256 MB -- the pivots and labels of a search, the row pointers of a Schur complement -- through the same
 //  buffers; larger ones -- a whole Schur complement for a host round -- keep the runtime's path, which pins once and streams)
 void d2h(void *dst, const void *src, size_t bytes, hipStream_t stream)
@@ -901,6 +922,7 @@ int spasm_hip_debug_block_cache_roundtrip(size_t bytes)
 void spasm_hip_release_cached_memory(void)
 {
 	big_trim(0);
+	sh::h2d_release();
 	if (g_scratch_cache.ptr != nullptr) {
 		sh::big_free(g_scratch_cache.ptr);
 		g_scratch_cache.ptr = nullptr;
