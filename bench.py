@@ -91,6 +91,109 @@ def cpu_baseline(A, rows, F, budget_s=20.0):
                       % (count, len(rows), t, threads)}
 
 
+class _ModEchelon:
+    """reduced row echelon basis mod p of the rows handed to add(), exact, in float64 (residues < 2^16: products summed over
+    <= 64 terms at a time stay far below 2^53) -- the stand-in for FFPACK in cpu_rank_time: panels of 64 rows are reduced row
+    by row, everything else is matrix products (numpy's BLAS, the threads of the box)."""
+
+    def __init__(self, m, p):
+        self.m, self.p = m, float(p)
+        self.ip = int(p)
+        self.basis = np.zeros((0, m), np.float64)
+        self.pivcols = []
+
+    def _mod(self, Y):
+        Y -= np.floor(Y / self.p) * self.p
+        return Y
+
+    def _minus_product(self, Y, Cf, B):
+        """Y -= Cf @ B mod p, 64 columns of Cf at a time (sums of 64 products of residues: < 2^38)"""
+        for k0 in range(0, Cf.shape[1], 64):
+            Y -= Cf[:, k0:k0 + 64] @ B[k0:k0 + 64]
+            self._mod(Y)
+
+    def add(self, S):
+        p = self.ip
+        Y = self._mod(S.astype(np.float64))
+        if self.pivcols:
+            self._minus_product(Y, Y[:, self.pivcols].copy(), self.basis)
+        Y = Y[np.any(Y != 0, axis=1)]
+        while Y.shape[0]:
+            P = Y[:64].copy()
+            rest = Y[64:]
+            cols, keep = [], []
+            for r in range(P.shape[0]):              # Gauss-Jordan inside the panel
+                nz = np.flatnonzero(P[r])
+                if nz.size == 0:
+                    continue
+                j = int(nz[0])
+                P[r] = self._mod(P[r] * float(pow(int(P[r, j]), p - 2, p)))
+                f = P[:, j].copy()
+                f[r] = 0.0
+                sel = f != 0
+                if sel.any():
+                    P[sel] = self._mod(P[sel] - np.outer(f[sel], P[r]))
+                cols.append(j)
+                keep.append(r)
+            if cols:
+                P = P[keep]
+                if rest.shape[0]:
+                    self._minus_product(rest, rest[:, cols].copy(), P)
+                if self.basis.shape[0]:
+                    self._minus_product(self.basis, self.basis[:, cols].copy(), P)
+                self.basis = np.vstack([self.basis, P])
+                self.pivcols.extend(cols)
+            Y = rest[np.any(rest != 0, axis=1)] if rest.shape[0] else rest
+
+
+def cpu_rank_time(A, budget_s=14.0, block=2048):
+    """The second half of the metric on the host cores: wall-clock time of a rank computation the way the reference does it
+    (tools/rank.c:76-104 -> spasm_echelonize, spasm_echelonize.c:473).  spasm_echelonize.c itself cannot be compiled here (FFPACK),
+    so the time is composed from the compiled reference's own pieces on the CPUs the box grants: spasm_pivots_extract_structural
+    (in full) + the dense finish the reference takes on a matrix whose Schur complement is dense (echelonize_dense,
+    spasm_echelonize.c:315-393: spasm_schur_dense on blocks of rows, each block reduced to echelon rows -- an exact numpy
+    elimination stands in for FFPACK).  Blocks run until the budget is spent; the rest is PROJECTED from the blocks done after
+    the rank of S stopped growing (their cost no longer changes) and reported as such."""
+    from oracle import oracle as orc
+    import spasm_amd
+    if not orc.ref_available():
+        return None
+    cores = spasm_amd.usable_cpus()
+    orc.ref_set_threads(cores)
+    p = A.prime
+    Ao = orc.CSR(A.n, A.m, A.p, A.j, A.x, p)
+    t_begin = time.perf_counter()
+    npiv, perm, F = orc.ref_pivots_extract_structural(Ao, orc.empty_fact(A.n, A.m, p))
+    t_piv = time.perf_counter() - t_begin
+    rows = perm[npiv:]
+    Sm = A.m - F.U.n
+    ech = _ModEchelon(Sm, p)
+    per_block, ranks = [], []
+    for lo in range(0, len(rows), block):
+        t0 = time.perf_counter()
+        S, _, _ = orc.ref_schur_dense(Ao, rows[lo:lo + block], F)
+        ech.add(np.asarray(S, np.int64))
+        per_block.append(time.perf_counter() - t0)
+        ranks.append(len(ech.pivcols))
+        if time.perf_counter() - t_begin > budget_s:
+            break
+    pivcols = ech.pivcols
+    done = len(per_block)
+    total = (len(rows) + block - 1) // block
+    measured = time.perf_counter() - t_begin
+    projected = done < total
+    if projected:
+        # blocks after the last growth of the rank all cost the same (schur_dense + one product with the basis)
+        steady = [t for t, r in zip(per_block, ranks) if r == ranks[-1]][1:] or per_block[-1:]
+        seconds = measured + (total - done) * statistics.median(steady)
+    else:
+        seconds = measured
+    return {"seconds": seconds, "projected": projected, "measured_s": measured, "pivots_s": t_piv, "pivots": int(npiv),
+            "blocks_done": done, "blocks_total": total, "rank_of_S_so_far": len(pivcols), "rank": (int(npiv) + len(pivcols)) if not projected else None,
+            "cores": cores, "kind": "reference + numpy",
+            "what": "spasm_pivots_extract_structural + spasm_schur_dense per %d rows (compiled reference, %d threads) + exact numpy echelon form" % (block, cores)}
+
+
 def cpu_baseline_sampled(A, rows, F, count=2000):
     """the reference's spasm_schur on `count` rows spread evenly over the batch (the rows of a stand-in's Schur complement differ
     by orders of magnitude from one end of the batch to the other: the first rows alone would not say much)"""
@@ -361,6 +464,10 @@ def sparse_path_probe(torch, spasm_amd, workloads, dev, name="mk14.b4", steps=3,
                                   "levels": levels1, "factor_image_ms": image_ms1}
         if st1.used_sparse_image:
             out["fixed_pivot_set"]["kernels_ms"] = {"sp_build_kernel": st1.ms_sparse_build, "sp_apply_kernel": st1.ms_sparse_apply, "scan + sp_gather_kernel": st1.ms_sparse_gather}
+            out["fixed_pivot_set"]["kernels_frac"] = {k: kernel_entry(m_, b_)["frac"] for k, m_, b_ in (
+                ("sp_build_kernel", st1.ms_sparse_build, st1.bytes_sparse_build), ("sp_apply_kernel", st1.ms_sparse_apply, st1.bytes_sparse_apply),
+                ("scan + sp_gather_kernel", st1.ms_sparse_gather, st1.bytes_sparse_gather))}
+            out["fixed_pivot_set"]["step_frac"] = (st1.bytes_sparse_build + st1.bytes_sparse_apply + st1.bytes_sparse_gather) / (st1.ms_total * 1e-3) / 1e9 / HBM_PEAK_GBS
             out["fixed_pivot_set"]["build_us_per_level"] = 1e3 * st1.ms_sparse_build / max(1, st1.sparse_image_levels)
     finally:
         rows, F, drows = rows_keep, F_keep, drows_keep
@@ -442,51 +549,59 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
+    # stdout carries ONE line, the last thing this process writes: whatever else lands on descriptor 1 while the bench runs
+    # (RCCL's banner, libdrm's "amdgpu.ids" warning on some boxes, a library's printf) goes to stderr instead
+    sys.stdout.flush()
+    real_stdout = os.dup(1)
+    os.dup2(2, 1)
+
+    def emit(full):
+        """bench_full.json + stderr get everything; stdout gets the compact line (tools/bench_format.py), last"""
+        import bench_format
+        full["full_path"] = "bench_full.json"
+        text = json.dumps(full)
+        for where in (os.path.join(ROOT, "bench_full.json"), os.path.join(ROOT, "gpurun_out", "bench_full.json")):
+            try:
+                if os.path.isdir(os.path.dirname(where)):
+                    with open(where, "w") as f:
+                        f.write(text + "\n")
+            except OSError as e:
+                sys.stderr.write("bench.py: cannot write %s: %s\n" % (where, e))
+        sys.stderr.write(text + "\n")
+        sys.stderr.flush()
+        sys.stdout.flush()
+        C.CDLL(None).fflush(None)
+        os.write(real_stdout, (bench_format.line(full) + "\n").encode())
+
     if world != args.gpus and world > 1:
         raise SystemExit("--gpus %d but WORLD_SIZE=%d" % (args.gpus, world))
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     dist = None
     use_dist = world > 1 or os.environ.get("SPASM_BENCH_FORCE_DIST") == "1"   # the flag lets a 1-GPU box run the RCCL path
-    class stdout_to_stderr:
-        """RCCL prints a version banner on stdout when a communicator is created: stdout carries the one JSON line only, so
-        the banner goes to stderr (file descriptor level: it is printed by the C library)"""
-
-        def __enter__(self):
-            sys.stdout.flush()
-            self.saved = os.dup(1)
-            os.dup2(2, 1)
-
-        def __exit__(self, *exc):
-            sys.stdout.flush()
-            C.CDLL(None).fflush(None)          # the banner sits in the C library's stdio buffer when stdout is a pipe
-            os.dup2(self.saved, 1)
-            os.close(self.saved)
-
     comm = None
     if use_dist:
         import torch.distributed as dist
         from spasm_amd.dist import Comm
-        with stdout_to_stderr():
-            dist.init_process_group("nccl", device_id=dev)
-            warm = torch.zeros(1, device=dev)
-            dist.all_reduce(warm)
-            torch.cuda.synchronize()
+        dist.init_process_group("nccl", device_id=dev)
+        warm = torch.zeros(1, device=dev)
+        dist.all_reduce(warm)
+        torch.cuda.synchronize()
 
-            # the library's own RCCL communicator (C ABI, section (M)); its id travels through torch.distributed
-            def exchange(raw):
-                box = [raw]
-                dist.broadcast_object_list(box, src=0)
-                return box[0]
-            comm = Comm(rank, world, exchange)
+        # the library's own RCCL communicator (C ABI, section (M)); its id travels through torch.distributed
+        def exchange(raw):
+            box = [raw]
+            dist.broadcast_object_list(box, src=0)
+            return box[0]
+        comm = Comm(rank, world, exchange)
 
     try:
         A, rows, F, source = workloads.round0(args.workload, PRIME)
     except FileNotFoundError as e:
         if rank == 0:
-            print(json.dumps({"metric": "rows eliminated/sec (sparse Schur complement, mod 42013)", "value": None,
-                              "unit": "rows/s", "n_gpus": world, "data": "absent", "config": {"workload": args.workload},
-                              "error": str(e)}))
+            emit({"metric": "rows eliminated/sec (sparse Schur complement, mod 42013)", "value": None,
+                  "unit": "rows/s", "n_gpus": world, "data": "absent", "config": {"workload": args.workload},
+                  "error": str(e)})
         return
     from spasm_amd.dist import shard_rows, column_slab
     split = args.split
@@ -716,6 +831,9 @@ def main():
                 return spasm_amd.echelonize_profile(), int(fact.U.n)
             out["end_to_end"] = dict(_calls(call, 5), what="spasm_hip_echelonize on the same matrix, options of the config (%s), 5 calls"
                                                            % (" ".join(rank_args) or "defaults"))
+            rounds = out["end_to_end"]["split_of_median_call"].get("sparse_rounds")
+            out["config"]["note"] = ("device-API step (spasm_hip_dschur); spasm_hip_echelonize on this matrix runs %s sparse round(s)%s"
+                                     % (rounds, ": S is dense, the call goes to the dense finish (summary.end_to_end)" if rounds == 0 else ""))
             # north_star keeps the pivot selection on the host; the library runs its greedy search on the device when it has
             # one.  The same call with the search where north_star puts it:
             os.environ["SPASM_HIP_PIVOT_SEARCH"] = "host"
@@ -751,7 +869,12 @@ def main():
                           for c, status, _ in workloads.discover()]
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(A_full, rows, F_full)
-        print(json.dumps(out))
+            rt = cpu_rank_time(A_full)
+            if rt:
+                out["cpu_baseline"]["rank_time"] = rt
+                if "end_to_end" in out:
+                    out["end_to_end"]["cpu_rank_time"] = {"seconds": float("%.4g" % rt["seconds"]), "projected": rt["projected"], "cores": rt["cores"]}
+        emit(out)
     if comm is not None:
         comm.close()
     if dist is not None:

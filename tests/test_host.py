@@ -456,3 +456,70 @@ def test_matrix_market_header_is_validated(tmp_path):
     code = "import spasm_amd; spasm_amd.load(%r, 257)" % str(end)
     out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, cwd=ROOT)
     assert out.returncode != 0 and "SMS end marker" in out.stderr
+
+
+def test_bench_line_is_compact_and_carries_roofline_and_cpu_baseline():
+    """the driver parses the LAST line of bench.py's stdout from a tail it keeps: the formatter must cut a recorded full
+    result (round 5's 38 KB object, which the driver could not parse) down to a line under 12 KB that still holds the
+    contract keys, roofline.frac and cpu_baseline.value"""
+    import json
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path.insert(0, os.path.join(root, "tools"))
+    import bench_format
+    full = json.loads(open(os.path.join(root, "profiles", "r05_bench_line.json")).read().strip().splitlines()[-1])
+    assert len(json.dumps(full)) > 30000
+    # grow it the way a later round might: the line must still fit
+    full["cpu_baseline"]["rank_time"] = {"seconds": 61.2, "projected": True, "measured_s": 14.8, "pivots_s": 0.9, "cores": 16,
+                                         "what": "x" * 300}
+    full["stand_ins"] = full["stand_ins"] * 3
+    line = bench_format.line(full)
+    assert "\n" not in line
+    assert len(line) < bench_format.LINE_LIMIT == 12288
+    got = json.loads(line)
+    for key in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "dtype", "data", "config", "roofline",
+                "cpu_baseline", "factor_image_ms", "rows_per_s_cold", "higher_is_better", "scaling", "vs_baseline"):
+        assert key in got, key
+    assert got["value"] == full["value"] and got["ms_per_step"] == full["ms_per_step"]
+    assert abs(got["roofline"]["frac"] - full["roofline"]["frac"]) < 1e-5
+    assert got["roofline"]["bound"] == "hbm" and got["roofline"]["kernels"]
+    assert got["cpu_baseline"]["value"] > 0 and got["cpu_baseline"]["rank_time"]["seconds"] == 61.2
+    assert "workload" in got["config"] and all(len(v) <= 100 for v in got["config"].values() if isinstance(v, str))
+    # an error object (data file absent) is a valid line too
+    err = json.loads(bench_format.line({"metric": "m", "value": None, "unit": "rows/s", "n_gpus": 1, "data": "absent",
+                                        "config": {"workload": "GL7d19"}, "error": "no such file"}))
+    assert err["value"] is None and err["error"] == "no such file"
+
+
+def test_bench_prints_its_line_last_on_stdout_and_nothing_else(tmp_path):
+    """bench.py sends everything else that reaches descriptor 1 to stderr: run its emit path in a child process whose C library
+    also writes to stdout, and look at what the pipe holds"""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = r'''
+import ctypes, json, os, sys
+sys.path.insert(0, %r); sys.path.insert(0, os.path.join(%r, "tools"))
+sys.argv = ["bench.py", "--workload", "no_such_config_file", "--gpus", "1"]
+import types
+torch = types.ModuleType("torch")
+class _Cuda:
+    def set_device(self, d): ctypes.CDLL(None).puts(b"a library prints to stdout")
+torch.cuda = _Cuda(); torch.device = lambda *a: None
+sys.modules["torch"] = torch
+import workloads
+def _absent(*a, **k): raise FileNotFoundError("GL7d19.sms is absent")
+workloads.round0 = _absent
+import bench
+bench.ROOT = %r
+bench.main()
+''' % (root, root, str(tmp_path))
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.strip()]
+    assert len(lines) == 1, r.stdout
+    got = json.loads(lines[-1])
+    assert got["data"] == "absent" and "absent" in got["error"]
+    assert "a library prints to stdout" in r.stderr
+    assert json.loads(open(os.path.join(str(tmp_path), "bench_full.json")).read())["error"]
