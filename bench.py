@@ -93,7 +93,7 @@ def cpu_baseline(A, rows, F, budget_s=20.0):
 
 class _ModEchelon:
     """reduced row echelon basis mod p of the rows handed to add(), exact, in float64 (residues < 2^16: products summed over
-    <= 64 terms at a time stay far below 2^53) -- the stand-in for FFPACK in cpu_rank_time: panels of 64 rows are reduced row
+    <= 2^20 terms at a time stay below 2^53) -- the stand-in for FFPACK in cpu_rank_time: panels of 64 rows are reduced row
     by row, everything else is matrix products (numpy's BLAS, the threads of the box)."""
 
     def __init__(self, m, p):
@@ -107,9 +107,9 @@ class _ModEchelon:
         return Y
 
     def _minus_product(self, Y, Cf, B):
-        """Y -= Cf @ B mod p, 64 columns of Cf at a time (sums of 64 products of residues: < 2^38)"""
-        for k0 in range(0, Cf.shape[1], 64):
-            Y -= Cf[:, k0:k0 + 64] @ B[k0:k0 + 64]
+        """Y -= Cf @ B mod p, 2^20 columns of Cf at a time (sums of 2^20 products of residues < 2^16: < 2^52)"""
+        for k0 in range(0, Cf.shape[1], 1 << 20):
+            Y -= Cf[:, k0:k0 + (1 << 20)] @ B[k0:k0 + (1 << 20)]
             self._mod(Y)
 
     def add(self, S):
@@ -146,7 +146,7 @@ class _ModEchelon:
             Y = rest[np.any(rest != 0, axis=1)] if rest.shape[0] else rest
 
 
-def cpu_rank_time(A, budget_s=14.0, block=2048):
+def cpu_rank_time(A, budget_s=20.0, block=2048):
     """The second half of the metric on the host cores: wall-clock time of a rank computation the way the reference does it
     (tools/rank.c:76-104 -> spasm_echelonize, spasm_echelonize.c:473).  spasm_echelonize.c itself cannot be compiled here (FFPACK),
     so the time is composed from the compiled reference's own pieces on the CPUs the box grants: spasm_pivots_extract_structural
@@ -184,11 +184,12 @@ def cpu_rank_time(A, budget_s=14.0, block=2048):
     projected = done < total
     if projected:
         # blocks after the last growth of the rank all cost the same (schur_dense + one product with the basis)
-        steady = [t for t, r in zip(per_block, ranks) if r == ranks[-1]][1:] or per_block[-1:]
-        seconds = measured + (total - done) * statistics.median(steady)
+        steady = [t for t, r in zip(per_block, ranks) if r == ranks[-1]][1:]
+        settled = len(steady) >= 2
+        seconds = measured + (total - done) * statistics.median(steady or per_block[-1:])
     else:
-        seconds = measured
-    return {"seconds": seconds, "projected": projected, "measured_s": measured, "pivots_s": t_piv, "pivots": int(npiv),
+        seconds, settled = measured, True
+    return {"seconds": seconds, "projected": projected, "upper_bound": not settled, "measured_s": measured, "pivots_s": t_piv, "pivots": int(npiv),
             "blocks_done": done, "blocks_total": total, "rank_of_S_so_far": len(pivcols), "rank": (int(npiv) + len(pivcols)) if not projected else None,
             "cores": cores, "kind": "reference + numpy",
             "what": "spasm_pivots_extract_structural + spasm_schur_dense per %d rows (compiled reference, %d threads) + exact numpy echelon form" % (block, cores)}
