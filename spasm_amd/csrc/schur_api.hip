@@ -50,6 +50,7 @@ bool sparse_image_planned(const spasm_hip_dfact *F, hipStream_t stream);
 bool sparse_image_plan_expected(const spasm_hip_dfact *F);
 void sparse_image_free(spasm_hip_dfact *F);
 bool sparse_image_build(const spasm_hip_dfact *F, hipStream_t stream);
+int64_t sparse_image_table_words(int64_t nrows, int nseg);
 void launch_sparse_image_apply(const SchurArgs &a, const spasm_hip_dfact *F, uint32_t *fpool, uint32_t *fpool_v, int64_t fcap,
                                uint64_t *T, unsigned long long *block_sum, int64_t *Sp, int *Sj, int *Sx, int64_t cap, hipStream_t stream,
                                hipEvent_t ev_gather);
@@ -1793,7 +1794,7 @@ int dschur_impl(const spasm_hip_dcsr *A, const int *d_rows, int nrows, const spa
 		a.list_count = nullptr;
 		a.done_ctr = CTR_DONE2;
 		bs_direct = true;          // rows land in W->d_Sj / d_Sx in their final order: no gather pass from the pool
-		const i64 twords = (i64) nrows * F->sp.nseg;
+		const i64 twords = sparse_image_table_words(nrows, F->sp.nseg);
 		if (W->spT_words < twords) {
 			if (W->d_spT != nullptr)
 				sh::big_free(W->d_spT);

@@ -47,7 +47,11 @@ __device__ __forceinline__ void sgn_mad(uint32_t w, int c, int &lo, int &hi)
 __device__ __forceinline__ int sgn_reduce(int t, const SgnDev &G)
 {
 	const int q = (int) __builtin_rintf((float) t * G.invp);
-	return t + __mul24(q, G.negp);
+	// q * (-p) + t in ONE full-rate instruction (|q| <= |t| / p + 1 < 2^17, p < 2^16: both fit 24 bits).  Written out: left to
+	// itself the compiler took v_mad_u64_u32 for `t + __mul24(q, negp)` in sparse_image.hip -- a quarter-rate instruction.
+	int r;
+	asm("v_mad_i32_i24 %0, %1, %2, %3" : "=v"(r) : "v"(q), "v"(G.negp), "v"(t));
+	return r;
 }
 
 __device__ __forceinline__ uint32_t sgn_pack(int lo, int hi)

@@ -67,11 +67,6 @@ template <typename T> void upload(T *dst, const std::vector<T> &src, hipStream_t
 		sh::h2d(dst, src.data(), src.size() * sizeof(T), s);
 }
 
-__device__ __forceinline__ const uint32_t *frag_ptr(const SpPools &P, uint64_t f)
-{
-	return P.base[(f >> (SP_LEN_BITS + SP_OFF_BITS)) & 15u] + ((f >> SP_LEN_BITS) & OFF_MASK);
-}
-
 // A value every lane holds alike, told to the compiler: branches on it are scalar branches.  (Without this the loop
 // of the single-launch driver -- whose exits hang on values loaded per lane from uniform addresses -- was compiled into
 // exec-masked loops in which lane 0, the lane that publishes, left on its own: tasks were redone for ever and nothing was
@@ -184,55 +179,55 @@ struct SpStamp {
 	}
 };
 
-// ---- a wave's LDS: the accumulators of one segment + one bit per column that was touched ----------
-// Columns are stored SWIZZLED: the emit pass gives lane L the columns [128 L, 128 L + 128) (so that what the lanes write,
-// lane after lane, is sorted by column), and unswizzled those 64 chunks of 256 bytes would all start on the same bank; word
-// w = column / 2 of chunk L = w / 64 lives at position (w + L) mod 64 of its chunk.
+// ---- a wave's LDS: the accumulators of one segment, one bit per column that was touched, and the list of those columns ----------
+// Round 6.  The kernels of the sparse image are bound by the vector instructions they issue per (row, segment) pair (SQ counters of
+// round 5: 262 of them, the vector unit busy 56 % of the time, half of it finding out WHICH columns a segment touched: a scan of
+// the bitmap, a loop per lane over the bits of its words -- the fill is clustered, so one lane walked 14 bits on average while
+// most lanes had none -- and a second pass over the list).  Now:
+//   * the FIRST visitor of a column lists it: the atomic OR that marks the column returns the old word, a ballot of the lanes
+//     that set a new bit gives every new column its place in the list (unsorted, each column once, no imbalance);
+//   * sorted output without sorting: the rank of column c among the touched columns is prefix[word of c] + popcount(bits of
+//     that word below c) -- the prefixes come from ONE packed scan of the bitmap's popcounts and stay in registers (a lane
+//     fetches the one it needs with ds_bpermute).  Columns whose sum came back to zero (common: boundary maps) are taken out of
+//     the bitmap by a first pass over the list, so the ranks have no holes;
+//   * no swizzle of the accumulators (it served the lane-by-lane walk of dense segments, which now goes 64 consecutive
+//     columns at a time -- conflict-free as it stands).
+// Segments that touch more than LISTCAP columns take that 64-columns-at-a-time walk over the bitmap.
 constexpr int BMW = SP_SEG / 32;          // bitmap words
 constexpr int WPL = BMW / 64;             // bitmap words per lane (2 or 4)
-constexpr int CW = SEGW / 64;             // accumulator words of the columns one lane owns in the lane-by-lane walk
 static_assert(WPL == 2 || WPL == 4, "segments of 4,096 or 8,192 columns");
-// The list of touched columns (sp_touched) stands IN the bitmap's words -- the bitmap is in registers by the time the list is
-// written, and is zeroed again once the list has been emitted -- plus LIST_EXTRA entries behind them (round 5: with a list of
-// its own, 2 KB, a wave took 10.75 KB and a CU held 14 of them; the kernels are bound by the waves in flight -- 10, 12, 14
-// waves per CU: 39.6, 34.3, 30.5 ms for the rows of S of mk15.b4).  448 extra entries: 9,600 bytes per wave, seventeen waves per CU
-// (192 -- eighteen by the arithmetic -- ran no faster, and the denser Schur complements of the sequential search's pivots, where
-// more segments outgrow the list, lost 5 %; 832 -- sixteen waves -- cost 10 % on mk15.b4).
-#ifndef SPASM_SP_LIST_EXTRA
-#define SPASM_SP_LIST_EXTRA 448
+#ifndef SPASM_SP_LISTCAP
+#define SPASM_SP_LISTCAP 464              // 8,192 + 512 + 928 bytes per wave: seventeen waves per CU
 #endif
-constexpr int LIST_EXTRA = SPASM_SP_LIST_EXTRA;
-constexpr int LISTCAP = 2 * BMW + LIST_EXTRA;          // touched columns a segment may have for the balanced emit (more: the lane-by-lane one)
+constexpr int LISTCAP = SPASM_SP_LISTCAP;
 struct __attribute__((aligned(16))) WaveLds {
-	uint32_t acc[SEGW];
+	uint32_t acc[SEGW];               // 16-bit accumulators, two per word, column c at halfword c
 	uint32_t bm[BMW];
-	uint16_t list_extra[LIST_EXTRA > 0 ? LIST_EXTRA : 1];
+	uint16_t list[LISTCAP];
+};
+// every odd prime below 2^32 (round 5): 32-bit accumulators, 8-byte fragment entries (column, plain residue in [0, p)),
+// coefficients in Montgomery form (c * 2^32 mod p: one montmul per multiply-add).  16 KB + 512 + 928 bytes: nine waves per CU.
+struct __attribute__((aligned(16))) WaveLds32 {
+	uint32_t acc[SP_SEG];
+	uint32_t bm[BMW];
+	uint16_t list[LISTCAP];
 };
 
-template <typename LDS> __device__ __forceinline__ uint16_t *sp_list(LDS &L) { return reinterpret_cast<uint16_t *>(L.bm); }
-
-template <typename LDS> __device__ __forceinline__ void sp_bm_clear(LDS &L, int lane)
+template <typename LDS> __device__ __forceinline__ void sp_lds_init(LDS &L, int lane)
 {
+	uint4 *a4 = reinterpret_cast<uint4 *>(L.acc);
+#pragma unroll
+	for (int t = 0; t < (int) (sizeof(L.acc) / 16 / 64); t++)
+		a4[t * 64 + lane] = uint4{0u, 0u, 0u, 0u};
 #pragma unroll
 	for (int t = 0; t < WPL; t++)
 		L.bm[64 * t + lane] = 0;
 }
 
-__device__ __forceinline__ uint32_t sp_swz(uint32_t c)          // column of the segment -> index of its 16-bit accumulator
-{
-	const uint32_t w = c >> 1;
-	return ((((w & ~(uint32_t) (CW - 1)) | ((w + (w / CW)) & (uint32_t) (CW - 1))) << 1) | (c & 1u));
-}
-
-__device__ __forceinline__ void sp_lds_init(WaveLds &L, int lane)
-{
-	uint4 *a4 = reinterpret_cast<uint4 *>(L.acc);
-#pragma unroll
-	for (int t = 0; t < SEGW / 4 / 64; t++)
-		a4[t * 64 + lane] = uint4{0u, 0u, 0u, 0u};
-	for (int t = lane; t < BMW; t += 64)
-		L.bm[t] = 0;
-}
+__device__ __forceinline__ int sp_acc_get(WaveLds &L, uint32_t c) { return (int) reinterpret_cast<short *>(L.acc)[c]; }
+__device__ __forceinline__ void sp_acc_zero(WaveLds &L, uint32_t c) { reinterpret_cast<short *>(L.acc)[c] = 0; }
+__device__ __forceinline__ uint32_t sp_acc_get(WaveLds32 &L, uint32_t c) { return L.acc[c]; }
+__device__ __forceinline__ void sp_acc_zero(WaveLds32 &L, uint32_t c) { L.acc[c] = 0; }
 
 template <bool SC1> __device__ __forceinline__ uint32_t sp_ld(const uint32_t *p)
 {
@@ -248,126 +243,6 @@ template <bool SC1> __device__ __forceinline__ void sp_st(uint32_t *p, uint32_t 
 		__hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);             // (write-through)
 	else
 		*p = v;
-}
-
-// acc[column] += coef * value for one entry (column | value << 16); the sum is reduced at once; the column is marked
-__device__ __forceinline__ void sp_entry(WaveLds &L, uint32_t e, int coef, const SgnDev &G)
-{
-	const uint32_t c = e & 0xFFFFu;
-	short *a = reinterpret_cast<short *>(L.acc) + sp_swz(c);
-	int t = (int) *a;
-	asm("v_mad_i32_i16 %0, %1, %2, %0 op_sel:[1,0,0,0]" : "+v"(t) : "v"(e), "v"(coef));
-	*a = (short) sgn_reduce(t, G);
-	atomicOr(&L.bm[c >> 5], 1u << (c & 31u));
-}
-
-// four entries of ONE fragment (distinct columns): the four reads are in flight together
-__device__ __forceinline__ void sp_entry4(WaveLds &L, uint32_t e0, uint32_t e1, uint32_t e2, uint32_t e3, int coef, const SgnDev &G)
-{
-	short *acc = reinterpret_cast<short *>(L.acc);
-	const uint32_t c0 = e0 & 0xFFFFu, c1 = e1 & 0xFFFFu, c2 = e2 & 0xFFFFu, c3 = e3 & 0xFFFFu;
-	short *a0 = acc + sp_swz(c0), *a1 = acc + sp_swz(c1), *a2 = acc + sp_swz(c2), *a3 = acc + sp_swz(c3);
-	int t0 = (int) *a0, t1 = (int) *a1, t2 = (int) *a2, t3 = (int) *a3;
-	asm("v_mad_i32_i16 %0, %1, %2, %0 op_sel:[1,0,0,0]" : "+v"(t0) : "v"(e0), "v"(coef));
-	asm("v_mad_i32_i16 %0, %1, %2, %0 op_sel:[1,0,0,0]" : "+v"(t1) : "v"(e1), "v"(coef));
-	asm("v_mad_i32_i16 %0, %1, %2, %0 op_sel:[1,0,0,0]" : "+v"(t2) : "v"(e2), "v"(coef));
-	asm("v_mad_i32_i16 %0, %1, %2, %0 op_sel:[1,0,0,0]" : "+v"(t3) : "v"(e3), "v"(coef));
-	*a0 = (short) sgn_reduce(t0, G);
-	*a1 = (short) sgn_reduce(t1, G);
-	*a2 = (short) sgn_reduce(t2, G);
-	*a3 = (short) sgn_reduce(t3, G);
-	atomicOr(&L.bm[c0 >> 5], 1u << (c0 & 31u));
-	atomicOr(&L.bm[c1 >> 5], 1u << (c1 & 31u));
-	atomicOr(&L.bm[c2 >> 5], 1u << (c2 & 31u));
-	atomicOr(&L.bm[c3 >> 5], 1u << (c3 & 31u));
-}
-
-// acc[column] += value (an entry of the row itself); value in [-p/2, p/2]
-__device__ __forceinline__ void sp_own_entry(WaveLds &L, uint32_t c, int val, const SgnDev &G)
-{
-	short *a = reinterpret_cast<short *>(L.acc) + sp_swz(c);
-	*a = (short) sgn_canonical((int) *a + val, G);
-	atomicOr(&L.bm[c >> 5], 1u << (c & 31u));
-}
-
-// acc += coef * fragment, for every lane whose fragment word f is not empty and for which `take` holds (wave-uniform loop
-// over those lanes).  Four fragments at a time: the first 64 entries of all four are in flight together (a reduced row
-// combines 3-5 rows of R per segment, each 1-3 batches long: the stage is the latency of these loads).
-// (A version that kept the four heads in a struct across calls -- to fetch the next segment's fragments before the current
-//  segment is emitted -- computed wrong sums on rows with more than four fragments (tests: mat364 mod 3) although it reads
-//  the same; it bought nothing measurable and is gone.  Loops with divergent tails followed by lane-crossing operations are
-//  kept in this one shape, which the tests pin.)
-template <bool SC1>
-__device__ __forceinline__ void sp_accumulate(WaveLds &L, uint64_t f, int coef, bool take, const SpPools &pools, int lane, const SgnDev &G,
-                                              unsigned long long &ops)
-{
-	uint64_t live = __ballot(take && (f & LEN_MASK) != 0);
-	while (live != 0) {
-		const uint32_t *src[4];
-		int len[4], cf[4];
-		uint32_t head[4];
-#pragma unroll
-		for (int u = 0; u < 4; u++) {
-			len[u] = 0;
-			cf[u] = 0;
-			src[u] = nullptr;
-			head[u] = 0;
-			if (live != 0) {
-				const int s = __builtin_ctzll(live);
-				live &= live - 1;
-				const uint64_t fc = readlane64(f, s);
-				cf[u] = __builtin_amdgcn_readlane(coef, s);
-				src[u] = frag_ptr(pools, fc);
-				len[u] = (int) (fc & LEN_MASK);
-				head[u] = (lane < len[u]) ? sp_ld<SC1>(src[u] + lane) : 0u;
-			}
-		}
-#pragma unroll
-		for (int u = 0; u < 4; u++) {
-			if (len[u] == 0)
-				continue;
-			ops += (unsigned long long) len[u];
-			if (lane < len[u])
-				sp_entry(L, head[u], cf[u], G);
-			int i = lane + 64;
-			for (; i + 192 < len[u]; i += 256) {
-				const uint32_t a0 = sp_ld<SC1>(src[u] + i), a1 = sp_ld<SC1>(src[u] + i + 64), a2 = sp_ld<SC1>(src[u] + i + 128),
-				               a3 = sp_ld<SC1>(src[u] + i + 192);
-				sp_entry4(L, a0, a1, a2, a3, cf[u], G);
-			}
-			for (; i < len[u]; i += 64)
-				sp_entry(L, sp_ld<SC1>(src[u] + i), cf[u], G);
-			__builtin_amdgcn_wave_barrier();          // (the lanes meet again before the next fragment touches the same columns)
-		}
-	}
-}
-
-// ---- the same for EVERY odd prime below 2^32 (round 5): 32-bit accumulators, 8-byte fragment entries -------------------------------
-// The signed 16-bit arithmetic above stops at p = 44,927; the reference takes every prime below 2^32 (spasm_ZZp.c:5-15; its own
-// tests run 65537, 67108859, 189812507, 4294967291), and a GL7d19-class factor with such a prime had no image at all (the dense
-// one is out of reach by size): minutes in the row-group kernel.  Same segments, same fragments, same drivers; what changes is
-// what an entry is: (column inside the segment, plain residue in [0, p)) in 8 bytes, accumulators of 32 bits (16 KB of LDS per
-// wave instead of 8: nine waves per CU instead of seventeen), coefficients in Montgomery form (c * 2^32 mod p: one montmul per
-// multiply-add, exact for every odd p < 2^32).  Fragments of S: columns and values in two arrays (the row pool of the workspace
-// is two arrays of 32-bit words).
-struct __attribute__((aligned(16))) WaveLds32 {
-	uint32_t acc[SP_SEG];
-	uint32_t bm[BMW];
-	uint16_t list_extra[LIST_EXTRA > 0 ? LIST_EXTRA : 1];
-};
-
-// column of the segment -> index of its accumulator: lane L of the lane-by-lane walk owns the 64 columns [64 L, 64 L + 64),
-// whose words would all start on the same bank: rotated by L inside the chunk
-__device__ __forceinline__ uint32_t sp_swz32(uint32_t c) { return (c & ~63u) | ((c + (c >> 6)) & 63u); }
-
-__device__ __forceinline__ void sp_lds_init(WaveLds32 &L, int lane)
-{
-	uint4 *a4 = reinterpret_cast<uint4 *>(L.acc);
-#pragma unroll
-	for (int t = 0; t < SP_SEG / 4 / 64; t++)
-		a4[t * 64 + lane] = uint4{0u, 0u, 0u, 0u};
-	for (int t = lane; t < BMW; t += 64)
-		L.bm[t] = 0;
 }
 
 template <bool SC1> __device__ __forceinline__ uint64_t sp_ld64(const uint64_t *p)
@@ -386,6 +261,92 @@ template <bool SC1> __device__ __forceinline__ void sp_st64(uint64_t *p, uint64_
 		*p = v;
 }
 
+// Column c is touched (lanes with `act`; the columns of the active lanes are distinct): its bit is set, and the lanes that set a
+// NEW bit list their columns -- nl counts the touched columns of the segment so far (wave-uniform; beyond LISTCAP the list is
+// no longer written and the segment will be walked from the bitmap).  All 64 lanes come here.
+template <typename LDS> __device__ __forceinline__ void sp_mark(LDS &L, uint32_t c, bool act, uint32_t &nl)
+{
+	const uint32_t bit = 1u << (c & 31u);
+	uint32_t old = bit;
+	if (act)
+		old = atomicOr(&L.bm[c >> 5], bit);
+	const bool first = (old & bit) == 0;
+	const uint64_t firsts = __ballot(first);
+	const uint32_t pos = __builtin_amdgcn_mbcnt_hi((uint32_t) (firsts >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t) firsts, nl));
+	if (first && pos < (uint32_t) LISTCAP)
+		L.list[pos] = (uint16_t) c;
+	nl += (uint32_t) __popcll(firsts);
+}
+
+// the second half of sp_mark for a lane that already holds the old word of its column's bit
+template <typename LDS> __device__ __forceinline__ void sp_list_new(LDS &L, uint32_t c, uint32_t old, uint32_t bit, uint32_t &nl)
+{
+	const bool first = (old & bit) == 0;
+	const uint64_t firsts = __ballot(first);
+	const uint32_t pos = __builtin_amdgcn_mbcnt_hi((uint32_t) (firsts >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t) firsts, nl));
+	if (first && pos < (uint32_t) LISTCAP)
+		L.list[pos] = (uint16_t) c;
+	nl += (uint32_t) __popcll(firsts);
+}
+
+// acc[column] += coef * value for one entry (column | value << 16) per active lane; the sum is reduced at once.  The read of the
+// accumulator and the atomic OR on the bitmap leave together: one trip to the LDS per batch, not two.
+__device__ __forceinline__ void sp_entry(WaveLds &L, uint32_t e, int coef, bool act, const SgnDev &G, uint32_t &nl)
+{
+	const uint32_t c = e & 0xFFFFu;
+	const uint32_t bit = 1u << (c & 31u);
+	short *a = reinterpret_cast<short *>(L.acc) + c;
+	uint32_t old = bit;
+	int t = 0;
+	if (act) {
+		t = (int) *a;
+		old = atomicOr(&L.bm[c >> 5], bit);
+	}
+	asm("v_mad_i32_i16 %0, %1, %2, %0 op_sel:[1,0,0,0]" : "+v"(t) : "v"(e), "v"(coef));
+	t = sgn_reduce(t, G);
+	if (act)
+		*a = (short) t;
+	sp_list_new(L, c, old, bit, nl);
+}
+
+// two batches of ONE fragment (distinct columns): four LDS reads in flight
+__device__ __forceinline__ void sp_entry2(WaveLds &L, uint32_t e0, uint32_t e1, int coef, bool act0, bool act1, const SgnDev &G, uint32_t &nl)
+{
+	const uint32_t c0 = e0 & 0xFFFFu, c1 = e1 & 0xFFFFu;
+	const uint32_t bit0 = 1u << (c0 & 31u), bit1 = 1u << (c1 & 31u);
+	short *acc = reinterpret_cast<short *>(L.acc);
+	uint32_t old0 = bit0, old1 = bit1;
+	int t0 = 0, t1 = 0;
+	if (act0) {
+		t0 = (int) acc[c0];
+		old0 = atomicOr(&L.bm[c0 >> 5], bit0);
+	}
+	if (act1) {
+		t1 = (int) acc[c1];
+		old1 = atomicOr(&L.bm[c1 >> 5], bit1);
+	}
+	asm("v_mad_i32_i16 %0, %1, %2, %0 op_sel:[1,0,0,0]" : "+v"(t0) : "v"(e0), "v"(coef));
+	asm("v_mad_i32_i16 %0, %1, %2, %0 op_sel:[1,0,0,0]" : "+v"(t1) : "v"(e1), "v"(coef));
+	t0 = sgn_reduce(t0, G);
+	t1 = sgn_reduce(t1, G);
+	if (act0)
+		acc[c0] = (short) t0;
+	if (act1)
+		acc[c1] = (short) t1;
+	sp_list_new(L, c0, old0, bit0, nl);
+	sp_list_new(L, c1, old1, bit1, nl);
+}
+
+// acc[column] += value (an entry of the row itself); value in [-p/2, p/2]
+__device__ __forceinline__ void sp_own_entry(WaveLds &L, uint32_t c, int val, bool act, const SgnDev &G, uint32_t &nl)
+{
+	if (act) {
+		short *a = reinterpret_cast<short *>(L.acc) + c;
+		*a = (short) sgn_canonical((int) *a + val, G);
+	}
+	sp_mark(L, act ? c : 0u, act, nl);
+}
+
 __device__ __forceinline__ uint32_t sp_addmod(uint32_t a, uint32_t b, uint32_t p)          // a, b in [0, p), any p < 2^32
 {
 	uint32_t s = a + b;
@@ -394,67 +355,188 @@ __device__ __forceinline__ uint32_t sp_addmod(uint32_t a, uint32_t b, uint32_t p
 	return s;
 }
 
-// acc[column] += coef * value for one entry (column | value << 32), coef in Montgomery form
-__device__ __forceinline__ void sp_entry(WaveLds32 &L, uint64_t e, uint32_t coef, const MontDev &F)
+// the 32-bit variant: acc[column] += coef * value for one entry (column | value << 32), coef in Montgomery form
+__device__ __forceinline__ void sp_entry(WaveLds32 &L, uint64_t e, uint32_t coef, bool act, const MontDev &F, uint32_t &nl)
 {
 	const uint32_t c = (uint32_t) e & 0xFFFFu;
-	uint32_t *a = L.acc + sp_swz32(c);
-	*a = sp_addmod(*a, montmul(coef, (uint32_t) (e >> 32), F), F.p);
-	atomicOr(&L.bm[c >> 5], 1u << (c & 31u));
+	if (act) {
+		uint32_t *a = L.acc + c;
+		*a = sp_addmod(*a, montmul(coef, (uint32_t) (e >> 32), F), F.p);
+	}
+	sp_mark(L, c, act, nl);
 }
 
-__device__ __forceinline__ void sp_own_entry(WaveLds32 &L, uint32_t c, uint32_t val, const MontDev &F)
+__device__ __forceinline__ void sp_entry2(WaveLds32 &L, uint64_t e0, uint64_t e1, uint32_t coef, bool act0, bool act1, const MontDev &F, uint32_t &nl)
 {
-	uint32_t *a = L.acc + sp_swz32(c);
-	*a = sp_addmod(*a, val, F.p);
-	atomicOr(&L.bm[c >> 5], 1u << (c & 31u));
+	sp_entry(L, e0, coef, act0, F, nl);
+	sp_entry(L, e1, coef, act1, F, nl);
 }
+
+__device__ __forceinline__ void sp_own_entry(WaveLds32 &L, uint32_t c, uint32_t val, bool act, const MontDev &F, uint32_t &nl)
+{
+	if (act) {
+		uint32_t *a = L.acc + c;
+		*a = sp_addmod(*a, val, F.p);
+	}
+	sp_mark(L, act ? c : 0u, act, nl);
+}
+
+// where a fragment lies: chunk 0 of the pool (the only one unless a build ran out of room) is a kernel argument in scalar
+// registers; the table of the other chunks is only read for fragments that live there
+__device__ __forceinline__ const uint32_t *frag_base(const SpPools &P, uint64_t f)
+{
+	const uint32_t k = (uint32_t) (f >> (SP_LEN_BITS + SP_OFF_BITS)) & 15u;
+	const uint32_t *b = P.base[0];
+	if (k != 0)
+		b = P.base[k];
+	return b;
+}
+
+__device__ __forceinline__ const uint32_t *frag_ptr(const SpPools &P, uint64_t f) { return frag_base(P, f) + ((f >> SP_LEN_BITS) & OFF_MASK); }
 
 __device__ __forceinline__ const uint64_t *frag_ptr64(const SpPools &P, uint64_t f)
 {
-	return reinterpret_cast<const uint64_t *>(P.base[(f >> (SP_LEN_BITS + SP_OFF_BITS)) & 15u]) + ((f >> SP_LEN_BITS) & OFF_MASK);
+	return reinterpret_cast<const uint64_t *>(frag_base(P, f)) + ((f >> SP_LEN_BITS) & OFF_MASK);
 }
 
-// acc += coef * fragment for every lane whose fragment word is not empty and for which `take` holds: the shape of
-// sp_accumulate above (four fragments' first 64 entries in flight together), 8-byte entries
-template <bool SC1>
-__device__ __forceinline__ void sp_accumulate(WaveLds32 &L, uint64_t f, uint32_t coef, bool take, const SpPools &pools, int lane, const MontDev &F,
-                                              unsigned long long &ops)
+template <typename ENT, bool SC1> __device__ __forceinline__ ENT sp_ldent(const ENT *p)
 {
-	uint64_t live = __ballot(take && (f & LEN_MASK) != 0);
+	if constexpr (sizeof(ENT) == 8)
+		return sp_ld64<SC1>(p);
+	else
+		return sp_ld<SC1>(p);
+}
+
+template <typename ENT> __device__ __forceinline__ const ENT *frag_ptr_as(const SpPools &P, uint64_t f)
+{
+	return reinterpret_cast<const ENT *>(frag_base(P, f)) + ((f >> SP_LEN_BITS) & OFF_MASK);
+}
+
+// acc += coef * fragment for the lanes of `live` (their fragment words f are not empty): a wave-uniform loop over those lanes.
+// Four fragments at a time: the first 128 entries of all four are in flight together (a reduced row combines 3-5 rows of R per
+// segment, each 1-3 batches long: the stage is the latency of these loads).
+// ENT: uint32_t (column | signed 16-bit value << 16) with LDS = WaveLds, COEF = int, FLD = SgnDev; uint64_t (column | residue << 32)
+// with WaveLds32, uint32_t (Montgomery form), MontDev.
+template <bool SC1, typename ENT, typename LDS, typename COEF, typename FLD>
+__device__ __forceinline__ void sp_accumulate_live(LDS &L, uint64_t live, uint64_t f, COEF coef, const SpPools &pools, int lane, const FLD &G,
+                                                   unsigned long long &ops, uint32_t &nl)
+{
 	while (live != 0) {
-		const uint64_t *src[4];
+		const ENT *src[4];
 		int len[4];
-		uint32_t cf[4];
-		uint64_t head[4];
+		COEF cf[4];
+		ENT h0[4], h1[4];
 #pragma unroll
 		for (int u = 0; u < 4; u++) {
 			len[u] = 0;
 			cf[u] = 0;
-			src[u] = nullptr;
-			head[u] = 0;
+			src[u] = reinterpret_cast<const ENT *>(pools.base[0]);
 			if (live != 0) {
 				const int s = __builtin_ctzll(live);
 				live &= live - 1;
 				const uint64_t fc = readlane64(f, s);
-				cf[u] = (uint32_t) __builtin_amdgcn_readlane((int) coef, s);
-				src[u] = frag_ptr64(pools, fc);
+				cf[u] = (COEF) __builtin_amdgcn_readlane((int) coef, s);
+				src[u] = frag_ptr_as<ENT>(pools, fc);
 				len[u] = (int) (fc & LEN_MASK);
-				head[u] = (lane < len[u]) ? sp_ld64<SC1>(src[u] + lane) : 0ull;
 			}
+			// (no branch around the loads: a lane without an entry reads the first word of its fragment, or of the pool)
+			h0[u] = sp_ldent<ENT, SC1>(src[u] + (lane < len[u] ? lane : 0));
+			h1[u] = sp_ldent<ENT, SC1>(src[u] + (lane + 64 < len[u] ? lane + 64 : 0));
 		}
 #pragma unroll
 		for (int u = 0; u < 4; u++) {
 			if (len[u] == 0)
 				continue;
 			ops += (unsigned long long) len[u];
-			if (lane < len[u])
-				sp_entry(L, head[u], cf[u], F);
-			for (int i = lane + 64; i < len[u]; i += 64)
-				sp_entry(L, sp_ld64<SC1>(src[u] + i), cf[u], F);
-			__builtin_amdgcn_wave_barrier();
+			if (len[u] > 64)
+				sp_entry2(L, h0[u], h1[u], cf[u], lane < len[u], lane + 64 < len[u], G, nl);
+			else
+				sp_entry(L, h0[u], cf[u], lane < len[u], G, nl);
+			for (int i0 = 128; i0 < len[u]; i0 += 128) {
+				const bool a0 = i0 + lane < len[u], a1 = i0 + 64 + lane < len[u];
+				const ENT e0 = sp_ldent<ENT, SC1>(src[u] + (a0 ? i0 + lane : 0)), e1 = sp_ldent<ENT, SC1>(src[u] + (a1 ? i0 + 64 + lane : 0));
+				sp_entry2(L, e0, e1, cf[u], a0, a1, G, nl);
+			}
 		}
 	}
+}
+
+template <bool SC1>
+__device__ __forceinline__ void sp_accumulate(WaveLds &L, uint64_t f, int coef, bool take, const SpPools &pools, int lane, const SgnDev &G,
+                                              unsigned long long &ops, uint32_t &nl)
+{
+	sp_accumulate_live<SC1, uint32_t>(L, __ballot(take && (f & LEN_MASK) != 0), f, coef, pools, lane, G, ops, nl);
+}
+
+template <bool SC1>
+__device__ __forceinline__ void sp_accumulate(WaveLds32 &L, uint64_t f, uint32_t coef, bool take, const SpPools &pools, int lane, const MontDev &F,
+                                              unsigned long long &ops, uint32_t &nl)
+{
+	sp_accumulate_live<SC1, uint64_t>(L, __ballot(take && (f & LEN_MASK) != 0), f, coef, pools, lane, F, ops, nl);
+}
+
+// The first four fragments of a (row, segment) pair, fetched AHEAD: sp_apply_kernel issues the loads of segment g + 1 before it
+// adds up and emits segment g (the fragment words of g + 1 are in registers by then), so that the latency of these loads -- what
+// the wave spent most of its "adding" time waiting for -- runs beside the LDS work of the segment before.  Every group issues
+// its eight loads whether or not there are fragments for them (an absent one reads the first word of the pool): the wait counts
+// are static.  Lanes whose fragments did not fit (a row combining more than four rows of R in one segment) are left in `rest`
+// for sp_accumulate_live.
+template <typename ENT, typename COEF> struct SpGroup {
+	ENT h0[4], h1[4];
+	const ENT *src[4];
+	int len[4];
+	COEF cf[4];
+	uint64_t rest;
+};
+
+template <typename ENT, typename COEF>
+__device__ __forceinline__ void sp_group_issue(SpGroup<ENT, COEF> &Q, uint64_t f, COEF coef, bool take, const SpPools &pools, int lane)
+{
+	uint64_t live = __ballot(take && (f & LEN_MASK) != 0);
+#pragma unroll
+	for (int u = 0; u < 4; u++) {
+		int len = 0;
+		COEF cf = 0;
+		const ENT *src = reinterpret_cast<const ENT *>(pools.base[0]);
+		if (live != 0) {
+			const int s = __builtin_ctzll(live);
+			live &= live - 1;
+			const uint64_t fc = readlane64(f, s);
+			cf = (COEF) __builtin_amdgcn_readlane((int) coef, s);
+			src = frag_ptr_as<ENT>(pools, fc);
+			len = (int) (fc & LEN_MASK);
+		}
+		Q.len[u] = len;
+		Q.cf[u] = cf;
+		Q.src[u] = src;
+		Q.h0[u] = sp_ldent<ENT, false>(src + (lane < len ? lane : 0));
+		Q.h1[u] = sp_ldent<ENT, false>(src + (lane + 64 < len ? lane + 64 : 0));
+	}
+	Q.rest = live;
+}
+
+template <typename ENT, typename LDS, typename COEF, typename FLD>
+__device__ __forceinline__ void sp_group_consume(LDS &L, const SpGroup<ENT, COEF> &Q, uint64_t f, COEF coef, const SpPools &pools, int lane, const FLD &G,
+                                                 unsigned long long &ops, uint32_t &nl)
+{
+#pragma unroll
+	for (int u = 0; u < 4; u++) {
+		const int len = Q.len[u];
+		if (len == 0)
+			continue;
+		ops += (unsigned long long) len;
+		if (len > 64)
+			sp_entry2(L, Q.h0[u], Q.h1[u], Q.cf[u], lane < len, lane + 64 < len, G, nl);
+		else
+			sp_entry(L, Q.h0[u], Q.cf[u], lane < len, G, nl);
+		for (int i0 = 128; i0 < len; i0 += 128) {
+			const bool a0 = i0 + lane < len, a1 = i0 + 64 + lane < len;
+			const ENT e0 = sp_ldent<ENT, false>(Q.src[u] + (a0 ? i0 + lane : 0)), e1 = sp_ldent<ENT, false>(Q.src[u] + (a1 ? i0 + 64 + lane : 0));
+			sp_entry2(L, e0, e1, Q.cf[u], a0, a1, G, nl);
+		}
+	}
+	if (Q.rest != 0)
+		sp_accumulate_live<false, ENT>(L, Q.rest, f, coef, pools, lane, G, ops, nl);
 }
 
 // inclusive prefix sum over the 64 lanes (DPP: shifts inside the rows of 16 lanes, then the row totals handed on)
@@ -469,256 +551,93 @@ __device__ __forceinline__ int wave_incl_scan(int x)
 	return x;
 }
 
-// What a segment has touched, ready to be emitted.  The fill of these matrices is CLUSTERED (mk14.b4: 1.9 % of R's entries
-// but 16 % of its 64-column tiles): a lane that owns 128 consecutive columns walks 40-60 of them while most lanes walk none
-// (the emit pass was 52 % of sp_apply_kernel that way).  So: lane L takes the bitmap words L, L + 64, L + 128, L + 192
-// (a cluster of 128 columns is spread over four lanes), one packed scan gives every word its place in column order, the
-// lanes list their columns in LDS (a cheap loop), and the entries themselves are produced 64 at a time from the list,
-// whoever touched them.  Segments with more than LISTCAP touched columns (dense fragments: balanced by themselves) keep
-// the lane-by-lane walk.
-struct SpTouched {
-	int ub;                       // touched columns: an upper bound of the entries (a sum that came back to zero gives none)
-	bool listed;                  // their columns stand in sp_list(L)[0 .. ub), sorted
-	uint64_t lo64, hi64;          // else: the bits of the lane's 128 consecutive columns ...
-	uint32_t prefix;              // ... and the touched columns before them
-};
-
-template <typename LDS> __device__ __forceinline__ void sp_touched(LDS &L, int lane, SpTouched &T)
+// The columns the segment touched whose sums are not zero, in column order, through put(position, column, raw sum); the
+// accumulators and the bitmap go back to zero.  nl = touched columns (sp_mark).  Returns the number of entries put.
+// All 64 lanes come here; put is called by the lanes that hold an entry.
+template <typename LDS, typename PUT> __device__ __forceinline__ int sp_emit_sorted(LDS &L, uint32_t nl, int lane, PUT put)
 {
-	const uint32_t w0 = L.bm[lane], w1 = L.bm[64 + lane], w2 = (WPL > 2) ? L.bm[(128 + lane) % BMW] : 0u, w3 = (WPL > 2) ? L.bm[(192 + lane) % BMW] : 0u;
-	const int c0 = __popc(w0), c1 = __popc(w1), c2 = __popc(w2), c3 = __popc(w3);
-	const int ia = wave_incl_scan(c0 | (c1 << 16)), ib = wave_incl_scan(c2 | (c3 << 16));          // (a field holds at most 64 * 32)
-	const int ta = __builtin_amdgcn_readlane(ia, 63), tb = __builtin_amdgcn_readlane(ib, 63);
-	const int t0 = ta & 0xFFFF, t1 = ta >> 16, t2 = tb & 0xFFFF, t3 = tb >> 16;
-	T.ub = t0 + t1 + t2 + t3;
-	T.listed = T.ub <= LISTCAP;
-	T.lo64 = T.hi64 = 0;
-	T.prefix = 0;
-	if (T.listed) {
-		// (the list goes over the bitmap's words, which every lane has read by now; whoever consumes the list -- sp_emit,
-		//  sp_emit32, sp_discard -- leaves the bitmap zeroed)
-		uint16_t *list = sp_list(L);
-		// where the columns of word j go, minus the columns this lane lists before them
-		const int adj0 = (ia & 0xFFFF) - c0;
-		const int adj1 = t0 + (ia >> 16) - c1 - c0;
-		const int adj2 = t0 + t1 + (ib & 0xFFFF) - c2 - (c0 + c1);
-		const int adj3 = t0 + t1 + t2 + (ib >> 16) - c3 - (c0 + c1 + c2);
-		uint64_t lo = ((uint64_t) w1 << 32) | w0, hi = ((uint64_t) w3 << 32) | w2;
-		int n = 0;
-		while (__ballot((lo | hi) != 0) != 0) {
-			if ((lo | hi) != 0) {
-				int b;
-				if (lo != 0) {
-					b = __builtin_ctzll(lo);
-					lo &= lo - 1;
-				} else {
-					b = 64 + __builtin_ctzll(hi);
-					hi &= hi - 1;
-				}
-				const int j = b >> 5;
-				const int adj = (j == 0) ? adj0 : (j == 1) ? adj1 : (j == 2) ? adj2 : adj3;
-				list[adj + n] = (uint16_t) ((((uint32_t) j * 64u + (uint32_t) lane) << 5) | ((uint32_t) b & 31u));
-				n += 1;
+	if (nl <= (uint32_t) LISTCAP) {
+		// (1) a column whose sum came back to zero leaves the bitmap
+		for (uint32_t i0 = 0; i0 < nl; i0 += 64) {
+			const uint32_t i = i0 + (uint32_t) lane;
+			if (i < nl) {
+				const uint32_t c = L.list[i];
+				if (sp_acc_get(L, c) == 0)
+					atomicAnd(&L.bm[c >> 5], ~(1u << (c & 31u)));
 			}
 		}
-		return;
-	}
-	// many columns: lane L owns the columns [32 WPL L, 32 WPL (L + 1))
-	uint32_t bw[4] = {0u, 0u, 0u, 0u};
+		// (2) lane l holds the words l, 64 + l (, 128 + l, 192 + l): how many columns stand before each of them
+		const uint32_t w0 = L.bm[lane], w1 = L.bm[64 + lane];
+		const uint32_t w2 = (WPL > 2) ? L.bm[(128 + lane) % BMW] : 0u, w3 = (WPL > 2) ? L.bm[(192 + lane) % BMW] : 0u;
+		const int c0 = __popc(w0), c1 = __popc(w1), c2 = __popc(w2), c3 = __popc(w3);
+		const int ia = wave_incl_scan(c0 | (c1 << 16));          // (a field holds at most 64 * 32)
+		const int ta = __builtin_amdgcn_readlane(ia, 63);
+		const int t0 = ta & 0xFFFF, t1 = ta >> 16;
+		int total = t0 + t1;
+		// exclusive prefixes of this lane's words, two to a register
+		const uint32_t pa = (uint32_t) ((ia & 0xFFFF) - c0) | ((uint32_t) (t0 + (ia >> 16) - c1) << 16);
+		uint32_t pb = 0;
+		if (WPL > 2) {
+			const int ib = wave_incl_scan(c2 | (c3 << 16));
+			const int tb = __builtin_amdgcn_readlane(ib, 63);
+			const int t2 = tb & 0xFFFF, t3 = tb >> 16;
+			pb = (uint32_t) (t0 + t1 + (ib & 0xFFFF) - c2) | ((uint32_t) (t0 + t1 + t2 + (ib >> 16) - c3) << 16);
+			total += t2 + t3;
+		}
+		// (3) every listed column whose sum is not zero goes to its rank
+		for (uint32_t i0 = 0; i0 < nl; i0 += 64) {
+			const uint32_t i = i0 + (uint32_t) lane;
+			const bool in = i < nl;
+			const uint32_t c = in ? (uint32_t) L.list[i] : 0u;
+			const uint32_t w = c >> 5;
+			const uint32_t bits = L.bm[w];
+			auto v = sp_acc_get(L, c);
+			if (in)
+				sp_acc_zero(L, c);
+			uint32_t pk = (uint32_t) __builtin_amdgcn_ds_bpermute((int) ((w & 63u) << 2), (int) pa);
+			if (WPL > 2) {
+				const uint32_t pk2 = (uint32_t) __builtin_amdgcn_ds_bpermute((int) ((w & 63u) << 2), (int) pb);
+				pk = (w & 128u) ? pk2 : pk;
+			}
+			const uint32_t before = (w & 64u) ? (pk >> 16) : (pk & 0xFFFFu);
+			const uint32_t rank = before + (uint32_t) __popc(bits & ((1u << (c & 31u)) - 1u));
+			if (in && v != 0)
+				put(rank, c, v);
+		}
 #pragma unroll
-	for (int t = 0; t < WPL; t++) {
-		bw[t] = L.bm[WPL * lane + t];
-		L.bm[WPL * lane + t] = 0;
+		for (int t = 0; t < WPL; t++)
+			L.bm[64 * t + lane] = 0;
+		return total;
 	}
-	T.lo64 = ((uint64_t) bw[1] << 32) | bw[0];
-	T.hi64 = ((uint64_t) bw[3] << 32) | bw[2];
-	const int mine = __popcll(T.lo64) + __popcll(T.hi64);
-	T.prefix = (uint32_t) (wave_incl_scan(mine) - mine);
-}
-
-// in-place compaction of out[0 .. ub) (zero words = columns whose sum came back to zero); returns what is left
-__device__ __forceinline__ int sp_compact(uint32_t *out, int ub, int lane)
-{
-	asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // (the words are read back, past the L1)
+	// many columns: 64 consecutive columns at a time, straight from the bitmap
 	uint32_t w = 0;
-	for (int i0 = 0; i0 < ub; i0 += 64) {
-		const uint32_t e = (i0 + lane < ub) ? sp_ld<true>(out + i0 + lane) : 0u;
-		const uint64_t m = __ballot(e != 0);
-		const uint32_t dst = __builtin_amdgcn_mbcnt_hi((uint32_t) (m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t) m, w));
-		if (e != 0)
-			sp_st<true>(out + dst, e);
-		w += (uint32_t) __popcll(m);
+	for (int ch = 0; ch < SP_SEG / 64; ch++) {
+		const uint32_t mlo = (uint32_t) __builtin_amdgcn_readfirstlane((int) L.bm[2 * ch]), mhi = (uint32_t) __builtin_amdgcn_readfirstlane((int) L.bm[2 * ch + 1]);
+		if ((mlo | mhi) == 0)
+			continue;
+		const uint32_t c = (uint32_t) ch * 64u + (uint32_t) lane;
+		const bool t = ((lane < 32 ? mlo >> lane : mhi >> (lane - 32)) & 1u) != 0;
+		auto v = sp_acc_get(L, c);
+		if (!t)
+			v = 0;
+		if (t)
+			sp_acc_zero(L, c);
+		const uint64_t nz = __ballot(v != 0);
+		const uint32_t pos = __builtin_amdgcn_mbcnt_hi((uint32_t) (nz >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t) nz, w));
+		if (v != 0)
+			put(pos, c, v);
+		w += (uint32_t) __popcll(nz);
 	}
+#pragma unroll
+	for (int t = 0; t < WPL; t++)
+		L.bm[64 * t + lane] = 0;
 	return (int) w;
 }
 
-// The touched columns as (column | value << 16) entries at out[0 .. ub), sorted by column; their accumulators go back to
-// zero.  A column whose sum is zero leaves a zero word, and when there was one (rare: a cancellation mod p) the words are
-// compacted in place afterwards.  Returns the number of entries.
-// CANON: values brought into [-p/2, p/2].  SC1: write-through stores (the fragment is read by other CUs in this launch).
-template <bool CANON, bool SC1>
-__device__ __forceinline__ int sp_emit(WaveLds &L, const SpTouched &T, uint32_t *out, int lane, const SgnDev &G)
-{
-	short *acc = reinterpret_cast<short *>(L.acc);
-	const int ub = T.ub;
-	int holes = 0;
-	if (T.listed) {
-		// 64 columns of the list at a time (two such batches in flight): the non-zero ones are written one behind the other --
-		// sums that came back to zero are common in these matrices (boundary maps: the products cancel), and leave no holes
-		uint32_t w = 0;
-		const uint16_t *list = sp_list(L);
-		for (int i0 = 0; i0 < ub; i0 += 128) {          // (a uniform loop: the lanes past the end idle)
-			const int i = i0 + lane;
-			const bool first = i < ub, second = i + 64 < ub;
-			const uint32_t c0 = first ? list[i] : 0u, c1 = second ? list[i + 64] : 0u;
-			short *a0 = acc + sp_swz(c0), *a1 = acc + sp_swz(c1);
-			int v0 = first ? (int) *a0 : 0, v1 = second ? (int) *a1 : 0;
-			if (first)
-				*a0 = 0;
-			if (second)
-				*a1 = 0;
-			if (CANON) {
-				v0 = sgn_canonical(v0, G);
-				v1 = sgn_canonical(v1, G);
-			}
-			const uint64_t m0 = __ballot(v0 != 0), m1 = __ballot(v1 != 0);
-			const uint32_t d0 = __builtin_amdgcn_mbcnt_hi((uint32_t) (m0 >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t) m0, w));
-			w += (uint32_t) __popcll(m0);
-			const uint32_t d1 = __builtin_amdgcn_mbcnt_hi((uint32_t) (m1 >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t) m1, w));
-			w += (uint32_t) __popcll(m1);
-			if (v0 != 0)
-				sp_st<SC1>(out + d0, c0 | ((uint32_t) v0 << 16));
-			if (v1 != 0)
-				sp_st<SC1>(out + d1, c1 | ((uint32_t) v1 << 16));
-		}
-		sp_bm_clear(L, lane);
-		return (int) w;
-	} else {
-		uint64_t lo64 = T.lo64, hi64 = T.hi64;
-		uint32_t pos = T.prefix;
-		while (__ballot((lo64 | hi64) != 0) != 0) {
-			if ((lo64 | hi64) != 0) {
-				int j;
-				if (lo64 != 0) {
-					j = __builtin_ctzll(lo64);
-					lo64 &= lo64 - 1;
-				} else {
-					j = 64 + __builtin_ctzll(hi64);
-					hi64 &= hi64 - 1;
-				}
-				const uint32_t c = (uint32_t) lane * (32u * WPL) + (uint32_t) j;
-				short *a = acc + sp_swz(c);
-				int v = (int) *a;
-				*a = 0;
-				if (CANON)
-					v = sgn_canonical(v, G);
-				holes += (v == 0);
-				sp_st<SC1>(out + pos, (v != 0) ? (c | ((uint32_t) v << 16)) : 0u);
-				pos += 1;
-			}
-		}
-		for (int sft = 32; sft >= 1; sft >>= 1)
-			holes += __shfl_xor(holes, sft);
-	}
-	if (holes == 0)
-		return ub;
-	return sp_compact(out, ub, lane);
-}
-
 // the same walk without output: a segment that cannot be written (no room) still leaves its accumulators at zero
-__device__ __forceinline__ void sp_discard(WaveLds &L, const SpTouched &T, int lane)
+template <typename LDS> __device__ __forceinline__ void sp_discard(LDS &L, uint32_t nl, int lane)
 {
-	short *acc = reinterpret_cast<short *>(L.acc);
-	if (T.listed) {
-		const uint16_t *list = sp_list(L);
-		for (int i = lane; i < T.ub; i += 64)
-			acc[sp_swz(list[i])] = 0;
-		sp_bm_clear(L, lane);
-		return;
-	}
-	uint64_t lo64 = T.lo64, hi64 = T.hi64;
-	while (__ballot((lo64 | hi64) != 0) != 0) {
-		if ((lo64 | hi64) != 0) {
-			int j;
-			if (lo64 != 0) {
-				j = __builtin_ctzll(lo64);
-				lo64 &= lo64 - 1;
-			} else {
-				j = 64 + __builtin_ctzll(hi64);
-				hi64 &= hi64 - 1;
-			}
-			acc[sp_swz((uint32_t) lane * (32u * WPL) + (uint32_t) j)] = 0;
-		}
-	}
-}
-
-// 32-bit accumulators: the touched columns with a non-zero sum go to out(position, column, value), sorted by column; the
-// accumulators go back to zero.  Returns the number of entries.  No holes: the lane-by-lane walk (segments with more than
-// LISTCAP touched columns) counts its non-zero sums first.
-template <typename OUT>
-__device__ __forceinline__ int sp_emit32(WaveLds32 &L, const SpTouched &T, int lane, OUT out)
-{
-	const int ub = T.ub;
-	if (T.listed) {
-		uint32_t w = 0;
-		const uint16_t *list = sp_list(L);
-		for (int i0 = 0; i0 < ub; i0 += 128) {
-			const int i = i0 + lane;
-			const bool first = i < ub, second = i + 64 < ub;
-			const uint32_t c0 = first ? list[i] : 0u, c1 = second ? list[i + 64] : 0u;
-			uint32_t *a0 = L.acc + sp_swz32(c0), *a1 = L.acc + sp_swz32(c1);
-			const uint32_t v0 = first ? *a0 : 0u, v1 = second ? *a1 : 0u;
-			if (first)
-				*a0 = 0;
-			if (second)
-				*a1 = 0;
-			const uint64_t m0 = __ballot(v0 != 0), m1 = __ballot(v1 != 0);
-			const uint32_t d0 = __builtin_amdgcn_mbcnt_hi((uint32_t) (m0 >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t) m0, w));
-			w += (uint32_t) __popcll(m0);
-			const uint32_t d1 = __builtin_amdgcn_mbcnt_hi((uint32_t) (m1 >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t) m1, w));
-			w += (uint32_t) __popcll(m1);
-			if (v0 != 0)
-				out(d0, c0, v0);
-			if (v1 != 0)
-				out(d1, c1, v1);
-		}
-		sp_bm_clear(L, lane);
-		return (int) w;
-	}
-	// lane L owns the columns [32 WPL L, 32 WPL (L + 1)): count, scan, write
-	const uint32_t col0 = (uint32_t) lane * (32u * WPL);
-	int mine = 0;
-	for (int half = 0; half < 2; half++)
-		for (uint64_t bits = half ? T.hi64 : T.lo64; bits != 0; bits &= bits - 1)
-			mine += L.acc[sp_swz32(col0 + 64u * half + (uint32_t) __builtin_ctzll(bits))] != 0;
-	const int incl = wave_incl_scan(mine);
-	uint32_t pos = (uint32_t) (incl - mine);
-	for (int half = 0; half < 2; half++)
-		for (uint64_t bits = half ? T.hi64 : T.lo64; bits != 0; bits &= bits - 1) {
-			const uint32_t c = col0 + 64u * half + (uint32_t) __builtin_ctzll(bits);
-			uint32_t *a = L.acc + sp_swz32(c);
-			const uint32_t v = *a;
-			*a = 0;
-			if (v != 0) {
-				out(pos, c, v);
-				pos += 1;
-			}
-		}
-	return __builtin_amdgcn_readlane(incl, 63);
-}
-
-__device__ __forceinline__ void sp_discard(WaveLds32 &L, const SpTouched &T, int lane)
-{
-	if (T.listed) {
-		const uint16_t *list = sp_list(L);
-		for (int i = lane; i < T.ub; i += 64)
-			L.acc[sp_swz32(list[i])] = 0;
-		sp_bm_clear(L, lane);
-		return;
-	}
-	for (int half = 0; half < 2; half++)
-		for (uint64_t bits = half ? T.hi64 : T.lo64; bits != 0; bits &= bits - 1)
-			L.acc[sp_swz32((uint32_t) lane * (32u * WPL) + 64u * half + (uint32_t) __builtin_ctzll(bits))] = 0;
+	(void) sp_emit_sorted(L, nl, lane, [](uint32_t, uint32_t, auto) {});
 }
 
 __device__ __forceinline__ uint32_t sp_hash(uint32_t c, uint32_t g)
@@ -843,6 +762,7 @@ __device__ __forceinline__ void sp_build_task(const SpBuildArgs &b, LDS &L, int 
 	const uint64_t d0 = sp_uniform(b.dep_rp[c]), d1 = sp_uniform(b.dep_rp[c + 1]), n0 = sp_uniform(b.np_rp[c]), n1 = sp_uniform(b.np_rp[c + 1]);
 	uint64_t *fout = b.frag + (uint64_t) c * b.nseg + g;
 	unsigned long long ops = 0;
+	uint32_t nl = 0;                               // columns of the segment touched so far (sp_mark)
 	bool touched = false, failed = false;          // (wave-uniform: they only ever change on ballots)
 	// the row's own non-pivotal entries that fall into this segment
 	for (uint64_t e = n0; e < n1; e += 64) {
@@ -856,12 +776,10 @@ __device__ __forceinline__ void sp_build_task(const SpBuildArgs &b, LDS &L, int 
 		const bool in = idx < (uint32_t) SP_SEG;
 		if (__ballot(in) != 0) {
 			touched = true;
-			if (in) {
-				if constexpr (W32)
-					sp_own_entry(L, idx, (uint32_t) val, M);
-				else
-					sp_own_entry(L, idx, val, G);
-			}
+			if constexpr (W32)
+				sp_own_entry(L, idx, (uint32_t) val, in, M, nl);
+			else
+				sp_own_entry(L, idx, val, in, G, nl);
 		}
 	}
 	// minus the rows of R its pivotal entries point at (coefficients are stored negated)
@@ -905,9 +823,9 @@ __device__ __forceinline__ void sp_build_task(const SpBuildArgs &b, LDS &L, int 
 			if (PERSISTENT)
 				sp_dbg(b, lane, 3, (long long) c * b.nseg + g, (int) (e - d0));
 			if constexpr (W32)
-				sp_accumulate<PERSISTENT>(L, f, (uint32_t) coef, true, b.pools, lane, M, ops);
+				sp_accumulate<PERSISTENT>(L, f, (uint32_t) coef, true, b.pools, lane, M, ops, nl);
 			else
-				sp_accumulate<PERSISTENT>(L, f, coef, true, b.pools, lane, G, ops);
+				sp_accumulate<PERSISTENT>(L, f, coef, true, b.pools, lane, G, ops, nl);
 			st.mark(3);
 		}
 	}
@@ -917,9 +835,7 @@ __device__ __forceinline__ void sp_build_task(const SpBuildArgs &b, LDS &L, int 
 	if (touched) {
 		if (PERSISTENT)
 			sp_dbg(b, lane, 4, (long long) c * b.nseg + g, failed ? 1 : 0);
-		SpTouched T;
-		sp_touched(L, lane, T);
-		const int ub = T.ub;
+		const int ub = (int) nl;          // touched columns: an upper bound of the entries (a sum that came back to zero gives none)
 		const uint32_t sh = sp_hash((uint32_t) c, (uint32_t) g);
 		unsigned long long *S = b.shard + (size_t) sh * SHARD_STRIDE;
 		unsigned long long off = 0;
@@ -946,13 +862,15 @@ __device__ __forceinline__ void sp_build_task(const SpBuildArgs &b, LDS &L, int 
 		}
 		st.mark(4);
 		if (failed) {
-			sp_discard(L, T, lane);
+			sp_discard(L, nl, lane);
 		} else if (ub > 0) {
 			if constexpr (W32) {
 				uint64_t *dst = reinterpret_cast<uint64_t *>(b.chunk_base) + off;
-				cnt = sp_emit32(L, T, lane, [&](uint32_t pos, uint32_t col, uint32_t v) { sp_st64<PERSISTENT>(dst + pos, (uint64_t) col | ((uint64_t) v << 32)); });
+				cnt = sp_emit_sorted(L, nl, lane, [&](uint32_t pos, uint32_t col, uint32_t v) { sp_st64<PERSISTENT>(dst + pos, (uint64_t) col | ((uint64_t) v << 32)); });
 			} else {
-				cnt = sp_emit<false, PERSISTENT>(L, T, b.chunk_base + off, lane, G);
+				// (values as they stand in the accumulators, |v| <= B: the readers' arithmetic takes them)
+				uint32_t *dst = b.chunk_base + off;
+				cnt = sp_emit_sorted(L, nl, lane, [&](uint32_t pos, uint32_t col, int v) { sp_st<PERSISTENT>(dst + pos, col | ((uint32_t) v << 16)); });
 			}
 			if (cnt > 0)
 				word = ((uint64_t) b.chunk << (SP_LEN_BITS + SP_OFF_BITS)) | ((uint64_t) off << SP_LEN_BITS) | (uint64_t) cnt;
@@ -1084,6 +1002,7 @@ struct SpApplyArgs {
 	uint32_t *fpool_v;            // the 32-bit variant: fpool holds the columns, this the values in [0, p)
 	int64_t fcap;
 	uint64_t *T;                  // nrows x nseg: offset << SP_LEN_BITS | length of the fragment of (row, segment)
+	uint32_t *D;                  // nrows x nseg: entries of the row in the segments before this one (where the gather puts the fragment)
 	unsigned long long *block_sum;// sum of the lengths of every block of 1024 rows (zeroed before the launch)
 	int arena;                    // entries a wave reserves from the pool at a time (0: every fragment on its own)
 	int *ticket;                  // SP_TICKETS counters handing out the rows (zeroed before the launch)
@@ -1092,7 +1011,8 @@ struct SpApplyArgs {
 
 // One wave per row of the batch, segment after segment: the entries of the row of A are read and relabelled once (rows
 // of at most 64 entries -- longer ones go through them once per segment), the fragment words of segment g + 1 are in
-// flight while segment g is added up, and the row's fragments of S land one behind the other in the wave's arena.
+// flight while segment g is added up, and the row's fragments of S land one behind the other in the wave's arena.  The
+// words of T and D stay in registers (lane g holds those of segment g) and leave in one store per row.
 template <bool W32> __global__ __launch_bounds__(64) void sp_apply_kernel(SpApplyArgs d)
 {
 	__shared__ typename std::conditional<W32, WaveLds32, WaveLds>::type L;
@@ -1108,16 +1028,10 @@ template <bool W32> __global__ __launch_bounds__(64) void sp_apply_kernel(SpAppl
 	sp_lds_init(L, lane);
 	SpStamp st;
 	st.begin(d.prof);
-	// what a (row, segment) leaves behind: its fragment in the pool and its word in T (or its dense values)
-	auto finish = [&](int k, int g, bool touched) -> int {
-		uint64_t *tout = d.T + (uint64_t) k * nseg + g;
-		if (!touched) {
-			l0_store_u64(tout, 0);
-			return 0;
-		}
-		SpTouched T;
-		sp_touched(L, lane, T);
-		const int ub = T.ub;
+	// what a touched (row, segment) leaves behind: its fragment in the pool; returns its word of T and the number of entries
+	auto finish = [&](uint32_t nl, int &cnt) -> uint64_t {
+		const int ub = (int) nl;
+		cnt = 0;
 		if (ar_cur + ub > ar_end) {
 			const long long want = (d.arena > ub) ? d.arena : ub;
 			const unsigned long long got = l0_atomic_add_u64_ret(&a.ctr64[C64_POOL], (unsigned long long) want);
@@ -1129,25 +1043,24 @@ template <bool W32> __global__ __launch_bounds__(64) void sp_apply_kernel(SpAppl
 			}
 		}
 		if (ar_cur + ub > ar_end) {
-			sp_discard(L, T, lane);
-			l0_store_u64(tout, 0);
+			sp_discard(L, nl, lane);
 			return 0;
 		}
 		st.mark(3);
-		int cnt;
 		if constexpr (W32) {
 			uint32_t *oc = d.fpool + ar_cur, *ov = d.fpool_v + ar_cur;
-			cnt = sp_emit32(L, T, lane, [&](uint32_t pos, uint32_t col, uint32_t v) {
+			cnt = sp_emit_sorted(L, nl, lane, [&](uint32_t pos, uint32_t col, uint32_t v) {
 				oc[pos] = col;
 				ov[pos] = v;
 			});
 		} else {
-			cnt = sp_emit<true, false>(L, T, d.fpool + ar_cur, lane, G);
+			uint32_t *out = d.fpool + ar_cur;
+			cnt = sp_emit_sorted(L, nl, lane, [&](uint32_t pos, uint32_t col, int v) { out[pos] = col | ((uint32_t) sgn_canonical(v, G) << 16); });
 		}
 		st.mark(4);
-		l0_store_u64(tout, (cnt > 0) ? (((uint64_t) ar_cur << SP_LEN_BITS) | (uint64_t) cnt) : 0);
+		const uint64_t word = (cnt > 0) ? (((uint64_t) ar_cur << SP_LEN_BITS) | (uint64_t) cnt) : 0;
 		ar_cur += cnt;
-		return cnt;
+		return word;
 	};
 	// rows are handed out by ticket counters (their costs differ by orders of magnitude: with a fixed share per wave the
 	// kernel ran 1.6 times as long as its average wave)
@@ -1161,6 +1074,24 @@ template <bool W32> __global__ __launch_bounds__(64) void sp_apply_kernel(SpAppl
 		const int64_t lo = (int64_t) sp_uniform((uint64_t) a.Ap[i]), hi = (int64_t) sp_uniform((uint64_t) a.Ap[i + 1]);
 		st_input += (unsigned long long) (hi - lo);
 		int total = 0;
+		uint64_t tw = 0;          // lane (g mod 64) holds the word of T of segment g ...
+		uint32_t td = 0;          // ... and the entries of the row before it
+		uint64_t *trow = d.T + (uint64_t) k * nseg;
+		uint32_t *drow = d.D + (uint64_t) k * nseg;
+		auto keep = [&](int g, uint64_t word, int cnt) {
+			if (lane == (g & 63)) {
+				tw = word;
+				td = (uint32_t) total;
+			}
+			total += cnt;
+			if ((g & 63) == 63 || g + 1 == nseg) {
+				const int g0 = g & ~63;
+				if (g0 + lane <= g) {
+					trow[g0 + lane] = tw;
+					drow[g0 + lane] = td;
+				}
+			}
+		};
 		if (hi - lo <= 64) {
 			// the row in registers: lane e holds entry e
 			uint32_t cid = 0xFFFFFFFFu;
@@ -1182,33 +1113,46 @@ template <bool W32> __global__ __launch_bounds__(64) void sp_apply_kernel(SpAppl
 			const uint32_t idx_all = cid - (uint32_t) d.r;          // (own entries: index among the non-pivotal columns)
 			const uint64_t *fin = d.frag + (piv ? (uint64_t) cid * nseg : 0);
 			st_piv += piv ? 1 : 0;
+			using ENT = typename std::conditional<W32, uint64_t, uint32_t>::type;
+			using COEF = typename std::conditional<W32, uint32_t, int>::type;
 			uint64_t f = piv ? fin[0] : 0;
+			uint64_t fn = (piv && nseg > 1) ? fin[1] : 0;
+			SpGroup<ENT, COEF> cur, nxt;
+			sp_group_issue(cur, f, (COEF) ncoef, piv, d.pools, lane);
 			st.mark(0);
 			for (int g = 0; g < nseg; g++) {
-				const uint64_t fnext = (piv && g + 1 < nseg) ? fin[g + 1] : 0;
+				const uint64_t fnn = (piv && g + 2 < nseg) ? fin[g + 2] : 0;
+				sp_group_issue(nxt, fn, (COEF) ncoef, piv, d.pools, lane);          // (beyond the last segment: fn = 0, eight loads of the pool's first word)
 				const uint32_t idx = idx_all - (uint32_t) g * SP_SEG;
 				const bool in = own && idx < (uint32_t) SP_SEG;
 				const bool touched = (__ballot(in) | __ballot(piv && (f & LEN_MASK) != 0)) != 0;
 				st.mark(1);
+				uint64_t word = 0;
+				int cnt = 0;
 				if (touched) {
+					uint32_t nl = 0;
 					if constexpr (W32) {
-						if (in)
-							sp_own_entry(L, idx, (uint32_t) bal, F);
-						sp_accumulate<false>(L, f, (uint32_t) ncoef, piv, d.pools, lane, F, ops);
+						if (__ballot(in) != 0)
+							sp_own_entry(L, idx, (uint32_t) bal, in, F, nl);
+						sp_group_consume(L, cur, f, (COEF) ncoef, d.pools, lane, F, ops, nl);
 					} else {
-						if (in)
-							sp_own_entry(L, idx, bal, G);
-						sp_accumulate<false>(L, f, ncoef, piv, d.pools, lane, G, ops);
+						if (__ballot(in) != 0)
+							sp_own_entry(L, idx, bal, in, G, nl);
+						sp_group_consume(L, cur, f, (COEF) ncoef, d.pools, lane, G, ops, nl);
 					}
+					st.mark(2);
+					word = finish(nl, cnt);
 				}
-				st.mark(2);
-				total += finish(k, g, touched);
+				keep(g, word, cnt);
 				st.mark(5);
-				f = fnext;
+				f = fn;
+				fn = fnn;
+				cur = nxt;
 			}
 		} else {
 			for (int g = 0; g < nseg; g++) {
 				const uint32_t col0 = (uint32_t) g * SP_SEG;
+				uint32_t nl = 0;
 				bool touched = false;
 				for (int64_t base = lo; base < hi; base += 64) {
 					uint64_t f = 0;
@@ -1238,16 +1182,20 @@ template <bool W32> __global__ __launch_bounds__(64) void sp_apply_kernel(SpAppl
 						continue;
 					touched = true;
 					if constexpr (W32) {
-						if (in)
-							sp_own_entry(L, idx, (uint32_t) bal, F);
-						sp_accumulate<false>(L, f, (uint32_t) ncoef, piv, d.pools, lane, F, ops);
+						if (__ballot(in) != 0)
+							sp_own_entry(L, idx, (uint32_t) bal, in, F, nl);
+						sp_accumulate<false>(L, f, (uint32_t) ncoef, piv, d.pools, lane, F, ops, nl);
 					} else {
-						if (in)
-							sp_own_entry(L, idx, bal, G);
-						sp_accumulate<false>(L, f, ncoef, piv, d.pools, lane, G, ops);
+						if (__ballot(in) != 0)
+							sp_own_entry(L, idx, bal, in, G, nl);
+						sp_accumulate<false>(L, f, ncoef, piv, d.pools, lane, G, ops, nl);
 					}
 				}
-				total += finish(k, g, touched);
+				uint64_t word = 0;
+				int cnt = 0;
+				if (touched)
+					word = finish(nl, cnt);
+				keep(g, word, cnt);
 			}
 		}
 		st_done += 1;
@@ -1269,52 +1217,96 @@ template <bool W32> __global__ __launch_bounds__(64) void sp_apply_kernel(SpAppl
 
 struct SpGatherArgs {
 	const uint64_t *T;
+	const uint32_t *D;
 	const uint32_t *fpool;
 	const uint32_t *fpool_v;      // 32-bit variant: the values (fpool: the columns)
 	uint32_t p;
-	int nrows, nseg;
+	int nrows, nseg, Sm;
 	const int64_t *Sp;
 	int *Sj, *Sx;
 	int64_t cap;
 	const int *q;                 // index among the non-pivotal columns -> column
 };
 
-// the fragments of a row, segment after segment, as (column, value) pairs at the row's final place
+// The fragments of S as (column, value) pairs at their final place, SEGMENT BY SEGMENT: a workgroup keeps the 4,096 columns of its
+// segment's piece of q in LDS (16 KB; by row, every entry paid a trip to the L1 for its column: 9.9 -> 6.4 ms measured without the
+// look-up in round 5) and walks SP_GATHER_ROWS rows; where a fragment goes inside its row is D, written by the apply kernel.
+constexpr int SP_GATHER_ROWS = 2048;
 template <bool W32> __global__ __launch_bounds__(256) void sp_gather_kernel(SpGatherArgs e)
 {
-	const int lane = threadIdx.x & 63;
-	const int wave = (int) ((blockIdx.x * blockDim.x + threadIdx.x) >> 6), nwaves = (int) ((gridDim.x * blockDim.x) >> 6);
-	for (int k = wave; k < e.nrows; k += nwaves) {
-		const int64_t off = e.Sp[k], end = e.Sp[k + 1];
-		if (end > e.cap || end == off)
-			continue;
-		int64_t w = off;
-		for (int g0 = 0; g0 < e.nseg; g0 += 64) {
-			const uint64_t t = (g0 + lane < e.nseg) ? e.T[(uint64_t) k * e.nseg + g0 + lane] : 0;
-			uint64_t live = __ballot((t & LEN_MASK) != 0);
-			while (live != 0) {
-				const int s = __builtin_ctzll(live);
-				live &= live - 1;
-				const uint64_t tt = readlane64(t, s);
-				const int len = (int) (tt & LEN_MASK);
-				const uint32_t *src = e.fpool + (tt >> SP_LEN_BITS);
-				const int *q = e.q + (int64_t) (g0 + s) * SP_SEG;
-				int *oj = e.Sj + w, *ox = e.Sx + w;
+	__shared__ int qs[SP_SEG];
+	const int g = (int) (blockIdx.x % (unsigned) e.nseg);
+	const int k_lo = (int) (blockIdx.x / (unsigned) e.nseg) * SP_GATHER_ROWS;
+	const int k_hi = (k_lo + SP_GATHER_ROWS < e.nrows) ? k_lo + SP_GATHER_ROWS : e.nrows;
+	const int ncols = (e.Sm - g * SP_SEG < SP_SEG) ? e.Sm - g * SP_SEG : SP_SEG;
+	for (int t = threadIdx.x; t < ncols; t += 256)
+		qs[t] = e.q[(int64_t) g * SP_SEG + t];
+	__syncthreads();
+	const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+	for (int k0 = k_lo + 64 * wave; k0 < k_hi; k0 += 256) {
+		const int k = k0 + lane;
+		uint64_t t = 0;
+		int64_t dst = 0;
+		if (k < k_hi) {
+			const int64_t off = e.Sp[k], end = e.Sp[k + 1];
+			if (end <= e.cap && end != off) {
+				t = e.T[(uint64_t) k * e.nseg + g];
+				dst = off + (int64_t) e.D[(uint64_t) k * e.nseg + g];
+			}
+		}
+		uint64_t live = __ballot((t & LEN_MASK) != 0);
+		// four fragments at a time, their first 64 entries in flight together (one at a time, a wave spent its time waiting for
+		// one load after the other: 40 M fragments of 20-60 entries)
+		while (live != 0) {
+			const uint32_t *src[4];
+			int len[4];
+			int64_t w[4];
+			uint32_t h[4], hv[4];
+#pragma unroll
+			for (int u = 0; u < 4; u++) {
+				len[u] = 0;
+				w[u] = 0;
+				src[u] = e.fpool;
+				if (live != 0) {
+					const int s = __builtin_ctzll(live);
+					live &= live - 1;
+					const uint64_t tt = readlane64(t, s);
+					w[u] = (int64_t) readlane64((uint64_t) dst, s);
+					len[u] = (int) (tt & LEN_MASK);
+					src[u] = e.fpool + (tt >> SP_LEN_BITS);
+				}
+				h[u] = src[u][lane < len[u] ? lane : 0];
+				hv[u] = 0;
+				if constexpr (W32)
+					hv[u] = (e.fpool_v + (src[u] - e.fpool))[lane < len[u] ? lane : 0];
+			}
+#pragma unroll
+			for (int u = 0; u < 4; u++) {
+				if (len[u] == 0)
+					continue;
+				int *oj = e.Sj + w[u], *ox = e.Sx + w[u];
 				if constexpr (W32) {
-					const uint32_t *sv = e.fpool_v + (tt >> SP_LEN_BITS);
-					for (int i = lane; i < len; i += 64) {
+					const uint32_t *sv = e.fpool_v + (src[u] - e.fpool);
+					if (lane < len[u]) {
+						oj[lane] = qs[h[u] & 0xFFFFu];
+						ox[lane] = (hv[u] > e.p / 2) ? (int) (hv[u] - e.p) : (int) hv[u];          // balanced representative (spasm_ZZp)
+					}
+					for (int i = lane + 64; i < len[u]; i += 64) {
 						const uint32_t v = sv[i];
-						oj[i] = q[src[i] & 0xFFFFu];
-						ox[i] = (v > e.p / 2) ? (int) (v - e.p) : (int) v;          // balanced representative (spasm_ZZp)
+						oj[i] = qs[src[u][i] & 0xFFFFu];
+						ox[i] = (v > e.p / 2) ? (int) (v - e.p) : (int) v;
 					}
 				} else {
-					for (int i = lane; i < len; i += 64) {
-						const uint32_t en = src[i];
-						oj[i] = q[en & 0xFFFFu];
+					if (lane < len[u]) {
+						oj[lane] = qs[h[u] & 0xFFFFu];
+						ox[lane] = (int) h[u] >> 16;
+					}
+					for (int i = lane + 64; i < len[u]; i += 64) {
+						const uint32_t en = src[u][i];
+						oj[i] = qs[en & 0xFFFFu];
 						ox[i] = (int) en >> 16;
 					}
 				}
-				w += len;
 			}
 		}
 	}
@@ -1921,6 +1913,9 @@ bool sparse_image_build(const spasm_hip_dfact *F, hipStream_t stream)
 	return true;
 }
 
+// 64-bit words of the tables of a Schur call: T (one word per (row, segment)) and D (32 bits each) behind it
+int64_t sparse_image_table_words(int64_t nrows, int nseg) { return nrows * nseg + (nrows * nseg + 1) / 2 + 8; }
+
 // S rows from the sparse image, as sparse rows in W's final arrays.
 //   fpool / fcap: room for the fragments of S (4-byte entries; the 32-bit variant: their columns, and fpool_v their values);
 //   T: nrows * nseg words; block_sum: (nrows + 1023) / 1024 words
@@ -1928,6 +1923,7 @@ void launch_sparse_image_apply(const SchurArgs &a, const spasm_hip_dfact *F, uin
                                uint64_t *T, unsigned long long *block_sum, int64_t *Sp, int *Sj, int *Sx, int64_t cap, hipStream_t stream,
                                hipEvent_t ev_gather)
 {
+	// (T: nrows * nseg 64-bit words, then as many 32-bit words of D: sparse_image_table_words)
 	const SpImage &S = F->sp;
 	if (!S.valid)
 		die("launch_sparse_image_apply: the sparse image has not been built");
@@ -1948,6 +1944,7 @@ void launch_sparse_image_apply(const SchurArgs &a, const spasm_hip_dfact *F, uin
 	d.fpool_v = fpool_v;
 	d.fcap = fcap;
 	d.T = T;
+	d.D = reinterpret_cast<uint32_t *>(T + (size_t) a.nrows * S.nseg);
 	d.block_sum = block_sum;
 	const int64_t ntasks = (int64_t) a.nrows;          // (a wave takes a row through all its segments)
 	if (ntasks <= 0)
@@ -1993,8 +1990,11 @@ void launch_sparse_image_apply(const SchurArgs &a, const spasm_hip_dfact *F, uin
 	if (ev_gather != nullptr)
 		HIP_CHECK(hipEventRecord(ev_gather, stream));
 	launch_scan_lengths(a.row_len, a.nrows, block_sum, Sp, cap, a.ctr, stream);
-	SpGatherArgs e{T, fpool, fpool_v, (uint32_t) F->prime, a.nrows, S.nseg, Sp, Sj, Sx, cap, a.q};
-	const int gblocks = std::max(1, std::min((a.nrows + 3) / 4, prop.multiProcessorCount * 8));
+	SpGatherArgs e{T, d.D, fpool, fpool_v, (uint32_t) F->prime, a.nrows, S.nseg, S.Sm, Sp, Sj, Sx, cap, a.q};
+	const int64_t gblocks64 = (int64_t) ((a.nrows + SP_GATHER_ROWS - 1) / SP_GATHER_ROWS) * S.nseg;
+	if (gblocks64 > 0x7FFFFFFFll)
+		die("launch_sparse_image_apply: %lld workgroups for the gather", (long long) gblocks64);
+	const int gblocks = (int) gblocks64;
 	if (S.wide)
 		hipLaunchKernelGGL(sp_gather_kernel<true>, dim3(gblocks), dim3(256), 0, stream, e);
 	else
