@@ -205,6 +205,9 @@ struct SpImage {
 	uint2 *d_np = nullptr;            // ... (index among the non-pivotal columns, balanced value; wide: plain residue)
 	uint64_t *d_segmask = nullptr;    // per compact row: the segments in which its row of R CAN have entries (its own non-pivotal entries
 	                                  // and those of the rows it depends on: structural, an upper bound) -- nullptr beyond 64 segments
+	uint2 *d_head = nullptr;          // per compact row, 8 words: both lists of a row of at most seven entries in one 64-byte line
+	uint64_t *d_rowmask = nullptr;    // per compact row, (nseg + 63) / 64 words: the segments in which its row of R HAS entries (from the
+	                                  // fragment words, after every build): sp_apply_kernel visits no other segment of a row
 	uint64_t *d_frag = nullptr;       // r * nseg words: chunk << 54 | offset << 14 | length
 	uint32_t *d_chunk[SP_MAX_CHUNKS] = {};
 	int64_t chunk_cap[SP_MAX_CHUNKS] = {};        // entries (4 bytes each; wide: 8)

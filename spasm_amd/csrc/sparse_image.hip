@@ -261,16 +261,13 @@ template <bool SC1> __device__ __forceinline__ void sp_st64(uint64_t *p, uint64_
 		*p = v;
 }
 
-// Column c is touched (lanes with `act`; the columns of the active lanes are distinct): its bit is set, and the lanes that set a
-// NEW bit list their columns -- nl counts the touched columns of the segment so far (wave-uniform; beyond LISTCAP the list is
-// no longer written and the segment will be walked from the bitmap).  All 64 lanes come here.
-template <typename LDS> __device__ __forceinline__ void sp_mark(LDS &L, uint32_t c, bool act, uint32_t &nl)
+// A lane whose accumulator was ZERO before its update lists its column (first: the lanes that found a zero; nl: the length of the
+// list, wave-uniform; beyond LISTCAP it is no longer written and the segment will be walked 64 columns at a time).  An accumulator
+// is zero when its column was never touched -- or when its sum has come back to zero for the time being: such a column can be
+// listed twice, which the emit pass copes with (both copies find the same sum and the same rank).  No bitmap, hence no atomic,
+// on the path of a multiply-add: the clustered fill put ten lanes of a batch on the same bitmap word, one after the other.
+template <typename LDS> __device__ __forceinline__ void sp_list_new(LDS &L, uint32_t c, bool first, uint32_t &nl)
 {
-	const uint32_t bit = 1u << (c & 31u);
-	uint32_t old = bit;
-	if (act)
-		old = atomicOr(&L.bm[c >> 5], bit);
-	const bool first = (old & bit) == 0;
 	const uint64_t firsts = __ballot(first);
 	const uint32_t pos = __builtin_amdgcn_mbcnt_hi((uint32_t) (firsts >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t) firsts, nl));
 	if (first && pos < (uint32_t) LISTCAP)
@@ -278,53 +275,34 @@ template <typename LDS> __device__ __forceinline__ void sp_mark(LDS &L, uint32_t
 	nl += (uint32_t) __popcll(firsts);
 }
 
-// the second half of sp_mark for a lane that already holds the old word of its column's bit
-template <typename LDS> __device__ __forceinline__ void sp_list_new(LDS &L, uint32_t c, uint32_t old, uint32_t bit, uint32_t &nl)
-{
-	const bool first = (old & bit) == 0;
-	const uint64_t firsts = __ballot(first);
-	const uint32_t pos = __builtin_amdgcn_mbcnt_hi((uint32_t) (firsts >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t) firsts, nl));
-	if (first && pos < (uint32_t) LISTCAP)
-		L.list[pos] = (uint16_t) c;
-	nl += (uint32_t) __popcll(firsts);
-}
-
-// acc[column] += coef * value for one entry (column | value << 16) per active lane; the sum is reduced at once.  The read of the
-// accumulator and the atomic OR on the bitmap leave together: one trip to the LDS per batch, not two.
+// acc[column] += coef * value for one entry (column | value << 16) per active lane (the columns of the active lanes are distinct;
+// coef and value are not zero mod p); the sum is reduced at once.  All 64 lanes come here.
 __device__ __forceinline__ void sp_entry(WaveLds &L, uint32_t e, int coef, bool act, const SgnDev &G, uint32_t &nl)
 {
 	const uint32_t c = e & 0xFFFFu;
-	const uint32_t bit = 1u << (c & 31u);
 	short *a = reinterpret_cast<short *>(L.acc) + c;
-	uint32_t old = bit;
-	int t = 0;
-	if (act) {
-		t = (int) *a;
-		old = atomicOr(&L.bm[c >> 5], bit);
-	}
+	int old = 1;
+	if (act)
+		old = (int) *a;
+	int t = old;
 	asm("v_mad_i32_i16 %0, %1, %2, %0 op_sel:[1,0,0,0]" : "+v"(t) : "v"(e), "v"(coef));
 	t = sgn_reduce(t, G);
 	if (act)
 		*a = (short) t;
-	sp_list_new(L, c, old, bit, nl);
+	sp_list_new(L, c, old == 0, nl);
 }
 
-// two batches of ONE fragment (distinct columns): four LDS reads in flight
+// two batches of ONE fragment (distinct columns): both reads in flight together
 __device__ __forceinline__ void sp_entry2(WaveLds &L, uint32_t e0, uint32_t e1, int coef, bool act0, bool act1, const SgnDev &G, uint32_t &nl)
 {
 	const uint32_t c0 = e0 & 0xFFFFu, c1 = e1 & 0xFFFFu;
-	const uint32_t bit0 = 1u << (c0 & 31u), bit1 = 1u << (c1 & 31u);
 	short *acc = reinterpret_cast<short *>(L.acc);
-	uint32_t old0 = bit0, old1 = bit1;
-	int t0 = 0, t1 = 0;
-	if (act0) {
-		t0 = (int) acc[c0];
-		old0 = atomicOr(&L.bm[c0 >> 5], bit0);
-	}
-	if (act1) {
-		t1 = (int) acc[c1];
-		old1 = atomicOr(&L.bm[c1 >> 5], bit1);
-	}
+	int old0 = 1, old1 = 1;
+	if (act0)
+		old0 = (int) acc[c0];
+	if (act1)
+		old1 = (int) acc[c1];
+	int t0 = old0, t1 = old1;
 	asm("v_mad_i32_i16 %0, %1, %2, %0 op_sel:[1,0,0,0]" : "+v"(t0) : "v"(e0), "v"(coef));
 	asm("v_mad_i32_i16 %0, %1, %2, %0 op_sel:[1,0,0,0]" : "+v"(t1) : "v"(e1), "v"(coef));
 	t0 = sgn_reduce(t0, G);
@@ -333,18 +311,20 @@ __device__ __forceinline__ void sp_entry2(WaveLds &L, uint32_t e0, uint32_t e1, 
 		acc[c0] = (short) t0;
 	if (act1)
 		acc[c1] = (short) t1;
-	sp_list_new(L, c0, old0, bit0, nl);
-	sp_list_new(L, c1, old1, bit1, nl);
+	sp_list_new(L, c0, old0 == 0, nl);
+	sp_list_new(L, c1, old1 == 0, nl);
 }
 
-// acc[column] += value (an entry of the row itself); value in [-p/2, p/2]
+// acc[column] += value (an entry of the row itself, not zero); value in [-p/2, p/2]
 __device__ __forceinline__ void sp_own_entry(WaveLds &L, uint32_t c, int val, bool act, const SgnDev &G, uint32_t &nl)
 {
+	int old = 1;
 	if (act) {
 		short *a = reinterpret_cast<short *>(L.acc) + c;
-		*a = (short) sgn_canonical((int) *a + val, G);
+		old = (int) *a;
+		*a = (short) sgn_canonical(old + val, G);
 	}
-	sp_mark(L, act ? c : 0u, act, nl);
+	sp_list_new(L, act ? c : 0u, old == 0, nl);
 }
 
 __device__ __forceinline__ uint32_t sp_addmod(uint32_t a, uint32_t b, uint32_t p)          // a, b in [0, p), any p < 2^32
@@ -359,11 +339,13 @@ __device__ __forceinline__ uint32_t sp_addmod(uint32_t a, uint32_t b, uint32_t p
 __device__ __forceinline__ void sp_entry(WaveLds32 &L, uint64_t e, uint32_t coef, bool act, const MontDev &F, uint32_t &nl)
 {
 	const uint32_t c = (uint32_t) e & 0xFFFFu;
+	uint32_t old = 1;
 	if (act) {
 		uint32_t *a = L.acc + c;
-		*a = sp_addmod(*a, montmul(coef, (uint32_t) (e >> 32), F), F.p);
+		old = *a;
+		*a = sp_addmod(old, montmul(coef, (uint32_t) (e >> 32), F), F.p);
 	}
-	sp_mark(L, c, act, nl);
+	sp_list_new(L, c, old == 0, nl);
 }
 
 __device__ __forceinline__ void sp_entry2(WaveLds32 &L, uint64_t e0, uint64_t e1, uint32_t coef, bool act0, bool act1, const MontDev &F, uint32_t &nl)
@@ -374,11 +356,13 @@ __device__ __forceinline__ void sp_entry2(WaveLds32 &L, uint64_t e0, uint64_t e1
 
 __device__ __forceinline__ void sp_own_entry(WaveLds32 &L, uint32_t c, uint32_t val, bool act, const MontDev &F, uint32_t &nl)
 {
+	uint32_t old = 1;
 	if (act) {
 		uint32_t *a = L.acc + c;
-		*a = sp_addmod(*a, val, F.p);
+		old = *a;
+		*a = sp_addmod(old, val, F.p);
 	}
-	sp_mark(L, act ? c : 0u, act, nl);
+	sp_list_new(L, act ? c : 0u, old == 0, nl);
 }
 
 // where a fragment lies: chunk 0 of the pool (the only one unless a build ran out of room) is a kernel argument in scalar
@@ -551,86 +535,123 @@ __device__ __forceinline__ int wave_incl_scan(int x)
 	return x;
 }
 
-// The columns the segment touched whose sums are not zero, in column order, through put(position, column, raw sum); the
-// accumulators and the bitmap go back to zero.  nl = touched columns (sp_mark).  Returns the number of entries put.
-// All 64 lanes come here; put is called by the lanes that hold an entry.
+// The columns of the segment whose sums are not zero, in column order, through put(position, column, raw sum); the accumulators
+// (and the bitmap this pass uses) go back to zero.  nl = length of the list (sp_list_new).  Returns the number of entries.
+// All 64 lanes come here; put is called by the lanes that hold an entry (a column listed twice is put twice: same place, same word).
+// Sorted output without sorting: the listed columns with a non-zero sum set their bits in the bitmap; the rank of column c is
+// prefix[word of c] + popcount(bits of that word below c) -- the prefixes come from ONE packed scan of the words' popcounts and
+// stay in registers (a lane fetches the one it needs with ds_bpermute).
 template <typename LDS, typename PUT> __device__ __forceinline__ int sp_emit_sorted(LDS &L, uint32_t nl, int lane, PUT put)
 {
 	if (nl <= (uint32_t) LISTCAP) {
-		// (1) a column whose sum came back to zero leaves the bitmap
-		for (uint32_t i0 = 0; i0 < nl; i0 += 64) {
-			const uint32_t i = i0 + (uint32_t) lane;
-			if (i < nl) {
-				const uint32_t c = L.list[i];
-				if (sp_acc_get(L, c) == 0)
-					atomicAnd(&L.bm[c >> 5], ~(1u << (c & 31u)));
+		// lane l holds the words l, 64 + l (, 128 + l, 192 + l) of the bitmap: how many columns stand before each of them
+		// (exclusive prefixes, two to a register)
+		uint32_t pa = 0, pb = 0;
+		int total = 0;
+		auto prefixes = [&]() {
+			const uint32_t w0 = L.bm[lane], w1 = L.bm[64 + lane];
+			const uint32_t w2 = (WPL > 2) ? L.bm[(128 + lane) % BMW] : 0u, w3 = (WPL > 2) ? L.bm[(192 + lane) % BMW] : 0u;
+			const int c0 = __popc(w0), c1 = __popc(w1), c2 = __popc(w2), c3 = __popc(w3);
+			const int ia = wave_incl_scan(c0 | (c1 << 16));          // (a field holds at most 64 * 32)
+			const int ta = __builtin_amdgcn_readlane(ia, 63);
+			const int t0 = ta & 0xFFFF, t1 = ta >> 16;
+			total = t0 + t1;
+			pa = (uint32_t) ((ia & 0xFFFF) - c0) | ((uint32_t) (t0 + (ia >> 16) - c1) << 16);
+			if (WPL > 2) {
+				const int ib = wave_incl_scan(c2 | (c3 << 16));
+				const int tb = __builtin_amdgcn_readlane(ib, 63);
+				const int t2 = tb & 0xFFFF, t3 = tb >> 16;
+				pb = (uint32_t) (t0 + t1 + (ib & 0xFFFF) - c2) | ((uint32_t) (t0 + t1 + t2 + (ib >> 16) - c3) << 16);
+				total += t2 + t3;
 			}
-		}
-		// (2) lane l holds the words l, 64 + l (, 128 + l, 192 + l): how many columns stand before each of them
-		const uint32_t w0 = L.bm[lane], w1 = L.bm[64 + lane];
-		const uint32_t w2 = (WPL > 2) ? L.bm[(128 + lane) % BMW] : 0u, w3 = (WPL > 2) ? L.bm[(192 + lane) % BMW] : 0u;
-		const int c0 = __popc(w0), c1 = __popc(w1), c2 = __popc(w2), c3 = __popc(w3);
-		const int ia = wave_incl_scan(c0 | (c1 << 16));          // (a field holds at most 64 * 32)
-		const int ta = __builtin_amdgcn_readlane(ia, 63);
-		const int t0 = ta & 0xFFFF, t1 = ta >> 16;
-		int total = t0 + t1;
-		// exclusive prefixes of this lane's words, two to a register
-		const uint32_t pa = (uint32_t) ((ia & 0xFFFF) - c0) | ((uint32_t) (t0 + (ia >> 16) - c1) << 16);
-		uint32_t pb = 0;
-		if (WPL > 2) {
-			const int ib = wave_incl_scan(c2 | (c3 << 16));
-			const int tb = __builtin_amdgcn_readlane(ib, 63);
-			const int t2 = tb & 0xFFFF, t3 = tb >> 16;
-			pb = (uint32_t) (t0 + t1 + (ib & 0xFFFF) - c2) | ((uint32_t) (t0 + t1 + t2 + (ib >> 16) - c3) << 16);
-			total += t2 + t3;
-		}
-		// (3) every listed column whose sum is not zero goes to its rank
-		for (uint32_t i0 = 0; i0 < nl; i0 += 64) {
-			const uint32_t i = i0 + (uint32_t) lane;
-			const bool in = i < nl;
-			const uint32_t c = in ? (uint32_t) L.list[i] : 0u;
+		};
+		// the rank of column c among the columns of the bitmap (all 64 lanes call this: ds_bpermute reads the lanes' registers)
+		auto rank_of = [&](uint32_t c) -> uint32_t {
 			const uint32_t w = c >> 5;
 			const uint32_t bits = L.bm[w];
-			auto v = sp_acc_get(L, c);
-			if (in)
-				sp_acc_zero(L, c);
 			uint32_t pk = (uint32_t) __builtin_amdgcn_ds_bpermute((int) ((w & 63u) << 2), (int) pa);
 			if (WPL > 2) {
 				const uint32_t pk2 = (uint32_t) __builtin_amdgcn_ds_bpermute((int) ((w & 63u) << 2), (int) pb);
 				pk = (w & 128u) ? pk2 : pk;
 			}
 			const uint32_t before = (w & 64u) ? (pk >> 16) : (pk & 0xFFFFu);
-			const uint32_t rank = before + (uint32_t) __popc(bits & ((1u << (c & 31u)) - 1u));
-			if (in && v != 0)
-				put(rank, c, v);
+			return before + (uint32_t) __popc(bits & ((1u << (c & 31u)) - 1u));
+		};
+		if (nl <= 128) {
+			// the usual case: the listed columns and their sums stay in registers between the two steps
+			const bool in0 = (uint32_t) lane < nl, in1 = (uint32_t) lane + 64 < nl;
+			const uint32_t c0 = in0 ? (uint32_t) L.list[lane] : 0u, c1 = in1 ? (uint32_t) L.list[lane + 64] : 0u;
+			auto v0 = sp_acc_get(L, c0), v1 = sp_acc_get(L, c1);
+			if (!in0)
+				v0 = 0;
+			if (!in1)
+				v1 = 0;
+			if (v0 != 0)
+				atomicOr(&L.bm[c0 >> 5], 1u << (c0 & 31u));
+			if (v1 != 0)
+				atomicOr(&L.bm[c1 >> 5], 1u << (c1 & 31u));
+			if (in0)
+				sp_acc_zero(L, c0);
+			if (in1)
+				sp_acc_zero(L, c1);
+			prefixes();
+			const uint32_t r0 = rank_of(c0);
+			if (v0 != 0)
+				put(r0, c0, v0);
+			if (nl > 64) {
+				const uint32_t r1 = rank_of(c1);
+				if (v1 != 0)
+					put(r1, c1, v1);
+			}
+		} else {
+			for (uint32_t i0 = 0; i0 < nl; i0 += 64) {
+				const uint32_t i = i0 + (uint32_t) lane;
+				if (i < nl) {
+					const uint32_t c = L.list[i];
+					if (sp_acc_get(L, c) != 0)
+						atomicOr(&L.bm[c >> 5], 1u << (c & 31u));
+				}
+			}
+			// (LDS operations of a wave are served in order: the reads see the bits)
+			prefixes();
+			for (uint32_t i0 = 0; i0 < nl; i0 += 64) {
+				const uint32_t i = i0 + (uint32_t) lane;
+				const bool in = i < nl;
+				const uint32_t c = in ? (uint32_t) L.list[i] : 0u;
+				auto v = sp_acc_get(L, c);
+				if (!in)
+					v = 0;
+				const uint32_t rank = rank_of(c);
+				if (v != 0)
+					put(rank, c, v);
+			}
+			// (a column listed twice must show its sum to both copies: the accumulators go back to zero last)
+			for (uint32_t i0 = 0; i0 < nl; i0 += 64) {
+				const uint32_t i = i0 + (uint32_t) lane;
+				if (i < nl)
+					sp_acc_zero(L, (uint32_t) L.list[i]);
+			}
 		}
 #pragma unroll
 		for (int t = 0; t < WPL; t++)
 			L.bm[64 * t + lane] = 0;
 		return total;
 	}
-	// many columns: 64 consecutive columns at a time, straight from the bitmap
+	// many columns: 64 consecutive columns at a time, straight from the accumulators
 	uint32_t w = 0;
 	for (int ch = 0; ch < SP_SEG / 64; ch++) {
-		const uint32_t mlo = (uint32_t) __builtin_amdgcn_readfirstlane((int) L.bm[2 * ch]), mhi = (uint32_t) __builtin_amdgcn_readfirstlane((int) L.bm[2 * ch + 1]);
-		if ((mlo | mhi) == 0)
-			continue;
 		const uint32_t c = (uint32_t) ch * 64u + (uint32_t) lane;
-		const bool t = ((lane < 32 ? mlo >> lane : mhi >> (lane - 32)) & 1u) != 0;
-		auto v = sp_acc_get(L, c);
-		if (!t)
-			v = 0;
-		if (t)
-			sp_acc_zero(L, c);
+		const auto v = sp_acc_get(L, c);
 		const uint64_t nz = __ballot(v != 0);
+		if (nz == 0)
+			continue;
 		const uint32_t pos = __builtin_amdgcn_mbcnt_hi((uint32_t) (nz >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t) nz, w));
-		if (v != 0)
+		if (v != 0) {
+			sp_acc_zero(L, c);
 			put(pos, c, v);
+		}
 		w += (uint32_t) __popcll(nz);
 	}
-#pragma unroll
-	for (int t = 0; t < WPL; t++)
-		L.bm[64 * t + lane] = 0;
 	return (int) w;
 }
 
@@ -667,6 +688,7 @@ constexpr uint64_t FRAG_FAILED = ~0ull - 1;              // could not be compute
 constexpr int SP_TICKETS = 16, SP_TICKET_STRIDE = 32;    // ticket counters, one 128-byte line each
 
 struct SpBuildArgs {
+	const uint2 *head;            // 8 words per row: the lists of a row of at most seven entries (word 0: counts; 0xFFFFFFFF: see the lists below)
 	const uint64_t *dep_rp;
 	const uint2 *dep;
 	const uint64_t *np_rp;
@@ -759,21 +781,14 @@ __device__ __forceinline__ void sp_build_task(const SpBuildArgs &b, LDS &L, int 
 	const uint32_t col0 = (uint32_t) g * SP_SEG;
 	const SgnDev G = b.G;
 	const MontDev M = b.M;
-	const uint64_t d0 = sp_uniform(b.dep_rp[c]), d1 = sp_uniform(b.dep_rp[c + 1]), n0 = sp_uniform(b.np_rp[c]), n1 = sp_uniform(b.np_rp[c + 1]);
 	uint64_t *fout = b.frag + (uint64_t) c * b.nseg + g;
 	unsigned long long ops = 0;
-	uint32_t nl = 0;                               // columns of the segment touched so far (sp_mark)
+	uint32_t nl = 0;                               // columns of the segment listed so far (sp_list_new)
 	bool touched = false, failed = false;          // (wave-uniform: they only ever change on ballots)
-	// the row's own non-pivotal entries that fall into this segment
-	for (uint64_t e = n0; e < n1; e += 64) {
-		uint32_t idx = 0xFFFFFFFFu;
-		int val = 0;
-		if (e + lane < n1) {
-			const uint2 en = b.np[e + lane];
-			idx = en.x - col0;
-			val = (int) en.y;
-		}
-		const bool in = idx < (uint32_t) SP_SEG;
+	// up to 64 non-pivotal entries of the row (lane: index among the non-pivotal columns, value): those of this segment
+	auto own_entries = [&](bool have, uint32_t x, int val) {
+		const uint32_t idx = x - col0;
+		const bool in = have && idx < (uint32_t) SP_SEG;
 		if (__ballot(in) != 0) {
 			touched = true;
 			if constexpr (W32)
@@ -781,21 +796,14 @@ __device__ __forceinline__ void sp_build_task(const SpBuildArgs &b, LDS &L, int 
 			else
 				sp_own_entry(L, idx, val, in, G, nl);
 		}
-	}
-	// minus the rows of R its pivotal entries point at (coefficients are stored negated)
-	for (uint64_t e = d0; e < d1; e += 64) {
+	};
+	// up to 64 pivotal entries of the row (lane: compact row of the pivot, negated coefficient): minus coefficient times their fragments
+	auto dependencies = [&](bool have, uint32_t row, int coef, int detail) {
 		uint64_t f = 0;
-		int coef = 0;
-		const bool have = e + lane < d1;
-		const uint64_t *fin = b.frag;
-		if (have) {
-			const uint2 de = b.dep[e + lane];
-			fin = b.frag + (uint64_t) de.x * b.nseg + g;
-			coef = (int) de.y;
-		}
+		const uint64_t *fin = have ? b.frag + (uint64_t) row * b.nseg + g : b.frag;
 		st.mark(1);
 		if (PERSISTENT) {
-			sp_dbg(b, lane, 2, (long long) c * b.nseg + g, (int) (e - d0));
+			sp_dbg(b, lane, 2, (long long) c * b.nseg + g, detail);
 			f = have ? __hip_atomic_load(fin, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0;
 			long long polls = 0;
 			while (__ballot(f == FRAG_PENDING) != 0) {
@@ -821,12 +829,35 @@ __device__ __forceinline__ void sp_build_task(const SpBuildArgs &b, LDS &L, int 
 		if (!failed && __ballot((f & LEN_MASK) != 0) != 0) {
 			touched = true;
 			if (PERSISTENT)
-				sp_dbg(b, lane, 3, (long long) c * b.nseg + g, (int) (e - d0));
+				sp_dbg(b, lane, 3, (long long) c * b.nseg + g, detail);
 			if constexpr (W32)
 				sp_accumulate<PERSISTENT>(L, f, (uint32_t) coef, true, b.pools, lane, M, ops, nl);
 			else
 				sp_accumulate<PERSISTENT>(L, f, coef, true, b.pools, lane, G, ops, nl);
 			st.mark(3);
+		}
+	};
+	// The row's lists.  Rows of U' are short (mk15.b4: five entries on average): a row of at most seven entries has them ALL in
+	// its 64-byte head -- word 0: the counts, then the pivotal entries, then the non-pivotal ones -- one trip to memory where the
+	// four row pointers and the two lists took three, one after the other (metadata: 26 % of the build's wave-cycles).
+	const uint2 hd = (lane < 8 && b.head != nullptr) ? b.head[(uint64_t) c * 8 + lane] : uint2{0xFFFFFFFFu, 0u};
+	const uint32_t counts = (uint32_t) __builtin_amdgcn_readfirstlane((int) hd.x);
+	if (counts != 0xFFFFFFFFu) {
+		const int nd = (int) (counts & 0xFFFFu), nn = (int) (counts >> 16);
+		own_entries(lane > nd && lane <= nd + nn, hd.x, (int) hd.y);
+		if (nd > 0)
+			dependencies(lane >= 1 && lane <= nd, hd.x, (int) hd.y, 0);
+	} else {
+		const uint64_t d0 = sp_uniform(b.dep_rp[c]), d1 = sp_uniform(b.dep_rp[c + 1]), n0 = sp_uniform(b.np_rp[c]), n1 = sp_uniform(b.np_rp[c + 1]);
+		for (uint64_t e = n0; e < n1; e += 64) {
+			const bool have = e + lane < n1;
+			const uint2 en = have ? b.np[e + lane] : uint2{0u, 0u};
+			own_entries(have, en.x, (int) en.y);
+		}
+		for (uint64_t e = d0; e < d1; e += 64) {
+			const bool have = e + lane < d1;
+			const uint2 de = have ? b.dep[e + lane] : uint2{0u, 0u};
+			dependencies(have, de.x, (int) de.y, (int) (e - d0));
 		}
 	}
 	st.mark(1);
@@ -916,6 +947,9 @@ template <bool PERSISTENT, bool W32 = false> __global__ __launch_bounds__(64) vo
 		const int q = (int) (blockIdx.x % SP_TICKETS);
 		const long long ntasks = (long long) (b.row_hi - b.row_lo) * b.nseg;
 		SpWaveState ws;
+		// (drawing the ticket of the next task before the current one runs -- the returning atomic costs 1.3 us of a task's 7.5 -- was
+		//  measured and LOST: 11.4 -> 12.9 ms on mk14.b4's factor, 14.8 -> 15.1 on mk15.b4's: a task held by a wave that is still
+		//  busy with the one before is a task the chain of levels waits for)
 		for (;;) {
 			const int j = l0_atomic_add_i32_ret(b.ticket + q * SP_TICKET_STRIDE, 1);
 			const long long t = (long long) j * SP_TICKETS + q;
@@ -941,6 +975,20 @@ template <bool PERSISTENT, bool W32 = false> __global__ __launch_bounds__(64) vo
 		l0_atomic_add_u64(&S[5], ws.reserved + (unsigned long long) (ws.ar_end - ws.ar_cur));
 	}
 	st.flush(lane);
+}
+
+// which segments of every row of R hold anything: one bit per segment, (nseg + 63) / 64 words per row
+__global__ __launch_bounds__(256) void sp_rowmask_kernel(const uint64_t *frag, int r, int nseg, uint64_t *mask)
+{
+	const int nmw = (nseg + 63) >> 6;
+	for (int64_t t = (int64_t) blockIdx.x * blockDim.x + threadIdx.x; t < (int64_t) r * nmw; t += (int64_t) gridDim.x * blockDim.x) {
+		const int64_t c = t / nmw;
+		const int b = (int) (t - c * nmw);
+		uint64_t m = 0;
+		for (int g = 64 * b; g < nseg && g < 64 * b + 64; g++)
+			m |= ((frag[(uint64_t) c * nseg + g] & LEN_MASK) != 0 ? 1ull : 0ull) << (g & 63);
+		mask[t] = m;
+	}
 }
 
 // entries of R: the lengths of all fragments (after a build that redid levels the counters of the shards count those twice)
@@ -996,13 +1044,14 @@ struct SpApplyArgs {
 	const int *col;               // column -> compact id of its pivot row, or r + index among the non-pivotal columns
 	int r, nseg;
 	const uint64_t *frag;
+	const uint64_t *rowmask;      // per row of R, (nseg + 63) / 64 words: its non-empty segments
 	SpPools pools;
 	SgnDev G;
 	uint32_t *fpool;              // fragments of S (column inside the segment | value << 16, values in [-p/2, p/2])
 	uint32_t *fpool_v;            // the 32-bit variant: fpool holds the columns, this the values in [0, p)
 	int64_t fcap;
-	uint64_t *T;                  // nrows x nseg: offset << SP_LEN_BITS | length of the fragment of (row, segment)
-	uint32_t *D;                  // nrows x nseg: entries of the row in the segments before this one (where the gather puts the fragment)
+	uint64_t *T;                  // nseg x nrows (segment-major: the gather walks a segment): offset << SP_LEN_BITS | length of the fragment of (row, segment)
+	uint32_t *D;                  // nseg x nrows: entries of the row in the segments before this one (where the gather puts the fragment)
 	unsigned long long *block_sum;// sum of the lengths of every block of 1024 rows (zeroed before the launch)
 	int arena;                    // entries a wave reserves from the pool at a time (0: every fragment on its own)
 	int *ticket;                  // SP_TICKETS counters handing out the rows (zeroed before the launch)
@@ -1076,21 +1125,22 @@ template <bool W32> __global__ __launch_bounds__(64) void sp_apply_kernel(SpAppl
 		int total = 0;
 		uint64_t tw = 0;          // lane (g mod 64) holds the word of T of segment g ...
 		uint32_t td = 0;          // ... and the entries of the row before it
-		uint64_t *trow = d.T + (uint64_t) k * nseg;
-		uint32_t *drow = d.D + (uint64_t) k * nseg;
+		// (T and D are segment-major: row k's words of segments [64 b, 64 b + 64) leave in one store, one line per lane)
 		auto keep = [&](int g, uint64_t word, int cnt) {
 			if (lane == (g & 63)) {
 				tw = word;
 				td = (uint32_t) total;
 			}
 			total += cnt;
-			if ((g & 63) == 63 || g + 1 == nseg) {
-				const int g0 = g & ~63;
-				if (g0 + lane <= g) {
-					trow[g0 + lane] = tw;
-					drow[g0 + lane] = td;
-				}
+		};
+		auto flush = [&](int b) {
+			const int g = 64 * b + lane;
+			if (g < nseg) {
+				d.T[(uint64_t) g * nrows + k] = tw;
+				d.D[(uint64_t) g * nrows + k] = td;
 			}
+			tw = 0;
+			td = 0;
 		};
 		if (hi - lo <= 64) {
 			// the row in registers: lane e holds entry e
@@ -1111,43 +1161,68 @@ template <bool W32> __global__ __launch_bounds__(64) void sp_apply_kernel(SpAppl
 			const bool piv = cid < (uint32_t) d.r && bal != 0;
 			const bool own = cid != 0xFFFFFFFFu && cid >= (uint32_t) d.r;
 			const uint32_t idx_all = cid - (uint32_t) d.r;          // (own entries: index among the non-pivotal columns)
+			const int own_seg = own ? (int) (idx_all / (uint32_t) SP_SEG) : -1;
 			const uint64_t *fin = d.frag + (piv ? (uint64_t) cid * nseg : 0);
 			st_piv += piv ? 1 : 0;
 			using ENT = typename std::conditional<W32, uint64_t, uint32_t>::type;
 			using COEF = typename std::conditional<W32, uint32_t, int>::type;
-			uint64_t f = piv ? fin[0] : 0;
-			uint64_t fn = (piv && nseg > 1) ? fin[1] : 0;
-			SpGroup<ENT, COEF> cur, nxt;
-			sp_group_issue(cur, f, (COEF) ncoef, piv, d.pools, lane);
-			st.mark(0);
-			for (int g = 0; g < nseg; g++) {
-				const uint64_t fnn = (piv && g + 2 < nseg) ? fin[g + 2] : 0;
-				sp_group_issue(nxt, fn, (COEF) ncoef, piv, d.pools, lane);          // (beyond the last segment: fn = 0, eight loads of the pool's first word)
-				const uint32_t idx = idx_all - (uint32_t) g * SP_SEG;
-				const bool in = own && idx < (uint32_t) SP_SEG;
-				const bool touched = (__ballot(in) | __ballot(piv && (f & LEN_MASK) != 0)) != 0;
-				st.mark(1);
-				uint64_t word = 0;
-				int cnt = 0;
-				if (touched) {
-					uint32_t nl = 0;
-					if constexpr (W32) {
-						if (__ballot(in) != 0)
-							sp_own_entry(L, idx, (uint32_t) bal, in, F, nl);
-						sp_group_consume(L, cur, f, (COEF) ncoef, d.pools, lane, F, ops, nl);
-					} else {
-						if (__ballot(in) != 0)
-							sp_own_entry(L, idx, bal, in, G, nl);
-						sp_group_consume(L, cur, f, (COEF) ncoef, d.pools, lane, G, ops, nl);
-					}
-					st.mark(2);
-					word = finish(nl, cnt);
+			const int nmw = (nseg + 63) >> 6;
+			const uint64_t piv_lanes = __ballot(piv), own_lanes = __ballot(own);
+			for (int b = 0; b < nmw; b++) {
+				// the segments of this block of 64 in which the row can hold anything: where one of its rows of R has entries,
+				// and where its own non-pivotal entries fall -- no other segment is visited
+				const uint64_t rm = piv ? d.rowmask[(uint64_t) cid * nmw + b] : 0;
+				uint64_t mask = 0;
+				for (uint64_t pl = piv_lanes; pl != 0; pl &= pl - 1)
+					mask |= readlane64(rm, __builtin_ctzll(pl));
+				for (uint64_t ol = own_lanes; ol != 0; ol &= ol - 1) {
+					const int sg = __builtin_amdgcn_readlane(own_seg, __builtin_ctzll(ol)) - 64 * b;
+					if (sg >= 0 && sg < 64)
+						mask |= 1ull << sg;
 				}
-				keep(g, word, cnt);
-				st.mark(5);
-				f = fn;
-				fn = fnn;
-				cur = nxt;
+				st.mark(0);
+				if (mask != 0) {
+					int g = 64 * b + __builtin_ctzll(mask);
+					uint64_t m = mask & (mask - 1);
+					int gn = (m != 0) ? 64 * b + __builtin_ctzll(m) : -1;
+					uint64_t f = piv ? fin[g] : 0;
+					uint64_t fn = (piv && gn >= 0) ? fin[gn] : 0;
+					SpGroup<ENT, COEF> cur, nxt;
+					sp_group_issue(cur, f, (COEF) ncoef, piv, d.pools, lane);
+					for (;;) {
+						const uint64_t m2 = (m != 0) ? (m & (m - 1)) : 0;
+						const int gnn = (m2 != 0) ? 64 * b + __builtin_ctzll(m2) : -1;
+						const uint64_t fnn = (piv && gnn >= 0) ? fin[gnn] : 0;
+						sp_group_issue(nxt, fn, (COEF) ncoef, piv, d.pools, lane);          // (after the last segment: fn = 0, eight loads of the pool's first word)
+						const uint32_t idx = idx_all - (uint32_t) g * SP_SEG;
+						const bool in = own && idx < (uint32_t) SP_SEG;
+						st.mark(1);
+						uint32_t nl = 0;
+						int cnt = 0;
+						if constexpr (W32) {
+							if (__ballot(in) != 0)
+								sp_own_entry(L, idx, (uint32_t) bal, in, F, nl);
+							sp_group_consume(L, cur, f, (COEF) ncoef, d.pools, lane, F, ops, nl);
+						} else {
+							if (__ballot(in) != 0)
+								sp_own_entry(L, idx, bal, in, G, nl);
+							sp_group_consume(L, cur, f, (COEF) ncoef, d.pools, lane, G, ops, nl);
+						}
+						st.mark(2);
+						const uint64_t word = (nl != 0) ? finish(nl, cnt) : 0;
+						keep(g, word, cnt);
+						st.mark(5);
+						if (gn < 0)
+							break;
+						g = gn;
+						gn = gnn;
+						m = m2;
+						f = fn;
+						fn = fnn;
+						cur = nxt;
+					}
+				}
+				flush(b);
 			}
 		} else {
 			for (int g = 0; g < nseg; g++) {
@@ -1196,6 +1271,8 @@ template <bool W32> __global__ __launch_bounds__(64) void sp_apply_kernel(SpAppl
 				if (touched)
 					word = finish(nl, cnt);
 				keep(g, word, cnt);
+				if ((g & 63) == 63 || g + 1 == nseg)
+					flush(g >> 6);
 			}
 		}
 		st_done += 1;
@@ -1228,42 +1305,53 @@ struct SpGatherArgs {
 	const int *q;                 // index among the non-pivotal columns -> column
 };
 
-// The fragments of S as (column, value) pairs at their final place, SEGMENT BY SEGMENT: a workgroup keeps the 4,096 columns of its
-// segment's piece of q in LDS (16 KB; by row, every entry paid a trip to the L1 for its column: 9.9 -> 6.4 ms measured without the
-// look-up in round 5) and walks SP_GATHER_ROWS rows; where a fragment goes inside its row is D, written by the apply kernel.
-constexpr int SP_GATHER_ROWS = 2048;
+// The fragments of S as (column, value) pairs at their final place.  A workgroup takes SP_GATHER_ROWS rows through the segments one
+// after the other, with the 4,096 columns of the segment's piece of q in LDS (by row, every entry paid a trip to the L1 for its
+// column: 9.9 -> 6.4 ms measured without the look-up in round 5); where a fragment goes inside its row is D, written by the apply
+// kernel.  The pieces of a row are written by ONE workgroup, one behind the other: the lines they share meet in one L2 (a grid of
+// (segment, row block) workgroups -- the first version of this kernel -- had them written from eight: 6.9 ms against round 5's 4.4
+// on mk14.b4).
+constexpr int SP_GATHER_ROWS = 256;
+#ifndef SPASM_SP_GATHER_UNROLL
+#define SPASM_SP_GATHER_UNROLL 8
+#endif
+constexpr int SP_GATHER_UNROLL = SPASM_SP_GATHER_UNROLL;
 template <bool W32> __global__ __launch_bounds__(256) void sp_gather_kernel(SpGatherArgs e)
 {
 	__shared__ int qs[SP_SEG];
-	const int g = (int) (blockIdx.x % (unsigned) e.nseg);
-	const int k_lo = (int) (blockIdx.x / (unsigned) e.nseg) * SP_GATHER_ROWS;
+	const int k_lo = (int) blockIdx.x * SP_GATHER_ROWS;
 	const int k_hi = (k_lo + SP_GATHER_ROWS < e.nrows) ? k_lo + SP_GATHER_ROWS : e.nrows;
-	const int ncols = (e.Sm - g * SP_SEG < SP_SEG) ? e.Sm - g * SP_SEG : SP_SEG;
-	for (int t = threadIdx.x; t < ncols; t += 256)
-		qs[t] = e.q[(int64_t) g * SP_SEG + t];
-	__syncthreads();
 	const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-	for (int k0 = k_lo + 64 * wave; k0 < k_hi; k0 += 256) {
-		const int k = k0 + lane;
+	const int k = k_lo + 64 * wave + lane;
+	int64_t off = 0;
+	bool row_ok = false;
+	if (k < k_hi) {
+		off = e.Sp[k];
+		const int64_t end = e.Sp[k + 1];
+		row_ok = end <= e.cap && end != off;
+	}
+	for (int g = 0; g < e.nseg; g++) {
+		const int ncols = (e.Sm - g * SP_SEG < SP_SEG) ? e.Sm - g * SP_SEG : SP_SEG;
+		__syncthreads();
+		for (int t = threadIdx.x; t < ncols; t += 256)
+			qs[t] = e.q[(int64_t) g * SP_SEG + t];
+		__syncthreads();
 		uint64_t t = 0;
 		int64_t dst = 0;
-		if (k < k_hi) {
-			const int64_t off = e.Sp[k], end = e.Sp[k + 1];
-			if (end <= e.cap && end != off) {
-				t = e.T[(uint64_t) k * e.nseg + g];
-				dst = off + (int64_t) e.D[(uint64_t) k * e.nseg + g];
-			}
+		if (row_ok) {
+			t = e.T[(uint64_t) g * e.nrows + k];
+			dst = off + (int64_t) e.D[(uint64_t) g * e.nrows + k];
 		}
 		uint64_t live = __ballot((t & LEN_MASK) != 0);
-		// four fragments at a time, their first 64 entries in flight together (one at a time, a wave spent its time waiting for
+		// SP_GATHER_UNROLL fragments at a time, their first 64 entries in flight together (one at a time, a wave spent its time waiting for
 		// one load after the other: 40 M fragments of 20-60 entries)
 		while (live != 0) {
-			const uint32_t *src[4];
-			int len[4];
-			int64_t w[4];
-			uint32_t h[4], hv[4];
+			const uint32_t *src[SP_GATHER_UNROLL];
+			int len[SP_GATHER_UNROLL];
+			int64_t w[SP_GATHER_UNROLL];
+			uint32_t h[SP_GATHER_UNROLL], hv[SP_GATHER_UNROLL];
 #pragma unroll
-			for (int u = 0; u < 4; u++) {
+			for (int u = 0; u < SP_GATHER_UNROLL; u++) {
 				len[u] = 0;
 				w[u] = 0;
 				src[u] = e.fpool;
@@ -1281,7 +1369,7 @@ template <bool W32> __global__ __launch_bounds__(256) void sp_gather_kernel(SpGa
 					hv[u] = (e.fpool_v + (src[u] - e.fpool))[lane < len[u] ? lane : 0];
 			}
 #pragma unroll
-			for (int u = 0; u < 4; u++) {
+			for (int u = 0; u < SP_GATHER_UNROLL; u++) {
 				if (len[u] == 0)
 					continue;
 				int *oj = e.Sj + w[u], *ox = e.Sx + w[u];
@@ -1336,7 +1424,7 @@ struct SpPending {
 	double t_start = 0.0, t_done = 0.0;
 	std::vector<int> colmap;
 	std::vector<uint64_t> dep_rp, np_rp, segmask;
-	std::vector<uint2> dep, np;
+	std::vector<uint2> dep, np, head;
 };
 
 // what the path choice reads: known at once
@@ -1453,6 +1541,25 @@ static void sparse_image_plan_host(const FactPlan &P, bool wide, SpPending &H)
 			}
 		}
 	});
+	// the 64-byte heads: word 0 = (pivotal entries | non-pivotal entries << 16, 0), then the entries themselves; rows of more than seven
+	// entries keep their lists (word 0 = all ones)
+	std::vector<uint2> &head = H.head;
+	head.assign((size_t) 8 * (size_t) (r > 0 ? r : 1), uint2{0u, 0u});
+	for_rows([&](int n_lo, int n_hi) {
+		for (int n = n_lo; n < n_hi; n++) {
+			const uint64_t nd = dep_rp[n + 1] - dep_rp[n], nn = np_rp[n + 1] - np_rp[n];
+			uint2 *h = &head[(size_t) 8 * (size_t) n];
+			if (nd + nn > 7) {
+				h[0] = uint2{0xFFFFFFFFu, 0u};
+				continue;
+			}
+			h[0] = uint2{(uint32_t) nd | ((uint32_t) nn << 16), 0u};
+			for (uint64_t e = 0; e < nd; e++)
+				h[1 + e] = dep[dep_rp[n] + e];
+			for (uint64_t e = 0; e < nn; e++)
+				h[1 + nd + e] = np[np_rp[n] + e];
+		}
+	});
 	// Which (row, segment) pairs can hold anything at all: a row's own non-pivotal entries and the segments of the rows it depends
 	// on (rows with larger compact ids: one pass from the last row to the first).  Half of the pairs of the generated families
 	// are empty (mk15.b4: 47-49 %), and their tasks used to read the row's lists and poll its dependencies to find that out
@@ -1482,6 +1589,8 @@ static void sparse_image_plan_device(SpImage &S, SpPending &H, int m, hipStream_
 	S.d_dep = dalloc<uint2>((int64_t) H.dep.size());
 	S.d_np_rp = dalloc<uint64_t>((int64_t) r + 1);
 	S.d_np = dalloc<uint2>((int64_t) H.np.size());
+	S.d_head = dalloc<uint2>((int64_t) H.head.size());
+	upload(S.d_head, H.head, stream);
 	upload(S.d_col, H.colmap, stream);
 	upload(S.d_dep_rp, H.dep_rp, stream);
 	upload(S.d_dep, H.dep, stream);
@@ -1570,6 +1679,8 @@ void sparse_image_free(spasm_hip_dfact *F)
 	sh::big_free(S.d_np_rp);
 	sh::big_free(S.d_np);
 	sh::big_free(S.d_segmask);
+	sh::big_free(S.d_head);
+	sh::big_free(S.d_rowmask);
 	sh::big_free(S.d_frag);
 	sh::big_free(S.d_shard);
 	if (S.ev0 != nullptr)
@@ -1630,6 +1741,7 @@ bool sparse_image_build(const spasm_hip_dfact *F, hipStream_t stream)
 		S.nchunks = 1;
 	}
 	SpBuildArgs b{};
+	b.head = S.d_head;
 	b.dep_rp = S.d_dep_rp;
 	b.dep = S.d_dep;
 	b.np_rp = S.d_np_rp;
@@ -1855,7 +1967,7 @@ bool sparse_image_build(const spasm_hip_dfact *F, hipStream_t stream)
 		S.failed = true;
 		HIP_CHECK(hipStreamSynchronize(stream));
 		sparse_image_drop_chunks(S);
-		for (void **ptr : {(void **) &S.d_frag, (void **) &S.d_shard, (void **) &S.d_col, (void **) &S.d_dep_rp, (void **) &S.d_dep, (void **) &S.d_np_rp, (void **) &S.d_np, (void **) &S.d_segmask}) {
+		for (void **ptr : {(void **) &S.d_frag, (void **) &S.d_shard, (void **) &S.d_col, (void **) &S.d_dep_rp, (void **) &S.d_dep, (void **) &S.d_np_rp, (void **) &S.d_np, (void **) &S.d_segmask, (void **) &S.d_rowmask, (void **) &S.d_head}) {
 			sh::big_free(*ptr);          // (the tables of the plan too: the dependencies and the non-pivotal entries of every row)
 			*ptr = nullptr;
 		}
@@ -1898,6 +2010,9 @@ bool sparse_image_build(const spasm_hip_dfact *F, hipStream_t stream)
 		fprintf(stderr, " %.3g cycles in all\n", tot);
 		sh::big_free(d_prof);
 	}
+	if (S.d_rowmask == nullptr)
+		S.d_rowmask = dalloc<uint64_t>((int64_t) S.r * ((S.nseg + 63) / 64));
+	hipLaunchKernelGGL(sp_rowmask_kernel, dim3(1024), dim3(256), 0, stream, S.d_frag, S.r, S.nseg, S.d_rowmask);
 	S.valid = true;
 	S.failed = false;
 	S.builds += 1;
@@ -1937,6 +2052,7 @@ void launch_sparse_image_apply(const SchurArgs &a, const spasm_hip_dfact *F, uin
 	d.r = S.r;
 	d.nseg = S.nseg;
 	d.frag = S.d_frag;
+	d.rowmask = S.d_rowmask;
 	for (int k = 0; k < SP_MAX_CHUNKS; k++)
 		d.pools.base[k] = S.d_chunk[k < S.nchunks ? k : 0];
 	d.G = sgn_setup(S.wide ? 3 : F->prime);
@@ -1991,10 +2107,7 @@ void launch_sparse_image_apply(const SchurArgs &a, const spasm_hip_dfact *F, uin
 		HIP_CHECK(hipEventRecord(ev_gather, stream));
 	launch_scan_lengths(a.row_len, a.nrows, block_sum, Sp, cap, a.ctr, stream);
 	SpGatherArgs e{T, d.D, fpool, fpool_v, (uint32_t) F->prime, a.nrows, S.nseg, S.Sm, Sp, Sj, Sx, cap, a.q};
-	const int64_t gblocks64 = (int64_t) ((a.nrows + SP_GATHER_ROWS - 1) / SP_GATHER_ROWS) * S.nseg;
-	if (gblocks64 > 0x7FFFFFFFll)
-		die("launch_sparse_image_apply: %lld workgroups for the gather", (long long) gblocks64);
-	const int gblocks = (int) gblocks64;
+	const int gblocks = (a.nrows + SP_GATHER_ROWS - 1) / SP_GATHER_ROWS;
 	if (S.wide)
 		hipLaunchKernelGGL(sp_gather_kernel<true>, dim3(gblocks), dim3(256), 0, stream, e);
 	else
