@@ -544,46 +544,52 @@ __device__ __forceinline__ int wave_incl_scan(int x)
 template <typename LDS, typename PUT> __device__ __forceinline__ int sp_emit_sorted(LDS &L, uint32_t nl, int lane, PUT put)
 {
 	if (nl <= (uint32_t) LISTCAP) {
-		// lane l holds the words l, 64 + l (, 128 + l, 192 + l) of the bitmap: how many columns stand before each of them
-		// (exclusive prefixes, two to a register)
+		// lane l holds the words 2l, 2l + 1 (, 128 + 2l, 129 + 2l) of the bitmap -- one 64-bit LDS access --: how many columns stand
+		// before its pair, and how many its first word holds (16 bits each in pa; pb: the second pair of a segment of 8,192 columns)
 		uint32_t pa = 0, pb = 0;
 		int total = 0;
+		uint64_t *bm64 = reinterpret_cast<uint64_t *>(L.bm);
 		auto prefixes = [&]() {
-			const uint32_t w0 = L.bm[lane], w1 = L.bm[64 + lane];
-			const uint32_t w2 = (WPL > 2) ? L.bm[(128 + lane) % BMW] : 0u, w3 = (WPL > 2) ? L.bm[(192 + lane) % BMW] : 0u;
-			const int c0 = __popc(w0), c1 = __popc(w1), c2 = __popc(w2), c3 = __popc(w3);
-			const int ia = wave_incl_scan(c0 | (c1 << 16));          // (a field holds at most 64 * 32)
-			const int ta = __builtin_amdgcn_readlane(ia, 63);
-			const int t0 = ta & 0xFFFF, t1 = ta >> 16;
-			total = t0 + t1;
-			pa = (uint32_t) ((ia & 0xFFFF) - c0) | ((uint32_t) (t0 + (ia >> 16) - c1) << 16);
-			if (WPL > 2) {
-				const int ib = wave_incl_scan(c2 | (c3 << 16));
-				const int tb = __builtin_amdgcn_readlane(ib, 63);
-				const int t2 = tb & 0xFFFF, t3 = tb >> 16;
-				pb = (uint32_t) (t0 + t1 + (ib & 0xFFFF) - c2) | ((uint32_t) (t0 + t1 + t2 + (ib >> 16) - c3) << 16);
-				total += t2 + t3;
-			}
+			const uint64_t wa = bm64[lane], wb = (WPL > 2) ? bm64[64 + lane] : 0ull;
+			const int ca = __popcll(wa), cb = __popcll(wb);
+			const int is = wave_incl_scan(ca | (cb << 16));          // (a field holds at most 64 * 64)
+			const int ts = __builtin_amdgcn_readlane(is, 63);
+			const int ta = ts & 0xFFFF;
+			total = ta + (ts >> 16);
+			pa = (uint32_t) ((is & 0xFFFF) - ca) | ((uint32_t) __popc((uint32_t) wa) << 16);
+			pb = (uint32_t) (ta + (is >> 16) - cb) | ((uint32_t) __popc((uint32_t) wb) << 16);
 		};
 		// the rank of column c among the columns of the bitmap (all 64 lanes call this: ds_bpermute reads the lanes' registers)
 		auto rank_of = [&](uint32_t c) -> uint32_t {
 			const uint32_t w = c >> 5;
 			const uint32_t bits = L.bm[w];
-			uint32_t pk = (uint32_t) __builtin_amdgcn_ds_bpermute((int) ((w & 63u) << 2), (int) pa);
+			uint32_t pk = (uint32_t) __builtin_amdgcn_ds_bpermute((int) (((w >> 1) & 63u) << 2), (int) pa);
 			if (WPL > 2) {
-				const uint32_t pk2 = (uint32_t) __builtin_amdgcn_ds_bpermute((int) ((w & 63u) << 2), (int) pb);
+				const uint32_t pk2 = (uint32_t) __builtin_amdgcn_ds_bpermute((int) (((w >> 1) & 63u) << 2), (int) pb);
 				pk = (w & 128u) ? pk2 : pk;
 			}
-			const uint32_t before = (w & 64u) ? (pk >> 16) : (pk & 0xFFFFu);
+			const uint32_t before = (pk & 0xFFFFu) + ((w & 1u) ? (pk >> 16) : 0u);
 			return before + (uint32_t) __popc(bits & ((1u << (c & 31u)) - 1u));
 		};
-		if (nl <= 128) {
-			// the usual case: the listed columns and their sums stay in registers between the two steps
-			const bool in0 = (uint32_t) lane < nl, in1 = (uint32_t) lane + 64 < nl;
-			const uint32_t c0 = in0 ? (uint32_t) L.list[lane] : 0u, c1 = in1 ? (uint32_t) L.list[lane + 64] : 0u;
-			auto v0 = sp_acc_get(L, c0), v1 = sp_acc_get(L, c1);
+		if (nl <= 64) {
+			// the usual case: one batch; the listed columns and their sums stay in registers between the two steps
+			const bool in0 = (uint32_t) lane < nl;
+			const uint32_t c0 = in0 ? (uint32_t) L.list[lane] : 0u;
+			auto v0 = sp_acc_get(L, c0);
 			if (!in0)
 				v0 = 0;
+			if (v0 != 0)
+				atomicOr(&L.bm[c0 >> 5], 1u << (c0 & 31u));
+			if (in0)
+				sp_acc_zero(L, c0);
+			prefixes();
+			const uint32_t r0 = rank_of(c0);
+			if (v0 != 0)
+				put(r0, c0, v0);
+		} else if (nl <= 128) {
+			const bool in0 = true, in1 = (uint32_t) lane + 64 < nl;
+			const uint32_t c0 = (uint32_t) L.list[lane], c1 = in1 ? (uint32_t) L.list[lane + 64] : 0u;
+			auto v0 = sp_acc_get(L, c0), v1 = sp_acc_get(L, c1);
 			if (!in1)
 				v1 = 0;
 			if (v0 != 0)
@@ -595,14 +601,11 @@ template <typename LDS, typename PUT> __device__ __forceinline__ int sp_emit_sor
 			if (in1)
 				sp_acc_zero(L, c1);
 			prefixes();
-			const uint32_t r0 = rank_of(c0);
+			const uint32_t r0 = rank_of(c0), r1 = rank_of(c1);
 			if (v0 != 0)
 				put(r0, c0, v0);
-			if (nl > 64) {
-				const uint32_t r1 = rank_of(c1);
-				if (v1 != 0)
-					put(r1, c1, v1);
-			}
+			if (v1 != 0)
+				put(r1, c1, v1);
 		} else {
 			for (uint32_t i0 = 0; i0 < nl; i0 += 64) {
 				const uint32_t i = i0 + (uint32_t) lane;
@@ -632,9 +635,9 @@ template <typename LDS, typename PUT> __device__ __forceinline__ int sp_emit_sor
 					sp_acc_zero(L, (uint32_t) L.list[i]);
 			}
 		}
-#pragma unroll
-		for (int t = 0; t < WPL; t++)
-			L.bm[64 * t + lane] = 0;
+		bm64[lane] = 0;
+		if (WPL > 2)
+			bm64[64 + lane] = 0;
 		return total;
 	}
 	// many columns: 64 consecutive columns at a time, straight from the accumulators
@@ -1039,6 +1042,11 @@ template <bool W32> __global__ __launch_bounds__(256) void sp_census_kernel(cons
 // ---------------------------------------------------------------------------------------------------
 // rows of S
 // ---------------------------------------------------------------------------------------------------
+#ifndef SPASM_SP_ROW_BATCH
+#define SPASM_SP_ROW_BATCH 4
+#endif
+constexpr int SP_ROW_BATCH = SPASM_SP_ROW_BATCH;          // rows of a ticket of sp_apply_kernel
+
 struct SpApplyArgs {
 	SchurArgs a;
 	const int *col;               // column -> compact id of its pivot row, or r + index among the non-pivotal columns
@@ -1114,13 +1122,53 @@ template <bool W32> __global__ __launch_bounds__(64) void sp_apply_kernel(SpAppl
 	// rows are handed out by ticket counters (their costs differ by orders of magnitude: with a fixed share per wave the
 	// kernel ran 1.6 times as long as its average wave)
 	const int q = (int) (blockIdx.x % SP_TICKETS);
+	// A ticket is a batch of SP_ROW_BATCH consecutive rows, and what the rows need before their first multiply-add -- row number,
+	// extent, entries, the pivot rows of their columns, the occupied segments of those -- is fetched for the whole batch at once:
+	// five trips to memory per batch where every row made them one after the other (7 % of the kernel's wave-cycles).
+	constexpr int RB = SP_ROW_BATCH;
 	for (;;) {
-		const long long kk = (long long) l0_atomic_add_i32_ret(d.ticket + q * SP_TICKET_STRIDE, 1) * SP_TICKETS + q;
-		if (kk >= nrows)
+		const long long k0 = ((long long) l0_atomic_add_i32_ret(d.ticket + q * SP_TICKET_STRIDE, 1) * SP_TICKETS + q) * RB;
+		if (k0 >= nrows)
 			break;
-		const int k = (int) kk;
-		const int i = __builtin_amdgcn_readfirstlane(a.rows[k]);
-		const int64_t lo = (int64_t) sp_uniform((uint64_t) a.Ap[i]), hi = (int64_t) sp_uniform((uint64_t) a.Ap[i + 1]);
+		const bool rl = lane < RB && k0 + lane < nrows;
+		const int i_l = rl ? a.rows[k0 + lane] : 0;
+		const int64_t lo_l = rl ? a.Ap[i_l] : 0, hi_l = rl ? a.Ap[i_l + 1] : 0;
+		int64_t lo_u[RB], hi_u[RB];
+		int aj_u[RB], ax_u[RB];
+		uint32_t cid_u[RB];
+		uint64_t rm_u[RB];
+		const int nmw0 = (nseg + 63) >> 6;
+#pragma unroll
+		for (int u = 0; u < RB; u++) {
+			lo_u[u] = (int64_t) readlane64((uint64_t) lo_l, u);
+			hi_u[u] = (int64_t) readlane64((uint64_t) hi_l, u);
+			const bool have = hi_u[u] - lo_u[u] <= 64 && lo_u[u] + lane < hi_u[u];
+			aj_u[u] = have ? a.Aj[lo_u[u] + lane] : -1;
+			ax_u[u] = have ? a.Ax[lo_u[u] + lane] : 0;
+		}
+#pragma unroll
+		for (int u = 0; u < RB; u++)
+			cid_u[u] = (aj_u[u] >= 0) ? (uint32_t) d.col[aj_u[u]] : 0xFFFFFFFFu;
+#pragma unroll
+		for (int u = 0; u < RB; u++)
+			rm_u[u] = (cid_u[u] < (uint32_t) d.r) ? d.rowmask[(uint64_t) cid_u[u] * nmw0] : 0;
+#pragma unroll 1
+		for (int u = 0; u < RB && k0 + u < nrows; u++) {
+		const int k = (int) k0 + u;
+		// (u is wave-uniform: the selections are scalar compares)
+		int64_t lo = lo_u[0], hi = hi_u[0];
+		uint32_t cid_pre = cid_u[0];
+		int ax_pre = ax_u[0];
+		uint64_t rm_pre = rm_u[0];
+#pragma unroll
+		for (int v = 1; v < RB; v++)
+			if (u == v) {
+				lo = lo_u[v];
+				hi = hi_u[v];
+				cid_pre = cid_u[v];
+				ax_pre = ax_u[v];
+				rm_pre = rm_u[v];
+			}
 		st_input += (unsigned long long) (hi - lo);
 		int total = 0;
 		uint64_t tw = 0;          // lane (g mod 64) holds the word of T of segment g ...
@@ -1144,12 +1192,11 @@ template <bool W32> __global__ __launch_bounds__(64) void sp_apply_kernel(SpAppl
 		};
 		if (hi - lo <= 64) {
 			// the row in registers: lane e holds entry e
-			uint32_t cid = 0xFFFFFFFFu;
+			const uint32_t cid = cid_pre;
 			int bal = 0;          // the entry: balanced (16-bit variant) / plain residue (32-bit variant)
 			int ncoef = 0;        // minus the entry, as the arithmetic wants a coefficient: negated balanced / Montgomery form of p - a
 			if (lo + lane < hi) {
-				cid = (uint32_t) d.col[a.Aj[lo + lane]];
-				const uint32_t av = reduce_sum(from_balanced(a.Ax[lo + lane], F), F);
+				const uint32_t av = reduce_sum(from_balanced(ax_pre, F), F);
 				if constexpr (W32) {
 					bal = (int) av;
 					ncoef = (int) montmul(av == 0 ? 0u : F.p - av, F.r2, F);
@@ -1171,7 +1218,7 @@ template <bool W32> __global__ __launch_bounds__(64) void sp_apply_kernel(SpAppl
 			for (int b = 0; b < nmw; b++) {
 				// the segments of this block of 64 in which the row can hold anything: where one of its rows of R has entries,
 				// and where its own non-pivotal entries fall -- no other segment is visited
-				const uint64_t rm = piv ? d.rowmask[(uint64_t) cid * nmw + b] : 0;
+				const uint64_t rm = (b == 0) ? rm_pre : (piv ? d.rowmask[(uint64_t) cid * nmw + b] : 0);
 				uint64_t mask = 0;
 				for (uint64_t pl = piv_lanes; pl != 0; pl &= pl - 1)
 					mask |= readlane64(rm, __builtin_ctzll(pl));
@@ -1278,6 +1325,7 @@ template <bool W32> __global__ __launch_bounds__(64) void sp_apply_kernel(SpAppl
 		st_done += 1;
 		l0_store_i32(a.row_len + k, total);
 		l0_atomic_add_u64(&d.block_sum[k >> 10], (unsigned long long) total);
+		}
 	}
 	st.flush(lane);
 	for (int sft = 32; sft >= 1; sft >>= 1)
