@@ -473,7 +473,7 @@ template <typename ENT, typename COEF> struct SpGroup {
 	uint64_t rest;
 };
 
-template <typename ENT, typename COEF>
+template <bool SC1, typename ENT, typename COEF>
 __device__ __forceinline__ void sp_group_issue(SpGroup<ENT, COEF> &Q, uint64_t f, COEF coef, bool take, const SpPools &pools, int lane)
 {
 	uint64_t live = __ballot(take && (f & LEN_MASK) != 0);
@@ -493,13 +493,13 @@ __device__ __forceinline__ void sp_group_issue(SpGroup<ENT, COEF> &Q, uint64_t f
 		Q.len[u] = len;
 		Q.cf[u] = cf;
 		Q.src[u] = src;
-		Q.h0[u] = sp_ldent<ENT, false>(src + (lane < len ? lane : 0));
-		Q.h1[u] = sp_ldent<ENT, false>(src + (lane + 64 < len ? lane + 64 : 0));
+		Q.h0[u] = sp_ldent<ENT, SC1>(src + (lane < len ? lane : 0));
+		Q.h1[u] = sp_ldent<ENT, SC1>(src + (lane + 64 < len ? lane + 64 : 0));
 	}
 	Q.rest = live;
 }
 
-template <typename ENT, typename LDS, typename COEF, typename FLD>
+template <bool SC1, typename ENT, typename LDS, typename COEF, typename FLD>
 __device__ __forceinline__ void sp_group_consume(LDS &L, const SpGroup<ENT, COEF> &Q, uint64_t f, COEF coef, const SpPools &pools, int lane, const FLD &G,
                                                  unsigned long long &ops, uint32_t &nl)
 {
@@ -515,12 +515,12 @@ __device__ __forceinline__ void sp_group_consume(LDS &L, const SpGroup<ENT, COEF
 			sp_entry(L, Q.h0[u], Q.cf[u], lane < len, G, nl);
 		for (int i0 = 128; i0 < len; i0 += 128) {
 			const bool a0 = i0 + lane < len, a1 = i0 + 64 + lane < len;
-			const ENT e0 = sp_ldent<ENT, false>(Q.src[u] + (a0 ? i0 + lane : 0)), e1 = sp_ldent<ENT, false>(Q.src[u] + (a1 ? i0 + 64 + lane : 0));
+			const ENT e0 = sp_ldent<ENT, SC1>(Q.src[u] + (a0 ? i0 + lane : 0)), e1 = sp_ldent<ENT, SC1>(Q.src[u] + (a1 ? i0 + 64 + lane : 0));
 			sp_entry2(L, e0, e1, Q.cf[u], a0, a1, G, nl);
 		}
 	}
 	if (Q.rest != 0)
-		sp_accumulate_live<false, ENT>(L, Q.rest, f, coef, pools, lane, G, ops, nl);
+		sp_accumulate_live<SC1, ENT>(L, Q.rest, f, coef, pools, lane, G, ops, nl);
 }
 
 // inclusive prefix sum over the 64 lanes (DPP: shifts inside the rows of 16 lanes, then the row totals handed on)
@@ -691,6 +691,7 @@ constexpr uint64_t FRAG_FAILED = ~0ull - 1;              // could not be compute
 constexpr int SP_TICKETS = 16, SP_TICKET_STRIDE = 32;    // ticket counters, one 128-byte line each
 
 struct SpBuildArgs {
+	const uint64_t *segmask;      // persistent: per row the segments whose words are pending (nullptr: all of them)
 	const uint2 *head;            // 8 words per row: the lists of a row of at most seven entries (word 0: counts; 0xFFFFFFFF: see the lists below)
 	const uint64_t *dep_rp;
 	const uint2 *dep;
@@ -708,6 +709,7 @@ struct SpBuildArgs {
 	int arena;                    // persistent: entries a wave reserves at a time from the cursor of shard 0, which then serves the whole
 	                              // chunk (0: every fragment reserves its own room from the shard its hash picks)
 	int *ticket;                  // persistent: SP_TICKETS counters
+	int retry;                    // persistent: not the first launch of this build (some words are done already)
 	int *abort_flag;              // persistent: a wave waited too long (the grid is not resident?): everybody gives up
 	long long poll_limit;         // ... polls of one batch of dependencies before that happens
 	unsigned long long *prof;     // SPASM_HIP_SPARSE_IMAGE_PROFILE=1: 8 cycle counters (ticket, metadata, polling, adding, reservation, emit, publication)
@@ -778,91 +780,19 @@ template <bool PERSISTENT> __device__ __forceinline__ void sp_publish(uint64_t *
 }
 
 // one task: the fragment of (row c, segment g).  One exit, one publication.
-template <bool PERSISTENT, bool W32, typename LDS>
-__device__ __forceinline__ void sp_build_task(const SpBuildArgs &b, LDS &L, int c, int g, int lane, SpStamp &st, SpWaveState &ws)
+// the 64-byte head of row c: lanes 0..7 (see sp_build_task)
+__device__ __forceinline__ uint2 sp_row_head(const SpBuildArgs &b, int c, int lane)
 {
-	const uint32_t col0 = (uint32_t) g * SP_SEG;
-	const SgnDev G = b.G;
-	const MontDev M = b.M;
+	return (lane < 8 && b.head != nullptr) ? b.head[(uint64_t) c * 8 + lane] : uint2{0xFFFFFFFFu, 0u};
+}
+
+// what a (row, segment) pair of the build leaves behind once its sums stand in the accumulators (nl columns listed): room in the
+// pool, the fragment, the statistics, and -- one exit, one publication -- its fragment word
+template <bool PERSISTENT, bool W32, typename LDS>
+__device__ __forceinline__ void sp_build_finish(const SpBuildArgs &b, LDS &L, int c, int g, int lane, SpStamp &st, SpWaveState &ws, uint32_t nl, unsigned long long ops,
+                                                bool touched, bool failed)
+{
 	uint64_t *fout = b.frag + (uint64_t) c * b.nseg + g;
-	unsigned long long ops = 0;
-	uint32_t nl = 0;                               // columns of the segment listed so far (sp_list_new)
-	bool touched = false, failed = false;          // (wave-uniform: they only ever change on ballots)
-	// up to 64 non-pivotal entries of the row (lane: index among the non-pivotal columns, value): those of this segment
-	auto own_entries = [&](bool have, uint32_t x, int val) {
-		const uint32_t idx = x - col0;
-		const bool in = have && idx < (uint32_t) SP_SEG;
-		if (__ballot(in) != 0) {
-			touched = true;
-			if constexpr (W32)
-				sp_own_entry(L, idx, (uint32_t) val, in, M, nl);
-			else
-				sp_own_entry(L, idx, val, in, G, nl);
-		}
-	};
-	// up to 64 pivotal entries of the row (lane: compact row of the pivot, negated coefficient): minus coefficient times their fragments
-	auto dependencies = [&](bool have, uint32_t row, int coef, int detail) {
-		uint64_t f = 0;
-		const uint64_t *fin = have ? b.frag + (uint64_t) row * b.nseg + g : b.frag;
-		st.mark(1);
-		if (PERSISTENT) {
-			sp_dbg(b, lane, 2, (long long) c * b.nseg + g, detail);
-			f = have ? __hip_atomic_load(fin, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0;
-			long long polls = 0;
-			while (__ballot(f == FRAG_PENDING) != 0) {
-				polls += 1;
-				int gave_up = (polls > b.poll_limit) ? 1 : 0;
-				if ((polls & 255) == 0)
-					gave_up |= __builtin_amdgcn_readfirstlane(__hip_atomic_load(b.abort_flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
-				if (gave_up != 0) {
-					l0_store_i32_sc1(b.abort_flag, 1);
-					f = (f == FRAG_PENDING) ? FRAG_FAILED : f;
-				} else {
-					__builtin_amdgcn_s_sleep(1);
-					if (f == FRAG_PENDING)
-						f = __hip_atomic_load(fin, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-				}
-			}
-			if (__ballot(f == FRAG_FAILED) != 0)
-				failed = true;
-		} else if (have) {
-			f = *fin;
-		}
-		st.mark(2);
-		if (!failed && __ballot((f & LEN_MASK) != 0) != 0) {
-			touched = true;
-			if (PERSISTENT)
-				sp_dbg(b, lane, 3, (long long) c * b.nseg + g, detail);
-			if constexpr (W32)
-				sp_accumulate<PERSISTENT>(L, f, (uint32_t) coef, true, b.pools, lane, M, ops, nl);
-			else
-				sp_accumulate<PERSISTENT>(L, f, coef, true, b.pools, lane, G, ops, nl);
-			st.mark(3);
-		}
-	};
-	// The row's lists.  Rows of U' are short (mk15.b4: five entries on average): a row of at most seven entries has them ALL in
-	// its 64-byte head -- word 0: the counts, then the pivotal entries, then the non-pivotal ones -- one trip to memory where the
-	// four row pointers and the two lists took three, one after the other (metadata: 26 % of the build's wave-cycles).
-	const uint2 hd = (lane < 8 && b.head != nullptr) ? b.head[(uint64_t) c * 8 + lane] : uint2{0xFFFFFFFFu, 0u};
-	const uint32_t counts = (uint32_t) __builtin_amdgcn_readfirstlane((int) hd.x);
-	if (counts != 0xFFFFFFFFu) {
-		const int nd = (int) (counts & 0xFFFFu), nn = (int) (counts >> 16);
-		own_entries(lane > nd && lane <= nd + nn, hd.x, (int) hd.y);
-		if (nd > 0)
-			dependencies(lane >= 1 && lane <= nd, hd.x, (int) hd.y, 0);
-	} else {
-		const uint64_t d0 = sp_uniform(b.dep_rp[c]), d1 = sp_uniform(b.dep_rp[c + 1]), n0 = sp_uniform(b.np_rp[c]), n1 = sp_uniform(b.np_rp[c + 1]);
-		for (uint64_t e = n0; e < n1; e += 64) {
-			const bool have = e + lane < n1;
-			const uint2 en = have ? b.np[e + lane] : uint2{0u, 0u};
-			own_entries(have, en.x, (int) en.y);
-		}
-		for (uint64_t e = d0; e < d1; e += 64) {
-			const bool have = e + lane < d1;
-			const uint2 de = have ? b.dep[e + lane] : uint2{0u, 0u};
-			dependencies(have, de.x, (int) de.y, (int) (e - d0));
-		}
-	}
 	st.mark(1);
 	uint64_t word = 0;
 	int cnt = 0;
@@ -934,6 +864,188 @@ __device__ __forceinline__ void sp_build_task(const SpBuildArgs &b, LDS &L, int 
 	st.mark(6);
 }
 
+
+template <bool PERSISTENT, bool W32, typename LDS>
+__device__ __forceinline__ void sp_build_task(const SpBuildArgs &b, LDS &L, int c, int g, int lane, SpStamp &st, SpWaveState &ws, const uint2 hd)
+{
+	const uint32_t col0 = (uint32_t) g * SP_SEG;
+	const SgnDev G = b.G;
+	const MontDev M = b.M;
+	uint64_t *fout = b.frag + (uint64_t) c * b.nseg + g;
+	unsigned long long ops = 0;
+	uint32_t nl = 0;                               // columns of the segment listed so far (sp_list_new)
+	bool touched = false, failed = false;          // (wave-uniform: they only ever change on ballots)
+	// up to 64 non-pivotal entries of the row (lane: index among the non-pivotal columns, value): those of this segment
+	auto own_entries = [&](bool have, uint32_t x, int val) {
+		const uint32_t idx = x - col0;
+		const bool in = have && idx < (uint32_t) SP_SEG;
+		if (__ballot(in) != 0) {
+			touched = true;
+			if constexpr (W32)
+				sp_own_entry(L, idx, (uint32_t) val, in, M, nl);
+			else
+				sp_own_entry(L, idx, val, in, G, nl);
+		}
+	};
+	// up to 64 pivotal entries of the row (lane: compact row of the pivot, negated coefficient): minus coefficient times their fragments
+	auto dependencies = [&](bool have, uint32_t row, int coef, int detail) {
+		uint64_t f = 0;
+		const uint64_t *fin = have ? b.frag + (uint64_t) row * b.nseg + g : b.frag;
+		st.mark(1);
+		if (PERSISTENT) {
+			sp_dbg(b, lane, 2, (long long) c * b.nseg + g, detail);
+			f = have ? __hip_atomic_load(fin, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0;
+			long long polls = 0;
+			while (__ballot(f == FRAG_PENDING) != 0) {
+				polls += 1;
+				int gave_up = (polls > b.poll_limit) ? 1 : 0;
+				if ((polls & 255) == 0)
+					gave_up |= __builtin_amdgcn_readfirstlane(__hip_atomic_load(b.abort_flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+				if (gave_up != 0) {
+					l0_store_i32_sc1(b.abort_flag, 1);
+					f = (f == FRAG_PENDING) ? FRAG_FAILED : f;
+				} else {
+					__builtin_amdgcn_s_sleep(1);
+					if (f == FRAG_PENDING)
+						f = __hip_atomic_load(fin, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+				}
+			}
+			if (__ballot(f == FRAG_FAILED) != 0)
+				failed = true;
+		} else if (have) {
+			f = *fin;
+		}
+		st.mark(2);
+		if (!failed && __ballot((f & LEN_MASK) != 0) != 0) {
+			touched = true;
+			if (PERSISTENT)
+				sp_dbg(b, lane, 3, (long long) c * b.nseg + g, detail);
+			if constexpr (W32)
+				sp_accumulate<PERSISTENT>(L, f, (uint32_t) coef, true, b.pools, lane, M, ops, nl);
+			else
+				sp_accumulate<PERSISTENT>(L, f, coef, true, b.pools, lane, G, ops, nl);
+			st.mark(3);
+		}
+	};
+	// The row's lists.  Rows of U' are short (mk15.b4: five entries on average): a row of at most seven entries has them ALL in
+	// its 64-byte head -- word 0: the counts, then the pivotal entries, then the non-pivotal ones -- one trip to memory where the
+	// four row pointers and the two lists took three, one after the other (metadata: 26 % of the build's wave-cycles).
+	const uint32_t counts = (uint32_t) __builtin_amdgcn_readfirstlane((int) hd.x);
+	if (counts != 0xFFFFFFFFu) {
+		const int nd = (int) (counts & 0xFFFFu), nn = (int) (counts >> 16);
+		own_entries(lane > nd && lane <= nd + nn, hd.x, (int) hd.y);
+		if (nd > 0)
+			dependencies(lane >= 1 && lane <= nd, hd.x, (int) hd.y, 0);
+	} else {
+		const uint64_t d0 = sp_uniform(b.dep_rp[c]), d1 = sp_uniform(b.dep_rp[c + 1]), n0 = sp_uniform(b.np_rp[c]), n1 = sp_uniform(b.np_rp[c + 1]);
+		for (uint64_t e = n0; e < n1; e += 64) {
+			const bool have = e + lane < n1;
+			const uint2 en = have ? b.np[e + lane] : uint2{0u, 0u};
+			own_entries(have, en.x, (int) en.y);
+		}
+		for (uint64_t e = d0; e < d1; e += 64) {
+			const bool have = e + lane < d1;
+			const uint2 de = have ? b.dep[e + lane] : uint2{0u, 0u};
+			dependencies(have, de.x, (int) de.y, (int) (e - d0));
+		}
+	}
+	sp_build_finish<PERSISTENT, W32>(b, L, c, g, lane, st, ws, nl, ops, touched, failed);
+}
+
+// A row whose lists stand in its head (at most seven entries: lanes 1..nd its pivotal entries, the next nn lanes its non-pivotal
+// ones), through the segments of `mask`.  While segment g runs, the fragment words of the dependencies for the NEXT segment are
+// already asked for; when they have all arrived by the time g's sums are formed, the fragments they name are fetched before g is
+// emitted -- their latency runs beside the emit, the drain of its stores and the publication.
+template <bool W32, typename LDS>
+__device__ __forceinline__ void sp_build_row_inline(const SpBuildArgs &b, LDS &L, int c, const uint2 hd, uint64_t mask, int lane, SpStamp &st, SpWaveState &ws)
+{
+	using ENT = typename std::conditional<W32, uint64_t, uint32_t>::type;
+	using COEF = typename std::conditional<W32, uint32_t, int>::type;
+	const SgnDev G = b.G;
+	const MontDev M = b.M;
+	const uint32_t counts = (uint32_t) __builtin_amdgcn_readfirstlane((int) hd.x);
+	const int nd = (int) (counts & 0xFFFFu), nn = (int) (counts >> 16);
+	const bool isdep = lane >= 1 && lane <= nd, isnp = lane > nd && lane <= nd + nn;
+	const uint64_t *fin = b.frag + (isdep ? (uint64_t) hd.x * b.nseg : 0);
+	const uint64_t *fown = b.frag + (uint64_t) c * b.nseg;
+	const COEF coef = (COEF) hd.y;
+	int g = __builtin_ctzll(mask);
+	uint64_t m = mask & (mask - 1);
+	uint64_t f = isdep ? __hip_atomic_load(fin + g, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0;
+	SpGroup<ENT, COEF> pre;
+	bool have_pre = false;
+	for (;;) {
+		const int gn = (m != 0) ? __builtin_ctzll(m) : -1;
+		uint64_t fn = (isdep && gn >= 0) ? __hip_atomic_load(fin + gn, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0;
+		bool skip = false;
+		if (b.retry != 0)          // (a launch that retries after a pool extension finds most fragments done)
+			skip = sp_uniform(__hip_atomic_load(fown + g, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) != FRAG_PENDING;
+		if (!skip) {
+			unsigned long long ops = 0;
+			uint32_t nl = 0;
+			bool touched = false, failed = false;
+			st.mark(1);
+			sp_dbg(b, lane, 2, (long long) c * b.nseg + g, 0);
+			long long polls = 0;
+			while (__ballot(f == FRAG_PENDING) != 0) {
+				polls += 1;
+				int gave_up = (polls > b.poll_limit) ? 1 : 0;
+				if ((polls & 255) == 0)
+					gave_up |= __builtin_amdgcn_readfirstlane(__hip_atomic_load(b.abort_flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+				if (gave_up != 0) {
+					l0_store_i32_sc1(b.abort_flag, 1);
+					f = (f == FRAG_PENDING) ? FRAG_FAILED : f;
+				} else {
+					__builtin_amdgcn_s_sleep(1);
+					if (f == FRAG_PENDING)
+						f = __hip_atomic_load(fin + g, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+				}
+			}
+			if (__ballot(f == FRAG_FAILED) != 0)
+				failed = true;
+			st.mark(2);
+			const uint32_t idx = hd.x - (uint32_t) g * SP_SEG;
+			const bool in = isnp && idx < (uint32_t) SP_SEG;
+			if (__ballot(in) != 0) {
+				touched = true;
+				if constexpr (W32)
+					sp_own_entry(L, idx, (uint32_t) hd.y, in, M, nl);
+				else
+					sp_own_entry(L, idx, (int) hd.y, in, G, nl);
+			}
+			if (!failed && __ballot(isdep && (f & LEN_MASK) != 0) != 0) {
+				touched = true;
+				sp_dbg(b, lane, 3, (long long) c * b.nseg + g, 0);
+				if constexpr (W32) {
+					if (have_pre)
+						sp_group_consume<true>(L, pre, f, coef, b.pools, lane, M, ops, nl);
+					else
+						sp_accumulate<true>(L, f, coef, isdep, b.pools, lane, M, ops, nl);
+				} else {
+					if (have_pre)
+						sp_group_consume<true>(L, pre, f, coef, b.pools, lane, G, ops, nl);
+					else
+						sp_accumulate<true>(L, f, coef, isdep, b.pools, lane, G, ops, nl);
+				}
+				st.mark(3);
+			}
+			have_pre = false;
+			if (gn >= 0 && __ballot(fn == FRAG_PENDING || fn == FRAG_FAILED) == 0 && __ballot(isdep && (fn & LEN_MASK) != 0) != 0) {
+				sp_group_issue<true>(pre, fn, coef, isdep, b.pools, lane);
+				have_pre = true;
+			}
+			sp_build_finish<true, W32>(b, L, c, g, lane, st, ws, nl, ops, touched, failed);
+		} else {
+			have_pre = false;
+		}
+		if (gn < 0)
+			break;
+		g = gn;
+		m &= m - 1;
+		f = fn;
+	}
+}
+
 template <bool PERSISTENT, bool W32 = false> __global__ __launch_bounds__(64) void sp_build_kernel(SpBuildArgs b)
 {
 	__shared__ typename std::conditional<W32, WaveLds32, WaveLds>::type L;
@@ -945,14 +1057,16 @@ template <bool PERSISTENT, bool W32 = false> __global__ __launch_bounds__(64) vo
 		const int task = blockIdx.x;
 		const int c = b.row_lo + task / b.nseg;
 		SpWaveState ws;
-		sp_build_task<false, W32>(b, L, c, task - (c - b.row_lo) * b.nseg, lane, st, ws);
+		sp_build_task<false, W32>(b, L, c, task - (c - b.row_lo) * b.nseg, lane, st, ws, sp_row_head(b, c, lane));
 	} else {
+		// A ticket is a ROW (round 6; a (row, segment) pair before): the wave reads the row's lists once and takes it through its
+		// segments, publishing every fragment word as it goes -- a row that depends on this one walks the same segments in the same
+		// order, one behind: the chain of levels advances by a segment (2-3 us), not by a task with its ticket, its lists and its
+		// publication (7.5 us), and there are 18 times fewer tickets.  Rows are handed out from the last to the first, i.e. every row
+		// after the rows it depends on: whoever waits, waits for a row with a larger number, which a running wave holds or has finished.
 		const int q = (int) (blockIdx.x % SP_TICKETS);
-		const long long ntasks = (long long) (b.row_hi - b.row_lo) * b.nseg;
+		const long long ntasks = (long long) (b.row_hi - b.row_lo);
 		SpWaveState ws;
-		// (drawing the ticket of the next task before the current one runs -- the returning atomic costs 1.3 us of a task's 7.5 -- was
-		//  measured and LOST: 11.4 -> 12.9 ms on mk14.b4's factor, 14.8 -> 15.1 on mk15.b4's: a task held by a wave that is still
-		//  busy with the one before is a task the chain of levels waits for)
 		for (;;) {
 			const int j = l0_atomic_add_i32_ret(b.ticket + q * SP_TICKET_STRIDE, 1);
 			const long long t = (long long) j * SP_TICKETS + q;
@@ -960,14 +1074,31 @@ template <bool PERSISTENT, bool W32 = false> __global__ __launch_bounds__(64) vo
 			sp_dbg(b, lane, 1, t, j);
 			if (t >= ntasks)
 				break;
-			const int c = b.row_hi - 1 - (int) (t / b.nseg);          // rows from the last to the first
-			const int g = (int) (t % b.nseg);
-			// (a launch that retries after a pool extension finds most fragments done)
-			const uint64_t cur = sp_uniform(__hip_atomic_load(b.frag + (uint64_t) c * b.nseg + g, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
-			if (cur == FRAG_PENDING) {
-				sp_build_task<true, W32>(b, L, c, g, lane, st, ws);
-				sp_dbg(b, lane, 5, t, 0);
+			const int c = b.row_hi - 1 - (int) t;          // rows from the last to the first
+			const uint2 hd = sp_row_head(b, c, lane);
+			const uint64_t *fown = b.frag + (uint64_t) c * b.nseg;
+			const bool inline_row = (uint32_t) __builtin_amdgcn_readfirstlane((int) hd.x) != 0xFFFFFFFFu;
+			if (b.segmask != nullptr && inline_row) {
+				const uint64_t m = sp_uniform(b.segmask[c]);
+				if (m != 0)
+					sp_build_row_inline<W32>(b, L, c, hd, m, lane, st, ws);
+			} else if (b.segmask != nullptr) {
+				// (the segments in which the row can hold anything: the words of the others were published as empty before the launch)
+				for (uint64_t m = sp_uniform(b.segmask[c]); m != 0; m &= m - 1) {
+					const int g = __builtin_ctzll(m);
+					// (a launch that retries after a pool extension finds most fragments done)
+					const uint64_t cur = sp_uniform(__hip_atomic_load(fown + g, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+					if (cur == FRAG_PENDING)
+						sp_build_task<true, W32>(b, L, c, g, lane, st, ws, hd);
+				}
+			} else {
+				for (int g = 0; g < b.nseg; g++) {
+					const uint64_t cur = sp_uniform(__hip_atomic_load(fown + g, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+					if (cur == FRAG_PENDING)
+						sp_build_task<true, W32>(b, L, c, g, lane, st, ws, hd);
+				}
 			}
+			sp_dbg(b, lane, 5, t, 0);
 		}
 		sp_dbg(b, lane, 9, 0, 0);
 		// the wave's share of the statistics (and what its last arena strands counts as reserved)
@@ -1235,12 +1366,12 @@ template <bool W32> __global__ __launch_bounds__(64) void sp_apply_kernel(SpAppl
 					uint64_t f = piv ? fin[g] : 0;
 					uint64_t fn = (piv && gn >= 0) ? fin[gn] : 0;
 					SpGroup<ENT, COEF> cur, nxt;
-					sp_group_issue(cur, f, (COEF) ncoef, piv, d.pools, lane);
+					sp_group_issue<false>(cur, f, (COEF) ncoef, piv, d.pools, lane);
 					for (;;) {
 						const uint64_t m2 = (m != 0) ? (m & (m - 1)) : 0;
 						const int gnn = (m2 != 0) ? 64 * b + __builtin_ctzll(m2) : -1;
 						const uint64_t fnn = (piv && gnn >= 0) ? fin[gnn] : 0;
-						sp_group_issue(nxt, fn, (COEF) ncoef, piv, d.pools, lane);          // (after the last segment: fn = 0, eight loads of the pool's first word)
+						sp_group_issue<false>(nxt, fn, (COEF) ncoef, piv, d.pools, lane);          // (after the last segment: fn = 0, eight loads of the pool's first word)
 						const uint32_t idx = idx_all - (uint32_t) g * SP_SEG;
 						const bool in = own && idx < (uint32_t) SP_SEG;
 						st.mark(1);
@@ -1249,11 +1380,11 @@ template <bool W32> __global__ __launch_bounds__(64) void sp_apply_kernel(SpAppl
 						if constexpr (W32) {
 							if (__ballot(in) != 0)
 								sp_own_entry(L, idx, (uint32_t) bal, in, F, nl);
-							sp_group_consume(L, cur, f, (COEF) ncoef, d.pools, lane, F, ops, nl);
+							sp_group_consume<false>(L, cur, f, (COEF) ncoef, d.pools, lane, F, ops, nl);
 						} else {
 							if (__ballot(in) != 0)
 								sp_own_entry(L, idx, bal, in, G, nl);
-							sp_group_consume(L, cur, f, (COEF) ncoef, d.pools, lane, G, ops, nl);
+							sp_group_consume<false>(L, cur, f, (COEF) ncoef, d.pools, lane, G, ops, nl);
 						}
 						st.mark(2);
 						const uint64_t word = (nl != 0) ? finish(nl, cnt) : 0;
@@ -1852,18 +1983,22 @@ bool sparse_image_build(const spasm_hip_dfact *F, hipStream_t stream)
 	S.launches = 0;
 	bool ok = true;
 	if (persistent) {
-		if (S.d_segmask != nullptr && env_sp("SPASM_HIP_SPARSE_IMAGE_MASKS", 1) != 0)
+		if (S.d_segmask != nullptr) {
 			hipLaunchKernelGGL(sp_init_frag_kernel, dim3(2048), dim3(256), 0, stream, S.d_frag, S.d_segmask, S.nseg, nfrag);
-		else
+			b.segmask = S.d_segmask;
+		} else {
 			HIP_CHECK(hipMemsetAsync(S.d_frag, 0xFF, (size_t) nfrag * sizeof(uint64_t), stream));          // every fragment pending
+			b.segmask = nullptr;
+		}
 		b.row_lo = 0;
 		b.row_hi = S.r;
-		const int64_t ntasks = nfrag;
+		const int64_t ntasks = S.r;          // (a ticket is a row)
 		const int blocks = (int) std::max<int64_t>(1, std::min<int64_t>(ntasks, (int64_t) cus * per_cu));
 		for (bool first = true;; first = false) {
 			set_chunk(chunk, first);
 			// (arenas of 16,384 entries when the chunk is large enough for every wave to strand one; tests with tiny chunks: none)
 			b.arena = (S.chunk_cap[chunk] >= (int64_t) blocks * 16384 * 4 && env_sp("SPASM_HIP_SPARSE_IMAGE_ARENAS", 1) != 0) ? 16384 : 0;
+			b.retry = first ? 0 : 1;
 			HIP_CHECK(hipMemsetAsync(d_sync, 0, (size_t) (SP_TICKETS * SP_TICKET_STRIDE + 2) * sizeof(int), stream));
 			int *d_dbg = nullptr;
 			if (env_sp("SPASM_HIP_SPARSE_IMAGE_DEBUG", 0) != 0) {
