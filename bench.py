@@ -609,7 +609,7 @@ def main():
     if split == "auto":
         # both image paths -- the dense one and, since round 4, the sparse one (no limit on the width) -- compute the columns of
         # S independently of each other: a slab of the non-pivotal columns per rank replicates nothing.  One rank: nothing to split
-        split = "columns" if world > 1 else "rows"
+        split = "columns" if (world > 1 or os.environ.get("SPASM_BENCH_FORCE_DIST") == "1") else "rows"
     if world == 1 and os.environ.get("SPASM_BENCH_FORCE_DIST") != "1":
         split = "rows"
     A_full, F_full = A, F
@@ -664,6 +664,24 @@ def main():
                 assert full.n == len(rows)
         return st
 
+    # Several ranks: the step the line reports is the PRODUCT's -- spasm_hip_schur with the communicator installed, as
+    # spasm_hip_echelonize calls it between two rounds: this rank's slab (or slice), the all-gatherv of all of S, the stitching into
+    # whole rows on every device.  The device-API step above (slabs left where they are, lengths exchanged) stays as a second object.
+    product = None
+    if use_dist:
+        if args.split != "auto" or world == 1:
+            os.environ["SPASM_HIP_EXPERIMENT"] = "1"
+            if args.split != "auto":
+                os.environ["SPASM_HIP_SHARD"] = args.split
+            if world == 1:
+                os.environ["SPASM_HIP_SHARD_FORCE"] = "1"          # (SPASM_BENCH_FORCE_DIST=1: the same code in a world of one)
+        comm.install()
+        product = spasm_amd.ResidentSchur(A_full, rows, F_full)
+        product_nnz = [0]
+
+    def product_step():
+        product_nnz[0] = product(forget=True)
+
     def run_steps(count):
         """count timed steps: (seconds, per-kernel device ms summed over the steps, their algorithmic bytes, last stats)"""
         ms = {}
@@ -698,32 +716,58 @@ def main():
         torch.cuda.synchronize()
         return time.perf_counter() - t0, ms, by, st
 
-    for _ in range(args.warmup):
-        step()
-    torch.cuda.synchronize()
-    if dist is not None:
-        dist.barrier()
-    torch.cuda.synchronize()
-    t_begin = time.perf_counter()
-    _, ms_sum, bytes_of, st = run_steps(args.steps)
-    if dist is not None:
-        dist.barrier()
-    torch.cuda.synchronize()
-    elapsed = time.perf_counter() - t_begin
-    if dist is not None:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
+    def timed(fn_steps):
+        """barrier + synchronize, the steps, barrier + synchronize; seconds (the maximum over the ranks) and what fn_steps returned"""
+        torch.cuda.synchronize()
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+        t_begin = time.perf_counter()
+        got = fn_steps()
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+        seconds = time.perf_counter() - t_begin
+        if dist is not None:
+            t = torch.tensor([seconds], dtype=torch.float64, device=dev)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            seconds = float(t.item())
+        return seconds, got
+
+    slab_only = None
+    if product is not None:
+        for _ in range(args.warmup):
+            product_step()
+        elapsed, _ = timed(lambda: [product_step() for _ in range(args.steps)])
+        # the device-API step, for the kernels' own times (the product's call does not hand out its stage timers) and as the
+        # second object: no gather of S, no stitching
+        for _ in range(min(args.warmup, 2)):
+            step()
+        n_slab = max(3, min(5, args.steps))
+        el_slab, (_, ms_sum, bytes_of, st) = timed(lambda: run_steps(n_slab))
+        kernel_steps = n_slab
+        slab_only = {"what": "device-API step of the same split: every rank its slab (or slice) through spasm_hip_dschur, %s -- what the product's "
+                             "step adds is the all-gatherv of S and the stitching" % ("row lengths all-gathered" if split == "columns" else "all-gatherv of S"),
+                     "steps": n_slab, "ms_per_step": 1e3 * el_slab / n_slab, "rows_per_s": len(rows) / (el_slab / n_slab)}
+    else:
+        for _ in range(args.warmup):
+            step()
+        elapsed, (_, ms_sum, bytes_of, st) = timed(lambda: run_steps(args.steps))
+        kernel_steps = args.steps
 
     total_nnz_all = int(st.nnz)
     if use_dist and split == "columns":
         total_nnz_all = int(all_len.sum().item())          # entries of the whole Schur complement, from the exchanged lengths
+    if product is not None:
+        if total_nnz_all != product_nnz[0] and split == "columns":
+            raise SystemExit("bench.py: the product's Schur complement holds %d entries, the slabs %d" % (product_nnz[0], total_nnz_all))
+        total_nnz_all = product_nnz[0]
     if rank == 0:
         total_rows = len(rows)
         ms_per_step = 1e3 * elapsed / args.steps
         kernels = {}
         for name, total in ms_sum.items():
-            k_ms = total / args.steps
+            k_ms = total / kernel_steps
             if k_ms <= 0.0005 or (k_ms < 0.02 and bytes_of[name] == 0):
                 continue
             kernels[name] = {"ms": k_ms, "algorithmic_bytes": int(bytes_of[name]),
@@ -777,17 +821,22 @@ def main():
                        "non_pivotal_columns": int(A_full.m - F_full.U.n), "schur_nnz": total_nnz_all,
                        "path": "sparse image" if st.used_sparse_image else "back-substituted factor image" if st.used_backsolve else "row-by-row elimination",
                        "why_this_workload": why,
-                       "sharding": ("columns: each of %d rank(s) reduces ALL rows on its slab of the non-pivotal columns (%d of %d here), no "
-                                    "replicated image, row lengths all-gathered (whole Schur complement: %d entries)"
-                                    % (world, A.m - F.U.n, A_full.m - F_full.U.n, total_nnz_all)) if split == "columns"
-                       else "rows over %d rank(s)%s" % (world, ", all-gatherv of S" if use_dist else "")},
+                       "sharding": ("spasm_hip_schur with the communicator installed (%d rank(s)): slabs of the non-pivotal columns (%d of %d here), "
+                                    "all-gatherv of S (%d entries) + stitching in the step" % (world, A.m - F.U.n, A_full.m - F_full.U.n, total_nnz_all)) if (split == "columns" and product is not None)
+                       else "rows over %d rank(s)%s" % (world, ", spasm_hip_schur with the communicator installed: all-gatherv of S in the step" if product is not None else "")},
             "roofline": roof,
             "factor_image_ms": statistics.median(image_ms),
             "factor_image_note": "host planning + upload of the factor image (spasm_hip_dfact_create), once per factor, NOT in a step; "
                                  "median of 3 builds after a first one that is not counted (it loads the code object and fills the buffer cache)",
             "rows_per_s_cold": total_rows / (elapsed / args.steps + 1e-3 * statistics.median(image_ms)),
         }
-        extras = world == 1 and not args.no_extras
+        if slab_only is not None:
+            out["dist_product_path"] = {"what": "value / ms_per_step: spasm_hip_schur_resident = spasm_hip_schur as the driver calls it, communicator installed "
+                                                "(slab or slice, all-gatherv of S, stitching); roofline.kernels: measured in the slab_only steps",
+                                        "ms_per_step": ms_per_step, "slab_only_ms_per_step": slab_only["ms_per_step"], "slab_only_rows_per_s": slab_only["rows_per_s"],
+                                        "schur_nnz": total_nnz_all, "split": split}
+            out["slab_only"] = slab_only
+        extras = world == 1 and not args.no_extras and product is None
         if extras and st.used_backsolve:
             # the same batch through the row-by-row elimination kernels (what round 1 measured), a few steps
             os.environ["SPASM_HIP_BACKSOLVE"] = "0"
@@ -876,6 +925,9 @@ def main():
                 if "end_to_end" in out:
                     out["end_to_end"]["cpu_rank_time"] = {"seconds": float("%.4g" % rt["seconds"]), "projected": rt["projected"], "cores": rt["cores"]}
         emit(out)
+    if product is not None:
+        product.close()
+        comm.uninstall()
     if comm is not None:
         comm.close()
     if dist is not None:

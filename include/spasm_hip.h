@@ -434,7 +434,14 @@ int spasm_hip_allgatherv_plan(int world, int me, const i64 *sizes, spasm_hip_xfe
 int spasm_hip_column_slab(const struct spasm_csr *A, const struct spasm_lu *fact, int part, int parts, struct spasm_csr **A_slab,
                           struct spasm_lu **fact_slab, int *cols);
 
-/* spasm_echelonize (spasm_echelonize.c:478) with every round's Schur complement sharded over the ranks of c; the pivot
+/* For callers that TIME the product's path of a sparse round (bench.py --gpus N): spasm_hip_schur (spasm_schur, spasm_schur.c:61) as
+ * spasm_hip_echelonize calls it between two rounds -- residency on, the entries of S left on the device, the installed communicator
+ * in force: with several ranks this is the column (or row) split with its all-gatherv and its stitching.  Returns nnz(S); S is
+ * dropped.  spasm_hip_forget_cached_images: the cached factor images forget R, so that the next call pays for all of spasm_schur. */
+i64 spasm_hip_schur_resident(const struct spasm_csr *A, const int *p, int n, const struct spasm_lu *fact, double est_density);
+void spasm_hip_forget_cached_images(void);
+
+/* spasm_echelonize (spasm_echelonize.c:473) with every round's Schur complement sharded over the ranks of c; the pivot
  * search runs on rank 0 and is broadcast.  Collective; same rank of the matrix on every rank. */
 struct spasm_lu *spasm_hip_echelonize_dist(const struct spasm_csr *A, struct echelonize_opts *opts, spasm_hip_comm *c);
 

@@ -8,7 +8,7 @@ loudly when no HIP device is present.
 """
 from .matrix import Csr, Fact, EchelonizeOpts                     # noqa: F401
 from ._lib import lib, device_count, usable_cpus, release_cached_memory, LIB_PATH                      # noqa: F401
-from .host import (load, compress, transpose, pivots_extract_structural, schur,       # noqa: F401
+from .host import (load, compress, transpose, pivots_extract_structural, schur, ResidentSchur,       # noqa: F401
                    empty_fact, schur_dense, ffpack_rref, ffpack_LU, echelonize, echelonize_profile, echelonize_counters, rref, kernel,
                    default_opts)
 from .device import DeviceCsr, DeviceFact, SchurWorkspace, dschur                    # noqa: F401

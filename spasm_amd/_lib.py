@@ -88,6 +88,8 @@ def lib():
         "spasm_hip_dschur_allgatherv": (ci, [vp, vp, vp, vp, vp, i64, pint, C.POINTER(i64), vp]),
         "spasm_hip_dstitch_slabs": (ci, [vp, vp, vp, ci, ci, vp, vp, vp, i64, vp]),
         "spasm_hip_echelonize_dist": (plu, [pcsr, C.POINTER(EchelonizeOpts), vp]),
+        "spasm_hip_schur_resident": (i64, [pcsr, pint, ci, plu, C.c_double]),
+        "spasm_hip_forget_cached_images": (None, []),
         "spasm_hip_allgatherv_plan": (ci, [ci, ci, C.POINTER(i64), vp, ci, C.POINTER(i64), C.POINTER(i64)]),
         "spasm_hip_column_slab": (ci, [pcsr, plu, ci, ci, C.POINTER(pcsr), C.POINTER(plu), pint]),
     }

@@ -756,8 +756,10 @@ struct FactCacheKey {
 		return device == o.device && n == o.n && m == o.m && nnz == o.nnz && prime == o.prime && sum == o.sum;
 	}
 };
-static FactCacheKey g_fact_key;
-static spasm_hip_dfact *g_fact = nullptr;
+// two slots, most recently used first: a call split by columns plans the image of its slab factor next to the image of the whole
+// factor, which the driver comes back to (density samples, the finish) -- one slot had each evict the other
+static FactCacheKey g_fact_key[2];
+static spasm_hip_dfact *g_fact[2] = {nullptr, nullptr};
 static std::mutex g_fact_mutex;
 
 static uint64_t hash_words(uint64_t h, const void *data, size_t bytes)
@@ -802,14 +804,22 @@ spasm_hip_dfact *cached_dfact(const struct spasm_csr *U, const int *qinv, hipStr
 	h = hash_words(h, U->x, (size_t) key.nnz * sizeof(spasm_ZZp));
 	key.sum = h;
 	// (an image built without the tables of the pull experiment does not serve a call that asks for that kernel)
-	if (g_fact != nullptr && key == g_fact_key && (g_fact->has_pull || env_int("SPASM_HIP_PULL", 0) == 0))
-		return g_fact;
-	if (g_fact != nullptr)
-		spasm_hip_dfact_destroy(g_fact);
-	g_fact = spasm_hip_dfact_create(U, qinv, stream);
+	for (int slot = 0; slot < 2; slot++)
+		if (g_fact[slot] != nullptr && key == g_fact_key[slot] && (g_fact[slot]->has_pull || env_int("SPASM_HIP_PULL", 0) == 0)) {
+			if (slot == 1) {
+				std::swap(g_fact[0], g_fact[1]);
+				std::swap(g_fact_key[0], g_fact_key[1]);
+			}
+			return g_fact[0];
+		}
+	if (g_fact[1] != nullptr)
+		spasm_hip_dfact_destroy(g_fact[1]);
+	g_fact[1] = g_fact[0];
+	g_fact_key[1] = g_fact_key[0];
+	g_fact[0] = spasm_hip_dfact_create(U, qinv, stream);
 	counters()[CNT_FACTOR_PLANS] += 1;
-	g_fact_key = key;
-	return g_fact;
+	g_fact_key[0] = key;
+	return g_fact[0];
 }
 }  // namespace sh
 
@@ -1555,6 +1565,15 @@ void spasm_hip_dfact_forget(spasm_hip_dfact *F)
 	}
 }
 
+// what spasm_hip_echelonize does around a sparse round, for callers that time it (bench.py --gpus N): the cached images forget
+// their derived state (R is rebuilt by the next call, as after a fresh factor) ...
+void spasm_hip_forget_cached_images(void)
+{
+	std::lock_guard<std::mutex> guard(g_fact_mutex);
+	for (int slot = 0; slot < 2; slot++)
+		spasm_hip_dfact_forget(g_fact[slot]);
+}
+
 // fill of R as the sparse image holds it: out[0] entries, out[1] occupied 64-column tiles, out[2] non-empty
 // fragments, out[3] (row, segment) pairs.  Returns 1 when the factor holds a valid sparse image, else 0 (out zeroed).
 int spasm_hip_dfact_sparse_image_census(const spasm_hip_dfact *F, i64 *out, void *stream)
@@ -2142,6 +2161,11 @@ void spasm_hip_dschur_fetch(const spasm_hip_dwork *W, i64 *d_Sp, int *d_Sj, spas
 // Every rank: its slab problem (host: spasm_hip_column_slab -- A and U with the other ranks' non-pivotal columns deleted),
 // its image, ALL n rows reduced on it (the ordinary one-GPU call below, communicator set aside), columns mapped back,
 // all-gatherv of the slabs, stitched into whole rows on every device, then downloaded / kept resident like any result.
+extern "C" {
+static struct spasm_csr *schur_entry(const struct spasm_csr *A, const int *p, int n, const struct spasm_lu *fact, double est_density, struct spasm_triplet *L,
+                                     const int *p_in, int *p_out, spasm_hip_dwork **keep_on_device);
+}
+
 static struct spasm_csr *schur_by_column_slabs(const struct spasm_csr *A, const int *p, int n, const struct spasm_lu *fact, double est_density,
                                                const int *p_in, int *p_out, spasm_hip_comm *comm)
 {
@@ -2154,30 +2178,15 @@ static struct spasm_csr *schur_by_column_slabs(const struct spasm_csr *A, const 
 	std::vector<int> cols((size_t) (m > 0 ? m : 1));
 	const int mm = spasm_hip_column_slab(A, fact, rank, world, &A_slab, &F_slab, cols.data());
 	const double t_slab = wtime() - t0;
-	// the slab's Schur complement, on this device only
-	spasm_hip_set_comm(nullptr);
-	const bool was_lazy = g_lazy_download;
-	g_lazy_download = false;
-	struct spasm_csr *S_slab = spasm_hip_schur(A_slab, p, n, F_slab, est_density, nullptr, nullptr, nullptr);
-	g_lazy_download = was_lazy;
-	spasm_hip_set_comm(comm);
-	// (the slab result came to the host with the call above: what travels between the devices is uploaded again -- the slab
-	//  is 1 / world of S; keeping it on the device needs the workspace of that call, which it has released)
-	const i64 snz = S_slab->p[n];
-	spasm_hip_dwork *W = spasm_hip_dwork_create(n, m, std::max<i64>(snz, 1));
-	HIP_CHECK(hipMemcpyAsync(W->d_Sp, S_slab->p, ((size_t) n + 1) * sizeof(i64), hipMemcpyHostToDevice, stream));
-	if (snz > 0) {
-		HIP_CHECK(hipMemcpyAsync(W->d_Sj, S_slab->j, (size_t) snz * sizeof(int), hipMemcpyHostToDevice, stream));
-		HIP_CHECK(hipMemcpyAsync(W->d_Sx, S_slab->x, (size_t) snz * sizeof(int), hipMemcpyHostToDevice, stream));
-	}
-	W->last_rows = n;
-	W->last_nnz = snz;
+	// the slab's Schur complement, on this device only, and kept there: the all-gatherv reads it from the workspace of the call
+	// (round 5 brought it to the host and sent it back: 1 / world of S over PCIe, twice)
+	spasm_hip_dwork *W = nullptr;
+	(void) schur_entry(A_slab, p, n, F_slab, est_density, nullptr, nullptr, nullptr, &W);
+	const i64 snz = W->last_nnz;
 	int *d_cols = dalloc<int>(mm);
 	upload(d_cols, cols.data(), mm, stream);
 	launch_map_columns(W->d_Sj, snz, d_cols, stream);
 	HIP_CHECK(hipStreamSynchronize(stream));
-	resident_forget(S_slab);
-	spasm_hip_csr_free(S_slab);
 	resident_forget(A_slab);
 	spasm_hip_csr_free(A_slab);
 	spasm_hip_lu_free(F_slab);
@@ -2234,8 +2243,20 @@ static struct spasm_csr *schur_by_column_slabs(const struct spasm_csr *A, const 
 // --------------------------------------------------------------------------
 // host-pointer drop-in for spasm_schur
 // --------------------------------------------------------------------------
+static struct spasm_csr *schur_entry(const struct spasm_csr *A, const int *p, int n, const struct spasm_lu *fact, double est_density, struct spasm_triplet *L,
+                                     const int *p_in, int *p_out, spasm_hip_dwork **keep_on_device);
+
 struct spasm_csr *spasm_hip_schur(const struct spasm_csr *A, const int *p, int n, const struct spasm_lu *fact,
                                   double est_density, struct spasm_triplet *L, const int *p_in, int *p_out)
+{
+	return schur_entry(A, p, n, fact, est_density, L, p_in, p_out, nullptr);
+}
+
+// keep_on_device != NULL: one device, no communicator, no download -- the workspace that holds the result (W->d_Sp / d_Sj / d_Sx,
+// W->last_rows, W->last_nnz) is handed to the caller, who destroys it, and NULL is returned (the column split: a rank's slab of S
+// goes from here into the all-gatherv without touching the host)
+static struct spasm_csr *schur_entry(const struct spasm_csr *A, const int *p, int n, const struct spasm_lu *fact, double est_density, struct spasm_triplet *L,
+                                     const int *p_in, int *p_out, spasm_hip_dwork **keep_on_device)
 {
 	if (spasm_hip_device_count() == 0)
 		die("spasm_hip_schur: no HIP device (this library has no CPU path)");
@@ -2248,7 +2269,7 @@ struct spasm_csr *spasm_hip_schur(const struct spasm_csr *A, const int *p, int n
 	// one process per GPU with a communicator installed (dist_api.hip): this rank reduces rows [lo, hi) of the list, the
 	// slices are reassembled on the devices.  Small batches (density samples) and calls that record L are not sharded:
 	// every rank computes them whole, which keeps the ranks in step without a collective.
-	spasm_hip_comm *comm = current_comm();
+	spasm_hip_comm *comm = (keep_on_device != nullptr) ? nullptr : current_comm();
 	int lo = 0, hi = n;
 	const bool shard = comm != nullptr && L == nullptr && (comm_world(comm) > 1 || env_int("SPASM_HIP_SHARD_FORCE", 0) != 0) &&
 	                   n >= env_int("SPASM_HIP_SHARD_MIN_ROWS", 2048) * comm_world(comm);
@@ -2432,6 +2453,16 @@ struct spasm_csr *spasm_hip_schur(const struct spasm_csr *A, const int *p, int n
 	const double t2 = wtime();
 	struct spasm_csr *S = nullptr;
 	bool lazy = false;
+	if (keep_on_device != nullptr) {
+		scratch_park(W);
+		sh::big_free(drows);
+		W->last_rows = n;
+		W->last_nnz = st.nnz;
+		*keep_on_device = W;
+		logmsg("Schur complement (kept on the device): %d * %d [%" PRId64 " nz], %.1fs (GPU kernels %.1f ms, %s; factor image %.2fs, alloc+run %.2fs)\n", n, m, (i64) st.nnz,
+		       wtime() - t0, st.ms_total + ms_sample, st.kernel, t_fact, t_run);
+		return nullptr;
+	}
 	if (shard) {
 		// all-gatherv of the slices (sizes first, then exact-count broadcasts), then one download of the whole
 		i64 total = 0;
@@ -2492,6 +2523,27 @@ struct spasm_csr *spasm_hip_schur(const struct spasm_csr *A, const int *p, int n
 		logmsg("[schur/hip] of alloc+run: %.2fs allocating the workspace (%" PRId64 " pool entries), scratch %.1f GB\n", t_wcreate, pool,
 		       (double) g_scratch_cache.bytes / 1073741824.0);
 	return S;
+}
+
+// ... and spasm_hip_schur the way the driver calls it between two rounds (host_echelonize.cpp): residency on, the entries of S left on
+// the device (row pointers only come to the host), the communicator in force -- so with several ranks this IS the column / row split
+// with its all-gatherv and its stitching.  Returns the entries of S; S itself is dropped.
+i64 spasm_hip_schur_resident(const struct spasm_csr *A, const int *p, int n, const struct spasm_lu *fact, double est_density)
+{
+	const bool was_on = resident_enabled();
+	if (!was_on)
+		resident_begin();
+	resident_lazy_downloads(true);
+	struct spasm_csr *S = spasm_hip_schur(A, p, n, fact, est_density, nullptr, nullptr, nullptr);
+	resident_lazy_downloads(false);
+	const i64 nnz = S->p[S->n];
+	resident_forget(S);
+	spasm_hip_csr_free(S);
+	if (!was_on) {
+		resident_forget(A);
+		g_resident_on = false;          // (not resident_end(): the block cache keeps its blocks for the next step)
+	}
+	return nnz;
 }
 
 }  // extern "C"

@@ -124,6 +124,30 @@ def schur(A, p, F, p_in=None, want_L=False):
     return S, p_out[:n], trip
 
 
+class ResidentSchur:
+    """spasm_hip_schur_resident on fixed arguments, call after call: spasm_hip_schur the way spasm_hip_echelonize calls it between
+    two rounds (entries of S left on the device, the installed communicator in force) -- what bench.py times on several GPUs.
+    forget=True: the cached factor images drop R before every call, so that a call pays for all of spasm_schur."""
+
+    def __init__(self, A, p, F):
+        require_gpu("ResidentSchur")
+        self._a = view_csr(A)
+        self._lu, self._up, self._qinv = _lu_for(F, 0, 0)
+        self._p = np.ascontiguousarray(p, np.int32)
+        self._keep = (A, F)
+
+    def __call__(self, forget=True, est_density=-1.0):
+        L = lib()
+        if forget:
+            L.spasm_hip_forget_cached_images()
+        return int(L.spasm_hip_schur_resident(C.byref(self._a), _ip(self._p), len(self._p), C.byref(self._lu), est_density))
+
+    def close(self):
+        if self._up is not None:
+            lib().spasm_hip_csr_free(self._up)
+            self._up = None
+
+
 SPASM_DOUBLE, SPASM_FLOAT, SPASM_I64 = 0, 1, 2      # spasm_datatype (spasm.h:139)
 _NP_OF = {SPASM_DOUBLE: np.float64, SPASM_FLOAT: np.float32, SPASM_I64: np.int64}
 
