@@ -95,30 +95,35 @@ def test_sharded_driver_with_a_sparse_round_at_scale(comm, split, monkeypatch):
 
 
 def test_bench_runs_its_rccl_path_on_one_gpu():
-    """bench.py with the all-gatherv of the C ABI forced on (world of one), on a small sibling of the bench matrix."""
+    """bench.py with the distributed path forced on (world of one), split by rows, on a small sibling of the bench matrix: the
+    timed step is the product's (spasm_hip_schur_resident with the communicator installed: all-gatherv of S in the step), the
+    device-API step comes as a second object."""
     env = dict(os.environ, SPASM_BENCH_FORCE_DIST="1", SPASM_HIP_VERBOSE="0", MASTER_ADDR="127.0.0.1", MASTER_PORT="29871",
                RANK="0", WORLD_SIZE="1", LOCAL_RANK="0")
     out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--workload", "mk11.b4", "--steps", "2", "--warmup", "1",
-                          "--no-extras", "--no-cpu-baseline"], capture_output=True, text=True, env=env, timeout=600)
+                          "--no-extras", "--no-cpu-baseline", "--split", "rows"], capture_output=True, text=True, env=env, timeout=600)
     assert out.returncode == 0, out.stderr[-3000:]
     import json
-    line = [x for x in out.stdout.splitlines() if x.startswith("{")][-1]
-    d = json.loads(line)
+    assert len([x for x in out.stdout.splitlines() if x.strip()]) == 1, out.stdout[:2000]          # one line, the last thing on stdout
+    d = json.loads(out.stdout.strip().splitlines()[-1])
     assert d["value"] > 0 and "all-gatherv" in d["config"]["sharding"]
+    prod = d["summary"]["dist_product_path"]
+    assert prod["split"] == "rows" and prod["ms_per_step"] >= prod["slab_only_ms_per_step"] * 0.5 and prod["schur_nnz"] == d["config"]["schur_nnz"] > 0
 
 
 def test_bench_runs_its_column_split_on_one_gpu():
     """bench.py --split columns with the distributed path forced on (world of one): the slab problem of rank 0 of 1 is the
-    whole problem; the row lengths go through the RCCL all-gather."""
+    whole problem.  The timed step is the product's: the slab reduced and kept on the device, all-gatherv, stitching; its entry
+    count must equal what the slab-only steps (row lengths through the RCCL all-gather) add up to -- bench.py checks it."""
     env = dict(os.environ, SPASM_BENCH_FORCE_DIST="1", SPASM_HIP_VERBOSE="0", MASTER_ADDR="127.0.0.1", MASTER_PORT="29873",
                RANK="0", WORLD_SIZE="1", LOCAL_RANK="0")
     out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--workload", "mk11.b4", "--steps", "2", "--warmup", "1",
                           "--no-extras", "--no-cpu-baseline", "--split", "columns"], capture_output=True, text=True, env=env, timeout=600)
     assert out.returncode == 0, out.stderr[-3000:]
     import json
-    line = [x for x in out.stdout.splitlines() if x.startswith("{")][-1]
-    d = json.loads(line)
-    assert d["value"] > 0 and d["config"]["sharding"].startswith("columns") and d["config"]["schur_nnz"] > 0
+    d = json.loads(out.stdout.strip().splitlines()[-1])
+    assert d["value"] > 0 and "slabs of the non-pivotal columns" in d["config"]["sharding"] and d["config"]["schur_nnz"] > 0
+    assert d["summary"]["dist_product_path"]["split"] == "columns"
 
 
 @pytest.mark.parametrize("name,parts", [("mk12.b4", 4), ("mk11.b4", 8), ("mk12.b3", 3)])
