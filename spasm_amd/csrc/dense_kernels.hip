@@ -652,11 +652,19 @@ struct BlockGjArgs {
 	// finish its panel raises *abort (1 + abort_value) and every later kernel of the super-panel returns at once
 	int *abort;
 	int abort_value;
+	// (passes that run the tries one panel ahead of the updates: a word per panel -- abort points at this panel's --, and the try that
+	//  fails raises the words of the LATER panels and the summary word the host reads: the kernels of the panels before it, which may not
+	//  have started yet, must run)
+	int *abort_words, *abort_summary;
+	int abort_count;
 	// ... and rref_try_inverse finds the first free rows itself (what rref_first_free does in its own launch otherwise):
 	// ff_flags != null: scan from *ff_hint, write try_rows / *try_count through ff_out / ff_count
 	const int *ff_flags;
 	int *ff_hint, *ff_out, *ff_count;
 	const int *live_list, *live_count;          // rref_mark_dead's list of this super-panel, or null
+	// rref_try_inverse: the 64 x 64 block of the candidates as rref_lookahead left it (row-major, residues), instead of A's -- the
+	// update of the panel before has not reached A yet
+	const uint32_t *alt;
 	// mode == 2 (SMALL only): a try that takes what its candidates give -- k <= 64 pivots, the other columns of the panel skipped
 	// as dependent -- and leaves the proof to the multiplier kernel (MultArgs::verify_flags): after the step every row without a
 	// pivot must be zero on the whole panel, which says that no skipped column could have had a pivot anywhere (then the
@@ -921,6 +929,16 @@ __global__ __launch_bounds__(128 * NPAR) void rref_block_gj(BlockGjArgs g)
 	}
 }
 
+__device__ __forceinline__ void raise_abort(const BlockGjArgs &g)
+{
+	*g.abort = 1 + g.abort_value;
+	if (g.abort_words != nullptr) {
+		for (int t = g.abort_value + 1; t < g.abort_count; t++)
+			g.abort_words[t] = 1 + g.abort_value;
+		*g.abort_summary = 1 + g.abort_value;
+	}
+}
+
 // the pivots of a mode-2 try whose proof failed are taken back (the matrix itself was not touched: the update returned at once)
 __global__ __launch_bounds__(64) void rref_rollback(const int *rho, int *knew, int *flags, int *rank)
 {
@@ -969,7 +987,7 @@ __global__ __launch_bounds__(256) void rref_try_inverse(BlockGjArgs g)
 		if (tid == 0) {
 			*g.gj_done = 0;
 			if (g.abort != nullptr)
-				*g.abort = 1 + g.abort_value;
+				raise_abort(g);
 		}
 		return;
 	}
@@ -995,7 +1013,7 @@ __global__ __launch_bounds__(256) void rref_try_inverse(BlockGjArgs g)
 	int x[16];
 #pragma unroll
 	for (int j = 0; j < 16; j++) {
-		const int v = (int) g.A[(int64_t) row * g.ld + g.c0 + 16 * w + j];
+		const int v = (g.alt != nullptr) ? (int) g.alt[lane * NB + 16 * w + j] : (int) g.A[(int64_t) row * g.ld + g.c0 + 16 * w + j];
 		x[j] = (v > half) ? v - p : v;
 	}
 	if (tid < NB)
@@ -1028,7 +1046,7 @@ __global__ __launch_bounds__(256) void rref_try_inverse(BlockGjArgs g)
 					*g.gj_done = 0;
 					g.try_state[0] = g.try_state[0] + 1;
 					if (g.abort != nullptr)
-						*g.abort = 1 + g.abort_value;
+						raise_abort(g);
 				}
 				return;
 			}
@@ -1318,6 +1336,106 @@ __global__ void rref_gather_pivot_rows(const uint32_t *A, int64_t ld, int c1, in
 	for (int64_t t = (int64_t) blockIdx.x * blockDim.x + threadIdx.x; t < total; t += (int64_t) gridDim.x * blockDim.x) {
 		const int row = (int) (t / mr), col = (int) (t % mr);
 		B[t] = A[(int64_t) rho[row] * ld + c1 + col];
+	}
+}
+
+
+// ---- one panel ahead ---------------------------------------------------------------------------------------------------
+// The chain of an optimistic super-panel is try(i) -> multipliers(i) -> update(i) -> try(i + 1), three dependent launches per
+// panel -- and all try(i + 1) reads of update(i) is ONE 64 x 64 tile: the next panel's columns of its 64 candidate rows.
+// rref_lookahead forms that tile by itself, from what try(i) left (Ginv, the pivot rows rho) and from A as update(i - 1) left it:
+//     M = -A[cand, panel i] Ginv            (the candidates hold no pivot: no +Ginv term -- multipliers_body)
+//     X = A[cand, panel i + 1] + M A[rho, panel i + 1]
+// so that try(i + 1) runs on its own stream BESIDE multipliers(i) and update(i), which bring A itself up to date.  It also picks
+// the candidates (what rref_try_inverse does for itself otherwise).  One workgroup; p < 2^16, a full panel (k = 64, gamma = identity).
+struct LookArgs {
+	const uint32_t *A;
+	int64_t ld;
+	int n, c0;                    // panel i starts at c0, panel i + 1 at c0 + NB
+	const uint32_t *Ginv;         // of panel i (Montgomery form)
+	const int *rho;               // pivot rows of panel i, by candidate (column r of M multiplies row rho[r])
+	const int *knew;
+	const int *flags;
+	int *hint, *out_rows, *out_count;
+	uint32_t *alt;                // NB x NB: the tile of the next try
+	const int *abort;
+	MontDev F;
+};
+
+constexpr int LOOK_WGS = 16, LOOK_COLS = NB / LOOK_WGS;          // workgroups of rref_lookahead, columns of the tile each of them forms
+
+__global__ __launch_bounds__(256) void rref_lookahead(LookArgs g)
+{
+	// X = A[cand, next] - A[cand, panel] (Ginv A[rho, next]): workgroup b forms LOOK_COLS columns of the tile -- first
+	// V = Ginv A[rho, its columns] (64 x 4), then its columns of X -- and every workgroup picks the candidates for itself
+	// (the same rows: a pure function of the flags); workgroup 0 alone writes them out.
+	__shared__ uint32_t sA[NB][NB + 1], sG[NB][NB + 1];
+	__shared__ uint32_t sB[NB][LOOK_COLS], sV[NB][LOOK_COLS];
+	__shared__ int srow[NB];
+	__shared__ int s_found, s_hint;
+	const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+	const int col0 = (int) blockIdx.x * LOOK_COLS;
+	const MontDev F = g.F;
+	if (g.abort != nullptr && *g.abort != 0)
+		return;
+	if (tid == 0)
+		s_hint = *g.hint;
+	__syncthreads();
+	if (w == 0) {
+		const int found = pick_candidates(g.flags, g.n, &s_hint, nullptr, nullptr, srow, lane);
+		if (lane == 0)
+			s_found = found;
+	}
+	__syncthreads();
+	if (blockIdx.x == 0) {
+		if (tid < NB)
+			g.out_rows[tid] = srow[tid];
+		if (tid == 0) {
+			*g.out_count = s_found;
+			*g.hint = s_hint;
+		}
+	}
+	if (s_found < NB || *g.knew != NB)
+		return;                          // (the try that follows gives up by itself: fewer than 64 candidates)
+	{
+		// all loads of a thread in flight together: Ginv (row-major), the candidates' panel entries, the pivot rows' and the
+		// candidates' entries on this workgroup's columns of the next panel
+		uint32_t gv[NB * NB / 256], av[NB * NB / 256];
+#pragma unroll
+		for (int u = 0; u < NB * NB / 256; u++) {
+			const int t = tid + 256 * u;
+			gv[u] = g.Ginv[t];
+			av[u] = g.A[(int64_t) srow[t / NB] * g.ld + g.c0 + t % NB];
+		}
+		const int rr = tid / LOOK_COLS, cc = tid % LOOK_COLS;          // (256 threads = 64 rows x 4 columns)
+		const uint32_t bv = g.A[(int64_t) g.rho[rr] * g.ld + g.c0 + NB + col0 + cc];
+#pragma unroll
+		for (int u = 0; u < NB * NB / 256; u++) {
+			const int t = tid + 256 * u;
+			sG[t / NB][t % NB] = (gv[u] != 0) ? montmul(gv[u], 1u, F) : 0u;          // plain residues
+			sA[t / NB][t % NB] = av[u];
+		}
+		sB[rr][cc] = bv;
+	}
+	__syncthreads();
+	const int i = tid / LOOK_COLS, c = tid % LOOK_COLS;
+	{
+		// V[s][c] = sum_r Ginv[s][r] A[rho[r]][next column c]  (column r of the multipliers multiplies the row that is candidate r)
+		unsigned long long acc = 0;
+#pragma unroll 8
+		for (int r = 0; r < NB; r++)
+			acc += (uint32_t) __umul24(sG[i][r], sB[r][c]);          // < 2^32 each, 64 of them
+		sV[i][c] = reduce_sum(acc, F);
+	}
+	__syncthreads();
+	{
+		unsigned long long acc = 0;
+#pragma unroll 8
+		for (int sidx = 0; sidx < NB; sidx++)
+			acc += (uint32_t) __umul24(sA[i][sidx], sV[sidx][c]);
+		const uint32_t sub = reduce_sum(acc, F);
+		const uint32_t old = g.A[(int64_t) srow[i] * g.ld + g.c0 + NB + col0 + c];
+		g.alt[i * NB + col0 + c] = (old >= sub) ? old - sub : old + F.p - sub;
 	}
 }
 
@@ -2007,11 +2125,11 @@ int device_rref(int64_t prime, int n, int m, uint32_t *dA, int64_t ld, int *d_pi
 		ws_malloc((void **) &candA, cand_len * sizeof(int));
 		ws_malloc((void **) &candB, cand_len * sizeof(int));
 		ws_malloc((void **) &free_count, 64);
-		ws_malloc((void **) &gamma, NB * sizeof(int));
+		ws_malloc((void **) &gamma, 2 * NB * sizeof(int));
 		ws_malloc((void **) &cand_first, NB * sizeof(int));
 		ws_malloc((void **) &first64, NB * sizeof(int));
 		ws_malloc((void **) &live_list, (size_t) n * sizeof(int));
-		ws_malloc((void **) &cand_pivot, NB * sizeof(int));
+		ws_malloc((void **) &cand_pivot, 2 * NB * sizeof(int));
 		HIP_CHECK(hipMemsetAsync(free_count, 0, 64, stream));          // [4]: scan hint of rref_first_free
 		ws_malloc((void **) &P4, (size_t) 2 * MAXSETS * (size_t) n * PW * sizeof(uint32_t));
 		ws_malloc((void **) &Bt4, (size_t) 4 * (size_t) NB * (size_t) m * sizeof(uint32_t));
@@ -2037,9 +2155,9 @@ int device_rref(int64_t prime, int n, int m, uint32_t *dA, int64_t ld, int *d_pi
 		ws_malloc((void **) &B8, (size_t) MAXSETS * 2 * (size_t) m * 64 + (size_t) 2 * (2 * MAXSETS * NB + 64) * 64);
 		ws_malloc((void **) &Zacc, (size_t) n * (size_t) (MAXSETS * NB) * sizeof(uint32_t));
 		ws_malloc((void **) &knew4, 2 * MAXSETS * 16 * sizeof(int));
-		ws_malloc((void **) &full_flag, 64);
-		HIP_CHECK(hipMemsetAsync(full_flag, 0, 64, stream));          // [0] full, [4] gj_done, [8] try_state
-		ws_malloc((void **) &Ginv, NB * NB * sizeof(uint32_t));
+		ws_malloc((void **) &full_flag, 256);
+		HIP_CHECK(hipMemsetAsync(full_flag, 0, 256, stream));          // [0] full, [4] gj_done, [8] try_state, [12] abort, [16 .. 16 + MAXSETS) abort by panel
+		ws_malloc((void **) &Ginv, 2 * NB * NB * sizeof(uint32_t));
 	}
 	unsigned int *coop_barrier = nullptr;
 	int *coop_cand = nullptr, *coop_err = nullptr;
@@ -2060,6 +2178,31 @@ int device_rref(int64_t prime, int n, int m, uint32_t *dA, int64_t ld, int *d_pi
 		HIP_CHECK(hipStreamCreateWithFlags(&stream2, hipStreamNonBlocking));
 		HIP_CHECK(hipEventCreate(&ev_near));
 		HIP_CHECK(hipEventCreate(&ev_far));
+	}
+	// one panel ahead (rref_lookahead): the tries of an optimistic super-panel on a stream of their own, beside the multipliers and
+	// updates of the panel before.  Streams and events are kept between calls (per host thread).
+	struct Ahead {
+		int dev = -1;
+		hipStream_t s_try = nullptr;
+		hipEvent_t ev_try[MAXSETS] = {}, ev_upd[MAXSETS] = {}, ev_look[MAXSETS] = {}, ev_start = nullptr;
+	};
+	static thread_local Ahead ahead;
+	const bool use_ahead = tournament && mfma_ok && prime < 65536 && (sh::env_get("SPASM_HIP_RREF_LOOKAHEAD") == nullptr || std::atoi(sh::env_get("SPASM_HIP_RREF_LOOKAHEAD")) != 0);
+	uint32_t *alt_tile = nullptr;
+	if (use_ahead) {
+		int dev = 0;
+		HIP_CHECK(hipGetDevice(&dev));
+		if (ahead.dev != dev) {
+			HIP_CHECK(hipStreamCreateWithFlags(&ahead.s_try, hipStreamNonBlocking));
+			for (int t = 0; t < MAXSETS; t++) {
+				HIP_CHECK(hipEventCreateWithFlags(&ahead.ev_try[t], hipEventDisableTiming));
+				HIP_CHECK(hipEventCreateWithFlags(&ahead.ev_upd[t], hipEventDisableTiming));
+				HIP_CHECK(hipEventCreateWithFlags(&ahead.ev_look[t], hipEventDisableTiming));
+			}
+			HIP_CHECK(hipEventCreateWithFlags(&ahead.ev_start, hipEventDisableTiming));
+			ahead.dev = dev;
+		}
+		ws_malloc((void **) &alt_tile, (size_t) 2 * NB * NB * sizeof(uint32_t));          // (two tiles: the try of panel i + 1 reads one while ... none writes the other)
 	}
 	auto timed = [&](auto &&launch) {
 		if (ms_update != nullptr)
@@ -2137,8 +2280,14 @@ int device_rref(int64_t prime, int n, int m, uint32_t *dA, int64_t ld, int *d_pi
 			const int mrT = m - sp_end;              // columns beyond the super-panel
 			UpdSets S{};
 			int *abort_d = full_flag + 12;          // optimistic super-panels: raised by a try that cannot finish its panel
-			auto run_panel = [&](int c0, int nsets, bool optimistic) {
-				const int *abort_c = optimistic ? abort_d : nullptr;
+			hipEvent_t wait_before_update = nullptr;          // (phase 2: the update kernel waits for this event -- the lookahead has read A)
+			bool abort_by_panel = false;                      // (passes with the tries one panel ahead: see BlockGjArgs::abort_words)
+			int *abort_pp = full_flag + 16;
+			auto run_panel = [&](int c0, int nsets, bool optimistic, int phase = 0, bool with_alt = false) {
+				hipStream_t stream_keep = stream;
+				hipStream_t stream = (phase == 1) ? ahead.s_try : stream_keep;          // (the launches below name `stream`)
+				const int *abort_c = optimistic ? (abort_by_panel ? abort_pp + nsets : abort_d) : nullptr;
+				const int par = nsets & 1;          // (Ginv, gamma, cand_pivot: two copies -- the try of panel i + 1 may run beside the multipliers of panel i)
 				const int width = std::min(NB, m - c0);
 				// (sets alternate between two halves by super-panel: the far update of the previous super-panel may
 				//  still be reading its multipliers on the second stream)
@@ -2161,15 +2310,15 @@ int device_rref(int64_t prime, int n, int m, uint32_t *dA, int64_t ld, int *d_pi
 				bg.cand = nullptr;
 				bg.cand_first = cand_first;
 				bg.full = full_flag;
-				bg.Ginv = Ginv;
-				bg.gamma = gamma;
+				bg.Ginv = Ginv + (size_t) par * NB * NB;
+				bg.gamma = gamma + par * NB;
 				bg.is_pivot_row = flags;
 				bg.pivrow = pivrow;
 				bg.pivcol = d_pivcol;
 				bg.rank = rank_d;
 				bg.knew = knew_s;
 				bg.rho = rho_s;
-				bg.cand_pivot = cand_pivot;
+				bg.cand_pivot = cand_pivot + par * NB;
 				bg.F = F;
 				bg.invtab = invtab;
 				bg.mode = 1;
@@ -2178,18 +2327,28 @@ int device_rref(int64_t prime, int n, int m, uint32_t *dA, int64_t ld, int *d_pi
 				bg.gj_done = full_flag + 4;
 				bg.try_state = full_flag + 8;
 				bg.panel_index = c0 / NB;
-				bg.abort = optimistic ? abort_d : nullptr;
+				bg.abort = optimistic ? const_cast<int *>(abort_c) : nullptr;
 				bg.abort_value = nsets;
+				bg.abort_words = (optimistic && abort_by_panel) ? abort_pp : nullptr;
+				bg.abort_summary = abort_d;
+				bg.abort_count = MAXSETS;
 				bg.ff_flags = optimistic ? flags : nullptr;
 				bg.ff_hint = free_count + 4;
 				bg.ff_out = first64;
 				bg.ff_count = free_count + 2;
 				bg.live_list = have_live ? live_list : nullptr;
 				bg.live_count = free_count + 10;
+				bg.alt = nullptr;
+				if (with_alt) {
+					bg.alt = alt_tile + (size_t) (nsets & 1) * NB * NB;
+					bg.ff_flags = nullptr;          // (rref_lookahead picked the candidates: first64 / free_count + 2)
+				}
 				// (a block on which tries fail -- dependent columns, or rows that depend on each other --: the try that takes what its
 				//  candidates give, with the proof in the multiplier kernel; see BlockGjArgs)
 				const bool take_what_comes = optimistic && have_live && small_prime && small16 && mfma_ok && width == NB;
-				if (take_what_comes) {
+				if (phase == 2) {
+					;                                // (the try ran on its own stream)
+				} else if (take_what_comes) {
 					bg.mode = 2;
 					hipLaunchKernelGGL((rref_block_gj<true, 8>), dim3(1), dim3(1024), invtab_bytes, stream, bg);
 					bg.mode = 1;
@@ -2201,6 +2360,8 @@ int device_rref(int64_t prime, int n, int m, uint32_t *dA, int64_t ld, int *d_pi
 					else
 						hipLaunchKernelGGL((rref_block_gj<false, 8>), dim3(1), dim3(1024), 0, stream, bg);
 				}
+				if (phase == 1)
+					return;
 				if (!optimistic) {
 				// the first 64 free rows alone, by selection (when the try was skipped or failed)
 				if (straight)
@@ -2239,7 +2400,7 @@ int device_rref(int64_t prime, int n, int m, uint32_t *dA, int64_t ld, int *d_pi
 					hipLaunchKernelGGL((rref_block_gj<false, 8>), dim3(1), dim3(1024), 0, stream, bg);
 				}
 				signed char *Mh_s = M8 + (size_t) slot * 2 * (size_t) n * 64, *Ml_s = Mh_s + (size_t) n * 64;
-				MultArgs ma{dA, ld, n, m, c0, Ginv, gamma, knew_s, P_s, F, rho_s, cand_pivot, mfma_ok ? Mh_s : nullptr, mfma_ok ? Ml_s : nullptr,
+				MultArgs ma{dA, ld, n, m, c0, Ginv + (size_t) par * NB * NB, gamma + par * NB, knew_s, P_s, F, rho_s, cand_pivot + par * NB, mfma_ok ? Mh_s : nullptr, mfma_ok ? Ml_s : nullptr,
 				            mfma_ok ? Zacc + (size_t) nsets * NB : nullptr /* M_s becomes block `nsets` of Z */, ldz, abort_c,
 				            take_what_comes ? flags : nullptr, abort_d, nsets};
 				const int nmult = (n + 63) / 64;
@@ -2280,6 +2441,8 @@ int device_rref(int64_t prime, int n, int m, uint32_t *dA, int64_t ld, int *d_pi
 						hipLaunchKernelGGL(rref_multipliers<false>, dim3(nmult), dim3(256), 0, stream, ma);
 					hipLaunchKernelGGL(rref_gather_pivot_rows, dim3(512), dim3(256), 0, stream, dA, ld, c0, mr_sp, rho_s, knew_s, B);
 				}
+				if (wait_before_update != nullptr)
+					HIP_CHECK(hipStreamWaitEvent(stream, wait_before_update, 0));
 				timed([&]() {
 					dim3 grid(tiles, (n + 63) / 64);
 					if (mfma_ok)
@@ -2309,8 +2472,49 @@ int device_rref(int64_t prime, int n, int m, uint32_t *dA, int64_t ld, int *d_pi
 					HIP_CHECK(hipMemsetAsync(abort_d, 0, sizeof(int), stream));
 					// (knew[1] of a slot = the pivots a mode-2 try has taken, for rref_rollback: nothing yet)
 					HIP_CHECK(hipMemset2DAsync(knew4 + (size_t) (spi & 1) * MAXSETS * 16 + 1, 16 * sizeof(int), 0, sizeof(int), MAXSETS, stream));
-					for (int i = start; i < npanels; i++)
-						run_panel(sp0 + i * NB, i, true);
+					// one panel ahead: plain optimistic passes only (full panels, no list of live rows, p < 2^16)
+					const bool look = use_ahead && !have_live && small16 && npanels - start >= 2;
+					if (!look) {
+						for (int i = start; i < npanels; i++)
+							run_panel(sp0 + i * NB, i, true);
+					} else {
+						abort_by_panel = true;
+						HIP_CHECK(hipMemsetAsync(abort_pp, 0, MAXSETS * sizeof(int), stream));
+						HIP_CHECK(hipEventRecord(ahead.ev_start, stream));
+						HIP_CHECK(hipStreamWaitEvent(ahead.s_try, ahead.ev_start, 0));
+						for (int i = start; i < npanels; i++) {
+							const int c0 = sp0 + i * NB;
+							// try(i) on the try stream: from A for the first panel of the pass, from the tile of look(i - 1) after that
+							run_panel(c0, i, true, 1, i > start);
+							HIP_CHECK(hipEventRecord(ahead.ev_try[i], ahead.s_try));
+							const bool next_full = i + 1 < npanels && c0 + 2 * NB <= m;
+							if (next_full) {
+								// look(i): needs try(i) (this stream) and A as update(i - 1) left it
+								if (i > start)
+									HIP_CHECK(hipStreamWaitEvent(ahead.s_try, ahead.ev_upd[i - 1], 0));
+								const int slot = (spi & 1) * MAXSETS + i;
+								LookArgs la{dA, ld, n, c0, Ginv + (size_t) (i & 1) * NB * NB, rho4 + slot * NB, knew4 + slot * 16, flags, free_count + 4, first64, free_count + 2,
+								            alt_tile + (size_t) ((i + 1) & 1) * NB * NB, abort_pp + i, F};
+								hipLaunchKernelGGL(rref_lookahead, dim3(LOOK_WGS), dim3(256), 0, ahead.s_try, la);
+							}
+							// multipliers(i) on the main stream as soon as try(i) is done, beside look(i); update(i) REWRITES what look(i) reads
+							// (the next panel's columns of the candidates and of the pivot rows): it waits for look(i)
+							HIP_CHECK(hipStreamWaitEvent(stream, ahead.ev_try[i], 0));
+							wait_before_update = nullptr;
+							if (next_full) {
+								HIP_CHECK(hipEventRecord(ahead.ev_look[i], ahead.s_try));
+								wait_before_update = ahead.ev_look[i];
+							}
+							run_panel(c0, i, true, 2);
+							wait_before_update = nullptr;
+							HIP_CHECK(hipEventRecord(ahead.ev_upd[i], stream));
+							if (!next_full && i + 1 < npanels) {
+								// (a narrow last panel: its try reads A, after update(i))
+								HIP_CHECK(hipStreamWaitEvent(ahead.s_try, ahead.ev_upd[i], 0));
+							}
+						}
+						abort_by_panel = false;
+					}
 					int raised = 0;
 					HIP_CHECK(hipMemcpyAsync(&raised, abort_d, sizeof(int), hipMemcpyDeviceToHost, stream));
 					HIP_CHECK(hipStreamSynchronize(stream));
