@@ -662,6 +662,7 @@ struct BlockGjArgs {
 	const int *ff_flags;
 	int *ff_hint, *ff_out, *ff_count;
 	const int *live_list, *live_count;          // rref_mark_dead's list of this super-panel, or null
+	int *done_word;        // rref_try_inverse: counted up when the kernel is through (null: nobody polls)
 	// rref_try_inverse: the 64 x 64 block of the candidates as rref_lookahead left it (row-major, residues), instead of A's -- the
 	// update of the panel before has not reached A yet
 	const uint32_t *alt;
@@ -929,6 +930,37 @@ __global__ __launch_bounds__(128 * NPAR) void rref_block_gj(BlockGjArgs g)
 	}
 }
 
+// ---- device-side hand-offs between the two streams of a pass that runs its tries one panel ahead --------------------------
+// Events between the streams cost ~10 us per hop (a record and a wait are barrier packets of their own: the trace showed 11 us
+// between the end of a try and the start of the lookahead behind it on the SAME queue).  Instead: the producer's workgroups count
+// themselves in on a word once their stores have left (every wave's stores drained, the workgroup's barrier, an agent-scope
+// release by one lane, then the atomic), the consumer's workgroups poll it with one lane (relaxed agent-scope loads), take an
+// agent-scope acquire and meet at a barrier before any of them reads.  (MI355X_MICROARCH.md, "Workgroup dispatch, XCD
+// placement & inter-workgroup visibility": the per-XCD L2s are not coherent with each other.)  Every exit of a producer
+// signals -- an aborted pass must not leave anybody polling.
+__device__ __forceinline__ void handoff_wait(const int *word, int value)
+{
+	if (word == nullptr)
+		return;
+	if (threadIdx.x == 0) {
+		while (__hip_atomic_load(word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < value)
+			__builtin_amdgcn_s_sleep(4);
+		__builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+	}
+	__syncthreads();
+}
+
+__device__ __forceinline__ void handoff_signal(int *word)
+{
+	if (word == nullptr)
+		return;
+	__syncthreads();          // (after every wave's s_waitcnt vmcnt(0): the compiler puts it before the barrier)
+	if (threadIdx.x == 0) {
+		__builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+		__hip_atomic_fetch_add(word, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+	}
+}
+
 __device__ __forceinline__ void raise_abort(const BlockGjArgs &g)
 {
 	*g.abort = 1 + g.abort_value;
@@ -965,7 +997,7 @@ __device__ __forceinline__ int gj_reduce(int t, int negp, float invp)
 	return t + __mul24(q, negp);
 }
 
-__global__ __launch_bounds__(256) void rref_try_inverse(BlockGjArgs g)
+__device__ __forceinline__ void try_inverse_body(const BlockGjArgs &g)
 {
 	extern __shared__ __attribute__((aligned(16))) unsigned short invtab[];
 	__shared__ int fcol[2][NB], s_pr[2], s_pv[2], s_inv[2];
@@ -1110,6 +1142,12 @@ __global__ __launch_bounds__(256) void rref_try_inverse(BlockGjArgs g)
 	}
 }
 
+__global__ __launch_bounds__(256) void rref_try_inverse(BlockGjArgs g)
+{
+	try_inverse_body(g);
+	handoff_signal(g.done_word);          // (every thread of the workgroup leaves the body the same way)
+}
+
 // (Tried: the same elimination BLK = 4 columns per round -- every wave factors the 64 x 4 block by itself, two barriers
 //  per round instead of two per column.  115 us against 88 us per panel: the 64 x 128 x 64 elimination is ~5 M
 //  lane-instructions, i.e. bound by the instruction issue of ONE compute unit, not by its 128 barriers.)
@@ -1143,6 +1181,9 @@ struct MultArgs {
 	const int *verify_flags;
 	int *abort_w;
 	int abort_value;
+	const int *wait_word;         // rref_mult_gather: the try of this panel counts itself in here (null: ordered by the stream)
+	const int *wait_word2;        // ... and before it ends: the workgroups of the lookahead of this panel
+	int wait_value2;
 };
 
 template <bool SMALL16> __device__ __forceinline__ void multipliers_body(const int bx, const MultArgs &g)
@@ -1359,12 +1400,23 @@ struct LookArgs {
 	int *hint, *out_rows, *out_count;
 	uint32_t *alt;                // NB x NB: the tile of the next try
 	const int *abort;
+	const int *wait_word;         // the update of the panel before counts its workgroups in here ...
+	int wait_value;               // ... all of them
+	int *done_word;               // this kernel's workgroups count themselves in
 	MontDev F;
 };
 
 constexpr int LOOK_WGS = 16, LOOK_COLS = NB / LOOK_WGS;          // workgroups of rref_lookahead, columns of the tile each of them forms
 
+__device__ __forceinline__ void lookahead_body(const LookArgs &g);
+
 __global__ __launch_bounds__(256) void rref_lookahead(LookArgs g)
+{
+	lookahead_body(g);
+	handoff_signal(g.done_word);
+}
+
+__device__ __forceinline__ void lookahead_body(const LookArgs &g)
 {
 	// X = A[cand, next] - A[cand, panel] (Ginv A[rho, next]): workgroup b forms LOOK_COLS columns of the tile -- first
 	// V = Ginv A[rho, its columns] (64 x 4), then its columns of X -- and every workgroup picks the candidates for itself
@@ -1378,6 +1430,7 @@ __global__ __launch_bounds__(256) void rref_lookahead(LookArgs g)
 	const MontDev F = g.F;
 	if (g.abort != nullptr && *g.abort != 0)
 		return;
+	handoff_wait(g.wait_word, g.wait_value);          // (A as the update of the panel before left it)
 	if (tid == 0)
 		s_hint = *g.hint;
 	__syncthreads();
@@ -1618,6 +1671,9 @@ struct UpdSets {
 	int64_t ld2;
 	int tiles1, mr2;
 	const int *abort;               // optimistic super-panels: not null and raised -> the launch does nothing
+	const int *wait_word;           // rref_update_mfma_multi: the lookahead of this panel has read A when this word holds wait_value
+	int wait_value;
+	int *done_word;                 // ... and its workgroups count themselves in here
 };
 
 
@@ -1715,10 +1771,15 @@ __global__ __launch_bounds__(256) void rref_gather_split_sets(const uint32_t *A,
 // launches costs ~8 us of idle device): workgroups 0 .. nmult - 1 compute multipliers, the others gather
 template <bool SMALL16> __global__ __launch_bounds__(256) void rref_mult_gather(MultArgs a, GatherArgs b, int nmult)
 {
+	handoff_wait(a.wait_word, 1);          // (the try of this panel, on the other stream)
 	if ((int) blockIdx.x < nmult)
 		multipliers_body<SMALL16>((int) blockIdx.x, a);
 	else
 		gather_split_body((int) blockIdx.x - nmult, b);
+	// the update that follows this kernel on its stream rewrites what the lookahead of this panel reads: nobody leaves before the
+	// lookahead is through (it started with this kernel and takes a quarter of its time: nobody waits here in practice, and the
+	// update -- a grid that can fill the chip -- has no reason to poll)
+	handoff_wait(a.wait_word2, a.wait_value2);
 }
 
 // digit planes of the accumulated multipliers Z[:, 64 s .. 64 s + 63] (set s), one thread per (row, 16 columns)
@@ -1822,8 +1883,11 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
 {
 	__shared__ __attribute__((aligned(16))) signed char Mhi[64][64 + 16], Mlo[64][64 + 16];   // [row][k]
 	__shared__ __attribute__((aligned(16))) signed char Bhi[64][64 + 16], Blo[64][64 + 16];   // [col][k]  (transposed)
-	if (S.abort != nullptr && *S.abort != 0)
+	if (S.abort != nullptr && *S.abort != 0) {
+		handoff_signal(S.done_word);
 		return;
+	}
+	handoff_wait(S.wait_word, S.wait_value);
 	const int tid = threadIdx.x;
 	const int row0 = blockIdx.y * 64;
 	int col0 = blockIdx.x * 64;
@@ -1907,6 +1971,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
 			sum -= F.p;
 		A[(int64_t) i * ld + c1 + j] = sum;
 	}
+	handoff_signal(S.done_word);
 }
 
 // The same update with a 64 x 128 tile per workgroup (round 5): every wave holds 32 rows x 64 columns -- two 32 x 32 blocks
@@ -2174,8 +2239,8 @@ int device_rref(int64_t prime, int n, int m, uint32_t *dA, int64_t ld, int *d_pi
 	const bool mfma_ok = use_mfma && prime <= 65279;      // two signed base-256 digits must fit int8
 	hipStream_t stream2 = nullptr;
 	hipEvent_t ev_near = nullptr, ev_far = nullptr;
-	if (tournament && mfma_ok && !sh::env_get("SPASM_HIP_RREF_ONE_STREAM")) {
-		HIP_CHECK(hipStreamCreateWithFlags(&stream2, hipStreamNonBlocking));
+	const bool two_streams = tournament && mfma_ok && !sh::env_get("SPASM_HIP_RREF_ONE_STREAM");
+	if (two_streams) {
 		HIP_CHECK(hipEventCreate(&ev_near));
 		HIP_CHECK(hipEventCreate(&ev_far));
 	}
@@ -2183,16 +2248,20 @@ int device_rref(int64_t prime, int n, int m, uint32_t *dA, int64_t ld, int *d_pi
 	// updates of the panel before.  Streams and events are kept between calls (per host thread).
 	struct Ahead {
 		int dev = -1;
-		hipStream_t s_try = nullptr;
+		hipStream_t s_try = nullptr, s_far = nullptr;
 		hipEvent_t ev_try[MAXSETS] = {}, ev_upd[MAXSETS] = {}, ev_look[MAXSETS] = {}, ev_start = nullptr;
 	};
 	static thread_local Ahead ahead;
 	const bool use_ahead = tournament && mfma_ok && prime < 65536 && (sh::env_get("SPASM_HIP_RREF_LOOKAHEAD") == nullptr || std::atoi(sh::env_get("SPASM_HIP_RREF_LOOKAHEAD")) != 0);
 	uint32_t *alt_tile = nullptr;
-	if (use_ahead) {
+	if (use_ahead || two_streams) {
 		int dev = 0;
 		HIP_CHECK(hipGetDevice(&dev));
 		if (ahead.dev != dev) {
+			// (Tried: disjoint compute units for the two streams (hipExtStreamCreateWithCUMask: sixteen for the tries, the rest for the far
+			//  updates) -- the trace shows a try at 75-79 us instead of 44 whenever the far update of the super-panel before shares its
+			//  compute unit.  The call went from 8.3 to 16 ms: masked queues are served far more slowly on this stack.  Plain streams.)
+			HIP_CHECK(hipStreamCreateWithFlags(&ahead.s_far, hipStreamNonBlocking));
 			HIP_CHECK(hipStreamCreateWithFlags(&ahead.s_try, hipStreamNonBlocking));
 			for (int t = 0; t < MAXSETS; t++) {
 				HIP_CHECK(hipEventCreateWithFlags(&ahead.ev_try[t], hipEventDisableTiming));
@@ -2202,7 +2271,10 @@ int device_rref(int64_t prime, int n, int m, uint32_t *dA, int64_t ld, int *d_pi
 			HIP_CHECK(hipEventCreateWithFlags(&ahead.ev_start, hipEventDisableTiming));
 			ahead.dev = dev;
 		}
-		ws_malloc((void **) &alt_tile, (size_t) 2 * NB * NB * sizeof(uint32_t));          // (two tiles: the try of panel i + 1 reads one while ... none writes the other)
+		if (use_ahead)
+			ws_malloc((void **) &alt_tile, (size_t) 2 * NB * NB * sizeof(uint32_t) + 3 * MAXSETS * sizeof(int));          // (two tiles, by parity of the panel; then the hand-off words)
+		if (two_streams)
+			stream2 = ahead.s_far;
 	}
 	auto timed = [&](auto &&launch) {
 		if (ms_update != nullptr)
@@ -2282,6 +2354,10 @@ int device_rref(int64_t prime, int n, int m, uint32_t *dA, int64_t ld, int *d_pi
 			int *abort_d = full_flag + 12;          // optimistic super-panels: raised by a try that cannot finish its panel
 			hipEvent_t wait_before_update = nullptr;          // (phase 2: the update kernel waits for this event -- the lookahead has read A)
 			bool abort_by_panel = false;                      // (passes with the tries one panel ahead: see BlockGjArgs::abort_words)
+			// hand-off words of such a pass (handoff_wait / handoff_signal): by panel, the try is through / workgroups of the lookahead / of the update
+			int *hand_try = use_ahead ? reinterpret_cast<int *>(alt_tile + (size_t) 2 * NB * NB) : nullptr, *hand_look = hand_try + MAXSETS, *hand_upd = hand_try + 2 * MAXSETS;
+			int upd_workgroups[MAXSETS] = {};
+			bool look_follows = false;                        // (phase 2 of a panel whose lookahead runs: the update waits for it)
 			int *abort_pp = full_flag + 16;
 			auto run_panel = [&](int c0, int nsets, bool optimistic, int phase = 0, bool with_alt = false) {
 				hipStream_t stream_keep = stream;
@@ -2339,6 +2415,7 @@ int device_rref(int64_t prime, int n, int m, uint32_t *dA, int64_t ld, int *d_pi
 				bg.live_list = have_live ? live_list : nullptr;
 				bg.live_count = free_count + 10;
 				bg.alt = nullptr;
+				bg.done_word = (phase == 1) ? hand_try + nsets : nullptr;
 				if (with_alt) {
 					bg.alt = alt_tile + (size_t) (nsets & 1) * NB * NB;
 					bg.ff_flags = nullptr;          // (rref_lookahead picked the candidates: first64 / free_count + 2)
@@ -2403,6 +2480,9 @@ int device_rref(int64_t prime, int n, int m, uint32_t *dA, int64_t ld, int *d_pi
 				MultArgs ma{dA, ld, n, m, c0, Ginv + (size_t) par * NB * NB, gamma + par * NB, knew_s, P_s, F, rho_s, cand_pivot + par * NB, mfma_ok ? Mh_s : nullptr, mfma_ok ? Ml_s : nullptr,
 				            mfma_ok ? Zacc + (size_t) nsets * NB : nullptr /* M_s becomes block `nsets` of Z */, ldz, abort_c,
 				            take_what_comes ? flags : nullptr, abort_d, nsets};
+				ma.wait_word = (phase == 2) ? hand_try + nsets : nullptr;
+				ma.wait_word2 = (phase == 2 && look_follows) ? hand_look + nsets : nullptr;
+				ma.wait_value2 = LOOK_WGS;
 				const int nmult = (n + 63) / 64;
 				// the columns of the super-panel, from this panel on, and (matrix cores) the multipliers of its earlier
 				// panels, blocks 0 .. nsets - 1 of Z: K = 64 update now
@@ -2443,6 +2523,10 @@ int device_rref(int64_t prime, int n, int m, uint32_t *dA, int64_t ld, int *d_pi
 				}
 				if (wait_before_update != nullptr)
 					HIP_CHECK(hipStreamWaitEvent(stream, wait_before_update, 0));
+				if (phase == 2) {
+					one.done_word = hand_upd + nsets;
+					upd_workgroups[nsets] = tiles * ((n + 63) / 64);
+				}
 				timed([&]() {
 					dim3 grid(tiles, (n + 63) / 64);
 					if (mfma_ok)
@@ -2473,43 +2557,41 @@ int device_rref(int64_t prime, int n, int m, uint32_t *dA, int64_t ld, int *d_pi
 					// (knew[1] of a slot = the pivots a mode-2 try has taken, for rref_rollback: nothing yet)
 					HIP_CHECK(hipMemset2DAsync(knew4 + (size_t) (spi & 1) * MAXSETS * 16 + 1, 16 * sizeof(int), 0, sizeof(int), MAXSETS, stream));
 					// one panel ahead: plain optimistic passes only (full panels, no list of live rows, p < 2^16)
-					const bool look = use_ahead && !have_live && small16 && npanels - start >= 2;
+					// (... and blocks of at most SPASM_HIP_RREF_LOOKAHEAD_ROWS rows, 6,144 by default: beyond, the multipliers and the update
+					//  of a panel take longer than its try -- the chain is no longer what the call waits for, and two streams of kernels that
+					//  poll each other only get in the way: 16,384 x 16,384 went from 40 to 53 ms with it)
+					const int look_rows = sh::env_get("SPASM_HIP_RREF_LOOKAHEAD_ROWS") ? std::atoi(sh::env_get("SPASM_HIP_RREF_LOOKAHEAD_ROWS")) : 6144;
+					const bool look = use_ahead && !have_live && small16 && npanels - start >= 2 && n <= look_rows;
 					if (!look) {
 						for (int i = start; i < npanels; i++)
 							run_panel(sp0 + i * NB, i, true);
 					} else {
 						abort_by_panel = true;
 						HIP_CHECK(hipMemsetAsync(abort_pp, 0, MAXSETS * sizeof(int), stream));
+						HIP_CHECK(hipMemsetAsync(hand_try, 0, 3 * MAXSETS * sizeof(int), stream));
 						HIP_CHECK(hipEventRecord(ahead.ev_start, stream));
 						HIP_CHECK(hipStreamWaitEvent(ahead.s_try, ahead.ev_start, 0));
+						// The try stream: try(start), look(start), try(start + 1), ... back to back, no event between them.  The main
+						// stream: multipliers(i) (its workgroups wait for try(i)'s word), update(i) (waits for look(i): it REWRITES the
+						// next panel's columns of the candidates and of the pivot rows, which look(i) reads), ...  look(i) waits for
+						// the workgroups of update(i - 1).  No cycle: every wait is for a kernel that is earlier in BOTH orders.
 						for (int i = start; i < npanels; i++) {
 							const int c0 = sp0 + i * NB;
-							// try(i) on the try stream: from A for the first panel of the pass, from the tile of look(i - 1) after that
-							run_panel(c0, i, true, 1, i > start);
-							HIP_CHECK(hipEventRecord(ahead.ev_try[i], ahead.s_try));
+							run_panel(c0, i, true, 1, i > start);          // try(i): from A for the first panel of the pass, from look(i - 1)'s tile after that
 							const bool next_full = i + 1 < npanels && c0 + 2 * NB <= m;
 							if (next_full) {
-								// look(i): needs try(i) (this stream) and A as update(i - 1) left it
-								if (i > start)
-									HIP_CHECK(hipStreamWaitEvent(ahead.s_try, ahead.ev_upd[i - 1], 0));
 								const int slot = (spi & 1) * MAXSETS + i;
 								LookArgs la{dA, ld, n, c0, Ginv + (size_t) (i & 1) * NB * NB, rho4 + slot * NB, knew4 + slot * 16, flags, free_count + 4, first64, free_count + 2,
-								            alt_tile + (size_t) ((i + 1) & 1) * NB * NB, abort_pp + i, F};
+								            alt_tile + (size_t) ((i + 1) & 1) * NB * NB, abort_pp + i, (i > start) ? hand_upd + (i - 1) : nullptr, (i > start) ? upd_workgroups[i - 1] : 0,
+								            hand_look + i, F};
 								hipLaunchKernelGGL(rref_lookahead, dim3(LOOK_WGS), dim3(256), 0, ahead.s_try, la);
 							}
-							// multipliers(i) on the main stream as soon as try(i) is done, beside look(i); update(i) REWRITES what look(i) reads
-							// (the next panel's columns of the candidates and of the pivot rows): it waits for look(i)
-							HIP_CHECK(hipStreamWaitEvent(stream, ahead.ev_try[i], 0));
-							wait_before_update = nullptr;
-							if (next_full) {
-								HIP_CHECK(hipEventRecord(ahead.ev_look[i], ahead.s_try));
-								wait_before_update = ahead.ev_look[i];
-							}
+							look_follows = next_full;
 							run_panel(c0, i, true, 2);
-							wait_before_update = nullptr;
-							HIP_CHECK(hipEventRecord(ahead.ev_upd[i], stream));
+							look_follows = false;
 							if (!next_full && i + 1 < npanels) {
-								// (a narrow last panel: its try reads A, after update(i))
+								// (a narrow last panel: its try reads A itself, after update(i))
+								HIP_CHECK(hipEventRecord(ahead.ev_upd[i], stream));
 								HIP_CHECK(hipStreamWaitEvent(ahead.s_try, ahead.ev_upd[i], 0));
 							}
 						}
@@ -2721,8 +2803,7 @@ int device_rref(int64_t prime, int n, int m, uint32_t *dA, int64_t ld, int *d_pi
 	int rank = 0, coop_failed = 0;
 	HIP_CHECK(hipMemcpyAsync(&rank, rank_d, sizeof(int), hipMemcpyDeviceToHost, stream));
 	if (stream2 != nullptr) {
-		HIP_CHECK(hipStreamSynchronize(stream2));
-		(void) hipStreamDestroy(stream2);
+		HIP_CHECK(hipStreamSynchronize(stream2));          // (the stream itself is kept for the next call)
 		(void) hipEventDestroy(ev_near);
 		(void) hipEventDestroy(ev_far);
 	}
