@@ -3,6 +3,7 @@
 
 #include <cstdarg>
 #include <cstdint>
+#include <functional>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -46,6 +47,8 @@ double wtime();
 // selects an experiment, a debugging aid or a code path kept for A/B runs and tests, and is only honoured when
 // SPASM_HIP_EXPERIMENT=1 is set as well (tests/conftest.py sets it).  Returns the value or nullptr.
 const char *env_get(const char *name);
+// fn(0) .. fn(ntasks - 1) on the library's worker threads and the caller (host_util.cpp); returns when all are done
+void pool_run(int ntasks, const std::function<void(int)> &fn);
 
 // verbosity of the progress messages on stderr (SPASM_HIP_VERBOSE=0 silences them)
 int verbose();

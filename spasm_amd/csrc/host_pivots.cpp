@@ -39,7 +39,15 @@ namespace sh {
 // one (cgroup v2 cpu.max, v1 cfs_quota_us).  The MI355X boxes of this pool report 256 hardware threads and grant 16 CPUs
 // (cpu.max = "1600000 100000"; tools/cpu_scaling.cpp: 16 threads run in the time of one, 32 take twice as long) --
 // which is why the threaded pivot search stopped scaling at 16 threads in round 2, not its commit lock.
+static int usable_cpus_uncached();
+
 int usable_cpus()
+{
+	static const int cached = usable_cpus_uncached();          // (two files of /sys/fs/cgroup are read: once per process)
+	return cached;
+}
+
+static int usable_cpus_uncached()
 {
 	int hw = (int) std::thread::hardware_concurrency();
 	if (hw <= 0)

@@ -6,6 +6,11 @@
 
 #include <cstring>
 #include <vector>
+#include <atomic>
+#include <condition_variable>
+#include <functional>
+#include <mutex>
+#include <thread>
 
 #include "common.h"
 
@@ -25,6 +30,87 @@ long long *counters()
 }
 
 // ---- environment switches --------------------------------------------------------------------
+// ---- a small pool of worker threads for the host planning loops ---------------------------------------------------
+// The plans of a factor image are a dozen loops of a few hundred microseconds each over 10^5 .. 10^6 rows; a std::thread per
+// part per loop cost more than the loops (50-100 us to create and join a thread on the boxes of this pool: eight threads, two
+// passes = 1.4 ms around 0.6 ms of work).  The workers are created once, sleep on a condition variable between jobs and are
+// never joined (the pool is leaked on purpose: no destructor runs at exit while a worker waits).  One job at a time; a job
+// started from inside a job (or while another thread's job runs) is run by its caller alone.
+namespace {
+struct WorkerPool {
+	std::mutex m;
+	std::condition_variable wake, done;
+	std::function<void(int)> job;
+	int ntasks = 0, next = 0, running = 0;
+	uint64_t generation = 0;
+	int nworkers = 0;
+	std::mutex one_job;
+
+	void worker()
+	{
+		uint64_t seen = 0;
+		std::unique_lock<std::mutex> lk(m);
+		for (;;) {
+			wake.wait(lk, [&] { return generation != seen; });
+			seen = generation;
+			while (next < ntasks) {
+				const int t = next++;
+				running += 1;
+				lk.unlock();
+				job(t);
+				lk.lock();
+				running -= 1;
+			}
+			if (running == 0)
+				done.notify_all();
+		}
+	}
+};
+WorkerPool *g_pool = nullptr;
+thread_local bool t_in_pool_job = false;
+}  // namespace
+
+int usable_cpus();
+
+void pool_run(int ntasks, const std::function<void(int)> &fn)
+{
+	if (ntasks <= 0)
+		return;
+	static std::once_flag once;
+	std::call_once(once, [] {
+		g_pool = new WorkerPool();
+		g_pool->nworkers = std::max(0, std::min(15, usable_cpus() - 1));
+		for (int t = 0; t < g_pool->nworkers; t++)
+			std::thread([] { t_in_pool_job = true; g_pool->worker(); }).detach();
+	});
+	WorkerPool &P = *g_pool;
+	if (ntasks == 1 || P.nworkers == 0 || t_in_pool_job || !P.one_job.try_lock()) {
+		for (int t = 0; t < ntasks; t++)
+			fn(t);
+		return;
+	}
+	std::unique_lock<std::mutex> lk(P.m);
+	P.job = fn;
+	P.ntasks = ntasks;
+	P.next = 0;
+	P.generation += 1;
+	P.wake.notify_all();
+	t_in_pool_job = true;
+	while (P.next < P.ntasks) {          // the caller works too
+		const int t = P.next++;
+		P.running += 1;
+		lk.unlock();
+		fn(t);
+		lk.lock();
+		P.running -= 1;
+	}
+	t_in_pool_job = false;
+	P.done.wait(lk, [&] { return P.running == 0 && P.next >= P.ntasks; });
+	P.job = nullptr;
+	lk.unlock();
+	P.one_job.unlock();
+}
+
 const char *env_get(const char *name)
 {
 	// (the list of include/spasm_hip.h, section "Environment")

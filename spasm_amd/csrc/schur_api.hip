@@ -1009,12 +1009,7 @@ static bool heights_from_hint(const struct spasm_csr *U, const int *qinv, std::v
 			}
 		}
 	};
-	std::vector<std::thread> pool;
-	for (int t = 1; t < T; t++)
-		pool.emplace_back(check, (int) ((i64) r * t / T), (int) ((i64) r * (t + 1) / T));
-	check(0, (int) ((i64) r / T));
-	for (auto &th : pool)
-		th.join();
+	sh::pool_run(T, [&](int t) { check((int) ((i64) r * t / T), (int) ((i64) r * (t + 1) / T)); });
 	if (bad.load() != 0)
 		return false;
 	// the labels of a search have gaps: heights without empty levels (same order)
@@ -1231,12 +1226,7 @@ static void plan_factor(const struct spasm_csr *U, const int *qinv, FactPlan &P)
 	P.ent.assign((size_t) (nnz > 0 ? nnz : 1), uint2{0, 0});
 	const int T_fill = (r < 20000) ? 1 : std::max(1, std::min(16, usable_cpus()));
 	auto in_threads = [&](auto &&body) {          // body(c0, c1) over equal ranges of the labels
-		std::vector<std::thread> pool;
-		for (int t = 1; t < T_fill; t++)
-			pool.emplace_back(body, (int) ((i64) rpad * t / T_fill), (int) ((i64) rpad * (t + 1) / T_fill));
-		body(0, (int) ((i64) rpad / T_fill));
-		for (auto &th : pool)
-			th.join();
+		sh::pool_run(T_fill, [&](int t) { body((int) ((i64) rpad * t / T_fill), (int) ((i64) rpad * (t + 1) / T_fill)); });
 	};
 	{
 		// (the lengths first -- a cache miss per label, by the threads --, then their running sum)

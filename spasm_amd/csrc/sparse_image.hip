@@ -1671,14 +1671,7 @@ static void sparse_image_plan_host(const FactPlan &P, bool wide, SpPending &H)
 	np_rp.assign((size_t) r + 1, 0);
 	const uint32_t mont_one = (uint32_t) ((1ull << 32) % (uint64_t) prime), mont_minus_one = (uint32_t) ((uint64_t) prime - mont_one);
 	const int T = (r < 50000) ? 1 : std::max(1, std::min(8, usable_cpus()));
-	auto for_rows = [&](auto &&body) {
-		std::vector<std::thread> pool;
-		for (int t = 1; t < T; t++)
-			pool.emplace_back([&, t]() { body((int) ((int64_t) r * t / T), (int) ((int64_t) r * (t + 1) / T)); });
-		body(0, (int) ((int64_t) r / T));
-		for (auto &th : pool)
-			th.join();
-	};
+	auto for_rows = [&](auto &&body) { sh::pool_run(T, [&](int t) { body((int) ((int64_t) r * t / T), (int) ((int64_t) r * (t + 1) / T)); }); };
 	for_rows([&](int n_lo, int n_hi) {
 		for (int n = n_lo; n < n_hi; n++) {
 			const int c = label_of[n];
