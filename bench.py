@@ -5,7 +5,7 @@ Workload (BASELINE.json configs[1]): mk13.b5, the 135135 x 270270 boundary matri
 of K13 (hpac "Homology" collection; rows = 6-edge matchings, columns = 5-edge matchings, 810,810 entries
 +-1), mod 42013, processed the way tools/rank does (tools/rank.c:76-104): transposed to 270270 x 135135,
 structural pivots found on the host, then ONE STEP = the Schur complement of every non-pivotal row w.r.t.
-those pivots (spasm_schur, spasm_schur.c:64) -- here spasm_hip_dschur with A, the factor image and the row
+those pivots (spasm_schur, spasm_schur.c:61) -- here spasm_hip_dschur with A, the factor image and the row
 list already resident in HBM.  Derived factor state (the back-substituted rows R = U_pp^-1 U_pn) is
 forgotten before every step, so a step pays for all of spasm_schur.  There is no network: the matrix is
 regenerated from its definition (tools/workloads.py) unless $SPASM_DATA/mk13.b5.sms exists; `data` says which.
@@ -295,7 +295,7 @@ def dense_tail_probe(torch, spasm_amd, dev, n=4096, m=32768):
 
 def dense_tail_real_probe(torch, spasm_amd, dev, dA, drows, dF, Sm, nrows=4096):
     """the dense tail on a block the flow really produces: the first `nrows` non-pivotal rows of the workload reduced to dense
-    rows by the factor (spasm_schur_dense, spasm_schur.c:258-343) -- for mk13.b5 a 4,096 x 4,952 block of rank ~1,600 (the
+    rows by the factor (spasm_schur_dense, spasm_schur.c:257-343) -- for mk13.b5 a 4,096 x 4,952 block of rank ~1,600 (the
     pivots of the run decide): its first 25 panels of 64 columns are full, then a few hundred live rows face panels with no
     pivot at all, 64 consecutive rows have rank ~40 on a panel, and rows that have become zero stay among the free ones --
     then its RREF (spasm_hip_drref), timed like the random block."""

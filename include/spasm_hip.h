@@ -27,6 +27,8 @@
  *   SPASM_HIP_THREADS=n           host threads of the pivot search and the planning (default: the CPU quota of the cgroup; 1: a
  *                                 sequential search on the host -- a pivot set that does not depend on timing)
  *   SPASM_HIP_PIVOT_SEARCH=host|device   where the greedy cycle-free search runs (default: the device when there is one)
+ *   SPASM_HIP_PIVOT_LABELS=0|1    greedy search without / with depth labels (default 1; 0 with SPASM_HIP_THREADS=1: the reference's
+ *                                 single-thread pivot set, whatever the size of the matrix)
  *   SPASM_HIP_SPARSE_IMAGE=0|1    never / always take the sparse image R = U_pp^-1 U_pn for a Schur complement (default: cost model)
  *   SPASM_HIP_BACKSOLVE=0|1       never / always take the dense image (default: cost model); both 0: row-by-row kernels
  *   SPASM_HIP_DEVICE_FINISH=0|1|2 dense / low-rank finish in the host loops / on the device / on the device only with the dense image
@@ -171,7 +173,7 @@ struct spasm_triplet *spasm_hip_triplet_load(FILE *f, i64 prime, u8 *hash);     
 void spasm_hip_triplet_save(const struct spasm_triplet *A, FILE *f);               /* spasm_io.c:183 */
 void spasm_hip_csr_save(const struct spasm_csr *A, FILE *f);                       /* spasm_io.c:163 */
 
-/* --- structural pivot search (replaces spasm_pivots.c:374) ---
+/* --- structural pivot search (replaces spasm_pivots.c:369) ---
  * The Faugere-Lachartre steps, the topological order and the rows of U are host work.  The greedy cycle-free search
  * (spasm_pivots.c:147-305) of a matrix with at least 20,000 rows runs ON THE DEVICE when the process has one
  * (spasm_amd/csrc/pivots_device.hip: one wavefront per candidate row; up to 2^25 columns; SPASM_HIP_PIVOT_SEARCH=host
@@ -179,11 +181,11 @@ void spasm_hip_csr_save(const struct spasm_csr *A, FILE *f);                    
  * the host search of host_pivots.cpp runs: same transactions, same guarantees (a cycle-free set; which one depends on
  * timing, as it does in the reference under OpenMP; one thread = the reference's sequential outcome). */
 int spasm_hip_pivots_extract_structural(const struct spasm_csr *A, const int *p_in, struct spasm_lu *fact,
-                                        int *p, struct echelonize_opts *opts);     /* spasm_pivots.c:374 */
+                                        int *p, struct echelonize_opts *opts);     /* spasm_pivots.c:369 */
 
 /* --- the hot path: Schur complement on the GPU --- */
 
-/* replaces spasm_schur (spasm_schur.c:64-193).  Row k of the result is the
+/* replaces spasm_schur (spasm_schur.c:61-193).  Row k of the result is the
  * reduction of row p[k] of A (the reference emits rows in thread-arrival
  * order and records the mapping in p_out; here the order is always p's).
  * Entries of a row are sorted by column.  L != NULL: the elimination coefficients are appended to L
@@ -191,15 +193,15 @@ int spasm_hip_pivots_extract_structural(const struct spasm_csr *A, const int *p_
 struct spasm_csr *spasm_hip_schur(const struct spasm_csr *A, const int *p, int n, const struct spasm_lu *fact,
                                   double est_density, struct spasm_triplet *L, const int *p_in, int *p_out);
 
-/* replaces spasm_schur_estimate_density (spasm_schur.c:12-48) */
+/* replaces spasm_schur_estimate_density (spasm_schur.c:11-48) */
 double spasm_hip_schur_estimate_density(const struct spasm_csr *A, const int *p, int n,
                                         const struct spasm_csr *U, const int *qinv, int R);
 
-/* replaces spasm_schur_dense (spasm_schur.c:258-343) */
+/* replaces spasm_schur_dense (spasm_schur.c:257-343) */
 void spasm_hip_schur_dense(const struct spasm_csr *A, const int *p, int n, const int *p_in,
                            struct spasm_lu *fact, void *S, spasm_datatype datatype, int *q, int *p_out);
 
-/* replaces spasm_schur_dense_randomized (spasm_schur.c:357-425) */
+/* replaces spasm_schur_dense_randomized (spasm_schur.c:346-425) */
 void spasm_hip_schur_dense_randomized(const struct spasm_csr *A, const int *p, int n, const struct spasm_csr *U,
                                       const int *qinv, void *S, spasm_datatype datatype, int *q, int N, int w);
 
@@ -328,11 +330,11 @@ typedef struct {
 	/* sparse image (S = A_n - A_p R with R kept as sparse fragments: spasm_amd/csrc/sparse_image.hip) */
 	int used_sparse_image;      /* 1: the rows were computed from the sparse image */
 	int sparse_image_built;     /* 1: ... and the image was (re)built by this call */
-	float ms_sparse_build;      /* device time of that build (sp_build_kernel, one launch per elimination level) */
+	float ms_sparse_build;      /* device time of that build (sp_build_kernel: one cooperative launch, rows handed out by tickets) */
 	float ms_sparse_apply;      /* ... of sp_apply_kernel (fragments of S) */
 	float ms_sparse_gather;     /* ... of the scan of the row lengths + sp_gather_kernel (rows in their final place) */
 	int sparse_image_levels;    /* elimination levels of the factor */
-	int sparse_image_launches;  /* kernels of the build (levels, + those redone after a pool extension) */
+	int sparse_image_launches;  /* launches of the build (1; + one per pool extension; the level-by-level fall-back: one per level) */
 	int sparse_image_pad;
 	i64 sparse_image_nnz;       /* entries of R */
 	i64 sparse_image_ops_build; /* multiply-adds of the build (entries of the fragments added up) */

@@ -299,7 +299,7 @@ void orc_scatter(const orc_csr *A, int i, orc_zp beta, orc_zp *x)
 }
 
 /* ------------------------------------------------------------------ */
-/* Gilbert-Peierls reach.  spasm_reach.c:22-85 (spasm_dfs) and         */
+/* Gilbert-Peierls reach.  spasm_reach.c:21-85 (spasm_dfs) and         */
 /* :100-135 (spasm_reach).  The visiting order (hence the order of     */
 /* xj[top:m]) is the reference's: a column is emitted after everything */
 /* reachable from it, neighbours are explored in row-storage order.    */
@@ -355,7 +355,7 @@ int orc_reach(const orc_csr *U, const orc_csr *B, int k, int *xj, const int *qin
 }
 
 /*
- * x * U = B[k]   (spasm_triangular.c:110-146).  On exit x_b*U + x_a == B[k]
+ * x * U = B[k]   (spasm_triangular.c:109-146).  On exit x_b*U + x_a == B[k]
  * with x_a = x on non-pivotal columns and x_b = x on pivotal ones.
  */
 int orc_sparse_triangular_solve(const orc_csr *U, const orc_csr *B, int k,
@@ -604,7 +604,7 @@ static int *solve_workspace(int m)
 	return xj;
 }
 
-/* spasm_schur.c:12-48 with a private LCG instead of rand() */
+/* spasm_schur.c:11-48 with a private LCG instead of rand() */
 double orc_schur_estimate_density(const orc_csr *A, const int *p, int n,
                                   const orc_csr *U, const int *qinv, int R, unsigned seed)
 {
@@ -631,7 +631,7 @@ double orc_schur_estimate_density(const orc_csr *A, const int *p, int n,
 }
 
 /*
- * spasm_schur.c:64-193 run by one thread: row k of S is the reduction of row
+ * spasm_schur.c:61-193 run by one thread: row k of S is the reduction of row
  * p[k] of A; entries come out in reach order.
  */
 orc_csr *orc_schur(const orc_csr *A, const int *p, int n, orc_lu *F,
@@ -672,7 +672,7 @@ orc_csr *orc_schur(const orc_csr *A, const int *p, int n, orc_lu *F,
 }
 
 /*
- * spasm_schur.c:258-343: dense rows of the Schur complement, columns q[0..Sm)
+ * spasm_schur.c:257-343: dense rows of the Schur complement, columns q[0..Sm)
  * = the non-pivotal columns in increasing order (prepare_q, :195-203).
  * S is n x Sm row-major, values as int64 (the SPASM_I64 datatype).
  */
@@ -916,7 +916,7 @@ static void finish_dense(const orc_csr *A, const int *p, int n, const int *p_in,
 	}
 }
 
-/* spasm_echelonize.c:478-616 */
+/* spasm_echelonize.c:473-616 */
 orc_lu *orc_echelonize(const orc_csr *A0, const orc_opts *opts_in)
 {
 	orc_opts o;

@@ -1,7 +1,7 @@
 // Back-substituted factor image and the Schur complement computed from it.
 //
 // The reference reduces every non-pivotal row a of A by a sparse triangular solve against U
-// (spasm_schur.c:86-171 -> spasm_triangular.c:110-146): x = a U_pp^-1, then s = a_n - x U_pn.  The
+// (spasm_schur.c:86-171 -> spasm_triangular.c:109-146): x = a U_pp^-1, then s = a_n - x U_pn.  The
 // same product can be bracketed the other way round:
 //
 //       S = A_n - A_p (U_pp^-1 U_pn) = A_n - A_p R,
@@ -1512,8 +1512,8 @@ bool backsolve_eligible(int r, int Sm, int64_t nnz_u, int64_t *bytes, int64_t pr
 		return false;
 	// the apply kernels keep one row of S in LDS (96 KB); the one for signed 16-bit entries (p <= 44,927) goes through wider
 	// rows in segments
-	const bool segments = prime < 65536 && sgn_eligible(prime) && env_bs("SPASM_HIP_BS_SIGNED", 1) != 0 && env_bs("SPASM_HIP_BS_PACKED", 1) != 0 &&
-	                      env_bs("SPASM_HIP_BS_STAGED", 1) != 0 && env_bs("SPASM_HIP_BS_SEGMENTS", 1) != 0;
+	const bool segments = prime < 65536 && sgn_eligible(prime) && env_bs("SPASM_HIP_BS_SIGNED", 1) != 0 && true &&
+	                      env_bs("SPASM_HIP_BS_STAGED", 1) != 0 && (1) != 0;
 	if (Sm > (segments ? 131072 : 24576))
 		return false;
 	if ((double) (nnz_u + r) * (double) Sm > 1.5e11)
@@ -1531,7 +1531,7 @@ void backsolve_plan(const FactPlan &P, spasm_hip_dfact *F, hipStream_t stream)
 	// p < 2^16: coefficients are kept as plain residues (the kernels multiply with 24-bit products + Barrett); small p: signed
 	// 16-bit entries of R, coefficients of the dependencies are NEGATED balanced residues (SgnDev above)
 	B.plain = P.prime < 65536;
-	B.sgn = B.plain && sgn_eligible(P.prime) && env_bs("SPASM_HIP_BS_SIGNED", 1) != 0 && env_bs("SPASM_HIP_BS_PACKED", 1) != 0;
+	B.sgn = B.plain && sgn_eligible(P.prime) && env_bs("SPASM_HIP_BS_SIGNED", 1) != 0 && true;
 	// Shape of the build kernel (the plan is cut for it).  0 = 128-byte slab rows, 16 waves; 1 = 128 B, 8 waves; 2 = 64 B, 8
 	// waves; 3 = 32-byte slab rows (16 columns), 8 waves, passes of 64 rows, TWO workgroups per CU.  The build is a chain
 	// (DESIGN.md section 5): a workgroup takes the same time whatever the width of its slab, phase A being bound by the
@@ -1544,11 +1544,11 @@ void backsolve_plan(const FactPlan &P, spasm_hip_dfact *F, hipStream_t stream)
 		hipDeviceProp_t prop;
 		HIP_CHECK(hipGetDeviceProperties(&prop, dev));
 		cus = prop.multiProcessorCount;
-		const bool packed = B.sgn || (P.prime < 65536 && env_bs("SPASM_HIP_BS_PACKED", 1) != 0);
+		const bool packed = B.sgn || (P.prime < 65536 && true);
 		const int slabs_small = packed ? (B.Sm + 31) / 32 : (B.Sm + 15) / 16;
 		const int slabs_narrow = (B.Sm + 15) / 16;
 		int shape = slabs_small <= (packed ? 2 * cus : cus) ? 2 : 0;
-		if (B.sgn && slabs_narrow <= 2 * cus && env_bs("SPASM_HIP_BS_NARROW", 0) != 0)
+		if (B.sgn && slabs_narrow <= 2 * cus && (0) != 0)
 			shape = 3;
 		// 4 / 5 = slabs of 10 / 12 words, as many waves as words (every wave ONE word of every row through phase B: passes of 64
 		// rows), chunks of 1,260 / 1,200 rows.  A workgroup's time is the vector work of its slab on ONE CU (phases A and B are
@@ -1559,7 +1559,7 @@ void backsolve_plan(const FactPlan &P, spasm_hip_dfact *F, hipStream_t stream)
 		const int words = (B.Sm + 1) / 2;
 		// (twelve waves = three per SIMD on all four; ten leave two SIMDs with three and two with two, and the fuller ones set
 		//  the pace: 2.18 against 2.26 ms on mk13.b5, 2.66 for the 64-byte slabs of round 2)
-		if (B.sgn && env_bs("SPASM_HIP_BS_BALANCED", 1) != 0 && (words + 11) / 12 <= cus)
+		if (B.sgn && (1) != 0 && (words + 11) / 12 <= cus)
 			shape = 5;
 		shape = env_bs("SPASM_HIP_BS_SHAPE", shape);
 		if (shape >= 3 && !B.sgn)
@@ -1835,7 +1835,7 @@ void backsolve_plan(const FactPlan &P, spasm_hip_dfact *F, hipStream_t stream)
 		}
 	}
 
-	if (env_bs("SPASM_HIP_BS_STATS", 0)) {
+	if ((0)) {
 		// shape of the plan (tuning aid)
 		int64_t cnt_hist[6] = {0, 0, 0, 0, 0, 0}, empty = 0;
 		for (size_t t = 0; t < ptab.size(); t++) {
@@ -1922,7 +1922,7 @@ void backsolve_build(const spasm_hip_dfact *F, hipStream_t stream)
 	if (!B.planned)
 		die("backsolve_build: the factor has no back-substitution plan");
 	// R is stored in 16 bits when the prime allows (42013, the reference's default, does): half the traffic, half the LDS
-	const bool packed = B.sgn || (F->prime < 65536 && env_bs("SPASM_HIP_BS_PACKED", 1) != 0);
+	const bool packed = B.sgn || (F->prime < 65536 && true);
 	const int elem = packed ? 2 : 4;
 	const size_t bytes = (size_t) B.r * (size_t) B.ldR * (size_t) elem;
 	if (B.d_R != nullptr && B.elem_bytes != elem) {
@@ -1958,7 +1958,7 @@ void backsolve_build(const spasm_hip_dfact *F, hipStream_t stream)
 	b.sgn = B.sgn ? 1 : 0;
 	b.G = sgn_setup(F->prime);
 	b.F = to_dev(F->mont);
-	b.dbg = env_bs("SPASM_HIP_BS_DEBUG", 0);
+	b.dbg = (0);
 	b.prof = nullptr;
 	if (env_bs("SPASM_HIP_BS_PROFILE", 0)) {
 		b.prof = dalloc<unsigned long long>(8);
@@ -2043,7 +2043,7 @@ void backsolve_build(const spasm_hip_dfact *F, hipStream_t stream)
 		fprintf(stderr, " total %.0f\n", (double) tot / B.nchunks);
 		sh::big_free(b.prof);
 	}
-	if (env_bs("SPASM_HIP_BS_CHECK", 0) && b.sparse_init && bytes < ((size_t) 1 << 30)) {
+	if ((0) && b.sparse_init && bytes < ((size_t) 1 << 30)) {
 		// debugging aid: the same build with R pre-filled (the other way of starting the rows), compared entry by entry
 		void *R2 = nullptr;
 		HIP_CHECK(sh::malloc_or_trim(&R2, bytes));
@@ -2109,7 +2109,7 @@ void launch_backsolve_apply(const SchurArgs &a, const spasm_hip_dfact *F, uint32
 	d.Smpad = (int) B.ldR;
 	d.dense_out = dense_out;
 	d.ldS = ldS;
-	d.dbg = env_bs("SPASM_HIP_BS_DEBUG", 0);
+	d.dbg = (0);
 	d.sgn = B.sgn ? 1 : 0;
 	d.G = sgn_setup(F->prime);
 	if (direct != nullptr && dense_out == nullptr) {

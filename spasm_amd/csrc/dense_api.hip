@@ -137,7 +137,7 @@ static int dschur_dense_impl(const spasm_hip_dcsr *A, const int *d_rows, int nro
 	const int cus = prop.multiProcessorCount;
 	i64 slot_bytes, off_bm, off_xn;
 	wave_dense_geometry(F->rpad, F->Sm, wide, &slot_bytes, &off_bm, &off_xn);
-	int slots = env_int("SPASM_HIP_WAVE_SLOTS", cus * 32);
+	int slots = (cus * 32);
 	const i64 budget = (i64) env_int("SPASM_HIP_SCRATCH_GB", 48) << 30;
 	slots = (int) std::max<i64>(cus, std::min<i64>(slots, budget / slot_bytes));
 	slots = std::max(1, std::min(slots, nrows));
@@ -259,7 +259,7 @@ void device_random_dense_rows(const spasm_hip_dcsr &dA, const int *d_rows, int n
 	unsigned long long *dY = (unsigned long long *) big_alloc((size_t) N * (size_t) m * sizeof(unsigned long long));
 	HIP_CHECK(hipMemsetAsync(dY, 0, (size_t) N * m * sizeof(unsigned long long), stream));
 	launch_combine(dA.p, dA.j, dA.x, d_rows, n, N, w, m, salt, dY, F->mont, stream, colmap, base, dA.nnz);
-	if (compact && env_int("SPASM_HIP_COMPACT_DIRECT", 1) != 0) {
+	if (compact && (1) != 0) {
 		// the rows combined hold non-pivotal columns only: their combinations, reduced mod p, ARE the dense rows on those columns
 		// (mk15.b4: 20-26 ms per 4,096 combinations through count / scan / pack / the elimination kernels, of a finish of 100)
 		launch_dense_reduce_rows(dY, N, m, F->mont, d_S, ldS, stream);
@@ -305,7 +305,7 @@ void device_random_dense_rows(const spasm_hip_dcsr &dA, const int *d_rows, int n
 	// a few very long rows: cut into pieces that are reduced side by side and added up (launch_split_rows)
 	const int Sm = F->Sm;
 	int pieces = 1;
-	if (N <= 64 && ynnz / N >= 8192 && env_int("SPASM_HIP_SPLIT_LONG_ROWS", 1) != 0)
+	if (N <= 64 && ynnz / N >= 8192 && (1) != 0)
 		pieces = (int) std::min<i64>(std::min<i64>(64, W->max_rows / N), (ynnz / N + 2047) / 2048);
 	if (pieces > 1) {
 		const int NP = N * pieces;
@@ -460,9 +460,9 @@ bool finish_on_device(const struct spasm_csr *A, const int *p, int n, struct spa
 	// Wide remainders (tens of thousands of columns, rank a few thousand): the rows are added by ROW panels
 	// (device_echelon_extend: one pass over the stack per 64 pivots, E is not factored again); narrow ones go through the
 	// column-panel RREF of the whole stack [E; Y], which is at its best there.  SPASM_HIP_ROW_PANELS=0/1 forces the choice.
-	const int rp_env = env_int("SPASM_HIP_ROW_PANELS", -1);
-	const bool row_panels = prime <= 65279 && (rp_env > 0 || (rp_env < 0 && Sm0 >= env_int("SPASM_HIP_ROW_PANELS_MIN_COLS", 16384)));
-	const bool row_panels_later = prime <= 65279 && rp_env != 0 && env_int("SPASM_HIP_ROW_PANELS_LATER", 1) != 0;
+	const int rp_env = (-1);
+	const bool row_panels = prime <= 65279 && (rp_env > 0 || (rp_env < 0 && Sm0 >= (16384)));
+	const bool row_panels_later = prime <= 65279 && rp_env != 0 && (1) != 0;
 	auto stack_and_reduce = [&](int rows_added) {
 		const double t0 = wtime();
 		const int rk = (row_panels || (row_panels_later && k > 0)) ? device_echelon_extend(prime, Sm0, dM, ld, k, rows_added, dpiv, stream)
@@ -503,7 +503,7 @@ bool finish_on_device(const struct spasm_csr *A, const int *p, int n, struct spa
 		const int *rows_left = drows + processed;
 		// (rows of a Schur complement by this very factor hold non-pivotal columns only -- checked, once: the accumulators of the
 		//  combinations then span Sm columns instead of m)
-		const bool compact = m > 2 * Sm0 && env_int("SPASM_HIP_COMPACT_COMBINATIONS", 1) != 0 &&
+		const bool compact = m > 2 * Sm0 && (1) != 0 &&
 		                     rows_are_nonpivotal(dA.p, dA.j, rows_left, nleft, F->d_lab, (uint32_t) F->rpad, stream);
 		rank_ub = std::min(nleft, Sm0 - k);
 		int w = (opts->low_rank_start_weight < 0) ? (int) std::ceil(-std::log(0.01) * nleft / (rank_ub > 0 ? rank_ub : 1))
@@ -692,7 +692,7 @@ void spasm_hip_schur_dense(const struct spasm_csr *A, const int *p, int n, const
 	logmsg("[schur/dense/hip] %d x %d dense rows in %.1fs\n", n, Sm, wtime() - t0);
 }
 
-// replaces spasm_schur_dense_randomized (spasm_schur.c:357-425): N random combinations of the rows
+// replaces spasm_schur_dense_randomized (spasm_schur.c:346-425): N random combinations of the rows
 // p[0..n) of A (w > 0: of w random rows each, first coefficient 1; w <= 0: of all the rows), reduced
 // by U, as dense rows on the non-pivotal columns.  Everything runs on the device.
 void spasm_hip_schur_dense_randomized(const struct spasm_csr *A, const int *p, int n, const struct spasm_csr *U,

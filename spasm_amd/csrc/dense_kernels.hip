@@ -1974,100 +1974,6 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
 	handoff_signal(S.done_word);
 }
 
-// The same update with a 64 x 128 tile per workgroup (round 5): every wave holds 32 rows x 64 columns -- two 32 x 32 blocks
-// that share the digits of M -- so a K-step of 32 takes six 16-byte LDS reads for eight matrix-core instructions (eight for
-// eight in the 64 x 64 kernel above) and the planes of M are fetched once per 128 columns instead of once per 64.  128
-// accumulator registers: two waves per SIMD.  For the trailing updates beyond a super-panel (no second block of columns).
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) void rref_update_mfma_wide(uint32_t *A, int64_t ld, int n, int c1, int mr, UpdSets S, MontDev F)
-{
-	__shared__ __attribute__((aligned(16))) signed char Mhi[64][64 + 16], Mlo[64][64 + 16];     // [row][k]
-	__shared__ __attribute__((aligned(16))) signed char Bhi[128][64 + 16], Blo[128][64 + 16];   // [col][k]  (transposed)
-	if (S.abort != nullptr && *S.abort != 0)
-		return;
-	const int tid = threadIdx.x;
-	const int row0 = blockIdx.y * 64, col0 = blockIdx.x * 128;
-	const int wave = tid >> 6, lane = tid & 63;
-	const int wr = (wave >> 1) * 32, wc = (wave & 1) * 64;      // this wave's 32 x 64 tile
-	const int rsel = lane & 31, khalf = (lane >> 5) * 16;
-	v16i acc[2][4];
-#pragma unroll
-	for (int b = 0; b < 2; b++)
-#pragma unroll
-		for (int d = 0; d < 4; d++)
-			acc[b][d] = v16i{0};
-	// (the entries of C are fetched after the products, not before: 32 registers that the accumulators need -- with them held
-	//  through the loop the kernel spilled)
-	// thread t moves 16 bytes of row t / 4 of M and of columns t / 4 and 64 + t / 4 of B, per plane
-	const int rr_t = tid >> 2, part = (tid & 3) * 16;
-	const int i_t = row0 + rr_t, j0_t = col0 + rr_t, j1_t = col0 + 64 + rr_t;
-	const int4 zero = make_int4(0, 0, 0, 0);
-	int4 mh, ml, bh0, bl0, bh1, bl1;
-	auto fetch = [&](int s) {
-		mh = (i_t < n) ? *reinterpret_cast<const int4 *>(S.Mh[s] + (int64_t) i_t * 64 + part) : zero;
-		ml = (i_t < n) ? *reinterpret_cast<const int4 *>(S.Ml[s] + (int64_t) i_t * 64 + part) : zero;
-		bh0 = (j0_t < mr) ? *reinterpret_cast<const int4 *>(S.Bh[s] + (int64_t) j0_t * 64 + part) : zero;
-		bl0 = (j0_t < mr) ? *reinterpret_cast<const int4 *>(S.Bl[s] + (int64_t) j0_t * 64 + part) : zero;
-		bh1 = (j1_t < mr) ? *reinterpret_cast<const int4 *>(S.Bh[s] + (int64_t) j1_t * 64 + part) : zero;
-		bl1 = (j1_t < mr) ? *reinterpret_cast<const int4 *>(S.Bl[s] + (int64_t) j1_t * 64 + part) : zero;
-	};
-	fetch(0);
-#pragma unroll
-	for (int s = 0; s < MAXSETS; s++) {          // (static indices into the kernel arguments)
-		if (s >= S.nsets)
-			break;
-		if (s > 0)
-			__syncthreads();
-		*reinterpret_cast<int4 *>(&Mhi[rr_t][part]) = mh;
-		*reinterpret_cast<int4 *>(&Mlo[rr_t][part]) = ml;
-		*reinterpret_cast<int4 *>(&Bhi[rr_t][part]) = bh0;
-		*reinterpret_cast<int4 *>(&Blo[rr_t][part]) = bl0;
-		*reinterpret_cast<int4 *>(&Bhi[64 + rr_t][part]) = bh1;
-		*reinterpret_cast<int4 *>(&Blo[64 + rr_t][part]) = bl1;
-		__syncthreads();
-		if (s + 1 < MAXSETS && s + 1 < S.nsets)
-			fetch(s + 1 < MAXSETS ? s + 1 : MAXSETS - 1);
-#pragma unroll
-		for (int ks = 0; ks < 64; ks += 32) {
-			const v4i a_hi = *reinterpret_cast<const v4i *>(&Mhi[wr + rsel][ks + khalf]);
-			const v4i a_lo = *reinterpret_cast<const v4i *>(&Mlo[wr + rsel][ks + khalf]);
-#pragma unroll
-			for (int b = 0; b < 2; b++) {
-				const v4i b_hi = *reinterpret_cast<const v4i *>(&Bhi[wc + 32 * b + rsel][ks + khalf]);
-				const v4i b_lo = *reinterpret_cast<const v4i *>(&Blo[wc + 32 * b + rsel][ks + khalf]);
-				acc[b][0] = __builtin_amdgcn_mfma_i32_32x32x32_i8(a_hi, b_hi, acc[b][0], 0, 0, 0);
-				acc[b][1] = __builtin_amdgcn_mfma_i32_32x32x32_i8(a_hi, b_lo, acc[b][1], 0, 0, 0);
-				acc[b][2] = __builtin_amdgcn_mfma_i32_32x32x32_i8(a_lo, b_hi, acc[b][2], 0, 0, 0);
-				acc[b][3] = __builtin_amdgcn_mfma_i32_32x32x32_i8(a_lo, b_lo, acc[b][3], 0, 0, 0);
-			}
-		}
-	}
-	const double pd = (double) F.p, invp = 1.0 / pd;
-#pragma unroll
-	for (int b = 0; b < 2; b++) {
-		uint32_t cval[16];
-#pragma unroll
-		for (int reg = 0; reg < 16; reg++) {
-			const int i = row0 + wr + (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5), j = col0 + wc + 32 * b + (lane & 31);
-			cval[reg] = (i < n && j < mr) ? A[(int64_t) i * ld + c1 + j] : 0u;
-		}
-#pragma unroll
-		for (int reg = 0; reg < 16; reg++) {
-			const int rr = (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5);
-			const int i = row0 + wr + rr, j = col0 + wc + 32 * b + (lane & 31);
-			if (i >= n || j >= mr)
-				continue;
-			const double sd = fma((double) acc[b][0][reg], 65536.0, fma((double) (acc[b][1][reg] + acc[b][2][reg]), 256.0, (double) acc[b][3][reg]));
-			const double qd = floor(sd * invp);
-			double rd = fma(-qd, pd, sd);
-			rd = (rd < 0.0) ? rd + pd : rd;
-			rd = (rd >= pd) ? rd - pd : rd;
-			uint32_t sum = cval[reg] + (uint32_t) rd;
-			if (sum >= F.p)
-				sum -= F.p;
-			A[(int64_t) i * ld + c1 + j] = sum;
-		}
-	}
-}
 
 // echelon rows to the top, in pivot-column order (rows that hold no pivot are zero after the
 // full elimination): tmp[t, :] = A[pivrow[t], :], then copied back.
@@ -2295,23 +2201,21 @@ int device_rref(int64_t prime, int n, int m, uint32_t *dA, int64_t ld, int *d_pi
 	int stat_opt_ok = 0, stat_regular = 0, stat_aborts = 0, stat_marked = 0;          // panels done by the optimistic pass / the regular way; super-panels
 	if (tournament) {
 		const bool small16 = prime < 65536;
-		const bool try_first = sh::env_get("SPASM_HIP_RREF_TRY") == nullptr || std::atoi(sh::env_get("SPASM_HIP_RREF_TRY")) != 0;
+		const bool try_first = true;
 		// the 64 x 64 inversion kernel for the try: signed representatives with deferred reduction need 4 B^2 + B < 2^31, B = p/2 + p/64 + 1
 		bool fast_try = small_prime && (4 * (prime / 2 + prime / 64 + 1) * (prime / 2 + prime / 64 + 1) + (prime / 2 + prime / 64 + 1) <= 0x7FFFFFFFll);
-		if (const char *e = sh::env_get("SPASM_HIP_RREF_FAST_TRY"))
-			fast_try = fast_try && std::atoi(e) != 0;
 		// panels per super-panel: eight on the matrix cores (K = 512 per pass over the matrix), four with VALU updates
-		const int SPW = mfma_ok ? std::min(MAXSETS, std::max(1, sh::env_get("SPASM_HIP_RREF_SPW") ? std::atoi(sh::env_get("SPASM_HIP_RREF_SPW")) : MAXSETS)) : 4;
+		const int SPW = mfma_ok ? MAXSETS : 4;
 		const int64_t ldz = (int64_t) MAXSETS * NB;
 		signed char *Bown_h = B8 + (size_t) MAXSETS * 2 * (size_t) m * 64, *Bown_l = Bown_h + (size_t) (2 * MAXSETS * NB + 64) * 64;
 		bool far_pending = false;
-		const bool optimistic_enabled = sh::env_get("SPASM_HIP_RREF_OPTIMISTIC") == nullptr || std::atoi(sh::env_get("SPASM_HIP_RREF_OPTIMISTIC")) != 0;
+		const bool optimistic_enabled = true;
 		bool optimistic_ok = optimistic_enabled;
 		int optimistic_skip = 0;
 		// a try has failed in this call: from the next super-panel on the zero rows are retired and the candidates of the tries
 		// are spread over the live ones (rref_mark_dead, pick_candidates)
 		bool deficient = false;
-		const bool retire_rows = sh::env_get("SPASM_HIP_RREF_RETIRE") == nullptr || std::atoi(sh::env_get("SPASM_HIP_RREF_RETIRE")) != 0;
+		const bool retire_rows = true;
 		uint32_t *set_P[MAXSETS] = {};
 		int *set_rho[MAXSETS] = {}, *set_knew[MAXSETS] = {};
 		signed char *set_Mh[MAXSETS] = {}, *set_Ml[MAXSETS] = {};
@@ -2557,10 +2461,10 @@ int device_rref(int64_t prime, int n, int m, uint32_t *dA, int64_t ld, int *d_pi
 					// (knew[1] of a slot = the pivots a mode-2 try has taken, for rref_rollback: nothing yet)
 					HIP_CHECK(hipMemset2DAsync(knew4 + (size_t) (spi & 1) * MAXSETS * 16 + 1, 16 * sizeof(int), 0, sizeof(int), MAXSETS, stream));
 					// one panel ahead: plain optimistic passes only (full panels, no list of live rows, p < 2^16)
-					// (... and blocks of at most SPASM_HIP_RREF_LOOKAHEAD_ROWS rows, 6,144 by default: beyond, the multipliers and the update
+					// (... and blocks of at most 6,144 rows: beyond, the multipliers and the update
 					//  of a panel take longer than its try -- the chain is no longer what the call waits for, and two streams of kernels that
 					//  poll each other only get in the way: 16,384 x 16,384 went from 40 to 53 ms with it)
-					const int look_rows = sh::env_get("SPASM_HIP_RREF_LOOKAHEAD_ROWS") ? std::atoi(sh::env_get("SPASM_HIP_RREF_LOOKAHEAD_ROWS")) : 6144;
+					const int look_rows = 6144;
 					const bool look = use_ahead && !have_live && small16 && npanels - start >= 2 && n <= look_rows;
 					if (!look) {
 						for (int i = start; i < npanels; i++)
@@ -2683,16 +2587,11 @@ int device_rref(int64_t prime, int n, int m, uint32_t *dA, int64_t ld, int *d_pi
 				S.nsets = nsets;
 				// near part (the next super-panel's own columns) on this stream, far part on the second one
 				const int near = (mfma_ok && stream2 != nullptr) ? std::min(mrT, SPW * NB) : mrT;
-				const char *mw_env = sh::env_get("SPASM_HIP_MFMA_WIDE");
-				// (off by default: serialised, the updates of a 4,096 x 32,768 block take 5.6 ms with it against 7.4 -- 24 % less --, but
-				//  the updates run BESIDE the chain of panel steps, which is what the call waits for, and two waves per SIMD of a
-				//  256-register kernel take more from that chain than the shorter updates give back: 9.8 ms against 9.3 for the call)
-				const int mfma_wide = (mw_env == nullptr || *mw_env == 0) ? 0 : std::atoi(mw_env);
+				// (a 64 x 128 tile kernel, two waves per SIMD, 256 registers, was built in round 5 and took 24 % less serialised time for the
+				//  updates -- and 5 % MORE for the call, with and without the lookahead of round 6: removed)
 				timed([&]() {
 					dim3 grid((near + 63) / 64, (n + 63) / 64);
-					if (mfma_ok && mfma_wide != 0 && S.Z2 == nullptr) {
-						hipLaunchKernelGGL(rref_update_mfma_wide, dim3((near + 127) / 128, (n + 63) / 64), dim3(256), 0, stream, dA, ld, n, sp_end, near, S, F);
-					} else if (mfma_ok) {
+					if (mfma_ok) {
 						hipLaunchKernelGGL(rref_update_mfma_multi, grid, dim3(256), 0, stream, dA, ld, n, sp_end, near, S, F);
 					} else {
 						for (int s = 0; s < nsets; s++)
@@ -2711,10 +2610,7 @@ int device_rref(int64_t prime, int n, int m, uint32_t *dA, int64_t ld, int *d_pi
 					dim3 grid((mrT - near + 63) / 64, (n + 63) / 64);
 					if (ms_update != nullptr)
 						HIP_CHECK(hipEventRecord(e0, stream2));
-					if (mfma_wide != 0 && Sf.Z2 == nullptr)
-						hipLaunchKernelGGL(rref_update_mfma_wide, dim3((mrT - near + 127) / 128, (n + 63) / 64), dim3(256), 0, stream2, dA, ld, n, sp_end + near, mrT - near, Sf, F);
-					else
-						hipLaunchKernelGGL(rref_update_mfma_multi, grid, dim3(256), 0, stream2, dA, ld, n, sp_end + near, mrT - near, Sf, F);
+					hipLaunchKernelGGL(rref_update_mfma_multi, grid, dim3(256), 0, stream2, dA, ld, n, sp_end + near, mrT - near, Sf, F);
 					HIP_CHECK(hipEventRecord(ev_far, stream2));
 					far_pending = true;
 					if (ms_update != nullptr) {          // (timing runs serialise the two streams)
@@ -3724,7 +3620,7 @@ void launch_combine(const int64_t *Ap, const int *Aj, const int *Ax, const int *
 {
 	const int64_t terms = (w > 0) ? (int64_t) w : (int64_t) nrows;
 	const int64_t total = (int64_t) N * terms;
-	if (w <= 0 && N <= 16 && nrows >= 4096 && M.p < 65536 && !sh::env_get("SPASM_HIP_COMBINE_PER_PAIR") && !sh::env_get("SPASM_HIP_COMBINE_ATOMIC")) {
+	if (w <= 0 && N <= 16 && nrows >= 4096 && M.p < 65536) {
 		// every row, few combinations, p < 2^16: block sums in LDS, one atomic per occupied (column, combination) and workgroup
 		const size_t lds = (size_t) CB_COLS * N * sizeof(uint32_t) + (size_t) CB_ROWS * N * sizeof(unsigned short);
 		static size_t configured = 0;
@@ -3781,7 +3677,7 @@ void launch_combine(const int64_t *Ap, const int *Aj, const int *Ax, const int *
 		// (rows that are not sorted by column: Y holds part of the sums -- start again, the other way)
 		HIP_CHECK(hipMemsetAsync(Y, 0, (size_t) N * m * sizeof(unsigned long long), stream));
 	}
-	if (w <= 0 && N <= 16 && nrows >= 4096 && !sh::env_get("SPASM_HIP_COMBINE_PER_PAIR")) {
+	if (w <= 0 && N <= 16 && nrows >= 4096) {
 		// every row, few combinations: each row once, the combinations side by side (combine_all_rows_kernel); Y arrives zeroed
 		unsigned long long *Yt = (unsigned long long *) big_alloc((size_t) m * 16 * sizeof(unsigned long long));
 		HIP_CHECK(hipMemsetAsync(Yt, 0, (size_t) m * 16 * sizeof(unsigned long long), stream));

@@ -107,7 +107,7 @@ void spasm_hip_debug_prng(i64 prime, uint64_t seed, uint32_t seq, int count, spa
 		out[i] = g.next_zp();
 }
 
-// replaces spasm_schur_estimate_density (spasm_schur.c:12-48): average density of R sampled rows
+// replaces spasm_schur_estimate_density (spasm_schur.c:11-48): average density of R sampled rows
 double spasm_hip_schur_estimate_density(const struct spasm_csr *A, const int *p, int n, const struct spasm_csr *U,
                                         const int *qinv, int R)
 {
@@ -462,7 +462,7 @@ extern "C" struct spasm_lu *spasm_hip_echelonize(const struct spasm_csr *A0, str
 		{
 			Stopwatch sw(3);
 			// the entries of S stay on the device until somebody needs them on the host (see below)
-			resident_lazy_downloads(round + 1 < opts->max_round && env_int_host("SPASM_HIP_LAZY_DOWNLOAD", 1) != 0);
+			resident_lazy_downloads(round + 1 < opts->max_round && (1) != 0);
 			S = spasm_hip_schur(A, p + npiv, n - npiv, fact, density, fact->Ltmp, p_in, p_out);
 			resident_lazy_downloads(false);
 		}
@@ -486,7 +486,7 @@ extern "C" struct spasm_lu *spasm_hip_echelonize(const struct spasm_csr *A0, str
 		// (the factor 8 is the largest ratio (pivots of a whole search) / (its first step) seen on the generated families, where it is
 		//  1.1-1.5; a matrix whose greedy step finds ten times what its leftmost entries give would be cut short here:
 		//  SPASM_HIP_CENSUS_FACTOR raises it, 0 switches the short cut off -- the round then runs and decides by itself)
-		const double census_factor = (double) env_int_host("SPASM_HIP_CENSUS_FACTOR", 8);
+		const double census_factor = (double) (8);
 		if (census >= 0 && census_factor > 0 && census_factor * census < opts->min_pivot_proportion * std::min(n, m - U->n)) {
 			logmsg("[echelonize] %d leftmost-entry pivots in the Schur complement (counted on the device): not enough for another round\n", census);
 			npiv = 0;

@@ -114,8 +114,8 @@ void pool_run(int ntasks, const std::function<void(int)> &fn)
 const char *env_get(const char *name)
 {
 	// (the list of include/spasm_hip.h, section "Environment")
-	static const char *const supported[] = {"SPASM_HIP_VERBOSE", "SPASM_HIP_THREADS", "SPASM_HIP_PIVOT_SEARCH", "SPASM_HIP_BACKSOLVE", "SPASM_HIP_SPARSE_IMAGE",
-	                                        "SPASM_HIP_DEVICE_FINISH", "SPASM_HIP_KEEP_GB", "SPASM_HIP_SCRATCH_GB", "SPASM_HIP_STAGE_GB",
+	static const char *const supported[] = {"SPASM_HIP_VERBOSE", "SPASM_HIP_THREADS", "SPASM_HIP_PIVOT_SEARCH", "SPASM_HIP_PIVOT_LABELS", "SPASM_HIP_BACKSOLVE",
+	                                        "SPASM_HIP_SPARSE_IMAGE", "SPASM_HIP_DEVICE_FINISH", "SPASM_HIP_KEEP_GB", "SPASM_HIP_SCRATCH_GB", "SPASM_HIP_STAGE_GB",
 	                                        "SPASM_HIP_SPARSE_IMAGE_GB", "SPASM_HIP_EXPERIMENT"};
 	const char *v = std::getenv(name);
 	if (v == nullptr)
@@ -123,12 +123,11 @@ const char *env_get(const char *name)
 	for (const char *s : supported)
 		if (std::strcmp(s, name) == 0)
 			return v;
-	static int experiment = -1;
-	if (experiment < 0) {
-		const char *e = std::getenv("SPASM_HIP_EXPERIMENT");
-		experiment = (e != nullptr && *e != 0 && std::strcmp(e, "0") != 0) ? 1 : 0;
-	}
-	if (experiment == 0) {
+	// (read at every look-up: a caller that sets SPASM_HIP_EXPERIMENT around one call -- tools/workloads.py does -- must neither
+	//  find it ignored because an earlier look-up cached "off", nor leave it on for the rest of the process)
+	const char *e = std::getenv("SPASM_HIP_EXPERIMENT");
+	const bool experiment = e != nullptr && *e != 0 && std::strcmp(e, "0") != 0;
+	if (!experiment) {
 		static bool warned = false;
 		if (!warned) {
 			warned = true;

@@ -1474,7 +1474,7 @@ int device_acyclic_greedy(const struct spasm_csr *A, int *pinv, int *qinv, std::
 	const int fifo_cap_labels = std::min(m + 4096, env_int("SPASM_HIP_PIVOT_LABEL_FIFO", 32768)) + 2 * casc_cap_late + 256;
 	// searches in flight per CU: 4 with the marks in LDS (the step is bound by instruction issue: more only adds speculation),
 	// 8 with the marks in HBM (bound by memory latency: mk14.b5 6.4 s at 2, 4.2 at 4, 3.4 at 8)
-	const int per_cu_wanted = env_int("SPASM_HIP_PIVOT_WAVES_PER_CU", global_bits ? 8 : 4);
+	const int per_cu_wanted = (global_bits ? 8 : 4);
 	int per_cu = std::max(1, std::min(per_cu_wanted, (int) ((160 * 1024) / lds)));
 	int per_cu_labels = std::max(1, std::min(per_cu_wanted, (int) ((160 * 1024) / lds_labels)));
 	// (a search owns a FIFO of m + 4096 columns, and m / 8 bytes of marks with global_bits: at most 16 GB in all)
@@ -1485,7 +1485,7 @@ int device_acyclic_greedy(const struct spasm_csr *A, int *pinv, int *qinv, std::
 	while (per_cu_labels > 1 && (size_t) cus * per_cu_labels * per_search_labels > ((size_t) 16 << 30))
 		per_cu_labels -= 1;
 	// (behind the labelled search the ticket search gets a fraction of the rows: 512 searches at a time are plenty)
-	const int grid = labels ? std::min(cus * per_cu, std::max(64, env_int("SPASM_HIP_PIVOT_SECOND_PASS_SEARCHES", 512))) : cus * per_cu;
+	const int grid = labels ? std::min(cus * per_cu, std::max(64, (512))) : cus * per_cu;
 	const int grid_labels = cus * per_cu_labels, grid_max = std::max(grid, labels ? grid_labels : 0);
 	std::vector<void *> owned;
 	auto dal = [&](size_t bytes) {
@@ -1753,14 +1753,14 @@ int device_acyclic_greedy(const struct spasm_csr *A, int *pinv, int *qinv, std::
 	// ---- the labels of the final pivot set (see the head of this function)
 	// (only when the ticket search added few pivots: every one of them hangs a long chain of sweeps under its row -- mk13.b5,
 	//  450 of them: not settled after 30 ms, which were then lost)
-	if (found >= 0 && labels && lab != nullptr && col_label != nullptr && ticket_pivots <= env_int("SPASM_HIP_PIVOT_ORDER_MAX_TICKET_PIVOTS", 64) &&
+	if (found >= 0 && labels && lab != nullptr && col_label != nullptr && ticket_pivots <= (64) &&
 	    env_int("SPASM_HIP_PIVOT_ORDER_BY_LABELS", 1) != 0) {
 		const double tl = wtime();
 		sh::h2d(d_qinv, qinv, (size_t) m * sizeof(int), stream);
 		hipLaunchKernelGGL(pivot_labels_states_kernel, dim3((m + 255) / 256), dim3(256), 0, stream, d_qinv, m, lab);
 		int sweeps = 0;
 		bool settled = false;
-		const double patience = 1e-3 * (double) env_int("SPASM_HIP_PIVOT_ORDER_MS", 30);
+		const double patience = 1e-3 * (double) (30);
 		// one sweep that lists what it raised, then the rounds of the chase in batches of 64 launches (see the kernels)
 		if (env_int("SPASM_HIP_PIVOT_ORDER_CHASE", 1) != 0) {
 			const int qcap = 1 << 22;
@@ -1769,7 +1769,7 @@ int device_acyclic_greedy(const struct spasm_csr *A, int *pinv, int *qinv, std::
 			HIP_CHECK(hipMemsetAsync(d_cnt, 0, 4 * sizeof(int), stream));
 			hipLaunchKernelGGL(pivot_labels_relax_list_kernel, dim3((m + 255) / 256), dim3(256), 0, stream, dA.p, dA.j, d_qinv, m, lab, d_q0, qcap, d_cnt);
 			int k = 0, listed = 0;
-			const int max_rounds = env_int("SPASM_HIP_PIVOT_ORDER_ROUNDS", 1 << 16);
+			const int max_rounds = (1 << 16);
 			for (;;) {
 				for (int t = 0; t < 64; t++, k++)
 					hipLaunchKernelGGL(pivot_labels_round_kernel, dim3(256), dim3(256), 0, stream, dA.p, dA.j, d_qinv, lab, (k & 1) ? d_q1 : d_q0, (k & 1) ? d_q0 : d_q1, qcap, d_cnt, k);
@@ -1790,7 +1790,7 @@ int device_acyclic_greedy(const struct spasm_csr *A, int *pinv, int *qinv, std::
 		// (without the chase: a sweep moves the labels one level down the chains that hang under the pivots of the ticket search: a dozen of them on
 		//  mk15.b4 -- 64-330 sweeps, 4-15 ms, against 35 + 8 ms of depth-first search and check on the host --, three thousand
 		//  on mk15.b5 -- 6,700 sweeps, 0.87 s: given up after 30 ms, the host then orders as before)
-		const int limit = env_int("SPASM_HIP_PIVOT_ORDER_SWEEPS", 16384);
+		const int limit = (16384);
 		while (!settled && sweeps >= 0 && sweeps < limit && wtime() - tl < patience) {
 			HIP_CHECK(hipMemsetAsync(d_changed_final, 0, sizeof(int), stream));
 			for (int t = 0; t < 8; t++)

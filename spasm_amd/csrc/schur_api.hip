@@ -132,7 +132,7 @@ void *big_alloc(size_t bytes)
 		// the call, which depends on timing, and differ by tens of percent from one call to the next.  With exact sizes and a
 		// window of 1.5x the third mk15.b4 call of a process still fetched 62 GB from the device (3.5 s inside one sparse round;
 		// spasm_hip_echelonize_counters: block_cache_miss_bytes), the fourth 21 GB.
-		static const bool classes = env_int("SPASM_HIP_BLOCK_CLASSES", 1) != 0;
+		static const bool classes = (1) != 0;
 		size_t step = (size_t) 1 << 20;
 		while ((step << 4) <= bytes)
 			step <<= 1;
@@ -149,7 +149,10 @@ void *big_alloc(size_t bytes)
 			// (... and in the end ANY parked block that is large enough, the smallest one first: the bench's first mk15.b4 call after
 			//  the phase with the 19 GB pools of the fixed pivot set found those parked, more than four times what it wanted, took 9 GB
 			//  fresh right after 100 GB had gone back to the device, and spent 2.9 s on their first touch)
-			const size_t most = !classes ? bytes + bytes / 2 : (bytes >= ((size_t) 256 << 20) ? ~(size_t) 0 : 2 * bytes);
+			// (round 6: bounded again, at four times the size or 8 GB more, whichever is larger -- a 300 MB buffer could pin a 19 GB block
+			//  for its lifetime and send the next 19 GB request to the device for 28 GB fresh; the bench's case above, a 9 GB request
+			//  that finds 19 GB parked, still fits)
+			const size_t most = !classes ? bytes + bytes / 2 : (bytes >= ((size_t) 256 << 20) ? std::max(4 * bytes, bytes + ((size_t) 8 << 30)) : 2 * bytes);
 			if (have >= bytes && have <= most && (best < 0 || have < g_big.free_blocks[(size_t) best].second))
 				best = (int) t;
 		}
@@ -179,8 +182,17 @@ void *big_alloc(size_t bytes)
 	// part nobody asked for is never touched and costs nothing but address space of a 288 GB device.
 	g_device_mallocs += 1;
 	size_t take = bytes;
-	if (big && bytes >= ((size_t) 256 << 20))
-		take = bytes + bytes / 100 * (size_t) std::max(0, std::min(100, env_int("SPASM_HIP_BLOCK_HEADROOM_PCT", 50)));
+	if (big && bytes >= ((size_t) 256 << 20)) {
+		// (the headroom follows what the device has left: half again when eight times the request is free, nothing when less than
+		//  twice is -- on a device smaller than these 288 GB, or shared, the headroom must not be what runs it out of memory)
+		size_t free_b = 0, total_b = 0;
+		if (hipMemGetInfo(&free_b, &total_b) != hipSuccess) {
+			(void) hipGetLastError();
+			free_b = 0;
+		}
+		const size_t pct = free_b >= 8 * bytes ? 50 : free_b >= 4 * bytes ? 25 : free_b >= 2 * bytes ? 10 : 0;
+		take = bytes + bytes / 100 * pct;
+	}
 	if (take > bytes && hipMalloc(&ptr, take) != hipSuccess) {
 		(void) hipGetLastError();
 		ptr = nullptr;
@@ -419,7 +431,7 @@ void h2d(void *dst, const void *src, size_t bytes, hipStream_t stream)
 {
 	if (bytes == 0)
 		return;
-	static const bool staged = env_int("SPASM_HIP_STAGED_H2D", 1) != 0;
+	static const bool staged = (1) != 0;
 	if (!staged || bytes < ((size_t) 256 << 10)) {
 		HIP_CHECK(hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, stream));
 		return;
@@ -493,7 +505,7 @@ void d2h(void *dst, const void *src, size_t bytes, hipStream_t stream)
 {
 	if (bytes == 0)
 		return;
-	static const bool staged = env_int("SPASM_HIP_STAGED_H2D", 1) != 0;
+	static const bool staged = (1) != 0;
 	bool direct = !staged || bytes < ((size_t) 256 << 10) || bytes > ((size_t) 256 << 20);
 	std::unique_lock<std::mutex> guard(g_h2d.mutex, std::defer_lock);
 	if (!direct) {
@@ -573,14 +585,14 @@ void resident_end()
 	// is erratic on these boxes -- 0.1 to 1 s apiece, now and then -- and made five of eight consecutive mk14.b4 calls take
 	// 1.0-2.3 s instead of 0.55 (keeping 32 or 64 GB did not help: whatever is handed back comes back slowly).
 	// spasm_hip_release_cached_memory() gives everything back; a failed hipMalloc of the library's own does too (big_alloc).
-	if (env_int("SPASM_HIP_KEEP_BLOCKS", 0) == 0) {
+	if ((0) == 0) {
 		// (default: a third of the device memory, at most the cap of the cache -- a quarter, 72 GB here, was tried in round 4 and is
 		//  less than one mk15.b4 call parks: every call then gave 10-20 GB back and paid 1-2 s to get them again, in whichever
 		//  stage asked first --; and whatever sat unused through two calls in a row goes back whatever the total)
 		size_t free_b = 0, total_b = 0;
 		HIP_CHECK(hipMemGetInfo(&free_b, &total_b));
 		const int dflt = (int) std::min<size_t>(96, (total_b >> 30) / 3);
-		big_age(env_int("SPASM_HIP_KEEP_CALLS", 2));
+		big_age((2));
 		big_trim((size_t) std::max(0, env_int("SPASM_HIP_KEEP_GB", dflt)) << 30);
 	}
 }
@@ -987,7 +999,7 @@ static bool heights_from_hint(const struct spasm_csr *U, const int *qinv, std::v
 	{
 		std::lock_guard<std::mutex> guard(sh::g_level_hint_mutex);
 		if (sh::g_level_hint.U != (const void *) U || sh::g_level_hint.rows != r || (int) sh::g_level_hint.height.size() != r || r < 20000 ||
-		    env_int("SPASM_HIP_LEVEL_HINT", 1) == 0)
+		    (1) == 0)
 			return false;
 		height = sh::g_level_hint.height;
 	}
@@ -1448,7 +1460,7 @@ spasm_hip_dfact *spasm_hip_dfact_create(const struct spasm_csr *U, const int *qi
 	const bool plan_sparse = sparse_image_possible(F->prime) && r > 0 && m - r > 0 &&
 	                         (env_int("SPASM_HIP_SPARSE_IMAGE", -1) == 1 || (m - r >= 8192 && (double) r * (double) (m - r) >= 5e8));
 	// (large factors: by a thread of their own, started below once the plan stands where it will stay)
-	const bool plan_sparse_async = plan_sparse && r >= 100000 && env_int("SPASM_HIP_SPARSE_IMAGE_PLAN_ASYNC", 1) != 0;
+	const bool plan_sparse_async = plan_sparse && r >= 100000 && (1) != 0;
 	if (plan_sparse && !plan_sparse_async)
 		sparse_image_plan(P, F, stream);
 	const double t_bs = wtime();
@@ -1456,7 +1468,7 @@ spasm_hip_dfact *spasm_hip_dfact_create(const struct spasm_csr *U, const int *qi
 		logmsg("[factor image] tables of the sparse image: %.1f ms\n", 1e3 * (t_bs - t_uploaded));
 	int64_t bs_bytes = 0;
 	if (env_int("SPASM_HIP_BACKSOLVE", -1) != 0 && backsolve_eligible(r, m - r, F->nnz, &bs_bytes, F->prime)) {
-		if (plan_sparse && env_int("SPASM_HIP_BACKSOLVE", -1) != 1 && env_int("SPASM_HIP_BS_PLAN_EAGER", 0) == 0) {
+		if (plan_sparse && env_int("SPASM_HIP_BACKSOLVE", -1) != 1 && (0) == 0) {
 			// the plan of the dense image waits for a batch that wants it (backsolve_build); what the path choice reads is known now
 			F->bs.r = r;
 			F->bs.Sm = m - r;
@@ -1657,7 +1669,7 @@ int dschur_impl(const spasm_hip_dcsr *A, const int *d_rows, int nrows, const spa
 	// ... and in the dense accumulators: a column receives at most maxdeg + 1 terms, each below 2p (the
 	// row-group kernel adds unreduced products)
 	bool wide_dense = false;          // (set below, once it is known that a row-by-row path runs: it needs the tables of ensure_row_tables)
-	const int sort_rows = env_int("SPASM_HIP_SORT_ROWS", 1);
+	const int sort_rows = (1);
 	const int small_table = 1024, big_table = 8192;
 	const int cus = cu_count();
 	// tests: 1 = start at the large LDS table, 2 = dense accumulators only.  The large table is otherwise
@@ -1665,7 +1677,7 @@ int dschur_impl(const spasm_hip_dcsr *A, const int *d_rows, int nrows, const spa
 	int force_tier = env_int("SPASM_HIP_FORCE_TIER", 0);
 	if (Lout != nullptr)
 		force_tier = 2;         // rows must not be restarted once coefficients have been recorded: no LDS tiers
-	const bool use_big = (force_tier == 1) || env_int("SPASM_HIP_USE_BIG_TABLE", 0);
+	const bool use_big = (force_tier == 1) || (0);
 
 	// row-group kernel (64 consecutive rows per wave, label-major state) for every row: default for
 	// batches large enough to fill the GPU with groups; SPASM_HIP_GROUP=0/1 forces the choice.
@@ -1692,14 +1704,14 @@ int dschur_impl(const spasm_hip_dcsr *A, const int *d_rows, int nrows, const spa
 	if (!want_bs && !want_sp) {
 		// (the components of the pivot graph are what the row-GROUP kernel regroups its rows by: a density sample of 100 rows on the
 		//  per-row tiers only needs the column degrees -- 10 ms of union-find on mk15.b4's factor that nothing ever read)
-		ensure_row_tables(F, stream, group_mode != 0 || env_int("SPASM_HIP_LAZY_COMPONENTS", 1) == 0);
+		ensure_row_tables(F, stream, group_mode != 0 || (1) == 0);
 		wide_dense = (2.0 * (double) F->prime * ((double) F->maxdeg + 3.0) >= 4294967296.0);
 	}
 	// per-wave dense scratch, (re)allocated when the factor geometry needs more
 	if (!want_bs && !want_sp) {
 		i64 slot_bytes, off_bm, off_xn;
 		wave_dense_geometry(F->rpad, F->Sm, wide_dense, &slot_bytes, &off_bm, &off_xn);
-		int slots = env_int("SPASM_HIP_WAVE_SLOTS", cus * 32);
+		int slots = (cus * 32);
 		// accumulator slices may take up to half of the free HBM (288 GB parts: be generous), or what
 		// SPASM_HIP_SCRATCH_GB says
 		size_t free_b = 0, total_b = 0;
@@ -1735,7 +1747,7 @@ int dschur_impl(const spasm_hip_dcsr *A, const int *d_rows, int nrows, const spa
 			// 641 ms against 334 ms with four waves per group)
 			const i64 in_flight = std::min<i64>(ngroups, budget / group_slot_bytes);
 			group_waves = env_int("SPASM_HIP_GROUP_WAVES", in_flight <= cus * 3 ? 4 : in_flight <= cus * 12 ? 2 : 1);
-			group_slots = (int) std::min<i64>(env_int("SPASM_HIP_GROUP_SLOTS", group_waves >= 4 ? cus * 2 : group_waves >= 2 ? cus * 4 : cus * 8),
+			group_slots = (int) std::min<i64>((group_waves >= 4 ? cus * 2 : group_waves >= 2 ? cus * 4 : cus * 8),
 			                                  budget / group_slot_bytes);
 			group_slots = std::max(1, std::min(group_slots, ngroups));
 			// with the automatic fallback the per-row tier may run in the same buffer afterwards
@@ -1888,7 +1900,7 @@ int dschur_impl(const spasm_hip_dcsr *A, const int *d_rows, int nrows, const spa
 			// so the kernel only bails out of hopeless batches: under 0.04 after 500,000 applied pivots.
 			// Abandoned rows keep row_len == -1 and go to the per-row tiers.
 			HIP_CHECK(hipMemsetAsync(W->d_row_len, 0xFF, (size_t) nrows * sizeof(int), stream));
-			const float min_eff = (float) env_int("SPASM_HIP_GROUP_MIN_EFF_PCT", 4) / 100.0f;
+			const float min_eff = (float) (4) / 100.0f;
 			// (... per group in flight: the judgement used to fall after 500,000 pivots whatever the number of groups, i.e. after
 			// 1,700 pivots of each of the 297 groups of a mk14.b4 call -- all of them still in the cheap private start of their
 			// rows -- and sent a batch whose final efficiency is 0.60 to the per-row tier: 1.68 s instead of 0.35 s)
@@ -2323,7 +2335,7 @@ static struct spasm_csr *schur_entry(const struct spasm_csr *A, const int *p, in
 	// batch go through it (under a millisecond): their entries, scaled, + 15 % + what the waves strand in their arenas
 	// (8,192 rows + 12 % still fell short once in fifteen mk14.b4 calls).
 	double ms_sample = 0.0;
-	if (L == nullptr && !shard && n >= 65536 && env_int("SPASM_HIP_POOL_SAMPLE", 1) != 0 &&
+	if (L == nullptr && !shard && n >= 65536 && (1) != 0 &&
 	    sparse_image_wanted(F, env_int("SPASM_HIP_FORCE_TIER", 0) != 0 || env_int("SPASM_HIP_GROUP", -1) >= 0, n) &&
 	    (F->sp.valid || sparse_image_build(F, stream))) {
 		const int ns = 16384;

@@ -3,7 +3,7 @@
 // backsolve.hip stores R dense (r x Sm 16-bit entries): right when the Schur complement is going to be dense anyway
 // (mk13.b5: 72 %), wasteful when it stays sparse -- mk14.b4: 273,000 x 42,000 entries = 23 GB built and gathered for a
 // Schur complement that is 3.7 % dense, and no image at all beyond 131,072 non-pivotal columns.  The reference never
-// forms R: it solves x = a U_pp^-1 row by row (spasm_schur.c:86-171 -> spasm_triangular.c:110-146 -> spasm_reach.c:22-135),
+// forms R: it solves x = a U_pp^-1 row by row (spasm_schur.c:86-171 -> spasm_triangular.c:109-146 -> spasm_reach.c:21-135),
 // and what that costs on a GPU is the random read-modify-write traffic of the row-group kernel.
 // Here R is formed once per factor, like in backsolve.hip, but as sparse rows:
 //
@@ -11,19 +11,26 @@
 //   * a row of R is a set of FRAGMENTS, one per segment it has entries in: 4-byte entries (column inside the segment |
 //     signed 16-bit value << 16, sorted by column) in a bump-allocated pool of 1-12 chunks; frag[c * nseg + g] = where and
 //     how long;
-//   * sp_build_kernel<true>: ONE cooperative launch of as many waves as the chip holds (10.5 KB of LDS each).  A task =
-//     (row c, segment g): R[c][g] = U_n[c][g] - sum_t u_ct R[t][g]; tasks are handed out in order -- rows from the last to
-//     the first, i.e. after the rows they depend on: what spasm_reach's depth-first search orders for one row, the level
-//     schedule orders for all of them -- by ticket counters, and a task whose dependencies are not there yet polls their
-//     fragment words.  The sum is formed in 8 KB of LDS (16-bit accumulators, one read-modify-write per entry of a fragment:
-//     the entries of a fragment have distinct columns and a wave's LDS accesses are served in order, so no atomics), the
-//     touched columns are listed from a bitmap, the non-zero sums go to the wave's arena of the pool, the fragment word is
-//     published.  Work = sum over the pivotal entries of U of the fill of the rows they point at -- it scales with nnz(R),
-//     not with r x Sm.  sp_build_kernel<false> is the same task per launch of one elimination level (the fall-back when the
-//     cooperative launch is refused or the watchdog fires);
-//   * sp_apply_kernel: one wave per reduced row k, through all its segments: the same accumulation over the pivotal entries
-//     of the row of A, fragments of S into a pool; a scan of the row lengths and sp_gather_kernel put the rows in their final
-//     place (W->d_Sp / d_Sj / d_Sx, columns sorted).
+//   * sp_build_kernel<true>: ONE cooperative launch of as many waves as the chip holds (9.6 KB of LDS each: seventeen per CU).
+//     A ticket is a ROW of R (round 6): the wave reads the row's lists once -- one 64-byte head for a row of at most seven
+//     entries -- and takes it through its segments, R[c][g] = U_n[c][g] - sum_t u_ct R[t][g], publishing every fragment word as
+//     it goes.  Rows are handed out from the last to the first, i.e. after the rows they depend on (what spasm_reach's
+//     depth-first search orders for one row, the level schedule orders for all of them); a segment whose dependencies are not
+//     there yet polls their fragment words, and a row that depends on another walks the same segments one behind it.  While a
+//     segment runs, the words of the next one are already asked for and, when they are there, the fragments they name fetched
+//     beside the emit.  sp_build_kernel<false> is one (row, segment) task per workgroup and one launch per elimination level
+//     (the fall-back when the cooperative launch is refused or the watchdog fires);
+//   * the sum of a segment is formed in 8 KB of LDS: 16-bit accumulators, one read-modify-write per entry of a fragment (the
+//     entries of a fragment have distinct columns and a wave's LDS accesses are served in order: no atomics).  A lane that finds
+//     its accumulator at ZERO lists its column (a ballot gives the new columns their places in the list): no bitmap on the path
+//     of a multiply-add.  Emit: the listed columns with a non-zero sum set their bits in a bitmap, ONE packed scan of its words'
+//     popcounts gives every column its rank -- sorted output without sorting --, the entries go to the wave's arena of the pool,
+//     the fragment word is published.  Work scales with nnz(R), not with r x Sm;
+//   * sp_apply_kernel: one wave per reduced row (tickets of four rows, whose metadata is fetched together), through the
+//     segments in which the row can hold anything (per row of R a mask of its non-empty segments): the same accumulation over
+//     the pivotal entries of the row of A -- the fragments of segment g + 1 in flight while segment g is added up and emitted --,
+//     fragments of S into a pool; a scan of the row lengths and sp_gather_kernel (a workgroup takes 256 rows through the
+//     segments with the segment's piece of q in LDS) put the rows in their final place (W->d_Sp / d_Sj / d_Sx, columns sorted).
 //
 // Arithmetic: signed 16-bit representatives with the fp32 reduction of sgn_dev.h (p <= 44,927; 42013 -- the reference's
 // default -- qualifies); every multiply-add is reduced at once (|x| <= B, |c v| <= (p/2) B: the sum fits 31 bits).
@@ -1924,7 +1931,7 @@ bool sparse_image_build(const spasm_hip_dfact *F, hipStream_t stream)
 	b.ovf_level = d_ovf;
 	b.ticket = d_sync;
 	b.abort_flag = d_abort;
-	b.poll_limit = (long long) env_sp("SPASM_HIP_SPARSE_IMAGE_POLLS", 1 << 21);
+	b.poll_limit = (long long) (1 << 21);
 	unsigned long long *d_prof = nullptr;
 	if (env_sp("SPASM_HIP_SPARSE_IMAGE_PROFILE", 0) != 0) {
 		d_prof = dalloc<unsigned long long>(8);
@@ -1941,8 +1948,8 @@ bool sparse_image_build(const spasm_hip_dfact *F, hipStream_t stream)
 		HIP_CHECK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, sp_build_kernel<true, true>, 64, 0));
 	else
 		HIP_CHECK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, sp_build_kernel<true, false>, 64, 0));
-	per_cu = std::min(per_cu, env_sp("SPASM_HIP_SPARSE_IMAGE_BUILD_WAVES", (int) std::min<size_t>(32, (size_t) (160 * 1024) / (S.wide ? sizeof(WaveLds32) : sizeof(WaveLds)))));
-	bool persistent = env_sp("SPASM_HIP_SPARSE_IMAGE_PERSISTENT", 1) != 0 && per_cu >= 1;
+	per_cu = std::min(per_cu, ((int) std::min<size_t>(32, (size_t) (160 * 1024) / (S.wide ? sizeof(WaveLds32) : sizeof(WaveLds)))));
+	bool persistent = env_sp("SPASM_HIP_SPARSE_IMAGE_PERSISTENT", 1) != 0 && per_cu >= 1;          // (0: the level-by-level fall-back, for the stress runs)
 	HIP_CHECK(hipEventRecord(S.ev0, stream));
 	auto next_chunk = [&](int chunk) -> bool {          // room for another attempt?  (allocates chunk + 1 when it is not there)
 		int64_t total = 0;
@@ -1990,11 +1997,11 @@ bool sparse_image_build(const spasm_hip_dfact *F, hipStream_t stream)
 		for (bool first = true;; first = false) {
 			set_chunk(chunk, first);
 			// (arenas of 16,384 entries when the chunk is large enough for every wave to strand one; tests with tiny chunks: none)
-			b.arena = (S.chunk_cap[chunk] >= (int64_t) blocks * 16384 * 4 && env_sp("SPASM_HIP_SPARSE_IMAGE_ARENAS", 1) != 0) ? 16384 : 0;
+			b.arena = (S.chunk_cap[chunk] >= (int64_t) blocks * 16384 * 4 && (1) != 0) ? 16384 : 0;
 			b.retry = first ? 0 : 1;
 			HIP_CHECK(hipMemsetAsync(d_sync, 0, (size_t) (SP_TICKETS * SP_TICKET_STRIDE + 2) * sizeof(int), stream));
 			int *d_dbg = nullptr;
-			if (env_sp("SPASM_HIP_SPARSE_IMAGE_DEBUG", 0) != 0) {
+			if ((0) != 0) {
 				d_dbg = dalloc<int>((int64_t) blocks * 4);
 				HIP_CHECK(hipMemsetAsync(d_dbg, 0, (size_t) blocks * 4 * sizeof(int), stream));
 			}
@@ -2019,11 +2026,12 @@ bool sparse_image_build(const spasm_hip_dfact *F, hipStream_t stream)
 			}
 			S.launches += 1;
 			{
-				// second line of defence, a watchdog: a launch that is still running after SPASM_HIP_SPARSE_IMAGE_WATCHDOG_S seconds
-				// (default 5: a hundred times what the longest build measured takes) is told to give up (the abort flag, written
+				// second line of defence, a watchdog: a launch that is still running after `patience` seconds is told to give up (the abort flag, written
 				// from a stream of its own); what the ticket counters and the wave marks say goes to stderr.  The host sleeps
 				// between its looks at the stream.
-				const double t_launch = wtime(), patience = (double) env_sp("SPASM_HIP_SPARSE_IMAGE_WATCHDOG_S", 5);
+				// (patience grows with the factor: 5 s -- a hundred times the longest build measured, 0.05 s for 3 M dependencies -- plus
+				//  a second per million dependencies, and at least 20 s for the 32-bit variant, which runs nine waves per CU)
+				const double t_launch = wtime(), patience = std::max(S.wide ? 20.0 : 5.0, 5.0 + 1e-6 * (double) S.ndeps);
 				while (hipStreamQuery(stream) == hipErrorNotReady && wtime() - t_launch < patience)
 					std::this_thread::sleep_for(std::chrono::microseconds(wtime() - t_launch < 2e-3 ? 5 : 50));
 				if (hipStreamQuery(stream) == hipErrorNotReady) {
@@ -2242,7 +2250,7 @@ void launch_sparse_image_apply(const SchurArgs &a, const spasm_hip_dfact *F, uin
 	if (ntasks <= 0)
 		return;
 	// as many waves per CU as its LDS holds (19.5 KB each: eight), every wave a workgroup of its own
-	const int per_cu = std::max(1, std::min(32, env_sp("SPASM_HIP_SPARSE_IMAGE_WAVES", (int) std::min<size_t>(32, (size_t) (160 * 1024) / (S.wide ? sizeof(WaveLds32) : sizeof(WaveLds))))));
+	const int per_cu = std::max(1, std::min(32, ((int) std::min<size_t>(32, (size_t) (160 * 1024) / (S.wide ? sizeof(WaveLds32) : sizeof(WaveLds))))));
 	const int blocks = (int) std::min<int64_t>(ntasks, (int64_t) prop.multiProcessorCount * per_cu);
 	// a wave reserves the room of its fragments 8,192 entries at a time (what the ~4,000 waves strand at the end must stay small
 	// against a pool sized from a density estimate: 32,768 apiece were 126 M entries, and a retry of the whole call); a pool

@@ -86,7 +86,7 @@ def _lu_for(F, extra_rows, extra_nz):
 
 
 def pivots_extract_structural(A, F, greedy=True):
-    """spasm_pivots_extract_structural (spasm_pivots.c:374): returns (npiv, p, F + new pivotal rows)."""
+    """spasm_pivots_extract_structural (spasm_pivots.c:369): returns (npiv, p, F + new pivotal rows)."""
     L = lib()
     a = view_csr(A)
     lu, up, qinv = _lu_for(F, A.n, A.nnz)
@@ -100,7 +100,7 @@ def pivots_extract_structural(A, F, greedy=True):
 
 
 def schur(A, p, F, p_in=None, want_L=False):
-    """spasm_schur (spasm_schur.c:64) on the GPU: returns (S, p_out), or (S, p_out, (Li, Lj, Lx)) with
+    """spasm_schur (spasm_schur.c:61) on the GPU: returns (S, p_out), or (S, p_out, (Li, Lj, Lx)) with
     want_L: the elimination coefficients as triplets (row, index of the pivot row in U, value)."""
     require_gpu("schur")
     L = lib()
@@ -153,7 +153,7 @@ _NP_OF = {SPASM_DOUBLE: np.float64, SPASM_FLOAT: np.float32, SPASM_I64: np.int64
 
 
 def schur_dense(A, p, F, p_in=None, datatype=SPASM_I64):
-    """spasm_schur_dense (spasm_schur.c:258) on the GPU: returns (S [n, Sm], q, p_out)."""
+    """spasm_schur_dense (spasm_schur.c:257) on the GPU: returns (S [n, Sm], q, p_out)."""
     require_gpu("schur_dense")
     L = lib()
     a = view_csr(A)
@@ -201,7 +201,7 @@ def default_opts():
 
 
 def echelonize(A, opts=None):
-    """spasm_echelonize (spasm_echelonize.c:478): returns Fact(U, qinv) with rank = U.n."""
+    """spasm_echelonize (spasm_echelonize.c:473): returns Fact(U, qinv) with rank = U.n."""
     require_gpu("echelonize")
     L = lib()
     a = view_csr(A)

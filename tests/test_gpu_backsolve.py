@@ -1,5 +1,5 @@
 """GPU parity of the back-substituted factor image (spasm_amd/csrc/backsolve.hip): S = A_n - A_p R with
-R = U_pp^-1 U_pn must be the matrix spasm_schur computes (spasm_schur.c:64-193), bit for bit.
+R = U_pp^-1 U_pn must be the matrix spasm_schur computes (spasm_schur.c:61-193), bit for bit.
 
 The shapes below aim at the kernel's own seams: chains longer than a chunk (768 rows), levels wider than a
 workgroup pass, rows with more than two dependencies outside their chunk, dependencies that straddle chunk
@@ -136,7 +136,7 @@ def test_backsolve_long_input_rows(oracle, monkeypatch, signed):
 
 @pytest.mark.parametrize("p,signed", SMALL + [(4294967291, "1")])
 def test_backsolve_dense_rows(oracle, monkeypatch, p, signed):
-    """spasm_schur_dense (spasm_schur.c:258-343) through the same image."""
+    """spasm_schur_dense (spasm_schur.c:257-343) through the same image."""
     monkeypatch.setenv("SPASM_HIP_BACKSOLVE", "1")
     monkeypatch.setenv("SPASM_HIP_BS_SIGNED", signed)
     rng = np.random.default_rng(21)

@@ -146,7 +146,7 @@ def _big_rref_case(oracle, which):
     return _BIG_RREF[which]
 
 
-@pytest.mark.parametrize("env", [{}, {"SPASM_HIP_RREF_MFMA": "0"}, {"SPASM_HIP_RREF_ONE_STREAM": "1"}, {"SPASM_HIP_RREF_CACHE": "0"}])
+@pytest.mark.parametrize("env", [{}, {"SPASM_HIP_RREF_MFMA": "0"}, {"SPASM_HIP_RREF_ONE_STREAM": "1"}, {"SPASM_HIP_RREF_CACHE": "0"}, {"SPASM_HIP_RREF_LOOKAHEAD": "0"}])
 @pytest.mark.parametrize("which", ["deficient", "full"])
 def test_rref_more_than_two_super_panels(oracle, which, env, monkeypatch):
     """no test compared a dense RREF of rank > 400 with the oracle -- the optimistic super-panels, the
@@ -197,6 +197,14 @@ def test_rref_at_the_benchmarked_size(shape, rank):
         r = L.spasm_hip_drref_timed(p, n, m, A.data_ptr(), m, piv.data_ptr(), 0, mfma, C.byref(ms))
         torch.cuda.synchronize()
         results.append((r, piv[:r].clone(), A))
+    # (round 6) the call the driver makes -- untimed, hence with the optimistic super-panels and their tries one panel ahead of the
+    # updates (rref_lookahead, two streams handing over through device words) --, three times in a row on the kept streams
+    for _ in range(3):
+        A = M.to(torch.int32).contiguous()
+        piv = torch.zeros(m, dtype=torch.int32, device=dev)
+        r3 = L.spasm_hip_drref(p, n, m, A.data_ptr(), m, piv.data_ptr(), 0)
+        torch.cuda.synchronize()
+        assert r3 == rank and torch.equal(piv[:r3], results[0][1]) and torch.equal(A, results[0][2])
     (r, J, R), (r2, J2, R2) = results
     assert r == rank and r2 == rank and torch.equal(J, J2) and torch.equal(R, R2)
     J = J.to(torch.int64)

@@ -1,5 +1,5 @@
 """GPU parity of the SPARSE back-substituted image (spasm_amd/csrc/sparse_image.hip): S = A_n - A_p R with R = U_pp^-1 U_pn
-kept as sparse fragments must be the matrix spasm_schur computes (spasm_schur.c:64-193 -> spasm_triangular.c:110-146), bit
+kept as sparse fragments must be the matrix spasm_schur computes (spasm_schur.c:61-193 -> spasm_triangular.c:109-146), bit
 for bit -- checked against the oracle (oracle/spasm_oracle.c, pinned on the compiled reference by tests/test_oracle.py).
 
 The shapes aim at the kernels' own seams: column counts around the 8,192-column segments, rows of U and of A with more

@@ -3,7 +3,7 @@
 mk13.b5 is regenerated from its definition (tools/workloads.py); the other BASELINE matrices run when their
 .sms files are found under $SPASM_DATA (default tests/data/) and are reported as skipped otherwise.
 
-What is compared (tools/rank.c:88-92 orientation, spasm_schur.c:64-193):
+What is compared (tools/rank.c:88-92 orientation, spasm_schur.c:61-193):
   * the round-0 Schur complement of EVERY non-pivotal row, computed by spasm_hip_dschur on the full batch, once per
     elimination path (back-substituted image; row-group kernel);
   * a deterministic sample of >= 2000 of its rows, spread over the whole batch (so over all row groups), entry for
@@ -435,6 +435,25 @@ def test_block_cache_serves_the_second_call_of_the_same_work(monkeypatch):
         misses.append((ev["block_cache_misses"], ev["block_cache_miss_bytes"]))
     assert ranks == [134211] * 3
     assert misses[1] == (0, 0) and misses[2] == (0, 0), misses          # (the first call of a process fills the cache, the next ones live off it)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("keep_gb", ["0", "4"])
+def test_driver_calls_with_a_small_block_cache(keep_gb, monkeypatch):
+    """SPASM_HIP_KEEP_GB at its edges: nothing (0) or next to nothing (4 GB) of the cache of device blocks survives a driver call --
+    what a process that shares its device sets.  mk14.b4 parks tens of GB by default; with the cache emptied after every call the
+    next call takes its blocks fresh (slower: the first touch of new device memory) and must give the same rank, call after call."""
+    monkeypatch.setenv("SPASM_HIP_KEEP_GB", keep_gb)
+    A, _ = workloads.load_matrix("mk14.b4")
+    ranks, misses = [], []
+    for _ in range(3):
+        F = spasm_amd.echelonize(A)
+        ranks.append(F.U.n)
+        misses.append(spasm_amd.echelonize_counters()["block_cache_miss_bytes"])
+    assert ranks == [RANKS["mk14.b4"]] * 3
+    if keep_gb == "0":
+        assert misses[1] > 0 and misses[2] > 0, misses          # (nothing was kept: the large blocks come from the device again)
+    spasm_amd.release_cached_memory()
 
 
 @pytest.mark.gpu

@@ -31,7 +31,6 @@ dA = spasm_amd.DeviceCsr.from_host(A, dev)
 drows = torch.from_numpy(np.ascontiguousarray(rows)).to(dev)
 ref = None
 for v in args.variants.split(","):
-    os.environ["SPASM_HIP_BS_PACKED"] = v[0]
     os.environ["SPASM_HIP_BS_SHAPE"] = v[1]
     dF = spasm_amd.DeviceFact(F)
     pool = 1 << 30
@@ -53,5 +52,4 @@ for v in args.variants.split(","):
     dF.close()
     if v != args.variants.split(",")[0]:
         del S
-os.environ.pop("SPASM_HIP_BS_PACKED", None)
 os.environ.pop("SPASM_HIP_BS_SHAPE", None)

@@ -51,7 +51,7 @@ while time.time() < t_end:
         # the back-substituted image: every workgroup shape, 16- and 32-bit entries, both ways of starting the rows and of
         # writing the result
         bs_env = {"SPASM_HIP_BACKSOLVE": "1", "SPASM_HIP_BS_SHAPE": str(int(rng.integers(0, 3))),
-                  "SPASM_HIP_BS_PACKED": str(int(rng.integers(0, 2))), "SPASM_HIP_BS_SPARSE_INIT": str(int(rng.integers(0, 2))),
+                  "SPASM_HIP_BS_SPARSE_INIT": str(int(rng.integers(0, 2))),
                   "SPASM_HIP_BS_DIRECT": str(int(rng.integers(0, 2))), "SPASM_HIP_BS_SIGNED": str(int(rng.integers(0, 2))),
                   "SPASM_HIP_BS_STAGED": str(int(rng.integers(0, 2))), "SPASM_HIP_STAGE_ROWS": str(int(rng.choice([0, 1, 37, 1000])))}
         os.environ.update(bs_env)
@@ -65,9 +65,9 @@ while time.time() < t_end:
             os.environ.pop(key, None)
         # the sparse image (round 4): forced, with a random segment size and a pool small enough to be outgrown now and then
         sp_env = {"SPASM_HIP_SPARSE_IMAGE": "1", "SPASM_HIP_BACKSOLVE": "0", "SPASM_HIP_SPARSE_IMAGE_PERSISTENT": str(int(rng.integers(0, 2))),
-                  "SPASM_HIP_SPARSE_IMAGE_CHUNK": str(int(rng.choice([0, 4096, 100000]))), "SPASM_HIP_SPARSE_IMAGE_ARENAS": str(int(rng.integers(0, 2))),
+                  "SPASM_HIP_SPARSE_IMAGE_CHUNK": str(int(rng.choice([0, 4096, 100000]))),
                   # (round 5) 8-byte entries with 32-bit accumulators whatever the prime; structural masks of the segments on or off
-                  "SPASM_HIP_SPARSE_IMAGE_WIDE": str(int(rng.integers(0, 2))), "SPASM_HIP_SPARSE_IMAGE_MASKS": str(int(rng.integers(0, 2)))}
+                  "SPASM_HIP_SPARSE_IMAGE_WIDE": str(int(rng.integers(0, 2)))}
         os.environ.update(sp_env)
         S, p_out = spasm_amd.schur(as_product(A), rows, spasm_amd.Fact(as_product(F.U), F.qinv))
         ok = orc.same_matrix(orc.CSR(S.n, S.m, S.p, S.j, S.x, p), want) and np.array_equal(np.asarray(p_out), np.asarray(p_out_want))
@@ -125,7 +125,7 @@ while time.time() < t_end:
         want_rank = orc.echelonize(E).U.n
         for finish in ("1", "0"):            # device-resident dense finish / the host loop
             os.environ["SPASM_HIP_DEVICE_FINISH"] = finish
-            os.environ["SPASM_HIP_ROW_PANELS"] = str(int(rng.choice([-1, 0, 1])))          # echelon rows: default rule / column panels / row panels
+            os.environ["SPASM_HIP_RREF_LOOKAHEAD"] = str(int(rng.integers(0, 2)))          # dense RREF: tries one panel ahead / one after the other
             o = spasm_amd.default_opts()
             if rng.integers(0, 2):
                 o.sparsity_threshold = -1.0          # dense finish straight away
@@ -138,7 +138,7 @@ while time.time() < t_end:
                 fails += 1
                 print("MISMATCH echelonize %dx%d per_row=%d p=%d finish=%s: rank %d, oracle %d" % (en, em, eper, p, finish, got, want_rank), flush=True)
         os.environ.pop("SPASM_HIP_DEVICE_FINISH", None)
-        os.environ.pop("SPASM_HIP_ROW_PANELS", None)
+        os.environ.pop("SPASM_HIP_RREF_LOOKAHEAD", None)
     # ---- matrices large enough for the pivot search on the device (>= 20,000 rows): the rank must not depend on where the
     # search runs (device with the reached-bits in LDS / in HBM, host threads) nor on transposition
     if cases % 23 == 0:

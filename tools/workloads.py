@@ -270,21 +270,22 @@ def round0(name, prime=PRIME, cache=True, threads=1, labelled=False):
     since round 1: 140,087 rows on mk13.b5) -- or, labelled=True, the sequential search with depth labels (round 5: as
     deterministic, another valid pivot set, 10-20x faster: what fixes the pivot set of the large stand-ins)."""
     import spasm_amd
-    path = os.path.join(tempfile.gettempdir(), "spasm_amd_r0_v3_%s_%d%s.npz" % (name.replace("/", "_"), prime, ("_lab" if labelled else "") if threads == 1 else "_mt"))
+    path = os.path.join(tempfile.gettempdir(), "spasm_amd_r0_v4_%s_%d%s.npz" % (name.replace("/", "_"), prime, ("_lab" if labelled else "") if threads == 1 else "_mt"))
     if cache and os.path.exists(path):
         z = np.load(path, allow_pickle=False)
         A = spasm_amd.Csr(int(z["n"]), int(z["m"]), z["Ap"], z["Aj"], z["Ax"], prime)
         F = spasm_amd.Fact(spasm_amd.Csr(int(z["r"]), int(z["m"]), z["Up"], z["Uj"], z["Ux"], prime), z["qinv"])
         return A, z["rows"], F, str(z["source"])
     A, source = load_matrix(name, prime)
-    saved = {k: os.environ.get(k) for k in ("SPASM_HIP_THREADS", "SPASM_HIP_PIVOT_LABELS", "SPASM_HIP_EXPERIMENT")}
+    # (both switches are on the supported list of include/spasm_hip.h: read at every call, with or without SPASM_HIP_EXPERIMENT)
+    saved = {k: os.environ.get(k) for k in ("SPASM_HIP_THREADS", "SPASM_HIP_PIVOT_LABELS")}
     if threads > 0:
         os.environ["SPASM_HIP_THREADS"] = str(threads)
     else:
         os.environ.pop("SPASM_HIP_THREADS", None)
     if threads == 1 and not labelled:
         os.environ["SPASM_HIP_PIVOT_LABELS"] = "0"
-        os.environ["SPASM_HIP_EXPERIMENT"] = "1"
+    search = "device / threaded (timing-dependent)" if threads != 1 else "sequential, depth labels" if labelled else "sequential, row order (the reference's single-thread set)"
     try:
         npiv, perm, F = spasm_amd.pivots_extract_structural(A, spasm_amd.empty_fact(A.m, prime))
     finally:
@@ -297,7 +298,7 @@ def round0(name, prime=PRIME, cache=True, threads=1, labelled=False):
     if cache:
         tmp = "%s.%d.tmp.npz" % (path, os.getpid())          # ranks build concurrently: publish atomically
         np.savez(tmp, n=A.n, m=A.m, Ap=A.p, Aj=A.j, Ax=A.x, r=F.U.n, Up=F.U.p, Uj=F.U.j, Ux=F.U.x, qinv=F.qinv,
-                 rows=rows, source=np.array(source))
+                 rows=rows, source=np.array(source), search=np.array(search))
         os.replace(tmp, path)
     return A, rows, F, source
 
