@@ -72,6 +72,8 @@ enum {
 	CNT_PIVOT_ROWS_LOST,
 	CNT_PIVOT_FREE_ACCEPTS,      // pivots accepted on their labels alone (no walk)
 	CNT_PIVOT_DEFERRED,          // rows the labelled search handed to the ticket search
+	CNT_SLABS_KEPT,              // Schur complements left as column slabs on the devices (column split, between two rounds)
+	CNT_SLABS_GATHERED,          // ... of them gathered into whole rows after all (another sparse round, a download)
 	CNT_COUNT
 };
 long long *counters();

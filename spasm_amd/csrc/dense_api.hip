@@ -407,11 +407,21 @@ bool finish_on_device(const struct spasm_csr *A, const int *p, int n, struct spa
 	const int block = std::max(1, block_env > 0 ? block_env : block_env == 0 ? opts->dense_block_size : std::max(opts->dense_block_size, 4096));
 	const int Sn_test = (int) std::ceil(128.0 / std::log2((double) prime));
 	const double start = wtime();
-	const i64 annz = A->p[A->n];
-	DeviceMatrix devA(A, stream);
+	// A Schur complement that is resident as column slabs (round 6: schur_api.hip) stays that way: dense rows and random
+	// combinations are linear in the columns, so every rank forms ITS columns of a block from its slab and the block is summed over
+	// the ranks (the slabs are disjoint ranges of columns: exact) -- Sn x Sm words per block instead of the whole of S gathered
+	// first; the echelon form is then extended on identical data on every rank, as before.
+	const i64 ld_of_stack = Sm0;
+	spasm_hip_comm *slab_comm = resident_slab_comm(A);
+	DeviceMatrix devA(A, stream, true);
+	const i64 annz = devA.nnz;
 	int *drows = dalloc<int>(n);
 	HIP_CHECK(hipMemcpy(drows, p, (size_t) n * sizeof(int), hipMemcpyHostToDevice));
 	spasm_hip_dcsr dA{A->n, m, annz, devA.p, devA.j, devA.x};
+	auto whole_block = [&](u32 *blockptr, int rows_of_block) {
+		if (slab_comm != nullptr)
+			comm_allreduce_sum_u32(slab_comm, blockptr, (i64) rows_of_block * ld_of_stack, stream);
+	};
 	const int maxblock = std::max(block, Sn_test);
 	spasm_hip_dwork *W = spasm_hip_dwork_create(maxblock, m, 64);
 	const i64 ld = Sm0;
@@ -481,6 +491,7 @@ bool finish_on_device(const struct spasm_csr *A, const int *p, int n, struct spa
 				break;
 			const double tr0 = wtime();
 			dschur_dense_impl(&dA, drows + processed, Sn, F, W, dM + (i64) k * ld, ld, stream, nullptr);
+			whole_block(dM + (i64) k * ld, Sn);
 			t_rows += wtime() - tr0;
 			const int rr = stack_and_reduce(Sn);
 			logmsg("[echelonize/dense/device] round %d: S[%d:%d], %d new pivots (%d in all)\n", round, processed, processed + Sn, rr, k);
@@ -516,6 +527,7 @@ bool finish_on_device(const struct spasm_csr *A, const int *p, int n, struct spa
 			salt += 0x9E3779B97F4A7C15ULL;
 			const double tr0 = wtime();
 			device_random_dense_rows(dA, rows_left, nleft, F, Sn, w, salt, dM + (i64) k * ld, ld, W, stream, compact);
+			whole_block(dM + (i64) k * ld, Sn);
 			t_rows += wtime() - tr0;
 			int rr = stack_and_reduce(Sn);
 			logmsg("[echelonize/dense/low-rank/device] round %d, weight %d, %d combinations: %d new pivots (%d in all)\n", round, w, Sn, rr, k);
@@ -523,6 +535,7 @@ bool finish_on_device(const struct spasm_csr *A, const int *p, int n, struct spa
 				// spasm_echelonize_test_completion (spasm_echelonize.c:30-52): a few combinations of ALL the rows
 				salt += 0x9E3779B97F4A7C15ULL;
 				device_random_dense_rows(dA, rows_left, nleft, F, Sn_test, 0, salt, dM + (i64) k * ld, ld, W, stream, compact);
+				whole_block(dM + (i64) k * ld, Sn_test);
 				rr = stack_and_reduce(Sn_test);
 				if (rr == 0)
 					break;

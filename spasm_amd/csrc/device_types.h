@@ -225,6 +225,12 @@ struct SpImage {
 struct SchurArgs;
 struct FactPlan;
 void launch_map_columns(int *d_Sj, int64_t nnz, const int *d_cols, hipStream_t stream);
+// dist_api.hip: collectives on plain device arrays (no-ops in a world of one)
+void comm_allreduce_min_i32(struct ::spasm_hip_comm *c, int *d_buf, int64_t count, hipStream_t stream);
+void comm_allreduce_sum_i32(struct ::spasm_hip_comm *c, int *d_buf, int64_t count, hipStream_t stream);
+void comm_allreduce_sum_u32(struct ::spasm_hip_comm *c, uint32_t *d_buf, int64_t count, hipStream_t stream);
+int comm_allgatherv_csr(struct ::spasm_hip_comm *c, int my_rows, int64_t my_nnz, const int64_t *own_Sp, const int *own_Sj, const int *own_Sx, int64_t *d_Sp, int *d_Sj,
+                        int *d_Sx, int64_t cap, int *total_rows, int64_t *total_nnz, hipStream_t stream);
 void launch_stitch_slabs(const int64_t *gSp, const int *gSj, const int *gSx, int n, int parts, int64_t *Sp, int *Sj, int *Sx, int64_t cap, int *d_len,
                          unsigned long long *d_block_sum, int *d_ctr, hipStream_t stream);
 void launch_scan_lengths(const int *len, int n, const unsigned long long *block_sum, int64_t *Sp, int64_t cap, int *ctr, hipStream_t stream);
@@ -235,7 +241,9 @@ struct DeviceMatrix {
 	int *j = nullptr, *x = nullptr;
 	int64_t nnz = 0;
 	bool owned = false;
-	DeviceMatrix(const struct spasm_csr *A, hipStream_t stream);
+	// slab_will_do: a matrix that is resident as column slabs (schur_api.hip, ResidentEntry) is handed out as it is -- this rank's
+	// slab; nnz = its entries -- instead of being gathered into whole rows first
+	DeviceMatrix(const struct spasm_csr *A, hipStream_t stream, bool slab_will_do = false);
 	~DeviceMatrix();
 	DeviceMatrix(const DeviceMatrix &) = delete;
 	DeviceMatrix &operator=(const DeviceMatrix &) = delete;
@@ -254,6 +262,8 @@ void d2h(void *dst, const void *src, size_t bytes, hipStream_t stream);
 void big_age(int max_idle);          // cached blocks unused through more than max_idle driver calls go back to the device
 hipError_t malloc_or_trim(void **ptr, size_t bytes);          // hipMalloc; on failure the cache is emptied and it is tried again
 void mem_info(size_t *free_b, size_t *total_b);                // hipMemGetInfo + what the cache parks (given back on demand)
+void resident_adopt_slab(const struct spasm_csr *host, int64_t *dp, int *dj, int *dx, int64_t local_nnz, struct ::spasm_hip_comm *comm);
+struct ::spasm_hip_comm *resident_slab_comm(const struct spasm_csr *A);
 void resident_begin();
 void resident_end();
 void resident_forget(const struct spasm_csr *A);

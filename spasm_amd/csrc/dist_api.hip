@@ -199,9 +199,45 @@ void spasm_hip_shard(int n, int rank, int world, int *lo, int *hi)
 int spasm_hip_dschur_allgatherv(spasm_hip_comm *c, const spasm_hip_dwork *W, i64 *d_Sp, int *d_Sj, spasm_ZZp *d_Sx, i64 cap,
                                 int *total_rows, i64 *total_nnz, void *stream_)
 {
-	hipStream_t stream = (hipStream_t) stream_;
+	return sh::comm_allgatherv_csr(c, W->last_rows, W->last_nnz, W->d_Sp, W->d_Sj, W->d_Sx, d_Sp, d_Sj, d_Sx, cap, total_rows, total_nnz, (hipStream_t) stream_);
+}
+
+}  // extern "C"
+
+namespace sh {
+
+// element-wise reductions over the ranks, in place, of device buffers every rank holds: the minimum of int32 words (the leftmost
+// column of every row of a Schur complement kept as column slabs) and the sum of uint32 words (dense rows formed slab by slab:
+// the slabs are disjoint ranges of columns, so at most one rank holds a non-zero word anywhere and the sum is exact)
+void comm_allreduce_min_i32(spasm_hip_comm *c, int *d_buf, int64_t count, hipStream_t stream)
+{
+	if (c == nullptr || c->world == 1 || count <= 0)
+		return;
+	NCCL_CHECK(ncclAllReduce(d_buf, d_buf, (size_t) count, ncclInt32, ncclMin, c->comm, stream));
+}
+
+void comm_allreduce_sum_u32(spasm_hip_comm *c, uint32_t *d_buf, int64_t count, hipStream_t stream)
+{
+	if (c == nullptr || c->world == 1 || count <= 0)
+		return;
+	// (in pieces of 2^30 words: a count is a size_t, but the ring works through it in one go)
+	for (int64_t at = 0; at < count; at += (int64_t) 1 << 30)
+		NCCL_CHECK(ncclAllReduce(d_buf + at, d_buf + at, (size_t) std::min<int64_t>((int64_t) 1 << 30, count - at), ncclUint32, ncclSum, c->comm, stream));
+}
+
+void comm_allreduce_sum_i32(spasm_hip_comm *c, int *d_buf, int64_t count, hipStream_t stream)
+{
+	if (c == nullptr || c->world == 1 || count <= 0)
+		return;
+	NCCL_CHECK(ncclAllReduce(d_buf, d_buf, (size_t) count, ncclInt32, ncclSum, c->comm, stream));
+}
+
+// the all-gatherv of spasm_hip_dschur_allgatherv on plain device arrays (my_rows rows, my_nnz entries: own_Sp / own_Sj / own_Sx)
+int comm_allgatherv_csr(spasm_hip_comm *c, int my_rows, int64_t my_nnz, const int64_t *own_Sp, const int *own_Sj, const int *own_Sx, int64_t *d_Sp, int *d_Sj,
+                        int *d_Sx, int64_t cap, int *total_rows, int64_t *total_nnz, hipStream_t stream)
+{
 	const int world = c->world;
-	const int64_t mine[2] = {(int64_t) W->last_rows, (int64_t) W->last_nnz};
+	const int64_t mine[2] = {(int64_t) my_rows, my_nnz};
 	HIP_CHECK(hipMemcpyAsync(c->d_sizes + 2 * c->rank, mine, sizeof(mine), hipMemcpyHostToDevice, stream));
 	NCCL_CHECK(ncclAllGather(c->d_sizes + 2 * c->rank, c->d_sizes, 2, ncclInt64, c->comm, stream));
 	std::vector<int64_t> sizes((size_t) 2 * world);
@@ -225,7 +261,7 @@ int spasm_hip_dschur_allgatherv(spasm_hip_comm *c, const spasm_hip_dwork *W, i64
 	// device-to-device copy.  SPASM_HIP_ALLGATHERV=bcast: one ncclBroadcast per rank and array instead.
 	const char *how = sh::env_get("SPASM_HIP_ALLGATHERV");
 	const bool use_bcast = how != nullptr && std::strcmp(how, "bcast") == 0;
-	const void *own[3] = {W->d_Sp, W->d_Sj, W->d_Sx};
+	const void *own[3] = {own_Sp, own_Sj, own_Sx};
 	void *all[3] = {d_Sp, d_Sj, d_Sx};
 	const size_t width[3] = {sizeof(int64_t), sizeof(int), sizeof(int)};
 	const ncclDataType_t type[3] = {ncclInt64, ncclInt32, ncclInt32};
@@ -234,10 +270,10 @@ int spasm_hip_dschur_allgatherv(spasm_hip_comm *c, const spasm_hip_dwork *W, i64
 		for (int r = 0; r < world; r++) {
 			const int64_t nr = sizes[2 * r], nz = sizes[2 * r + 1];
 			if (nr > 0)
-				NCCL_CHECK(ncclBroadcast(W->d_Sp, d_Sp + row_base[r], (size_t) nr, ncclInt64, r, c->comm, stream));
+				NCCL_CHECK(ncclBroadcast(own_Sp, d_Sp + row_base[r], (size_t) nr, ncclInt64, r, c->comm, stream));
 			if (nz > 0) {
-				NCCL_CHECK(ncclBroadcast(W->d_Sj, d_Sj + nz_base[r], (size_t) nz, ncclInt32, r, c->comm, stream));
-				NCCL_CHECK(ncclBroadcast(W->d_Sx, d_Sx + nz_base[r], (size_t) nz, ncclInt32, r, c->comm, stream));
+				NCCL_CHECK(ncclBroadcast(own_Sj, d_Sj + nz_base[r], (size_t) nz, ncclInt32, r, c->comm, stream));
+				NCCL_CHECK(ncclBroadcast(own_Sx, d_Sx + nz_base[r], (size_t) nz, ncclInt32, r, c->comm, stream));
 			}
 		}
 	} else {
@@ -264,6 +300,10 @@ int spasm_hip_dschur_allgatherv(spasm_hip_comm *c, const spasm_hip_dwork *W, i64
 	HIP_CHECK(hipStreamSynchronize(stream));        // (nz_base dies here)
 	return 0;
 }
+
+}  // namespace sh
+
+extern "C" {
 
 // Test hook (and building block of the column split): `parts` slabs of n rows each, stacked in device arrays (gSp: parts * n + 1
 // offsets into gSj / gSx), stitched into whole rows -- row i = slab 0's row i, then slab 1's, ... -- in d_Sp (n + 1) / d_Sj /

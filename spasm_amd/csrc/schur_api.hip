@@ -402,6 +402,12 @@ struct ResidentEntry {
 	int *j, *x;
 	i64 nnz;
 	bool host_stale;          // the host struct has its row pointers only: j and x were never downloaded (resident_materialize)
+	// A Schur complement computed by column slabs (round 6): p / j / x hold THIS RANK'S slab -- all rows, its range of the columns,
+	// column numbers of the whole matrix --, the host struct the row pointers of the whole rows (nnz: their total).  It becomes
+	// whole rows (all-gatherv + stitching: resident_unslab) only when somebody needs whole rows: another sparse round, a download.
+	bool slab = false;
+	spasm_hip_comm *comm = nullptr;
+	i64 local_nnz = 0;
 };
 static std::vector<ResidentEntry> g_resident;
 // ---- host -> device copies ---------------------------------------------------------------------------
@@ -575,11 +581,14 @@ void resident_forget(const struct spasm_csr *A)
 		}
 }
 
+void fact_cache_age();
+
 void resident_end()
 {
 	while (!g_resident.empty())
 		resident_forget(g_resident.back().host);
 	g_resident_on = false;
+	fact_cache_age();
 	// The driver is done.  Its large blocks (images, row pools, accumulators, FIFOs: 60-90 GB on mk14.b4) STAY in the cache, up
 	// to SPASM_HIP_KEEP_GB (default: the cap of the cache, 96; 0: everything goes back): allocating and freeing multi-GB blocks
 	// is erratic on these boxes -- 0.1 to 1 s apiece, now and then -- and made five of eight consecutive mk14.b4 calls take
@@ -614,9 +623,76 @@ void resident_adopt(const struct spasm_csr *host, i64 *dp, int *dj, int *dx, boo
 // whether the next round needs them on the host at all is decided by a census on the device first (resident_fl_census).
 void resident_lazy_downloads(bool on) { g_lazy_download = on; }
 
+void resident_adopt_slab(const struct spasm_csr *host, i64 *dp, int *dj, int *dx, i64 local_nnz, spasm_hip_comm *comm)
+{
+	resident_forget(host);
+	ResidentEntry e{host, dp, dj, dx, host->p[host->n], true};
+	e.slab = true;
+	e.comm = comm;
+	e.local_nnz = local_nnz;
+	g_resident.push_back(e);
+}
+
+// the communicator of a matrix that is resident as column slabs, else null
+spasm_hip_comm *resident_slab_comm(const struct spasm_csr *A)
+{
+	for (const ResidentEntry &e : g_resident)
+		if (e.host == A && e.slab)
+			return e.comm;
+	return nullptr;
+}
+
+// slabs -> whole rows on every device (collective: every rank holds a slab of the same matrix and gets here at the same point)
+static void resident_unslab(ResidentEntry &e, hipStream_t stream)
+{
+	if (!e.slab)
+		return;
+	const int n = e.host->n;
+	const int world = comm_world(e.comm);
+	i64 total = 0;
+	int rows_all = 0;
+	(void) comm_allgatherv_csr(e.comm, n, e.local_nnz, e.p, e.j, e.x, nullptr, nullptr, nullptr, -1, &rows_all, &total, stream);
+	if (rows_all != n * world || total != e.nnz)
+		die("column slabs: the ranks hold %d slab rows and %lld entries in all, %d and %lld expected", rows_all, (long long) total, n * world, (long long) e.nnz);
+	i64 *gSp = dalloc<i64>((i64) rows_all + 1);
+	int *gSj = dalloc<int>(total);
+	int *gSx = dalloc<int>(total);
+	if (comm_allgatherv_csr(e.comm, n, e.local_nnz, e.p, e.j, e.x, gSp, gSj, gSx, total, nullptr, nullptr, stream) != 0)
+		die("column slabs: the all-gatherv failed");
+	i64 *dSp = dalloc<i64>((i64) n + 1);
+	int *dSj = static_cast<int *>(big_alloc((size_t) std::max<i64>(total, 1) * sizeof(int)));
+	int *dSx = static_cast<int *>(big_alloc((size_t) std::max<i64>(total, 1) * sizeof(int)));
+	int *d_len = dalloc<int>(n);
+	unsigned long long *d_bs = dalloc<unsigned long long>((i64) (n + 1023) / 1024 + 16);
+	int *d_ctr = dalloc<int>(CTR_COUNT);
+	HIP_CHECK(hipMemsetAsync(d_ctr, 0, CTR_COUNT * sizeof(int), stream));
+	launch_stitch_slabs(gSp, gSj, gSx, n, world, dSp, dSj, dSx, total, d_len, d_bs, d_ctr, stream);
+	HIP_CHECK(hipStreamSynchronize(stream));
+	sh::big_free(gSp);
+	sh::big_free(gSj);
+	sh::big_free(gSx);
+	sh::big_free(d_len);
+	sh::big_free(d_bs);
+	sh::big_free(d_ctr);
+	sh::big_free(e.p);
+	big_free(e.j);
+	big_free(e.x);
+	e.p = dSp;
+	e.j = dSj;
+	e.x = dSx;
+	e.slab = false;
+	e.comm = nullptr;
+	counters()[CNT_SLABS_GATHERED] += 1;
+	if (verbose() >= 2)
+		logmsg("[schur/hip] column slabs gathered and stitched into whole rows on every device (%lld entries): somebody needs whole rows\n", (long long) total);
+}
+
 // brings the entries of a lazily returned Schur complement to its host struct (no-op when they are there)
 void resident_materialize(const struct spasm_csr *A)
 {
+	for (ResidentEntry &e : g_resident)
+		if (e.host == A && e.slab)
+			resident_unslab(e, nullptr);
 	for (ResidentEntry &e : g_resident)
 		if (e.host == A && e.host_stale) {
 			if (e.nnz > 0) {
@@ -657,6 +733,34 @@ __global__ __launch_bounds__(256) void popcount_kernel(const uint32_t *bitmap, i
 // How many pivots would the first step of the structural search (Faugere-Lachartre: the leftmost entry of every row, one
 // row per column -- spasm_pivots.c:35-80, host_pivots.cpp leftmost_entries) find on this device-resident matrix?  = the
 // number of distinct leftmost columns.  -1 when the matrix is not resident.
+__global__ __launch_bounds__(256) void row_min_column_kernel(const i64 *Ap, const int *Aj, int n, int *out)
+{
+	const int row = (int) ((blockIdx.x * 256 + threadIdx.x) >> 6), lane = threadIdx.x & 63;
+	if (row >= n)
+		return;
+	int best = 0x7FFFFFFF;
+	for (i64 px = Ap[row] + lane; px < Ap[row + 1]; px += 64)
+		best = min(best, Aj[px]);
+	for (int d = 32; d >= 1; d >>= 1)
+		best = min(best, __shfl_xor(best, d));
+	if (lane == 0)
+		out[row] = best;
+}
+
+__global__ __launch_bounds__(256) void columns_to_bitmap_kernel(const int *col, int n, uint32_t *bitmap)
+{
+	const int i = blockIdx.x * 256 + threadIdx.x;
+	if (i < n && col[i] != 0x7FFFFFFF)
+		atomicOr(&bitmap[col[i] >> 5], 1u << (col[i] & 31));
+}
+
+__global__ __launch_bounds__(256) void row_lengths_kernel(const i64 *Sp, int n, int *len)
+{
+	const int i = blockIdx.x * 256 + threadIdx.x;
+	if (i < n)
+		len[i] = (int) (Sp[i + 1] - Sp[i]);
+}
+
 int resident_fl_census(const struct spasm_csr *A)
 {
 	for (const ResidentEntry &e : g_resident)
@@ -666,7 +770,16 @@ int resident_fl_census(const struct spasm_csr *A)
 			uint32_t *bm = nullptr;
 			HIP_CHECK(sh::malloc_or_trim((void **) &bm, ((size_t) nwords + 1) * sizeof(uint32_t)));
 			HIP_CHECK(hipMemset(bm, 0, ((size_t) nwords + 1) * sizeof(uint32_t)));
-			if (n > 0)
+			if (e.slab && n > 0) {
+				// column slabs: the leftmost entry of a row is the smallest of the leftmost entries of its pieces -- one minimum per row
+				// over the ranks (4 bytes per row: nothing next to the rows themselves)
+				int *d_left = dalloc<int>(n);
+				hipLaunchKernelGGL(row_min_column_kernel, dim3((unsigned) (((i64) n * 64 + 255) / 256)), dim3(256), 0, nullptr, e.p, e.j, n, d_left);
+				comm_allreduce_min_i32(e.comm, d_left, n, nullptr);
+				hipLaunchKernelGGL(columns_to_bitmap_kernel, dim3((unsigned) ((n + 255) / 256)), dim3(256), 0, nullptr, d_left, n, bm);
+				HIP_CHECK(hipStreamSynchronize(nullptr));
+				sh::big_free(d_left);
+			} else if (n > 0)
 				hipLaunchKernelGGL(fl_census_kernel, dim3((unsigned) (((i64) n * 64 + 255) / 256)), dim3(256), 0, nullptr, e.p, e.j, n, bm);
 			hipLaunchKernelGGL(popcount_kernel, dim3(64), dim3(256), 0, nullptr, bm, nwords, reinterpret_cast<int *>(bm + nwords));
 			int count = 0;
@@ -710,11 +823,15 @@ void resident_prefetch_matrix(const struct spasm_csr *A, int dev)          // (c
 	resident_prefetch(A);
 }
 
-DeviceMatrix::DeviceMatrix(const struct spasm_csr *A, hipStream_t stream)
+DeviceMatrix::DeviceMatrix(const struct spasm_csr *A, hipStream_t stream, bool slab_will_do)
 {
 	nnz = A->p[A->n];
-	for (const ResidentEntry &e : g_resident)
+	for (ResidentEntry &e : g_resident)
 		if (e.host == A && e.nnz == nnz) {
+			if (e.slab && !slab_will_do)
+				resident_unslab(e, stream);          // (whoever reads whole rows: another sparse round, a density sample)
+			if (e.slab)
+				nnz = e.local_nnz;
 			p = e.p;
 			j = e.j;
 			x = e.x;
@@ -770,9 +887,23 @@ struct FactCacheKey {
 };
 // two slots, most recently used first: a call split by columns plans the image of its slab factor next to the image of the whole
 // factor, which the driver comes back to (density samples, the finish) -- one slot had each evict the other
+static std::mutex g_fact_mutex;
 static FactCacheKey g_fact_key[2];
 static spasm_hip_dfact *g_fact[2] = {nullptr, nullptr};
-static std::mutex g_fact_mutex;
+static long long g_fact_call[2] = {0, 0};          // the driver call (g_driver_calls) that last used the slot
+static long long g_driver_calls = 0;
+
+// the end of a driver call: the second slot goes when the call did not use it (an image can hold gigabytes -- the dense R of
+// ch7-8.b5's factor, 15 GB, sat there through every later call of the process on other matrices)
+void fact_cache_age()
+{
+	std::lock_guard<std::mutex> guard(g_fact_mutex);
+	if (g_fact[1] != nullptr && g_fact_call[1] != g_driver_calls) {
+		spasm_hip_dfact_destroy(g_fact[1]);
+		g_fact[1] = nullptr;
+	}
+	g_driver_calls += 1;
+}
 
 static uint64_t hash_words(uint64_t h, const void *data, size_t bytes)
 {
@@ -821,16 +952,20 @@ spasm_hip_dfact *cached_dfact(const struct spasm_csr *U, const int *qinv, hipStr
 			if (slot == 1) {
 				std::swap(g_fact[0], g_fact[1]);
 				std::swap(g_fact_key[0], g_fact_key[1]);
+				std::swap(g_fact_call[0], g_fact_call[1]);
 			}
+			g_fact_call[0] = g_driver_calls;
 			return g_fact[0];
 		}
 	if (g_fact[1] != nullptr)
 		spasm_hip_dfact_destroy(g_fact[1]);
 	g_fact[1] = g_fact[0];
 	g_fact_key[1] = g_fact_key[0];
+	g_fact_call[1] = g_fact_call[0];
 	g_fact[0] = spasm_hip_dfact_create(U, qinv, stream);
 	counters()[CNT_FACTOR_PLANS] += 1;
 	g_fact_key[0] = key;
+	g_fact_call[0] = g_driver_calls;
 	return g_fact[0];
 }
 }  // namespace sh
@@ -2192,6 +2327,39 @@ static struct spasm_csr *schur_by_column_slabs(const struct spasm_csr *A, const 
 	resident_forget(A_slab);
 	spasm_hip_csr_free(A_slab);
 	spasm_hip_lu_free(F_slab);
+	// Between two rounds of the driver (residency on, entries left on the device) the slabs STAY slabs: what the next step reads of S
+	// is column-separable -- the census of leftmost entries (a minimum per row over the ranks), the random combinations and the
+	// dense rows of the finish (every rank forms its columns of them: dense_api.hip) -- and whole rows are only gathered when
+	// another sparse round or the host asks for them (resident_unslab).  The ranks exchange the row lengths: 4 bytes a row.
+	if (g_lazy_download && resident_enabled() && n >= 1024) {
+		int *d_len = dalloc<int>(n);
+		hipLaunchKernelGGL(row_lengths_kernel, dim3((unsigned) ((n + 255) / 256)), dim3(256), 0, stream, W->d_Sp, n, d_len);
+		comm_allreduce_sum_i32(comm, d_len, n, stream);
+		std::vector<int> len((size_t) n);
+		sh::d2h(len.data(), d_len, (size_t) n * sizeof(int), stream);
+		sh::big_free(d_len);
+		i64 total = 0;
+		for (int i = 0; i < n; i++)
+			total += len[(size_t) i];
+		struct spasm_csr *S = spasm_hip_csr_alloc(n, m, total, prime, true);
+		S->p[0] = 0;
+		for (int i = 0; i < n; i++)
+			S->p[i + 1] = S->p[i] + len[(size_t) i];
+		resident_adopt_slab(S, W->d_Sp, W->d_Sj, W->d_Sx, snz, comm);
+		counters()[CNT_SLABS_KEPT] += 1;
+		W->d_Sp = nullptr;
+		W->d_Sj = nullptr;
+		W->d_Sx = nullptr;
+		sh::big_free(d_cols);
+		spasm_hip_dwork_destroy(W);
+		if (p_out != nullptr)
+			for (int k = 0; k < n; k++)
+				p_out[k] = (p_in != nullptr) ? p_in[p[k]] : p[k];
+		const double density = (n > 0 && m > 0) ? (double) total / ((double) m * n) : 0.0;
+		logmsg("Schur complement: %d * %d [%" PRId64 " nz / density= %.3f], %.1fs (split by columns: rank %d of %d holds its slab of %d of the %d non-pivotal columns, "
+		       "%" PRId64 " entries, on the device; slab problem %.2fs)\n", n, m, total, density, wtime() - t0, rank, world, mm - fact->U->n, m - fact->U->n, snz, t_slab);
+		return S;
+	}
 	// stack of the slabs, then whole rows
 	i64 total = 0;
 	int rows_all = 0;

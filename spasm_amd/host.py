@@ -230,7 +230,7 @@ def echelonize_profile():
 COUNTER_NAMES = ("pool_retries", "pools_sized_from_a_sample", "sparse_image_chunk_extensions", "sparse_image_build_aborts",
                  "block_cache_misses", "block_cache_miss_bytes", "factor_plans", "pivot_visits", "pivot_visits_of_searches_with_a_pivot",
                  "pivot_cascade_items", "pivot_rows_with_a_pivot", "pivot_rows_without", "pivots_accepted_on_labels_alone",
-                 "pivot_rows_deferred_to_the_ticket_search")
+                 "pivot_rows_deferred_to_the_ticket_search", "schur_complements_kept_as_column_slabs", "column_slabs_gathered_into_whole_rows")
 
 
 def echelonize_counters():

@@ -195,3 +195,74 @@ def test_column_split_gloo(tmp_path, name, world):
     mp.spawn(_column_worker, args=(world, port, name, 42013, str(tmp_path)), nprocs=world, join=True)
     for r in range(world):
         assert open(os.path.join(str(tmp_path), "rank%d" % r)).read() == "ok"
+
+
+# --------------------------------------------------------------------------
+# round 6: the column slabs stay slabs between two rounds -- what the driver reads of them is column-separable
+# --------------------------------------------------------------------------
+def _slab_finish_worker(rank, world, port, name, prime, result_dir):
+    """what schur_api.hip / dense_api.hip do with a Schur complement kept as column slabs, with the oracle as the compute and gloo as
+    the collectives: (1) row lengths = sum over the ranks, (2) leftmost entry of every row = minimum over the ranks (the census of
+    the next round's Faugere-Lachartre step), (3) random combinations of ALL rows, formed by every rank on its own columns and
+    summed over the ranks (the slabs are disjoint: exact), equal the combinations of the whole rows."""
+    sys.path.insert(0, ROOT)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from oracle import oracle as orc
+    import spasm_amd
+    from spasm_amd.dist import column_slab
+    A = orc.load_sms(matrix_path(name), prime)
+    npiv, perm, F = orc.pivots_extract_structural(A, orc.empty_fact(A.n, A.m, prime))
+    rows = perm[npiv:]
+    n = len(rows)
+    Ap = spasm_amd.Csr(A.n, A.m, A.p, A.j, A.x, prime)
+    Fp = spasm_amd.Fact(spasm_amd.Csr(F.U.n, F.U.m, F.U.p, F.U.j, F.U.x, prime), F.qinv)
+    As, Fs, cols = column_slab(Ap, Fp, rank, world)
+    S, _, _ = orc.schur(orc.CSR(As.n, As.m, As.p, As.j, As.x, prime), rows,
+                        orc.Fact(orc.CSR(Fs.U.n, Fs.U.m, Fs.U.p, Fs.U.j, Fs.U.x, prime), Fs.qinv))
+    want, _, _ = orc.schur(A, rows, F)
+    ok = True
+    # (1) lengths
+    lens = torch.from_numpy(np.diff(S.p).astype(np.int32))
+    if n:
+        dist.all_reduce(lens, op=dist.ReduceOp.SUM)
+    ok = ok and np.array_equal(lens.numpy(), np.diff(want.p))
+    # (2) leftmost entries
+    left = np.full(n, 0x7FFFFFFF, np.int32)
+    for k in range(n):
+        gj, _ = S.row(k)
+        if len(gj):
+            left[k] = int(cols[gj].min())
+    left = torch.from_numpy(left)
+    if n:
+        dist.all_reduce(left, op=dist.ReduceOp.MIN)
+    want_left = np.array([int(want.row(k)[0].min()) if len(want.row(k)[0]) else 0x7FFFFFFF for k in range(n)], np.int64)
+    ok = ok and np.array_equal(left.numpy().astype(np.int64), want_left)
+    # (3) combinations of all rows, on every rank's own columns, summed: the same draws on every rank (keyed by the problem)
+    rng = np.random.default_rng(n * 1000003 + A.m)
+    N = 5
+    Cf = rng.integers(0, prime, size=(N, max(n, 1)), dtype=np.int64)[:, :n]
+    mine = np.zeros((N, A.m), np.int64)
+    for k in range(n):
+        gj, gx = S.row(k)
+        if len(gj):
+            mine[:, cols[gj]] = (mine[:, cols[gj]] + Cf[:, [k]] * (np.asarray(gx, np.int64) % prime)[None, :]) % prime
+    total = torch.from_numpy(mine.astype(np.int64))
+    dist.all_reduce(total, op=dist.ReduceOp.SUM)          # (disjoint supports: at most one rank holds a non-zero word anywhere)
+    whole = np.zeros((N, A.m), np.int64)
+    for k in range(n):
+        wj, wx = want.row(k)
+        if len(wj):
+            whole[:, wj] = (whole[:, wj] + Cf[:, [k]] * (np.asarray(wx, np.int64) % prime)[None, :]) % prime
+    ok = ok and np.array_equal(total.numpy(), whole)
+    open(os.path.join(result_dir, "rank%d" % rank), "w").write("ok" if ok else "FAIL")
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("name,world", [("mat364.sms", 2), ("medium.sms", 3), ("rectangular_h.sms", 2)])
+def test_column_slabs_kept_through_the_census_and_the_finish_gloo(tmp_path, name, world):
+    port = 33500 + (os.getpid() + hash(name)) % 2000
+    mp.spawn(_slab_finish_worker, args=(world, port, name, 42013, str(tmp_path)), nprocs=world, join=True)
+    for r in range(world):
+        assert open(os.path.join(str(tmp_path), "rank%d" % r)).read() == "ok"

@@ -94,6 +94,32 @@ def test_sharded_driver_with_a_sparse_round_at_scale(comm, split, monkeypatch):
     assert prof["sparse_rounds"] >= 1
 
 
+def test_column_slabs_stay_slabs_until_somebody_needs_whole_rows(comm, monkeypatch):
+    """Round 6: between two rounds of the driver a Schur complement computed by column slabs stays on the devices AS SLABS -- the
+    census of leftmost entries is a minimum per row over the ranks, the dense finish sums the ranks' columns of every block -- and
+    is gathered into whole rows only when another sparse round reads it.  mk13.b4 with its default flow (one sparse round, then the
+    low-rank finish: nothing is ever gathered) and without the greedy search (two sparse rounds: the first complement is gathered
+    for the second round, the second one is not).  World of one: the same code, collectives of one rank."""
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import workloads
+    monkeypatch.setenv("SPASM_HIP_SHARD_FORCE", "1")
+    A, _ = workloads.load_matrix("mk13.b4")
+    o = spasm_amd.default_opts()
+    o.sparsity_threshold = 0.1
+    F = echelonize_dist(A, comm, o)
+    ev = spasm_amd.echelonize_counters()
+    assert F.U.n == 111463
+    assert ev["schur_complements_kept_as_column_slabs"] >= 1 and ev["column_slabs_gathered_into_whole_rows"] == 0, ev
+    o = spasm_amd.default_opts()
+    o.enable_greedy_pivot_search = 0
+    o.sparsity_threshold = 0.05
+    F = echelonize_dist(A, comm, o)
+    ev = spasm_amd.echelonize_counters()
+    prof = spasm_amd.echelonize_profile()
+    assert F.U.n == 111463 and prof["sparse_rounds"] >= 2
+    assert ev["schur_complements_kept_as_column_slabs"] >= 2 and ev["column_slabs_gathered_into_whole_rows"] >= 1, ev
+
+
 def test_bench_runs_its_rccl_path_on_one_gpu():
     """bench.py with the distributed path forced on (world of one), split by rows, on a small sibling of the bench matrix: the
     timed step is the product's (spasm_hip_schur_resident with the communicator installed: all-gatherv of S in the step), the
