@@ -679,8 +679,13 @@ def main():
         product = spasm_amd.ResidentSchur(A_full, rows, F_full)
         product_nnz = [0]
 
+    # (the driver hands spasm_hip_schur its density estimate -- spasm_schur_estimate_density, 100 rows --, from which the row pool of S is
+    #  sized; a first call without one finds the size the hard way and gives the estimate of the timed calls)
+    product_density = [-1.0]
+
     def product_step():
-        product_nnz[0] = product(forget=True)
+        product_nnz[0] = product(forget=True, est_density=product_density[0])
+        product_density[0] = 1.02 * product_nnz[0] / (max(len(rows), 1) * float(max(A_full.m - F_full.U.n, 1)))
 
     def run_steps(count):
         """count timed steps: (seconds, per-kernel device ms summed over the steps, their algorithmic bytes, last stats)"""
