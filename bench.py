@@ -831,6 +831,7 @@ def main():
                        else "rows over %d rank(s)%s" % (world, ", spasm_hip_schur with the communicator installed: all-gatherv of S in the step" if product is not None else "")},
             "roofline": roof,
             "factor_image_ms": statistics.median(image_ms),
+            "factor_image_ms_all": image_ms,
             "factor_image_note": "host planning + upload of the factor image (spasm_hip_dfact_create), once per factor, NOT in a step; "
                                  "median of 3 builds after a first one that is not counted (it loads the code object and fills the buffer cache)",
             "rows_per_s_cold": total_rows / (elapsed / args.steps + 1e-3 * statistics.median(image_ms)),

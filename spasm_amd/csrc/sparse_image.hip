@@ -1118,6 +1118,28 @@ template <bool PERSISTENT, bool W32 = false> __global__ __launch_bounds__(64) vo
 	st.flush(lane);
 }
 
+// the 64-byte head of every row (sp_build_task): word 0 = (pivotal entries | non-pivotal entries << 16, 0), then the pivotal entries
+// (compact row, coefficient), then the non-pivotal ones (index, value); a row of more than seven entries keeps its lists (word 0 = all ones)
+__global__ __launch_bounds__(256) void sp_make_heads_kernel(const uint64_t *dep_rp, const uint2 *dep, const uint64_t *np_rp, const uint2 *np, int r, uint2 *head)
+{
+	const int n = blockIdx.x * 256 + threadIdx.x;
+	if (n >= r)
+		return;
+	const uint64_t d0 = dep_rp[n], nd = dep_rp[n + 1] - d0, n0 = np_rp[n], nn = np_rp[n + 1] - n0;
+	uint2 *h = head + (size_t) 8 * (size_t) n;
+	if (nd + nn > 7) {
+		h[0] = uint2{0xFFFFFFFFu, 0u};
+		return;
+	}
+	h[0] = uint2{(uint32_t) nd | ((uint32_t) nn << 16), 0u};
+	for (uint64_t e = 0; e < nd; e++)
+		h[1 + e] = dep[d0 + e];
+	for (uint64_t e = 0; e < nn; e++)
+		h[1 + nd + e] = np[n0 + e];
+	for (uint64_t e = 1 + nd + nn; e < 8; e++)
+		h[e] = uint2{0u, 0u};
+}
+
 // which segments of every row of R hold anything: one bit per segment, (nseg + 63) / 64 words per row
 __global__ __launch_bounds__(256) void sp_rowmask_kernel(const uint64_t *frag, int r, int nseg, uint64_t *mask)
 {
@@ -1610,7 +1632,7 @@ struct SpPending {
 	double t_start = 0.0, t_done = 0.0;
 	std::vector<int> colmap;
 	std::vector<uint64_t> dep_rp, np_rp, segmask;
-	std::vector<uint2> dep, np, head;
+	std::vector<uint2> dep, np;
 };
 
 // what the path choice reads: known at once
@@ -1720,25 +1742,6 @@ static void sparse_image_plan_host(const FactPlan &P, bool wide, SpPending &H)
 			}
 		}
 	});
-	// the 64-byte heads: word 0 = (pivotal entries | non-pivotal entries << 16, 0), then the entries themselves; rows of more than seven
-	// entries keep their lists (word 0 = all ones)
-	std::vector<uint2> &head = H.head;
-	head.assign((size_t) 8 * (size_t) (r > 0 ? r : 1), uint2{0u, 0u});
-	for_rows([&](int n_lo, int n_hi) {
-		for (int n = n_lo; n < n_hi; n++) {
-			const uint64_t nd = dep_rp[n + 1] - dep_rp[n], nn = np_rp[n + 1] - np_rp[n];
-			uint2 *h = &head[(size_t) 8 * (size_t) n];
-			if (nd + nn > 7) {
-				h[0] = uint2{0xFFFFFFFFu, 0u};
-				continue;
-			}
-			h[0] = uint2{(uint32_t) nd | ((uint32_t) nn << 16), 0u};
-			for (uint64_t e = 0; e < nd; e++)
-				h[1 + e] = dep[dep_rp[n] + e];
-			for (uint64_t e = 0; e < nn; e++)
-				h[1 + nd + e] = np[np_rp[n] + e];
-		}
-	});
 	// Which (row, segment) pairs can hold anything at all: a row's own non-pivotal entries and the segments of the rows it depends
 	// on (rows with larger compact ids: one pass from the last row to the first).  Half of the pairs of the generated families
 	// are empty (mk15.b4: 47-49 %), and their tasks used to read the row's lists and poll its dependencies to find that out
@@ -1768,8 +1771,7 @@ static void sparse_image_plan_device(SpImage &S, SpPending &H, int m, hipStream_
 	S.d_dep = dalloc<uint2>((int64_t) H.dep.size());
 	S.d_np_rp = dalloc<uint64_t>((int64_t) r + 1);
 	S.d_np = dalloc<uint2>((int64_t) H.np.size());
-	S.d_head = dalloc<uint2>((int64_t) H.head.size());
-	upload(S.d_head, H.head, stream);
+	S.d_head = dalloc<uint2>((int64_t) 8 * (r > 0 ? r : 1));
 	upload(S.d_col, H.colmap, stream);
 	upload(S.d_dep_rp, H.dep_rp, stream);
 	upload(S.d_dep, H.dep, stream);
@@ -1779,6 +1781,10 @@ static void sparse_image_plan_device(SpImage &S, SpPending &H, int m, hipStream_
 		S.d_segmask = dalloc<uint64_t>((int64_t) r);
 		upload(S.d_segmask, H.segmask, stream);
 	}
+	// the 64-byte heads of the rows are made on the device, from the lists that are there now (on the host they were 38 MB to
+	// fill and send for mk15.b4's factor: 5 of the 22 ms the caller of the first Schur complement partly waits for)
+	if (r > 0)
+		hipLaunchKernelGGL(sp_make_heads_kernel, dim3((unsigned) ((r + 255) / 256)), dim3(256), 0, stream, S.d_dep_rp, S.d_dep, S.d_np_rp, S.d_np, r, S.d_head);
 	HIP_CHECK(hipStreamSynchronize(stream));          // the host vectors die here
 	S.planned = true;
 	S.valid = false;
