@@ -12,7 +12,7 @@ OUT=gpurun_out/prof_spimage_$TAG
 cd "$(dirname "$0")/.." || exit 1
 mkdir -p $OUT
 export TMPDIR=/tmp
-ARGS="tools/probe_sparse_image.py --workload $NAME --steps 2 --paths sparse --no-check --pool $POOL"
+ARGS="tools/probe_sparse_image.py --workload $NAME --steps 2 --paths sparse --no-check --pool $POOL ${EXTRA:-}"
 python3 $ARGS > $OUT/warm.log 2>&1          # (the round-0 pivots are cached in /tmp by the first run: the traced runs reduce the same rows)
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -- python3 $ARGS > $OUT/run_trace.log 2> $OUT/trace.log
 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $OUT/pmc_fetch -- python3 $ARGS > /dev/null 2> $OUT/pmc_fetch.log

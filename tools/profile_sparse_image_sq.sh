@@ -12,7 +12,7 @@ OUT=gpurun_out/prof_spimage_sq_$TAG
 cd "$(dirname "$0")/.." || exit 1
 mkdir -p $OUT
 export TMPDIR=/tmp
-ARGS="tools/probe_sparse_image.py --workload $NAME --steps 2 --paths sparse --no-check --pool $POOL"
+ARGS="tools/probe_sparse_image.py --workload $NAME --steps 2 --paths sparse --no-check --pool $POOL ${EXTRA:-}"
 CTRS="SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_VMEM_RD SQ_INSTS_LDS"
 python3 $ARGS > $OUT/warm.log 2>&1
 rocprofv3 --pmc $CTRS --output-format csv -d $OUT/pmc_sq -- python3 $ARGS > $OUT/run.log 2> $OUT/pmc_sq.log
