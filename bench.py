@@ -19,7 +19,7 @@ every rank with an all-gatherv over RCCL (the row-by-row kernels, whose rows nev
 
 Everything in the `roofline` object is measured in this run (HIP events of the library on the launch
 stream, the kernels' own work counters) except `traffic`, which rocprofv3 has to collect in separate
-passes: it is quoted from profiles/r05_traffic.json (written by tools/profile.sh; older rounds' files are looked at
+passes: it is quoted from profiles/r06_traffic.json (written by tools/profile.sh; older rounds' files are looked at
 next) only when that file was recorded for the same kernel on the same workload, with its path in
 `traffic_source`; otherwise null.
 
@@ -48,7 +48,7 @@ PRIME = 42013
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8 TB/s
 MFMA_I8_PEAK_TOPS = 5000.0     # dense i8 (the guide's ~5 P op/s class; AMD's sparsity figures are not used)
 # rocprofv3 PMC passes (tools/profile.sh): newest first; a file only counts for the workload, row count and kernel it names
-TRAFFIC_FILES = ["profiles/r05_traffic.json", "profiles/r04_traffic.json", "profiles/r04_sparse_traffic.json", "profiles/r03_traffic.json", "profiles/r03_sparse_traffic.json",
+TRAFFIC_FILES = ["profiles/r06_traffic.json", "profiles/r05_traffic.json", "profiles/r04_traffic.json", "profiles/r04_sparse_traffic.json", "profiles/r03_traffic.json", "profiles/r03_sparse_traffic.json",
                  "profiles/r02_traffic.json"]
 
 
@@ -278,7 +278,7 @@ def dense_tail_probe(torch, spasm_amd, dev, n=4096, m=32768):
            "update_kernels_ms_serialised": ms_upd.value, "update_kernels_Tmacs_per_s": tmacs_upd,
            # 4 int8 digit products per useful multiply-add (two base-256 digits each side), 2 ops per product
            "mfma_i8_frac_of_peak": (8 * tmacs_upd / MFMA_I8_PEAK_TOPS) if tmacs_upd else None}
-    for rel in ("profiles/r05_dense_tail.json", "profiles/r04_dense_tail.json", "profiles/r03_dense_tail.json", "profiles/r02_dense_tail.json"):
+    for rel in ("profiles/r06_dense_tail.json", "profiles/r05_dense_tail.json", "profiles/r04_dense_tail.json", "profiles/r03_dense_tail.json", "profiles/r02_dense_tail.json"):
         path = os.path.join(ROOT, rel)
         if not os.path.exists(path):
             continue
@@ -801,6 +801,24 @@ def main():
                 "step_algorithmic_bytes": int(step_bytes),
                 "step_GB_per_s": step_bytes / (ms_per_step * 1e-3) / 1e9,
                 "step_frac": step_bytes / (ms_per_step * 1e-3) / 1e9 / HBM_PEAK_GBS}
+        # The dense image's build is not bound by bytes: its workgroups -- one per slab of columns, 207 on mk13.b5 -- are bound
+        # by what ONE compute unit issues.  From the SQ counters of profiles/r06_backsolve_sq.json (tools/profile_backsolve_sq.sh), when
+        # they were recorded for this kernel: the time the vector instructions alone need on the compute units the kernel occupies.
+        sq_path = os.path.join(ROOT, "profiles", "r06_backsolve_sq.json")
+        if st.used_backsolve and os.path.exists(sq_path):
+            try:
+                sq = json.load(open(sq_path))["kernels"]
+                key = [k for k in sq if k.replace(" ", "") == kernel_id.replace(" ", "")]
+                if key:
+                    pl = sq[key[0]]["per_launch"]
+                    words = (int(A_full.m - F_full.U.n) + 1) // 2
+                    wgs = min(256, (words + 11) // 12)
+                    valu_ms = 1e3 * pl["SQ_INSTS_VALU"] * 4.0 / (wgs * 4) / 2.4e9          # a wave64 vector instruction holds its SIMD for four cycles
+                    roof["issue_bound"] = {"what": "vector instructions of the kernel x 4 cycles / (4 SIMDs x the %d compute units its %d workgroups occupy) / 2.4 GHz" % (wgs, wgs),
+                                           "valu_wave_instructions": pl["SQ_INSTS_VALU"], "lds_wave_instructions": pl.get("SQ_INSTS_LDS"), "compute_units_used": wgs,
+                                           "valu_bound_ms": valu_ms, "frac_of_valu_bound": valu_ms / dom["ms"], "source": "profiles/r06_backsolve_sq.json"}
+            except (ValueError, KeyError):
+                pass
         if st.used_backsolve and st.bytes_staged > 0:
             roof["staged_bytes"] = int(st.bytes_staged)
             roof["staged_bytes_note"] = "packed rows of S between the apply and the expansion kernels: written once, read once; not algorithmic bytes"
