@@ -938,16 +938,48 @@ __global__ __launch_bounds__(128 * NPAR) void rref_block_gj(BlockGjArgs g)
 // agent-scope acquire and meet at a barrier before any of them reads.  (MI355X_MICROARCH.md, "Workgroup dispatch, XCD
 // placement & inter-workgroup visibility": the per-XCD L2s are not coherent with each other.)  Every exit of a producer
 // signals -- an aborted pass must not leave anybody polling.
+// A consumer can only be served if its producer is on the device at the same time.  Tools that let one kernel run at a time
+// (rocprofv3 --pmc, AMD_SERIALIZE_KERNEL) break that: the host asks handoff_probe once per pair of streams whether two kernels of
+// the two streams DO meet (no -> the pass runs without the lookahead), and every wait is bounded all the same: a wait that runs
+// out raises g_handoff_stuck, later waits return at once, and the call fails loudly instead of hanging.
+__device__ int g_handoff_stuck;
+constexpr long long HANDOFF_PATIENCE = 200000000ll;          // ticks of the 100 MHz wall clock: two seconds (a wait is tens of microseconds)
+
+__device__ __forceinline__ bool handoff_poll(const int *word, int value, long long patience)
+{
+	unsigned int spins = 0;
+	long long t0 = 0;
+	while (__hip_atomic_load(word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < value) {
+		__builtin_amdgcn_s_sleep(4);
+		if ((++spins & 255u) == 0) {
+			const long long now = wall_clock64();
+			if (t0 == 0)
+				t0 = now;
+			else if (now - t0 > patience || __hip_atomic_load(&g_handoff_stuck, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0)
+				return false;
+		}
+	}
+	return true;
+}
+
 __device__ __forceinline__ void handoff_wait(const int *word, int value)
 {
 	if (word == nullptr)
 		return;
 	if (threadIdx.x == 0) {
-		while (__hip_atomic_load(word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < value)
-			__builtin_amdgcn_s_sleep(4);
+		if (!handoff_poll(word, value, HANDOFF_PATIENCE))
+			__hip_atomic_store(&g_handoff_stuck, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 		__builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
 	}
 	__syncthreads();
+}
+
+// The question to the device: do a kernel of one stream and a kernel of the other run side by side?  Each of the two raises its
+// own word and waits (3 ms at most) for the other's; met[side] = 1 when it saw it.
+__global__ void handoff_probe(int *words, int side, int *met)
+{
+	__hip_atomic_store(words + side, 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+	met[side] = handoff_poll(words + (side ^ 1), 1, 300000ll) ? 1 : 0;
 }
 
 __device__ __forceinline__ void handoff_signal(int *word)
@@ -1144,6 +1176,9 @@ __device__ __forceinline__ void try_inverse_body(const BlockGjArgs &g)
 
 __global__ __launch_bounds__(256) void rref_try_inverse(BlockGjArgs g)
 {
+	// (Tried: s_setprio 3 here, in rref_lookahead and in rref_mult_gather -- the chain shares its SIMDs with the far update of the
+	//  super-panel before, twelve waves of matrix instructions per CU, and a try takes 75 us instead of 44 beside them.  No
+	//  difference: 7.54-7.66 against 7.54-7.84 ms.)
 	try_inverse_body(g);
 	handoff_signal(g.done_word);          // (every thread of the workgroup leaves the body the same way)
 }
@@ -2158,7 +2193,7 @@ int device_rref(int64_t prime, int n, int m, uint32_t *dA, int64_t ld, int *d_pi
 		hipEvent_t ev_try[MAXSETS] = {}, ev_upd[MAXSETS] = {}, ev_look[MAXSETS] = {}, ev_start = nullptr;
 	};
 	static thread_local Ahead ahead;
-	const bool use_ahead = tournament && mfma_ok && prime < 65536 && (sh::env_get("SPASM_HIP_RREF_LOOKAHEAD") == nullptr || std::atoi(sh::env_get("SPASM_HIP_RREF_LOOKAHEAD")) != 0);
+	bool use_ahead = tournament && mfma_ok && prime < 65536 && (sh::env_get("SPASM_HIP_RREF_LOOKAHEAD") == nullptr || std::atoi(sh::env_get("SPASM_HIP_RREF_LOOKAHEAD")) != 0);
 	uint32_t *alt_tile = nullptr;
 	if (use_ahead || two_streams) {
 		int dev = 0;
@@ -2176,6 +2211,35 @@ int device_rref(int64_t prime, int n, int m, uint32_t *dA, int64_t ld, int *d_pi
 			}
 			HIP_CHECK(hipEventCreateWithFlags(&ahead.ev_start, hipEventDisableTiming));
 			ahead.dev = dev;
+		}
+		if (use_ahead) {
+			// the hand-offs need a kernel of each stream on the device at the same time: asked once per pair of streams (handoff_probe)
+			struct Probed {
+				hipStream_t main = nullptr, tries = nullptr;
+				bool met = false, asked = false;
+			};
+			static thread_local Probed probed;
+			if (!probed.asked || probed.main != stream || probed.tries != ahead.s_try) {
+				int *pw = nullptr, met[2] = {0, 0};
+				ws_malloc((void **) &pw, 4 * sizeof(int));
+				HIP_CHECK(hipMemsetAsync(pw, 0, 4 * sizeof(int), stream));
+				HIP_CHECK(hipEventRecord(ahead.ev_start, stream));
+				HIP_CHECK(hipStreamWaitEvent(ahead.s_try, ahead.ev_start, 0));
+				hipLaunchKernelGGL(handoff_probe, dim3(1), dim3(1), 0, stream, pw, 0, pw + 2);
+				hipLaunchKernelGGL(handoff_probe, dim3(1), dim3(1), 0, ahead.s_try, pw, 1, pw + 2);
+				HIP_CHECK(hipEventRecord(ahead.ev_look[0], ahead.s_try));
+				HIP_CHECK(hipStreamWaitEvent(stream, ahead.ev_look[0], 0));
+				HIP_CHECK(hipMemcpyAsync(met, pw + 2, sizeof(met), hipMemcpyDeviceToHost, stream));
+				HIP_CHECK(hipStreamSynchronize(stream));
+				ws_free(pw);
+				probed.main = stream;
+				probed.tries = ahead.s_try;
+				probed.met = met[0] != 0 && met[1] != 0;
+				probed.asked = true;
+				if (!probed.met && sh::verbose() >= 1)
+					fprintf(stderr, "[spasm_hip] dense RREF: kernels of two streams do not run side by side here (a tool that serialises launches?): no lookahead\n");
+			}
+			use_ahead = probed.met;
 		}
 		if (use_ahead)
 			ws_malloc((void **) &alt_tile, (size_t) 2 * NB * NB * sizeof(uint32_t) + 3 * MAXSETS * sizeof(int));          // (two tiles, by parity of the panel; then the hand-off words)
@@ -2221,16 +2285,27 @@ int device_rref(int64_t prime, int n, int m, uint32_t *dA, int64_t ld, int *d_pi
 		signed char *set_Mh[MAXSETS] = {}, *set_Ml[MAXSETS] = {};
 		for (int sp0 = 0, spi = 0; sp0 < m; sp0 += SPW * NB, spi++) {
 			if (spi == 1 || spi == 2 || (spi > 0 && spi % 4 == 0)) {
-				if (far_pending)
-					HIP_CHECK(hipStreamWaitEvent(stream, ev_far, 0));
 				// done when every row holds a pivot, or when the rows that do not are zero from here on (a block of
-				// low rank: most of its panels would find nothing)
+				// low rank: most of its panels would find nothing).  First on the columns of this super-panel, which the far
+				// update of the previous one -- still running on the second stream -- does not write: a free row that is not
+				// zero there settles the question, and the panels start beside that update (the trace of round 6 showed the
+				// chain idle for the whole of it, 0.55 ms, at each of these checks); only when they are all zero there is the
+				// update waited for and the rest looked at.
 				int rk_nz[2] = {0, 0};
-				HIP_CHECK(hipMemsetAsync(free_count + 8, 0, sizeof(int), stream));
-				hipLaunchKernelGGL(rref_free_nonzero, dim3(512), dim3(256), 0, stream, dA, ld, n, m, sp0, flags, free_count + 8);
-				HIP_CHECK(hipMemcpyAsync(&rk_nz[0], rank_d, sizeof(int), hipMemcpyDeviceToHost, stream));
-				HIP_CHECK(hipMemcpyAsync(&rk_nz[1], free_count + 8, sizeof(int), hipMemcpyDeviceToHost, stream));
-				HIP_CHECK(hipStreamSynchronize(stream));
+				const int own_end = std::min(m, sp0 + SPW * NB);
+				const bool split = far_pending && own_end < m;          // (no update in flight: one look at everything)
+				for (int pass = 0; pass < 2; pass++) {
+					const bool rest = pass == 1;
+					if (rest)
+						HIP_CHECK(hipStreamWaitEvent(stream, ev_far, 0));
+					HIP_CHECK(hipMemsetAsync(free_count + 8, 0, sizeof(int), stream));
+					hipLaunchKernelGGL(rref_free_nonzero, dim3(512), dim3(256), 0, stream, dA, ld, n, (split && !rest) ? own_end : m, rest ? own_end : sp0, flags, free_count + 8);
+					HIP_CHECK(hipMemcpyAsync(&rk_nz[0], rank_d, sizeof(int), hipMemcpyDeviceToHost, stream));
+					HIP_CHECK(hipMemcpyAsync(&rk_nz[1], free_count + 8, sizeof(int), hipMemcpyDeviceToHost, stream));
+					HIP_CHECK(hipStreamSynchronize(stream));
+					if (rk_nz[0] >= n || rk_nz[1] != 0 || !split)
+						break;
+				}
 				if (rk_nz[0] >= n || rk_nz[1] == 0)
 					break;
 			}
@@ -2588,7 +2663,13 @@ int device_rref(int64_t prime, int n, int m, uint32_t *dA, int64_t ld, int *d_pi
 				// near part (the next super-panel's own columns) on this stream, far part on the second one
 				const int near = (mfma_ok && stream2 != nullptr) ? std::min(mrT, SPW * NB) : mrT;
 				// (a 64 x 128 tile kernel, two waves per SIMD, 256 registers, was built in round 5 and took 24 % less serialised time for the
-				//  updates -- and 5 % MORE for the call, with and without the lookahead of round 6: removed)
+				//  updates -- and 5 % MORE for the call, with and without the lookahead of round 6: removed.  Round 6 also built a 128 x 128
+				//  tile kernel for the far part -- 64 x 64 per wave, three accumulators per 32 x 32 tile, half the LDS bytes per matrix
+				//  instruction, operands read one phase ahead, two LDS buffers, ONE workgroup per CU (320 registers): bit-identical and no
+				//  faster, 5.08 against 5.00 ms serialised.  With K = 512 a workgroup is prologue (its 64 KB of C, the first planes),
+				//  eight short sets whose planes arrive later than the 0.43 us the set before takes to multiply, and an epilogue; with one
+				//  workgroup per CU these phases have nothing to hide behind.  What the far update needs is several workgroups per CU in
+				//  different phases, which is what the 64 x 64 kernel has: NOTES/round6.md.)
 				timed([&]() {
 					dim3 grid((near + 63) / 64, (n + 63) / 64);
 					if (mfma_ok) {
@@ -2704,7 +2785,14 @@ int device_rref(int64_t prime, int n, int m, uint32_t *dA, int64_t ld, int *d_pi
 		(void) hipEventDestroy(ev_far);
 	}
 	HIP_CHECK(hipMemcpyAsync(&coop_failed, coop_err, sizeof(int), hipMemcpyDeviceToHost, stream));
+	int stuck = 0;
+	if (use_ahead)
+		HIP_CHECK(hipMemcpyFromSymbolAsync(&stuck, HIP_SYMBOL(g_handoff_stuck), sizeof(int), 0, hipMemcpyDeviceToHost, stream));
 	HIP_CHECK(hipStreamSynchronize(stream));
+	if (stuck) {
+		const int zero = 0;
+		HIP_CHECK(hipMemcpyToSymbol(HIP_SYMBOL(g_handoff_stuck), &zero, sizeof(int)));
+	}
 	if (tournament) {
 		ws_free(candA);
 		ws_free(candB);
@@ -2730,6 +2818,8 @@ int device_rref(int64_t prime, int n, int m, uint32_t *dA, int64_t ld, int *d_pi
 	ws_free(coop_err);
 	if (coop_failed)
 		die("dense RREF: a grid-wide barrier timed out (cooperative panel kernel)");
+	if (stuck)
+		die("dense RREF: a hand-off between the two streams of a lookahead pass timed out (SPASM_HIP_EXPERIMENT=1 SPASM_HIP_RREF_LOOKAHEAD=0 runs without them)");
 	if (rank > 0) {
 		uint32_t *tmp = nullptr;
 		ws_malloc((void **) &tmp, (size_t) rank * (size_t) m * sizeof(uint32_t));

@@ -8,8 +8,8 @@ OUT=gpurun_out/prof_dense_$TAG
 cd "$(dirname "$0")/.." || exit 1
 mkdir -p $OUT
 export TMPDIR=/tmp
-rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -- python3 tools/bench_dense.py --mfma-only > $OUT/bench.json 2> $OUT/trace.log
-rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE --output-format csv -d $OUT/pmc -- python3 tools/bench_dense.py --mfma-only > /dev/null 2> $OUT/pmc.log
+timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -- python3 tools/bench_dense.py --mfma-only > $OUT/bench.json 2> $OUT/trace.log
+timeout 600 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE --output-format csv -d $OUT/pmc -- python3 tools/bench_dense.py --mfma-only > /dev/null 2> $OUT/pmc.log
 python3 - "$OUT" <<'PY'
 import csv, glob, json, os, sys
 from collections import defaultdict
