@@ -46,11 +46,15 @@ __device__ __forceinline__ void sgn_mad(uint32_t w, int c, int &lo, int &hi)
 
 __device__ __forceinline__ int sgn_reduce(int t, const SgnDev &G)
 {
-	const int q = (int) __builtin_rintf((float) t * G.invp);
+	// q = round(t / p) out of the mantissa: fl(t) * (1/p) + 1.5 * 2^23 in one fused operation leaves q + 2^22 in the low 23 bits
+	// (|q| < 2^17), rounded once to nearest -- two instructions where multiply, round and convert were three; the error of
+	// q against t / p is at most 1/2 + |q| 2^-23, as before
+	const int q = __float_as_int(__builtin_fmaf((float) t, G.invp, 12582912.0f)) - 0x4B400000;
 	// q * (-p) + t in ONE full-rate instruction (|q| <= |t| / p + 1 < 2^17, p < 2^16: both fit 24 bits).  Written out: left to
 	// itself the compiler took v_mad_u64_u32 for `t + __mul24(q, negp)` in sparse_image.hip -- a quarter-rate instruction.
 	int r;
-	asm("v_mad_i32_i24 %0, %1, %2, %3" : "=v"(r) : "v"(q), "v"(G.negp), "v"(t));
+	// (-p as a scalar operand: G is wave-uniform everywhere; through a "v" constraint it cost a v_mov per reduction)
+	asm("v_mad_i32_i24 %0, %1, %2, %3" : "=v"(r) : "v"(q), "s"(G.negp), "v"(t));
 	return r;
 }
 
