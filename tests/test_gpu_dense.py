@@ -164,6 +164,34 @@ def test_rref_more_than_two_super_panels(oracle, which, env, monkeypatch):
         assert not np.any(R[r:])
 
 
+def test_rref_where_launches_are_serialised(oracle, tmp_path):
+    """The lookahead pass hands over between two streams through device words: a consumer is only served if its producer is on
+    the device at the same time.  Where one kernel runs at a time (AMD_SERIALIZE_KERNEL=3 here; rocprofv3 --pmc does the same, and
+    such a run of round 6 hung for 39 minutes) handoff_probe must find that out and the call must take the pass without the
+    lookahead: the same echelon form, in seconds.  (A child process: the variable is read when the runtime starts.)"""
+    import os
+    import subprocess
+    import sys
+    p, M, r_want, R_want, q_want = _big_rref_case(oracle, "full")
+    np.save(tmp_path / "M.npy", M)
+    code = ("import sys, numpy as np; sys.path.insert(0, %r); import spasm_amd\n"
+            "M = np.load(%r)\n"
+            "for k in range(2):\n"
+            "    r, R, q = spasm_amd.ffpack_rref(%d, M)\n"
+            "np.save(%r, R); np.save(%r, q); print('rank', r)\n"
+            % (os.path.dirname(os.path.dirname(os.path.abspath(__file__))), str(tmp_path / "M.npy"), p, str(tmp_path / "R.npy"), str(tmp_path / "q.npy")))
+    env = dict(os.environ, AMD_SERIALIZE_KERNEL="3", SPASM_HIP_VERBOSE="1")
+    done = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=600)
+    assert done.returncode == 0, done.stderr[-2000:]
+    assert "rank %d" % r_want in done.stdout
+    assert np.array_equal(np.load(tmp_path / "q.npy"), q_want)
+    assert np.array_equal(np.load(tmp_path / "R.npy")[:r_want], R_want[:r_want])
+    # (the runtime may ignore the variable on some stack: then the probe finds the two kernels side by side and there is nothing
+    #  more to check; where it is honoured the library says that it went without the lookahead)
+    if "side by side" not in done.stderr:
+        pytest.skip("AMD_SERIALIZE_KERNEL=3 did not keep two streams' kernels apart here: the probe had nothing to find")
+
+
 @pytest.mark.parametrize("shape,rank", [((4096, 32768), 4096), ((4096, 32768), 2500)])
 def test_rref_at_the_benchmarked_size(shape, rank):
     """The size bench.py times (4096 x 32768 mod 42013) is beyond what the CPU oracle finishes in a test, so the result of
