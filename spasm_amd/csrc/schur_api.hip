@@ -722,7 +722,9 @@ __global__ __launch_bounds__(256) void fl_census_kernel(const i64 *Ap, const int
 		best = min(best, Aj[px]);
 	for (int d = 32; d >= 1; d >>= 1)
 		best = min(best, __shfl_xor(best, d));
-	if (lane == 0 && best != 0x7FFFFFFF)
+	// (the rows of a dense Schur complement nearly all start in its first few columns: millions of atomics on the same word are
+	//  served one after the other -- look first)
+	if (lane == 0 && best != 0x7FFFFFFF && (__builtin_nontemporal_load(&bitmap[best >> 5]) & (1u << (best & 31))) == 0)
 		atomicOr(&bitmap[best >> 5], 1u << (best & 31));
 }
 
