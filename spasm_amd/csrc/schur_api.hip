@@ -765,8 +765,12 @@ __global__ __launch_bounds__(256) void row_min_column_kernel(const i64 *Ap, cons
 __global__ __launch_bounds__(256) void columns_to_bitmap_kernel(const int *col, int n, uint32_t *bitmap)
 {
 	const int i = blockIdx.x * 256 + threadIdx.x;
-	if (i < n && col[i] != 0x7FFFFFFF)
-		atomicOr(&bitmap[col[i] >> 5], 1u << (col[i] & 31));
+	if (i >= n)
+		return;
+	const int c = col[i];
+	// (as in fl_census_kernel: most rows name the same few columns -- look before the atomic)
+	if (c != 0x7FFFFFFF && (__builtin_nontemporal_load(&bitmap[c >> 5]) & (1u << (c & 31))) == 0)
+		atomicOr(&bitmap[c >> 5], 1u << (c & 31));
 }
 
 __global__ __launch_bounds__(256) void row_lengths_kernel(const i64 *Sp, int n, int *len)
