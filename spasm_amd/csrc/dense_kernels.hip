@@ -2913,8 +2913,22 @@ constexpr int RP_COLS = RP_WIN + RP_ROWS;
 constexpr int RP_THREADS = 1024, RP_GROUPS = RP_THREADS / 256;
 
 __global__ __launch_bounds__(RP_THREADS) void rowpanel_window(const uint32_t *P, int64_t ld, int m, int rows, const int *left, int *state, int *newpiv,
-                                                              uint32_t *T_out, unsigned char *is_piv, MontDev F)
+                                                              uint32_t *T_out, unsigned char *is_piv, MontDev F, const unsigned short *invtab)
 {
+	// p < 2^16 here (device_echelon_extend): products of residues fit 32 bits -- one full-rate 24-bit multiply and a Barrett
+	// reduction (two quarter-rate multiplies) where the Montgomery mulmod took eight, the elimination a x - f y as ONE reduction of
+	// x + (p - f) y < p + p^2, and the inverse of a pivot out of the table of rref_inverse_table instead of a Fermat power of 2 x 16
+	// dependent mulmods computed by every thread (round 6: the kernel took 742 us per full panel, 11.6 us per pivot, and was
+	// 190 ms of the 450 ms of the no-greedy flow on mk13.b5)
+	const uint32_t bm = (uint32_t) (0x100000000ull / F.p);
+	const bool q24 = F.p >= 256;          // v / p < 2^24 for every v < 2^32
+	auto red = [&](uint32_t v) -> uint32_t {
+		const uint32_t q = __umulhi(v, bm);
+		uint32_t rem = v - (q24 ? __umul24(q, F.p) : q * F.p);
+		rem = (rem >= F.p) ? rem - F.p : rem;
+		rem = (rem >= F.p) ? rem - F.p : rem;
+		return rem;
+	};
 	extern __shared__ uint32_t rp_lds[];
 	uint32_t(*W)[RP_COLS + 1] = reinterpret_cast<uint32_t(*)[RP_COLS + 1]>(rp_lds);
 	uint32_t(*T)[RP_ROWS + 1] = reinterpret_cast<uint32_t(*)[RP_ROWS + 1]>(rp_lds + RP_ROWS * (RP_COLS + 1));
@@ -2992,9 +3006,9 @@ __global__ __launch_bounds__(RP_THREADS) void rowpanel_window(const uint32_t *P,
 			__syncthreads();
 			continue;                        // zero on every column looked at: the row waits for the next step
 		}
-		const uint32_t inv = invmod(W[t][c], F);
-		const uint32_t wt = mulmod(W[t][col], inv, F);
-		const uint32_t wt2 = (col < RP_ROWS) ? mulmod(W[t][RP_WIN + col], inv, F) : 0u, tt = (col < RP_ROWS) ? mulmod(T[t][col], inv, F) : 0u;
+		const uint32_t inv = (uint32_t) invtab[W[t][c]];
+		const uint32_t wt = red(__umul24(W[t][col], inv));
+		const uint32_t wt2 = (col < RP_ROWS) ? red(__umul24(W[t][RP_WIN + col], inv)) : 0u, tt = (col < RP_ROWS) ? red(__umul24(T[t][col], inv)) : 0u;
 		if (tid < RP_ROWS)
 			fac[tid] = (tid == t) ? 0u : W[tid][c];
 		__syncthreads();
@@ -3009,10 +3023,11 @@ __global__ __launch_bounds__(RP_THREADS) void rowpanel_window(const uint32_t *P,
 			const uint32_t f = fac[s2];
 			if (f == 0)
 				continue;                    // (uniform: a group is whole waves)
-			W[s2][col] = submod(W[s2][col], mulmod(f, wt, F), F);
+			const uint32_t nf = F.p - f;
+			W[s2][col] = red(W[s2][col] + __umul24(nf, wt));
 			if (col < RP_ROWS) {
-				W[s2][RP_WIN + col] = submod(W[s2][RP_WIN + col], mulmod(f, wt2, F), F);
-				T[s2][col] = submod(T[s2][col], mulmod(f, tt, F), F);
+				W[s2][RP_WIN + col] = red(W[s2][RP_WIN + col] + __umul24(nf, wt2));
+				T[s2][col] = red(T[s2][col] + __umul24(nf, tt));
 			}
 		}
 		if (tid == 0) {
@@ -3186,6 +3201,8 @@ int device_echelon_extend(int64_t prime, int m, uint32_t *dM, int64_t ld, int k,
 	uint32_t *d_T = (uint32_t *) dal(RP_ROWS * RP_ROWS * sizeof(uint32_t));
 	unsigned char *d_ispiv = (unsigned char *) dal((size_t) m);
 	HIP_CHECK(hipMemsetAsync(d_ispiv, 0, (size_t) m, stream));
+	unsigned short *d_invtab = (unsigned short *) dal(((size_t) prime * 2 + 79) / 16 * 16);          // inverses of 0 .. p - 1 (rowpanel_window)
+	hipLaunchKernelGGL(rref_inverse_table, dim3(((unsigned) prime + 255) / 256), dim3(256), 0, stream, d_invtab, F);
 	if (k > 0)
 		hipLaunchKernelGGL(rowpanel_mark_pivots, dim3((k + 255) / 256), dim3(256), 0, stream, d_piv, k, d_ispiv);
 	const size_t win_lds = ((size_t) RP_ROWS * (RP_COLS + 1) + (size_t) RP_ROWS * (RP_ROWS + 1)) * sizeof(uint32_t);
@@ -3330,7 +3347,7 @@ int device_echelon_extend(int64_t prime, int m, uint32_t *dM, int64_t ld, int k,
 			signed char *Mh, *Ml, *Bh, *Bl;
 			planes_of_set(0, Mh, Ml, Bh, Bl);
 			split_panel(r0, 0);
-			hipLaunchKernelGGL(rowpanel_window, dim3(1), dim3(RP_THREADS), win_lds, stream, P, ld, m, rows_here, d_left, d_state, d_newpiv, d_T, d_ispiv, F);
+			hipLaunchKernelGGL(rowpanel_window, dim3(1), dim3(RP_THREADS), win_lds, stream, P, ld, m, rows_here, d_left, d_state, d_newpiv, d_T, d_ispiv, F, d_invtab);
 			total_iters += 1;
 			hipLaunchKernelGGL(rowpanel_multipliers, dim3(1), dim3(256), 0, stream, P, ld, rows_here, 0, d_newpiv, d_T, Mh, Ml, F);
 			UpdSets S{};
