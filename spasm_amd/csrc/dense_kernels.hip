@@ -3308,6 +3308,48 @@ int device_echelon_extend(int64_t prime, int m, uint32_t *dM, int64_t ld, int k,
 		passes += 1;
 		npend = 0;
 	};
+	// A block of FULL rank is the other extreme (the 4,096 combinations of a finish whose remainder still has thousands of
+	// dimensions: the no-greedy flow on mk13.b5, four blocks of 4,096 x 17,185): every row panel finds its 64 pivots, and 64 of them
+	// one after the other -- window, multipliers, updates, two round trips to the host each -- took 62-70 ms per block where the
+	// column-panel RREF of the same rows takes 5.  After two full panels in a row the rest of the block goes to device_rref (the
+	// waiting panels are passed on first, so that the rest is reduced by everything found so far), and the new pivot columns
+	// leave the rows above in passes of 512.  Only where the block is not much wider than tall: on a remainder of 70,000 columns
+	// a rest of low rank would pay a try per 64 columns.
+	int full_run = 0, rest_rows = 0, rest_rank = 0;
+	auto rest_by_columns = [&](int rest0) {
+		const int nr = Sn - rest0;
+		uint32_t *Yr = Y + (int64_t) rest0 * ld;
+		int *d_pivr = (int *) dal((size_t) m * sizeof(int));
+		int *d_pad = (int *) dal((size_t) SETS * RP_ROWS * sizeof(int));
+		const int rnew = device_rref(prime, nr, m, Yr, ld, d_pivr, stream, 1, nullptr);
+		rest_rows = nr;
+		rest_rank = rnew;
+		if (rnew <= 0)
+			return;
+		std::vector<int> pv((size_t) rnew);
+		HIP_CHECK(hipMemcpyAsync(pv.data(), d_pivr, (size_t) rnew * sizeof(int), hipMemcpyDeviceToHost, stream));
+		HIP_CHECK(hipStreamSynchronize(stream));
+		for (int t = 0; t < rnew; t++)
+			pivot_of[(size_t) rest0 + t] = pv[(size_t) t];
+		const int above = k + rest0;          // E and the panels done: they lose the new pivot columns
+		for (int t0 = 0; t0 < rnew && above > 0; t0 += RP_ROWS * SETS) {
+			const int count = std::min(rnew - t0, RP_ROWS * SETS), nsets = (count + RP_ROWS - 1) / RP_ROWS;
+			std::vector<int> pad((size_t) SETS * RP_ROWS, -1);
+			for (int t = 0; t < count; t++)
+				pad[(size_t) t] = pv[(size_t) t0 + t];
+			const int last = count - RP_ROWS * (nsets - 1);
+			HIP_CHECK(hipMemcpyAsync(d_pad, pad.data(), pad.size() * sizeof(int), hipMemcpyHostToDevice, stream));
+			HIP_CHECK(hipMemcpyAsync(d_cnt + 2, &last, sizeof(int), hipMemcpyHostToDevice, stream));
+			for (int s2 = 0; s2 < nsets; s2++) {
+				signed char *Mh, *Ml, *Bh, *Bl;
+				planes_of_set(s2, Mh, Ml, Bh, Bl);
+				hipLaunchKernelGGL(rref_split_B, dim3((m + 255) / 256), dim3(256), 0, stream, Yr + (int64_t) (t0 + RP_ROWS * s2) * ld, ld, m, d_cnt + (s2 + 1 < nsets ? 0 : 2), Bh, Bl, F);
+			}
+			clear_columns(dM, above, -1, -1, d_pad, nsets);
+			HIP_CHECK(hipStreamSynchronize(stream));          // (pad and last die here)
+			passes += 1;
+		}
+	};
 	for (int r0 = 0; r0 < Sn && !all_zero_at_start; r0 += RP_ROWS) {
 		const int rows_here = std::min(RP_ROWS, Sn - r0);
 		uint32_t *P = Y + (int64_t) r0 * ld;
@@ -3375,6 +3417,12 @@ int device_echelon_extend(int64_t prime, int m, uint32_t *dM, int64_t ld, int k,
 				break;
 		}
 		found_since_check = found_since_check || any;
+		{
+			int got = 0;
+			for (int t = 0; t < rows_here; t++)
+				got += state[t] >= 0;
+			full_run = (got == RP_ROWS) ? full_run + 1 : 0;
+		}
 		if (!any && npend == 0)
 			continue;                        // nothing but zero rows, and no panel waits: nothing to pass on
 		if (npend > 0) {          // (iii) the waiting panels lose its pivot columns
@@ -3387,6 +3435,12 @@ int device_echelon_extend(int64_t prime, int m, uint32_t *dM, int64_t ld, int k,
 		npend += 1;
 		if (npend == SETS)
 			flush();
+		const int rest0 = r0 + RP_ROWS;
+		if (full_run >= 2 && Sn - rest0 >= 512 && (int64_t) m <= 8 * (int64_t) (Sn - rest0)) {
+			flush();
+			rest_by_columns(rest0);
+			break;
+		}
 	}
 	flush();
 	HIP_CHECK(hipStreamSynchronize(stream));
@@ -3417,8 +3471,8 @@ int device_echelon_extend(int64_t prime, int m, uint32_t *dM, int64_t ld, int k,
 	for (void *ptr : owned)
 		big_free(ptr);
 	if (verbose() >= 2)
-		logmsg("[echelon rows] %d + %d rows x %d: reduction by the echelon rows %.1f ms, %d panels in %d steps and %d passes (%d looks at the rows left) %.1f ms, compaction %.1f ms; %d new\n",
-		       k, Sn, m, 1e3 * (t_A - t_start), (Sn + RP_ROWS - 1) / RP_ROWS, total_iters, passes, zero_checks, 1e3 * (t_B - t_A), 1e3 * (wtime() - t_B), rr);
+		logmsg("[echelon rows] %d + %d rows x %d: reduction by the echelon rows %.1f ms, %d panels in %d steps and %d passes (%d looks at the rows left; %d rows by column panels: %d pivots) %.1f ms, compaction %.1f ms; %d new\n",
+		       k, Sn, m, 1e3 * (t_A - t_start), (Sn + RP_ROWS - 1) / RP_ROWS, total_iters, passes, zero_checks, rest_rows, rest_rank, 1e3 * (t_B - t_A), 1e3 * (wtime() - t_B), rr);
 	return k + rr;
 }
 

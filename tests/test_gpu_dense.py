@@ -498,7 +498,7 @@ def _mod_matmul(torch, A, B, p):
 
 
 @pytest.mark.parametrize("p", [42013, 257, 65267])
-@pytest.mark.parametrize("case", ["two_blocks", "ragged", "dependent_on_E", "zeros", "sparse_wide", "many_windows"])
+@pytest.mark.parametrize("case", ["two_blocks", "ragged", "dependent_on_E", "zeros", "sparse_wide", "many_windows", "full_rank_blocks", "full_then_deficient"])
 def test_echelon_extend_by_row_panels(oracle, case, p):
     import torch
     dev = torch.device("cuda:0")
@@ -519,6 +519,13 @@ def test_echelon_extend_by_row_panels(oracle, case, p):
         m = 300
         blocks = [torch.zeros((100, m), dtype=torch.int32, device=dev), _low_rank(torch, g, p, 64, m, 10),
                   torch.zeros((5, m), dtype=torch.int32, device=dev)]
+    elif case == "full_rank_blocks":  # (round 6) blocks of full rank: after two full row panels the rest goes to the column-panel RREF,
+        m = 1500                      # and its pivot columns leave the rows above (E and the first panels) in passes of 512
+        blocks = [torch.randint(0, p, (740, m), dtype=torch.int32, device=dev, generator=g),
+                  torch.randint(0, p, (700, m), dtype=torch.int32, device=dev, generator=g)]
+    elif case == "full_then_deficient":   # ... a rest of lower rank than its rows (zero rows behind the echelon rows), a partial last set of pivots
+        m = 1400
+        blocks = [torch.randint(0, p, (200, m), dtype=torch.int32, device=dev, generator=g), _low_rank(torch, g, p, 900, m, 333)]
     elif case == "sparse_wide":       # wide and sparse: leftmost entries far apart, several windows per panel
         m = 20000
         blocks = [_low_rank(torch, g, p, 192, m, 120, density=0.02), _low_rank(torch, g, p, 192, m, 150, density=0.02)]
