@@ -3362,12 +3362,17 @@ int device_echelon_extend(int64_t prime, int m, uint32_t *dM, int64_t ld, int k,
 		for (int t = 0; t < RP_ROWS; t++)
 			state[t] = (t < rows_here) ? -1 : -2;
 		HIP_CHECK(hipMemcpyAsync(d_state, state, sizeof(state), hipMemcpyHostToDevice, stream));
-		for (int iter = 0;; iter++) {          // (ii) its rows find their pivots
+		// (the leftmost entries for the NEXT step are looked up behind the update of this one, on the device's own copy of the
+		//  states: one round trip to the host per step instead of two)
+		auto look = [&]() {
 			HIP_CHECK(hipMemsetAsync(d_left, 0x7F, RP_ROWS * sizeof(int), stream));          // 0x7F7F7F7F: larger than any column
 			hipLaunchKernelGGL(rowpanel_leftmost, dim3((m + 1023) / 1024, rows_here), dim3(64), 0, stream, P, ld, m, d_state, d_left);
-			int left[RP_ROWS];
-			HIP_CHECK(hipMemcpyAsync(left, d_left, sizeof(left), hipMemcpyDeviceToHost, stream));
-			HIP_CHECK(hipStreamSynchronize(stream));
+		};
+		int left[RP_ROWS];
+		look();
+		HIP_CHECK(hipMemcpyAsync(left, d_left, sizeof(left), hipMemcpyDeviceToHost, stream));
+		HIP_CHECK(hipStreamSynchronize(stream));
+		for (int iter = 0;; iter++) {          // (ii) its rows find their pivots
 			bool changed = false, waiting = false;
 			for (int t = 0; t < rows_here; t++) {
 				if (state[t] != -1)
@@ -3399,7 +3404,9 @@ int device_echelon_extend(int64_t prime, int m, uint32_t *dM, int64_t ld, int k,
 			S.Bl[0] = Bl;
 			S.nsets = 1;
 			hipLaunchKernelGGL(rref_update_mfma_multi, dim3((m + 63) / 64, 1), dim3(256), 0, stream, P, ld, rows_here, 0, m, S, F);
+			look();
 			HIP_CHECK(hipMemcpyAsync(state, d_state, sizeof(state), hipMemcpyDeviceToHost, stream));
+			HIP_CHECK(hipMemcpyAsync(left, d_left, sizeof(left), hipMemcpyDeviceToHost, stream));
 			HIP_CHECK(hipStreamSynchronize(stream));
 		}
 		HIP_CHECK(hipStreamSynchronize(stream));          // (state may have just gone up)
