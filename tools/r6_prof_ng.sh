@@ -3,7 +3,7 @@ cd /root/repo || exit 1
 export TMPDIR=/tmp
 OUT=gpurun_out/prof_ng
 rm -rf $OUT; mkdir -p $OUT
-SPASM_HIP_VERBOSE=0 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -- python3 tools/probe_no_greedy.py mk13.b5:0.05 > $OUT/run.log 2> $OUT/trace.log
+SPASM_HIP_VERBOSE=0 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -- python3 tools/probe_no_greedy.py ${1:-mk13.b5:0.05} > $OUT/run.log 2> $OUT/trace.log
 python3 - <<'PY'
 import csv,glob,os,re
 from collections import defaultdict
