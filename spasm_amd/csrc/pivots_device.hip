@@ -1614,9 +1614,11 @@ int device_acyclic_greedy(const struct spasm_csr *A, int *pinv, int *qinv, std::
 			// the host's depth-first search (mk15.b4 104 -> 79 ms, mk14.b4 58 -> 46) -- unless the rows were deferred by the gap
 			// rule rather than by the cap (mk13.b5 65 : 1, ch8-8.b5 4 : 1): those sit far above their rows, their cascades are the
 			// longest, and the ticket search takes them faster (mk13.b5 20 against 27-36 ms, ch8-8.b5 76 against 93-114).
-			const bool many = ndeferred >= env_int("SPASM_HIP_PIVOT_SECOND_PASS_MANY_ROWS", 32768);
+			// (SPASM_HIP_PIVOT_SECOND_PASS_ALWAYS: 1 = the pass runs whatever deferred the rows, 2 = ... and as with many rows)
+			const int second_always = env_int("SPASM_HIP_PIVOT_SECOND_PASS_ALWAYS", 0);
+			const bool many = second_always >= 2 || ndeferred >= 32768;
 			late_cap_now = many ? casc_cap_late : std::min(casc_cap_late, std::max(casc_cap, 16384));
-			if (!many && c.deferred_gap > 3 * c.deferred_cap && env_int("SPASM_HIP_PIVOT_SECOND_PASS_ALWAYS", 0) == 0)
+			if (!many && c.deferred_gap > 3 * c.deferred_cap && second_always == 0)
 				break;
 		}
 		if (labels) {

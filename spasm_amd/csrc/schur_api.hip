@@ -2058,8 +2058,9 @@ int dschur_impl(const spasm_hip_dcsr *A, const int *d_rows, int nrows, const spa
 			// (... per group in flight: the judgement used to fall after 500,000 pivots whatever the number of groups, i.e. after
 			// 1,700 pivots of each of the 297 groups of a mk14.b4 call -- all of them still in the cheap private start of their
 			// rows -- and sent a batch whose final efficiency is 0.60 to the per-row tier: 1.68 s instead of 0.35 s)
-			const long long min_w = std::max<long long>(env_int("SPASM_HIP_GROUP_MIN_PIVOTS", 500000),
-			                                            (long long) env_int("SPASM_HIP_GROUP_MIN_PIVOTS_PER_GROUP", 8192) * group_slots);
+			// (SPASM_HIP_GROUP_MIN_PIVOTS, when set, is the threshold as it stands: tests judge early with it)
+			const char *min_w_env = sh::env_get("SPASM_HIP_GROUP_MIN_PIVOTS");
+			const long long min_w = (min_w_env != nullptr) ? std::atoll(min_w_env) : std::max<long long>(500000, 8192ll * group_slots);
 			// several connected components in the pivot graph: rows of different components share nothing, so the
 			// rows are grouped by component from the start (the order of the list is kept inside a component; with a
 			// single or a dominant component -- mk13.b5: 109,966 of its 111,177 pivots -- nothing is done)

@@ -139,7 +139,7 @@ def test_device_search_with_long_rows_on_a_matrix_too_wide_for_the_lds():
 @pytest.mark.parametrize("switches", [{"SPASM_HIP_PIVOT_CASCADE": "64", "SPASM_HIP_PIVOT_CASCADE_LATE": "64"},
                                       {"SPASM_HIP_PIVOT_GAP": "0"},
                                       {"SPASM_HIP_PIVOT_LABEL_FIFO": "256"},
-                                      {"SPASM_HIP_PIVOT_SECOND_PASS_ALWAYS": "1", "SPASM_HIP_PIVOT_SECOND_PASS_MANY_ROWS": "0"},
+                                      {"SPASM_HIP_PIVOT_SECOND_PASS_ALWAYS": "2"},
                                       {"SPASM_HIP_PIVOT_LABEL_PASSES": "1"},
                                       {"SPASM_HIP_PIVOT_ORDER_BY_LABELS": "0"},
                                       {"SPASM_HIP_PIVOT_ORDER_CHASE": "0"},

@@ -233,7 +233,6 @@ def test_row_group_kernel_gives_up_on_unrelated_rows(oracle, regroup, monkeypatc
     monkeypatch.setenv("SPASM_HIP_BACKSOLVE", "0")
     monkeypatch.setenv("SPASM_HIP_GROUP_WATCH_ROWS", "0")
     monkeypatch.setenv("SPASM_HIP_GROUP_MIN_PIVOTS", "20000")      # the batch is small: judge early
-    monkeypatch.setenv("SPASM_HIP_GROUP_MIN_PIVOTS_PER_GROUP", "0")
     p = 42013
     rng = np.random.default_rng(11)
     B, W, extra = 520, 32, 8
